@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — candidate overlaps scored per second in the edge-calculation stage.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (hc_score_batch_device: compute_overlap +
+overlap_score + admission class for every candidate) over one device-resident batch
+of synthetic candidates.  Workload = BASELINE.json configs[1]: 50k synthetic 2x150 bp
+read pairs, 2,000,000 p-p candidate overlaps per GPU (weak scaling: every rank scores
+its own 2M-candidate shard against the replicated read store; for N > 1 the admitted
+edge records are then gathered with one RCCL all-gather-v).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline":     algorithmic bytes (32 + 16 + 4*L_sub per candidate) over
+                  the scoring kernel's mean launch time (hipEvents on the launch stream), vs 8 TB/s HBM
+  "cpu_baseline": the CPU oracle (a port of the reference algorithm, oracle/hc_oracle.c) timed
+                  with OpenMP on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_workload(workload, rank):
+    from haploconduct_amd import synth
+
+    if workload == "c2":
+        n_pairs, glen, n_cand = 50000, 45000, 2000000
+    elif workload == "c2-small":
+        n_pairs, glen, n_cand = 5000, 1800, 200000
+    elif workload == "c3":
+        n_pairs, glen, n_cand = 500000, 34000, 100000000
+    else:
+        raise SystemExit(f"unknown workload {workload}")
+    reads, meta = synth.make_paired_dataset(n_pairs, glen, seed=1)
+    cand = synth.paired_candidates(meta, n_candidates=n_cand, seed=2 + rank)
+    return reads, cand, {"workload": f"{workload}: {n_pairs} synthetic 2x150 bp read pairs, {n_cand} p-p candidates per GPU",
+                         "read_pairs": n_pairs, "candidates_per_gpu": n_cand, "genome_len": glen}
+
+
+def cpu_baseline(reads, settings, cand, budget_s=15.0):
+    from tests import _oracle
+
+    cores = os.cpu_count() or 1
+    probe = cand[: min(cand.size, 20000)]
+    t0 = time.perf_counter()
+    _oracle.score_batch(reads, settings, probe, n_threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    n = int(min(cand.size, max(probe.size, probe.size / dt * budget_s)))
+    sample = cand[:n]
+    t0 = time.perf_counter()
+    _oracle.score_batch(reads, settings, sample, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "candidate overlaps/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} candidates of the rank-0 batch, oracle/hc_oracle.c with {cores} OpenMP threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: libhcedge has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import haploconduct_amd as hc
+
+    settings = hc.Settings(edge_threshold=0.97, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=150, device=local_rank)
+    reads, cand, cfg = build_workload(args.workload, rank)
+    n = int(cand.size)
+    sc = hc.EdgeScorer(settings)
+    sc.set_reads(reads)
+    d_in = torch.from_numpy(cand.view(np.uint8).reshape(-1)).cuda()
+    d_out = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+    positions, subs = sc.count_positions_device(d_in.data_ptr(), n)
+    alg_bytes = 48 * n + 4 * positions  # 32 B record + 16 B result + 4 B per overlapped position
+
+    def gather_edges():
+        # admitted-edge records to every rank: counts, then padded payload
+        res = d_out.view(torch.int64).view(-1, 3)
+        cls = (res[:, 2] >> 60) & 0xF
+        keep = (cls >= 2) & (cls <= 4)
+        idx = torch.nonzero(keep).squeeze(1)
+        mine = torch.cat([idx.unsqueeze(1), res[idx]], dim=1).contiguous()  # [k, 4] int64
+        cnt = torch.tensor([mine.shape[0]], device="cuda", dtype=torch.int64)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        kmax = int(max(int(c.item()) for c in cnts))
+        pad = torch.zeros((kmax, 4), device="cuda", dtype=torch.int64)
+        pad[: mine.shape[0]] = mine
+        allr = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(allr, pad)
+        return allr, cnts
+
+    def step():
+        sc.score_batch_device(d_in.data_ptr(), n, d_out.data_ptr())
+        if world > 1:
+            sc.synchronize()
+            gather_edges()
+
+    for _ in range(args.warmup):
+        step()
+    sc.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sc.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # kernel-only: hipEvents on the stream the kernel is launched on
+    kern_ms = sc.time_kernel(d_in.data_ptr(), n, d_out.data_ptr(), max(10, min(args.steps, 200)))
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "candidate overlaps scored/sec (edge-calc stage)",
+            "value": world * n * args.steps / dt,
+            "unit": "candidate overlaps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": dict(cfg, parallelism=f"candidate shards x{world}, replicated read store",
+                           edge_threshold=settings.edge_threshold, mean_positions_per_candidate=positions / n),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "hc::score_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_candidates_per_s": n / (kern_ms * 1e-3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(reads, settings, cand)
+        print(json.dumps(out))
+    sc.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""ctypes bindings for libhcedge.so (include/hcedge.h).  Fails loudly if the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "csrc", "libhcedge.so")
+
+
+class HcError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        try:
+            msg = lib.hc_strerror(status).decode()
+            detail = lib.hc_last_error().decode()
+        except Exception:  # pragma: no cover
+            msg, detail = "?", ""
+        super().__init__(f"{where}: {msg} ({status}) {detail}".strip())
+
+
+if not os.path.exists(lib_path):
+    raise ImportError(
+        f"{lib_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C haploconduct_amd/csrc`.  haploconduct_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(lib_path)
+
+
+class hc_settings(C.Structure):
+    _fields_ = [
+        ("edge_threshold", C.c_double),
+        ("ov_threshold", C.c_double),
+        ("merge_contigs", C.c_double),
+        ("mismatch", C.c_double),
+        ("min_read_len", C.c_uint32),
+        ("min_overlap_len", C.c_uint32),
+        ("min_overlap_perc", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("max_overlaps", C.c_uint64),
+        ("device", C.c_int32),
+        ("n_threads", C.c_uint32),
+    ]
+
+
+_vp = C.c_void_p
+_sig = {
+    "hc_version": (C.c_char_p, []),
+    "hc_strerror": (C.c_char_p, [C.c_int]),
+    "hc_last_error": (C.c_char_p, []),
+    "hc_device_count": (C.c_int, []),
+    "hc_create": (C.c_int, [C.POINTER(_vp), C.POINTER(hc_settings)]),
+    "hc_destroy": (C.c_int, [_vp]),
+    "hc_set_reads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32]),
+    "hc_score_batch": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "hc_score_batch_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "hc_synchronize": (C.c_int, [_vp]),
+    "hc_time_score_kernel": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_int, C.POINTER(C.c_float)]),
+    "hc_count_positions_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hc_finalize": (C.c_int, [C.POINTER(hc_settings), _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "hc_finalize_batch": (C.c_int, [C.POINTER(hc_settings), _vp, C.c_uint64, _vp, _vp, _vp]),
+    "hc_get_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)] + [C.POINTER(C.c_double)] * 4),
+}
+for _name, (_res, _args) in _sig.items():
+    _f = getattr(lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def check(status, where=""):
+    if status != 0:
+        raise HcError(status, where)
+
+
+def device_count():
+    return int(lib.hc_device_count())
+
+
+def version():
+    return lib.hc_version().decode()

@@ -1,0 +1,444 @@
+// hc_api.cpp — C-ABI glue of libhcedge.so (include/hcedge.h): context, HBM read
+// store, host-built log-probability table, threshold inversion, launches.
+// Compiled with hipcc for gfx950.  There is NO CPU fallback in this library: without
+// a HIP device hc_create fails with HC_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hcedge.h"
+#include "hc_device.h"
+
+namespace hc {
+hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
+                         const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, void* sym, uint8_t* seq_flags,
+                         hipStream_t stream);
+hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
+                        uint64_t n, hc_result_rec* out, uint32_t n_cu, hipStream_t stream);
+hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,
+                                  unsigned long long* totals, hipStream_t stream);
+hipError_t set_score_kernel_lds_limit();
+}  // namespace hc
+
+static thread_local std::string g_last_error;
+
+static int fail(int status, const std::string& what) {
+    g_last_error = what;
+    return status;
+}
+
+#define HC_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(HC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));               \
+    } while (0)
+
+struct hc_ctx {
+    hc_settings settings;
+    int device = 0;
+    uint32_t n_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // read store
+    bool have_reads = false;
+    void* d_sym = nullptr;
+    uint64_t* d_seq_off = nullptr;
+    uint32_t* d_seq_len = nullptr;
+    uint8_t* d_seq_flags = nullptr;
+    uint32_t* d_read_first_seq = nullptr;
+    double* d_lut = nullptr;
+    uint64_t store_bytes = 0;
+    hc::StoreView view{};
+    hc::ScoreParams params{};
+    // grow-only workspace for the host-buffer entry point
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    uint64_t ws_cap = 0;
+    unsigned long long* d_totals = nullptr;
+};
+
+// --------------------------------------------------------------------------
+// Threshold inversion: exp(x) > T decided in x-space.
+// glibc's exp/log are accurate to < 1 ULP, and the true exp is monotone, so
+//   true exp(x) > T + 1.5 ulp(T)  =>  fl(exp(x)) > T,   true exp(x) < T - 1.5 ulp(T)  =>  fl(exp(x)) <= T.
+// In x that is |x - ln T| > 1.5 * 2^-52 (+ the error of log()).  Everything inside
+// [ln T - d, ln T + d], d = 2^-49 * max(1, |ln T|), is handed to the host libm
+// (HC_CLS_AMBIG); the band covers ~1e-13 of the x values that occur.
+static hc::Band make_band(double T) {
+    hc::Band b;
+    const double inf = std::numeric_limits<double>::infinity();
+    if (T != T) {  // NaN: `score > T` is never true
+        b.lo = inf;
+        b.hi = inf;
+    } else if (T < 0) {  // every score (>= 0, including 0 = exp(-inf)) passes
+        b.lo = -inf;
+        b.hi = -inf;
+    } else if (T == 0) {  // exp(x) > 0 unless it underflows to 0 (x < ~ -745.13)
+        b.lo = -760.0;
+        b.hi = -740.0;
+    } else if (T >= 1) {  // x <= 0 always, exp(x) <= 1 <= T
+        b.lo = inf;
+        b.hi = inf;
+    } else {
+        const double lt = std::log(T);
+        const double d = std::ldexp(1.0, -49) * std::fmax(1.0, std::fabs(lt));
+        b.lo = lt - d;
+        b.hi = lt + d;
+    }
+    return b;
+}
+// x = -inf (score 0): -inf > hi is false unless hi = -inf is meant as "always": handle T < 0 on the device by
+// comparing with >= when hi == -inf?  Simpler: for T < 0 we use hi = -inf and the device test `x > hi`
+// fails only for x = -inf; score 0 > T (T<0) is true in the reference.  hc_finalize and the device both
+// special-case this through ScoreParams.flags bits below.
+static const uint32_t kParamEdgeAlways = 1u;  // edge_threshold < 0
+static const uint32_t kParamOvAlways = 2u;    // ov_threshold < 0
+
+extern "C" {
+
+const char* hc_version(void) { return "hcedge 0.1.0 (gfx950)"; }
+
+const char* hc_strerror(int status) {
+    switch (status) {
+        case HC_OK: return "ok";
+        case HC_ERR_ARG: return "invalid argument";
+        case HC_ERR_NOMEM: return "out of memory";
+        case HC_ERR_HIP: return "HIP runtime error";
+        case HC_ERR_NO_DEVICE: return "no HIP device (libhcedge has no CPU fallback)";
+        case HC_ERR_STATE: return "call order violated";
+        case HC_ERR_BAD_READ: return "malformed read set";
+        case HC_ERR_BAD_OVERLAP: return "malformed overlap record";
+        case HC_ERR_IO: return "I/O error";
+        case HC_ERR_FORMAT: return "input format the reference rejects";
+        case HC_ERR_DATA: return "overlap touches a base/quality the reference asserts on";
+        default: return "unknown status";
+    }
+}
+
+const char* hc_last_error(void) { return g_last_error.c_str(); }
+
+int hc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int hc_create(hc_ctx** out, const hc_settings* settings) {
+    if (!out || !settings) return fail(HC_ERR_ARG, "hc_create: null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(HC_ERR_NO_DEVICE, "hc_create: no HIP device visible");
+    if (settings->device < 0 || settings->device >= n) return fail(HC_ERR_ARG, "hc_create: device ordinal out of range");
+    hc_ctx* c = new (std::nothrow) hc_ctx();
+    if (!c) return fail(HC_ERR_NOMEM, "hc_create: host allocation failed");
+    c->settings = *settings;
+    c->device = settings->device;
+    HC_HIP(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HC_HIP(hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    HC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HC_HIP(hipEventCreate(&c->ev0));
+    HC_HIP(hipEventCreate(&c->ev1));
+    HC_HIP(hipMalloc((void**)&c->d_totals, 2 * sizeof(unsigned long long)));
+    HC_HIP(hc::set_score_kernel_lds_limit());
+    c->params.edge = make_band(settings->edge_threshold);
+    c->params.ov = make_band(settings->ov_threshold);
+    c->params.merge_contigs = settings->merge_contigs;
+    c->params.min_read_len = settings->min_read_len;
+    c->params.flags = (settings->edge_threshold < 0 ? kParamEdgeAlways : 0u) | (settings->ov_threshold < 0 ? kParamOvAlways : 0u);
+    *out = c;
+    return HC_OK;
+}
+
+static void free_store(hc_ctx* c) {
+    if (c->d_sym) (void)hipFree(c->d_sym);
+    if (c->d_seq_off) (void)hipFree(c->d_seq_off);
+    if (c->d_seq_len) (void)hipFree(c->d_seq_len);
+    if (c->d_seq_flags) (void)hipFree(c->d_seq_flags);
+    if (c->d_read_first_seq) (void)hipFree(c->d_read_first_seq);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    c->d_sym = nullptr;
+    c->d_seq_off = nullptr;
+    c->d_seq_len = nullptr;
+    c->d_seq_flags = nullptr;
+    c->d_read_first_seq = nullptr;
+    c->d_lut = nullptr;
+    c->have_reads = false;
+    c->store_bytes = 0;
+}
+
+int hc_destroy(hc_ctx* c) {
+    if (!c) return HC_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_store(c);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_totals) (void)hipFree(c->d_totals);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return HC_OK;
+}
+
+// The log-probability table, K x K x 2 doubles: [qa][qb][mismatch].  Built with the HOST
+// libm by the reference's own expressions (EdgeCalculator.cpp:41,44,52,60) so that every
+// term the device adds is bit-identical to the reference's log(p).
+static void build_lut(const std::vector<int>& phred, double mismatch_setting, std::vector<double>& lut) {
+    const size_t K = phred.size();
+    lut.assign(K * K * 2, 0.0);
+    const double inf = std::numeric_limits<double>::infinity();
+    for (size_t a = 0; a < K; a++) {
+        const double p1 = pow(10, -phred[a] / 10.0);  // phred_to_prob, :59-63
+        for (size_t b = 0; b < K; b++) {
+            const double p2 = pow(10, -phred[b] / 10.0);
+            const double pm = (1 - p1) * (1 - p2) + (p1 * p2) / 3.0;                               // :41
+            const double px = p1 * (1 - p2) / 3.0 + p2 * (1 - p1) / 3.0 + (2 / 9.0) * p1 * p2;  // :44
+            lut[(a * K + b) * 2 + 0] = (pm < mismatch_setting) ? inf : log(pm);  // :49-52
+            lut[(a * K + b) * 2 + 1] = (px < mismatch_setting) ? inf : log(px);
+        }
+    }
+}
+
+int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const uint64_t* seq_off,
+                 const uint32_t* read_first_seq, uint32_t n_reads) {
+    if (!c || !seq_off || !read_first_seq) return fail(HC_ERR_ARG, "hc_set_reads: null argument");
+    HC_HIP(hipSetDevice(c->device));
+    const uint32_t n_seq = read_first_seq[n_reads];
+    if (read_first_seq[0] != 0) return fail(HC_ERR_BAD_READ, "hc_set_reads: read_first_seq[0] != 0");
+    for (uint32_t r = 0; r < n_reads; r++) {
+        const uint32_t k = read_first_seq[r + 1] - read_first_seq[r];
+        if (k != 1 && k != 2) return fail(HC_ERR_BAD_READ, "hc_set_reads: a read must own 1 or 2 sequences");
+    }
+    const uint64_t total = seq_off[n_seq];
+    if (total > 0 && (!bases || !quals)) return fail(HC_ERR_ARG, "hc_set_reads: null bases/quals");
+    if (seq_off[0] != 0) return fail(HC_ERR_BAD_READ, "hc_set_reads: seq_off[0] != 0");
+    std::vector<uint32_t> seq_len(n_seq ? n_seq : 1);
+    for (uint32_t q = 0; q < n_seq; q++) {
+        if (seq_off[q + 1] <= seq_off[q])  // FastqStorage.cpp:143-146,218-221: empty sequence => exit(1)
+            return fail(HC_ERR_BAD_READ, "hc_set_reads: empty sequence");
+        const uint64_t len = seq_off[q + 1] - seq_off[q];
+        if (len >= (1ull << 28)) return fail(HC_ERR_BAD_READ, "hc_set_reads: sequence longer than 2^28-1");
+        seq_len[q] = (uint32_t)len;
+    }
+    // dense quality alphabet over the bytes the reference accepts: Q = byte-33 >= 0 as a signed char
+    uint64_t hist[256] = {0};
+    for (uint64_t i = 0; i < total; i++) hist[quals[i]]++;
+    std::vector<int> phred;
+    uint8_t qmap[256];
+    memset(qmap, 255, sizeof qmap);
+    for (int b = 33; b <= 127; b++)
+        if (hist[b]) {
+            qmap[b] = (uint8_t)phred.size();
+            phred.push_back(b - 33);
+        }
+    if (phred.empty()) phred.push_back(0);
+    const uint32_t K = (uint32_t)phred.size();
+    const uint32_t symbytes = K <= 32 ? 1 : 2;
+
+    std::vector<uint64_t> sym_off(n_seq ? n_seq : 1);
+    uint64_t nsym = 0;
+    for (uint32_t q = 0; q < n_seq; q++) {
+        sym_off[q] = nsym;
+        nsym += 2 * hc::slot_stride(seq_len[q], symbytes);
+    }
+    std::vector<double> lut;
+    build_lut(phred, c->settings.mismatch, lut);
+
+    free_store(c);
+    uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_qmap = nullptr;
+    uint64_t* d_raw_off = nullptr;
+    const uint64_t sym_bytes_total = (nsym ? nsym : 1) * symbytes;
+    HC_HIP(hipMalloc(&c->d_sym, sym_bytes_total));
+    HC_HIP(hipMalloc((void**)&c->d_seq_off, sizeof(uint64_t) * (n_seq ? n_seq : 1)));
+    HC_HIP(hipMalloc((void**)&c->d_seq_len, sizeof(uint32_t) * (n_seq ? n_seq : 1)));
+    HC_HIP(hipMalloc((void**)&c->d_seq_flags, (n_seq ? n_seq : 1)));
+    HC_HIP(hipMalloc((void**)&c->d_read_first_seq, sizeof(uint32_t) * (n_reads + 1)));
+    HC_HIP(hipMalloc((void**)&c->d_lut, sizeof(double) * lut.size()));
+    HC_HIP(hipMalloc((void**)&d_bases, total ? total : 1));
+    HC_HIP(hipMalloc((void**)&d_quals, total ? total : 1));
+    HC_HIP(hipMalloc((void**)&d_raw_off, sizeof(uint64_t) * (n_seq + 1)));
+    HC_HIP(hipMalloc((void**)&d_qmap, 256));
+    if (total) {
+        HC_HIP(hipMemcpyAsync(d_bases, bases, total, hipMemcpyHostToDevice, c->stream));
+        HC_HIP(hipMemcpyAsync(d_quals, quals, total, hipMemcpyHostToDevice, c->stream));
+    }
+    HC_HIP(hipMemcpyAsync(d_raw_off, seq_off, sizeof(uint64_t) * (n_seq + 1), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(hipMemcpyAsync(d_qmap, qmap, 256, hipMemcpyHostToDevice, c->stream));
+    HC_HIP(hipMemcpyAsync(c->d_seq_off, sym_off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, c->stream));
+    HC_HIP(hipMemcpyAsync(c->d_seq_len, seq_len.data(), sizeof(uint32_t) * n_seq, hipMemcpyHostToDevice, c->stream));
+    HC_HIP(hipMemcpyAsync(c->d_read_first_seq, read_first_seq, sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice,
+                          c->stream));
+    HC_HIP(hipMemcpyAsync(c->d_lut, lut.data(), sizeof(double) * lut.size(), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(hc::launch_encode(symbytes, d_bases, d_quals, d_raw_off, c->d_seq_off, d_qmap, n_seq, c->d_sym, c->d_seq_flags,
+                             c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_bases);
+    (void)hipFree(d_quals);
+    (void)hipFree(d_raw_off);
+    (void)hipFree(d_qmap);
+
+    c->view.sym = c->d_sym;
+    c->view.seq_off = c->d_seq_off;
+    c->view.seq_len = c->d_seq_len;
+    c->view.seq_flags = c->d_seq_flags;
+    c->view.read_first_seq = c->d_read_first_seq;
+    c->view.n_reads = n_reads;
+    c->view.n_seq = n_seq;
+    c->view.K = K;
+    c->view.symbytes = symbytes;
+    c->store_bytes = sym_bytes_total;
+    c->have_reads = true;
+    return HC_OK;
+}
+
+int hc_score_batch_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, void* hip_stream) {
+    if (!c) return fail(HC_ERR_ARG, "hc_score_batch_device: null context");
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_score_batch_device: hc_set_reads has not been called");
+    if (n == 0) return HC_OK;
+    if (!d_in || !d_out) return fail(HC_ERR_ARG, "hc_score_batch_device: null buffer");
+    HC_HIP(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    HC_HIP(hc::launch_score(c->view, c->params, c->d_lut, (const hc_overlap_rec*)d_in, n, (hc_result_rec*)d_out, c->n_cu,
+                            s));
+    return HC_OK;
+}
+
+int hc_synchronize(hc_ctx* c) {
+    if (!c) return fail(HC_ERR_ARG, "hc_synchronize: null context");
+    HC_HIP(hipSetDevice(c->device));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    return HC_OK;
+}
+
+static int ensure_workspace(hc_ctx* c, uint64_t n) {
+    if (n <= c->ws_cap) return HC_OK;
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    c->d_in = c->d_out = nullptr;
+    c->ws_cap = 0;
+    HC_HIP(hipMalloc(&c->d_in, n * sizeof(hc_overlap_rec)));
+    HC_HIP(hipMalloc(&c->d_out, n * sizeof(hc_result_rec)));
+    c->ws_cap = n;
+    return HC_OK;
+}
+
+int hc_score_batch(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, hc_result_rec* out) {
+    if (!c) return fail(HC_ERR_ARG, "hc_score_batch: null context");
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_score_batch: hc_set_reads has not been called");
+    if (n == 0) return HC_OK;
+    if (!in || !out) return fail(HC_ERR_ARG, "hc_score_batch: null buffer");
+    HC_HIP(hipSetDevice(c->device));
+    int rc = ensure_workspace(c, n);
+    if (rc) return rc;
+    HC_HIP(hipMemcpyAsync(c->d_in, in, n * sizeof(hc_overlap_rec), hipMemcpyHostToDevice, c->stream));
+    rc = hc_score_batch_device(c, c->d_in, n, c->d_out, c->stream);
+    if (rc) return rc;
+    HC_HIP(hipMemcpyAsync(out, c->d_out, n * sizeof(hc_result_rec), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    return HC_OK;
+}
+
+int hc_time_score_kernel(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, int iters, float* ms_per_launch) {
+    if (!c || !ms_per_launch || iters <= 0) return fail(HC_ERR_ARG, "hc_time_score_kernel: bad argument");
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_time_score_kernel: hc_set_reads has not been called");
+    HC_HIP(hipSetDevice(c->device));
+    HC_HIP(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters; i++) {
+        int rc = hc_score_batch_device(c, d_in, n, d_out, c->stream);
+        if (rc) return rc;
+    }
+    HC_HIP(hipEventRecord(c->ev1, c->stream));
+    HC_HIP(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HC_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_per_launch = ms / (float)iters;
+    return HC_OK;
+}
+
+int hc_count_positions_device(hc_ctx* c, const void* d_in, uint64_t n, uint64_t* total_positions, uint64_t* total_subs) {
+    if (!c || !total_positions || !total_subs) return fail(HC_ERR_ARG, "hc_count_positions_device: null argument");
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_count_positions_device: hc_set_reads has not been called");
+    HC_HIP(hipSetDevice(c->device));
+    HC_HIP(hipMemsetAsync(c->d_totals, 0, 2 * sizeof(unsigned long long), c->stream));
+    HC_HIP(hc::launch_count_positions(c->view, c->params.min_read_len, (const hc_overlap_rec*)d_in, n, c->d_totals,
+                                      c->stream));
+    unsigned long long h[2] = {0, 0};
+    HC_HIP(hipMemcpyAsync(h, c->d_totals, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    *total_positions = h[0];
+    *total_subs = h[1];
+    return HC_OK;
+}
+
+int hc_finalize(const hc_settings* s, const hc_result_rec* r, double* score, double* mismatch_rate, uint32_t* cls) {
+    if (!s || !r) return fail(HC_ERR_ARG, "hc_finalize: null argument");
+    const uint32_t dcls = HC_RES_CLS(*r);
+    if (dcls == HC_CLS_ERROR) {
+        if (score) *score = 0;
+        if (mismatch_rate) *mismatch_rate = -1;
+        if (cls) *cls = HC_CLS_ERROR;
+        return HC_ERR_DATA;
+    }
+    const uint32_t n = HC_RES_N(*r);
+    const double mrate = (float)r->mm / (double)n;  // EdgeCalculator.cpp:132
+    const double ov1 = exp(r->x1);                   // :138 (exp(-inf) == 0: every `return 0` of overlap_score)
+    double sc;
+    if (r->x2 != r->x2) {  // one sub-overlap (s-s)
+        sc = ov1;
+    } else {
+        const double ov2 = exp(r->x2);
+        if (ov1 > s->edge_threshold && ov2 > s->edge_threshold) sc = 0.5 * (ov1 + ov2);  // :256-258
+        else sc = ov2 < ov1 ? ov2 : ov1;                                                  // std::min, :260
+    }
+    uint32_t k;
+    if (sc > s->edge_threshold) k = HC_CLS_EDGE;             // :404
+    else if (mrate <= s->merge_contigs) k = HC_CLS_EDGE_MC;  // :407 (mismatch_rate is never -1 here)
+    else if (sc > s->ov_threshold) k = HC_CLS_NONEDGE;       // :410
+    else k = HC_CLS_DROP;
+    if (score) *score = sc;
+    if (mismatch_rate) *mismatch_rate = mrate;
+    if (cls) *cls = k;
+    return HC_OK;
+}
+
+int hc_finalize_batch(const hc_settings* s, const hc_result_rec* r, uint64_t n, double* score, double* mismatch_rate,
+                      uint32_t* cls) {
+    if (!s || (!r && n)) return fail(HC_ERR_ARG, "hc_finalize_batch: null argument");
+    int rc = HC_OK;
+    for (uint64_t i = 0; i < n; i++) {
+        double sc, mr;
+        uint32_t k;
+        if (hc_finalize(s, &r[i], &sc, &mr, &k) != HC_OK) rc = HC_ERR_DATA;
+        if (score) score[i] = sc;
+        if (mismatch_rate) mismatch_rate[i] = mr;
+        if (cls) cls[i] = k;
+    }
+    if (rc) return fail(rc, "hc_finalize_batch: a record touched an invalid base/quality");
+    return HC_OK;
+}
+
+int hc_get_info(hc_ctx* c, uint32_t* qual_alphabet, uint64_t* store_bytes, double* x_edge_lo, double* x_edge_hi,
+                double* x_ov_lo, double* x_ov_hi) {
+    if (!c) return fail(HC_ERR_ARG, "hc_get_info: null context");
+    if (qual_alphabet) *qual_alphabet = c->have_reads ? c->view.K : 0;
+    if (store_bytes) *store_bytes = c->store_bytes;
+    if (x_edge_lo) *x_edge_lo = c->params.edge.lo;
+    if (x_edge_hi) *x_edge_hi = c->params.edge.hi;
+    if (x_ov_lo) *x_ov_lo = c->params.ov.lo;
+    if (x_ov_hi) *x_ov_hi = c->params.ov.hi;
+    return HC_OK;
+}
+
+}  // extern "C"

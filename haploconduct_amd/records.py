@@ -1,0 +1,63 @@
+"""numpy views of the C-ABI records (include/hcedge.h)."""
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._native import hc_settings
+
+# hc_overlap_rec, 32 bytes
+OVERLAP_DTYPE = np.dtype(
+    [
+        ("read1", "<u4"), ("read2", "<u4"), ("pos1", "<u4"), ("pos2", "<u4"),
+        ("ori1", "u1"), ("ori2", "u1"), ("ord", "u1"), ("flags", "u1"),
+        ("len1", "<u4"), ("len2", "<u4"), ("perc", "<u4"),
+    ],
+    align=False,
+)
+assert OVERLAP_DTYPE.itemsize == 32
+
+# hc_result_rec, 24 bytes
+RESULT_DTYPE = np.dtype([("x1", "<f8"), ("x2", "<f8"), ("mm", "<u4"), ("n_cls", "<u4")], align=False)
+assert RESULT_DTYPE.itemsize == 24
+
+CLS_DROP, CLS_NONEDGE, CLS_EDGE, CLS_EDGE_MC, CLS_AMBIG, CLS_ERROR = 0, 1, 2, 3, 4, 7
+CLS_NAMES = {0: "drop", 1: "nonedge", 2: "edge", 3: "edge_mc", 4: "ambig", 7: "error"}
+
+FLAG_ADD_DUPLICATES = 0x1
+FLAG_RESOLVE_ORIENTATIONS = 0x2
+FLAG_IGNORE_INCLUSIONS = 0x4
+FLAG_RELAX_PE_EDGES = 0x8
+FLAG_ALLOW_SPACES = 0x10
+FLAG_VERBOSE = 0x20
+
+
+@dataclass
+class Settings:
+    """The ProgramSettings fields the hot path reads (reference src/Types.h:19-67),
+    with the defaults of src/ViralQuasispecies.cpp:49-99."""
+
+    edge_threshold: float = 0.99
+    ov_threshold: float = 0.9
+    merge_contigs: float = 0.0
+    mismatch: float = 0.0
+    min_read_len: int = 0
+    min_overlap_len: int = 150
+    min_overlap_perc: int = 0
+    flags: int = FLAG_RESOLVE_ORIENTATIONS
+    max_overlaps: int = 100000000
+    device: int = 0
+    n_threads: int = 1
+
+    def to_c(self):
+        return hc_settings(
+            self.edge_threshold, self.ov_threshold, self.merge_contigs, self.mismatch, self.min_read_len,
+            self.min_overlap_len, self.min_overlap_perc, self.flags, self.max_overlaps, self.device, self.n_threads,
+        )
+
+
+def result_n(res):
+    return res["n_cls"] & 0x0FFFFFFF
+
+
+def result_cls(res):
+    return res["n_cls"] >> 28

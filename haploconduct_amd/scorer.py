@@ -1,0 +1,97 @@
+"""EdgeScorer — Python face of the hc_ctx C-ABI (include/hcedge.h).
+
+It plays the role of the reference's ``EdgeCalculator`` object for the scoring half
+of the path (reference src/EdgeCalculator.h:25-64): constructed from the settings,
+given the reads once, then fed batches of candidate overlaps."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .records import OVERLAP_DTYPE, RESULT_DTYPE, Settings
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class EdgeScorer:
+    def __init__(self, settings: Settings = None):
+        self.settings = settings or Settings()
+        self._cs = self.settings.to_c()
+        self._ctx = C.c_void_p()
+        N.check(N.lib.hc_create(C.byref(self._ctx), C.byref(self._cs)), "hc_create")
+        self._reads = None
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            N.lib.hc_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- reads --------------------------------------------------------------
+    def set_reads(self, reads):
+        self._reads = reads
+        N.check(
+            N.lib.hc_set_reads(self._ctx, _ptr(reads.bases), _ptr(reads.quals), _ptr(reads.seq_off),
+                               _ptr(reads.read_first_seq), reads.n_reads),
+            "hc_set_reads",
+        )
+
+    def info(self):
+        k, sb = C.c_uint32(), C.c_uint64()
+        d = [C.c_double() for _ in range(4)]
+        N.check(N.lib.hc_get_info(self._ctx, C.byref(k), C.byref(sb), *[C.byref(x) for x in d]), "hc_get_info")
+        return {"qual_alphabet": k.value, "store_bytes": sb.value, "x_edge": (d[0].value, d[1].value),
+                "x_ov": (d[2].value, d[3].value)}
+
+    # -- scoring ------------------------------------------------------------
+    def score_batch(self, overlaps):
+        """Host buffers in, host buffers out (hc_score_batch)."""
+        ov = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE)
+        out = np.empty(ov.shape[0], dtype=RESULT_DTYPE)
+        N.check(N.lib.hc_score_batch(self._ctx, _ptr(ov), ov.shape[0], _ptr(out)), "hc_score_batch")
+        return out
+
+    def score_batch_device(self, d_in_ptr, n, d_out_ptr, stream=None):
+        """Device pointers (ints, e.g. torch tensor .data_ptr()); asynchronous."""
+        N.check(N.lib.hc_score_batch_device(self._ctx, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr),
+                                            C.c_void_p(stream or 0)), "hc_score_batch_device")
+
+    def synchronize(self):
+        N.check(N.lib.hc_synchronize(self._ctx), "hc_synchronize")
+
+    def time_kernel(self, d_in_ptr, n, d_out_ptr, iters):
+        ms = C.c_float()
+        N.check(N.lib.hc_time_score_kernel(self._ctx, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), iters,
+                                           C.byref(ms)), "hc_time_score_kernel")
+        return float(ms.value)
+
+    def count_positions_device(self, d_in_ptr, n):
+        a, b = C.c_uint64(), C.c_uint64()
+        N.check(N.lib.hc_count_positions_device(self._ctx, C.c_void_p(d_in_ptr), n, C.byref(a), C.byref(b)),
+                "hc_count_positions_device")
+        return int(a.value), int(b.value)
+
+    def finalize(self, results, allow_errors=False):
+        """Host libm finalisation -> (score, mismatch_rate, cls) arrays (hc_finalize_batch)."""
+        res = np.ascontiguousarray(results, dtype=RESULT_DTYPE)
+        n = res.shape[0]
+        score = np.empty(n, np.float64)
+        mrate = np.empty(n, np.float64)
+        cls = np.empty(n, np.uint32)
+        st = N.lib.hc_finalize_batch(C.byref(self._cs), _ptr(res), n, _ptr(score), _ptr(mrate), _ptr(cls))
+        if st != 0 and not (allow_errors and st == -10):
+            raise N.HcError(st, "hc_finalize_batch")
+        return score, mrate, cls

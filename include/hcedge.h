@@ -1,0 +1,187 @@
+/*
+ * hcedge.h — C ABI of libhcedge.so: the MI355X (gfx950) replacement for the
+ * overlap-graph edge-calculation hot path of HaploConduct's ViralQuasispecies
+ * binary.
+ *
+ * The reference has no FFI of its own (it is one statically linked C++ binary),
+ * so this header *defines* the cut.  Every entry point names the reference
+ * interface it replaces (file:line relative to the HaploConduct source tree).
+ *
+ *   reference                                        this ABI
+ *   ------------------------------------------------ ---------------------------
+ *   EdgeCalculator::EdgeCalculator (EdgeCalculator.h:43-53)   hc_create
+ *     + ProgramSettings fields it reads (Types.h:19-67)       hc_settings
+ *   FastqStorage::m_read_vec / Read::get_seq,get_phred,
+ *     get_rev_comp,get_rev_phred (FastqStorage.h:48-55,
+ *     Read.h:144-201)                                         hc_set_reads
+ *   the `omp for` body of EdgeCalculator::process_overlaps
+ *     = compute_overlap + 3-way classification
+ *     (EdgeCalculator.cpp:400-414, 143-385, 67-139, 26-63)    hc_score_batch[_device]
+ *   score = exp(...), 0.5*(ov1+ov2) / min(ov1,ov2)
+ *     (EdgeCalculator.cpp:137-138, 254-261)                   hc_finalize
+ *   EdgeCalculator::~EdgeCalculator                           hc_destroy
+ *   EdgeCalculator::construct_edges() and the serial insert
+ *     of process_overlaps (EdgeCalculator.cpp:427-545,
+ *     561-666) over OverlapGraph (OverlapGraph.cpp:94-311)    hc_ec_* (host side, below)
+ *
+ * Conventions: plain pointers and sizes only; every function returns HC_OK (0)
+ * or a negative hc_status and never calls exit()/abort(); the caller owns all
+ * host buffers; one context is used from one thread at a time (the reference
+ * has exactly one batch in flight, EdgeCalculator.cpp:636-644).
+ */
+#ifndef HCEDGE_H_
+#define HCEDGE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum hc_status {
+    HC_OK = 0,
+    HC_ERR_ARG = -1,         /* null pointer / bad size / bad enum value                */
+    HC_ERR_NOMEM = -2,       /* host or device allocation failed                        */
+    HC_ERR_HIP = -3,         /* a HIP runtime call failed (hc_last_error has the text)  */
+    HC_ERR_NO_DEVICE = -4,   /* no gfx950 device visible: there is NO CPU fallback      */
+    HC_ERR_STATE = -5,       /* call order violated (e.g. score before set_reads)       */
+    HC_ERR_BAD_READ = -6,    /* empty sequence / base+quality length mismatch           */
+    HC_ERR_BAD_OVERLAP = -7, /* read index out of range, read1==read2, bad ord/ori      */
+    HC_ERR_IO = -8,          /* file could not be opened / read / written               */
+    HC_ERR_FORMAT = -9,      /* input the reference would exit(1)/assert on             */
+    HC_ERR_DATA = -10        /* an overlap touched a base/quality byte the reference
+                                asserts on (EdgeCalculator.cpp:29-30,61)                */
+} hc_status;
+
+/* ---- settings: the ProgramSettings fields the hot path reads (Types.h:19-67) ---- */
+#define HC_FLAG_ADD_DUPLICATES       0x1u /* --add_duplicates                            */
+#define HC_FLAG_RESOLVE_ORIENTATIONS 0x2u /* --resolve_orientations (default true)       */
+#define HC_FLAG_IGNORE_INCLUSIONS    0x4u /* --ignore_inclusions                         */
+#define HC_FLAG_RELAX_PE_EDGES       0x8u /* --relax_PE_edges                            */
+#define HC_FLAG_ALLOW_SPACES         0x10u /* --allow_spaced_overlaps                    */
+#define HC_FLAG_VERBOSE              0x20u /* --verbose                                  */
+
+typedef struct hc_settings {
+    double edge_threshold;     /* --edge_threshold  (default 0.99)                       */
+    double ov_threshold;       /* --ov_threshold    (default 0.9)                        */
+    double merge_contigs;      /* --merge_contigs   (default 0)                          */
+    double mismatch;           /* --mismatch        (default 0)                          */
+    uint32_t min_read_len;     /* --min_read_len    (default 0)                          */
+    uint32_t min_overlap_len;  /* --min_overlap_len (default 150)  [host prefilter]      */
+    uint32_t min_overlap_perc; /* --min_overlap_perc (default 0)   [host prefilter]      */
+    uint32_t flags;            /* HC_FLAG_*                                              */
+    uint64_t max_overlaps;     /* --max_ov          (default 1e8)  [host parser]         */
+    int32_t device;            /* HIP device ordinal                                     */
+    uint32_t n_threads;        /* --threads: host-side worker threads (parser)           */
+} hc_settings;
+
+/* ---- one candidate overlap, as it enters process_overlaps (Overlap.h:20-73) ----
+ * read1/read2 index FastqStorage::m_read_vec (singles first, then pairs,
+ * FastqStorage.h:88-97); the id->index map lookup of EdgeCalculator.cpp:164-171
+ * is done once by the host parser. */
+typedef struct hc_overlap_rec {
+    uint32_t read1, read2;
+    uint32_t pos1, pos2;
+    uint8_t ori1, ori2; /* 1 = "+", 0 = "-"                                               */
+    uint8_t ord;        /* '-', '1' or '2'                                                */
+    uint8_t flags;      /* bit0: type1=='p', bit1: type2=='p' as WRITTEN in the file
+                           (prefilter only; scoring uses the reads' own types,
+                           EdgeCalculator.cpp:186-187)                                    */
+    uint32_t len1, len2;
+    uint32_t perc;      /* Overlap::get_perc() (Overlap.h:203-210)                        */
+} hc_overlap_rec;       /* 32 bytes */
+
+/* ---- per-candidate result of the device pass --------------------------------
+ * x_k = (1.0/total_len) * total_score of sub-overlap k, i.e. the argument of the
+ * final exp() at EdgeCalculator.cpp:137-138, bit-identical to the reference's
+ * value (same libm-built log table, same summation order, no FMA contraction).
+ * x_k = -inf encodes every `return 0` of overlap_score (score 0, mismatch 1.0).
+ * x2 = NaN for s-s overlaps (one sub-overlap).
+ * (mm, n): mismatch_count / total_len of the sub-overlap with the larger
+ * mismatch rate (max() at EdgeCalculator.cpp:254); 1/1 for early exits.
+ * cls: the 3-way decision of EdgeCalculator.cpp:404-413 taken on the device in
+ * x-space (thresholds pre-inverted through the host libm exp);
+ * HC_CLS_AMBIG = x inside the (normally empty) guard band, host decides. */
+#define HC_CLS_DROP 0u
+#define HC_CLS_NONEDGE 1u /* goes to nonedge_overlaps.txt (EdgeCalculator.cpp:410-413)  */
+#define HC_CLS_EDGE 2u    /* score > edge_threshold (EdgeCalculator.cpp:404)             */
+#define HC_CLS_EDGE_MC 3u /* mismatch_rate <= merge_contigs (EdgeCalculator.cpp:407)     */
+#define HC_CLS_AMBIG 4u
+#define HC_CLS_ERROR 7u   /* touched an invalid base / quality byte                      */
+
+typedef struct hc_result_rec {
+    double x1;
+    double x2;
+    uint32_t mm;
+    uint32_t n_cls; /* bits 0..27 total_len, bits 28..31 HC_CLS_*                         */
+} hc_result_rec;    /* 24 bytes */
+
+#define HC_RES_N(r) ((r).n_cls & 0x0FFFFFFFu)
+#define HC_RES_CLS(r) ((r).n_cls >> 28)
+
+typedef struct hc_ctx hc_ctx; /* opaque: device read store, log-prob table, streams */
+
+/* Library / device ----------------------------------------------------------- */
+const char* hc_version(void);
+const char* hc_strerror(int status);
+/* Text of the last failure on this thread ("" if none). */
+const char* hc_last_error(void);
+/* Number of visible HIP devices (0 if none); does not create a context. */
+int hc_device_count(void);
+
+/* Replaces EdgeCalculator's constructor (EdgeCalculator.h:43-53).  Builds the
+ * pow/log table with the host libm exactly as EdgeCalculator.cpp:41,44,52,60 do. */
+int hc_create(hc_ctx** out, const hc_settings* settings);
+int hc_destroy(hc_ctx* ctx);
+
+/* Replaces the Read getters used by compute_overlap (Read.h:144-201).
+ *   bases, quals : concatenated sequences / quality strings (ASCII, 1 byte per base)
+ *   seq_off      : n_seq+1 offsets into bases/quals
+ *   read_first_seq : n_reads+1; read r owns sequences [read_first_seq[r], read_first_seq[r+1]):
+ *                  one (single-end) or two (/1, /2 of a pair)
+ * Buffers are borrowed until return; the store (both orientations, re-encoded)
+ * lives in HBM until hc_destroy or the next hc_set_reads. */
+int hc_set_reads(hc_ctx* ctx, const uint8_t* bases, const uint8_t* quals, const uint64_t* seq_off,
+                 const uint32_t* read_first_seq, uint32_t n_reads);
+
+/* Replaces the omp-for of process_overlaps (EdgeCalculator.cpp:400-414).
+ * Synchronous; out[i] <-> in[i]; host buffers. */
+int hc_score_batch(hc_ctx* ctx, const hc_overlap_rec* in, uint64_t n, hc_result_rec* out);
+
+/* Same, but in/out are DEVICE pointers (hipMalloc'd, or torch CUDA tensors) and
+ * the launch is asynchronous on `hip_stream` (a hipStream_t, NULL = the context's
+ * own stream).  This is the entry bench.py times: inputs already resident in HBM. */
+int hc_score_batch_device(hc_ctx* ctx, const void* d_in, uint64_t n, void* d_out, void* hip_stream);
+int hc_synchronize(hc_ctx* ctx);
+
+/* Times `iters` back-to-back launches of the scoring kernel on the context's own
+ * stream with hipEvents recorded on THAT stream; returns the mean milliseconds
+ * per launch.  Used for the roofline figure. */
+int hc_time_score_kernel(hc_ctx* ctx, const void* d_in, uint64_t n, void* d_out, int iters, float* ms_per_launch);
+
+/* Sum over the batch of the overlapped positions sum_sub L_sub,
+ * L_sub = min(L1 - pos, L2) (EdgeCalculator.cpp:86-88), computed on the device:
+ * the exact multiplier for the algorithmic-bytes figure 32 + 16 + 4*L_sub. */
+int hc_count_positions_device(hc_ctx* ctx, const void* d_in, uint64_t n, uint64_t* total_positions,
+                              uint64_t* total_subs);
+
+/* Host finalisation of one record with the host libm exp(): score as the
+ * reference returns it (EdgeCalculator.cpp:137-138, 254-261), mismatch_rate
+ * (EdgeCalculator.cpp:132) and the class, AMBIG resolved. Pure function. */
+int hc_finalize(const hc_settings* s, const hc_result_rec* r, double* score, double* mismatch_rate, uint32_t* cls);
+
+/* hc_finalize over n records; any of the three output arrays may be NULL.  Returns
+ * HC_ERR_DATA (after filling everything) if some record has class HC_CLS_ERROR. */
+int hc_finalize_batch(const hc_settings* s, const hc_result_rec* r, uint64_t n, double* score, double* mismatch_rate,
+                      uint32_t* cls);
+
+/* Introspection used by the tests: quality alphabet size K of the current store,
+ * and the x-space guard band [lo, hi] of a threshold (x <= lo fails, x > hi passes). */
+int hc_get_info(hc_ctx* ctx, uint32_t* qual_alphabet, uint64_t* store_bytes, double* x_edge_lo,
+                double* x_edge_hi, double* x_ov_lo, double* x_ov_hi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HCEDGE_H_ */

@@ -1,0 +1,253 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bit-exact bar: x1/x2 (the argument of the final exp), mismatch counts,
+total_len, the 3-way admission class, and — after host finalisation with the same
+libm — score and mismatch_rate as IEEE bit patterns."""
+import numpy as np
+import pytest
+
+import haploconduct_amd as hc
+from haploconduct_amd import synth
+from haploconduct_amd.records import OVERLAP_DTYPE, result_cls, result_n
+
+pytestmark = pytest.mark.gpu
+
+HQ = np.array([20, 30, 37, 37, 37, 40, 40, 40, 40], dtype=np.uint8) + 33
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def check_parity(oracle, reads, settings, cand, expect_classes=None):
+    ref = oracle.score_batch(reads, settings, cand)
+    assert (ref["status"] == 0).all(), "oracle rejected an input the test meant to be valid"
+    with hc.EdgeScorer(settings) as sc:
+        sc.set_reads(reads)
+        res = sc.score_batch(cand)
+        score, mrate, cls = sc.finalize(res)
+    assert np.array_equal(bits(res["x1"]), bits(ref["x1"])), "x1 (sub-overlap 1 mean log-prob) not bit-exact"
+    x2_nan = np.isnan(ref["x2"])
+    assert np.array_equal(np.isnan(res["x2"]), x2_nan)
+    assert np.array_equal(bits(res["x2"])[~x2_nan], bits(ref["x2"])[~x2_nan]), "x2 not bit-exact"
+    assert np.array_equal(res["mm"], ref["mm"]), "mismatch_count differs"
+    assert np.array_equal(result_n(res), ref["n"]), "total_len differs"
+    assert np.array_equal(cls, ref["cls"]), "admission class differs (host-finalised)"
+    dev = result_cls(res)
+    assert ((dev == ref["cls"]) | (dev == 4)).all(), "device-side admission class differs"
+    assert (dev == 4).mean() < 1e-3, "guard band should be (nearly) empty"
+    assert np.array_equal(bits(score), bits(ref["score"])), "score not bit-exact"
+    assert np.array_equal(bits(mrate), bits(ref["mismatch_rate"])), "mismatch_rate not bit-exact"
+    # the north star's tolerance, stated: |score - ref| <= 1e-6 (we are at 0)
+    assert np.max(np.abs(score - ref["score"]), initial=0.0) <= 1e-6
+    if expect_classes:
+        present = set(np.unique(ref["cls"]).tolist())
+        assert set(expect_classes) <= present, f"test data should exercise classes {expect_classes}, has {present}"
+    return ref, res
+
+
+def test_pp_all_orientations(oracle):
+    reads, meta = synth.make_paired_dataset(1500, 3000, flip_frac=0.3, seed=21)
+    reads.quals[:] = HQ[np.random.default_rng(5).integers(0, HQ.size, reads.quals.size)]
+    cand = synth.paired_candidates(meta, n_candidates=20000, seed=22)
+    assert set(np.unique(cand["ord"]).tolist()) == {ord("1"), ord("2")}
+    assert (cand["ori1"] == 0).any() and (cand["ori2"] == 0).any()
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.9)
+    check_parity(oracle, reads, st, cand, expect_classes=[0, 1, 2])
+
+
+def test_pp_survey_quality_mix_merge_contigs(oracle):
+    # SURVEY §8(d) quality set {2,...,40}: clause 1 almost never fires, clause 2 (0 mismatches) does
+    reads, meta = synth.make_paired_dataset(1200, 2500, flip_frac=0.25, seed=31)
+    cand = synth.paired_candidates(meta, n_candidates=15000, seed=32)
+    for mc in (0.0, 0.01):
+        st = hc.Settings(edge_threshold=0.97, merge_contigs=mc)
+        ref, _ = check_parity(oracle, reads, st, cand)
+        assert (ref["cls"] == 3).any()
+
+
+def test_ss_mixed_lengths_both_orientations(oracle):
+    reads, meta = synth.make_single_dataset(1500, 6000, len_lo=150, len_hi=1200, flip_frac=0.4, seed=41, quals=HQ,
+                                            log_uniform=True)
+    cand = synth.single_candidates(meta, min_overlap=60, n_candidates=20000)
+    st = hc.Settings(edge_threshold=0.995, ov_threshold=0.9, min_overlap_len=100)
+    ref, _ = check_parity(oracle, reads, st, cand, expect_classes=[0, 2])
+    assert np.isnan(ref["x2"]).all()
+
+
+def test_polyte_threshold_one(oracle):
+    # POLYTE iterations run with --edge_threshold=1: admission is "zero mismatches" only (polyte.py:620)
+    reads, meta = synth.make_single_dataset(800, 3000, len_lo=250, len_hi=250, flip_frac=0.5, seed=51, quals=HQ)
+    cand = synth.single_candidates(meta, min_overlap=127)
+    st = hc.Settings(edge_threshold=1.0, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=127)
+    ref, _ = check_parity(oracle, reads, st, cand)
+    assert not (ref["cls"] == 2).any() and (ref["cls"] == 3).any()
+
+
+def _mixed_reads(seed, n_single=300, n_pair=300, glen=2500):
+    """Singles (contig-like, 200-500 bp) and pairs (2x150) over one genome."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rng.integers(0, 4, glen)]
+    singles, pairs, spos, ppos = [], [], [], []
+
+    def noisy(seg):
+        seg = seg.copy()
+        k = rng.random(seg.size) < 0.004
+        seg[k] = acgt[rng.integers(0, 4, int(k.sum()))]
+        seg[rng.random(seg.size) < 0.002] = ord("N")
+        return seg.tobytes()
+
+    def q(n):
+        return HQ[rng.integers(0, HQ.size, n)].tobytes()
+
+    for _ in range(n_single):
+        L = int(rng.integers(200, 500))
+        s = int(rng.integers(0, glen - L))
+        singles.append((noisy(genome[s:s + L]), q(L)))
+        spos.append((s, L))
+    for _ in range(n_pair):
+        ins = int(rng.integers(350, 600))
+        s = int(rng.integers(0, glen - ins))
+        pairs.append(((noisy(genome[s:s + 150]), q(150)), (noisy(genome[s + ins - 150:s + ins]), q(150))))
+        ppos.append((s, ins))
+    return hc.ReadSet.from_lists(singles, pairs), spos, ppos
+
+
+def test_sp_ps_mixed_types(oracle):
+    reads, spos, ppos = _mixed_reads(61)
+    ns = len(spos)
+    rec = []
+    # s-p: single A covers both mates of pair B.  p-s: /1 of pair A starts before single B ... enumerate by geometry
+    for i, (s, L) in enumerate(spos):
+        for j, (ps, ins) in enumerate(ppos):
+            p1 = ps - s                  # /1 of the pair starts at p1 inside the single
+            p2 = ps + ins - 150 - s      # /2 of the pair starts at p2 inside the single
+            if 0 <= p1 < L - 40 and 0 <= p2 < L - 40:
+                rec.append((i, ns + j, p1, p2, 1, 1, ord("-"), 2, min(L - p1, 150), min(L - p2, 150), 90))
+            q1 = s - ps                  # single starts at q1 inside /1 of the pair
+            q2 = ps + ins - 150 - s      # /2 of the pair starts at q2 inside the single
+            if 0 <= q1 < 110 and 0 <= q2 < L - 40:
+                rec.append((ns + j, i, q1, q2, 1, 1, ord("-"), 1, min(150 - q1, L), min(L - q2, 150), 90))
+    cand = np.array(rec, dtype=OVERLAP_DTYPE)
+    assert cand.size > 500
+    # add wrong-orientation variants too (they score badly but must agree)
+    flip = cand.copy()
+    flip["ori1"] = 0
+    flip2 = cand.copy()
+    flip2["ori2"] = 0
+    both = cand.copy()
+    both["ori1"] = 0
+    both["ori2"] = 0
+    cand = np.concatenate([cand, flip[:400], flip2[:400], both[:400]])
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.5)
+    ref, _ = check_parity(oracle, reads, st, cand, expect_classes=[0, 2])
+    assert (ref["n_subs"] == 2).all()
+
+
+def test_n_rich_q0_and_wide_alphabet_uint16_symbols(oracle):
+    # > 32 distinct quality bytes forces 16-bit symbols; Q0 ('!') and 'N' runs as in savage/example read @2000
+    rng = np.random.default_rng(71)
+    reads, meta = synth.make_single_dataset(600, 2500, len_lo=200, len_hi=400, flip_frac=0.3, seed=72, n_rate=0.05)
+    reads.quals[:] = (rng.integers(0, 60, reads.quals.size) + 33).astype(np.uint8)
+    reads.quals[rng.random(reads.quals.size) < 0.05] = ord("!")
+    cand = synth.single_candidates(meta, min_overlap=50, n_candidates=8000)
+    st = hc.Settings(edge_threshold=0.5, ov_threshold=0.1)
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        assert sc.info()["qual_alphabet"] > 32
+    check_parity(oracle, reads, st, cand)
+
+
+def test_all_n_overlap_and_early_exits(oracle):
+    singles = [("N" * 120, "I" * 120), ("ACGT" * 30, "I" * 120), ("ACGT" * 10, "5" * 40), ("ACGT" * 30, "I" * 120)]
+    reads = hc.ReadSet.from_lists(singles)
+    rows = [
+        (0, 1, 0, 0, 1, 1, ord("-"), 0, 120, 0, 100),    # all-N: total_len == 0 -> score 0
+        (1, 3, 0, 0, 1, 1, ord("-"), 0, 120, 0, 100),    # identical: perfect
+        (1, 3, 4, 0, 1, 1, ord("-"), 0, 116, 0, 96),     # in phase: perfect
+        (1, 3, 1, 0, 1, 1, ord("-"), 0, 119, 0, 99),     # out of phase: all mismatches
+        (1, 3, 120, 0, 1, 1, ord("-"), 0, 1, 0, 1),      # pos == len: early exit (:76)
+        (1, 3, 500, 0, 1, 1, ord("-"), 0, 1, 0, 1),      # pos > len
+        (1, 2, 100, 0, 1, 1, ord("-"), 0, 20, 0, 50),    # short second read
+        (2, 1, 0, 0, 0, 0, ord("-"), 0, 40, 0, 100),     # both reverse-complemented
+    ]
+    cand = np.array(rows, dtype=OVERLAP_DTYPE)
+    for st in (hc.Settings(edge_threshold=0.9), hc.Settings(edge_threshold=0.9, min_read_len=100),
+               hc.Settings(edge_threshold=0.9, merge_contigs=1.0), hc.Settings(edge_threshold=-1.0, ov_threshold=-1.0),
+               hc.Settings(edge_threshold=0.0, ov_threshold=0.0)):
+        check_parity(oracle, reads, st, cand)
+
+
+def test_mismatch_setting_rejects(oracle):
+    reads, meta = synth.make_single_dataset(500, 2000, len_lo=150, len_hi=300, flip_frac=0.3, seed=81, quals=HQ)
+    cand = synth.single_candidates(meta, min_overlap=60, n_candidates=6000)
+    for mm_setting in (1e-4, 0.05, 0.5):
+        st = hc.Settings(edge_threshold=0.97, ov_threshold=0.5, mismatch=mm_setting)
+        ref, _ = check_parity(oracle, reads, st, cand)
+        assert np.isinf(ref["x1"]).any(), "--mismatch should reject some overlaps"
+
+
+def test_threshold_sweep_decisions(oracle):
+    reads, meta = synth.make_paired_dataset(800, 2000, flip_frac=0.2, seed=91)
+    reads.quals[:] = HQ[np.random.default_rng(6).integers(0, HQ.size, reads.quals.size)]
+    cand = synth.paired_candidates(meta, n_candidates=8000, seed=92)
+    for et, ot, mc in ((0.97, 0.9, 0.0), (0.995, 0.9, 0.0), (1.0, 0.9, 0.0), (0.9, 0.95, 0.01), (0.99, 0.0, 0.0)):
+        check_parity(oracle, reads, hc.Settings(edge_threshold=et, ov_threshold=ot, merge_contigs=mc), cand)
+
+
+def test_invalid_bases_and_quals_are_errors():
+    # lower-case bases in a PAIRED read abort the reference (EdgeCalculator.cpp:29-30); quality < '!' too (:61)
+    singles = [("ACGTACGTACGTACGTACGT", "IIIIIIIIIIIIIIIIIIII"), ("ACGTACGTacGTACGTACGT", "IIIIIIIIIIIIIIIIIIII"),
+               ("ACGTACGTACGTACGTACGT", "IIIIIIII IIIIIIIIIII"), ("ACGTACGTACGTACGTACGT", "IIIIIIIIIIIIIIIIIIII")]
+    reads = hc.ReadSet.from_lists(singles)
+    rows = [(0, 3, 0, 0, 1, 1, ord("-"), 0, 20, 0, 100), (0, 1, 0, 0, 1, 1, ord("-"), 0, 20, 0, 100),
+            (0, 2, 0, 0, 1, 1, ord("-"), 0, 20, 0, 100), (0, 1, 12, 0, 1, 1, ord("-"), 0, 8, 0, 40),
+            (3, 1, 0, 0, 1, 0, ord("-"), 0, 20, 0, 100)]
+    cand = np.array(rows, dtype=OVERLAP_DTYPE)
+    with hc.EdgeScorer(hc.Settings(edge_threshold=0.9)) as sc:
+        sc.set_reads(reads)
+        res = sc.score_batch(cand)
+        cls = result_cls(res)
+        # row 3 overlaps read 1 at positions 0..7 only (the lower-case bases sit at 8,9): valid
+        assert cls.tolist() == [2, 7, 7, 2, 7]
+        with pytest.raises(hc.HcError):
+            sc.finalize(res)
+
+
+def test_api_errors_and_empty_batch():
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        with pytest.raises(hc.HcError):
+            sc.score_batch(np.zeros(1, dtype=OVERLAP_DTYPE))  # no reads yet
+        reads = hc.ReadSet.from_lists([("ACGT", "IIII"), ("ACGT", "IIII")])
+        sc.set_reads(reads)
+        assert sc.score_batch(np.zeros(0, dtype=OVERLAP_DTYPE)).size == 0
+        bad = np.zeros(2, dtype=OVERLAP_DTYPE)
+        bad[0]["read1"], bad[0]["read2"] = 0, 0     # self overlap
+        bad[1]["read1"], bad[1]["read2"] = 0, 9     # out of range
+        assert result_cls(sc.score_batch(bad)).tolist() == [7, 7]
+    empty = hc.ReadSet(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(2, np.uint64), np.array([0, 1], np.uint32),
+                       np.zeros(1, np.uint64))
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        with pytest.raises(hc.HcError):
+            sc.set_reads(empty)  # empty sequence: FastqStorage exits (FastqStorage.cpp:143-146)
+
+
+def test_device_resident_entry_matches_host_entry(oracle):
+    import torch
+
+    reads, meta = synth.make_paired_dataset(1000, 2500, seed=101)
+    cand = synth.paired_candidates(meta, n_candidates=10000, seed=102)
+    st = hc.Settings(edge_threshold=0.97)
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        host = sc.score_batch(cand)
+        d_in = torch.from_numpy(cand.view(np.uint8).reshape(-1)).cuda()
+        d_out = torch.empty(cand.size * 24, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        sc.score_batch_device(d_in.data_ptr(), cand.size, d_out.data_ptr())
+        sc.synchronize()
+        dev = d_out.cpu().numpy().view(hc.RESULT_DTYPE)
+        assert np.array_equal(dev.view(np.uint8), host.view(np.uint8))
+        pos, subs = sc.count_positions_device(d_in.data_ptr(), cand.size)
+    ref = oracle.score_batch(reads, st, cand)
+    assert pos == int(ref["positions"].sum()) and subs == int(ref["n_subs"].sum())
