@@ -48,21 +48,23 @@ def build_workload(workload, rank):
                          "read_pairs": n_pairs, "candidates_per_gpu": n_cand, "genome_len": glen}
 
 
-def cpu_baseline(reads, settings, cand, budget_s=15.0):
+def cpu_baseline(reads, settings, cand, budget_s=12.0):
+    """The oracle (a port of the reference algorithm) on the host cores, ~budget_s of CPU wall time."""
     from tests import _oracle
 
     cores = os.cpu_count() or 1
-    probe = cand[: min(cand.size, 20000)]
-    t0 = time.perf_counter()
-    _oracle.score_batch(reads, settings, probe, n_threads=cores)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    n = int(min(cand.size, max(probe.size, probe.size / dt * budget_s)))
-    sample = cand[:n]
-    t0 = time.perf_counter()
-    _oracle.score_batch(reads, settings, sample, n_threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "candidate overlaps/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} candidates of the rank-0 batch, oracle/hc_oracle.c with {cores} OpenMP threads, {dt:.1f} s"}
+    sample = cand[: min(cand.size, 1000000)]
+    _oracle.score_batch(reads, settings, sample[:20000], n_threads=cores)  # spin the OpenMP team up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        _oracle.score_batch(reads, settings, sample, n_threads=cores)
+        done += sample.size
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return {"value": done / dt, "unit": "candidate overlaps/s", "cores": cores, "kind": "port",
+            "sample": f"{done} candidates ({done // sample.size} passes over the first {sample.size} of the rank-0 batch), "
+                      f"oracle/hc_oracle.c with {cores} OpenMP threads, {dt:.1f} s"}
 
 
 def main():

@@ -23,6 +23,14 @@ if not os.path.exists(lib_path):
         "or `make -C haploconduct_amd/csrc`.  haploconduct_amd has no CPU fallback."
     )
 
+# PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in
+# one process cannot both own the GPU, so when torch is installed let it load its runtime
+# first: libhcedge.so (linked against libamdhip64.so.7 by SONAME) then binds to that copy.
+try:  # pragma: no cover - depends on the environment
+    import torch  # noqa: F401
+except Exception:  # torch is optional for the C ABI itself
+    pass
+
 lib = C.CDLL(lib_path)
 
 
