@@ -18,7 +18,8 @@
 
 namespace hc {
 hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
-                         const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, void* sym, uint8_t* seq_flags,
+                         const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
+                         uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
                          hipStream_t stream);
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
                         uint64_t n, hc_result_rec* out, uint32_t n_cu, hipStream_t stream);
@@ -50,10 +51,7 @@ struct hc_ctx {
     // read store
     bool have_reads = false;
     void* d_sym = nullptr;
-    uint64_t* d_seq_off = nullptr;
-    uint32_t* d_seq_len = nullptr;
-    uint8_t* d_seq_flags = nullptr;
-    uint32_t* d_read_first_seq = nullptr;
+    hc::ReadDesc* d_reads = nullptr;
     double* d_lut = nullptr;
     uint64_t store_bytes = 0;
     hc::StoreView view{};
@@ -162,16 +160,10 @@ int hc_create(hc_ctx** out, const hc_settings* settings) {
 
 static void free_store(hc_ctx* c) {
     if (c->d_sym) (void)hipFree(c->d_sym);
-    if (c->d_seq_off) (void)hipFree(c->d_seq_off);
-    if (c->d_seq_len) (void)hipFree(c->d_seq_len);
-    if (c->d_seq_flags) (void)hipFree(c->d_seq_flags);
-    if (c->d_read_first_seq) (void)hipFree(c->d_read_first_seq);
+    if (c->d_reads) (void)hipFree(c->d_reads);
     if (c->d_lut) (void)hipFree(c->d_lut);
     c->d_sym = nullptr;
-    c->d_seq_off = nullptr;
-    c->d_seq_len = nullptr;
-    c->d_seq_flags = nullptr;
-    c->d_read_first_seq = nullptr;
+    c->d_reads = nullptr;
     c->d_lut = nullptr;
     c->have_reads = false;
     c->store_bytes = 0;
@@ -192,21 +184,33 @@ int hc_destroy(hc_ctx* c) {
     return HC_OK;
 }
 
-// The log-probability table, K x K x 2 doubles: [qa][qb][mismatch].  Built with the HOST
-// libm by the reference's own expressions (EdgeCalculator.cpp:41,44,52,60) so that every
-// term the device adds is bit-identical to the reference's log(p).
-static void build_lut(const std::vector<int>& phred, double mismatch_setting, std::vector<double>& lut) {
-    const size_t K = phred.size();
-    lut.assign(K * K * 2, 0.0);
+// The log-probability table.  Built with the HOST libm by the reference's own expressions
+// (EdgeCalculator.cpp:41,44,52,60) so that every term the device adds is bit-identical to the
+// reference's log(p).  Dimension Kp = K + 2: index K is the N row/column (0.0: the position is
+// skipped, :35-39), index K+1 the invalid-symbol row/column (NaN poison).  Layouts: hc_device.h.
+static void build_lut(const std::vector<int>& phred, double mismatch_setting, uint32_t symbytes, std::vector<double>& lut) {
+    const size_t K = phred.size(), Kp = K + 2;
     const double inf = std::numeric_limits<double>::infinity();
-    for (size_t a = 0; a < K; a++) {
-        const double p1 = pow(10, -phred[a] / 10.0);  // phred_to_prob, :59-63
-        for (size_t b = 0; b < K; b++) {
-            const double p2 = pow(10, -phred[b] / 10.0);
-            const double pm = (1 - p1) * (1 - p2) + (p1 * p2) / 3.0;                               // :41
-            const double px = p1 * (1 - p2) / 3.0 + p2 * (1 - p1) / 3.0 + (2 / 9.0) * p1 * p2;  // :44
-            lut[(a * K + b) * 2 + 0] = (pm < mismatch_setting) ? inf : log(pm);  // :49-52
-            lut[(a * K + b) * 2 + 1] = (px < mismatch_setting) ? inf : log(px);
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    const size_t row = symbytes == 1 ? hc::kLutRowBytesU8 / 8 : Kp * 2;  // doubles per qa row
+    lut.assign(Kp * row, 0.0);
+    for (size_t a = 0; a < Kp; a++) {
+        for (size_t b = 0; b < Kp; b++) {
+            double vm, vx;
+            if (a == K + 1 || b == K + 1) {
+                vm = vx = nan;
+            } else if (a == K || b == K) {
+                vm = vx = 0.0;
+            } else {
+                const double p1 = pow(10, -phred[a] / 10.0);  // phred_to_prob, :59-63
+                const double p2 = pow(10, -phred[b] / 10.0);
+                const double pm = (1 - p1) * (1 - p2) + (p1 * p2) / 3.0;                               // :41
+                const double px = p1 * (1 - p2) / 3.0 + p2 * (1 - p1) / 3.0 + (2 / 9.0) * p1 * p2;  // :44
+                vm = (pm < mismatch_setting) ? inf : log(pm);  // :49-52
+                vx = (px < mismatch_setting) ? inf : log(px);
+            }
+            lut[a * row + b * 2 + 0] = vm;
+            lut[a * row + b * 2 + 1] = vx;
         }
     }
 }
@@ -245,7 +249,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         }
     if (phred.empty()) phred.push_back(0);
     const uint32_t K = (uint32_t)phred.size();
-    const uint32_t symbytes = K <= 32 ? 1 : 2;
+    const uint32_t symbytes = (K + 2 <= 32) ? 1 : 2;
 
     std::vector<uint64_t> sym_off(n_seq ? n_seq : 1);
     uint64_t nsym = 0;
@@ -254,18 +258,19 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         nsym += 2 * hc::slot_stride(seq_len[q], symbytes);
     }
     std::vector<double> lut;
-    build_lut(phred, c->settings.mismatch, lut);
+    build_lut(phred, c->settings.mismatch, symbytes, lut);
 
     free_store(c);
-    uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_qmap = nullptr;
-    uint64_t* d_raw_off = nullptr;
+    uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_qmap = nullptr, *d_seq_bad = nullptr;
+    uint64_t *d_raw_off = nullptr, *d_seq_off = nullptr;
+    uint32_t* d_first = nullptr;
     const uint64_t sym_bytes_total = (nsym ? nsym : 1) * symbytes;
     HC_HIP(hipMalloc(&c->d_sym, sym_bytes_total));
-    HC_HIP(hipMalloc((void**)&c->d_seq_off, sizeof(uint64_t) * (n_seq ? n_seq : 1)));
-    HC_HIP(hipMalloc((void**)&c->d_seq_len, sizeof(uint32_t) * (n_seq ? n_seq : 1)));
-    HC_HIP(hipMalloc((void**)&c->d_seq_flags, (n_seq ? n_seq : 1)));
-    HC_HIP(hipMalloc((void**)&c->d_read_first_seq, sizeof(uint32_t) * (n_reads + 1)));
+    HC_HIP(hipMalloc((void**)&c->d_reads, sizeof(hc::ReadDesc) * (n_reads ? n_reads : 1)));
     HC_HIP(hipMalloc((void**)&c->d_lut, sizeof(double) * lut.size()));
+    HC_HIP(hipMalloc((void**)&d_seq_off, sizeof(uint64_t) * (n_seq ? n_seq : 1)));
+    HC_HIP(hipMalloc((void**)&d_seq_bad, (n_seq ? n_seq : 1)));
+    HC_HIP(hipMalloc((void**)&d_first, sizeof(uint32_t) * (n_reads + 1)));
     HC_HIP(hipMalloc((void**)&d_bases, total ? total : 1));
     HC_HIP(hipMalloc((void**)&d_quals, total ? total : 1));
     HC_HIP(hipMalloc((void**)&d_raw_off, sizeof(uint64_t) * (n_seq + 1)));
@@ -276,28 +281,27 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     }
     HC_HIP(hipMemcpyAsync(d_raw_off, seq_off, sizeof(uint64_t) * (n_seq + 1), hipMemcpyHostToDevice, c->stream));
     HC_HIP(hipMemcpyAsync(d_qmap, qmap, 256, hipMemcpyHostToDevice, c->stream));
-    HC_HIP(hipMemcpyAsync(c->d_seq_off, sym_off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, c->stream));
-    HC_HIP(hipMemcpyAsync(c->d_seq_len, seq_len.data(), sizeof(uint32_t) * n_seq, hipMemcpyHostToDevice, c->stream));
-    HC_HIP(hipMemcpyAsync(c->d_read_first_seq, read_first_seq, sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice,
-                          c->stream));
+    HC_HIP(hipMemcpyAsync(d_seq_off, sym_off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, c->stream));
+    HC_HIP(hipMemcpyAsync(d_first, read_first_seq, sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, c->stream));
     HC_HIP(hipMemcpyAsync(c->d_lut, lut.data(), sizeof(double) * lut.size(), hipMemcpyHostToDevice, c->stream));
-    HC_HIP(hc::launch_encode(symbytes, d_bases, d_quals, d_raw_off, c->d_seq_off, d_qmap, n_seq, c->d_sym, c->d_seq_flags,
-                             c->stream));
+    HC_HIP(hc::launch_encode(symbytes, d_bases, d_quals, d_raw_off, d_seq_off, d_qmap, n_seq, K, c->d_sym, d_seq_bad,
+                             d_first, n_reads, c->d_reads, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(d_bases);
     (void)hipFree(d_quals);
     (void)hipFree(d_raw_off);
     (void)hipFree(d_qmap);
+    (void)hipFree(d_seq_off);
+    (void)hipFree(d_seq_bad);
+    (void)hipFree(d_first);
 
     c->view.sym = c->d_sym;
-    c->view.seq_off = c->d_seq_off;
-    c->view.seq_len = c->d_seq_len;
-    c->view.seq_flags = c->d_seq_flags;
-    c->view.read_first_seq = c->d_read_first_seq;
+    c->view.reads = c->d_reads;
     c->view.n_reads = n_reads;
     c->view.n_seq = n_seq;
     c->view.K = K;
     c->view.symbytes = symbytes;
+    c->view.lut_bytes = (uint32_t)(lut.size() * sizeof(double));
     c->store_bytes = sym_bytes_total;
     c->have_reads = true;
     return HC_OK;

@@ -2,16 +2,21 @@
 //
 // Read store in HBM (built once per hc_set_reads, see DESIGN.md "Data layout"):
 //   every stored sequence q (a single read, or mate /1 or /2 of a pair) owns two
-//   SLOTS of symbols: forward at seq_off[q], reverse-complement at
-//   seq_off[q] + slot_stride(len).  One symbol per base:
+//   SLOTS of symbols: forward at off, reverse-complement at off + slot_stride(len).
+//   One symbol per base:
 //       sym = (qidx << 3) | code
-//   qidx = index of the quality byte in the store's dense quality alphabet
-//   (K distinct bytes in the read set, K <= 32 -> uint8 symbols, else uint16);
 //   code = 0..3 for A,C,G,T (complement = 3 - code), 4 = N,
 //          6 = quality byte outside [33,127]  (reference asserts, EdgeCalculator.cpp:61,97-98)
 //          7 = base outside ACGTN             (reference asserts, EdgeCalculator.cpp:29-30)
-//   Slots are padded with zero symbols to a multiple of 16 bytes plus 16 bytes,
-//   so chunked loads may over-read safely.
+//   qidx = index of the quality byte in the store's dense quality alphabet (K distinct
+//          bytes in the read set), EXCEPT: an N base gets qidx = K (the all-zero row/column
+//          of the log table: the position adds 0.0, EdgeCalculator.cpp:35-39,122-124) and an
+//          invalid symbol gets qidx = K+1 (the NaN row: poisons the sum, the lane then
+//          re-scans the overlap position by position to report exactly what the reference
+//          would do).  Table dimension Kp = K + 2.
+//   Kp <= 32 -> uint8 symbols (5-bit qidx), else uint16 symbols.
+//   Slots are padded with N symbols to a multiple of 16 bytes plus 32 bytes, so chunked
+//   (16-symbol) loads may over-read safely.
 #pragma once
 #include <stdint.h>
 
@@ -20,26 +25,42 @@ namespace hc {
 constexpr uint32_t kCodeN = 4;
 constexpr uint32_t kCodeBadQual = 6;
 constexpr uint32_t kCodeBadBase = 7;
-constexpr uint32_t kSeqFlagBadBase = 1u;  // sequence holds a base outside ACGTN: build_rev_comp exits (Types.h:124-127)
+
+// per-read flags in ReadDesc
+constexpr uint32_t kReadPaired = 1u;
+constexpr uint32_t kReadBadBase1 = 2u;  // sequence /1 (or the single) holds a base outside ACGTN:
+constexpr uint32_t kReadBadBase2 = 4u;  // build_rev_comp exits when it is reverse-complemented (Types.h:124-127)
 
 // slot stride in SYMBOLS for a sequence of `len` symbols of `symbytes` bytes each
 __host__ __device__ inline uint64_t slot_stride(uint32_t len, uint32_t symbytes) {
     uint64_t bytes = (uint64_t)len * symbytes;
-    bytes = ((bytes + 15) & ~(uint64_t)15) + 16;
+    bytes = ((bytes + 15) & ~(uint64_t)15) + 32;
     return bytes / symbytes;
 }
 
+// One 32-byte descriptor per read: everything compute_overlap needs to pick the oriented
+// sequences (one dependent load instead of three levels of tables).
+struct ReadDesc {
+    uint64_t off1, off2;  // forward-slot offsets (symbols) of /1 (or the single sequence) and /2
+    uint32_t len1, len2;
+    uint32_t flags;
+    uint32_t pad;
+};
+
 struct StoreView {
-    const void* sym;                 // uint8_t* or uint16_t*
-    const uint64_t* seq_off;         // [n_seq]  forward-slot offset, in symbols
-    const uint32_t* seq_len;         // [n_seq]
-    const uint8_t* seq_flags;        // [n_seq]
-    const uint32_t* read_first_seq;  // [n_reads + 1]
+    const void* sym;        // uint8_t* or uint16_t*
+    const ReadDesc* reads;  // [n_reads]
     uint32_t n_reads;
     uint32_t n_seq;
-    uint32_t K;                      // quality alphabet size
-    uint32_t symbytes;               // 1 or 2
+    uint32_t K;         // quality alphabet size; table dimension Kp = K + 2
+    uint32_t symbytes;  // 1 or 2
+    uint32_t lut_bytes; // bytes of the log table as laid out for this symbol width
 };
+
+// Log table layouts (doubles):
+//   uint8 symbols : byte address = qa*512 + qb*16 + mismatch*8   (row stride 512 B, Kp rows)
+//   uint16 symbols: byte address = (qa*Kp + qb)*16 + mismatch*8
+constexpr uint32_t kLutRowBytesU8 = 512;
 
 // x-space image of a score threshold T: exp(x) > T  <=>  x > hi ; x <= lo => exp(x) <= T;
 // lo < x <= hi is the guard band the host libm decides (normally empty).
@@ -51,7 +72,7 @@ struct ScoreParams {
     Band edge, ov;
     double merge_contigs;
     uint32_t min_read_len;
-    uint32_t flags;
+    uint32_t flags;  // bit0: edge_threshold < 0 (every score passes), bit1: ov_threshold < 0
 };
 
 }  // namespace hc

@@ -10,12 +10,18 @@
 //     by the reference's own expressions, so every term equals the reference's.
 //   * terms are added in increasing position order into one fp64 accumulator per
 //     candidate (one lane owns one candidate), exactly the order of :106-128;
-//     an N position adds nothing; a `p < --mismatch` term is +inf (poison).
+//     an N position adds +0.0 (S + 0.0 == S); a `p < --mismatch` term is +inf (poison).
 //   * x = (1.0/total_len) * total_score uses IEEE fp64 divide and multiply; the
 //     file is compiled with -ffp-contract=off so nothing is fused.
 //   * exp() is NOT taken on the device: thresholds are inverted into x-space on the
-//     host through the host libm exp (guard band => HC_CLS_AMBIG, host decides).
+//     host through the host libm (guard band => HC_CLS_AMBIG, host decides).
 // No MFMA: this is byte gathering + table lookup + a serial fp64 add chain.
+//
+// Mapping (DESIGN.md "Kernel"): one lane = one candidate.  Per 16 positions a lane
+// loads 16 symbols of each read (16 B per load for 8-bit symbols), derives N / mismatch
+// masks and counts with packed-byte integer ops (4 positions per VALU op), builds the 16
+// LDS addresses of the log table with one v_perm_b32 + one shift each, issues the 16
+// ds_read_b64 back to back, and only then runs the 16 dependent v_add_f64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,12 +38,13 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                                                            const uint8_t* __restrict__ quals,
                                                            const uint64_t* __restrict__ raw_off,  // [n_seq+1]
                                                            const uint64_t* __restrict__ seq_off,  // [n_seq] symbols
-                                                           const uint8_t* __restrict__ qmap,      // [256] byte -> qidx, 255 = invalid
-                                                           uint32_t n_seq, SymT* __restrict__ sym,
-                                                           uint8_t* __restrict__ seq_flags) {
+                                                           const uint8_t* __restrict__ qmap,  // [256] byte -> qidx, 255 = invalid
+                                                           uint32_t n_seq, uint32_t K, SymT* __restrict__ sym,
+                                                           uint8_t* __restrict__ seq_bad) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const SymT nsym = (SymT)((K << 3) | kCodeN);
     for (uint32_t q = wave; q < n_seq; q += n_waves) {
         const uint64_t r0 = raw_off[q];
         const uint32_t len = (uint32_t)(raw_off[q + 1] - r0);
@@ -45,7 +52,6 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
         const uint64_t stride = slot_stride(len, sizeof(SymT));
         uint32_t bad = 0;
         for (uint32_t i = lane; i < (uint32_t)stride; i += 64) {
-            SymT sf = 0, sr = 0;
             if (i < len) {
                 const uint8_t b = bases[r0 + i];
                 const uint8_t qi = qmap[quals[r0 + i]];
@@ -58,109 +64,129 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                     case 'N': code = kCodeN; break;
                     default: code = kCodeBadBase; bad = 1; break;
                 }
-                uint32_t q3 = (uint32_t)qi << 3;
-                if (qi == 255) { code = kCodeBadQual; q3 = 0; }
-                sf = (SymT)(q3 | code);
+                uint32_t qx = qi;
+                if (code == kCodeN) qx = K;            // zero row of the log table
+                if (code == kCodeBadBase) qx = K + 1;  // NaN row
+                if (qi == 255) {                       // quality outside [33,127]: always fatal inside an overlap
+                    code = kCodeBadQual;
+                    qx = K + 1;
+                }
                 const uint32_t rcode = code < 4 ? 3 - code : code;
-                sr = (SymT)(q3 | rcode);
-                sym[f0 + i] = sf;
-                sym[f0 + stride + (len - 1 - i)] = sr;
+                sym[f0 + i] = (SymT)((qx << 3) | code);
+                sym[f0 + stride + (len - 1 - i)] = (SymT)((qx << 3) | rcode);
             } else {
-                // padding of both slots
-                sym[f0 + i] = 0;
-                sym[f0 + stride + i] = 0;
+                sym[f0 + i] = nsym;
+                sym[f0 + stride + i] = nsym;
             }
         }
         const unsigned long long any_bad = __ballot(bad != 0);
-        if (lane == 0) seq_flags[q] = any_bad ? kSeqFlagBadBase : 0;
+        if (lane == 0) seq_bad[q] = any_bad ? 1 : 0;
     }
+}
+
+__global__ __launch_bounds__(256) void build_read_desc_kernel(const uint32_t* __restrict__ read_first_seq,
+                                                              const uint64_t* __restrict__ seq_off,
+                                                              const uint64_t* __restrict__ raw_off,
+                                                              const uint8_t* __restrict__ seq_bad, uint32_t n_reads,
+                                                              ReadDesc* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t f = read_first_seq[r];
+    const bool paired = (read_first_seq[r + 1] - f) == 2;
+    ReadDesc d;
+    d.off1 = seq_off[f];
+    d.len1 = (uint32_t)(raw_off[f + 1] - raw_off[f]);
+    d.flags = (paired ? kReadPaired : 0u) | (seq_bad[f] ? kReadBadBase1 : 0u);
+    d.off2 = 0;
+    d.len2 = 0;
+    if (paired) {
+        d.off2 = seq_off[f + 1];
+        d.len2 = (uint32_t)(raw_off[f + 2] - raw_off[f + 1]);
+        d.flags |= seq_bad[f + 1] ? kReadBadBase2 : 0u;
+    }
+    d.pad = 0;
+    out[r] = d;
 }
 
 // ---------------------------------------------------------------------------
 // Candidate -> sub-overlap descriptors (reference compute_overlap, :197-380).
+struct View {
+    uint64_t off;  // symbol offset of the oriented sequence
+    uint32_t len;
+    uint32_t fatal;  // reverse-complementing a sequence that holds an invalid base: build_rev_comp exits
+};
+
+__device__ __forceinline__ ReadDesc load_desc(const ReadDesc* p) {
+    const uint4* q = (const uint4*)p;
+    const uint4 a = q[0], b = q[1];
+    ReadDesc d;
+    d.off1 = ((uint64_t)a.y << 32) | a.x;
+    d.off2 = ((uint64_t)a.w << 32) | a.z;
+    d.len1 = b.x;
+    d.len2 = b.y;
+    d.flags = b.z;
+    d.pad = 0;
+    return d;
+}
+
+// mate: 0 = /1 (or the single sequence), 1 = /2
+__device__ __forceinline__ View make_view(const ReadDesc& d, uint32_t mate, uint32_t fwd, uint32_t symbytes) {
+    View v;
+    const uint64_t off = mate ? d.off2 : d.off1;
+    v.len = mate ? d.len2 : d.len1;
+    v.off = off + (fwd ? 0 : slot_stride(v.len, symbytes));
+    v.fatal = (!fwd && (d.flags & (mate ? kReadBadBase2 : kReadBadBase1))) ? 1u : 0u;
+    return v;
+}
+
 struct Sub {
-    uint64_t offA, offB;  // symbol offsets of the oriented views
-    uint32_t lenA, lenB, pos;
-    uint32_t fatal;  // reverse-complement of a sequence holding an invalid base: build_rev_comp exits
+    uint64_t offA, offB;
+    uint32_t lenA, lenB, pos, fatal;
 };
 
-struct SeqRef {
-    uint32_t q;
-    uint32_t fwd;
-};
-
-__device__ __forceinline__ void make_sub(const StoreView& st, SeqRef A, SeqRef B, uint32_t pos, Sub& s) {
-    const uint32_t la = st.seq_len[A.q], lb = st.seq_len[B.q];
-    s.lenA = la;
-    s.lenB = lb;
+__device__ __forceinline__ Sub make_sub(const View& A, const View& B, uint32_t pos) {
+    Sub s;
+    s.offA = A.off;
+    s.offB = B.off;
+    s.lenA = A.len;
+    s.lenB = B.len;
     s.pos = pos;
-    s.offA = st.seq_off[A.q] + (A.fwd ? 0 : slot_stride(la, st.symbytes));
-    s.offB = st.seq_off[B.q] + (B.fwd ? 0 : slot_stride(lb, st.symbytes));
-    s.fatal = ((!A.fwd) & (st.seq_flags[A.q] & kSeqFlagBadBase)) | ((!B.fwd) & (st.seq_flags[B.q] & kSeqFlagBadBase));
+    s.fatal = A.fatal | B.fatal;
+    return s;
 }
 
 // Returns the number of sub-overlaps (1 or 2); 0 = malformed record.
-__device__ __forceinline__ int resolve(const StoreView& st, const hc_overlap_rec& r, Sub (&sub)[2]) {
+__device__ __forceinline__ int resolve(const StoreView& st, const hc_overlap_rec& r, Sub& s0, Sub& s1) {
     if (r.read1 >= st.n_reads || r.read2 >= st.n_reads || r.read1 == r.read2) return 0;
-    const uint32_t f1 = st.read_first_seq[r.read1], f2 = st.read_first_seq[r.read2];
-    const bool p1 = (st.read_first_seq[r.read1 + 1] - f1) == 2;
-    const bool p2 = (st.read_first_seq[r.read2 + 1] - f2) == 2;
+    const ReadDesc d1 = load_desc(st.reads + r.read1);
+    const ReadDesc d2 = load_desc(st.reads + r.read2);
+    const uint32_t p1 = d1.flags & kReadPaired, p2 = d2.flags & kReadPaired;
     const uint32_t o1 = r.ori1 ? 1u : 0u, o2 = r.ori2 ? 1u : 0u;
-    // single: S(R,o); paired: F(R,o) = o ? /1 : rc(/2), K(R,o) = o ? /2 : rc(/1)
-    const SeqRef F1 = {p1 ? (o1 ? f1 : f1 + 1) : f1, o1};
-    const SeqRef K1 = {p1 ? (o1 ? f1 + 1 : f1) : f1, o1};
-    const SeqRef F2 = {p2 ? (o2 ? f2 : f2 + 1) : f2, o2};
-    const SeqRef K2 = {p2 ? (o2 ? f2 + 1 : f2) : f2, o2};
-    if (!p1 && !p2) {  // s-s :199-233
-        make_sub(st, F1, F2, r.pos1, sub[0]);
-        return 1;
+    // single: S(R,o); paired: F(R,o) = o ? /1 : rc(/2) ("front"), K(R,o) = o ? /2 : rc(/1) ("back")
+    const View F1 = make_view(d1, p1 ? (o1 ? 0u : 1u) : 0u, o1, st.symbytes);
+    const View F2 = make_view(d2, p2 ? (o2 ? 0u : 1u) : 0u, o2, st.symbytes);
+    s0 = make_sub(F1, F2, r.pos1);  // every type: (front1, front2, pos1)
+    if (!p1 && !p2) return 1;       // s-s :199-233
+    const View K1 = make_view(d1, p1 ? (o1 ? 1u : 0u) : 0u, o1, st.symbytes);
+    const View K2 = make_view(d2, p2 ? (o2 ? 1u : 0u) : 0u, o2, st.symbytes);
+    if (!p1) {  // s-p :234-271: (S1, K2, pos2)
+        s1 = make_sub(F1, K2, r.pos2);
+    } else if (!p2) {  // p-s :272-309: (S2, K1, pos2)
+        s1 = make_sub(F2, K1, r.pos2);
+    } else {  // p-p :312-380
+        if (r.ord == '1') s1 = make_sub(K1, K2, r.pos2);
+        else if (r.ord == '2') s1 = make_sub(K2, K1, r.pos2);
+        else return 0;
     }
-    if (!p1 && p2) {  // s-p :234-271
-        make_sub(st, F1, F2, r.pos1, sub[0]);
-        make_sub(st, F1, K2, r.pos2, sub[1]);
-        return 2;
-    }
-    if (p1 && !p2) {  // p-s :272-309
-        make_sub(st, F1, F2, r.pos1, sub[0]);
-        make_sub(st, F2, K1, r.pos2, sub[1]);
-        return 2;
-    }
-    // p-p :312-380
-    make_sub(st, F1, F2, r.pos1, sub[0]);
-    if (r.ord == '1') make_sub(st, K1, K2, r.pos2, sub[1]);
-    else if (r.ord == '2') make_sub(st, K2, K1, r.pos2, sub[1]);
-    else return 0;
     return 2;
 }
 
 __device__ __forceinline__ uint32_t sub_positions(const Sub& s, uint32_t min_read_len) {
-    if (s.pos >= s.lenA) return 0;
-    if (s.lenA < min_read_len || s.lenB < min_read_len) return 0;
-    const uint32_t rem = s.lenA - s.pos;
+    if (s.pos >= s.lenA) return 0;                                  // :76-79
+    if (s.lenA < min_read_len || s.lenB < min_read_len) return 0;  // :82-84
+    const uint32_t rem = s.lenA - s.pos;                            // :88
     return rem < s.lenB ? rem : s.lenB;
 }
-
-// ---------------------------------------------------------------------------
-// 8 symbols per chunk: 8 bytes (uint8 symbols) or 16 bytes (uint16 symbols).
-template <typename SymT>
-struct Chunk;
-template <>
-struct Chunk<uint8_t> {
-    uint64_t w;
-    __device__ __forceinline__ void load(const uint8_t* p) { __builtin_memcpy(&w, p, 8); }
-    __device__ __forceinline__ uint32_t get(int k) const { return (uint32_t)(w >> (8 * k)) & 0xFFu; }
-};
-template <>
-struct Chunk<uint16_t> {
-    uint64_t w0, w1;
-    __device__ __forceinline__ void load(const uint16_t* p) {
-        __builtin_memcpy(&w0, p, 8);
-        __builtin_memcpy(&w1, p + 4, 8);
-    }
-    __device__ __forceinline__ uint32_t get(int k) const {
-        return (uint32_t)((k < 4 ? w0 : w1) >> (16 * (k & 3))) & 0xFFFFu;
-    }
-};
 
 struct SubScore {
     double x;  // (1.0/total_len)*total_score, or -inf
@@ -168,47 +194,142 @@ struct SubScore {
     uint32_t err;
 };
 
+// ---------------------------------------------------------------------------
+// Symbol-width traits.  A "word" is 32 bits = 4 (uint8) or 2 (uint16) symbols; a chunk is 16 symbols.
+template <typename SymT>
+struct Tr;
+template <>
+struct Tr<uint8_t> {
+    static constexpr int kSymsPerWord = 4;
+    static constexpr int kWords = 4;  // per 16-symbol chunk
+    static constexpr uint32_t kLow1 = 0x01010101u;
+    static constexpr uint32_t kQMask = 0xF8F8F8F8u;
+    static constexpr int kSymBits = 8;
+};
+template <>
+struct Tr<uint16_t> {
+    static constexpr int kSymsPerWord = 2;
+    static constexpr int kWords = 8;
+    static constexpr uint32_t kLow1 = 0x00010001u;
+    static constexpr uint32_t kQMask = 0xFFF8FFF8u;
+    static constexpr int kSymBits = 16;
+};
+
+__device__ __forceinline__ double lds_f64(const char* lut, uint32_t byte_addr) {
+    return *(const double*)(lut + byte_addr);
+}
+
+// Exact per-position re-scan (rare: only when the fast sum came out NaN, i.e. the window
+// holds an invalid base / quality byte).  Mirrors the reference's order of checks:
+// all quality bytes of the window first (:92-101), then position by position (:106-128).
+template <typename SymT>
+__device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, const SymT* __restrict__ b, uint32_t L,
+                                                const char* lut, uint32_t Kp) {
+    SubScore r;
+    r.x = -__builtin_inf();
+    r.mm = 1;
+    r.n = 1;
+    r.err = 0;
+    for (uint32_t i = 0; i < L; ++i)
+        if ((a[i] & 7u) == kCodeBadQual || (b[i] & 7u) == kCodeBadQual) {
+            r.err = 1;
+            return r;
+        }
+    double S = 0.0;
+    uint32_t cn = 0, cm = 0;
+    for (uint32_t i = 0; i < L; ++i) {
+        const uint32_t sa = a[i], sb = b[i];
+        const uint32_t ca = sa & 7u, cb = sb & 7u;
+        if (ca == kCodeBadBase || cb == kCodeBadBase) {  // :29-30 assert
+            r.err = 1;
+            return r;
+        }
+        if ((ca | cb) & 4u) continue;  // N: :35-39, :122-124
+        const uint32_t m = ca != cb;
+        const uint32_t qa = sa >> 3, qb = sb >> 3;
+        const uint32_t addr = sizeof(SymT) == 1 ? qa * kLutRowBytesU8 + qb * 16u + m * 8u : (qa * Kp + qb) * 16u + m * 8u;
+        const double t = lds_f64(lut, addr);
+        if (t == __builtin_inf()) return r;  // :125-127
+        S += t;
+        cn += 1;
+        cm += m;
+    }
+    if (cn == 0) return r;
+    r.x = (1.0 / (double)cn) * S;
+    r.mm = cm;
+    r.n = cn;
+    return r;
+}
+
 // overlap_score (:67-139) for one sub-overlap, one lane.
 template <typename SymT>
-__device__ __forceinline__ SubScore score_sub(const SymT* __restrict__ sym, const Sub& s, const double* lut, uint32_t K,
-                                              uint32_t min_read_len) {
+__device__ __forceinline__ SubScore score_sub(const SymT* __restrict__ sym, const Sub& s, const char* lut, uint32_t Kp,
+                                              uint32_t nsym_word, uint32_t min_read_len) {
+    using T = Tr<SymT>;
     SubScore r;
     r.x = -__builtin_inf();
     r.mm = 1;
     r.n = 1;
     r.err = s.fatal;
-    const uint32_t L = sub_positions(s, min_read_len);  // :76-88
+    const uint32_t L = sub_positions(s, min_read_len);
     if (L == 0) return r;
     const SymT* a = sym + s.offA + s.pos;
     const SymT* b = sym + s.offB;
     double S = 0.0;
-    uint32_t cn = 0, cm = 0, bad = 0;
-    for (uint32_t i = 0; i < L; i += 8) {
-        Chunk<SymT> ca, cb;
-        ca.load(a + i);
-        cb.load(b + i);
+    uint32_t skipped = 0, cm = 0;
+    const uint32_t nchunks = (L + 15u) >> 4;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        uint32_t wa[T::kWords], wb[T::kWords];
+        __builtin_memcpy(wa, a + 16u * c, sizeof(wa));  // unaligned (pos is arbitrary): global_load_dwordx4
+        __builtin_memcpy(wb, b + 16u * c, sizeof(wb));
+        const int rem = (int)(L - 16u * c);
+        double t[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (i + k < L) {
-                const uint32_t sa = ca.get(k), sb = cb.get(k);
-                const uint32_t ba = sa & 7u, bb = sb & 7u;
-                const uint32_t skip = (ba | bb) & 4u;  // N (or an invalid symbol) on either side: :35-39
-                const uint32_t mmf = (ba != bb) ? 1u : 0u;
-                bad |= (ba == kCodeBadQual) | (bb == kCodeBadQual);             // :97-98, before any scoring
-                bad |= ((ba == kCodeBadBase) | (bb == kCodeBadBase)) & (S < __builtin_inf());  // :29-30, unless already rejected
-                const double t = lut[((sa >> 3) * K + (sb >> 3)) * 2u + mmf];
-                if (!skip) {
-                    S += t;  // :119, in position order
-                    cn += 1;
-                    cm += mmf;
+        for (int j = 0; j < T::kWords; ++j) {
+            // symbols at or beyond L become N: they add 0.0 and count as skipped
+            const int left = rem - j * T::kSymsPerWord;
+            const uint32_t keep = left >= T::kSymsPerWord ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << (left * T::kSymBits)) - 1u));
+            const uint32_t aw = (wa[j] & keep) | (nsym_word & ~keep);
+            const uint32_t bw = wb[j];
+            const uint32_t nm = ((aw | bw) >> 2) & T::kLow1;  // code bit 2 on either side: N (or invalid)
+            const uint32_t e = aw ^ bw;
+            const uint32_t mk = ((e | (e >> 1)) & T::kLow1) & ~nm;  // bases differ, neither is N: mismatch
+            skipped += __builtin_popcount(nm);
+            cm += __builtin_popcount(mk);
+            if (sizeof(SymT) == 1) {
+                const uint32_t aq = (aw >> 3) & 0x1F1F1F1Fu;        // qa per byte
+                const uint32_t bm = (bw & T::kQMask) | (mk << 2);   // qb*8 + mismatch*4 per byte
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // v_perm_b32: (qa << 8) | (qb*8 + m*4);  << 1  ->  qa*512 + qb*16 + m*8
+                    const uint32_t p = __builtin_amdgcn_perm(aq, bm, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k);
+                    t[j * 4 + k] = lds_f64(lut, p << 1);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint32_t qa = (aw >> (16 * k + 3)) & 0x1FFFu;
+                    const uint32_t qb = (bw >> (16 * k + 3)) & 0x1FFFu;
+                    const uint32_t m = (mk >> (16 * k)) & 1u;
+                    t[j * 2 + k] = lds_f64(lut, (qa * Kp + qb) * 16u + m * 8u);
                 }
             }
         }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) S += t[k];  // :119, strictly in position order
     }
-    r.err |= bad;
+    if (S != S) {  // an invalid symbol inside the window
+        const SubScore e = score_sub_slow<SymT>(a, b, L, lut, Kp);
+        r.x = e.x;
+        r.mm = e.mm;
+        r.n = e.n;
+        r.err |= e.err;
+        return r;
+    }
     if (S == __builtin_inf()) return r;  // a position fell below --mismatch: :125-127
-    if (cn == 0) return r;               // :129-131
-    r.x = (1.0 / (double)cn) * S;        // :137
+    const uint32_t cn = 16u * nchunks - skipped;
+    if (cn == 0) return r;         // :129-131
+    r.x = (1.0 / (double)cn) * S;  // :137
     r.mm = cm;
     r.n = cn;
     return r;
@@ -221,23 +342,27 @@ template <typename SymT>
 __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                     const hc_overlap_rec* __restrict__ in, uint64_t n,
                                                     hc_result_rec* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) double lut[];
-    const uint32_t lut_n = st.K * st.K * 2u;
-    for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut[i] = lut_g[i];
+    extern __shared__ __attribute__((aligned(16))) double lut_s[];
+    const uint32_t lut_n = st.lut_bytes >> 3;
+    for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
     __syncthreads();
+    const char* lut = (const char*)lut_s;
 
     const SymT* sym = (const SymT*)st.sym;
+    const uint32_t Kp = st.K + 2u;
+    const uint32_t nsym = (st.K << 3) | kCodeN;
+    const uint32_t nsym_word = sizeof(SymT) == 1 ? nsym * 0x01010101u : nsym * 0x00010001u;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         hc_overlap_rec rec;
         {
             const uint4* p = (const uint4*)(in + i);
-            uint4 a = p[0], b = p[1];
+            const uint4 a = p[0], b = p[1];
             __builtin_memcpy(&rec, &a, 16);
             __builtin_memcpy((char*)&rec + 16, &b, 16);
         }
-        Sub sub[2];
-        const int ns = resolve(st, rec, sub);
+        Sub sub0, sub1;
+        const int ns = resolve(st, rec, sub0, sub1);
         hc_result_rec res;
         if (ns == 0) {
             res.x1 = -__builtin_inf();
@@ -247,13 +372,13 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
             out[i] = res;
             continue;
         }
-        const SubScore s1 = score_sub<SymT>(sym, sub[0], lut, st.K, prm.min_read_len);
+        const SubScore s1 = score_sub<SymT>(sym, sub0, lut, Kp, nsym_word, prm.min_read_len);
         SubScore s2;
         s2.x = __builtin_nan("");
         s2.mm = 0;
         s2.n = 1;
         s2.err = 0;
-        if (ns == 2) s2 = score_sub<SymT>(sym, sub[1], lut, st.K, prm.min_read_len);
+        if (ns == 2) s2 = score_sub<SymT>(sym, sub1, lut, Kp, nsym_word, prm.min_read_len);
 
         // mismatch_rate = float(mismatch_count)/total_len (:132); std::max over the two (:254)
         const double m1 = (double)(float)s1.mm / (double)s1.n;
@@ -267,8 +392,7 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
                 nn = s2.n;
             }
         }
-        // :404-413 in x-space
-        // flags bit0 / bit1: threshold < 0, every score (0 included) passes
+        // :404-413 in x-space; flags bit0 / bit1: threshold < 0, every score (0 included) passes
         const bool e_all = prm.flags & 1u, o_all = prm.flags & 2u;
         uint32_t e = e_all ? 1u : band_test(s1.x, prm.edge);
         uint32_t o = o_all ? 1u : band_test(s1.x, prm.ov);
@@ -301,9 +425,10 @@ __global__ __launch_bounds__(256) void count_positions_kernel(StoreView st, uint
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const hc_overlap_rec rec = in[i];
-        Sub sub[2];
-        const int ns = resolve(st, rec, sub);
-        for (int k = 0; k < ns; ++k) pos += sub_positions(sub[k], min_read_len);
+        Sub s0, s1;
+        const int ns = resolve(st, rec, s0, s1);
+        if (ns >= 1) pos += sub_positions(s0, min_read_len);
+        if (ns == 2) pos += sub_positions(s1, min_read_len);
         subs += (unsigned long long)ns;
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -319,7 +444,8 @@ __global__ __launch_bounds__(256) void count_positions_kernel(StoreView st, uint
 // ---------------------------------------------------------------------------
 // Launch wrappers (called from hc_api.cpp).
 hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
-                         const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, void* sym, uint8_t* seq_flags,
+                         const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
+                         uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
                          hipStream_t stream) {
     if (n_seq == 0) return hipSuccess;
     const uint32_t waves_per_block = 4;
@@ -327,17 +453,22 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
     if (blocks > 65536) blocks = 65536;
     if (symbytes == 1)
         hipLaunchKernelGGL(encode_store_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off, seq_off,
-                           qmap, n_seq, (uint8_t*)sym, seq_flags);
+                           qmap, n_seq, K, (uint8_t*)sym, seq_bad);
     else
         hipLaunchKernelGGL(encode_store_kernel<uint16_t>, dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
-                           seq_off, qmap, n_seq, (uint16_t*)sym, seq_flags);
+                           seq_off, qmap, n_seq, K, (uint16_t*)sym, seq_bad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (n_reads)
+        hipLaunchKernelGGL(build_read_desc_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, read_first_seq,
+                           seq_off, raw_off, seq_bad, n_reads, descs);
     return hipGetLastError();
 }
 
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
                         uint64_t n, hc_result_rec* out, uint32_t n_cu, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    const size_t lds = (size_t)st.K * st.K * 2 * sizeof(double);
+    const size_t lds = st.lut_bytes;
     const uint32_t block = 256;
     // Fill the chip: enough 256-thread blocks for 8 waves per SIMD, bounded by LDS.
     uint32_t blocks_per_cu = 8;
