@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order", default="sfo", choices=["sfo", "grouped", "shuffled"],
+                    help="candidate order inside the batch: sfo = sorted by (min id, max id) as scripts/sfo2overlaps.py:53 "
+                         "writes overlap files (default); grouped = by read1; shuffled = random (experiment knobs)")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +99,10 @@ def main():
 
     settings = hc.Settings(edge_threshold=0.97, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=150, device=local_rank)
     reads, cand, cfg = build_workload(args.workload, rank)
+    if args.order == "grouped":
+        cand = cand[np.argsort(cand["read1"], kind="stable")]
+    elif args.order == "shuffled":
+        cand = cand[np.random.default_rng(5).permutation(cand.size)]
     n = int(cand.size)
     sc = hc.EdgeScorer(settings)
     sc.set_reads(reads)

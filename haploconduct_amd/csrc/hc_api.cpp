@@ -22,7 +22,7 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
                          uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
                          hipStream_t stream);
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
-                        uint64_t n, hc_result_rec* out, uint32_t n_cu, hipStream_t stream);
+                        uint64_t n, hc_result_rec* out, uint32_t n_cu, int variant, hipStream_t stream);
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,
                                   unsigned long long* totals, hipStream_t stream);
 hipError_t set_score_kernel_lds_limit();
@@ -46,6 +46,7 @@ struct hc_ctx {
     hc_settings settings;
     int device = 0;
     uint32_t n_cu = 256;
+    int variant = 2;  // scoring-kernel variant (HC_SCORE_VARIANT overrides; tuning knob, results are identical)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // read store
@@ -149,6 +150,7 @@ int hc_create(hc_ctx** out, const hc_settings* settings) {
     HC_HIP(hipEventCreate(&c->ev1));
     HC_HIP(hipMalloc((void**)&c->d_totals, 2 * sizeof(unsigned long long)));
     HC_HIP(hc::set_score_kernel_lds_limit());
+    if (const char* v = getenv("HC_SCORE_VARIANT")) c->variant = atoi(v);
     c->params.edge = make_band(settings->edge_threshold);
     c->params.ov = make_band(settings->ov_threshold);
     c->params.merge_contigs = settings->merge_contigs;
@@ -315,7 +317,7 @@ int hc_score_batch_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, 
     HC_HIP(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     HC_HIP(hc::launch_score(c->view, c->params, c->d_lut, (const hc_overlap_rec*)d_in, n, (hc_result_rec*)d_out, c->n_cu,
-                            s));
+                            c->variant, s));
     return HC_OK;
 }
 

@@ -130,11 +130,14 @@ __device__ __forceinline__ ReadDesc load_desc(const ReadDesc* p) {
 }
 
 // mate: 0 = /1 (or the single sequence), 1 = /2
-__device__ __forceinline__ View make_view(const ReadDesc& d, uint32_t mate, uint32_t fwd, uint32_t symbytes) {
+template <int SB>
+__device__ __forceinline__ View make_view(const ReadDesc& d, uint32_t mate, uint32_t fwd) {
     View v;
     const uint64_t off = mate ? d.off2 : d.off1;
     v.len = mate ? d.len2 : d.len1;
-    v.off = off + (fwd ? 0 : slot_stride(v.len, symbytes));
+    // slot_stride() with a compile-time symbol size (no 64-bit division)
+    const uint32_t stride = SB == 1 ? (((v.len + 15u) & ~15u) + 32u) : ((((2u * v.len + 15u) & ~15u) + 32u) >> 1);
+    v.off = off + (fwd ? 0u : stride);
     v.fatal = (!fwd && (d.flags & (mate ? kReadBadBase2 : kReadBadBase1))) ? 1u : 0u;
     return v;
 }
@@ -156,6 +159,7 @@ __device__ __forceinline__ Sub make_sub(const View& A, const View& B, uint32_t p
 }
 
 // Returns the number of sub-overlaps (1 or 2); 0 = malformed record.
+template <int SB>
 __device__ __forceinline__ int resolve(const StoreView& st, const hc_overlap_rec& r, Sub& s0, Sub& s1) {
     if (r.read1 >= st.n_reads || r.read2 >= st.n_reads || r.read1 == r.read2) return 0;
     const ReadDesc d1 = load_desc(st.reads + r.read1);
@@ -163,12 +167,12 @@ __device__ __forceinline__ int resolve(const StoreView& st, const hc_overlap_rec
     const uint32_t p1 = d1.flags & kReadPaired, p2 = d2.flags & kReadPaired;
     const uint32_t o1 = r.ori1 ? 1u : 0u, o2 = r.ori2 ? 1u : 0u;
     // single: S(R,o); paired: F(R,o) = o ? /1 : rc(/2) ("front"), K(R,o) = o ? /2 : rc(/1) ("back")
-    const View F1 = make_view(d1, p1 ? (o1 ? 0u : 1u) : 0u, o1, st.symbytes);
-    const View F2 = make_view(d2, p2 ? (o2 ? 0u : 1u) : 0u, o2, st.symbytes);
+    const View F1 = make_view<SB>(d1, p1 ? (o1 ? 0u : 1u) : 0u, o1);
+    const View F2 = make_view<SB>(d2, p2 ? (o2 ? 0u : 1u) : 0u, o2);
     s0 = make_sub(F1, F2, r.pos1);  // every type: (front1, front2, pos1)
     if (!p1 && !p2) return 1;       // s-s :199-233
-    const View K1 = make_view(d1, p1 ? (o1 ? 1u : 0u) : 0u, o1, st.symbytes);
-    const View K2 = make_view(d2, p2 ? (o2 ? 1u : 0u) : 0u, o2, st.symbytes);
+    const View K1 = make_view<SB>(d1, p1 ? (o1 ? 1u : 0u) : 0u, o1);
+    const View K2 = make_view<SB>(d2, p2 ? (o2 ? 1u : 0u) : 0u, o2);
     if (!p1) {  // s-p :234-271: (S1, K2, pos2)
         s1 = make_sub(F1, K2, r.pos2);
     } else if (!p2) {  // p-s :272-309: (S2, K1, pos2)
@@ -261,90 +265,160 @@ __device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, cons
     return r;
 }
 
-// overlap_score (:67-139) for one sub-overlap, one lane.
+// Tail masks: kMaskTab[r][j] keeps the first r symbols of a 16-symbol chunk, as four (uint8) or
+// eight (uint16) 32-bit words.  Lives in LDS right behind the log table (one ds_read_b128 per
+// chunk instead of ~35 VALU instructions of shift/compare/select).
 template <typename SymT>
-__device__ __forceinline__ SubScore score_sub(const SymT* __restrict__ sym, const Sub& s, const char* lut, uint32_t Kp,
-                                              uint32_t nsym_word, uint32_t min_read_len) {
+__device__ __forceinline__ void fill_mask_table(uint32_t* tab /* 17 * kWords */, uint32_t tid, uint32_t nthreads) {
     using T = Tr<SymT>;
-    SubScore r;
-    r.x = -__builtin_inf();
-    r.mm = 1;
-    r.n = 1;
-    r.err = s.fatal;
-    const uint32_t L = sub_positions(s, min_read_len);
-    if (L == 0) return r;
-    const SymT* a = sym + s.offA + s.pos;
-    const SymT* b = sym + s.offB;
-    double S = 0.0;
-    uint32_t skipped = 0, cm = 0;
-    const uint32_t nchunks = (L + 15u) >> 4;
-    for (uint32_t c = 0; c < nchunks; ++c) {
-        uint32_t wa[T::kWords], wb[T::kWords];
-        __builtin_memcpy(wa, a + 16u * c, sizeof(wa));  // unaligned (pos is arbitrary): global_load_dwordx4
-        __builtin_memcpy(wb, b + 16u * c, sizeof(wb));
-        const int rem = (int)(L - 16u * c);
-        double t[16];
+    for (uint32_t i = tid; i < 17u * T::kWords; i += nthreads) {
+        const int r = (int)(i / T::kWords), j = (int)(i % T::kWords);
+        const int left = r - j * T::kSymsPerWord;
+        tab[i] = left >= T::kSymsPerWord ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << (left * T::kSymBits)) - 1u));
+    }
+}
+
+template <typename SymT>
+struct ChunkData {
+    uint32_t a[Tr<SymT>::kWords], b[Tr<SymT>::kWords];
+};
+
+// overlap_score (:67-139) for NS sub-overlaps of one candidate, one lane, interleaved:
+// NS independent fp64 accumulators (each summed strictly in position order) so that the
+// dependent v_add_f64 chains of the sub-overlaps overlap, and the next chunk of every stream is
+// loaded while the current one is scored.
+template <typename SymT, int NS, bool PREFETCH>
+__device__ __forceinline__ void score_subs(const SymT* __restrict__ sym, const Sub* s, const char* lut,
+                                           const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word,
+                                           uint32_t min_read_len, SubScore* out) {
+    using T = Tr<SymT>;
+    uint32_t L[NS], nch[NS];
+    const SymT* a[NS];
+    const SymT* b[NS];
+    double S[NS];
+    uint32_t skipped[NS], cm[NS];
+    uint32_t nmax = 0;
 #pragma unroll
-        for (int j = 0; j < T::kWords; ++j) {
-            // symbols at or beyond L become N: they add 0.0 and count as skipped
-            const int left = rem - j * T::kSymsPerWord;
-            const uint32_t keep = left >= T::kSymsPerWord ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << (left * T::kSymBits)) - 1u));
-            const uint32_t aw = (wa[j] & keep) | (nsym_word & ~keep);
-            const uint32_t bw = wb[j];
-            const uint32_t nm = ((aw | bw) >> 2) & T::kLow1;  // code bit 2 on either side: N (or invalid)
-            const uint32_t e = aw ^ bw;
-            const uint32_t mk = ((e | (e >> 1)) & T::kLow1) & ~nm;  // bases differ, neither is N: mismatch
-            skipped += __builtin_popcount(nm);
-            cm += __builtin_popcount(mk);
-            if (sizeof(SymT) == 1) {
-                const uint32_t aq = (aw >> 3) & 0x1F1F1F1Fu;        // qa per byte
-                const uint32_t bm = (bw & T::kQMask) | (mk << 2);   // qb*8 + mismatch*4 per byte
+    for (int u = 0; u < NS; ++u) {
+        out[u].x = -__builtin_inf();
+        out[u].mm = 1;
+        out[u].n = 1;
+        out[u].err = s[u].fatal;
+        L[u] = sub_positions(s[u], min_read_len);
+        nch[u] = (L[u] + 15u) >> 4;
+        nmax = nch[u] > nmax ? nch[u] : nmax;
+        // an exhausted / empty sub keeps loading its (valid) first chunk: masked to N, adds 0.0
+        a[u] = sym + s[u].offA + (L[u] ? s[u].pos : 0u);
+        b[u] = sym + s[u].offB;
+        S[u] = 0.0;
+        skipped[u] = 0;
+        cm[u] = 0;
+    }
+    if (nmax == 0) return;
+    ChunkData<SymT> nxt[NS];
+    if (PREFETCH) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // v_perm_b32: (qa << 8) | (qb*8 + m*4);  << 1  ->  qa*512 + qb*16 + m*8
-                    const uint32_t p = __builtin_amdgcn_perm(aq, bm, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k);
-                    t[j * 4 + k] = lds_f64(lut, p << 1);
-                }
+        for (int u = 0; u < NS; ++u) {
+            __builtin_memcpy(nxt[u].a, a[u], sizeof(nxt[u].a));  // unaligned (pos is arbitrary)
+            __builtin_memcpy(nxt[u].b, b[u], sizeof(nxt[u].b));
+        }
+    }
+    for (uint32_t c = 0; c < nmax; ++c) {
+        ChunkData<SymT> cur[NS];
+        uint32_t keep[NS][T::kWords];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (PREFETCH) {
+                cur[u] = nxt[u];
+                const uint32_t cn = c + 1u < nch[u] ? c + 1u : (nch[u] ? nch[u] - 1u : 0u);  // clamped in-bounds
+                __builtin_memcpy(nxt[u].a, a[u] + 16u * cn, sizeof(nxt[u].a));
+                __builtin_memcpy(nxt[u].b, b[u] + 16u * cn, sizeof(nxt[u].b));
             } else {
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const uint32_t qa = (aw >> (16 * k + 3)) & 0x1FFFu;
-                    const uint32_t qb = (bw >> (16 * k + 3)) & 0x1FFFu;
-                    const uint32_t m = (mk >> (16 * k)) & 1u;
-                    t[j * 2 + k] = lds_f64(lut, (qa * Kp + qb) * 16u + m * 8u);
-                }
+                const uint32_t cc = c < nch[u] ? c : (nch[u] ? nch[u] - 1u : 0u);
+                __builtin_memcpy(cur[u].a, a[u] + 16u * cc, sizeof(cur[u].a));
+                __builtin_memcpy(cur[u].b, b[u] + 16u * cc, sizeof(cur[u].b));
             }
+            const int rem = (int)L[u] - (int)(16u * c);
+            const uint32_t r = rem >= 16 ? 16u : (rem <= 0 ? 0u : (uint32_t)rem);
+            __builtin_memcpy(keep[u], masktab + r * T::kWords, sizeof(keep[u]));
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) S += t[k];  // :119, strictly in position order
+        for (int h = 0; h < 2; ++h) {  // two half-chunks of 8 positions: bounds the registers held by table reads
+            double t[NS][8];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+#pragma unroll
+                for (int jj = 0; jj < T::kWords / 2; ++jj) {
+                    const int j = h * (T::kWords / 2) + jj;
+                    // symbols at or beyond L become N: they add 0.0 and count as skipped
+                    const uint32_t aw = (cur[u].a[j] & keep[u][j]) | (nsym_word & ~keep[u][j]);
+                    const uint32_t bw = cur[u].b[j];
+                    const uint32_t x = aw | bw, e = aw ^ bw;
+                    const uint32_t nm = x & (T::kLow1 << 2);  // code bit 2 on either side: N (or invalid)
+                    const uint32_t mk = ((e << 1) | (e << 2)) & (T::kLow1 << 2) & ~x;  // bases differ, neither is N
+                    skipped[u] += __builtin_popcount(nm);
+                    cm[u] += __builtin_popcount(mk);
+                    if (sizeof(SymT) == 1) {
+                        const uint32_t aq = (aw >> 3) & 0x1F1F1F1Fu;   // qa per byte
+                        const uint32_t bm = (bw & T::kQMask) | mk;     // qb*8 + mismatch*4 per byte
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            // v_perm_b32: (qa << 8) | (qb*8 + m*4);  << 1  ->  qa*512 + qb*16 + m*8
+                            const uint32_t p = __builtin_amdgcn_perm(aq, bm, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k);
+                            t[u][jj * 4 + k] = lds_f64(lut, p << 1);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const uint32_t qa = (aw >> (16 * k + 3)) & 0x1FFFu;
+                            const uint32_t qb = (bw >> (16 * k + 3)) & 0x1FFFu;
+                            const uint32_t m = (mk >> (16 * k + 2)) & 1u;
+                            t[u][jj * 2 + k] = lds_f64(lut, (qa * Kp + qb) * 16u + m * 8u);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) S[u] += t[u][k];  // :119, strictly in position order per sub-overlap
+            }
+        }
     }
-    if (S != S) {  // an invalid symbol inside the window
-        const SubScore e = score_sub_slow<SymT>(a, b, L, lut, Kp);
-        r.x = e.x;
-        r.mm = e.mm;
-        r.n = e.n;
-        r.err |= e.err;
-        return r;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        if (L[u] == 0) continue;
+        if (S[u] != S[u]) {  // an invalid symbol inside the window
+            const SubScore e = score_sub_slow<SymT>(a[u], b[u], L[u], lut, Kp);
+            out[u].x = e.x;
+            out[u].mm = e.mm;
+            out[u].n = e.n;
+            out[u].err |= e.err;
+            continue;
+        }
+        if (S[u] == __builtin_inf()) continue;  // a position fell below --mismatch: :125-127
+        const uint32_t cn = 16u * nmax - skipped[u];
+        if (cn == 0) continue;                  // :129-131
+        out[u].x = (1.0 / (double)cn) * S[u];   // :137
+        out[u].mm = cm[u];
+        out[u].n = cn;
     }
-    if (S == __builtin_inf()) return r;  // a position fell below --mismatch: :125-127
-    const uint32_t cn = 16u * nchunks - skipped;
-    if (cn == 0) return r;         // :129-131
-    r.x = (1.0 / (double)cn) * S;  // :137
-    r.mm = cm;
-    r.n = cn;
-    return r;
 }
 
 // exp(x) > T  in x-space: 1 pass, 0 fail, 2 ambiguous
 __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return x > b.hi ? 1u : (x <= b.lo ? 0u : 2u); }
 
-template <typename SymT>
-__global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+// VAR bit0: interleave the two sub-overlaps of a candidate; bit1: software prefetch of the next
+// chunk; bit2: cap registers for 8 waves per SIMD.
+template <typename SymT, int VAR>
+__global__ __launch_bounds__(256, (VAR & 4) ? 8 : 1) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                     const hc_overlap_rec* __restrict__ in, uint64_t n,
                                                     hc_result_rec* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double lut_s[];
     const uint32_t lut_n = st.lut_bytes >> 3;
     for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
+    uint32_t* masktab = (uint32_t*)(lut_s + lut_n);
+    fill_mask_table<SymT>(masktab, threadIdx.x, blockDim.x);
     __syncthreads();
     const char* lut = (const char*)lut_s;
 
@@ -362,7 +436,7 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
             __builtin_memcpy((char*)&rec + 16, &b, 16);
         }
         Sub sub0, sub1;
-        const int ns = resolve(st, rec, sub0, sub1);
+        const int ns = resolve<(int)sizeof(SymT)>(st, rec, sub0, sub1);
         hc_result_rec res;
         if (ns == 0) {
             res.x1 = -__builtin_inf();
@@ -372,13 +446,26 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
             out[i] = res;
             continue;
         }
-        const SubScore s1 = score_sub<SymT>(sym, sub0, lut, Kp, nsym_word, prm.min_read_len);
-        SubScore s2;
+        SubScore s1, s2;
         s2.x = __builtin_nan("");
         s2.mm = 0;
         s2.n = 1;
         s2.err = 0;
-        if (ns == 2) s2 = score_sub<SymT>(sym, sub1, lut, Kp, nsym_word, prm.min_read_len);
+        constexpr bool kPre = (VAR & 2) != 0;
+        if (ns == 2) {
+            if (VAR & 1) {
+                const Sub subs[2] = {sub0, sub1};
+                SubScore r[2];
+                score_subs<SymT, 2, kPre>(sym, subs, lut, masktab, Kp, nsym_word, prm.min_read_len, r);
+                s1 = r[0];
+                s2 = r[1];
+            } else {
+                score_subs<SymT, 1, kPre>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
+                score_subs<SymT, 1, kPre>(sym, &sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, &s2);
+            }
+        } else {
+            score_subs<SymT, 1, kPre>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
+        }
 
         // mismatch_rate = float(mismatch_count)/total_len (:132); std::max over the two (:254)
         const double m1 = (double)(float)s1.mm / (double)s1.n;
@@ -426,7 +513,7 @@ __global__ __launch_bounds__(256) void count_positions_kernel(StoreView st, uint
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const hc_overlap_rec rec = in[i];
         Sub s0, s1;
-        const int ns = resolve(st, rec, s0, s1);
+        const int ns = st.symbytes == 1 ? resolve<1>(st, rec, s0, s1) : resolve<2>(st, rec, s0, s1);
         if (ns >= 1) pos += sub_positions(s0, min_read_len);
         if (ns == 2) pos += sub_positions(s1, min_read_len);
         subs += (unsigned long long)ns;
@@ -465,10 +552,33 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
     return hipGetLastError();
 }
 
+template <typename SymT, int VAR>
+static void launch_score_var(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
+                             uint64_t n, hc_result_rec* out, uint32_t blocks, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((score_kernel<SymT, VAR>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out);
+}
+
+template <typename SymT>
+static hipError_t launch_score_t(int var, const StoreView& st, const ScoreParams& prm, const double* lut_g,
+                                 const hc_overlap_rec* in, uint64_t n, hc_result_rec* out, uint32_t blocks, size_t lds,
+                                 hipStream_t stream) {
+    switch (var & 7) {
+        case 0: launch_score_var<SymT, 0>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
+        case 1: launch_score_var<SymT, 1>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
+        case 2: launch_score_var<SymT, 2>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
+        case 3: launch_score_var<SymT, 3>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
+        case 4: launch_score_var<SymT, 4>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
+        case 5: launch_score_var<SymT, 5>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
+        case 6: launch_score_var<SymT, 6>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
+        default: launch_score_var<SymT, 7>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
-                        uint64_t n, hc_result_rec* out, uint32_t n_cu, hipStream_t stream) {
+                        uint64_t n, hc_result_rec* out, uint32_t n_cu, int variant, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    const size_t lds = st.lut_bytes;
+    const size_t lds = st.lut_bytes + 17 * (st.symbytes == 1 ? 4 : 8) * sizeof(uint32_t);
     const uint32_t block = 256;
     // Fill the chip: enough 256-thread blocks for 8 waves per SIMD, bounded by LDS.
     uint32_t blocks_per_cu = 8;
@@ -479,13 +589,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     uint64_t blocks = (n + block - 1) / block;
     const uint64_t cap = (uint64_t)n_cu * blocks_per_cu * 4;  // grid-stride beyond this
     if (blocks > cap) blocks = cap;
-    if (st.symbytes == 1)
-        hipLaunchKernelGGL(score_kernel<uint8_t>, dim3((uint32_t)blocks), dim3(block), lds, stream, st, prm, lut_g, in, n,
-                           out);
-    else
-        hipLaunchKernelGGL(score_kernel<uint16_t>, dim3((uint32_t)blocks), dim3(block), lds, stream, st, prm, lut_g, in, n,
-                           out);
-    return hipGetLastError();
+    if (st.symbytes == 1) return launch_score_t<uint8_t>(variant, st, prm, lut_g, in, n, out, (uint32_t)blocks, lds, stream);
+    return launch_score_t<uint16_t>(variant, st, prm, lut_g, in, n, out, (uint32_t)blocks, lds, stream);
 }
 
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,
@@ -498,13 +603,27 @@ hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, co
     return hipGetLastError();
 }
 
+template <typename SymT, int VAR>
+static hipError_t set_lds_limit_one() {
+    return hipFuncSetAttribute((const void*)score_kernel<SymT, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int VAR>
+static hipError_t set_lds_limit_var() {
+    hipError_t e = set_lds_limit_one<uint8_t, VAR>();
+    if (e != hipSuccess) return e;
+    return set_lds_limit_one<uint16_t, VAR>();
+}
 hipError_t set_score_kernel_lds_limit() {
     // allow the full 160 KiB of LDS for large quality alphabets
-    hipError_t e = hipFuncSetAttribute((const void*)score_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)score_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024);
+    hipError_t e;
+    if ((e = set_lds_limit_var<0>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_var<1>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_var<2>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_var<3>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_var<4>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_var<5>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_var<6>()) != hipSuccess) return e;
+    return set_lds_limit_var<7>();
 }
 
 }  // namespace hc

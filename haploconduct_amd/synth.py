@@ -124,7 +124,11 @@ def paired_candidates(meta, n_candidates=None, min_len=75, seed=2, max_window=10
     rec["len2"] = rl - np.abs(d2)
     rec["perc"] = (0.5 * (np.floor(100.0 * rec["len1"] / rl) + np.floor(100.0 * rec["len2"] / rl))).astype(np.uint32)
     rec["flags"] = 3
-    return rec
+    # Emit in the order real overlap files have: scripts/sfo2overlaps.py:53 sorts the lines by
+    # (smaller read id, larger read id) before writing them, and FNO writes a sorted std::set of lines.
+    lo = np.minimum(rec["read1"], rec["read2"]).astype(np.uint64)
+    hi = np.maximum(rec["read1"], rec["read2"]).astype(np.uint64)
+    return rec[np.argsort((lo << np.uint64(32)) | hi, kind="stable")]
 
 
 def make_single_dataset(n_reads, genome_len, len_lo=150, len_hi=150, n_strains=2, divergence=0.001, err=0.005,
@@ -189,7 +193,9 @@ def single_candidates(meta, min_overlap=100, n_candidates=None, seed=4, max_wind
     rec["ori2"] = ~flipped[j]
     rec["len1"] = ovl
     rec["perc"] = np.minimum(np.floor(100.0 * ovl / np.minimum(lens[i], lens[j])), 100).astype(np.uint32)
-    return rec
+    lo = np.minimum(rec["read1"], rec["read2"]).astype(np.uint64)
+    hi = np.maximum(rec["read1"], rec["read2"]).astype(np.uint64)
+    return rec[np.argsort((lo << np.uint64(32)) | hi, kind="stable")]  # sfo2overlaps.py:53 order
 
 
 def records_to_lines(rec, reads):
