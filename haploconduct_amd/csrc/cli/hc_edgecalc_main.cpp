@@ -1,0 +1,282 @@
+// hc-edgecalc — the edge-calculation stage of ViralQuasispecies as a stand-alone program.
+// It accepts the reference binary's complete flag surface (src/ViralQuasispecies.cpp:49-99,
+// same names, short forms, defaults, `--x=v` and `--x v` spellings, same validation messages and
+// exit codes, :103-154), runs the stages up to and including EdgeCalculator::construct_edges()
+// (:233-293) on the MI355X, and stops there: graph cleaning, cliques, super-reads and FNO are
+// outside this build's scope.  Outputs: nonedge_overlaps.txt (as the reference),
+// viralquasispecies.log (settings block, :160-218), and edges.tsv — the admitted edges in
+// adjacency-list order, one line per Edge with %.17g score / mismatch rate.
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <sys/time.h>
+#include <vector>
+
+#include "../host/EdgeCalculator.h"
+
+using namespace hc;
+
+struct Opt {
+    std::string name;
+    char shortname;
+    bool is_flag_without_value;
+    std::function<bool(const std::string&)> set;
+    std::string help;
+};
+
+static bool to_bool(const std::string& v, bool& out) {  // boost::program_options bool: true/false/1/0/yes/no/on/off
+    std::string s;
+    for (char c : v) s.push_back((char)tolower((unsigned char)c));
+    if (s == "true" || s == "1" || s == "yes" || s == "on") { out = true; return true; }
+    if (s == "false" || s == "0" || s == "no" || s == "off") { out = false; return true; }
+    return false;
+}
+
+template <typename T>
+static bool to_num(const std::string& v, T& out) {
+    if (v.empty()) return false;
+    char* end = nullptr;
+    if (std::is_floating_point<T>::value) {
+        const double d = strtod(v.c_str(), &end);
+        if (*end) return false;
+        out = (T)d;
+    } else if (std::is_signed<T>::value) {
+        const long long d = strtoll(v.c_str(), &end, 10);
+        if (*end) return false;
+        out = (T)d;
+    } else {
+        if (v[0] == '-') return false;
+        const unsigned long long d = strtoull(v.c_str(), &end, 10);
+        if (*end) return false;
+        out = (T)d;
+    }
+    return true;
+}
+
+static double now_s() {
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    return tv.tv_sec + tv.tv_usec * 1e-6;
+}
+
+int main(int argc, char** argv) {
+    ProgramSettings ps;
+    std::vector<Opt> opts;
+    std::map<std::string, int> seen;
+    auto S = [&](const char* n, char sh, std::string* p, const char* h) {
+        opts.push_back({n, sh, false, [p](const std::string& v) { *p = v; return true; }, h});
+    };
+    auto B = [&](const char* n, char sh, bool* p, const char* h) {
+        opts.push_back({n, sh, false, [p](const std::string& v) { return to_bool(v, *p); }, h});
+    };
+#define NUM(n, sh, p, h) opts.push_back({n, sh, false, [&](const std::string& v) { return to_num(v, p); }, h})
+    opts.push_back({"help", 0, true, [](const std::string&) { return true; }, "produce help message"});
+    S("fastq", 0, &ps.fastq_file, "path to fastq files: paired_1.fastq, paired_2.fastq and single.fastq");
+    S("singles", 's', &ps.singles_file, "path to single-end read fastq file");
+    S("paired1", 0, &ps.paired1_file, "path to paired-end read /1 fastq file");
+    S("paired2", 0, &ps.paired2_file, "path to paired-end read /2 fastq file");
+    S("overlaps", 0, &ps.overlaps_file, "path to overlap file");
+    S("output", 'O', &ps.output_dir, "path to output files");
+    S("IDs", 0, &ps.id_correspondence, "path to ID correspondence file");
+    NUM("max_ov", 0, ps.max_overlaps, "set the maximum number of overlaps considered");
+    NUM("max_reads", 0, ps.max_reads, "set the maximum number of reads used");
+    NUM("threads", 't', ps.n_threads, "set the number of threads used");
+    NUM("min_clique_size", 0, ps.min_clique_size, "set the minimum clique size for a superread");
+    NUM("min_qual", 0, ps.min_qual, "set the minimum base quality for a superread");
+    NUM("min_overlap_perc", 0, ps.min_overlap_perc, "set the minimum overlap percentage");
+    NUM("min_overlap_len", 0, ps.min_overlap_len, "set the minimum overlap length (bp)");
+    NUM("edge_threshold", 0, ps.edge_threshold, "set the minimal overlap score for creating an edge");
+    NUM("ov_threshold", 0, ps.ov_threshold, "set the minimal overlap score for keeping non-edge overlap");
+    B("allow_spaced_overlaps", 0, &ps.allow_spaces, "allow space-delimited overlaps instead of tabs");
+    B("first_it", 0, &ps.first_it, "set to true when there is no subreads file");
+    B("add_duplicates", 0, &ps.add_duplicates, "deal with reverse complements by adding duplicate vertices");
+    B("resolve_orientations", 0, &ps.resolve_orientations, "deal with reverse complements by labelling vertices");
+    NUM("keep_singletons", 0, ps.keep_singletons, "minimal read length for singletons not to be removed");
+    B("error_correction", 0, &ps.error_correction, "only do error correction");
+    B("cliques", 0, &ps.cliques, "clique-merging instead of edge-merging");
+    B("ignore_inclusions", 0, &ps.ignore_inclusions, "ignore full inclusion edges in overlap graph");
+    B("graph_only", 0, &ps.graph_only, "only do the graph construction");
+    NUM("FNO", 0, ps.fno, "set the FindNextOverlaps function desired");
+    NUM("original_readcount", 0, ps.original_readcount, "the number of original reads");
+    NUM("mismatch", 0, ps.mismatch, "minimal score per position in overlap");
+    B("optimize", 0, &ps.optimize, "optimize FNO by not reconsidering non-edge overlaps");
+    B("no_inclusion_overlaps", 0, &ps.no_inclusions, "do not add full inclusion overlaps");
+    NUM("merge_contigs", 0, ps.merge_contigs, "allow edge construction based on <merge_contigs> mismatch rate");
+    B("remove_multi_occ", 0, &ps.remove_multi_occ, "remove clique nodes when used before");
+    NUM("remove_trans", 0, ps.remove_trans, "remove (0) no, (1) single, (2) double, (3) triple transitive edges");
+    B("remove_branches", 0, &ps.remove_branches, "remove branches from overlap graph");
+    B("remove_tips", 0, &ps.remove_tips, "remove tips from overlap graph to reduce branching");
+    NUM("min_read_len", 0, ps.min_read_len, "set the minimum read length (bp) for allowing edges");
+    NUM("max_tip_len", 0, ps.max_tip_len, "set the maximum extension length for a node to be considered a tip");
+    B("separate_tips", 0, &ps.store_tips_separately, "store tip-sequences in a separate file");
+    S("base_path", 0, &ps.base_path, "set path to SAVAGE directory containing quick-cliques-1.0");
+    B("diploid", 0, &ps.diploid, "apply edge filtering for diploid genomes");
+    B("relax_PE_edges", 0, &ps.relax_PE_edges, "relax edge restrictions for paired-end overlaps");
+    S("original_fastq", 0, &ps.original_fastq, "original reads for applying read-based branch reduction");
+    B("branch_reduction", 0, &ps.branch_reduction, "read-based branch reduction");
+    NUM("branch_SE_c", 0, ps.branch_SE_c, "number of single-end input reads in original fastq");
+    NUM("branch_PE_c", 0, ps.branch_PE_c, "number of paired-end input reads in original fastq");
+    B("careful_diploid", 0, &ps.careful, "more careful merging by avoiding neighboring components");
+    B("verbose", 'v', &ps.verbose, "output additional information during assembly");
+    NUM("device", 0, ps.device, "[hc-edgecalc] HIP device ordinal");
+
+    auto usage = [&]() {
+        puts("Program options:");
+        for (const Opt& o : opts) {
+            std::string n = "  --" + o.name;
+            if (o.shortname) n = std::string("  -") + o.shortname + " [ --" + o.name + " ]";
+            if (!o.is_flag_without_value) n += " arg";
+            printf("%-44s %s\n", n.c_str(), o.help.c_str());
+        }
+        puts("");
+    };
+    auto find = [&](const std::string& n, char sh) -> Opt* {
+        for (Opt& o : opts)
+            if ((!n.empty() && o.name == n) || (sh && o.shortname == sh)) return &o;
+        return nullptr;
+    };
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i], name, val;
+        bool has_val = false;
+        Opt* o = nullptr;
+        if (a.rfind("--", 0) == 0) {
+            const size_t eq = a.find('=');
+            name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            if (eq != std::string::npos) { val = a.substr(eq + 1); has_val = true; }
+            o = find(name, 0);
+        } else if (a.size() >= 2 && a[0] == '-') {
+            o = find("", a[1]);
+            name = a.substr(1, 1);
+            if (a.size() > 2) { val = a.substr(2); has_val = true; }
+        }
+        if (!o) {
+            fprintf(stderr, "unrecognised option '%s'\n", a.c_str());
+            return 1;
+        }
+        if (!o->is_flag_without_value && !has_val) {
+            if (i + 1 >= argc) {
+                fprintf(stderr, "the required argument for option '--%s' is missing\n", o->name.c_str());
+                return 1;
+            }
+            val = argv[++i];
+        }
+        if (!o->set(val)) {
+            fprintf(stderr, "the argument ('%s') for option '--%s' is invalid\n", val.c_str(), o->name.c_str());
+            return 1;
+        }
+        seen[o->name]++;
+    }
+    // options with a default_value() count as present in the reference's variables_map (vm.count)
+    for (const char* d : {"singles", "paired1", "paired2"}) seen[d]++;
+    auto count = [&](const char* n) { return seen.count(n) ? seen[n] : 0; };
+
+    if (count("help")) {  // src/ViralQuasispecies.cpp:104-107
+        usage();
+        return 0;
+    }
+    if (!(count("fastq") || count("singles") || count("paired1") || count("paired2"))) {  // :111-115
+        fputs("No fastq file(s) provided.\n\n", stderr);
+        usage();
+        return 1;
+    } else if (count("fastq") && (!ps.singles_file.empty() || !ps.paired1_file.empty() || !ps.paired2_file.empty())) {  // :116-120
+        fputs("Cannot combine --fastq option with --singles, --paired1 or --paired2. \n\n", stderr);
+        usage();
+        return 1;
+    }
+    if (!count("overlaps")) {  // :128-132
+        fputs("No overlaps file provided.\n\n", stderr);
+        usage();
+        return 1;
+    }
+    if (!count("original_readcount")) {  // :134-138
+        fputs("No original readcount provided.\n\n", stderr);
+        usage();
+        return 1;
+    }
+    if (ps.add_duplicates && ps.resolve_orientations) {  // :144-148
+        fputs("Add duplicates and resolve orientations are exclusive options, use at most 1.\n\n", stderr);
+        usage();
+        return 1;
+    }
+    if (ps.error_correction && !ps.cliques) {  // :150-154
+        fputs("Error correction requires clique enumeration. Set --cliques=true.\n", stderr);
+        usage();
+        return 1;
+    }
+
+    {  // settings block of viralquasispecies.log, :160-218 (the fields the edge-calculation stage reads)
+        FILE* lf = fopen((ps.output_dir + "viralquasispecies.log").c_str(), "w");
+        if (lf) {
+            time_t raw;
+            time(&raw);
+            fprintf(lf, "%s\n\nInput:\n%s\n%s\n%s\n%s\n\n", ctime(&raw), ps.singles_file.c_str(), ps.paired1_file.c_str(),
+                    ps.paired2_file.c_str(), ps.overlaps_file.c_str());
+            fprintf(lf, "Output directory: %s\nMaximum number of overlaps: %lu\nThreads: %u\n", ps.output_dir.c_str(),
+                    ps.max_overlaps, ps.n_threads);
+            fprintf(lf, "Minimal overlap percentage: %u\nMinimal overlap length: %u\nEdge threshold: %g\nOverlap threshold: %g\n",
+                    ps.min_overlap_perc, ps.min_overlap_len, ps.edge_threshold, ps.ov_threshold);
+            fprintf(lf, "Add duplicates: %d\nResolve read orientations: %d\nIgnore inclusions: %d\nMismatch prob: %g\n",
+                    ps.add_duplicates, ps.resolve_orientations, ps.ignore_inclusions, ps.mismatch);
+            fprintf(lf, "Merge contigs: %g\nMinimal read length: %u\nRelax PE edges: %d\nVerbose: %d\n", ps.merge_contigs,
+                    ps.min_read_len, ps.relax_PE_edges, ps.verbose);
+            fclose(lf);
+        }
+    }
+    if (count("fastq")) {  // :226-230
+        ps.singles_file = ps.fastq_file + "/singles.fastq";
+        ps.paired1_file = ps.fastq_file + "/paired1.fastq";
+        ps.paired2_file = ps.fastq_file + "/paired2.fastq";
+    }
+    try {
+        double t0 = now_s();
+        auto fastq = std::make_shared<FastqStorage>(ps);  // :233
+        if (ps.verbose) printf("FastqStorage ready! Construction took %g seconds.\n", now_s() - t0);
+        t0 = now_s();
+        auto graph = std::make_shared<OverlapGraph>(fastq->get_readcount(), fastq, ps);  // :252-261
+        if (ps.verbose) puts("Adding vertices...");
+        for (Read* r : fastq->m_read_vec) r->set_vertex_id(true, graph->addVertex(r->get_read_id()));  // :266-271
+        if (ps.verbose) {
+            printf("Overlap graph ready! Construction took %g seconds.\n", now_s() - t0);
+            printf("Number of vertices: %u\n", graph->getVertexCount());
+        }
+        EdgeCalculator calc(fastq, graph, ps);  // :279
+        t0 = now_s();
+        calc.construct_edges();  // :281
+        const double dt = now_s() - t0;
+        if (graph->getEdgeCount() == 0) {  // :284-291
+            if (ps.verbose) puts("There were no edges constructed, so there is nothing to be done.");
+            remove((ps.output_dir + "graph.txt").c_str());
+            return 0;
+        } else if (ps.verbose) {
+            printf("%u edges have been constructed in %g seconds.\n", graph->getEdgeCount(), dt);
+            printf("[hc-edgecalc] parse %.3f s, score (H2D + kernel + D2H) %.3f s, insert %.3f s, write %.3f s; %lu candidates scored\n",
+                   calc.stats.t_parse, calc.stats.t_score, calc.stats.t_insert, calc.stats.t_write,
+                   (unsigned long)calc.stats.scored);
+        }
+        FILE* ef = fopen((ps.output_dir + "edges.tsv").c_str(), "w");
+        if (ef) {
+            for (const auto& L : graph->adj_out)
+                for (const Edge& e : L)
+                    fprintf(ef, "%lu\t%lu\t%lu\t%lu\t%d\t%d\t%d\t%d\t%c\t%c\t%c\t%d\t%d\t%d\t%d\t%.17g\t%.17g\n", e.get_vertex(1),
+                            e.get_vertex(2), e.get_read(1)->get_read_id(), e.get_read(2)->get_read_id(), e.get_pos(1),
+                            e.get_pos(2), e.get_extra_pos(1), e.get_extra_pos(2), e.get_ori(1) ? '+' : '-',
+                            e.get_ori(2) ? '+' : '-', e.get_ord() ? e.get_ord() : '-', e.get_perc(), e.get_len(0), e.get_len(1),
+                            e.get_len(2), e.get_score(), e.get_mismatch_rate());
+            fclose(ef);
+        }
+        FILE* sf = fopen((ps.output_dir + "edgecalc_stats.txt").c_str(), "w");
+        if (sf) {
+            fprintf(sf, "vertex_count\t%u\nedge_count\t%u\ninclusion_count\t%u\ndup_count\t%u\nself_overlap_count\t%u\n",
+                    graph->getVertexCount(), graph->getEdgeCount(), calc.inclusion_count, calc.dup_count, calc.self_overlap_count);
+            fclose(sf);
+        }
+    } catch (const FatalError& e) {  // every exit(1) / assert of the reference on this path
+        fprintf(stderr, "%s\n", e.what.c_str());
+        return 1;
+    }
+    return 0;
+}

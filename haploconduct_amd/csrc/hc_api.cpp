@@ -34,6 +34,9 @@ static int fail(int status, const std::string& what) {
     g_last_error = what;
     return status;
 }
+namespace hc {
+int set_last_error(int status, const std::string& what) { return fail(status, what); }  // for host/*.cpp
+}
 
 #define HC_HIP(call)                                                                                   \
     do {                                                                                               \

@@ -1,0 +1,259 @@
+// EdgeCalculator.cpp — construct_edges / process_overlaps of the reference
+// (src/EdgeCalculator.cpp:389-666) with the OpenMP scoring loop replaced by the HIP path
+// behind include/hcedge.h.  The serial insert (duplicate resolution with the reference's
+// tie-break chain) and the nonedge_overlaps.txt bookkeeping stay on the host.
+#include "EdgeCalculator.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace hc {
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+hc_settings to_hc_settings(const ProgramSettings& ps) {
+    hc_settings s;
+    memset(&s, 0, sizeof s);
+    s.edge_threshold = ps.edge_threshold;
+    s.ov_threshold = ps.ov_threshold;
+    s.merge_contigs = ps.merge_contigs;
+    s.mismatch = ps.mismatch;
+    s.min_read_len = ps.min_read_len;
+    s.min_overlap_len = ps.min_overlap_len;
+    s.min_overlap_perc = ps.min_overlap_perc;
+    s.flags = (ps.add_duplicates ? HC_FLAG_ADD_DUPLICATES : 0u) | (ps.resolve_orientations ? HC_FLAG_RESOLVE_ORIENTATIONS : 0u) |
+              (ps.ignore_inclusions ? HC_FLAG_IGNORE_INCLUSIONS : 0u) | (ps.relax_PE_edges ? HC_FLAG_RELAX_PE_EDGES : 0u) |
+              (ps.allow_spaces ? HC_FLAG_ALLOW_SPACES : 0u) | (ps.verbose ? HC_FLAG_VERBOSE : 0u);
+    s.max_overlaps = ps.max_overlaps;
+    s.device = ps.device;
+    s.n_threads = ps.n_threads;
+    return s;
+}
+
+static void check(int status, const char* where) {
+    if (status != HC_OK) throw FatalError{status, std::string(where) + ": " + hc_strerror(status) + " " + hc_last_error()};
+}
+
+EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_ptr<OverlapGraph> graph,
+                               const ProgramSettings& ps)
+    : program_settings(ps), fastq_storage(std::move(fastq)), overlap_graph(std::move(graph)) {
+    if (ps.add_duplicates) throw FatalError{HC_ERR_ARG, "--add_duplicates is not supported (the pipelines never set it)"};
+    m_cs = to_hc_settings(ps);
+    check(hc_create(&m_ctx, &m_cs), "hc_create");
+    const FastqStorage& f = *fastq_storage;
+    check(hc_set_reads(m_ctx, f.bases().data(), f.quals().data(), f.seq_off().data(), f.read_first_seq().data(),
+                       f.get_readcount()),
+          "hc_set_reads");
+}
+
+EdgeCalculator::~EdgeCalculator() {
+    if (m_ctx) hc_destroy(m_ctx);
+}
+
+double EdgeCalculator::phred_to_prob(int phred) const { return pow(10, -phred / 10.0); }  // :59-63
+
+double EdgeCalculator::overlap_score(const std::string& seq1, const std::string& seq2, const std::string& score1,
+                                     const std::string& score2, unsigned int pos, double& mismatch_rate) {
+    // a scratch context holding the two strings as two single-end reads
+    if (seq1.empty() || seq2.empty() || seq1.size() != score1.size() || seq2.size() != score2.size())
+        throw FatalError{HC_ERR_ARG, "overlap_score: empty or mismatched strings"};
+    hc_settings cs = m_cs;
+    hc_ctx* ctx = nullptr;
+    check(hc_create(&ctx, &cs), "hc_create");
+    std::string bases = seq1 + seq2, quals = score1 + score2;
+    const uint64_t off[3] = {0, seq1.size(), seq1.size() + seq2.size()};
+    const uint32_t first[3] = {0, 1, 2};
+    hc_overlap_rec rec;
+    memset(&rec, 0, sizeof rec);
+    rec.read1 = 0; rec.read2 = 1; rec.pos1 = pos; rec.ori1 = rec.ori2 = 1; rec.ord = '-';
+    hc_result_rec res;
+    int st = hc_set_reads(ctx, (const uint8_t*)bases.data(), (const uint8_t*)quals.data(), off, first, 2);
+    if (st == HC_OK) st = hc_score_batch(ctx, &rec, 1, &res);
+    hc_destroy(ctx);
+    check(st, "overlap_score");
+    double score;
+    uint32_t cls;
+    check(hc_finalize(&cs, &res, &score, &mismatch_rate, &cls), "hc_finalize");
+    return score;
+}
+
+// src/EdgeCalculator.cpp:441-538
+void insert_edge(OverlapGraph& g, const ProgramSettings& program_settings, Edge& e, InsertCounters& c) {
+    node_id_t v1 = e.get_vertex(1), v2 = e.get_vertex(2);
+    if (e.get_pos(1) == 0 && v1 > v2) {  // :443-448: undetermined direction => small id to large id
+        std::swap(v1, v2);
+        e.swap_reads();
+    }
+    if (e.get_perc() == 100) c.inclusion_count++;  // :449-451, before de-duplication
+    const bool opposite_orientations = (e.get_ori(1) == e.get_ori(2));
+    const double score = g.checkEdgeWithOri(v1, v2, opposite_orientations);
+    if (score < 0) {  // :455-469
+        g.addEdge(e);
+        c.edges_added++;
+        if (program_settings.ignore_inclusions && e.get_perc() == 100 && e.get_mismatch_rate() < 0.000001 &&
+            e.get_mismatch_rate() >= 0) {
+            if (e.get_extra_pos(1) < 0) {
+                if (e.get_pos(1) == 0) g.inclusions[v1] = 1;  // otherwise only an effect of rounding the percentage
+            } else {
+                g.inclusions[v2] = 1;
+            }
+        }
+        return;
+    }
+    c.dup_count++;  // `doubles++` on both remaining branches, :472,537
+    if (!(e.get_score() >= score)) return;  // :535-538
+    Edge* ex = g.getEdgeInfoWithOri(v1, v2, opposite_orientations, true);
+    if (score == e.get_score()) {  // deterministic tie-break chain, :474-521
+        if (ex->get_len(0) != e.get_len(0)) {
+            if (ex->get_len(0) > e.get_len(0)) return;
+        } else if (ex->get_mismatch_rate() != e.get_mismatch_rate()) {
+            if (ex->get_mismatch_rate() < e.get_mismatch_rate()) return;
+        } else if (ex->get_vertex(1) != e.get_vertex(1)) {
+            if (ex->get_vertex(1) < e.get_vertex(1)) return;
+        } else if (ex->get_ori(1) != e.get_ori(1)) {
+            if (ex->get_ori(1)) return;
+        } else if (ex->get_ori(2) != e.get_ori(2)) {
+            if (ex->get_ori(2)) return;
+        } else if (ex->get_pos(1) != e.get_pos(1)) {
+            if (ex->get_pos(1) < e.get_pos(1)) return;
+        } else if (ex->get_pos(2) != e.get_pos(2)) {
+            if (ex->get_pos(2) < e.get_pos(2)) return;
+        }
+    }
+    if (ex->get_vertex(1) == v1) g.removeEdgeWithOri(v1, v2, opposite_orientations);  // :523-528
+    else g.removeEdgeWithOri(v2, v1, opposite_orientations);
+    g.addEdge(e);  // :530
+}
+
+// src/EdgeCalculator.cpp:389-557
+void EdgeCalculator::process_overlaps(const std::vector<ParsedOverlap>& batch) {
+    const size_t n = batch.size();
+    if (n == 0) return;
+    double t0 = now_s();
+    m_rec.resize(n);
+    m_res.resize(n);
+    for (size_t i = 0; i < n; i++) m_rec[i] = batch[i].rec;
+    check(hc_score_batch(m_ctx, m_rec.data(), n, m_res.data()), "hc_score_batch");  // the omp-for, :395-414
+    stats.scored += n;
+    double t1 = now_s();
+    stats.t_score += t1 - t0;
+    if (program_settings.verbose) puts("build edges / write overlaps to file");
+
+    const FastqStorage& f = *fastq_storage;
+    unsigned int count_before = overlap_graph->getEdgeCount(), dups_before = dup_count;
+    uint64_t added_before = stats.edges_added;
+    m_nonedge_buf.clear();
+    char linebuf[192];
+    for (size_t i = 0; i < n; i++) {
+        const hc_result_rec& r = m_res[i];
+        uint32_t cls = HC_RES_CLS(r);
+        if (cls == HC_CLS_DROP) continue;
+        if (cls == HC_CLS_ERROR)
+            throw FatalError{HC_ERR_DATA, "overlap " + batch[i].line.get_overlap_line() + " touches an invalid base or quality byte"};
+        if (cls == HC_CLS_NONEDGE) {  // :410-413
+            m_nonedge_buf.append(linebuf, batch[i].line.write_line(linebuf));
+            stats.nonedges_written++;
+            continue;
+        }
+        double score, mismatch_rate;
+        if (cls == HC_CLS_AMBIG) stats.ambiguous++;
+        check(hc_finalize(&m_cs, &r, &score, &mismatch_rate, &cls), "hc_finalize");  // exp() with the host libm
+        if (cls == HC_CLS_DROP) continue;
+        if (cls == HC_CLS_NONEDGE) {
+            m_nonedge_buf.append(linebuf, batch[i].line.write_line(linebuf));
+            stats.nonedges_written++;
+            continue;
+        }
+        // build the Edge as compute_overlap does, :219-232 / :254-270 / :292-308 / :353-379
+        const hc_overlap_rec& o = m_rec[i];
+        Read* r1 = f.m_read_vec[o.read1];
+        Read* r2 = f.m_read_vec[o.read2];
+        const bool p1 = r1->is_paired(), p2 = r2->is_paired();
+        const int pos1 = (int)o.pos1, pos2 = (int)o.pos2;
+        int pos3, pos4 = 0;
+        if (!p1 && !p2) {
+            pos3 = (int)r1->get_seq_len(0) - pos1 - (int)r2->get_seq_len(0);                 // :222
+        } else if (!p1 && p2) {
+            pos3 = (int)r1->get_seq_len(0) - pos2 - (int)r2->get_seq_len(2);                 // :262
+            pos4 = (int)r1->get_seq_len(0) - pos1 - (int)r2->get_seq_len(1);                 // :263
+        } else if (p1 && !p2) {
+            pos3 = (int)r1->get_seq_len(2) + pos2 - (int)r2->get_seq_len(0);                 // :300
+            pos4 = (int)r2->get_seq_len(0) + pos1 - (int)r1->get_seq_len(1);                 // :301
+        } else {
+            pos3 = o.ord == '1' ? (int)r1->get_seq_len(2) - pos2 - (int)r2->get_seq_len(2)   // :363
+                                : (int)r1->get_seq_len(2) + pos2 - (int)r2->get_seq_len(2);  // :370
+            pos4 = (int)r1->get_seq_len(1) - pos1 - (int)r2->get_seq_len(1);                 // :372
+        }
+        Edge e(score, pos1, pos2, o.ori1 != 0, o.ori2 != 0, std::string(1, (char)o.ord), r1, r2);
+        e.set_vertices(r1->get_vertex_id(true), r2->get_vertex_id(true));  // :180-183
+        e.set_extra_pos(pos3, pos4);
+        e.set_perc((int)o.perc);
+        e.set_len((int)o.len1, (!p1 && !p2) ? 0 : (int)o.len2);  // :227 / :268
+        e.set_mismatch(mismatch_rate);
+        InsertCounters ic;
+        insert_edge(*overlap_graph, program_settings, e, ic);
+        inclusion_count += ic.inclusion_count;
+        dup_count += ic.dup_count;
+        stats.edges_added += ic.edges_added;
+    }
+    double t2 = now_s();
+    stats.t_insert += t2 - t1;
+    if (program_settings.verbose) {
+        (void)count_before;
+        printf("Number of edges found: %lu\n", (unsigned long)(stats.edges_added - added_before));
+        printf("Number of duplicates: %u\n", dup_count - dups_before);
+    }
+    if (!m_nonedge_buf.empty() || true) {  // :546-555 (the file is opened in append mode even when nothing is written)
+        FILE* fo = fopen((program_settings.output_dir + "nonedge_overlaps.txt").c_str(), "a");
+        if (fo) {
+            fwrite(m_nonedge_buf.data(), 1, m_nonedge_buf.size(), fo);
+            fclose(fo);
+        }
+    }
+    stats.t_write += now_s() - t2;
+}
+
+// src/EdgeCalculator.cpp:561-666
+void EdgeCalculator::construct_edges() {
+    std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
+    std::vector<Overlap> rejected;
+    OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
+    if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
+    if (program_settings.verbose) puts("reading overlaps file... ");
+    const size_t overlaps_per_vec = 1000000;  // :571
+    std::vector<ParsedOverlap> batch;
+    batch.reserve(overlaps_per_vec);
+    ParseCounters pc;
+    for (;;) {
+        const double t0 = now_s();
+        const bool more = parser.next_batch(batch, overlaps_per_vec, rejected, pc, /*print_malformed=*/true);
+        stats.t_parse += now_s() - t0;
+        if (!batch.empty()) process_overlaps(batch);  // :636-644
+        if (!more) break;
+    }
+    stats.lines_read = pc.lines_read;
+    stats.malformed = pc.malformed;
+    stats.self_overlaps = pc.self_overlaps;
+    stats.prefilter_rejected = pc.prefilter_rejected;
+    stats.silently_dropped = pc.silently_dropped;
+    if (program_settings.verbose) {  // :646-649
+        printf("Number of self-overlapping reads: %u\n", self_overlap_count);
+        printf("Number of inclusion edges: %u\n", inclusion_count);
+    }
+    const double t0 = now_s();
+    FILE* fo = fopen((program_settings.output_dir + "nonedge_overlaps.txt").c_str(), "a");  // :654-660
+    if (fo) {
+        char linebuf[192];
+        std::string buf;
+        for (const Overlap& o : rejected) buf.append(linebuf, o.write_line(linebuf));
+        fwrite(buf.data(), 1, buf.size(), fo);
+        fclose(fo);
+    }
+    stats.t_write += now_s() - t0;
+}
+
+}  // namespace hc

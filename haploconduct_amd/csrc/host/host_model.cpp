@@ -1,0 +1,367 @@
+// host_model.cpp — Read, FastqStorage, Overlap, OverlapGraph: the host-side mirror of the
+// reference's data model for the edge-calculation path.  Own implementation; every routine
+// cites the reference lines whose behaviour it reproduces.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "../../../include/hcedge.h"
+#include "Edge.h"
+#include "FastqStorage.h"
+#include "Overlap.h"
+#include "OverlapGraph.h"
+
+namespace hc {
+
+// ------------------------------------------------------------------ Read
+node_id_t Read::get_vertex_id(bool normal) const {  // src/Read.h:111-120
+    if (normal ? !m_N_set : !m_R_set) throw FatalError{HC_ERR_STATE, "Read::get_vertex_id: vertex id not set"};
+    return normal ? m_vertex_N : m_vertex_R;
+}
+
+static void check_mate(bool paired, int i) {  // asserts of src/Read.h:145-149
+    if (paired ? !(i == 1 || i == 2) : i != 0) throw FatalError{HC_ERR_ARG, "Read: mate index must be 0 (single) or 1/2 (paired)"};
+}
+
+unsigned int Read::get_seq_len(int i) const {
+    check_mate(m_is_paired, i);
+    return m_store->seq_len(m_store->seq_index(m_index, i));
+}
+
+std::string Read::get_seq(int i) const {
+    check_mate(m_is_paired, i);
+    const uint32_t q = m_store->seq_index(m_index, i);
+    const uint8_t* p = m_store->bases().data() + m_store->seq_off()[q];
+    return std::string((const char*)p, m_store->seq_len(q));
+}
+
+std::string Read::get_phred(int i) const {
+    check_mate(m_is_paired, i);
+    const uint32_t q = m_store->seq_index(m_index, i);
+    const uint8_t* p = m_store->quals().data() + m_store->seq_off()[q];
+    return std::string((const char*)p, m_store->seq_len(q));
+}
+
+std::string Read::get_rev_comp(int i) const {  // src/Read.h:172-184 + src/Types.h:109-129
+    std::string s = get_seq(i);
+    std::reverse(s.begin(), s.end());
+    for (char& c : s) {
+        switch (c) {
+            case 'A': c = 'T'; break;
+            case 'T': c = 'A'; break;
+            case 'C': c = 'G'; break;
+            case 'G': c = 'C'; break;
+            case 'N': break;
+            default: throw FatalError{HC_ERR_FORMAT, "Invalid sequence character. Aborting."};
+        }
+    }
+    return s;
+}
+
+std::string Read::get_rev_phred(int i) const {  // src/Read.h:186-201
+    std::string s = get_phred(i);
+    std::reverse(s.begin(), s.end());
+    return s;
+}
+
+unsigned int Read::get_len() const {  // src/Read.h:203-212
+    return m_is_paired ? get_seq_len(1) + get_seq_len(2) : get_seq_len(0);
+}
+
+// ------------------------------------------------------------------ FastqStorage
+static bool read_lines(const std::string& path, uint64_t max_lines, std::vector<std::string>& out) {  // src/FastqStorage.cpp:42-57
+    std::ifstream f(path.c_str());
+    if (!f.is_open()) return false;
+    std::string line;
+    uint64_t count = 0;
+    while (std::getline(f, line) && count < max_lines) {
+        out.push_back(line);
+        count++;
+    }
+    return true;
+}
+
+static std::string first_token(const std::string& s) {  // `stream >> id1` on line.substr(1)
+    size_t a = 0;
+    while (a < s.size() && isspace((unsigned char)s[a])) a++;
+    size_t b = a;
+    while (b < s.size() && !isspace((unsigned char)s[b])) b++;
+    return s.substr(a, b - a);
+}
+
+read_id_t FastqStorage::resolve_id(const std::string& token) const {  // src/FastqStorage.cpp:112-117
+    if (m_have_new_ids) {
+        auto it = m_new_readIDs.find(token);
+        if (it == m_new_readIDs.end()) throw FatalError{HC_ERR_FORMAT, "read id '" + token + "' missing from the --IDs file"};
+        return str_to_read_id(it->second);
+    }
+    return str_to_read_id(token);
+}
+
+void FastqStorage::read_new_ids(const std::string& path) {  // src/FastqStorage.cpp:60-90
+    std::ifstream f(path.c_str());
+    if (!f.is_open()) throw FatalError{HC_ERR_IO, "Unable to open read-to-overlapID file"};
+    std::string line;
+    unsigned int max_id = 0;
+    while (std::getline(f, line)) {
+        const size_t t1 = line.find('\t');
+        std::string new_id = line.substr(0, t1);
+        std::string old_id;
+        if (t1 != std::string::npos) {
+            const size_t t2 = line.find('\t', t1 + 1);
+            old_id = line.substr(t1 + 1, t2 == std::string::npos ? std::string::npos : t2 - t1 - 1);
+        }
+        if (old_id.empty()) throw FatalError{HC_ERR_FORMAT, "--IDs line without an old id"};  // .at(0) throws in the reference
+        if (old_id[0] == '>') old_id = old_id.substr(1);
+        const read_id_t nid = str_to_read_id(new_id);
+        if (nid > max_id) max_id = (unsigned int)nid;
+        m_new_readIDs.insert(std::make_pair(old_id, new_id));
+    }
+    m_largest_read_id = max_id;
+    m_have_new_ids = true;
+}
+
+void FastqStorage::push_sequence(const char* s, size_t ns, const char* q, size_t nq, bool upper) {
+    if (ns != nq)  // the reference would index past the shorter string (.at() throws) or misalign rev_phred
+        throw FatalError{HC_ERR_BAD_READ, "FASTQ record with sequence and quality strings of different length"};
+    const size_t o = m_bases.size();
+    m_bases.resize(o + ns);
+    m_quals.resize(o + ns);
+    for (size_t i = 0; i < ns; i++) m_bases[o + i] = upper ? (uint8_t)toupper((unsigned char)s[i]) : (uint8_t)s[i];
+    memcpy(m_quals.data() + o, q, ns);
+    m_seq_off.push_back(o + ns);
+}
+
+void FastqStorage::read_singles(const std::string& path, unsigned long max_reads) {  // src/FastqStorage.cpp:92-152
+    std::vector<std::string> lines;
+    if (!read_lines(path, 4ull * (unsigned int)max_reads, lines)) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + path};
+    for (size_t r = 0; r + 3 < lines.size(); r += 4) {
+        const std::string& h = lines[r];
+        if (h.empty() || h[0] != '@') throw FatalError{HC_ERR_FORMAT, "Read ID does not start with @. Exiting read_singles."};
+        const read_id_t id = resolve_id(first_token(h.substr(1)));
+        const std::string& seq = lines[r + 1];
+        const std::string& ph = lines[r + 3];
+        if (seq.empty()) throw FatalError{HC_ERR_BAD_READ, "single read with ID " + std::to_string(id) + " has an empty sequence... exiting."};
+        push_sequence(seq.data(), seq.size(), ph.data(), ph.size(), /*upper=*/true);  // boost::to_upper_copy, :122
+        m_first.push_back(m_first.back() + 1);
+        m_singles_vec.emplace_back(this, 0u, false, id);
+    }
+}
+
+void FastqStorage::read_pairs(const std::string& p1, const std::string& p2, unsigned long max_reads) {  // :154-235
+    std::vector<std::string> l1, l2;
+    if (!read_lines(p1, 4ull * (unsigned int)max_reads, l1)) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + p1};
+    if (!read_lines(p2, 4ull * (unsigned int)max_reads, l2)) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + p2};
+    const size_t n = std::min(l1.size(), l2.size());
+    for (size_t r = 0; r + 3 < n; r += 4) {
+        if (l1[r].empty() || l1[r][0] != '@') throw FatalError{HC_ERR_FORMAT, "Read ID does not start with @. Exiting read_pairs."};
+        const std::string id1 = first_token(l1[r].substr(1));
+        const std::string id2 = first_token(l2[r].empty() ? std::string() : l2[r].substr(1));
+        if (id1 != id2) throw FatalError{HC_ERR_FORMAT, "Fastq files /1 /2 are not ordered identically. Exiting read_pairs."};
+        const read_id_t id = resolve_id(id1);
+        if (l1[r + 1].empty() || l2[r + 1].empty())
+            throw FatalError{HC_ERR_BAD_READ, "paired read with ID " + std::to_string(id) + " has an empty sequence... exiting."};
+        push_sequence(l1[r + 1].data(), l1[r + 1].size(), l1[r + 3].data(), l1[r + 3].size(), /*upper=*/false);  // pairs are NOT upper-cased, :197-198
+        push_sequence(l2[r + 1].data(), l2[r + 1].size(), l2[r + 3].data(), l2[r + 3].size(), false);
+        m_first.push_back(m_first.back() + 2);
+        m_paired_vec.emplace_back(this, 0u, true, id);
+    }
+}
+
+FastqStorage::FastqStorage(const ProgramSettings& ps) {  // src/FastqStorage.h:58-98
+    if (!ps.id_correspondence.empty()) read_new_ids(ps.id_correspondence);
+    if (!ps.singles_file.empty() && ps.singles_file != "None") read_singles(ps.singles_file, ps.max_reads);
+    m_readcount_single = (unsigned int)m_singles_vec.size();
+    if (!ps.paired1_file.empty() && ps.paired1_file != "None") read_pairs(ps.paired1_file, ps.paired2_file, ps.max_reads);
+    m_readcount_paired = (unsigned int)m_paired_vec.size();
+    if (ps.verbose) {
+        printf("Singles: %u\n", m_readcount_single);
+        printf("Pairs: %u\n", m_readcount_paired);
+    }
+    unsigned int count = 0;
+    m_read_vec.reserve(m_singles_vec.size() + m_paired_vec.size());
+    for (auto& r : m_singles_vec) {
+        r = Read(this, count, false, r.get_read_id());
+        m_read_vec.push_back(&r);
+        m_ID_to_index.insert(std::make_pair(r.get_read_id(), count));
+        count++;
+    }
+    for (auto& r : m_paired_vec) {
+        r = Read(this, count, true, r.get_read_id());
+        m_read_vec.push_back(&r);
+        m_ID_to_index.insert(std::make_pair(r.get_read_id(), count));
+        count++;
+    }
+}
+
+Read* FastqStorage::get_read(read_id_t ID) {
+    auto it = m_ID_to_index.find(ID);
+    if (it == m_ID_to_index.end()) throw FatalError{HC_ERR_BAD_OVERLAP, "read id not in the FASTQ input"};
+    return m_read_vec[it->second];
+}
+
+// ------------------------------------------------------------------ Overlap
+static void strip(std::string& s, const char* drop) {
+    s.erase(std::remove_if(s.begin(), s.end(), [&](char c) { return strchr(drop, c) != nullptr; }), s.end());
+}
+
+static bool all_digits(const char* p, size_t n) {
+    if (n == 0 || n > 18) return false;
+    for (size_t i = 0; i < n; i++)
+        if (p[i] < '0' || p[i] > '9') return false;
+    return true;
+}
+
+static unsigned long parse_id(const char* p, size_t n) {  // strtoul(s, NULL, 0), src/Types.h:99-102
+    if (all_digits(p, n) && (p[0] != '0' || n == 1)) {
+        unsigned long v = 0;
+        for (size_t i = 0; i < n; i++) v = v * 10 + (unsigned long)(p[i] - '0');
+        return v;
+    }
+    return strtoul(std::string(p, n).c_str(), nullptr, 0);
+}
+
+static int parse_int(const char* p, size_t n) {  // atoi
+    if (n <= 9 && all_digits(p, n)) {
+        int v = 0;
+        for (size_t i = 0; i < n; i++) v = v * 10 + (p[i] - '0');
+        return v;
+    }
+    return atoi(std::string(p, n).c_str());
+}
+
+static char one_char(const char* p, size_t n, const char* strip_set, const char* what) {
+    if (n == 1) return p[0];
+    std::string s(p, n);
+    strip(s, strip_set);
+    if (s.size() != 1) throw FatalError{HC_ERR_FORMAT, std::string("overlap field '") + what + "' is not a single character"};
+    return s[0];
+}
+
+Overlap Overlap::from_fields(const char* const f[13], const size_t n[13]) {  // src/Overlap.h:39-73
+    Overlap o;
+    o.m_id1 = parse_id(f[0], n[0]);
+    o.m_id2 = parse_id(f[1], n[1]);
+    o.m_pos1 = (unsigned int)parse_int(f[2], n[2]);
+    o.m_pos2 = (unsigned int)parse_int(f[3], n[3]);
+    o.m_perc1 = (unsigned int)parse_int(f[7], n[7]);
+    o.m_perc2 = (unsigned int)parse_int(f[8], n[8]);
+    o.m_len1 = (unsigned int)parse_int(f[9], n[9]);
+    o.m_len2 = (unsigned int)parse_int(f[10], n[10]);
+    if (n[3] == 1 && f[3][0] == '-') {  // :55-59
+        o.m_pos2 = 0;
+        o.m_perc2 = 0;
+        o.m_len2 = 0;
+    }
+    if ((int)o.m_pos1 < 0 || (int)o.m_pos2 < 0) throw FatalError{HC_ERR_FORMAT, "overlap.m_pos < 0; Exiting."};  // :102-107
+    o.m_ori1 = one_char(f[5], n[5], " ", "ori1");                                                                 // :121-130
+    o.m_ori2 = one_char(f[6], n[6], " ", "ori2");
+    if ((o.m_ori1 != '+' && o.m_ori1 != '-') || (o.m_ori2 != '+' && o.m_ori2 != '-'))
+        throw FatalError{HC_ERR_FORMAT, "overlap.m_ori not of the right format (+, -). Exiting."};
+    if ((int)o.m_perc1 < 0 || (int)o.m_perc1 > 100 || (int)o.m_perc2 < 0 || (int)o.m_perc2 > 100)               // :132-138
+        throw FatalError{HC_ERR_FORMAT, "overlap.m_perc not of the right format (0 <= perc <= 100). Exiting."};
+    if ((int)o.m_len1 < 0 || (int)o.m_len2 < 0) throw FatalError{HC_ERR_FORMAT, "overlap.m_len < 0. Exiting."};  // :140-145
+    o.m_type1 = one_char(f[11], n[11], "\n\t ", "type1");                                                         // :147-158
+    o.m_type2 = one_char(f[12], n[12], "\n\t ", "type2");
+    if ((o.m_type1 != 's' && o.m_type1 != 'p') || (o.m_type2 != 's' && o.m_type2 != 'p'))
+        throw FatalError{HC_ERR_FORMAT, "overlap type not of the form 's' or 'p'. Exiting."};
+    o.m_ord = one_char(f[4], n[4], " ", "ord");                                                                   // :109-119
+    if (o.m_ord != '1' && o.m_ord != '2' && o.m_ord != '-') throw FatalError{HC_ERR_FORMAT, "overlap ord must be 1, 2 or -"};
+    if (o.m_type1 == 's' || o.m_type2 == 's') {
+        if (o.m_ord != '-') throw FatalError{HC_ERR_FORMAT, "overlap ord must be - when a read is single-end"};
+    } else if (o.m_ord == '-') {
+        throw FatalError{HC_ERR_FORMAT, "overlap ord must be 1 or 2 for a paired-paired overlap"};
+    }
+    return o;
+}
+
+static char* put_u(char* p, unsigned long v) {
+    char tmp[24];
+    int k = 0;
+    do {
+        tmp[k++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (k) *p++ = tmp[--k];
+    return p;
+}
+
+size_t Overlap::write_line(char* buf) const {  // src/Overlap.h:234-237
+    char* p = buf;
+    p = put_u(p, m_id1); *p++ = '\t';
+    p = put_u(p, m_id2); *p++ = '\t';
+    p = put_u(p, m_pos1); *p++ = '\t';
+    p = put_u(p, m_pos2); *p++ = '\t';
+    *p++ = m_ord; *p++ = '\t';
+    *p++ = m_ori1; *p++ = '\t';
+    *p++ = m_ori2; *p++ = '\t';
+    p = put_u(p, m_perc1); *p++ = '\t';
+    p = put_u(p, m_perc2); *p++ = '\t';
+    p = put_u(p, m_len1); *p++ = '\t';
+    p = put_u(p, m_len2); *p++ = '\t';
+    *p++ = m_type1; *p++ = '\t';
+    *p++ = m_type2; *p++ = '\n';
+    return (size_t)(p - buf);
+}
+
+std::string Overlap::get_overlap_line() const {
+    char buf[192];
+    return std::string(buf, write_line(buf));
+}
+
+// ------------------------------------------------------------------ OverlapGraph
+void OverlapGraph::addEdge(const Edge& edge) {  // src/OverlapGraph.cpp:94-101
+    const node_id_t v = edge.get_vertex(1), w = edge.get_vertex(2);
+    adj_out[v].push_back(edge);
+    adj_in[w].push_back(v);
+    edge_count++;
+}
+
+static inline bool same_ori_class(const Edge& e, bool opposite_orientations) {
+    return (e.get_ori(1) == e.get_ori(2)) == opposite_orientations;
+}
+
+Edge OverlapGraph::removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) {  // :150-194
+    auto& L = adj_out.at(v);
+    Edge removed;
+    bool found = false;
+    for (auto it = L.begin(); it != L.end(); ++it) {
+        if (it->get_vertex(2) == w && same_ori_class(*it, opposite_orientations)) {
+            removed = *it;
+            L.erase(it);
+            edge_count--;
+            found = true;
+            break;
+        }
+    }
+    if (!found) throw FatalError{HC_ERR_STATE, "Edge to be removed not found..."};
+    auto& I = adj_in.at(w);
+    for (auto it = I.begin(); it != I.end(); ++it) {
+        if (*it == v) {
+            I.erase(it);
+            break;
+        }
+    }
+    return removed;
+}
+
+double OverlapGraph::checkEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) const {  // :198-229
+    for (const Edge& e : adj_out.at(v))
+        if (e.get_vertex(2) == w && same_ori_class(e, opposite_orientations)) return e.get_score();
+    for (const Edge& e : adj_out.at(w))
+        if (e.get_vertex(2) == v && same_ori_class(e, opposite_orientations)) return e.get_score();
+    return -1;
+}
+
+Edge* OverlapGraph::getEdgeInfoWithOri(node_id_t v, node_id_t w, bool opposite_orientations, bool reverse_allowed) {  // :285-306
+    for (Edge& e : adj_out.at(v))
+        if (e.get_vertex(2) == w && same_ori_class(e, opposite_orientations)) return &e;
+    if (reverse_allowed)
+        for (Edge& e : adj_out.at(w))
+            if (e.get_vertex(2) == v && same_ori_class(e, opposite_orientations)) return &e;
+    throw FatalError{HC_ERR_STATE, "Edge not found. Exiting."};
+}
+
+}  // namespace hc

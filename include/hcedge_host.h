@@ -1,0 +1,111 @@
+/*
+ * hcedge_host.h — C ABI of the host side of the edge-calculation stage in libhcedge.so:
+ * the mirror of the reference classes FastqStorage / OverlapGraph / EdgeCalculator
+ * (haploconduct_amd/csrc/host/, C++) driven the way src/ViralQuasispecies.cpp:233-283 drives
+ * them.  Everything here is plain C so that the Python tests, the CLI and a foreign caller
+ * bind the same entry points.  Citations: reference file:line.
+ */
+#ifndef HCEDGE_HOST_H_
+#define HCEDGE_HOST_H_
+
+#include "hcedge.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* File arguments of the stage: --singles/--paired1/--paired2/--IDs/--overlaps/--output/--max_reads
+ * (src/ViralQuasispecies.cpp:52-59).  NULL or "" = absent; "None" = absent for the FASTQ files
+ * (src/FastqStorage.h:71,75). */
+typedef struct hc_ec_paths {
+    const char* singles_file;
+    const char* paired1_file;
+    const char* paired2_file;
+    const char* id_correspondence;
+    const char* overlaps_file;
+    const char* output_dir;
+    uint64_t max_reads;
+} hc_ec_paths;
+
+/* One Edge of OverlapGraph::adj_out (src/Edge.h:21-38), flattened. read1/read2 index m_read_vec. */
+typedef struct hc_edge_rec {
+    double score, mismatch_rate;
+    int32_t pos1, pos2, pos3, pos4;
+    uint8_t ori1, ori2, ord, pad;
+    uint32_t read1, read2;
+    uint64_t v1, v2;
+    int32_t perc, len0, len1, len2;
+} hc_edge_rec; /* 80 bytes */
+
+typedef struct hc_ec_counters {
+    uint64_t self_overlap_count, inclusion_count, dup_count; /* src/EdgeCalculator.h:40-42 */
+    uint64_t edges_added, nonedges_written, prefilter_rejected, malformed_lines, lines_read, scored;
+    uint64_t ambiguous, silently_dropped;
+    double t_parse, t_score, t_insert, t_write; /* seconds, build-owned breakdown */
+} hc_ec_counters;
+
+typedef struct hc_ec hc_ec; /* FastqStorage + OverlapGraph + EdgeCalculator */
+
+/* new FastqStorage(ps); new OverlapGraph(readcount, ...); addVertex + set_vertex_id per read;
+ * EdgeCalculator(fastq, graph, ps)  — src/ViralQuasispecies.cpp:233-279.  Needs a HIP device. */
+int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* paths);
+/* EdgeCalculator::construct_edges() — src/EdgeCalculator.cpp:561-666 */
+int hc_ec_construct_edges(hc_ec* ec);
+int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* out);
+uint64_t hc_ec_read_count(hc_ec* ec);
+uint64_t hc_ec_edge_count(hc_ec* ec); /* OverlapGraph::getEdgeCount */
+/* adj_out flattened in vertex order, each list in list order; *n_out = number of edges (may exceed cap). */
+int hc_ec_get_edges(hc_ec* ec, hc_edge_rec* out, uint64_t cap, uint64_t* n_out);
+int hc_ec_get_inclusions(hc_ec* ec, uint8_t* out, uint64_t cap); /* OverlapGraph::inclusions */
+/* EdgeCalculator::overlap_score on caller strings (src/EdgeCalculator.cpp:67-139), scored on the device. */
+int hc_ec_overlap_score(hc_ec* ec, const char* seq1, const char* seq2, const char* phred1, const char* phred2,
+                        uint32_t pos, double* score, double* mismatch_rate);
+int hc_ec_close(hc_ec* ec);
+
+/* ---- host-only pieces (no device needed): exercised by the CPU test-suite ---- */
+
+/* The tokenizer of construct_edges (src/EdgeCalculator.cpp:584-597). Returns the token count;
+ * off/len describe the first min(count, max_fields) tokens relative to `line`. */
+int hc_host_split_line(const char* line, uint64_t n, int allow_spaces, uint32_t* off, uint32_t* len, int max_fields);
+
+/* Overlap(std::vector<std::string>) + get_perc + get_overlap_line (src/Overlap.h:39-237) on one text
+ * line.  Returns HC_OK, HC_ERR_ARG when the line does not have 13 fields, or HC_ERR_FORMAT where the
+ * reference exits/asserts.  `text` (>= 192 bytes) receives the re-serialised line. */
+typedef struct hc_overlap_fields {
+    uint64_t id1, id2;
+    uint32_t pos1, pos2, perc1, perc2, len1, len2, perc;
+    char ord, ori1, ori2, type1, type2, pad[3];
+} hc_overlap_fields;
+int hc_host_parse_overlap(const char* line, uint64_t n, int allow_spaces, hc_overlap_fields* out, char* text);
+
+/* FastqStorage alone (src/FastqStorage.cpp:92-235): loads the files and exposes the flat layout
+ * hc_set_reads takes.  Pointers stay valid until hc_host_fastq_free. */
+typedef struct hc_fastq hc_fastq;
+typedef struct hc_fastq_view {
+    const uint8_t* bases;
+    const uint8_t* quals;
+    const uint64_t* seq_off;
+    const uint32_t* read_first_seq;
+    const uint64_t* read_ids; /* read id of m_read_vec[i] */
+    uint32_t n_reads, n_seq, n_single, n_paired;
+} hc_fastq_view;
+int hc_host_fastq_load(hc_fastq** out, const hc_ec_paths* paths, hc_fastq_view* view);
+int hc_host_fastq_free(hc_fastq* f);
+
+/* Parser + prefilter of construct_edges (src/EdgeCalculator.cpp:581-635) over a whole file: the
+ * candidates that would enter process_overlaps, in order.  *n_out may exceed cap. */
+int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* overlaps_path, hc_overlap_rec* out,
+                       uint64_t cap, uint64_t* n_out, hc_ec_counters* counters);
+
+/* The serial insert of process_overlaps (src/EdgeCalculator.cpp:441-538) on a bare graph. */
+typedef struct hc_host_graph hc_host_graph;
+int hc_host_graph_new(hc_host_graph** out, uint64_t n_vertices, const hc_settings* settings);
+int hc_host_graph_insert(hc_host_graph* g, const hc_edge_rec* edge);
+int hc_host_graph_get(hc_host_graph* g, hc_edge_rec* out, uint64_t cap, uint64_t* n_out, uint8_t* inclusions,
+                      hc_ec_counters* counters);
+int hc_host_graph_free(hc_host_graph* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HCEDGE_HOST_H_ */

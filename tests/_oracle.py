@@ -142,7 +142,7 @@ class Graph:
         self.g = C.c_void_p(lib.hco_graph_new(n_vertices))
 
     def __del__(self):
-        if self.g:
+        if self.g and lib is not None:
             lib.hco_graph_free(self.g)
             self.g = None
 

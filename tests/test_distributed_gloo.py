@@ -1,0 +1,81 @@
+"""World-size-2 test of the multi-GPU path on CPU (gloo): contiguous candidate shards, one
+all-gather-v of the admitted records, same admitted set as the single-process run.  The scoring
+itself is stood in for by the oracle here (no GPU in this container); on the GPU box the same
+functions run over RCCL from bench.py --gpus N."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["HC_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import haploconduct_amd as hc
+from haploconduct_amd import synth, parallel
+from haploconduct_amd.records import RESULT_DTYPE
+from tests import _oracle
+
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["HC_PORT"],
+                        rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+reads, meta = synth.make_paired_dataset(500, 1500, flip_frac=0.2, seed=5)
+reads.quals[:] = ord("I")
+cand = synth.paired_candidates(meta, n_candidates=5001, seed=6)
+st = hc.Settings(edge_threshold=0.97)
+lo, hi = parallel.shard_range(cand.size, rank, world)
+ref = _oracle.score_batch(reads, st, cand[lo:hi])          # stands in for hc_score_batch on this rank's GPU
+res = np.zeros(hi - lo, dtype=RESULT_DTYPE)
+res["x1"], res["x2"], res["mm"] = ref["x1"], ref["x2"], ref["mm"]
+res["n_cls"] = ref["n"] | (ref["cls"].astype(np.uint32) << 28)
+rows, counts = parallel.gather_admitted(res, lo)
+np.save(os.path.join(os.environ["HC_OUT"], f"rows{rank}.npy"), rows.numpy())
+np.save(os.path.join(os.environ["HC_OUT"], f"counts{rank}.npy"), np.array(counts))
+dist.destroy_process_group()
+'''
+
+
+def test_shard_range_partitions_exactly():
+    from haploconduct_amd.parallel import shard_range
+
+    for n in (0, 1, 7, 64, 1000003):
+        for w in (1, 2, 3, 8):
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gather_equals_single_process(oracle):
+    import haploconduct_amd as hc
+    from haploconduct_amd import synth
+
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "worker.py")
+        open(script, "w").write(WORKER)
+        port = str(29500 + os.getpid() % 2000)
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", HC_PORT=port, HC_ROOT=ROOT, HC_OUT=d,
+                       OMP_NUM_THREADS="1")
+            procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        for p in procs:
+            out, _ = p.communicate(timeout=300)
+            assert p.returncode == 0, out.decode()[-2000:]
+        rows0, rows1 = np.load(os.path.join(d, "rows0.npy")), np.load(os.path.join(d, "rows1.npy"))
+        counts = np.load(os.path.join(d, "counts0.npy"))
+    assert np.array_equal(rows0, rows1), "every rank must hold the same gathered set"
+    reads, meta = synth.make_paired_dataset(500, 1500, flip_frac=0.2, seed=5)
+    reads.quals[:] = ord("I")
+    cand = synth.paired_candidates(meta, n_candidates=5001, seed=6)
+    ref = oracle.score_batch(reads, hc.Settings(edge_threshold=0.97), cand)
+    want = np.nonzero((ref["cls"] == 2) | (ref["cls"] == 3))[0]
+    assert want.size > 50
+    assert np.array_equal(rows0[:, 0], want), "admitted set / order differs from the single-process run"
+    assert np.array_equal(rows0[:, 1].view(np.float64).view(np.uint64), ref["x1"][want].view(np.uint64))
+    assert counts.sum() == want.size and len(counts) == 2

@@ -1,0 +1,195 @@
+"""The whole edge-calculation stage on the GPU box: EdgeCalculator::construct_edges of the host
+mirror (FASTQ + overlaps text file in; populated OverlapGraph, nonedge_overlaps.txt and counters
+out) against the oracle's hco_construct_edges on the same files.  Edge set compared as the
+flattened adjacency lists in list order (stronger than a set compare); doubles as bit patterns."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import haploconduct_amd as hc
+from haploconduct_amd import host, synth
+from haploconduct_amd.records import FLAG_IGNORE_INCLUSIONS, FLAG_RELAX_PE_EDGES, FLAG_RESOLVE_ORIENTATIONS
+
+pytestmark = pytest.mark.gpu
+
+HQ = np.array([20, 30, 37, 37, 37, 40, 40, 40, 40], dtype=np.uint8) + 33
+FIELDS = ("score", "mismatch_rate", "pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "read1", "read2", "v1", "v2",
+          "perc", "len0", "len1", "len2")
+
+
+def run_both(oracle, tmp_path, reads, lines, st, tag):
+    d = tmp_path / tag
+    d.mkdir()
+    ov = str(d / "overlaps.txt")
+    with open(ov, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    s = str(d / "singles.fastq") if any(not reads.is_paired(r) for r in range(reads.n_reads)) else None
+    p1 = str(d / "paired1.fastq") if any(reads.is_paired(r) for r in range(reads.n_reads)) else None
+    p2 = str(d / "paired2.fastq") if p1 else None
+    reads.write_fastq(s, p1, p2)
+    ref_nonedge = str(d / "ref_nonedge.txt")
+    rc, g, oc = oracle.construct_edges(reads, st, ov, ref_nonedge)
+    assert rc == 0
+    out_dir = str(d / "out") + "/"
+    os.mkdir(out_dir)
+    with host.EdgeCalculatorStage(st, singles=s, paired1=p1, paired2=p2, overlaps=ov, output_dir=out_dir) as ec:
+        ec.construct_edges()
+        edges, inc, c = ec.edges(), ec.inclusions(), ec.counters()
+        assert ec.edge_count() == edges.size
+    want = g.all_edges()
+    assert edges.size == want.size, (edges.size, want.size)
+    for k in FIELDS:
+        a, b = edges[k], want[k]
+        if a.dtype.kind == "f":
+            a, b = a.view(np.uint64), b.view(np.uint64)
+        assert np.array_equal(a, b), f"edge field {k} differs"
+    assert np.array_equal(inc, g.inclusions())
+    assert open(out_dir + "nonedge_overlaps.txt", "rb").read() == open(ref_nonedge, "rb").read()
+    for k in ("inclusion_count", "dup_count", "edges_added", "nonedges_written", "prefilter_rejected", "malformed_lines",
+              "lines_read", "scored"):
+        assert c[k] == getattr(oc, k), k
+    assert c["self_overlap_count"] == 0
+    return edges, c
+
+
+def test_stage_paired_with_duplicates_and_junk_lines(oracle, tmp_path):
+    reads, meta = synth.make_paired_dataset(1500, 3000, flip_frac=0.3, seed=3)
+    reads.quals[:] = HQ[np.random.default_rng(1).integers(0, HQ.size, reads.quals.size)]
+    cand = synth.paired_candidates(meta, n_candidates=20000, seed=4)
+    lines = synth.records_to_lines(cand, reads)
+    rng = random.Random(2)
+    # a third of the candidates once more, shuffled in: exercises the replace / keep / tie-break chain
+    for ln in rng.sample(lines, len(lines) // 3):
+        lines.insert(rng.randrange(len(lines)), ln)
+    for junk in ("", "only\tthree\tfields", "9\t9\t0\t0\t1\t+\t+\t100\t100\t150\t150\tp\tp", "   "):
+        lines.insert(rng.randrange(len(lines)), junk)
+    for st in (hc.Settings(edge_threshold=0.97, min_overlap_len=150),
+               hc.Settings(edge_threshold=0.97, min_overlap_len=220, min_overlap_perc=60,
+                           flags=FLAG_RESOLVE_ORIENTATIONS | FLAG_RELAX_PE_EDGES),
+               hc.Settings(edge_threshold=0.995, merge_contigs=0.01, min_overlap_len=150,
+                           flags=FLAG_RESOLVE_ORIENTATIONS | FLAG_IGNORE_INCLUSIONS)):
+        edges, c = run_both(oracle, tmp_path, reads, lines, st, f"pp{st.edge_threshold}{st.min_overlap_len}")
+        assert edges.size > 100 and c["dup_count"] > 50 and c["nonedges_written"] > 0
+
+
+def test_stage_singles_contigs_inclusions(oracle, tmp_path):
+    reads, meta = synth.make_single_dataset(1200, 5000, len_lo=150, len_hi=900, flip_frac=0.4, seed=5, quals=HQ,
+                                            log_uniform=True)
+    cand = synth.single_candidates(meta, min_overlap=80, n_candidates=20000)
+    lines = synth.records_to_lines(cand, reads)
+    # the same overlaps reported from the other read's point of view on the opposite strand:
+    # (A, B, pos, oa, ob) ~ (B, A, lenB - L, !ob, !oa) when A's suffix lies inside B.  The two sum the same
+    # terms in opposite order, so their scores differ in the last bits: the tie-break chain must agree.
+    lens = meta["lens"]
+    ids = reads.read_ids
+    twin = []
+    for r in cand[::3]:
+        la, lb = int(lens[r["read1"]]), int(lens[r["read2"]])
+        L = la - int(r["pos1"])
+        if 0 < L <= lb:
+            twin.append("\t".join([str(int(ids[r["read2"]])), str(int(ids[r["read1"]])), str(lb - L), "-", "-",
+                                   "-" if r["ori2"] else "+", "-" if r["ori1"] else "+", str(int(r["perc"])), "-",
+                                   str(int(r["len1"])), "-", "s", "s"]))
+    assert len(twin) > 1000
+    rng = random.Random(8)
+    for t in twin:
+        lines.insert(rng.randrange(len(lines)), t)
+    st = hc.Settings(edge_threshold=0.995, ov_threshold=0.9, min_overlap_len=100,
+                     flags=FLAG_RESOLVE_ORIENTATIONS | FLAG_IGNORE_INCLUSIONS)
+    edges, c = run_both(oracle, tmp_path, reads, lines, st, "ss")
+    assert edges.size > 100 and c["inclusion_count"] > 0 and c["dup_count"] > 200
+    st = hc.Settings(edge_threshold=1.0, merge_contigs=0.0, min_overlap_len=100)
+    run_both(oracle, tmp_path, reads, lines, st, "ss_polyte")
+
+
+def test_stage_mixed_single_and_paired_reads(oracle, tmp_path):
+    from tests.test_gpu_parity import _mixed_reads
+
+    reads, spos, ppos = _mixed_reads(13, n_single=200, n_pair=200, glen=2000)
+    ns = len(spos)
+    ids = reads.read_ids
+    lines = []
+    for i, (s, L) in enumerate(spos):
+        for j, (ps, ins) in enumerate(ppos):
+            p1, p2 = ps - s, ps + ins - 150 - s
+            if 0 <= p1 < L - 40 and 0 <= p2 < L - 40:
+                l1, l2 = min(L - p1, 150), min(L - p2, 150)
+                lines.append(f"{ids[i]}\t{ids[ns + j]}\t{p1}\t{p2}\t-\t+\t+\t{100 * l1 // 150}\t{100 * l2 // 150}\t{l1}\t{l2}\ts\tp")
+            q1, q2 = s - ps, ps + ins - 150 - s
+            if 0 <= q1 < 110 and 0 <= q2 < L - 40:
+                l1, l2 = min(150 - q1, L), min(L - q2, 150)
+                lines.append(f"{ids[ns + j]}\t{ids[i]}\t{q1}\t{q2}\t-\t+\t+\t{100 * l1 // 150}\t{100 * l2 // 150}\t{l1}\t{l2}\tp\ts")
+    assert len(lines) > 300
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.5, min_overlap_len=100)
+    edges, _ = run_both(oracle, tmp_path, reads, lines, st, "mixed")
+    assert edges.size > 20
+
+
+def test_stage_overlap_score_entry_point(oracle, tmp_path):
+    reads = hc.ReadSet.from_lists([("ACGTACGTAC", "IIIIIIIIII"), ("ACGTACGTAC", "IIIIIIIIII")])
+    reads.write_fastq(str(tmp_path / "s.fastq"))
+    ov = str(tmp_path / "ov.txt")
+    open(ov, "w").write("")
+    with host.EdgeCalculatorStage(hc.Settings(), singles=str(tmp_path / "s.fastq"), overlaps=ov,
+                                  output_dir=str(tmp_path) + "/") as ec:
+        for a, b, qa, qb, pos in ((b"ACGTTGCAAGGCTA", b"TGCAAGGCTAAC", b"IIIII55555IIII", b"II5555IIII!I", 4),
+                                  (b"ACGTNNNN", b"ACGAACGT", b"IIIIIIII", b"55555555", 0), (b"ACGT", b"ACGT", b"IIII", b"IIII", 9)):
+            sc, mr = ec.overlap_score(a, b, qa, qb, pos)
+            want = oracle.overlap_score(a, b, qa, qb, pos)
+            assert sc.hex() == want["score"].hex() and mr.hex() == want["mismatch_rate"].hex()
+
+
+def test_stage_errors(tmp_path):
+    reads = hc.ReadSet.from_lists([("ACGTACGTAC", "IIIIIIIIII"), ("ACGTACGTAC", "IIIIIIIIII")])
+    reads.write_fastq(str(tmp_path / "s.fastq"))
+    bad = str(tmp_path / "bad.txt")
+    open(bad, "w").write("0\t1\t0\t-\t-\t*\t+\t100\t-\t10\t-\ts\ts\n")  # ori '*': the reference exits
+    with host.EdgeCalculatorStage(hc.Settings(min_overlap_len=5), singles=str(tmp_path / "s.fastq"), overlaps=bad,
+                                  output_dir=str(tmp_path) + "/") as ec:
+        with pytest.raises(hc.HcError):
+            ec.construct_edges()
+    unknown = str(tmp_path / "unknown.txt")
+    open(unknown, "w").write("0\t7\t0\t-\t-\t+\t+\t100\t-\t10\t-\ts\ts\n")  # read 7 does not exist: map::at throws
+    with host.EdgeCalculatorStage(hc.Settings(min_overlap_len=5), singles=str(tmp_path / "s.fastq"), overlaps=unknown,
+                                  output_dir=str(tmp_path) + "/") as ec:
+        with pytest.raises(hc.HcError):
+            ec.construct_edges()
+    with host.EdgeCalculatorStage(hc.Settings(), singles=str(tmp_path / "s.fastq"), overlaps=str(tmp_path / "nope.txt"),
+                                  output_dir=str(tmp_path) + "/") as ec:
+        with pytest.raises(hc.HcError):
+            ec.construct_edges()  # "Unable to open overlaps file"
+
+
+def test_cli_accepts_reference_argv_and_matches_oracle(oracle, tmp_path):
+    """hc-edgecalc driven with the argv scripts/pipeline_per_stage.py:381-407 builds for ViralQuasispecies."""
+    import subprocess
+
+    reads, meta = synth.make_paired_dataset(800, 2000, flip_frac=0.2, seed=21)
+    reads.quals[:] = HQ[np.random.default_rng(3).integers(0, HQ.size, reads.quals.size)]
+    cand = synth.paired_candidates(meta, n_candidates=8000, seed=22)
+    d = str(tmp_path) + "/"
+    open(d + "overlaps.txt", "w").write("\n".join(synth.records_to_lines(cand, reads)) + "\n")
+    reads.write_fastq(None, d + "paired1.fastq", d + "paired2.fastq")
+    exe = os.path.join(os.path.dirname(hc.lib_path), "hc-edgecalc")
+    argv = [exe, "--singles=None", "--paired1=" + d + "paired1.fastq", "--paired2=" + d + "paired2.fastq",
+            "--overlaps=" + d + "overlaps.txt", "--threads=4", "--edge_threshold=0.970000", "--first_it=true",
+            "--cliques=true", "--error_correction=true", "--keep_singletons=0", "--min_clique_size=4", "--min_overlap_perc=0",
+            "--min_overlap_len=150", "--merge_contigs=0.000000", "--FNO=3", "--original_readcount=800", "--remove_trans=2",
+            "--optimize=false", "--base_path=/nowhere", "--min_qual=0.9", "--verbose=true", "--output=" + d]
+    r = subprocess.run(argv, cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "edges have been constructed in" in r.stdout and "Number of inclusion edges:" in r.stdout
+    st = hc.Settings(edge_threshold=0.97, min_overlap_len=150)
+    rc, g, oc = oracle.construct_edges(reads, st, d + "overlaps.txt", d + "ref_nonedge.txt")
+    want = g.all_edges()
+    rows = [ln.split("\t") for ln in open(d + "edges.tsv").read().splitlines()]
+    assert len(rows) == want.size
+    for row, e in zip(rows, want):
+        assert (int(row[0]), int(row[1]), int(row[4]), int(row[5]), int(row[6]), int(row[7])) == \
+               (e["v1"], e["v2"], e["pos1"], e["pos2"], e["pos3"], e["pos4"])
+        assert float(row[15]) == e["score"] and float(row[16]) == e["mismatch_rate"]
+    assert open(d + "nonedge_overlaps.txt", "rb").read() == open(d + "ref_nonedge.txt", "rb").read()
+    stats = dict(ln.split("\t") for ln in open(d + "edgecalc_stats.txt").read().splitlines())
+    assert int(stats["dup_count"]) == oc.dup_count and int(stats["inclusion_count"]) == oc.inclusion_count

@@ -1,0 +1,186 @@
+"""Host logic of the stage (csrc/host/, through include/hcedge_host.h) against the oracle and the
+golden vectors — no GPU needed: tokenizer, Overlap record parsing, FastqStorage, the parser +
+prefilter of construct_edges, and the serial insert / duplicate resolution of process_overlaps."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import haploconduct_amd as hc
+from haploconduct_amd import host, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_tokenizer_matches_oracle(oracle):
+    rng = random.Random(3)
+    alphabet = ["\t", "\t", " ", "a", "12", "-", "+", "s", "p", ""]
+    lines = ["", " ", "\t", "a", "a\tb", "a\t\tb", " a \t b ", "\ta\tb\t", "a b\tc", "1\t2\t3\t-\t-\t+\t+\t9\t-\t8\t-\ts\ts"]
+    for _ in range(500):
+        lines.append("".join(rng.choice(alphabet) for _ in range(rng.randrange(0, 30))))
+    for ln in lines:
+        for sp in (False, True):
+            assert host.split_line(ln, sp) == oracle.split_line(ln, sp), repr(ln)
+
+
+def test_overlap_parsing_matches_reference_golden_and_oracle(oracle):
+    gold = json.load(open(os.path.join(HERE, "golden", "ref_headers.json")))
+    for v in gold["overlap_parse"]:
+        rc, o = host.parse_overlap("\t".join(v["fields"]))
+        if any(f != f.strip(" ") or f == "" for f in v["fields"]):
+            continue  # outer spaces are trimmed at line level before the split; covered by the fuzz below
+        assert rc == 0
+        for k in ("id1", "id2", "pos1", "pos2", "ord", "ori1", "ori2", "type1", "type2", "perc", "len1", "len2", "line"):
+            assert o[k] == v[k], (k, v["fields"])
+    rng = random.Random(5)
+    pool = ["0", "7", "150", "-", "+", "1", "2", "s", "p", "-3", "101", "x", " 1", "0x1f", "", "s ", "12 ", "99999999999"]
+    n_ok = n_bad = 0
+    for _ in range(3000):
+        f = [rng.choice(pool) for _ in range(13)]
+        if rng.random() < 0.6:  # mostly well-formed
+            t1, t2 = rng.choice("sp"), rng.choice("sp")
+            f = [str(rng.randrange(1000)), str(rng.randrange(1000)), str(rng.randrange(300)), rng.choice(["-", "5", "0"]),
+                 rng.choice("12") if t1 == t2 == "p" else "-", rng.choice("+-"), rng.choice("+-"), str(rng.randrange(101)),
+                 rng.choice(["-", "0", "50"]), str(rng.randrange(500)), rng.choice(["-", "0", "80"]), t1, t2]
+            if rng.random() < 0.2:
+                f[rng.randrange(13)] = rng.choice(pool)
+        line = "\t".join(f)
+        n, toks = oracle.split_line(line, False)
+        rc, o = host.parse_overlap(line)
+        if n != 13:
+            assert rc == -1
+            continue
+        orc, oo = oracle.parse_fields(toks)
+        assert (rc == 0) == (orc == 0), (f, rc, orc)
+        if rc == 0:
+            n_ok += 1
+            assert o == oo, f
+        else:
+            n_bad += 1
+    assert n_ok > 1000 and n_bad > 100
+
+
+def _write(path, text):
+    with open(path, "w") as f:
+        f.write(text)
+    return path
+
+
+def test_fastq_storage_semantics(tmp_path):
+    s = _write(tmp_path / "s.fastq", "@10 extra words\nacgtNNac\n+\nIIIIIIII\n@0x11\nGGGG\n+anything\n!!!!\n@trailing\nAC\n")
+    p1 = _write(tmp_path / "p1.fastq", "@20/1\nacgt\n+\nIIII\n@21\nTTTTT\n+\n55555\n")
+    p2 = _write(tmp_path / "p2.fastq", "@20/1\nCCcc\n+\n####\n@21\nGG\n+\nII\n")
+    f = host.Fastq(singles=s, paired1=p1, paired2=p2)
+    assert (f.n_reads, f.n_single, f.n_paired, f.n_seq) == (4, 2, 2, 6)
+    assert f.read_ids.tolist() == [10, 17, 20, 21]         # strtoul(base 0): "0x11" = 17, "20/1" stops at the slash
+    rs = f.readset()
+    assert rs.seq(0) == (b"ACGTNNAC", b"IIIIIIII")         # singles are upper-cased (FastqStorage.cpp:122)
+    assert rs.seq(2) == (b"acgt", b"IIII")                  # pairs are not (FastqStorage.cpp:197-198)
+    assert rs.seq(3) == (b"CCcc", b"####")
+    assert f.read_first_seq.tolist() == [0, 1, 2, 4, 6]
+    # "None" means absent (FastqStorage.h:71,75)
+    g = host.Fastq(singles=s, paired1="None", paired2="None")
+    assert (g.n_single, g.n_paired) == (2, 0)
+    h = host.Fastq(singles=s, max_reads=1)
+    assert h.n_single == 1
+
+
+def test_fastq_ids_file_and_errors(tmp_path):
+    s = _write(tmp_path / "s.fastq", "@readA\nACGT\n+\nIIII\n@readB\nAC\n+\nII\n")
+    ids = _write(tmp_path / "ids.txt", "5\t>readA\n9\treadB\n")
+    f = host.Fastq(singles=s, ids=ids)
+    assert f.read_ids.tolist() == [5, 9]
+    with pytest.raises(hc.HcError):
+        host.Fastq(singles=s, ids=_write(tmp_path / "ids2.txt", "5\t>readA\n"))        # missing id: map::at throws
+    with pytest.raises(hc.HcError):
+        host.Fastq(singles=_write(tmp_path / "bad1.fastq", "readA\nACGT\n+\nIIII\n"))  # no '@': exit(1)
+    with pytest.raises(hc.HcError):
+        host.Fastq(singles=_write(tmp_path / "bad2.fastq", "@r\n\n+\n\n"))             # empty sequence: exit(1)
+    with pytest.raises(hc.HcError):
+        host.Fastq(singles=str(tmp_path / "missing.fastq"))                              # cannot open: exit(1)
+    with pytest.raises(hc.HcError):
+        host.Fastq(paired1=_write(tmp_path / "q1.fastq", "@a\nAC\n+\nII\n"),
+                   paired2=_write(tmp_path / "q2.fastq", "@b\nAC\n+\nII\n"))            # /1 /2 ids differ: exit(1)
+
+
+def _dataset(tmp_path, seed=7):
+    reads, meta = synth.make_paired_dataset(300, 1200, flip_frac=0.2, seed=seed)
+    reads.quals[:] = ord("I")
+    sreads, smeta = synth.make_single_dataset(200, 1500, len_lo=150, len_hi=400, seed=seed + 1, quals=[ord("I"), ord("5")])
+    return reads, meta, sreads, smeta
+
+
+def test_parser_and_prefilter_match_oracle(oracle, tmp_path):
+    reads, meta, _, _ = _dataset(tmp_path)
+    cand = synth.paired_candidates(meta, n_candidates=4000, seed=3)
+    lines = synth.records_to_lines(cand, reads)
+    rng = random.Random(9)
+    extra = ["", "garbage", "1\t2\t3", lines[0] + "\textra", "5\t5\t0\t0\t1\t+\t+\t90\t90\t100\t100\tp\tp",  # self overlap
+             "1\t2\t0\t0\t1\t+\t+\t90\t90\t10\t10\tp\tp", "  " + lines[1] + "\t "]
+    for e in extra:
+        lines.insert(rng.randrange(len(lines)), e)
+    path = str(tmp_path / "overlaps.txt")
+    _write(path, "\n".join(lines) + "\n")
+    reads.write_fastq(paired1_path=str(tmp_path / "p1.fastq"), paired2_path=str(tmp_path / "p2.fastq"))
+    f = host.Fastq(paired1=str(tmp_path / "p1.fastq"), paired2=str(tmp_path / "p2.fastq"))
+    for st in (hc.Settings(min_overlap_len=150), hc.Settings(min_overlap_len=200, min_overlap_perc=70),
+               hc.Settings(min_overlap_len=260, flags=hc.records.FLAG_RELAX_PE_EDGES | hc.records.FLAG_RESOLVE_ORIENTATIONS),
+               hc.Settings(min_overlap_len=150, max_overlaps=1000)):
+        recs, c = f.parse_file(st, path)
+        rc, g, oc = oracle.construct_edges(reads, st, path, None)
+        assert rc == 0
+        assert c["lines_read"] == oc.lines_read and c["malformed_lines"] == oc.malformed_lines
+        assert c["prefilter_rejected"] == oc.prefilter_rejected and recs.size == oc.scored
+    # the records themselves: what the parser hands to the device == what the generator meant
+    recs, _ = f.parse_file(hc.Settings(min_overlap_len=150), path)
+    key = lambda a: np.stack([a[k].astype(np.int64) for k in ("read1", "read2", "pos1", "pos2", "ori1", "ori2", "ord", "len1", "len2", "perc")], 1)
+    want = cand[(cand["len1"] >= 75) & (cand["len2"] >= 75)]
+    got = recs[: recs.size]
+    assert got.size == want.size + 1  # + the trimmed duplicate of lines[1]
+    assert set(map(tuple, key(want).tolist())) == set(map(tuple, key(got).tolist()))
+
+
+def _random_edge_stream(rng, V, n):
+    """Edges with many duplicates of the same unordered pair / orientation class and engineered ties."""
+    out = np.zeros(n, dtype=host.EDGE_DTYPE)
+    scores = [0.97, 0.98, 0.98, 0.99, 0.5, 1.0]
+    for i in range(n):
+        a, b = rng.sample(range(V), 2)
+        e = out[i]
+        e["v1"], e["v2"], e["read1"], e["read2"] = a, b, a, b
+        e["score"] = rng.choice(scores)
+        e["mismatch_rate"] = rng.choice([0.0, 0.0, 0.01, 0.5])
+        e["pos1"] = rng.choice([0, 0, 3, 7])
+        e["pos2"] = rng.choice([0, 2, 5])
+        e["pos3"] = rng.choice([-5, 0, 5])
+        e["pos4"] = rng.choice([-2, 0, 2])
+        e["ori1"], e["ori2"] = rng.randrange(2), rng.randrange(2)
+        e["ord"] = ord(rng.choice("-12"))
+        e["perc"] = rng.choice([100, 100, 80])
+        e["len1"] = rng.choice([100, 120]); e["len2"] = rng.choice([0, 50]); e["len0"] = e["len1"] + e["len2"]
+    return out
+
+
+def test_serial_insert_and_tie_break_chain_match_oracle(oracle):
+    rng = random.Random(11)
+    for flags in (hc.records.FLAG_RESOLVE_ORIENTATIONS, hc.records.FLAG_RESOLVE_ORIENTATIONS | hc.records.FLAG_IGNORE_INCLUSIONS):
+        st = hc.Settings(flags=flags)
+        V = 12  # few vertices => most inserts hit an existing pair
+        stream = _random_edge_stream(rng, V, 4000)
+        g = host.HostGraph(V, st)
+        og = oracle.Graph(V)
+        oc = oracle.hco_counters()
+        for e in stream:
+            assert g.insert(e.copy()) == 0
+            assert og.insert(st, np.array([e], dtype=oracle.GEDGE_DTYPE), oc) == 0
+        edges, inc, c = g.get()
+        want = og.all_edges()
+        assert edges.size == want.size == og.edge_count()
+        for k in ("score", "mismatch_rate", "pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "read1", "read2", "v1",
+                  "v2", "perc", "len0", "len1", "len2"):
+            assert np.array_equal(edges[k], want[k]), k
+        assert np.array_equal(inc, og.inclusions())
+        assert c["dup_count"] == oc.dup_count > 1000 and c["inclusion_count"] == oc.inclusion_count
+        assert c["edges_added"] == oc.edges_added
