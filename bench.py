@@ -31,6 +31,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def pmc_traffic(workload, order):
+    """HBM bytes per launch of the scoring kernel from committed rocprofv3 PMC passes
+    (profiles/traffic_<workload>.json, produced by tools/collect_traffic.sh: FETCH_SIZE and WRITE_SIZE
+    in separate --pmc passes; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950)."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("order") == order:
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def build_workload(workload, rank):
     from haploconduct_amd import synth
 
@@ -112,21 +127,11 @@ def main():
     alg_bytes = 48 * n + 4 * positions  # 32 B record + 16 B result + 4 B per overlapped position
 
     def gather_edges():
-        # admitted-edge records to every rank: counts, then padded payload
-        res = d_out.view(torch.int64).view(-1, 3)
-        cls = (res[:, 2] >> 60) & 0xF
-        keep = (cls >= 2) & (cls <= 4)
-        idx = torch.nonzero(keep).squeeze(1)
-        mine = torch.cat([idx.unsqueeze(1), res[idx]], dim=1).contiguous()  # [k, 4] int64
-        cnt = torch.tensor([mine.shape[0]], device="cuda", dtype=torch.int64)
-        cnts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(cnts, cnt)
-        kmax = int(max(int(c.item()) for c in cnts))
-        pad = torch.zeros((kmax, 4), device="cuda", dtype=torch.int64)
-        pad[: mine.shape[0]] = mine
-        allr = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(allr, pad)
-        return allr, cnts
+        # admitted-edge records to every rank — counts, then padded payload (one all-gather-v)
+        from haploconduct_amd import parallel
+
+        lo = rank * n  # weak scaling: rank r owns global candidates [r*n, (r+1)*n)
+        return parallel.gather_admitted(d_out, lo)
 
     def step():
         sc.score_batch_device(d_in.data_ptr(), n, d_out.data_ptr())
@@ -174,7 +179,7 @@ def main():
             "config": dict(cfg, parallelism=f"candidate shards x{world}, replicated read store",
                            edge_threshold=settings.edge_threshold, mean_positions_per_candidate=positions / n),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, args.order),
                          "kernel": "hc::score_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_candidates_per_s": n / (kern_ms * 1e-3)},
