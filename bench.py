@@ -47,20 +47,43 @@ def pmc_traffic(workload, order):
 
 
 def build_workload(workload, rank):
+    """BASELINE.json configs; candidates in sfo2overlaps order."""
     from haploconduct_amd import synth
+    import haploconduct_amd as hc
 
-    if workload == "c2":
-        n_pairs, glen, n_cand = 50000, 45000, 2000000
-    elif workload == "c2-small":
-        n_pairs, glen, n_cand = 5000, 1800, 200000
-    elif workload == "c3":
-        n_pairs, glen, n_cand = 500000, 34000, 100000000
+    st = dict(edge_threshold=0.97, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=150)
+    if workload in ("c2", "c2-small", "c3", "c3-lite"):
+        n_pairs, glen, n_cand = {"c2": (50000, 45000, 2000000), "c2-small": (5000, 1800, 200000),
+                                 "c3": (500000, 90000, 100000000), "c3-lite": (500000, 90000, 20000000)}[workload]
+        reads, meta = synth.make_paired_dataset(n_pairs, glen, seed=1)
+        cand = synth.paired_candidates(meta, n_candidates=n_cand, seed=2 + rank)
+        desc = f"{workload}: {n_pairs} synthetic 2x150 bp read pairs, {n_cand} p-p candidates per GPU"
+        cfg = {"read_pairs": n_pairs, "genome_len": glen}
+    elif workload == "c4":
+        # POLYTE diploid 20x per haplotype, 2x250 bp, every read a single (polyte.py:283-288), both orientations,
+        # edge_threshold 1 / merge_contigs 0 (polyte.py:617-626), 35 distinct quality values as in polyte/example
+        glen, cov = 400000, 40
+        n_reads = glen * cov // 250
+        quals = (np.arange(1, 36) + 33).astype(np.uint8)
+        reads, meta = synth.make_single_dataset(n_reads, glen, len_lo=250, len_hi=250, n_strains=2, divergence=0.001,
+                                                flip_frac=0.5, seed=4, quals=quals)
+        cand = synth.single_candidates(meta, min_overlap=127)
+        st = dict(edge_threshold=1.0, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=127)
+        desc = f"c4: {n_reads} synthetic 250 bp reads as singles (diploid, 20x per haplotype), {cand.size} s-s candidates"
+        cfg = {"reads": n_reads, "genome_len": glen, "quality_alphabet": 35}
+    elif workload == "c5":
+        # mixed-length contig + read re-overlap (SAVAGE stage b/c): log-uniform 150..6000 bp singles
+        n_reads, glen = 60000, 300000
+        reads, meta = synth.make_single_dataset(n_reads, glen, len_lo=150, len_hi=6000, n_strains=3, divergence=0.01,
+                                                flip_frac=0.5, seed=5, log_uniform=True)
+        cand = synth.single_candidates(meta, min_overlap=100, n_candidates=2000000)
+        st = dict(edge_threshold=0.995, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=100)
+        desc = f"c5: {n_reads} synthetic singles of log-uniform length 150..6000 bp, {cand.size} s-s candidates"
+        cfg = {"reads": n_reads, "genome_len": glen}
     else:
         raise SystemExit(f"unknown workload {workload}")
-    reads, meta = synth.make_paired_dataset(n_pairs, glen, seed=1)
-    cand = synth.paired_candidates(meta, n_candidates=n_cand, seed=2 + rank)
-    return reads, cand, {"workload": f"{workload}: {n_pairs} synthetic 2x150 bp read pairs, {n_cand} p-p candidates per GPU",
-                         "read_pairs": n_pairs, "candidates_per_gpu": n_cand, "genome_len": glen}
+    cfg = dict(cfg, workload=desc, candidates_per_gpu=int(cand.size))
+    return reads, cand, cfg, hc.Settings(**st)
 
 
 def cpu_baseline(reads, settings, cand, budget_s=12.0):
@@ -112,8 +135,8 @@ def main():
 
     import haploconduct_amd as hc
 
-    settings = hc.Settings(edge_threshold=0.97, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=150, device=local_rank)
-    reads, cand, cfg = build_workload(args.workload, rank)
+    reads, cand, cfg, settings = build_workload(args.workload, rank)
+    settings.device = local_rank
     if args.order == "grouped":
         cand = cand[np.argsort(cand["read1"], kind="stable")]
     elif args.order == "shuffled":

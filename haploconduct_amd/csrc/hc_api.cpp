@@ -359,6 +359,20 @@ int hc_score_batch(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, hc_result_re
     return HC_OK;
 }
 
+int hc_host_alloc(hc_ctx* c, void** ptr, uint64_t bytes) {
+    if (!c || !ptr) return fail(HC_ERR_ARG, "hc_host_alloc: null argument");
+    *ptr = nullptr;
+    HC_HIP(hipSetDevice(c->device));
+    HC_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return HC_OK;
+}
+
+int hc_host_free(hc_ctx* c, void* ptr) {
+    if (!c) return fail(HC_ERR_ARG, "hc_host_free: null context");
+    if (ptr) HC_HIP(hipHostFree(ptr));
+    return HC_OK;
+}
+
 int hc_time_score_kernel(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, int iters, float* ms_per_launch) {
     if (!c || !ms_per_launch || iters <= 0) return fail(HC_ERR_ARG, "hc_time_score_kernel: bad argument");
     if (!c->have_reads) return fail(HC_ERR_STATE, "hc_time_score_kernel: hc_set_reads has not been called");

@@ -51,7 +51,11 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
 }
 
 EdgeCalculator::~EdgeCalculator() {
-    if (m_ctx) hc_destroy(m_ctx);
+    if (m_ctx) {
+        hc_host_free(m_ctx, m_rec);
+        hc_host_free(m_ctx, m_res);
+        hc_destroy(m_ctx);
+    }
 }
 
 double EdgeCalculator::phred_to_prob(int phred) const { return pow(10, -phred / 10.0); }  // :59-63
@@ -134,10 +138,19 @@ void EdgeCalculator::process_overlaps(const std::vector<ParsedOverlap>& batch) {
     const size_t n = batch.size();
     if (n == 0) return;
     double t0 = now_s();
-    m_rec.resize(n);
-    m_res.resize(n);
+    if (n > m_cap) {
+        hc_host_free(m_ctx, m_rec);
+        hc_host_free(m_ctx, m_res);
+        m_rec = nullptr;
+        m_res = nullptr;
+        m_cap = 0;
+        const size_t cap = n + n / 8;
+        check(hc_host_alloc(m_ctx, (void**)&m_rec, cap * sizeof(hc_overlap_rec)), "hc_host_alloc");
+        check(hc_host_alloc(m_ctx, (void**)&m_res, cap * sizeof(hc_result_rec)), "hc_host_alloc");
+        m_cap = cap;
+    }
     for (size_t i = 0; i < n; i++) m_rec[i] = batch[i].rec;
-    check(hc_score_batch(m_ctx, m_rec.data(), n, m_res.data()), "hc_score_batch");  // the omp-for, :395-414
+    check(hc_score_batch(m_ctx, m_rec, n, m_res), "hc_score_batch");  // the omp-for, :395-414
     stats.scored += n;
     double t1 = now_s();
     stats.t_score += t1 - t0;
@@ -232,8 +245,8 @@ void EdgeCalculator::construct_edges() {
         const double t0 = now_s();
         const bool more = parser.next_batch(batch, overlaps_per_vec, rejected, pc, /*print_malformed=*/true);
         stats.t_parse += now_s() - t0;
-        if (!batch.empty()) process_overlaps(batch);  // :636-644
         if (!more) break;
+        if (!batch.empty()) process_overlaps(batch);  // :636-644
     }
     stats.lines_read = pc.lines_read;
     stats.malformed = pc.malformed;

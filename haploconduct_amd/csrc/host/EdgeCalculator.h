@@ -58,8 +58,9 @@ private:
     std::shared_ptr<OverlapGraph> overlap_graph;
     hc_settings m_cs;
     hc_ctx* m_ctx = nullptr;
-    std::vector<hc_overlap_rec> m_rec;
-    std::vector<hc_result_rec> m_res;
+    hc_overlap_rec* m_rec = nullptr;  // page-locked staging (hc_host_alloc), grow-only
+    hc_result_rec* m_res = nullptr;
+    size_t m_cap = 0;
     std::string m_nonedge_buf;
 };
 

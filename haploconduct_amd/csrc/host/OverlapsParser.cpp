@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace hc {
 
@@ -49,8 +50,112 @@ int split_overlap_line(const char* s, size_t n, bool allow_spaces, const char* f
     return nf;
 }
 
+IdIndex::IdIndex(const FastqStorage& fastq) {
+    const auto& map = fastq.m_ID_to_index;
+    const size_t n = map.size();
+    read_id_t max_id = 0;
+    for (const auto& kv : map) max_id = kv.first > max_id ? kv.first : max_id;
+    if (n == 0 || max_id < 8 * n + 1024) {
+        m_direct = true;
+        m_table.assign(n ? (size_t)max_id + 1 : 0, kNone);
+        for (const auto& kv : map) m_table[kv.first] = kv.second;  // the map already holds the first occurrence
+    } else {
+        m_direct = false;
+        size_t cap = 16;
+        int bits = 4;
+        while (cap < 2 * n) { cap <<= 1; bits++; }
+        m_shift = 64 - bits;
+        m_table.assign(cap, kNone);
+        m_keys.assign(cap, 0);
+        for (const auto& kv : map) {
+            uint64_t h = (kv.first * 0x9E3779B97F4A7C15ull) >> m_shift;
+            while (m_table[h] != kNone) h = (h + 1) & (cap - 1);
+            m_table[h] = kv.second;
+            m_keys[h] = kv.first;
+        }
+    }
+}
+
+// One contiguous piece of the file, parsed independently by one thread.
+struct OverlapsParser::Segment {
+    size_t begin = 0, end = 0;      // byte range, begin at a line start
+    uint64_t first_line = 0;        // index of its first line in the file
+    uint64_t line_limit = 0;        // lines with index >= line_limit are not read (max_overlaps, :581)
+    std::vector<ParsedOverlap> pass;
+    std::vector<Overlap> rejected;
+    std::vector<uint32_t> reject_before;  // rejected[k] precedes pass[reject_before[k]] in file order (unused: order is kept per kind)
+    ParseCounters c;
+    uint64_t malformed_prints = 0;
+    bool failed = false;
+    FatalError error{0, ""};
+};
+
+void OverlapsParser::parse_segment(Segment& seg) const {
+    const bool allow_spaces = m_ps.allow_spaces;
+    const char* field[14];
+    size_t flen[14];
+    size_t pos = seg.begin;
+    uint64_t line_no = seg.first_line;
+    try {
+        while (pos < seg.end) {
+            const char* nl = (const char*)memchr(m_data + pos, '\n', seg.end - pos);
+            const size_t end = nl ? (size_t)(nl - m_data) : seg.end;
+            const char* line = m_data + pos;
+            const size_t n = end - pos;
+            pos = nl ? end + 1 : seg.end;
+            if (!(line_no < seg.line_limit)) break;  // `&& i < max_overlaps`, :581
+            line_no++;
+            seg.c.lines_read++;
+            const int nf = split_overlap_line(line, n, allow_spaces, field, flen, 14);
+            if (nf != 13) {  // :598-603
+                seg.c.malformed++;
+                continue;
+            }
+            ParsedOverlap po;
+            po.line = Overlap::from_fields(field, flen);
+            const Overlap& o = po.line;
+            if (o.m_id1 == o.m_id2) { seg.c.self_overlaps++; continue; }  // :605-607
+            const unsigned int perc = o.get_perc();
+            const bool ss = o.m_type1 == 's' && o.m_type2 == 's';
+            const bool anyp = o.m_type1 == 'p' || o.m_type2 == 'p';
+            bool pass = false;
+            if (o.m_len1 >= m_ps.min_overlap_len && ss) {  // :612-617
+                pass = perc >= m_ps.min_overlap_perc;
+                if (!pass) seg.c.silently_dropped++;
+            } else if (o.m_len1 >= 0.5 * m_ps.min_overlap_len && o.m_len2 >= 0.5 * m_ps.min_overlap_len && anyp) {  // :618-624
+                pass = perc >= m_ps.min_overlap_perc;
+                if (!pass) seg.c.silently_dropped++;
+            } else if (m_ps.relax_PE_edges && o.m_len1 + o.m_len2 >= m_ps.min_overlap_len && anyp) {  // :626-632
+                pass = perc >= m_ps.min_overlap_perc;
+                if (!pass) seg.c.silently_dropped++;
+            } else {  // :633-635
+                seg.rejected.push_back(o);
+                seg.c.prefilter_rejected++;
+            }
+            if (!pass) continue;
+            // id -> index: std::map::at in compute_overlap, :170-171 (throws => the reference aborts)
+            hc_overlap_rec& r = po.rec;
+            if (!m_ids.find(o.m_id1, r.read1) || !m_ids.find(o.m_id2, r.read2))
+                throw FatalError{HC_ERR_BAD_OVERLAP, "overlap refers to a read id that is not in the FASTQ input"};
+            r.pos1 = o.m_pos1;
+            r.pos2 = o.m_pos2;
+            r.ori1 = o.m_ori1 == '+';
+            r.ori2 = o.m_ori2 == '+';
+            r.ord = (uint8_t)o.m_ord;
+            r.flags = (uint8_t)((o.m_type1 == 'p') | ((o.m_type2 == 'p') << 1));
+            r.len1 = o.m_len1;
+            r.len2 = o.m_len2;
+            r.perc = perc;
+            seg.pass.push_back(po);
+        }
+    } catch (const FatalError& e) {
+        seg.failed = true;
+        seg.error = e;
+    }
+}
+
 OverlapsParser::OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq)
-    : m_ps(ps), m_fastq(fastq) {
+    : m_ps(ps), m_fastq(fastq), m_ids(fastq), m_threads(ps.n_threads ? ps.n_threads : 1) {
     m_fd = open(path.c_str(), O_RDONLY);
     if (m_fd < 0) return;
     struct stat st;
@@ -70,71 +175,89 @@ OverlapsParser::~OverlapsParser() {
     if (m_fd >= 0) close(m_fd);
 }
 
+// Parses the next block of the file with m_threads threads: the block is cut into segments at line
+// starts, the lines of each segment are numbered from a parallel newline count (so that the
+// max_overlaps line limit is honoured exactly), segments are parsed concurrently and concatenated in
+// file order.  `max_batch` bounds the block by bytes (~64 bytes of text per accepted candidate), not
+// exactly by count: batch boundaries do not influence the result (the insert is sequential anyway).
 bool OverlapsParser::next_batch(std::vector<ParsedOverlap>& batch, size_t max_batch, std::vector<Overlap>& rejected,
                                 ParseCounters& c, bool print_malformed) {
     batch.clear();
     if (!m_open || m_done) return false;
-    const bool allow_spaces = m_ps.allow_spaces;
-    const char* field[14];
-    size_t flen[14];
-    while (batch.size() < max_batch) {
-        if (m_pos >= m_size) { m_done = true; break; }                     // getline fails at EOF
-        const char* nl = (const char*)memchr(m_data + m_pos, '\n', m_size - m_pos);
-        const size_t end = nl ? (size_t)(nl - m_data) : m_size;
-        const char* line = m_data + m_pos;
-        const size_t n = end - m_pos;
-        m_pos = nl ? end + 1 : m_size;
-        if (!(m_line_no < m_ps.max_overlaps)) { m_done = true; break; }    // `&& i < max_overlaps`, :581
-        m_line_no++;
-        c.lines_read++;
-        const int nf = split_overlap_line(line, n, allow_spaces, field, flen, 14);
-        if (nf != 13) {                                                    // :598-603
-            c.malformed++;
-            if (print_malformed) puts("incorrect overlap; skipping");
-            continue;
-        }
-        ParsedOverlap po;
-        po.line = Overlap::from_fields(field, flen);
-        const Overlap& o = po.line;
-        if (o.m_id1 == o.m_id2) { c.self_overlaps++; continue; }           // :605-607
-        const unsigned int perc = o.get_perc();
-        const bool ss = o.m_type1 == 's' && o.m_type2 == 's';
-        const bool anyp = o.m_type1 == 'p' || o.m_type2 == 'p';
-        bool pass = false;
-        if (o.m_len1 >= m_ps.min_overlap_len && ss) {                      // :612-617
-            pass = perc >= m_ps.min_overlap_perc;
-            if (!pass) c.silently_dropped++;
-        } else if (o.m_len1 >= 0.5 * m_ps.min_overlap_len && o.m_len2 >= 0.5 * m_ps.min_overlap_len && anyp) {  // :618-624
-            pass = perc >= m_ps.min_overlap_perc;
-            if (!pass) c.silently_dropped++;
-        } else if (m_ps.relax_PE_edges && o.m_len1 + o.m_len2 >= m_ps.min_overlap_len && anyp) {                // :626-632
-            pass = perc >= m_ps.min_overlap_perc;
-            if (!pass) c.silently_dropped++;
-        } else {                                                           // :633-635
-            rejected.push_back(o);
-            c.prefilter_rejected++;
-        }
-        if (!pass) continue;
-        // id -> index: std::map::at in compute_overlap, :170-171 (throws => the reference aborts)
-        auto i1 = m_fastq.m_ID_to_index.find(o.m_id1);
-        auto i2 = m_fastq.m_ID_to_index.find(o.m_id2);
-        if (i1 == m_fastq.m_ID_to_index.end() || i2 == m_fastq.m_ID_to_index.end())
-            throw FatalError{HC_ERR_BAD_OVERLAP, "overlap refers to a read id that is not in the FASTQ input"};
-        hc_overlap_rec& r = po.rec;
-        r.read1 = i1->second;
-        r.read2 = i2->second;
-        r.pos1 = o.m_pos1;
-        r.pos2 = o.m_pos2;
-        r.ori1 = o.m_ori1 == '+';
-        r.ori2 = o.m_ori2 == '+';
-        r.ord = (uint8_t)o.m_ord;
-        r.flags = (uint8_t)((o.m_type1 == 'p') | ((o.m_type2 == 'p') << 1));
-        r.len1 = o.m_len1;
-        r.len2 = o.m_len2;
-        r.perc = perc;
-        batch.push_back(po);
+    if (m_pos >= m_size || !(m_line_no < m_ps.max_overlaps)) {
+        m_done = true;
+        return false;
     }
-    return !batch.empty() || !m_done;
+    // block = up to max_batch * 40 bytes of text (a line is >= ~26 bytes), ending at a line end
+    size_t block_end = m_pos + max_batch * 40;
+    if (block_end >= m_size) block_end = m_size;
+    else {
+        const char* nl = (const char*)memchr(m_data + block_end, '\n', m_size - block_end);
+        block_end = nl ? (size_t)(nl - m_data) + 1 : m_size;
+    }
+    const size_t bytes = block_end - m_pos;
+    unsigned int T = m_threads;
+    if (bytes < (size_t)T * 65536) T = (unsigned int)(bytes / 65536) + 1;
+    std::vector<Segment> segs(T);
+    size_t cut = m_pos;
+    for (unsigned int t = 0; t < T; t++) {
+        segs[t].begin = cut;
+        size_t e = t + 1 == T ? block_end : m_pos + bytes * (t + 1) / T;
+        if (e < cut) e = cut;
+        if (e < block_end) {
+            const char* nl = (const char*)memchr(m_data + e, '\n', block_end - e);
+            e = nl ? (size_t)(nl - m_data) + 1 : block_end;
+        }
+        segs[t].end = e;
+        cut = e;
+    }
+    auto run = [&](auto&& fn) {
+        if (T == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned int t = 1; t < T; t++) th.emplace_back(fn, t);
+        fn(0u);
+        for (auto& x : th) x.join();
+    };
+    // pass 1: lines per segment (a final piece without a trailing newline is a line too)
+    std::vector<uint64_t> nlines(T, 0);
+    run([&](unsigned int t) {
+        uint64_t k = 0;
+        size_t p = segs[t].begin;
+        while (p < segs[t].end) {
+            const char* nl = (const char*)memchr(m_data + p, '\n', segs[t].end - p);
+            k++;
+            if (!nl) break;
+            p = (size_t)(nl - m_data) + 1;
+        }
+        nlines[t] = k;
+    });
+    uint64_t line = m_line_no;
+    for (unsigned int t = 0; t < T; t++) {
+        segs[t].first_line = line;
+        segs[t].line_limit = m_ps.max_overlaps;
+        line += nlines[t];
+    }
+    // pass 2: parse
+    run([&](unsigned int t) { parse_segment(segs[t]); });
+    size_t total = 0;
+    for (auto& sg : segs) total += sg.pass.size();
+    batch.reserve(total);
+    for (auto& sg : segs) {
+        c.lines_read += sg.c.lines_read;
+        c.malformed += sg.c.malformed;
+        c.self_overlaps += sg.c.self_overlaps;
+        c.prefilter_rejected += sg.c.prefilter_rejected;
+        c.silently_dropped += sg.c.silently_dropped;
+        if (print_malformed)
+            for (uint64_t k = 0; k < sg.c.malformed; k++) puts("incorrect overlap; skipping");
+        if (sg.failed) throw sg.error;  // first failing segment in file order
+        batch.insert(batch.end(), sg.pass.begin(), sg.pass.end());
+        rejected.insert(rejected.end(), sg.rejected.begin(), sg.rejected.end());
+    }
+    m_pos = block_end;
+    m_line_no = line;
+    if (m_pos >= m_size || !(m_line_no < m_ps.max_overlaps)) m_done = true;
+    return true;
 }
 
 }  // namespace hc

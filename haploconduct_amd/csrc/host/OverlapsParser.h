@@ -27,6 +27,35 @@ struct ParseCounters {
 // beyond `max_fields` are counted but not stored.  The line is not modified.
 int split_overlap_line(const char* s, size_t n, bool allow_spaces, const char* field[], size_t len[], int max_fields);
 
+// id -> m_read_vec index with the semantics of FastqStorage::m_ID_to_index (first occurrence of an id
+// wins, FastqStorage.h:88-97) but O(1): a direct table when the ids are dense, else open addressing.
+class IdIndex {
+public:
+    explicit IdIndex(const FastqStorage& fastq);
+    // returns false when the id is unknown (std::map::at would throw, EdgeCalculator.cpp:170-171)
+    bool find(read_id_t id, uint32_t& index) const {
+        if (m_direct) {
+            if (id >= m_table.size() || m_table[id] == kNone) return false;
+            index = m_table[id];
+            return true;
+        }
+        uint64_t h = (id * 0x9E3779B97F4A7C15ull) >> m_shift;
+        for (;;) {
+            const uint32_t v = m_table[h];
+            if (v == kNone) return false;
+            if (m_keys[h] == id) { index = v; return true; }
+            h = (h + 1) & (m_table.size() - 1);
+        }
+    }
+
+private:
+    static constexpr uint32_t kNone = 0xFFFFFFFFu;
+    bool m_direct = true;
+    int m_shift = 0;
+    std::vector<uint32_t> m_table;
+    std::vector<read_id_t> m_keys;
+};
+
 class OverlapsParser {
 public:
     OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq);
@@ -40,8 +69,13 @@ public:
                     ParseCounters& c, bool print_malformed);
 
 private:
+    struct Segment;
+    void parse_segment(Segment& seg) const;
+
     const ProgramSettings& m_ps;
     const FastqStorage& m_fastq;
+    IdIndex m_ids;
+    unsigned int m_threads = 1;
     bool m_open = false;
     int m_fd = -1;
     const char* m_data = nullptr;

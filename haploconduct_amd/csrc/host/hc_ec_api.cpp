@@ -260,11 +260,11 @@ int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* ove
         uint64_t n = 0;
         for (;;) {
             const bool more = parser.next_batch(batch, 1000000, rejected, pc, false);
+            if (!more) break;
             for (const auto& b : batch) {
                 if (out && n < cap) out[n] = b.rec;
                 n++;
             }
-            if (!more) break;
         }
         *n_out = n;
         if (counters) {

@@ -83,11 +83,20 @@ def make_paired_dataset(n_pairs, genome_len, n_strains=3, divergence=0.01, read_
     return reads, {"s": s, "e": e, "flipped": flipped, "read_len": read_len, "strain": strain}
 
 
+def _sfo_order(read1, read2):
+    """Order real overlap files have: scripts/sfo2overlaps.py:53 sorts the lines by (smaller read id,
+    larger read id) before writing them, and FNO writes a sorted std::set of lines."""
+    lo = np.minimum(read1, read2).astype(np.uint64)
+    hi = np.maximum(read1, read2).astype(np.uint64)
+    return np.argsort((lo << np.uint64(32)) | hi, kind="stable")
+
+
 def paired_candidates(meta, n_candidates=None, min_len=75, seed=2, max_window=100000):
-    """All p-p candidates (len1 >= min_len and len2 >= min_len), optionally sub-sampled to n_candidates."""
+    """All p-p candidates (len1 >= min_len and len2 >= min_len), optionally sub-sampled to n_candidates,
+    in sfo2overlaps order.  int32 intermediates: 1e8 candidates need ~8 GB of host memory."""
     s, e, flipped, rl = meta["s"], meta["e"], meta["flipped"], meta["read_len"]
-    order = np.argsort(s, kind="stable")
-    ss, ee = s[order], e[order]
+    order = np.argsort(s, kind="stable").astype(np.int32)
+    ss, ee = s[order].astype(np.int32), e[order].astype(np.int32)
     n = ss.size
     maxd = rl - min_len
     out_i, out_j, out_p1, out_d2 = [], [], [], []
@@ -101,18 +110,22 @@ def paired_candidates(meta, n_candidates=None, min_len=75, seed=2, max_window=10
         idx = np.nonzero(m)[0]
         out_i.append(order[idx])
         out_j.append(order[idx + k])
-        out_p1.append(ds[idx])
-        out_d2.append(d2[idx])
-    i = np.concatenate(out_i) if out_i else np.zeros(0, np.int64)
-    j = np.concatenate(out_j) if out_j else np.zeros(0, np.int64)
-    p1 = np.concatenate(out_p1) if out_p1 else np.zeros(0, np.int64)
-    d2 = np.concatenate(out_d2) if out_d2 else np.zeros(0, np.int64)
+        out_p1.append(ds[idx].astype(np.int16))
+        out_d2.append(d2[idx].astype(np.int16))
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    i, j, p1, d2 = cat(out_i, np.int32), cat(out_j, np.int32), cat(out_p1, np.int16), cat(out_d2, np.int16)
+    del out_i, out_j, out_p1, out_d2
     rng = np.random.default_rng(seed)
     if n_candidates is not None:
         if i.size < n_candidates:
             raise ValueError(f"only {i.size} candidates exist, {n_candidates} requested: lower genome_len")
-        pick = np.sort(rng.choice(i.size, n_candidates, replace=False))
-        i, j, p1, d2 = i[pick], j[pick], p1[pick], d2[pick]
+        if i.size > n_candidates:
+            pick = np.sort(rng.choice(i.size, n_candidates, replace=False))
+            i, j, p1, d2 = i[pick], j[pick], p1[pick], d2[pick]
+            del pick
+    o = _sfo_order(i, j)
+    i, j, p1, d2 = i[o], j[o], p1[o].astype(np.int32), d2[o].astype(np.int32)
+    del o
     rec = np.zeros(i.size, dtype=OVERLAP_DTYPE)
     rec["read1"], rec["read2"] = i, j
     rec["pos1"] = p1
@@ -124,11 +137,7 @@ def paired_candidates(meta, n_candidates=None, min_len=75, seed=2, max_window=10
     rec["len2"] = rl - np.abs(d2)
     rec["perc"] = (0.5 * (np.floor(100.0 * rec["len1"] / rl) + np.floor(100.0 * rec["len2"] / rl))).astype(np.uint32)
     rec["flags"] = 3
-    # Emit in the order real overlap files have: scripts/sfo2overlaps.py:53 sorts the lines by
-    # (smaller read id, larger read id) before writing them, and FNO writes a sorted std::set of lines.
-    lo = np.minimum(rec["read1"], rec["read2"]).astype(np.uint64)
-    hi = np.maximum(rec["read1"], rec["read2"]).astype(np.uint64)
-    return rec[np.argsort((lo << np.uint64(32)) | hi, kind="stable")]
+    return rec
 
 
 def make_single_dataset(n_reads, genome_len, len_lo=150, len_hi=150, n_strains=2, divergence=0.001, err=0.005,
@@ -193,9 +202,7 @@ def single_candidates(meta, min_overlap=100, n_candidates=None, seed=4, max_wind
     rec["ori2"] = ~flipped[j]
     rec["len1"] = ovl
     rec["perc"] = np.minimum(np.floor(100.0 * ovl / np.minimum(lens[i], lens[j])), 100).astype(np.uint32)
-    lo = np.minimum(rec["read1"], rec["read2"]).astype(np.uint64)
-    hi = np.maximum(rec["read1"], rec["read2"]).astype(np.uint64)
-    return rec[np.argsort((lo << np.uint64(32)) | hi, kind="stable")]  # sfo2overlaps.py:53 order
+    return rec[_sfo_order(rec["read1"], rec["read2"])]
 
 
 def records_to_lines(rec, reads):

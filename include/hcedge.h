@@ -149,6 +149,11 @@ int hc_set_reads(hc_ctx* ctx, const uint8_t* bases, const uint8_t* quals, const 
  * Synchronous; out[i] <-> in[i]; host buffers. */
 int hc_score_batch(hc_ctx* ctx, const hc_overlap_rec* in, uint64_t n, hc_result_rec* out);
 
+/* Page-locked host memory for the in/out arrays of hc_score_batch (hipHostMalloc): DMA at full
+ * PCIe rate instead of staging through the driver's bounce buffers.  Optional; any host memory works. */
+int hc_host_alloc(hc_ctx* ctx, void** ptr, uint64_t bytes);
+int hc_host_free(hc_ctx* ctx, void* ptr);
+
 /* Same, but in/out are DEVICE pointers (hipMalloc'd, or torch CUDA tensors) and
  * the launch is asynchronous on `hip_stream` (a hipStream_t, NULL = the context's
  * own stream).  This is the entry bench.py times: inputs already resident in HBM. */

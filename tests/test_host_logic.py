@@ -142,6 +142,28 @@ def test_parser_and_prefilter_match_oracle(oracle, tmp_path):
     assert set(map(tuple, key(want).tolist())) == set(map(tuple, key(got).tolist()))
 
 
+def test_parallel_parser_equals_serial(tmp_path):
+    reads, meta = synth.make_paired_dataset(1500, 1500, seed=17)
+    cand = synth.paired_candidates(meta, n_candidates=30000, seed=5)
+    lines = synth.records_to_lines(cand, reads)
+    rng = random.Random(4)
+    for junk in ["", "x\ty", "7\t7\t0\t0\t1\t+\t+\t90\t90\t100\t100\tp\tp", "1\t2\t0\t0\t1\t+\t+\t90\t90\t10\t10\tp\tp"] * 25:
+        lines.insert(rng.randrange(len(lines)), junk)
+    path = str(tmp_path / "overlaps.txt")
+    _write(path, "\n".join(lines))  # no trailing newline on purpose
+    reads.write_fastq(paired1_path=str(tmp_path / "p1.fastq"), paired2_path=str(tmp_path / "p2.fastq"))
+    f = host.Fastq(paired1=str(tmp_path / "p1.fastq"), paired2=str(tmp_path / "p2.fastq"))
+    for max_ov in (100000000, 12345, 1, len(lines), len(lines) - 1):
+        base = None
+        for threads in (1, 2, 7, 32):
+            recs, c = f.parse_file(hc.Settings(min_overlap_len=150, max_overlaps=max_ov, n_threads=threads), path)
+            got = (recs.tobytes(), c["lines_read"], c["malformed_lines"], c["prefilter_rejected"], c["scored"])
+            if base is None:
+                base = got
+                assert c["lines_read"] == min(max_ov, len(lines))
+            assert got == base, (max_ov, threads)
+
+
 def _random_edge_stream(rng, V, n):
     """Edges with many duplicates of the same unordered pair / orientation class and engineered ties."""
     out = np.zeros(n, dtype=host.EDGE_DTYPE)

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the edge-calculation stage (text overlaps file + FASTQ in -> populated
+OverlapGraph + nonedge_overlaps.txt out) through the host mirror, with its parse / score / insert /
+write breakdown, next to the oracle's construct_edges on the same files (1 thread) for reference."""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--threads", type=int, default=16, help="--threads of the stage (parser workers)")
+    ap.add_argument("--oracle-lines", type=int, default=200000, help="lines of the file the 1-thread oracle is timed on")
+    args = ap.parse_args()
+    import bench
+    import haploconduct_amd as hc
+    from haploconduct_amd import host, synth
+    from tests import _oracle
+
+    reads, cand, cfg, st = bench.build_workload(args.workload, 0)
+    st.n_threads = args.threads
+    d = tempfile.mkdtemp(prefix="hcstage_") + "/"
+    t0 = time.time()
+    lines = synth.records_to_lines(cand, reads)
+    with open(d + "overlaps.txt", "w") as f:
+        f.write("\n".join(lines) + "\n")
+    paired = reads.is_paired(0)
+    reads.write_fastq(None if paired else d + "singles.fastq", d + "paired1.fastq" if paired else None,
+                      d + "paired2.fastq" if paired else None)
+    print(f"files written in {time.time()-t0:.1f} s: {os.path.getsize(d+'overlaps.txt')/1e6:.1f} MB overlaps, {len(lines)} lines")
+    kw = dict(singles=None if paired else d + "singles.fastq", paired1=d + "paired1.fastq" if paired else None,
+              paired2=d + "paired2.fastq" if paired else None, overlaps=d + "overlaps.txt", output_dir=d)
+    for rep in range(2):
+        if os.path.exists(d + "nonedge_overlaps.txt"):
+            os.remove(d + "nonedge_overlaps.txt")
+        t0 = time.time()
+        ec = host.EdgeCalculatorStage(st, **kw)
+        t1 = time.time()
+        ec.construct_edges()
+        t2 = time.time()
+        c = ec.counters()
+        print(f"run {rep}: open (FASTQ + store upload) {t1-t0:.3f} s, construct_edges {t2-t1:.3f} s -> "
+              f"{c['scored']/(t2-t1)/1e6:.2f} M candidates/s end-to-end; parse {c['t_parse']:.3f} score {c['t_score']:.3f} "
+              f"insert {c['t_insert']:.3f} write {c['t_write']:.3f}; edges {ec.edge_count()} dups {c['dup_count']} "
+              f"nonedges {c['nonedges_written']}")
+        ec.close()
+    n = min(args.oracle_lines, len(lines))
+    with open(d + "head.txt", "w") as f:
+        f.write("\n".join(lines[:n]) + "\n")
+    t0 = time.time()
+    rc, g, oc = _oracle.construct_edges(reads, st, d + "head.txt", d + "ref_nonedge.txt")
+    dt = time.time() - t0
+    print(f"oracle construct_edges (1 thread) on the first {n} lines: {dt:.2f} s -> {oc.scored/dt/1e3:.1f} k candidates/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,7 @@ def main():
     import bench
     import haploconduct_amd as hc
 
-    reads, cand, cfg = bench.build_workload(args.workload, 0)
+    reads, cand, cfg, st = bench.build_workload(args.workload, 0)
     if args.order == "grouped":
         cand = cand[np.argsort(cand["read1"], kind="stable")]
     elif args.order == "shuffled":
@@ -31,7 +31,6 @@ def main():
     n = cand.size
     d_in = torch.from_numpy(cand.view(np.uint8).reshape(-1)).cuda()
     d_out = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
-    st = hc.Settings(edge_threshold=0.97)
     scorers, outs = {}, {}
     for v in [int(x) for x in args.variants.split(",")]:
         os.environ["HC_SCORE_VARIANT"] = str(v)
