@@ -22,7 +22,11 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
                          uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
                          hipStream_t stream);
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
-                        uint64_t n, hc_result_rec* out, uint32_t n_cu, int variant, hipStream_t stream);
+                        uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int variant,
+                        hipStream_t stream);
+size_t reorder_temp_bytes(uint32_t n);
+hipError_t launch_reorder(const hc_overlap_rec* in, uint32_t n, uint32_t n_reads, uint32_t* keys_in, uint32_t* keys_out,
+                          uint32_t* idx_in, uint32_t* perm_out, void* temp, size_t temp_bytes, hipStream_t stream);
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,
                                   unsigned long long* totals, hipStream_t stream);
 hipError_t set_score_kernel_lds_limit();
@@ -65,6 +69,12 @@ struct hc_ctx {
     void* d_out = nullptr;
     uint64_t ws_cap = 0;
     unsigned long long* d_totals = nullptr;
+    // candidate reorder (HC_REORDER_*): scratch for the (key, index) radix sort, grow-only
+    int reorder_mode = HC_REORDER_AUTO;
+    uint32_t* d_sort = nullptr;  // 4 arrays of sort_cap uint32: keys_in, keys_out, idx_in, perm
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint64_t sort_cap = 0;
 };
 
 // --------------------------------------------------------------------------
@@ -182,6 +192,8 @@ int hc_destroy(hc_ctx* c) {
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_totals) (void)hipFree(c->d_totals);
+    if (c->d_sort) (void)hipFree(c->d_sort);
+    if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -312,6 +324,44 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     return HC_OK;
 }
 
+static int ensure_sort_workspace(hc_ctx* c, uint64_t n) {
+    if (n <= c->sort_cap) return HC_OK;
+    if (c->d_sort) (void)hipFree(c->d_sort);
+    if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
+    c->d_sort = nullptr;
+    c->d_sort_tmp = nullptr;
+    c->sort_cap = 0;
+    c->sort_tmp_bytes = hc::reorder_temp_bytes((uint32_t)n);
+    HC_HIP(hipMalloc((void**)&c->d_sort, 4 * n * sizeof(uint32_t)));
+    HC_HIP(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes ? c->sort_tmp_bytes : 16));
+    c->sort_cap = n;
+    return HC_OK;
+}
+
+static int score_on_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, hipStream_t s, bool reorder) {
+    const uint32_t* perm = nullptr;
+    if (reorder && n > 1 && n < (1ull << 31)) {
+        int rc = ensure_sort_workspace(c, n);
+        if (rc) return rc;
+        uint32_t* keys_in = c->d_sort;
+        uint32_t* keys_out = c->d_sort + c->sort_cap;
+        uint32_t* idx_in = c->d_sort + 2 * c->sort_cap;
+        uint32_t* perm_out = c->d_sort + 3 * c->sort_cap;
+        HC_HIP(hc::launch_reorder((const hc_overlap_rec*)d_in, (uint32_t)n, c->view.n_reads, keys_in, keys_out, idx_in,
+                                  perm_out, c->d_sort_tmp, c->sort_tmp_bytes, s));
+        perm = perm_out;
+    }
+    HC_HIP(hc::launch_score(c->view, c->params, c->d_lut, (const hc_overlap_rec*)d_in, n, (hc_result_rec*)d_out, perm,
+                            c->n_cu, c->variant, s));
+    return HC_OK;
+}
+
+int hc_set_reorder(hc_ctx* c, int mode) {
+    if (!c || mode < HC_REORDER_NEVER || mode > HC_REORDER_AUTO) return fail(HC_ERR_ARG, "hc_set_reorder: bad argument");
+    c->reorder_mode = mode;
+    return HC_OK;
+}
+
 int hc_score_batch_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, void* hip_stream) {
     if (!c) return fail(HC_ERR_ARG, "hc_score_batch_device: null context");
     if (!c->have_reads) return fail(HC_ERR_STATE, "hc_score_batch_device: hc_set_reads has not been called");
@@ -319,9 +369,8 @@ int hc_score_batch_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, 
     if (!d_in || !d_out) return fail(HC_ERR_ARG, "hc_score_batch_device: null buffer");
     HC_HIP(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    HC_HIP(hc::launch_score(c->view, c->params, c->d_lut, (const hc_overlap_rec*)d_in, n, (hc_result_rec*)d_out, c->n_cu,
-                            c->variant, s));
-    return HC_OK;
+    // device-resident records cannot be inspected without a synchronisation: AUTO means "as given"
+    return score_on_device(c, d_in, n, d_out, s, c->reorder_mode == HC_REORDER_ALWAYS);
 }
 
 int hc_synchronize(hc_ctx* c) {
@@ -352,7 +401,21 @@ int hc_score_batch(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, hc_result_re
     int rc = ensure_workspace(c, n);
     if (rc) return rc;
     HC_HIP(hipMemcpyAsync(c->d_in, in, n * sizeof(hc_overlap_rec), hipMemcpyHostToDevice, c->stream));
-    rc = hc_score_batch_device(c, c->d_in, n, c->d_out, c->stream);
+    bool reorder = c->reorder_mode == HC_REORDER_ALWAYS;
+    if (c->reorder_mode == HC_REORDER_AUTO && n >= 4096) {
+        // Sampled locality probe on the host copy: in overlap files as sfo2overlaps / FNO write them,
+        // consecutive lines share a read almost always; if fewer than half of the sampled neighbours
+        // do, the batch is reordered on the device.
+        const uint64_t samples = 4096, step = (n - 1) / samples;
+        uint64_t share = 0;
+        for (uint64_t k = 0; k < samples; k++) {
+            const hc_overlap_rec& a = in[k * step];
+            const hc_overlap_rec& b = in[k * step + 1];
+            share += (a.read1 == b.read1) | (a.read1 == b.read2) | (a.read2 == b.read1) | (a.read2 == b.read2);
+        }
+        reorder = share * 2 < samples;
+    }
+    rc = score_on_device(c, c->d_in, n, c->d_out, c->stream, reorder);
     if (rc) return rc;
     HC_HIP(hipMemcpyAsync(out, c->d_out, n * sizeof(hc_result_rec), hipMemcpyDeviceToHost, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));

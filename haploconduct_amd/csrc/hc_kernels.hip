@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <hipcub/hipcub.hpp>
+
 #include "../../include/hcedge.h"
 #include "hc_device.h"
 
@@ -413,7 +415,8 @@ __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return 
 template <typename SymT, int VAR>
 __global__ __launch_bounds__(256, (VAR & 4) ? 8 : 1) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                     const hc_overlap_rec* __restrict__ in, uint64_t n,
-                                                    hc_result_rec* __restrict__ out) {
+                                                    hc_result_rec* __restrict__ out,
+                                                    const uint32_t* __restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) double lut_s[];
     const uint32_t lut_n = st.lut_bytes >> 3;
     for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
@@ -427,7 +430,10 @@ __global__ __launch_bounds__(256, (VAR & 4) ? 8 : 1) void score_kernel(StoreView
     const uint32_t nsym = (st.K << 3) | kCodeN;
     const uint32_t nsym_word = sizeof(SymT) == 1 ? nsym * 0x01010101u : nsym * 0x00010001u;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += stride) {
+        // with a permutation, lane `slot` scores candidate perm[slot] (neighbouring lanes share reads) and
+        // writes its record back to the candidate's own position: out[i] <-> in[i] always holds
+        const uint64_t i = perm ? (uint64_t)perm[slot] : slot;
         hc_overlap_rec rec;
         {
             const uint4* p = (const uint4*)(in + i);
@@ -529,6 +535,37 @@ __global__ __launch_bounds__(256) void count_positions_kernel(StoreView st, uint
 }
 
 // ---------------------------------------------------------------------------
+// Candidate reorder for locality: key = the smaller read index of the pair (the grouping real
+// overlap files have, scripts/sfo2overlaps.py:53); a stable LSD radix sort of (key, index) pairs
+// gives the permutation the scoring kernel walks.  hipCUB is used as a utility here; the hot op
+// stays the hand-written kernel above.
+__global__ __launch_bounds__(256) void make_keys_kernel(const hc_overlap_rec* __restrict__ in, uint32_t n,
+                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 r = *(const uint2*)(in + i);  // read1, read2
+    keys[i] = r.x < r.y ? r.x : r.y;
+    idx[i] = i;
+}
+
+size_t reorder_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                       (uint32_t*)nullptr, (int)n);
+    return bytes;
+}
+
+// keys_in/idx_in are scratch (n each); perm_out receives the permutation.
+hipError_t launch_reorder(const hc_overlap_rec* in, uint32_t n, uint32_t n_reads, uint32_t* keys_in, uint32_t* keys_out,
+                          uint32_t* idx_in, uint32_t* perm_out, void* temp, size_t temp_bytes, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(make_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, n, keys_in, idx_in);
+    int end_bit = 1;
+    while (end_bit < 32 && (n_reads >> end_bit)) end_bit++;  // keys < n_reads
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm_out, (int)n, 0, end_bit, stream);
+}
+
+// ---------------------------------------------------------------------------
 // Launch wrappers (called from hc_api.cpp).
 hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
                          const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
@@ -554,29 +591,31 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
 
 template <typename SymT, int VAR>
 static void launch_score_var(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
-                             uint64_t n, hc_result_rec* out, uint32_t blocks, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((score_kernel<SymT, VAR>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out);
+                             uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t blocks, size_t lds,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL((score_kernel<SymT, VAR>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out, perm);
 }
 
 template <typename SymT>
 static hipError_t launch_score_t(int var, const StoreView& st, const ScoreParams& prm, const double* lut_g,
-                                 const hc_overlap_rec* in, uint64_t n, hc_result_rec* out, uint32_t blocks, size_t lds,
-                                 hipStream_t stream) {
+                                 const hc_overlap_rec* in, uint64_t n, hc_result_rec* out, const uint32_t* perm,
+                                 uint32_t blocks, size_t lds, hipStream_t stream) {
     switch (var & 7) {
-        case 0: launch_score_var<SymT, 0>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
-        case 1: launch_score_var<SymT, 1>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
-        case 2: launch_score_var<SymT, 2>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
-        case 3: launch_score_var<SymT, 3>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
-        case 4: launch_score_var<SymT, 4>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
-        case 5: launch_score_var<SymT, 5>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
-        case 6: launch_score_var<SymT, 6>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
-        default: launch_score_var<SymT, 7>(st, prm, lut_g, in, n, out, blocks, lds, stream); break;
+        case 0: launch_score_var<SymT, 0>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        case 1: launch_score_var<SymT, 1>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        case 2: launch_score_var<SymT, 2>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        case 3: launch_score_var<SymT, 3>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        case 4: launch_score_var<SymT, 4>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        case 5: launch_score_var<SymT, 5>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        case 6: launch_score_var<SymT, 6>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        default: launch_score_var<SymT, 7>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
-                        uint64_t n, hc_result_rec* out, uint32_t n_cu, int variant, hipStream_t stream) {
+                        uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int variant,
+                        hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const size_t lds = st.lut_bytes + 17 * (st.symbytes == 1 ? 4 : 8) * sizeof(uint32_t);
     const uint32_t block = 256;
@@ -589,8 +628,9 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     uint64_t blocks = (n + block - 1) / block;
     const uint64_t cap = (uint64_t)n_cu * blocks_per_cu * 4;  // grid-stride beyond this
     if (blocks > cap) blocks = cap;
-    if (st.symbytes == 1) return launch_score_t<uint8_t>(variant, st, prm, lut_g, in, n, out, (uint32_t)blocks, lds, stream);
-    return launch_score_t<uint16_t>(variant, st, prm, lut_g, in, n, out, (uint32_t)blocks, lds, stream);
+    if (st.symbytes == 1)
+        return launch_score_t<uint8_t>(variant, st, prm, lut_g, in, n, out, perm, (uint32_t)blocks, lds, stream);
+    return launch_score_t<uint16_t>(variant, st, prm, lut_g, in, n, out, perm, (uint32_t)blocks, lds, stream);
 }
 
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,

@@ -56,6 +56,10 @@ class EdgeScorer:
         return {"qual_alphabet": k.value, "store_bytes": sb.value, "x_edge": (d[0].value, d[1].value),
                 "x_ov": (d[2].value, d[3].value)}
 
+    def set_reorder(self, mode):
+        """0 never, 1 always, 2 auto (hc_set_reorder)."""
+        N.check(N.lib.hc_set_reorder(self._ctx, int(mode)), "hc_set_reorder")
+
     # -- scoring ------------------------------------------------------------
     def score_batch(self, overlaps):
         """Host buffers in, host buffers out (hc_score_batch)."""

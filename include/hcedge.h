@@ -149,6 +149,18 @@ int hc_set_reads(hc_ctx* ctx, const uint8_t* bases, const uint8_t* quals, const 
  * Synchronous; out[i] <-> in[i]; host buffers. */
 int hc_score_batch(hc_ctx* ctx, const hc_overlap_rec* in, uint64_t n, hc_result_rec* out);
 
+/* Candidate order.  The kernel is fastest when neighbouring candidates share a read, as they do in
+ * overlap files written by sfo2overlaps (sorted by smaller/larger read id, scripts/sfo2overlaps.py:53)
+ * and by FNO (a sorted std::set).  Results never depend on the order; out[i] <-> in[i] always.
+ *   HC_REORDER_NEVER  score the batch as given
+ *   HC_REORDER_ALWAYS sort candidate indices by min(read1, read2) on the device first
+ *   HC_REORDER_AUTO   (default) hc_score_batch probes its host copy and reorders only unordered batches;
+ *                     hc_score_batch_device scores as given (it cannot look without synchronising) */
+#define HC_REORDER_NEVER 0
+#define HC_REORDER_ALWAYS 1
+#define HC_REORDER_AUTO 2
+int hc_set_reorder(hc_ctx* ctx, int mode);
+
 /* Page-locked host memory for the in/out arrays of hc_score_batch (hipHostMalloc): DMA at full
  * PCIe rate instead of staging through the driver's bounce buffers.  Optional; any host memory works. */
 int hc_host_alloc(hc_ctx* ctx, void** ptr, uint64_t bytes);

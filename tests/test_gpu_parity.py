@@ -251,3 +251,30 @@ def test_device_resident_entry_matches_host_entry(oracle):
         pos, subs = sc.count_positions_device(d_in.data_ptr(), cand.size)
     ref = oracle.score_batch(reads, st, cand)
     assert pos == int(ref["positions"].sum()) and subs == int(ref["n_subs"].sum())
+
+
+def test_reorder_modes_give_identical_records(oracle):
+    """hc_set_reorder: results never depend on the candidate order or on the reorder policy."""
+    import torch
+
+    reads, meta = synth.make_paired_dataset(3000, 4000, flip_frac=0.2, seed=111)
+    cand = synth.paired_candidates(meta, n_candidates=60000, seed=112)
+    shuf = cand[np.random.default_rng(1).permutation(cand.size)]
+    st = hc.Settings(edge_threshold=0.97)
+    ref = oracle.score_batch(reads, st, shuf)
+    outs = []
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        for mode in (0, 1, 2):
+            sc.set_reorder(mode)
+            outs.append(sc.score_batch(shuf))          # host entry: AUTO probes and reorders the shuffled batch
+            d_in = torch.from_numpy(shuf.view(np.uint8).reshape(-1)).cuda()
+            d_out = torch.zeros(shuf.size * 24, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            sc.score_batch_device(d_in.data_ptr(), shuf.size, d_out.data_ptr())
+            sc.synchronize()
+            outs.append(d_out.cpu().numpy().view(hc.RESULT_DTYPE))
+    for o in outs:
+        assert o.tobytes() == outs[0].tobytes()
+    assert np.array_equal(outs[0]["x1"].view(np.uint64), ref["x1"].view(np.uint64))
+    assert np.array_equal(result_n(outs[0]), ref["n"])

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--order", default="sfo")
+    ap.add_argument("--reorder", type=int, default=0, help="hc_set_reorder mode for the device entry (0 never, 1 always)")
     args = ap.parse_args()
     import torch
 
@@ -36,6 +37,7 @@ def main():
         os.environ["HC_SCORE_VARIANT"] = str(v)
         sc = hc.EdgeScorer(st)
         sc.set_reads(reads)
+        sc.set_reorder(args.reorder)
         scorers[v] = sc
         sc.time_kernel(d_in.data_ptr(), n, d_out.data_ptr(), 3)
         outs[v] = d_out.cpu().numpy().copy()
