@@ -25,8 +25,9 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int variant,
                         hipStream_t stream);
 size_t reorder_temp_bytes(uint32_t n);
-hipError_t launch_reorder(const hc_overlap_rec* in, uint32_t n, uint32_t n_reads, uint32_t* keys_in, uint32_t* keys_out,
-                          uint32_t* idx_in, uint32_t* perm_out, void* temp, size_t temp_bytes, hipStream_t stream);
+hipError_t launch_reorder(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint32_t n,
+                          bool use_buckets, uint32_t* keys_in, uint32_t* keys_out, uint32_t* idx_in, uint32_t* perm_out,
+                          void* temp, size_t temp_bytes, hipStream_t stream);
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,
                                   unsigned long long* totals, hipStream_t stream);
 hipError_t set_score_kernel_lds_limit();
@@ -71,6 +72,7 @@ struct hc_ctx {
     unsigned long long* d_totals = nullptr;
     // candidate reorder (HC_REORDER_*): scratch for the (key, index) radix sort, grow-only
     int reorder_mode = HC_REORDER_AUTO;
+    bool reorder_buckets = false;  // length-bucket major key: measured slower on C2/C4/C5 (locality beats divergence); HC_REORDER_BUCKETS=1 to experiment
     uint32_t* d_sort = nullptr;  // 4 arrays of sort_cap uint32: keys_in, keys_out, idx_in, perm
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -164,6 +166,7 @@ int hc_create(hc_ctx** out, const hc_settings* settings) {
     HC_HIP(hipMalloc((void**)&c->d_totals, 2 * sizeof(unsigned long long)));
     HC_HIP(hc::set_score_kernel_lds_limit());
     if (const char* v = getenv("HC_SCORE_VARIANT")) c->variant = atoi(v);
+    if (const char* v = getenv("HC_REORDER_BUCKETS")) c->reorder_buckets = atoi(v) != 0;
     c->params.edge = make_band(settings->edge_threshold);
     c->params.ov = make_band(settings->ov_threshold);
     c->params.merge_contigs = settings->merge_contigs;
@@ -347,8 +350,9 @@ static int score_on_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out,
         uint32_t* keys_out = c->d_sort + c->sort_cap;
         uint32_t* idx_in = c->d_sort + 2 * c->sort_cap;
         uint32_t* perm_out = c->d_sort + 3 * c->sort_cap;
-        HC_HIP(hc::launch_reorder((const hc_overlap_rec*)d_in, (uint32_t)n, c->view.n_reads, keys_in, keys_out, idx_in,
-                                  perm_out, c->d_sort_tmp, c->sort_tmp_bytes, s));
+        HC_HIP(hc::launch_reorder(c->view, c->params.min_read_len, (const hc_overlap_rec*)d_in, (uint32_t)n,
+                                  c->reorder_buckets, keys_in, keys_out, idx_in, perm_out, c->d_sort_tmp,
+                                  c->sort_tmp_bytes, s));
         perm = perm_out;
     }
     HC_HIP(hc::launch_score(c->view, c->params, c->d_lut, (const hc_overlap_rec*)d_in, n, (hc_result_rec*)d_out, perm,

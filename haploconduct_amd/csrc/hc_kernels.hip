@@ -539,12 +539,38 @@ __global__ __launch_bounds__(256) void count_positions_kernel(StoreView st, uint
 // overlap files have, scripts/sfo2overlaps.py:53); a stable LSD radix sort of (key, index) pairs
 // gives the permutation the scoring kernel walks.  hipCUB is used as a utility here; the hot op
 // stays the hand-written kernel above.
-__global__ __launch_bounds__(256) void make_keys_kernel(const hc_overlap_rec* __restrict__ in, uint32_t n,
-                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+// key = [length bucket : 6 bits][smaller read index : 26 bits].  The bucket is floor(log2) of the
+// candidate's overlapped positions in quarter-octave steps, so that the lanes of a wave run a
+// similar number of chunks (mixed-length contigs, BASELINE config 5) while candidates of one read
+// stay together inside a bucket.  bucket_shift = 32 disables bucketing (key = read index only).
+template <int SB>
+__global__ __launch_bounds__(256) void make_keys_kernel(StoreView st, uint32_t min_read_len,
+                                                        const hc_overlap_rec* __restrict__ in, uint32_t n,
+                                                        uint32_t use_buckets, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint2 r = *(const uint2*)(in + i);  // read1, read2
-    keys[i] = r.x < r.y ? r.x : r.y;
+    const hc_overlap_rec rec = in[i];
+    uint32_t key = rec.read1 < rec.read2 ? rec.read1 : rec.read2;
+    if (use_buckets) {
+        Sub s0, s1;
+        const int ns = resolve<SB>(st, rec, s0, s1);
+        uint32_t L = 0;
+        if (ns >= 1) L = sub_positions(s0, min_read_len);
+        if (ns == 2) {
+            const uint32_t L1 = sub_positions(s1, min_read_len);
+            L = L1 > L ? L1 : L;
+        }
+        const uint32_t chunks = (L + 15u) >> 4;
+        uint32_t b = 0;
+        if (chunks > 1) {
+            const uint32_t lg = 31u - __builtin_clz(chunks);          // floor(log2)
+            const uint32_t frac = lg >= 2 ? (chunks >> (lg - 2)) & 3u : 0u;  // quarter-octave
+            b = lg * 4u + frac;
+        }
+        key = (key & 0x03FFFFFFu) | ((63u - (b > 63u ? 63u : b)) << 26);  // longest first
+    }
+    keys[i] = key;
     idx[i] = i;
 }
 
@@ -556,12 +582,22 @@ size_t reorder_temp_bytes(uint32_t n) {
 }
 
 // keys_in/idx_in are scratch (n each); perm_out receives the permutation.
-hipError_t launch_reorder(const hc_overlap_rec* in, uint32_t n, uint32_t n_reads, uint32_t* keys_in, uint32_t* keys_out,
-                          uint32_t* idx_in, uint32_t* perm_out, void* temp, size_t temp_bytes, hipStream_t stream) {
+hipError_t launch_reorder(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint32_t n,
+                          bool use_buckets, uint32_t* keys_in, uint32_t* keys_out, uint32_t* idx_in, uint32_t* perm_out,
+                          void* temp, size_t temp_bytes, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(make_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, n, keys_in, idx_in);
-    int end_bit = 1;
-    while (end_bit < 32 && (n_reads >> end_bit)) end_bit++;  // keys < n_reads
+    const uint32_t ub = use_buckets && st.n_reads < (1u << 26) ? 1u : 0u;
+    if (st.symbytes == 1)
+        hipLaunchKernelGGL(make_keys_kernel<1>, dim3((n + 255) / 256), dim3(256), 0, stream, st, min_read_len, in, n, ub,
+                           keys_in, idx_in);
+    else
+        hipLaunchKernelGGL(make_keys_kernel<2>, dim3((n + 255) / 256), dim3(256), 0, stream, st, min_read_len, in, n, ub,
+                           keys_in, idx_in);
+    int end_bit = 32;
+    if (!ub) {
+        end_bit = 1;
+        while (end_bit < 32 && (st.n_reads >> end_bit)) end_bit++;  // keys < n_reads
+    }
     return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm_out, (int)n, 0, end_bit, stream);
 }
 
