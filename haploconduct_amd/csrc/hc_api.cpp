@@ -212,8 +212,8 @@ static void build_lut(const std::vector<int>& phred, double mismatch_setting, ui
     const size_t K = phred.size(), Kp = K + 2;
     const double inf = std::numeric_limits<double>::infinity();
     const double nan = std::numeric_limits<double>::quiet_NaN();
-    const size_t row = symbytes == 1 ? hc::kLutRowBytesU8 / 8 : Kp * 2;  // doubles per qa row
-    lut.assign(Kp * row, 0.0);
+    const uint32_t lg = hc::lut_lg((uint32_t)K);
+    lut.assign(symbytes == 1 ? (size_t)2 << (2 * lg) : Kp * Kp * 2, 0.0);
     for (size_t a = 0; a < Kp; a++) {
         for (size_t b = 0; b < Kp; b++) {
             double vm, vx;
@@ -229,8 +229,13 @@ static void build_lut(const std::vector<int>& phred, double mismatch_setting, ui
                 vm = (pm < mismatch_setting) ? inf : log(pm);  // :49-52
                 vx = (px < mismatch_setting) ? inf : log(px);
             }
-            lut[a * row + b * 2 + 0] = vm;
-            lut[a * row + b * 2 + 1] = vx;
+            if (symbytes == 1) {
+                lut[hc::lut_addr_u8(lg, (uint32_t)a, (uint32_t)b, 0) / 8] = vm;
+                lut[hc::lut_addr_u8(lg, (uint32_t)a, (uint32_t)b, 1) / 8] = vx;
+            } else {
+                lut[(a * Kp + b) * 2 + 0] = vm;
+                lut[(a * Kp + b) * 2 + 1] = vx;
+            }
         }
     }
 }

@@ -58,9 +58,17 @@ struct StoreView {
 };
 
 // Log table layouts (doubles):
-//   uint8 symbols : byte address = qa*512 + qb*16 + mismatch*8   (row stride 512 B, Kp rows)
+//   uint8 symbols : two dense planes (match, mismatch) of 2^LG x 2^LG entries, LG = ceil(log2(Kp)) in {3,4,5}:
+//                   byte address = m * (8 << 2LG) + qa * (8 << LG) + ((qb ^ qa) & (2^LG - 1)) * 8.
+//                   The address of a position is exactly the 16-bit value one v_perm_b32 assembles from two
+//                   pre-masked symbol bytes (no shift, no multiply); the XOR of the column with the row
+//                   spreads the few hot (qa, qb) pairs over the LDS banks (rows of a power-of-two table
+//                   would otherwise alias bank for bank).
 //   uint16 symbols: byte address = (qa*Kp + qb)*16 + mismatch*8
-constexpr uint32_t kLutRowBytesU8 = 512;
+__host__ __device__ inline uint32_t lut_lg(uint32_t K) { return K + 2 <= 8 ? 3u : (K + 2 <= 16 ? 4u : 5u); }
+__host__ __device__ inline uint32_t lut_addr_u8(uint32_t lg, uint32_t qa, uint32_t qb, uint32_t m) {
+    return m * (8u << (2 * lg)) + qa * (8u << lg) + ((qb ^ qa) & ((1u << lg) - 1u)) * 8u;
+}
 
 // x-space image of a score threshold T: exp(x) > T  <=>  x > hi ; x <= lo => exp(x) <= T;
 // lo < x <= hi is the guard band the host libm decides (normally empty).

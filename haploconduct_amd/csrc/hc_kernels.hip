@@ -231,6 +231,7 @@ __device__ __forceinline__ double lds_f64(const char* lut, uint32_t byte_addr) {
 template <typename SymT>
 __device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, const SymT* __restrict__ b, uint32_t L,
                                                 const char* lut, uint32_t Kp) {
+    const uint32_t lg = lut_lg(Kp - 2u);
     SubScore r;
     r.x = -__builtin_inf();
     r.mm = 1;
@@ -253,7 +254,7 @@ __device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, cons
         if ((ca | cb) & 4u) continue;  // N: :35-39, :122-124
         const uint32_t m = ca != cb;
         const uint32_t qa = sa >> 3, qb = sb >> 3;
-        const uint32_t addr = sizeof(SymT) == 1 ? qa * kLutRowBytesU8 + qb * 16u + m * 8u : (qa * Kp + qb) * 16u + m * 8u;
+        const uint32_t addr = sizeof(SymT) == 1 ? lut_addr_u8(lg, qa, qb, m) : (qa * Kp + qb) * 16u + m * 8u;
         const double t = lds_f64(lut, addr);
         if (t == __builtin_inf()) return r;  // :125-127
         S += t;
@@ -280,6 +281,53 @@ __device__ __forceinline__ void fill_mask_table(uint32_t* tab /* 17 * kWords */,
     }
 }
 
+// The table reads of one half-chunk (8 positions): packed-byte N / mismatch masks and counters, then
+// one LDS address per position.  aw/bw/keep point at the half's 32-bit words.
+template <typename SymT, int LG>
+__device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint32_t* wb, const uint32_t* keep,
+                                                 uint32_t nsym_word, const char* lut, uint32_t Kp, double (&t)[8],
+                                                 uint32_t& skipped, uint32_t& cm) {
+    using T = Tr<SymT>;
+#pragma unroll
+    for (int jj = 0; jj < T::kWords / 2; ++jj) {
+        // symbols at or beyond L become N: they add 0.0 and count as skipped
+        const uint32_t aw = (wa[jj] & keep[jj]) | (nsym_word & ~keep[jj]);
+        const uint32_t bw = wb[jj];
+        const uint32_t x = aw | bw, e = aw ^ bw;
+        const uint32_t nm = x & (T::kLow1 << 2);                             // code bit 2 on either side: N (or invalid)
+        const uint32_t mk = ((e << 1) | (e << 2)) & (T::kLow1 << 2) & ~x;  // bases differ, neither is N
+        skipped += __builtin_popcount(nm);
+        cm += __builtin_popcount(mk);
+        if (sizeof(SymT) == 1) {
+            // Two bytes per position whose concatenation IS the table's byte address
+            //   m * (8 << 2LG) + qa * (8 << LG) + (qb ^ qa) * 8        (hc_device.h)
+            // symbol byte = qidx << 3 | code, mk holds the mismatch flag at bit 2 of each byte, e = aw ^ bw.
+            uint32_t lo, hi;
+            if (LG == 5) {         // bits 3-7: qb^qa | bits 8-12: qa, bit 13: m
+                lo = e & 0xF8F8F8F8u;
+                hi = ((aw >> 3) & 0x1F1F1F1Fu) | (mk << 3);
+            } else if (LG == 4) {  // bits 3-6: qb^qa, bit 7: qa0 | bits 8-10: qa>>1, bit 11: m
+                lo = (e & 0x78787878u) | ((aw << 4) & 0x80808080u);
+                hi = ((aw >> 4) & 0x07070707u) | (mk << 1);
+            } else {               // bits 3-5: qb^qa, bits 6-7: qa&3 | bit 8: qa>>2, bit 9: m
+                lo = (e & 0x38383838u) | ((aw << 3) & 0xC0C0C0C0u);
+                hi = ((aw >> 5) & 0x01010101u) | (mk >> 1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                t[jj * 4 + k] = lds_f64(lut, __builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t qa = (aw >> (16 * k + 3)) & 0x1FFFu;
+                const uint32_t qb = (bw >> (16 * k + 3)) & 0x1FFFu;
+                const uint32_t m = (mk >> (16 * k + 2)) & 1u;
+                t[jj * 2 + k] = lds_f64(lut, (qa * Kp + qb) * 16u + m * 8u);
+            }
+        }
+    }
+}
+
 template <typename SymT>
 struct ChunkData {
     uint32_t a[Tr<SymT>::kWords], b[Tr<SymT>::kWords];
@@ -289,7 +337,7 @@ struct ChunkData {
 // NS independent fp64 accumulators (each summed strictly in position order) so that the
 // dependent v_add_f64 chains of the sub-overlaps overlap, and the next chunk of every stream is
 // loaded while the current one is scored.
-template <typename SymT, int NS, bool PREFETCH>
+template <typename SymT, int NS, bool PREFETCH, int LG>
 __device__ __forceinline__ void score_subs(const SymT* __restrict__ sym, const Sub* s, const char* lut,
                                            const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word,
                                            uint32_t min_read_len, SubScore* out) {
@@ -317,28 +365,33 @@ __device__ __forceinline__ void score_subs(const SymT* __restrict__ sym, const S
         cm[u] = 0;
     }
     if (nmax == 0) return;
-    ChunkData<SymT> nxt[NS];
+    // Loads are predicated, never clamped: a lane that has finished its sub-overlap issues no more
+    // memory requests while the longest lane of the wave is still running (the vector-memory front
+    // end is this kernel's bottleneck; its cost is per lane request).
+    ChunkData<SymT> nxt[NS] = {};
     if (PREFETCH) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
-            __builtin_memcpy(nxt[u].a, a[u], sizeof(nxt[u].a));  // unaligned (pos is arbitrary)
-            __builtin_memcpy(nxt[u].b, b[u], sizeof(nxt[u].b));
+            if (nch[u]) {
+                __builtin_memcpy(nxt[u].a, a[u], sizeof(nxt[u].a));  // unaligned (pos is arbitrary)
+                __builtin_memcpy(nxt[u].b, b[u], sizeof(nxt[u].b));
+            }
         }
     }
     for (uint32_t c = 0; c < nmax; ++c) {
-        ChunkData<SymT> cur[NS];
+        ChunkData<SymT> cur[NS] = {};
         uint32_t keep[NS][T::kWords];
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             if (PREFETCH) {
                 cur[u] = nxt[u];
-                const uint32_t cn = c + 1u < nch[u] ? c + 1u : (nch[u] ? nch[u] - 1u : 0u);  // clamped in-bounds
-                __builtin_memcpy(nxt[u].a, a[u] + 16u * cn, sizeof(nxt[u].a));
-                __builtin_memcpy(nxt[u].b, b[u] + 16u * cn, sizeof(nxt[u].b));
-            } else {
-                const uint32_t cc = c < nch[u] ? c : (nch[u] ? nch[u] - 1u : 0u);
-                __builtin_memcpy(cur[u].a, a[u] + 16u * cc, sizeof(cur[u].a));
-                __builtin_memcpy(cur[u].b, b[u] + 16u * cc, sizeof(cur[u].b));
+                if (c + 1u < nch[u]) {
+                    __builtin_memcpy(nxt[u].a, a[u] + 16u * (c + 1u), sizeof(nxt[u].a));
+                    __builtin_memcpy(nxt[u].b, b[u] + 16u * (c + 1u), sizeof(nxt[u].b));
+                }
+            } else if (c < nch[u]) {
+                __builtin_memcpy(cur[u].a, a[u] + 16u * c, sizeof(cur[u].a));
+                __builtin_memcpy(cur[u].b, b[u] + 16u * c, sizeof(cur[u].b));
             }
             const int rem = (int)L[u] - (int)(16u * c);
             const uint32_t r = rem >= 16 ? 16u : (rem <= 0 ? 0u : (uint32_t)rem);
@@ -348,38 +401,9 @@ __device__ __forceinline__ void score_subs(const SymT* __restrict__ sym, const S
         for (int h = 0; h < 2; ++h) {  // two half-chunks of 8 positions: bounds the registers held by table reads
             double t[NS][8];
 #pragma unroll
-            for (int u = 0; u < NS; ++u) {
-#pragma unroll
-                for (int jj = 0; jj < T::kWords / 2; ++jj) {
-                    const int j = h * (T::kWords / 2) + jj;
-                    // symbols at or beyond L become N: they add 0.0 and count as skipped
-                    const uint32_t aw = (cur[u].a[j] & keep[u][j]) | (nsym_word & ~keep[u][j]);
-                    const uint32_t bw = cur[u].b[j];
-                    const uint32_t x = aw | bw, e = aw ^ bw;
-                    const uint32_t nm = x & (T::kLow1 << 2);  // code bit 2 on either side: N (or invalid)
-                    const uint32_t mk = ((e << 1) | (e << 2)) & (T::kLow1 << 2) & ~x;  // bases differ, neither is N
-                    skipped[u] += __builtin_popcount(nm);
-                    cm[u] += __builtin_popcount(mk);
-                    if (sizeof(SymT) == 1) {
-                        const uint32_t aq = (aw >> 3) & 0x1F1F1F1Fu;   // qa per byte
-                        const uint32_t bm = (bw & T::kQMask) | mk;     // qb*8 + mismatch*4 per byte
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            // v_perm_b32: (qa << 8) | (qb*8 + m*4);  << 1  ->  qa*512 + qb*16 + m*8
-                            const uint32_t p = __builtin_amdgcn_perm(aq, bm, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k);
-                            t[u][jj * 4 + k] = lds_f64(lut, p << 1);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const uint32_t qa = (aw >> (16 * k + 3)) & 0x1FFFu;
-                            const uint32_t qb = (bw >> (16 * k + 3)) & 0x1FFFu;
-                            const uint32_t m = (mk >> (16 * k + 2)) & 1u;
-                            t[u][jj * 2 + k] = lds_f64(lut, (qa * Kp + qb) * 16u + m * 8u);
-                        }
-                    }
-                }
-            }
+            for (int u = 0; u < NS; ++u)
+                half_chunk_terms<SymT, LG>(cur[u].a + h * (T::kWords / 2), cur[u].b + h * (T::kWords / 2),
+                                       keep[u] + h * (T::kWords / 2), nsym_word, lut, Kp, t[u], skipped[u], cm[u]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
 #pragma unroll
@@ -411,9 +435,9 @@ __device__ __forceinline__ void score_subs(const SymT* __restrict__ sym, const S
 __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return x > b.hi ? 1u : (x <= b.lo ? 0u : 2u); }
 
 // VAR bit0: interleave the two sub-overlaps of a candidate; bit1: software prefetch of the next
-// chunk; bit2: cap registers for 8 waves per SIMD.
-template <typename SymT, int VAR>
-__global__ __launch_bounds__(256, (VAR & 4) ? 8 : 1) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+// chunk.  LG: log2 of the 8-bit-symbol table dimension (3, 4 or 5; ignored for 16-bit symbols).
+template <typename SymT, int VAR, int LG>
+__global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                     const hc_overlap_rec* __restrict__ in, uint64_t n,
                                                     hc_result_rec* __restrict__ out,
                                                     const uint32_t* __restrict__ perm) {
@@ -462,15 +486,15 @@ __global__ __launch_bounds__(256, (VAR & 4) ? 8 : 1) void score_kernel(StoreView
             if (VAR & 1) {
                 const Sub subs[2] = {sub0, sub1};
                 SubScore r[2];
-                score_subs<SymT, 2, kPre>(sym, subs, lut, masktab, Kp, nsym_word, prm.min_read_len, r);
+                score_subs<SymT, 2, kPre, LG>(sym, subs, lut, masktab, Kp, nsym_word, prm.min_read_len, r);
                 s1 = r[0];
                 s2 = r[1];
             } else {
-                score_subs<SymT, 1, kPre>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
-                score_subs<SymT, 1, kPre>(sym, &sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, &s2);
+                score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
+                score_subs<SymT, 1, kPre, LG>(sym, &sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, &s2);
             }
         } else {
-            score_subs<SymT, 1, kPre>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
+            score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
         }
 
         // mismatch_rate = float(mismatch_count)/total_len (:132); std::max over the two (:254)
@@ -486,6 +510,210 @@ __global__ __launch_bounds__(256, (VAR & 4) ? 8 : 1) void score_kernel(StoreView
             }
         }
         // :404-413 in x-space; flags bit0 / bit1: threshold < 0, every score (0 included) passes
+        const bool e_all = prm.flags & 1u, o_all = prm.flags & 2u;
+        uint32_t e = e_all ? 1u : band_test(s1.x, prm.edge);
+        uint32_t o = o_all ? 1u : band_test(s1.x, prm.ov);
+        if (ns == 2) {
+            const uint32_t e2 = e_all ? 1u : band_test(s2.x, prm.edge), o2 = o_all ? 1u : band_test(s2.x, prm.ov);
+            e = (e == 0 || e2 == 0) ? 0u : ((e == 1 && e2 == 1) ? 1u : 2u);
+            o = (o == 0 || o2 == 0) ? 0u : ((o == 1 && o2 == 1) ? 1u : 2u);
+        }
+        uint32_t cls;
+        if (s1.err | s2.err) cls = HC_CLS_ERROR;
+        else if (e == 1) cls = HC_CLS_EDGE;
+        else if (e == 2) cls = HC_CLS_AMBIG;
+        else if (mrate <= prm.merge_contigs) cls = HC_CLS_EDGE_MC;
+        else if (o == 1) cls = HC_CLS_NONEDGE;
+        else if (o == 2) cls = HC_CLS_AMBIG;
+        else cls = HC_CLS_DROP;
+        res.x1 = s1.x;
+        res.x2 = s2.x;
+        res.mm = mm;
+        res.n_cls = (nn & 0x0FFFFFFFu) | (cls << 28);
+        out[i] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row-staged variant.  The per-lane gather of the kernel above makes every load instruction touch
+// up to 64 different cache lines, and the vector-memory front end (TA) is what saturates first
+// (profiles/traffic_c2.json: TA busy 87 %).  Here a wave first copies the windows of its 64
+// candidates into wave-private LDS with ROW-COALESCED loads — 6 consecutive lanes fetch the 6
+// 16-byte pieces of one 96-byte row, so an instruction touches ~20 lines instead of ~64+ and every
+// fetched line is used at once — and then every lane scores its own two rows out of LDS
+// (row stride 112 B: conflict-free for ds_read_b128).  Same arithmetic, same order, same results.
+constexpr int kStageRowBytes = 112;   // 96 data bytes + 16: 28-word stride, conflict-free b128 reads
+constexpr int kStagePieces = 6;       // 16-byte pieces per row and round
+constexpr int kStageDescBytes = 32;   // per-lane {offA, offB, L}
+constexpr int kStageWaveBytes = 2 * 64 * kStageRowBytes + 64 * kStageDescBytes;
+typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
+
+template <typename SymT, int LG>
+__global__ __launch_bounds__(256) void score_kernel_staged(StoreView st, ScoreParams prm,
+                                                           const double* __restrict__ lut_g,
+                                                           const hc_overlap_rec* __restrict__ in, uint64_t n,
+                                                           hc_result_rec* __restrict__ out,
+                                                           const uint32_t* __restrict__ perm) {
+    using T = Tr<SymT>;
+    constexpr int SB = (int)sizeof(SymT);
+    constexpr uint32_t RSYM = 96 / SB;    // symbols per row and round
+    constexpr int CH = (int)RSYM / 16;    // 16-symbol chunks per round
+    constexpr uint32_t PSYM = 16 / SB;    // symbols per 16-byte piece
+    extern __shared__ __attribute__((aligned(16))) double lut_s[];
+    const uint32_t lut_n = st.lut_bytes >> 3;
+    for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
+    uint32_t* masktab = (uint32_t*)(lut_s + lut_n);
+    fill_mask_table<SymT>(masktab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const char* lut = (const char*)lut_s;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    char* stage = (char*)(masktab + 17 * T::kWords);
+    stage += (16 - ((uintptr_t)stage & 15)) & 15;
+    char* rowsA = stage + wib * kStageWaveBytes;
+    char* rowsB = rowsA + 64 * kStageRowBytes;
+    char* desc = rowsB + 64 * kStageRowBytes;
+
+    const SymT* sym = (const SymT*)st.sym;
+    const uint32_t Kp = st.K + 2u;
+    const uint32_t nsym = (st.K << 3) | kCodeN;
+    const uint32_t nsym_word = SB == 1 ? nsym * 0x01010101u : nsym * 0x00010001u;
+    const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6) * 64u;
+    for (uint64_t base = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wib) * 64u; base < n; base += wave_stride) {
+        const uint64_t slot = base + lane;
+        const bool active = slot < n;
+        uint64_t i = 0;
+        hc_overlap_rec rec;
+        Sub sub0, sub1;
+        int ns = 0;
+        if (active) {
+            i = perm ? (uint64_t)perm[slot] : slot;
+            const uint4* p = (const uint4*)(in + i);
+            const uint4 a = p[0], b = p[1];
+            __builtin_memcpy(&rec, &a, 16);
+            __builtin_memcpy((char*)&rec + 16, &b, 16);
+            ns = resolve<SB>(st, rec, sub0, sub1);
+        }
+        // one sub-overlap of every lane's candidate: wave-cooperative staging, lane-private scoring
+        auto run_sub = [&](const Sub& sb, bool have, SubScore& r) {
+            uint32_t L = 0;
+            uint64_t offA = 0, offB = 0;
+            if (have) {
+                r.x = -__builtin_inf();
+                r.mm = 1;
+                r.n = 1;
+                r.err = sb.fatal;
+                L = sub_positions(sb, prm.min_read_len);
+                offA = sb.offA + sb.pos;
+                offB = sb.offB;
+            }
+            // publish this lane's row descriptor to the wave
+            *(uint2*)(desc + lane * kStageDescBytes) = make_uint2((uint32_t)offA, (uint32_t)(offA >> 32));
+            *(uint2*)(desc + lane * kStageDescBytes + 8) = make_uint2((uint32_t)offB, (uint32_t)(offB >> 32));
+            *(uint32_t*)(desc + lane * kStageDescBytes + 16) = L;
+            uint32_t Lmax = L;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)Lmax, o, 64);
+                Lmax = other > Lmax ? other : Lmax;
+            }
+            Lmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Lmax);
+            __builtin_amdgcn_wave_barrier();
+            double S = 0.0;
+            uint32_t skipped = 0, cm = 0;
+            for (uint32_t rb = 0; rb < Lmax; rb += RSYM) {
+                // ---- stage: row-coalesced global loads -> wave-private LDS rows
+#pragma unroll
+                for (int k = 0; k < kStagePieces; ++k) {
+                    const uint32_t f = (uint32_t)k * 64u + lane;
+                    const uint32_t row = f / kStagePieces, piece = f - row * kStagePieces;
+                    const uint4 d0 = *(const uint4*)(desc + row * kStageDescBytes);
+                    const uint32_t rowL = *(const uint32_t*)(desc + row * kStageDescBytes + 16);
+                    const uint32_t so = rb + piece * PSYM;
+                    if (so < rowL) {
+                        const uint64_t oa = (((uint64_t)d0.y << 32) | d0.x) + so;
+                        const uint64_t ob = (((uint64_t)d0.w << 32) | d0.z) + so;
+                        // unaligned: the A window starts at an arbitrary symbol
+                        const uint4 va = *(const uint4_unaligned*)(sym + oa);
+                        const uint4 vb = *(const uint4_unaligned*)(sym + ob);
+                        const uint32_t dst = row * kStageRowBytes + piece * 16u;
+                        *(uint4*)(rowsA + dst) = va;
+                        *(uint4*)(rowsB + dst) = vb;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // ---- score: every lane walks its own two rows
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const uint32_t p0 = rb + 16u * (uint32_t)c;
+                    if (p0 < L) {
+                        uint32_t wa[T::kWords], wb[T::kWords], keep[T::kWords];
+                        __builtin_memcpy(wa, rowsA + lane * kStageRowBytes + c * 16 * SB, sizeof(wa));
+                        __builtin_memcpy(wb, rowsB + lane * kStageRowBytes + c * 16 * SB, sizeof(wb));
+                        const uint32_t rem = L - p0;
+                        __builtin_memcpy(keep, masktab + (rem >= 16u ? 16u : rem) * T::kWords, sizeof(keep));
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            double t[8];
+                            half_chunk_terms<SymT, LG>(wa + h * (T::kWords / 2), wb + h * (T::kWords / 2), keep + h * (T::kWords / 2),
+                                                   nsym_word, lut, Kp, t, skipped, cm);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) S += t[k];  // :119, strictly in position order
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (L == 0) return;
+            if (S != S) {  // an invalid symbol inside the window
+                const SubScore e = score_sub_slow<SymT>(sym + offA, sym + offB, L, lut, Kp);
+                r.x = e.x;
+                r.mm = e.mm;
+                r.n = e.n;
+                r.err |= e.err;
+                return;
+            }
+            if (S == __builtin_inf()) return;
+            const uint32_t cn = 16u * ((L + 15u) >> 4) - skipped;
+            if (cn == 0) return;
+            r.x = (1.0 / (double)cn) * S;
+            r.mm = cm;
+            r.n = cn;
+        };
+        SubScore s1, s2;
+        s1.x = -__builtin_inf();
+        s1.mm = 1;
+        s1.n = 1;
+        s1.err = 0;
+        s2.x = __builtin_nan("");
+        s2.mm = 0;
+        s2.n = 1;
+        s2.err = 0;
+        run_sub(sub0, active && ns >= 1, s1);
+        const unsigned long long any2 = __ballot(active && ns == 2);
+        if (any2) run_sub(sub1, active && ns == 2, s2);
+        if (!active) continue;
+        hc_result_rec res;
+        if (ns == 0) {
+            res.x1 = -__builtin_inf();
+            res.x2 = __builtin_nan("");
+            res.mm = 1;
+            res.n_cls = 1u | (HC_CLS_ERROR << 28);
+            out[i] = res;
+            continue;
+        }
+        const double m1 = (double)(float)s1.mm / (double)s1.n;
+        uint32_t mm = s1.mm, nn = s1.n;
+        double mrate = m1;
+        if (ns == 2) {
+            const double m2 = (double)(float)s2.mm / (double)s2.n;
+            if (m1 < m2) {
+                mrate = m2;
+                mm = s2.mm;
+                nn = s2.n;
+            }
+        }
         const bool e_all = prm.flags & 1u, o_all = prm.flags & 2u;
         uint32_t e = e_all ? 1u : band_test(s1.x, prm.edge);
         uint32_t o = o_all ? 1u : band_test(s1.x, prm.ov);
@@ -625,27 +853,31 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
     return hipGetLastError();
 }
 
-template <typename SymT, int VAR>
-static void launch_score_var(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
+template <typename SymT, int VAR, int LG>
+static void launch_score_one(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
                              uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t blocks, size_t lds,
                              hipStream_t stream) {
-    hipLaunchKernelGGL((score_kernel<SymT, VAR>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out, perm);
+    hipLaunchKernelGGL((score_kernel<SymT, VAR, LG>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out, perm);
 }
 
-template <typename SymT>
-static hipError_t launch_score_t(int var, const StoreView& st, const ScoreParams& prm, const double* lut_g,
-                                 const hc_overlap_rec* in, uint64_t n, hc_result_rec* out, const uint32_t* perm,
-                                 uint32_t blocks, size_t lds, hipStream_t stream) {
-    switch (var & 7) {
-        case 0: launch_score_var<SymT, 0>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
-        case 1: launch_score_var<SymT, 1>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
-        case 2: launch_score_var<SymT, 2>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
-        case 3: launch_score_var<SymT, 3>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
-        case 4: launch_score_var<SymT, 4>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
-        case 5: launch_score_var<SymT, 5>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
-        case 6: launch_score_var<SymT, 6>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
-        default: launch_score_var<SymT, 7>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+template <typename SymT, int LG>
+static hipError_t launch_score_lg(int var, const StoreView& st, const ScoreParams& prm, const double* lut_g,
+                                  const hc_overlap_rec* in, uint64_t n, hc_result_rec* out, const uint32_t* perm,
+                                  uint32_t blocks, size_t lds, hipStream_t stream) {
+    switch (var & 3) {
+        case 0: launch_score_one<SymT, 0, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        case 1: launch_score_one<SymT, 1, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        case 2: launch_score_one<SymT, 2, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
+        default: launch_score_one<SymT, 3, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
     }
+    return hipGetLastError();
+}
+
+template <typename SymT, int LG>
+static hipError_t launch_staged_lg(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
+                                   uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t blocks, size_t lds,
+                                   hipStream_t stream) {
+    hipLaunchKernelGGL((score_kernel_staged<SymT, LG>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out, perm);
     return hipGetLastError();
 }
 
@@ -655,6 +887,20 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     if (n == 0) return hipSuccess;
     const size_t lds = st.lut_bytes + 17 * (st.symbytes == 1 ? 4 : 8) * sizeof(uint32_t);
     const uint32_t block = 256;
+    const uint32_t lg = lut_lg(st.K);
+    const size_t lds_staged = lds + 16 + 4 * kStageWaveBytes;
+    if ((variant & 8) && lds_staged <= 160 * 1024) {  // experimental row-staged variant
+        uint32_t bpc = (uint32_t)((160 * 1024) / lds_staged);
+        if (bpc > 8) bpc = 8;
+        uint64_t blocks = (n + block - 1) / block;
+        const uint64_t cap = (uint64_t)n_cu * bpc * 2;
+        if (blocks > cap) blocks = cap;
+        const uint32_t nb = (uint32_t)blocks;
+        if (st.symbytes == 2) return launch_staged_lg<uint16_t, 5>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
+        if (lg == 3) return launch_staged_lg<uint8_t, 3>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
+        if (lg == 4) return launch_staged_lg<uint8_t, 4>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
+        return launch_staged_lg<uint8_t, 5>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
+    }
     // Fill the chip: enough 256-thread blocks for 8 waves per SIMD, bounded by LDS.
     uint32_t blocks_per_cu = 8;
     if (lds > 0) {
@@ -664,9 +910,11 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     uint64_t blocks = (n + block - 1) / block;
     const uint64_t cap = (uint64_t)n_cu * blocks_per_cu * 4;  // grid-stride beyond this
     if (blocks > cap) blocks = cap;
-    if (st.symbytes == 1)
-        return launch_score_t<uint8_t>(variant, st, prm, lut_g, in, n, out, perm, (uint32_t)blocks, lds, stream);
-    return launch_score_t<uint16_t>(variant, st, prm, lut_g, in, n, out, perm, (uint32_t)blocks, lds, stream);
+    const uint32_t nb = (uint32_t)blocks;
+    if (st.symbytes == 2) return launch_score_lg<uint16_t, 5>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
+    if (lg == 3) return launch_score_lg<uint8_t, 3>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
+    if (lg == 4) return launch_score_lg<uint8_t, 4>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
+    return launch_score_lg<uint8_t, 5>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
 }
 
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,
@@ -679,27 +927,22 @@ hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, co
     return hipGetLastError();
 }
 
-template <typename SymT, int VAR>
-static hipError_t set_lds_limit_one() {
-    return hipFuncSetAttribute((const void*)score_kernel<SymT, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-template <int VAR>
-static hipError_t set_lds_limit_var() {
-    hipError_t e = set_lds_limit_one<uint8_t, VAR>();
-    if (e != hipSuccess) return e;
-    return set_lds_limit_one<uint16_t, VAR>();
+template <typename SymT, int LG>
+static hipError_t set_lds_limit_lg() {
+    const int kMax = 160 * 1024;  // allow the full 160 KiB of LDS for large quality alphabets
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 0, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 1, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 2, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 3, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)score_kernel_staged<SymT, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
 }
 hipError_t set_score_kernel_lds_limit() {
-    // allow the full 160 KiB of LDS for large quality alphabets
     hipError_t e;
-    if ((e = set_lds_limit_var<0>()) != hipSuccess) return e;
-    if ((e = set_lds_limit_var<1>()) != hipSuccess) return e;
-    if ((e = set_lds_limit_var<2>()) != hipSuccess) return e;
-    if ((e = set_lds_limit_var<3>()) != hipSuccess) return e;
-    if ((e = set_lds_limit_var<4>()) != hipSuccess) return e;
-    if ((e = set_lds_limit_var<5>()) != hipSuccess) return e;
-    if ((e = set_lds_limit_var<6>()) != hipSuccess) return e;
-    return set_lds_limit_var<7>();
+    if ((e = set_lds_limit_lg<uint8_t, 3>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_lg<uint8_t, 4>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_lg<uint8_t, 5>()) != hipSuccess) return e;
+    return set_lds_limit_lg<uint16_t, 5>();
 }
 
 }  // namespace hc
