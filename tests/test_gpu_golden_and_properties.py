@@ -121,3 +121,37 @@ def test_strand_twin_property_singles(oracle):
     fin = np.isfinite(ra["x1"])
     assert np.array_equal(fin, np.isfinite(rb["x1"]))
     np.testing.assert_allclose(ra["x1"][fin], rb["x1"][fin], rtol=1e-11, atol=0)
+
+
+def test_rccl_gather_path_single_rank():
+    """The all-gather-v of admitted records over the nccl (= RCCL) backend, world size 1: the same code
+    bench.py --gpus N runs, on device tensors produced by the scoring kernel."""
+    import torch
+    import torch.distributed as dist
+
+    from haploconduct_amd import parallel
+
+    reads, meta = synth.make_paired_dataset(2000, 3000, seed=5)
+    reads.quals[:] = ord("I")
+    cand = synth.paired_candidates(meta, n_candidates=30000, seed=6)
+    st = hc.Settings(edge_threshold=0.97)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29621", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        with hc.EdgeScorer(st) as sc:
+            sc.set_reads(reads)
+            d_in = torch.from_numpy(cand.view(np.uint8).reshape(-1)).cuda()
+            d_out = torch.empty(cand.size * 24, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            sc.score_batch_device(d_in.data_ptr(), cand.size, d_out.data_ptr())
+            sc.synchronize()
+            rows, counts = parallel.gather_admitted(d_out, 0)
+            host = d_out.cpu().numpy().view(hc.RESULT_DTYPE)
+        cls = result_cls(host)
+        want = np.nonzero((cls >= 2) & (cls <= 4))[0]
+        assert counts == [want.size] and want.size > 100
+        rows = rows.cpu().numpy()
+        assert np.array_equal(rows[:, 0], want)
+        assert np.array_equal(rows[:, 1].view(np.uint64), host["x1"][want].view(np.uint64))
+    finally:
+        dist.destroy_process_group()
