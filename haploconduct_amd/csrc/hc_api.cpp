@@ -233,8 +233,8 @@ static void build_lut(const std::vector<int>& phred, double mismatch_setting, ui
                 lut[hc::lut_addr_u8(lg, (uint32_t)a, (uint32_t)b, 0) / 8] = vm;
                 lut[hc::lut_addr_u8(lg, (uint32_t)a, (uint32_t)b, 1) / 8] = vx;
             } else {
-                lut[(a * Kp + b) * 2 + 0] = vm;
-                lut[(a * Kp + b) * 2 + 1] = vx;
+                lut[hc::lut_addr_u16((uint32_t)Kp, (uint32_t)a, (uint32_t)b, 0) / 8] = vm;
+                lut[hc::lut_addr_u16((uint32_t)Kp, (uint32_t)a, (uint32_t)b, 1) / 8] = vx;
             }
         }
     }

@@ -64,8 +64,12 @@ struct StoreView {
 //                   pre-masked symbol bytes (no shift, no multiply); the XOR of the column with the row
 //                   spreads the few hot (qa, qb) pairs over the LDS banks (rows of a power-of-two table
 //                   would otherwise alias bank for bank).
-//   uint16 symbols: byte address = (qa*Kp + qb)*16 + mismatch*8
+//   uint16 symbols: two dense planes of Kp x Kp entries: byte address = (m*Kp*Kp + qa*Kp + qb) * 8
+//                   (entry index < 2*97*97 fits 16 bits: two positions per packed-16-bit VALU op)
 __host__ __device__ inline uint32_t lut_lg(uint32_t K) { return K + 2 <= 8 ? 3u : (K + 2 <= 16 ? 4u : 5u); }
+__host__ __device__ inline uint32_t lut_addr_u16(uint32_t Kp, uint32_t qa, uint32_t qb, uint32_t m) {
+    return (m * Kp * Kp + qa * Kp + qb) * 8u;
+}
 __host__ __device__ inline uint32_t lut_addr_u8(uint32_t lg, uint32_t qa, uint32_t qb, uint32_t m) {
     return m * (8u << (2 * lg)) + qa * (8u << lg) + ((qb ^ qa) & ((1u << lg) - 1u)) * 8u;
 }

@@ -254,7 +254,7 @@ __device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, cons
         if ((ca | cb) & 4u) continue;  // N: :35-39, :122-124
         const uint32_t m = ca != cb;
         const uint32_t qa = sa >> 3, qb = sb >> 3;
-        const uint32_t addr = sizeof(SymT) == 1 ? lut_addr_u8(lg, qa, qb, m) : (qa * Kp + qb) * 16u + m * 8u;
+        const uint32_t addr = sizeof(SymT) == 1 ? lut_addr_u8(lg, qa, qb, m) : lut_addr_u16(Kp, qa, qb, m);
         const double t = lds_f64(lut, addr);
         if (t == __builtin_inf()) return r;  // :125-127
         S += t;
@@ -317,13 +317,16 @@ __device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint3
             for (int k = 0; k < 4; ++k)
                 t[jj * 4 + k] = lds_f64(lut, __builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
         } else {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const uint32_t qa = (aw >> (16 * k + 3)) & 0x1FFFu;
-                const uint32_t qb = (bw >> (16 * k + 3)) & 0x1FFFu;
-                const uint32_t m = (mk >> (16 * k + 2)) & 1u;
-                t[jj * 2 + k] = lds_f64(lut, (qa * Kp + qb) * 16u + m * 8u);
-            }
+            // two positions per packed 16-bit op: entry = m*Kp*Kp + qa*Kp + qb (< 2*97*97, fits 16 bits)
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const u16x2 qa2 = __builtin_bit_cast(u16x2, aw) >> (unsigned short)3;  // the code bits fall off each lane
+            const u16x2 qb2 = __builtin_bit_cast(u16x2, bw) >> (unsigned short)3;
+            const u16x2 m2 = __builtin_bit_cast(u16x2, mk >> 2);                    // 0 / 1 per lane
+            const u16x2 kp2 = {(unsigned short)Kp, (unsigned short)Kp};
+            const u16x2 pl2 = {(unsigned short)(Kp * Kp), (unsigned short)(Kp * Kp)};
+            const uint32_t e2 = __builtin_bit_cast(uint32_t, (u16x2)(m2 * pl2 + (qa2 * kp2 + qb2)));
+            t[jj * 2 + 0] = lds_f64(lut, (e2 << 3) & 0x7FFF8u);
+            t[jj * 2 + 1] = lds_f64(lut, (e2 >> 13) & 0x7FFF8u);
         }
     }
 }
