@@ -64,13 +64,14 @@ def build_workload(workload, rank):
         # edge_threshold 1 / merge_contigs 0 (polyte.py:617-626), 35 distinct quality values as in polyte/example
         glen, cov = 400000, 40
         n_reads = glen * cov // 250
-        quals = (np.arange(1, 36) + 33).astype(np.uint8)
+        nq = int(os.environ.get("HC_C4_K", "35"))  # distinct quality values (35 as in polyte/example)
+        quals = (np.arange(1, nq + 1) + 33).astype(np.uint8)
         reads, meta = synth.make_single_dataset(n_reads, glen, len_lo=250, len_hi=250, n_strains=2, divergence=0.001,
                                                 flip_frac=0.5, seed=4, quals=quals)
         cand = synth.single_candidates(meta, min_overlap=127)
         st = dict(edge_threshold=1.0, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=127)
         desc = f"c4: {n_reads} synthetic 250 bp reads as singles (diploid, 20x per haplotype), {cand.size} s-s candidates"
-        cfg = {"reads": n_reads, "genome_len": glen, "quality_alphabet": 35}
+        cfg = {"reads": n_reads, "genome_len": glen, "quality_alphabet": nq}
     elif workload == "c5":
         # mixed-length contig + read re-overlap (SAVAGE stage b/c): log-uniform 150..6000 bp singles
         n_reads, glen = 60000, 300000

@@ -213,13 +213,20 @@ static void build_lut(const std::vector<int>& phred, double mismatch_setting, ui
     const double inf = std::numeric_limits<double>::infinity();
     const double nan = std::numeric_limits<double>::quiet_NaN();
     const uint32_t lg = hc::lut_lg((uint32_t)K);
-    lut.assign(symbytes == 1 ? (size_t)2 << (2 * lg) : Kp * Kp * 2, 0.0);
-    for (size_t a = 0; a < Kp; a++) {
-        for (size_t b = 0; b < Kp; b++) {
+    const bool wide = symbytes == 1 && lg == 6;
+    const size_t dim = symbytes == 1 ? ((size_t)1 << lg) : Kp;  // rows / columns that can be addressed
+    lut.assign(symbytes == 1 ? (size_t)2 << (2 * lg) : Kp * Kp * 2, nan);
+    for (size_t a = 0; a < dim; a++) {
+        for (size_t b = 0; b < dim; b++) {
+            // which index means N / invalid depends on the encoding (hc_device.h)
+            const bool bad = wide ? (a >= hc::kWideBadQual || b >= hc::kWideBadQual || (a >= K && a != hc::kWideN) ||
+                                     (b >= K && b != hc::kWideN))
+                                  : (a >= K + 1 || b >= K + 1);
+            const bool isn = wide ? (a == hc::kWideN || b == hc::kWideN) : (a == K || b == K);
             double vm, vx;
-            if (a == K + 1 || b == K + 1) {
+            if (bad) {
                 vm = vx = nan;
-            } else if (a == K || b == K) {
+            } else if (isn) {
                 vm = vx = 0.0;
             } else {
                 const double p1 = pow(10, -phred[a] / 10.0);  // phred_to_prob, :59-63
@@ -274,7 +281,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         }
     if (phred.empty()) phred.push_back(0);
     const uint32_t K = (uint32_t)phred.size();
-    const uint32_t symbytes = (K + 2 <= 32) ? 1 : 2;
+    const uint32_t symbytes = hc::sym_bytes_for(K);
 
     std::vector<uint64_t> sym_off(n_seq ? n_seq : 1);
     uint64_t nsym = 0;

@@ -14,7 +14,10 @@
 //          invalid symbol gets qidx = K+1 (the NaN row: poisons the sum, the lane then
 //          re-scans the overlap position by position to report exactly what the reference
 //          would do).  Table dimension Kp = K + 2.
-//   Kp <= 32 -> uint8 symbols (5-bit qidx), else uint16 symbols.
+//   K <= 30 -> uint8 symbols as above (5-bit qidx, 3-bit code);
+//   31 <= K <= 48 -> "wide" uint8 symbols  sym = (qidx << 2) | base2  (6-bit qidx, A,C,G,T = 0..3) with the
+//          reserved indices 48 = N, 49 = invalid quality, 50 = invalid base (recognisable by the two top bits);
+//   K > 48 -> uint16 symbols  (qidx << 3) | code.
 //   Slots are padded with N symbols to a multiple of 16 bytes plus 32 bytes, so chunked
 //   (16-symbol) loads may over-read safely.
 #pragma once
@@ -66,7 +69,10 @@ struct StoreView {
 //                   would otherwise alias bank for bank).
 //   uint16 symbols: two dense planes of Kp x Kp entries: byte address = (m*Kp*Kp + qa*Kp + qb) * 8
 //                   (entry index < 2*97*97 fits 16 bits: two positions per packed-16-bit VALU op)
-__host__ __device__ inline uint32_t lut_lg(uint32_t K) { return K + 2 <= 8 ? 3u : (K + 2 <= 16 ? 4u : 5u); }
+constexpr uint32_t kWideN = 48, kWideBadQual = 49, kWideBadBase = 50;  // reserved qidx of the wide 8-bit encoding
+// LG: log2 of the 8-bit-symbol table dimension; 6 selects the wide encoding.
+__host__ __device__ inline uint32_t lut_lg(uint32_t K) { return K + 2 <= 8 ? 3u : (K + 2 <= 16 ? 4u : (K + 2 <= 32 ? 5u : 6u)); }
+__host__ __device__ inline uint32_t sym_bytes_for(uint32_t K) { return K <= kWideN ? 1u : 2u; }
 __host__ __device__ inline uint32_t lut_addr_u16(uint32_t Kp, uint32_t qa, uint32_t qb, uint32_t m) {
     return (m * Kp * Kp + qa * Kp + qb) * 8u;
 }

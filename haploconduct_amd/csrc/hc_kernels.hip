@@ -24,6 +24,7 @@
 // ds_read_b64 back to back, and only then runs the 16 dependent v_add_f64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <hipcub/hipcub.hpp>
 
@@ -35,7 +36,7 @@ namespace hc {
 // ---------------------------------------------------------------------------
 // Store encoding: raw ASCII bases + quality bytes -> symbol slots (both orientations).
 // One wave per sequence; lanes stride over positions (coalesced reads and writes).
-template <typename SymT>
+template <typename SymT, bool WIDE>
 __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __restrict__ bases,
                                                            const uint8_t* __restrict__ quals,
                                                            const uint64_t* __restrict__ raw_off,  // [n_seq+1]
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    const SymT nsym = (SymT)((K << 3) | kCodeN);
+    const SymT nsym = WIDE ? (SymT)(kWideN << 2) : (SymT)((K << 3) | kCodeN);
     for (uint32_t q = wave; q < n_seq; q += n_waves) {
         const uint64_t r0 = raw_off[q];
         const uint32_t len = (uint32_t)(raw_off[q + 1] - r0);
@@ -67,15 +68,26 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                     default: code = kCodeBadBase; bad = 1; break;
                 }
                 uint32_t qx = qi;
-                if (code == kCodeN) qx = K;            // zero row of the log table
-                if (code == kCodeBadBase) qx = K + 1;  // NaN row
-                if (qi == 255) {                       // quality outside [33,127]: always fatal inside an overlap
-                    code = kCodeBadQual;
-                    qx = K + 1;
+                if (WIDE) {
+                    // sym = qidx << 2 | base2; N / invalid are reserved quality indices with base bits 0
+                    uint32_t b2 = code < 4 ? code : 0u;
+                    if (code == kCodeN) qx = kWideN;
+                    if (code == kCodeBadBase) qx = kWideBadBase;
+                    if (qi == 255) { qx = kWideBadQual; b2 = 0; }  // quality outside [33,127]: always fatal inside an overlap
+                    const uint32_t rb2 = qx < kWideN ? 3u - b2 : 0u;
+                    sym[f0 + i] = (SymT)((qx << 2) | b2);
+                    sym[f0 + stride + (len - 1 - i)] = (SymT)((qx << 2) | rb2);
+                } else {
+                    if (code == kCodeN) qx = K;            // zero row of the log table
+                    if (code == kCodeBadBase) qx = K + 1;  // NaN row
+                    if (qi == 255) {                       // quality outside [33,127]: always fatal inside an overlap
+                        code = kCodeBadQual;
+                        qx = K + 1;
+                    }
+                    const uint32_t rcode = code < 4 ? 3 - code : code;
+                    sym[f0 + i] = (SymT)((qx << 3) | code);
+                    sym[f0 + stride + (len - 1 - i)] = (SymT)((qx << 3) | rcode);
                 }
-                const uint32_t rcode = code < 4 ? 3 - code : code;
-                sym[f0 + i] = (SymT)((qx << 3) | code);
-                sym[f0 + stride + (len - 1 - i)] = (SymT)((qx << 3) | rcode);
             } else {
                 sym[f0 + i] = nsym;
                 sym[f0 + stride + i] = nsym;
@@ -237,8 +249,18 @@ __device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, cons
     r.mm = 1;
     r.n = 1;
     r.err = 0;
+    const bool wide = sizeof(SymT) == 1 && lg == 6;
+    // kind of a symbol: 0 = base, 1 = N, 2 = invalid quality, 3 = invalid base
+    auto kind = [&](uint32_t sy) -> uint32_t {
+        if (wide) {
+            const uint32_t q = sy >> 2;
+            return q == kWideN ? 1u : (q == kWideBadQual ? 2u : (q == kWideBadBase ? 3u : 0u));
+        }
+        const uint32_t c = sy & 7u;
+        return c == kCodeN ? 1u : (c == kCodeBadQual ? 2u : (c == kCodeBadBase ? 3u : 0u));
+    };
     for (uint32_t i = 0; i < L; ++i)
-        if ((a[i] & 7u) == kCodeBadQual || (b[i] & 7u) == kCodeBadQual) {
+        if (kind(a[i]) == 2u || kind(b[i]) == 2u) {
             r.err = 1;
             return r;
         }
@@ -246,14 +268,14 @@ __device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, cons
     uint32_t cn = 0, cm = 0;
     for (uint32_t i = 0; i < L; ++i) {
         const uint32_t sa = a[i], sb = b[i];
-        const uint32_t ca = sa & 7u, cb = sb & 7u;
-        if (ca == kCodeBadBase || cb == kCodeBadBase) {  // :29-30 assert
+        const uint32_t ka = kind(sa), kb = kind(sb);
+        if (ka == 3u || kb == 3u) {  // :29-30 assert
             r.err = 1;
             return r;
         }
-        if ((ca | cb) & 4u) continue;  // N: :35-39, :122-124
-        const uint32_t m = ca != cb;
-        const uint32_t qa = sa >> 3, qb = sb >> 3;
+        if (ka == 1u || kb == 1u) continue;  // N: :35-39, :122-124
+        const uint32_t m = wide ? ((sa & 3u) != (sb & 3u)) : ((sa & 7u) != (sb & 7u));
+        const uint32_t qa = wide ? sa >> 2 : sa >> 3, qb = wide ? sb >> 2 : sb >> 3;
         const uint32_t addr = sizeof(SymT) == 1 ? lut_addr_u8(lg, qa, qb, m) : lut_addr_u16(Kp, qa, qb, m);
         const double t = lds_f64(lut, addr);
         if (t == __builtin_inf()) return r;  // :125-127
@@ -293,7 +315,22 @@ __device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint3
         // symbols at or beyond L become N: they add 0.0 and count as skipped
         const uint32_t aw = (wa[jj] & keep[jj]) | (nsym_word & ~keep[jj]);
         const uint32_t bw = wb[jj];
-        const uint32_t x = aw | bw, e = aw ^ bw;
+        const uint32_t e = aw ^ bw;
+        if (sizeof(SymT) == 1 && LG == 6) {
+            // wide 8-bit encoding: byte = qidx << 2 | base2; qidx >= 48 (both top bits set) is N / invalid.
+            // address = m << 15 | qa << 9 | ((qb ^ qa) & 63) << 3
+            const uint32_t nm = ((aw & (aw << 1)) | (bw & (bw << 1))) & 0x80808080u;
+            const uint32_t mk = ((e << 7) | (e << 6)) & 0x80808080u & ~nm;  // base bits differ, neither is N
+            skipped += __builtin_popcount(nm);
+            cm += __builtin_popcount(mk);
+            const uint32_t lo = (e << 1) & 0xF8F8F8F8u;
+            const uint32_t hi = ((e >> 7) & 0x01010101u) | ((aw >> 1) & 0x7E7E7E7Eu) | mk;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                t[jj * 4 + k] = lds_f64(lut, __builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
+            continue;
+        }
+        const uint32_t x = aw | bw;
         const uint32_t nm = x & (T::kLow1 << 2);                             // code bit 2 on either side: N (or invalid)
         const uint32_t mk = ((e << 1) | (e << 2)) & (T::kLow1 << 2) & ~x;  // bases differ, neither is N
         skipped += __builtin_popcount(nm);
@@ -454,7 +491,7 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
 
     const SymT* sym = (const SymT*)st.sym;
     const uint32_t Kp = st.K + 2u;
-    const uint32_t nsym = (st.K << 3) | kCodeN;
+    const uint32_t nsym = (sizeof(SymT) == 1 && LG == 6) ? (kWideN << 2) : ((st.K << 3) | kCodeN);
     const uint32_t nsym_word = sizeof(SymT) == 1 ? nsym * 0x01010101u : nsym * 0x00010001u;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += stride) {
@@ -578,7 +615,7 @@ __global__ __launch_bounds__(256) void score_kernel_staged(StoreView st, ScorePa
 
     const SymT* sym = (const SymT*)st.sym;
     const uint32_t Kp = st.K + 2u;
-    const uint32_t nsym = (st.K << 3) | kCodeN;
+    const uint32_t nsym = (SB == 1 && LG == 6) ? (kWideN << 2) : ((st.K << 3) | kCodeN);
     const uint32_t nsym_word = SB == 1 ? nsym * 0x01010101u : nsym * 0x00010001u;
     const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6) * 64u;
     for (uint64_t base = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wib) * 64u; base < n; base += wave_stride) {
@@ -842,11 +879,14 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
     const uint32_t waves_per_block = 4;
     uint32_t blocks = (n_seq + waves_per_block - 1) / waves_per_block;
     if (blocks > 65536) blocks = 65536;
-    if (symbytes == 1)
-        hipLaunchKernelGGL(encode_store_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off, seq_off,
-                           qmap, n_seq, K, (uint8_t*)sym, seq_bad);
+    if (symbytes == 1 && lut_lg(K) == 6)
+        hipLaunchKernelGGL((encode_store_kernel<uint8_t, true>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
+                           seq_off, qmap, n_seq, K, (uint8_t*)sym, seq_bad);
+    else if (symbytes == 1)
+        hipLaunchKernelGGL((encode_store_kernel<uint8_t, false>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
+                           seq_off, qmap, n_seq, K, (uint8_t*)sym, seq_bad);
     else
-        hipLaunchKernelGGL(encode_store_kernel<uint16_t>, dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
+        hipLaunchKernelGGL((encode_store_kernel<uint16_t, false>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
                            seq_off, qmap, n_seq, K, (uint16_t*)sym, seq_bad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -888,7 +928,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int variant,
                         hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    const size_t lds = st.lut_bytes + 17 * (st.symbytes == 1 ? 4 : 8) * sizeof(uint32_t);
+    static const size_t lds_pad = getenv("HC_LDS_PAD") ? (size_t)atol(getenv("HC_LDS_PAD")) : 0;  // occupancy experiments
+    const size_t lds = st.lut_bytes + 17 * (st.symbytes == 1 ? 4 : 8) * sizeof(uint32_t) + lds_pad;
     const uint32_t block = 256;
     const uint32_t lg = lut_lg(st.K);
     const size_t lds_staged = lds + 16 + 4 * kStageWaveBytes;
@@ -902,7 +943,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
         if (st.symbytes == 2) return launch_staged_lg<uint16_t, 5>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
         if (lg == 3) return launch_staged_lg<uint8_t, 3>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
         if (lg == 4) return launch_staged_lg<uint8_t, 4>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
-        return launch_staged_lg<uint8_t, 5>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
+        if (lg == 5) return launch_staged_lg<uint8_t, 5>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
+        return launch_staged_lg<uint8_t, 6>(st, prm, lut_g, in, n, out, perm, nb, lds_staged, stream);
     }
     // Fill the chip: enough 256-thread blocks for 8 waves per SIMD, bounded by LDS.
     uint32_t blocks_per_cu = 8;
@@ -917,7 +959,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     if (st.symbytes == 2) return launch_score_lg<uint16_t, 5>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
     if (lg == 3) return launch_score_lg<uint8_t, 3>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
     if (lg == 4) return launch_score_lg<uint8_t, 4>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
-    return launch_score_lg<uint8_t, 5>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
+    if (lg == 5) return launch_score_lg<uint8_t, 5>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
+    return launch_score_lg<uint8_t, 6>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
 }
 
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,
@@ -945,6 +988,7 @@ hipError_t set_score_kernel_lds_limit() {
     if ((e = set_lds_limit_lg<uint8_t, 3>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 4>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 5>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_lg<uint8_t, 6>()) != hipSuccess) return e;
     return set_lds_limit_lg<uint16_t, 5>();
 }
 

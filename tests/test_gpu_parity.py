@@ -195,23 +195,36 @@ def test_threshold_sweep_decisions(oracle):
         check_parity(oracle, reads, hc.Settings(edge_threshold=et, ov_threshold=ot, merge_contigs=mc), cand)
 
 
-def test_invalid_bases_and_quals_are_errors():
+@pytest.mark.parametrize("n_quals", [3, 40, 70])  # 8-bit symbols, wide 8-bit symbols (31..48 values), 16-bit symbols
+def test_invalid_bases_and_quals_are_errors(oracle, n_quals):
     # lower-case bases in a PAIRED read abort the reference (EdgeCalculator.cpp:29-30); quality < '!' too (:61)
+    filler = "".join(chr(33 + (i % n_quals)) for i in range(70))  # forces the size of the quality alphabet
     singles = [("ACGTACGTACGTACGTACGT", "IIIIIIIIIIIIIIIIIIII"), ("ACGTACGTacGTACGTACGT", "IIIIIIIIIIIIIIIIIIII"),
-               ("ACGTACGTACGTACGTACGT", "IIIIIIII IIIIIIIIIII"), ("ACGTACGTACGTACGTACGT", "IIIIIIIIIIIIIIIIIIII")]
+               ("ACGTACGTACGTACGTACGT", "IIIIIIII IIIIIIIIIII"), ("ACGTACGTACGTACGTACGT", "IIIIIIIIIIIIIIIIIIII"),
+               ("ACGTNACGTN" * 7, filler), ("ACGTNACGTN" * 7, filler[::-1])]
+    singles = [(s_, q_[: len(s_)]) for s_, q_ in singles]
     reads = hc.ReadSet.from_lists(singles)
     rows = [(0, 3, 0, 0, 1, 1, ord("-"), 0, 20, 0, 100), (0, 1, 0, 0, 1, 1, ord("-"), 0, 20, 0, 100),
             (0, 2, 0, 0, 1, 1, ord("-"), 0, 20, 0, 100), (0, 1, 12, 0, 1, 1, ord("-"), 0, 8, 0, 40),
-            (3, 1, 0, 0, 1, 0, ord("-"), 0, 20, 0, 100)]
+            (3, 1, 0, 0, 1, 0, ord("-"), 0, 20, 0, 100), (4, 5, 0, 0, 1, 1, ord("-"), 0, 70, 0, 100),
+            (4, 5, 3, 0, 1, 0, ord("-"), 0, 67, 0, 95), (5, 4, 10, 0, 0, 0, ord("-"), 0, 60, 0, 85)]
     cand = np.array(rows, dtype=OVERLAP_DTYPE)
-    with hc.EdgeScorer(hc.Settings(edge_threshold=0.9)) as sc:
+    st = hc.Settings(edge_threshold=0.9, ov_threshold=0.1)
+    with hc.EdgeScorer(st) as sc:
         sc.set_reads(reads)
+        k = sc.info()["qual_alphabet"]
+        assert (k <= 30) == (n_quals == 3) and (k > 48) == (n_quals == 70)
         res = sc.score_batch(cand)
         cls = result_cls(res)
         # row 3 overlaps read 1 at positions 0..7 only (the lower-case bases sit at 8,9): valid
-        assert cls.tolist() == [2, 7, 7, 2, 7]
+        assert cls[:5].tolist() == [2, 7, 7, 2, 7]
         with pytest.raises(hc.HcError):
             sc.finalize(res)
+        ok = np.array([0, 3, 5, 6, 7])
+        ref = oracle.score_batch(reads, st, cand[ok])
+        assert (ref["status"] == 0).all()
+        assert np.array_equal(res["x1"][ok].view(np.uint64), ref["x1"].view(np.uint64))
+        assert np.array_equal(result_n(res)[ok], ref["n"]) and np.array_equal(res["mm"][ok], ref["mm"])
 
 
 def test_api_errors_and_empty_batch():
