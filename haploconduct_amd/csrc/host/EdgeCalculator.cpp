@@ -8,30 +8,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace hc {
 
 static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-hc_settings to_hc_settings(const ProgramSettings& ps) {
-    hc_settings s;
-    memset(&s, 0, sizeof s);
-    s.edge_threshold = ps.edge_threshold;
-    s.ov_threshold = ps.ov_threshold;
-    s.merge_contigs = ps.merge_contigs;
-    s.mismatch = ps.mismatch;
-    s.min_read_len = ps.min_read_len;
-    s.min_overlap_len = ps.min_overlap_len;
-    s.min_overlap_perc = ps.min_overlap_perc;
-    s.flags = (ps.add_duplicates ? HC_FLAG_ADD_DUPLICATES : 0u) | (ps.resolve_orientations ? HC_FLAG_RESOLVE_ORIENTATIONS : 0u) |
-              (ps.ignore_inclusions ? HC_FLAG_IGNORE_INCLUSIONS : 0u) | (ps.relax_PE_edges ? HC_FLAG_RELAX_PE_EDGES : 0u) |
-              (ps.allow_spaces ? HC_FLAG_ALLOW_SPACES : 0u) | (ps.verbose ? HC_FLAG_VERBOSE : 0u);
-    s.max_overlaps = ps.max_overlaps;
-    s.device = ps.device;
-    s.n_threads = ps.n_threads;
-    return s;
 }
 
 static void check(int status, const char* where) {
@@ -83,54 +65,6 @@ double EdgeCalculator::overlap_score(const std::string& seq1, const std::string&
     uint32_t cls;
     check(hc_finalize(&cs, &res, &score, &mismatch_rate, &cls), "hc_finalize");
     return score;
-}
-
-// src/EdgeCalculator.cpp:441-538
-void insert_edge(OverlapGraph& g, const ProgramSettings& program_settings, Edge& e, InsertCounters& c) {
-    node_id_t v1 = e.get_vertex(1), v2 = e.get_vertex(2);
-    if (e.get_pos(1) == 0 && v1 > v2) {  // :443-448: undetermined direction => small id to large id
-        std::swap(v1, v2);
-        e.swap_reads();
-    }
-    if (e.get_perc() == 100) c.inclusion_count++;  // :449-451, before de-duplication
-    const bool opposite_orientations = (e.get_ori(1) == e.get_ori(2));
-    const double score = g.checkEdgeWithOri(v1, v2, opposite_orientations);
-    if (score < 0) {  // :455-469
-        g.addEdge(e);
-        c.edges_added++;
-        if (program_settings.ignore_inclusions && e.get_perc() == 100 && e.get_mismatch_rate() < 0.000001 &&
-            e.get_mismatch_rate() >= 0) {
-            if (e.get_extra_pos(1) < 0) {
-                if (e.get_pos(1) == 0) g.inclusions[v1] = 1;  // otherwise only an effect of rounding the percentage
-            } else {
-                g.inclusions[v2] = 1;
-            }
-        }
-        return;
-    }
-    c.dup_count++;  // `doubles++` on both remaining branches, :472,537
-    if (!(e.get_score() >= score)) return;  // :535-538
-    Edge* ex = g.getEdgeInfoWithOri(v1, v2, opposite_orientations, true);
-    if (score == e.get_score()) {  // deterministic tie-break chain, :474-521
-        if (ex->get_len(0) != e.get_len(0)) {
-            if (ex->get_len(0) > e.get_len(0)) return;
-        } else if (ex->get_mismatch_rate() != e.get_mismatch_rate()) {
-            if (ex->get_mismatch_rate() < e.get_mismatch_rate()) return;
-        } else if (ex->get_vertex(1) != e.get_vertex(1)) {
-            if (ex->get_vertex(1) < e.get_vertex(1)) return;
-        } else if (ex->get_ori(1) != e.get_ori(1)) {
-            if (ex->get_ori(1)) return;
-        } else if (ex->get_ori(2) != e.get_ori(2)) {
-            if (ex->get_ori(2)) return;
-        } else if (ex->get_pos(1) != e.get_pos(1)) {
-            if (ex->get_pos(1) < e.get_pos(1)) return;
-        } else if (ex->get_pos(2) != e.get_pos(2)) {
-            if (ex->get_pos(2) < e.get_pos(2)) return;
-        }
-    }
-    if (ex->get_vertex(1) == v1) g.removeEdgeWithOri(v1, v2, opposite_orientations);  // :523-528
-    else g.removeEdgeWithOri(v2, v1, opposite_orientations);
-    g.addEdge(e);  // :530
 }
 
 // src/EdgeCalculator.cpp:389-557
@@ -237,17 +171,47 @@ void EdgeCalculator::construct_edges() {
     OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
     if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
     if (program_settings.verbose) puts("reading overlaps file... ");
-    const size_t overlaps_per_vec = 1000000;  // :571
-    std::vector<ParsedOverlap> batch;
-    batch.reserve(overlaps_per_vec);
+    const size_t overlaps_per_vec = 250000;  // the reference batches 1,000,000 (:571); batch boundaries do not influence the result
+    // Two-stage pipeline: while block k is scored on the device and inserted into the graph, block
+    // k+1 is tokenised by the parser's worker threads.  Blocks are consumed strictly in file order,
+    // so the graph, the counters and nonedge_overlaps.txt are those of the sequential loop.
+    std::vector<ParsedOverlap> batch[2];
+    batch[0].reserve(overlaps_per_vec);
+    batch[1].reserve(overlaps_per_vec);
     ParseCounters pc;
-    for (;;) {
-        const double t0 = now_s();
-        const bool more = parser.next_batch(batch, overlaps_per_vec, rejected, pc, /*print_malformed=*/true);
-        stats.t_parse += now_s() - t0;
-        if (!more) break;
-        if (!batch.empty()) process_overlaps(batch);  // :636-644
+    bool more[2] = {false, false};
+    FatalError parse_error{0, ""};
+    bool parse_failed = false;
+    auto parse_into = [&](int slot) {
+        try {
+            more[slot] = parser.next_batch(batch[slot], overlaps_per_vec, rejected, pc, /*print_malformed=*/true);
+        } catch (const FatalError& e) {
+            parse_failed = true;
+            parse_error = e;
+            more[slot] = false;
+        }
+    };
+    double t0 = now_s();
+    parse_into(0);
+    stats.t_parse += now_s() - t0;
+    int cur = 0;
+    while (more[cur]) {
+        if (parse_failed) throw parse_error;
+        std::thread ahead(parse_into, cur ^ 1);
+        const double t1 = now_s();
+        try {
+            if (!batch[cur].empty()) process_overlaps(batch[cur]);  // :636-644
+        } catch (...) {
+            ahead.join();
+            throw;
+        }
+        const double t2 = now_s();
+        ahead.join();
+        stats.t_parse += now_s() - t2;  // only the part of the parse that was not hidden
+        (void)t1;
+        cur ^= 1;
     }
+    if (parse_failed) throw parse_error;
     stats.lines_read = pc.lines_read;
     stats.malformed = pc.malformed;
     stats.self_overlaps = pc.self_overlaps;
@@ -257,7 +221,7 @@ void EdgeCalculator::construct_edges() {
         printf("Number of self-overlapping reads: %u\n", self_overlap_count);
         printf("Number of inclusion edges: %u\n", inclusion_count);
     }
-    const double t0 = now_s();
+    t0 = now_s();
     FILE* fo = fopen((program_settings.output_dir + "nonedge_overlaps.txt").c_str(), "a");  // :654-660
     if (fo) {
         char linebuf[192];

@@ -1,0 +1,167 @@
+// hc_host_api.cpp — the host-only entry points of include/hcedge_host.h (no device needed): tokenizer,
+// Overlap record parsing, FastqStorage, parser + prefilter, serial insert on a bare graph.
+#include "api_helpers.h"
+
+struct hc_fastq {
+    ProgramSettings ps;
+    std::shared_ptr<FastqStorage> fastq;
+    std::vector<uint64_t> ids;
+};
+
+struct hc_host_graph {
+    ProgramSettings ps;
+    std::unique_ptr<OverlapGraph> graph;
+    std::vector<Read> reads;
+    InsertCounters counters;
+};
+
+extern "C" {
+
+int hc_host_split_line(const char* line, uint64_t n, int allow_spaces, uint32_t* off, uint32_t* len, int max_fields) {
+    if (!line || max_fields < 0 || max_fields > 64) return HC_ERR_ARG;
+    const char* f[64];
+    size_t l[64];
+    const int nf = split_overlap_line(line, n, allow_spaces != 0, f, l, max_fields);
+    for (int i = 0; i < nf && i < max_fields; i++) {
+        if (off) off[i] = (uint32_t)(f[i] - line);
+        if (len) len[i] = (uint32_t)l[i];
+    }
+    return nf;
+}
+
+int hc_host_parse_overlap(const char* line, uint64_t n, int allow_spaces, hc_overlap_fields* out, char* text) {
+    if (!line || !out) return set_last_error(HC_ERR_ARG, "hc_host_parse_overlap: null");
+    const char* f[14];
+    size_t l[14];
+    if (split_overlap_line(line, n, allow_spaces != 0, f, l, 14) != 13) return HC_ERR_ARG;
+    return guarded("Overlap", [&] {
+        const Overlap o = Overlap::from_fields(f, l);
+        memset(out, 0, sizeof *out);
+        out->id1 = o.m_id1; out->id2 = o.m_id2;
+        out->pos1 = o.m_pos1; out->pos2 = o.m_pos2;
+        out->perc1 = o.m_perc1; out->perc2 = o.m_perc2;
+        out->len1 = o.m_len1; out->len2 = o.m_len2;
+        out->perc = o.get_perc();
+        out->ord = o.m_ord; out->ori1 = o.m_ori1; out->ori2 = o.m_ori2; out->type1 = o.m_type1; out->type2 = o.m_type2;
+        if (text) {
+            const size_t k = o.write_line(text);
+            text[k] = 0;
+        }
+    });
+}
+
+int hc_host_fastq_load(hc_fastq** out, const hc_ec_paths* paths, hc_fastq_view* view) {
+    if (!out || !paths || !view) return set_last_error(HC_ERR_ARG, "hc_host_fastq_load: null");
+    *out = nullptr;
+    std::unique_ptr<hc_fastq> f(new hc_fastq());
+    hc_settings s;
+    memset(&s, 0, sizeof s);
+    s.max_overlaps = 100000000;
+    int rc = guarded("FastqStorage", [&] {
+        f->ps = make_ps(&s, paths);
+        f->fastq = std::make_shared<FastqStorage>(f->ps);
+        for (Read* r : f->fastq->m_read_vec) f->ids.push_back(r->get_read_id());
+    });
+    if (rc) return rc;
+    const FastqStorage& q = *f->fastq;
+    view->bases = q.bases().data();
+    view->quals = q.quals().data();
+    view->seq_off = q.seq_off().data();
+    view->read_first_seq = q.read_first_seq().data();
+    view->read_ids = f->ids.data();
+    view->n_reads = q.get_readcount();
+    view->n_seq = (uint32_t)(q.seq_off().size() - 1);
+    view->n_single = q.m_readcount_single;
+    view->n_paired = q.m_readcount_paired;
+    *out = f.release();
+    return HC_OK;
+}
+
+int hc_host_fastq_free(hc_fastq* f) {
+    delete f;
+    return HC_OK;
+}
+
+int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* overlaps_path, hc_overlap_rec* out,
+                       uint64_t cap, uint64_t* n_out, hc_ec_counters* counters) {
+    if (!settings || !f || !overlaps_path || !n_out) return set_last_error(HC_ERR_ARG, "hc_host_parse_file: null");
+    *n_out = 0;
+    return guarded("parse", [&] {
+        ProgramSettings ps = make_ps(settings, nullptr);
+        ps.overlaps_file = overlaps_path;
+        OverlapsParser parser(ps.overlaps_file, ps, *f->fastq);
+        if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};
+        std::vector<ParsedOverlap> batch;
+        std::vector<Overlap> rejected;
+        ParseCounters pc;
+        uint64_t n = 0;
+        for (;;) {
+            const bool more = parser.next_batch(batch, 1000000, rejected, pc, false);
+            if (!more) break;
+            for (const auto& b : batch) {
+                if (out && n < cap) out[n] = b.rec;
+                n++;
+            }
+        }
+        *n_out = n;
+        if (counters) {
+            memset(counters, 0, sizeof *counters);
+            counters->lines_read = pc.lines_read;
+            counters->malformed_lines = pc.malformed;
+            counters->prefilter_rejected = pc.prefilter_rejected;
+            counters->silently_dropped = pc.silently_dropped;
+            counters->scored = n;
+        }
+    });
+}
+
+int hc_host_graph_new(hc_host_graph** out, uint64_t n_vertices, const hc_settings* settings) {
+    if (!out || !settings) return set_last_error(HC_ERR_ARG, "hc_host_graph_new: null");
+    std::unique_ptr<hc_host_graph> g(new hc_host_graph());
+    g->ps = make_ps(settings, nullptr);
+    g->graph.reset(new OverlapGraph((unsigned int)n_vertices, nullptr, g->ps));
+    g->reads.reserve(n_vertices);
+    for (uint64_t i = 0; i < n_vertices; i++) {
+        g->reads.emplace_back(nullptr, (unsigned int)i, false, (read_id_t)i);
+        g->graph->addVertex(i);
+    }
+    *out = g.release();
+    return HC_OK;
+}
+
+int hc_host_graph_insert(hc_host_graph* g, const hc_edge_rec* r) {
+    if (!g || !r) return set_last_error(HC_ERR_ARG, "hc_host_graph_insert: null");
+    return guarded("insert", [&] {
+        if (r->read1 >= g->reads.size() || r->read2 >= g->reads.size()) throw FatalError{HC_ERR_ARG, "read index out of range"};
+        Edge e(r->score, r->pos1, r->pos2, r->ori1 != 0, r->ori2 != 0, std::string(1, (char)r->ord), &g->reads[r->read1],
+               &g->reads[r->read2]);
+        e.set_vertices(r->v1, r->v2);
+        e.set_extra_pos(r->pos3, r->pos4);
+        e.set_perc(r->perc);
+        e.set_len(r->len1, r->len2);
+        e.set_mismatch(r->mismatch_rate);
+        insert_edge(*g->graph, g->ps, e, g->counters);
+    });
+}
+
+int hc_host_graph_get(hc_host_graph* g, hc_edge_rec* out, uint64_t cap, uint64_t* n_out, uint8_t* inclusions,
+                      hc_ec_counters* counters) {
+    if (!g || !n_out) return set_last_error(HC_ERR_ARG, "hc_host_graph_get: null");
+    *n_out = dump_edges(*g->graph, out, cap);
+    if (inclusions)
+        for (size_t i = 0; i < g->graph->inclusions.size(); i++) inclusions[i] = g->graph->inclusions[i];
+    if (counters) {
+        memset(counters, 0, sizeof *counters);
+        counters->inclusion_count = g->counters.inclusion_count;
+        counters->dup_count = g->counters.dup_count;
+        counters->edges_added = g->counters.edges_added;
+    }
+    return HC_OK;
+}
+
+int hc_host_graph_free(hc_host_graph* g) {
+    delete g;
+    return HC_OK;
+}
+
+}  // extern "C"

@@ -9,6 +9,7 @@
 
 #include "../../../include/hcedge.h"
 #include "Edge.h"
+#include "EdgeCalculator.h"
 #include "FastqStorage.h"
 #include "Overlap.h"
 #include "OverlapGraph.h"
@@ -362,6 +363,74 @@ Edge* OverlapGraph::getEdgeInfoWithOri(node_id_t v, node_id_t w, bool opposite_o
         for (Edge& e : adj_out.at(w))
             if (e.get_vertex(2) == v && same_ori_class(e, opposite_orientations)) return &e;
     throw FatalError{HC_ERR_STATE, "Edge not found. Exiting."};
+}
+
+// ------------------------------------------------------------------ pieces of EdgeCalculator without device dependencies
+hc_settings to_hc_settings(const ProgramSettings& ps) {
+    hc_settings s;
+    memset(&s, 0, sizeof s);
+    s.edge_threshold = ps.edge_threshold;
+    s.ov_threshold = ps.ov_threshold;
+    s.merge_contigs = ps.merge_contigs;
+    s.mismatch = ps.mismatch;
+    s.min_read_len = ps.min_read_len;
+    s.min_overlap_len = ps.min_overlap_len;
+    s.min_overlap_perc = ps.min_overlap_perc;
+    s.flags = (ps.add_duplicates ? HC_FLAG_ADD_DUPLICATES : 0u) | (ps.resolve_orientations ? HC_FLAG_RESOLVE_ORIENTATIONS : 0u) |
+              (ps.ignore_inclusions ? HC_FLAG_IGNORE_INCLUSIONS : 0u) | (ps.relax_PE_edges ? HC_FLAG_RELAX_PE_EDGES : 0u) |
+              (ps.allow_spaces ? HC_FLAG_ALLOW_SPACES : 0u) | (ps.verbose ? HC_FLAG_VERBOSE : 0u);
+    s.max_overlaps = ps.max_overlaps;
+    s.device = ps.device;
+    s.n_threads = ps.n_threads;
+    return s;
+}
+
+// src/EdgeCalculator.cpp:441-538
+void insert_edge(OverlapGraph& g, const ProgramSettings& program_settings, Edge& e, InsertCounters& c) {
+    node_id_t v1 = e.get_vertex(1), v2 = e.get_vertex(2);
+    if (e.get_pos(1) == 0 && v1 > v2) {  // :443-448: undetermined direction => small id to large id
+        std::swap(v1, v2);
+        e.swap_reads();
+    }
+    if (e.get_perc() == 100) c.inclusion_count++;  // :449-451, before de-duplication
+    const bool opposite_orientations = (e.get_ori(1) == e.get_ori(2));
+    const double score = g.checkEdgeWithOri(v1, v2, opposite_orientations);
+    if (score < 0) {  // :455-469
+        g.addEdge(e);
+        c.edges_added++;
+        if (program_settings.ignore_inclusions && e.get_perc() == 100 && e.get_mismatch_rate() < 0.000001 &&
+            e.get_mismatch_rate() >= 0) {
+            if (e.get_extra_pos(1) < 0) {
+                if (e.get_pos(1) == 0) g.inclusions[v1] = 1;  // otherwise only an effect of rounding the percentage
+            } else {
+                g.inclusions[v2] = 1;
+            }
+        }
+        return;
+    }
+    c.dup_count++;  // `doubles++` on both remaining branches, :472,537
+    if (!(e.get_score() >= score)) return;  // :535-538
+    Edge* ex = g.getEdgeInfoWithOri(v1, v2, opposite_orientations, true);
+    if (score == e.get_score()) {  // deterministic tie-break chain, :474-521
+        if (ex->get_len(0) != e.get_len(0)) {
+            if (ex->get_len(0) > e.get_len(0)) return;
+        } else if (ex->get_mismatch_rate() != e.get_mismatch_rate()) {
+            if (ex->get_mismatch_rate() < e.get_mismatch_rate()) return;
+        } else if (ex->get_vertex(1) != e.get_vertex(1)) {
+            if (ex->get_vertex(1) < e.get_vertex(1)) return;
+        } else if (ex->get_ori(1) != e.get_ori(1)) {
+            if (ex->get_ori(1)) return;
+        } else if (ex->get_ori(2) != e.get_ori(2)) {
+            if (ex->get_ori(2)) return;
+        } else if (ex->get_pos(1) != e.get_pos(1)) {
+            if (ex->get_pos(1) < e.get_pos(1)) return;
+        } else if (ex->get_pos(2) != e.get_pos(2)) {
+            if (ex->get_pos(2) < e.get_pos(2)) return;
+        }
+    }
+    if (ex->get_vertex(1) == v1) g.removeEdgeWithOri(v1, v2, opposite_orientations);  // :523-528
+    else g.removeEdgeWithOri(v2, v1, opposite_orientations);
+    g.addEdge(e);  // :530
 }
 
 }  // namespace hc

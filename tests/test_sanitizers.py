@@ -1,0 +1,119 @@
+"""AddressSanitizer + UBSan over the host-only code (FASTQ reader, overlaps tokenizer / record parser /
+parallel block parser / prefilter, serial insert) and over the oracle: a CPU build with g++/gcc
+-fsanitize=address,undefined driven through the same C entry points on hostile inputs.  (GPU
+sanitizers are not available on the pool; the device code is covered by the parity tests.)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "build", "asan")
+
+DRIVER = r'''
+import ctypes as C, os, random, sys
+host = C.CDLL(os.environ["HC_ASAN_HOST"])
+orc = C.CDLL(os.environ["HC_ASAN_ORACLE"])
+rng = random.Random(1)
+d = os.environ["HC_TMP"]
+
+class S(C.Structure):
+    _fields_ = [("edge_threshold", C.c_double), ("ov_threshold", C.c_double), ("merge_contigs", C.c_double),
+                ("mismatch", C.c_double), ("min_read_len", C.c_uint32), ("min_overlap_len", C.c_uint32),
+                ("min_overlap_perc", C.c_uint32), ("flags", C.c_uint32), ("max_overlaps", C.c_uint64),
+                ("device", C.c_int32), ("n_threads", C.c_uint32)]
+class P(C.Structure):
+    _fields_ = [(k, C.c_char_p) for k in ("singles", "p1", "p2", "ids", "ov", "out")] + [("max_reads", C.c_uint64)]
+class V(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("bases", "quals", "seq_off", "first", "ids")] + [(k, C.c_uint32) for k in ("n_reads", "n_seq", "n_single", "n_paired")]
+
+# 1. tokenizer + record parser on hostile lines
+host.hc_host_split_line.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+host.hc_host_parse_overlap.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_void_p, C.c_char_p]
+alphabet = ["\t", "\t", " ", "0", "12", "-", "+", "s", "p", "", "99999999999999999999", "-5", "0x1F", "\x00", "\xff", "1" * 80]
+out = C.create_string_buffer(256); text = C.create_string_buffer(256)
+off = (C.c_uint32 * 64)(); ln = (C.c_uint32 * 64)()
+for _ in range(20000):
+    line = "".join(rng.choice(alphabet) for _ in range(rng.randrange(0, 40))).encode("latin1")
+    for sp in (0, 1):
+        host.hc_host_split_line(line, len(line), sp, off, ln, rng.choice([0, 1, 13, 14, 64]))
+        host.hc_host_parse_overlap(line, len(line), sp, out, text)
+good = b"7\t9\t12\t30\t1\t+\t-\t80\t70\t120\t105\tp\tp"
+assert host.hc_host_parse_overlap(good, len(good), 0, out, text) == 0
+
+# 2. FASTQ reader on hostile files, then parser + prefilter with many threads
+def w(name, data):
+    open(d + name, "wb").write(data); return (d + name).encode()
+fq = b"".join(b"@%d\nACGTNACGTN%s\n+\nIIIIIIIIII%s\n" % (i, b"ACGT" * (i % 7), b"5555" * (i % 7)) for i in range(300))
+s = w("s.fastq", fq)
+for bad in (b"", b"@1\n", b"@1\nACGT\n+\nII\n", b"x\nACGT\n+\nIIII\n", b"@1\n\n+\n\n", b"@1\nACGT\n+\nIIII", b"\n\n\n\n"):
+    h = C.c_void_p(); v = V(); p = P(w("bad.fastq", bad), None, None, None, None, None, 0)
+    rc = host.hc_host_fastq_load(C.byref(h), C.byref(p), C.byref(v))
+    if rc == 0: host.hc_host_fastq_free(h)
+h = C.c_void_p(); v = V(); p = P(s, None, None, None, None, None, 0)
+assert host.hc_host_fastq_load(C.byref(h), C.byref(p), C.byref(v)) == 0 and v.n_reads == 300
+lines = []
+for _ in range(30000):
+    a, b = rng.randrange(300), rng.randrange(300)
+    lines.append("%d\t%d\t%d\t-\t-\t%s\t%s\t%d\t-\t%d\t-\ts\ts" % (a, b, rng.randrange(12), rng.choice("+-"), rng.choice("+-"), rng.randrange(101), rng.randrange(1, 40)))
+for junk in ("", "x", "1\t2", "\t\t\t", lines[0] + "\tz"):
+    lines.insert(rng.randrange(len(lines)), junk)
+ov = w("ov.txt", ("\n".join(lines)).encode())
+n = C.c_uint64()
+host.hc_host_parse_file.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+for threads in (1, 3, 16):
+    for mo in (10**8, 1, 777):
+        st = S(0.97, 0.9, 0, 0, 0, 10, 0, 2, mo, 0, threads)
+        buf = (C.c_char * (32 * 40000))()
+        assert host.hc_host_parse_file(C.byref(st), h, ov, buf, 40000, C.byref(n), None) == 0
+# unknown read id -> error, not a crash
+ov2 = w("ov2.txt", b"0\t9999\t0\t-\t-\t+\t+\t100\t-\t30\t-\ts\ts\n")
+st = S(0.97, 0.9, 0, 0, 0, 10, 0, 2, 10**8, 0, 4)
+assert host.hc_host_parse_file(C.byref(st), h, ov2, None, 0, C.byref(n), None) != 0
+host.hc_host_fastq_free(h)
+
+# 3. serial insert under duplicates
+g = C.c_void_p(); st = S(0.97, 0.9, 0, 0, 0, 10, 0, 2 | 4, 10**8, 0, 1)
+assert host.hc_host_graph_new(C.byref(g), 10, C.byref(st)) == 0
+import struct
+for _ in range(5000):
+    a, b = rng.sample(range(10), 2)
+    rec = struct.pack("<ddiiiiBBBBIIIQQiiii", rng.choice([0.97, 0.98, 1.0]), rng.choice([0.0, 0.1]), rng.choice([0, 3]), 0, rng.choice([-2, 2]), 0,
+                      rng.randrange(2), rng.randrange(2), ord(rng.choice("-12")), 0, a, b, 0, a, b, rng.choice([100, 50]), 100, 100, 0)
+    assert host.hc_host_graph_insert(g, rec) == 0
+host.hc_host_graph_free(g)
+
+# 4. oracle on odd inputs
+orc.hco_overlap_score.restype = C.c_double
+mr = C.c_double(); x = C.c_double(); mm = C.c_uint32(); nn = C.c_uint32(); pos = C.c_uint64(); stt = C.c_int()
+for a, b, qa, qb, p in ((b"ACGT", b"ACGT", b"IIII", b"IIII", 0), (b"ACGT", b"AC", b"IIII", b"II", 3), (b"NNNN", b"ACGT", b"!!!!", b"IIII", 0),
+                        (b"ACGT", b"ACGT", b"IIII", b"IIII", 77), (b"acgt", b"ACGT", b"IIII", b"IIII", 0), (b"ACGT", b"ACGT", b"  II", b"IIII", 0)):
+    orc.hco_overlap_score(a, C.c_size_t(len(a)), b, C.c_size_t(len(b)), qa, qb, C.c_uint(p), C.c_uint(0), C.c_double(0.0), C.byref(mr), C.byref(x),
+                          C.byref(mm), C.byref(nn), C.byref(pos), C.byref(stt))
+print("sanitizer driver finished")
+'''
+
+
+def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
+    os.makedirs(BUILD, exist_ok=True)
+    host_so = os.path.join(BUILD, "libhchost_asan.so")
+    orc_so = os.path.join(BUILD, "liboracle_asan.so")
+    hd = os.path.join(ROOT, "haploconduct_amd", "csrc", "host")
+    stub = os.path.join(BUILD, "stub.cpp")
+    open(stub, "w").write('#include <string>\nnamespace hc { int set_last_error(int s, const std::string&) { return s; } }\n'
+                          'extern "C" { const char* hc_strerror(int) { return ""; } const char* hc_last_error(void) { return ""; } }\n')
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-fPIC", "-shared"]
+    r = subprocess.run(["g++", "-std=c++17", *san, "-pthread", "-o", host_so, os.path.join(hd, "host_model.cpp"),
+                        os.path.join(hd, "OverlapsParser.cpp"), os.path.join(hd, "hc_host_api.cpp"), stub],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run(["gcc", "-std=gnu11", "-ffp-contract=off", "-fopenmp", *san, "-o", orc_so,
+                        os.path.join(ROOT, "oracle", "hc_oracle.c"), "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    libstdcpp = subprocess.run(["gcc", "-print-file-name=libstdc++.so.6"], capture_output=True, text=True).stdout.strip()
+    # libstdc++ must be loaded before the ASan runtime initialises, or its __cxa_throw interceptor has no target
+    env = dict(os.environ, LD_PRELOAD=libasan + " " + libstdcpp, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", HC_ASAN_HOST=host_so,
+               HC_ASAN_ORACLE=orc_so, HC_TMP=str(tmp_path) + "/", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-c", DRIVER], env=env, capture_output=True, text=True, timeout=600)
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "sanitizer driver finished" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
