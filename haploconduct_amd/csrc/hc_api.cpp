@@ -24,6 +24,11 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
                         uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int variant,
                         hipStream_t stream);
+size_t compact_temp_bytes(uint32_t n);
+hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_out, unsigned long long* count_out, void* temp,
+                          size_t temp_bytes, hipStream_t stream);
+hipError_t launch_gather_results(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count,
+                                 hc_result_rec* out, uint32_t n_cu, hipStream_t stream);
 size_t reorder_temp_bytes(uint32_t n);
 hipError_t launch_reorder(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint32_t n,
                           bool use_buckets, uint32_t* keys_in, uint32_t* keys_out, uint32_t* idx_in, uint32_t* perm_out,
@@ -77,6 +82,12 @@ struct hc_ctx {
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint64_t sort_cap = 0;
+    // compaction scratch, grow-only
+    void* d_compact_tmp = nullptr;
+    size_t compact_tmp_bytes = 0;
+    uint32_t* d_compact_idx = nullptr;
+    hc_result_rec* d_compact_res = nullptr;
+    uint64_t compact_cap = 0;
 };
 
 // --------------------------------------------------------------------------
@@ -197,6 +208,9 @@ int hc_destroy(hc_ctx* c) {
     if (c->d_totals) (void)hipFree(c->d_totals);
     if (c->d_sort) (void)hipFree(c->d_sort);
     if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
+    if (c->d_compact_tmp) (void)hipFree(c->d_compact_tmp);
+    if (c->d_compact_idx) (void)hipFree(c->d_compact_idx);
+    if (c->d_compact_res) (void)hipFree(c->d_compact_res);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -339,10 +353,27 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     return HC_OK;
 }
 
+// Sampled locality probe on a host copy of a batch: in overlap files as sfo2overlaps / FNO write them,
+// consecutive lines share a read almost always; if fewer than half of the sampled neighbours do, the
+// batch is worth reordering on the device.
+static bool host_batch_is_ordered(const hc_overlap_rec* in, uint64_t n) {
+    const uint64_t samples = 4096, step = (n - 1) / samples;
+    uint64_t share = 0;
+    for (uint64_t k = 0; k < samples; k++) {
+        const hc_overlap_rec& a = in[k * step];
+        const hc_overlap_rec& b = in[k * step + 1];
+        share += (a.read1 == b.read1) | (a.read1 == b.read2) | (a.read2 == b.read1) | (a.read2 == b.read2);
+    }
+    return share * 2 >= samples;
+}
+
 static int ensure_sort_workspace(hc_ctx* c, uint64_t n) {
     if (n <= c->sort_cap) return HC_OK;
     if (c->d_sort) (void)hipFree(c->d_sort);
     if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
+    if (c->d_compact_tmp) (void)hipFree(c->d_compact_tmp);
+    if (c->d_compact_idx) (void)hipFree(c->d_compact_idx);
+    if (c->d_compact_res) (void)hipFree(c->d_compact_res);
     c->d_sort = nullptr;
     c->d_sort_tmp = nullptr;
     c->sort_cap = 0;
@@ -418,19 +449,7 @@ int hc_score_batch(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, hc_result_re
     if (rc) return rc;
     HC_HIP(hipMemcpyAsync(c->d_in, in, n * sizeof(hc_overlap_rec), hipMemcpyHostToDevice, c->stream));
     bool reorder = c->reorder_mode == HC_REORDER_ALWAYS;
-    if (c->reorder_mode == HC_REORDER_AUTO && n >= 4096) {
-        // Sampled locality probe on the host copy: in overlap files as sfo2overlaps / FNO write them,
-        // consecutive lines share a read almost always; if fewer than half of the sampled neighbours
-        // do, the batch is reordered on the device.
-        const uint64_t samples = 4096, step = (n - 1) / samples;
-        uint64_t share = 0;
-        for (uint64_t k = 0; k < samples; k++) {
-            const hc_overlap_rec& a = in[k * step];
-            const hc_overlap_rec& b = in[k * step + 1];
-            share += (a.read1 == b.read1) | (a.read1 == b.read2) | (a.read2 == b.read1) | (a.read2 == b.read2);
-        }
-        reorder = share * 2 < samples;
-    }
+    if (c->reorder_mode == HC_REORDER_AUTO && n >= 4096) reorder = !host_batch_is_ordered(in, n);
     rc = score_on_device(c, c->d_in, n, c->d_out, c->stream, reorder);
     if (rc) return rc;
     HC_HIP(hipMemcpyAsync(out, c->d_out, n * sizeof(hc_result_rec), hipMemcpyDeviceToHost, c->stream));
@@ -449,6 +468,80 @@ int hc_host_alloc(hc_ctx* c, void** ptr, uint64_t bytes) {
 int hc_host_free(hc_ctx* c, void* ptr) {
     if (!c) return fail(HC_ERR_ARG, "hc_host_free: null context");
     if (ptr) HC_HIP(hipHostFree(ptr));
+    return HC_OK;
+}
+
+static int ensure_compact_workspace(hc_ctx* c, uint64_t n, bool with_buffers) {
+    const size_t need = hc::compact_temp_bytes((uint32_t)n);
+    if (need > c->compact_tmp_bytes) {
+        if (c->d_compact_tmp) (void)hipFree(c->d_compact_tmp);
+        c->d_compact_tmp = nullptr;
+        c->compact_tmp_bytes = 0;
+        HC_HIP(hipMalloc(&c->d_compact_tmp, need));
+        c->compact_tmp_bytes = need;
+    }
+    if (with_buffers && n > c->compact_cap) {
+        if (c->d_compact_idx) (void)hipFree(c->d_compact_idx);
+        if (c->d_compact_res) (void)hipFree(c->d_compact_res);
+        c->d_compact_idx = nullptr;
+        c->d_compact_res = nullptr;
+        c->compact_cap = 0;
+        HC_HIP(hipMalloc((void**)&c->d_compact_idx, n * sizeof(uint32_t)));
+        HC_HIP(hipMalloc((void**)&c->d_compact_res, n * sizeof(hc_result_rec)));
+        c->compact_cap = n;
+    }
+    return HC_OK;
+}
+
+int hc_compact_device(hc_ctx* c, const void* d_results, uint64_t n, void* d_indices, void* d_count, void* hip_stream) {
+    if (!c || !d_count) return fail(HC_ERR_ARG, "hc_compact_device: null argument");
+    if (n >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_compact_device: n must be < 2^31");
+    HC_HIP(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (n == 0) {
+        HC_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
+        return HC_OK;
+    }
+    if (!d_results || !d_indices) return fail(HC_ERR_ARG, "hc_compact_device: null buffer");
+    int rc = ensure_compact_workspace(c, n, false);
+    if (rc) return rc;
+    HC_HIP(hc::launch_compact((const hc_result_rec*)d_results, (uint32_t)n, (uint32_t*)d_indices, (unsigned long long*)d_count,
+                              c->d_compact_tmp, c->compact_tmp_bytes, s));
+    return HC_OK;
+}
+
+int hc_score_batch_compact(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, uint32_t* idx_out, hc_result_rec* res_out,
+                           uint64_t cap, uint64_t* n_out) {
+    if (!c || !n_out) return fail(HC_ERR_ARG, "hc_score_batch_compact: null argument");
+    *n_out = 0;
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_score_batch_compact: hc_set_reads has not been called");
+    if (n == 0) return HC_OK;
+    if (!in || (cap && (!idx_out || !res_out))) return fail(HC_ERR_ARG, "hc_score_batch_compact: null buffer");
+    if (n >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_score_batch_compact: n must be < 2^31");
+    HC_HIP(hipSetDevice(c->device));
+    int rc = ensure_workspace(c, n);
+    if (rc) return rc;
+    rc = ensure_compact_workspace(c, n, true);
+    if (rc) return rc;
+    HC_HIP(hipMemcpyAsync(c->d_in, in, n * sizeof(hc_overlap_rec), hipMemcpyHostToDevice, c->stream));
+    bool reorder = c->reorder_mode == HC_REORDER_ALWAYS;
+    if (c->reorder_mode == HC_REORDER_AUTO && n >= 4096) reorder = !host_batch_is_ordered(in, n);
+    rc = score_on_device(c, c->d_in, n, c->d_out, c->stream, reorder);
+    if (rc) return rc;
+    HC_HIP(hc::launch_compact((const hc_result_rec*)c->d_out, (uint32_t)n, c->d_compact_idx, c->d_totals, c->d_compact_tmp,
+                              c->compact_tmp_bytes, c->stream));
+    HC_HIP(hc::launch_gather_results((const hc_result_rec*)c->d_out, c->d_compact_idx, c->d_totals, c->d_compact_res, c->n_cu,
+                                     c->stream));
+    unsigned long long k = 0;
+    HC_HIP(hipMemcpyAsync(&k, c->d_totals, sizeof k, hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    *n_out = k;
+    if (k > cap) return fail(HC_ERR_ARG, "hc_score_batch_compact: output capacity too small");
+    if (k) {
+        HC_HIP(hipMemcpyAsync(idx_out, c->d_compact_idx, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HC_HIP(hipMemcpyAsync(res_out, c->d_compact_res, k * sizeof(hc_result_rec), hipMemcpyDeviceToHost, c->stream));
+        HC_HIP(hipStreamSynchronize(c->stream));
+    }
     return HC_OK;
 }
 

@@ -870,6 +870,42 @@ hipError_t launch_reorder(const StoreView& st, uint32_t min_read_len, const hc_o
 }
 
 // ---------------------------------------------------------------------------
+// Compaction of the records the host / the gather still need (class != DROP), in sequence order.
+struct NotDropped {
+    const hc_result_rec* res;
+    __device__ __forceinline__ bool operator()(const uint32_t& i) const { return (res[i].n_cls >> 28) != HC_CLS_DROP; }
+};
+
+size_t compact_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    hipcub::CountingInputIterator<uint32_t> it(0);
+    hipcub::DeviceSelect::If(nullptr, bytes, it, (uint32_t*)nullptr, (unsigned long long*)nullptr, (int)n, NotDropped{nullptr});
+    return bytes;
+}
+
+hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_out, unsigned long long* count_out, void* temp,
+                          size_t temp_bytes, hipStream_t stream) {
+    hipcub::CountingInputIterator<uint32_t> it(0);
+    return hipcub::DeviceSelect::If(temp, temp_bytes, it, idx_out, count_out, (int)n, NotDropped{res}, stream);
+}
+
+__global__ __launch_bounds__(256) void gather_results_kernel(const hc_result_rec* __restrict__ res,
+                                                             const uint32_t* __restrict__ idx,
+                                                             const unsigned long long* __restrict__ count,
+                                                             hc_result_rec* __restrict__ out) {
+    const unsigned long long k = *count;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < k;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        out[i] = res[idx[i]];
+}
+
+hipError_t launch_gather_results(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count,
+                                 hc_result_rec* out, uint32_t n_cu, hipStream_t stream) {
+    hipLaunchKernelGGL(gather_results_kernel, dim3(n_cu * 4), dim3(256), 0, stream, res, idx, count, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Launch wrappers (called from hc_api.cpp).
 hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
                          const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,

@@ -24,6 +24,7 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
                                const ProgramSettings& ps)
     : program_settings(ps), fastq_storage(std::move(fastq)), overlap_graph(std::move(graph)) {
     if (ps.add_duplicates) throw FatalError{HC_ERR_ARG, "--add_duplicates is not supported (the pipelines never set it)"};
+    if (const char* m = getenv("HC_INSERT_MODE")) m_sorted_insert = std::string(m) == "sorted";
     m_cs = to_hc_settings(ps);
     check(hc_create(&m_ctx, &m_cs), "hc_create");
     const FastqStorage& f = *fastq_storage;
@@ -36,6 +37,7 @@ EdgeCalculator::~EdgeCalculator() {
     if (m_ctx) {
         hc_host_free(m_ctx, m_rec);
         hc_host_free(m_ctx, m_res);
+        hc_host_free(m_ctx, m_idx);
         hc_destroy(m_ctx);
     }
 }
@@ -75,16 +77,21 @@ void EdgeCalculator::process_overlaps(const std::vector<ParsedOverlap>& batch) {
     if (n > m_cap) {
         hc_host_free(m_ctx, m_rec);
         hc_host_free(m_ctx, m_res);
+        hc_host_free(m_ctx, m_idx);
         m_rec = nullptr;
         m_res = nullptr;
+        m_idx = nullptr;
         m_cap = 0;
         const size_t cap = n + n / 8;
         check(hc_host_alloc(m_ctx, (void**)&m_rec, cap * sizeof(hc_overlap_rec)), "hc_host_alloc");
         check(hc_host_alloc(m_ctx, (void**)&m_res, cap * sizeof(hc_result_rec)), "hc_host_alloc");
+        check(hc_host_alloc(m_ctx, (void**)&m_idx, cap * sizeof(uint32_t)), "hc_host_alloc");
         m_cap = cap;
     }
     for (size_t i = 0; i < n; i++) m_rec[i] = batch[i].rec;
-    check(hc_score_batch(m_ctx, m_rec, n, m_res), "hc_score_batch");  // the omp-for, :395-414
+    // the omp-for of :395-414 on the device; only the records that are not dropped come back
+    uint64_t n_kept = 0;
+    check(hc_score_batch_compact(m_ctx, m_rec, n, m_idx, m_res, m_cap, &n_kept), "hc_score_batch_compact");
     stats.scored += n;
     double t1 = now_s();
     stats.t_score += t1 - t0;
@@ -95,8 +102,9 @@ void EdgeCalculator::process_overlaps(const std::vector<ParsedOverlap>& batch) {
     uint64_t added_before = stats.edges_added;
     m_nonedge_buf.clear();
     char linebuf[192];
-    for (size_t i = 0; i < n; i++) {
-        const hc_result_rec& r = m_res[i];
+    for (uint64_t k = 0; k < n_kept; k++) {
+        const size_t i = m_idx[k];
+        const hc_result_rec& r = m_res[k];
         uint32_t cls = HC_RES_CLS(r);
         if (cls == HC_CLS_DROP) continue;
         if (cls == HC_CLS_ERROR)
@@ -141,15 +149,19 @@ void EdgeCalculator::process_overlaps(const std::vector<ParsedOverlap>& batch) {
         e.set_perc((int)o.perc);
         e.set_len((int)o.len1, (!p1 && !p2) ? 0 : (int)o.len2);  // :227 / :268
         e.set_mismatch(mismatch_rate);
-        InsertCounters ic;
-        insert_edge(*overlap_graph, program_settings, e, ic);
-        inclusion_count += ic.inclusion_count;
-        dup_count += ic.dup_count;
-        stats.edges_added += ic.edges_added;
+        if (m_sorted_insert) {
+            m_admitted.push_back(e);  // resolved once, after the last batch (resolve_admitted_edges)
+        } else {
+            InsertCounters ic;
+            insert_edge(*overlap_graph, program_settings, e, ic);
+            inclusion_count += ic.inclusion_count;
+            dup_count += ic.dup_count;
+            stats.edges_added += ic.edges_added;
+        }
     }
     double t2 = now_s();
     stats.t_insert += t2 - t1;
-    if (program_settings.verbose) {
+    if (program_settings.verbose && !m_sorted_insert) {
         (void)count_before;
         printf("Number of edges found: %lu\n", (unsigned long)(stats.edges_added - added_before));
         printf("Number of duplicates: %u\n", dup_count - dups_before);
@@ -212,6 +224,21 @@ void EdgeCalculator::construct_edges() {
         cur ^= 1;
     }
     if (parse_failed) throw parse_error;
+    if (m_sorted_insert) {
+        const double tr = now_s();
+        InsertCounters ic;
+        resolve_admitted_edges(*overlap_graph, program_settings, m_admitted, ic);
+        inclusion_count += ic.inclusion_count;
+        dup_count += ic.dup_count;
+        stats.edges_added += ic.edges_added;
+        if (program_settings.verbose) {  // totals instead of the reference's per-batch lines
+            printf("Number of edges found: %lu\n", (unsigned long)ic.edges_added);
+            printf("Number of duplicates: %u\n", ic.dup_count);
+        }
+        m_admitted.clear();
+        m_admitted.shrink_to_fit();
+        stats.t_insert += now_s() - tr;
+    }
     stats.lines_read = pc.lines_read;
     stats.malformed = pc.malformed;
     stats.self_overlaps = pc.self_overlaps;

@@ -26,6 +26,21 @@ struct InsertCounters {
 };
 void insert_edge(OverlapGraph& g, const ProgramSettings& ps, Edge& e, InsertCounters& c);
 
+// The same result as calling insert_edge() on every element of `admitted` in order, computed by
+// sorting instead of scanning adjacency lists:
+//   * candidates for one graph slot — same unordered vertex pair and same (ori1 == ori2) class — are
+//     independent of all others, so the admitted edges are grouped by that key (stable: sequence
+//     order is kept inside a group);
+//   * inside a group the reference's replace / keep decisions (score, then the tie-break chain of
+//     src/EdgeCalculator.cpp:470-521) are replayed in sequence order: the survivor, the number of
+//     duplicates and the record that was inserted FIRST (it alone decides OverlapGraph::inclusions,
+//     :459-468) come out exactly as in the sequential loop;
+//   * an adjacency list holds its surviving edges in the order of their own insertion (a replaced
+//     edge is erased and the winner appended, :523-530), i.e. ordered by the survivors' sequence
+//     numbers: survivors are appended to the graph in that order.
+// The graph must not hold edges yet.  `admitted` is consumed (edges are normalised in place).
+void resolve_admitted_edges(OverlapGraph& g, const ProgramSettings& ps, std::vector<Edge>& admitted, InsertCounters& c);
+
 class EdgeCalculator {
 public:
     unsigned int self_overlap_count = 0;   // never incremented by the reference either (its counting code is commented out)
@@ -59,8 +74,11 @@ private:
     hc_settings m_cs;
     hc_ctx* m_ctx = nullptr;
     hc_overlap_rec* m_rec = nullptr;  // page-locked staging (hc_host_alloc), grow-only
-    hc_result_rec* m_res = nullptr;
+    hc_result_rec* m_res = nullptr;   // compacted: records of the non-DROP candidates only
+    uint32_t* m_idx = nullptr;        // their positions in the batch, ascending
     size_t m_cap = 0;
+    bool m_sorted_insert = false;     // HC_INSERT_MODE=sorted: resolve_admitted_edges() after the last batch instead of per-edge inserts
+    std::vector<Edge> m_admitted;     // admitted edges of the whole file, in sequence order (sorted insert)
     std::string m_nonedge_buf;
 };
 

@@ -144,6 +144,28 @@ int hc_host_graph_insert(hc_host_graph* g, const hc_edge_rec* r) {
     });
 }
 
+int hc_host_graph_resolve(hc_host_graph* g, const hc_edge_rec* edges, uint64_t n) {
+    if (!g || (!edges && n)) return set_last_error(HC_ERR_ARG, "hc_host_graph_resolve: null");
+    return guarded("resolve", [&] {
+        if (g->graph->getEdgeCount() != 0) throw FatalError{HC_ERR_STATE, "hc_host_graph_resolve needs an empty graph"};
+        std::vector<Edge> adm;
+        adm.reserve(n);
+        for (uint64_t i = 0; i < n; i++) {
+            const hc_edge_rec* r = &edges[i];
+            if (r->read1 >= g->reads.size() || r->read2 >= g->reads.size()) throw FatalError{HC_ERR_ARG, "read index out of range"};
+            Edge e(r->score, r->pos1, r->pos2, r->ori1 != 0, r->ori2 != 0, std::string(1, (char)r->ord), &g->reads[r->read1],
+                   &g->reads[r->read2]);
+            e.set_vertices(r->v1, r->v2);
+            e.set_extra_pos(r->pos3, r->pos4);
+            e.set_perc(r->perc);
+            e.set_len(r->len1, r->len2);
+            e.set_mismatch(r->mismatch_rate);
+            adm.push_back(e);
+        }
+        resolve_admitted_edges(*g->graph, g->ps, adm, g->counters);
+    });
+}
+
 int hc_host_graph_get(hc_host_graph* g, hc_edge_rec* out, uint64_t cap, uint64_t* n_out, uint8_t* inclusions,
                       hc_ec_counters* counters) {
     if (!g || !n_out) return set_last_error(HC_ERR_ARG, "hc_host_graph_get: null");

@@ -433,4 +433,72 @@ void insert_edge(OverlapGraph& g, const ProgramSettings& program_settings, Edge&
     g.addEdge(e);  // :530
 }
 
+// true when the reference keeps the existing edge although the new one scores at least as high
+// (src/EdgeCalculator.cpp:474-521; all-equal falls through to "replace")
+static inline bool chain_keeps_existing(const Edge& ex, const Edge& e) {
+    if (ex.get_len(0) != e.get_len(0)) return ex.get_len(0) > e.get_len(0);
+    if (ex.get_mismatch_rate() != e.get_mismatch_rate()) return ex.get_mismatch_rate() < e.get_mismatch_rate();
+    if (ex.get_vertex(1) != e.get_vertex(1)) return ex.get_vertex(1) < e.get_vertex(1);
+    if (ex.get_ori(1) != e.get_ori(1)) return ex.get_ori(1);
+    if (ex.get_ori(2) != e.get_ori(2)) return ex.get_ori(2);
+    if (ex.get_pos(1) != e.get_pos(1)) return ex.get_pos(1) < e.get_pos(1);
+    if (ex.get_pos(2) != e.get_pos(2)) return ex.get_pos(2) < e.get_pos(2);
+    return false;
+}
+
+void resolve_admitted_edges(OverlapGraph& g, const ProgramSettings& ps, std::vector<Edge>& admitted, InsertCounters& c) {
+    const size_t n = admitted.size();
+    if (n == 0) return;
+    struct Item {
+        uint64_t key;  // smaller vertex << 33 | larger vertex << 1 | (ori1 == ori2)
+        uint32_t seq;
+    };
+    std::vector<Item> items(n);
+    for (size_t i = 0; i < n; i++) {
+        Edge& e = admitted[i];
+        if (e.get_pos(1) == 0 && e.get_vertex(1) > e.get_vertex(2)) e.swap_reads();  // :443-448
+        if (e.get_perc() == 100) c.inclusion_count++;                                 // :449-451
+        const uint64_t a = e.get_vertex(1), b = e.get_vertex(2);
+        const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+        items[i].key = (lo << 33) | (hi << 1) | (uint64_t)(e.get_ori(1) == e.get_ori(2));
+        items[i].seq = (uint32_t)i;
+    }
+    std::sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.key != y.key ? x.key < y.key : x.seq < y.seq; });
+    std::vector<uint32_t> survivors;
+    survivors.reserve(n);
+    for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        while (j < n && items[j].key == items[i].key) j++;
+        const Edge& first = admitted[items[i].seq];  // the only record that is inserted into an empty slot: :455-469
+        if (ps.ignore_inclusions && first.get_perc() == 100 && first.get_mismatch_rate() < 0.000001 &&
+            first.get_mismatch_rate() >= 0) {
+            if (first.get_extra_pos(1) < 0) {
+                if (first.get_pos(1) == 0) g.inclusions[first.get_vertex(1)] = 1;
+            } else {
+                g.inclusions[first.get_vertex(2)] = 1;
+            }
+        }
+        uint32_t ex = items[i].seq;
+        for (size_t k = i + 1; k < j; k++) {  // the later records of the slot, in sequence order
+            c.dup_count++;
+            const Edge& e = admitted[items[k].seq];
+            const Edge& cur = admitted[ex];
+            if (!(e.get_score() >= cur.get_score())) continue;                                      // :535-538
+            if (e.get_score() == cur.get_score() && chain_keeps_existing(cur, e)) continue;        // :474-521
+            ex = items[k].seq;                                                                      // :523-530
+        }
+        survivors.push_back(ex);
+        i = j;
+    }
+    std::sort(survivors.begin(), survivors.end());
+    for (uint32_t sidx : survivors) g.addEdge(admitted[sidx]);
+    // edges_added counts first insertions (one per slot), as the sequential loop does
+    {
+        uint64_t slots = 0;
+        for (size_t i = 0; i < n; i++)
+            if (i == 0 || items[i].key != items[i - 1].key) slots++;
+        c.edges_added += slots;
+    }
+}
+
 }  // namespace hc

@@ -63,6 +63,7 @@ _sig = {
                                      C.POINTER(hc_ec_counters)]),
     "hc_host_graph_new": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.POINTER(N.hc_settings)]),
     "hc_host_graph_insert": (C.c_int, [_vp, _vp]),
+    "hc_host_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64]),
     "hc_host_graph_get": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), _vp, C.POINTER(hc_ec_counters)]),
     "hc_host_graph_free": (C.c_int, [_vp]),
 }
@@ -162,6 +163,10 @@ class HostGraph:
     def insert(self, edge_rec):
         e = np.ascontiguousarray(edge_rec, dtype=EDGE_DTYPE).reshape(1)
         return N.lib.hc_host_graph_insert(self._h, e.ctypes.data)
+
+    def resolve(self, edge_recs):
+        e = np.ascontiguousarray(edge_recs, dtype=EDGE_DTYPE)
+        return N.lib.hc_host_graph_resolve(self._h, e.ctypes.data, e.shape[0])
 
     def get(self):
         n = C.c_uint64()

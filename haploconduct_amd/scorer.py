@@ -68,6 +68,21 @@ class EdgeScorer:
         N.check(N.lib.hc_score_batch(self._ctx, _ptr(ov), ov.shape[0], _ptr(out)), "hc_score_batch")
         return out
 
+    def score_batch_compact(self, overlaps):
+        """hc_score_batch_compact: (indices, records) of the non-DROP candidates only."""
+        ov = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE)
+        n = ov.shape[0]
+        idx = np.empty(n, dtype=np.uint32)
+        res = np.empty(n, dtype=RESULT_DTYPE)
+        k = C.c_uint64()
+        N.check(N.lib.hc_score_batch_compact(self._ctx, _ptr(ov), n, _ptr(idx), _ptr(res), n, C.byref(k)),
+                "hc_score_batch_compact")
+        return idx[: k.value].copy(), res[: k.value].copy()
+
+    def compact_device(self, d_results_ptr, n, d_indices_ptr, d_count_ptr, stream=None):
+        N.check(N.lib.hc_compact_device(self._ctx, C.c_void_p(d_results_ptr), n, C.c_void_p(d_indices_ptr),
+                                        C.c_void_p(d_count_ptr), C.c_void_p(stream or 0)), "hc_compact_device")
+
     def score_batch_device(self, d_in_ptr, n, d_out_ptr, stream=None):
         """Device pointers (ints, e.g. torch tensor .data_ptr()); asynchronous."""
         N.check(N.lib.hc_score_batch_device(self._ctx, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr),

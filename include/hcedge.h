@@ -172,6 +172,20 @@ int hc_host_free(hc_ctx* ctx, void* ptr);
 int hc_score_batch_device(hc_ctx* ctx, const void* d_in, uint64_t n, void* d_out, void* hip_stream);
 int hc_synchronize(hc_ctx* ctx);
 
+/* Stream compaction of a scored batch: the indices (ascending = sequence order) of the records whose
+ * class is not HC_CLS_DROP — admitted edges, non-edges kept for FNO, ambiguous and error records —
+ * i.e. everything the host or the multi-GPU gather still has to look at (typically a few per cent).
+ * d_results: n hc_result_rec on the device; d_indices: room for n uint32; d_count: one uint64 on the
+ * device.  Asynchronous on `hip_stream` (NULL = the context's stream). */
+int hc_compact_device(hc_ctx* ctx, const void* d_results, uint64_t n, void* d_indices, void* d_count, void* hip_stream);
+
+/* hc_score_batch + compaction in one call for host callers: scores `in` on the device and copies back
+ * only the non-DROP records: idx_out[k] (ascending) and res_out[k] = result of in[idx_out[k]].
+ * cap = capacity of idx_out / res_out in records; *n_out = number of non-DROP records (if it exceeds
+ * cap, HC_ERR_ARG is returned and nothing is copied). */
+int hc_score_batch_compact(hc_ctx* ctx, const hc_overlap_rec* in, uint64_t n, uint32_t* idx_out, hc_result_rec* res_out,
+                           uint64_t cap, uint64_t* n_out);
+
 /* Times `iters` back-to-back launches of the scoring kernel on the context's own
  * stream with hipEvents recorded on THAT stream; returns the mean milliseconds
  * per launch.  Used for the roofline figure. */

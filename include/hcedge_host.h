@@ -101,6 +101,9 @@ int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* ove
 typedef struct hc_host_graph hc_host_graph;
 int hc_host_graph_new(hc_host_graph** out, uint64_t n_vertices, const hc_settings* settings);
 int hc_host_graph_insert(hc_host_graph* g, const hc_edge_rec* edge);
+/* The sort-based equivalent on an EMPTY graph: resolves n edges given in sequence
+ * order in one call; must leave the graph exactly as n hc_host_graph_insert calls would. */
+int hc_host_graph_resolve(hc_host_graph* g, const hc_edge_rec* edges, uint64_t n);
 int hc_host_graph_get(hc_host_graph* g, hc_edge_rec* out, uint64_t cap, uint64_t* n_out, uint8_t* inclusions,
                       hc_ec_counters* counters);
 int hc_host_graph_free(hc_host_graph* g);

@@ -291,3 +291,32 @@ def test_reorder_modes_give_identical_records(oracle):
         assert o.tobytes() == outs[0].tobytes()
     assert np.array_equal(outs[0]["x1"].view(np.uint64), ref["x1"].view(np.uint64))
     assert np.array_equal(result_n(outs[0]), ref["n"])
+
+
+def test_compaction_entry_points(oracle):
+    import torch
+
+    reads, meta = synth.make_paired_dataset(2000, 3000, flip_frac=0.2, seed=121)
+    reads.quals[:] = HQ[np.random.default_rng(2).integers(0, HQ.size, reads.quals.size)]
+    cand = synth.paired_candidates(meta, n_candidates=50000, seed=122)
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.9)
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        full = sc.score_batch(cand)
+        idx, res = sc.score_batch_compact(cand)
+        keep = np.nonzero(result_cls(full) != 0)[0]
+        assert 0 < keep.size < cand.size
+        assert np.array_equal(idx, keep) and res.tobytes() == full[keep].tobytes()
+        # device-resident form
+        d_in = torch.from_numpy(cand.view(np.uint8).reshape(-1)).cuda()
+        d_out = torch.empty(cand.size * 24, dtype=torch.uint8, device="cuda")
+        d_idx = torch.zeros(cand.size, dtype=torch.int32, device="cuda")
+        d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        sc.score_batch_device(d_in.data_ptr(), cand.size, d_out.data_ptr())
+        sc.compact_device(d_out.data_ptr(), cand.size, d_idx.data_ptr(), d_cnt.data_ptr())
+        sc.synchronize()
+        k = int(d_cnt.item())
+        assert k == keep.size and np.array_equal(d_idx[:k].cpu().numpy().view(np.uint32), keep)
+        empty_idx, empty_res = sc.score_batch_compact(cand[:0])
+        assert empty_idx.size == 0

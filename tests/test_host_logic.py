@@ -206,3 +206,9 @@ def test_serial_insert_and_tie_break_chain_match_oracle(oracle):
         assert np.array_equal(inc, og.inclusions())
         assert c["dup_count"] == oc.dup_count > 1000 and c["inclusion_count"] == oc.inclusion_count
         assert c["edges_added"] == oc.edges_added
+        # the sort-based resolution must leave the identical graph and counters
+        g2 = host.HostGraph(V, st)
+        assert g2.resolve(stream) == 0
+        edges2, inc2, c2 = g2.get()
+        assert edges2.tobytes() == edges.tobytes() and np.array_equal(inc2, inc)
+        assert (c2["dup_count"], c2["inclusion_count"], c2["edges_added"]) == (c["dup_count"], c["inclusion_count"], c["edges_added"])
