@@ -59,7 +59,8 @@ struct hc_ctx {
     hc_settings settings;
     int device = 0;
     uint32_t n_cu = 256;
-    int variant = 2;  // scoring-kernel variant (HC_SCORE_VARIANT overrides; tuning knob, results are identical)
+    int variant = -1;  // scoring-kernel variant: -1 = chosen per read set in hc_set_reads (HC_SCORE_VARIANT overrides;
+                       // a tuning knob only, results are identical)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // read store
@@ -350,6 +351,12 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     c->view.lut_bytes = (uint32_t)(lut.size() * sizeof(double));
     c->store_bytes = sym_bytes_total;
     c->have_reads = true;
+    if (!getenv("HC_SCORE_VARIANT")) {
+        // 64-symbol fetch groups (variant 4) for short-read sets, 32-symbol groups (variant 5) when the
+        // sequences are long (contigs): measured on BASELINE configs 2-5, see DESIGN.md
+        const uint64_t mean_len = n_seq ? total / n_seq : 0;
+        c->variant = mean_len > 600 ? 5 : 4;
+    }
     return HC_OK;
 }
 

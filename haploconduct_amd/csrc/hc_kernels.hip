@@ -471,6 +471,83 @@ __device__ __forceinline__ void score_subs(const SymT* __restrict__ sym, const S
     }
 }
 
+// One sub-overlap with 64-symbol fetch groups: a lane pulls four consecutive 16-byte pieces of each
+// stream back to back (one whole 64-byte line of an aligned stream), so a line is fetched into L1 once
+// and consumed at once instead of being re-requested by four separate loop iterations that other
+// waves' lines evict in between.  The next group is prefetched while the current one is scored.
+template <typename SymT, int LG, int G /* 16-symbol chunks per group */>
+__device__ __forceinline__ void score_sub_wide(const SymT* __restrict__ sym, const Sub& s, const char* lut,
+                                               const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word,
+                                               uint32_t min_read_len, SubScore& out) {
+    using T = Tr<SymT>;
+    out.x = -__builtin_inf();
+    out.mm = 1;
+    out.n = 1;
+    out.err = s.fatal;
+    const uint32_t L = sub_positions(s, min_read_len);
+    if (L == 0) return;
+    const uint32_t nch = (L + 15u) >> 4;
+    const SymT* a = sym + s.offA + s.pos;
+    const SymT* b = sym + s.offB;
+    double S = 0.0;
+    uint32_t skipped = 0, cm = 0;
+    uint32_t na[G][T::kWords] = {}, nb[G][T::kWords] = {};
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+        if ((uint32_t)q < nch) {
+            __builtin_memcpy(na[q], a + 16u * q, sizeof(na[q]));
+            __builtin_memcpy(nb[q], b + 16u * q, sizeof(nb[q]));
+        }
+    for (uint32_t c0 = 0; c0 < nch; c0 += G) {
+        uint32_t ca[G][T::kWords], cb[G][T::kWords];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+#pragma unroll
+            for (int w = 0; w < T::kWords; ++w) {
+                ca[q][w] = na[q][w];
+                cb[q][w] = nb[q][w];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+            if (c0 + G + q < nch) {
+                __builtin_memcpy(na[q], a + 16u * (c0 + G + q), sizeof(na[q]));
+                __builtin_memcpy(nb[q], b + 16u * (c0 + G + q), sizeof(nb[q]));
+            }
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const uint32_t c = c0 + q;
+            if (c < nch) {
+                uint32_t keep[T::kWords];
+                const uint32_t rem = L - 16u * c;
+                __builtin_memcpy(keep, masktab + (rem >= 16u ? 16u : rem) * T::kWords, sizeof(keep));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double t[8];
+                    half_chunk_terms<SymT, LG>(ca[q] + h * (T::kWords / 2), cb[q] + h * (T::kWords / 2), keep + h * (T::kWords / 2),
+                                               nsym_word, lut, Kp, t, skipped, cm);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) S += t[k];  // :119, strictly in position order
+                }
+            }
+        }
+    }
+    if (S != S) {  // an invalid symbol inside the window
+        const SubScore e = score_sub_slow<SymT>(a, b, L, lut, Kp);
+        out.x = e.x;
+        out.mm = e.mm;
+        out.n = e.n;
+        out.err |= e.err;
+        return;
+    }
+    if (S == __builtin_inf()) return;
+    const uint32_t cn = 16u * nch - skipped;
+    if (cn == 0) return;
+    out.x = (1.0 / (double)cn) * S;
+    out.mm = cm;
+    out.n = cn;
+}
+
 // exp(x) > T  in x-space: 1 pass, 0 fail, 2 ambiguous
 __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return x > b.hi ? 1u : (x <= b.lo ? 0u : 2u); }
 
@@ -522,7 +599,11 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
         s2.n = 1;
         s2.err = 0;
         constexpr bool kPre = (VAR & 2) != 0;
-        if (ns == 2) {
+        if (VAR & 4) {
+            constexpr int kG = (VAR & 3) == 0 ? 4 : ((VAR & 3) == 1 ? 2 : ((VAR & 3) == 2 ? 8 : 3));
+            score_sub_wide<SymT, LG, kG>(sym, sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, s1);
+            if (ns == 2) score_sub_wide<SymT, LG, kG>(sym, sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, s2);
+        } else if (ns == 2) {
             if (VAR & 1) {
                 const Sub subs[2] = {sub0, sub1};
                 SubScore r[2];
@@ -943,6 +1024,13 @@ template <typename SymT, int LG>
 static hipError_t launch_score_lg(int var, const StoreView& st, const ScoreParams& prm, const double* lut_g,
                                   const hc_overlap_rec* in, uint64_t n, hc_result_rec* out, const uint32_t* perm,
                                   uint32_t blocks, size_t lds, hipStream_t stream) {
+    switch (var & 7) {
+        case 4: launch_score_one<SymT, 4, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); return hipGetLastError();
+        case 5: launch_score_one<SymT, 5, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); return hipGetLastError();
+        case 6: launch_score_one<SymT, 6, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); return hipGetLastError();
+        case 7: launch_score_one<SymT, 7, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); return hipGetLastError();
+        default: break;
+    }
     switch (var & 3) {
         case 0: launch_score_one<SymT, 0, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
         case 1: launch_score_one<SymT, 1, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); break;
@@ -1017,6 +1105,10 @@ static hipError_t set_lds_limit_lg() {
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 1, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 2, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 3, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 4, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 5, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 6, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 7, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)score_kernel_staged<SymT, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
 }
 hipError_t set_score_kernel_lds_limit() {
