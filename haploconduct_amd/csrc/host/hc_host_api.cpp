@@ -15,7 +15,31 @@ struct hc_host_graph {
     InsertCounters counters;
 };
 
+namespace hc {
+std::string sfo_to_overlaps(const std::string& sfo_text, long ns, long np, uint64_t& n_lines);  // Sfo2Overlaps.cpp
+}
+
 extern "C" {
+
+int hc_sfo2overlaps(const char* sfo_path, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines) {
+    if (!sfo_path || !out_path) return set_last_error(HC_ERR_ARG, "hc_sfo2overlaps: null path");
+    return guarded("sfo2overlaps", [&] {
+        FILE* f = fopen(sfo_path, "rb");
+        if (!f) throw FatalError{HC_ERR_IO, std::string("cannot open ") + sfo_path};
+        std::string text;
+        char buf[1 << 16];
+        size_t k;
+        while ((k = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, k);
+        fclose(f);
+        uint64_t n = 0;
+        const std::string out = hc::sfo_to_overlaps(text, (long)num_singles, (long)num_pairs, n);
+        FILE* o = fopen(out_path, "wb");
+        if (!o) throw FatalError{HC_ERR_IO, std::string("cannot write ") + out_path};
+        fwrite(out.data(), 1, out.size(), o);
+        fclose(o);
+        if (n_lines) *n_lines = n;
+    });
+}
 
 int hc_host_split_line(const char* line, uint64_t n, int allow_spaces, uint32_t* off, uint32_t* len, int max_fields) {
     if (!line || max_fields < 0 || max_fields > 64) return HC_ERR_ARG;

@@ -61,6 +61,7 @@ _sig = {
     "hc_host_fastq_free": (C.c_int, [_vp]),
     "hc_host_parse_file": (C.c_int, [C.POINTER(N.hc_settings), _vp, C.c_char_p, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                      C.POINTER(hc_ec_counters)]),
+    "hc_sfo2overlaps": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_host_graph_new": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.POINTER(N.hc_settings)]),
     "hc_host_graph_insert": (C.c_int, [_vp, _vp]),
     "hc_host_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64]),
@@ -99,6 +100,13 @@ def parse_overlap(line, allow_spaces=False):
     return 0, {"id1": o.id1, "id2": o.id2, "pos1": o.pos1, "pos2": o.pos2, "ord": o.ord.decode(), "ori1": o.ori1.decode(),
                "ori2": o.ori2.decode(), "type1": o.type1.decode(), "type2": o.type2.decode(), "perc": o.perc,
                "len1": o.len1, "len2": o.len2, "line": text.value.decode()}
+
+
+def sfo2overlaps(sfo_path, out_path, num_singles, num_pairs):
+    """scripts/sfo2overlaps.py --in --out --num_singles --num_pairs, natively (hc_sfo2overlaps)."""
+    n = C.c_uint64()
+    N.check(N.lib.hc_sfo2overlaps(_b(sfo_path), _b(out_path), num_singles, num_pairs, C.byref(n)), "hc_sfo2overlaps")
+    return int(n.value)
 
 
 class Fastq:

@@ -97,6 +97,11 @@ int hc_host_fastq_free(hc_fastq* f);
 int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* overlaps_path, hc_overlap_rec* out,
                        uint64_t cap, uint64_t* n_out, hc_ec_counters* counters);
 
+/* SFO ingest: rust-overlaps' 8-column SFO file -> SAVAGE's 13-column overlaps file with
+ * the semantics of the reference's scripts/sfo2overlaps.py (--in, --out, --num_singles, --num_pairs),
+ * including its sort / uniq passes.  *n_lines receives the number of overlap lines written. */
+int hc_sfo2overlaps(const char* sfo_path, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines);
+
 /* The serial insert of process_overlaps (src/EdgeCalculator.cpp:441-538) on a bare graph. */
 typedef struct hc_host_graph hc_host_graph;
 int hc_host_graph_new(hc_host_graph** out, uint64_t n_vertices, const hc_settings* settings);

@@ -82,6 +82,16 @@ for _ in range(5000):
     assert host.hc_host_graph_insert(g, rec) == 0
 host.hc_host_graph_free(g)
 
+# 3b. SFO ingest on plausible and hostile files
+host.hc_sfo2overlaps.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p]
+sfo = []
+for _ in range(5000):
+    a, b = rng.randrange(120), rng.randrange(120)
+    sfo.append("%d %d %s %d %d %d %d %d" % (a, b, rng.choice("NNI"), rng.randrange(-100, 100), rng.randrange(-100, 100), rng.randrange(1, 150), rng.randrange(1, 150), rng.randrange(3)))
+assert host.hc_sfo2overlaps(w("a.sfo", "\n".join(sfo).encode()), (d + "a.out").encode(), 40, 40, None) == 0
+for bad in (b"", b"\n\n", b"1 2 N 3\n", b"1 2 N 0 0 0 0 0\n", b"1 2 N a b c d e\n", b"999 2 N 1 1 1 1 0\n", b"1 2 " + b"N" * 5000 + b" 1 1 1 1 0\n"):
+    host.hc_sfo2overlaps(w("b.sfo", bad), (d + "b.out").encode(), 40, 40, None)
+
 # 4. oracle on odd inputs
 orc.hco_overlap_score.restype = C.c_double
 mr = C.c_double(); x = C.c_double(); mm = C.c_uint32(); nn = C.c_uint32(); pos = C.c_uint64(); stt = C.c_int()
@@ -103,7 +113,8 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
                           'extern "C" { const char* hc_strerror(int) { return ""; } const char* hc_last_error(void) { return ""; } }\n')
     san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-fPIC", "-shared"]
     r = subprocess.run(["g++", "-std=c++17", *san, "-pthread", "-o", host_so, os.path.join(hd, "host_model.cpp"),
-                        os.path.join(hd, "OverlapsParser.cpp"), os.path.join(hd, "hc_host_api.cpp"), stub],
+                        os.path.join(hd, "OverlapsParser.cpp"), os.path.join(hd, "hc_host_api.cpp"),
+                        os.path.join(hd, "Sfo2Overlaps.cpp"), stub],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run(["gcc", "-std=gnu11", "-ffp-contract=off", "-fopenmp", *san, "-o", orc_so,

@@ -1,0 +1,71 @@
+"""SFO ingest: the native hc_sfo2overlaps and the Python oracle restatement against
+outputs of the reference's own scripts/sfo2overlaps.py (tests/golden/sfo/, see make_golden_sfo.py),
+plus native-vs-oracle on fresh seeded inputs.  No GPU needed."""
+import glob
+import os
+import sys
+
+import pytest
+
+import haploconduct_amd as hc
+from haploconduct_amd import host
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from sfo2overlaps_oracle import sfo2overlaps as oracle_sfo2overlaps  # noqa: E402
+
+CASES = sorted(glob.glob(os.path.join(HERE, "golden", "sfo", "*.sfo")))
+
+
+@pytest.mark.parametrize("sfo", CASES, ids=[os.path.basename(c) for c in CASES])
+def test_against_reference_script_outputs(sfo, tmp_path):
+    s, p = map(int, open(sfo[:-4] + ".args").read().split())
+    want = open(sfo[:-4] + ".expected", "rb").read()
+    assert len(want) > 1000
+    got_oracle = "".join(l + "\n" for l in oracle_sfo2overlaps(open(sfo).read().splitlines(), s, p)).encode()
+    assert got_oracle == want, "oracle restatement differs from the reference script"
+    out = str(tmp_path / "overlaps.txt")
+    n = host.sfo2overlaps(sfo, out, s, p)
+    assert open(out, "rb").read() == want, "native ingest differs from the reference script"
+    assert n == want.count(b"\n")
+
+
+def test_native_equals_oracle_on_fresh_inputs(tmp_path):
+    from make_golden_sfo import synth_sfo
+
+    for seed, s, p, n, sep in ((11, 50, 0, 2000, "\t"), (12, 0, 60, 3000, " "), (13, 40, 40, 4000, "\t"), (14, 5, 200, 6000, "\t")):
+        lines = synth_sfo(seed, s, p, n, sep)
+        sfo = str(tmp_path / f"in{seed}.sfo")
+        open(sfo, "w").write("\n".join(lines))  # no trailing newline
+        want = "".join(l + "\n" for l in oracle_sfo2overlaps(lines, s, p))
+        out = str(tmp_path / f"out{seed}.txt")
+        host.sfo2overlaps(sfo, out, s, p)
+        assert open(out).read() == want
+        assert len(want) > 5000
+
+
+def test_the_output_feeds_the_overlaps_parser(tmp_path):
+    # every line the ingest writes is a well-formed 13-column record for the stage's parser
+    sfo = CASES[0]
+    s, p = map(int, open(sfo[:-4] + ".args").read().split())
+    out = str(tmp_path / "overlaps.txt")
+    host.sfo2overlaps(sfo, out, s, p)
+    for line in open(out).read().splitlines():
+        rc, o = host.parse_overlap(line)
+        assert rc == 0 and o["type1"] in "sp" and o["type2"] in "sp"
+
+
+def test_errors(tmp_path):
+    bad = str(tmp_path / "bad.sfo")
+    open(bad, "w").write("1 2 N 3 4 5\n")
+    with pytest.raises(hc.HcError):
+        host.sfo2overlaps(bad, str(tmp_path / "o.txt"), 10, 0)
+    open(bad, "w").write("1 2 N x 4 5 6 0\n")
+    with pytest.raises(hc.HcError):
+        host.sfo2overlaps(bad, str(tmp_path / "o.txt"), 10, 0)
+    open(bad, "w").write("1 99 N 3 4 5 6 0\n")
+    with pytest.raises(hc.HcError):
+        host.sfo2overlaps(bad, str(tmp_path / "o.txt"), 5, 5)  # id out of range
+    with pytest.raises(hc.HcError):
+        host.sfo2overlaps(str(tmp_path / "missing.sfo"), str(tmp_path / "o.txt"), 1, 0)
