@@ -351,6 +351,15 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     c->view.lut_bytes = (uint32_t)(lut.size() * sizeof(double));
     c->store_bytes = sym_bytes_total;
     c->have_reads = true;
+    {
+        uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
+        for (uint32_t q = 0; q < n_seq; q++) {
+            lmin = seq_len[q] < lmin ? seq_len[q] : lmin;
+            lmax = seq_len[q] > lmax ? seq_len[q] : lmax;
+        }
+        c->view.balance = (n_seq && lmax > 2u * lmin) ? 1u : 0u;  // mixed-length read set (contigs + reads)
+        if (const char* b = getenv("HC_BALANCE")) c->view.balance = atoi(b) != 0;
+    }
     if (!getenv("HC_SCORE_VARIANT")) {
         // 64-symbol fetch groups (variant 4) for short-read sets, 32-symbol groups (variant 5) when the
         // sequences are long (contigs): measured on BASELINE configs 2-5, see DESIGN.md

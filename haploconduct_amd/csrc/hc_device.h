@@ -58,6 +58,7 @@ struct StoreView {
     uint32_t K;         // quality alphabet size; table dimension Kp = K + 2
     uint32_t symbytes;  // 1 or 2
     uint32_t lut_bytes; // bytes of the log table as laid out for this symbol width
+    uint32_t balance;   // 1: sequence lengths differ widely -> block-local length balancing in the scoring kernel
 };
 
 // Log table layouts (doubles):

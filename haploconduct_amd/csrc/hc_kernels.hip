@@ -551,9 +551,86 @@ __device__ __forceinline__ void score_sub_wide(const SymT* __restrict__ sym, con
 // exp(x) > T  in x-space: 1 pass, 0 fail, 2 ambiguous
 __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return x > b.hi ? 1u : (x <= b.lo ? 0u : 2u); }
 
-// VAR bit0: interleave the two sub-overlaps of a candidate; bit1: software prefetch of the next
-// chunk.  LG: log2 of the 8-bit-symbol table dimension (3, 4 or 5; ignored for 16-bit symbols).
+// One candidate, one lane: score its sub-overlaps and write the result record.
 template <typename SymT, int VAR, int LG>
+__device__ __forceinline__ void score_candidate(const ScoreParams& prm, const SymT* __restrict__ sym, const char* lut,
+                                                const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word, int ns,
+                                                const Sub& sub0, const Sub& sub1, uint64_t i,
+                                                hc_result_rec* __restrict__ out) {
+    hc_result_rec res;
+    if (ns == 0) {
+        res.x1 = -__builtin_inf();
+        res.x2 = __builtin_nan("");
+        res.mm = 1;
+        res.n_cls = 1u | (HC_CLS_ERROR << 28);
+        out[i] = res;
+        return;
+    }
+    SubScore s1, s2;
+    s2.x = __builtin_nan("");
+    s2.mm = 0;
+    s2.n = 1;
+    s2.err = 0;
+    constexpr bool kPre = (VAR & 2) != 0;
+    if (VAR & 4) {
+        constexpr int kG = (VAR & 3) == 0 ? 4 : ((VAR & 3) == 1 ? 2 : ((VAR & 3) == 2 ? 8 : 3));
+        score_sub_wide<SymT, LG, kG>(sym, sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, s1);
+        if (ns == 2) score_sub_wide<SymT, LG, kG>(sym, sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, s2);
+    } else if (ns == 2) {
+        if (VAR & 1) {
+            const Sub subs[2] = {sub0, sub1};
+            SubScore r[2];
+            score_subs<SymT, 2, kPre, LG>(sym, subs, lut, masktab, Kp, nsym_word, prm.min_read_len, r);
+            s1 = r[0];
+            s2 = r[1];
+        } else {
+            score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
+            score_subs<SymT, 1, kPre, LG>(sym, &sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, &s2);
+        }
+    } else {
+        score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
+    }
+
+    // mismatch_rate = float(mismatch_count)/total_len (:132); std::max over the two (:254)
+    const double m1 = (double)(float)s1.mm / (double)s1.n;
+    uint32_t mm = s1.mm, nn = s1.n;
+    double mrate = m1;
+    if (ns == 2) {
+        const double m2 = (double)(float)s2.mm / (double)s2.n;
+        if (m1 < m2) {
+            mrate = m2;
+            mm = s2.mm;
+            nn = s2.n;
+        }
+    }
+    // :404-413 in x-space; flags bit0 / bit1: threshold < 0, every score (0 included) passes
+    const bool e_all = prm.flags & 1u, o_all = prm.flags & 2u;
+    uint32_t e = e_all ? 1u : band_test(s1.x, prm.edge);
+    uint32_t o = o_all ? 1u : band_test(s1.x, prm.ov);
+    if (ns == 2) {
+        const uint32_t e2 = e_all ? 1u : band_test(s2.x, prm.edge), o2 = o_all ? 1u : band_test(s2.x, prm.ov);
+        e = (e == 0 || e2 == 0) ? 0u : ((e == 1 && e2 == 1) ? 1u : 2u);
+        o = (o == 0 || o2 == 0) ? 0u : ((o == 1 && o2 == 1) ? 1u : 2u);
+    }
+    uint32_t cls;
+    if (s1.err | s2.err) cls = HC_CLS_ERROR;
+    else if (e == 1) cls = HC_CLS_EDGE;
+    else if (e == 2) cls = HC_CLS_AMBIG;
+    else if (mrate <= prm.merge_contigs) cls = HC_CLS_EDGE_MC;
+    else if (o == 1) cls = HC_CLS_NONEDGE;
+    else if (o == 2) cls = HC_CLS_AMBIG;
+    else cls = HC_CLS_DROP;
+    res.x1 = s1.x;
+    res.x2 = s2.x;
+    res.mm = mm;
+    res.n_cls = (nn & 0x0FFFFFFFu) | (cls << 28);
+    out[i] = res;
+}
+
+// VAR bit0: interleave the two sub-overlaps of a candidate; bit1: software prefetch of the next
+// chunk; bit2: 64/32/128/48-symbol fetch groups (score_sub_wide).  LG: log2 of the 8-bit-symbol table
+// dimension (3..6; ignored for 16-bit symbols).  BAL: block-local length balancing (below).
+template <typename SymT, int VAR, int LG, bool BAL>
 __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                     const hc_overlap_rec* __restrict__ in, uint64_t n,
                                                     hc_result_rec* __restrict__ out,
@@ -570,88 +647,108 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
     const uint32_t Kp = st.K + 2u;
     const uint32_t nsym = (sizeof(SymT) == 1 && LG == 6) ? (kWideN << 2) : ((st.K << 3) | kCodeN);
     const uint32_t nsym_word = sizeof(SymT) == 1 ? nsym * 0x01010101u : nsym * 0x00010001u;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += stride) {
-        // with a permutation, lane `slot` scores candidate perm[slot] (neighbouring lanes share reads) and
-        // writes its record back to the candidate's own position: out[i] <-> in[i] always holds
-        const uint64_t i = perm ? (uint64_t)perm[slot] : slot;
-        hc_overlap_rec rec;
-        {
-            const uint4* p = (const uint4*)(in + i);
-            const uint4 a = p[0], b = p[1];
-            __builtin_memcpy(&rec, &a, 16);
-            __builtin_memcpy((char*)&rec + 16, &b, 16);
-        }
-        Sub sub0, sub1;
-        const int ns = resolve<(int)sizeof(SymT)>(st, rec, sub0, sub1);
-        hc_result_rec res;
-        if (ns == 0) {
-            res.x1 = -__builtin_inf();
-            res.x2 = __builtin_nan("");
-            res.mm = 1;
-            res.n_cls = 1u | (HC_CLS_ERROR << 28);
-            out[i] = res;
-            continue;
-        }
-        SubScore s1, s2;
-        s2.x = __builtin_nan("");
-        s2.mm = 0;
-        s2.n = 1;
-        s2.err = 0;
-        constexpr bool kPre = (VAR & 2) != 0;
-        if (VAR & 4) {
-            constexpr int kG = (VAR & 3) == 0 ? 4 : ((VAR & 3) == 1 ? 2 : ((VAR & 3) == 2 ? 8 : 3));
-            score_sub_wide<SymT, LG, kG>(sym, sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, s1);
-            if (ns == 2) score_sub_wide<SymT, LG, kG>(sym, sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, s2);
-        } else if (ns == 2) {
-            if (VAR & 1) {
-                const Sub subs[2] = {sub0, sub1};
-                SubScore r[2];
-                score_subs<SymT, 2, kPre, LG>(sym, subs, lut, masktab, Kp, nsym_word, prm.min_read_len, r);
-                s1 = r[0];
-                s2 = r[1];
-            } else {
-                score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
-                score_subs<SymT, 1, kPre, LG>(sym, &sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, &s2);
+    // with a permutation, slot s scores candidate perm[s] (neighbouring lanes share reads) and writes its
+    // record back to the candidate's own position: out[i] <-> in[i] always holds
+    if (!BAL) {
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += stride) {
+            const uint64_t i = perm ? (uint64_t)perm[slot] : slot;
+            hc_overlap_rec rec;
+            {
+                const uint4* p = (const uint4*)(in + i);
+                const uint4 a = p[0], b = p[1];
+                __builtin_memcpy(&rec, &a, 16);
+                __builtin_memcpy((char*)&rec + 16, &b, 16);
             }
-        } else {
-            score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
+            Sub sub0, sub1;
+            const int ns = resolve<(int)sizeof(SymT)>(st, rec, sub0, sub1);
+            score_candidate<SymT, VAR, LG>(prm, sym, lut, masktab, Kp, nsym_word, ns, sub0, sub1, i, out);
         }
-
-        // mismatch_rate = float(mismatch_count)/total_len (:132); std::max over the two (:254)
-        const double m1 = (double)(float)s1.mm / (double)s1.n;
-        uint32_t mm = s1.mm, nn = s1.n;
-        double mrate = m1;
-        if (ns == 2) {
-            const double m2 = (double)(float)s2.mm / (double)s2.n;
-            if (m1 < m2) {
-                mrate = m2;
-                mm = s2.mm;
-                nn = s2.n;
+        return;
+    }
+    // Block-local length balancing (read sets with mixed sequence lengths).  A wave runs as long as its
+    // longest lane; with mixed-length contigs (BASELINE config 5) the mean lane is busy 29 % of that time.
+    // When the overlap lengths of the 256 candidates of this workgroup differ widely, they are
+    // redistributed over the lanes by length (LDS counting sort over quarter-octave length classes, longest
+    // first), so every wave gets similar work; the candidates stay inside their workgroup, which keeps the
+    // read-sharing locality (reordering over larger windows measured slower).
+    uint32_t* bal = masktab + 17 * Tr<SymT>::kWords;  // [0..127] class histogram / offsets, [128..383] order, [384..391] reduce
+    const uint32_t tid = threadIdx.x;
+    for (uint64_t block_base = (uint64_t)blockIdx.x * blockDim.x; block_base < n; block_base += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t slot = block_base + tid;
+        // phase 1: the length class of the candidate in this lane's own slot (its state is dead before phase 2)
+        uint32_t chunks = 0;
+        if (slot < n) {
+            const hc_overlap_rec rec = in[perm ? (uint64_t)perm[slot] : slot];
+            Sub s0, s1;
+            const int ns = resolve<(int)sizeof(SymT)>(st, rec, s0, s1);
+            if (ns >= 1) chunks = (sub_positions(s0, prm.min_read_len) + 15u) >> 4;
+            if (ns == 2) {
+                const uint32_t c1 = (sub_positions(s1, prm.min_read_len) + 15u) >> 4;
+                chunks = c1 > chunks ? c1 : chunks;
             }
         }
-        // :404-413 in x-space; flags bit0 / bit1: threshold < 0, every score (0 included) passes
-        const bool e_all = prm.flags & 1u, o_all = prm.flags & 2u;
-        uint32_t e = e_all ? 1u : band_test(s1.x, prm.edge);
-        uint32_t o = o_all ? 1u : band_test(s1.x, prm.ov);
-        if (ns == 2) {
-            const uint32_t e2 = e_all ? 1u : band_test(s2.x, prm.edge), o2 = o_all ? 1u : band_test(s2.x, prm.ov);
-            e = (e == 0 || e2 == 0) ? 0u : ((e == 1 && e2 == 1) ? 1u : 2u);
-            o = (o == 0 || o2 == 0) ? 0u : ((o == 1 && o2 == 1) ? 1u : 2u);
+        uint32_t wmax = chunks, wsum = chunks;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t m = (uint32_t)__shfl_xor((int)wmax, o, 64);
+            wmax = m > wmax ? m : wmax;
+            wsum += (uint32_t)__shfl_xor((int)wsum, o, 64);
         }
-        uint32_t cls;
-        if (s1.err | s2.err) cls = HC_CLS_ERROR;
-        else if (e == 1) cls = HC_CLS_EDGE;
-        else if (e == 2) cls = HC_CLS_AMBIG;
-        else if (mrate <= prm.merge_contigs) cls = HC_CLS_EDGE_MC;
-        else if (o == 1) cls = HC_CLS_NONEDGE;
-        else if (o == 2) cls = HC_CLS_AMBIG;
-        else cls = HC_CLS_DROP;
-        res.x1 = s1.x;
-        res.x2 = s2.x;
-        res.mm = mm;
-        res.n_cls = (nn & 0x0FFFFFFFu) | (cls << 28);
-        out[i] = res;
+        if ((tid & 63u) == 0) {
+            bal[384 + (tid >> 6)] = wmax;
+            bal[388 + (tid >> 6)] = wsum;
+        }
+        if (tid < 128) bal[tid] = 0;
+        __syncthreads();
+        uint32_t bmax = 0, bsum = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+            bmax = bal[384 + w] > bmax ? bal[384 + w] : bmax;
+            bsum += bal[388 + w];
+        }
+        // worth it when the longest overlap is at least twice the block's mean and there is real work to balance
+        if (bmax >= 16u && (uint64_t)bmax * blockDim.x > 2ull * bsum) {
+            uint32_t cls = 0;  // quarter-octave class of the chunk count
+            if (chunks > 1) {
+                const uint32_t lg = 31u - (uint32_t)__builtin_clz(chunks);
+                cls = lg * 4u + (lg >= 2 ? (chunks >> (lg - 2)) & 3u : 0u);
+            }
+            cls = cls > 127u ? 127u : cls;
+            atomicAdd(&bal[cls], 1u);
+            __syncthreads();
+            if (tid < 64) {  // exclusive scan over the classes, longest class first
+                const uint32_t c0 = bal[127 - 2 * tid], c1 = bal[126 - 2 * tid];
+                uint32_t incl = c0 + c1;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+                    if ((int)tid >= o) incl += up;
+                }
+                const uint32_t excl = incl - (c0 + c1);
+                bal[127 - 2 * tid] = excl;
+                bal[126 - 2 * tid] = excl + c0;
+            }
+            __syncthreads();
+            const uint32_t at = atomicAdd(&bal[cls], 1u);
+            bal[128 + at] = tid;
+            __syncthreads();
+            slot = block_base + bal[128 + tid];
+        }
+        __syncthreads();  // bal is reused by the next iteration
+        // phase 2: score the candidate of the (possibly reassigned) slot
+        if (slot < n) {
+            const uint64_t i = perm ? (uint64_t)perm[slot] : slot;
+            hc_overlap_rec rec;
+            {
+                const uint4* p = (const uint4*)(in + i);
+                const uint4 a = p[0], b = p[1];
+                __builtin_memcpy(&rec, &a, 16);
+                __builtin_memcpy((char*)&rec + 16, &b, 16);
+            }
+            Sub sub0, sub1;
+            const int ns = resolve<(int)sizeof(SymT)>(st, rec, sub0, sub1);
+            score_candidate<SymT, VAR, LG>(prm, sym, lut, masktab, Kp, nsym_word, ns, sub0, sub1, i, out);
+        }
     }
 }
 
@@ -1017,7 +1114,12 @@ template <typename SymT, int VAR, int LG>
 static void launch_score_one(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
                              uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t blocks, size_t lds,
                              hipStream_t stream) {
-    hipLaunchKernelGGL((score_kernel<SymT, VAR, LG>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out, perm);
+    if (st.balance)
+        hipLaunchKernelGGL((score_kernel<SymT, VAR, LG, true>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out,
+                           perm);
+    else
+        hipLaunchKernelGGL((score_kernel<SymT, VAR, LG, false>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out,
+                           perm);
 }
 
 template <typename SymT, int LG>
@@ -1053,7 +1155,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         hipStream_t stream) {
     if (n == 0) return hipSuccess;
     static const size_t lds_pad = getenv("HC_LDS_PAD") ? (size_t)atol(getenv("HC_LDS_PAD")) : 0;  // occupancy experiments
-    const size_t lds = st.lut_bytes + 17 * (st.symbytes == 1 ? 4 : 8) * sizeof(uint32_t) + lds_pad;
+    const size_t lds = st.lut_bytes + (17 * (st.symbytes == 1 ? 4 : 8) + 392) * sizeof(uint32_t) + lds_pad;
     const uint32_t block = 256;
     const uint32_t lg = lut_lg(st.K);
     const size_t lds_staged = lds + 16 + 4 * kStageWaveBytes;
@@ -1101,14 +1203,22 @@ template <typename SymT, int LG>
 static hipError_t set_lds_limit_lg() {
     const int kMax = 160 * 1024;  // allow the full 160 KiB of LDS for large quality alphabets
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 0, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 1, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 2, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 3, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 4, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 5, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 6, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 7, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 0, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 0, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 1, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 1, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 2, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 2, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 3, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 3, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 4, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 4, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 5, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 5, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 6, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 6, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 7, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 7, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)score_kernel_staged<SymT, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
 }
 hipError_t set_score_kernel_lds_limit() {

@@ -29,6 +29,19 @@ def main():
         cand = cand[np.argsort(cand["read1"], kind="stable")]
     elif args.order == "shuffled":
         cand = cand[np.random.default_rng(5).permutation(cand.size)]
+    elif args.order.startswith("sfo-w"):
+        # experiment: inside windows of W consecutive candidates, order by overlap length (longest first)
+        W = int(args.order[5:])
+        lens = (reads.seq_off[1:] - reads.seq_off[:-1]).astype(np.int64)
+        f = reads.read_first_seq.astype(np.int64)
+        paired = (f[1:] - f[:-1]) == 2
+        if paired.all():
+            L = np.maximum(lens[f[cand["read1"]]] - cand["pos1"], lens[f[cand["read1"]] + 1] - cand["pos2"])
+        else:
+            L = np.minimum(lens[f[cand["read1"]]] - cand["pos1"], lens[f[cand["read2"]]])
+        ch = (L + 15) // 16
+        win = np.arange(cand.size) // W
+        cand = cand[np.lexsort((-ch, win))]
     n = cand.size
     d_in = torch.from_numpy(cand.view(np.uint8).reshape(-1)).cuda()
     d_out = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
