@@ -551,46 +551,11 @@ __device__ __forceinline__ void score_sub_wide(const SymT* __restrict__ sym, con
 // exp(x) > T  in x-space: 1 pass, 0 fail, 2 ambiguous
 __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return x > b.hi ? 1u : (x <= b.lo ? 0u : 2u); }
 
-// One candidate, one lane: score its sub-overlaps and write the result record.
-template <typename SymT, int VAR, int LG>
-__device__ __forceinline__ void score_candidate(const ScoreParams& prm, const SymT* __restrict__ sym, const char* lut,
-                                                const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word, int ns,
-                                                const Sub& sub0, const Sub& sub1, uint64_t i,
-                                                hc_result_rec* __restrict__ out) {
+// The tail of compute_overlap + the 3-way class of process_overlaps for one candidate whose sub-overlap
+// results are known: mismatch_rate = max of the two (:254), class in x-space (:404-413), result record.
+__device__ __forceinline__ void classify_and_store(const ScoreParams& prm, int ns, const SubScore& s1, const SubScore& s2,
+                                                   uint64_t i, hc_result_rec* __restrict__ out) {
     hc_result_rec res;
-    if (ns == 0) {
-        res.x1 = -__builtin_inf();
-        res.x2 = __builtin_nan("");
-        res.mm = 1;
-        res.n_cls = 1u | (HC_CLS_ERROR << 28);
-        out[i] = res;
-        return;
-    }
-    SubScore s1, s2;
-    s2.x = __builtin_nan("");
-    s2.mm = 0;
-    s2.n = 1;
-    s2.err = 0;
-    constexpr bool kPre = (VAR & 2) != 0;
-    if (VAR & 4) {
-        constexpr int kG = (VAR & 3) == 0 ? 4 : ((VAR & 3) == 1 ? 2 : ((VAR & 3) == 2 ? 8 : 3));
-        score_sub_wide<SymT, LG, kG>(sym, sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, s1);
-        if (ns == 2) score_sub_wide<SymT, LG, kG>(sym, sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, s2);
-    } else if (ns == 2) {
-        if (VAR & 1) {
-            const Sub subs[2] = {sub0, sub1};
-            SubScore r[2];
-            score_subs<SymT, 2, kPre, LG>(sym, subs, lut, masktab, Kp, nsym_word, prm.min_read_len, r);
-            s1 = r[0];
-            s2 = r[1];
-        } else {
-            score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
-            score_subs<SymT, 1, kPre, LG>(sym, &sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, &s2);
-        }
-    } else {
-        score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
-    }
-
     // mismatch_rate = float(mismatch_count)/total_len (:132); std::max over the two (:254)
     const double m1 = (double)(float)s1.mm / (double)s1.n;
     uint32_t mm = s1.mm, nn = s1.n;
@@ -625,6 +590,49 @@ __device__ __forceinline__ void score_candidate(const ScoreParams& prm, const Sy
     res.mm = mm;
     res.n_cls = (nn & 0x0FFFFFFFu) | (cls << 28);
     out[i] = res;
+}
+
+// One candidate, one lane: score its sub-overlaps and write the result record.
+template <typename SymT, int VAR, int LG>
+__device__ __forceinline__ void score_candidate(const ScoreParams& prm, const SymT* __restrict__ sym, const char* lut,
+                                                const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word, int ns,
+                                                const Sub& sub0, const Sub& sub1, uint64_t i,
+                                                hc_result_rec* __restrict__ out) {
+    if (ns == 0) {
+        hc_result_rec res;
+        res.x1 = -__builtin_inf();
+        res.x2 = __builtin_nan("");
+        res.mm = 1;
+        res.n_cls = 1u | (HC_CLS_ERROR << 28);
+        out[i] = res;
+        return;
+    }
+    SubScore s1, s2;
+    s2.x = __builtin_nan("");
+    s2.mm = 0;
+    s2.n = 1;
+    s2.err = 0;
+    constexpr bool kPre = (VAR & 2) != 0;
+    if (VAR & 4) {
+        constexpr int kG = (VAR & 3) == 0 ? 4 : ((VAR & 3) == 1 ? 2 : ((VAR & 3) == 2 ? 8 : 3));
+        score_sub_wide<SymT, LG, kG>(sym, sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, s1);
+        if (ns == 2) score_sub_wide<SymT, LG, kG>(sym, sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, s2);
+    } else if (ns == 2) {
+        if (VAR & 1) {
+            const Sub subs[2] = {sub0, sub1};
+            SubScore r[2];
+            score_subs<SymT, 2, kPre, LG>(sym, subs, lut, masktab, Kp, nsym_word, prm.min_read_len, r);
+            s1 = r[0];
+            s2 = r[1];
+        } else {
+            score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
+            score_subs<SymT, 1, kPre, LG>(sym, &sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, &s2);
+        }
+    } else {
+        score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
+    }
+
+    classify_and_store(prm, ns, s1, s2, i, out);
 }
 
 // VAR bit0: interleave the two sub-overlaps of a candidate; bit1: software prefetch of the next
@@ -1022,8 +1030,8 @@ __global__ __launch_bounds__(256) void make_keys_kernel(StoreView st, uint32_t m
 
 size_t reorder_temp_bytes(uint32_t n) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, (int)n);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
     return bytes;
 }
 
@@ -1057,7 +1065,8 @@ struct NotDropped {
 size_t compact_temp_bytes(uint32_t n) {
     size_t bytes = 0;
     hipcub::CountingInputIterator<uint32_t> it(0);
-    hipcub::DeviceSelect::If(nullptr, bytes, it, (uint32_t*)nullptr, (unsigned long long*)nullptr, (int)n, NotDropped{nullptr});
+    (void)hipcub::DeviceSelect::If(nullptr, bytes, it, (uint32_t*)nullptr, (unsigned long long*)nullptr, (int)n,
+                                   NotDropped{nullptr});
     return bytes;
 }
 
