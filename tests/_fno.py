@@ -1,0 +1,168 @@
+"""Shared by the FNO tests and tests/golden/make_golden_fno.py: ctypes face of oracle/libfnooracle.so
+(test infrastructure) and seeded scenario generators for include/hcfno.h inputs."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from haploconduct_amd import fno as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libfnooracle.so")
+_vp = C.c_void_p
+
+
+def load_oracle():
+    lib = C.CDLL(ORACLE_LIB)
+    for name, args in {
+        "oracle_fno1": [C.POINTER(F.hc_fno1_input), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(F.hc_fno_counters), C.c_char_p, C.c_uint64],
+        "oracle_fno3": [C.POINTER(F.hc_fno3_input), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(F.hc_fno_counters), C.c_char_p, C.c_uint64],
+        "oracle_fno_compute_overlap_data": [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp],
+    }.items():
+        f = getattr(lib, name)
+        f.restype, f.argtypes = C.c_int, args
+    lib.oracle_fno_free.restype, lib.oracle_fno_free.argtypes = None, [_vp]
+    return lib
+
+
+class OracleAbort(Exception):
+    """The reference would assert / exit / throw on this input."""
+
+
+def _oracle_run(fn, lib, inp):
+    s = inp.struct()
+    text, n, c = _vp(), C.c_uint64(), F.hc_fno_counters()
+    why = C.create_string_buffer(512)
+    if fn(C.byref(s), C.byref(text), C.byref(n), C.byref(c), why, 512) != 0:
+        raise OracleAbort(why.value.decode())
+    try:
+        return (C.string_at(text, n.value) if n.value else b""), c.as_dict()
+    finally:
+        lib.oracle_fno_free(text)
+
+
+def oracle_fno1(lib, inp):
+    return _oracle_run(lib.oracle_fno1, lib, inp)
+
+
+def oracle_fno3(lib, inp):
+    return _oracle_run(lib.oracle_fno3, lib, inp)
+
+
+def oracle_compute_overlap_data(lib, sr1, sr2, idx, edge):
+    a, b = F._arr([sr1], F.FNO_READ_DTYPE), F._arr([sr2], F.FNO_READ_DTYPE)
+    e, ix = F._arr([edge], F.FNO_EDGE_DTYPE), F._arr(idx, np.int32)
+    out, ok = np.zeros(9, np.int32), C.c_int32()
+    if lib.oracle_fno_compute_overlap_data(a.ctypes.data, b.ctypes.data, ix.ctypes.data, e.ctypes.data, C.byref(ok), out.ctypes.data) != 0:
+        raise OracleAbort("computeOverlapData")
+    return int(ok.value), [int(x) for x in out]
+
+
+# ---------------------------------------------------------------------------------------------------------
+def make_read(id_, len1, len2=0, paired=0, visited=0, orientation=1):
+    r = np.zeros((), F.FNO_READ_DTYPE)
+    r["id"], r["len1"], r["len2"], r["paired"], r["visited"], r["orientation"] = id_, len1, len2 if paired else 0, paired, visited, orientation
+    return r
+
+
+def make_edge(v1, v2, pos1, pos2=0, ord_="-", score=1.0, len1=50, len2=0, perc=40, ori1=1, ori2=1):
+    e = np.zeros((), F.FNO_EDGE_DTYPE)
+    e["v1"], e["v2"], e["score"], e["pos1"], e["pos2"] = v1, v2, score, pos1, pos2
+    e["len1"], e["len2"], e["perc"], e["ord"], e["ori1"], e["ori2"] = len1, len2, perc, ord(ord_), ori1, ori2
+    return e
+
+
+def random_edges(rng, nodes, n, score=None, perc100=0.1):
+    out = np.zeros(n, F.FNO_EDGE_DTYPE)
+    V = len(nodes)
+    for i in range(n):
+        u = int(rng.integers(V))
+        v = int(rng.integers(V - 1))
+        v += v >= u
+        both_paired = nodes[u]["paired"] and nodes[v]["paired"]
+        any_paired = nodes[u]["paired"] or nodes[v]["paired"]
+        out[i] = make_edge(
+            u, v, int(rng.integers(0, 260)), int(rng.integers(0, 260)) if any_paired else 0,
+            "12"[int(rng.integers(2))] if both_paired else "-",
+            score=(float(rng.choice([0.0, 0.5, 0.98, 1.0])) if score is None else score),
+            len1=int(rng.integers(1, 300)), len2=int(rng.integers(0, 300)) if any_paired else 0,
+            perc=100 if rng.random() < perc100 else int(rng.integers(0, 100)),
+            ori1=int(rng.integers(2)), ori2=int(rng.integers(2)))
+    return out
+
+
+def fno1_scenario(seed, n_nodes=40, n_srs=14, n_edges=120, paired_frac=0.4, flags=F.RESOLVE_ORIENTATIONS, with_extras=False,
+                  trimmed_frac=0.3, n_threads=0):
+    """A random but well-formed FNO=1 input: every precondition the reference asserts holds."""
+    rng = np.random.default_rng(seed)
+    paired = rng.random(n_nodes) < paired_frac
+    cliques, sr_paired = [], []
+    for _ in range(n_srs):
+        p = bool(rng.random() < paired_frac)
+        k = int(rng.integers(2, 7))
+        pool = np.flatnonzero(paired) if (p and paired.sum() >= 2) else np.arange(n_nodes)
+        cliques.append(rng.choice(pool, size=min(k, len(pool)), replace=False).astype(np.uint64))
+        sr_paired.append(p)
+    visited = np.zeros(n_nodes, bool)
+    for c in cliques:
+        visited[c.astype(int)] = True
+    extra_visited = rng.random(n_nodes) < 0.03  # merged somewhere, but no super-read lists it
+    visited |= extra_visited
+    nodes = np.zeros(n_nodes, F.FNO_READ_DTYPE)
+    next_id = 0
+    for u in range(n_nodes):
+        nodes[u] = make_read(0, int(rng.integers(40, 300)), int(rng.integers(40, 300)), int(paired[u]), int(visited[u]), int(rng.integers(2)))
+        if not visited[u]:
+            nodes[u]["id"] = next_id
+            next_id += 1
+    srs = np.zeros(n_srs, F.FNO_READ_DTYPE)
+    subreads = []
+    for i in range(n_srs):
+        srs[i] = make_read(next_id, int(rng.integers(100, 900)), int(rng.integers(100, 900)), int(sr_paired[i]))
+        next_id += 1
+        sub = np.zeros(len(cliques[i]), F.FNO_SUBREAD_DTYPE)
+        for k, node in enumerate(cliques[i]):
+            sub[k]["node"] = node
+            for a, b in (("index1", "startpos1"), ("index2", "startpos2")):
+                if rng.random() < trimmed_frac:
+                    sub[k][b] = int(rng.integers(0, 60))
+                else:
+                    sub[k][a] = int(rng.integers(0, 500))
+        subreads.append(sub[rng.permutation(len(sub))])
+    graph_edges = random_edges(rng, nodes, n_edges)
+    graph_edges["score"] = np.where(graph_edges["score"] == 0, 0.99, graph_edges["score"])
+    graph_edges = graph_edges[np.argsort(graph_edges["v1"], kind="stable")]  # adj_out order: by out-vertex
+    kw = {}
+    if with_extras:
+        kw["branching_edges"] = random_edges(rng, nodes, n_edges // 6, score=1.0)
+        kw["nonedges"] = random_edges(rng, nodes, n_edges // 2, score=0.0)
+        groups = []  # OverlapGraph::removeInclusions (src/GraphAlgos.cpp:20-42): all edges around an inclusion vertex w
+        for _ in range(6):
+            vs = rng.choice(n_nodes, size=min(6, n_nodes), replace=False)
+            w, rest = int(vs[0]), [int(x) for x in vs[1:]]
+            n_out = int(rng.integers(1, len(rest)))
+            star = [make_edge(w, x, int(rng.integers(0, 30)), perc=100, ori1=int(rng.integers(2)), ori2=int(rng.integers(2))) for x in rest[:n_out]]
+            star += [make_edge(y, w, int(rng.integers(0, 30)), perc=100, ori1=int(rng.integers(2)), ori2=int(rng.integers(2))) for y in rest[n_out:]]
+            groups.append(np.array(star, F.FNO_EDGE_DTYPE))
+        kw["inclusion_groups"] = groups
+    return F.Fno1Input(nodes, srs, cliques, subreads, graph_edges, new_read_count=next_id, flags=flags, n_threads=n_threads, **kw)
+
+
+def fno3_scenario(seed, n_single=12, n_paired=8, n_trivial=10, n_originals=60, flags=0, n_threads=0):
+    rng = np.random.default_rng(seed)
+    n = n_single + n_paired + n_trivial
+    srs = np.zeros(n, F.FNO_READ_DTYPE)
+    originals = []
+    ids = rng.permutation(n)
+    orig_ids = rng.choice(np.arange(1, 10 * n_originals), size=n_originals, replace=False)
+    for i in range(n):
+        p = n_single <= i < n_single + n_paired or (i >= n_single + n_paired and rng.random() < 0.4)
+        srs[i] = make_read(int(ids[i]), int(rng.integers(60, 700)), int(rng.integers(60, 700)), int(p))
+        k = 1 if i >= n_single + n_paired else int(rng.integers(2, 8))
+        o = np.zeros(k, F.FNO_ORIGINAL_DTYPE)
+        o["original_id"] = rng.choice(orig_ids, size=k, replace=False)
+        o["index1"] = rng.integers(-20, 600, size=k)
+        o["index2"] = rng.integers(-20, 600, size=k)
+        originals.append(o)
+    return F.Fno3Input(srs, n_single, n_paired, n_trivial, originals, new_read_count=n, original_readcount=n_originals, flags=flags,
+                       n_threads=n_threads)

@@ -1,0 +1,237 @@
+"""Find-next-overlaps (include/hcfno.h): host code, runs without a GPU.
+
+Three layers of evidence:
+  * tests/golden/fno/*.json — outputs of the reference's own updateOverlap / computeOverlapData / deduceOverlap
+    (fragment probe, tests/golden/make_golden_fno.py); both the oracle and the product must reproduce them;
+  * product vs oracle (oracle/fno_oracle.cpp) on seeded whole-run scenarios: edge order, non-edges behind the
+    checkEdge filter, inclusion-induced edges, branching edges, the FNO=3 candidate walk;
+  * properties: thread-count invariance, sortedness/uniqueness, error parity where the reference would abort.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from haploconduct_amd import HcError
+from haploconduct_amd import fno as F
+from tests import _fno as T
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fno")
+
+
+@pytest.fixture(scope="module")
+def olib():
+    return T.load_oracle()
+
+
+def _rec(rows, dtype, names):
+    a = np.zeros(len(rows), dtype)
+    for k, name in enumerate(names):
+        a[name] = [r[k] for r in rows]
+    return a
+
+
+def _golden_fno1_inputs():
+    g = json.load(open(os.path.join(GOLD, "fno1_update.json")))
+    assert "fragment probe" in g["source"]
+    for c in g["cases"]:
+        nodes = _rec(c["nodes"], F.FNO_READ_DTYPE, ["id", "len1", "len2", "paired", "visited", "orientation"])
+        srs = _rec(c["srs"], F.FNO_READ_DTYPE, ["id", "len1", "len2", "paired"])
+        subs = _rec(c["subreads"], F.FNO_SUBREAD_DTYPE, ["node", "index1", "index2", "startpos1", "startpos2"])
+        edges = _rec(c["edges"], F.FNO_EDGE_DTYPE, ["v1", "v2", "score", "pos1", "pos2", "len1", "len2", "perc", "ord", "ori1", "ori2"])
+        co, so = c["clique_off"], c["subread_off"]
+        cliques = [np.array(c["clique_nodes"][co[i]:co[i + 1]], np.uint64) for i in range(len(srs))]
+        subreads = [subs[so[i]:so[i + 1]] for i in range(len(srs))]
+        yield F.Fno1Input(nodes, srs, cliques, subreads, edges, new_read_count=c["new_read_count"], flags=c["flags"]), c
+
+
+def test_golden_update_overlap_oracle_and_product(olib):
+    n = 0
+    for inp, c in _golden_fno1_inputs():
+        want = c["text"].encode()
+        for text, cnt in (T.oracle_fno1(olib, inp), F.find_next_overlaps(inp)):
+            assert text == want
+            assert [cnt["copied"], cnt["u2sr"], cnt["v2sr"], cnt["sr2sr"]] == c["counters"]
+            assert cnt["n_lines"] == want.count(b"\n")
+        n += 1
+    assert n == 12
+
+
+def test_golden_compute_overlap_data(olib):
+    g = json.load(open(os.path.join(GOLD, "fno1_cod.json")))
+    n_ok = 0
+    for v in g["vectors"]:
+        s1 = T.make_read(1, v["s1"][0], v["s1"][1], v["s1"][2])
+        s2 = T.make_read(2, v["s2"][0], v["s2"][1], v["s2"][2])
+        e = T.make_edge(0, 1, v["pos1"], v["pos2"], v["ord"])
+        for ok, out in (T.oracle_compute_overlap_data(olib, s1, s2, v["idx"], e), F.compute_overlap_data(s1, s2, v["idx"], e)):
+            assert ok == v["ok"], v
+            if ok:
+                assert out == v["out"], v
+        n_ok += v["ok"]
+    assert len(g["vectors"]) == 800 and 100 < n_ok < 700  # both outcomes are well represented
+
+
+@pytest.mark.parametrize("flags", [0, F.NO_INCLUSIONS])
+def test_golden_deduce_overlap(olib, flags):
+    g = json.load(open(os.path.join(GOLD, "fno3_deduce.json")))
+    written = 0
+    for v in g["vectors"]:
+        srs = np.array([T.make_read(v["s1"][0], v["s1"][1], v["s1"][2], v["s1"][3]), T.make_read(v["s2"][0], v["s2"][1], v["s2"][2], v["s2"][3])],
+                       F.FNO_READ_DTYPE)
+        origs = []
+        for o in (v["o1"], v["o2"]):
+            a = np.zeros(1, F.FNO_ORIGINAL_DTYPE)
+            a["original_id"], a["index1"], a["index2"] = 5, o[0], o[1]
+            origs.append(a)
+        inp = F.Fno3Input(srs, 0, 0, 2, origs, new_read_count=2000, original_readcount=1, flags=flags)
+        # nodeDictApproach :149-157: inclusion filter first, then "written only if len1 > 0"
+        want = v["line"].encode() if (v["len1"] > 0 and not (flags & F.NO_INCLUSIONS and v["perc"] == 100)) else b""
+        for text, cnt in (T.oracle_fno3(olib, inp), F.find_next_overlaps3(inp)):
+            assert text == want, v
+            assert cnt["candidates"] == 1 and cnt["n_lines"] == (1 if want else 0)
+        written += bool(want)
+    assert 200 < written < 800
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fno1_product_matches_oracle(olib, seed):
+    flags = [F.RESOLVE_ORIENTATIONS, F.RESOLVE_ORIENTATIONS | F.NO_INCLUSIONS, F.RESOLVE_ORIENTATIONS | F.OPTIMIZE, 0][seed % 4]
+    inp = T.fno1_scenario(seed, n_nodes=60, n_srs=20, n_edges=300, with_extras=True, flags=flags, paired_frac=[0.0, 0.4, 1.0][seed % 3],
+                          n_threads=[1, 0, 3][seed % 3])
+    want, wc = T.oracle_fno1(olib, inp)
+    got, gc = F.find_next_overlaps(inp)
+    assert got == want and gc == wc
+    lines = got.split(b"\n")[:-1]
+    assert lines == sorted(set(lines))  # std::set<std::string> order: bytewise, unique
+    assert all(l.count(b"\t") == 12 and l.split(b"\t")[8] == b"0" for l in lines)  # 13 columns, PERC2 always 0 (:63,142)
+    if flags & F.NO_INCLUSIONS:
+        assert all(l.split(b"\t")[7] != b"100" for l in lines)
+
+
+def test_fno1_sections_contribute(olib):
+    """Branching edges, stored non-edges and inclusion-induced edges each add lines (so the walk over them is exercised)."""
+    base = T.fno1_scenario(5, n_nodes=60, n_srs=20, n_edges=200, with_extras=True)
+    full, _ = F.find_next_overlaps(base)
+    e0 = np.zeros(0, F.FNO_EDGE_DTYPE)
+    for attr in ("branching_edges", "nonedges"):
+        saved = getattr(base, attr)
+        setattr(base, attr, e0)
+        less, _ = F.find_next_overlaps(base)
+        assert less != full and less == T.oracle_fno1(olib, base)[0]
+        setattr(base, attr, saved)
+    saved = (base.inclusion_off, base.inclusion_edges, base.n_inclusion_groups)
+    base.inclusion_off, base.inclusion_edges, base.n_inclusion_groups = np.zeros(1, np.uint64), e0, 0
+    less, _ = F.find_next_overlaps(base)
+    assert less != full and less == T.oracle_fno1(olib, base)[0]
+    base.inclusion_off, base.inclusion_edges, base.n_inclusion_groups = saved
+    # OPTIMIZE skips exactly the stored non-edges (:914)
+    base.flags |= F.OPTIMIZE
+    opt, _ = F.find_next_overlaps(base)
+    base.flags &= ~F.OPTIMIZE
+    base.nonedges = e0
+    assert opt == F.find_next_overlaps(base)[0]
+
+
+def test_fno1_nonedge_behind_existing_edge_is_skipped(olib):
+    """reconsiderNonedgeOverlaps :702: a stored non-edge whose pair already has an edge (either direction) is dropped."""
+    nodes = np.array([T.make_read(i, 100) for i in range(4)], F.FNO_READ_DTYPE)
+    graph = np.array([T.make_edge(0, 1, 10, score=0.99, len1=90, perc=90)], F.FNO_EDGE_DTYPE)
+    non = np.array([T.make_edge(1, 0, 5, score=0.0, len1=95, perc=95), T.make_edge(2, 3, 7, score=0.0, len1=93, perc=93, ori2=0)], F.FNO_EDGE_DTYPE)
+    inp = F.Fno1Input(nodes, np.zeros(0, F.FNO_READ_DTYPE), [], [], graph, nonedges=non, new_read_count=4)
+    got, cnt = F.find_next_overlaps(inp)
+    assert got == b"0\t1\t10\t0\t-\t+\t+\t90\t0\t90\t0\ts\ts\n2\t3\t7\t0\t-\t+\t-\t93\t0\t93\t0\ts\ts\n"
+    assert cnt["copied"] == 2 and (got, cnt) == T.oracle_fno1(olib, inp)
+    # an edge with score exactly 0 (admitted through merge_contigs) does not hide the non-edge: checkEdge(...) > 0
+    graph["score"] = 0.0
+    inp = F.Fno1Input(nodes, np.zeros(0, F.FNO_READ_DTYPE), [], [], graph, nonedges=non, new_read_count=4)
+    got, cnt = F.find_next_overlaps(inp)
+    assert cnt["copied"] == 3 and (got, cnt) == T.oracle_fno1(olib, inp)
+
+
+def test_fno1_first_edge_wins_per_superread_pair(olib):
+    """overlaps_found: only the first edge (in walk order) that connects two super-reads produces their overlap."""
+    nodes = np.array([T.make_read(0, 100, visited=1) for _ in range(4)], F.FNO_READ_DTYPE)
+    srs = np.array([T.make_read(0, 300), T.make_read(1, 300)], F.FNO_READ_DTYPE)
+    cliques = [np.array([0, 1], np.uint64), np.array([2, 3], np.uint64)]
+
+    def sub(node, idx):
+        s = np.zeros((), F.FNO_SUBREAD_DTYPE)
+        s["node"], s["index1"], s["index2"] = node, idx, idx
+        return s
+    subs = [np.array([sub(0, 0), sub(1, 50)], F.FNO_SUBREAD_DTYPE), np.array([sub(2, 0), sub(3, 40)], F.FNO_SUBREAD_DTYPE)]
+    e_a = T.make_edge(0, 2, 120)  # sr0 -> sr1 at 120
+    e_b = T.make_edge(1, 3, 60)   # would put sr1 at 50 + 60 - 40 = 70
+    for order, pos in (([e_a, e_b], b"120"), ([e_b, e_a], b"70")):
+        g = np.array(order, F.FNO_EDGE_DTYPE)
+        inp = F.Fno1Input(nodes, srs, cliques, subs, g, new_read_count=2)
+        got, cnt = F.find_next_overlaps(inp)
+        assert got.split(b"\t")[:3] == [b"0", b"1", pos] and cnt["sr2sr"] == 1
+        assert (got, cnt) == T.oracle_fno1(olib, inp)
+
+
+def test_fno1_aborts_where_the_reference_does(olib):
+    good = T.fno1_scenario(3)
+    # a clique vertex missing from the super-read's subreadMap: Read::get_subread_info -> .at() throws
+    bad = T.fno1_scenario(3)
+    bad.subreads["node"][0] = 10 ** 6
+    # an id at or above new_read_count: overlaps_found.at() throws
+    bad2 = T.fno1_scenario(3)
+    bad2.new_read_count = 3
+    # both index and startpos positive: findCliqueIndex asserts
+    bad3 = T.fno1_scenario(3)
+    bad3.subreads["index1"] = 5
+    bad3.subreads["startpos1"] = 5
+    assert F.find_next_overlaps(good)[0] == T.oracle_fno1(olib, good)[0]
+    for b in (bad, bad2, bad3):
+        with pytest.raises(T.OracleAbort):
+            T.oracle_fno1(olib, b)
+        with pytest.raises(HcError) as ei:
+            F.find_next_overlaps(b)
+        assert ei.value.status == -9 and "reference stops here" in str(ei.value)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fno3_product_matches_oracle(olib, seed):
+    inp = T.fno3_scenario(seed, n_single=30, n_paired=20, n_trivial=25, n_originals=90, flags=[0, F.NO_INCLUSIONS][seed % 2],
+                          n_threads=[1, 0, 5][seed % 3])
+    want, wc = T.oracle_fno3(olib, inp)
+    got, gc = F.find_next_overlaps3(inp)
+    assert got == want and gc == wc and gc["candidates"] >= gc["n_lines"] > 0
+    for l in got.split(b"\n")[:-1]:
+        f = l.split(b"\t")
+        assert len(f) == 13 and f[5] == f[6] == b"+" and int(f[9]) > 0
+
+
+def test_fno3_aborts_where_the_reference_does(olib):
+    inp = T.fno3_scenario(1)
+    inp.original_readcount = 3  # nodes_to_SR.at(index) throws once a fourth original shows up
+    with pytest.raises(T.OracleAbort):
+        T.oracle_fno3(olib, inp)
+    with pytest.raises(HcError) as ei:
+        F.find_next_overlaps3(inp)
+    assert ei.value.status == -9
+
+
+def test_output_write_and_thread_invariance(tmp_path, olib):
+    inp = T.fno1_scenario(11, n_nodes=300, n_srs=120, n_edges=6000, with_extras=True)
+    texts = []
+    for th in (1, 2, 7, 0):
+        inp.n_threads = th
+        p = tmp_path / f"overlaps_{th}.txt"
+        text, cnt = F.find_next_overlaps(inp, out_path=p)
+        assert p.read_bytes() == text
+        texts.append((text, cnt))
+    assert all(t == texts[0] for t in texts) and texts[0] == T.oracle_fno1(olib, inp)
+
+
+def test_edges_from_records_roundtrip():
+    from haploconduct_amd.records import OVERLAP_DTYPE
+    r = np.zeros(2, OVERLAP_DTYPE)
+    r["read1"], r["read2"], r["pos1"], r["pos2"] = [3, 4], [5, 6], [7, 8], [0, 9]
+    r["ori1"], r["ori2"], r["ord"] = [1, 0], [1, 1], [ord("-"), ord("2")]
+    r["len1"], r["len2"], r["perc"] = [50, 60], [0, 70], [40, 90]
+    e = F.edges_from_records(r)
+    assert e["v1"].tolist() == [3, 4] and e["ord"].tolist() == [ord("-"), ord("2")] and (e["score"] == 0).all()
+    assert e["len2"].tolist() == [0, 70] and e["ori1"].tolist() == [1, 0]

@@ -92,6 +92,46 @@ assert host.hc_sfo2overlaps(w("a.sfo", "\n".join(sfo).encode()), (d + "a.out").e
 for bad in (b"", b"\n\n", b"1 2 N 3\n", b"1 2 N 0 0 0 0 0\n", b"1 2 N a b c d e\n", b"999 2 N 1 1 1 1 0\n", b"1 2 " + b"N" * 5000 + b" 1 1 1 1 0\n"):
     host.hc_sfo2overlaps(w("b.sfo", bad), (d + "b.out").encode(), 40, 40, None)
 
+# 3c. find-next-overlaps on the scenarios the parent process saved (well-formed and hostile ones)
+import glob
+import numpy as np
+vp = C.c_void_p
+class F1(C.Structure):
+    _fields_ = [("nodes", vp), ("n_nodes", C.c_uint64), ("srs", vp), ("n_srs", C.c_uint64), ("clique_off", vp), ("clique_nodes", vp),
+                ("subread_off", vp), ("subreads", vp), ("graph_edges", vp), ("n_graph_edges", C.c_uint64), ("branching_edges", vp),
+                ("n_branching_edges", C.c_uint64), ("nonedges", vp), ("n_nonedges", C.c_uint64), ("inclusion_off", vp), ("inclusion_edges", vp),
+                ("n_inclusion_groups", C.c_uint64), ("new_read_count", C.c_uint64), ("edge_threshold", C.c_double), ("flags", C.c_uint32),
+                ("n_threads", C.c_uint32)]
+class F3(C.Structure):
+    _fields_ = [("srs", vp), ("n_single", C.c_uint64), ("n_paired", C.c_uint64), ("n_trivial", C.c_uint64), ("orig_off", vp), ("originals", vp),
+                ("new_read_count", C.c_uint64), ("original_readcount", C.c_uint64), ("flags", C.c_uint32), ("n_threads", C.c_uint32)]
+def P(a):
+    return a.ctypes.data if a.size else None
+n_fno = 0
+for f in sorted(glob.glob(d + "fno1_*.npz")):
+    z = dict(np.load(f))
+    s1 = F1(P(z["nodes"]), len(z["nodes"]) // 24, P(z["srs"]), len(z["srs"]) // 24, P(z["clique_off"]), P(z["clique_nodes"]), P(z["subread_off"]),
+            P(z["subreads"]), P(z["graph_edges"]), len(z["graph_edges"]) // 48, P(z["branching_edges"]), len(z["branching_edges"]) // 48,
+            P(z["nonedges"]), len(z["nonedges"]) // 48, P(z["inclusion_off"]), P(z["inclusion_edges"]), len(z["inclusion_off"]) - 1,
+            int(z["scalars"][0]), 0.97, int(z["scalars"][1]), int(z["scalars"][2]))
+    out = vp()
+    rc = host.hc_fno1_run(C.byref(s1), C.byref(out))
+    assert (rc == 0) == (int(z["scalars"][3]) == 1), (f, rc)
+    if rc == 0:
+        host.hc_fno_output_free(out)
+    n_fno += 1
+for f in sorted(glob.glob(d + "fno3_*.npz")):
+    z = dict(np.load(f))
+    s3 = F3(P(z["srs"]), int(z["scalars"][0]), int(z["scalars"][1]), int(z["scalars"][2]), P(z["orig_off"]), P(z["originals"]), int(z["scalars"][3]),
+            int(z["scalars"][4]), int(z["scalars"][5]), int(z["scalars"][6]))
+    out = vp()
+    rc = host.hc_fno3_run(C.byref(s3), C.byref(out))
+    assert (rc == 0) == (int(z["scalars"][7]) == 1), (f, rc)
+    if rc == 0:
+        host.hc_fno_output_free(out)
+    n_fno += 1
+assert n_fno >= 10
+
 # 4. oracle on odd inputs
 orc.hco_overlap_score.restype = C.c_double
 mr = C.c_double(); x = C.c_double(); mm = C.c_uint32(); nn = C.c_uint32(); pos = C.c_uint64(); stt = C.c_int()
@@ -101,6 +141,44 @@ for a, b, qa, qb, p in ((b"ACGT", b"ACGT", b"IIII", b"IIII", 0), (b"ACGT", b"AC"
                           C.byref(mm), C.byref(nn), C.byref(pos), C.byref(stt))
 print("sanitizer driver finished")
 '''
+
+
+def _save_fno_scenarios(d):
+    """FNO inputs as raw bytes for the sanitizer child (which must not import the package: that would load the real library)."""
+    import numpy as np
+
+    from tests import _fno as T
+
+    def raw(a):
+        return np.frombuffer(np.ascontiguousarray(a).tobytes(), np.uint8)
+
+    def save1(name, inp, ok):
+        np.savez(d + name, nodes=raw(inp.nodes), srs=raw(inp.srs), clique_off=inp.clique_off, clique_nodes=inp.clique_nodes,
+                 subread_off=inp.subread_off, subreads=raw(inp.subreads), graph_edges=raw(inp.graph_edges),
+                 branching_edges=raw(inp.branching_edges), nonedges=raw(inp.nonedges), inclusion_off=inp.inclusion_off,
+                 inclusion_edges=raw(inp.inclusion_edges), scalars=np.array([inp.new_read_count, inp.flags, inp.n_threads, ok], np.int64))
+
+    for seed in range(6):
+        save1(f"fno1_{seed}.npz", T.fno1_scenario(seed, n_nodes=80, n_srs=30, n_edges=800, with_extras=True, flags=[1, 3, 5][seed % 3],
+                                                  n_threads=[1, 4][seed % 2]), 1)
+    bad = T.fno1_scenario(3)
+    bad.subreads["node"][0] = 10 ** 6
+    save1("fno1_bad_a.npz", bad, 0)
+    bad = T.fno1_scenario(3)
+    bad.new_read_count = 3
+    save1("fno1_bad_b.npz", bad, 0)
+    bad = T.fno1_scenario(3)
+    bad.graph_edges["v2"][5] = 10 ** 9
+    save1("fno1_bad_c.npz", bad, 0)
+    empty = T.fno1_scenario(3, n_edges=0)
+    save1("fno1_empty.npz", empty, 1)
+    for seed in range(4):
+        inp = T.fno3_scenario(seed, n_single=30, n_paired=20, n_trivial=25, n_originals=90, n_threads=[1, 4][seed % 2])
+        ok = 1
+        if seed == 3:
+            inp.original_readcount, ok = 2, 0
+        np.savez(d + f"fno3_{seed}.npz", srs=raw(inp.srs), orig_off=inp.orig_off, originals=raw(inp.originals),
+                 scalars=np.array([*inp.counts, inp.new_read_count, inp.original_readcount, inp.flags, inp.n_threads, ok], np.int64))
 
 
 def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
@@ -114,12 +192,13 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
     san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-fPIC", "-shared"]
     r = subprocess.run(["g++", "-std=c++17", *san, "-pthread", "-o", host_so, os.path.join(hd, "host_model.cpp"),
                         os.path.join(hd, "OverlapsParser.cpp"), os.path.join(hd, "hc_host_api.cpp"),
-                        os.path.join(hd, "Sfo2Overlaps.cpp"), stub],
+                        os.path.join(hd, "Sfo2Overlaps.cpp"), os.path.join(hd, "FindNextOverlaps.cpp"), stub],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run(["gcc", "-std=gnu11", "-ffp-contract=off", "-fopenmp", *san, "-o", orc_so,
                         os.path.join(ROOT, "oracle", "hc_oracle.c"), "-lm"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+    _save_fno_scenarios(str(tmp_path) + "/")
     libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
     libstdcpp = subprocess.run(["gcc", "-print-file-name=libstdc++.so.6"], capture_output=True, text=True).stdout.strip()
     # libstdc++ must be loaded before the ASan runtime initialises, or its __cxa_throw interceptor has no target
