@@ -48,6 +48,7 @@ using hc::FatalError;
 
 unsigned thread_count(uint32_t asked) {
     unsigned n = asked ? asked : std::thread::hardware_concurrency();
+    if (!asked && n > 64) n = 64;  // past 64 threads the merge/scatter steps only add overhead (tools/fno_bench.py)
     return n ? n : 1;
 }
 
