@@ -193,3 +193,55 @@ def test_cli_accepts_reference_argv_and_matches_oracle(oracle, tmp_path):
     assert open(d + "nonedge_overlaps.txt", "rb").read() == open(d + "ref_nonedge.txt", "rb").read()
     stats = dict(ln.split("\t") for ln in open(d + "edgecalc_stats.txt").read().splitlines())
     assert int(stats["dup_count"]) == oc.dup_count and int(stats["inclusion_count"]) == oc.inclusion_count
+
+
+def test_inter_iteration_path_edge_calc_fno_edge_calc(oracle, tmp_path):
+    """BASELINE config 4's shape: edge calculation -> find-next-overlaps -> edge calculation.  With no super-read
+    merged in between, FNO=1 copies every edge and every stored non-edge into the next overlaps file (new id = old
+    id), so the second edge calculation must rebuild the same graph, bit for bit, from FNO's text."""
+    from haploconduct_amd import fno as F
+
+    for tag, (reads, cand) in {
+        "singles": (lambda rm: (rm[0], synth.single_candidates(rm[1], min_overlap=100, n_candidates=15000)))(
+            synth.make_single_dataset(1500, 6000, len_lo=250, len_hi=250, flip_frac=0.0, seed=21, quals=HQ)),
+        "pairs": (lambda rm: (rm[0], synth.paired_candidates(rm[1], n_candidates=15000, seed=23)))(
+            synth.make_paired_dataset(1200, 2500, flip_frac=0.0, seed=22)),
+    }.items():
+        if tag == "pairs":
+            reads.quals[:] = HQ[np.random.default_rng(5).integers(0, HQ.size, reads.quals.size)]
+        st = hc.Settings(edge_threshold=0.97, ov_threshold=0.5, min_overlap_len=120 if tag == "singles" else 150)
+        lines = synth.records_to_lines(cand, reads)
+        edges_a, ca = run_both(oracle, tmp_path, reads, lines, st, tag + "_a")
+        assert edges_a.size > 200 and ca["nonedges_written"] > 20
+        d = tmp_path / (tag + "_a")
+        s = str(d / "singles.fastq") if tag == "singles" else None
+        p1, p2 = (None, None) if tag == "singles" else (str(d / "paired1.fastq"), str(d / "paired2.fastq"))
+        # the facts FNO reads: every vertex unvisited, new id = read id, no super-reads
+        n = reads.n_reads
+        nodes = np.zeros(n, F.FNO_READ_DTYPE)
+        nodes["id"] = reads.read_ids
+        for r in range(n):
+            q = int(reads.read_first_seq[r])
+            nodes["len1"][r] = int(reads.seq_off[q + 1] - reads.seq_off[q])
+            if reads.is_paired(r):
+                nodes["len2"][r] = int(reads.seq_off[q + 2] - reads.seq_off[q + 1])
+                nodes["paired"][r] = 1
+        nodes["orientation"] = 1
+        g = np.zeros(edges_a.size, F.FNO_EDGE_DTYPE)
+        for k in ("v1", "v2", "score", "pos1", "pos2", "len1", "len2", "perc", "ord", "ori1", "ori2"):
+            g[k] = edges_a[k]
+        fq = host.Fastq(singles=s, paired1=p1, paired2=p2)
+        recs, _ = fq.parse_file(hc.Settings(edge_threshold=0.97, min_overlap_len=0), str(d / "out" / "nonedge_overlaps.txt"))
+        fq.close()
+        # the file holds the scored non-edges and, at its end, the lines that failed the length/type prefilter (:654-660)
+        assert recs.size == sum(1 for _ in open(d / "out" / "nonedge_overlaps.txt")) >= ca["nonedges_written"]
+        inp = F.Fno1Input(nodes, np.zeros(0, F.FNO_READ_DTYPE), [], [], g, nonedges=F.edges_from_records(recs),
+                          new_read_count=int(reads.read_ids.max()) + 1)
+        text, cnt = F.find_next_overlaps(inp)
+        assert cnt["copied"] == cnt["n_lines"] == edges_a.size + recs.size  # nothing merged, nothing shadowed, nothing duplicated
+        lines_b = text.decode().split("\n")[:-1]
+        edges_b, cb = run_both(oracle, tmp_path, reads, lines_b, st, tag + "_b")
+        assert cb["dup_count"] == 0 and cb["nonedges_written"] == ca["nonedges_written"] and cb["edges_added"] == edges_a.size
+        assert cb["prefilter_rejected"] == ca["prefilter_rejected"]
+        key = lambda e: sorted(zip(*(e[k].view(np.uint64).tolist() if e[k].dtype.kind == "f" else e[k].tolist() for k in FIELDS)))
+        assert key(edges_a) == key(edges_b)
