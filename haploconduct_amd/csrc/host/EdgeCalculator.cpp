@@ -35,7 +35,6 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
 
 EdgeCalculator::~EdgeCalculator() {
     if (m_ctx) {
-        hc_host_free(m_ctx, m_rec);
         hc_host_free(m_ctx, m_res);
         hc_host_free(m_ctx, m_idx);
         hc_destroy(m_ctx);
@@ -69,111 +68,176 @@ double EdgeCalculator::overlap_score(const std::string& seq1, const std::string&
     return score;
 }
 
-// src/EdgeCalculator.cpp:389-557
-void EdgeCalculator::process_overlaps(const std::vector<ParsedOverlap>& batch) {
+// src/EdgeCalculator.cpp:395-414 (+ the Edge construction of compute_overlap): device scoring, then finalise and
+// build on a few host threads; sequence order is kept by concatenating the threads' pieces in order.
+void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) {
+    out.edges.clear();
+    out.nonedge_text.clear();
+    out.nonedges = 0;
     const size_t n = batch.size();
     if (n == 0) return;
     double t0 = now_s();
     if (n > m_cap) {
-        hc_host_free(m_ctx, m_rec);
         hc_host_free(m_ctx, m_res);
         hc_host_free(m_ctx, m_idx);
-        m_rec = nullptr;
         m_res = nullptr;
         m_idx = nullptr;
         m_cap = 0;
         const size_t cap = n + n / 8;
-        check(hc_host_alloc(m_ctx, (void**)&m_rec, cap * sizeof(hc_overlap_rec)), "hc_host_alloc");
         check(hc_host_alloc(m_ctx, (void**)&m_res, cap * sizeof(hc_result_rec)), "hc_host_alloc");
         check(hc_host_alloc(m_ctx, (void**)&m_idx, cap * sizeof(uint32_t)), "hc_host_alloc");
         m_cap = cap;
     }
-    for (size_t i = 0; i < n; i++) m_rec[i] = batch[i].rec;
-    // the omp-for of :395-414 on the device; only the records that are not dropped come back
+    // the omp-for of :395-414 on the device, straight from the (page-locked) records the parser wrote; only the
+    // records that are not dropped come back
+    const hc_overlap_rec* m_rec = batch.recs;
     uint64_t n_kept = 0;
     check(hc_score_batch_compact(m_ctx, m_rec, n, m_idx, m_res, m_cap, &n_kept), "hc_score_batch_compact");
     stats.scored += n;
-    double t1 = now_s();
-    stats.t_score += t1 - t0;
     if (program_settings.verbose) puts("build edges / write overlaps to file");
 
     const FastqStorage& f = *fastq_storage;
-    unsigned int count_before = overlap_graph->getEdgeCount(), dups_before = dup_count;
-    uint64_t added_before = stats.edges_added;
-    m_nonedge_buf.clear();
-    char linebuf[192];
-    for (uint64_t k = 0; k < n_kept; k++) {
-        const size_t i = m_idx[k];
-        const hc_result_rec& r = m_res[k];
-        uint32_t cls = HC_RES_CLS(r);
-        if (cls == HC_CLS_DROP) continue;
-        if (cls == HC_CLS_ERROR)
-            throw FatalError{HC_ERR_DATA, "overlap " + batch[i].line.get_overlap_line() + " touches an invalid base or quality byte"};
-        if (cls == HC_CLS_NONEDGE) {  // :410-413
-            m_nonedge_buf.append(linebuf, batch[i].line.write_line(linebuf));
-            stats.nonedges_written++;
-            continue;
+    struct Piece {
+        std::vector<Edge> edges;
+        std::string nonedge_text;
+        uint64_t nonedges = 0, ambiguous = 0;
+        FatalError error{0, ""};
+    };
+    auto build = [&](uint64_t kb, uint64_t ke, Piece& pc) {
+        char linebuf[192];
+        for (uint64_t k = kb; k < ke; k++) {
+            const size_t i = m_idx[k];
+            const hc_result_rec& r = m_res[k];
+            uint32_t cls = HC_RES_CLS(r);
+            if (cls == HC_CLS_DROP) continue;
+            if (cls == HC_CLS_ERROR) {
+                pc.error = FatalError{HC_ERR_DATA, "overlap " + batch.lines[i].get_overlap_line() + " touches an invalid base or quality byte"};
+                return;
+            }
+            if (cls == HC_CLS_NONEDGE) {  // :410-413
+                pc.nonedge_text.append(linebuf, batch.lines[i].write_line(linebuf));
+                pc.nonedges++;
+                continue;
+            }
+            double score, mismatch_rate;
+            if (cls == HC_CLS_AMBIG) pc.ambiguous++;
+            const int st = hc_finalize(&m_cs, &r, &score, &mismatch_rate, &cls);  // exp() with the host libm
+            if (st != HC_OK) {
+                pc.error = FatalError{st, "hc_finalize"};
+                return;
+            }
+            if (cls == HC_CLS_DROP) continue;
+            if (cls == HC_CLS_NONEDGE) {
+                pc.nonedge_text.append(linebuf, batch.lines[i].write_line(linebuf));
+                pc.nonedges++;
+                continue;
+            }
+            // build the Edge as compute_overlap does, :219-232 / :254-270 / :292-308 / :353-379
+            const hc_overlap_rec& o = m_rec[i];
+            Read* r1 = f.m_read_vec[o.read1];
+            Read* r2 = f.m_read_vec[o.read2];
+            const bool p1 = r1->is_paired(), p2 = r2->is_paired();
+            const int pos1 = (int)o.pos1, pos2 = (int)o.pos2;
+            int pos3, pos4 = 0;
+            if (!p1 && !p2) {
+                pos3 = (int)r1->get_seq_len(0) - pos1 - (int)r2->get_seq_len(0);                 // :222
+            } else if (!p1 && p2) {
+                pos3 = (int)r1->get_seq_len(0) - pos2 - (int)r2->get_seq_len(2);                 // :262
+                pos4 = (int)r1->get_seq_len(0) - pos1 - (int)r2->get_seq_len(1);                 // :263
+            } else if (p1 && !p2) {
+                pos3 = (int)r1->get_seq_len(2) + pos2 - (int)r2->get_seq_len(0);                 // :300
+                pos4 = (int)r2->get_seq_len(0) + pos1 - (int)r1->get_seq_len(1);                 // :301
+            } else {
+                pos3 = o.ord == '1' ? (int)r1->get_seq_len(2) - pos2 - (int)r2->get_seq_len(2)   // :363
+                                    : (int)r1->get_seq_len(2) + pos2 - (int)r2->get_seq_len(2);  // :370
+                pos4 = (int)r1->get_seq_len(1) - pos1 - (int)r2->get_seq_len(1);                 // :372
+            }
+            Edge e(score, pos1, pos2, o.ori1 != 0, o.ori2 != 0, std::string(1, (char)o.ord), r1, r2);
+            e.set_vertices(r1->get_vertex_id(true), r2->get_vertex_id(true));  // :180-183
+            e.set_extra_pos(pos3, pos4);
+            e.set_perc((int)o.perc);
+            e.set_len((int)o.len1, (!p1 && !p2) ? 0 : (int)o.len2);  // :227 / :268
+            e.set_mismatch(mismatch_rate);
+            pc.edges.push_back(e);
         }
-        double score, mismatch_rate;
-        if (cls == HC_CLS_AMBIG) stats.ambiguous++;
-        check(hc_finalize(&m_cs, &r, &score, &mismatch_rate, &cls), "hc_finalize");  // exp() with the host libm
-        if (cls == HC_CLS_DROP) continue;
-        if (cls == HC_CLS_NONEDGE) {
-            m_nonedge_buf.append(linebuf, batch[i].line.write_line(linebuf));
-            stats.nonedges_written++;
-            continue;
-        }
-        // build the Edge as compute_overlap does, :219-232 / :254-270 / :292-308 / :353-379
-        const hc_overlap_rec& o = m_rec[i];
-        Read* r1 = f.m_read_vec[o.read1];
-        Read* r2 = f.m_read_vec[o.read2];
-        const bool p1 = r1->is_paired(), p2 = r2->is_paired();
-        const int pos1 = (int)o.pos1, pos2 = (int)o.pos2;
-        int pos3, pos4 = 0;
-        if (!p1 && !p2) {
-            pos3 = (int)r1->get_seq_len(0) - pos1 - (int)r2->get_seq_len(0);                 // :222
-        } else if (!p1 && p2) {
-            pos3 = (int)r1->get_seq_len(0) - pos2 - (int)r2->get_seq_len(2);                 // :262
-            pos4 = (int)r1->get_seq_len(0) - pos1 - (int)r2->get_seq_len(1);                 // :263
-        } else if (p1 && !p2) {
-            pos3 = (int)r1->get_seq_len(2) + pos2 - (int)r2->get_seq_len(0);                 // :300
-            pos4 = (int)r2->get_seq_len(0) + pos1 - (int)r1->get_seq_len(1);                 // :301
-        } else {
-            pos3 = o.ord == '1' ? (int)r1->get_seq_len(2) - pos2 - (int)r2->get_seq_len(2)   // :363
-                                : (int)r1->get_seq_len(2) + pos2 - (int)r2->get_seq_len(2);  // :370
-            pos4 = (int)r1->get_seq_len(1) - pos1 - (int)r2->get_seq_len(1);                 // :372
-        }
-        Edge e(score, pos1, pos2, o.ori1 != 0, o.ori2 != 0, std::string(1, (char)o.ord), r1, r2);
-        e.set_vertices(r1->get_vertex_id(true), r2->get_vertex_id(true));  // :180-183
-        e.set_extra_pos(pos3, pos4);
-        e.set_perc((int)o.perc);
-        e.set_len((int)o.len1, (!p1 && !p2) ? 0 : (int)o.len2);  // :227 / :268
-        e.set_mismatch(mismatch_rate);
-        if (m_sorted_insert) {
-            m_admitted.push_back(e);  // resolved once, after the last batch (resolve_admitted_edges)
-        } else {
+    };
+    unsigned T = program_settings.n_threads > 1 ? std::min<unsigned>(program_settings.n_threads, 4) : 1;
+    if (n_kept < 4096) T = 1;
+    std::vector<Piece> pieces(T);
+    if (T == 1) {
+        build(0, n_kept, pieces[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) th.emplace_back([&, t] { build(n_kept * t / T, n_kept * (t + 1) / T, pieces[t]); });
+        for (auto& x : th) x.join();
+    }
+    size_t n_edges = 0;
+    for (const Piece& pc : pieces) {
+        if (pc.error.status) throw pc.error;  // the first one in sequence order
+        n_edges += pc.edges.size();
+    }
+    out.edges.reserve(n_edges);
+    for (Piece& pc : pieces) {
+        out.edges.insert(out.edges.end(), pc.edges.begin(), pc.edges.end());
+        out.nonedge_text += pc.nonedge_text;
+        out.nonedges += pc.nonedges;
+        stats.ambiguous += pc.ambiguous;
+    }
+    stats.t_score += now_s() - t0;
+}
+
+// src/EdgeCalculator.cpp:431-555: the serial half
+void EdgeCalculator::insert_block(BuiltBlock& blk) {
+    const double t1 = now_s();
+    const unsigned int dups_before = dup_count;
+    const uint64_t added_before = stats.edges_added;
+    stats.nonedges_written += blk.nonedges;
+    if (m_sorted_insert) {
+        m_admitted.insert(m_admitted.end(), blk.edges.begin(), blk.edges.end());  // resolved once, after the last block
+    } else {
+        // The second read of an edge is a random place in the graph's slot index and in the in-lists: ask for the
+        // slot and the list header 2*kAhead edges early, and for the end of the list (its header is in cache by
+        // then) kAhead edges early.
+        constexpr size_t kAhead = 8;
+        const size_t m = blk.edges.size();
+        for (size_t k = 0; k < m; k++) {
+            if (k + 2 * kAhead < m) {
+                const Edge& a = blk.edges[k + 2 * kAhead];
+                overlap_graph->prefetch_slot(a.get_vertex(1), a.get_vertex(2), a.get_ori(1) == a.get_ori(2));
+                if (a.get_pos(1) == 0) overlap_graph->prefetch_slot(a.get_vertex(2), a.get_vertex(1), false);  // may be swapped, :443-448
+            }
+            if (k + kAhead < m) {
+                const Edge& a = blk.edges[k + kAhead];
+                overlap_graph->prefetch_in_list(a.get_vertex(2));
+                if (a.get_pos(1) == 0) overlap_graph->prefetch_in_list(a.get_vertex(1));
+            }
             InsertCounters ic;
-            insert_edge(*overlap_graph, program_settings, e, ic);
+            insert_edge(*overlap_graph, program_settings, blk.edges[k], ic);
             inclusion_count += ic.inclusion_count;
             dup_count += ic.dup_count;
             stats.edges_added += ic.edges_added;
         }
     }
-    double t2 = now_s();
+    const double t2 = now_s();
     stats.t_insert += t2 - t1;
     if (program_settings.verbose && !m_sorted_insert) {
-        (void)count_before;
         printf("Number of edges found: %lu\n", (unsigned long)(stats.edges_added - added_before));
         printf("Number of duplicates: %u\n", dup_count - dups_before);
     }
-    if (!m_nonedge_buf.empty() || true) {  // :546-555 (the file is opened in append mode even when nothing is written)
-        FILE* fo = fopen((program_settings.output_dir + "nonedge_overlaps.txt").c_str(), "a");
-        if (fo) {
-            fwrite(m_nonedge_buf.data(), 1, m_nonedge_buf.size(), fo);
-            fclose(fo);
-        }
+    // :546-555 (the file is opened in append mode even when nothing is written)
+    FILE* fo = fopen((program_settings.output_dir + "nonedge_overlaps.txt").c_str(), "a");
+    if (fo) {
+        fwrite(blk.nonedge_text.data(), 1, blk.nonedge_text.size(), fo);
+        fclose(fo);
     }
     stats.t_write += now_s() - t2;
+}
+
+// src/EdgeCalculator.cpp:389-557
+void EdgeCalculator::process_overlaps(const ParsedBatch& batch) {
+    BuiltBlock blk;
+    score_and_build(batch, blk);
+    insert_block(blk);
 }
 
 // src/EdgeCalculator.cpp:561-666
@@ -184,12 +248,19 @@ void EdgeCalculator::construct_edges() {
     if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
     if (program_settings.verbose) puts("reading overlaps file... ");
     const size_t overlaps_per_vec = 250000;  // the reference batches 1,000,000 (:571); batch boundaries do not influence the result
-    // Two-stage pipeline: while block k is scored on the device and inserted into the graph, block
-    // k+1 is tokenised by the parser's worker threads.  Blocks are consumed strictly in file order,
-    // so the graph, the counters and nonedge_overlaps.txt are those of the sequential loop.
-    std::vector<ParsedOverlap> batch[2];
-    batch[0].reserve(overlaps_per_vec);
-    batch[1].reserve(overlaps_per_vec);
+    // Three-stage pipeline: block k+1 is tokenised by the parser's worker threads while block k is scored on the
+    // device and its edges are built, while the edges of block k-1 are inserted into the graph.  Every stage
+    // consumes the blocks strictly in file order, so the graph, the counters and nonedge_overlaps.txt are those
+    // of the sequential loop.
+    ParsedBatch::RecStorage pinned;  // the parser writes its records where the device reads them
+    pinned.ctx = m_ctx;
+    pinned.alloc = [](void* ctx, size_t n) -> hc_overlap_rec* {
+        void* p = nullptr;
+        check(hc_host_alloc((hc_ctx*)ctx, &p, n * sizeof(hc_overlap_rec)), "hc_host_alloc");
+        return (hc_overlap_rec*)p;
+    };
+    pinned.release = [](void* ctx, hc_overlap_rec* p) { hc_host_free((hc_ctx*)ctx, p); };
+    ParsedBatch batch[2] = {ParsedBatch(pinned), ParsedBatch(pinned)};
     ParseCounters pc;
     bool more[2] = {false, false};
     FatalError parse_error{0, ""};
@@ -203,26 +274,50 @@ void EdgeCalculator::construct_edges() {
             more[slot] = false;
         }
     };
+    BuiltBlock built[2];
+    std::thread inserter;
+    FatalError insert_error{0, ""};
+    auto finish_insert = [&] {
+        if (inserter.joinable()) inserter.join();
+        if (insert_error.status) throw insert_error;
+    };
     double t0 = now_s();
     parse_into(0);
     stats.t_parse += now_s() - t0;
-    int cur = 0;
+    int cur = 0, slot = 0;
     while (more[cur]) {
-        if (parse_failed) throw parse_error;
+        if (parse_failed) {
+            if (inserter.joinable()) inserter.join();
+            throw parse_error;
+        }
         std::thread ahead(parse_into, cur ^ 1);
-        const double t1 = now_s();
         try {
-            if (!batch[cur].empty()) process_overlaps(batch[cur]);  // :636-644
+            if (!batch[cur].empty()) {  // :636-644
+                score_and_build(batch[cur], built[slot]);
+                finish_insert();  // block k-1 is in the graph
+                BuiltBlock* blk = &built[slot];
+                inserter = std::thread([this, blk, &insert_error] {
+                    try {
+                        insert_block(*blk);
+                    } catch (const FatalError& e) {
+                        insert_error = e;
+                    } catch (const std::exception& e) {
+                        insert_error = FatalError{HC_ERR_STATE, e.what()};
+                    }
+                });
+                slot ^= 1;
+            }
         } catch (...) {
             ahead.join();
+            if (inserter.joinable()) inserter.join();
             throw;
         }
         const double t2 = now_s();
         ahead.join();
         stats.t_parse += now_s() - t2;  // only the part of the parse that was not hidden
-        (void)t1;
         cur ^= 1;
     }
+    finish_insert();
     if (parse_failed) throw parse_error;
     if (m_sorted_insert) {
         const double tr = now_s();

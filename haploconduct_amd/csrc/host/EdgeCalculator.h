@@ -67,19 +67,27 @@ public:
     } stats;
 
 private:
-    void process_overlaps(const std::vector<ParsedOverlap>& batch);   // src/EdgeCalculator.cpp:389-557
+    // process_overlaps (src/EdgeCalculator.cpp:389-557) in its two halves: the parallel one (:395-414: score on the
+    // device, finalise, build the Edge objects) and the serial one (:431-555: insert in sequence order, append the
+    // non-edge lines).  construct_edges() runs the serial half of block k beside the parallel half of block k+1.
+    struct BuiltBlock {
+        std::vector<Edge> edges;   // admitted edges in sequence order
+        std::string nonedge_text;  // lines for nonedge_overlaps.txt in sequence order
+        uint64_t nonedges = 0;
+    };
+    void score_and_build(const ParsedBatch& batch, BuiltBlock& out);
+    void insert_block(BuiltBlock& blk);
+    void process_overlaps(const ParsedBatch& batch);
     ProgramSettings program_settings;
     std::shared_ptr<FastqStorage> fastq_storage;
     std::shared_ptr<OverlapGraph> overlap_graph;
     hc_settings m_cs;
     hc_ctx* m_ctx = nullptr;
-    hc_overlap_rec* m_rec = nullptr;  // page-locked staging (hc_host_alloc), grow-only
-    hc_result_rec* m_res = nullptr;   // compacted: records of the non-DROP candidates only
+    hc_result_rec* m_res = nullptr;   // page-locked (hc_host_alloc), grow-only; compacted: records of the non-DROP candidates only
     uint32_t* m_idx = nullptr;        // their positions in the batch, ascending
     size_t m_cap = 0;
     bool m_sorted_insert = false;     // HC_INSERT_MODE=sorted: resolve_admitted_edges() after the last batch instead of per-edge inserts
     std::vector<Edge> m_admitted;     // admitted edges of the whole file, in sequence order (sorted insert)
-    std::string m_nonedge_buf;
 };
 
 }  // namespace hc

@@ -12,6 +12,81 @@
 
 namespace hc {
 
+// Which (unordered vertex pair, orientation class) slots hold an edge.  The reference answers that by walking
+// two adjacency lists per candidate edge (checkEdgeWithOri); almost every answer is "none", and the list of the
+// in-vertex is a cold place in memory.  One probe of this table (whose address is known from the candidate
+// record alone, so it can be prefetched) settles the common case; the lists are only walked on a hit.
+class EdgeSlotIndex {
+public:
+    EdgeSlotIndex() { rebuild(1u << 12); }
+    static bool representable(uint64_t v, uint64_t w) { return (v | w) < ((uint64_t)1 << 31); }
+    static uint64_t key(uint64_t v, uint64_t w, bool opposite_orientations) {
+        const uint64_t lo = v < w ? v : w, hi = v < w ? w : v;
+        return (lo << 33) | (hi << 1) | (uint64_t)opposite_orientations;
+    }
+    bool contains(uint64_t k) const {
+        for (size_t h = slot_of(k);; h = (h + 1) & mask_) {
+            if (tab_[h].key == k) return tab_[h].count != 0;
+            if (tab_[h].key == kEmpty) return false;
+        }
+    }
+    void add(uint64_t k) {
+        if ((filled_ + 1) * 10 > (mask_ + 1) * 6) rebuild((mask_ + 1) * (live_ * 4 > filled_ ? 2 : 1));
+        for (size_t h = slot_of(k);; h = (h + 1) & mask_) {
+            if (tab_[h].key == k) {
+                if (tab_[h].count++ == 0) live_++;
+                return;
+            }
+            if (tab_[h].key == kEmpty) {
+                tab_[h].key = k;
+                tab_[h].count = 1;
+                filled_++;
+                live_++;
+                return;
+            }
+        }
+    }
+    void remove(uint64_t k) {  // the slot stays (count 0) and is dropped at the next rebuild
+        for (size_t h = slot_of(k);; h = (h + 1) & mask_) {
+            if (tab_[h].key == k) {
+                if (tab_[h].count && --tab_[h].count == 0) live_--;
+                return;
+            }
+            if (tab_[h].key == kEmpty) return;
+        }
+    }
+    void prefetch(uint64_t k) const { __builtin_prefetch(&tab_[slot_of(k)]); }
+
+private:
+    struct Entry {
+        uint64_t key;
+        uint32_t count;
+    };
+    static constexpr uint64_t kEmpty = ~(uint64_t)0;
+    size_t slot_of(uint64_t k) const {
+        uint64_t x = k * 0x9E3779B97F4A7C15ull;
+        x ^= x >> 29;
+        return (size_t)x & mask_;
+    }
+    void rebuild(size_t cap) {
+        std::vector<Entry> old;
+        old.swap(tab_);
+        tab_.assign(cap, Entry{kEmpty, 0});
+        mask_ = cap - 1;
+        filled_ = live_ = 0;
+        for (const Entry& e : old)
+            if (e.key != kEmpty && e.count) {
+                size_t h = slot_of(e.key);
+                while (tab_[h].key != kEmpty) h = (h + 1) & mask_;
+                tab_[h] = e;
+                filled_++;
+                live_++;
+            }
+    }
+    std::vector<Entry> tab_;
+    size_t mask_ = 0, filled_ = 0, live_ = 0;
+};
+
 class OverlapGraph {
 public:
     OverlapGraph(unsigned int V, std::shared_ptr<FastqStorage> fastq, const ProgramSettings& ps)
@@ -26,6 +101,16 @@ public:
     Edge removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations);             // :150-194
     double checkEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) const;      // :198-229
     Edge* getEdgeInfoWithOri(node_id_t v, node_id_t w, bool opposite_orientations, bool reverse_allowed = true);  // :285-306
+    // Hints for the serial insert (an edge lands at random places in memory): the slot of the pair in the
+    // index and the header of the in-vertex's in-list first; a few edges later, once the header is in cache,
+    // the end of that list.
+    void prefetch_slot(node_id_t v, node_id_t w, bool opposite_orientations) const {
+        if (EdgeSlotIndex::representable(v, w)) slots.prefetch(EdgeSlotIndex::key(v, w, opposite_orientations));
+        if (w < adj_in.size()) __builtin_prefetch(&adj_in[w]);
+    }
+    void prefetch_in_list(node_id_t w) const {
+        if (w < adj_in.size() && !adj_in[w].empty()) __builtin_prefetch(adj_in[w].data() + adj_in[w].size() - 1, 1);
+    }
     unsigned int getEdgeCount() const { return edge_count; }
     unsigned int getVertexCount() const { return vertex_count; }
 
@@ -35,6 +120,7 @@ public:
     std::vector<uint8_t> inclusions;                      // boost::dynamic_bitset in the reference
 
 private:
+    EdgeSlotIndex slots;  // kept in step with adj_out by addEdge / removeEdgeWithOri
     unsigned int vertex_count = 0;
     unsigned int edge_count = 0;
     std::shared_ptr<FastqStorage> fastq_storage;

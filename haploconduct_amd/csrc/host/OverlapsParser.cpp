@@ -9,6 +9,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 namespace hc {
@@ -81,7 +84,9 @@ struct OverlapsParser::Segment {
     size_t begin = 0, end = 0;      // byte range, begin at a line start
     uint64_t first_line = 0;        // index of its first line in the file
     uint64_t line_limit = 0;        // lines with index >= line_limit are not read (max_overlaps, :581)
-    std::vector<ParsedOverlap> pass;
+    Overlap* out_line = nullptr;        // where this segment's passing candidates go (room for one per line + 1)
+    hc_overlap_rec* out_rec = nullptr;
+    size_t n_pass = 0;
     std::vector<Overlap> rejected;
     std::vector<uint32_t> reject_before;  // rejected[k] precedes pass[reject_before[k]] in file order (unused: order is kept per kind)
     ParseCounters c;
@@ -111,9 +116,9 @@ void OverlapsParser::parse_segment(Segment& seg) const {
                 seg.c.malformed++;
                 continue;
             }
-            ParsedOverlap po;
-            po.line = Overlap::from_fields(field, flen);
-            const Overlap& o = po.line;
+            Overlap& o_slot = seg.out_line[seg.n_pass];  // becomes part of the block only if the line passes
+            o_slot = Overlap::from_fields(field, flen);
+            const Overlap& o = o_slot;
             if (o.m_id1 == o.m_id2) { seg.c.self_overlaps++; continue; }  // :605-607
             const unsigned int perc = o.get_perc();
             const bool ss = o.m_type1 == 's' && o.m_type2 == 's';
@@ -134,7 +139,7 @@ void OverlapsParser::parse_segment(Segment& seg) const {
             }
             if (!pass) continue;
             // id -> index: std::map::at in compute_overlap, :170-171 (throws => the reference aborts)
-            hc_overlap_rec& r = po.rec;
+            hc_overlap_rec& r = seg.out_rec[seg.n_pass];
             if (!m_ids.find(o.m_id1, r.read1) || !m_ids.find(o.m_id2, r.read2))
                 throw FatalError{HC_ERR_BAD_OVERLAP, "overlap refers to a read id that is not in the FASTQ input"};
             r.pos1 = o.m_pos1;
@@ -146,13 +151,78 @@ void OverlapsParser::parse_segment(Segment& seg) const {
             r.len1 = o.m_len1;
             r.len2 = o.m_len2;
             r.perc = perc;
-            seg.pass.push_back(po);
+            seg.n_pass++;
         }
     } catch (const FatalError& e) {
         seg.failed = true;
         seg.error = e;
     }
 }
+
+// Worker threads that live as long as the parser: a block is parsed in two short parallel passes, and starting
+// 2 x (threads - 1) threads per block costs more than parsing it.
+class OverlapsParser::Pool {
+public:
+    explicit Pool(unsigned int workers) {
+        for (unsigned int w = 0; w < workers; w++) m_threads.emplace_back([this, w] { loop(w + 1); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(m_mu);
+            m_stop = true;
+            m_generation++;
+        }
+        m_cv.notify_all();
+        for (auto& t : m_threads) t.join();
+    }
+    unsigned int workers() const { return (unsigned int)m_threads.size(); }
+    // fn(t) for t in [0, n): t = 0 on the caller, the rest on the workers (n - 1 <= workers())
+    void run(unsigned int n, const std::function<void(unsigned int)>& fn) {
+        if (n <= 1) {
+            fn(0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_mu);
+            m_fn = &fn;
+            m_n = n;
+            m_pending = n - 1;
+            m_generation++;
+        }
+        m_cv.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(m_mu);
+        m_done.wait(g, [this] { return m_pending == 0; });
+        m_fn = nullptr;
+    }
+
+private:
+    void loop(unsigned int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned int)>* fn = nullptr;
+            {
+                std::unique_lock<std::mutex> g(m_mu);
+                m_cv.wait(g, [&] { return m_generation != seen; });
+                seen = m_generation;
+                if (m_stop) return;
+                if (id < m_n) fn = m_fn;
+            }
+            if (fn) {
+                (*fn)(id);
+                std::lock_guard<std::mutex> g(m_mu);
+                if (--m_pending == 0) m_done.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> m_threads;
+    std::mutex m_mu;
+    std::condition_variable m_cv, m_done;
+    const std::function<void(unsigned int)>* m_fn = nullptr;
+    unsigned int m_n = 0, m_pending = 0;
+    uint64_t m_generation = 0;
+    bool m_stop = false;
+};
 
 OverlapsParser::OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq)
     : m_ps(ps), m_fastq(fastq), m_ids(fastq), m_threads(ps.n_threads ? ps.n_threads : 1) {
@@ -168,9 +238,11 @@ OverlapsParser::OverlapsParser(const std::string& path, const ProgramSettings& p
         m_data = (const char*)p;
     }
     m_open = true;
+    if (m_threads > 1) m_pool.reset(new Pool(m_threads - 1));
 }
 
 OverlapsParser::~OverlapsParser() {
+    m_pool.reset();
     if (m_data) munmap((void*)m_data, m_size);
     if (m_fd >= 0) close(m_fd);
 }
@@ -180,8 +252,8 @@ OverlapsParser::~OverlapsParser() {
 // max_overlaps line limit is honoured exactly), segments are parsed concurrently and concatenated in
 // file order.  `max_batch` bounds the block by bytes (~64 bytes of text per accepted candidate), not
 // exactly by count: batch boundaries do not influence the result (the insert is sequential anyway).
-bool OverlapsParser::next_batch(std::vector<ParsedOverlap>& batch, size_t max_batch, std::vector<Overlap>& rejected,
-                                ParseCounters& c, bool print_malformed) {
+bool OverlapsParser::next_batch(ParsedBatch& batch, size_t max_batch, std::vector<Overlap>& rejected, ParseCounters& c,
+                                bool print_malformed) {
     batch.clear();
     if (!m_open || m_done) return false;
     if (m_pos >= m_size || !(m_line_no < m_ps.max_overlaps)) {
@@ -211,12 +283,12 @@ bool OverlapsParser::next_batch(std::vector<ParsedOverlap>& batch, size_t max_ba
         segs[t].end = e;
         cut = e;
     }
-    auto run = [&](auto&& fn) {
-        if (T == 1) { fn(0u); return; }
-        std::vector<std::thread> th;
-        for (unsigned int t = 1; t < T; t++) th.emplace_back(fn, t);
-        fn(0u);
-        for (auto& x : th) x.join();
+    auto run = [&](const std::function<void(unsigned int)>& fn) {
+        if (T == 1 || !m_pool) {
+            for (unsigned int t = 0; t < T; t++) fn(t);
+            return;
+        }
+        m_pool->run(T, fn);
     };
     // pass 1: lines per segment (a final piece without a trailing newline is a line too)
     std::vector<uint64_t> nlines(T, 0);
@@ -232,16 +304,36 @@ bool OverlapsParser::next_batch(std::vector<ParsedOverlap>& batch, size_t max_ba
         nlines[t] = k;
     });
     uint64_t line = m_line_no;
+    size_t room = 0;
     for (unsigned int t = 0; t < T; t++) {
         segs[t].first_line = line;
         segs[t].line_limit = m_ps.max_overlaps;
         line += nlines[t];
+        room += nlines[t] + 1;  // one spare element per segment: a line is parsed in place before it is known to pass
     }
-    // pass 2: parse
+    // pass 2: parse, every segment straight into its own stretch of the block
+    batch.ensure(room);
+    {
+        size_t at = 0;
+        for (unsigned int t = 0; t < T; t++) {
+            segs[t].out_line = batch.lines.data() + at;
+            segs[t].out_rec = batch.recs + at;
+            at += nlines[t] + 1;
+        }
+    }
     run([&](unsigned int t) { parse_segment(segs[t]); });
-    size_t total = 0;
-    for (auto& sg : segs) total += sg.pass.size();
-    batch.reserve(total);
+    // close the gaps (lines that did not pass, the spare elements): nothing moves in front of the first gap
+    {
+        size_t at = 0;
+        for (auto& sg : segs) {
+            if (sg.out_rec != batch.recs + at && sg.n_pass) {
+                memmove((void*)(batch.lines.data() + at), (const void*)sg.out_line, sg.n_pass * sizeof(Overlap));
+                memmove((void*)(batch.recs + at), (const void*)sg.out_rec, sg.n_pass * sizeof(hc_overlap_rec));
+            }
+            at += sg.n_pass;
+        }
+        batch.n = at;
+    }
     for (auto& sg : segs) {
         c.lines_read += sg.c.lines_read;
         c.malformed += sg.c.malformed;
@@ -250,8 +342,10 @@ bool OverlapsParser::next_batch(std::vector<ParsedOverlap>& batch, size_t max_ba
         c.silently_dropped += sg.c.silently_dropped;
         if (print_malformed)
             for (uint64_t k = 0; k < sg.c.malformed; k++) puts("incorrect overlap; skipping");
-        if (sg.failed) throw sg.error;  // first failing segment in file order
-        batch.insert(batch.end(), sg.pass.begin(), sg.pass.end());
+        if (sg.failed) {  // first failing segment in file order
+            batch.n = 0;
+            throw sg.error;
+        }
         rejected.insert(rejected.end(), sg.rejected.begin(), sg.rejected.end());
     }
     m_pos = block_end;

@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../../include/hcedge.h"
@@ -13,9 +14,48 @@
 
 namespace hc {
 
-struct ParsedOverlap {
-    Overlap line;        // what get_overlap_line() re-serialises
-    hc_overlap_rec rec;  // what the device scores (read ids resolved to m_read_vec indices)
+// One block of candidates, structure of arrays: lines[i] is what get_overlap_line() re-serialises, recs[i] what
+// the device scores (read ids resolved to m_read_vec indices).  The storage only grows (a block reuses the
+// elements of the one before it), and the record array can live in memory the caller provides — page-locked
+// memory in the stage, so that the parser's output is what the device reads, without a copy in between.
+struct ParsedBatch {
+    struct RecStorage {  // optional provider of the record array
+        void* ctx = nullptr;
+        hc_overlap_rec* (*alloc)(void* ctx, size_t n) = nullptr;
+        void (*release)(void* ctx, hc_overlap_rec* p) = nullptr;
+    };
+    ParsedBatch() = default;
+    explicit ParsedBatch(const RecStorage& st) : storage(st) {}
+    ParsedBatch(const ParsedBatch&) = delete;
+    ParsedBatch& operator=(const ParsedBatch&) = delete;
+    ~ParsedBatch() {
+        if (recs && storage.release) storage.release(storage.ctx, recs);
+    }
+    void ensure(size_t room) {  // contents are not kept
+        if (lines.size() < room) lines.resize(room);
+        if (cap >= room) return;
+        const size_t want = room + room / 8;
+        if (storage.alloc) {
+            if (recs) storage.release(storage.ctx, recs);
+            recs = storage.alloc(storage.ctx, want);
+        } else {
+            own.resize(want);
+            recs = own.data();
+        }
+        cap = want;
+    }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void clear() { n = 0; }
+
+    std::vector<Overlap> lines;
+    hc_overlap_rec* recs = nullptr;
+    size_t n = 0;  // the first n lines / recs are this block
+
+private:
+    RecStorage storage;
+    std::vector<hc_overlap_rec> own;
+    size_t cap = 0;
 };
 
 struct ParseCounters {
@@ -65,12 +105,13 @@ public:
     // order; lines that fail the length/type test are appended to `rejected` (written to
     // nonedge_overlaps.txt at the end, :654-660).  Returns false when the input is exhausted
     // (or max_overlaps lines have been read, :581).
-    bool next_batch(std::vector<ParsedOverlap>& batch, size_t max_batch, std::vector<Overlap>& rejected,
-                    ParseCounters& c, bool print_malformed);
+    bool next_batch(ParsedBatch& batch, size_t max_batch, std::vector<Overlap>& rejected, ParseCounters& c, bool print_malformed);
 
 private:
     struct Segment;
     void parse_segment(Segment& seg) const;
+    class Pool;  // the parser's worker threads, started once
+    std::unique_ptr<Pool> m_pool;
 
     const ProgramSettings& m_ps;
     const FastqStorage& m_fastq;

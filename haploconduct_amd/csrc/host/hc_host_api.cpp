@@ -1,5 +1,9 @@
 // hc_host_api.cpp — the host-only entry points of include/hcedge_host.h (no device needed): tokenizer,
 // Overlap record parsing, FastqStorage, parser + prefilter, serial insert on a bare graph.
+#include <algorithm>
+#include <thread>
+#include <vector>
+
 #include "api_helpers.h"
 
 struct hc_fastq {
@@ -38,6 +42,90 @@ int hc_sfo2overlaps(const char* sfo_path, const char* out_path, uint64_t num_sin
         fwrite(out.data(), 1, out.size(), o);
         fclose(o);
         if (n_lines) *n_lines = n;
+    });
+}
+
+int hc_host_write_overlaps(const char* path, const hc_overlap_rec* recs, uint64_t n, const uint64_t* read_ids, const uint8_t* read_paired,
+                           uint64_t n_reads, uint32_t n_threads) {
+    if (!path || (n && (!recs || !read_ids || !read_paired))) return set_last_error(HC_ERR_ARG, "hc_host_write_overlaps: null");
+    return guarded("write_overlaps", [&] {
+        FILE* o = fopen(path, "wb");
+        if (!o) throw FatalError{HC_ERR_IO, std::string("cannot write ") + path};
+        unsigned T = n_threads ? n_threads : std::thread::hardware_concurrency();
+        if (T == 0) T = 1;
+        if (T > 64) T = 64;
+        auto put = [](char* p, uint64_t v) {
+            char tmp[24];
+            int k = 0;
+            do {
+                tmp[k++] = (char)('0' + v % 10);
+                v /= 10;
+            } while (v);
+            while (k) *p++ = tmp[--k];
+            return p;
+        };
+        const uint64_t kBlock = 1u << 22;  // records per round: bounds the text held in memory
+        std::vector<std::vector<char>> buf(T);
+        bool bad = false;
+        for (uint64_t base = 0; base < n && !bad; base += kBlock) {
+            const uint64_t m = std::min<uint64_t>(kBlock, n - base);
+            std::vector<std::thread> th;
+            std::vector<int> err(T, 0);
+            for (unsigned t = 0; t < T; t++)
+                th.emplace_back([&, t] {
+                    const uint64_t b = base + m * t / T, e = base + m * (t + 1) / T;
+                    buf[t].resize((e - b) * 128);
+                    char* p = buf[t].data();
+                    for (uint64_t i = b; i < e; i++) {
+                        const hc_overlap_rec& r = recs[i];
+                        if (r.read1 >= n_reads || r.read2 >= n_reads) {
+                            err[t] = 1;
+                            break;
+                        }
+                        const bool p1 = read_paired[r.read1], p2 = read_paired[r.read2], ss = !p1 && !p2;
+                        p = put(p, read_ids[r.read1]);
+                        *p++ = '\t';
+                        p = put(p, read_ids[r.read2]);
+                        *p++ = '\t';
+                        p = put(p, r.pos1);
+                        *p++ = '\t';
+                        if (ss) *p++ = '-';
+                        else p = put(p, r.pos2);
+                        *p++ = '\t';
+                        *p++ = (char)r.ord;
+                        *p++ = '\t';
+                        *p++ = r.ori1 ? '+' : '-';
+                        *p++ = '\t';
+                        *p++ = r.ori2 ? '+' : '-';
+                        *p++ = '\t';
+                        p = put(p, r.perc);
+                        *p++ = '\t';
+                        if (ss) *p++ = '-';
+                        else p = put(p, r.perc);
+                        *p++ = '\t';
+                        p = put(p, r.len1);
+                        *p++ = '\t';
+                        if (ss) *p++ = '-';
+                        else p = put(p, r.len2);
+                        *p++ = '\t';
+                        *p++ = p1 ? 'p' : 's';
+                        *p++ = '\t';
+                        *p++ = p2 ? 'p' : 's';
+                        *p++ = '\n';
+                    }
+                    buf[t].resize((size_t)(p - buf[t].data()));
+                });
+            for (auto& x : th) x.join();
+            for (unsigned t = 0; t < T; t++) {
+                if (err[t]) bad = true;
+                if (!bad && !buf[t].empty() && fwrite(buf[t].data(), 1, buf[t].size(), o) != buf[t].size()) {
+                    fclose(o);
+                    throw FatalError{HC_ERR_IO, std::string("short write to ") + path};
+                }
+            }
+        }
+        if (fclose(o) != 0) throw FatalError{HC_ERR_IO, std::string("cannot close ") + path};
+        if (bad) throw FatalError{HC_ERR_BAD_OVERLAP, "hc_host_write_overlaps: read index out of range"};
     });
 }
 
@@ -115,15 +203,15 @@ int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* ove
         ps.overlaps_file = overlaps_path;
         OverlapsParser parser(ps.overlaps_file, ps, *f->fastq);
         if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};
-        std::vector<ParsedOverlap> batch;
+        ParsedBatch batch;
         std::vector<Overlap> rejected;
         ParseCounters pc;
         uint64_t n = 0;
         for (;;) {
             const bool more = parser.next_batch(batch, 1000000, rejected, pc, false);
             if (!more) break;
-            for (const auto& b : batch) {
-                if (out && n < cap) out[n] = b.rec;
+            for (size_t i = 0; i < batch.size(); i++) {
+                if (out && n < cap) out[n] = batch.recs[i];
                 n++;
             }
         }

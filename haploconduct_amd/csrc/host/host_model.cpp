@@ -315,9 +315,12 @@ std::string Overlap::get_overlap_line() const {
 // ------------------------------------------------------------------ OverlapGraph
 void OverlapGraph::addEdge(const Edge& edge) {  // src/OverlapGraph.cpp:94-101
     const node_id_t v = edge.get_vertex(1), w = edge.get_vertex(2);
+    if (adj_out[v].capacity() == 0) adj_out[v].reserve(4);  // skips the 1 -> 2 -> 4 reallocations of nearly every vertex
+    if (adj_in[w].capacity() == 0) adj_in[w].reserve(8);
     adj_out[v].push_back(edge);
     adj_in[w].push_back(v);
     edge_count++;
+    if (EdgeSlotIndex::representable(v, w)) slots.add(EdgeSlotIndex::key(v, w, edge.get_ori(1) == edge.get_ori(2)));
 }
 
 static inline bool same_ori_class(const Edge& e, bool opposite_orientations) {
@@ -334,6 +337,7 @@ Edge OverlapGraph::removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_ori
             L.erase(it);
             edge_count--;
             found = true;
+            if (EdgeSlotIndex::representable(v, w)) slots.remove(EdgeSlotIndex::key(v, w, opposite_orientations));
             break;
         }
     }
@@ -349,6 +353,7 @@ Edge OverlapGraph::removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_ori
 }
 
 double OverlapGraph::checkEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) const {  // :198-229
+    if (EdgeSlotIndex::representable(v, w) && !slots.contains(EdgeSlotIndex::key(v, w, opposite_orientations))) return -1;
     for (const Edge& e : adj_out.at(v))
         if (e.get_vertex(2) == w && same_ori_class(e, opposite_orientations)) return e.get_score();
     for (const Edge& e : adj_out.at(w))

@@ -62,6 +62,7 @@ _sig = {
     "hc_host_parse_file": (C.c_int, [C.POINTER(N.hc_settings), _vp, C.c_char_p, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                      C.POINTER(hc_ec_counters)]),
     "hc_sfo2overlaps": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "hc_host_write_overlaps": (C.c_int, [C.c_char_p, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint32]),
     "hc_host_graph_new": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.POINTER(N.hc_settings)]),
     "hc_host_graph_insert": (C.c_int, [_vp, _vp]),
     "hc_host_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64]),
@@ -100,6 +101,16 @@ def parse_overlap(line, allow_spaces=False):
     return 0, {"id1": o.id1, "id2": o.id2, "pos1": o.pos1, "pos2": o.pos2, "ord": o.ord.decode(), "ori1": o.ori1.decode(),
                "ori2": o.ori2.decode(), "type1": o.type1.decode(), "type2": o.type2.decode(), "perc": o.perc,
                "len1": o.len1, "len2": o.len2, "line": text.value.decode()}
+
+
+def write_overlaps(path, recs, reads, n_threads=0):
+    """Candidate records -> 13-column overlaps file (hc_host_write_overlaps): what synth.records_to_lines does, natively."""
+    recs = np.ascontiguousarray(recs)
+    ids = np.ascontiguousarray(reads.read_ids, dtype=np.uint64)
+    rfs = np.asarray(reads.read_first_seq)
+    paired = np.ascontiguousarray((rfs[1:] - rfs[:-1]) == 2, dtype=np.uint8)
+    N.check(N.lib.hc_host_write_overlaps(_b(path), recs.ctypes.data, recs.size, ids.ctypes.data, paired.ctypes.data, ids.size, n_threads),
+            "hc_host_write_overlaps")
 
 
 def sfo2overlaps(sfo_path, out_path, num_singles, num_pairs):

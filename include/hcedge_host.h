@@ -97,6 +97,13 @@ int hc_host_fastq_free(hc_fastq* f);
 int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* overlaps_path, hc_overlap_rec* out,
                        uint64_t cap, uint64_t* n_out, hc_ec_counters* counters);
 
+/* The inverse of the parser: n candidate records as 13-column overlaps-file lines (SURVEY.md Appendix A;
+ * Overlap::get_overlap_line, src/Overlap.h:234-237, with "-" in the POS2/PERC2/LEN2 columns of a
+ * single-single overlap as scripts/sfo2overlaps.py:153 writes them).  read_ids[r] / read_paired[r] describe
+ * read index r.  Formats on n_threads threads (0 = all), writes sequentially. */
+int hc_host_write_overlaps(const char* path, const hc_overlap_rec* recs, uint64_t n, const uint64_t* read_ids,
+                           const uint8_t* read_paired, uint64_t n_reads, uint32_t n_threads);
+
 /* SFO ingest: rust-overlaps' 8-column SFO file -> SAVAGE's 13-column overlaps file with
  * the semantics of the reference's scripts/sfo2overlaps.py (--in, --out, --num_singles, --num_pairs),
  * including its sort / uniq passes.  *n_lines receives the number of overlap lines written. */

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--threads", type=int, default=16, help="--threads of the stage (parser workers)")
     ap.add_argument("--oracle-lines", type=int, default=200000, help="lines of the file the 1-thread oracle is timed on")
+    ap.add_argument("--reps", type=int, default=2)
     args = ap.parse_args()
     import bench
     import haploconduct_amd as hc
@@ -28,16 +29,15 @@ def main():
     st.n_threads = args.threads
     d = tempfile.mkdtemp(prefix="hcstage_") + "/"
     t0 = time.time()
-    lines = synth.records_to_lines(cand, reads)
-    with open(d + "overlaps.txt", "w") as f:
-        f.write("\n".join(lines) + "\n")
+    host.write_overlaps(d + "overlaps.txt", cand, reads)
+    n_lines = int(cand.size)
     paired = reads.is_paired(0)
     reads.write_fastq(None if paired else d + "singles.fastq", d + "paired1.fastq" if paired else None,
                       d + "paired2.fastq" if paired else None)
-    print(f"files written in {time.time()-t0:.1f} s: {os.path.getsize(d+'overlaps.txt')/1e6:.1f} MB overlaps, {len(lines)} lines")
+    print(f"files written in {time.time()-t0:.1f} s: {os.path.getsize(d+'overlaps.txt')/1e6:.1f} MB overlaps, {n_lines} lines")
     kw = dict(singles=None if paired else d + "singles.fastq", paired1=d + "paired1.fastq" if paired else None,
               paired2=d + "paired2.fastq" if paired else None, overlaps=d + "overlaps.txt", output_dir=d)
-    for rep in range(2):
+    for rep in range(args.reps):
         if os.path.exists(d + "nonedge_overlaps.txt"):
             os.remove(d + "nonedge_overlaps.txt")
         t0 = time.time()
@@ -51,13 +51,14 @@ def main():
               f"insert {c['t_insert']:.3f} write {c['t_write']:.3f}; edges {ec.edge_count()} dups {c['dup_count']} "
               f"nonedges {c['nonedges_written']}")
         ec.close()
-    n = min(args.oracle_lines, len(lines))
-    with open(d + "head.txt", "w") as f:
-        f.write("\n".join(lines[:n]) + "\n")
+    n = min(args.oracle_lines, n_lines)
+    host.write_overlaps(d + "head.txt", cand[:n], reads)
     t0 = time.time()
     rc, g, oc = _oracle.construct_edges(reads, st, d + "head.txt", d + "ref_nonedge.txt")
     dt = time.time() - t0
     print(f"oracle construct_edges (1 thread) on the first {n} lines: {dt:.2f} s -> {oc.scored/dt/1e3:.1f} k candidates/s")
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":
