@@ -129,6 +129,12 @@ def main():
                          "writes overlap files (default); grouped = by read1; shuffled = random (experiment knobs)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON record of rank 0.  Libraries underneath write there too (RCCL prints
+    # its version banner through C stdio, flushed at exit): park fd 1 on stderr until the record is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,10 +146,17 @@ def main():
         raise SystemExit("bench.py needs a HIP device: libhcedge has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # HC_BENCH_FORCE_GATHER=1: run the N > 1 step (compaction + pack + all-gathers) on a single rank too, to time
+    # and test that code path on one GPU; never set by the driver
+    with_gather = world > 1 or os.environ.get("HC_BENCH_FORCE_GATHER") == "1"
+    if with_gather:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
 
     import haploconduct_amd as hc
 
@@ -161,21 +174,34 @@ def main():
     positions, subs = sc.count_positions_device(d_in.data_ptr(), n)
     alg_bytes = 48 * n + 4 * positions  # 32 B record + 16 B result + 4 B per overlapped position
 
-    def gather_edges():
-        # admitted-edge records to every rank — counts, then padded payload (one all-gather-v)
+    # N > 1: rank r owns global candidates [r*n, (r+1)*n) (weak scaling) against a replicated read
+    # store; per step, the non-dropped records of every rank are collected on every rank: device compaction, one
+    # pack kernel, then the all-gather-v as two all-gathers (counts, rows padded to a fixed capacity) over RCCL.
+    # Everything is enqueued on one HIP stream, nothing synchronises with the host inside a step, and the
+    # all-gather of step i overlaps the scoring kernel of step i+1 (parallel.StreamedGather).
+    stream = torch.cuda.current_stream().cuda_stream
+    gather = None
+    if with_gather:
         from haploconduct_amd import parallel
 
-        lo = rank * n  # weak scaling: rank r owns global candidates [r*n, (r+1)*n)
-        return parallel.gather_admitted(d_out, lo)
+        sc.score_batch_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        kept = torch.tensor([int((((d_out.view(torch.int64).view(-1, 3)[:, 2] >> 60) & 0xF) != 0).sum().item())], device="cuda")
+        dist.all_reduce(kept, op=dist.ReduceOp.MAX)  # one capacity for all ranks
+        gather = parallel.StreamedGather(sc, n, base_index=rank * n, cap_rows=int(kept.item()) * 5 // 4 + 1024)
+
+    last = None
 
     def step():
-        sc.score_batch_device(d_in.data_ptr(), n, d_out.data_ptr())
-        if world > 1:
-            sc.synchronize()
-            gather_edges()
+        nonlocal last
+        sc.score_batch_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
+        if gather:
+            last = gather.step(d_out)
 
     for _ in range(args.warmup):
         step()
+    if gather:
+        gather.finish()
     sc.synchronize()
     torch.cuda.synchronize()
     if dist:
@@ -183,11 +209,16 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if gather:
+        gather.finish()  # every all-gather of the timed steps has completed
     sc.synchronize()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if gather:  # outside the timed region: the collected set is what it should be
+        rows, counts = gather.collect(last)
+        assert len(counts) == world and rows.shape[0] == sum(counts) and bool((rows[1:, 0] > rows[:-1, 0]).all()), "gathered rows out of order"
     if dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,10 +252,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(reads, settings, cand)
-        print(json.dumps(out))
     sc.close()
     if dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)  # whatever C stdio still holds goes to stderr
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
 size_t compact_temp_bytes(uint32_t n);
 hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_out, unsigned long long* count_out, void* temp,
                           size_t temp_bytes, hipStream_t stream);
+hipError_t launch_pack_rows(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count, uint64_t cap, uint64_t base,
+                            hc_gather_row* rows, uint32_t n_cu, hipStream_t stream);
 hipError_t launch_gather_results(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count,
                                  hc_result_rec* out, uint32_t n_cu, hipStream_t stream);
 size_t reorder_temp_bytes(uint32_t n);
@@ -523,6 +525,18 @@ int hc_compact_device(hc_ctx* c, const void* d_results, uint64_t n, void* d_indi
     if (rc) return rc;
     HC_HIP(hc::launch_compact((const hc_result_rec*)d_results, (uint32_t)n, (uint32_t*)d_indices, (unsigned long long*)d_count,
                               c->d_compact_tmp, c->compact_tmp_bytes, s));
+    return HC_OK;
+}
+
+int hc_pack_rows_device(hc_ctx* c, const void* d_results, const void* d_indices, const void* d_count, uint64_t cap, uint64_t base_index,
+                        void* d_rows, void* hip_stream) {
+    if (!c || !d_count) return fail(HC_ERR_ARG, "hc_pack_rows_device: null argument");
+    if (cap == 0) return HC_OK;
+    if (!d_results || !d_indices || !d_rows) return fail(HC_ERR_ARG, "hc_pack_rows_device: null buffer");
+    HC_HIP(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    HC_HIP(hc::launch_pack_rows((const hc_result_rec*)d_results, (const uint32_t*)d_indices, (const unsigned long long*)d_count, cap,
+                                base_index, (hc_gather_row*)d_rows, c->n_cu, s));
     return HC_OK;
 }
 

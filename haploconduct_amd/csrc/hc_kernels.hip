@@ -1092,6 +1092,32 @@ hipError_t launch_gather_results(const hc_result_rec* res, const uint32_t* idx, 
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void pack_rows_kernel(const hc_result_rec* __restrict__ res, const uint32_t* __restrict__ idx,
+                                                        const unsigned long long* __restrict__ count, unsigned long long cap,
+                                                        unsigned long long base, hc_gather_row* __restrict__ rows) {
+    unsigned long long k = *count;
+    k = k < cap ? k : cap;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < k;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t j = idx[i];
+        const hc_result_rec r = res[j];
+        hc_gather_row o;
+        o.index = base + j;
+        o.x1 = r.x1;
+        o.x2 = r.x2;
+        o.mm = r.mm;
+        o.n_cls = r.n_cls;
+        rows[i] = o;
+    }
+}
+
+hipError_t launch_pack_rows(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count, uint64_t cap, uint64_t base,
+                            hc_gather_row* rows, uint32_t n_cu, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(n_cu * 4), dim3(256), 0, stream, res, idx, count, (unsigned long long)cap,
+                       (unsigned long long)base, rows);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // Launch wrappers (called from hc_api.cpp).
 hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,

@@ -83,6 +83,11 @@ class EdgeScorer:
         N.check(N.lib.hc_compact_device(self._ctx, C.c_void_p(d_results_ptr), n, C.c_void_p(d_indices_ptr),
                                         C.c_void_p(d_count_ptr), C.c_void_p(stream or 0)), "hc_compact_device")
 
+    def pack_rows_device(self, d_results_ptr, d_indices_ptr, d_count_ptr, cap, base_index, d_rows_ptr, stream=None):
+        """hc_pack_rows_device: compacted records -> 32-byte rows tagged with their global candidate index."""
+        N.check(N.lib.hc_pack_rows_device(self._ctx, C.c_void_p(d_results_ptr), C.c_void_p(d_indices_ptr), C.c_void_p(d_count_ptr),
+                                          cap, base_index, C.c_void_p(d_rows_ptr), C.c_void_p(stream or 0)), "hc_pack_rows_device")
+
     def score_batch_device(self, d_in_ptr, n, d_out_ptr, stream=None):
         """Device pointers (ints, e.g. torch tensor .data_ptr()); asynchronous."""
         N.check(N.lib.hc_score_batch_device(self._ctx, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr),

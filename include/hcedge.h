@@ -179,6 +179,18 @@ int hc_synchronize(hc_ctx* ctx);
  * device.  Asynchronous on `hip_stream` (NULL = the context's stream). */
 int hc_compact_device(hc_ctx* ctx, const void* d_results, uint64_t n, void* d_indices, void* d_count, void* hip_stream);
 
+/* The payload of the multi-GPU collection: for k < min(*d_count, cap),
+ *   d_rows[k] = { uint64 base_index + d_indices[k]; double x1; double x2; uint32 mm; uint32 n_cls }   (32 bytes)
+ * i.e. the compacted records of this rank's shard tagged with their global candidate index, ready for one
+ * all-gather.  Rows at and beyond *d_count are left untouched.  Asynchronous on `hip_stream`. */
+typedef struct hc_gather_row {
+    uint64_t index;
+    double x1, x2;
+    uint32_t mm, n_cls;
+} hc_gather_row; /* 32 bytes */
+int hc_pack_rows_device(hc_ctx* ctx, const void* d_results, const void* d_indices, const void* d_count, uint64_t cap,
+                        uint64_t base_index, void* d_rows, void* hip_stream);
+
 /* hc_score_batch + compaction in one call for host callers: scores `in` on the device and copies back
  * only the non-DROP records: idx_out[k] (ascending) and res_out[k] = result of in[idx_out[k]].
  * cap = capacity of idx_out / res_out in records; *n_out = number of non-DROP records (if it exceeds
