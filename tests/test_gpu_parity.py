@@ -320,3 +320,77 @@ def test_compaction_entry_points(oracle):
         assert k == keep.size and np.array_equal(d_idx[:k].cpu().numpy().view(np.uint32), keep)
         empty_idx, empty_res = sc.score_batch_compact(cand[:0])
         assert empty_idx.size == 0
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_random_read_sets_settings_and_geometry(oracle, seed):
+    """Everything at once, seeded: singles / pairs / both, sequence lengths from 1 to a few hundred, quality
+    alphabets of 1..70 symbols (all three symbol encodings), N runs, random orientations and ord, positions
+    from the true geometry and at random (including pos >= length), random thresholds / --mismatch /
+    min_read_len / merge_contigs.  The HIP path must reproduce the oracle bit for bit on all of it."""
+    rng = np.random.default_rng(9000 + seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    glen = int(rng.integers(400, 3000))
+    genome = acgt[rng.integers(0, 4, glen)]
+    K = int(rng.choice([1, 2, 5, 9, 20, 29, 30, 31, 40, 47, 48, 49, 60, 70]))
+    alphabet = (rng.choice(np.arange(33, 127), size=min(K, 94), replace=False)).astype(np.uint8)
+    err, nrate = float(rng.choice([0.0, 0.003, 0.02])), float(rng.choice([0.0, 0.002, 0.05]))
+    lo, hi = (1, 40) if seed % 5 == 0 else (30, int(rng.integers(120, 700)))
+
+    def piece(s, L, rc):
+        seg = genome[s:s + L].copy()
+        k = rng.random(L) < err
+        seg[k] = acgt[rng.integers(0, 4, int(k.sum()))]
+        if nrate:
+            seg[rng.random(L) < nrate] = ord("N")
+            if L > 20 and rng.random() < 0.3:
+                a = int(rng.integers(0, L - 10))
+                seg[a:a + int(rng.integers(1, 10))] = ord("N")
+        if rc:  # stored reverse-complemented: the candidate then carries ori '-'
+            comp = np.zeros(256, np.uint8)
+            comp[list(b"ACGTN")] = list(b"TGCAN")
+            seg = comp[seg][::-1]
+        return seg.tobytes(), alphabet[rng.integers(0, alphabet.size, L)].tobytes()
+
+    mode = seed % 3  # 0 singles, 1 pairs, 2 both
+    singles, pairs, geo = [], [], []  # geo: (start, len1, start2, len2, rc)
+    n_s = 0 if mode == 1 else int(rng.integers(20, 120))
+    n_p = 0 if mode == 0 else int(rng.integers(20, 120))
+    for _ in range(n_s):
+        L = int(rng.integers(lo, hi))
+        s = int(rng.integers(0, glen - L))
+        rc = bool(rng.random() < 0.3)
+        singles.append(piece(s, L, rc))
+        geo.append((s, L, 0, 0, rc))
+    for _ in range(n_p):
+        L1, L2 = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
+        ins = L1 + L2 + int(rng.integers(0, 200))
+        s = int(rng.integers(0, max(1, glen - ins)))
+        s2 = min(s + ins - L2, glen - L2)
+        pairs.append((piece(s, L1, False), piece(s2, L2, False)))
+        geo.append((s, L1, s2, L2, False))
+    reads = hc.ReadSet.from_lists(singles, pairs)
+    n = reads.n_reads
+    m = 1500
+    cand = np.zeros(m, OVERLAP_DTYPE)
+    a = rng.integers(0, n, m)
+    b = (a + 1 + rng.integers(0, n - 1, m)) % n
+    cand["read1"], cand["read2"] = a, b
+    for i in range(m):
+        ga, gb = geo[a[i]], geo[b[i]]
+        pa, pb = a[i] >= n_s, b[i] >= n_s
+        true_geo = rng.random() < 0.6
+        cand["pos1"][i] = max(0, gb[0] - ga[0]) if true_geo else int(rng.integers(0, hi + 20))
+        cand["pos2"][i] = (max(0, gb[2] - ga[2]) if true_geo else int(rng.integers(0, hi + 20))) if (pa or pb) else 0
+        cand["ori1"][i] = (0 if ga[4] else 1) if true_geo else int(rng.integers(0, 2))
+        cand["ori2"][i] = (0 if gb[4] else 1) if true_geo else int(rng.integers(0, 2))
+        cand["ord"][i] = ord("12"[int(rng.integers(2))]) if (pa and pb) else ord("-")
+        cand["flags"][i] = int(pa) | (int(pb) << 1)
+    cand["len1"], cand["len2"], cand["perc"] = rng.integers(1, 300, m), rng.integers(0, 300, m), rng.integers(0, 101, m)
+    st = hc.Settings(edge_threshold=float(rng.choice([0.5, 0.9, 0.97, 0.995, 1.0])), ov_threshold=float(rng.choice([0.0, 0.3, 0.9])),
+                     merge_contigs=float(rng.choice([0.0, 0.0, 0.01, 0.2])), mismatch=float(rng.choice([0.0, 0.0, 1e-4, 0.05])),
+                     min_read_len=int(rng.choice([0, 0, 20, 60])))
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        assert sc.info()["qual_alphabet"] == np.unique(reads.quals).size
+    check_parity(oracle, reads, st, cand)
