@@ -7,6 +7,7 @@ set -e
 W=${1:-c2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
+rm -rf $R/gpurun_out/traffic_fetch $R/gpurun_out/traffic_write $R/gpurun_out/traffic_l2 $R/gpurun_out/traffic_l1 $R/gpurun_out/traffic_sq $R/gpurun_out/traffic_lds
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/traffic_fetch -- $B > /dev/null 2>&1
