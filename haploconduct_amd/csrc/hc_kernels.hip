@@ -639,10 +639,9 @@ __device__ __forceinline__ void score_candidate(const ScoreParams& prm, const Sy
 // chunk; bit2: 64/32/128/48-symbol fetch groups (score_sub_wide).  LG: log2 of the 8-bit-symbol table
 // dimension (3..6; ignored for 16-bit symbols).  BAL: block-local length balancing (below).
 template <typename SymT, int VAR, int LG, bool BAL>
-__global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
-                                                    const hc_overlap_rec* __restrict__ in, uint64_t n,
-                                                    hc_result_rec* __restrict__ out,
-                                                    const uint32_t* __restrict__ perm) {
+__device__ __forceinline__ void score_kernel_body(const StoreView& st, const ScoreParams& prm, const double* __restrict__ lut_g,
+                                                  const hc_overlap_rec* __restrict__ in, uint64_t n,
+                                                  hc_result_rec* __restrict__ out, const uint32_t* __restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) double lut_s[];
     const uint32_t lut_n = st.lut_bytes >> 3;
     for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
@@ -758,6 +757,26 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
             score_candidate<SymT, VAR, LG>(prm, sym, lut, masktab, Kp, nsym_word, ns, sub0, sub1, i, out);
         }
     }
+}
+
+template <typename SymT, int VAR, int LG, bool BAL>
+__global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+                                                    const hc_overlap_rec* __restrict__ in, uint64_t n,
+                                                    hc_result_rec* __restrict__ out,
+                                                    const uint32_t* __restrict__ perm) {
+    score_kernel_body<SymT, VAR, LG, BAL>(st, prm, lut_g, in, n, out, perm);
+}
+
+// The same kernel for workgroups of up to 1 024 lanes.  A large quality alphabet means a large log table in LDS
+// (64 KiB for the wide 8-bit symbols, up to 150 KiB for 16-bit symbols), and with one table per 256-lane
+// workgroup only 2 (or 1) workgroups fit a CU: 8 (4) waves, too few to hide the gather latency.  One table
+// shared by 512 lanes restores 16 waves per CU (used for the wide 8-bit symbols; see launch_score).
+template <typename SymT, int VAR, int LG>
+__global__ __launch_bounds__(1024) void score_kernel_wide_wg(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+                                                             const hc_overlap_rec* __restrict__ in, uint64_t n,
+                                                             hc_result_rec* __restrict__ out,
+                                                             const uint32_t* __restrict__ perm) {
+    score_kernel_body<SymT, VAR, LG, false>(st, prm, lut_g, in, n, out, perm);
 }
 
 // ---------------------------------------------------------------------------
@@ -1148,7 +1167,13 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
 template <typename SymT, int VAR, int LG>
 static void launch_score_one(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
                              uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t blocks, size_t lds,
-                             hipStream_t stream) {
+                             hipStream_t stream, uint32_t block = 256) {
+    if (block > 256) {
+        if constexpr (LG >= 5 && (VAR == 4 || VAR == 5))  // the instantiations set_reads can select for large tables
+            hipLaunchKernelGGL((score_kernel_wide_wg<SymT, VAR, LG>), dim3(blocks), dim3(block), lds, stream, st, prm, lut_g, in, n,
+                               out, perm);
+        return;
+    }
     if (st.balance)
         hipLaunchKernelGGL((score_kernel<SymT, VAR, LG, true>), dim3(blocks), dim3(256), lds, stream, st, prm, lut_g, in, n, out,
                            perm);
@@ -1160,10 +1185,10 @@ static void launch_score_one(const StoreView& st, const ScoreParams& prm, const 
 template <typename SymT, int LG>
 static hipError_t launch_score_lg(int var, const StoreView& st, const ScoreParams& prm, const double* lut_g,
                                   const hc_overlap_rec* in, uint64_t n, hc_result_rec* out, const uint32_t* perm,
-                                  uint32_t blocks, size_t lds, hipStream_t stream) {
+                                  uint32_t blocks, size_t lds, hipStream_t stream, uint32_t block = 256) {
     switch (var & 7) {
-        case 4: launch_score_one<SymT, 4, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); return hipGetLastError();
-        case 5: launch_score_one<SymT, 5, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); return hipGetLastError();
+        case 4: launch_score_one<SymT, 4, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream, block); return hipGetLastError();
+        case 5: launch_score_one<SymT, 5, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream, block); return hipGetLastError();
         case 6: launch_score_one<SymT, 6, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); return hipGetLastError();
         case 7: launch_score_one<SymT, 7, LG>(st, prm, lut_g, in, n, out, perm, blocks, lds, stream); return hipGetLastError();
         default: break;
@@ -1213,6 +1238,24 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
         const uint32_t by_lds = (uint32_t)((160 * 1024) / lds);
         if (by_lds < blocks_per_cu) blocks_per_cu = by_lds < 1 ? 1 : by_lds;
     }
+    // large table, few workgroups per CU: let more lanes share each table (score_kernel_wide_wg)
+    static const long wg_env = getenv("HC_WG") ? atol(getenv("HC_WG")) : 0;  // experiment knob: 256 / 512 / 1024
+    // measured (C4, 35 quality values, 64 KiB table): 256 lanes 0.169 ms, 512 lanes 0.152 ms, 1 024 lanes 0.174 ms;
+    // the 16-bit-symbol instantiations need more than the 128 registers a 1 024-lane bound leaves and get slower
+    uint32_t wg = 256;
+    if (!st.balance && (variant & 7) >= 4 && (variant & 7) <= 5 && !(st.symbytes == 1 && lg < 5)) {
+        if (st.symbytes == 1 && blocks_per_cu <= 2) wg = 512;
+        if (wg_env == 256 || wg_env == 512 || wg_env == 1024) wg = (uint32_t)wg_env;
+    }
+    if (wg > 256) {
+        uint64_t wblocks = (n + wg - 1) / wg;
+        const uint64_t wcap = (uint64_t)n_cu * blocks_per_cu * 4;
+        if (wblocks > wcap) wblocks = wcap;
+        const uint32_t wnb = (uint32_t)wblocks;
+        if (st.symbytes == 2) return launch_score_lg<uint16_t, 5>(variant, st, prm, lut_g, in, n, out, perm, wnb, lds, stream, wg);
+        if (lg == 5) return launch_score_lg<uint8_t, 5>(variant, st, prm, lut_g, in, n, out, perm, wnb, lds, stream, wg);
+        return launch_score_lg<uint8_t, 6>(variant, st, prm, lut_g, in, n, out, perm, wnb, lds, stream, wg);
+    }
     uint64_t blocks = (n + block - 1) / block;
     const uint64_t cap = (uint64_t)n_cu * blocks_per_cu * 4;  // grid-stride beyond this
     if (blocks > cap) blocks = cap;
@@ -1254,6 +1297,10 @@ static hipError_t set_lds_limit_lg() {
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 6, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 7, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 7, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if constexpr (LG >= 5) {
+        if ((e = hipFuncSetAttribute((const void*)score_kernel_wide_wg<SymT, 4, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)score_kernel_wide_wg<SymT, 5, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    }
     return hipFuncSetAttribute((const void*)score_kernel_staged<SymT, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
 }
 hipError_t set_score_kernel_lds_limit() {
