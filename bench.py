@@ -191,16 +191,28 @@ def main():
         gather = parallel.StreamedGather(sc, n, base_index=rank * n, cap_rows=int(kept.item()) * 5 // 4 + 1024)
 
     last = None
+    gather_mode = "streamed" if gather else None
 
     def step():
         nonlocal last
         sc.score_batch_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
-        if gather:
+        if gather_mode == "streamed":
             last = gather.step(d_out)
+        elif gather_mode == "plain":  # counts, then padded payload, with host round trips (parallel.gather_admitted)
+            torch.cuda.synchronize()
+            last = parallel.gather_admitted(d_out, rank * n)
 
+    if gather:
+        try:  # one step of the streamed collection, checked; the plain form is the fallback if RCCL objects
+            step()
+            gather.finish()
+            gather.collect(last)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: streamed gather failed ({e!r}); using the plain all-gather-v", file=sys.stderr)
+            gather_mode = "plain"
     for _ in range(args.warmup):
         step()
-    if gather:
+    if gather_mode == "streamed":
         gather.finish()
     sc.synchronize()
     torch.cuda.synchronize()
@@ -209,15 +221,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if gather:
+    if gather_mode == "streamed":
         gather.finish()  # every all-gather of the timed steps has completed
     sc.synchronize()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if gather:  # outside the timed region: the collected set is what it should be
-        rows, counts = gather.collect(last)
+    if gather_mode:  # outside the timed region: the collected set is what it should be
+        rows, counts = gather.collect(last) if gather_mode == "streamed" else last
         assert len(counts) == world and rows.shape[0] == sum(counts) and bool((rows[1:, 0] > rows[:-1, 0]).all()), "gathered rows out of order"
     if dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -242,7 +254,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": dict(cfg, parallelism=f"candidate shards x{world}, replicated read store",
+            "config": dict(cfg, parallelism=f"candidate shards x{world}, replicated read store" + (f", {gather_mode} all-gather-v of the non-dropped records per step" if gather_mode else ""),
                            edge_threshold=settings.edge_threshold, mean_positions_per_candidate=positions / n),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, args.order),
