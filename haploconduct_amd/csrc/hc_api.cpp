@@ -15,6 +15,7 @@
 
 #include "../../include/hcedge.h"
 #include "hc_device.h"
+#include "hc_overlap_finder.h"
 
 namespace hc {
 hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
@@ -73,6 +74,9 @@ struct hc_ctx {
     uint64_t store_bytes = 0;
     hc::StoreView view{};
     hc::ScoreParams params{};
+    // what the overlap finder needs of the sequences (host copies, filled by hc_set_reads)
+    std::vector<hc::SeqRef> seq_refs;  // by store sequence index
+    bool singles_first = true;
     // grow-only workspace for the host-buffer entry point
     void* d_in = nullptr;
     void* d_out = nullptr;
@@ -92,6 +96,19 @@ struct hc_ctx {
     hc_result_rec* d_compact_res = nullptr;
     uint64_t compact_cap = 0;
 };
+
+namespace {
+struct DevBuf {  // hipFree on scope exit
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    T* as() const { return (T*)p; }
+};
+}  // namespace
+
+#define HC_ALLOC(buf, bytes) HC_HIP(hipMalloc(&(buf).p, (bytes) ? (bytes) : 16))
 
 // --------------------------------------------------------------------------
 // Threshold inversion: exp(x) > T decided in x-space.
@@ -344,6 +361,30 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     (void)hipFree(d_seq_bad);
     (void)hipFree(d_first);
 
+    {  // SFO ids: singles, then every /1 mate, then every /2 mate (s_p1_p2.fasta, savage.py:643-664)
+        uint32_t n_single = 0, n_pairs = 0;
+        c->singles_first = true;
+        for (uint32_t r = 0; r < n_reads; r++) {
+            const bool paired = read_first_seq[r + 1] - read_first_seq[r] == 2;
+            if (paired) n_pairs++;
+            else {
+                if (n_pairs) c->singles_first = false;
+                n_single++;
+            }
+        }
+        c->seq_refs.assign(n_seq, hc::SeqRef{0, 0, 0});
+        uint32_t pair_no = 0;
+        for (uint32_t r = 0; r < n_reads; r++) {
+            const uint32_t q = read_first_seq[r];
+            if (read_first_seq[r + 1] - q == 2) {
+                c->seq_refs[q] = hc::SeqRef{sym_off[q], seq_len[q], n_single + pair_no};
+                c->seq_refs[q + 1] = hc::SeqRef{sym_off[q + 1], seq_len[q + 1], n_single + n_pairs + pair_no};
+                pair_no++;
+            } else {
+                c->seq_refs[q] = hc::SeqRef{sym_off[q], seq_len[q], r};
+            }
+        }
+    }
     c->view.sym = c->d_sym;
     c->view.reads = c->d_reads;
     c->view.n_reads = n_reads;
@@ -525,6 +566,151 @@ int hc_compact_device(hc_ctx* c, const void* d_results, uint64_t n, void* d_indi
     if (rc) return rc;
     HC_HIP(hc::launch_compact((const hc_result_rec*)d_results, (uint32_t)n, (uint32_t*)d_indices, (unsigned long long*)d_count,
                               c->d_compact_tmp, c->compact_tmp_bytes, s));
+    return HC_OK;
+}
+
+// ---- candidate generation ------------------------------------------------------------------------------------
+int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, uint64_t cap, uint64_t* n_out) {
+    if (!c || !n_out) return fail(HC_ERR_ARG, "hc_find_overlaps: null argument");
+    *n_out = 0;
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_find_overlaps: hc_set_reads has not been called");
+    if (cap && !out) return fail(HC_ERR_ARG, "hc_find_overlaps: null output buffer");
+    if (!(err_rate >= 0.0) || err_rate >= 1.0 || min_overlap == 0) return fail(HC_ERR_ARG, "hc_find_overlaps: need 0 <= err_rate < 1, min_overlap > 0");
+    if (!c->singles_first) return fail(HC_ERR_ARG, "hc_find_overlaps: the read set must list single-end reads before pairs (SFO ids)");
+    const uint32_t n_seq = (uint32_t)c->seq_refs.size();
+    if (n_seq >= (1u << 24) - 1) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^24-2 sequences");
+    uint32_t max_len = 0;
+    for (const hc::SeqRef& r : c->seq_refs) max_len = r.len > max_len ? r.len : max_len;
+    if (max_len >= (1u << 14)) return fail(HC_ERR_ARG, "hc_find_overlaps: sequences of 16384 symbols or more are not supported");
+    if (n_seq < 2 || max_len < min_overlap) return HC_OK;
+    // the longest stretch without a mismatch that every reportable overlap is guaranteed to contain
+    uint32_t w = 0xFFFFFFFFu;
+    for (uint32_t L = min_overlap; L <= max_len; L++) {
+        const uint32_t K = (uint32_t)(err_rate * (double)L);
+        const uint32_t wl = (L - K) / (K + 1);
+        w = wl < w ? wl : w;
+    }
+    if (w < 12)
+        return fail(HC_ERR_ARG, "hc_find_overlaps: err_rate too high for this min_overlap: an overlap need not contain 12 error-free positions in a row");
+    const uint32_t k = w < 31 ? w : 31, s = w - k + 1;
+    const uint32_t n_ori = (flags & HC_FIND_REVERSALS) ? 2u : 1u;
+    const bool wide = c->view.symbytes == 1 && hc::lut_lg(c->view.K) == 6;
+    HC_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+
+    // host-side layout of the index and of the seeds
+    std::vector<uint64_t> pos_start(n_seq + 1, 0), seed_start(n_seq + 1, 0);
+    std::vector<hc::SeqRef> by_sfo(n_seq);
+    for (uint32_t q = 0; q < n_seq; q++) {
+        const hc::SeqRef& r = c->seq_refs[q];
+        pos_start[q + 1] = pos_start[q] + r.len;
+        seed_start[q + 1] = seed_start[q] + (r.len >= k ? (uint64_t)((r.len - k) / s + 1) * n_ori : 0);
+        by_sfo[r.sfo_id] = r;
+    }
+    const uint64_t P = pos_start[n_seq], S = seed_start[n_seq];
+    if (P >= (1ull << 31) || S >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: read set too large for one call (2^31 positions)");
+
+    DevBuf d_seqs, d_by_sfo, d_pos_start, d_seed_start, d_k0, d_k1, d_v0, d_v1, d_tmp, d_lo, d_cnt, d_off, d_count;
+    HC_ALLOC(d_seqs, n_seq * sizeof(hc::SeqRef));
+    HC_ALLOC(d_by_sfo, n_seq * sizeof(hc::SeqRef));
+    HC_ALLOC(d_pos_start, (n_seq + 1) * sizeof(uint64_t));
+    HC_ALLOC(d_seed_start, (n_seq + 1) * sizeof(uint64_t));
+    HC_ALLOC(d_count, sizeof(unsigned long long));
+    HC_HIP(hipMemcpyAsync(d_seqs.p, c->seq_refs.data(), n_seq * sizeof(hc::SeqRef), hipMemcpyHostToDevice, st));
+    HC_HIP(hipMemcpyAsync(d_by_sfo.p, by_sfo.data(), n_seq * sizeof(hc::SeqRef), hipMemcpyHostToDevice, st));
+    HC_HIP(hipMemcpyAsync(d_pos_start.p, pos_start.data(), (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HC_HIP(hipMemcpyAsync(d_seed_start.p, seed_start.data(), (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+
+    // 1. index: (k-mer, sequence|position) of every forward position, sorted by k-mer
+    HC_ALLOC(d_k0, P * 8);
+    HC_ALLOC(d_k1, P * 8);
+    HC_ALLOC(d_v0, P * 8);
+    HC_ALLOC(d_v1, P * 8);
+    HC_HIP(hc::finder_index(c->d_sym, c->view.symbytes, wide, d_seqs.as<hc::SeqRef>(), d_pos_start.as<uint64_t>(), n_seq, k, d_k0.as<uint64_t>(),
+                            d_v0.as<uint64_t>(), st));
+    size_t tmp_bytes = 0;
+    HC_HIP(hc::finder_sort_pairs(nullptr, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
+    HC_ALLOC(d_tmp, tmp_bytes);
+    HC_HIP(hc::finder_sort_pairs(d_tmp.p, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
+    // 2. seeds: range of every seed k-mer in the index
+    HC_ALLOC(d_lo, S * 8);
+    HC_ALLOC(d_cnt, (S + 1) * 8);
+    HC_ALLOC(d_off, (S + 1) * 8);
+    HC_HIP(hipMemsetAsync(d_cnt.p, 0, (S + 1) * 8, st));
+    HC_HIP(hc::finder_seeds(c->d_sym, c->view.symbytes, wide, d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori,
+                            d_k1.as<uint64_t>(), P, d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), st));
+    {
+        size_t b = 0;
+        HC_HIP(hc::finder_scan(nullptr, b, d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
+        if (b > tmp_bytes) {
+            HC_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_tmp.p);
+            d_tmp.p = nullptr;
+            HC_ALLOC(d_tmp, b);
+            tmp_bytes = b;
+        }
+        HC_HIP(hc::finder_scan(d_tmp.p, b, d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
+    }
+    uint64_t H = 0;  // number of hits = last element of the exclusive scan over S + 1 counts (the extra one is 0)
+    HC_HIP(hipMemcpyAsync(&H, d_off.as<uint64_t>() + S, 8, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipStreamSynchronize(st));
+    if (H == 0) return HC_OK;
+    if (H >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 seed hits (repeat-rich input): raise min_overlap or split the read set");
+    // 3. one key per hit, sorted, unique: the candidate diagonals.  The index keys are no longer needed.
+    (void)hipFree(d_k0.p);
+    d_k0.p = nullptr;
+    (void)hipFree(d_v0.p);
+    d_v0.p = nullptr;
+    DevBuf d_h0, d_h1;
+    HC_ALLOC(d_h0, H * 8);
+    HC_ALLOC(d_h1, H * 8);
+    HC_HIP(hc::finder_expand(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori, d_v1.as<uint64_t>(), d_lo.as<uint64_t>(),
+                             d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), d_h0.as<uint64_t>(), st));
+    {
+        size_t b = 0, b2 = 0;
+        HC_HIP(hc::finder_sort_keys(nullptr, b, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), H, st));
+        HC_HIP(hc::finder_unique(nullptr, b2, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), H, st));
+        if (b2 > b) b = b2;
+        if (b > tmp_bytes) {
+            HC_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_tmp.p);
+            d_tmp.p = nullptr;
+            HC_ALLOC(d_tmp, b);
+            tmp_bytes = b;
+        }
+        size_t bs = tmp_bytes;
+        HC_HIP(hc::finder_sort_keys(d_tmp.p, bs, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), H, st));
+        bs = tmp_bytes;
+        HC_HIP(hc::finder_unique(d_tmp.p, bs, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), H, st));
+    }
+    unsigned long long M = 0;
+    HC_HIP(hipMemcpyAsync(&M, d_count.p, sizeof M, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipStreamSynchronize(st));
+    if (M == 0) return HC_OK;
+    // 4. verify every candidate, keep the overlaps
+    DevBuf d_r0, d_r1;
+    HC_ALLOC(d_r0, M * sizeof(hc_sfo_rec));
+    HC_ALLOC(d_r1, M * sizeof(hc_sfo_rec));
+    HC_HIP(hc::finder_verify(c->d_sym, c->view.symbytes, wide, d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), M, err_rate, min_overlap, flags,
+                             d_r0.as<hc_sfo_rec>(), st));
+    {
+        size_t b = 0;
+        HC_HIP(hc::finder_select_valid(nullptr, b, d_r0.as<hc_sfo_rec>(), d_r1.as<hc_sfo_rec>(), d_count.as<unsigned long long>(), M, st));
+        if (b > tmp_bytes) {
+            HC_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_tmp.p);
+            d_tmp.p = nullptr;
+            HC_ALLOC(d_tmp, b);
+            tmp_bytes = b;
+        }
+        HC_HIP(hc::finder_select_valid(d_tmp.p, b, d_r0.as<hc_sfo_rec>(), d_r1.as<hc_sfo_rec>(), d_count.as<unsigned long long>(), M, st));
+    }
+    unsigned long long R = 0;
+    HC_HIP(hipMemcpyAsync(&R, d_count.p, sizeof R, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipStreamSynchronize(st));
+    *n_out = R;
+    const uint64_t take = R < cap ? R : cap;
+    if (take) HC_HIP(hipMemcpy(out, d_r1.p, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
     return HC_OK;
 }
 

@@ -1,0 +1,266 @@
+// hc_overlap_finder.hip — candidate generation on the device: all suffix–prefix overlaps
+// (and inclusions) between the sequences of the read store, under a Hamming error rate — the job the pipelines
+// give to the external `rust-overlaps` tool (savage.py:664,713; polyte.py:514,542) — reported as SFO records
+// (idA idB N|I OHA OHB OLA OLB K, scripts/sfo2overlaps.py:36).
+//
+// Exact, not heuristic.  An overlap of length L >= T with K <= floor(e*L) mismatches contains an error-free window
+// of at least w(L) = floor((L - K) / (K + 1)) positions; with w = min over L in [T, max length] and seeds of k
+// symbols taken at every s-th position of a sequence, k + s - 1 <= w guarantees that one seed lies inside that
+// window.  So:
+//   index    every k-mer of every forward sequence (2 bits per base, a k-mer with a non-ACGT symbol never
+//            matches) -> radix sort by k-mer                                             [hipCUB]
+//   seeds    k-mers at positions 0, s, 2s, ... of every sequence B, forward and (with reversals) reverse
+//            complement — the store holds both orientations — binary-searched in the index
+//   expand   every hit (A, q) with id(A) < id(B) gives a diagonal d = q - p: key (A, B, orientation, d)
+//   unique   radix sort + unique of the keys (many seeds find the same diagonal)          [hipCUB]
+//   verify   one lane per candidate: overlap region, length >= T, mismatches <= floor(e*L) (N matches nothing)
+//   compact  the verified records, in key order                                          [hipCUB]
+// Every unordered pair is examined once (the lower id is the indexed side), so no record appears twice.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <hipcub/hipcub.hpp>
+
+#include "../../include/hcedge.h"
+#include "hc_device.h"
+#include "hc_overlap_finder.h"
+
+namespace hc {
+
+// 0..3 = A,C,G,T; 4 = anything else (N, invalid): matches nothing
+template <int SB, bool WIDE>
+__device__ __forceinline__ uint32_t base_at(const void* __restrict__ sym, uint64_t i) {
+    if (SB == 1) {
+        const uint32_t s = ((const uint8_t*)sym)[i];
+        if (WIDE) return (s >> 2) >= kWideN ? 4u : (s & 3u);
+        const uint32_t c = s & 7u;
+        return c < 4u ? c : 4u;
+    }
+    const uint32_t c = ((const uint16_t*)sym)[i] & 7u;
+    return c < 4u ? c : 4u;
+}
+
+constexpr uint64_t kNoKmer = ~(uint64_t)0;
+
+template <int SB, bool WIDE>
+__device__ __forceinline__ uint64_t kmer_at(const void* __restrict__ sym, uint64_t at, uint32_t k) {
+    uint64_t code = 0;
+    for (uint32_t i = 0; i < k; i++) {
+        const uint32_t b = base_at<SB, WIDE>(sym, at + i);
+        if (b > 3u) return kNoKmer;
+        code = (code << 2) | b;
+    }
+    return code;
+}
+
+// one wave per sequence, lanes stride over its positions
+template <int SB, bool WIDE>
+__global__ __launch_bounds__(256) void finder_index_kernel(const void* __restrict__ sym, const SeqRef* __restrict__ seqs,
+                                                           const uint64_t* __restrict__ pos_start, uint32_t n_seq, uint32_t k,
+                                                           uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t q = wave; q < n_seq; q += n_waves) {
+        const SeqRef r = seqs[q];
+        const uint64_t base = pos_start[q];
+        for (uint32_t p = lane; p < r.len; p += 64u) {
+            keys[base + p] = p + k <= r.len ? kmer_at<SB, WIDE>(sym, r.off + p, k) : kNoKmer;
+            vals[base + p] = ((uint64_t)q << 32) | p;
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t lower_bound_u64(const uint64_t* __restrict__ a, uint64_t n, uint64_t v) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// seeds of sequence q: orientation o in [0, n_ori), t-th seed at position t*s; flat id = seed_start[q] + o*nt + t
+template <int SB, bool WIDE>
+__global__ __launch_bounds__(256) void finder_seed_kernel(const void* __restrict__ sym, const SeqRef* __restrict__ seqs,
+                                                          const uint64_t* __restrict__ seed_start, uint32_t n_seq, uint32_t k,
+                                                          uint32_t s, uint32_t n_ori, uint32_t symbytes,
+                                                          const uint64_t* __restrict__ keys, uint64_t n_keys,
+                                                          uint64_t* __restrict__ seed_lo, uint64_t* __restrict__ seed_cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t q = wave; q < n_seq; q += n_waves) {
+        const SeqRef r = seqs[q];
+        if (r.len < k) continue;
+        const uint32_t nt = (r.len - k) / s + 1;
+        const uint64_t rc_off = r.off + slot_stride(r.len, symbytes);
+        for (uint32_t j = lane; j < nt * n_ori; j += 64u) {
+            const uint32_t o = j / nt, t = j - o * nt;
+            const uint64_t code = kmer_at<SB, WIDE>(sym, (o ? rc_off : r.off) + (uint64_t)t * s, k);
+            uint64_t lo = 0, cnt = 0;
+            if (code != kNoKmer) {
+                lo = lower_bound_u64(keys, n_keys, code);
+                cnt = lower_bound_u64(keys, n_keys, code + 1) - lo;
+            }
+            seed_lo[seed_start[q] + j] = lo;
+            seed_cnt[seed_start[q] + j] = cnt;
+        }
+    }
+}
+
+constexpr uint64_t kNoKey = ~(uint64_t)0;
+constexpr int kDiagBias = 1 << 14;  // diagonals in (-2^14, 2^14)
+
+__device__ __forceinline__ uint64_t pack_key(uint32_t idA, uint32_t idB, uint32_t o, int d) {
+    return ((uint64_t)idA << 40) | ((uint64_t)idB << 16) | ((uint64_t)o << 15) | (uint64_t)(uint32_t)(d + kDiagBias);
+}
+
+__global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __restrict__ seqs, const uint64_t* __restrict__ seed_start,
+                                                            uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
+                                                            const uint64_t* __restrict__ vals, const uint64_t* __restrict__ seed_lo,
+                                                            const uint64_t* __restrict__ seed_cnt,
+                                                            const uint64_t* __restrict__ seed_out, uint64_t* __restrict__ out_keys) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t q = wave; q < n_seq; q += n_waves) {
+        const SeqRef r = seqs[q];
+        if (r.len < k) continue;
+        const uint32_t nt = (r.len - k) / s + 1;
+        // the hits of one seed are spread over the lanes: a repeat-rich k-mer does not stall a single lane
+        for (uint32_t j = 0; j < nt * n_ori; j++) {
+            const uint64_t sid = seed_start[q] + j;
+            const uint64_t cnt = seed_cnt[sid];
+            if (cnt == 0) continue;
+            const uint32_t o = j / nt, t = j - o * nt;
+            const int p = (int)(t * s);
+            const uint64_t lo = seed_lo[sid], at = seed_out[sid];
+            for (uint64_t h = lane; h < cnt; h += 64u) {
+                const uint64_t v = vals[lo + h];
+                const uint32_t qa = (uint32_t)(v >> 32);
+                const uint32_t ida = seqs[qa].sfo_id;
+                uint64_t key = kNoKey;
+                if (ida < r.sfo_id) key = pack_key(ida, r.sfo_id, o, (int)(uint32_t)v - p);
+                out_keys[at + h] = key;
+            }
+        }
+    }
+}
+
+struct RecValid {
+    __device__ bool operator()(const hc_sfo_rec& r) const { return r.idA != 0xFFFFFFFFu; }
+};
+
+template <int SB, bool WIDE>
+__global__ __launch_bounds__(256) void finder_verify_kernel(const void* __restrict__ sym, const SeqRef* __restrict__ by_sfo,
+                                                            uint32_t symbytes, const uint64_t* __restrict__ keys, uint64_t n,
+                                                            double err_rate, uint32_t min_overlap, uint32_t flags,
+                                                            hc_sfo_rec* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i];
+        hc_sfo_rec rec;
+        rec.idA = 0xFFFFFFFFu;
+        rec.idB = 0;
+        rec.OHA = rec.OHB = 0;
+        rec.OLA = rec.OLB = rec.K = 0;
+        rec.inverted = 0;
+        if (key != kNoKey) {
+            const uint32_t ida = (uint32_t)(key >> 40), idb = (uint32_t)(key >> 16) & 0xFFFFFFu, o = (uint32_t)(key >> 15) & 1u;
+            const int d = (int)(uint32_t)(key & 0x7FFFu) - kDiagBias;
+            const SeqRef A = by_sfo[ida], B = by_sfo[idb];
+            const int la = (int)A.len, lb = (int)B.len;
+            const int start = d > 0 ? d : 0, end = la < d + lb ? la : d + lb;
+            const int L = end - start;
+            const bool inclusion = (d >= 0 && d + lb <= la) || (d <= 0 && d + lb >= la);
+            if (L >= (int)min_overlap && (!inclusion || (flags & HC_FIND_INCLUSIONS))) {
+                const uint32_t kmax = (uint32_t)(err_rate * (double)L);
+                const uint64_t offb = o ? B.off + slot_stride(B.len, symbytes) : B.off;
+                uint32_t mm = 0;
+                for (int x = start; x < end && mm <= kmax; x++) {
+                    const uint32_t a = base_at<SB, WIDE>(sym, A.off + (uint64_t)x);
+                    const uint32_t b = base_at<SB, WIDE>(sym, offb + (uint64_t)(x - d));
+                    mm += (a != b) | (a > 3u);
+                }
+                if (mm <= kmax) {
+                    rec.idA = ida;
+                    rec.idB = idb;
+                    rec.OHA = d;
+                    rec.OHB = d + lb - la;
+                    rec.OLA = rec.OLB = (uint32_t)L;
+                    rec.K = mm;
+                    rec.inverted = o;
+                }
+            }
+        }
+        out[i] = rec;
+    }
+}
+
+// ---- launch wrappers -----------------------------------------------------------------------------------------
+static uint32_t wave_grid(uint32_t n_seq) {
+    uint64_t blocks = ((uint64_t)n_seq + 3) / 4;  // 4 waves per 256-thread block
+    if (blocks > 65536) blocks = 65536;
+    return blocks ? (uint32_t)blocks : 1u;
+}
+
+#define HC_FINDER_DISPATCH(KERNEL, GRID, ...)                                                                              \
+    do {                                                                                                                   \
+        if (symbytes == 2) hipLaunchKernelGGL((KERNEL<2, false>), dim3(GRID), dim3(256), 0, stream, __VA_ARGS__);          \
+        else if (wide) hipLaunchKernelGGL((KERNEL<1, true>), dim3(GRID), dim3(256), 0, stream, __VA_ARGS__);               \
+        else hipLaunchKernelGGL((KERNEL<1, false>), dim3(GRID), dim3(256), 0, stream, __VA_ARGS__);                        \
+    } while (0)
+
+hipError_t finder_index(const void* sym, uint32_t symbytes, bool wide, const SeqRef* seqs, const uint64_t* pos_start, uint32_t n_seq,
+                        uint32_t k, uint64_t* keys, uint64_t* vals, hipStream_t stream) {
+    HC_FINDER_DISPATCH(finder_index_kernel, wave_grid(n_seq), sym, seqs, pos_start, n_seq, k, keys, vals);
+    return hipGetLastError();
+}
+
+hipError_t finder_seeds(const void* sym, uint32_t symbytes, bool wide, const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq,
+                        uint32_t k, uint32_t s, uint32_t n_ori, const uint64_t* keys, uint64_t n_keys, uint64_t* seed_lo,
+                        uint64_t* seed_cnt, hipStream_t stream) {
+    HC_FINDER_DISPATCH(finder_seed_kernel, wave_grid(n_seq), sym, seqs, seed_start, n_seq, k, s, n_ori, symbytes, keys, n_keys, seed_lo,
+                       seed_cnt);
+    return hipGetLastError();
+}
+
+hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
+                         const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, const uint64_t* seed_out,
+                         uint64_t* out_keys, hipStream_t stream) {
+    hipLaunchKernelGGL(finder_expand_kernel, dim3(wave_grid(n_seq)), dim3(256), 0, stream, seqs, seed_start, n_seq, k, s, n_ori, vals,
+                       seed_lo, seed_cnt, seed_out, out_keys);
+    return hipGetLastError();
+}
+
+hipError_t finder_verify(const void* sym, uint32_t symbytes, bool wide, const SeqRef* by_sfo, const uint64_t* keys, uint64_t n,
+                         double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    HC_FINDER_DISPATCH(finder_verify_kernel, (uint32_t)blocks, sym, by_sfo, symbytes, keys, n, err_rate, min_overlap, flags, out);
+    return hipGetLastError();
+}
+
+// hipCUB steps; temp == nullptr returns the scratch size in *temp_bytes
+hipError_t finder_sort_pairs(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint64_t* v_in, uint64_t* v_out,
+                             uint64_t n, int end_bit, hipStream_t stream) {
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (int64_t)n, 0, end_bit, stream);
+}
+hipError_t finder_sort_keys(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, uint64_t n, hipStream_t stream) {
+    return hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, k_in, k_out, (int64_t)n, 0, 64, stream);
+}
+hipError_t finder_scan(void* temp, size_t& temp_bytes, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t stream) {
+    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int64_t)n, stream);
+}
+hipError_t finder_unique(void* temp, size_t& temp_bytes, const uint64_t* in, uint64_t* out, unsigned long long* n_out, uint64_t n,
+                         hipStream_t stream) {
+    return hipcub::DeviceSelect::Unique(temp, temp_bytes, in, out, n_out, (int64_t)n, stream);
+}
+hipError_t finder_select_valid(void* temp, size_t& temp_bytes, const hc_sfo_rec* in, hc_sfo_rec* out, unsigned long long* n_out, uint64_t n,
+                               hipStream_t stream) {
+    return hipcub::DeviceSelect::If(temp, temp_bytes, in, out, n_out, (int64_t)n, RecValid{}, stream);
+}
+
+}  // namespace hc

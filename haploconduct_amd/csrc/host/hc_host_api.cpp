@@ -129,6 +129,31 @@ int hc_host_write_overlaps(const char* path, const hc_overlap_rec* recs, uint64_
     });
 }
 
+int hc_host_write_sfo(const char* path, const hc_sfo_rec* recs, uint64_t n) {
+    if (!path || (n && !recs)) return set_last_error(HC_ERR_ARG, "hc_host_write_sfo: null");
+    return guarded("write_sfo", [&] {
+        FILE* o = fopen(path, "wb");
+        if (!o) throw FatalError{HC_ERR_IO, std::string("cannot write ") + path};
+        std::vector<char> buf;
+        buf.reserve(1 << 22);
+        char line[128];
+        for (uint64_t i = 0; i < n; i++) {
+            const hc_sfo_rec& r = recs[i];
+            const int m = snprintf(line, sizeof line, "%u\t%u\t%c\t%d\t%d\t%u\t%u\t%u\n", r.idA, r.idB, r.inverted ? 'I' : 'N', r.OHA, r.OHB,
+                                   r.OLA, r.OLB, r.K);
+            buf.insert(buf.end(), line, line + m);
+            if (buf.size() > (1u << 22) - 256 || i + 1 == n) {
+                if (fwrite(buf.data(), 1, buf.size(), o) != buf.size()) {
+                    fclose(o);
+                    throw FatalError{HC_ERR_IO, std::string("short write to ") + path};
+                }
+                buf.clear();
+            }
+        }
+        if (fclose(o) != 0) throw FatalError{HC_ERR_IO, std::string("cannot close ") + path};
+    });
+}
+
 int hc_host_split_line(const char* line, uint64_t n, int allow_spaces, uint32_t* off, uint32_t* len, int max_fields) {
     if (!line || max_fields < 0 || max_fields > 64) return HC_ERR_ARG;
     const char* f[64];

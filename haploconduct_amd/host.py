@@ -62,6 +62,7 @@ _sig = {
     "hc_host_parse_file": (C.c_int, [C.POINTER(N.hc_settings), _vp, C.c_char_p, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                      C.POINTER(hc_ec_counters)]),
     "hc_sfo2overlaps": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "hc_host_write_sfo": (C.c_int, [C.c_char_p, _vp, C.c_uint64]),
     "hc_host_write_overlaps": (C.c_int, [C.c_char_p, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint32]),
     "hc_host_graph_new": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.POINTER(N.hc_settings)]),
     "hc_host_graph_insert": (C.c_int, [_vp, _vp]),
@@ -111,6 +112,12 @@ def write_overlaps(path, recs, reads, n_threads=0):
     paired = np.ascontiguousarray((rfs[1:] - rfs[:-1]) == 2, dtype=np.uint8)
     N.check(N.lib.hc_host_write_overlaps(_b(path), recs.ctypes.data, recs.size, ids.ctypes.data, paired.ctypes.data, ids.size, n_threads),
             "hc_host_write_overlaps")
+
+
+def write_sfo(path, recs):
+    """SFO records (records.SFO_DTYPE) as the text file rust-overlaps writes."""
+    recs = np.ascontiguousarray(recs)
+    N.check(N.lib.hc_host_write_sfo(_b(path), recs.ctypes.data, recs.size), "hc_host_write_sfo")
 
 
 def sfo2overlaps(sfo_path, out_path, num_singles, num_pairs):

@@ -61,3 +61,10 @@ def result_n(res):
 
 def result_cls(res):
     return res["n_cls"] >> 28
+
+
+# hc_sfo_rec (include/hcedge.h): one suffix-prefix overlap as rust-overlaps reports it
+SFO_DTYPE = np.dtype([("idA", "<u4"), ("idB", "<u4"), ("OHA", "<i4"), ("OHB", "<i4"), ("OLA", "<u4"), ("OLB", "<u4"), ("K", "<u4"),
+                      ("inverted", "<u4")])
+assert SFO_DTYPE.itemsize == 32
+FIND_REVERSALS, FIND_INCLUSIONS = 1, 2

@@ -83,6 +83,18 @@ class EdgeScorer:
         N.check(N.lib.hc_compact_device(self._ctx, C.c_void_p(d_results_ptr), n, C.c_void_p(d_indices_ptr),
                                         C.c_void_p(d_count_ptr), C.c_void_p(stream or 0)), "hc_compact_device")
 
+    def find_overlaps(self, err_rate, min_overlap, reversals=True, inclusions=True):
+        """hc_find_overlaps: all suffix-prefix overlaps / inclusions between the stored sequences (SFO records)."""
+        from .records import FIND_INCLUSIONS, FIND_REVERSALS, SFO_DTYPE
+
+        flags = (FIND_REVERSALS if reversals else 0) | (FIND_INCLUSIONS if inclusions else 0)
+        n = C.c_uint64()
+        N.check(N.lib.hc_find_overlaps(self._ctx, err_rate, min_overlap, flags, None, 0, C.byref(n)), "hc_find_overlaps")
+        out = np.zeros(n.value, SFO_DTYPE)
+        if n.value:
+            N.check(N.lib.hc_find_overlaps(self._ctx, err_rate, min_overlap, flags, out.ctypes.data, out.size, C.byref(n)), "hc_find_overlaps")
+        return out[: n.value]
+
     def pack_rows_device(self, d_results_ptr, d_indices_ptr, d_count_ptr, cap, base_index, d_rows_ptr, stream=None):
         """hc_pack_rows_device: compacted records -> 32-byte rows tagged with their global candidate index."""
         N.check(N.lib.hc_pack_rows_device(self._ctx, C.c_void_p(d_results_ptr), C.c_void_p(d_indices_ptr), C.c_void_p(d_count_ptr),

@@ -191,6 +191,31 @@ typedef struct hc_gather_row {
 int hc_pack_rows_device(hc_ctx* ctx, const void* d_results, const void* d_indices, const void* d_count, uint64_t cap,
                         uint64_t base_index, void* d_rows, void* hip_stream);
 
+/* ---- candidate generation ----------------------------------------------------------------
+ * All suffix–prefix overlaps and inclusions between the sequences of the read store under a Hamming error rate:
+ * the job the pipelines hand to the external tool `rust-overlaps -i -r <fasta> <out> <err_rate> <min_overlap>`
+ * (savage.py:664,713; polyte.py:514,542), whose 8-column SFO records scripts/sfo2overlaps.py:36 reads:
+ *      idA idB N|I OHA OHB OLA OLB K
+ * Sequence ids are the SFO ids: singles 0..S-1, /1 mates S..S+P-1, /2 mates S+P..S+2P-1 (the s_p1_p2.fasta order;
+ * the read set must list its single-end reads first, as FastqStorage does).  With B placed at offset d in A's
+ * coordinates (B reverse-complemented when inverted): OHA = d, OHB = d + len(B) - len(A), OLA = OLB = L = length of
+ * the common stretch, K = its mismatches.  Reported: every pair idA < idB, orientation and d with L >= min_overlap
+ * and K <= floor(err_rate * L); a non-ACGT symbol matches nothing.  Exact (a seed filter with a pigeonhole
+ * guarantee, then full verification), sorted by (idA, idB, orientation, d), no duplicates.
+ * rust-overlaps itself is not part of the reference tree: its output is NOT available to compare with here. */
+#define HC_FIND_REVERSALS  0x1u /* rust-overlaps -r: also B reverse-complemented ("I" records) */
+#define HC_FIND_INCLUSIONS 0x2u /* rust-overlaps -i: also report a sequence lying entirely inside the other */
+typedef struct hc_sfo_rec {
+    uint32_t idA, idB;
+    int32_t OHA, OHB;
+    uint32_t OLA, OLB, K;
+    uint32_t inverted; /* 0 = "N", 1 = "I" */
+} hc_sfo_rec; /* 32 bytes */
+/* Runs on the device against the store of hc_set_reads.  *n_out = number of records found; the first
+ * min(cap, *n_out) are copied to out (host memory; may be NULL when cap == 0). */
+int hc_find_overlaps(hc_ctx* ctx, double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, uint64_t cap,
+                     uint64_t* n_out);
+
 /* hc_score_batch + compaction in one call for host callers: scores `in` on the device and copies back
  * only the non-DROP records: idx_out[k] (ascending) and res_out[k] = result of in[idx_out[k]].
  * cap = capacity of idx_out / res_out in records; *n_out = number of non-DROP records (if it exceeds

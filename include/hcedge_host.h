@@ -104,6 +104,9 @@ int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* ove
 int hc_host_write_overlaps(const char* path, const hc_overlap_rec* recs, uint64_t n, const uint64_t* read_ids,
                            const uint8_t* read_paired, uint64_t n_reads, uint32_t n_threads);
 
+/* SFO records as the text file rust-overlaps writes (tab separated, one record per line). */
+int hc_host_write_sfo(const char* path, const hc_sfo_rec* recs, uint64_t n);
+
 /* SFO ingest: rust-overlaps' 8-column SFO file -> SAVAGE's 13-column overlaps file with
  * the semantics of the reference's scripts/sfo2overlaps.py (--in, --out, --num_singles, --num_pairs),
  * including its sort / uniq passes.  *n_lines receives the number of overlap lines written. */
