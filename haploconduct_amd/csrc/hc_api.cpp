@@ -77,6 +77,13 @@ struct hc_ctx {
     // what the overlap finder needs of the sequences (host copies, filled by hc_set_reads)
     std::vector<hc::SeqRef> seq_refs;  // by store sequence index
     bool singles_first = true;
+    // result of the last hc_find_overlaps, kept on the device so that the usual "ask for the count, then fetch"
+    // pair of calls computes once
+    hc_sfo_rec* d_found = nullptr;
+    uint64_t n_found = 0;
+    double found_err = -1;
+    uint32_t found_min = 0, found_flags = 0;
+    bool found_valid = false;
     // grow-only workspace for the host-buffer entry point
     void* d_in = nullptr;
     void* d_out = nullptr;
@@ -98,17 +105,31 @@ struct hc_ctx {
 };
 
 namespace {
-struct DevBuf {  // hipFree on scope exit
+// Scratch of one call, from the stream-ordered pool (hipMallocAsync): the overlap finder takes and returns
+// gigabytes per call, and plain hipMalloc / hipFree of such blocks cost more wall time than its kernels.
+struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
+    hipStream_t stream = nullptr;
+    bool pooled = false;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) {
+            if (pooled) (void)hipFreeAsync(p, stream);
+            else (void)hipFree(p);
+        }
+        p = nullptr;
     }
     template <typename T>
     T* as() const { return (T*)p; }
 };
 }  // namespace
 
-#define HC_ALLOC(buf, bytes) HC_HIP(hipMalloc(&(buf).p, (bytes) ? (bytes) : 16))
+#define HC_ALLOC(buf, bytes)                                                          \
+    do {                                                                              \
+        (buf).stream = st;                                                            \
+        (buf).pooled = true;                                                          \
+        HC_HIP(hipMallocAsync(&(buf).p, (bytes) ? (size_t)(bytes) : 16, st));         \
+    } while (0)
 
 // --------------------------------------------------------------------------
 // Threshold inversion: exp(x) > T decided in x-space.
@@ -208,6 +229,10 @@ int hc_create(hc_ctx** out, const hc_settings* settings) {
 }
 
 static void free_store(hc_ctx* c) {
+    if (c->d_found) (void)hipFree(c->d_found);
+    c->d_found = nullptr;
+    c->n_found = 0;
+    c->found_valid = false;
     if (c->d_sym) (void)hipFree(c->d_sym);
     if (c->d_reads) (void)hipFree(c->d_reads);
     if (c->d_lut) (void)hipFree(c->d_lut);
@@ -583,6 +608,27 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     for (const hc::SeqRef& r : c->seq_refs) max_len = r.len > max_len ? r.len : max_len;
     if (max_len >= (1u << 14)) return fail(HC_ERR_ARG, "hc_find_overlaps: sequences of 16384 symbols or more are not supported");
     if (n_seq < 2 || max_len < min_overlap) return HC_OK;
+    HC_HIP(hipSetDevice(c->device));
+    const bool recompute = flags & HC_FIND_RECOMPUTE;
+    flags &= ~HC_FIND_RECOMPUTE;
+    if (!recompute && c->found_valid && c->found_err == err_rate && c->found_min == min_overlap && c->found_flags == flags) {
+        *n_out = c->n_found;
+        const uint64_t take = c->n_found < cap ? c->n_found : cap;
+        if (take) HC_HIP(hipMemcpy(out, c->d_found, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
+        return HC_OK;
+    }
+    if (c->d_found) (void)hipFree(c->d_found);
+    c->d_found = nullptr;
+    c->n_found = 0;
+    c->found_valid = false;
+    auto remember = [&](hc_sfo_rec* d, uint64_t n) {
+        c->d_found = d;
+        c->n_found = n;
+        c->found_err = err_rate;
+        c->found_min = min_overlap;
+        c->found_flags = flags;
+        c->found_valid = true;
+    };
     // the longest stretch without a mismatch that every reportable overlap is guaranteed to contain
     uint32_t w = 0xFFFFFFFFu;
     for (uint32_t L = min_overlap; L <= max_len; L++) {
@@ -595,8 +641,14 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     const uint32_t k = w < 31 ? w : 31, s = w - k + 1;
     const uint32_t n_ori = (flags & HC_FIND_REVERSALS) ? 2u : 1u;
     const bool wide = c->view.symbytes == 1 && hc::lut_lg(c->view.K) == 6;
-    HC_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    {  // keep the pool's blocks between the phases of this call; they are handed back at the end (trim below)
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, c->device) == hipSuccess && pool) {
+            uint64_t keep = ~(uint64_t)0;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+    }
 
     // host-side layout of the index and of the seeds
     std::vector<uint64_t> pos_start(n_seq + 1, 0), seed_start(n_seq + 1, 0);
@@ -643,9 +695,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         size_t b = 0;
         HC_HIP(hc::finder_scan(nullptr, b, d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
         if (b > tmp_bytes) {
-            HC_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_tmp.p);
-            d_tmp.p = nullptr;
+            d_tmp.release();
             HC_ALLOC(d_tmp, b);
             tmp_bytes = b;
         }
@@ -654,13 +704,14 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     uint64_t H = 0;  // number of hits = last element of the exclusive scan over S + 1 counts (the extra one is 0)
     HC_HIP(hipMemcpyAsync(&H, d_off.as<uint64_t>() + S, 8, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
-    if (H == 0) return HC_OK;
+    if (H == 0) {
+        remember(nullptr, 0);
+        return HC_OK;
+    }
     if (H >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 seed hits (repeat-rich input): raise min_overlap or split the read set");
     // 3. one key per hit, sorted, unique: the candidate diagonals.  The index keys are no longer needed.
-    (void)hipFree(d_k0.p);
-    d_k0.p = nullptr;
-    (void)hipFree(d_v0.p);
-    d_v0.p = nullptr;
+    d_k0.release();
+    d_v0.release();
     DevBuf d_h0, d_h1;
     HC_ALLOC(d_h0, H * 8);
     HC_ALLOC(d_h1, H * 8);
@@ -672,9 +723,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         HC_HIP(hc::finder_unique(nullptr, b2, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), H, st));
         if (b2 > b) b = b2;
         if (b > tmp_bytes) {
-            HC_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_tmp.p);
-            d_tmp.p = nullptr;
+            d_tmp.release();
             HC_ALLOC(d_tmp, b);
             tmp_bytes = b;
         }
@@ -686,20 +735,21 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     unsigned long long M = 0;
     HC_HIP(hipMemcpyAsync(&M, d_count.p, sizeof M, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
-    if (M == 0) return HC_OK;
+    if (M == 0) {
+        remember(nullptr, 0);
+        return HC_OK;
+    }
     // 4. verify every candidate, keep the overlaps
     DevBuf d_r0, d_r1;
     HC_ALLOC(d_r0, M * sizeof(hc_sfo_rec));
-    HC_ALLOC(d_r1, M * sizeof(hc_sfo_rec));
+    HC_HIP(hipMalloc(&d_r1.p, M * sizeof(hc_sfo_rec)));  // outlives the call (kept by the context): not from the pool
     HC_HIP(hc::finder_verify(c->d_sym, c->view.symbytes, wide, d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), M, err_rate, min_overlap, flags,
                              d_r0.as<hc_sfo_rec>(), st));
     {
         size_t b = 0;
         HC_HIP(hc::finder_select_valid(nullptr, b, d_r0.as<hc_sfo_rec>(), d_r1.as<hc_sfo_rec>(), d_count.as<unsigned long long>(), M, st));
         if (b > tmp_bytes) {
-            HC_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_tmp.p);
-            d_tmp.p = nullptr;
+            d_tmp.release();
             HC_ALLOC(d_tmp, b);
             tmp_bytes = b;
         }
@@ -711,6 +761,17 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     *n_out = R;
     const uint64_t take = R < cap ? R : cap;
     if (take) HC_HIP(hipMemcpy(out, d_r1.p, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
+    remember((hc_sfo_rec*)d_r1.p, R);  // the context owns the records now
+    d_r1.p = nullptr;
+    // hand the scratch back: release the buffers now (not at scope exit) and trim the pool
+    d_seqs.release(); d_by_sfo.release(); d_pos_start.release(); d_seed_start.release(); d_k0.release(); d_k1.release();
+    d_v0.release(); d_v1.release(); d_tmp.release(); d_lo.release(); d_cnt.release(); d_off.release(); d_count.release();
+    d_h0.release(); d_h1.release(); d_r0.release();
+    HC_HIP(hipStreamSynchronize(st));
+    {
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, c->device) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
+    }
     return HC_OK;
 }
 

@@ -83,13 +83,16 @@ class EdgeScorer:
         N.check(N.lib.hc_compact_device(self._ctx, C.c_void_p(d_results_ptr), n, C.c_void_p(d_indices_ptr),
                                         C.c_void_p(d_count_ptr), C.c_void_p(stream or 0)), "hc_compact_device")
 
-    def find_overlaps(self, err_rate, min_overlap, reversals=True, inclusions=True):
-        """hc_find_overlaps: all suffix-prefix overlaps / inclusions between the stored sequences (SFO records)."""
+    def find_overlaps(self, err_rate, min_overlap, reversals=True, inclusions=True, count_only=False):
+        """hc_find_overlaps: all suffix-prefix overlaps / inclusions between the stored sequences (SFO records).
+        count_only: compute on the device (always afresh) and return the number of records."""
         from .records import FIND_INCLUSIONS, FIND_REVERSALS, SFO_DTYPE
 
         flags = (FIND_REVERSALS if reversals else 0) | (FIND_INCLUSIONS if inclusions else 0)
         n = C.c_uint64()
-        N.check(N.lib.hc_find_overlaps(self._ctx, err_rate, min_overlap, flags, None, 0, C.byref(n)), "hc_find_overlaps")
+        N.check(N.lib.hc_find_overlaps(self._ctx, err_rate, min_overlap, flags | 4, None, 0, C.byref(n)), "hc_find_overlaps")
+        if count_only:
+            return int(n.value)
         out = np.zeros(n.value, SFO_DTYPE)
         if n.value:
             N.check(N.lib.hc_find_overlaps(self._ctx, err_rate, min_overlap, flags, out.ctypes.data, out.size, C.byref(n)), "hc_find_overlaps")

@@ -205,6 +205,7 @@ int hc_pack_rows_device(hc_ctx* ctx, const void* d_results, const void* d_indice
  * rust-overlaps itself is not part of the reference tree: its output is NOT available to compare with here. */
 #define HC_FIND_REVERSALS  0x1u /* rust-overlaps -r: also B reverse-complemented ("I" records) */
 #define HC_FIND_INCLUSIONS 0x2u /* rust-overlaps -i: also report a sequence lying entirely inside the other */
+#define HC_FIND_RECOMPUTE  0x4u /* ignore the records kept from an identical earlier call (timing runs) */
 typedef struct hc_sfo_rec {
     uint32_t idA, idB;
     int32_t OHA, OHB;
@@ -212,7 +213,9 @@ typedef struct hc_sfo_rec {
     uint32_t inverted; /* 0 = "N", 1 = "I" */
 } hc_sfo_rec; /* 32 bytes */
 /* Runs on the device against the store of hc_set_reads.  *n_out = number of records found; the first
- * min(cap, *n_out) are copied to out (host memory; may be NULL when cap == 0). */
+ * min(cap, *n_out) are copied to out (host memory; may be NULL when cap == 0).  The records of the last call stay on
+ * the device until the next hc_set_reads / hc_find_overlaps with other parameters: asking for the count first and
+ * fetching with a second, identical call computes once. */
 int hc_find_overlaps(hc_ctx* ctx, double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, uint64_t cap,
                      uint64_t* n_out);
 
