@@ -8,11 +8,13 @@
 //   * the last group of paired candidates in the file is never matched (no flush after the loop), :63-103;
 //   * ties of the four numeric sort keys are ordered by the whole line, bytewise (sort under LC_ALL=C).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/hcedge_host.h"
@@ -27,9 +29,12 @@ struct SfoRec {
     long sfo[2];       // SFO ids in the order of the stored line
     char ori;          // 'N' / 'I' (anything else is carried through like the script does)
     long oha, ohb, ola, olb;
-    std::string k;     // last column, passed through untouched
-    std::string text;  // the line as the script writes it to its temporary file (sort tie-break, uniq)
+    // the line as the script writes it to its temporary file (sort tie-break, uniq): a slice of one arena
+    size_t text_off;
+    uint32_t text_len;
 };
+
+
 
 bool parse_long(const char* p, size_t n, long& v) {  // Python int(): optional sign, digits, surrounding blanks were split off
     if (n == 0 || n > 30) return false;
@@ -52,6 +57,111 @@ bool is_paired(long id, long ns, long np) {  // :124-134
     if (!(id >= 0 && id < ns + np)) throw FatalError{HC_ERR_FORMAT, "read id out of range for --num_singles/--num_pairs"};
     return id >= ns;
 }
+
+inline char* put_long(char* p, long v) {  // what "%ld" prints
+    unsigned long u = v < 0 ? 0ul - (unsigned long)v : (unsigned long)v;
+    if (v < 0) *p++ = '-';
+    char tmp[24];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+unsigned worker_count(size_t items) {
+    unsigned t = std::thread::hardware_concurrency();
+    if (t == 0) t = 1;
+    if (t > 16) t = 16;
+    const size_t by_size = items / 50000 + 1;  // not worth a thread below ~50 k items each
+    return (unsigned)(by_size < t ? by_size : t);
+}
+
+template <typename It, typename Cmp>
+void parallel_sort(It begin, It end, Cmp cmp) {  // sorted chunks, then pairwise merges; any total order
+    const size_t n = (size_t)(end - begin);
+    const unsigned T = worker_count(n);
+    if (T <= 1) {
+        std::sort(begin, end, cmp);
+        return;
+    }
+    std::vector<size_t> cut(T + 1);
+    for (unsigned t = 0; t <= T; t++) cut[t] = n * t / T;
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) th.emplace_back([&, t] { std::sort(begin + cut[t], begin + cut[t + 1], cmp); });
+        for (auto& x : th) x.join();
+    }
+    while (cut.size() > 2) {
+        std::vector<size_t> next{0};
+        std::vector<std::thread> th;
+        for (size_t k = 0; k + 2 < cut.size(); k += 2) {
+            th.emplace_back([&, k] { std::inplace_merge(begin + cut[k], begin + cut[k + 1], begin + cut[k + 2], cmp); });
+            next.push_back(cut[k + 2]);
+        }
+        for (auto& x : th) x.join();
+        if (next.back() != cut.back()) next.push_back(cut.back());
+        cut.swap(next);
+    }
+}
+
+struct Ingest {  // the records of one SFO input and the text arena behind them
+    std::vector<SfoRec> recs;
+    std::string arena;
+    long ns, np;
+
+    // one SFO record: ids, orientation text, the four numbers, the last column, and the line verbatim
+    void add(long ida, long idb, const char* ori, size_t ori_len, long oha, long ohb, long ola, long olb, const char* k, size_t k_len,
+             const char* line, size_t line_len) {
+        SfoRec r;
+        const long na = original_id(ida, ns, np), nb = original_id(idb, ns, np);
+        r.ori = ori_len == 1 ? ori[0] : '?';
+        r.oha = oha; r.ohb = ohb; r.ola = ola; r.olb = olb;
+        r.text_off = arena.size();
+        char buf[320];
+        if (na > nb) {  // flip_N / flip_I, :112-122
+            r.id[0] = nb; r.id[1] = na;
+            r.sfo[0] = idb; r.sfo[1] = ida;
+            if (ori_len == 1 && ori[0] == 'I') std::swap(r.oha, r.ohb);
+            else { r.oha = -r.oha; r.ohb = -r.ohb; }
+            std::swap(r.ola, r.olb);
+            if (ori_len + k_len > 128) throw FatalError{HC_ERR_FORMAT, "SFO line with an oversized field"};
+            char* q = buf;
+            const long head[4] = {nb, na, idb, ida};
+            for (long v : head) {
+                q = put_long(q, v);
+                *q++ = '\t';
+            }
+            memcpy(q, ori, ori_len);
+            q += ori_len;
+            const long nums[4] = {r.oha, r.ohb, r.ola, r.olb};
+            for (long v : nums) {
+                *q++ = '\t';
+                q = put_long(q, v);
+            }
+            *q++ = '\t';
+            memcpy(q, k, k_len);
+            q += k_len;
+            *q++ = '\n';
+            arena.append(buf, (size_t)(q - buf));
+        } else {
+            r.id[0] = na; r.id[1] = nb;
+            r.sfo[0] = ida; r.sfo[1] = idb;
+            char* q = put_long(buf, na);
+            *q++ = '\t';
+            q = put_long(q, nb);
+            *q++ = '\t';
+            arena.append(buf, (size_t)(q - buf));
+            arena.append(line, line_len);  // the original line verbatim (its own separators), :48
+            arena.push_back('\n');
+        }
+        r.text_len = (uint32_t)(arena.size() - r.text_off);
+        recs.push_back(r);
+    }
+    std::string finish(uint64_t& n_lines);
+};
 
 struct SS {  // one single-single overlap in SAVAGE columns, :150-200
     long id1, id2, pos1, perc, len;
@@ -129,11 +239,86 @@ bool paired_overlap(const SfoRec& c1, const SfoRec& c2, bool type_a, bool type_b
     return true;
 }
 
+std::string Ingest::finish(uint64_t& n_lines) {
+    // sort -k1,1n -k2,2n -k3,3n -k4,4n | uniq   (:53), LC_ALL=C — on indices, the records stay where they are
+    std::vector<uint32_t> order(recs.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    const char* A = arena.data();
+    auto text_cmp = [&](const SfoRec& x, const SfoRec& y) {
+        const int c = memcmp(A + x.text_off, A + y.text_off, x.text_len < y.text_len ? x.text_len : y.text_len);
+        return c ? c : (x.text_len < y.text_len ? -1 : (x.text_len > y.text_len ? 1 : 0));
+    };
+    bool small_ids = true;  // all four numeric keys fit 32 bits: sort compact keys instead of chasing the records
+    for (const SfoRec& r : recs)
+        if ((unsigned long)r.id[0] >> 32 || (unsigned long)r.id[1] >> 32 || (unsigned long)r.sfo[0] >> 32 || (unsigned long)r.sfo[1] >> 32) {
+            small_ids = false;
+            break;
+        }
+    if (small_ids) {
+        struct Key {
+            uint64_t ids, sfos;
+            uint32_t idx;
+        };
+        std::vector<Key> keys(recs.size());
+        for (size_t i = 0; i < recs.size(); i++)
+            keys[i] = Key{((uint64_t)recs[i].id[0] << 32) | (uint64_t)recs[i].id[1], ((uint64_t)recs[i].sfo[0] << 32) | (uint64_t)recs[i].sfo[1],
+                          (uint32_t)i};
+        parallel_sort(keys.begin(), keys.end(), [&](const Key& x, const Key& y) {
+            if (x.ids != y.ids) return x.ids < y.ids;
+            if (x.sfos != y.sfos) return x.sfos < y.sfos;
+            return text_cmp(recs[x.idx], recs[y.idx]) < 0;
+        });
+        for (size_t i = 0; i < keys.size(); i++) order[i] = keys[i].idx;
+    } else {
+        parallel_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            const SfoRec &x = recs[a], &y = recs[b];
+            if (x.id[0] != y.id[0]) return x.id[0] < y.id[0];
+            if (x.id[1] != y.id[1]) return x.id[1] < y.id[1];
+            if (x.sfo[0] != y.sfo[0]) return x.sfo[0] < y.sfo[0];
+            if (x.sfo[1] != y.sfo[1]) return x.sfo[1] < y.sfo[1];
+            return text_cmp(x, y) < 0;
+        });
+    }
+    std::string out, last_line, cur;
+    n_lines = 0;
+    auto emit = [&](const std::string& l) {  // the final `uniq`, :107
+        if (n_lines && l == last_line) return;
+        out += l;
+        last_line = l;
+        n_lines++;
+    };
+    std::vector<const SfoRec*> cands;
+    for (size_t i = 0; i < order.size(); i++) {
+        const SfoRec& r = recs[order[i]];
+        if (i && text_cmp(r, recs[order[i - 1]]) == 0) continue;  // uniq
+        if (r.id[0] == r.id[1]) continue;  // self-overlap, :69-70
+        const bool pa = is_paired(r.id[0], ns, np), pb = is_paired(r.id[1], ns, np);
+        if (!pa && !pb) {  // :79-85
+            cur.clear();
+            put_ss(cur, s_s_overlap(r));
+            emit(cur);
+            continue;
+        }
+        if (!cands.empty() && (cands[0]->id[0] != r.id[0] || cands[0]->id[1] != r.id[1])) {  // :89-102
+            if (cands.size() >= 2)
+                for (size_t a = 0; a < cands.size(); a++)
+                    for (size_t b = a + 1; b < cands.size(); b++)
+                        if (paired_overlap(*cands[a], *cands[b], pa, pb, cur)) emit(cur);
+            cands.clear();
+        }
+        cands.push_back(&r);
+    }
+    return out;
+}
+
 }  // namespace
 
 // Returns the output text; n_lines receives the number of lines.
 std::string sfo_to_overlaps(const std::string& sfo_text, long ns, long np, uint64_t& n_lines) {
-    std::vector<SfoRec> recs;
+    Ingest in;
+    in.ns = ns;
+    in.np = np;
+    in.arena.reserve(sfo_text.size() + sfo_text.size() / 2);
     size_t pos = 0;
     const size_t N = sfo_text.size();
     while (pos < N) {  // :31-50
@@ -155,74 +340,87 @@ std::string sfo_to_overlaps(const std::string& sfo_text, long ns, long np, uint6
             nf++;
         }
         if (nf != 8) throw FatalError{HC_ERR_FORMAT, "SFO line does not have 8 fields (assert in the reference)"};
-        SfoRec r;
-        long ida, idb;
-        if (!parse_long(f[0], fl[0], ida) || !parse_long(f[1], fl[1], idb) || !parse_long(f[3], fl[3], r.oha) ||
-            !parse_long(f[4], fl[4], r.ohb) || !parse_long(f[5], fl[5], r.ola) || !parse_long(f[6], fl[6], r.olb))
+        long ida, idb, oha, ohb, ola, olb;
+        if (!parse_long(f[0], fl[0], ida) || !parse_long(f[1], fl[1], idb) || !parse_long(f[3], fl[3], oha) ||
+            !parse_long(f[4], fl[4], ohb) || !parse_long(f[5], fl[5], ola) || !parse_long(f[6], fl[6], olb))
             throw FatalError{HC_ERR_FORMAT, "SFO line with a non-integer field"};
-        const long na = original_id(ida, ns, np), nb = original_id(idb, ns, np);
-        const std::string ori(f[2], fl[2]);
-        r.ori = ori.size() == 1 ? ori[0] : '?';
-        r.k.assign(f[7], fl[7]);
-        char head[64];
-        if (na > nb) {  // flip_N / flip_I, :112-122
-            r.id[0] = nb; r.id[1] = na;
-            r.sfo[0] = idb; r.sfo[1] = ida;
-            if (ori == "I") std::swap(r.oha, r.ohb);
-            else { r.oha = -r.oha; r.ohb = -r.ohb; }
-            std::swap(r.ola, r.olb);
-            char buf[256];
-            const int k = snprintf(buf, sizeof buf, "%ld\t%ld\t%ld\t%ld\t%s\t%ld\t%ld\t%ld\t%ld\t%s\n", nb, na, idb, ida, ori.c_str(), r.oha,
-                                   r.ohb, r.ola, r.olb, r.k.c_str());
-            r.text.assign(buf, (size_t)k);
-        } else {
-            r.id[0] = na; r.id[1] = nb;
-            r.sfo[0] = ida; r.sfo[1] = idb;
-            const int k = snprintf(head, sizeof head, "%ld\t%ld\t", na, nb);
-            r.text.assign(head, (size_t)k);
-            r.text.append(line, len);  // the original line verbatim (its own separators), :48
-            r.text.push_back('\n');
-        }
-        recs.push_back(std::move(r));
+        in.add(ida, idb, f[2], fl[2], oha, ohb, ola, olb, f[7], fl[7], line, len);
         pos = nl ? end + 1 : N;
     }
-    // sort -k1,1n -k2,2n -k3,3n -k4,4n | uniq   (:53), LC_ALL=C
-    std::sort(recs.begin(), recs.end(), [](const SfoRec& x, const SfoRec& y) {
-        if (x.id[0] != y.id[0]) return x.id[0] < y.id[0];
-        if (x.id[1] != y.id[1]) return x.id[1] < y.id[1];
-        if (x.sfo[0] != y.sfo[0]) return x.sfo[0] < y.sfo[0];
-        if (x.sfo[1] != y.sfo[1]) return x.sfo[1] < y.sfo[1];
-        return x.text < y.text;
-    });
-    std::string out, last_line, cur;
-    n_lines = 0;
-    auto emit = [&](const std::string& l) {  // the final `uniq`, :107
-        if (n_lines && l == last_line) return;
-        out += l;
-        last_line = l;
-        n_lines++;
+    return in.finish(n_lines);
+}
+
+// The same from binary records (hc_find_overlaps): exactly what the text path yields for the file hc_host_write_sfo
+// writes for them, without writing or parsing it.
+std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns, long np, uint64_t& n_lines) {
+    const auto t0 = std::chrono::steady_clock::now();
+    Ingest in;
+    in.ns = ns;
+    in.np = np;
+    const unsigned T = worker_count(n);
+    std::vector<Ingest> part(T);
+    std::vector<FatalError> errs(T, FatalError{0, ""});
+    auto build = [&](unsigned t) {
+      try {
+        Ingest& in = part[t];
+        in.ns = ns;
+        in.np = np;
+        const uint64_t b = n * t / T, e = n * (t + 1) / T;
+        in.recs.reserve(e - b);
+        in.arena.reserve((e - b) * 48);
+        char line[160], kbuf[16];
+        for (uint64_t i = b; i < e; i++) {
+        const hc_sfo_rec& r = recs[i];
+        const char ori = r.inverted ? 'I' : 'N';
+        const size_t kl = (size_t)(put_long(kbuf, (long)r.K) - kbuf);
+        char* q = put_long(line, (long)r.idA);  // the line hc_host_write_sfo writes
+        *q++ = '\t';
+        q = put_long(q, (long)r.idB);
+        *q++ = '\t';
+        *q++ = ori;
+        const long nums[5] = {r.OHA, r.OHB, (long)r.OLA, (long)r.OLB, (long)r.K};
+        for (long v : nums) {
+            *q++ = '\t';
+            q = put_long(q, v);
+        }
+        in.add((long)r.idA, (long)r.idB, &ori, 1, r.OHA, r.OHB, (long)r.OLA, (long)r.OLB, kbuf, kl, line, (size_t)(q - line));
+        }
+      } catch (const FatalError& e) {
+        errs[t] = e;
+      }
     };
-    std::vector<const SfoRec*> cands;
-    for (size_t i = 0; i < recs.size(); i++) {
-        if (i && recs[i].text == recs[i - 1].text) continue;  // uniq
-        const SfoRec& r = recs[i];
-        if (r.id[0] == r.id[1]) continue;  // self-overlap, :69-70
-        const bool pa = is_paired(r.id[0], ns, np), pb = is_paired(r.id[1], ns, np);
-        if (!pa && !pb) {  // :79-85
-            cur.clear();
-            put_ss(cur, s_s_overlap(r));
-            emit(cur);
-            continue;
-        }
-        if (!cands.empty() && (cands[0]->id[0] != r.id[0] || cands[0]->id[1] != r.id[1])) {  // :89-102
-            if (cands.size() >= 2)
-                for (size_t a = 0; a < cands.size(); a++)
-                    for (size_t b = a + 1; b < cands.size(); b++)
-                        if (paired_overlap(*cands[a], *cands[b], pa, pb, cur)) emit(cur);
-            cands.clear();
-        }
-        cands.push_back(&r);
+    if (T == 1) {
+        build(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) th.emplace_back(build, t);
+        for (auto& x : th) x.join();
     }
+    for (const FatalError& e : errs)
+        if (e.status) throw e;
+    {  // one arena, one record array: the pieces in order, text offsets rebased
+        size_t n_recs = 0, n_text = 0;
+        for (const Ingest& p : part) {
+            n_recs += p.recs.size();
+            n_text += p.arena.size();
+        }
+        in.recs.reserve(n_recs);
+        in.arena.reserve(n_text);
+        for (Ingest& p : part) {
+            const size_t base = in.arena.size();
+            in.arena += p.arena;
+            for (SfoRec r : p.recs) {
+                r.text_off += base;
+                in.recs.push_back(r);
+            }
+            p = Ingest();
+        }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    std::string out = in.finish(n_lines);
+    if (getenv("HC_SFO_TIMING"))
+        fprintf(stderr, "sfo_records_to_overlaps: build %.3f s, sort+match %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     return out;
 }
 

@@ -21,6 +21,7 @@ struct hc_host_graph {
 
 namespace hc {
 std::string sfo_to_overlaps(const std::string& sfo_text, long ns, long np, uint64_t& n_lines);  // Sfo2Overlaps.cpp
+std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns, long np, uint64_t& n_lines);
 }
 
 extern "C" {
@@ -126,6 +127,20 @@ int hc_host_write_overlaps(const char* path, const hc_overlap_rec* recs, uint64_
         }
         if (fclose(o) != 0) throw FatalError{HC_ERR_IO, std::string("cannot close ") + path};
         if (bad) throw FatalError{HC_ERR_BAD_OVERLAP, "hc_host_write_overlaps: read index out of range"};
+    });
+}
+
+int hc_sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, const char* out_path, uint64_t num_singles, uint64_t num_pairs,
+                               uint64_t* n_lines) {
+    if (!out_path || (n && !recs)) return set_last_error(HC_ERR_ARG, "hc_sfo_records_to_overlaps: null");
+    return guarded("sfo_records_to_overlaps", [&] {
+        uint64_t k = 0;
+        const std::string out = hc::sfo_records_to_overlaps(recs, n, (long)num_singles, (long)num_pairs, k);
+        FILE* o = fopen(out_path, "wb");
+        if (!o) throw FatalError{HC_ERR_IO, std::string("cannot write ") + out_path};
+        const size_t w = out.empty() ? 0 : fwrite(out.data(), 1, out.size(), o);
+        if (fclose(o) != 0 || w != out.size()) throw FatalError{HC_ERR_IO, std::string("short write to ") + out_path};
+        if (n_lines) *n_lines = k;
     });
 }
 

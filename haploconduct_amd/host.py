@@ -62,6 +62,7 @@ _sig = {
     "hc_host_parse_file": (C.c_int, [C.POINTER(N.hc_settings), _vp, C.c_char_p, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                      C.POINTER(hc_ec_counters)]),
     "hc_sfo2overlaps": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "hc_sfo_records_to_overlaps": (C.c_int, [_vp, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_host_write_sfo": (C.c_int, [C.c_char_p, _vp, C.c_uint64]),
     "hc_host_write_overlaps": (C.c_int, [C.c_char_p, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint32]),
     "hc_host_graph_new": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.POINTER(N.hc_settings)]),
@@ -118,6 +119,16 @@ def write_sfo(path, recs):
     """SFO records (records.SFO_DTYPE) as the text file rust-overlaps writes."""
     recs = np.ascontiguousarray(recs)
     N.check(N.lib.hc_host_write_sfo(_b(path), recs.ctypes.data, recs.size), "hc_host_write_sfo")
+
+
+def sfo_records_to_overlaps(recs, out_path, num_singles, num_pairs):
+    """SFO records straight to the 13-column overlaps file (hc_sfo_records_to_overlaps): write_sfo + sfo2overlaps
+    without the intermediate text."""
+    recs = np.ascontiguousarray(recs)
+    n = C.c_uint64()
+    N.check(N.lib.hc_sfo_records_to_overlaps(recs.ctypes.data, recs.size, _b(out_path), num_singles, num_pairs, C.byref(n)),
+            "hc_sfo_records_to_overlaps")
+    return int(n.value)
 
 
 def sfo2overlaps(sfo_path, out_path, num_singles, num_pairs):

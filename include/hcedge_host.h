@@ -112,6 +112,11 @@ int hc_host_write_sfo(const char* path, const hc_sfo_rec* recs, uint64_t n);
  * including its sort / uniq passes.  *n_lines receives the number of overlap lines written. */
 int hc_sfo2overlaps(const char* sfo_path, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines);
 
+/* The same from the binary records of hc_find_overlaps: the result is what hc_sfo2overlaps gives for the file
+ * hc_host_write_sfo writes for those records, without writing or parsing it. */
+int hc_sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, const char* out_path, uint64_t num_singles, uint64_t num_pairs,
+                               uint64_t* n_lines);
+
 /* The serial insert of process_overlaps (src/EdgeCalculator.cpp:441-538) on a bare graph. */
 typedef struct hc_host_graph hc_host_graph;
 int hc_host_graph_new(hc_host_graph** out, uint64_t n_vertices, const hc_settings* settings);

@@ -48,3 +48,26 @@ def test_sfo_text_writer_roundtrip(tmp_path):
     n = host.sfo2overlaps(str(p), str(out), 8, 0)
     want = "".join(l + "\n" for l in S.sfo2overlaps(p.read_text().splitlines(), 8, 0))
     assert n == 3 and out.read_text() == want
+
+
+def test_records_path_equals_text_path(tmp_path):
+    """hc_sfo_records_to_overlaps == hc_host_write_sfo + hc_sfo2overlaps, byte for byte (singles, pairs, both)."""
+    rng = np.random.default_rng(7)
+    for ns, npairs in ((40, 0), (0, 30), (15, 20)):
+        n_ids = ns + 2 * npairs
+        n = 4000
+        recs = np.zeros(n, SFO_DTYPE)
+        a = rng.integers(0, n_ids, n)
+        b = (a + 1 + rng.integers(0, n_ids - 1, n)) % n_ids
+        recs["idA"], recs["idB"] = np.minimum(a, b), np.maximum(a, b)
+        recs["OHA"], recs["OHB"] = rng.integers(-60, 60, n), rng.integers(-60, 60, n)
+        recs["OLA"] = recs["OLB"] = rng.integers(40, 150, n)
+        recs["K"], recs["inverted"] = rng.integers(0, 3, n), rng.integers(0, 2, n)
+        recs = recs[rng.permutation(n)]  # any order: the ingest sorts
+        host.write_sfo(str(tmp_path / "a.sfo"), recs)
+        n_text = host.sfo2overlaps(str(tmp_path / "a.sfo"), str(tmp_path / "text.txt"), ns, npairs)
+        n_rec = host.sfo_records_to_overlaps(recs, str(tmp_path / "rec.txt"), ns, npairs)
+        assert n_text == n_rec > 0
+        assert (tmp_path / "text.txt").read_bytes() == (tmp_path / "rec.txt").read_bytes()
+        want = "".join(l + "\n" for l in S.sfo2overlaps((tmp_path / "a.sfo").read_text().splitlines(), ns, npairs))
+        assert (tmp_path / "rec.txt").read_text() == want

@@ -40,11 +40,8 @@ def main():
         recs = sc.find_overlaps(a.err, a.min_overlap)
         t["find_overlaps"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    host.write_sfo(d + "sfoverlaps.out", recs)
-    t["write_sfo"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    n_lines = host.sfo2overlaps(d + "sfoverlaps.out", d + "overlaps.txt", n_single, n_pairs)
-    t["sfo2overlaps"] = time.perf_counter() - t0
+    n_lines = host.sfo_records_to_overlaps(recs, d + "overlaps.txt", n_single, n_pairs)  # == write_sfo + sfo2overlaps
+    t["sfo_records_to_overlaps"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     kw = dict(singles=None if paired else d + "singles.fastq", paired1=d + "p1.fastq" if paired else None,
               paired2=d + "p2.fastq" if paired else None, overlaps=d + "overlaps.txt", output_dir=d)
