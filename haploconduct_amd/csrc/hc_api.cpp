@@ -4,6 +4,7 @@
 // a HIP device hc_create fails with HC_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +80,10 @@ struct hc_ctx {
     bool singles_first = true;
     // result of the last hc_find_overlaps, kept on the device so that the usual "ask for the count, then fetch"
     // pair of calls computes once
+    struct Scratch {  // grow-only device scratch of the finder, one slot per buffer, freed with the store
+        void* p = nullptr;
+        size_t cap = 0;
+    } finder_scratch[20];
     hc_sfo_rec* d_found = nullptr;
     uint64_t n_found = 0;
     double found_err = -1;
@@ -105,30 +110,34 @@ struct hc_ctx {
 };
 
 namespace {
-// Scratch of one call, from the stream-ordered pool (hipMallocAsync): the overlap finder takes and returns
-// gigabytes per call, and plain hipMalloc / hipFree of such blocks cost more wall time than its kernels.
+// A view of one of the context's grow-only scratch slots (hc_ctx::finder_scratch).  The overlap finder needs
+// gigabytes of scratch per call; allocating and freeing them every call (hipMalloc/hipFree or the stream-ordered
+// pool alike) costs several times its kernels, so the blocks stay with the context until the store is replaced.
 struct DevBuf {
     void* p = nullptr;
-    hipStream_t stream = nullptr;
-    bool pooled = false;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) {
-            if (pooled) (void)hipFreeAsync(p, stream);
-            else (void)hipFree(p);
-        }
-        p = nullptr;
+    hc_ctx::Scratch* slot = nullptr;
+    void* own = nullptr;  // a block that is not a slot (the result, which outlives the call)
+    ~DevBuf() {
+        if (own) (void)hipFree(own);
     }
     template <typename T>
     T* as() const { return (T*)p; }
 };
 }  // namespace
 
-#define HC_ALLOC(buf, bytes)                                                          \
-    do {                                                                              \
-        (buf).stream = st;                                                            \
-        (buf).pooled = true;                                                          \
-        HC_HIP(hipMallocAsync(&(buf).p, (bytes) ? (size_t)(bytes) : 16, st));         \
+#define HC_ALLOC(buf, bytes)                                                                  \
+    do {                                                                                      \
+        hc_ctx::Scratch& sl__ = c->finder_scratch[n_slots++];                                 \
+        const size_t need__ = (bytes) ? (size_t)(bytes) : 16;                                 \
+        if (sl__.cap < need__) {                                                              \
+            if (sl__.p) (void)hipFree(sl__.p);                                                \
+            sl__.p = nullptr;                                                                 \
+            sl__.cap = 0;                                                                     \
+            HC_HIP(hipMalloc(&sl__.p, need__ + need__ / 8));                                  \
+            sl__.cap = need__ + need__ / 8;                                                   \
+        }                                                                                     \
+        (buf).slot = &sl__;                                                                   \
+        (buf).p = sl__.p;                                                                     \
     } while (0)
 
 // --------------------------------------------------------------------------
@@ -229,6 +238,11 @@ int hc_create(hc_ctx** out, const hc_settings* settings) {
 }
 
 static void free_store(hc_ctx* c) {
+    for (auto& sl : c->finder_scratch) {
+        if (sl.p) (void)hipFree(sl.p);
+        sl.p = nullptr;
+        sl.cap = 0;
+    }
     if (c->d_found) (void)hipFree(c->d_found);
     c->d_found = nullptr;
     c->n_found = 0;
@@ -609,6 +623,16 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     if (max_len >= (1u << 14)) return fail(HC_ERR_ARG, "hc_find_overlaps: sequences of 16384 symbols or more are not supported");
     if (n_seq < 2 || max_len < min_overlap) return HC_OK;
     HC_HIP(hipSetDevice(c->device));
+    const bool timing = getenv("HC_FIND_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tmark = now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(c->stream);
+        const double t = now();
+        fprintf(stderr, "hc_find_overlaps: %-28s %.4f s\n", what, t - tmark);
+        tmark = t;
+    };
     const bool recompute = flags & HC_FIND_RECOMPUTE;
     flags &= ~HC_FIND_RECOMPUTE;
     if (!recompute && c->found_valid && c->found_err == err_rate && c->found_min == min_overlap && c->found_flags == flags) {
@@ -621,6 +645,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     c->d_found = nullptr;
     c->n_found = 0;
     c->found_valid = false;
+    lap("free previous result");
     auto remember = [&](hc_sfo_rec* d, uint64_t n) {
         c->d_found = d;
         c->n_found = n;
@@ -642,13 +667,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     const uint32_t n_ori = (flags & HC_FIND_REVERSALS) ? 2u : 1u;
     const bool wide = c->view.symbytes == 1 && hc::lut_lg(c->view.K) == 6;
     hipStream_t st = c->stream;
-    {  // keep the pool's blocks between the phases of this call; they are handed back at the end (trim below)
-        hipMemPool_t pool = nullptr;
-        if (hipDeviceGetDefaultMemPool(&pool, c->device) == hipSuccess && pool) {
-            uint64_t keep = ~(uint64_t)0;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        }
-    }
+    unsigned n_slots = 0;  // HC_ALLOC takes the context's scratch slots in order
 
     // host-side layout of the index and of the seeds
     std::vector<uint64_t> pos_start(n_seq + 1, 0), seed_start(n_seq + 1, 0);
@@ -684,6 +703,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     HC_HIP(hc::finder_sort_pairs(nullptr, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
     HC_ALLOC(d_tmp, tmp_bytes);
     HC_HIP(hc::finder_sort_pairs(d_tmp.p, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
+    lap("index + sort");
     // 2. seeds: range of every seed k-mer in the index
     HC_ALLOC(d_lo, S * 8);
     HC_ALLOC(d_cnt, (S + 1) * 8);
@@ -695,8 +715,13 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         size_t b = 0;
         HC_HIP(hc::finder_scan(nullptr, b, d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
         if (b > tmp_bytes) {
-            d_tmp.release();
-            HC_ALLOC(d_tmp, b);
+            HC_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_tmp.slot->p);
+            d_tmp.slot->p = nullptr;
+            d_tmp.slot->cap = 0;
+            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
+            d_tmp.slot->cap = b;
+            d_tmp.p = d_tmp.slot->p;
             tmp_bytes = b;
         }
         HC_HIP(hc::finder_scan(d_tmp.p, b, d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
@@ -704,14 +729,14 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     uint64_t H = 0;  // number of hits = last element of the exclusive scan over S + 1 counts (the extra one is 0)
     HC_HIP(hipMemcpyAsync(&H, d_off.as<uint64_t>() + S, 8, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
+    lap("seeds + scan");
     if (H == 0) {
         remember(nullptr, 0);
         return HC_OK;
     }
     if (H >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 seed hits (repeat-rich input): raise min_overlap or split the read set");
     // 3. one key per hit, sorted, unique: the candidate diagonals.  The index keys are no longer needed.
-    d_k0.release();
-    d_v0.release();
+    // (the index keys d_k0 / d_v0 are dead from here on; their slots are simply not used again in this call)
     DevBuf d_h0, d_h1;
     HC_ALLOC(d_h0, H * 8);
     HC_ALLOC(d_h1, H * 8);
@@ -723,8 +748,13 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         HC_HIP(hc::finder_unique(nullptr, b2, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), H, st));
         if (b2 > b) b = b2;
         if (b > tmp_bytes) {
-            d_tmp.release();
-            HC_ALLOC(d_tmp, b);
+            HC_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_tmp.slot->p);
+            d_tmp.slot->p = nullptr;
+            d_tmp.slot->cap = 0;
+            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
+            d_tmp.slot->cap = b;
+            d_tmp.p = d_tmp.slot->p;
             tmp_bytes = b;
         }
         size_t bs = tmp_bytes;
@@ -735,43 +765,56 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     unsigned long long M = 0;
     HC_HIP(hipMemcpyAsync(&M, d_count.p, sizeof M, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
+    lap("expand + sort + unique");
     if (M == 0) {
         remember(nullptr, 0);
         return HC_OK;
     }
-    // 4. verify every candidate, keep the overlaps
-    DevBuf d_r0, d_r1;
-    HC_ALLOC(d_r0, M * sizeof(hc_sfo_rec));
-    HC_HIP(hipMalloc(&d_r1.p, M * sizeof(hc_sfo_rec)));  // outlives the call (kept by the context): not from the pool
+    // 4. verify every candidate (8 bytes out per candidate), scan the flags, emit the records of the verified ones
+    if (M >= (1ull << 31) - 1) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 candidate diagonals");
+    DevBuf d_kout, d_flag, d_pos, d_r1;
+    HC_ALLOC(d_kout, M * 4);
+    HC_ALLOC(d_flag, (M + 1) * 4);
+    HC_ALLOC(d_pos, (M + 1) * 4);
+    HC_HIP(hipMemsetAsync(d_flag.as<uint32_t>() + M, 0, 4, st));
     HC_HIP(hc::finder_verify(c->d_sym, c->view.symbytes, wide, d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), M, err_rate, min_overlap, flags,
-                             d_r0.as<hc_sfo_rec>(), st));
+                             d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), st));
     {
         size_t b = 0;
-        HC_HIP(hc::finder_select_valid(nullptr, b, d_r0.as<hc_sfo_rec>(), d_r1.as<hc_sfo_rec>(), d_count.as<unsigned long long>(), M, st));
+        HC_HIP(hc::finder_scan32(nullptr, b, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M + 1, st));
         if (b > tmp_bytes) {
-            d_tmp.release();
-            HC_ALLOC(d_tmp, b);
+            HC_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_tmp.slot->p);
+            d_tmp.slot->p = nullptr;
+            d_tmp.slot->cap = 0;
+            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
+            d_tmp.slot->cap = b;
+            d_tmp.p = d_tmp.slot->p;
             tmp_bytes = b;
         }
-        HC_HIP(hc::finder_select_valid(d_tmp.p, b, d_r0.as<hc_sfo_rec>(), d_r1.as<hc_sfo_rec>(), d_count.as<unsigned long long>(), M, st));
+        HC_HIP(hc::finder_scan32(d_tmp.p, b, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M + 1, st));
     }
-    unsigned long long R = 0;
-    HC_HIP(hipMemcpyAsync(&R, d_count.p, sizeof R, hipMemcpyDeviceToHost, st));
+    uint32_t R32 = 0;
+    HC_HIP(hipMemcpyAsync(&R32, d_pos.as<uint32_t>() + M, 4, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
+    lap("verify + scan");
+    const unsigned long long R = R32;
+    if (R == 0) {
+        remember(nullptr, 0);
+        return HC_OK;
+    }
+    HC_HIP(hipMalloc(&d_r1.own, R * sizeof(hc_sfo_rec)));  // outlives the call (kept by the context): not a scratch slot
+    d_r1.p = d_r1.own;
+    HC_HIP(hc::finder_emit(d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M,
+                           (hc_sfo_rec*)d_r1.p, st));
+    HC_HIP(hipStreamSynchronize(st));
+    lap("alloc result + emit");
     *n_out = R;
     const uint64_t take = R < cap ? R : cap;
     if (take) HC_HIP(hipMemcpy(out, d_r1.p, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
+    lap("copy to host");
     remember((hc_sfo_rec*)d_r1.p, R);  // the context owns the records now
-    d_r1.p = nullptr;
-    // hand the scratch back: release the buffers now (not at scope exit) and trim the pool
-    d_seqs.release(); d_by_sfo.release(); d_pos_start.release(); d_seed_start.release(); d_k0.release(); d_k1.release();
-    d_v0.release(); d_v1.release(); d_tmp.release(); d_lo.release(); d_cnt.release(); d_off.release(); d_count.release();
-    d_h0.release(); d_h1.release(); d_r0.release();
-    HC_HIP(hipStreamSynchronize(st));
-    {
-        hipMemPool_t pool = nullptr;
-        if (hipDeviceGetDefaultMemPool(&pool, c->device) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
-    }
+    d_r1.own = nullptr;
     return HC_OK;
 }
 

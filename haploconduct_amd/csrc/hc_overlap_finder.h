@@ -25,14 +25,15 @@ hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_
                          const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, const uint64_t* seed_out,
                          uint64_t* out_keys, hipStream_t stream);
 hipError_t finder_verify(const void* sym, uint32_t symbytes, bool wide, const SeqRef* by_sfo, const uint64_t* keys, uint64_t n,
-                         double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, hipStream_t stream);
+                         double err_rate, uint32_t min_overlap, uint32_t flags, uint32_t* kout, uint32_t* flag, hipStream_t stream);
+hipError_t finder_emit(const SeqRef* by_sfo, const uint64_t* keys, const uint32_t* kout, const uint32_t* flag, const uint32_t* pos, uint64_t n,
+                       hc_sfo_rec* out, hipStream_t stream);
 hipError_t finder_sort_pairs(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint64_t* v_in, uint64_t* v_out,
                              uint64_t n, int end_bit, hipStream_t stream);
 hipError_t finder_sort_keys(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, uint64_t n, hipStream_t stream);
 hipError_t finder_scan(void* temp, size_t& temp_bytes, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t stream);
 hipError_t finder_unique(void* temp, size_t& temp_bytes, const uint64_t* in, uint64_t* out, unsigned long long* n_out, uint64_t n,
                          hipStream_t stream);
-hipError_t finder_select_valid(void* temp, size_t& temp_bytes, const hc_sfo_rec* in, hc_sfo_rec* out, unsigned long long* n_out, uint64_t n,
-                               hipStream_t stream);
+hipError_t finder_scan32(void* temp, size_t& temp_bytes, const uint32_t* in, uint32_t* out, uint64_t n, hipStream_t stream);
 
 }  // namespace hc

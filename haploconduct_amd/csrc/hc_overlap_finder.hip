@@ -13,8 +13,9 @@
 //            complement — the store holds both orientations — binary-searched in the index
 //   expand   every hit (A, q) with id(A) < id(B) gives a diagonal d = q - p: key (A, B, orientation, d)
 //   unique   radix sort + unique of the keys (many seeds find the same diagonal)          [hipCUB]
-//   verify   one lane per candidate: overlap region, length >= T, mismatches <= floor(e*L) (N matches nothing)
-//   compact  the verified records, in key order                                          [hipCUB]
+//   verify   one lane per candidate: overlap region, length >= T, mismatches <= floor(e*L) (N matches nothing);
+//            writes 8 bytes per candidate (mismatch count, flag), not a record
+//   emit     exclusive scan of the flags [hipCUB], then the records of the verified candidates in key order
 // Every unordered pair is examined once (the lower id is the indexed side), so no record appears twice.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -149,23 +150,30 @@ __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __rest
     }
 }
 
-struct RecValid {
-    __device__ bool operator()(const hc_sfo_rec& r) const { return r.idA != 0xFFFFFFFFu; }
-};
+// Mismatches among the first `nbytes` (1..8) symbol bytes of two 8-byte words of 8-bit symbols: a position counts when
+// the bases differ or either symbol is not A,C,G,T.
+template <bool WIDE>
+__device__ __forceinline__ uint32_t mismatches8(uint64_t a, uint64_t b, int nbytes) {
+    uint64_t m;
+    if (WIDE) {  // base in bits 0-1; quality index >= 48 (both top bits set) marks N / invalid
+        m = ((a ^ b) & 0x0303030303030303ull) | (((a & (a << 1)) | (b & (b << 1))) & 0x8080808080808080ull);
+    } else {  // code in bits 0-2: 0..3 bases, 4 N, 6/7 invalid
+        m = ((a ^ b) | (a & 0x0404040404040404ull)) & 0x0707070707070707ull;
+    }
+    if (nbytes < 8) m &= ~(uint64_t)0 >> (8 * (8 - nbytes));
+    const uint64_t nz = (((m & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | m) & 0x8080808080808080ull;
+    return (uint32_t)__popcll(nz);
+}
 
+// Verifies candidate i: kout[i] = number of mismatches if it is a reportable overlap, flag[i] = 1; else flag[i] = 0.
 template <int SB, bool WIDE>
 __global__ __launch_bounds__(256) void finder_verify_kernel(const void* __restrict__ sym, const SeqRef* __restrict__ by_sfo,
                                                             uint32_t symbytes, const uint64_t* __restrict__ keys, uint64_t n,
                                                             double err_rate, uint32_t min_overlap, uint32_t flags,
-                                                            hc_sfo_rec* __restrict__ out) {
+                                                            uint32_t* __restrict__ kout, uint32_t* __restrict__ flag) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t key = keys[i];
-        hc_sfo_rec rec;
-        rec.idA = 0xFFFFFFFFu;
-        rec.idB = 0;
-        rec.OHA = rec.OHB = 0;
-        rec.OLA = rec.OLB = rec.K = 0;
-        rec.inverted = 0;
+        uint32_t ok = 0, mm = 0;
         if (key != kNoKey) {
             const uint32_t ida = (uint32_t)(key >> 40), idb = (uint32_t)(key >> 16) & 0xFFFFFFu, o = (uint32_t)(key >> 15) & 1u;
             const int d = (int)(uint32_t)(key & 0x7FFFu) - kDiagBias;
@@ -177,24 +185,50 @@ __global__ __launch_bounds__(256) void finder_verify_kernel(const void* __restri
             if (L >= (int)min_overlap && (!inclusion || (flags & HC_FIND_INCLUSIONS))) {
                 const uint32_t kmax = (uint32_t)(err_rate * (double)L);
                 const uint64_t offb = o ? B.off + slot_stride(B.len, symbytes) : B.off;
-                uint32_t mm = 0;
-                for (int x = start; x < end && mm <= kmax; x++) {
-                    const uint32_t a = base_at<SB, WIDE>(sym, A.off + (uint64_t)x);
-                    const uint32_t b = base_at<SB, WIDE>(sym, offb + (uint64_t)(x - d));
-                    mm += (a != b) | (a > 3u);
+                if (SB == 1) {  // 8 symbols per step (slots are padded: reading a few bytes past the end is safe)
+                    const uint8_t* pa = (const uint8_t*)sym + A.off + (uint64_t)start;
+                    const uint8_t* pb = (const uint8_t*)sym + offb + (uint64_t)(start - d);
+                    for (int x = 0; x < L && mm <= kmax; x += 8) {
+                        uint64_t a, b;
+                        __builtin_memcpy(&a, pa + x, 8);
+                        __builtin_memcpy(&b, pb + x, 8);
+                        mm += mismatches8<WIDE>(a, b, L - x < 8 ? L - x : 8);
+                    }
+                } else {
+                    for (int x = start; x < end && mm <= kmax; x++) {
+                        const uint32_t a = base_at<SB, WIDE>(sym, A.off + (uint64_t)x);
+                        const uint32_t b = base_at<SB, WIDE>(sym, offb + (uint64_t)(x - d));
+                        mm += (a != b) | (a > 3u);
+                    }
                 }
-                if (mm <= kmax) {
-                    rec.idA = ida;
-                    rec.idB = idb;
-                    rec.OHA = d;
-                    rec.OHB = d + lb - la;
-                    rec.OLA = rec.OLB = (uint32_t)L;
-                    rec.K = mm;
-                    rec.inverted = o;
-                }
+                ok = mm <= kmax;
             }
         }
-        out[i] = rec;
+        kout[i] = mm;
+        flag[i] = ok;
+    }
+}
+
+// The records of the verified candidates, in candidate (= key) order: pos[] is the exclusive scan of flag[].
+__global__ __launch_bounds__(256) void finder_emit_kernel(const SeqRef* __restrict__ by_sfo, const uint64_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ kout, const uint32_t* __restrict__ flag,
+                                                          const uint32_t* __restrict__ pos, uint64_t n, hc_sfo_rec* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!flag[i]) continue;
+        const uint64_t key = keys[i];
+        const uint32_t ida = (uint32_t)(key >> 40), idb = (uint32_t)(key >> 16) & 0xFFFFFFu, o = (uint32_t)(key >> 15) & 1u;
+        const int d = (int)(uint32_t)(key & 0x7FFFu) - kDiagBias;
+        const int la = (int)by_sfo[ida].len, lb = (int)by_sfo[idb].len;
+        const int start = d > 0 ? d : 0, end = la < d + lb ? la : d + lb;
+        hc_sfo_rec rec;
+        rec.idA = ida;
+        rec.idB = idb;
+        rec.OHA = d;
+        rec.OHB = d + lb - la;
+        rec.OLA = rec.OLB = (uint32_t)(end - start);
+        rec.K = kout[i];
+        rec.inverted = o;
+        out[pos[i]] = rec;
     }
 }
 
@@ -235,11 +269,20 @@ hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_
 }
 
 hipError_t finder_verify(const void* sym, uint32_t symbytes, bool wide, const SeqRef* by_sfo, const uint64_t* keys, uint64_t n,
-                         double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, hipStream_t stream) {
+                         double err_rate, uint32_t min_overlap, uint32_t flags, uint32_t* kout, uint32_t* flag, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    HC_FINDER_DISPATCH(finder_verify_kernel, (uint32_t)blocks, sym, by_sfo, symbytes, keys, n, err_rate, min_overlap, flags, out);
+    HC_FINDER_DISPATCH(finder_verify_kernel, (uint32_t)blocks, sym, by_sfo, symbytes, keys, n, err_rate, min_overlap, flags, kout, flag);
+    return hipGetLastError();
+}
+
+hipError_t finder_emit(const SeqRef* by_sfo, const uint64_t* keys, const uint32_t* kout, const uint32_t* flag, const uint32_t* pos, uint64_t n,
+                       hc_sfo_rec* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(finder_emit_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, by_sfo, keys, kout, flag, pos, n, out);
     return hipGetLastError();
 }
 
@@ -258,9 +301,8 @@ hipError_t finder_unique(void* temp, size_t& temp_bytes, const uint64_t* in, uin
                          hipStream_t stream) {
     return hipcub::DeviceSelect::Unique(temp, temp_bytes, in, out, n_out, (int64_t)n, stream);
 }
-hipError_t finder_select_valid(void* temp, size_t& temp_bytes, const hc_sfo_rec* in, hc_sfo_rec* out, unsigned long long* n_out, uint64_t n,
-                               hipStream_t stream) {
-    return hipcub::DeviceSelect::If(temp, temp_bytes, in, out, n_out, (int64_t)n, RecValid{}, stream);
+hipError_t finder_scan32(void* temp, size_t& temp_bytes, const uint32_t* in, uint32_t* out, uint64_t n, hipStream_t stream) {
+    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int64_t)n, stream);
 }
 
 }  // namespace hc
