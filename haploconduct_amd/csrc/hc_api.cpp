@@ -734,19 +734,46 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         remember(nullptr, 0);
         return HC_OK;
     }
-    if (H >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 seed hits (repeat-rich input): raise min_overlap or split the read set");
-    // 3. one key per hit, sorted, unique: the candidate diagonals.  The index keys are no longer needed.
-    // (the index keys d_k0 / d_v0 are dead from here on; their slots are simply not used again in this call)
-    DevBuf d_h0, d_h1;
-    HC_ALLOC(d_h0, H * 8);
-    HC_ALLOC(d_h1, H * 8);
-    HC_HIP(hc::finder_expand(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori, d_v1.as<uint64_t>(), d_lo.as<uint64_t>(),
-                             d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), d_h0.as<uint64_t>(), st));
+    // 3./4. in batches of seed sequences, so that the hits in flight stay bounded whatever the coverage of the data:
+    //   one key per hit -> sort -> unique (the candidate diagonals) -> verify (8 bytes out per candidate) -> scan of the
+    //   flags -> emit the records of the verified ones behind those of the batches before.
+    // Keys start with the ids, batches are id ranges of the seed side: the concatenation is still sorted and unique.
+    std::vector<uint64_t> h_off(S + 1);
+    HC_HIP(hipMemcpy(h_off.data(), d_off.p, (S + 1) * 8, hipMemcpyDeviceToHost));
+    uint64_t batch_hits = 1ull << 29;
+    if (const char* e = getenv("HC_FIND_BATCH_HITS")) batch_hits = strtoull(e, nullptr, 10);
+    if (batch_hits < 1024) batch_hits = 1024;
+    struct Batch {
+        uint32_t q0, q1;
+        uint64_t base, hits;
+    };
+    std::vector<Batch> batches;
+    uint64_t Hmax = 0;
+    for (uint32_t q0 = 0; q0 < n_seq;) {
+        const uint64_t base = h_off[seed_start[q0]];
+        uint32_t q1 = q0 + 1;
+        while (q1 < n_seq && h_off[seed_start[q1 + 1]] - base <= batch_hits) q1++;
+        const uint64_t hits = h_off[seed_start[q1]] - base;
+        if (hits >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: one sequence alone has more than 2^31 seed hits");
+        if (hits) {
+            batches.push_back(Batch{q0, q1, base, hits});
+            Hmax = hits > Hmax ? hits : Hmax;
+        }
+        q0 = q1;
+    }
+    DevBuf d_h0, d_h1, d_kout, d_flag, d_pos, d_r1;
+    HC_ALLOC(d_h0, Hmax * 8);
+    HC_ALLOC(d_h1, Hmax * 8);
+    HC_ALLOC(d_kout, Hmax * 4);
+    HC_ALLOC(d_flag, (Hmax + 1) * 4);
+    HC_ALLOC(d_pos, (Hmax + 1) * 4);
     {
-        size_t b = 0, b2 = 0;
-        HC_HIP(hc::finder_sort_keys(nullptr, b, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), H, st));
-        HC_HIP(hc::finder_unique(nullptr, b2, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), H, st));
-        if (b2 > b) b = b2;
+        size_t b = 0, b2 = 0, b3 = 0;
+        HC_HIP(hc::finder_sort_keys(nullptr, b, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), Hmax, st));
+        HC_HIP(hc::finder_unique(nullptr, b2, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), Hmax, st));
+        HC_HIP(hc::finder_scan32(nullptr, b3, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), Hmax + 1, st));
+        b = b2 > b ? b2 : b;
+        b = b3 > b ? b3 : b;
         if (b > tmp_bytes) {
             HC_HIP(hipStreamSynchronize(st));
             (void)hipFree(d_tmp.slot->p);
@@ -757,58 +784,75 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
             d_tmp.p = d_tmp.slot->p;
             tmp_bytes = b;
         }
+    }
+    unsigned long long R = 0;
+    size_t res_cap = 0;  // records; the result buffer grows by doubling (it outlives the call: not a scratch slot)
+    for (const Batch& bt : batches) {
+        const uint64_t Hb = bt.hits;
+        HC_HIP(hc::finder_expand(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), bt.q0, bt.q1, bt.base, k, s, n_ori, d_v1.as<uint64_t>(),
+                                 d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), d_h0.as<uint64_t>(), st));
         size_t bs = tmp_bytes;
-        HC_HIP(hc::finder_sort_keys(d_tmp.p, bs, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), H, st));
+        HC_HIP(hc::finder_sort_keys(d_tmp.p, bs, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), Hb, st));
         bs = tmp_bytes;
-        HC_HIP(hc::finder_unique(d_tmp.p, bs, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), H, st));
-    }
-    unsigned long long M = 0;
-    HC_HIP(hipMemcpyAsync(&M, d_count.p, sizeof M, hipMemcpyDeviceToHost, st));
-    HC_HIP(hipStreamSynchronize(st));
-    lap("expand + sort + unique");
-    if (M == 0) {
-        remember(nullptr, 0);
-        return HC_OK;
-    }
-    // 4. verify every candidate (8 bytes out per candidate), scan the flags, emit the records of the verified ones
-    if (M >= (1ull << 31) - 1) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 candidate diagonals");
-    DevBuf d_kout, d_flag, d_pos, d_r1;
-    HC_ALLOC(d_kout, M * 4);
-    HC_ALLOC(d_flag, (M + 1) * 4);
-    HC_ALLOC(d_pos, (M + 1) * 4);
-    HC_HIP(hipMemsetAsync(d_flag.as<uint32_t>() + M, 0, 4, st));
-    HC_HIP(hc::finder_verify(c->d_sym, c->view.symbytes, wide, d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), M, err_rate, min_overlap, flags,
-                             d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), st));
-    {
-        size_t b = 0;
-        HC_HIP(hc::finder_scan32(nullptr, b, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M + 1, st));
-        if (b > tmp_bytes) {
+        HC_HIP(hc::finder_unique(d_tmp.p, bs, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), Hb, st));
+        unsigned long long M = 0;
+        HC_HIP(hipMemcpyAsync(&M, d_count.p, sizeof M, hipMemcpyDeviceToHost, st));
+        HC_HIP(hipStreamSynchronize(st));
+        if (M == 0) continue;
+        HC_HIP(hipMemsetAsync(d_flag.as<uint32_t>() + M, 0, 4, st));
+        HC_HIP(hc::finder_verify(c->d_sym, c->view.symbytes, wide, d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), M, err_rate, min_overlap, flags,
+                                 d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), st));
+        bs = tmp_bytes;
+        HC_HIP(hc::finder_scan32(d_tmp.p, bs, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M + 1, st));
+        uint32_t Rb = 0;
+        HC_HIP(hipMemcpyAsync(&Rb, d_pos.as<uint32_t>() + M, 4, hipMemcpyDeviceToHost, st));
+        HC_HIP(hipStreamSynchronize(st));
+        if (Rb == 0) continue;
+        if (R + Rb > res_cap) {
+            size_t want = res_cap ? res_cap * 2 : (size_t)Rb;
+            if (want < R + Rb) want = R + Rb;
+            if (batches.size() == 1) want = Rb;
+            void* bigger = nullptr;
+            HC_HIP(hipMalloc(&bigger, want * sizeof(hc_sfo_rec)));
+            if (R) HC_HIP(hipMemcpyAsync(bigger, d_r1.own, R * sizeof(hc_sfo_rec), hipMemcpyDeviceToDevice, st));
             HC_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_tmp.slot->p);
-            d_tmp.slot->p = nullptr;
-            d_tmp.slot->cap = 0;
-            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
-            d_tmp.slot->cap = b;
-            d_tmp.p = d_tmp.slot->p;
-            tmp_bytes = b;
+            if (d_r1.own) (void)hipFree(d_r1.own);
+            d_r1.own = bigger;
+            d_r1.p = bigger;
+            res_cap = want;
         }
-        HC_HIP(hc::finder_scan32(d_tmp.p, b, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M + 1, st));
+        HC_HIP(hc::finder_emit(d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M,
+                               (hc_sfo_rec*)d_r1.p + R, st));
+        R += Rb;
     }
-    uint32_t R32 = 0;
-    HC_HIP(hipMemcpyAsync(&R32, d_pos.as<uint32_t>() + M, 4, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
-    lap("verify + scan");
-    const unsigned long long R = R32;
+    lap("expand/sort/unique/verify/emit");
     if (R == 0) {
         remember(nullptr, 0);
         return HC_OK;
     }
-    HC_HIP(hipMalloc(&d_r1.own, R * sizeof(hc_sfo_rec)));  // outlives the call (kept by the context): not a scratch slot
-    d_r1.p = d_r1.own;
-    HC_HIP(hc::finder_emit(d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M,
-                           (hc_sfo_rec*)d_r1.p, st));
-    HC_HIP(hipStreamSynchronize(st));
-    lap("alloc result + emit");
+    if (batches.size() > 1) {  // every batch is sorted; one more sort (key, position) + gather for the global order
+        if (R >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 overlaps");
+        DevBuf sk0, sk1, si0, si1;
+        void* sorted = nullptr;
+        HC_HIP(hipMalloc(&sk0.own, R * 8));
+        HC_HIP(hipMalloc(&sk1.own, R * 8));
+        HC_HIP(hipMalloc(&si0.own, R * 8));
+        HC_HIP(hipMalloc(&si1.own, R * 8));
+        HC_HIP(hc::finder_rekey((const hc_sfo_rec*)d_r1.p, R, (uint64_t*)sk0.own, (uint64_t*)si0.own, st));
+        size_t b = 0;
+        HC_HIP(hc::finder_sort_pairs(nullptr, b, (uint64_t*)sk0.own, (uint64_t*)sk1.own, (uint64_t*)si0.own, (uint64_t*)si1.own, R, 64, st));
+        DevBuf stmp;
+        HC_HIP(hipMalloc(&stmp.own, b ? b : 16));
+        HC_HIP(hc::finder_sort_pairs(stmp.own, b, (uint64_t*)sk0.own, (uint64_t*)sk1.own, (uint64_t*)si0.own, (uint64_t*)si1.own, R, 64, st));
+        HC_HIP(hipMalloc(&sorted, R * sizeof(hc_sfo_rec)));
+        HC_HIP(hc::finder_gather((const hc_sfo_rec*)d_r1.p, (const uint64_t*)si1.own, R, (hc_sfo_rec*)sorted, st));
+        HC_HIP(hipStreamSynchronize(st));
+        (void)hipFree(d_r1.own);
+        d_r1.own = sorted;
+        d_r1.p = sorted;
+        lap("global order of the batches");
+    }
     *n_out = R;
     const uint64_t take = R < cap ? R : cap;
     if (take) HC_HIP(hipMemcpy(out, d_r1.p, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));

@@ -11,7 +11,8 @@
 //            matches) -> radix sort by k-mer                                             [hipCUB]
 //   seeds    k-mers at positions 0, s, 2s, ... of every sequence B, forward and (with reversals) reverse
 //            complement — the store holds both orientations — binary-searched in the index
-//   expand   every hit (A, q) with id(A) < id(B) gives a diagonal d = q - p: key (A, B, orientation, d)
+//   expand   every hit (A, q) with id(A) < id(B) gives a diagonal d = q - p: key (A, B, orientation, d); done in
+//            batches of seed sequences so that the number of hits in flight stays bounded whatever the coverage
 //   unique   radix sort + unique of the keys (many seeds find the same diagonal)          [hipCUB]
 //   verify   one lane per candidate: overlap region, length >= T, mismatches <= floor(e*L) (N matches nothing);
 //            writes 8 bytes per candidate (mismatch count, flag), not a record
@@ -119,14 +120,15 @@ __device__ __forceinline__ uint64_t pack_key(uint32_t idA, uint32_t idB, uint32_
 }
 
 __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __restrict__ seqs, const uint64_t* __restrict__ seed_start,
-                                                            uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
+                                                            uint32_t q_begin, uint32_t n_seq, uint64_t out_base, uint32_t k, uint32_t s,
+                                                            uint32_t n_ori,
                                                             const uint64_t* __restrict__ vals, const uint64_t* __restrict__ seed_lo,
                                                             const uint64_t* __restrict__ seed_cnt,
                                                             const uint64_t* __restrict__ seed_out, uint64_t* __restrict__ out_keys) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t q = wave; q < n_seq; q += n_waves) {
+    for (uint32_t q = q_begin + wave; q < n_seq; q += n_waves) {  // the seed sequences [q_begin, n_seq) of this batch
         const SeqRef r = seqs[q];
         if (r.len < k) continue;
         const uint32_t nt = (r.len - k) / s + 1;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __rest
             if (cnt == 0) continue;
             const uint32_t o = j / nt, t = j - o * nt;
             const int p = (int)(t * s);
-            const uint64_t lo = seed_lo[sid], at = seed_out[sid];
+            const uint64_t lo = seed_lo[sid], at = seed_out[sid] - out_base;
             for (uint64_t h = lane; h < cnt; h += 64u) {
                 const uint64_t v = vals[lo + h];
                 const uint32_t qa = (uint32_t)(v >> 32);
@@ -232,6 +234,20 @@ __global__ __launch_bounds__(256) void finder_emit_kernel(const SeqRef* __restri
     }
 }
 
+// After a batched run: the records of the batches, each sorted, are brought into one global order.
+__global__ __launch_bounds__(256) void finder_rekey_kernel(const hc_sfo_rec* __restrict__ recs, uint64_t n, uint64_t* __restrict__ keys,
+                                                           uint64_t* __restrict__ idx) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const hc_sfo_rec r = recs[i];
+        keys[i] = pack_key(r.idA, r.idB, r.inverted, r.OHA);
+        idx[i] = i;
+    }
+}
+__global__ __launch_bounds__(256) void finder_gather_kernel(const hc_sfo_rec* __restrict__ recs, const uint64_t* __restrict__ idx, uint64_t n,
+                                                            hc_sfo_rec* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = recs[idx[i]];
+}
+
 // ---- launch wrappers -----------------------------------------------------------------------------------------
 static uint32_t wave_grid(uint32_t n_seq) {
     uint64_t blocks = ((uint64_t)n_seq + 3) / 4;  // 4 waves per 256-thread block
@@ -260,11 +276,11 @@ hipError_t finder_seeds(const void* sym, uint32_t symbytes, bool wide, const Seq
     return hipGetLastError();
 }
 
-hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
-                         const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, const uint64_t* seed_out,
-                         uint64_t* out_keys, hipStream_t stream) {
-    hipLaunchKernelGGL(finder_expand_kernel, dim3(wave_grid(n_seq)), dim3(256), 0, stream, seqs, seed_start, n_seq, k, s, n_ori, vals,
-                       seed_lo, seed_cnt, seed_out, out_keys);
+hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_t q_begin, uint32_t q_end, uint64_t out_base, uint32_t k,
+                         uint32_t s, uint32_t n_ori, const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt,
+                         const uint64_t* seed_out, uint64_t* out_keys, hipStream_t stream) {
+    hipLaunchKernelGGL(finder_expand_kernel, dim3(wave_grid(q_end - q_begin)), dim3(256), 0, stream, seqs, seed_start, q_begin, q_end,
+                       out_base, k, s, n_ori, vals, seed_lo, seed_cnt, seed_out, out_keys);
     return hipGetLastError();
 }
 
@@ -283,6 +299,19 @@ hipError_t finder_emit(const SeqRef* by_sfo, const uint64_t* keys, const uint32_
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(finder_emit_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, by_sfo, keys, kout, flag, pos, n, out);
+    return hipGetLastError();
+}
+
+hipError_t finder_rekey(const hc_sfo_rec* recs, uint64_t n, uint64_t* keys, uint64_t* idx, hipStream_t stream) {
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(finder_rekey_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, recs, n, keys, idx);
+    return hipGetLastError();
+}
+hipError_t finder_gather(const hc_sfo_rec* recs, const uint64_t* idx, uint64_t n, hc_sfo_rec* out, hipStream_t stream) {
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(finder_gather_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, recs, idx, n, out);
     return hipGetLastError();
 }
 

@@ -136,3 +136,15 @@ def test_reads_to_graph_without_external_tools(oracle, tmp_path):
     assert rc == 0 and want.size == edges.size
     assert np.array_equal(edges["score"].view(np.uint64), want["score"].view(np.uint64))
     assert np.array_equal(edges["v1"], want["v1"]) and np.array_equal(edges["v2"], want["v2"])
+
+
+def test_batched_run_gives_the_same_records(monkeypatch):
+    """HC_FIND_BATCH_HITS bounds the seed hits in flight: many small batches must give exactly the records of one."""
+    reads = make_reads(77, n_single=60, n_pair=40, glen=900, lo=60, hi=160, err=0.004, repeat=True)
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        monkeypatch.delenv("HC_FIND_BATCH_HITS", raising=False)
+        one = as_tuples(sc.find_overlaps(0.02, 50))
+        monkeypatch.setenv("HC_FIND_BATCH_HITS", "1024")
+        many = as_tuples(sc.find_overlaps(0.02, 50))
+    assert one == many == O.find_overlaps(reads, 0.02, 50) and len(one) > 500
