@@ -175,10 +175,10 @@ def main():
     alg_bytes = 48 * n + 4 * positions  # 32 B record + 16 B result + 4 B per overlapped position
 
     # N > 1: rank r owns global candidates [r*n, (r+1)*n) (weak scaling) against a replicated read
-    # store; per step, the non-dropped records of every rank are collected on every rank: device compaction, one
-    # pack kernel, then the all-gather-v as two all-gathers (counts, rows padded to a fixed capacity) over RCCL.
-    # Everything is enqueued on one HIP stream, nothing synchronises with the host inside a step, and the
-    # all-gather of step i overlaps the scoring kernel of step i+1 (parallel.StreamedGather).
+    # store; per step, the non-dropped records of every rank are collected on every rank.  The scoring kernel itself
+    # appends them (tagged with their global index) to a payload whose row 0 is the count, so the all-gather-v is ONE
+    # all-gather over RCCL per step, on a side stream, overlapping the scoring kernel of the next step; nothing
+    # synchronises with the host inside a step (parallel.StreamedGather).
     stream = torch.cuda.current_stream().cuda_stream
     gather = None
     if with_gather:
@@ -193,12 +193,16 @@ def main():
     last = None
     gather_mode = "streamed" if gather else None
 
+    n_steps = 0
+
     def step():
-        nonlocal last
+        nonlocal last, n_steps
+        if gather_mode == "streamed":  # the scoring kernel appends the collection payload itself; the all-gather
+            n_steps += 1               # of step i runs on a side stream beside the kernel of step i+1
+            last = gather.score_step(d_in.data_ptr(), d_out)
+            return
         sc.score_batch_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
-        if gather_mode == "streamed":
-            last = gather.step(d_out)
-        elif gather_mode == "plain":  # counts, then padded payload, with host round trips (parallel.gather_admitted)
+        if gather_mode == "plain":  # counts, then padded payload, with host round trips (parallel.gather_admitted)
             torch.cuda.synchronize()
             last = parallel.gather_admitted(d_out, rank * n)
 

@@ -64,6 +64,8 @@ _sig = {
     "hc_synchronize": (C.c_int, [_vp]),
     "hc_compact_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "hc_find_overlaps": (C.c_int, [_vp, C.c_double, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "hc_score_pack_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, _vp, C.POINTER(C.c_int)]),
+    "hc_compact_pack_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp]),
     "hc_pack_rows_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp]),
     "hc_score_batch_compact": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_set_reorder": (C.c_int, [_vp, C.c_int]),

@@ -31,6 +31,10 @@ hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_ou
                           size_t temp_bytes, hipStream_t stream);
 hipError_t launch_pack_rows(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count, uint64_t cap, uint64_t base,
                             hc_gather_row* rows, uint32_t n_cu, hipStream_t stream);
+hipError_t launch_pack_header(const unsigned long long* count, hc_gather_row* header, hipStream_t stream);
+hipError_t launch_score_rows(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in, uint64_t n,
+                             hc_result_rec* out, uint32_t n_cu, int variant, hc_gather_row* payload, uint64_t cap, uint64_t base_index,
+                             hipStream_t stream);
 hipError_t launch_gather_results(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count,
                                  hc_result_rec* out, uint32_t n_cu, hipStream_t stream);
 size_t reorder_temp_bytes(uint32_t n);
@@ -872,6 +876,45 @@ int hc_pack_rows_device(hc_ctx* c, const void* d_results, const void* d_indices,
     HC_HIP(hc::launch_pack_rows((const hc_result_rec*)d_results, (const uint32_t*)d_indices, (const unsigned long long*)d_count, cap,
                                 base_index, (hc_gather_row*)d_rows, c->n_cu, s));
     return HC_OK;
+}
+
+int hc_compact_pack_device(hc_ctx* c, const void* d_results, uint64_t n, void* d_indices, void* d_count, uint64_t cap, uint64_t base_index,
+                           void* d_payload, void* hip_stream) {
+    if (!c || !d_payload) return fail(HC_ERR_ARG, "hc_compact_pack_device: null argument");
+    int rc = hc_compact_device(c, d_results, n, d_indices, d_count, hip_stream);
+    if (rc) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    HC_HIP(hc::launch_pack_header((const unsigned long long*)d_count, (hc_gather_row*)d_payload, s));
+    if (n == 0 || cap == 0) return HC_OK;
+    return hc_pack_rows_device(c, d_results, d_indices, d_count, cap, base_index, (hc_gather_row*)d_payload + 1, hip_stream);
+}
+
+int hc_score_pack_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index, void* d_payload,
+                         void* hip_stream, int* fused) {
+    if (!c || !d_payload) return fail(HC_ERR_ARG, "hc_score_pack_device: null argument");
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_score_pack_device: hc_set_reads has not been called");
+    if (n && (!d_in || !d_out)) return fail(HC_ERR_ARG, "hc_score_pack_device: null buffer");
+    if (n >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_score_pack_device: n must be < 2^31");
+    HC_HIP(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (fused) *fused = 0;
+    if (c->reorder_mode != HC_REORDER_ALWAYS) {
+        HC_HIP(hipMemsetAsync(d_payload, 0, sizeof(hc_gather_row), s));  // row 0: the count
+        const hipError_t e = hc::launch_score_rows(c->view, c->params, c->d_lut, (const hc_overlap_rec*)d_in, n, (hc_result_rec*)d_out, c->n_cu,
+                                                   c->variant, (hc_gather_row*)d_payload, cap, base_index, s);
+        if (e == hipSuccess) {
+            if (fused) *fused = 1;
+            return HC_OK;
+        }
+        if (e != hipErrorNotSupported) return fail(HC_ERR_HIP, std::string("score_kernel_rows: ") + hipGetErrorString(e));
+    }
+    // no fused instantiation for this read set: score, then compact + pack
+    int rc = hc_score_batch_device(c, d_in, n, d_out, hip_stream);
+    if (rc) return rc;
+    rc = ensure_compact_workspace(c, n ? n : 1, true);
+    if (rc) return rc;
+    if (!c->d_totals) HC_HIP(hipMalloc((void**)&c->d_totals, 2 * sizeof(unsigned long long)));
+    return hc_compact_pack_device(c, d_out, n, c->d_compact_idx, c->d_totals, cap, base_index, d_payload, hip_stream);
 }
 
 int hc_score_batch_compact(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, uint32_t* idx_out, hc_result_rec* res_out,

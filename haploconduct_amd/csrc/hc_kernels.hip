@@ -553,8 +553,8 @@ __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return 
 
 // The tail of compute_overlap + the 3-way class of process_overlaps for one candidate whose sub-overlap
 // results are known: mismatch_rate = max of the two (:254), class in x-space (:404-413), result record.
-__device__ __forceinline__ void classify_and_store(const ScoreParams& prm, int ns, const SubScore& s1, const SubScore& s2,
-                                                   uint64_t i, hc_result_rec* __restrict__ out) {
+__device__ __forceinline__ hc_result_rec classify_and_store(const ScoreParams& prm, int ns, const SubScore& s1, const SubScore& s2,
+                                                            uint64_t i, hc_result_rec* __restrict__ out) {
     hc_result_rec res;
     // mismatch_rate = float(mismatch_count)/total_len (:132); std::max over the two (:254)
     const double m1 = (double)(float)s1.mm / (double)s1.n;
@@ -590,14 +590,15 @@ __device__ __forceinline__ void classify_and_store(const ScoreParams& prm, int n
     res.mm = mm;
     res.n_cls = (nn & 0x0FFFFFFFu) | (cls << 28);
     out[i] = res;
+    return res;
 }
 
 // One candidate, one lane: score its sub-overlaps and write the result record.
 template <typename SymT, int VAR, int LG>
-__device__ __forceinline__ void score_candidate(const ScoreParams& prm, const SymT* __restrict__ sym, const char* lut,
-                                                const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word, int ns,
-                                                const Sub& sub0, const Sub& sub1, uint64_t i,
-                                                hc_result_rec* __restrict__ out) {
+__device__ __forceinline__ hc_result_rec score_candidate(const ScoreParams& prm, const SymT* __restrict__ sym, const char* lut,
+                                                         const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word, int ns,
+                                                         const Sub& sub0, const Sub& sub1, uint64_t i,
+                                                         hc_result_rec* __restrict__ out) {
     if (ns == 0) {
         hc_result_rec res;
         res.x1 = -__builtin_inf();
@@ -605,7 +606,7 @@ __device__ __forceinline__ void score_candidate(const ScoreParams& prm, const Sy
         res.mm = 1;
         res.n_cls = 1u | (HC_CLS_ERROR << 28);
         out[i] = res;
-        return;
+        return res;
     }
     SubScore s1, s2;
     s2.x = __builtin_nan("");
@@ -632,16 +633,63 @@ __device__ __forceinline__ void score_candidate(const ScoreParams& prm, const Sy
         score_subs<SymT, 1, kPre, LG>(sym, &sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, &s1);
     }
 
-    classify_and_store(prm, ns, s1, s2, i, out);
+    return classify_and_store(prm, ns, s1, s2, i, out);
+}
+
+// What the multi-GPU collection needs of a batch, produced by the scoring kernel itself (score_kernel_rows): every
+// record that is not dropped is appended, tagged with its global candidate index, to a payload whose row 0 counts
+// them.  One atomic per wave and iteration; the rows arrive in no particular order (they carry their index).
+struct RowSink {
+    hc_gather_row* payload;  // cap + 1 rows; payload[0].index = number of appended rows (may exceed cap: overflow)
+    uint64_t cap;
+    uint64_t base_index;
+};
+
+// Called by ALL lanes of the workgroup (uniform control flow; `valid` = this lane scored candidate i).  One atomic per
+// workgroup and iteration: same-address atomics serialise in L2, and one per wave cost 0.1 ms per 2 M candidates.
+__device__ __forceinline__ void append_rows_block(const RowSink& sink, bool valid, const hc_result_rec& res, uint64_t i, uint32_t* lds4) {
+    const bool keep = valid && (res.n_cls >> 28) != HC_CLS_DROP;
+    const uint64_t m = __ballot(keep);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    if (lane == 0) lds4[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < n_waves; w++) {
+            const uint32_t c = lds4[w];
+            lds4[w] = total;  // exclusive offsets of the waves
+            total += c;
+        }
+        unsigned long long base = 0;
+        if (total) base = atomicAdd((unsigned long long*)&sink.payload[0].index, (unsigned long long)total);
+        lds4[16] = (uint32_t)base;
+        lds4[17] = (uint32_t)(base >> 32);
+    }
+    __syncthreads();
+    if (keep) {
+        const uint64_t base = ((uint64_t)lds4[17] << 32) | lds4[16];
+        const uint64_t pos = base + lds4[wave] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < sink.cap) {
+            hc_gather_row r;
+            r.index = sink.base_index + i;
+            r.x1 = res.x1;
+            r.x2 = res.x2;
+            r.mm = res.mm;
+            r.n_cls = res.n_cls;
+            sink.payload[1 + pos] = r;
+        }
+    }
+    __syncthreads();  // lds4 is reused by the next iteration
 }
 
 // VAR bit0: interleave the two sub-overlaps of a candidate; bit1: software prefetch of the next
 // chunk; bit2: 64/32/128/48-symbol fetch groups (score_sub_wide).  LG: log2 of the 8-bit-symbol table
 // dimension (3..6; ignored for 16-bit symbols).  BAL: block-local length balancing (below).
-template <typename SymT, int VAR, int LG, bool BAL>
+template <typename SymT, int VAR, int LG, bool BAL, bool ROWS = false>
 __device__ __forceinline__ void score_kernel_body(const StoreView& st, const ScoreParams& prm, const double* __restrict__ lut_g,
                                                   const hc_overlap_rec* __restrict__ in, uint64_t n,
-                                                  hc_result_rec* __restrict__ out, const uint32_t* __restrict__ perm) {
+                                                  hc_result_rec* __restrict__ out, const uint32_t* __restrict__ perm,
+                                                  const RowSink* sink = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lut_s[];
     const uint32_t lut_n = st.lut_bytes >> 3;
     for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
@@ -656,6 +704,27 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
     const uint32_t nsym_word = sizeof(SymT) == 1 ? nsym * 0x01010101u : nsym * 0x00010001u;
     // with a permutation, slot s scores candidate perm[s] (neighbouring lanes share reads) and writes its
     // record back to the candidate's own position: out[i] <-> in[i] always holds
+    if (ROWS) {  // workgroup-uniform loop: every lane reaches the row append (it synchronises the workgroup)
+        uint32_t* lds4 = masktab + 17 * Tr<SymT>::kWords;  // 18 words of the 392 behind the mask table
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t block_base = (uint64_t)blockIdx.x * blockDim.x; block_base < n; block_base += stride) {
+            const uint64_t i = block_base + threadIdx.x;
+            hc_result_rec res;
+            res.n_cls = 0;
+            if (i < n) {
+                hc_overlap_rec rec;
+                const uint4* p = (const uint4*)(in + i);
+                const uint4 a = p[0], b = p[1];
+                __builtin_memcpy(&rec, &a, 16);
+                __builtin_memcpy((char*)&rec + 16, &b, 16);
+                Sub sub0, sub1;
+                const int ns = resolve<(int)sizeof(SymT)>(st, rec, sub0, sub1);
+                res = score_candidate<SymT, VAR, LG>(prm, sym, lut, masktab, Kp, nsym_word, ns, sub0, sub1, i, out);
+            }
+            append_rows_block(*sink, i < n, res, i, lds4);
+        }
+        return;
+    }
     if (!BAL) {
         const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
         for (uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += stride) {
@@ -765,6 +834,15 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
                                                     hc_result_rec* __restrict__ out,
                                                     const uint32_t* __restrict__ perm) {
     score_kernel_body<SymT, VAR, LG, BAL>(st, prm, lut_g, in, n, out, perm);
+}
+
+// The scoring kernel that also feeds the multi-GPU collection (RowSink above); read sets without length balancing.
+template <typename SymT, int VAR, int LG>
+__global__ __launch_bounds__(256) void score_kernel_rows(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+                                                         const hc_overlap_rec* __restrict__ in, uint64_t n,
+                                                         hc_result_rec* __restrict__ out, const uint32_t* __restrict__ perm,
+                                                         RowSink sink) {
+    score_kernel_body<SymT, VAR, LG, false, true>(st, prm, lut_g, in, n, out, perm, &sink);
 }
 
 // The same kernel for workgroups of up to 1 024 lanes.  A large quality alphabet means a large log table in LDS
@@ -1130,6 +1208,21 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const hc_result_rec* __r
     }
 }
 
+__global__ void pack_header_kernel(const unsigned long long* __restrict__ count, hc_gather_row* __restrict__ header) {
+    hc_gather_row h;
+    h.index = *count;
+    h.x1 = 0;
+    h.x2 = 0;
+    h.mm = 0;
+    h.n_cls = 0;
+    *header = h;
+}
+
+hipError_t launch_pack_header(const unsigned long long* count, hc_gather_row* header, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_header_kernel, dim3(1), dim3(1), 0, stream, count, header);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_rows(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count, uint64_t cap, uint64_t base,
                             hc_gather_row* rows, uint32_t n_cu, hipStream_t stream) {
     hipLaunchKernelGGL(pack_rows_kernel, dim3(n_cu * 4), dim3(256), 0, stream, res, idx, count, (unsigned long long)cap,
@@ -1267,6 +1360,42 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     return launch_score_lg<uint8_t, 6>(variant, st, prm, lut_g, in, n, out, perm, nb, lds, stream);
 }
 
+// Scoring + row append in one kernel.  Returns hipErrorNotSupported when the read set needs an instantiation that has
+// no row-appending twin (length balancing, 16-bit symbols, experimental variants): the caller then compacts separately.
+hipError_t launch_score_rows(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in, uint64_t n,
+                             hc_result_rec* out, uint32_t n_cu, int variant, hc_gather_row* payload, uint64_t cap, uint64_t base_index,
+                             hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const int v = variant & 7;
+    if (st.balance || st.symbytes != 1 || (variant & 8) || (v != 4 && v != 5)) return hipErrorNotSupported;
+    const size_t lds = st.lut_bytes + (17 * 4 + 392) * sizeof(uint32_t);
+    uint32_t blocks_per_cu = 8;
+    const uint32_t by_lds = (uint32_t)((160 * 1024) / lds);
+    if (by_lds < blocks_per_cu) blocks_per_cu = by_lds < 1 ? 1 : by_lds;
+    uint64_t blocks = (n + 255) / 256;
+    const uint64_t cap_blocks = (uint64_t)n_cu * blocks_per_cu * 4;
+    if (blocks > cap_blocks) blocks = cap_blocks;
+    const uint32_t nb = (uint32_t)blocks;
+    const RowSink sink{payload, cap, base_index};
+    const uint32_t lg = lut_lg(st.K);
+#define HC_ROWS(VARV, LGV) \
+    hipLaunchKernelGGL((score_kernel_rows<uint8_t, VARV, LGV>), dim3(nb), dim3(256), lds, stream, st, prm, lut_g, in, n, out, \
+                       (const uint32_t*)nullptr, sink)
+    if (v == 4) {
+        if (lg == 3) HC_ROWS(4, 3);
+        else if (lg == 4) HC_ROWS(4, 4);
+        else if (lg == 5) HC_ROWS(4, 5);
+        else HC_ROWS(4, 6);
+    } else {
+        if (lg == 3) HC_ROWS(5, 3);
+        else if (lg == 4) HC_ROWS(5, 4);
+        else if (lg == 5) HC_ROWS(5, 5);
+        else HC_ROWS(5, 6);
+    }
+#undef HC_ROWS
+    return hipGetLastError();
+}
+
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,
                                   unsigned long long* totals, hipStream_t stream) {
     if (n == 0) return hipSuccess;
@@ -1297,6 +1426,10 @@ static hipError_t set_lds_limit_lg() {
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 6, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 7, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 7, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if constexpr (sizeof(SymT) == 1) {
+        if ((e = hipFuncSetAttribute((const void*)score_kernel_rows<SymT, 4, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)score_kernel_rows<SymT, 5, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    }
     if constexpr (LG >= 5) {
         if ((e = hipFuncSetAttribute((const void*)score_kernel_wide_wg<SymT, 4, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
         if ((e = hipFuncSetAttribute((const void*)score_kernel_wide_wg<SymT, 5, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;

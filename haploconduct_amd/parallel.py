@@ -57,54 +57,95 @@ def gather_admitted(results_np_or_tensor, global_offset, group=None, device=None
 class StreamedGather:
     """The same collection without a host round trip per batch — what `bench.py --gpus N` runs.
 
-    Per batch, on torch's current HIP stream: device stream compaction of the non-dropped records
-    (`hc_compact_device`), one kernel that tags them with their global candidate index (`hc_pack_rows_device`,
-    32-byte rows), then two asynchronous all-gathers over RCCL: the counts and the rows padded to a fixed
-    capacity.  Nothing synchronises with the host; the buffers are double-buffered, so the all-gather of batch i
-    overlaps the scoring kernel of batch i+1.  `collect()` is the host side: waits, checks the capacity, trims.
+    Per batch: device stream compaction of the non-dropped records (`hc_compact_device`), one kernel that tags
+    them with their global candidate index (`hc_pack_rows_device`, 32-byte rows), then two asynchronous all-gathers
+    over RCCL: the counts and the rows padded to a fixed capacity.  All of it runs on a SIDE stream that only waits
+    for the scoring kernel of its own batch, so with two result buffers the scoring kernel of batch i+1 starts
+    right behind that of batch i and the collection of batch i overlaps it.  Nothing synchronises with the host;
+    `collect()` is the host side: waits, checks the capacity, trims.
+
+    Protocol per batch:  before_write(results) -> launch the scoring kernel into `results` on the current stream
+    -> step(results).  Use at least two `results` tensors in turn; with one, before_write serialises.
     """
 
     def __init__(self, scorer, n_local, base_index, cap_rows, group=None, depth=2):
         self.sc, self.n, self.base, self.cap, self.group, self.depth = scorer, int(n_local), int(base_index), int(cap_rows), group, depth
         self.world = dist.get_world_size(group)
         dev = torch.device("cuda", torch.cuda.current_device())
+        self.side = torch.cuda.Stream(device=dev)
         # zero-initialised: entries beyond the count of a batch are stale but always valid indices
         self.idx = torch.zeros(max(self.n, 1), dtype=torch.int32, device=dev)
+        rows = self.cap + 1  # row 0 carries the count: one all-gather per batch is the whole all-gather-v
         self.bufs = [{"count": torch.zeros(1, dtype=torch.int64, device=dev),
-                      "rows": torch.zeros((self.cap, 4), dtype=torch.int64, device=dev),
-                      "counts_all": torch.zeros(self.world, dtype=torch.int64, device=dev),
-                      "rows_all": torch.zeros((self.world * self.cap, 4), dtype=torch.int64, device=dev),
-                      "work": ()} for _ in range(depth)]
+                      "payload": torch.zeros((rows, 4), dtype=torch.int64, device=dev),
+                      "all": torch.zeros((self.world * rows, 4), dtype=torch.int64, device=dev),
+                      "scored": torch.cuda.Event(), "packed": torch.cuda.Event(), "work": None, "unordered": False}
+                     for _ in range(depth)]
         self.i = 0
+        self.packed = {}  # data_ptr of a results tensor -> event: its rows have been packed, it may be overwritten
+
+    def before_write(self, d_results):
+        """The current stream waits until the batch that last used `d_results` has been read out of it."""
+        ev = self.packed.get(d_results.data_ptr())
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def step(self, d_results):
-        """d_results: uint8/int64 CUDA tensor holding this rank's n hc_result_rec.  Enqueues; returns the buffer set."""
+        """d_results: uint8/int64 CUDA tensor holding this rank's n hc_result_rec, written by work already enqueued
+        on the current stream.  Enqueues the collection on the side stream; returns the buffer set."""
         b = self.bufs[self.i % self.depth]
         self.i += 1
-        for w in b["work"]:
-            w.wait()  # the batch that used these buffers `depth` batches ago has been gathered
-        stream = torch.cuda.current_stream().cuda_stream
-        self.sc.compact_device(d_results.data_ptr(), self.n, self.idx.data_ptr(), b["count"].data_ptr(), stream)
-        self.sc.pack_rows_device(d_results.data_ptr(), self.idx.data_ptr(), b["count"].data_ptr(), self.cap, self.base,
-                                 b["rows"].data_ptr(), stream)
-        b["work"] = (dist.all_gather_into_tensor(b["counts_all"], b["count"], group=self.group, async_op=True),
-                     dist.all_gather_into_tensor(b["rows_all"], b["rows"], group=self.group, async_op=True))
+        b["unordered"] = False
+        b["scored"].record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(b["scored"])
+            if b["work"] is not None:
+                b["work"].wait()  # the batch that used these buffers `depth` batches ago has been gathered
+            # (self.idx is shared: compaction and pack of consecutive batches are ordered on the side stream)
+            self.sc.compact_pack_device(d_results.data_ptr(), self.n, self.idx.data_ptr(), b["count"].data_ptr(), self.cap, self.base,
+                                        b["payload"].data_ptr(), self.side.cuda_stream)
+            b["packed"].record(self.side)
+            self.packed[d_results.data_ptr()] = b["packed"]
+            b["work"] = dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
+        return b
+
+    def score_step(self, d_in_ptr, d_results):
+        """Scoring and collection of one batch with the payload written by the scoring kernel itself
+        (`hc_score_pack_device`): no compaction pass.  d_in_ptr: device pointer of this rank's n candidate records;
+        d_results: CUDA tensor receiving the n result records.  The all-gather runs on the side stream."""
+        b = self.bufs[self.i % self.depth]
+        self.i += 1
+        main = torch.cuda.current_stream()
+        if b["work"] is not None:
+            b["work"].wait()  # the payload buffer of `depth` batches ago has been gathered
+        b["unordered"] = self.sc.score_pack_device(d_in_ptr, self.n, d_results.data_ptr(), self.cap, self.base, b["payload"].data_ptr(),
+                                                   main.cuda_stream)
+        b["scored"].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(b["scored"])
+            b["work"] = dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
         return b
 
     def collect(self, b):
         """Host side of one batch: (rows [sum k_r, 4] int64 ordered by global index, counts per rank)."""
-        for w in b["work"]:
-            w.wait()
-        torch.cuda.current_stream().synchronize()
-        counts = [int(c) for c in b["counts_all"].tolist()]
+        with torch.cuda.stream(self.side):
+            if b["work"] is not None:
+                b["work"].wait()
+        self.side.synchronize()
+        rows = self.cap + 1
+        counts = [int(b["all"][r * rows, 0]) for r in range(self.world)]
         if max(counts) > self.cap:
             raise OverflowError(f"a rank produced {max(counts)} records, capacity is {self.cap}: rerun the batch with a larger cap_rows")
-        rows = torch.cat([b["rows_all"][r * self.cap: r * self.cap + counts[r]] for r in range(self.world)], dim=0)
-        return rows, counts
+        out = torch.cat([b["all"][r * rows + 1: r * rows + 1 + counts[r]] for r in range(self.world)], dim=0)
+        if b.get("unordered"):  # rows appended by the scoring kernel arrive in any order; they carry their index
+            out = out[torch.argsort(out[:, 0])]
+        return out, counts
 
     def finish(self):
-        for b in self.bufs:
-            for w in b["work"]:
-                w.wait()
-            b["work"] = ()
+        with torch.cuda.stream(self.side):
+            for b in self.bufs:
+                if b["work"] is not None:
+                    b["work"].wait()
+                b["work"] = None
+        self.side.synchronize()
         torch.cuda.current_stream().synchronize()

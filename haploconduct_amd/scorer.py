@@ -98,6 +98,18 @@ class EdgeScorer:
             N.check(N.lib.hc_find_overlaps(self._ctx, err_rate, min_overlap, flags, out.ctypes.data, out.size, C.byref(n)), "hc_find_overlaps")
         return out[: n.value]
 
+    def score_pack_device(self, d_in_ptr, n, d_out_ptr, cap, base_index, d_payload_ptr, stream=None):
+        """hc_score_pack_device: scoring + the collection payload in one kernel.  Returns True when fused (rows unordered)."""
+        fused = C.c_int()
+        N.check(N.lib.hc_score_pack_device(self._ctx, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), cap, base_index,
+                                           C.c_void_p(d_payload_ptr), C.c_void_p(stream or 0), C.byref(fused)), "hc_score_pack_device")
+        return bool(fused.value)
+
+    def compact_pack_device(self, d_results_ptr, n, d_indices_ptr, d_count_ptr, cap, base_index, d_payload_ptr, stream=None):
+        """hc_compact_pack_device: compaction + pack, the count in row 0 of the (cap + 1)-row payload."""
+        N.check(N.lib.hc_compact_pack_device(self._ctx, C.c_void_p(d_results_ptr), n, C.c_void_p(d_indices_ptr), C.c_void_p(d_count_ptr),
+                                             cap, base_index, C.c_void_p(d_payload_ptr), C.c_void_p(stream or 0)), "hc_compact_pack_device")
+
     def pack_rows_device(self, d_results_ptr, d_indices_ptr, d_count_ptr, cap, base_index, d_rows_ptr, stream=None):
         """hc_pack_rows_device: compacted records -> 32-byte rows tagged with their global candidate index."""
         N.check(N.lib.hc_pack_rows_device(self._ctx, C.c_void_p(d_results_ptr), C.c_void_p(d_indices_ptr), C.c_void_p(d_count_ptr),

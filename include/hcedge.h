@@ -219,6 +219,21 @@ typedef struct hc_sfo_rec {
 int hc_find_overlaps(hc_ctx* ctx, double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, uint64_t cap,
                      uint64_t* n_out);
 
+/* hc_compact_device + hc_pack_rows_device in one call, with the count travelling inside the payload: d_payload is
+ * (cap + 1) rows; row 0 = { index = *d_count, x1 = x2 = 0, mm = 0, n_cls = 0 }, rows 1.. as hc_pack_rows_device writes
+ * them.  One all-gather of this buffer is the whole all-gather-v.  d_indices: room for n uint32; d_count: one uint64. */
+int hc_compact_pack_device(hc_ctx* ctx, const void* d_results, uint64_t n, void* d_indices, void* d_count, uint64_t cap,
+                           uint64_t base_index, void* d_payload, void* hip_stream);
+
+/* Scoring and collection payload in ONE kernel: like hc_score_batch_device, and every record that is not dropped is also
+ * appended (tagged with base_index + its position) to d_payload in the layout of hc_compact_pack_device — row 0 counts
+ * them — by the scoring kernel itself: no compaction pass over the results.  The rows arrive in no particular order
+ * (sort by index if sequence order matters); a count above cap means rows were dropped: rerun with a larger cap.
+ * *fused = 1 when the kernel did it, 0 when the read set needs an instantiation without a row-appending twin
+ * (length balancing, 16-bit symbols) and the call fell back to scoring + hc_compact_pack_device (ordered rows). */
+int hc_score_pack_device(hc_ctx* ctx, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index, void* d_payload,
+                         void* hip_stream, int* fused);
+
 /* hc_score_batch + compaction in one call for host callers: scores `in` on the device and copies back
  * only the non-DROP records: idx_out[k] (ascending) and res_out[k] = result of in[idx_out[k]].
  * cap = capacity of idx_out / res_out in records; *n_out = number of non-DROP records (if it exceeds

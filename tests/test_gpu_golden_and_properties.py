@@ -163,6 +163,18 @@ def test_rccl_gather_path_single_rank():
             assert np.array_equal(srows[:, 1].view(np.uint64), host["x1"][kept].view(np.uint64))
             assert np.array_equal(srows[:, 2].view(np.uint64), host["x2"][kept].view(np.uint64))
             assert np.array_equal(srows[:, 3].view(np.uint64), host["mm"][kept].astype(np.uint64) | (host["n_cls"][kept].astype(np.uint64) << 32))
+            # the fused form: the scoring kernel appends the payload itself (rows unordered until collect() sorts them)
+            g2 = parallel.StreamedGather(sc, cand.size, base_index=7, cap_rows=kept.size + 3)
+            for _ in range(4):
+                last = g2.score_step(d_in.data_ptr(), d_out)
+            assert last["unordered"]
+            frows, fcounts = g2.collect(last)
+            g2.finish()
+            frows = frows.cpu().numpy()
+            assert fcounts == [kept.size] and np.array_equal(frows[:, 0], kept + 7)
+            assert np.array_equal(frows[:, 1].view(np.uint64), host["x1"][kept].view(np.uint64))
+            assert np.array_equal(frows[:, 3].view(np.uint64), host["mm"][kept].astype(np.uint64) | (host["n_cls"][kept].astype(np.uint64) << 32))
+            assert np.array_equal(d_out.cpu().numpy().view(hc.RESULT_DTYPE).tobytes(), host.tobytes())  # the results themselves are unchanged
             small = parallel.StreamedGather(sc, cand.size, base_index=0, cap_rows=max(1, kept.size // 2))
             with pytest.raises(OverflowError):
                 small.collect(small.step(d_out))
