@@ -715,9 +715,15 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     HC_HIP(hipMemsetAsync(d_cnt.p, 0, (S + 1) * 8, st));
     HC_HIP(hc::finder_seeds(c->d_sym, c->view.symbytes, wide, d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori,
                             d_k1.as<uint64_t>(), P, d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), st));
+    // only hits whose indexed sequence has the lower id become candidates: count those, and lay the keys out by them
+    DevBuf d_val;
+    HC_ALLOC(d_val, (S + 1) * 8);
+    HC_HIP(hipMemsetAsync(d_val.p, 0, (S + 1) * 8, st));
+    HC_HIP(hc::finder_count_valid(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori, d_v1.as<uint64_t>(),
+                                  d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_val.as<uint64_t>(), st));
     {
         size_t b = 0;
-        HC_HIP(hc::finder_scan(nullptr, b, d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
+        HC_HIP(hc::finder_scan(nullptr, b, d_val.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
         if (b > tmp_bytes) {
             HC_HIP(hipStreamSynchronize(st));
             (void)hipFree(d_tmp.slot->p);
@@ -728,9 +734,9 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
             d_tmp.p = d_tmp.slot->p;
             tmp_bytes = b;
         }
-        HC_HIP(hc::finder_scan(d_tmp.p, b, d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
+        HC_HIP(hc::finder_scan(d_tmp.p, b, d_val.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
     }
-    uint64_t H = 0;  // number of hits = last element of the exclusive scan over S + 1 counts (the extra one is 0)
+    uint64_t H = 0;  // number of candidate hits = last element of the exclusive scan over S + 1 counts (the extra one is 0)
     HC_HIP(hipMemcpyAsync(&H, d_off.as<uint64_t>() + S, 8, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
     lap("seeds + scan");
@@ -742,8 +748,14 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     //   one key per hit -> sort -> unique (the candidate diagonals) -> verify (8 bytes out per candidate) -> scan of the
     //   flags -> emit the records of the verified ones behind those of the batches before.
     // Keys start with the ids, batches are id ranges of the seed side: the concatenation is still sorted and unique.
-    std::vector<uint64_t> h_off(S + 1);
-    HC_HIP(hipMemcpy(h_off.data(), d_off.p, (S + 1) * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> h_bound(n_seq + 1);  // candidate hits before sequence q = off[seed_start[q]]
+    {
+        DevBuf d_bound;
+        HC_ALLOC(d_bound, (n_seq + 1) * 8);
+        HC_HIP(hc::finder_boundaries(d_off.as<uint64_t>(), d_seed_start.as<uint64_t>(), n_seq + 1, d_bound.as<uint64_t>(), st));
+        HC_HIP(hipMemcpyAsync(h_bound.data(), d_bound.p, (n_seq + 1) * 8, hipMemcpyDeviceToHost, st));
+        HC_HIP(hipStreamSynchronize(st));
+    }
     uint64_t batch_hits = 1ull << 29;
     if (const char* e = getenv("HC_FIND_BATCH_HITS")) batch_hits = strtoull(e, nullptr, 10);
     if (batch_hits < 1024) batch_hits = 1024;
@@ -754,10 +766,10 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     std::vector<Batch> batches;
     uint64_t Hmax = 0;
     for (uint32_t q0 = 0; q0 < n_seq;) {
-        const uint64_t base = h_off[seed_start[q0]];
+        const uint64_t base = h_bound[q0];
         uint32_t q1 = q0 + 1;
-        while (q1 < n_seq && h_off[seed_start[q1 + 1]] - base <= batch_hits) q1++;
-        const uint64_t hits = h_off[seed_start[q1]] - base;
+        while (q1 < n_seq && h_bound[q1 + 1] - base <= batch_hits) q1++;
+        const uint64_t hits = h_bound[q1] - base;
         if (hits >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: one sequence alone has more than 2^31 seed hits");
         if (hits) {
             batches.push_back(Batch{q0, q1, base, hits});

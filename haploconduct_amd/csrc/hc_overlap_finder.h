@@ -21,6 +21,8 @@ hipError_t finder_index(const void* sym, uint32_t symbytes, bool wide, const Seq
 hipError_t finder_seeds(const void* sym, uint32_t symbytes, bool wide, const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq,
                         uint32_t k, uint32_t s, uint32_t n_ori, const uint64_t* keys, uint64_t n_keys, uint64_t* seed_lo,
                         uint64_t* seed_cnt, hipStream_t stream);
+hipError_t finder_count_valid(const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
+                              const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, uint64_t* seed_valid, hipStream_t stream);
 hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_t q_begin, uint32_t q_end, uint64_t out_base, uint32_t k,
                          uint32_t s, uint32_t n_ori, const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt,
                          const uint64_t* seed_out, uint64_t* out_keys, hipStream_t stream);
@@ -28,6 +30,7 @@ hipError_t finder_verify(const void* sym, uint32_t symbytes, bool wide, const Se
                          double err_rate, uint32_t min_overlap, uint32_t flags, uint32_t* kout, uint32_t* flag, hipStream_t stream);
 hipError_t finder_emit(const SeqRef* by_sfo, const uint64_t* keys, const uint32_t* kout, const uint32_t* flag, const uint32_t* pos, uint64_t n,
                        hc_sfo_rec* out, hipStream_t stream);
+hipError_t finder_boundaries(const uint64_t* off, const uint64_t* seed_start, uint32_t n, uint64_t* out, hipStream_t stream);
 hipError_t finder_rekey(const hc_sfo_rec* recs, uint64_t n, uint64_t* keys, uint64_t* idx, hipStream_t stream);
 hipError_t finder_gather(const hc_sfo_rec* recs, const uint64_t* idx, uint64_t n, hc_sfo_rec* out, hipStream_t stream);
 hipError_t finder_sort_pairs(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint64_t* v_in, uint64_t* v_out,

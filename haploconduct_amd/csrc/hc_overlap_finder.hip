@@ -119,6 +119,43 @@ __device__ __forceinline__ uint64_t pack_key(uint32_t idA, uint32_t idB, uint32_
     return ((uint64_t)idA << 40) | ((uint64_t)idB << 16) | ((uint64_t)o << 15) | (uint64_t)(uint32_t)(d + kDiagBias);
 }
 
+constexpr uint64_t kFewHits = 24;  // up to this many hits a seed is handled by one lane, above by a whole wave
+
+// Number of hits of every seed that will become a candidate: the indexed sequence has the lower id (every unordered pair
+// once).  Replaces the raw hit counts before the scan, so that only those keys are written and sorted.
+__global__ __launch_bounds__(256) void finder_count_valid_kernel(const SeqRef* __restrict__ seqs, const uint64_t* __restrict__ seed_start,
+                                                                 uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
+                                                                 const uint64_t* __restrict__ vals, const uint64_t* __restrict__ seed_lo,
+                                                                 const uint64_t* __restrict__ seed_cnt, uint64_t* __restrict__ seed_valid) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t q = wave; q < n_seq; q += n_waves) {
+        const SeqRef r = seqs[q];
+        if (r.len < k) continue;
+        const uint32_t nt = (r.len - k) / s + 1;
+        // seeds with few hits: one lane each; repeat-rich seeds: the whole wave per seed
+        for (uint32_t j = lane; j < nt * n_ori; j += 64u) {
+            const uint64_t sid = seed_start[q] + j;
+            const uint64_t cnt = seed_cnt[sid], lo = seed_lo[sid];
+            if (cnt > kFewHits) continue;
+            uint32_t mine = 0;
+            for (uint64_t h = 0; h < cnt; h++) mine += seqs[(uint32_t)(vals[lo + h] >> 32)].sfo_id < r.sfo_id;
+            seed_valid[sid] = mine;
+        }
+        for (uint32_t j = 0; j < nt * n_ori; j++) {
+            const uint64_t sid = seed_start[q] + j;
+            const uint64_t cnt = seed_cnt[sid], lo = seed_lo[sid];
+            if (cnt <= kFewHits) continue;
+            uint32_t mine = 0;
+            for (uint64_t h = lane; h < cnt; h += 64u) mine += seqs[(uint32_t)(vals[lo + h] >> 32)].sfo_id < r.sfo_id;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor((int)mine, o, 64);
+            if (lane == 0) seed_valid[sid] = mine;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __restrict__ seqs, const uint64_t* __restrict__ seed_start,
                                                             uint32_t q_begin, uint32_t n_seq, uint64_t out_base, uint32_t k, uint32_t s,
                                                             uint32_t n_ori,
@@ -132,21 +169,41 @@ __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __rest
         const SeqRef r = seqs[q];
         if (r.len < k) continue;
         const uint32_t nt = (r.len - k) / s + 1;
-        // the hits of one seed are spread over the lanes: a repeat-rich k-mer does not stall a single lane
+        // seeds with few hits: one lane each
+        for (uint32_t j = lane; j < nt * n_ori; j += 64u) {
+            const uint64_t sid = seed_start[q] + j;
+            const uint64_t cnt = seed_cnt[sid];
+            if (cnt == 0 || cnt > kFewHits) continue;
+            const uint32_t o = j / nt, t = j - o * nt;
+            const int p = (int)(t * s);
+            const uint64_t lo = seed_lo[sid];
+            uint64_t at = seed_out[sid] - out_base;
+            for (uint64_t h = 0; h < cnt; h++) {
+                const uint64_t v = vals[lo + h];
+                const uint32_t ida = seqs[(uint32_t)(v >> 32)].sfo_id;
+                if (ida < r.sfo_id) out_keys[at++] = pack_key(ida, r.sfo_id, o, (int)(uint32_t)v - p);
+            }
+        }
+        // repeat-rich seeds: the hits of one seed are spread over the lanes, so that it does not stall a single lane
         for (uint32_t j = 0; j < nt * n_ori; j++) {
             const uint64_t sid = seed_start[q] + j;
             const uint64_t cnt = seed_cnt[sid];
-            if (cnt == 0) continue;
+            if (cnt <= kFewHits) continue;
             const uint32_t o = j / nt, t = j - o * nt;
             const int p = (int)(t * s);
-            const uint64_t lo = seed_lo[sid], at = seed_out[sid] - out_base;
-            for (uint64_t h = lane; h < cnt; h += 64u) {
-                const uint64_t v = vals[lo + h];
-                const uint32_t qa = (uint32_t)(v >> 32);
-                const uint32_t ida = seqs[qa].sfo_id;
+            const uint64_t lo = seed_lo[sid];
+            uint64_t at = seed_out[sid] - out_base;  // where this seed's candidates go (exclusive scan of the valid counts)
+            for (uint64_t h0 = 0; h0 < cnt; h0 += 64u) {
+                const uint64_t h = h0 + lane;
                 uint64_t key = kNoKey;
-                if (ida < r.sfo_id) key = pack_key(ida, r.sfo_id, o, (int)(uint32_t)v - p);
-                out_keys[at + h] = key;
+                if (h < cnt) {
+                    const uint64_t v = vals[lo + h];
+                    const uint32_t ida = seqs[(uint32_t)(v >> 32)].sfo_id;
+                    if (ida < r.sfo_id) key = pack_key(ida, r.sfo_id, o, (int)(uint32_t)v - p);
+                }
+                const uint64_t m = __ballot(key != kNoKey);
+                if (key != kNoKey) out_keys[at + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+                at += (uint64_t)__popcll(m);
             }
         }
     }
@@ -248,6 +305,13 @@ __global__ __launch_bounds__(256) void finder_gather_kernel(const hc_sfo_rec* __
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = recs[idx[i]];
 }
 
+// out[q] = off[seed_start[q]]: the running total of candidate hits at every sequence boundary (what the host needs
+// to cut batches), instead of copying the whole per-seed scan to the host.
+__global__ __launch_bounds__(256) void finder_boundaries_kernel(const uint64_t* __restrict__ off, const uint64_t* __restrict__ seed_start,
+                                                                uint32_t n, uint64_t* __restrict__ out) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) out[q] = off[seed_start[q]];
+}
+
 // ---- launch wrappers -----------------------------------------------------------------------------------------
 static uint32_t wave_grid(uint32_t n_seq) {
     uint64_t blocks = ((uint64_t)n_seq + 3) / 4;  // 4 waves per 256-thread block
@@ -273,6 +337,13 @@ hipError_t finder_seeds(const void* sym, uint32_t symbytes, bool wide, const Seq
                         uint64_t* seed_cnt, hipStream_t stream) {
     HC_FINDER_DISPATCH(finder_seed_kernel, wave_grid(n_seq), sym, seqs, seed_start, n_seq, k, s, n_ori, symbytes, keys, n_keys, seed_lo,
                        seed_cnt);
+    return hipGetLastError();
+}
+
+hipError_t finder_count_valid(const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
+                              const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, uint64_t* seed_valid, hipStream_t stream) {
+    hipLaunchKernelGGL(finder_count_valid_kernel, dim3(wave_grid(n_seq)), dim3(256), 0, stream, seqs, seed_start, n_seq, k, s, n_ori, vals,
+                       seed_lo, seed_cnt, seed_valid);
     return hipGetLastError();
 }
 
@@ -302,6 +373,12 @@ hipError_t finder_emit(const SeqRef* by_sfo, const uint64_t* keys, const uint32_
     return hipGetLastError();
 }
 
+hipError_t finder_boundaries(const uint64_t* off, const uint64_t* seed_start, uint32_t n, uint64_t* out, hipStream_t stream) {
+    uint32_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(finder_boundaries_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, off, seed_start, n, out);
+    return hipGetLastError();
+}
 hipError_t finder_rekey(const hc_sfo_rec* recs, uint64_t n, uint64_t* keys, uint64_t* idx, hipStream_t stream) {
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;

@@ -247,7 +247,8 @@ void EdgeCalculator::construct_edges() {
     OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
     if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
     if (program_settings.verbose) puts("reading overlaps file... ");
-    const size_t overlaps_per_vec = 250000;  // the reference batches 1,000,000 (:571); batch boundaries do not influence the result
+    size_t overlaps_per_vec = 250000;
+    if (const char* e = getenv("HC_STAGE_BLOCK")) overlaps_per_vec = (size_t)strtoull(e, nullptr, 10);  // experiment knob  // the reference batches 1,000,000 (:571); batch boundaries do not influence the result
     // Three-stage pipeline: block k+1 is tokenised by the parser's worker threads while block k is scored on the
     // device and its edges are built, while the edges of block k-1 are inserted into the graph.  Every stage
     // consumes the blocks strictly in file order, so the graph, the counters and nonedge_overlaps.txt are those
