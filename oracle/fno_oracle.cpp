@@ -7,12 +7,15 @@
 // walk order of FNO=3 — that order is a property of the host's libstdc++ in the reference too).
 // Only tests/ may load this.  Inputs/outputs use the flat records of include/hcfno.h.
 //
-// PINNING: the reference's FNO translation units need Boost (absent here) and cannot be built.  Their
-// Boost-free member functions updateOverlap / findCliqueIndex / computeOverlapData (FindNextOverlaps.cpp:25-565)
-// and deduceOverlap (FindNextOverlaps3.cpp:176-406) are compiled as a FRAGMENT PROBE (oracle/Makefile `ref`,
-// _ref/libhcref_fno.so) and this file is checked against it on the committed vectors tests/golden/fno/*.json.
-// The walk around those functions (edge order, the checkEdge filter, inclusion-induced edges, the FNO=3
-// candidate list) is restated here without a reference binary to compare with: "parity unpinned" for those parts.
+// PINNING: the reference's FNO translation units need Boost (absent here) and cannot be built.  Almost all of their
+// text is Boost-free, though, and is compiled as a FRAGMENT PROBE (oracle/Makefile `ref`, _ref/libhcref_fno.so) behind
+// build-owned class shells: FindNextOverlaps.cpp:25-631 and :816-958 (updateOverlap, findCliqueIndex, computeOverlapData,
+// processOverlaps, reconsiderEdgeOverlaps, findInclusionOverlaps, findNextOverlaps), OverlapGraph.cpp:233-259 (checkEdge)
+// and FindNextOverlaps3.cpp:20-406 (the whole of FNO=3).  This file is checked against it on the committed vectors
+// tests/golden/fno/*.json: whole findNextOverlaps() and findNextOverlaps3() runs (the files they write), updateOverlap
+// sequences, computeOverlapData and deduceOverlap calls.  The one part without a reference execution is
+// reconsiderNonedgeOverlaps (FindNextOverlaps.cpp:635-813: boost::trim_if): reading the stored non-edges and the
+// checkEdge filter in front of them (:702) are restated here — "parity unpinned" for that branch only.
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -67,6 +67,68 @@ def main():
     json.dump({"source": "fragment probe of src/FindNextOverlaps.cpp:25-565 (updateOverlap)", "cases": cases},
               open(os.path.join(OUT, "fno1_update.json"), "w"), separators=(",", ":"))
 
+    # ---- whole findNextOverlaps() runs: the walk over adj_out, branching edges and inclusion-induced edges with the
+    # reference's own checkEdge; optimize = true (the stored non-edges are the one part the probe cannot run)
+    ref.frag_fno1_run.argtypes = [C.POINTER(F.hc_fno1_input), C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    import tempfile
+    runs = []
+    for seed in range(10):
+        flags = [F.RESOLVE_ORIENTATIONS, F.RESOLVE_ORIENTATIONS | F.NO_INCLUSIONS, 0][seed % 3] | F.OPTIMIZE
+        inp = T.fno1_scenario(2000 + seed, n_nodes=40, n_srs=13, n_edges=100, paired_frac=[0.0, 0.4, 1.0, 0.5][seed % 4], flags=flags,
+                              with_extras=True)
+        inp.nonedges = np.zeros(0, F.FNO_EDGE_DTYPE)
+        inp.edge_threshold = [0.97, 0.0, 1.0][seed % 3]
+        s = inp.struct()
+        text, n, nl = _vp(), C.c_uint64(), C.c_uint64()
+        with tempfile.TemporaryDirectory() as d:
+            ref.frag_fno1_run(C.byref(s), d.encode(), C.byref(text), C.byref(n), C.byref(nl))
+        got = C.string_at(text, n.value).decode()
+        ref.frag_fno_free(text)
+        ecols = ["v1", "v2", "score", "pos1", "pos2", "len1", "len2", "perc", "ord", "ori1", "ori2"]
+        runs.append({
+            "flags": flags, "new_read_count": int(inp.new_read_count), "edge_threshold": inp.edge_threshold,
+            "nodes": rec_list(inp.nodes[["id", "len1", "len2", "paired", "visited", "orientation"]]),
+            "srs": rec_list(inp.srs[["id", "len1", "len2", "paired"]]),
+            "clique_off": inp.clique_off.tolist(), "clique_nodes": inp.clique_nodes.tolist(),
+            "subread_off": inp.subread_off.tolist(), "subreads": rec_list(inp.subreads),
+            "graph_edges": rec_list(inp.graph_edges[ecols]), "branching_edges": rec_list(inp.branching_edges[ecols]),
+            "inclusion_off": inp.inclusion_off.tolist(), "inclusion_edges": rec_list(inp.inclusion_edges[ecols]),
+            "text": got, "n_lines": int(nl.value),
+        })
+    json.dump({"source": "fragment probe of src/FindNextOverlaps.cpp:25-631,816-958 + src/OverlapGraph.cpp:233-259 (findNextOverlaps, optimize = true)",
+               "cases": runs}, open(os.path.join(OUT, "fno1_run.json"), "w"), separators=(",", ":"))
+
+    # ---- whole findNextOverlaps3() runs.  hc_fno3_input lists the originals of a super-read in the iteration order of
+    # its std::unordered_map; the probe is given an insertion order and tells which iteration order results.
+    ref.frag_fno3_run.argtypes = [C.POINTER(F.hc_fno3_input), C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    ref.frag_fno3_iteration_order.argtypes = [_vp, C.c_uint64, _vp]
+    runs3 = []
+    for seed in range(8):
+        flags = [0, F.NO_INCLUSIONS][seed % 2]
+        probe_in = T.fno3_scenario(3000 + seed, n_single=14, n_paired=10, n_trivial=12, n_originals=50, flags=flags)
+        api_originals = []
+        for i in range(len(probe_in.srs)):
+            o = probe_in.originals[int(probe_in.orig_off[i]):int(probe_in.orig_off[i + 1])]
+            ids = np.ascontiguousarray(o["original_id"], dtype=np.uint64)
+            order = np.zeros(len(ids), np.uint64)
+            ref.frag_fno3_iteration_order(ids.ctypes.data, len(ids), order.ctypes.data)
+            api_originals.append(o[order.astype(np.int64)])
+        s = probe_in.struct()
+        text, n, nl = _vp(), C.c_uint64(), C.c_uint64()
+        with tempfile.TemporaryDirectory() as d:
+            ref.frag_fno3_run(C.byref(s), d.encode(), C.byref(text), C.byref(n), C.byref(nl))
+        got = C.string_at(text, n.value).decode()
+        ref.frag_fno_free(text)
+        runs3.append({
+            "flags": flags, "counts": list(probe_in.counts), "new_read_count": int(probe_in.new_read_count),
+            "original_readcount": int(probe_in.original_readcount),
+            "srs": rec_list(probe_in.srs[["id", "len1", "len2", "paired"]]),
+            "orig_off": probe_in.orig_off.tolist(), "originals_in_iteration_order": rec_list(np.concatenate(api_originals)),
+            "text": got, "n_lines": int(nl.value),
+        })
+    json.dump({"source": "fragment probe of src/FindNextOverlaps3.cpp:20-406 (findNextOverlaps3, nodeDictApproach, deduceOverlap)",
+               "cases": runs3}, open(os.path.join(OUT, "fno3_run.json"), "w"), separators=(",", ":"))
+
     # ---- computeOverlapData
     rng = np.random.default_rng(77)
     vec = []

@@ -58,6 +58,55 @@ def test_golden_update_overlap_oracle_and_product(olib):
     assert n == 12
 
 
+def test_golden_whole_find_next_overlaps_runs(olib):
+    """The reference's own findNextOverlaps() — nodes_to_SR from the cliques, the adj_out walk, branching edges,
+    inclusion-induced edges with the reference's checkEdge, the sorted set as written to overlaps.txt — run through
+    the fragment probe with optimize = true; oracle and product must produce the same file."""
+    g = json.load(open(os.path.join(GOLD, "fno1_run.json")))
+    assert "findNextOverlaps" in g["source"] and len(g["cases"]) == 10
+    ecols = ["v1", "v2", "score", "pos1", "pos2", "len1", "len2", "perc", "ord", "ori1", "ori2"]
+    some_induced = 0
+    for c in g["cases"]:
+        nodes = _rec(c["nodes"], F.FNO_READ_DTYPE, ["id", "len1", "len2", "paired", "visited", "orientation"])
+        srs = _rec(c["srs"], F.FNO_READ_DTYPE, ["id", "len1", "len2", "paired"])
+        subs = _rec(c["subreads"], F.FNO_SUBREAD_DTYPE, ["node", "index1", "index2", "startpos1", "startpos2"])
+        co, so, io = c["clique_off"], c["subread_off"], c["inclusion_off"]
+        cliques = [np.array(c["clique_nodes"][co[i]:co[i + 1]], np.uint64) for i in range(len(srs))]
+        subreads = [subs[so[i]:so[i + 1]] for i in range(len(srs))]
+        incl = _rec(c["inclusion_edges"], F.FNO_EDGE_DTYPE, ecols)
+        groups = [incl[io[i]:io[i + 1]] for i in range(len(io) - 1)]
+        inp = F.Fno1Input(nodes, srs, cliques, subreads, _rec(c["graph_edges"], F.FNO_EDGE_DTYPE, ecols),
+                          branching_edges=_rec(c["branching_edges"], F.FNO_EDGE_DTYPE, ecols), inclusion_groups=groups,
+                          new_read_count=c["new_read_count"], edge_threshold=c["edge_threshold"], flags=c["flags"])
+        want = c["text"].encode()
+        for text, cnt in (T.oracle_fno1(olib, inp), F.find_next_overlaps(inp)):
+            assert text == want and cnt["n_lines"] == c["n_lines"] == want.count(b"\n")
+        # the inclusion-induced edges matter in these cases: without them the file is different
+        inp.inclusion_off, inp.inclusion_edges, inp.n_inclusion_groups = np.zeros(1, np.uint64), np.zeros(0, F.FNO_EDGE_DTYPE), 0
+        some_induced += F.find_next_overlaps(inp)[0] != want
+    assert some_induced >= 5
+
+
+def test_golden_whole_find_next_overlaps3_runs(olib):
+    """The reference's own findNextOverlaps3() as a whole (original_to_index walk in its unordered_map order, the
+    candidate list, deduceOverlap, the file): oracle and product reproduce overlaps.txt byte for byte."""
+    g = json.load(open(os.path.join(GOLD, "fno3_run.json")))
+    assert "findNextOverlaps3" in g["source"] and len(g["cases"]) == 8
+    total = 0
+    for c in g["cases"]:
+        srs = _rec(c["srs"], F.FNO_READ_DTYPE, ["id", "len1", "len2", "paired"])
+        orig = _rec(c["originals_in_iteration_order"], F.FNO_ORIGINAL_DTYPE, ["original_id", "index1", "index2"])
+        oo = c["orig_off"]
+        originals = [orig[oo[i]:oo[i + 1]] for i in range(len(srs))]
+        inp = F.Fno3Input(srs, *c["counts"], originals, new_read_count=c["new_read_count"], original_readcount=c["original_readcount"],
+                          flags=c["flags"])
+        want = c["text"].encode()
+        for text, cnt in (T.oracle_fno3(olib, inp), F.find_next_overlaps3(inp)):
+            assert text == want and cnt["n_lines"] == c["n_lines"] == want.count(b"\n")
+        total += c["n_lines"]
+    assert total > 100
+
+
 def test_golden_compute_overlap_data(olib):
     g = json.load(open(os.path.join(GOLD, "fno1_cod.json")))
     n_ok = 0
