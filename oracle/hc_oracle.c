@@ -1,8 +1,8 @@
 /*
  * hc_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
  * Plain-C restatement of HaploConduct's edge-calculation path; see hc_oracle.h
- * for scope and pinning status ("parity unpinned" for the scoring TU: the
- * reference cannot be compiled here without Boost stand-ins).
+ * for scope and pinning status (compute_overlap / process_overlaps are held to outputs of the reference's
+ * own code; "parity unpinned" only for construct_edges' tokeniser + prefilter and the FASTQ reader).
  *
  * Build: gcc -O2 -ffp-contract=off -fopenmp (no -ffast-math, no -march): the
  * reference is built with g++ -O2 for baseline x86-64, i.e. IEEE double, no FMA

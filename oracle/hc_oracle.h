@@ -8,22 +8,19 @@
  * product library (libhcedge.so) never links or calls anything in oracle/.
  *
  * PINNING STATUS (see DESIGN.md "Oracle"):
- *   - The reference ships no tests / golden vectors for this path.
- *   - The reference's scoring translation unit (EdgeCalculator.cpp) cannot be
- *     compiled here: it includes Boost headers that are absent from the image,
- *     and writing stand-ins for them is not allowed.  => for score(),
- *     overlap_score(), compute_overlap(), process_overlaps(), construct_edges()
- *     this oracle is "PARITY UNPINNED" by execution of the full reference.
- *   - What IS pinned by executing genuine reference code (oracle/_ref, built by
- *     oracle/Makefile from the files where they lie under /root/reference/src):
- *       * Overlap.h  (13-column record parsing, get_perc, get_overlap_line)
- *       * Types.h    (build_rev_comp, str_to_read_id)
- *       * Edge.h     (swap_reads field effects, default field values)
- *       * Read.h     (get_seq/get_phred/get_rev_comp/get_rev_phred selection)
- *     and, as a separately labelled FRAGMENT PROBE (reference lines piped
- *     verbatim from EdgeCalculator.cpp:26-139 into the compiler, never stored),
- *     score()/phred_to_prob()/overlap_score().  tests/golden/ holds the vectors
- *     those produced, with the generating script.
+ *   - The reference ships no tests / golden vectors for this path, and none of its translation
+ *     units compiles here as a whole (Boost headers are absent; stand-ins are not allowed).
+ *   - Boost is used in very few lines, though.  Everything else is executed AS IT IS through fragment probes
+ *     (oracle/Makefile `ref`: reference lines piped verbatim into the compiler behind class shells that repeat
+ *     declarations only; outputs in oracle/_ref, vectors + generating scripts in tests/golden/):
+ *       * Types.h, Overlap.h, Read.h, Edge.h      whole headers                       (libhcref_headers.so)
+ *       * EdgeCalculator.cpp:26-139                score / phred_to_prob / overlap_score (libhcref_fragment.so)
+ *       * EdgeCalculator.cpp:26-557 + OverlapGraph.cpp:83-101,150-229,285-319
+ *                                                  compute_overlap, process_overlaps incl. the serial insert and
+ *                                                  the tie-break chain, the graph methods  (libhcref_edgecalc.so)
+ *     tests/test_oracle_golden.py and tests/test_ec_golden.py hold this oracle to those outputs bit for bit.
+ *   - "PARITY UNPINNED" (restated, no reference execution possible): construct_edges' line trimming / splitting
+ *     and prefilter (EdgeCalculator.cpp:561-666, Boost at :584-587) and the FASTQ reader (FastqStorage.cpp).
  *
  * Every function cites the reference file:line it follows.
  */

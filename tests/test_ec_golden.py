@@ -1,0 +1,72 @@
+"""The oracle's compute_overlap / process_overlaps against the reference's own (tests/golden/ec/*.json: outputs of the
+genuine src/EdgeCalculator.cpp:26-557 and the OverlapGraph methods it calls, run through the fragment probe by
+tests/golden/make_golden_ec.py): adjacency lists in list order with scores and mismatch rates as IEEE bit patterns,
+inclusions bits, nonedge_overlaps.txt, inclusion_count, dup_count.  CPU only; the device path is held to the same
+vectors in tests/test_gpu_stage.py."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import haploconduct_amd as hc
+from haploconduct_amd.records import FLAG_IGNORE_INCLUSIONS, FLAG_RESOLVE_ORIENTATIONS
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ec")
+CASES = sorted(glob.glob(os.path.join(GOLD, "*.json")))
+
+
+def load_case(path):
+    c = json.load(open(path))
+    assert "fragment probe" in c["source"]
+    ns, npair = c["n_single"], c["n_paired"]
+    singles = [(c["seqs"][i], c["quals"][i]) for i in range(ns)]
+    pairs = [((c["seqs"][ns + 2 * j], c["quals"][ns + 2 * j]), (c["seqs"][ns + 2 * j + 1], c["quals"][ns + 2 * j + 1])) for j in range(npair)]
+    reads = hc.ReadSet.from_lists(singles, pairs, single_ids=c["read_ids"][:ns], pair_ids=c["read_ids"][ns:])
+    s = c["settings"]
+    st = hc.Settings(edge_threshold=s["edge_threshold"], ov_threshold=s["ov_threshold"], merge_contigs=s["merge_contigs"], mismatch=s["mismatch"],
+                     min_read_len=s["min_read_len"], min_overlap_len=0, min_overlap_perc=0,
+                     flags=FLAG_RESOLVE_ORIENTATIONS | (FLAG_IGNORE_INCLUSIONS if s["ignore_inclusions"] else 0))
+    want = {k: [e[i] for e in c["edges"]] for i, k in enumerate(c["edge_fields"])}
+    for k in ("score", "mismatch_rate"):
+        want[k] = np.array([float.fromhex(x) for x in want[k]], np.float64)
+    return c, reads, st, want
+
+
+def compare_edges(edges, want, what):
+    assert edges.size == len(want["v1"]), f"{what}: {edges.size} edges, the reference built {len(want['v1'])}"
+    for k in ("score", "mismatch_rate"):
+        assert np.array_equal(np.ascontiguousarray(edges[k]).view(np.uint64), want[k].view(np.uint64)), f"{what}: {k} not bit-identical"
+    for k in ("pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"):
+        assert np.array_equal(np.asarray(edges[k]).astype(np.int64), np.array(want[k], np.int64)), f"{what}: {k} differs"
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
+def test_oracle_reproduces_the_references_process_overlaps(oracle, tmp_path, path):
+    c, reads, st, want = load_case(path)
+    ov = tmp_path / "overlaps.txt"
+    ov.write_text("\n".join(c["lines"]) + "\n")
+    rc, g, oc = oracle.construct_edges(reads, st, str(ov), str(tmp_path / "nonedge.txt"))
+    assert rc == 0
+    compare_edges(g.all_edges(), want, "oracle")
+    assert g.inclusions().tolist() == c["inclusions"]
+    assert (tmp_path / "nonedge.txt").read_text() == c["nonedge_overlaps"]
+    assert oc.inclusion_count == c["inclusion_count"] and oc.dup_count == c["dup_count"]
+
+
+def test_the_vectors_cover_the_branches():
+    assert len(CASES) == 7
+    tot = {"edges": 0, "nonedges": 0, "dups": 0, "incl_bits": 0, "incl_count": 0}
+    ords, oris = set(), set()
+    for p in CASES:
+        c = json.load(open(p))
+        tot["edges"] += len(c["edges"])
+        tot["nonedges"] += c["nonedge_overlaps"].count("\n")
+        tot["dups"] += c["dup_count"]
+        tot["incl_bits"] += sum(c["inclusions"])
+        tot["incl_count"] += c["inclusion_count"]
+        ords |= {chr(e[8]) for e in c["edges"]}
+        oris |= {(e[6], e[7]) for e in c["edges"]}
+    assert tot["edges"] > 500 and tot["nonedges"] > 1500 and tot["dups"] > 100 and tot["incl_bits"] > 10 and tot["incl_count"] > 50
+    assert ords == {"-", "1", "2"} and len(oris) == 4

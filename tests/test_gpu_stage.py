@@ -245,3 +245,36 @@ def test_inter_iteration_path_edge_calc_fno_edge_calc(oracle, tmp_path):
         assert cb["prefilter_rejected"] == ca["prefilter_rejected"]
         key = lambda e: sorted(zip(*(e[k].view(np.uint64).tolist() if e[k].dtype.kind == "f" else e[k].tolist() for k in FIELDS)))
         assert key(edges_a) == key(edges_b)
+
+
+def _ec_golden_cases():
+    import glob
+
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ec", "*.json")))
+
+
+@pytest.mark.parametrize("path", _ec_golden_cases(), ids=[os.path.basename(p)[:-5] for p in _ec_golden_cases()])
+def test_stage_reproduces_the_references_own_process_overlaps(tmp_path, path):
+    """The device path against the REFERENCE ITSELF: tests/golden/ec/*.json hold what the genuine compute_overlap /
+    process_overlaps (src/EdgeCalculator.cpp:26-557, run through the fragment probe) built from these reads and
+    candidate lines — adjacency lists in list order, scores and mismatch rates as bit patterns, inclusions,
+    nonedge_overlaps.txt, counters.  The HIP stage must leave exactly the same behind."""
+    from tests.test_ec_golden import compare_edges, load_case
+
+    c, reads, st, want = load_case(path)
+    d = tmp_path
+    (d / "overlaps.txt").write_text("\n".join(c["lines"]) + "\n")
+    s = str(d / "singles.fastq") if c["n_single"] else None
+    p1 = str(d / "paired1.fastq") if c["n_paired"] else None
+    p2 = str(d / "paired2.fastq") if c["n_paired"] else None
+    reads.write_fastq(s, p1, p2)
+    out = d / "out"
+    out.mkdir()
+    st.n_threads = 4
+    with host.EdgeCalculatorStage(st, singles=s, paired1=p1, paired2=p2, overlaps=str(d / "overlaps.txt"), output_dir=str(out) + "/") as ec:
+        ec.construct_edges()
+        edges, inc, cnt = ec.edges(), ec.inclusions(), ec.counters()
+    compare_edges(edges, want, "HIP stage")
+    assert inc.tolist() == c["inclusions"]
+    assert (out / "nonedge_overlaps.txt").read_text() == c["nonedge_overlaps"]
+    assert cnt["inclusion_count"] == c["inclusion_count"] and cnt["dup_count"] == c["dup_count"]
