@@ -12,6 +12,7 @@ from haploconduct_amd.records import OVERLAP_DTYPE, result_cls, result_n
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 
 
 def test_device_overlap_score_matches_reference_fragment_vectors():
@@ -187,3 +188,53 @@ def test_rccl_gather_path_single_rank():
         assert np.array_equal(rows[:, 1].view(np.uint64), host["x1"][want].view(np.uint64))
     finally:
         dist.destroy_process_group()
+
+
+def test_c2_slice_against_the_references_own_code(tmp_path):
+    """At the size and in the shape of the bench workload: 150 000 candidates of BASELINE config 2 through the
+    REFERENCE'S OWN compute_overlap / process_overlaps (the fragment probe oracle/_ref/libhcref_edgecalc.so, built in
+    the build container and shipped with the repository) and through the HIP stage.  Same adjacency lists, in list
+    order, scores and mismatch rates as bit patterns; same non-edge file."""
+    import ctypes as C
+    import importlib.util
+
+    lib_path = os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("oracle/_ref/libhcref_edgecalc.so is built only where /root/reference exists")
+    spec = importlib.util.spec_from_file_location("make_golden_ec", os.path.join(ROOT, "tests", "golden", "make_golden_ec.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from haploconduct_amd import host
+    from tests.test_ec_golden import compare_edges
+
+    import bench
+
+    reads, cand, cfg, st = bench.build_workload("c2", 0)
+    cand = cand[:150000]
+    lines = synth.records_to_lines(cand, reads)
+    ref = C.CDLL(lib_path)
+    ref.frag_process_overlaps.restype = C.c_int
+    ref.frag_process_overlaps.argtypes = [C.POINTER(mg.FragSettings), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_uint64, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
+    ref.frag_ec_free.argtypes = [C.c_void_p]
+    settings = dict(edge_threshold=st.edge_threshold, ov_threshold=st.ov_threshold, merge_contigs=st.merge_contigs, mismatch=st.mismatch,
+                    min_read_len=st.min_read_len, ignore_inclusions=0)
+    edges, incl, nonedge, counters = mg.run_probe(ref, reads, lines, settings)
+    assert len(edges) > 3000
+    names = ["score", "mismatch_rate", "pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"]
+    want = {k: [e[i] for e in edges] for i, k in enumerate(names)}
+    for k in ("score", "mismatch_rate"):
+        want[k] = np.array([float.fromhex(x) for x in want[k]], np.float64)
+    (tmp_path / "overlaps.txt").write_text("\n".join(lines) + "\n")
+    reads.write_fastq(None, str(tmp_path / "p1.fastq"), str(tmp_path / "p2.fastq"))
+    out = tmp_path / "out"
+    out.mkdir()
+    st.min_overlap_len, st.min_overlap_perc, st.n_threads = 0, 0, 8
+    with host.EdgeCalculatorStage(st, paired1=str(tmp_path / "p1.fastq"), paired2=str(tmp_path / "p2.fastq"),
+                                  overlaps=str(tmp_path / "overlaps.txt"), output_dir=str(out) + "/") as ec:
+        ec.construct_edges()
+        got, cnt = ec.edges(), ec.counters()
+    compare_edges(got, want, "HIP stage vs the reference's own code")
+    assert (out / "nonedge_overlaps.txt").read_text() == nonedge
+    assert cnt["inclusion_count"] == counters[0] and cnt["dup_count"] == counters[1]
