@@ -148,3 +148,34 @@ def test_batched_run_gives_the_same_records(monkeypatch):
         monkeypatch.setenv("HC_FIND_BATCH_HITS", "1024")
         many = as_tuples(sc.find_overlaps(0.02, 50))
     assert one == many == O.find_overlaps(reads, 0.02, 50) and len(one) > 500
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HC_FUZZ_FINDER_SEEDS", "6"))))
+def test_fuzz_against_brute_force(seed):
+    """Random read sets (lengths, error and N rates, repeats, duplicated reads) and random (err_rate, min_overlap,
+    flags) within what the exact seed filter accepts: the record lists must equal the brute-force oracle's."""
+    rng = np.random.default_rng(5000 + seed)
+    lo = int(rng.integers(30, 90))
+    hi = lo + int(rng.integers(10, 200))
+    reads = make_reads(6000 + seed, n_single=int(rng.integers(0, 40)), n_pair=int(rng.integers(1, 25)), glen=int(rng.integers(300, 1200)),
+                       lo=lo, hi=hi, err=float(rng.choice([0.0, 0.004, 0.02])), n_rate=float(rng.choice([0.0, 0.005])),
+                       rc_frac=float(rng.choice([0.0, 0.5])), repeat=bool(rng.integers(0, 2)))
+    if rng.random() < 0.5:  # exact duplicates of some reads: d = 0 inclusions both ways, reported once
+        k = reads.n_seq
+        singles = [reads.seq(q) for q in range(min(5, k))]
+        s0 = sum(1 for r in range(reads.n_reads) if not reads.is_paired(r))
+        allsingles = [reads.seq(int(reads.read_first_seq[r])) for r in range(s0)] + singles
+        pairs = [(reads.seq(int(reads.read_first_seq[r])), reads.seq(int(reads.read_first_seq[r]) + 1)) for r in range(s0, reads.n_reads)]
+        reads = hc.ReadSet.from_lists(allsingles, pairs)
+    min_overlap = int(rng.integers(20, lo + 1))
+    err_rate = float(rng.choice([0.0, 0.01, 0.02, 0.04]))
+    rev, inc = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        try:
+            got = as_tuples(sc.find_overlaps(err_rate, min_overlap, reversals=rev, inclusions=inc))
+        except hc.HcError as e:
+            assert "err_rate too high" in str(e)  # the filter refuses what it cannot do exactly
+            return
+    want = O.find_overlaps(reads, err_rate, min_overlap, reversals=rev, inclusions=inc)
+    assert got == want, (len(got), len(want), sorted(set(want) - set(got))[:3], sorted(set(got) - set(want))[:3])
