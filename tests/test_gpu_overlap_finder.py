@@ -179,3 +179,33 @@ def test_fuzz_against_brute_force(seed):
             return
     want = O.find_overlaps(reads, err_rate, min_overlap, reversals=rev, inclusions=inc)
     assert got == want, (len(got), len(want), sorted(set(want) - set(got))[:3], sorted(set(got) - set(want))[:3])
+
+
+def test_real_reads_to_graph(oracle, tmp_path):
+    """The excerpt of the reference's own SAVAGE example data (merged singles + 2x250 pairs with N and Q0 bases,
+    tests/golden/savage_*.fastq.gz) from reads to graph with nothing but this library: device overlap finder at
+    POLYTE's error rate, SFO ingest, overlaps file, edge-calculation stage — the stage compared with the oracle."""
+    from tests.test_gpu_example_data import compare_stage, gunzip_to
+
+    src = dict(singles=gunzip_to("savage_singles.fastq", str(tmp_path / "s0.fastq")),
+               paired1=gunzip_to("savage_paired1.fastq", str(tmp_path / "a0.fastq")),
+               paired2=gunzip_to("savage_paired2.fastq", str(tmp_path / "b0.fastq")))
+    f = host.Fastq(**src)
+    orig = f.readset()
+    n_single, n_pairs = f.n_single, f.n_paired
+    # the pipelines number the reads 0..n-1 (singles, then pairs) before rust-overlaps sees them (savage.py:643-664)
+    reads = hc.ReadSet(orig.bases, orig.quals, orig.seq_off, orig.read_first_seq, np.arange(orig.n_reads, dtype=np.uint64))
+    fq = dict(singles=str(tmp_path / "singles.fastq"), paired1=str(tmp_path / "paired1.fastq"), paired2=str(tmp_path / "paired2.fastq"))
+    reads.write_fastq(fq["singles"], fq["paired1"], fq["paired2"])
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        recs = sc.find_overlaps(0.02, 100)
+    assert recs.size > 3000 and recs["inverted"].any() and (recs["K"] > 0).any()
+    n_lines = host.sfo_records_to_overlaps(recs, str(tmp_path / "overlaps.txt"), n_single, n_pairs)
+    assert n_lines > 1000
+    lines = (tmp_path / "overlaps.txt").read_text().split("\n")[:-1]
+    types = {tuple(l.split("\t")[11:13]) for l in lines}
+    assert ("s", "s") in types and len(types) >= 2  # single-single and overlaps involving pairs
+    st = hc.Settings(edge_threshold=0.97, min_overlap_len=200)
+    edges, c = compare_stage(oracle, tmp_path, st, fq, lines, "real")
+    assert edges.size > 100 and c["scored"] > 500
