@@ -209,3 +209,38 @@ def test_real_reads_to_graph(oracle, tmp_path):
     st = hc.Settings(edge_threshold=0.97, min_overlap_len=200)
     edges, c = compare_stage(oracle, tmp_path, st, fq, lines, "real")
     assert edges.size > 100 and c["scored"] > 500
+    # and against the reference's own compute_overlap / process_overlaps where its probe library is present
+    # (no prefilter on either side: process_overlaps sees every line)
+    import ctypes as C
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_path = os.path.join(root, "oracle", "_ref", "libhcref_edgecalc.so")
+    if not os.path.exists(lib_path):
+        return
+    spec = importlib.util.spec_from_file_location("make_golden_ec", os.path.join(root, "tests", "golden", "make_golden_ec.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from tests.test_ec_golden import compare_edges
+
+    ref = C.CDLL(lib_path)
+    ref.frag_process_overlaps.restype = C.c_int
+    ref.frag_process_overlaps.argtypes = [C.POINTER(mg.FragSettings), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_uint64, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
+    ref.frag_ec_free.argtypes = [C.c_void_p]
+    redges, rincl, rnonedge, rcounters = mg.run_probe(ref, reads, lines, dict(edge_threshold=0.97, ov_threshold=st.ov_threshold,
+                                                                              merge_contigs=0.0, mismatch=0.0, min_read_len=0, ignore_inclusions=0))
+    names = ["score", "mismatch_rate", "pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"]
+    want = {k: [e[i] for e in redges] for i, k in enumerate(names)}
+    for k in ("score", "mismatch_rate"):
+        want[k] = np.array([float.fromhex(x) for x in want[k]], np.float64)
+    st0 = hc.Settings(edge_threshold=0.97, ov_threshold=st.ov_threshold, min_overlap_len=0, min_overlap_perc=0)
+    out = tmp_path / "out0"
+    out.mkdir()
+    with host.EdgeCalculatorStage(st0, overlaps=str(tmp_path / "overlaps.txt"), output_dir=str(out) + "/", **fq) as ec:
+        ec.construct_edges()
+        got, cnt = ec.edges(), ec.counters()
+    compare_edges(got, want, "HIP stage vs the reference's own code on real reads")
+    assert (out / "nonedge_overlaps.txt").read_text() == rnonedge
+    assert cnt["inclusion_count"] == rcounters[0] and cnt["dup_count"] == rcounters[1] and len(redges) > 200
