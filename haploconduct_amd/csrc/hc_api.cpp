@@ -666,7 +666,8 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         w = wl < w ? wl : w;
     }
     if (w < 12)
-        return fail(HC_ERR_ARG, "hc_find_overlaps: err_rate too high for this min_overlap: an overlap need not contain 12 error-free positions in a row");
+        return fail(HC_ERR_ARG, min_overlap < 12 ? "hc_find_overlaps: min_overlap below 12 is not supported by the seed filter"
+                                                 : "hc_find_overlaps: err_rate too high for this min_overlap: an overlap need not contain 12 error-free positions in a row");
     const uint32_t k = w < 31 ? w : 31, s = w - k + 1;
     const uint32_t n_ori = (flags & HC_FIND_REVERSALS) ? 2u : 1u;
     const bool wide = c->view.symbytes == 1 && hc::lut_lg(c->view.K) == 6;
