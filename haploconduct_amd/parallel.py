@@ -54,84 +54,75 @@ def gather_admitted(results_np_or_tensor, global_offset, group=None, device=None
     return rows, counts
 
 
-class StreamedGather:
-    """The same collection without a host round trip per batch — what `bench.py --gpus N` runs.
+def pack_payload(results, base_index, cap_rows, shuffle_seed=None):
+    """The collection payload of one batch, built on the host (numpy) — the layout `hc_score_pack_device` /
+    `hc_compact_pack_device` write on the device: int64 rows [index, x1 bits, x2 bits, mm | n_cls << 32], row 0 =
+    [count, 0, 0, 0], then the records whose class is not DROP.  shuffle_seed: emit the rows in a random order,
+    as the fused scoring kernel does.  Used where no device is involved (host callers, the gloo tests)."""
+    res = np.asarray(results)
+    cls = res["n_cls"] >> 28
+    kept = np.nonzero(cls != 0)[0]
+    if shuffle_seed is not None:
+        kept = kept[np.random.default_rng(shuffle_seed).permutation(kept.size)]
+    out = np.zeros((cap_rows + 1, 4), np.int64)
+    out[0, 0] = kept.size
+    k = kept[:cap_rows]
+    out[1:1 + k.size, 0] = base_index + k
+    out[1:1 + k.size, 1] = res["x1"][k].view(np.int64)
+    out[1:1 + k.size, 2] = res["x2"][k].view(np.int64)
+    out[1:1 + k.size, 3] = res["mm"][k].astype(np.int64) | (res["n_cls"][k].astype(np.int64) << 32)
+    return torch.from_numpy(out)
 
-    Per batch: device stream compaction of the non-dropped records (`hc_compact_device`), one kernel that tags
-    them with their global candidate index (`hc_pack_rows_device`, 32-byte rows), then two asynchronous all-gathers
-    over RCCL: the counts and the rows padded to a fixed capacity.  All of it runs on a SIDE stream that only waits
-    for the scoring kernel of its own batch, so with two result buffers the scoring kernel of batch i+1 starts
-    right behind that of batch i and the collection of batch i overlaps it.  Nothing synchronises with the host;
-    `collect()` is the host side: waits, checks the capacity, trims.
 
-    Protocol per batch:  before_write(results) -> launch the scoring kernel into `results` on the current stream
-    -> step(results).  Use at least two `results` tensors in turn; with one, before_write serialises.
-    """
+class PayloadGather:
+    """The all-gather-v of the collection payloads as ONE all-gather per batch, on any backend (nccl = RCCL, gloo):
+    every rank contributes a fixed-capacity payload whose row 0 is its count; `depth` buffer sets in turn, the
+    all-gather asynchronous; `collect` (host side) waits, checks the capacity, trims by the counts, and sorts the
+    rows by global index when their producer wrote them in no particular order."""
 
-    def __init__(self, scorer, n_local, base_index, cap_rows, group=None, depth=2):
-        self.sc, self.n, self.base, self.cap, self.group, self.depth = scorer, int(n_local), int(base_index), int(cap_rows), group, depth
+    def __init__(self, cap_rows, group=None, depth=2, device=None):
+        self.cap, self.group, self.depth = int(cap_rows), group, depth
         self.world = dist.get_world_size(group)
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.side = torch.cuda.Stream(device=dev)
-        # zero-initialised: entries beyond the count of a batch are stale but always valid indices
-        self.idx = torch.zeros(max(self.n, 1), dtype=torch.int32, device=dev)
-        rows = self.cap + 1  # row 0 carries the count: one all-gather per batch is the whole all-gather-v
-        self.bufs = [{"count": torch.zeros(1, dtype=torch.int64, device=dev),
-                      "payload": torch.zeros((rows, 4), dtype=torch.int64, device=dev),
-                      "all": torch.zeros((self.world * rows, 4), dtype=torch.int64, device=dev),
-                      "scored": torch.cuda.Event(), "packed": torch.cuda.Event(), "work": None, "unordered": False}
-                     for _ in range(depth)]
+        self.device = device if device is not None else torch.device("cpu")
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        rows = self.cap + 1
+        self.bufs = [{"payload": torch.zeros((rows, 4), dtype=torch.int64, device=self.device),
+                      "all": torch.zeros((self.world * rows, 4), dtype=torch.int64, device=self.device),
+                      "scored": torch.cuda.Event() if self.cuda else None, "packed": torch.cuda.Event() if self.cuda else None,
+                      "work": None, "unordered": False} for _ in range(depth)]
         self.i = 0
-        self.packed = {}  # data_ptr of a results tensor -> event: its rows have been packed, it may be overwritten
 
-    def before_write(self, d_results):
-        """The current stream waits until the batch that last used `d_results` has been read out of it."""
-        ev = self.packed.get(d_results.data_ptr())
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-
-    def step(self, d_results):
-        """d_results: uint8/int64 CUDA tensor holding this rank's n hc_result_rec, written by work already enqueued
-        on the current stream.  Enqueues the collection on the side stream; returns the buffer set."""
+    def next_buffers(self):
+        """The buffer set of the next batch; its payload may be written once the all-gather that last used it is done
+        (on CUDA the current stream is made to wait for it, on CPU the call blocks)."""
         b = self.bufs[self.i % self.depth]
         self.i += 1
-        b["unordered"] = False
-        b["scored"].record(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(b["scored"])
-            if b["work"] is not None:
-                b["work"].wait()  # the batch that used these buffers `depth` batches ago has been gathered
-            # (self.idx is shared: compaction and pack of consecutive batches are ordered on the side stream)
-            self.sc.compact_pack_device(d_results.data_ptr(), self.n, self.idx.data_ptr(), b["count"].data_ptr(), self.cap, self.base,
-                                        b["payload"].data_ptr(), self.side.cuda_stream)
-            b["packed"].record(self.side)
-            self.packed[d_results.data_ptr()] = b["packed"]
-            b["work"] = dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
+        if b["work"] is not None:
+            b["work"].wait()
+            b["work"] = None
         return b
 
-    def score_step(self, d_in_ptr, d_results):
-        """Scoring and collection of one batch with the payload written by the scoring kernel itself
-        (`hc_score_pack_device`): no compaction pass.  d_in_ptr: device pointer of this rank's n candidate records;
-        d_results: CUDA tensor receiving the n result records.  The all-gather runs on the side stream."""
-        b = self.bufs[self.i % self.depth]
-        self.i += 1
-        main = torch.cuda.current_stream()
-        if b["work"] is not None:
-            b["work"].wait()  # the payload buffer of `depth` batches ago has been gathered
-        b["unordered"] = self.sc.score_pack_device(d_in_ptr, self.n, d_results.data_ptr(), self.cap, self.base, b["payload"].data_ptr(),
-                                                   main.cuda_stream)
-        b["scored"].record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(b["scored"])
+    def submit(self, b):
+        """Launch the all-gather of b["payload"] (written by work already enqueued on the current stream)."""
+        if self.cuda:
+            b["scored"].record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(b["scored"])
+                b["work"] = dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
+        else:
             b["work"] = dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
         return b
 
     def collect(self, b):
         """Host side of one batch: (rows [sum k_r, 4] int64 ordered by global index, counts per rank)."""
-        with torch.cuda.stream(self.side):
-            if b["work"] is not None:
+        if b["work"] is not None:
+            if self.cuda:
+                with torch.cuda.stream(self.side):
+                    b["work"].wait()
+                self.side.synchronize()
+            else:
                 b["work"].wait()
-        self.side.synchronize()
         rows = self.cap + 1
         counts = [int(b["all"][r * rows, 0]) for r in range(self.world)]
         if max(counts) > self.cap:
@@ -142,10 +133,60 @@ class StreamedGather:
         return out, counts
 
     def finish(self):
-        with torch.cuda.stream(self.side):
-            for b in self.bufs:
-                if b["work"] is not None:
+        for b in self.bufs:
+            if b["work"] is not None:
+                if self.cuda:
+                    with torch.cuda.stream(self.side):
+                        b["work"].wait()
+                else:
                     b["work"].wait()
                 b["work"] = None
-        self.side.synchronize()
-        torch.cuda.current_stream().synchronize()
+        if self.cuda:
+            self.side.synchronize()
+            torch.cuda.current_stream().synchronize()
+
+
+class StreamedGather(PayloadGather):
+    """PayloadGather fed by the device — what `bench.py --gpus N` runs: no host round trip per batch.
+
+    score_step: `hc_score_pack_device` — the scoring kernel's row-appending twin writes the payload itself (rows
+    unordered), then the all-gather on a side stream, overlapping the scoring kernel of the next batch.
+    step: for results that exist already: `hc_compact_pack_device` (hipCUB select + pack kernel, rows ordered) on the
+    side stream; call before_write(results) before overwriting a results tensor that a step may still be reading.
+    """
+
+    def __init__(self, scorer, n_local, base_index, cap_rows, group=None, depth=2):
+        super().__init__(cap_rows, group, depth, torch.device("cuda", torch.cuda.current_device()))
+        self.sc, self.n, self.base = scorer, int(n_local), int(base_index)
+        # zero-initialised: entries beyond the count of a batch are stale but always valid indices
+        self.idx = torch.zeros(max(self.n, 1), dtype=torch.int32, device=self.device)
+        self.count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.packed = {}  # data_ptr of a results tensor -> event: its rows have been packed, it may be overwritten
+
+    def score_step(self, d_in_ptr, d_results):
+        """Score this rank's n candidate records (device pointer) into d_results and collect the batch."""
+        b = self.next_buffers()
+        b["unordered"] = self.sc.score_pack_device(d_in_ptr, self.n, d_results.data_ptr(), self.cap, self.base, b["payload"].data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream)
+        return self.submit(b)
+
+    def before_write(self, d_results):
+        """The current stream waits until the batch that last used `d_results` has been read out of it."""
+        ev = self.packed.get(d_results.data_ptr())
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def step(self, d_results):
+        """Collect a batch whose n result records were written by work already enqueued on the current stream."""
+        b = self.next_buffers()
+        b["unordered"] = False
+        b["scored"].record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(b["scored"])
+            # (self.idx / self.count are shared: consecutive batches are ordered on the side stream)
+            self.sc.compact_pack_device(d_results.data_ptr(), self.n, self.idx.data_ptr(), self.count.data_ptr(), self.cap, self.base,
+                                        b["payload"].data_ptr(), self.side.cuda_stream)
+            b["packed"].record(self.side)
+            self.packed[d_results.data_ptr()] = b["packed"]
+            b["work"] = dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
+        return b

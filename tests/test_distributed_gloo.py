@@ -35,6 +35,34 @@ res["n_cls"] = ref["n"] | (ref["cls"].astype(np.uint32) << 28)
 rows, counts = parallel.gather_admitted(res, lo)
 np.save(os.path.join(os.environ["HC_OUT"], f"rows{rank}.npy"), rows.numpy())
 np.save(os.path.join(os.environ["HC_OUT"], f"counts{rank}.npy"), np.array(counts))
+# the form bench.py --gpus N runs: ONE all-gather per batch of a fixed-capacity payload (count in row 0), double
+# buffered; here the payload is packed on the host in the layout the device kernels write (rows unordered, as the
+# fused scoring kernel emits them), several batches in a row so that the buffers are reused
+kept = int((res["n_cls"] >> 28 != 0).sum())
+cap = torch.tensor([kept])
+dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+pg = parallel.PayloadGather(int(cap.item()) + 5, depth=2)
+last = None
+for it in range(5):
+    b = pg.next_buffers()
+    b["payload"].copy_(parallel.pack_payload(res, lo, pg.cap, shuffle_seed=100 * rank + it))
+    b["unordered"] = True
+    last = pg.submit(b)
+prows, pcounts = pg.collect(last)
+pg.finish()
+np.save(os.path.join(os.environ["HC_OUT"], f"prows{rank}.npy"), prows.numpy())
+np.save(os.path.join(os.environ["HC_OUT"], f"pcounts{rank}.npy"), np.array(pcounts))
+lowest = torch.tensor([kept])
+dist.all_reduce(lowest, op=dist.ReduceOp.MIN)  # one capacity for all ranks: the payloads must have one size
+small = parallel.PayloadGather(max(1, int(lowest.item()) // 3))
+b = small.next_buffers()
+b["payload"].copy_(parallel.pack_payload(res, lo, small.cap))
+try:
+    small.collect(small.submit(b))
+    overflow = False
+except OverflowError:
+    overflow = True
+np.save(os.path.join(os.environ["HC_OUT"], f"overflow{rank}.npy"), np.array([overflow]))
 dist.destroy_process_group()
 '''
 
@@ -69,6 +97,9 @@ def test_two_rank_gather_equals_single_process(oracle):
             assert p.returncode == 0, out.decode()[-2000:]
         rows0, rows1 = np.load(os.path.join(d, "rows0.npy")), np.load(os.path.join(d, "rows1.npy"))
         counts = np.load(os.path.join(d, "counts0.npy"))
+        prows = [np.load(os.path.join(d, f"prows{r}.npy")) for r in range(2)]
+        pcounts = [np.load(os.path.join(d, f"pcounts{r}.npy")) for r in range(2)]
+        overflow = [bool(np.load(os.path.join(d, f"overflow{r}.npy"))[0]) for r in range(2)]
     assert np.array_equal(rows0, rows1), "every rank must hold the same gathered set"
     reads, meta = synth.make_paired_dataset(500, 1500, flip_frac=0.2, seed=5)
     reads.quals[:] = ord("I")
@@ -79,3 +110,10 @@ def test_two_rank_gather_equals_single_process(oracle):
     assert np.array_equal(rows0[:, 0], want), "admitted set / order differs from the single-process run"
     assert np.array_equal(rows0[:, 1].view(np.float64).view(np.uint64), ref["x1"][want].view(np.uint64))
     assert counts.sum() == want.size and len(counts) == 2
+    # the single-all-gather payload form: every non-dropped record (edges and non-edges), on both ranks, in global order
+    kept = np.nonzero(ref["cls"] != 0)[0]
+    assert np.array_equal(prows[0], prows[1]) and np.array_equal(pcounts[0], pcounts[1]) and pcounts[0].sum() == kept.size
+    assert np.array_equal(prows[0][:, 0], kept)
+    assert np.array_equal(prows[0][:, 1].view(np.float64).view(np.uint64), ref["x1"][kept].view(np.uint64))
+    assert np.array_equal(prows[0][:, 3] >> 60, ref["cls"][kept].astype(np.int64))
+    assert overflow == [True, True]
