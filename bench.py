@@ -240,7 +240,11 @@ def main():
     # appends them (tagged with their global index) to a payload whose row 0 is the count, so the all-gather-v is ONE
     # all-gather over RCCL per step, on a side stream, overlapping the scoring kernel of the next step; nothing
     # synchronises with the host inside a step (parallel.StreamedGather).
-    stream = torch.cuda.current_stream().cuda_stream
+    # an explicit (non-default) stream for the scoring launches: events and the collection's side stream order
+    # against it by themselves, without leaning on the legacy default stream's implicit synchronisation
+    launch_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(launch_stream)
+    stream = launch_stream.cuda_stream
     gather = None
     if with_gather:
         from haploconduct_amd import parallel
