@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2")
-    ap.add_argument("--err", type=float, default=0.0, help="rust-overlaps err_rate (SAVAGE stage a passes 0, POLYTE 0.02)")
+    ap.add_argument("--err", type=float, default=0.0, help="rust-overlaps err_rate (SAVAGE stage a passes 1/200: exact matching below 200 bp; de novo / POLYTE 0.02)")
     ap.add_argument("--min-overlap", type=int, default=90, help="rust-overlaps threshold (SAVAGE: 60 %% of the read length)")
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
