@@ -274,6 +274,11 @@ private:
 
     void check_input() {
         if (in_.n_srs >= 0xFFFFFFFFull) throw FatalError{HC_ERR_ARG, "too many super-reads"};
+        // single_SR_vec comes before paired_SR_vec (:893-906): the order of nodes_to_SR decides which combination of a
+        // pair of super-reads is met first, i.e. it is observable
+        for (uint64_t i = 1; i < in_.n_srs; ++i)
+            if (in_.srs && in_.srs[i - 1].paired && !in_.srs[i].paired)
+                throw FatalError{HC_ERR_ARG, "super-reads must be listed single-end first, then paired (single_SR_vec, paired_SR_vec)"};
         if (in_.n_nodes >= ((uint64_t)1 << 32)) throw FatalError{HC_ERR_ARG, "too many vertices"};
         if ((in_.n_nodes && !in_.nodes) || (in_.n_srs && (!in_.srs || !in_.clique_off || !in_.subread_off)))
             throw FatalError{HC_ERR_ARG, "null array"};

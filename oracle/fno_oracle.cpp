@@ -368,6 +368,8 @@ struct Fno1 {
     }
 
     void run() {
+        for (uint64_t i = 1; i < in->n_srs; ++i)  // single_SR_vec, then paired_SR_vec (:893-906)
+            if (in->srs[i - 1].paired && !in->srs[i].paired) throw RefAbort{"input contract: super-reads single-end first, then paired"};
         for (uint64_t i = 0; i < in->n_nodes; ++i) nodes.push_back(rd_of(in->nodes[i]));
         for (uint64_t i = 0; i < in->n_srs; ++i) {
             Sr s;

@@ -103,6 +103,8 @@ def fno1_scenario(seed, n_nodes=40, n_srs=14, n_edges=120, paired_frac=0.4, flag
         pool = np.flatnonzero(paired) if (p and paired.sum() >= 2) else np.arange(n_nodes)
         cliques.append(rng.choice(pool, size=min(k, len(pool)), replace=False).astype(np.uint64))
         sr_paired.append(p)
+    order = sorted(range(n_srs), key=lambda i: sr_paired[i])  # single_SR_vec before paired_SR_vec (the API's contract)
+    cliques, sr_paired = [cliques[i] for i in order], [sr_paired[i] for i in order]
     visited = np.zeros(n_nodes, bool)
     for c in cliques:
         visited[c.astype(int)] = True

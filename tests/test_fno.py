@@ -284,3 +284,16 @@ def test_edges_from_records_roundtrip():
     e = F.edges_from_records(r)
     assert e["v1"].tolist() == [3, 4] and e["ord"].tolist() == [ord("-"), ord("2")] and (e["score"] == 0).all()
     assert e["len2"].tolist() == [0, 70] and e["ori1"].tolist() == [1, 0]
+
+
+def test_super_read_order_is_part_of_the_contract(olib):
+    """single_SR_vec before paired_SR_vec: the order of nodes_to_SR decides which combination of two super-reads is met
+    first, so an input that lists a paired super-read before a single one is refused, not silently reordered."""
+    inp = T.fno1_scenario(4, paired_frac=0.5)
+    assert inp.srs["paired"].any() and not inp.srs["paired"].all()
+    inp.srs["paired"] = inp.srs["paired"][::-1].copy()
+    with pytest.raises(HcError) as ei:
+        F.find_next_overlaps(inp)
+    assert ei.value.status == -1 and "single-end first" in str(ei.value)
+    with pytest.raises(T.OracleAbort):
+        T.oracle_fno1(olib, inp)

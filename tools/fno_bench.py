@@ -29,7 +29,7 @@ def big_fno1(n_nodes, n_srs, n_edges, seed=1):
     nodes["id"] = np.where(visited, 0, np.cumsum(~visited) - 1)
     n_unvisited = int((~visited).sum())
     srs = np.zeros(n_srs, F.FNO_READ_DTYPE)
-    sp = rng.random(n_srs) < 0.4
+    sp = np.sort(rng.random(n_srs) < 0.4)  # single-end super-reads first, then paired (the API's contract)
     srs["id"] = n_unvisited + np.arange(n_srs)
     srs["len1"], srs["len2"], srs["paired"] = rng.integers(300, 900, n_srs), np.where(sp, rng.integers(300, 900, n_srs), 0), sp
     sub = np.zeros(n_srs * k, F.FNO_SUBREAD_DTYPE)
@@ -107,6 +107,34 @@ def main():
         want, wc = T.oracle_fno1(lib, inp)
         res["oracle_s"] = round(time.perf_counter() - t, 3)
         res["identical_to_oracle"] = bool(want == ref_text and wc == cnt)
+    # the reference's own findNextOverlaps() (fragment probe, single thread as SRBuilder forces it, SRBuilder.h:92) on the
+    # same input without the stored non-edges (the one branch the probe cannot run), and the product on that input
+    import ctypes as C
+    import tempfile
+
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libhcref_fno.so")
+    if os.path.exists(ref_path):
+        ref = C.CDLL(ref_path)
+        vp = C.c_void_p
+        ref.frag_fno1_run.argtypes = [C.POINTER(F.hc_fno1_input), C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        ref.frag_fno_free.argtypes = [vp]
+        saved, inp.nonedges = inp.nonedges, np.zeros(0, F.FNO_EDGE_DTYPE)
+        inp.flags |= F.OPTIMIZE
+        inp.n_threads = 0
+        t = time.perf_counter()
+        ptext, pcnt = F.find_next_overlaps(inp)
+        tp = time.perf_counter() - t
+        s_, text, nb, nl = inp.struct(), vp(), C.c_uint64(), C.c_uint64()
+        with tempfile.TemporaryDirectory() as d:
+            t = time.perf_counter()
+            ref.frag_fno1_run(C.byref(s_), d.encode(), C.byref(text), C.byref(nb), C.byref(nl))
+            tr = time.perf_counter() - t
+        same = C.string_at(text, nb.value) == ptext
+        ref.frag_fno_free(text)
+        res["without_nonedges"] = {"lines": pcnt["n_lines"], "product_s": round(tp, 3), "reference_own_code_s": round(tr, 3),
+                                   "identical_to_reference": bool(same)}
+        inp.nonedges = saved
+        inp.flags &= ~F.OPTIMIZE
     print(json.dumps(res))
 
     inp3 = big_fno3(a.srs, a.nodes)
