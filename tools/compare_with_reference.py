@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""The whole bench workload (BASELINE config 2: 2 000 000 candidates) through the REFERENCE'S OWN compute_overlap /
+process_overlaps (fragment probe oracle/_ref/libhcref_edgecalc.so, one thread: the configuration with a defined insert
+order) and through the HIP stage; compares the two graphs edge by edge, bit by bit.  Takes about a minute of CPU."""
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import bench
+    import haploconduct_amd as hc
+    from haploconduct_amd import host, synth
+    from tests.test_ec_golden import compare_edges
+
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
+    spec = importlib.util.spec_from_file_location("make_golden_ec", os.path.join(ROOT, "tests", "golden", "make_golden_ec.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    reads, cand, cfg, st = bench.build_workload("c2", 0)
+    cand = cand[:n]
+    lines = synth.records_to_lines(cand, reads)
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so"))
+    ref.frag_process_overlaps.restype = C.c_int
+    ref.frag_process_overlaps.argtypes = [C.POINTER(mg.FragSettings), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_uint64, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
+    ref.frag_ec_free.argtypes = [C.c_void_p]
+    t0 = time.perf_counter()
+    edges, incl, nonedge, counters = mg.run_probe(ref, reads, lines, dict(edge_threshold=st.edge_threshold, ov_threshold=st.ov_threshold,
+                                                                          merge_contigs=st.merge_contigs, mismatch=st.mismatch,
+                                                                          min_read_len=st.min_read_len, ignore_inclusions=0))
+    t_ref = time.perf_counter() - t0
+    names = ["score", "mismatch_rate", "pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"]
+    want = {k: [e[i] for e in edges] for i, k in enumerate(names)}
+    for k in ("score", "mismatch_rate"):
+        want[k] = np.array([float.fromhex(x) for x in want[k]], np.float64)
+    d = tempfile.mkdtemp(prefix="hccmp_") + "/"
+    host.write_overlaps(d + "overlaps.txt", cand, reads)
+    reads.write_fastq(None, d + "p1.fastq", d + "p2.fastq")
+    st.min_overlap_len, st.min_overlap_perc, st.n_threads = 0, 0, 32
+    t0 = time.perf_counter()
+    with host.EdgeCalculatorStage(st, paired1=d + "p1.fastq", paired2=d + "p2.fastq", overlaps=d + "overlaps.txt", output_dir=d) as ec:
+        ec.construct_edges()
+        got, cnt = ec.edges(), ec.counters()
+    t_hip = time.perf_counter() - t0
+    compare_edges(got, want, "HIP stage vs the reference's own code")
+    assert open(d + "nonedge_overlaps.txt").read() == nonedge and cnt["dup_count"] == counters[1] and cnt["inclusion_count"] == counters[0]
+    print(json.dumps({"workload": cfg["workload"], "candidates": n, "edges": len(edges), "identical_graph": True,
+                      "reference_process_overlaps_1_thread_s": round(t_ref, 2), "hip_stage_open_plus_construct_edges_s": round(t_hip, 3)}))
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
