@@ -23,10 +23,11 @@ def main():
     from tests.test_ec_golden import compare_edges
 
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
+    workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
     spec = importlib.util.spec_from_file_location("make_golden_ec", os.path.join(ROOT, "tests", "golden", "make_golden_ec.py"))
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
-    reads, cand, cfg, st = bench.build_workload("c2", 0)
+    reads, cand, cfg, st = bench.build_workload(workload, 0)
     cand = cand[:n]
     lines = synth.records_to_lines(cand, reads)
     ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so"))
@@ -46,10 +47,12 @@ def main():
         want[k] = np.array([float.fromhex(x) for x in want[k]], np.float64)
     d = tempfile.mkdtemp(prefix="hccmp_") + "/"
     host.write_overlaps(d + "overlaps.txt", cand, reads)
-    reads.write_fastq(None, d + "p1.fastq", d + "p2.fastq")
+    paired = reads.is_paired(0)
+    fq = dict(paired1=d + "p1.fastq", paired2=d + "p2.fastq") if paired else dict(singles=d + "s.fastq")
+    reads.write_fastq(fq.get("singles"), fq.get("paired1"), fq.get("paired2"))
     st.min_overlap_len, st.min_overlap_perc, st.n_threads = 0, 0, 32
     t0 = time.perf_counter()
-    with host.EdgeCalculatorStage(st, paired1=d + "p1.fastq", paired2=d + "p2.fastq", overlaps=d + "overlaps.txt", output_dir=d) as ec:
+    with host.EdgeCalculatorStage(st, overlaps=d + "overlaps.txt", output_dir=d, **fq) as ec:
         ec.construct_edges()
         got, cnt = ec.edges(), ec.counters()
     t_hip = time.perf_counter() - t0
