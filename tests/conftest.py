@@ -10,15 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Make sure the in-tree native pieces exist (oracle + cross-compiled libhcedge.so) BEFORE the test modules are
+    # collected: they import haploconduct_amd, which refuses to load without its library.  `make` makes this a no-op
+    # when everything is up to date.
+    if not hasattr(config, "workerinput"):  # not in pytest-xdist workers
+        import __graft_entry__ as g
 
-
-@pytest.fixture(scope="session", autouse=True)
-def _build_everything():
-    """Make sure the in-tree native pieces exist (CPU: oracle + cross-compiled libhcedge.so)."""
-    import __graft_entry__ as g
-
-    g.build(quiet=True)
-    yield
+        g.build(quiet=True)
 
 
 @pytest.fixture(scope="session")
