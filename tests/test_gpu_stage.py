@@ -278,3 +278,66 @@ def test_stage_reproduces_the_references_own_process_overlaps(tmp_path, path):
     assert inc.tolist() == c["inclusions"]
     assert (out / "nonedge_overlaps.txt").read_text() == c["nonedge_overlaps"]
     assert cnt["inclusion_count"] == c["inclusion_count"] and cnt["dup_count"] == c["dup_count"]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HC_FUZZ_STAGE_SEEDS", "6"))))
+def test_fuzz_stage_against_oracle(oracle, tmp_path, seed):
+    """The whole stage on random inputs: read types, duplicates and strand twins shuffled in, junk lines, spaces,
+    random prefilter and scoring settings, random block size and thread count — graph, inclusions, non-edge file and
+    counters must equal the oracle's construct_edges."""
+    rng = np.random.default_rng(7000 + seed)
+    pyrng = random.Random(seed)
+    mode = seed % 3
+    if mode == 0:
+        reads, meta = synth.make_paired_dataset(int(rng.integers(200, 800)), int(rng.integers(600, 2500)), flip_frac=float(rng.choice([0, 0.3])),
+                                                seed=100 + seed)
+        reads.quals[:] = HQ[rng.integers(0, HQ.size, reads.quals.size)]
+        cand = synth.paired_candidates(meta, n_candidates=None, seed=seed)[: int(rng.integers(2000, 9000))]
+    elif mode == 1:
+        reads, meta = synth.make_single_dataset(int(rng.integers(200, 800)), int(rng.integers(1500, 6000)), len_lo=120, len_hi=int(rng.integers(200, 900)),
+                                                flip_frac=float(rng.choice([0, 0.4])), seed=100 + seed, quals=HQ, log_uniform=bool(rng.integers(0, 2)))
+        cand = synth.single_candidates(meta, min_overlap=int(rng.integers(40, 100)), n_candidates=None)[: int(rng.integers(2000, 9000))]
+    else:
+        from tests.test_gpu_parity import _mixed_reads
+        from haploconduct_amd.records import OVERLAP_DTYPE
+
+        reads, spos, ppos = _mixed_reads(300 + seed, n_single=120, n_pair=120, glen=1500)
+        ns = len(spos)
+        rec = []
+        for i, (s, L) in enumerate(spos):
+            for j, (ps, ins) in enumerate(ppos):
+                p1, p2 = ps - s, ps + ins - 150 - s
+                if 0 <= p1 < L - 40 and 0 <= p2 < L - 40:
+                    rec.append((i, ns + j, p1, p2, 1, 1, ord("-"), 2, min(L - p1, 150), min(L - p2, 150), 90))
+                q1, q2 = s - ps, ps + ins - 150 - s
+                if 0 <= q1 < 110 and 0 <= q2 < L - 40:
+                    rec.append((ns + j, i, q1, q2, 1, 1, ord("-"), 1, min(150 - q1, L), min(L - q2, 150), 90))
+        cand = np.array(rec, dtype=OVERLAP_DTYPE)
+    lines = synth.records_to_lines(cand, reads)
+    for ln in pyrng.sample(lines, len(lines) // 4):  # duplicates: replace / keep / tie-break chain
+        lines.insert(pyrng.randrange(len(lines)), ln)
+    for junk in ("", "a\tb", "   ", "1\t2\t3", "\t".join(["7"] * 14)):
+        lines.insert(pyrng.randrange(len(lines)), junk)
+    allow_spaces = bool(rng.integers(0, 2))
+    if allow_spaces:  # --allow_spaced_overlaps: spaces separate fields too
+        for k in pyrng.sample(range(len(lines)), len(lines) // 10):
+            if lines[k].count("\t") == 12:
+                lines[k] = "  " + lines[k].replace("\t", " \t", 3) + " "
+    from haploconduct_amd.records import FLAG_ALLOW_SPACES
+
+    flags = FLAG_RESOLVE_ORIENTATIONS | (FLAG_IGNORE_INCLUSIONS if rng.integers(0, 2) else 0) | (FLAG_RELAX_PE_EDGES if rng.integers(0, 2) else 0) | \
+        (FLAG_ALLOW_SPACES if allow_spaces else 0)
+    st = hc.Settings(edge_threshold=float(rng.choice([0.9, 0.97, 0.995, 1.0])), ov_threshold=float(rng.choice([0.0, 0.5, 0.9])),
+                     merge_contigs=float(rng.choice([0.0, 0.0, 0.01])), mismatch=float(rng.choice([0.0, 0.0, 0.02])),
+                     min_read_len=int(rng.choice([0, 0, 100])), min_overlap_len=int(rng.choice([0, 100, 150, 220])),
+                     min_overlap_perc=int(rng.choice([0, 0, 60])), flags=flags, max_overlaps=int(rng.choice([10 ** 8, 10 ** 8, len(lines) // 2])))
+    st.n_threads = int(rng.choice([1, 3, 8]))
+    os.environ["HC_STAGE_BLOCK"] = str(int(rng.choice([700, 5000, 250000])))
+    try:
+        edges, c = run_both(oracle, tmp_path, reads, lines, st, f"fz{seed}")
+        if os.environ.get("HC_FUZZ_REPORT"):  # coverage of the soak: what the scenarios actually exercised
+            with open(os.environ["HC_FUZZ_REPORT"], "a") as f:
+                f.write(f"{seed} mode={mode} lines={len(lines)} edges={edges.size} " + " ".join(f"{k}={c[k]}" for k in (
+                    "scored", "dup_count", "inclusion_count", "nonedges_written", "prefilter_rejected", "malformed_lines")) + "\n")
+    finally:
+        os.environ.pop("HC_STAGE_BLOCK", None)
