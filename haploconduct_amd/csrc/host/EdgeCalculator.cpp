@@ -7,7 +7,10 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <sys/mman.h>
 #include <cstring>
+#include <type_traits>
 #include <thread>
 
 namespace hc {
@@ -24,7 +27,7 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
                                const ProgramSettings& ps)
     : program_settings(ps), fastq_storage(std::move(fastq)), overlap_graph(std::move(graph)) {
     if (ps.add_duplicates) throw FatalError{HC_ERR_ARG, "--add_duplicates is not supported (the pipelines never set it)"};
-    if (const char* m = getenv("HC_INSERT_MODE")) m_sorted_insert = std::string(m) == "sorted";
+    if (const char* m = getenv("HC_INSERT_MODE")) m_serial_insert = std::string(m) == "serial";
     m_cs = to_hc_settings(ps);
     check(hc_create(&m_ctx, &m_cs), "hc_create");
     const FastqStorage& f = *fastq_storage;
@@ -68,6 +71,21 @@ double EdgeCalculator::overlap_score(const std::string& seq1, const std::string&
     return score;
 }
 
+void EdgeCalculator::collect_read_info() {
+    const FastqStorage& f = *fastq_storage;
+    m_read_info.resize(f.m_read_vec.size());
+    for (size_t i = 0; i < m_read_info.size(); i++) {
+        Read* r = f.m_read_vec[i];
+        ReadInfo& x = m_read_info[i];
+        x.read = r;
+        x.paired = r->is_paired();
+        x.len_a = r->get_seq_len(x.paired ? 1 : 0);
+        x.len_b = x.paired ? r->get_seq_len(2) : 0;
+        x.vertex_set = r->has_vertex_id(true);
+        x.vertex = x.vertex_set ? r->get_vertex_id(true) : 0;
+    }
+}
+
 // src/EdgeCalculator.cpp:395-414 (+ the Edge construction of compute_overlap): device scoring, then finalise and
 // build on a few host threads; sequence order is kept by concatenating the threads' pieces in order.
 void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) {
@@ -94,9 +112,10 @@ void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) 
     uint64_t n_kept = 0;
     check(hc_score_batch_compact(m_ctx, m_rec, n, m_idx, m_res, m_cap, &n_kept), "hc_score_batch_compact");
     stats.scored += n;
+    const double t_dev = now_s();
     if (program_settings.verbose) puts("build edges / write overlaps to file");
 
-    const FastqStorage& f = *fastq_storage;
+    if (m_read_info.size() != fastq_storage->m_read_vec.size()) collect_read_info();
     struct Piece {
         std::vector<Edge> edges;
         std::string nonedge_text;
@@ -105,7 +124,13 @@ void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) 
     };
     auto build = [&](uint64_t kb, uint64_t ke, Piece& pc) {
         char linebuf[192];
+        constexpr uint64_t kAhead = 12;  // the two rows of m_read_info are random places in a table of n_reads * 32 bytes
         for (uint64_t k = kb; k < ke; k++) {
+            if (k + kAhead < ke) {
+                const hc_overlap_rec& a = m_rec[m_idx[k + kAhead]];
+                __builtin_prefetch(&m_read_info[a.read1]);
+                __builtin_prefetch(&m_read_info[a.read2]);
+            }
             const size_t i = m_idx[k];
             const hc_result_rec& r = m_res[k];
             uint32_t cls = HC_RES_CLS(r);
@@ -134,26 +159,30 @@ void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) 
             }
             // build the Edge as compute_overlap does, :219-232 / :254-270 / :292-308 / :353-379
             const hc_overlap_rec& o = m_rec[i];
-            Read* r1 = f.m_read_vec[o.read1];
-            Read* r2 = f.m_read_vec[o.read2];
-            const bool p1 = r1->is_paired(), p2 = r2->is_paired();
+            const ReadInfo& i1 = m_read_info[o.read1];
+            const ReadInfo& i2 = m_read_info[o.read2];
+            if (!i1.vertex_set || !i2.vertex_set) {
+                pc.error = FatalError{HC_ERR_STATE, "Read::get_vertex_id: vertex id not set"};  // :180-183 asserts it
+                return;
+            }
+            const bool p1 = i1.paired, p2 = i2.paired;
             const int pos1 = (int)o.pos1, pos2 = (int)o.pos2;
             int pos3, pos4 = 0;
             if (!p1 && !p2) {
-                pos3 = (int)r1->get_seq_len(0) - pos1 - (int)r2->get_seq_len(0);                 // :222
+                pos3 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :222
             } else if (!p1 && p2) {
-                pos3 = (int)r1->get_seq_len(0) - pos2 - (int)r2->get_seq_len(2);                 // :262
-                pos4 = (int)r1->get_seq_len(0) - pos1 - (int)r2->get_seq_len(1);                 // :263
+                pos3 = (int)i1.len_a - pos2 - (int)i2.len_b;                 // :262
+                pos4 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :263
             } else if (p1 && !p2) {
-                pos3 = (int)r1->get_seq_len(2) + pos2 - (int)r2->get_seq_len(0);                 // :300
-                pos4 = (int)r2->get_seq_len(0) + pos1 - (int)r1->get_seq_len(1);                 // :301
+                pos3 = (int)i1.len_b + pos2 - (int)i2.len_a;                 // :300
+                pos4 = (int)i2.len_a + pos1 - (int)i1.len_a;                 // :301
             } else {
-                pos3 = o.ord == '1' ? (int)r1->get_seq_len(2) - pos2 - (int)r2->get_seq_len(2)   // :363
-                                    : (int)r1->get_seq_len(2) + pos2 - (int)r2->get_seq_len(2);  // :370
-                pos4 = (int)r1->get_seq_len(1) - pos1 - (int)r2->get_seq_len(1);                 // :372
+                pos3 = o.ord == '1' ? (int)i1.len_b - pos2 - (int)i2.len_b   // :363
+                                    : (int)i1.len_b + pos2 - (int)i2.len_b;  // :370
+                pos4 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :372
             }
-            Edge e(score, pos1, pos2, o.ori1 != 0, o.ori2 != 0, std::string(1, (char)o.ord), r1, r2);
-            e.set_vertices(r1->get_vertex_id(true), r2->get_vertex_id(true));  // :180-183
+            Edge e(score, pos1, pos2, o.ori1 != 0, o.ori2 != 0, std::string(1, (char)o.ord), i1.read, i2.read);
+            e.set_vertices(i1.vertex, i2.vertex);  // :180-183
             e.set_extra_pos(pos3, pos4);
             e.set_perc((int)o.perc);
             e.set_len((int)o.len1, (!p1 && !p2) ? 0 : (int)o.len2);  // :227 / :268
@@ -171,6 +200,7 @@ void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) 
         for (unsigned t = 0; t < T; t++) th.emplace_back([&, t] { build(n_kept * t / T, n_kept * (t + 1) / T, pieces[t]); });
         for (auto& x : th) x.join();
     }
+    const double t_built = now_s();
     size_t n_edges = 0;
     for (const Piece& pc : pieces) {
         if (pc.error.status) throw pc.error;  // the first one in sequence order
@@ -183,7 +213,13 @@ void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) 
         out.nonedges += pc.nonedges;
         stats.ambiguous += pc.ambiguous;
     }
-    stats.t_score += now_s() - t0;
+    const double t1 = now_s();
+    stats.t_score += t1 - t0;
+    if (static const bool detail = getenv("HC_STAGE_TIMING") != nullptr; detail) {  // where the score stage spends its time
+        static double dev = 0, build_s = 0, concat = 0;
+        dev += t_dev - t0, build_s += t_built - t_dev, concat += t1 - t_built;
+        fprintf(stderr, "[hc stage] score stage so far: device %.3f s, build %.3f s, concat %.3f s\n", dev, build_s, concat);
+    }
 }
 
 // src/EdgeCalculator.cpp:431-555: the serial half
@@ -193,7 +229,8 @@ void EdgeCalculator::insert_block(BuiltBlock& blk) {
     const uint64_t added_before = stats.edges_added;
     stats.nonedges_written += blk.nonedges;
     if (m_sorted_insert) {
-        m_admitted.insert(m_admitted.end(), blk.edges.begin(), blk.edges.end());  // resolved once, after the last block
+        m_admitted.emplace_back(std::move(blk.edges));  // resolved once, after the last block
+        blk.edges = std::vector<Edge>();
     } else {
         // The second read of an edge is a random place in the graph's slot index and in the in-lists: ask for the
         // slot and the list header 2*kAhead edges early, and for the end of the list (its header is in cache by
@@ -242,6 +279,13 @@ void EdgeCalculator::process_overlaps(const ParsedBatch& batch) {
 
 // src/EdgeCalculator.cpp:561-666
 void EdgeCalculator::construct_edges() {
+    collect_read_info();  // vertex ids may have been assigned since the last call
+    // An empty graph (every pipeline call) takes the bulk path: admitted edges are collected in sequence order and
+    // resolved + filled in once after the last block (resolve_admitted_edges).  A graph that already holds edges,
+    // or HC_INSERT_MODE=serial, takes the per-edge insert of the reference's serial half.
+    m_sorted_insert = !m_serial_insert && overlap_graph->getEdgeCount() == 0 &&
+                      EdgeSlotIndex::representable(overlap_graph->adj_out.size(), overlap_graph->adj_out.size());
+    m_admitted.clear();
     std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
     std::vector<Overlap> rejected;
     OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
@@ -323,7 +367,36 @@ void EdgeCalculator::construct_edges() {
     if (m_sorted_insert) {
         const double tr = now_s();
         InsertCounters ic;
-        resolve_admitted_edges(*overlap_graph, program_settings, m_admitted, ic);
+        // one array in sequence order (the blocks are copied side by side by a few threads), resolved and filled in
+        static_assert(std::is_trivially_copyable<Edge>::value, "Edge is copied with memcpy");
+        std::vector<size_t> at(m_admitted.size() + 1, 0);
+        for (size_t b = 0; b < m_admitted.size(); b++) at[b + 1] = at[b] + m_admitted[b].size();
+        const size_t total = at.back();
+        Edge* all = nullptr;
+        if (total) {
+            const size_t bytes = (total * sizeof(Edge) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            if (posix_memalign((void**)&all, (size_t)2 << 20, bytes) != 0) throw FatalError{HC_ERR_NOMEM, "construct_edges: out of memory"};
+            madvise(all, bytes, MADV_HUGEPAGE);  // a hint: 2 MiB pages where the system grants them (fewer first-touch faults)
+        }
+        {
+            const unsigned T = total < (1u << 16) ? 1u : std::max(1u, std::min<unsigned>(program_settings.n_threads, 16u));
+            std::vector<std::thread> th;
+            auto copy = [&](unsigned t) {
+                for (size_t b = t; b < m_admitted.size(); b += T)
+                    if (!m_admitted[b].empty()) memcpy((void*)(all + at[b]), (const void*)m_admitted[b].data(), m_admitted[b].size() * sizeof(Edge));
+            };
+            for (unsigned t = 1; t < T; t++) th.emplace_back(copy, t);
+            copy(0);
+            for (auto& x : th) x.join();
+        }
+        if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] admitted edges side by side: %.3f s\n", now_s() - tr);
+        try {
+            resolve_admitted_edges(*overlap_graph, program_settings, all, total, ic);
+        } catch (...) {
+            free(all);
+            throw;
+        }
+        free(all);
         inclusion_count += ic.inclusion_count;
         dup_count += ic.dup_count;
         stats.edges_added += ic.edges_added;
@@ -333,6 +406,8 @@ void EdgeCalculator::construct_edges() {
         }
         m_admitted.clear();
         m_admitted.shrink_to_fit();
+        if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] resolve total %.3f s\n", now_s() - tr);
+        m_sorted_insert = false;
         stats.t_insert += now_s() - tr;
     }
     stats.lines_read = pc.lines_read;

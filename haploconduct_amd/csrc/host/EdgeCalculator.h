@@ -38,8 +38,8 @@ void insert_edge(OverlapGraph& g, const ProgramSettings& ps, Edge& e, InsertCoun
 //   * an adjacency list holds its surviving edges in the order of their own insertion (a replaced
 //     edge is erased and the winner appended, :523-530), i.e. ordered by the survivors' sequence
 //     numbers: survivors are appended to the graph in that order.
-// The graph must not hold edges yet.  `admitted` is consumed (edges are normalised in place).
-void resolve_admitted_edges(OverlapGraph& g, const ProgramSettings& ps, std::vector<Edge>& admitted, InsertCounters& c);
+// The graph must not hold edges yet.  `admitted[0..n)` is consumed (edges are normalised in place).
+void resolve_admitted_edges(OverlapGraph& g, const ProgramSettings& ps, Edge* admitted, size_t n, InsertCounters& c);
 
 class EdgeCalculator {
 public:
@@ -75,6 +75,16 @@ private:
         std::string nonedge_text;  // lines for nonedge_overlaps.txt in sequence order
         uint64_t nonedges = 0;
     };
+    // What building an Edge needs to know about a read, in one 32-byte row instead of a walk over m_read_vec ->
+    // Read -> FastqStorage's offset arrays (five dependent, cold loads per read otherwise).
+    struct ReadInfo {
+        Read* read;
+        node_id_t vertex;       // get_vertex_id(true)
+        uint32_t len_a, len_b;  // get_seq_len(0) of a single-end read; get_seq_len(1), get_seq_len(2) of a pair
+        uint32_t paired, vertex_set;
+    };
+    std::vector<ReadInfo> m_read_info;
+    void collect_read_info();
     void score_and_build(const ParsedBatch& batch, BuiltBlock& out);
     void insert_block(BuiltBlock& blk);
     void process_overlaps(const ParsedBatch& batch);
@@ -86,8 +96,9 @@ private:
     hc_result_rec* m_res = nullptr;   // page-locked (hc_host_alloc), grow-only; compacted: records of the non-DROP candidates only
     uint32_t* m_idx = nullptr;        // their positions in the batch, ascending
     size_t m_cap = 0;
-    bool m_sorted_insert = false;     // HC_INSERT_MODE=sorted: resolve_admitted_edges() after the last batch instead of per-edge inserts
-    std::vector<Edge> m_admitted;     // admitted edges of the whole file, in sequence order (sorted insert)
+    bool m_serial_insert = false;     // HC_INSERT_MODE=serial: per-edge inserts even into an empty graph
+    bool m_sorted_insert = false;     // this construct_edges() call resolves the admitted edges after the last block
+    std::vector<std::vector<Edge>> m_admitted;  // admitted edges of the whole file, block by block in sequence order
 };
 
 }  // namespace hc

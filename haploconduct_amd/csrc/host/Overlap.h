@@ -13,6 +13,10 @@ public:
     // From the 13 tokens of a line (src/Overlap.h:39-73).  Throws FatalError where the
     // reference exits / asserts (negative pos/len, perc outside 0..100, bad ori/type/ord).
     static Overlap from_fields(const char* const field[13], const size_t len[13]);
+    // One pass over a line of the plain form — 13 fields, single tabs, decimal numbers (or "-"), valid one-character
+    // fields — filling `o` with exactly what the tokeniser + from_fields produce for it.  Returns false for every
+    // other line (malformed, padded, out of range, ...): those take the general path, which also owns all errors.
+    static bool from_plain_line(const char* line, size_t n, Overlap& o);
 
     read_id_t get_id(int i) const { return i == 1 ? m_id1 : m_id2; }
     int get_pos(int i) const { return (int)(i == 1 ? m_pos1 : m_pos2); }

@@ -56,6 +56,7 @@ public:
         }
     }
     void prefetch(uint64_t k) const { __builtin_prefetch(&tab_[slot_of(k)]); }
+    void bulk_add(const uint64_t* keys, size_t n, unsigned n_threads);  // add(keys[0..n)), on several threads
 
 private:
     struct Entry {
@@ -98,6 +99,8 @@ public:
         return vertex_to_read.size() - 1;
     }
     void addEdge(const Edge& edge);                       // :94-101
+    // the addEdge calls of pool[order[0]], pool[order[1]], ... as one parallel fill
+    void bulk_add_edges(const Edge* pool, const std::vector<uint32_t>& order, unsigned n_threads);
     Edge removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations);             // :150-194
     double checkEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) const;      // :198-229
     Edge* getEdgeInfoWithOri(node_id_t v, node_id_t w, bool opposite_orientations, bool reverse_allowed = true);  // :285-306

@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <condition_variable>
@@ -111,13 +112,15 @@ void OverlapsParser::parse_segment(Segment& seg) const {
             if (!(line_no < seg.line_limit)) break;  // `&& i < max_overlaps`, :581
             line_no++;
             seg.c.lines_read++;
-            const int nf = split_overlap_line(line, n, allow_spaces, field, flen, 14);
-            if (nf != 13) {  // :598-603
-                seg.c.malformed++;
-                continue;
-            }
             Overlap& o_slot = seg.out_line[seg.n_pass];  // becomes part of the block only if the line passes
-            o_slot = Overlap::from_fields(field, flen);
+            if (!Overlap::from_plain_line(line, n, o_slot)) {  // nearly every line is plain; the rest: the reference's steps
+                const int nf = split_overlap_line(line, n, allow_spaces, field, flen, 14);
+                if (nf != 13) {  // :598-603
+                    seg.c.malformed++;
+                    continue;
+                }
+                o_slot = Overlap::from_fields(field, flen);
+            }
             const Overlap& o = o_slot;
             if (o.m_id1 == o.m_id2) { seg.c.self_overlaps++; continue; }  // :605-607
             const unsigned int perc = o.get_perc();
@@ -293,46 +296,44 @@ bool OverlapsParser::next_batch(ParsedBatch& batch, size_t max_batch, std::vecto
     // pass 1: lines per segment (a final piece without a trailing newline is a line too)
     std::vector<uint64_t> nlines(T, 0);
     run([&](unsigned int t) {
-        uint64_t k = 0;
-        size_t p = segs[t].begin;
-        while (p < segs[t].end) {
-            const char* nl = (const char*)memchr(m_data + p, '\n', segs[t].end - p);
-            k++;
-            if (!nl) break;
-            p = (size_t)(nl - m_data) + 1;
-        }
+        // newline count, plus one for a final piece without a trailing newline
+        const char* b = m_data + segs[t].begin;
+        const char* e = m_data + segs[t].end;
+        uint64_t k = (uint64_t)std::count(b, e, '\n');
+        if (e > b && e[-1] != '\n') k++;
         nlines[t] = k;
     });
     uint64_t line = m_line_no;
-    size_t room = 0;
     for (unsigned int t = 0; t < T; t++) {
         segs[t].first_line = line;
         segs[t].line_limit = m_ps.max_overlaps;
         line += nlines[t];
-        room += nlines[t] + 1;  // one spare element per segment: a line is parsed in place before it is known to pass
     }
-    // pass 2: parse, every segment straight into its own stretch of the block
-    batch.ensure(room);
-    {
-        size_t at = 0;
-        for (unsigned int t = 0; t < T; t++) {
-            segs[t].out_line = batch.lines.data() + at;
-            segs[t].out_rec = batch.recs + at;
-            at += nlines[t] + 1;
+    // pass 2: parse, every segment into its own scratch (how many of its lines pass is not known before)
+    if (m_scratch.size() < T) m_scratch.resize(T);
+    run([&](unsigned int t) {
+        Scratch& sc = m_scratch[t];
+        const size_t room = nlines[t] + 1;  // one spare element: a line is parsed in place before it is known to pass
+        if (sc.lines.size() < room) {
+            sc.lines.resize(room + room / 8);
+            sc.recs.resize(room + room / 8);
         }
-    }
-    run([&](unsigned int t) { parse_segment(segs[t]); });
-    // close the gaps (lines that did not pass, the spare elements): nothing moves in front of the first gap
+        segs[t].out_line = sc.lines.data();
+        segs[t].out_rec = sc.recs.data();
+        parse_segment(segs[t]);
+    });
+    // pass 3: the passing candidates of all segments, concatenated in file order — copied by the same workers
+    // (a serial compaction of a 250 000-line block costs more than parsing it on 32 threads)
     {
-        size_t at = 0;
-        for (auto& sg : segs) {
-            if (sg.out_rec != batch.recs + at && sg.n_pass) {
-                memmove((void*)(batch.lines.data() + at), (const void*)sg.out_line, sg.n_pass * sizeof(Overlap));
-                memmove((void*)(batch.recs + at), (const void*)sg.out_rec, sg.n_pass * sizeof(hc_overlap_rec));
-            }
-            at += sg.n_pass;
-        }
-        batch.n = at;
+        std::vector<size_t> at(T + 1, 0);
+        for (unsigned int t = 0; t < T; t++) at[t + 1] = at[t] + segs[t].n_pass;
+        batch.ensure(at[T]);
+        run([&](unsigned int t) {
+            if (!segs[t].n_pass) return;
+            memcpy((void*)(batch.lines.data() + at[t]), (const void*)segs[t].out_line, segs[t].n_pass * sizeof(Overlap));
+            memcpy((void*)(batch.recs + at[t]), (const void*)segs[t].out_rec, segs[t].n_pass * sizeof(hc_overlap_rec));
+        });
+        batch.n = at[T];
     }
     for (auto& sg : segs) {
         c.lines_read += sg.c.lines_read;

@@ -112,6 +112,11 @@ private:
     void parse_segment(Segment& seg) const;
     class Pool;  // the parser's worker threads, started once
     std::unique_ptr<Pool> m_pool;
+    struct Scratch {  // where one segment parses to before its place in the block is known; kept between blocks
+        std::vector<Overlap> lines;
+        std::vector<hc_overlap_rec> recs;
+    };
+    std::vector<Scratch> m_scratch;
 
     const ProgramSettings& m_ps;
     const FastqStorage& m_fastq;

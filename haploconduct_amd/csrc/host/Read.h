@@ -21,6 +21,7 @@ public:
     void set_vertex_id(bool normal, node_id_t id) {                // src/Read.h:92-101
         if (normal) { m_vertex_N = id; m_N_set = true; } else { m_vertex_R = id; m_R_set = true; }
     }
+    bool has_vertex_id(bool normal) const { return normal ? m_N_set : m_R_set; }
     node_id_t get_vertex_id(bool normal) const;                    // src/Read.h:111-120 (asserts the id was set)
     // i = 0 for a single-end read, 1 / 2 for the mates of a pair (src/Read.h:144-201)
     std::string get_seq(int i) const;

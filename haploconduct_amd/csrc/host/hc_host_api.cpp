@@ -185,9 +185,12 @@ int hc_host_parse_overlap(const char* line, uint64_t n, int allow_spaces, hc_ove
     if (!line || !out) return set_last_error(HC_ERR_ARG, "hc_host_parse_overlap: null");
     const char* f[14];
     size_t l[14];
-    if (split_overlap_line(line, n, allow_spaces != 0, f, l, 14) != 13) return HC_ERR_ARG;
+    Overlap plain;
+    // as the stage does: the one-pass reader for plain lines first, the reference's steps for every other line
+    const bool is_plain = !(allow_spaces & 2) && Overlap::from_plain_line(line, n, plain);
+    if (!is_plain && split_overlap_line(line, n, (allow_spaces & 1) != 0, f, l, 14) != 13) return HC_ERR_ARG;
     return guarded("Overlap", [&] {
-        const Overlap o = Overlap::from_fields(f, l);
+        const Overlap o = is_plain ? plain : Overlap::from_fields(f, l);
         memset(out, 0, sizeof *out);
         out->id1 = o.m_id1; out->id2 = o.m_id2;
         out->pos1 = o.m_pos1; out->pos2 = o.m_pos2;
@@ -314,7 +317,7 @@ int hc_host_graph_resolve(hc_host_graph* g, const hc_edge_rec* edges, uint64_t n
             e.set_mismatch(r->mismatch_rate);
             adm.push_back(e);
         }
-        resolve_admitted_edges(*g->graph, g->ps, adm, g->counters);
+        resolve_admitted_edges(*g->graph, g->ps, adm.data(), adm.size(), g->counters);
     });
 }
 

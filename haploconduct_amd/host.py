@@ -93,11 +93,11 @@ def split_line(line, allow_spaces=False, max_fields=32):
     return n, [raw[int(off[i]):int(off[i] + ln[i])].decode() for i in range(min(n, max_fields))]
 
 
-def parse_overlap(line, allow_spaces=False):
+def parse_overlap(line, allow_spaces=False, general_only=False):
     raw = line if isinstance(line, bytes) else line.encode()
     o = hc_overlap_fields()
     text = C.create_string_buffer(256)
-    rc = N.lib.hc_host_parse_overlap(raw, len(raw), 1 if allow_spaces else 0, C.byref(o), text)
+    rc = N.lib.hc_host_parse_overlap(raw, len(raw), (1 if allow_spaces else 0) | (2 if general_only else 0), C.byref(o), text)
     if rc:
         return rc, None
     return 0, {"id1": o.id1, "id2": o.id2, "pos1": o.pos1, "pos2": o.pos2, "ord": o.ord.decode(), "ori1": o.ori1.decode(),

@@ -70,7 +70,10 @@ int hc_host_split_line(const char* line, uint64_t n, int allow_spaces, uint32_t*
 
 /* Overlap(std::vector<std::string>) + get_perc + get_overlap_line (src/Overlap.h:39-237) on one text
  * line.  Returns HC_OK, HC_ERR_ARG when the line does not have 13 fields, or HC_ERR_FORMAT where the
- * reference exits/asserts.  `text` (>= 192 bytes) receives the re-serialised line. */
+ * reference exits/asserts.  `text` (>= 192 bytes) receives the re-serialised line.
+ * `allow_spaces`: bit 0 = --allow_spaced_overlaps; bit 1 = skip the one-pass reader the stage tries first on every
+ * line (13 plain fields, single tabs) and go through the tokeniser + Overlap constructor steps only — both routes
+ * must agree on every line, tests/test_host_logic.py. */
 typedef struct hc_overlap_fields {
     uint64_t id1, id2;
     uint32_t pos1, pos2, perc1, perc2, len1, len2, perc;

@@ -212,3 +212,70 @@ def test_serial_insert_and_tie_break_chain_match_oracle(oracle):
         edges2, inc2, c2 = g2.get()
         assert edges2.tobytes() == edges.tobytes() and np.array_equal(inc2, inc)
         assert (c2["dup_count"], c2["inclusion_count"], c2["edges_added"]) == (c["dup_count"], c["inclusion_count"], c["edges_added"])
+
+
+def test_parallel_resolution_and_bulk_fill_match_the_serial_insert():
+    """Enough edges for the threaded phases (slot partitions, vertex-range fill, concurrent slot index): the graph after
+    resolve() must equal the one the per-edge insert leaves, and must keep behaving like it for later inserts."""
+    rng = random.Random(5)
+    for flags, V, n_threads in ((hc.records.FLAG_RESOLVE_ORIENTATIONS, 900, 8),
+                                (hc.records.FLAG_RESOLVE_ORIENTATIONS | hc.records.FLAG_IGNORE_INCLUSIONS, 5000, 3),
+                                (hc.records.FLAG_RESOLVE_ORIENTATIONS, 40, 32)):
+        st = hc.Settings(flags=flags, n_threads=n_threads)
+        stream = _random_edge_stream(rng, V, 40000)
+        later = _random_edge_stream(rng, V, 3000)
+        g = host.HostGraph(V, st)
+        for e in stream:
+            assert g.insert(e.copy()) == 0
+        g2 = host.HostGraph(V, st)
+        assert g2.resolve(stream) == 0
+        edges, inc, c = g.get()
+        edges2, inc2, c2 = g2.get()
+        assert edges2.tobytes() == edges.tobytes() and np.array_equal(inc2, inc)
+        assert (c2["dup_count"], c2["inclusion_count"], c2["edges_added"]) == (c["dup_count"], c["inclusion_count"], c["edges_added"])
+        for e in later:
+            assert g.insert(e.copy()) == 0 and g2.insert(e.copy()) == 0
+        edges, inc, c = g.get()
+        edges2, inc2, c2 = g2.get()
+        assert edges2.tobytes() == edges.tobytes() and np.array_equal(inc2, inc)
+        assert (c2["dup_count"], c2["inclusion_count"], c2["edges_added"]) == (c["dup_count"], c["inclusion_count"], c["edges_added"])
+
+
+def test_one_pass_line_reader_agrees_with_the_general_path(oracle):
+    """The stage reads plain lines in one pass (Overlap::from_plain_line) and everything else through the reference's
+    tokenise + construct steps; mutate valid lines character by character and require both routes — and the oracle —
+    to agree on acceptance and on every field."""
+    rng = random.Random(17)
+
+    def valid():
+        t1, t2 = rng.choice("sp"), rng.choice("sp")
+        ss = t1 == t2 == "s"
+        return "\t".join([str(rng.choice([0, 7, 10, 123456, 99999999, 123456789012345678])), str(rng.randrange(5000)),
+                          str(rng.randrange(300)), "-" if ss else str(rng.randrange(300)), rng.choice("12") if t1 == t2 == "p" else "-",
+                          rng.choice("+-"), rng.choice("+-"), str(rng.randrange(101)), "-" if ss else str(rng.randrange(101)),
+                          str(rng.randrange(1, 999999999)), "-" if ss else str(rng.randrange(500)), t1, t2])
+
+    junk = ["\t", " ", "0", "9", "-", "+", "x", "s", "p", "1", "\r", "00", "1234567890", "0x1f", "101", ""]
+    n_plain = n_general = n_bad = 0
+    for it in range(6000):
+        line = valid()
+        for _ in range(rng.choice([0, 0, 1, 1, 2, 4])):
+            k = rng.randrange(len(line) + 1)
+            line = line[:k] + rng.choice(junk) + line[k + rng.choice([0, 1, 1]):]
+        for sp in (False, True):
+            rc, o = host.parse_overlap(line, sp)
+            rc2, o2 = host.parse_overlap(line, sp, general_only=True)
+            assert rc == rc2 and o == o2, (line, sp, rc, rc2, o, o2)
+            n, toks = oracle.split_line(line, sp)
+            if n != 13:
+                assert rc == -1, line
+                n_bad += 1
+                continue
+            orc, oo = oracle.parse_fields(toks)
+            assert (rc == 0) == (orc == 0), (line, rc, orc)
+            if rc == 0:
+                assert o == oo, line
+                n_plain += 1
+            else:
+                n_general += 1
+    assert n_plain > 4000 and n_general > 500 and n_bad > 500

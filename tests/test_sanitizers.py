@@ -82,6 +82,20 @@ for _ in range(5000):
     assert host.hc_host_graph_insert(g, rec) == 0
 host.hc_host_graph_free(g)
 
+# 3a. the threaded resolution + bulk fill (slot partitions, vertex-range fill, concurrent slot index), then serial inserts on top
+g = C.c_void_p(); st = S(0.97, 0.9, 0, 0, 0, 10, 0, 2 | 4, 10**8, 0, 8)
+assert host.hc_host_graph_new(C.byref(g), 400, C.byref(st)) == 0
+recs = []
+for _ in range(30000):
+    a, b = rng.sample(range(400), 2)
+    recs.append(struct.pack("<ddiiiiBBBBIIIQQiiii", rng.choice([0.97, 0.98, 1.0]), rng.choice([0.0, 0.1]), rng.choice([0, 3]), 0, rng.choice([-2, 2]), 0,
+                            rng.randrange(2), rng.randrange(2), ord(rng.choice("-12")), 0, a, b, 0, a, b, rng.choice([100, 50]), 100, 100, 0))
+host.hc_host_graph_resolve.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+assert host.hc_host_graph_resolve(g, b"".join(recs), len(recs)) == 0
+for r in recs[:2000]:
+    assert host.hc_host_graph_insert(g, r) == 0
+host.hc_host_graph_free(g)
+
 # 3b. SFO ingest on plausible and hostile files
 host.hc_sfo2overlaps.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p]
 sfo = []
