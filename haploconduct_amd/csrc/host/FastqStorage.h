@@ -43,6 +43,7 @@ private:
     void read_pairs(const std::string& p1, const std::string& p2, unsigned long max_reads);
     void push_sequence(const char* s, size_t ns, const char* q, size_t nq, bool upper);
     read_id_t resolve_id(const std::string& token) const;
+    read_id_t resolve_id(const char* token, size_t n) const;
 
     std::map<std::string, std::string> m_new_readIDs;    // fastq id -> overlaps-file id (--IDs)
     bool m_have_new_ids = false;

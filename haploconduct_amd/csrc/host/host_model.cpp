@@ -1,7 +1,13 @@
 // host_model.cpp — Read, FastqStorage, Overlap, OverlapGraph: the host-side mirror of the
 // reference's data model for the edge-calculation path.  Own implementation; every routine
 // cites the reference lines whose behaviour it reproduces.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -74,24 +80,89 @@ unsigned int Read::get_len() const {  // src/Read.h:203-212
 }
 
 // ------------------------------------------------------------------ FastqStorage
-static bool read_lines(const std::string& path, uint64_t max_lines, std::vector<std::string>& out) {  // src/FastqStorage.cpp:42-57
-    std::ifstream f(path.c_str());
-    if (!f.is_open()) return false;
-    std::string line;
-    uint64_t count = 0;
-    while (std::getline(f, line) && count < max_lines) {
-        out.push_back(line);
-        count++;
+// The lines of a file as std::getline yields them (src/FastqStorage.cpp:42-57: split at '\n' only, a final piece
+// without a newline is a line, nothing after a trailing newline), at most max_lines of them, over a read-only mapping
+// instead of one std::string per line.
+class LineFile {
+public:
+    LineFile(const std::string& path, uint64_t max_lines) : m_left(max_lines) {
+        m_fd = open(path.c_str(), O_RDONLY);
+        if (m_fd < 0) return;
+        struct stat st;
+        if (fstat(m_fd, &st) != 0 || !S_ISREG(st.st_mode)) {  // not mappable (a pipe, ...): read it whole
+            FILE* f = fdopen(m_fd, "rb");
+            if (!f) { close(m_fd); m_fd = -1; return; }
+            char buf[1 << 16];
+            size_t k;
+            while ((k = fread(buf, 1, sizeof buf, f)) > 0) m_owned.append(buf, k);
+            fclose(f);
+            m_fd = -1;
+            m_p = m_owned.data();
+            m_end = m_p + m_owned.size();
+            m_ok = true;
+            return;
+        }
+        m_size = (size_t)st.st_size;
+        if (m_size) {
+            void* p = mmap(nullptr, m_size, PROT_READ, MAP_PRIVATE, m_fd, 0);
+            if (p == MAP_FAILED) { close(m_fd); m_fd = -1; return; }
+            madvise(p, m_size, MADV_SEQUENTIAL);
+            m_map = p;
+            m_p = (const char*)p;
+            m_end = m_p + m_size;
+        }
+        m_ok = true;
     }
-    return true;
+    ~LineFile() {
+        if (m_map) munmap(m_map, m_size);
+        if (m_fd >= 0) close(m_fd);
+    }
+    LineFile(const LineFile&) = delete;
+    LineFile& operator=(const LineFile&) = delete;
+    bool is_open() const { return m_ok; }
+    size_t bytes() const { return (size_t)(m_end - m_p); }
+    // the next four lines, or false when fewer than four are left (an incomplete record is ignored, :109 / :170)
+    bool next4(const char* line[4], size_t len[4]) {
+        if (m_left < 4) return false;
+        const char* p = m_p;
+        for (int k = 0; k < 4; k++) {
+            if (p >= m_end) return false;
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(m_end - p));
+            line[k] = p;
+            len[k] = nl ? (size_t)(nl - p) : (size_t)(m_end - p);
+            p = nl ? nl + 1 : m_end;
+        }
+        m_p = p;
+        m_left -= 4;
+        return true;
+    }
+
+private:
+    int m_fd = -1;
+    void* m_map = nullptr;
+    size_t m_size = 0;
+    std::string m_owned;
+    const char* m_p = nullptr;
+    const char* m_end = nullptr;
+    uint64_t m_left;
+    bool m_ok = false;
+};
+
+// `stream >> id` on the header line without its first character: the first whitespace-delimited token
+static void first_token(const char* s, size_t n, const char*& tok, size_t& tok_len) {
+    size_t a = n ? 1 : 0;
+    while (a < n && isspace((unsigned char)s[a])) a++;
+    size_t b = a;
+    while (b < n && !isspace((unsigned char)s[b])) b++;
+    tok = s + a;
+    tok_len = b - a;
 }
 
-static std::string first_token(const std::string& s) {  // `stream >> id1` on line.substr(1)
-    size_t a = 0;
-    while (a < s.size() && isspace((unsigned char)s[a])) a++;
-    size_t b = a;
-    while (b < s.size() && !isspace((unsigned char)s[b])) b++;
-    return s.substr(a, b - a);
+unsigned long parse_id(const char* p, size_t n);
+
+read_id_t FastqStorage::resolve_id(const char* tok, size_t n) const {  // src/FastqStorage.cpp:112-117
+    if (m_have_new_ids) return resolve_id(std::string(tok, n));
+    return parse_id(tok, n);  // str_to_read_id
 }
 
 read_id_t FastqStorage::resolve_id(const std::string& token) const {  // src/FastqStorage.cpp:112-117
@@ -129,45 +200,60 @@ void FastqStorage::read_new_ids(const std::string& path) {  // src/FastqStorage.
 void FastqStorage::push_sequence(const char* s, size_t ns, const char* q, size_t nq, bool upper) {
     if (ns != nq)  // the reference would index past the shorter string (.at() throws) or misalign rev_phred
         throw FatalError{HC_ERR_BAD_READ, "FASTQ record with sequence and quality strings of different length"};
+    static const std::array<uint8_t, 256> up = [] {  // toupper() once per byte value instead of once per base
+        std::array<uint8_t, 256> t{};
+        for (int c = 0; c < 256; c++) t[(size_t)c] = (uint8_t)toupper(c);
+        return t;
+    }();
     const size_t o = m_bases.size();
-    m_bases.resize(o + ns);
-    m_quals.resize(o + ns);
-    for (size_t i = 0; i < ns; i++) m_bases[o + i] = upper ? (uint8_t)toupper((unsigned char)s[i]) : (uint8_t)s[i];
-    memcpy(m_quals.data() + o, q, ns);
+    m_bases.insert(m_bases.end(), (const uint8_t*)s, (const uint8_t*)s + ns);
+    if (upper)
+        for (size_t i = 0; i < ns; i++) m_bases[o + i] = up[m_bases[o + i]];
+    m_quals.insert(m_quals.end(), (const uint8_t*)q, (const uint8_t*)q + ns);
     m_seq_off.push_back(o + ns);
 }
 
 void FastqStorage::read_singles(const std::string& path, unsigned long max_reads) {  // src/FastqStorage.cpp:92-152
-    std::vector<std::string> lines;
-    if (!read_lines(path, 4ull * (unsigned int)max_reads, lines)) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + path};
-    for (size_t r = 0; r + 3 < lines.size(); r += 4) {
-        const std::string& h = lines[r];
-        if (h.empty() || h[0] != '@') throw FatalError{HC_ERR_FORMAT, "Read ID does not start with @. Exiting read_singles."};
-        const read_id_t id = resolve_id(first_token(h.substr(1)));
-        const std::string& seq = lines[r + 1];
-        const std::string& ph = lines[r + 3];
-        if (seq.empty()) throw FatalError{HC_ERR_BAD_READ, "single read with ID " + std::to_string(id) + " has an empty sequence... exiting."};
-        push_sequence(seq.data(), seq.size(), ph.data(), ph.size(), /*upper=*/true);  // boost::to_upper_copy, :122
+    LineFile f(path, 4ull * (unsigned int)max_reads);
+    if (!f.is_open()) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + path};
+    m_bases.reserve(m_bases.size() + f.bytes() / 2);
+    m_quals.reserve(m_quals.size() + f.bytes() / 2);
+    const char* l[4];
+    size_t n[4];
+    while (f.next4(l, n)) {
+        if (n[0] == 0 || l[0][0] != '@') throw FatalError{HC_ERR_FORMAT, "Read ID does not start with @. Exiting read_singles."};
+        const char* tok;
+        size_t tn;
+        first_token(l[0], n[0], tok, tn);
+        const read_id_t id = resolve_id(tok, tn);
+        if (n[1] == 0) throw FatalError{HC_ERR_BAD_READ, "single read with ID " + std::to_string(id) + " has an empty sequence... exiting."};
+        push_sequence(l[1], n[1], l[3], n[3], /*upper=*/true);  // boost::to_upper_copy, :122
         m_first.push_back(m_first.back() + 1);
         m_singles_vec.emplace_back(this, 0u, false, id);
     }
 }
 
 void FastqStorage::read_pairs(const std::string& p1, const std::string& p2, unsigned long max_reads) {  // :154-235
-    std::vector<std::string> l1, l2;
-    if (!read_lines(p1, 4ull * (unsigned int)max_reads, l1)) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + p1};
-    if (!read_lines(p2, 4ull * (unsigned int)max_reads, l2)) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + p2};
-    const size_t n = std::min(l1.size(), l2.size());
-    for (size_t r = 0; r + 3 < n; r += 4) {
-        if (l1[r].empty() || l1[r][0] != '@') throw FatalError{HC_ERR_FORMAT, "Read ID does not start with @. Exiting read_pairs."};
-        const std::string id1 = first_token(l1[r].substr(1));
-        const std::string id2 = first_token(l2[r].empty() ? std::string() : l2[r].substr(1));
-        if (id1 != id2) throw FatalError{HC_ERR_FORMAT, "Fastq files /1 /2 are not ordered identically. Exiting read_pairs."};
-        const read_id_t id = resolve_id(id1);
-        if (l1[r + 1].empty() || l2[r + 1].empty())
+    LineFile f1(p1, 4ull * (unsigned int)max_reads);
+    if (!f1.is_open()) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + p1};
+    LineFile f2(p2, 4ull * (unsigned int)max_reads);
+    if (!f2.is_open()) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + p2};
+    m_bases.reserve(m_bases.size() + (f1.bytes() + f2.bytes()) / 2);
+    m_quals.reserve(m_quals.size() + (f1.bytes() + f2.bytes()) / 2);
+    const char *l1[4], *l2[4];
+    size_t n1[4], n2[4];
+    while (f1.next4(l1, n1) && f2.next4(l2, n2)) {  // records up to the shorter file, :170
+        if (n1[0] == 0 || l1[0][0] != '@') throw FatalError{HC_ERR_FORMAT, "Read ID does not start with @. Exiting read_pairs."};
+        const char *t1, *t2;
+        size_t tn1, tn2;
+        first_token(l1[0], n1[0], t1, tn1);
+        first_token(l2[0], n2[0], t2, tn2);
+        if (tn1 != tn2 || memcmp(t1, t2, tn1) != 0) throw FatalError{HC_ERR_FORMAT, "Fastq files /1 /2 are not ordered identically. Exiting read_pairs."};
+        const read_id_t id = resolve_id(t1, tn1);
+        if (n1[1] == 0 || n2[1] == 0)
             throw FatalError{HC_ERR_BAD_READ, "paired read with ID " + std::to_string(id) + " has an empty sequence... exiting."};
-        push_sequence(l1[r + 1].data(), l1[r + 1].size(), l1[r + 3].data(), l1[r + 3].size(), /*upper=*/false);  // pairs are NOT upper-cased, :197-198
-        push_sequence(l2[r + 1].data(), l2[r + 1].size(), l2[r + 3].data(), l2[r + 3].size(), false);
+        push_sequence(l1[1], n1[1], l1[3], n1[3], /*upper=*/false);  // pairs are NOT upper-cased, :197-198
+        push_sequence(l2[1], n2[1], l2[3], n2[3], false);
         m_first.push_back(m_first.back() + 2);
         m_paired_vec.emplace_back(this, 0u, true, id);
     }
@@ -188,13 +274,13 @@ FastqStorage::FastqStorage(const ProgramSettings& ps) {  // src/FastqStorage.h:5
     for (auto& r : m_singles_vec) {
         r = Read(this, count, false, r.get_read_id());
         m_read_vec.push_back(&r);
-        m_ID_to_index.insert(std::make_pair(r.get_read_id(), count));
+        m_ID_to_index.emplace_hint(m_ID_to_index.end(), r.get_read_id(), count);  // first occurrence wins, as insert(); ids mostly ascend
         count++;
     }
     for (auto& r : m_paired_vec) {
         r = Read(this, count, true, r.get_read_id());
         m_read_vec.push_back(&r);
-        m_ID_to_index.insert(std::make_pair(r.get_read_id(), count));
+        m_ID_to_index.emplace_hint(m_ID_to_index.end(), r.get_read_id(), count);
         count++;
     }
 }
@@ -217,7 +303,7 @@ static bool all_digits(const char* p, size_t n) {
     return true;
 }
 
-static unsigned long parse_id(const char* p, size_t n) {  // strtoul(s, NULL, 0), src/Types.h:99-102
+unsigned long parse_id(const char* p, size_t n) {  // strtoul(s, NULL, 0), src/Types.h:99-102
     if (all_digits(p, n) && (p[0] != '0' || n == 1)) {
         unsigned long v = 0;
         for (size_t i = 0; i < n; i++) v = v * 10 + (unsigned long)(p[i] - '0');

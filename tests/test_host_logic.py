@@ -279,3 +279,29 @@ def test_one_pass_line_reader_agrees_with_the_general_path(oracle):
             else:
                 n_general += 1
     assert n_plain > 4000 and n_general > 500 and n_bad > 500
+
+
+def test_fastq_reader_line_semantics(tmp_path):
+    """std::getline semantics of the reference's reader (src/FastqStorage.cpp:42-57) over the mapped file: lines end
+    at '\\n' only, a last line without a newline counts, an incomplete record is ignored, the shorter mate file bounds
+    the pairs, --max_reads counts records."""
+    f = host.Fastq(singles=_write(tmp_path / "a.fastq", "@1\nACGT\n+\nIIII\n@2\nGG\n+\n55"))       # no newline at the end
+    assert f.read_ids.tolist() == [1, 2] and f.readset().seq(1) == (b"GG", b"55")
+    f = host.Fastq(singles=_write(tmp_path / "b.fastq", "@1\nACGT\n+\nIIII\n@2\nGG\n+\n"))          # fourth line missing
+    assert f.read_ids.tolist() == [1]
+    with pytest.raises(hc.HcError):                                                                   # ... but an empty fourth line is a line
+        host.Fastq(singles=_write(tmp_path / "b2.fastq", "@1\nACGT\n+\nIIII\n@2\nGG\n+\n\n"))
+    f = host.Fastq(singles=_write(tmp_path / "c.fastq", ""))
+    assert f.n_reads == 0
+    f = host.Fastq(singles=_write(tmp_path / "d.fastq", "@7\tx\nAC\r\n+\nII\r\n"))                   # '\\r' stays part of the line
+    assert f.readset().seq(0) == (b"AC\r", b"II\r")
+    f = host.Fastq(singles=_write(tmp_path / "e.fastq", "@  12 z\nAC\n+\nII\n"))                     # operator>> skips leading blanks
+    assert f.read_ids.tolist() == [12]
+    p1 = _write(tmp_path / "p1.fastq", "@1\nAC\n+\nII\n@2\nGG\n+\nII\n@3\nTT\n+\nII\n")
+    p2 = _write(tmp_path / "p2.fastq", "@1\nCA\n+\nII\n@2\nCC\n+\nII\n@3\nAA\n+\n")                  # third record incomplete in /2
+    f = host.Fastq(paired1=p1, paired2=p2)
+    assert f.read_ids.tolist() == [1, 2]
+    f = host.Fastq(paired1=p1, paired2=p2, max_reads=1)
+    assert f.read_ids.tolist() == [1]
+    with pytest.raises(hc.HcError):
+        host.Fastq(singles=_write(tmp_path / "g.fastq", "@1\nACGT\n+\nIII\n"))                        # lengths differ
