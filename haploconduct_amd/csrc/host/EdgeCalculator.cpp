@@ -124,6 +124,7 @@ void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) 
     };
     auto build = [&](uint64_t kb, uint64_t ke, Piece& pc) {
         char linebuf[192];
+        pc.edges.reserve((size_t)(ke - kb));
         constexpr uint64_t kAhead = 12;  // the two rows of m_read_info are random places in a table of n_reads * 32 bytes
         for (uint64_t k = kb; k < ke; k++) {
             if (k + kAhead < ke) {
@@ -190,15 +191,21 @@ void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) 
             pc.edges.push_back(e);
         }
     };
-    unsigned T = program_settings.n_threads > 1 ? std::min<unsigned>(program_settings.n_threads, 4) : 1;
+    static const unsigned build_cap = getenv("HC_BUILD_THREADS") ? (unsigned)atoi(getenv("HC_BUILD_THREADS")) : 8u;  // experiment knob
+    unsigned T = program_settings.n_threads > 1 ? std::min<unsigned>(program_settings.n_threads, std::max(1u, build_cap)) : 1;
     if (n_kept < 4096) T = 1;
     std::vector<Piece> pieces(T);
     if (T == 1) {
         build(0, n_kept, pieces[0]);
     } else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < T; t++) th.emplace_back([&, t] { build(n_kept * t / T, n_kept * (t + 1) / T, pieces[t]); });
-        for (auto& x : th) x.join();
+        if (!m_build_pool || m_build_pool->workers() + 1 < T) m_build_pool.reset(new WorkerPool(T - 1));
+        m_build_pool->run(T, [&](unsigned int t) {
+            try {
+                build(n_kept * t / T, n_kept * (t + 1) / T, pieces[t]);
+            } catch (const FatalError& e) {  // Edge's own checks (src/Edge.h:43-57, :211-218); reported in sequence order below
+                pieces[t].error = e;
+            }
+        });
     }
     const double t_built = now_s();
     size_t n_edges = 0;

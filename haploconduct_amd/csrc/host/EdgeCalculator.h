@@ -12,6 +12,7 @@
 #include "Overlap.h"
 #include "OverlapGraph.h"
 #include "OverlapsParser.h"
+#include "WorkerPool.h"
 #include "Types.h"
 
 namespace hc {
@@ -84,6 +85,7 @@ private:
         uint32_t paired, vertex_set;
     };
     std::vector<ReadInfo> m_read_info;
+    std::unique_ptr<WorkerPool> m_build_pool;  // the Edge build of every block runs on these
     void collect_read_info();
     void score_and_build(const ParsedBatch& batch, BuiltBlock& out);
     void insert_block(BuiltBlock& blk);

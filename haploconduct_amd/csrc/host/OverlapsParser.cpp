@@ -2,6 +2,8 @@
 // overlaps file (reference src/EdgeCalculator.cpp:569-635).
 #include "OverlapsParser.h"
 
+#include "WorkerPool.h"
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -112,7 +114,7 @@ void OverlapsParser::parse_segment(Segment& seg) const {
             if (!(line_no < seg.line_limit)) break;  // `&& i < max_overlaps`, :581
             line_no++;
             seg.c.lines_read++;
-            Overlap& o_slot = seg.out_line[seg.n_pass];  // becomes part of the block only if the line passes
+            Overlap o_slot;  // copied into the block only if the line passes
             if (!Overlap::from_plain_line(line, n, o_slot)) {  // nearly every line is plain; the rest: the reference's steps
                 const int nf = split_overlap_line(line, n, allow_spaces, field, flen, 14);
                 if (nf != 13) {  // :598-603
@@ -142,6 +144,7 @@ void OverlapsParser::parse_segment(Segment& seg) const {
             }
             if (!pass) continue;
             // id -> index: std::map::at in compute_overlap, :170-171 (throws => the reference aborts)
+            seg.out_line[seg.n_pass] = o;
             hc_overlap_rec& r = seg.out_rec[seg.n_pass];
             if (!m_ids.find(o.m_id1, r.read1) || !m_ids.find(o.m_id2, r.read2))
                 throw FatalError{HC_ERR_BAD_OVERLAP, "overlap refers to a read id that is not in the FASTQ input"};
@@ -162,69 +165,10 @@ void OverlapsParser::parse_segment(Segment& seg) const {
     }
 }
 
-// Worker threads that live as long as the parser: a block is parsed in two short parallel passes, and starting
-// 2 x (threads - 1) threads per block costs more than parsing it.
-class OverlapsParser::Pool {
+// The parser's worker threads, started once (WorkerPool.h).
+class OverlapsParser::Pool : public WorkerPool {
 public:
-    explicit Pool(unsigned int workers) {
-        for (unsigned int w = 0; w < workers; w++) m_threads.emplace_back([this, w] { loop(w + 1); });
-    }
-    ~Pool() {
-        {
-            std::lock_guard<std::mutex> g(m_mu);
-            m_stop = true;
-            m_generation++;
-        }
-        m_cv.notify_all();
-        for (auto& t : m_threads) t.join();
-    }
-    unsigned int workers() const { return (unsigned int)m_threads.size(); }
-    // fn(t) for t in [0, n): t = 0 on the caller, the rest on the workers (n - 1 <= workers())
-    void run(unsigned int n, const std::function<void(unsigned int)>& fn) {
-        if (n <= 1) {
-            fn(0);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> g(m_mu);
-            m_fn = &fn;
-            m_n = n;
-            m_pending = n - 1;
-            m_generation++;
-        }
-        m_cv.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> g(m_mu);
-        m_done.wait(g, [this] { return m_pending == 0; });
-        m_fn = nullptr;
-    }
-
-private:
-    void loop(unsigned int id) {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<void(unsigned int)>* fn = nullptr;
-            {
-                std::unique_lock<std::mutex> g(m_mu);
-                m_cv.wait(g, [&] { return m_generation != seen; });
-                seen = m_generation;
-                if (m_stop) return;
-                if (id < m_n) fn = m_fn;
-            }
-            if (fn) {
-                (*fn)(id);
-                std::lock_guard<std::mutex> g(m_mu);
-                if (--m_pending == 0) m_done.notify_one();
-            }
-        }
-    }
-    std::vector<std::thread> m_threads;
-    std::mutex m_mu;
-    std::condition_variable m_cv, m_done;
-    const std::function<void(unsigned int)>* m_fn = nullptr;
-    unsigned int m_n = 0, m_pending = 0;
-    uint64_t m_generation = 0;
-    bool m_stop = false;
+    using WorkerPool::WorkerPool;
 };
 
 OverlapsParser::OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq)
@@ -309,30 +253,42 @@ bool OverlapsParser::next_batch(ParsedBatch& batch, size_t max_batch, std::vecto
         segs[t].line_limit = m_ps.max_overlaps;
         line += nlines[t];
     }
-    // pass 2: parse, every segment into its own scratch (how many of its lines pass is not known before)
-    if (m_scratch.size() < T) m_scratch.resize(T);
+    // pass 2: parse, every segment straight into the stretch of the block its line count reserves — the records
+    // array is the page-locked memory the device reads from.  When every line passes (the usual case) the block is
+    // complete after this pass.
+    std::vector<size_t> src(T + 1, 0);
+    for (unsigned int t = 0; t < T; t++) src[t + 1] = src[t] + nlines[t];
+    batch.ensure(src[T]);
     run([&](unsigned int t) {
-        Scratch& sc = m_scratch[t];
-        const size_t room = nlines[t] + 1;  // one spare element: a line is parsed in place before it is known to pass
-        if (sc.lines.size() < room) {
-            sc.lines.resize(room + room / 8);
-            sc.recs.resize(room + room / 8);
-        }
-        segs[t].out_line = sc.lines.data();
-        segs[t].out_rec = sc.recs.data();
+        segs[t].out_line = batch.lines.data() + src[t];
+        segs[t].out_rec = batch.recs + src[t];
         parse_segment(segs[t]);
     });
-    // pass 3: the passing candidates of all segments, concatenated in file order — copied by the same workers
-    // (a serial compaction of a 250 000-line block costs more than parsing it on 32 threads)
+    // pass 3, only when lines were left out: close the gaps.  Every segment moves towards the front and may land on
+    // a neighbour's not-yet-moved entries, so the moving segments go through their workers' scratch: out, then in —
+    // both by the same workers (one thread closing the gaps of a 250 000-line block costs more than parsing it on 32).
     {
         std::vector<size_t> at(T + 1, 0);
         for (unsigned int t = 0; t < T; t++) at[t + 1] = at[t] + segs[t].n_pass;
-        batch.ensure(at[T]);
-        run([&](unsigned int t) {
-            if (!segs[t].n_pass) return;
-            memcpy((void*)(batch.lines.data() + at[t]), (const void*)segs[t].out_line, segs[t].n_pass * sizeof(Overlap));
-            memcpy((void*)(batch.recs + at[t]), (const void*)segs[t].out_rec, segs[t].n_pass * sizeof(hc_overlap_rec));
-        });
+        if (at[T] != src[T]) {
+            if (m_scratch.size() < T) m_scratch.resize(T);
+            auto moves = [&](unsigned int t) { return segs[t].n_pass != 0 && at[t] != src[t]; };
+            run([&](unsigned int t) {
+                if (!moves(t)) return;
+                Scratch& sc = m_scratch[t];
+                if (sc.lines.size() < segs[t].n_pass) {
+                    sc.lines.resize(segs[t].n_pass + segs[t].n_pass / 8);
+                    sc.recs.resize(segs[t].n_pass + segs[t].n_pass / 8);
+                }
+                memcpy((void*)sc.lines.data(), (const void*)segs[t].out_line, segs[t].n_pass * sizeof(Overlap));
+                memcpy((void*)sc.recs.data(), (const void*)segs[t].out_rec, segs[t].n_pass * sizeof(hc_overlap_rec));
+            });
+            run([&](unsigned int t) {
+                if (!moves(t)) return;
+                memcpy((void*)(batch.lines.data() + at[t]), (const void*)m_scratch[t].lines.data(), segs[t].n_pass * sizeof(Overlap));
+                memcpy((void*)(batch.recs + at[t]), (const void*)m_scratch[t].recs.data(), segs[t].n_pass * sizeof(hc_overlap_rec));
+            });
+        }
         batch.n = at[T];
     }
     for (auto& sg : segs) {

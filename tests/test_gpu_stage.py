@@ -341,3 +341,25 @@ def test_fuzz_stage_against_oracle(oracle, tmp_path, seed):
                     "scored", "dup_count", "inclusion_count", "nonedges_written", "prefilter_rejected", "malformed_lines")) + "\n")
     finally:
         os.environ.pop("HC_STAGE_BLOCK", None)
+
+
+def test_edge_invariant_violation_in_a_threaded_build_is_an_error_not_a_crash(tmp_path):
+    """Edge::set_len asserts len1 > 0 (src/Edge.h:211-218).  With enough admitted edges the Edge objects are built on
+    pool threads: the violation must come back as an error of construct_edges."""
+    reads, meta = synth.make_paired_dataset(3000, 4000, seed=21)
+    reads.quals[:] = ord("I")
+    cand = synth.paired_candidates(meta, n_candidates=None, seed=3)[:60000]
+    cand = cand.copy()
+    cand["len1"] = 0
+    lines = synth.records_to_lines(cand, reads)
+    ov = str(tmp_path / "overlaps.txt")
+    with open(ov, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    p1, p2 = str(tmp_path / "p1.fastq"), str(tmp_path / "p2.fastq")
+    reads.write_fastq(None, p1, p2)
+    st = hc.Settings(edge_threshold=0.5, ov_threshold=0.0, min_overlap_len=0, flags=FLAG_RESOLVE_ORIENTATIONS)
+    st.n_threads = 8
+    os.mkdir(str(tmp_path / "out"))
+    with host.EdgeCalculatorStage(st, paired1=p1, paired2=p2, overlaps=ov, output_dir=str(tmp_path / "out") + "/") as ec:
+        with pytest.raises(hc.HcError):
+            ec.construct_edges()
