@@ -35,6 +35,10 @@ def main():
     reads.write_fastq(None if paired else d + "singles.fastq", d + "paired1.fastq" if paired else None,
                       d + "paired2.fastq" if paired else None)
     print(f"files written in {time.time()-t0:.1f} s: {os.path.getsize(d+'overlaps.txt')/1e6:.1f} MB overlaps, {n_lines} lines")
+    try:  # the host side shares its cores with whatever else runs on the machine: say how busy it is
+        print(f"host: {os.cpu_count()} hardware threads, load average {open('/proc/loadavg').read().split()[0]} before the runs")
+    except OSError:
+        pass
     kw = dict(singles=None if paired else d + "singles.fastq", paired1=d + "paired1.fastq" if paired else None,
               paired2=d + "paired2.fastq" if paired else None, overlaps=d + "overlaps.txt", output_dir=d)
     for rep in range(args.reps):
