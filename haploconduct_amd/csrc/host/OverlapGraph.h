@@ -101,6 +101,11 @@ public:
     void addEdge(const Edge& edge);                       // :94-101
     // the addEdge calls of pool[order[0]], pool[order[1]], ... as one parallel fill
     void bulk_add_edges(const Edge* pool, const std::vector<uint32_t>& order, unsigned n_threads);
+    // src/OverlapGraph.cpp:722-764, the call that follows construct_edges in every workflow: out-lists sorted by
+    // non-overlap length, then vertex2 (std::sort, as the reference: its order among fully tied edges is part of the
+    // behaviour), adj_in rebuilt from the sorted out-lists.  len_by_read[r] = Read::get_len() of m_read_vec[r];
+    // lists are independent, so vertex ranges are sorted on n_threads threads.
+    void sortEdges(const uint32_t* len_by_read, unsigned n_threads = 1);
     Edge removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations);             // :150-194
     double checkEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) const;      // :198-229
     Edge* getEdgeInfoWithOri(node_id_t v, node_id_t w, bool opposite_orientations, bool reverse_allowed = true);  // :285-306

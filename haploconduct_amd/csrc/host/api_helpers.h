@@ -81,6 +81,18 @@ inline void fill_edge_rec(const Edge& e, hc_edge_rec& r) {
     r.len2 = e.get_len(2);
 }
 
+inline void dump_in_lists(const OverlapGraph& g, uint64_t* in_off, uint64_t* in_nodes, uint64_t cap) {
+    uint64_t m = 0;
+    for (size_t v = 0; v < g.adj_in.size(); v++) {
+        in_off[v] = m;
+        for (node_id_t w : g.adj_in[v]) {
+            if (in_nodes && m < cap) in_nodes[m] = w;
+            m++;
+        }
+    }
+    in_off[g.adj_in.size()] = m;
+}
+
 inline uint64_t dump_edges(const OverlapGraph& g, hc_edge_rec* out, uint64_t cap) {
     uint64_t n = 0;
     for (const auto& L : g.adj_out)

@@ -80,6 +80,21 @@ int hc_ec_get_inclusions(hc_ec* ec, uint8_t* out, uint64_t cap) {
     return HC_OK;
 }
 
+int hc_ec_sort_edges(hc_ec* ec) {
+    if (!ec) return set_last_error(HC_ERR_ARG, "hc_ec_sort_edges: null");
+    return guarded("sortEdges", [&] {
+        std::vector<uint32_t> len(ec->fastq->m_read_vec.size());
+        for (size_t r = 0; r < len.size(); r++) len[r] = ec->fastq->m_read_vec[r]->get_len();
+        ec->graph->sortEdges(len.data(), ec->ps.n_threads);
+    });
+}
+
+int hc_ec_get_in_lists(hc_ec* ec, uint64_t* in_off, uint64_t* in_nodes, uint64_t cap) {
+    if (!ec || !in_off) return set_last_error(HC_ERR_ARG, "hc_ec_get_in_lists: null");
+    dump_in_lists(*ec->graph, in_off, in_nodes, cap);
+    return HC_OK;
+}
+
 int hc_ec_overlap_score(hc_ec* ec, const char* seq1, const char* seq2, const char* phred1, const char* phred2,
                         uint32_t pos, double* score, double* mismatch_rate) {
     if (!ec || !seq1 || !seq2 || !phred1 || !phred2 || !score || !mismatch_rate)

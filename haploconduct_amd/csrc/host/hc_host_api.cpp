@@ -321,6 +321,18 @@ int hc_host_graph_resolve(hc_host_graph* g, const hc_edge_rec* edges, uint64_t n
     });
 }
 
+int hc_host_graph_sort_edges(hc_host_graph* g, const uint32_t* len_by_read, uint64_t n_reads) {
+    if (!g || !len_by_read) return set_last_error(HC_ERR_ARG, "hc_host_graph_sort_edges: null");
+    if (n_reads != g->reads.size()) return set_last_error(HC_ERR_ARG, "hc_host_graph_sort_edges: one length per read");
+    return guarded("sortEdges", [&] { g->graph->sortEdges(len_by_read, g->ps.n_threads); });
+}
+
+int hc_host_graph_get_in_lists(hc_host_graph* g, uint64_t* in_off, uint64_t* in_nodes, uint64_t cap) {
+    if (!g || !in_off) return set_last_error(HC_ERR_ARG, "hc_host_graph_get_in_lists: null");
+    dump_in_lists(*g->graph, in_off, in_nodes, cap);
+    return HC_OK;
+}
+
 int hc_host_graph_get(hc_host_graph* g, hc_edge_rec* out, uint64_t cap, uint64_t* n_out, uint8_t* inclusions,
                       hc_ec_counters* counters) {
     if (!g || !n_out) return set_last_error(HC_ERR_ARG, "hc_host_graph_get: null");

@@ -681,6 +681,50 @@ void OverlapGraph::bulk_add_edges(const Edge* pool, const std::vector<uint32_t>&
     edge_count += (unsigned int)m;
 }
 
+void OverlapGraph::sortEdges(const uint32_t* len_by_read, unsigned n_threads) {  // src/OverlapGraph.cpp:722-764
+    const size_t V = adj_out.size();
+    const unsigned T = edge_count < (1u << 14) ? 1u : std::max(1u, std::min(n_threads, 32u));
+    struct Key {
+        unsigned int nonoverlap;  // src/Edge.h:58-63, unsigned arithmetic
+        node_id_t v2;
+        uint32_t at;
+    };
+    run_workers(T, [&](unsigned t) {
+        std::vector<Key> keys;
+        std::vector<Edge> sorted;
+        for (size_t v = V * t / T; v < V * (t + 1) / T; v++) {
+            std::vector<Edge>& L = adj_out[v];
+            if (L.size() < 2) continue;
+            keys.clear();
+            for (size_t k = 0; k < L.size(); k++) {
+                const Edge& e = L[k];
+                keys.push_back(Key{(unsigned int)len_by_read[e.get_read(1)->get_index()] + (unsigned int)len_by_read[e.get_read(2)->get_index()] -
+                                       2u * (unsigned int)e.get_len(0),
+                                   e.get_vertex(2), (uint32_t)k});
+            }
+            // the comparator of :733-742 on the same sequence: std::sort's result depends on the comparisons only
+            std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+                if (a.nonoverlap == b.nonoverlap) return a.v2 < b.v2;
+                return a.nonoverlap < b.nonoverlap;
+            });
+            sorted.clear();
+            for (const Key& k : keys) sorted.push_back(L[k.at]);
+            std::copy(sorted.begin(), sorted.end(), L.begin());
+        }
+    });
+    // adj_in, :751-762: for every vertex in order, for every edge of its sorted list, vertex1 appended to the in-list
+    // of vertex2 — by ranges of vertex2, every worker walking the out-lists in that same order
+    run_workers(T, [&](unsigned t) {
+        const size_t lo = V * t / T, hi = V * (t + 1) / T;
+        for (size_t v = lo; v < hi; v++) adj_in[v].clear();
+        for (size_t v = 0; v < V; v++)
+            for (const Edge& e : adj_out[v]) {
+                const node_id_t w = e.get_vertex(2);
+                if (w >= lo && w < hi) adj_in[w].push_back(e.get_vertex(1));
+            }
+    });
+}
+
 void EdgeSlotIndex::bulk_add(const uint64_t* keys, size_t n, unsigned n_threads) {
     size_t cap = mask_ + 1;
     while ((filled_ + n) * 10 > cap * 6) cap *= 2;

@@ -68,6 +68,10 @@ _sig = {
     "hc_host_graph_new": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.POINTER(N.hc_settings)]),
     "hc_host_graph_insert": (C.c_int, [_vp, _vp]),
     "hc_host_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "hc_host_graph_sort_edges": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "hc_host_graph_get_in_lists": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "hc_ec_sort_edges": (C.c_int, [_vp]),
+    "hc_ec_get_in_lists": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "hc_host_graph_get": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), _vp, C.POINTER(hc_ec_counters)]),
     "hc_host_graph_free": (C.c_int, [_vp]),
 }
@@ -205,6 +209,17 @@ class HostGraph:
         e = np.ascontiguousarray(edge_recs, dtype=EDGE_DTYPE)
         return N.lib.hc_host_graph_resolve(self._h, e.ctypes.data, e.shape[0])
 
+    def sort_edges(self, len_by_read):
+        """OverlapGraph::sortEdges (src/OverlapGraph.cpp:722-764); len_by_read[r] = total length of read r."""
+        L = np.ascontiguousarray(len_by_read, dtype=np.uint32)
+        N.check(N.lib.hc_host_graph_sort_edges(self._h, L.ctypes.data, L.size), "hc_host_graph_sort_edges")
+
+    def in_lists(self, n_edges):
+        off = np.zeros(self.V + 1, np.uint64)
+        nodes = np.zeros(max(n_edges, 1), np.uint64)
+        N.check(N.lib.hc_host_graph_get_in_lists(self._h, off.ctypes.data, nodes.ctypes.data, n_edges), "hc_host_graph_get_in_lists")
+        return off, nodes[:n_edges]
+
     def get(self):
         n = C.c_uint64()
         c = hc_ec_counters()
@@ -258,6 +273,17 @@ class EdgeCalculatorStage:
         out = np.zeros(self.read_count(), np.uint8)
         N.check(N.lib.hc_ec_get_inclusions(self._h, out.ctypes.data, out.size), "hc_ec_get_inclusions")
         return out
+
+    def sort_edges(self):
+        """overlap_graph->sortEdges(), the call after construct_edges in src/ViralQuasispecies.cpp:297."""
+        N.check(N.lib.hc_ec_sort_edges(self._h), "hc_ec_sort_edges")
+
+    def in_lists(self):
+        n = self.edge_count()
+        off = np.zeros(self.read_count() + 1, np.uint64)
+        nodes = np.zeros(max(n, 1), np.uint64)
+        N.check(N.lib.hc_ec_get_in_lists(self._h, off.ctypes.data, nodes.ctypes.data, n), "hc_ec_get_in_lists")
+        return off, nodes[:n]
 
     def overlap_score(self, seq1, seq2, phred1, phred2, pos):
         sc, mr = C.c_double(), C.c_double()

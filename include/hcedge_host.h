@@ -57,6 +57,11 @@ uint64_t hc_ec_edge_count(hc_ec* ec); /* OverlapGraph::getEdgeCount */
 /* adj_out flattened in vertex order, each list in list order; *n_out = number of edges (may exceed cap). */
 int hc_ec_get_edges(hc_ec* ec, hc_edge_rec* out, uint64_t cap, uint64_t* n_out);
 int hc_ec_get_inclusions(hc_ec* ec, uint8_t* out, uint64_t cap); /* OverlapGraph::inclusions */
+/* OverlapGraph::sortEdges() — src/OverlapGraph.cpp:722-764, called right after construct_edges in every workflow
+ * (src/ViralQuasispecies.cpp:297,359,434): every out-list sorted by non-overlap length, then vertex2; adj_in rebuilt. */
+int hc_ec_sort_edges(hc_ec* ec);
+/* adj_in as offsets (read_count + 1) and vertex ids (edge_count), each list in list order. */
+int hc_ec_get_in_lists(hc_ec* ec, uint64_t* in_off, uint64_t* in_nodes, uint64_t cap);
 /* EdgeCalculator::overlap_score on caller strings (src/EdgeCalculator.cpp:67-139), scored on the device. */
 int hc_ec_overlap_score(hc_ec* ec, const char* seq1, const char* seq2, const char* phred1, const char* phred2,
                         uint32_t pos, double* score, double* mismatch_rate);
@@ -129,6 +134,9 @@ int hc_host_graph_insert(hc_host_graph* g, const hc_edge_rec* edge);
 int hc_host_graph_resolve(hc_host_graph* g, const hc_edge_rec* edges, uint64_t n);
 int hc_host_graph_get(hc_host_graph* g, hc_edge_rec* out, uint64_t cap, uint64_t* n_out, uint8_t* inclusions,
                       hc_ec_counters* counters);
+/* OverlapGraph::sortEdges on the bare graph; len_by_read[r] = Read::get_len() of read r (n_reads = n_vertices). */
+int hc_host_graph_sort_edges(hc_host_graph* g, const uint32_t* len_by_read, uint64_t n_reads);
+int hc_host_graph_get_in_lists(hc_host_graph* g, uint64_t* in_off, uint64_t* in_nodes, uint64_t cap);
 int hc_host_graph_free(hc_host_graph* g);
 
 #ifdef __cplusplus

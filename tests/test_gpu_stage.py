@@ -363,3 +363,48 @@ def test_edge_invariant_violation_in_a_threaded_build_is_an_error_not_a_crash(tm
     with host.EdgeCalculatorStage(st, paired1=p1, paired2=p2, overlaps=ov, output_dir=str(tmp_path / "out") + "/") as ec:
         with pytest.raises(hc.HcError):
             ec.construct_edges()
+
+
+@pytest.mark.parametrize("kind", ["singles", "pairs"])
+def test_sort_edges_after_construct_edges(tmp_path, kind):
+    """construct_edges then sortEdges — the first two calls of every assembly iteration (src/ViralQuasispecies.cpp:281,297)
+    — against the sortEdges oracle (itself pinned to the reference's own code, tests/test_sort_edges.py)."""
+    import ctypes as C
+
+    if kind == "singles":
+        reads, meta = synth.make_single_dataset(6000, 9000, len_lo=120, len_hi=700, flip_frac=0.4, seed=41, quals=HQ, log_uniform=True)
+        cand = synth.single_candidates(meta, min_overlap=60, n_candidates=None)[:120000]
+        paths = dict(singles=str(tmp_path / "s.fastq"))
+        reads.write_fastq(paths["singles"], None, None)
+    else:
+        reads, meta = synth.make_paired_dataset(4000, 5000, flip_frac=0.3, seed=42)
+        reads.quals[:] = HQ[np.random.default_rng(1).integers(0, HQ.size, reads.quals.size)]
+        cand = synth.paired_candidates(meta, n_candidates=None, seed=4)[:120000]
+        paths = dict(paired1=str(tmp_path / "p1.fastq"), paired2=str(tmp_path / "p2.fastq"))
+        reads.write_fastq(None, paths["paired1"], paths["paired2"])
+    ov = str(tmp_path / "overlaps.txt")
+    host.write_overlaps(ov, cand, reads)
+    st = hc.Settings(edge_threshold=0.9, ov_threshold=0.5, min_overlap_len=0, flags=FLAG_RESOLVE_ORIENTATIONS)
+    st.n_threads = 8
+    os.mkdir(str(tmp_path / "out"))
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libgraphoracle.so"))
+    lib.hco_sort_edges.restype = C.c_int
+    lib.hco_sort_edges.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    with host.EdgeCalculatorStage(st, overlaps=ov, output_dir=str(tmp_path / "out") + "/", **paths) as ec:
+        ec.construct_edges()
+        before = ec.edges()
+        assert before.size > (1 << 14)  # the threaded path
+        V = ec.read_count()
+        rfs = np.asarray(reads.read_first_seq)
+        seq_len = np.diff(np.asarray(reads.seq_off)).astype(np.uint32)
+        total = np.add.reduceat(seq_len, rfs[:-1].astype(np.int64)).astype(np.uint32)
+        want = np.zeros(before.size, dtype=host.EDGE_DTYPE)
+        woff = np.zeros(V + 1, np.uint64)
+        wnodes = np.zeros(before.size, np.uint64)
+        assert lib.hco_sort_edges(before.ctypes.data, before.size, V, total.ctypes.data, want.ctypes.data, woff.ctypes.data, wnodes.ctypes.data) == 0
+        ec.sort_edges()
+        after = ec.edges()
+        off, nodes = ec.in_lists()
+    assert after.tobytes() == want.tobytes()
+    assert not np.array_equal(after["v2"], before["v2"])  # it did reorder something
+    assert np.array_equal(off, woff) and np.array_equal(nodes, wnodes)

@@ -54,6 +54,9 @@ def main():
               f"{c['scored']/(t2-t1)/1e6:.2f} M candidates/s end-to-end; parse {c['t_parse']:.3f} score {c['t_score']:.3f} "
               f"insert {c['t_insert']:.3f} write {c['t_write']:.3f}; edges {ec.edge_count()} dups {c['dup_count']} "
               f"nonedges {c['nonedges_written']}")
+        t3 = time.time()
+        ec.sort_edges()  # the next call of every assembly iteration (src/ViralQuasispecies.cpp:297)
+        print(f"        sortEdges {time.time()-t3:.3f} s")
         ec.close()
     n = min(args.oracle_lines, n_lines)
     host.write_overlaps(d + "head.txt", cand[:n], reads)
