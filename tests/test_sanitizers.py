@@ -94,6 +94,10 @@ host.hc_host_graph_resolve.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
 assert host.hc_host_graph_resolve(g, b"".join(recs), len(recs)) == 0
 for r in recs[:2000]:
     assert host.hc_host_graph_insert(g, r) == 0
+lens = (C.c_uint32 * 400)(*[rng.choice([100, 150, 400]) for _ in range(400)])
+host.hc_host_graph_sort_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+assert host.hc_host_graph_sort_edges(g, lens, 400) == 0
+assert host.hc_host_graph_sort_edges(g, lens, 399) != 0
 host.hc_host_graph_free(g)
 
 # 3b. SFO ingest on plausible and hostile files
