@@ -8,14 +8,18 @@
 //   * the last group of paired candidates in the file is never matched (no flush after the loop), :63-103;
 //   * ties of the four numeric sort keys are ordered by the whole line, bytewise (sort under LC_ALL=C).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "../../../include/hcedge_host.h"
 #include "Types.h"
@@ -350,77 +354,272 @@ std::string sfo_to_overlaps(const std::string& sfo_text, long ns, long np, uint6
     return in.finish(n_lines);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
 // The same from binary records (hc_find_overlaps): exactly what the text path yields for the file hc_host_write_sfo
-// writes for them, without writing or parsing it.
+// writes for them, without writing, parsing or even building that text.  With binary input the line of the script's
+// temporary file is a function of ten numbers — id0 id1 sfo0 sfo1 ori OHA OHB OLA OLB K after the flip of :112-122 —
+// so `sort -k1,1n -k2,2n -k3,3n -k4,4n` with the whole line as last resort (LC_ALL=C) is: the four numbers, then `ori`,
+// then the remaining five as DECIMAL STRINGS (a tab ends the shorter one and sorts below every digit and '-'), and
+// `uniq` is equality of the ten.  Records are partitioned by id0 into one bucket per thread (sampled splitters),
+// buckets are sorted and matched independently, and the one thing that crosses a bucket border — the group of paired
+// candidates still open at its end, which the script matches when the NEXT non-single line arrives, with that line's
+// read types (:89-102) — is stitched in afterwards.
+namespace {
+
+struct BRec {
+    uint32_t id0, id1, s0, s1;
+    int64_t oha, ohb;
+    uint32_t ola, olb, k;
+    char ori;
+};
+
+inline int cmp_decimal(long a, long b) {  // order of the "%ld" texts inside a tab-separated line
+    if (a == b) return 0;
+    char x[24], y[24];
+    const size_t nx = (size_t)(put_long(x, a) - x), ny = (size_t)(put_long(y, b) - y);
+    const int c = memcmp(x, y, nx < ny ? nx : ny);
+    if (c) return c;
+    return nx < ny ? -1 : 1;  // the shorter one is followed by '\t' / '\n'
+}
+
+inline bool brec_less(const BRec& x, const BRec& y) {
+    if (x.id0 != y.id0) return x.id0 < y.id0;
+    if (x.id1 != y.id1) return x.id1 < y.id1;
+    if (x.s0 != y.s0) return x.s0 < y.s0;
+    if (x.s1 != y.s1) return x.s1 < y.s1;
+    if (x.ori != y.ori) return (unsigned char)x.ori < (unsigned char)y.ori;
+    int c;
+    if ((c = cmp_decimal((long)x.oha, (long)y.oha))) return c < 0;
+    if ((c = cmp_decimal((long)x.ohb, (long)y.ohb))) return c < 0;
+    if ((c = cmp_decimal((long)x.ola, (long)y.ola))) return c < 0;
+    if ((c = cmp_decimal((long)x.olb, (long)y.olb))) return c < 0;
+    return cmp_decimal((long)x.k, (long)y.k) < 0;
+}
+
+inline bool brec_same(const BRec& x, const BRec& y) {
+    return x.id0 == y.id0 && x.id1 == y.id1 && x.s0 == y.s0 && x.s1 == y.s1 && x.ori == y.ori && x.oha == y.oha && x.ohb == y.ohb &&
+           x.ola == y.ola && x.olb == y.olb && x.k == y.k;
+}
+
+inline SfoRec to_sfo(const BRec& r) {
+    SfoRec o;
+    o.id[0] = r.id0; o.id[1] = r.id1;
+    o.sfo[0] = r.s0; o.sfo[1] = r.s1;
+    o.ori = r.ori;
+    o.oha = (long)r.oha; o.ohb = (long)r.ohb; o.ola = r.ola; o.olb = r.olb;
+    o.text_off = 0;
+    o.text_len = 0;
+    return o;
+}
+
+struct RecArray {  // n records, not initialised: the workers touch (and so place) their own stretches first
+    BRec* p = nullptr;
+    explicit RecArray(size_t n) {
+        if (!n) return;
+        const size_t bytes = (n * sizeof(BRec) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        if (posix_memalign((void**)&p, (size_t)2 << 20, bytes) != 0) throw FatalError{HC_ERR_NOMEM, "sfo_records_to_overlaps: out of memory"};
+        madvise(p, bytes, MADV_HUGEPAGE);  // a hint: 2 MiB pages where the system grants them (fewer first-touch faults)
+    }
+    ~RecArray() { free(p); }
+    RecArray(const RecArray&) = delete;
+    RecArray& operator=(const RecArray&) = delete;
+    void release() {
+        free(p);
+        p = nullptr;
+    }
+};
+
+struct Emitter {  // the output lines of one stretch, with the final `uniq` (:107) applied inside it
+    std::string text, last, cur;
+    uint64_t n_lines = 0;
+    void line(const std::string& l) {
+        if (n_lines && l == last) return;
+        text += l;
+        last = l;
+        n_lines++;
+    }
+    void match_group(const std::vector<BRec>& cands, bool pa, bool pb) {  // match_candidates, :89-102 / :203-219
+        if (cands.size() < 2) return;
+        std::vector<SfoRec> c;
+        c.reserve(cands.size());
+        for (const BRec& r : cands) c.push_back(to_sfo(r));
+        for (size_t a = 0; a < c.size(); a++)
+            for (size_t b = a + 1; b < c.size(); b++)
+                if (paired_overlap(c[a], c[b], pa, pb, cur)) line(cur);
+    }
+};
+
+struct BucketResult {
+    Emitter before, after;      // output up to / from the first non-single record of the bucket
+    bool has_paired = false;    // the bucket holds a record that involves a paired read ...
+    bool pa = false, pb = false;  // ... and these are the types of the first such record
+    std::vector<BRec> open;     // the group still open at the end of the bucket
+    FatalError error{0, ""};
+};
+
+void match_bucket(const BRec* r, size_t n, long ns, long np, BucketResult& out) {
+    std::vector<BRec> cands;
+    Emitter* em = &out.before;
+    for (size_t i = 0; i < n; i++) {
+        if (i && brec_same(r[i], r[i - 1])) continue;  // uniq
+        if (r[i].id0 == r[i].id1) continue;             // self-overlap, :69-70
+        const bool pa = is_paired(r[i].id0, ns, np), pb = is_paired(r[i].id1, ns, np);
+        if (!pa && !pb) {  // :79-85
+            em->cur.clear();
+            put_ss(em->cur, s_s_overlap(to_sfo(r[i])));
+            const std::string l = em->cur;
+            em->line(l);
+            continue;
+        }
+        if (!out.has_paired) {  // whatever group is open from earlier buckets is matched here, by the stitching pass
+            out.has_paired = true;
+            out.pa = pa;
+            out.pb = pb;
+            em = &out.after;
+        }
+        if (!cands.empty() && (cands[0].id0 != r[i].id0 || cands[0].id1 != r[i].id1)) {
+            em->match_group(cands, pa, pb);
+            cands.clear();
+        }
+        cands.push_back(r[i]);
+    }
+    out.open.swap(cands);
+}
+
+}  // namespace
+
 std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns, long np, uint64_t& n_lines) {
     const auto t0 = std::chrono::steady_clock::now();
-    Ingest in;
-    in.ns = ns;
-    in.np = np;
-    const unsigned T = worker_count(n);
-    std::vector<Ingest> part(T);
-    std::vector<FatalError> errs(T, FatalError{0, ""});
-    auto build = [&](unsigned t) {
-      try {
-        Ingest& in = part[t];
-        in.ns = ns;
-        in.np = np;
-        const uint64_t b = n * t / T, e = n * (t + 1) / T;
-        in.recs.reserve(e - b);
-        in.arena.reserve((e - b) * 48);
-        char line[160], kbuf[16];
-        for (uint64_t i = b; i < e; i++) {
-        const hc_sfo_rec& r = recs[i];
-        const char ori = r.inverted ? 'I' : 'N';
-        const size_t kl = (size_t)(put_long(kbuf, (long)r.K) - kbuf);
-        char* q = put_long(line, (long)r.idA);  // the line hc_host_write_sfo writes
-        *q++ = '\t';
-        q = put_long(q, (long)r.idB);
-        *q++ = '\t';
-        *q++ = ori;
-        const long nums[5] = {r.OHA, r.OHB, (long)r.OLA, (long)r.OLB, (long)r.K};
-        for (long v : nums) {
-            *q++ = '\t';
-            q = put_long(q, v);
+    unsigned T = std::thread::hardware_concurrency();
+    if (T == 0) T = 1;
+    if (T > 32) T = 32;
+    if (n / 20000 + 1 < T) T = (unsigned)(n / 20000 + 1);
+    if (const char* e = getenv("HC_SFO_BUCKETS")) T = (unsigned)std::max(1, atoi(e));  // test knob: many buckets on small inputs
+    auto workers = [&](unsigned count, const std::function<void(unsigned)>& body) {
+        if (count <= 1) {
+            body(0);
+            return;
         }
-        in.add((long)r.idA, (long)r.idB, &ori, 1, r.OHA, r.OHB, (long)r.OLA, (long)r.OLB, kbuf, kl, line, (size_t)(q - line));
-        }
-      } catch (const FatalError& e) {
-        errs[t] = e;
-      }
-    };
-    if (T == 1) {
-        build(0);
-    } else {
         std::vector<std::thread> th;
-        for (unsigned t = 0; t < T; t++) th.emplace_back(build, t);
+        for (unsigned t = 1; t < count; t++) th.emplace_back(body, t);
+        body(0);
         for (auto& x : th) x.join();
-    }
+    };
+    // 1. the flip of :112-122 (smaller original id first)
+    RecArray flipped_mem(n);
+    BRec* flipped = flipped_mem.p;
+    std::vector<FatalError> errs(T, FatalError{0, ""});
+    workers(T, [&](unsigned t) {
+        try {
+            for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) {
+                const hc_sfo_rec& r = recs[i];
+                const long na = original_id((long)r.idA, ns, np), nb = original_id((long)r.idB, ns, np);
+                BRec& o = flipped[i];
+                o.ori = r.inverted ? 'I' : 'N';
+                o.k = r.K;
+                if (na > nb) {
+                    o.id0 = (uint32_t)nb; o.id1 = (uint32_t)na;
+                    o.s0 = r.idB; o.s1 = r.idA;
+                    if (r.inverted) { o.oha = r.OHB; o.ohb = r.OHA; }
+                    else { o.oha = -(int64_t)r.OHA; o.ohb = -(int64_t)r.OHB; }
+                    o.ola = r.OLB; o.olb = r.OLA;
+                } else {
+                    o.id0 = (uint32_t)na; o.id1 = (uint32_t)nb;
+                    o.s0 = r.idA; o.s1 = r.idB;
+                    o.oha = r.OHA; o.ohb = r.OHB;
+                    o.ola = r.OLA; o.olb = r.OLB;
+                }
+            }
+        } catch (const FatalError& e) {
+            errs[t] = e;
+        }
+    });
     for (const FatalError& e : errs)
         if (e.status) throw e;
-    {  // one arena, one record array: the pieces in order, text offsets rebased
-        size_t n_recs = 0, n_text = 0;
-        for (const Ingest& p : part) {
-            n_recs += p.recs.size();
-            n_text += p.arena.size();
-        }
-        in.recs.reserve(n_recs);
-        in.arena.reserve(n_text);
-        for (Ingest& p : part) {
-            const size_t base = in.arena.size();
-            in.arena += p.arena;
-            for (SfoRec r : p.recs) {
-                r.text_off += base;
-                in.recs.push_back(r);
-            }
-            p = Ingest();
+    // 2. buckets of id0 ranges: splitters from a sample, a counting pass, a scatter pass
+    std::vector<uint32_t> split;  // bucket b holds id0 in [split[b-1], split[b])
+    if (T > 1) {
+        std::vector<uint32_t> sample;
+        const uint64_t step = std::max<uint64_t>(1, n / ((uint64_t)T * 256));
+        for (uint64_t i = 0; i < n; i += step) sample.push_back(flipped[i].id0);
+        std::sort(sample.begin(), sample.end());
+        for (unsigned b = 1; b < T; b++) {
+            const uint32_t v = sample[sample.size() * b / T];
+            if (split.empty() || v > split.back()) split.push_back(v);
         }
     }
+    const unsigned B = (unsigned)split.size() + 1;
+    auto bucket_of = [&](uint32_t id0) { return (unsigned)(std::upper_bound(split.begin(), split.end(), id0) - split.begin()); };
+    std::vector<std::vector<uint64_t>> counts(T, std::vector<uint64_t>(B, 0));
+    workers(T, [&](unsigned t) {
+        std::vector<uint64_t>& c = counts[t];
+        for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) c[bucket_of(flipped[i].id0)]++;
+    });
+    std::vector<uint64_t> start(B + 1, 0);
+    for (unsigned b = 0; b < B; b++) {
+        uint64_t m = 0;
+        for (unsigned t = 0; t < T; t++) {
+            const uint64_t c = counts[t][b];
+            counts[t][b] = start[b] + m;  // where thread t writes its records of bucket b
+            m += c;
+        }
+        start[b + 1] = start[b] + m;
+    }
+    RecArray sorted_mem(n);
+    BRec* sorted = sorted_mem.p;
+    workers(T, [&](unsigned t) {
+        std::vector<uint64_t> at = counts[t];
+        for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) sorted[at[bucket_of(flipped[i].id0)]++] = flipped[i];
+    });
+    flipped_mem.release();
     const auto t1 = std::chrono::steady_clock::now();
-    std::string out = in.finish(n_lines);
+    // 3. sort and match every bucket on its own
+    std::vector<BucketResult> res(B);
+    {
+        std::vector<unsigned> order(B);  // largest buckets first: they bound the makespan
+        for (unsigned b = 0; b < B; b++) order[b] = b;
+        std::sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return start[x + 1] - start[x] > start[y + 1] - start[y]; });
+        std::atomic<unsigned> next{0};
+        workers(std::min(T, B), [&](unsigned) {
+            for (;;) {
+                const unsigned k = next.fetch_add(1);
+                if (k >= B) return;
+                const unsigned b = order[k];
+                try {
+                    std::sort(sorted + start[b], sorted + start[b + 1], brec_less);
+                    match_bucket(sorted + start[b], start[b + 1] - start[b], ns, np, res[b]);
+                } catch (const FatalError& e) {
+                    res[b].error = e;
+                }
+            }
+        });
+    }
+    // 4. stitch: the open group travels to the next bucket that holds a non-single record and is matched there
+    std::string out;
+    n_lines = 0;
+    {
+        size_t bytes = 0;
+        for (const BucketResult& r : res) bytes += r.before.text.size() + r.after.text.size();
+        out.reserve(bytes + bytes / 16);
+    }
+    std::vector<BRec> open;
+    for (BucketResult& r : res) {
+        if (r.error.status) throw r.error;
+        out += r.before.text;
+        n_lines += r.before.n_lines;
+        if (r.has_paired) {
+            Emitter em;
+            em.match_group(open, r.pa, r.pb);
+            out += em.text;
+            n_lines += em.n_lines;
+            open.swap(r.open);
+        }
+        out += r.after.text;
+        n_lines += r.after.n_lines;
+    }  // the group open at the very end is never matched (:63-103)
     if (getenv("HC_SFO_TIMING"))
-        fprintf(stderr, "sfo_records_to_overlaps: build %.3f s, sort+match %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+        fprintf(stderr, "sfo_records_to_overlaps: flip + partition %.3f s, sort + match + stitch %.3f s (%u buckets)\n",
+                std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), B);
     return out;
 }
 

@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 import haploconduct_amd as hc
 from haploconduct_amd import host
@@ -71,3 +72,31 @@ def test_records_path_equals_text_path(tmp_path):
         assert (tmp_path / "text.txt").read_bytes() == (tmp_path / "rec.txt").read_bytes()
         want = "".join(l + "\n" for l in S.sfo2overlaps((tmp_path / "a.sfo").read_text().splitlines(), ns, npairs))
         assert (tmp_path / "rec.txt").read_text() == want
+
+
+@pytest.mark.parametrize("buckets", ["1", "7", "64"])
+def test_bucketed_records_path_equals_text_path(tmp_path, monkeypatch, buckets):
+    """The records path partitions by id0, sorts and matches the buckets independently and stitches the group that is
+    open at a bucket border into the next bucket: with few reads and many buckets nearly every border carries one.
+    Byte for byte the text path (hc_host_write_sfo + hc_sfo2overlaps) and the Python oracle of the script."""
+    monkeypatch.setenv("HC_SFO_BUCKETS", buckets)
+    rng = np.random.default_rng(int(buckets))
+    for ns, npairs, n in ((0, 25, 30000), (12, 18, 30000), (300, 0, 20000), (3, 400, 40000)):
+        n_ids = ns + 2 * npairs
+        recs = np.zeros(n, SFO_DTYPE)
+        a = rng.integers(0, n_ids, n)
+        b = (a + 1 + rng.integers(0, n_ids - 1, n)) % n_ids
+        recs["idA"], recs["idB"] = a, b                      # both id orders: the flip of :112-122
+        recs["OHA"], recs["OHB"] = rng.integers(-12, 120, n), rng.integers(-12, 12, n)   # few values: ties down to the text order
+        recs["OLA"] = rng.integers(95, 105, n)
+        recs["OLB"] = recs["OLA"] + rng.integers(0, 2, n)
+        recs["K"], recs["inverted"] = rng.integers(0, 12, n), rng.integers(0, 2, n)      # K = 9 / 10 / 11: string order != numeric order
+        recs[: n // 10] = recs[n // 2: n // 2 + n // 10]     # exact duplicates for uniq
+        recs = recs[rng.permutation(n)]
+        host.write_sfo(str(tmp_path / "a.sfo"), recs)
+        n_text = host.sfo2overlaps(str(tmp_path / "a.sfo"), str(tmp_path / "text.txt"), ns, npairs)
+        n_rec = host.sfo_records_to_overlaps(recs, str(tmp_path / "rec.txt"), ns, npairs)
+        assert (tmp_path / "text.txt").read_bytes() == (tmp_path / "rec.txt").read_bytes()
+        assert n_text == n_rec > 0
+    want = "".join(l + "\n" for l in S.sfo2overlaps((tmp_path / "a.sfo").read_text().splitlines(), ns, npairs))
+    assert (tmp_path / "rec.txt").read_text() == want

@@ -110,6 +110,16 @@ assert host.hc_sfo2overlaps(w("a.sfo", "\n".join(sfo).encode()), (d + "a.out").e
 for bad in (b"", b"\n\n", b"1 2 N 3\n", b"1 2 N 0 0 0 0 0\n", b"1 2 N a b c d e\n", b"999 2 N 1 1 1 1 0\n", b"1 2 " + b"N" * 5000 + b" 1 1 1 1 0\n"):
     host.hc_sfo2overlaps(w("b.sfo", bad), (d + "b.out").encode(), 40, 40, None)
 
+# 3b'. the records path of the same ingest (buckets sorted and matched on threads, open groups stitched across borders)
+host.hc_sfo_records_to_overlaps.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p]
+os.environ["HC_SFO_BUCKETS"] = "9"
+raw = b"".join(struct.pack("<IIiiIIII", rng.randrange(120), rng.randrange(120), rng.randrange(-100, 100), rng.randrange(-100, 100),
+                           rng.randrange(1, 150), rng.randrange(1, 150), rng.randrange(12), rng.randrange(2)) for _ in range(30000))
+nl = C.c_uint64()
+host.hc_sfo_records_to_overlaps(raw, 30000, (d + "c.out").encode(), 40, 40, C.byref(nl))
+assert host.hc_sfo_records_to_overlaps(raw, 30000, (d + "c.out").encode(), 10, 10, C.byref(nl)) != 0  # ids out of range: an error
+del os.environ["HC_SFO_BUCKETS"]
+
 # 3c. find-next-overlaps on the scenarios the parent process saved (well-formed and hostile ones)
 import glob
 import numpy as np
