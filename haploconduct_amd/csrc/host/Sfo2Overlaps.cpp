@@ -317,18 +317,121 @@ std::string Ingest::finish(uint64_t& n_lines) {
 
 }  // namespace
 
+std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns, long np, uint64_t& n_lines);
+
+namespace {
+
+// One field of a CANONICAL line: "0" or [1-9][0-9]* (optionally after one '-'), ended by `end`.
+inline bool canonical_int(const char*& p, const char* e, char end, bool allow_negative, int64_t lo, int64_t hi, int64_t& v) {
+    bool neg = false;
+    if (p < e && *p == '-') {
+        if (!allow_negative) return false;
+        neg = true;
+        p++;
+    }
+    const char* b = p;
+    uint64_t u = 0;
+    while (p < e && (unsigned)(*p - '0') <= 9u && p - b < 11) u = u * 10 + (uint64_t)(*p++ - '0');
+    const size_t d = (size_t)(p - b);
+    if (d == 0 || d > 10 || (b[0] == '0' && (d > 1 || neg))) return false;  // no leading zeros, no "-0"
+    v = neg ? -(int64_t)u : (int64_t)u;
+    if (v < lo || v > hi) return false;
+    if (end == '\n') return p == e;
+    if (p >= e || *p != end) return false;
+    p++;
+    return true;
+}
+
+// A file as hc_host_write_sfo (and a tab-separated rust-overlaps run) writes it: eight fields, single tabs, canonical
+// decimal numbers in the ranges of hc_sfo_rec, `N` or `I`.  For such a file the line the script keeps for its sort and
+// uniq is exactly the ten-number line the records path reasons about, so the whole ingest can run there.  Returns false
+// at the first line of any other shape (the general path below then handles — and diagnoses — the file).
+bool parse_canonical_sfo(const char* text, size_t N, std::vector<hc_sfo_rec>& recs) {
+    if (N == 0) return false;
+    unsigned T = std::thread::hardware_concurrency();
+    if (T == 0) T = 1;
+    if (T > 32) T = 32;
+    if (N / (1u << 20) + 1 < T) T = (unsigned)(N / (1u << 20) + 1);
+    std::vector<size_t> cut(T + 1, N);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; t++) {
+        size_t c = std::max(cut[t - 1], N * t / T);
+        const char* nl = c < N ? (const char*)memchr(text + c, '\n', N - c) : nullptr;
+        cut[t] = nl ? (size_t)(nl - text) + 1 : N;
+    }
+    std::vector<uint64_t> lines(T, 0);
+    auto run = [&](const std::function<void(unsigned)>& body) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++) th.emplace_back(body, t);
+        body(0);
+        for (auto& x : th) x.join();
+    };
+    run([&](unsigned t) {
+        const char* b = text + cut[t];
+        const char* e = text + cut[t + 1];
+        uint64_t k = (uint64_t)std::count(b, e, '\n');
+        if (e > b && e[-1] != '\n') k++;
+        lines[t] = k;
+    });
+    std::vector<uint64_t> at(T + 1, 0);
+    for (unsigned t = 0; t < T; t++) at[t + 1] = at[t] + lines[t];
+    recs.resize(at[T]);
+    std::vector<uint8_t> ok(T, 1);
+    run([&](unsigned t) {
+        const char* p = text + cut[t];
+        const char* const end = text + cut[t + 1];
+        hc_sfo_rec* out = recs.data() + at[t];
+        while (p < end) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* e = nl ? nl : end;
+            int64_t a, b, oha, ohb, ola, olb, k;
+            const char* q = p;
+            bool good = canonical_int(q, e, '\t', false, 0, 0xFFFFFFFFll, a) && canonical_int(q, e, '\t', false, 0, 0xFFFFFFFFll, b);
+            char ori = 0;
+            if (good) {
+                good = q + 1 < e && (q[0] == 'N' || q[0] == 'I') && q[1] == '\t';
+                ori = q[0];
+                q += 2;
+            }
+            good = good && canonical_int(q, e, '\t', true, -2147483647ll, 2147483647ll, oha) && canonical_int(q, e, '\t', true, -2147483647ll, 2147483647ll, ohb) &&
+                   canonical_int(q, e, '\t', false, 0, 0xFFFFFFFFll, ola) && canonical_int(q, e, '\t', false, 0, 0xFFFFFFFFll, olb) &&
+                   canonical_int(q, e, '\n', false, 0, 0xFFFFFFFFll, k);
+            if (!good) {
+                ok[t] = 0;
+                return;
+            }
+            out->idA = (uint32_t)a; out->idB = (uint32_t)b;
+            out->OHA = (int32_t)oha; out->OHB = (int32_t)ohb;
+            out->OLA = (uint32_t)ola; out->OLB = (uint32_t)olb;
+            out->K = (uint32_t)k;
+            out->inverted = ori == 'I';
+            out++;
+            p = nl ? nl + 1 : end;
+        }
+    });
+    for (uint8_t x : ok)
+        if (!x) return false;
+    return true;
+}
+
+}  // namespace
+
 // Returns the output text; n_lines receives the number of lines.
-std::string sfo_to_overlaps(const std::string& sfo_text, long ns, long np, uint64_t& n_lines) {
+std::string sfo_to_overlaps(const char* sfo_text, size_t sfo_bytes, long ns, long np, uint64_t& n_lines) {
+    if (!getenv("HC_SFO_TEXT_GENERAL")) {  // (test knob: always take the general path)
+        std::vector<hc_sfo_rec> recs;
+        if (parse_canonical_sfo(sfo_text, sfo_bytes, recs)) return sfo_records_to_overlaps(recs.data(), recs.size(), ns, np, n_lines);
+    }
     Ingest in;
     in.ns = ns;
     in.np = np;
-    in.arena.reserve(sfo_text.size() + sfo_text.size() / 2);
+    in.arena.reserve(sfo_bytes + sfo_bytes / 2);
     size_t pos = 0;
-    const size_t N = sfo_text.size();
+    const size_t N = sfo_bytes;
     while (pos < N) {  // :31-50
-        const char* nl = (const char*)memchr(sfo_text.data() + pos, '\n', N - pos);
-        const size_t end = nl ? (size_t)(nl - sfo_text.data()) : N;
-        const char* line = sfo_text.data() + pos;
+        const char* nl = (const char*)memchr(sfo_text + pos, '\n', N - pos);
+        const size_t end = nl ? (size_t)(nl - sfo_text) : N;
+        const char* line = sfo_text + pos;
         const size_t len = end - pos;
         // line.strip('\n').split(): any run of whitespace separates
         const char* f[9];

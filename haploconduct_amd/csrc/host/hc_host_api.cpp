@@ -1,5 +1,10 @@
 // hc_host_api.cpp — the host-only entry points of include/hcedge_host.h (no device needed): tokenizer,
 // Overlap record parsing, FastqStorage, parser + prefilter, serial insert on a bare graph.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <thread>
 #include <vector>
@@ -20,7 +25,7 @@ struct hc_host_graph {
 };
 
 namespace hc {
-std::string sfo_to_overlaps(const std::string& sfo_text, long ns, long np, uint64_t& n_lines);  // Sfo2Overlaps.cpp
+std::string sfo_to_overlaps(const char* sfo_text, size_t sfo_bytes, long ns, long np, uint64_t& n_lines);  // Sfo2Overlaps.cpp
 std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns, long np, uint64_t& n_lines);
 }
 
@@ -29,15 +34,34 @@ extern "C" {
 int hc_sfo2overlaps(const char* sfo_path, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines) {
     if (!sfo_path || !out_path) return set_last_error(HC_ERR_ARG, "hc_sfo2overlaps: null path");
     return guarded("sfo2overlaps", [&] {
-        FILE* f = fopen(sfo_path, "rb");
-        if (!f) throw FatalError{HC_ERR_IO, std::string("cannot open ") + sfo_path};
-        std::string text;
-        char buf[1 << 16];
-        size_t k;
-        while ((k = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, k);
-        fclose(f);
+        // the file mapped read-only (a pipe or another unmappable input is read whole)
+        const int fd = open(sfo_path, O_RDONLY);
+        if (fd < 0) throw FatalError{HC_ERR_IO, std::string("cannot open ") + sfo_path};
+        struct stat stt;
+        std::string owned;
+        const char* text = nullptr;
+        size_t bytes = 0;
+        void* map = nullptr;
+        if (fstat(fd, &stt) == 0 && S_ISREG(stt.st_mode) && stt.st_size > 0) {
+            map = mmap(nullptr, (size_t)stt.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map == MAP_FAILED) map = nullptr;
+        }
+        if (map) {
+            text = (const char*)map;
+            bytes = (size_t)stt.st_size;
+        } else {
+            char buf[1 << 16];
+            ssize_t k;
+            while ((k = read(fd, buf, sizeof buf)) > 0) owned.append(buf, (size_t)k);
+            text = owned.data();
+            bytes = owned.size();
+        }
+        struct Unmap {
+            void* p; size_t n; int fd;
+            ~Unmap() { if (p) munmap(p, n); close(fd); }
+        } unmap{map, bytes, fd};
         uint64_t n = 0;
-        const std::string out = hc::sfo_to_overlaps(text, (long)num_singles, (long)num_pairs, n);
+        const std::string out = hc::sfo_to_overlaps(text, bytes, (long)num_singles, (long)num_pairs, n);
         FILE* o = fopen(out_path, "wb");
         if (!o) throw FatalError{HC_ERR_IO, std::string("cannot write ") + out_path};
         fwrite(out.data(), 1, out.size(), o);

@@ -51,8 +51,9 @@ def test_sfo_text_writer_roundtrip(tmp_path):
     assert n == 3 and out.read_text() == want
 
 
-def test_records_path_equals_text_path(tmp_path):
+def test_records_path_equals_text_path(tmp_path, monkeypatch):
     """hc_sfo_records_to_overlaps == hc_host_write_sfo + hc_sfo2overlaps, byte for byte (singles, pairs, both)."""
+    monkeypatch.setenv("HC_SFO_TEXT_GENERAL", "1")  # the text side through the line-keeping path, not through the records path
     rng = np.random.default_rng(7)
     for ns, npairs in ((40, 0), (0, 30), (15, 20)):
         n_ids = ns + 2 * npairs
@@ -80,6 +81,7 @@ def test_bucketed_records_path_equals_text_path(tmp_path, monkeypatch, buckets):
     open at a bucket border into the next bucket: with few reads and many buckets nearly every border carries one.
     Byte for byte the text path (hc_host_write_sfo + hc_sfo2overlaps) and the Python oracle of the script."""
     monkeypatch.setenv("HC_SFO_BUCKETS", buckets)
+    monkeypatch.setenv("HC_SFO_TEXT_GENERAL", "1")  # the text side through the line-keeping path, not through the records path
     rng = np.random.default_rng(int(buckets))
     for ns, npairs, n in ((0, 25, 30000), (12, 18, 30000), (300, 0, 20000), (3, 400, 40000)):
         n_ids = ns + 2 * npairs

@@ -18,6 +18,17 @@ from sfo2overlaps_oracle import sfo2overlaps as oracle_sfo2overlaps  # noqa: E40
 CASES = sorted(glob.glob(os.path.join(HERE, "golden", "sfo", "*.sfo")))
 
 
+@pytest.fixture(autouse=True, params=["auto", "general"])
+def ingest_route(request, monkeypatch):
+    """Files of the plain shape (eight fields, single tabs, canonical numbers) are parsed into records and run through
+    the partitioned records path; every other file — and every file under HC_SFO_TEXT_GENERAL — through the line-keeping
+    general path.  Every test below runs both ways."""
+    if request.param == "general":
+        monkeypatch.setenv("HC_SFO_TEXT_GENERAL", "1")
+    monkeypatch.setenv("HC_SFO_BUCKETS", "5")  # several buckets even on the small fixtures
+    return request.param
+
+
 @pytest.mark.parametrize("sfo", CASES, ids=[os.path.basename(c) for c in CASES])
 def test_against_reference_script_outputs(sfo, tmp_path):
     s, p = map(int, open(sfo[:-4] + ".args").read().split())
