@@ -173,21 +173,52 @@ int hc_host_write_sfo(const char* path, const hc_sfo_rec* recs, uint64_t n) {
     return guarded("write_sfo", [&] {
         FILE* o = fopen(path, "wb");
         if (!o) throw FatalError{HC_ERR_IO, std::string("cannot write ") + path};
-        std::vector<char> buf;
-        buf.reserve(1 << 22);
-        char line[128];
-        for (uint64_t i = 0; i < n; i++) {
-            const hc_sfo_rec& r = recs[i];
-            const int m = snprintf(line, sizeof line, "%u\t%u\t%c\t%d\t%d\t%u\t%u\t%u\n", r.idA, r.idB, r.inverted ? 'I' : 'N', r.OHA, r.OHB,
-                                   r.OLA, r.OLB, r.K);
-            buf.insert(buf.end(), line, line + m);
-            if (buf.size() > (1u << 22) - 256 || i + 1 == n) {
-                if (fwrite(buf.data(), 1, buf.size(), o) != buf.size()) {
+        unsigned T = std::thread::hardware_concurrency();
+        if (T == 0) T = 1;
+        if (T > 32) T = 32;
+        auto put = [](char* p, int64_t v) {  // "%d" / "%u"
+            uint64_t u = v < 0 ? 0ull - (uint64_t)v : (uint64_t)v;
+            if (v < 0) *p++ = '-';
+            char tmp[24];
+            int k = 0;
+            do {
+                tmp[k++] = (char)('0' + u % 10);
+                u /= 10;
+            } while (u);
+            while (k) *p++ = tmp[--k];
+            return p;
+        };
+        const uint64_t kBlock = 1u << 22;  // records per round: bounds the text held in memory
+        std::vector<std::vector<char>> buf(T);
+        for (uint64_t base = 0; base < n; base += kBlock) {
+            const uint64_t m = std::min<uint64_t>(kBlock, n - base);
+            const unsigned Tr = m < 65536 ? 1u : T;
+            std::vector<std::thread> th;
+            auto fill = [&](unsigned t) {
+                const uint64_t b = base + m * t / Tr, e = base + m * (t + 1) / Tr;
+                buf[t].resize((e - b) * 96);
+                char* p = buf[t].data();
+                for (uint64_t i = b; i < e; i++) {  // idA idB N|I OHA OHB OLA OLB K, tab-separated (scripts/sfo2overlaps.py:36)
+                    const hc_sfo_rec& r = recs[i];
+                    p = put(p, r.idA); *p++ = '\t';
+                    p = put(p, r.idB); *p++ = '\t';
+                    *p++ = r.inverted ? 'I' : 'N'; *p++ = '\t';
+                    p = put(p, r.OHA); *p++ = '\t';
+                    p = put(p, r.OHB); *p++ = '\t';
+                    p = put(p, r.OLA); *p++ = '\t';
+                    p = put(p, r.OLB); *p++ = '\t';
+                    p = put(p, r.K); *p++ = '\n';
+                }
+                buf[t].resize((size_t)(p - buf[t].data()));
+            };
+            for (unsigned t = 1; t < Tr; t++) th.emplace_back(fill, t);
+            fill(0);
+            for (auto& x : th) x.join();
+            for (unsigned t = 0; t < Tr; t++)
+                if (!buf[t].empty() && fwrite(buf[t].data(), 1, buf[t].size(), o) != buf[t].size()) {
                     fclose(o);
                     throw FatalError{HC_ERR_IO, std::string("short write to ") + path};
                 }
-                buf.clear();
-            }
         }
         if (fclose(o) != 0) throw FatalError{HC_ERR_IO, std::string("cannot close ") + path};
     });
