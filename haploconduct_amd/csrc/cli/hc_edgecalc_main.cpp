@@ -4,8 +4,9 @@
 // exit codes, :103-154), runs the stages up to and including EdgeCalculator::construct_edges()
 // (:233-293) on the MI355X, and stops there: graph cleaning, cliques, super-reads and FNO are
 // outside this build's scope.  Outputs: nonedge_overlaps.txt (as the reference),
-// viralquasispecies.log (settings block, :160-218), and edges.tsv — the admitted edges in
-// adjacency-list order, one line per Edge with %.17g score / mismatch rate.
+// viralquasispecies.log (settings block, :160-218), edges.tsv — the admitted edges in adjacency-list order as
+// construct_edges leaves them, one line per Edge with %.17g score / mismatch rate — and edges_sorted.tsv, the same
+// after overlap_graph->sortEdges() (:297), the order every later stage of the reference sees.
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -257,8 +258,9 @@ int main(int argc, char** argv) {
                    calc.stats.t_parse, calc.stats.t_score, calc.stats.t_insert, calc.stats.t_write,
                    (unsigned long)calc.stats.scored);
         }
-        FILE* ef = fopen((ps.output_dir + "edges.tsv").c_str(), "w");
-        if (ef) {
+        auto write_edges = [&](const char* name) {
+            FILE* ef = fopen((ps.output_dir + name).c_str(), "w");
+            if (!ef) return;
             for (const auto& L : graph->adj_out)
                 for (const Edge& e : L)
                     fprintf(ef, "%lu\t%lu\t%lu\t%lu\t%d\t%d\t%d\t%d\t%c\t%c\t%c\t%d\t%d\t%d\t%d\t%.17g\t%.17g\n", e.get_vertex(1),
@@ -267,7 +269,14 @@ int main(int argc, char** argv) {
                             e.get_ori(2) ? '+' : '-', e.get_ord() ? e.get_ord() : '-', e.get_perc(), e.get_len(0), e.get_len(1),
                             e.get_len(2), e.get_score(), e.get_mismatch_rate());
             fclose(ef);
+        };
+        write_edges("edges.tsv");
+        {  // overlap_graph->sortEdges(), :297
+            std::vector<uint32_t> len(fastq->m_read_vec.size());
+            for (size_t r = 0; r < len.size(); r++) len[r] = fastq->m_read_vec[r]->get_len();
+            graph->sortEdges(len.data(), ps.n_threads);
         }
+        write_edges("edges_sorted.tsv");
         FILE* sf = fopen((ps.output_dir + "edgecalc_stats.txt").c_str(), "w");
         if (sf) {
             fprintf(sf, "vertex_count\t%u\nedge_count\t%u\ninclusion_count\t%u\ndup_count\t%u\nself_overlap_count\t%u\n",

@@ -191,6 +191,11 @@ def test_cli_accepts_reference_argv_and_matches_oracle(oracle, tmp_path):
                (e["v1"], e["v2"], e["pos1"], e["pos2"], e["pos3"], e["pos4"])
         assert float(row[15]) == e["score"] and float(row[16]) == e["mismatch_rate"]
     assert open(d + "nonedge_overlaps.txt", "rb").read() == open(d + "ref_nonedge.txt", "rb").read()
+    # edges_sorted.tsv: the same edges after sortEdges — per out-list non-decreasing (non-overlap length, vertex2)
+    srows = [ln.split("\t") for ln in open(d + "edges_sorted.tsv").read().splitlines()]
+    assert sorted(map(tuple, srows)) == sorted(map(tuple, rows))
+    keys = [(int(r[0]), 600 - 2 * int(r[12]), int(r[1])) for r in srows]  # every read is 2 x 150 bp
+    assert keys == sorted(keys) and srows != rows
     stats = dict(ln.split("\t") for ln in open(d + "edgecalc_stats.txt").read().splitlines())
     assert int(stats["dup_count"]) == oc.dup_count and int(stats["inclusion_count"]) == oc.inclusion_count
 
