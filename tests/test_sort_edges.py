@@ -105,3 +105,34 @@ def test_sort_edges_on_large_random_graphs_matches_the_oracle(graph_oracle):
         e = after[123].copy()
         assert g.insert(e) == 0
         assert g.get()[2]["dup_count"] == 1
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so")),
+                    reason="the reference fragment probe is built only where /root/reference exists (it ships with the repository's built files)")
+def test_sort_edges_against_the_live_reference_probe(graph_oracle):
+    """Beyond the committed vectors: seeded random graphs — hubs with up to a thousand out-edges, two or three distinct
+    lengths so that nearly everything ties — through the reference's own sortEdges (fragment probe), the oracle and the
+    product."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden_sort_edges", os.path.join(HERE, "golden", "make_golden_sort_edges.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so"))
+    ref.frag_sort_edges.restype = C.c_int
+    ref.frag_sort_edges.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for seed in range(12):
+        V = [30, 300, 1500][seed % 3]
+        n = [400, 3000, 2500][seed % 3]
+        read_len, rows = mg.random_case(100 + seed, V, n, [300, 300, 450][: 1 + seed % 3], [100, 101][: 1 + seed % 2], [1, 2] if seed % 2 else [0])
+        want_rows, want_off, want_nodes = mg.run(ref, V, read_len, rows)
+        want = _recs(want_rows)
+        got, off, nodes = graph_oracle(_grouped(_recs(rows)), V, read_len)
+        assert got.tobytes() == want.tobytes() and off.tolist() == want_off and nodes.tolist() == want_nodes, f"oracle, seed {seed}"
+        g = host.HostGraph(V, hc.Settings(flags=hc.records.FLAG_RESOLVE_ORIENTATIONS, n_threads=4))
+        assert g.resolve(_recs(rows)) == 0
+        g.sort_edges(read_len)
+        after, _, _ = g.get()
+        assert after.tobytes() == want.tobytes(), f"product, seed {seed}"
+        poff, pnodes = g.in_lists(after.size)
+        assert poff.tolist() == want_off and pnodes.tolist() == want_nodes
