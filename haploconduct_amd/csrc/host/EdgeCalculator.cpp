@@ -73,17 +73,32 @@ double EdgeCalculator::overlap_score(const std::string& seq1, const std::string&
 
 void EdgeCalculator::collect_read_info() {
     const FastqStorage& f = *fastq_storage;
-    m_read_info.resize(f.m_read_vec.size());
-    for (size_t i = 0; i < m_read_info.size(); i++) {
-        Read* r = f.m_read_vec[i];
-        ReadInfo& x = m_read_info[i];
-        x.read = r;
-        x.paired = r->is_paired();
-        x.len_a = r->get_seq_len(x.paired ? 1 : 0);
-        x.len_b = x.paired ? r->get_seq_len(2) : 0;
-        x.vertex_set = r->has_vertex_id(true);
-        x.vertex = x.vertex_set ? r->get_vertex_id(true) : 0;
+    const std::vector<uint32_t>& first = f.read_first_seq();  // lengths straight from the flat layout (Read::get_seq_len goes there too)
+    const std::vector<uint64_t>& off = f.seq_off();
+    const size_t n = f.m_read_vec.size();
+    m_read_info.resize(n);
+    auto fill = [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            Read* r = f.m_read_vec[i];
+            ReadInfo& x = m_read_info[i];
+            const uint32_t q = first[i];
+            x.read = r;
+            x.paired = r->is_paired();
+            x.len_a = (uint32_t)(off[q + 1] - off[q]);
+            x.len_b = x.paired ? (uint32_t)(off[q + 2] - off[q + 1]) : 0;
+            x.vertex_set = r->has_vertex_id(true);
+            x.vertex = x.vertex_set ? r->get_vertex_id(true) : 0;
+        }
+    };
+    const unsigned T = n < (1u << 16) ? 1u : std::max(1u, std::min<unsigned>(program_settings.n_threads, 8u));
+    if (T == 1) {
+        fill(0, n);
+        return;
     }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(fill, n * t / T, n * (t + 1) / T);
+    fill(0, n / T);
+    for (auto& x : th) x.join();
 }
 
 // src/EdgeCalculator.cpp:395-414 (+ the Edge construction of compute_overlap): device scoring, then finalise and

@@ -57,14 +57,19 @@ int split_overlap_line(const char* s, size_t n, bool allow_spaces, const char* f
 }
 
 IdIndex::IdIndex(const FastqStorage& fastq) {
-    const auto& map = fastq.m_ID_to_index;
-    const size_t n = map.size();
+    // m_ID_to_index (a std::map, src/FastqStorage.h:83-96) maps an id to its FIRST occurrence in m_read_vec; the same
+    // table is built from m_read_vec itself, in index order, without walking the tree
+    const std::vector<Read*>& reads = fastq.m_read_vec;
+    const size_t n = reads.size();
     read_id_t max_id = 0;
-    for (const auto& kv : map) max_id = kv.first > max_id ? kv.first : max_id;
+    for (const Read* r : reads) max_id = r->get_read_id() > max_id ? r->get_read_id() : max_id;
     if (n == 0 || max_id < 8 * n + 1024) {
         m_direct = true;
         m_table.assign(n ? (size_t)max_id + 1 : 0, kNone);
-        for (const auto& kv : map) m_table[kv.first] = kv.second;  // the map already holds the first occurrence
+        for (size_t i = 0; i < n; i++) {
+            uint32_t& slot = m_table[reads[i]->get_read_id()];
+            if (slot == kNone) slot = (uint32_t)i;
+        }
     } else {
         m_direct = false;
         size_t cap = 16;
@@ -73,11 +78,14 @@ IdIndex::IdIndex(const FastqStorage& fastq) {
         m_shift = 64 - bits;
         m_table.assign(cap, kNone);
         m_keys.assign(cap, 0);
-        for (const auto& kv : map) {
-            uint64_t h = (kv.first * 0x9E3779B97F4A7C15ull) >> m_shift;
-            while (m_table[h] != kNone) h = (h + 1) & (cap - 1);
-            m_table[h] = kv.second;
-            m_keys[h] = kv.first;
+        for (size_t i = 0; i < n; i++) {
+            const read_id_t id = reads[i]->get_read_id();
+            uint64_t h = (id * 0x9E3779B97F4A7C15ull) >> m_shift;
+            while (m_table[h] != kNone && m_keys[h] != id) h = (h + 1) & (cap - 1);
+            if (m_table[h] == kNone) {
+                m_table[h] = (uint32_t)i;
+                m_keys[h] = id;
+            }
         }
     }
 }

@@ -305,3 +305,19 @@ def test_fastq_reader_line_semantics(tmp_path):
     assert f.read_ids.tolist() == [1]
     with pytest.raises(hc.HcError):
         host.Fastq(singles=_write(tmp_path / "g.fastq", "@1\nACGT\n+\nIII\n"))                        # lengths differ
+
+
+def test_id_lookup_sparse_and_duplicate_ids(tmp_path):
+    """Overlaps-file ids -> read indices (std::map::at on m_ID_to_index in the reference): ids far beyond the read
+    count take the hashed table, small ones the direct table; a duplicated id resolves to its first read."""
+    for big in (10 ** 12, 900):
+        ids = [7, big, 7, 41]
+        s = _write(tmp_path / f"s{big}.fastq", "".join(f"@{i}\nACGTACGTAC\n+\nIIIIIIIIII\n" for i in ids))
+        f = host.Fastq(singles=s)
+        assert f.read_ids.tolist() == ids
+        ov = _write(tmp_path / f"ov{big}.txt", f"7\t{big}\t3\t-\t-\t+\t+\t70\t-\t7\t-\ts\ts\n41\t7\t2\t-\t-\t+\t-\t80\t-\t8\t-\ts\ts\n")
+        recs, c = f.parse_file(hc.Settings(min_overlap_len=0), ov)
+        assert recs["read1"].tolist() == [0, 3] and recs["read2"].tolist() == [1, 0]
+        bad = _write(tmp_path / f"bad{big}.txt", f"7\t{big + 1}\t3\t-\t-\t+\t+\t70\t-\t7\t-\ts\ts\n")
+        with pytest.raises(hc.HcError):
+            f.parse_file(hc.Settings(min_overlap_len=0), bad)
