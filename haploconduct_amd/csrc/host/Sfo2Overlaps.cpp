@@ -570,8 +570,7 @@ void match_bucket(const BRec* r, size_t n, long ns, long np, BucketResult& out) 
         if (!pa && !pb) {  // :79-85
             em->cur.clear();
             put_ss(em->cur, s_s_overlap(to_sfo(r[i])));
-            const std::string l = em->cur;
-            em->line(l);
+            em->line(em->cur);
             continue;
         }
         if (!out.has_paired) {  // whatever group is open from earlier buckets is matched here, by the stitching pass
