@@ -473,9 +473,6 @@ static int ensure_sort_workspace(hc_ctx* c, uint64_t n) {
     if (n <= c->sort_cap) return HC_OK;
     if (c->d_sort) (void)hipFree(c->d_sort);
     if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
-    if (c->d_compact_tmp) (void)hipFree(c->d_compact_tmp);
-    if (c->d_compact_idx) (void)hipFree(c->d_compact_idx);
-    if (c->d_compact_res) (void)hipFree(c->d_compact_res);
     c->d_sort = nullptr;
     c->d_sort_tmp = nullptr;
     c->sort_cap = 0;

@@ -397,3 +397,29 @@ def test_fuzz_random_read_sets_settings_and_geometry(oracle, seed):
         sc.set_reads(reads)
         assert sc.info()["qual_alphabet"] == np.unique(reads.quals).size
     check_parity(oracle, reads, st, cand)
+
+
+@pytest.mark.gpu
+def test_unordered_batches_of_growing_size_through_the_compact_path():
+    """Regression: an unordered batch takes the device re-ordering (its scratch grows with the batch) inside
+    hc_score_batch_compact, after the compaction scratch was sized — growing the one must not disturb the other.
+    Shuffled candidates in batches of increasing size; indices and records must be those of the plain call."""
+    from haploconduct_amd import synth
+
+    reads, meta = synth.make_paired_dataset(20000, 30000, seed=71)
+    cand = synth.paired_candidates(meta, n_candidates=None, seed=5)
+    rng = np.random.default_rng(3)
+    cand = cand[rng.permutation(cand.size)]
+    assert cand.size > 480000
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.9, min_overlap_len=0)
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        at = 0
+        for n in (5000, 90000, 150000, 230000):
+            batch = np.ascontiguousarray(cand[at:at + n])
+            at += n
+            idx, res = sc.score_batch_compact(batch)
+            full = sc.score_batch(batch)
+            keep = np.nonzero((full["n_cls"] >> 28) != 0)[0]
+            assert np.array_equal(idx, keep.astype(idx.dtype)), n
+            assert res.tobytes() == full[keep].tobytes(), n

@@ -413,3 +413,23 @@ def test_sort_edges_after_construct_edges(tmp_path, kind):
     assert after.tobytes() == want.tobytes()
     assert not np.array_equal(after["v2"], before["v2"])  # it did reorder something
     assert np.array_equal(off, woff) and np.array_equal(nodes, wnodes)
+
+
+def test_unordered_overlaps_file_over_many_blocks(oracle, tmp_path):
+    """An overlaps file in no particular order (duplicates shuffled in), long enough for many pipeline blocks of
+    different line counts: every block takes the device re-ordering before the kernel and the compaction after it."""
+    reads, meta = synth.make_paired_dataset(12000, 16000, flip_frac=0.3, seed=61)
+    reads.quals[:] = HQ[np.random.default_rng(2).integers(0, HQ.size, reads.quals.size)]
+    cand = synth.paired_candidates(meta, n_candidates=None, seed=7)[:260000]
+    rng = np.random.default_rng(5)
+    cand = np.concatenate([cand, cand[rng.integers(0, cand.size, 40000)]])
+    cand = cand[rng.permutation(cand.size)]
+    lines = synth.records_to_lines(cand, reads)
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.9, min_overlap_len=0, flags=FLAG_RESOLVE_ORIENTATIONS)
+    st.n_threads = 8
+    os.environ["HC_STAGE_BLOCK"] = "37000"
+    try:
+        edges, c = run_both(oracle, tmp_path, reads, lines, st, "unordered")
+    finally:
+        os.environ.pop("HC_STAGE_BLOCK", None)
+    assert c["dup_count"] > 1000 and edges.size > 5000

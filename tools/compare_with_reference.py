@@ -29,6 +29,11 @@ def main():
     spec.loader.exec_module(mg)
     reads, cand, cfg, st = bench.build_workload(workload, 0)
     cand = cand[:n]
+    dup_frac = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+    if dup_frac > 0:  # duplicates of random candidates shuffled in: the replace / keep decisions and the tie-break chain at scale
+        rng = np.random.default_rng(11)
+        extra = cand[rng.integers(0, cand.size, int(cand.size * dup_frac))]
+        cand = np.concatenate([cand, extra])[rng.permutation(cand.size + extra.size)]
     lines = synth.records_to_lines(cand, reads)
     ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so"))
     ref.frag_process_overlaps.restype = C.c_int
@@ -58,7 +63,7 @@ def main():
     t_hip = time.perf_counter() - t0
     compare_edges(got, want, "HIP stage vs the reference's own code")
     assert open(d + "nonedge_overlaps.txt").read() == nonedge and cnt["dup_count"] == counters[1] and cnt["inclusion_count"] == counters[0]
-    print(json.dumps({"workload": cfg["workload"], "candidates": n, "edges": len(edges), "identical_graph": True,
+    print(json.dumps({"workload": cfg["workload"], "candidates": int(cand.size), "duplicates_resolved": int(counters[1]), "edges": len(edges), "identical_graph": True,
                       "reference_process_overlaps_1_thread_s": round(t_ref, 2), "hip_stage_open_plus_construct_edges_s": round(t_hip, 3)}))
     import shutil
     shutil.rmtree(d, ignore_errors=True)
