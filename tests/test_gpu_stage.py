@@ -433,3 +433,23 @@ def test_unordered_overlaps_file_over_many_blocks(oracle, tmp_path):
     finally:
         os.environ.pop("HC_STAGE_BLOCK", None)
     assert c["dup_count"] > 1000 and edges.size > 5000
+
+
+def test_prefilter_rejecting_half_of_the_lines_over_many_blocks(oracle, tmp_path):
+    """Every block loses lines to the prefilter and to the line limit: the parser closes the gaps inside each block
+    (through the workers' scratch), the rejected lines end up in nonedge_overlaps.txt after the scored non-edges."""
+    reads, meta = synth.make_paired_dataset(9000, 12000, flip_frac=0.2, seed=63)
+    reads.quals[:] = HQ[np.random.default_rng(4).integers(0, HQ.size, reads.quals.size)]
+    cand = synth.paired_candidates(meta, n_candidates=None, seed=9)[:200000]
+    lines = synth.records_to_lines(cand, reads)
+    for junk_at in range(0, len(lines), 997):
+        lines[junk_at] = "not\tan\toverlap"
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.5, min_overlap_len=230, min_overlap_perc=0, flags=FLAG_RESOLVE_ORIENTATIONS,
+                     max_overlaps=len(lines) - 12345)
+    st.n_threads = 16
+    os.environ["HC_STAGE_BLOCK"] = "21000"
+    try:
+        edges, c = run_both(oracle, tmp_path, reads, lines, st, "prefilter")
+    finally:
+        os.environ.pop("HC_STAGE_BLOCK", None)
+    assert c["prefilter_rejected"] > 50000 and c["scored"] > 30000 and c["malformed_lines"] > 100 and edges.size > 1000
