@@ -238,3 +238,77 @@ def test_c2_slice_against_the_references_own_code(tmp_path):
     compare_edges(got, want, "HIP stage vs the reference's own code")
     assert (out / "nonedge_overlaps.txt").read_text() == nonedge
     assert cnt["inclusion_count"] == counters[0] and cnt["dup_count"] == counters[1]
+
+
+def test_mixed_read_types_against_the_references_own_code(tmp_path):
+    """Singles against pairs and pairs against singles (the s-p / p-s branches of compute_overlap, src/EdgeCalculator.cpp:
+    236-308, with their pos3 / pos4 arithmetic), some ten thousand candidates with wrong and right geometry, duplicates
+    shuffled in: the REFERENCE'S OWN compute_overlap / process_overlaps (fragment probe) and the HIP stage must leave
+    the same graph, non-edge file and counters."""
+    import ctypes as C
+    import importlib.util
+
+    lib_path = os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("oracle/_ref/libhcref_edgecalc.so is built only where /root/reference exists")
+    spec = importlib.util.spec_from_file_location("make_golden_ec", os.path.join(ROOT, "tests", "golden", "make_golden_ec.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from haploconduct_amd import host
+    from haploconduct_amd.records import OVERLAP_DTYPE
+    from tests.test_ec_golden import compare_edges
+    from tests.test_gpu_parity import _mixed_reads
+
+    reads, spos, ppos = _mixed_reads(77, n_single=900, n_pair=900, glen=9000)
+    ns = len(spos)
+    sp = np.array(spos, dtype=np.int64)
+    pp = np.array(ppos, dtype=np.int64)
+    S, L = sp[:, 0][:, None], sp[:, 1][:, None]
+    PS, INS = pp[:, 0][None, :], pp[:, 1][None, :]
+    rec = []
+    p1, p2 = PS - S, PS + INS - 150 - S                       # s-p: both mates start inside the single
+    i, j = np.nonzero((p1 >= 0) & (p1 < L - 40) & (p2 >= 0) & (p2 < L - 40))
+    for a, b in zip(i.tolist(), j.tolist()):
+        Ls = int(sp[a, 1])
+        rec.append((a, ns + b, int(p1[a, b]), int(p2[a, b]), 1, 1, ord("-"), 2, min(Ls - int(p1[a, b]), 150), min(Ls - int(p2[a, b]), 150), 90))
+    q1, q2 = S - PS, PS + INS - 150 - S                        # p-s: the single starts inside /1, /2 starts inside the single
+    i, j = np.nonzero((q1 >= 0) & (q1 < 110) & (q2 >= 0) & (q2 < L - 40))
+    for a, b in zip(i.tolist(), j.tolist()):
+        Ls = int(sp[a, 1])
+        rec.append((ns + b, a, int(q1[a, b]), int(q2[a, b]), 1, 1, ord("-"), 1, min(150 - int(q1[a, b]), Ls), min(Ls - int(q2[a, b]), 150), 90))
+    cand = np.array(rec, dtype=OVERLAP_DTYPE)
+    rng = np.random.default_rng(8)
+    wrong = cand[rng.integers(0, cand.size, cand.size // 5)].copy()  # wrong offsets: mismatching overlaps, non-edges
+    wrong["pos1"] = (wrong["pos1"] + rng.integers(1, 30, wrong.size)) % 100
+    cand = np.concatenate([cand, wrong, cand[rng.integers(0, cand.size, cand.size // 4)]])
+    cand = cand[rng.permutation(cand.size)]
+    assert cand.size > 10000
+    lines = synth.records_to_lines(cand, reads)
+    ref = C.CDLL(lib_path)
+    ref.frag_process_overlaps.restype = C.c_int
+    ref.frag_process_overlaps.argtypes = [C.POINTER(mg.FragSettings), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_uint64, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
+    ref.frag_ec_free.argtypes = [C.c_void_p]
+    st = hc.Settings(edge_threshold=0.9, ov_threshold=0.3, min_overlap_len=0, min_overlap_perc=0)
+    st.flags |= hc.records.FLAG_RESOLVE_ORIENTATIONS
+    st.n_threads = 8
+    settings = dict(edge_threshold=st.edge_threshold, ov_threshold=st.ov_threshold, merge_contigs=st.merge_contigs, mismatch=st.mismatch,
+                    min_read_len=st.min_read_len, ignore_inclusions=0)
+    edges, incl, nonedge, counters = mg.run_probe(ref, reads, lines, settings)
+    assert len(edges) > 2000 and counters[1] > 500 and nonedge.count("\n") > 200
+    names = ["score", "mismatch_rate", "pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"]
+    want = {k: [e[i] for e in edges] for i, k in enumerate(names)}
+    for k in ("score", "mismatch_rate"):
+        want[k] = np.array([float.fromhex(x) for x in want[k]], np.float64)
+    (tmp_path / "overlaps.txt").write_text("\n".join(lines) + "\n")
+    reads.write_fastq(str(tmp_path / "s.fastq"), str(tmp_path / "p1.fastq"), str(tmp_path / "p2.fastq"))
+    out = tmp_path / "out"
+    out.mkdir()
+    with host.EdgeCalculatorStage(st, singles=str(tmp_path / "s.fastq"), paired1=str(tmp_path / "p1.fastq"), paired2=str(tmp_path / "p2.fastq"),
+                                  overlaps=str(tmp_path / "overlaps.txt"), output_dir=str(out) + "/") as ec:
+        ec.construct_edges()
+        got, cnt = ec.edges(), ec.counters()
+    compare_edges(got, want, "HIP stage vs the reference's own code, mixed read types")
+    assert (out / "nonedge_overlaps.txt").read_text() == nonedge
+    assert cnt["dup_count"] == counters[1] and cnt["inclusion_count"] == counters[0]
