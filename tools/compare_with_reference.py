@@ -41,10 +41,14 @@ def main():
                                           C.c_uint64, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
     ref.frag_ec_free.argtypes = [C.c_void_p]
+    ign = int(os.environ.get("HC_CMP_IGNORE_INCLUSIONS", "0"))  # --ignore_inclusions
+    st.merge_contigs = float(os.environ.get("HC_CMP_MERGE_CONTIGS", st.merge_contigs))  # --merge_contigs
+    if ign:
+        st.flags |= hc.records.FLAG_IGNORE_INCLUSIONS
     t0 = time.perf_counter()
     edges, incl, nonedge, counters = mg.run_probe(ref, reads, lines, dict(edge_threshold=st.edge_threshold, ov_threshold=st.ov_threshold,
                                                                           merge_contigs=st.merge_contigs, mismatch=st.mismatch,
-                                                                          min_read_len=st.min_read_len, ignore_inclusions=0))
+                                                                          min_read_len=st.min_read_len, ignore_inclusions=ign))
     t_ref = time.perf_counter() - t0
     names = ["score", "mismatch_rate", "pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"]
     want = {k: [e[i] for e in edges] for i, k in enumerate(names)}
@@ -59,11 +63,13 @@ def main():
     t0 = time.perf_counter()
     with host.EdgeCalculatorStage(st, overlaps=d + "overlaps.txt", output_dir=d, **fq) as ec:
         ec.construct_edges()
-        got, cnt = ec.edges(), ec.counters()
+        got, cnt, got_incl = ec.edges(), ec.counters(), ec.inclusions()
     t_hip = time.perf_counter() - t0
+    assert got_incl.tolist() == list(incl), "inclusions bits differ"
+
     compare_edges(got, want, "HIP stage vs the reference's own code")
     assert open(d + "nonedge_overlaps.txt").read() == nonedge and cnt["dup_count"] == counters[1] and cnt["inclusion_count"] == counters[0]
-    print(json.dumps({"workload": cfg["workload"], "candidates": int(cand.size), "duplicates_resolved": int(counters[1]), "edges": len(edges), "identical_graph": True,
+    print(json.dumps({"workload": cfg["workload"], "candidates": int(cand.size), "duplicates_resolved": int(counters[1]), "edges": len(edges), "identical_graph": True, "inclusion_bits_set": int(sum(incl)), "merge_contigs": st.merge_contigs, "ignore_inclusions": ign,
                       "reference_process_overlaps_1_thread_s": round(t_ref, 2), "hip_stage_open_plus_construct_edges_s": round(t_hip, 3)}))
     import shutil
     shutil.rmtree(d, ignore_errors=True)
