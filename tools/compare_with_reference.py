@@ -43,6 +43,8 @@ def main():
     ref.frag_ec_free.argtypes = [C.c_void_p]
     ign = int(os.environ.get("HC_CMP_IGNORE_INCLUSIONS", "0"))  # --ignore_inclusions
     st.merge_contigs = float(os.environ.get("HC_CMP_MERGE_CONTIGS", st.merge_contigs))  # --merge_contigs
+    st.mismatch = float(os.environ.get("HC_CMP_MISMATCH", st.mismatch))  # --mismatch
+    st.min_read_len = int(os.environ.get("HC_CMP_MIN_READ_LEN", st.min_read_len))  # --min_read_len
     if ign:
         st.flags |= hc.records.FLAG_IGNORE_INCLUSIONS
     t0 = time.perf_counter()
@@ -69,7 +71,7 @@ def main():
 
     compare_edges(got, want, "HIP stage vs the reference's own code")
     assert open(d + "nonedge_overlaps.txt").read() == nonedge and cnt["dup_count"] == counters[1] and cnt["inclusion_count"] == counters[0]
-    print(json.dumps({"workload": cfg["workload"], "candidates": int(cand.size), "duplicates_resolved": int(counters[1]), "edges": len(edges), "identical_graph": True, "inclusion_bits_set": int(sum(incl)), "merge_contigs": st.merge_contigs, "ignore_inclusions": ign,
+    print(json.dumps({"workload": cfg["workload"], "candidates": int(cand.size), "duplicates_resolved": int(counters[1]), "edges": len(edges), "identical_graph": True, "inclusion_bits_set": int(sum(incl)), "merge_contigs": st.merge_contigs, "mismatch": st.mismatch, "min_read_len": st.min_read_len, "ignore_inclusions": ign,
                       "reference_process_overlaps_1_thread_s": round(t_ref, 2), "hip_stage_open_plus_construct_edges_s": round(t_hip, 3)}))
     import shutil
     shutil.rmtree(d, ignore_errors=True)
