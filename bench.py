@@ -4,18 +4,24 @@
     python bench.py --gpus N --steps K --warmup W            (N = 1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (hc_score_batch_device: compute_overlap +
-overlap_score + admission class for every candidate) over one device-resident batch
-of synthetic candidates.  Workload = BASELINE.json configs[1]: 50k synthetic 2x150 bp
-read pairs, 2,000,000 p-p candidate overlaps per GPU (weak scaling: every rank scores
-its own 2M-candidate shard against the replicated read store; for N > 1 the admitted
-edge records are then gathered with one RCCL all-gather-v).
+A "step" is one pass of the hot path (hc_score_cands_device: compute_overlap + overlap_score + admission
+class for every candidate) over one device-resident batch of synthetic candidates, in the record form the stage
+sends to the device (hc_cand_rec, 16 bytes).  Workload = the configuration BASELINE.json's target is quoted on, which
+fits one GPU: configs[2] "c3" — 500k synthetic 2x150 bp read pairs, 1e8 p-p candidate overlaps (--max_ov's default,
+src/ViralQuasispecies.cpp:58).  N > 1: --scaling weak (default; every rank scores its own 1e8-candidate shard against
+the replicated read store) or strong (the 1e8 candidates are split over the ranks); the non-dropped records of every
+rank are collected on every rank with one RCCL all-gather per step.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline":     algorithmic bytes (32 + 16 + 4*L_sub per candidate) over
-                  the scoring kernel's mean launch time (hipEvents on the launch stream), vs 8 TB/s HBM
-  "cpu_baseline": the CPU oracle (a port of the reference algorithm, oracle/hc_oracle.c) timed
-                  with OpenMP on this box's host cores on a bounded sample of the same workload.
+  "roofline":     the scoring kernel's mean launch time (hipEvents on the launch stream) against 8 TB/s HBM:
+                  `achieved` / `frac` from the memory-side bytes the PMC counters measured for this workload
+                  (profiles/traffic_<workload>.json: a bound that cannot be exceeded), `algorithmic_GBps` /
+                  `frac_algorithmic` from SURVEY.md §8(d)'s 32 + 16 + 4*L_sub bytes per candidate (no credit for cache
+                  reuse: exceeds the peak when the read store is served from the caches), `issue_bound` = the busy
+                  fractions of the units that actually bound the kernel (vector-memory front end, VALU, LDS)
+  "stage_end_to_end": text overlaps file + FASTQ -> populated, sorted OverlapGraph (hc_ec_construct_edges_sorted)
+  "cpu_baseline": the reference's own process_overlaps (fragment probe) / the CPU oracle timed on this box's host cores
+  "also":         the same measurements on configs[1] "c2" (2M candidates), the round-1 headline
 """
 import argparse
 import json
@@ -31,19 +37,49 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def pmc_traffic(workload, order):
-    """HBM bytes per launch of the scoring kernel from committed rocprofv3 PMC passes
-    (profiles/traffic_<workload>.json, produced by tools/collect_traffic.sh: FETCH_SIZE and WRITE_SIZE
-    in separate --pmc passes; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950)."""
+def pmc_profile(workload, order):
+    """The committed rocprofv3 PMC passes of the scoring kernel on this workload (profiles/traffic_<workload>.json,
+    produced by tools/collect_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md §HBM prescribes for gfx950), or None."""
     path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("order") == order:
-            return t["hbm_bytes_per_launch"]
+        if t.get("order") == order and t.get("record_bytes", 32) == 16:
+            return t
     except Exception:
         pass
     return None
+
+
+def roofline_record(workload, order, n, positions, kern_ms):
+    """See the module docstring.  Memory-side bytes come from the PMC pass of the same workload and record format."""
+    alg_bytes = 48 * n + 4 * positions  # SURVEY.md §8(d): 32 B record + 16 B result + 4 B per overlapped position
+    alg = alg_bytes / (kern_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+         "kernel": "hc::score_kernel", "kernel_ms": kern_ms, "kernel_candidates_per_s": n / (kern_ms * 1e-3),
+         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg, "frac_algorithmic": alg / HBM_PEAK_GBS,
+         "note": "achieved/frac: memory-side bytes of the PMC pass (FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included) over the "
+                 "live kernel time — bounded by the peak; frac_algorithmic: SURVEY 8(d) bytes without cache-reuse credit, not a bound "
+                 "(the read store is re-read out of L1/L2/Infinity Cache); the kernel is bound by vector-memory (TA) and VALU issue, see issue_bound"}
+    t = pmc_profile(workload, order)
+    if t:
+        c = t.get("counters_per_launch", {})
+        r["traffic"] = t["hbm_bytes_per_launch"]
+        r["achieved"] = t["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        busy = {}
+        if c.get("GRBM_GUI_ACTIVE") and c.get("TA_BUSY_avr"):
+            busy["ta_busy"] = c["TA_BUSY_avr"] / (c["GRBM_GUI_ACTIVE"] / 8.0)  # GRBM_GUI_ACTIVE sums the 8 XCDs
+        if c.get("SQ_WAVE_CYCLES"):
+            for k, name in (("SQ_ACTIVE_INST_VALU", "valu_active_of_wave_cycles"), ("SQ_ACTIVE_INST_LDS", "lds_active_of_wave_cycles"),
+                            ("SQ_WAIT_ANY", "waiting_of_wave_cycles")):
+                if c.get(k):
+                    busy[name] = c[k] / c["SQ_WAVE_CYCLES"]
+        if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
+            busy["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        r["issue_bound"] = dict(busy, source=f"profiles/traffic_{workload}.json")
+    return r
 
 
 def build_workload(workload, rank):
@@ -178,13 +214,153 @@ def cpu_baseline_reference(reads, settings, cand, budget_s=10.0, n_lines=200000)
                       f"is not part of it), {best_t} OpenMP threads (fastest of 1, 1/2 ... 1/16 of {hw} hardware threads), {total:.1f} s"}
 
 
+def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, world, with_gather):
+    """Timed steps + kernel timing of one workload on this rank; returns (record for the JSON line, reads, candidates, settings)."""
+    import haploconduct_amd as hc
+    from haploconduct_amd import parallel
+    from haploconduct_amd.records import REC_COMPACT
+
+    strong = scaling == "strong" and world > 1
+    reads, cand, cfg, settings = build_workload(workload, 0 if strong else rank)
+    settings.device = local_rank
+    if order == "grouped":
+        cand = cand[np.argsort(cand["read1"], kind="stable")]
+    elif order == "shuffled":
+        cand = cand[np.random.default_rng(5).permutation(cand.size)]
+    n_job = int(cand.size) * (1 if strong else world)  # candidates one step scores over all ranks
+    if strong:  # the one candidate set split over the ranks: contiguous, order-preserving shards
+        lo, hi = parallel.shard_range(int(cand.size), rank, world)
+        cand, base_index = cand[lo:hi], lo
+    else:
+        base_index = rank * int(cand.size)
+    n = int(cand.size)
+    sc = hc.EdgeScorer(settings)
+    sc.set_reads(reads)
+    cd = sc.pack_cands(cand)  # hc_cand_rec: the 16 bytes per candidate the stage sends to the device
+    d_in = torch.from_numpy(cd.view(np.uint8).reshape(-1)).cuda()
+    d_out = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+    positions, subs = sc.count_positions_device(d_in.data_ptr(), n, REC_COMPACT)
+
+    # N > 1 (SURVEY.md §8(e)): every rank scores its shard against a replicated read store; per step, the non-dropped
+    # records of every rank are collected on every rank.  The scoring kernel itself appends them (tagged with their
+    # global index) to a payload whose row 0 is the count, so the all-gather-v is ONE all-gather over RCCL per step, on
+    # a side stream, overlapping the scoring kernel of the next step; nothing synchronises with the host inside a step
+    # (parallel.StreamedGather).  An explicit (non-default) stream for the scoring launches: events and the
+    # collection's side stream order against it by themselves.
+    launch_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(launch_stream)
+    stream = launch_stream.cuda_stream
+    gather = None
+    if with_gather:
+        sc.score_cands_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        kept = torch.tensor([int((((d_out.view(torch.int64).view(-1, 3)[:, 2] >> 60) & 0xF) != 0).sum().item())], device="cuda")
+        dist.all_reduce(kept, op=dist.ReduceOp.MAX)  # one capacity for all ranks
+        gather = parallel.StreamedGather(sc, n, base_index=base_index, cap_rows=int(kept.item()) * 5 // 4 + 1024, rec_fmt=REC_COMPACT)
+    last = None
+
+    def step():
+        nonlocal last
+        if gather:  # the scoring kernel appends the collection payload itself; the all-gather of step i runs on a
+            last = gather.score_step(d_in.data_ptr(), d_out)  # side stream beside the kernel of step i + 1
+        else:
+            sc.score_cands_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    if gather:
+        gather.finish()
+    sc.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if gather:
+        gather.finish()  # every all-gather of the timed steps has completed
+    sc.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if gather:  # outside the timed region: the collected set is what it should be
+        rows, counts = gather.collect(last)
+        assert len(counts) == world and rows.shape[0] == sum(counts) and bool((rows[1:, 0] > rows[:-1, 0]).all()), "gathered rows out of order"
+    if dist:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # kernel-only: hipEvents on the stream the kernel is launched on
+    kern_ms = sc.time_kernel(d_in.data_ptr(), n, d_out.data_ptr(), max(5, min(args.steps, 200)), REC_COMPACT)
+    rec = {
+        "value": n_job * args.steps / dt,
+        "ms_per_step": dt / args.steps * 1e3,
+        "config": dict(cfg, candidates_per_gpu=n, candidates_per_step=n_job, record_bytes=16,
+                       parallelism=f"candidate shards x{world}, replicated read store" +
+                                   (", one all-gather of the non-dropped records per step" if gather else ""),
+                       edge_threshold=settings.edge_threshold, mean_positions_per_candidate=positions / max(n, 1)),
+        "roofline": roofline_record(workload, order, n, positions, kern_ms),
+    }
+    sc.close()
+    del d_in, d_out
+    torch.cuda.empty_cache()
+    return rec, reads, cand, settings
+
+
+def stage_end_to_end(reads, cand, settings, threads, reps=2):
+    """text overlaps file + FASTQ in -> populated OverlapGraph in sortEdges order + nonedge_overlaps.txt
+    out, through the host mirror (hc_ec_open, hc_ec_construct_edges_sorted) on this box; files in a scratch directory."""
+    import shutil
+    import tempfile
+
+    from haploconduct_amd import host
+
+    d = tempfile.mkdtemp(prefix="hcstage_") + "/"
+    try:
+        t0 = time.perf_counter()
+        host.write_overlaps(d + "overlaps.txt", cand, reads)
+        paired = reads.is_paired(0)
+        reads.write_fastq(None if paired else d + "singles.fastq", d + "paired1.fastq" if paired else None, d + "paired2.fastq" if paired else None)
+        t_files = time.perf_counter() - t0
+        settings.n_threads = threads
+        kw = dict(singles=None if paired else d + "singles.fastq", paired1=d + "paired1.fastq" if paired else None,
+                  paired2=d + "paired2.fastq" if paired else None, overlaps=d + "overlaps.txt", output_dir=d)
+        runs = []
+        for _ in range(reps):
+            if os.path.exists(d + "nonedge_overlaps.txt"):
+                os.remove(d + "nonedge_overlaps.txt")
+            t0 = time.perf_counter()
+            ec = host.EdgeCalculatorStage(settings, **kw)
+            t1 = time.perf_counter()
+            ec.construct_edges_sorted()
+            t2 = time.perf_counter()
+            c = ec.counters()
+            runs.append({"open_s": t1 - t0, "construct_edges_sorted_s": t2 - t1, "edges": ec.edge_count(), "scored": c["scored"],
+                         "parse_s": c["t_parse"], "collect_s": c["t_score"], "resolve_s": c["t_insert"], "write_s": c["t_write"]})
+            ec.close()
+        best = min(runs, key=lambda r: r["construct_edges_sorted_s"])
+        return {"value": best["scored"] / best["construct_edges_sorted_s"], "unit": "candidate overlaps/s", "threads": threads,
+                "text_bytes": os.path.getsize(d + "overlaps.txt"), "files_written_s": t_files, "best": best, "runs": runs,
+                "what": "hc_ec_construct_edges_sorted: overlaps text file -> parse -> H2D of 16-byte records -> scoring kernel -> non-dropped rows "
+                        "-> host exp() -> device duplicate resolution + adjacency in sortEdges order -> OverlapGraph; FASTQ load + store "
+                        "upload (open_s) not included, as in the reference's own timing (src/ViralQuasispecies.cpp:280-283)"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--also", default="c2", help="second workload measured on one GPU and reported under \"also\" ('none' = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank scores its own candidate set of the workload's size; strong = the one set is split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage", action="store_true", help="skip the stage end-to-end measurement")
+    ap.add_argument("--stage-threads", type=int, default=0, help="--threads of the stage (0 = min(32, hardware threads))")
     ap.add_argument("--order", default="sfo", choices=["sfo", "grouped", "shuffled"],
                     help="candidate order inside the batch: sfo = sorted by (min id, max id) as scripts/sfo2overlaps.py:53 "
                          "writes overlap files (default); grouped = by read1; shuffled = random (experiment knobs)")
@@ -207,8 +383,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device: libhcedge has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    # HC_BENCH_FORCE_GATHER=1: run the N > 1 step (compaction + pack + all-gathers) on a single rank too, to time
-    # and test that code path on one GPU; never set by the driver
+    # HC_BENCH_FORCE_GATHER=1: run the N > 1 step (payload + all-gather) on a single rank too, to time and test that
+    # code path on one GPU; never set by the driver
     with_gather = world > 1 or os.environ.get("HC_BENCH_FORCE_GATHER") == "1"
     if with_gather:
         import torch.distributed as dist
@@ -219,119 +395,32 @@ def main():
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1,
                                     device_id=torch.device("cuda", local_rank))
 
-    import haploconduct_amd as hc
-
-    reads, cand, cfg, settings = build_workload(args.workload, rank)
-    settings.device = local_rank
-    if args.order == "grouped":
-        cand = cand[np.argsort(cand["read1"], kind="stable")]
-    elif args.order == "shuffled":
-        cand = cand[np.random.default_rng(5).permutation(cand.size)]
-    n = int(cand.size)
-    sc = hc.EdgeScorer(settings)
-    sc.set_reads(reads)
-    d_in = torch.from_numpy(cand.view(np.uint8).reshape(-1)).cuda()
-    d_out = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
-    positions, subs = sc.count_positions_device(d_in.data_ptr(), n)
-    alg_bytes = 48 * n + 4 * positions  # 32 B record + 16 B result + 4 B per overlapped position
-
-    # N > 1: rank r owns global candidates [r*n, (r+1)*n) (weak scaling) against a replicated read
-    # store; per step, the non-dropped records of every rank are collected on every rank.  The scoring kernel itself
-    # appends them (tagged with their global index) to a payload whose row 0 is the count, so the all-gather-v is ONE
-    # all-gather over RCCL per step, on a side stream, overlapping the scoring kernel of the next step; nothing
-    # synchronises with the host inside a step (parallel.StreamedGather).
-    # an explicit (non-default) stream for the scoring launches: events and the collection's side stream order
-    # against it by themselves, without leaning on the legacy default stream's implicit synchronisation
-    launch_stream = torch.cuda.Stream()
-    torch.cuda.set_stream(launch_stream)
-    stream = launch_stream.cuda_stream
-    gather = None
-    if with_gather:
-        from haploconduct_amd import parallel
-
-        sc.score_batch_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
-        torch.cuda.synchronize()
-        kept = torch.tensor([int((((d_out.view(torch.int64).view(-1, 3)[:, 2] >> 60) & 0xF) != 0).sum().item())], device="cuda")
-        dist.all_reduce(kept, op=dist.ReduceOp.MAX)  # one capacity for all ranks
-        gather = parallel.StreamedGather(sc, n, base_index=rank * n, cap_rows=int(kept.item()) * 5 // 4 + 1024)
-
-    last = None
-    gather_mode = "streamed" if gather else None
-
-    n_steps = 0
-
-    def step():
-        nonlocal last, n_steps
-        if gather_mode == "streamed":  # the scoring kernel appends the collection payload itself; the all-gather
-            n_steps += 1               # of step i runs on a side stream beside the kernel of step i+1
-            last = gather.score_step(d_in.data_ptr(), d_out)
-            return
-        sc.score_batch_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
-        if gather_mode == "plain":  # counts, then padded payload, with host round trips (parallel.gather_admitted)
-            torch.cuda.synchronize()
-            last = parallel.gather_admitted(d_out, rank * n)
-
-    if gather:
-        try:  # one step of the streamed collection, checked; the plain form is the fallback if RCCL objects
-            step()
-            gather.finish()
-            gather.collect(last)
-        except Exception as e:  # noqa: BLE001
-            print(f"bench.py: streamed gather failed ({e!r}); using the plain all-gather-v", file=sys.stderr)
-            gather_mode = "plain"
-    for _ in range(args.warmup):
-        step()
-    if gather_mode == "streamed":
-        gather.finish()
-    sc.synchronize()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if gather_mode == "streamed":
-        gather.finish()  # every all-gather of the timed steps has completed
-    sc.synchronize()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if gather_mode:  # outside the timed region: the collected set is what it should be
-        rows, counts = gather.collect(last) if gather_mode == "streamed" else last
-        assert len(counts) == world and rows.shape[0] == sum(counts) and bool((rows[1:, 0] > rows[:-1, 0]).all()), "gathered rows out of order"
-    if dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # kernel-only: hipEvents on the stream the kernel is launched on
-    kern_ms = sc.time_kernel(d_in.data_ptr(), n, d_out.data_ptr(), max(10, min(args.steps, 200)))
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-
+    main_rec, reads, cand, settings = run_workload(args.workload, args.order, args.scaling, args, torch, dist, rank, local_rank, world, with_gather)
+    out = None
     if rank == 0:
         out = {
             "metric": "candidate overlaps scored/sec (edge-calc stage)",
-            "value": world * n * args.steps / dt,
+            "value": main_rec["value"],
             "unit": "candidate overlaps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": main_rec["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": dict(cfg, parallelism=f"candidate shards x{world}, replicated read store" + (f", {gather_mode} all-gather-v of the non-dropped records per step" if gather_mode else ""),
-                           edge_threshold=settings.edge_threshold, mean_positions_per_candidate=positions / n),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, args.order),
-                         "kernel": "hc::score_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_candidates_per_s": n / (kern_ms * 1e-3)},
+            "config": main_rec["config"],
+            "roofline": main_rec["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline:
+    if dist:
+        dist.barrier()
+    if rank == 0 and world == 1:
+        if not args.no_stage:
+            threads = args.stage_threads or min(32, os.cpu_count() or 1)
+            out["stage_end_to_end"] = stage_end_to_end(reads, cand, settings, threads)
+        if not args.no_cpu_baseline:
             # the reference's own code where its probe library is present (it is built by __graft_entry__.build() in the
             # build container and travels with the repository), and always the oracle (a port) beside it
             port = cpu_baseline(reads, settings, cand)
@@ -339,8 +428,21 @@ def main():
             out["cpu_baseline"] = genuine if genuine else port
             if genuine:
                 out["cpu_baseline_port"] = port
-    sc.close()
+            # the reference's stage = its serial text parser + process_overlaps: SURVEY.md §0.6 measured the parser alone at
+            # ~4 us per line on one thread (it is not parallel); with the loop's rate measured above:
+            po = out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["stage_estimate"] = {
+                "value": 1.0 / (1.0 / po + 4.0e-6), "unit": "candidate overlaps/s",
+                "how": "1 / (1 / process_overlaps rate measured here + 4 us per line of construct_edges' serial getline/stringstream parser, "
+                       "SURVEY.md §0.6 probe; the parser cannot run here: it needs Boost)"}
+        del reads, cand
+        if args.also and args.also not in ("none", args.workload):
+            also_rec, r2, c2, s2 = run_workload(args.also, args.order, "weak", args, torch, None, 0, local_rank, 1, False)
+            if not args.no_stage:
+                also_rec["stage_end_to_end"] = stage_end_to_end(r2, c2, s2, args.stage_threads or min(32, os.cpu_count() or 1), reps=3)
+            out["also"] = {args.also: also_rec}
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()
     import ctypes

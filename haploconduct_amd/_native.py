@@ -47,7 +47,14 @@ class hc_settings(C.Structure):
         ("max_overlaps", C.c_uint64),
         ("device", C.c_int32),
         ("n_threads", C.c_uint32),
+        ("device_mask", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
+
+
+class hc_graph_counts(C.Structure):
+    _fields_ = [("n_admitted", C.c_uint64), ("n_edges", C.c_uint64), ("inclusion_count", C.c_uint64), ("dup_count", C.c_uint64),
+                ("n_tied_lists", C.c_uint64), ("first_bad", C.c_int64)]
 
 
 _vp = C.c_void_p
@@ -64,15 +71,24 @@ _sig = {
     "hc_synchronize": (C.c_int, [_vp]),
     "hc_compact_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "hc_find_overlaps": (C.c_int, [_vp, C.c_double, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
-    "hc_score_pack_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, _vp, C.POINTER(C.c_int)]),
+    "hc_score_pack_device": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, _vp]),
+    "hc_pack_cands": (None, [_vp, C.c_uint64, _vp]),
+    "hc_score_cands": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "hc_score_cands_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "hc_block_create": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    "hc_block_submit": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
+    "hc_block_wait": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64)]),
+    "hc_block_destroy": (C.c_int, [_vp]),
+    "hc_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, C.POINTER(hc_graph_counts)]),
+    "hc_graph_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hc_compact_pack_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp]),
     "hc_pack_rows_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp]),
     "hc_score_batch_compact": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_set_reorder": (C.c_int, [_vp, C.c_int]),
     "hc_host_alloc": (C.c_int, [_vp, C.POINTER(_vp), C.c_uint64]),
     "hc_host_free": (C.c_int, [_vp, _vp]),
-    "hc_time_score_kernel": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_int, C.POINTER(C.c_float)]),
-    "hc_count_positions_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hc_time_score_kernel": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64, _vp, C.c_int, C.POINTER(C.c_float)]),
+    "hc_count_positions_device": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "hc_finalize": (C.c_int, [C.POINTER(hc_settings), _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "hc_finalize_batch": (C.c_int, [C.POINTER(hc_settings), _vp, C.c_uint64, _vp, _vp, _vp]),
     "hc_get_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)] + [C.POINTER(C.c_double)] * 4),

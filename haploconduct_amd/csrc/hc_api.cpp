@@ -15,36 +15,7 @@
 #include <vector>
 
 #include "../../include/hcedge.h"
-#include "hc_device.h"
-#include "hc_overlap_finder.h"
-
-namespace hc {
-hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
-                         const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
-                         uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
-                         hipStream_t stream);
-hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in,
-                        uint64_t n, hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int variant,
-                        hipStream_t stream);
-size_t compact_temp_bytes(uint32_t n);
-hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_out, unsigned long long* count_out, void* temp,
-                          size_t temp_bytes, hipStream_t stream);
-hipError_t launch_pack_rows(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count, uint64_t cap, uint64_t base,
-                            hc_gather_row* rows, uint32_t n_cu, hipStream_t stream);
-hipError_t launch_pack_header(const unsigned long long* count, hc_gather_row* header, hipStream_t stream);
-hipError_t launch_score_rows(const StoreView& st, const ScoreParams& prm, const double* lut_g, const hc_overlap_rec* in, uint64_t n,
-                             hc_result_rec* out, uint32_t n_cu, int variant, hc_gather_row* payload, uint64_t cap, uint64_t base_index,
-                             hipStream_t stream);
-hipError_t launch_gather_results(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count,
-                                 hc_result_rec* out, uint32_t n_cu, hipStream_t stream);
-size_t reorder_temp_bytes(uint32_t n);
-hipError_t launch_reorder(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint32_t n,
-                          bool use_buckets, uint32_t* keys_in, uint32_t* keys_out, uint32_t* idx_in, uint32_t* perm_out,
-                          void* temp, size_t temp_bytes, hipStream_t stream);
-hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, const hc_overlap_rec* in, uint64_t n,
-                                  unsigned long long* totals, hipStream_t stream);
-hipError_t set_score_kernel_lds_limit();
-}  // namespace hc
+#include "hc_ctx.h"
 
 static thread_local std::string g_last_error;
 
@@ -53,96 +24,8 @@ static int fail(int status, const std::string& what) {
     return status;
 }
 namespace hc {
-int set_last_error(int status, const std::string& what) { return fail(status, what); }  // for host/*.cpp
+int set_last_error(int status, const std::string& what) { return fail(status, what); }
 }
-
-#define HC_HIP(call)                                                                                   \
-    do {                                                                                               \
-        hipError_t e__ = (call);                                                                       \
-        if (e__ != hipSuccess)                                                                         \
-            return fail(HC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));               \
-    } while (0)
-
-struct hc_ctx {
-    hc_settings settings;
-    int device = 0;
-    uint32_t n_cu = 256;
-    int variant = -1;  // scoring-kernel variant: -1 = chosen per read set in hc_set_reads (HC_SCORE_VARIANT overrides;
-                       // a tuning knob only, results are identical)
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // read store
-    bool have_reads = false;
-    void* d_sym = nullptr;
-    hc::ReadDesc* d_reads = nullptr;
-    double* d_lut = nullptr;
-    uint64_t store_bytes = 0;
-    hc::StoreView view{};
-    hc::ScoreParams params{};
-    // what the overlap finder needs of the sequences (host copies, filled by hc_set_reads)
-    std::vector<hc::SeqRef> seq_refs;  // by store sequence index
-    bool singles_first = true;
-    // result of the last hc_find_overlaps, kept on the device so that the usual "ask for the count, then fetch"
-    // pair of calls computes once
-    struct Scratch {  // grow-only device scratch of the finder, one slot per buffer, freed with the store
-        void* p = nullptr;
-        size_t cap = 0;
-    } finder_scratch[20];
-    hc_sfo_rec* d_found = nullptr;
-    uint64_t n_found = 0;
-    double found_err = -1;
-    uint32_t found_min = 0, found_flags = 0;
-    bool found_valid = false;
-    // grow-only workspace for the host-buffer entry point
-    void* d_in = nullptr;
-    void* d_out = nullptr;
-    uint64_t ws_cap = 0;
-    unsigned long long* d_totals = nullptr;
-    // candidate reorder (HC_REORDER_*): scratch for the (key, index) radix sort, grow-only
-    int reorder_mode = HC_REORDER_AUTO;
-    bool reorder_buckets = false;  // length-bucket major key: measured slower on C2/C4/C5 (locality beats divergence); HC_REORDER_BUCKETS=1 to experiment
-    uint32_t* d_sort = nullptr;  // 4 arrays of sort_cap uint32: keys_in, keys_out, idx_in, perm
-    void* d_sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
-    uint64_t sort_cap = 0;
-    // compaction scratch, grow-only
-    void* d_compact_tmp = nullptr;
-    size_t compact_tmp_bytes = 0;
-    uint32_t* d_compact_idx = nullptr;
-    hc_result_rec* d_compact_res = nullptr;
-    uint64_t compact_cap = 0;
-};
-
-namespace {
-// A view of one of the context's grow-only scratch slots (hc_ctx::finder_scratch).  The overlap finder needs
-// gigabytes of scratch per call; allocating and freeing them every call (hipMalloc/hipFree or the stream-ordered
-// pool alike) costs several times its kernels, so the blocks stay with the context until the store is replaced.
-struct DevBuf {
-    void* p = nullptr;
-    hc_ctx::Scratch* slot = nullptr;
-    void* own = nullptr;  // a block that is not a slot (the result, which outlives the call)
-    ~DevBuf() {
-        if (own) (void)hipFree(own);
-    }
-    template <typename T>
-    T* as() const { return (T*)p; }
-};
-}  // namespace
-
-#define HC_ALLOC(buf, bytes)                                                                  \
-    do {                                                                                      \
-        hc_ctx::Scratch& sl__ = c->finder_scratch[n_slots++];                                 \
-        const size_t need__ = (bytes) ? (size_t)(bytes) : 16;                                 \
-        if (sl__.cap < need__) {                                                              \
-            if (sl__.p) (void)hipFree(sl__.p);                                                \
-            sl__.p = nullptr;                                                                 \
-            sl__.cap = 0;                                                                     \
-            HC_HIP(hipMalloc(&sl__.p, need__ + need__ / 8));                                  \
-            sl__.cap = need__ + need__ / 8;                                                   \
-        }                                                                                     \
-        (buf).slot = &sl__;                                                                   \
-        (buf).p = sl__.p;                                                                     \
-    } while (0)
 
 // --------------------------------------------------------------------------
 // Threshold inversion: exp(x) > T decided in x-space.
@@ -230,8 +113,6 @@ int hc_create(hc_ctx** out, const hc_settings* settings) {
     HC_HIP(hipEventCreate(&c->ev1));
     HC_HIP(hipMalloc((void**)&c->d_totals, 2 * sizeof(unsigned long long)));
     HC_HIP(hc::set_score_kernel_lds_limit());
-    if (const char* v = getenv("HC_SCORE_VARIANT")) c->variant = atoi(v);
-    if (const char* v = getenv("HC_REORDER_BUCKETS")) c->reorder_buckets = atoi(v) != 0;
     c->params.edge = make_band(settings->edge_threshold);
     c->params.ov = make_band(settings->ov_threshold);
     c->params.merge_contigs = settings->merge_contigs;
@@ -446,11 +327,13 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         c->view.balance = (n_seq && lmax > 2u * lmin) ? 1u : 0u;  // mixed-length read set (contigs + reads)
         if (const char* b = getenv("HC_BALANCE")) c->view.balance = atoi(b) != 0;
     }
-    if (!getenv("HC_SCORE_VARIANT")) {
-        // 64-symbol fetch groups (variant 4) for short-read sets, 32-symbol groups (variant 5) when the
+    if (const char* v = getenv("HC_FETCH_GROUP")) {
+        c->fetch_group = atoi(v) == 2 ? 2 : 4;
+    } else {
+        // 64-symbol fetch groups for short-read sets, 32-symbol groups when the
         // sequences are long (contigs): measured on BASELINE configs 2-5, see DESIGN.md
         const uint64_t mean_len = n_seq ? total / n_seq : 0;
-        c->variant = mean_len > 600 ? 5 : 4;
+        c->fetch_group = mean_len > 600 ? 2 : 4;
     }
     return HC_OK;
 }
@@ -458,13 +341,15 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
 // Sampled locality probe on a host copy of a batch: in overlap files as sfo2overlaps / FNO write them,
 // consecutive lines share a read almost always; if fewer than half of the sampled neighbours do, the
 // batch is worth reordering on the device.
-static bool host_batch_is_ordered(const hc_overlap_rec* in, uint64_t n) {
-    const uint64_t samples = 4096, step = (n - 1) / samples;
+static bool host_batch_is_ordered(const void* in, size_t rec_bytes, uint64_t n) {
+    if (n < 2) return true;
+    const uint64_t samples = n - 1 < 4096 ? n - 1 : 4096;
+    const uint64_t step = (n - 2) / samples > 0 ? (n - 2) / samples : 1;  // k * step + 1 <= n - 1
     uint64_t share = 0;
     for (uint64_t k = 0; k < samples; k++) {
-        const hc_overlap_rec& a = in[k * step];
-        const hc_overlap_rec& b = in[k * step + 1];
-        share += (a.read1 == b.read1) | (a.read1 == b.read2) | (a.read2 == b.read1) | (a.read2 == b.read2);
+        const uint32_t* a = (const uint32_t*)((const char*)in + k * step * rec_bytes);  // both formats start with read1, read2
+        const uint32_t* b = (const uint32_t*)((const char*)in + (k * step + 1) * rec_bytes);
+        share += (a[0] == b[0]) | (a[0] == b[1]) | (a[1] == b[0]) | (a[1] == b[1]);
     }
     return share * 2 >= samples;
 }
@@ -483,7 +368,10 @@ static int ensure_sort_workspace(hc_ctx* c, uint64_t n) {
     return HC_OK;
 }
 
-static int score_on_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, hipStream_t s, bool reorder) {
+}  // extern "C"
+
+int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, hipStream_t s, bool reorder,
+                 hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index) {
     const uint32_t* perm = nullptr;
     if (reorder && n > 1 && n < (1ull << 31)) {
         int rc = ensure_sort_workspace(c, n);
@@ -492,15 +380,18 @@ static int score_on_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out,
         uint32_t* keys_out = c->d_sort + c->sort_cap;
         uint32_t* idx_in = c->d_sort + 2 * c->sort_cap;
         uint32_t* perm_out = c->d_sort + 3 * c->sort_cap;
-        HC_HIP(hc::launch_reorder(c->view, c->params.min_read_len, (const hc_overlap_rec*)d_in, (uint32_t)n,
-                                  c->reorder_buckets, keys_in, keys_out, idx_in, perm_out, c->d_sort_tmp,
+        HC_HIP(hc::launch_reorder(c->view.n_reads, fmt, d_in, (uint32_t)n, keys_in, keys_out, idx_in, perm_out, c->d_sort_tmp,
                                   c->sort_tmp_bytes, s));
         perm = perm_out;
     }
-    HC_HIP(hc::launch_score(c->view, c->params, c->d_lut, (const hc_overlap_rec*)d_in, n, (hc_result_rec*)d_out, perm,
-                            c->n_cu, c->variant, s));
+    hc::ScoreParams prm = c->params;
+    prm.rec_fmt = fmt;
+    HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->fetch_group, rows, row_count, cap,
+                            base_index, s));
     return HC_OK;
 }
+
+extern "C" {
 
 int hc_set_reorder(hc_ctx* c, int mode) {
     if (!c || mode < HC_REORDER_NEVER || mode > HC_REORDER_AUTO) return fail(HC_ERR_ARG, "hc_set_reorder: bad argument");
@@ -516,7 +407,30 @@ int hc_score_batch_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, 
     HC_HIP(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     // device-resident records cannot be inspected without a synchronisation: AUTO means "as given"
-    return score_on_device(c, d_in, n, d_out, s, c->reorder_mode == HC_REORDER_ALWAYS);
+    return hc_ctx_score(c, HC_REC_FULL, d_in, n, d_out, s, c->reorder_mode == HC_REORDER_ALWAYS, nullptr, nullptr, 0, 0);
+}
+
+int hc_score_cands_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, void* hip_stream) {
+    if (!c) return fail(HC_ERR_ARG, "hc_score_cands_device: null context");
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_score_cands_device: hc_set_reads has not been called");
+    if (n == 0) return HC_OK;
+    if (!d_in || !d_out) return fail(HC_ERR_ARG, "hc_score_cands_device: null buffer");
+    HC_HIP(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return hc_ctx_score(c, HC_REC_COMPACT, d_in, n, d_out, s, c->reorder_mode == HC_REORDER_ALWAYS, nullptr, nullptr, 0, 0);
+}
+
+void hc_pack_cands(const hc_overlap_rec* in, uint64_t n, hc_cand_rec* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const hc_overlap_rec& r = in[i];
+        const uint32_t p1 = r.pos1 < HC_CAND_POS_MASK ? r.pos1 : HC_CAND_POS_MASK;
+        const uint32_t p2 = r.pos2 < HC_CAND_POS_MASK ? r.pos2 : HC_CAND_POS_MASK;
+        const uint32_t oc = r.ord == '-' ? 0u : (r.ord == '1' ? 1u : (r.ord == '2' ? 2u : 3u));
+        out[i].read1 = r.read1;
+        out[i].read2 = r.read2;
+        out[i].pos1_bits = p1 | (r.ori1 ? 1u << 28 : 0u) | (r.ori2 ? 1u << 29 : 0u) | (oc << 30);
+        out[i].pos2_bits = p2;
+    }
 }
 
 int hc_synchronize(hc_ctx* c) {
@@ -538,22 +452,31 @@ static int ensure_workspace(hc_ctx* c, uint64_t n) {
     return HC_OK;
 }
 
-int hc_score_batch(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, hc_result_rec* out) {
-    if (!c) return fail(HC_ERR_ARG, "hc_score_batch: null context");
-    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_score_batch: hc_set_reads has not been called");
+static int score_host(hc_ctx* c, const char* who, uint32_t fmt, const void* in, uint64_t n, hc_result_rec* out) {
+    if (!c) return fail(HC_ERR_ARG, std::string(who) + ": null context");
+    if (!c->have_reads) return fail(HC_ERR_STATE, std::string(who) + ": hc_set_reads has not been called");
     if (n == 0) return HC_OK;
-    if (!in || !out) return fail(HC_ERR_ARG, "hc_score_batch: null buffer");
+    if (!in || !out) return fail(HC_ERR_ARG, std::string(who) + ": null buffer");
     HC_HIP(hipSetDevice(c->device));
     int rc = ensure_workspace(c, n);
     if (rc) return rc;
-    HC_HIP(hipMemcpyAsync(c->d_in, in, n * sizeof(hc_overlap_rec), hipMemcpyHostToDevice, c->stream));
+    const size_t rb = fmt == HC_REC_COMPACT ? sizeof(hc_cand_rec) : sizeof(hc_overlap_rec);
+    HC_HIP(hipMemcpyAsync(c->d_in, in, n * rb, hipMemcpyHostToDevice, c->stream));
     bool reorder = c->reorder_mode == HC_REORDER_ALWAYS;
-    if (c->reorder_mode == HC_REORDER_AUTO && n >= 4096) reorder = !host_batch_is_ordered(in, n);
-    rc = score_on_device(c, c->d_in, n, c->d_out, c->stream, reorder);
+    if (c->reorder_mode == HC_REORDER_AUTO && n >= 4096) reorder = !host_batch_is_ordered(in, rb, n);
+    rc = hc_ctx_score(c, fmt, c->d_in, n, c->d_out, c->stream, reorder, nullptr, nullptr, 0, 0);
     if (rc) return rc;
     HC_HIP(hipMemcpyAsync(out, c->d_out, n * sizeof(hc_result_rec), hipMemcpyDeviceToHost, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
     return HC_OK;
+}
+
+int hc_score_batch(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, hc_result_rec* out) {
+    return score_host(c, "hc_score_batch", HC_REC_FULL, in, n, out);
+}
+
+int hc_score_cands(hc_ctx* c, const hc_cand_rec* in, uint64_t n, hc_result_rec* out) {
+    return score_host(c, "hc_score_cands", HC_REC_COMPACT, in, n, out);
 }
 
 int hc_host_alloc(hc_ctx* c, void** ptr, uint64_t bytes) {
@@ -609,273 +532,6 @@ int hc_compact_device(hc_ctx* c, const void* d_results, uint64_t n, void* d_indi
     return HC_OK;
 }
 
-// ---- candidate generation ------------------------------------------------------------------------------------
-int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, uint64_t cap, uint64_t* n_out) {
-    if (!c || !n_out) return fail(HC_ERR_ARG, "hc_find_overlaps: null argument");
-    *n_out = 0;
-    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_find_overlaps: hc_set_reads has not been called");
-    if (cap && !out) return fail(HC_ERR_ARG, "hc_find_overlaps: null output buffer");
-    if (!(err_rate >= 0.0) || err_rate >= 1.0 || min_overlap == 0) return fail(HC_ERR_ARG, "hc_find_overlaps: need 0 <= err_rate < 1, min_overlap > 0");
-    if (!c->singles_first) return fail(HC_ERR_ARG, "hc_find_overlaps: the read set must list single-end reads before pairs (SFO ids)");
-    const uint32_t n_seq = (uint32_t)c->seq_refs.size();
-    if (n_seq >= (1u << 24) - 1) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^24-2 sequences");
-    uint32_t max_len = 0;
-    for (const hc::SeqRef& r : c->seq_refs) max_len = r.len > max_len ? r.len : max_len;
-    if (max_len >= (1u << 14)) return fail(HC_ERR_ARG, "hc_find_overlaps: sequences of 16384 symbols or more are not supported");
-    if (n_seq < 2 || max_len < min_overlap) return HC_OK;
-    HC_HIP(hipSetDevice(c->device));
-    const bool timing = getenv("HC_FIND_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double tmark = now();
-    auto lap = [&](const char* what) {
-        if (!timing) return;
-        (void)hipStreamSynchronize(c->stream);
-        const double t = now();
-        fprintf(stderr, "hc_find_overlaps: %-28s %.4f s\n", what, t - tmark);
-        tmark = t;
-    };
-    const bool recompute = flags & HC_FIND_RECOMPUTE;
-    flags &= ~HC_FIND_RECOMPUTE;
-    if (!recompute && c->found_valid && c->found_err == err_rate && c->found_min == min_overlap && c->found_flags == flags) {
-        *n_out = c->n_found;
-        const uint64_t take = c->n_found < cap ? c->n_found : cap;
-        if (take) HC_HIP(hipMemcpy(out, c->d_found, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
-        return HC_OK;
-    }
-    if (c->d_found) (void)hipFree(c->d_found);
-    c->d_found = nullptr;
-    c->n_found = 0;
-    c->found_valid = false;
-    lap("free previous result");
-    auto remember = [&](hc_sfo_rec* d, uint64_t n) {
-        c->d_found = d;
-        c->n_found = n;
-        c->found_err = err_rate;
-        c->found_min = min_overlap;
-        c->found_flags = flags;
-        c->found_valid = true;
-    };
-    // the longest stretch without a mismatch that every reportable overlap is guaranteed to contain
-    uint32_t w = 0xFFFFFFFFu;
-    for (uint32_t L = min_overlap; L <= max_len; L++) {
-        const uint32_t K = (uint32_t)(err_rate * (double)L);
-        const uint32_t wl = (L - K) / (K + 1);
-        w = wl < w ? wl : w;
-    }
-    if (w < 12)
-        return fail(HC_ERR_ARG, min_overlap < 12 ? "hc_find_overlaps: min_overlap below 12 is not supported by the seed filter"
-                                                 : "hc_find_overlaps: err_rate too high for this min_overlap: an overlap need not contain 12 error-free positions in a row");
-    const uint32_t k = w < 31 ? w : 31, s = w - k + 1;
-    const uint32_t n_ori = (flags & HC_FIND_REVERSALS) ? 2u : 1u;
-    const bool wide = c->view.symbytes == 1 && hc::lut_lg(c->view.K) == 6;
-    hipStream_t st = c->stream;
-    unsigned n_slots = 0;  // HC_ALLOC takes the context's scratch slots in order
-
-    // host-side layout of the index and of the seeds
-    std::vector<uint64_t> pos_start(n_seq + 1, 0), seed_start(n_seq + 1, 0);
-    std::vector<hc::SeqRef> by_sfo(n_seq);
-    for (uint32_t q = 0; q < n_seq; q++) {
-        const hc::SeqRef& r = c->seq_refs[q];
-        pos_start[q + 1] = pos_start[q] + r.len;
-        seed_start[q + 1] = seed_start[q] + (r.len >= k ? (uint64_t)((r.len - k) / s + 1) * n_ori : 0);
-        by_sfo[r.sfo_id] = r;
-    }
-    const uint64_t P = pos_start[n_seq], S = seed_start[n_seq];
-    if (P >= (1ull << 31) || S >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: read set too large for one call (2^31 positions)");
-
-    DevBuf d_seqs, d_by_sfo, d_pos_start, d_seed_start, d_k0, d_k1, d_v0, d_v1, d_tmp, d_lo, d_cnt, d_off, d_count;
-    HC_ALLOC(d_seqs, n_seq * sizeof(hc::SeqRef));
-    HC_ALLOC(d_by_sfo, n_seq * sizeof(hc::SeqRef));
-    HC_ALLOC(d_pos_start, (n_seq + 1) * sizeof(uint64_t));
-    HC_ALLOC(d_seed_start, (n_seq + 1) * sizeof(uint64_t));
-    HC_ALLOC(d_count, sizeof(unsigned long long));
-    HC_HIP(hipMemcpyAsync(d_seqs.p, c->seq_refs.data(), n_seq * sizeof(hc::SeqRef), hipMemcpyHostToDevice, st));
-    HC_HIP(hipMemcpyAsync(d_by_sfo.p, by_sfo.data(), n_seq * sizeof(hc::SeqRef), hipMemcpyHostToDevice, st));
-    HC_HIP(hipMemcpyAsync(d_pos_start.p, pos_start.data(), (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    HC_HIP(hipMemcpyAsync(d_seed_start.p, seed_start.data(), (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-
-    // 1. index: (k-mer, sequence|position) of every forward position, sorted by k-mer
-    HC_ALLOC(d_k0, P * 8);
-    HC_ALLOC(d_k1, P * 8);
-    HC_ALLOC(d_v0, P * 8);
-    HC_ALLOC(d_v1, P * 8);
-    HC_HIP(hc::finder_index(c->d_sym, c->view.symbytes, wide, d_seqs.as<hc::SeqRef>(), d_pos_start.as<uint64_t>(), n_seq, k, d_k0.as<uint64_t>(),
-                            d_v0.as<uint64_t>(), st));
-    size_t tmp_bytes = 0;
-    HC_HIP(hc::finder_sort_pairs(nullptr, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
-    HC_ALLOC(d_tmp, tmp_bytes);
-    HC_HIP(hc::finder_sort_pairs(d_tmp.p, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
-    lap("index + sort");
-    // 2. seeds: range of every seed k-mer in the index
-    HC_ALLOC(d_lo, S * 8);
-    HC_ALLOC(d_cnt, (S + 1) * 8);
-    HC_ALLOC(d_off, (S + 1) * 8);
-    HC_HIP(hipMemsetAsync(d_cnt.p, 0, (S + 1) * 8, st));
-    HC_HIP(hc::finder_seeds(c->d_sym, c->view.symbytes, wide, d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori,
-                            d_k1.as<uint64_t>(), P, d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), st));
-    // only hits whose indexed sequence has the lower id become candidates: count those, and lay the keys out by them
-    DevBuf d_val;
-    HC_ALLOC(d_val, (S + 1) * 8);
-    HC_HIP(hipMemsetAsync(d_val.p, 0, (S + 1) * 8, st));
-    HC_HIP(hc::finder_count_valid(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori, d_v1.as<uint64_t>(),
-                                  d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_val.as<uint64_t>(), st));
-    {
-        size_t b = 0;
-        HC_HIP(hc::finder_scan(nullptr, b, d_val.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
-        if (b > tmp_bytes) {
-            HC_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_tmp.slot->p);
-            d_tmp.slot->p = nullptr;
-            d_tmp.slot->cap = 0;
-            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
-            d_tmp.slot->cap = b;
-            d_tmp.p = d_tmp.slot->p;
-            tmp_bytes = b;
-        }
-        HC_HIP(hc::finder_scan(d_tmp.p, b, d_val.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
-    }
-    uint64_t H = 0;  // number of candidate hits = last element of the exclusive scan over S + 1 counts (the extra one is 0)
-    HC_HIP(hipMemcpyAsync(&H, d_off.as<uint64_t>() + S, 8, hipMemcpyDeviceToHost, st));
-    HC_HIP(hipStreamSynchronize(st));
-    lap("seeds + scan");
-    if (H == 0) {
-        remember(nullptr, 0);
-        return HC_OK;
-    }
-    // 3./4. in batches of seed sequences, so that the hits in flight stay bounded whatever the coverage of the data:
-    //   one key per hit -> sort -> unique (the candidate diagonals) -> verify (8 bytes out per candidate) -> scan of the
-    //   flags -> emit the records of the verified ones behind those of the batches before.
-    // Keys start with the ids, batches are id ranges of the seed side: the concatenation is still sorted and unique.
-    std::vector<uint64_t> h_bound(n_seq + 1);  // candidate hits before sequence q = off[seed_start[q]]
-    {
-        DevBuf d_bound;
-        HC_ALLOC(d_bound, (n_seq + 1) * 8);
-        HC_HIP(hc::finder_boundaries(d_off.as<uint64_t>(), d_seed_start.as<uint64_t>(), n_seq + 1, d_bound.as<uint64_t>(), st));
-        HC_HIP(hipMemcpyAsync(h_bound.data(), d_bound.p, (n_seq + 1) * 8, hipMemcpyDeviceToHost, st));
-        HC_HIP(hipStreamSynchronize(st));
-    }
-    uint64_t batch_hits = 1ull << 29;
-    if (const char* e = getenv("HC_FIND_BATCH_HITS")) batch_hits = strtoull(e, nullptr, 10);
-    if (batch_hits < 1024) batch_hits = 1024;
-    struct Batch {
-        uint32_t q0, q1;
-        uint64_t base, hits;
-    };
-    std::vector<Batch> batches;
-    uint64_t Hmax = 0;
-    for (uint32_t q0 = 0; q0 < n_seq;) {
-        const uint64_t base = h_bound[q0];
-        uint32_t q1 = q0 + 1;
-        while (q1 < n_seq && h_bound[q1 + 1] - base <= batch_hits) q1++;
-        const uint64_t hits = h_bound[q1] - base;
-        if (hits >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: one sequence alone has more than 2^31 seed hits");
-        if (hits) {
-            batches.push_back(Batch{q0, q1, base, hits});
-            Hmax = hits > Hmax ? hits : Hmax;
-        }
-        q0 = q1;
-    }
-    DevBuf d_h0, d_h1, d_kout, d_flag, d_pos, d_r1;
-    HC_ALLOC(d_h0, Hmax * 8);
-    HC_ALLOC(d_h1, Hmax * 8);
-    HC_ALLOC(d_kout, Hmax * 4);
-    HC_ALLOC(d_flag, (Hmax + 1) * 4);
-    HC_ALLOC(d_pos, (Hmax + 1) * 4);
-    {
-        size_t b = 0, b2 = 0, b3 = 0;
-        HC_HIP(hc::finder_sort_keys(nullptr, b, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), Hmax, st));
-        HC_HIP(hc::finder_unique(nullptr, b2, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), Hmax, st));
-        HC_HIP(hc::finder_scan32(nullptr, b3, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), Hmax + 1, st));
-        b = b2 > b ? b2 : b;
-        b = b3 > b ? b3 : b;
-        if (b > tmp_bytes) {
-            HC_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_tmp.slot->p);
-            d_tmp.slot->p = nullptr;
-            d_tmp.slot->cap = 0;
-            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
-            d_tmp.slot->cap = b;
-            d_tmp.p = d_tmp.slot->p;
-            tmp_bytes = b;
-        }
-    }
-    unsigned long long R = 0;
-    size_t res_cap = 0;  // records; the result buffer grows by doubling (it outlives the call: not a scratch slot)
-    for (const Batch& bt : batches) {
-        const uint64_t Hb = bt.hits;
-        HC_HIP(hc::finder_expand(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), bt.q0, bt.q1, bt.base, k, s, n_ori, d_v1.as<uint64_t>(),
-                                 d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), d_h0.as<uint64_t>(), st));
-        size_t bs = tmp_bytes;
-        HC_HIP(hc::finder_sort_keys(d_tmp.p, bs, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), Hb, st));
-        bs = tmp_bytes;
-        HC_HIP(hc::finder_unique(d_tmp.p, bs, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), Hb, st));
-        unsigned long long M = 0;
-        HC_HIP(hipMemcpyAsync(&M, d_count.p, sizeof M, hipMemcpyDeviceToHost, st));
-        HC_HIP(hipStreamSynchronize(st));
-        if (M == 0) continue;
-        HC_HIP(hipMemsetAsync(d_flag.as<uint32_t>() + M, 0, 4, st));
-        HC_HIP(hc::finder_verify(c->d_sym, c->view.symbytes, wide, d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), M, err_rate, min_overlap, flags,
-                                 d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), st));
-        bs = tmp_bytes;
-        HC_HIP(hc::finder_scan32(d_tmp.p, bs, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M + 1, st));
-        uint32_t Rb = 0;
-        HC_HIP(hipMemcpyAsync(&Rb, d_pos.as<uint32_t>() + M, 4, hipMemcpyDeviceToHost, st));
-        HC_HIP(hipStreamSynchronize(st));
-        if (Rb == 0) continue;
-        if (R + Rb > res_cap) {
-            size_t want = res_cap ? res_cap * 2 : (size_t)Rb;
-            if (want < R + Rb) want = R + Rb;
-            if (batches.size() == 1) want = Rb;
-            void* bigger = nullptr;
-            HC_HIP(hipMalloc(&bigger, want * sizeof(hc_sfo_rec)));
-            if (R) HC_HIP(hipMemcpyAsync(bigger, d_r1.own, R * sizeof(hc_sfo_rec), hipMemcpyDeviceToDevice, st));
-            HC_HIP(hipStreamSynchronize(st));
-            if (d_r1.own) (void)hipFree(d_r1.own);
-            d_r1.own = bigger;
-            d_r1.p = bigger;
-            res_cap = want;
-        }
-        HC_HIP(hc::finder_emit(d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M,
-                               (hc_sfo_rec*)d_r1.p + R, st));
-        R += Rb;
-    }
-    HC_HIP(hipStreamSynchronize(st));
-    lap("expand/sort/unique/verify/emit");
-    if (R == 0) {
-        remember(nullptr, 0);
-        return HC_OK;
-    }
-    if (batches.size() > 1) {  // every batch is sorted; one more sort (key, position) + gather for the global order
-        if (R >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 overlaps");
-        DevBuf sk0, sk1, si0, si1;
-        void* sorted = nullptr;
-        HC_HIP(hipMalloc(&sk0.own, R * 8));
-        HC_HIP(hipMalloc(&sk1.own, R * 8));
-        HC_HIP(hipMalloc(&si0.own, R * 8));
-        HC_HIP(hipMalloc(&si1.own, R * 8));
-        HC_HIP(hc::finder_rekey((const hc_sfo_rec*)d_r1.p, R, (uint64_t*)sk0.own, (uint64_t*)si0.own, st));
-        size_t b = 0;
-        HC_HIP(hc::finder_sort_pairs(nullptr, b, (uint64_t*)sk0.own, (uint64_t*)sk1.own, (uint64_t*)si0.own, (uint64_t*)si1.own, R, 64, st));
-        DevBuf stmp;
-        HC_HIP(hipMalloc(&stmp.own, b ? b : 16));
-        HC_HIP(hc::finder_sort_pairs(stmp.own, b, (uint64_t*)sk0.own, (uint64_t*)sk1.own, (uint64_t*)si0.own, (uint64_t*)si1.own, R, 64, st));
-        HC_HIP(hipMalloc(&sorted, R * sizeof(hc_sfo_rec)));
-        HC_HIP(hc::finder_gather((const hc_sfo_rec*)d_r1.p, (const uint64_t*)si1.own, R, (hc_sfo_rec*)sorted, st));
-        HC_HIP(hipStreamSynchronize(st));
-        (void)hipFree(d_r1.own);
-        d_r1.own = sorted;
-        d_r1.p = sorted;
-        lap("global order of the batches");
-    }
-    *n_out = R;
-    const uint64_t take = R < cap ? R : cap;
-    if (take) HC_HIP(hipMemcpy(out, d_r1.p, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
-    lap("copy to host");
-    remember((hc_sfo_rec*)d_r1.p, R);  // the context owns the records now
-    d_r1.own = nullptr;
-    return HC_OK;
-}
-
 int hc_pack_rows_device(hc_ctx* c, const void* d_results, const void* d_indices, const void* d_count, uint64_t cap, uint64_t base_index,
                         void* d_rows, void* hip_stream) {
     if (!c || !d_count) return fail(HC_ERR_ARG, "hc_pack_rows_device: null argument");
@@ -899,32 +555,19 @@ int hc_compact_pack_device(hc_ctx* c, const void* d_results, uint64_t n, void* d
     return hc_pack_rows_device(c, d_results, d_indices, d_count, cap, base_index, (hc_gather_row*)d_payload + 1, hip_stream);
 }
 
-int hc_score_pack_device(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index, void* d_payload,
-                         void* hip_stream, int* fused) {
+int hc_score_pack_device(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index,
+                         void* d_payload, void* hip_stream) {
     if (!c || !d_payload) return fail(HC_ERR_ARG, "hc_score_pack_device: null argument");
+    if (fmt != HC_REC_FULL && fmt != HC_REC_COMPACT) return fail(HC_ERR_ARG, "hc_score_pack_device: unknown record format");
     if (!c->have_reads) return fail(HC_ERR_STATE, "hc_score_pack_device: hc_set_reads has not been called");
     if (n && (!d_in || !d_out)) return fail(HC_ERR_ARG, "hc_score_pack_device: null buffer");
     if (n >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_score_pack_device: n must be < 2^31");
     HC_HIP(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    if (fused) *fused = 0;
-    if (c->reorder_mode != HC_REORDER_ALWAYS) {
-        HC_HIP(hipMemsetAsync(d_payload, 0, sizeof(hc_gather_row), s));  // row 0: the count
-        const hipError_t e = hc::launch_score_rows(c->view, c->params, c->d_lut, (const hc_overlap_rec*)d_in, n, (hc_result_rec*)d_out, c->n_cu,
-                                                   c->variant, (hc_gather_row*)d_payload, cap, base_index, s);
-        if (e == hipSuccess) {
-            if (fused) *fused = 1;
-            return HC_OK;
-        }
-        if (e != hipErrorNotSupported) return fail(HC_ERR_HIP, std::string("score_kernel_rows: ") + hipGetErrorString(e));
-    }
-    // no fused instantiation for this read set: score, then compact + pack
-    int rc = hc_score_batch_device(c, d_in, n, d_out, hip_stream);
-    if (rc) return rc;
-    rc = ensure_compact_workspace(c, n ? n : 1, true);
-    if (rc) return rc;
-    if (!c->d_totals) HC_HIP(hipMalloc((void**)&c->d_totals, 2 * sizeof(unsigned long long)));
-    return hc_compact_pack_device(c, d_out, n, c->d_compact_idx, c->d_totals, cap, base_index, d_payload, hip_stream);
+    hc_gather_row* payload = (hc_gather_row*)d_payload;
+    HC_HIP(hipMemsetAsync(payload, 0, sizeof(hc_gather_row), s));  // row 0: the count
+    return hc_ctx_score(c, fmt, d_in, n, d_out, s, c->reorder_mode == HC_REORDER_ALWAYS, payload + 1,
+                        (unsigned long long*)&payload[0].index, cap, base_index);
 }
 
 int hc_score_batch_compact(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, uint32_t* idx_out, hc_result_rec* res_out,
@@ -942,8 +585,8 @@ int hc_score_batch_compact(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, uint
     if (rc) return rc;
     HC_HIP(hipMemcpyAsync(c->d_in, in, n * sizeof(hc_overlap_rec), hipMemcpyHostToDevice, c->stream));
     bool reorder = c->reorder_mode == HC_REORDER_ALWAYS;
-    if (c->reorder_mode == HC_REORDER_AUTO && n >= 4096) reorder = !host_batch_is_ordered(in, n);
-    rc = score_on_device(c, c->d_in, n, c->d_out, c->stream, reorder);
+    if (c->reorder_mode == HC_REORDER_AUTO && n >= 4096) reorder = !host_batch_is_ordered(in, sizeof(hc_overlap_rec), n);
+    rc = hc_ctx_score(c, HC_REC_FULL, c->d_in, n, c->d_out, c->stream, reorder, nullptr, nullptr, 0, 0);
     if (rc) return rc;
     HC_HIP(hc::launch_compact((const hc_result_rec*)c->d_out, (uint32_t)n, c->d_compact_idx, c->d_totals, c->d_compact_tmp,
                               c->compact_tmp_bytes, c->stream));
@@ -962,13 +605,14 @@ int hc_score_batch_compact(hc_ctx* c, const hc_overlap_rec* in, uint64_t n, uint
     return HC_OK;
 }
 
-int hc_time_score_kernel(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, int iters, float* ms_per_launch) {
-    if (!c || !ms_per_launch || iters <= 0) return fail(HC_ERR_ARG, "hc_time_score_kernel: bad argument");
+int hc_time_score_kernel(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, int iters, float* ms_per_launch) {
+    if (!c || !ms_per_launch || iters <= 0 || (fmt != HC_REC_FULL && fmt != HC_REC_COMPACT))
+        return fail(HC_ERR_ARG, "hc_time_score_kernel: bad argument");
     if (!c->have_reads) return fail(HC_ERR_STATE, "hc_time_score_kernel: hc_set_reads has not been called");
     HC_HIP(hipSetDevice(c->device));
     HC_HIP(hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < iters; i++) {
-        int rc = hc_score_batch_device(c, d_in, n, d_out, c->stream);
+        int rc = fmt == HC_REC_COMPACT ? hc_score_cands_device(c, d_in, n, d_out, c->stream) : hc_score_batch_device(c, d_in, n, d_out, c->stream);
         if (rc) return rc;
     }
     HC_HIP(hipEventRecord(c->ev1, c->stream));
@@ -979,13 +623,13 @@ int hc_time_score_kernel(hc_ctx* c, const void* d_in, uint64_t n, void* d_out, i
     return HC_OK;
 }
 
-int hc_count_positions_device(hc_ctx* c, const void* d_in, uint64_t n, uint64_t* total_positions, uint64_t* total_subs) {
-    if (!c || !total_positions || !total_subs) return fail(HC_ERR_ARG, "hc_count_positions_device: null argument");
+int hc_count_positions_device(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, uint64_t* total_positions, uint64_t* total_subs) {
+    if (!c || !total_positions || !total_subs || (fmt != HC_REC_FULL && fmt != HC_REC_COMPACT))
+        return fail(HC_ERR_ARG, "hc_count_positions_device: bad argument");
     if (!c->have_reads) return fail(HC_ERR_STATE, "hc_count_positions_device: hc_set_reads has not been called");
     HC_HIP(hipSetDevice(c->device));
     HC_HIP(hipMemsetAsync(c->d_totals, 0, 2 * sizeof(unsigned long long), c->stream));
-    HC_HIP(hc::launch_count_positions(c->view, c->params.min_read_len, (const hc_overlap_rec*)d_in, n, c->d_totals,
-                                      c->stream));
+    HC_HIP(hc::launch_count_positions(c->view, c->params.min_read_len, fmt, d_in, n, c->d_totals, c->stream));
     unsigned long long h[2] = {0, 0};
     HC_HIP(hipMemcpyAsync(h, c->d_totals, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));

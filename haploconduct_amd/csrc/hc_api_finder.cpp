@@ -1,0 +1,318 @@
+// hc_api_finder.cpp — hc_find_overlaps (include/hcedge.h): candidate generation on the device against the read store
+// (SURVEY.md §8(f4)); kernels in hc_overlap_finder.hip.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hcedge.h"
+#include "hc_ctx.h"
+
+static int fail(int status, const std::string& what) { return hc::set_last_error(status, what); }
+
+namespace {
+// A view of one of the context's grow-only scratch slots (hc_ctx::finder_scratch).  The overlap finder needs
+// gigabytes of scratch per call; allocating and freeing them every call (hipMalloc/hipFree or the stream-ordered
+// pool alike) costs several times its kernels, so the blocks stay with the context until the store is replaced.
+struct DevBuf {
+    void* p = nullptr;
+    hc_ctx::Scratch* slot = nullptr;
+    void* own = nullptr;  // a block that is not a slot (the result, which outlives the call)
+    ~DevBuf() {
+        if (own) (void)hipFree(own);
+    }
+    template <typename T>
+    T* as() const { return (T*)p; }
+};
+}  // namespace
+
+#define HC_ALLOC(buf, bytes)                                                                  \
+    do {                                                                                      \
+        hc_ctx::Scratch& sl__ = c->finder_scratch[n_slots++];                                 \
+        const size_t need__ = (bytes) ? (size_t)(bytes) : 16;                                 \
+        if (sl__.cap < need__) {                                                              \
+            if (sl__.p) (void)hipFree(sl__.p);                                                \
+            sl__.p = nullptr;                                                                 \
+            sl__.cap = 0;                                                                     \
+            HC_HIP(hipMalloc(&sl__.p, need__ + need__ / 8));                                  \
+            sl__.cap = need__ + need__ / 8;                                                   \
+        }                                                                                     \
+        (buf).slot = &sl__;                                                                   \
+        (buf).p = sl__.p;                                                                     \
+    } while (0)
+
+
+extern "C" {
+
+// ---- candidate generation ------------------------------------------------------------------------------------
+int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, uint64_t cap, uint64_t* n_out) {
+    if (!c || !n_out) return fail(HC_ERR_ARG, "hc_find_overlaps: null argument");
+    *n_out = 0;
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_find_overlaps: hc_set_reads has not been called");
+    if (cap && !out) return fail(HC_ERR_ARG, "hc_find_overlaps: null output buffer");
+    if (!(err_rate >= 0.0) || err_rate >= 1.0 || min_overlap == 0) return fail(HC_ERR_ARG, "hc_find_overlaps: need 0 <= err_rate < 1, min_overlap > 0");
+    if (!c->singles_first) return fail(HC_ERR_ARG, "hc_find_overlaps: the read set must list single-end reads before pairs (SFO ids)");
+    const uint32_t n_seq = (uint32_t)c->seq_refs.size();
+    if (n_seq >= (1u << 24) - 1) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^24-2 sequences");
+    uint32_t max_len = 0;
+    for (const hc::SeqRef& r : c->seq_refs) max_len = r.len > max_len ? r.len : max_len;
+    if (max_len >= (1u << 14)) return fail(HC_ERR_ARG, "hc_find_overlaps: sequences of 16384 symbols or more are not supported");
+    if (n_seq < 2 || max_len < min_overlap) return HC_OK;
+    HC_HIP(hipSetDevice(c->device));
+    const bool timing = getenv("HC_FIND_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tmark = now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(c->stream);
+        const double t = now();
+        fprintf(stderr, "hc_find_overlaps: %-28s %.4f s\n", what, t - tmark);
+        tmark = t;
+    };
+    const bool recompute = flags & HC_FIND_RECOMPUTE;
+    flags &= ~HC_FIND_RECOMPUTE;
+    if (!recompute && c->found_valid && c->found_err == err_rate && c->found_min == min_overlap && c->found_flags == flags) {
+        *n_out = c->n_found;
+        const uint64_t take = c->n_found < cap ? c->n_found : cap;
+        if (take) HC_HIP(hipMemcpy(out, c->d_found, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
+        return HC_OK;
+    }
+    if (c->d_found) (void)hipFree(c->d_found);
+    c->d_found = nullptr;
+    c->n_found = 0;
+    c->found_valid = false;
+    lap("free previous result");
+    auto remember = [&](hc_sfo_rec* d, uint64_t n) {
+        c->d_found = d;
+        c->n_found = n;
+        c->found_err = err_rate;
+        c->found_min = min_overlap;
+        c->found_flags = flags;
+        c->found_valid = true;
+    };
+    // the longest stretch without a mismatch that every reportable overlap is guaranteed to contain
+    uint32_t w = 0xFFFFFFFFu;
+    for (uint32_t L = min_overlap; L <= max_len; L++) {
+        const uint32_t K = (uint32_t)(err_rate * (double)L);
+        const uint32_t wl = (L - K) / (K + 1);
+        w = wl < w ? wl : w;
+    }
+    if (w < 12)
+        return fail(HC_ERR_ARG, min_overlap < 12 ? "hc_find_overlaps: min_overlap below 12 is not supported by the seed filter"
+                                                 : "hc_find_overlaps: err_rate too high for this min_overlap: an overlap need not contain 12 error-free positions in a row");
+    const uint32_t k = w < 31 ? w : 31, s = w - k + 1;
+    const uint32_t n_ori = (flags & HC_FIND_REVERSALS) ? 2u : 1u;
+    const bool wide = c->view.symbytes == 1 && hc::lut_lg(c->view.K) == 6;
+    hipStream_t st = c->stream;
+    unsigned n_slots = 0;  // HC_ALLOC takes the context's scratch slots in order
+
+    // host-side layout of the index and of the seeds
+    std::vector<uint64_t> pos_start(n_seq + 1, 0), seed_start(n_seq + 1, 0);
+    std::vector<hc::SeqRef> by_sfo(n_seq);
+    for (uint32_t q = 0; q < n_seq; q++) {
+        const hc::SeqRef& r = c->seq_refs[q];
+        pos_start[q + 1] = pos_start[q] + r.len;
+        seed_start[q + 1] = seed_start[q] + (r.len >= k ? (uint64_t)((r.len - k) / s + 1) * n_ori : 0);
+        by_sfo[r.sfo_id] = r;
+    }
+    const uint64_t P = pos_start[n_seq], S = seed_start[n_seq];
+    if (P >= (1ull << 31) || S >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: read set too large for one call (2^31 positions)");
+
+    DevBuf d_seqs, d_by_sfo, d_pos_start, d_seed_start, d_k0, d_k1, d_v0, d_v1, d_tmp, d_lo, d_cnt, d_off, d_count;
+    HC_ALLOC(d_seqs, n_seq * sizeof(hc::SeqRef));
+    HC_ALLOC(d_by_sfo, n_seq * sizeof(hc::SeqRef));
+    HC_ALLOC(d_pos_start, (n_seq + 1) * sizeof(uint64_t));
+    HC_ALLOC(d_seed_start, (n_seq + 1) * sizeof(uint64_t));
+    HC_ALLOC(d_count, sizeof(unsigned long long));
+    HC_HIP(hipMemcpyAsync(d_seqs.p, c->seq_refs.data(), n_seq * sizeof(hc::SeqRef), hipMemcpyHostToDevice, st));
+    HC_HIP(hipMemcpyAsync(d_by_sfo.p, by_sfo.data(), n_seq * sizeof(hc::SeqRef), hipMemcpyHostToDevice, st));
+    HC_HIP(hipMemcpyAsync(d_pos_start.p, pos_start.data(), (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HC_HIP(hipMemcpyAsync(d_seed_start.p, seed_start.data(), (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+
+    // 1. index: (k-mer, sequence|position) of every forward position, sorted by k-mer
+    HC_ALLOC(d_k0, P * 8);
+    HC_ALLOC(d_k1, P * 8);
+    HC_ALLOC(d_v0, P * 8);
+    HC_ALLOC(d_v1, P * 8);
+    HC_HIP(hc::finder_index(c->d_sym, c->view.symbytes, wide, d_seqs.as<hc::SeqRef>(), d_pos_start.as<uint64_t>(), n_seq, k, d_k0.as<uint64_t>(),
+                            d_v0.as<uint64_t>(), st));
+    size_t tmp_bytes = 0;
+    HC_HIP(hc::finder_sort_pairs(nullptr, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
+    HC_ALLOC(d_tmp, tmp_bytes);
+    HC_HIP(hc::finder_sort_pairs(d_tmp.p, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
+    lap("index + sort");
+    // 2. seeds: range of every seed k-mer in the index
+    HC_ALLOC(d_lo, S * 8);
+    HC_ALLOC(d_cnt, (S + 1) * 8);
+    HC_ALLOC(d_off, (S + 1) * 8);
+    HC_HIP(hipMemsetAsync(d_cnt.p, 0, (S + 1) * 8, st));
+    HC_HIP(hc::finder_seeds(c->d_sym, c->view.symbytes, wide, d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori,
+                            d_k1.as<uint64_t>(), P, d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), st));
+    // only hits whose indexed sequence has the lower id become candidates: count those, and lay the keys out by them
+    DevBuf d_val;
+    HC_ALLOC(d_val, (S + 1) * 8);
+    HC_HIP(hipMemsetAsync(d_val.p, 0, (S + 1) * 8, st));
+    HC_HIP(hc::finder_count_valid(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori, d_v1.as<uint64_t>(),
+                                  d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_val.as<uint64_t>(), st));
+    {
+        size_t b = 0;
+        HC_HIP(hc::finder_scan(nullptr, b, d_val.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
+        if (b > tmp_bytes) {
+            HC_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_tmp.slot->p);
+            d_tmp.slot->p = nullptr;
+            d_tmp.slot->cap = 0;
+            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
+            d_tmp.slot->cap = b;
+            d_tmp.p = d_tmp.slot->p;
+            tmp_bytes = b;
+        }
+        HC_HIP(hc::finder_scan(d_tmp.p, b, d_val.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
+    }
+    uint64_t H = 0;  // number of candidate hits = last element of the exclusive scan over S + 1 counts (the extra one is 0)
+    HC_HIP(hipMemcpyAsync(&H, d_off.as<uint64_t>() + S, 8, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipStreamSynchronize(st));
+    lap("seeds + scan");
+    if (H == 0) {
+        remember(nullptr, 0);
+        return HC_OK;
+    }
+    // 3./4. in batches of seed sequences, so that the hits in flight stay bounded whatever the coverage of the data:
+    //   one key per hit -> sort -> unique (the candidate diagonals) -> verify (8 bytes out per candidate) -> scan of the
+    //   flags -> emit the records of the verified ones behind those of the batches before.
+    // Keys start with the ids, batches are id ranges of the seed side: the concatenation is still sorted and unique.
+    std::vector<uint64_t> h_bound(n_seq + 1);  // candidate hits before sequence q = off[seed_start[q]]
+    {
+        DevBuf d_bound;
+        HC_ALLOC(d_bound, (n_seq + 1) * 8);
+        HC_HIP(hc::finder_boundaries(d_off.as<uint64_t>(), d_seed_start.as<uint64_t>(), n_seq + 1, d_bound.as<uint64_t>(), st));
+        HC_HIP(hipMemcpyAsync(h_bound.data(), d_bound.p, (n_seq + 1) * 8, hipMemcpyDeviceToHost, st));
+        HC_HIP(hipStreamSynchronize(st));
+    }
+    uint64_t batch_hits = 1ull << 29;
+    if (const char* e = getenv("HC_FIND_BATCH_HITS")) batch_hits = strtoull(e, nullptr, 10);
+    if (batch_hits < 1024) batch_hits = 1024;
+    struct Batch {
+        uint32_t q0, q1;
+        uint64_t base, hits;
+    };
+    std::vector<Batch> batches;
+    uint64_t Hmax = 0;
+    for (uint32_t q0 = 0; q0 < n_seq;) {
+        const uint64_t base = h_bound[q0];
+        uint32_t q1 = q0 + 1;
+        while (q1 < n_seq && h_bound[q1 + 1] - base <= batch_hits) q1++;
+        const uint64_t hits = h_bound[q1] - base;
+        if (hits >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: one sequence alone has more than 2^31 seed hits");
+        if (hits) {
+            batches.push_back(Batch{q0, q1, base, hits});
+            Hmax = hits > Hmax ? hits : Hmax;
+        }
+        q0 = q1;
+    }
+    DevBuf d_h0, d_h1, d_kout, d_flag, d_pos, d_r1;
+    HC_ALLOC(d_h0, Hmax * 8);
+    HC_ALLOC(d_h1, Hmax * 8);
+    HC_ALLOC(d_kout, Hmax * 4);
+    HC_ALLOC(d_flag, (Hmax + 1) * 4);
+    HC_ALLOC(d_pos, (Hmax + 1) * 4);
+    {
+        size_t b = 0, b2 = 0, b3 = 0;
+        HC_HIP(hc::finder_sort_keys(nullptr, b, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), Hmax, st));
+        HC_HIP(hc::finder_unique(nullptr, b2, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), Hmax, st));
+        HC_HIP(hc::finder_scan32(nullptr, b3, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), Hmax + 1, st));
+        b = b2 > b ? b2 : b;
+        b = b3 > b ? b3 : b;
+        if (b > tmp_bytes) {
+            HC_HIP(hipStreamSynchronize(st));
+            (void)hipFree(d_tmp.slot->p);
+            d_tmp.slot->p = nullptr;
+            d_tmp.slot->cap = 0;
+            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
+            d_tmp.slot->cap = b;
+            d_tmp.p = d_tmp.slot->p;
+            tmp_bytes = b;
+        }
+    }
+    unsigned long long R = 0;
+    size_t res_cap = 0;  // records; the result buffer grows by doubling (it outlives the call: not a scratch slot)
+    for (const Batch& bt : batches) {
+        const uint64_t Hb = bt.hits;
+        HC_HIP(hc::finder_expand(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), bt.q0, bt.q1, bt.base, k, s, n_ori, d_v1.as<uint64_t>(),
+                                 d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), d_h0.as<uint64_t>(), st));
+        size_t bs = tmp_bytes;
+        HC_HIP(hc::finder_sort_keys(d_tmp.p, bs, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), Hb, st));
+        bs = tmp_bytes;
+        HC_HIP(hc::finder_unique(d_tmp.p, bs, d_h1.as<uint64_t>(), d_h0.as<uint64_t>(), d_count.as<unsigned long long>(), Hb, st));
+        unsigned long long M = 0;
+        HC_HIP(hipMemcpyAsync(&M, d_count.p, sizeof M, hipMemcpyDeviceToHost, st));
+        HC_HIP(hipStreamSynchronize(st));
+        if (M == 0) continue;
+        HC_HIP(hipMemsetAsync(d_flag.as<uint32_t>() + M, 0, 4, st));
+        HC_HIP(hc::finder_verify(c->d_sym, c->view.symbytes, wide, d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), M, err_rate, min_overlap, flags,
+                                 d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), st));
+        bs = tmp_bytes;
+        HC_HIP(hc::finder_scan32(d_tmp.p, bs, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M + 1, st));
+        uint32_t Rb = 0;
+        HC_HIP(hipMemcpyAsync(&Rb, d_pos.as<uint32_t>() + M, 4, hipMemcpyDeviceToHost, st));
+        HC_HIP(hipStreamSynchronize(st));
+        if (Rb == 0) continue;
+        if (R + Rb > res_cap) {
+            size_t want = res_cap ? res_cap * 2 : (size_t)Rb;
+            if (want < R + Rb) want = R + Rb;
+            if (batches.size() == 1) want = Rb;
+            void* bigger = nullptr;
+            HC_HIP(hipMalloc(&bigger, want * sizeof(hc_sfo_rec)));
+            if (R) HC_HIP(hipMemcpyAsync(bigger, d_r1.own, R * sizeof(hc_sfo_rec), hipMemcpyDeviceToDevice, st));
+            HC_HIP(hipStreamSynchronize(st));
+            if (d_r1.own) (void)hipFree(d_r1.own);
+            d_r1.own = bigger;
+            d_r1.p = bigger;
+            res_cap = want;
+        }
+        HC_HIP(hc::finder_emit(d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M,
+                               (hc_sfo_rec*)d_r1.p + R, st));
+        R += Rb;
+    }
+    HC_HIP(hipStreamSynchronize(st));
+    lap("expand/sort/unique/verify/emit");
+    if (R == 0) {
+        remember(nullptr, 0);
+        return HC_OK;
+    }
+    if (batches.size() > 1) {  // every batch is sorted; one more sort (key, position) + gather for the global order
+        if (R >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 overlaps");
+        DevBuf sk0, sk1, si0, si1;
+        void* sorted = nullptr;
+        HC_HIP(hipMalloc(&sk0.own, R * 8));
+        HC_HIP(hipMalloc(&sk1.own, R * 8));
+        HC_HIP(hipMalloc(&si0.own, R * 8));
+        HC_HIP(hipMalloc(&si1.own, R * 8));
+        HC_HIP(hc::finder_rekey((const hc_sfo_rec*)d_r1.p, R, (uint64_t*)sk0.own, (uint64_t*)si0.own, st));
+        size_t b = 0;
+        HC_HIP(hc::finder_sort_pairs(nullptr, b, (uint64_t*)sk0.own, (uint64_t*)sk1.own, (uint64_t*)si0.own, (uint64_t*)si1.own, R, 64, st));
+        DevBuf stmp;
+        HC_HIP(hipMalloc(&stmp.own, b ? b : 16));
+        HC_HIP(hc::finder_sort_pairs(stmp.own, b, (uint64_t*)sk0.own, (uint64_t*)sk1.own, (uint64_t*)si0.own, (uint64_t*)si1.own, R, 64, st));
+        HC_HIP(hipMalloc(&sorted, R * sizeof(hc_sfo_rec)));
+        HC_HIP(hc::finder_gather((const hc_sfo_rec*)d_r1.p, (const uint64_t*)si1.own, R, (hc_sfo_rec*)sorted, st));
+        HC_HIP(hipStreamSynchronize(st));
+        (void)hipFree(d_r1.own);
+        d_r1.own = sorted;
+        d_r1.p = sorted;
+        lap("global order of the batches");
+    }
+    *n_out = R;
+    const uint64_t take = R < cap ? R : cap;
+    if (take) HC_HIP(hipMemcpy(out, d_r1.p, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
+    lap("copy to host");
+    remember((hc_sfo_rec*)d_r1.p, R);  // the context owns the records now
+    d_r1.own = nullptr;
+    return HC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// hc_ctx.h — the context behind the C ABI (include/hcedge.h), shared by the hc_api*.cpp translation units, and the
+// launch interface of the kernel translation units.  Internal: nothing here is part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/hcedge.h"
+#include "hc_device.h"
+#include "hc_overlap_finder.h"
+
+namespace hc {
+// hc_kernels.hip
+hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
+                         const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
+                         uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
+                         hipStream_t stream);
+hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const void* in, uint64_t n,
+                        hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, hc_gather_row* rows,
+                        unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream);
+hipError_t set_score_kernel_lds_limit();
+// hc_util_kernels.hip
+size_t compact_temp_bytes(uint32_t n);
+hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_out, unsigned long long* count_out, void* temp,
+                          size_t temp_bytes, hipStream_t stream);
+hipError_t launch_pack_rows(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count, uint64_t cap, uint64_t base,
+                            hc_gather_row* rows, uint32_t n_cu, hipStream_t stream);
+hipError_t launch_pack_header(const unsigned long long* count, hc_gather_row* header, hipStream_t stream);
+hipError_t launch_gather_results(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count,
+                                 hc_result_rec* out, uint32_t n_cu, hipStream_t stream);
+size_t reorder_temp_bytes(uint32_t n);
+hipError_t launch_reorder(uint32_t n_reads, uint32_t fmt, const void* in, uint32_t n, uint32_t* keys_in, uint32_t* keys_out,
+                          uint32_t* idx_in, uint32_t* perm_out, void* temp, size_t temp_bytes, hipStream_t stream);
+hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, uint32_t fmt, const void* in, uint64_t n,
+                                  unsigned long long* totals, hipStream_t stream);
+
+int set_last_error(int status, const std::string& what);  // thread-local text behind hc_last_error()
+}  // namespace hc
+
+#define HC_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return hc::set_last_error(HC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// A grow-only device (or page-locked host) block owned by the context: allocating and freeing per call costs more
+// than most of the kernels here.
+struct hc_scratch {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool host = false;  // hipHostMalloc (mapped) instead of hipMalloc
+    int ensure(size_t bytes) {  // contents are not kept
+        if (bytes <= cap) return HC_OK;
+        release();
+        const size_t want = bytes + bytes / 8;
+        if (host) HC_HIP(hipHostMalloc(&p, want, hipHostMallocMapped));
+        else HC_HIP(hipMalloc(&p, want));
+        cap = want;
+        return HC_OK;
+    }
+    void release() {
+        if (p) (void)(host ? hipHostFree(p) : hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const { return (T*)p; }
+    hc_scratch() = default;
+    hc_scratch(const hc_scratch&) = delete;
+    hc_scratch& operator=(const hc_scratch&) = delete;
+    ~hc_scratch() { release(); }
+};
+
+struct hc_ctx {
+    hc_settings settings;
+    int device = 0;
+    uint32_t n_cu = 256;
+    int fetch_group = 4;  // 16-symbol chunks per fetch group of the scoring kernel: 4 (short reads) or 2 (contigs);
+                          // chosen per read set in hc_set_reads (HC_FETCH_GROUP overrides: a tuning knob only)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // read store
+    bool have_reads = false;
+    void* d_sym = nullptr;
+    hc::ReadDesc* d_reads = nullptr;
+    double* d_lut = nullptr;
+    uint64_t store_bytes = 0;
+    hc::StoreView view{};
+    hc::ScoreParams params{};
+    // what the overlap finder needs of the sequences (host copies, filled by hc_set_reads)
+    std::vector<hc::SeqRef> seq_refs;  // by store sequence index
+    bool singles_first = true;
+    // result of the last hc_find_overlaps, kept on the device so that the usual "ask for the count, then fetch"
+    // pair of calls computes once
+    struct Scratch {  // grow-only device scratch of the finder, one slot per buffer, freed with the store
+        void* p = nullptr;
+        size_t cap = 0;
+    } finder_scratch[20];
+    hc_sfo_rec* d_found = nullptr;
+    uint64_t n_found = 0;
+    double found_err = -1;
+    uint32_t found_min = 0, found_flags = 0;
+    bool found_valid = false;
+    // grow-only workspace for the host-buffer entry points
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    uint64_t ws_cap = 0;
+    unsigned long long* d_totals = nullptr;
+    // candidate reorder (HC_REORDER_*): scratch for the (key, index) radix sort, grow-only
+    int reorder_mode = HC_REORDER_AUTO;
+    uint32_t* d_sort = nullptr;  // 4 arrays of sort_cap uint32: keys_in, keys_out, idx_in, perm
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint64_t sort_cap = 0;
+    // compaction scratch, grow-only
+    void* d_compact_tmp = nullptr;
+    size_t compact_tmp_bytes = 0;
+    uint32_t* d_compact_idx = nullptr;
+    hc_result_rec* d_compact_res = nullptr;
+    uint64_t compact_cap = 0;
+    // hc_graph_resolve / hc_graph_fetch (hc_api_stage.cpp): device-resident result of the last resolve
+    struct Graph {
+        hc_scratch adm, E, key0, key1, idx0, idx1, keep, incl, tied, counters, surv, k32a, k32b, k64a, k64b, tmp_idx, o_out, o_in,
+            out_off, in_off, edges_out, in_nodes, vtx, temp, tied_list;
+        uint64_t n_vertices = 0, n_edges = 0, n_tied = 0;
+        bool valid = false;
+    } graph;
+};
+
+int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, hipStream_t s, bool reorder,
+                 hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index);

@@ -92,6 +92,8 @@ struct ScoreParams {
     double merge_contigs;
     uint32_t min_read_len;
     uint32_t flags;  // bit0: edge_threshold < 0 (every score passes), bit1: ov_threshold < 0
+    uint32_t rec_fmt;  // HC_REC_FULL / HC_REC_COMPACT: layout of the candidate records of this launch
+    uint32_t pad;
 };
 
 }  // namespace hc

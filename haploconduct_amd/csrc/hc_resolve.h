@@ -1,0 +1,130 @@
+// hc_resolve.h — device-side: candidate record -> sub-overlap descriptors (reference compute_overlap,
+// src/EdgeCalculator.cpp:197-380).  Shared by the scoring kernel, the position counter and the
+// candidate reorder.  Two record formats enter here (include/hcedge.h): hc_overlap_rec (32 bytes, the parser's full
+// record) and hc_cand_rec (16 bytes: only what the device reads, the form that crosses PCIe in the stage).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hcedge.h"
+#include "hc_device.h"
+
+namespace hc {
+
+// What resolve() reads of a candidate, whichever record format it arrived in.
+struct Cand {
+    uint32_t read1, read2, pos1, pos2;
+    uint32_t ori1, ori2;  // 1 = "+"
+    uint32_t ord;         // '-', '1', '2'; anything else is malformed for a p-p overlap
+};
+
+// fmt: HC_REC_FULL (hc_overlap_rec) or HC_REC_COMPACT (hc_cand_rec); wave-uniform
+__device__ __forceinline__ Cand load_cand(const void* __restrict__ in, uint64_t i, uint32_t fmt) {
+    Cand c;
+    if (fmt == HC_REC_COMPACT) {
+        const uint4 a = ((const uint4*)in)[i];
+        c.read1 = a.x;
+        c.read2 = a.y;
+        c.pos1 = a.z & HC_CAND_POS_MASK;
+        c.pos2 = a.w & HC_CAND_POS_MASK;
+        c.ori1 = (a.z >> 28) & 1u;
+        c.ori2 = (a.z >> 29) & 1u;
+        const uint32_t oc = a.z >> 30;
+        c.ord = oc == 1u ? (uint32_t)'1' : (oc == 2u ? (uint32_t)'2' : (oc == 0u ? (uint32_t)'-' : 0u));
+    } else {
+        const uint4 a = ((const uint4*)in)[2 * i];  // the second half (len1, len2, perc) is host-only
+        c.read1 = a.x;
+        c.read2 = a.y;
+        c.pos1 = a.z;
+        c.pos2 = a.w;
+        const uint32_t w = ((const uint32_t*)in)[8 * i + 4];
+        c.ori1 = (w & 0xFFu) ? 1u : 0u;
+        c.ori2 = ((w >> 8) & 0xFFu) ? 1u : 0u;
+        c.ord = (w >> 16) & 0xFFu;
+    }
+    return c;
+}
+
+struct View {
+    uint64_t off;  // symbol offset of the oriented sequence
+    uint32_t len;
+    uint32_t fatal;  // reverse-complementing a sequence that holds an invalid base: build_rev_comp exits
+};
+
+__device__ __forceinline__ ReadDesc load_desc(const ReadDesc* p) {
+    const uint4* q = (const uint4*)p;
+    const uint4 a = q[0], b = q[1];
+    ReadDesc d;
+    d.off1 = ((uint64_t)a.y << 32) | a.x;
+    d.off2 = ((uint64_t)a.w << 32) | a.z;
+    d.len1 = b.x;
+    d.len2 = b.y;
+    d.flags = b.z;
+    d.pad = 0;
+    return d;
+}
+
+// mate: 0 = /1 (or the single sequence), 1 = /2
+template <int SB>
+__device__ __forceinline__ View make_view(const ReadDesc& d, uint32_t mate, uint32_t fwd) {
+    View v;
+    const uint64_t off = mate ? d.off2 : d.off1;
+    v.len = mate ? d.len2 : d.len1;
+    // slot_stride() with a compile-time symbol size (no 64-bit division)
+    const uint32_t stride = SB == 1 ? (((v.len + 15u) & ~15u) + 32u) : ((((2u * v.len + 15u) & ~15u) + 32u) >> 1);
+    v.off = off + (fwd ? 0u : stride);
+    v.fatal = (!fwd && (d.flags & (mate ? kReadBadBase2 : kReadBadBase1))) ? 1u : 0u;
+    return v;
+}
+
+struct Sub {
+    uint64_t offA, offB;
+    uint32_t lenA, lenB, pos, fatal;
+};
+
+__device__ __forceinline__ Sub make_sub(const View& A, const View& B, uint32_t pos) {
+    Sub s;
+    s.offA = A.off;
+    s.offB = B.off;
+    s.lenA = A.len;
+    s.lenB = B.len;
+    s.pos = pos;
+    s.fatal = A.fatal | B.fatal;
+    return s;
+}
+
+// Returns the number of sub-overlaps (1 or 2); 0 = malformed record.
+template <int SB>
+__device__ __forceinline__ int resolve(const StoreView& st, const Cand& r, Sub& s0, Sub& s1) {
+    if (r.read1 >= st.n_reads || r.read2 >= st.n_reads || r.read1 == r.read2) return 0;
+    const ReadDesc d1 = load_desc(st.reads + r.read1);
+    const ReadDesc d2 = load_desc(st.reads + r.read2);
+    const uint32_t p1 = d1.flags & kReadPaired, p2 = d2.flags & kReadPaired;
+    const uint32_t o1 = r.ori1, o2 = r.ori2;
+    // single: S(R,o); paired: F(R,o) = o ? /1 : rc(/2) ("front"), K(R,o) = o ? /2 : rc(/1) ("back")
+    const View F1 = make_view<SB>(d1, p1 ? (o1 ? 0u : 1u) : 0u, o1);
+    const View F2 = make_view<SB>(d2, p2 ? (o2 ? 0u : 1u) : 0u, o2);
+    s0 = make_sub(F1, F2, r.pos1);  // every type: (front1, front2, pos1)
+    if (!p1 && !p2) return 1;       // s-s :199-233
+    const View K1 = make_view<SB>(d1, p1 ? (o1 ? 1u : 0u) : 0u, o1);
+    const View K2 = make_view<SB>(d2, p2 ? (o2 ? 1u : 0u) : 0u, o2);
+    if (!p1) {  // s-p :234-271: (S1, K2, pos2)
+        s1 = make_sub(F1, K2, r.pos2);
+    } else if (!p2) {  // p-s :272-309: (S2, K1, pos2)
+        s1 = make_sub(F2, K1, r.pos2);
+    } else {  // p-p :312-380
+        if (r.ord == '1') s1 = make_sub(K1, K2, r.pos2);
+        else if (r.ord == '2') s1 = make_sub(K2, K1, r.pos2);
+        else return 0;
+    }
+    return 2;
+}
+
+__device__ __forceinline__ uint32_t sub_positions(const Sub& s, uint32_t min_read_len) {
+    if (s.pos >= s.lenA) return 0;                                  // :76-79
+    if (s.lenA < min_read_len || s.lenB < min_read_len) return 0;  // :82-84
+    const uint32_t rem = s.lenA - s.pos;                            // :88
+    return rem < s.lenB ? rem : s.lenB;
+}
+
+}  // namespace hc

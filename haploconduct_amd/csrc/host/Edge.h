@@ -18,6 +18,11 @@ public:
         if (!(score == 0 || score == -1 || score > 0)) throw FatalError{-9, "Edge: score must be 0, -1 or positive"};
     }
 
+    Edge(double s, int p1, int p2, bool orientation1, bool orientation2, char o, Read* r1, Read* r2)
+        : score(s), pos1(p1), pos2(p2), ori1(orientation1), ori2(orientation2), read1(r1), read2(r2), ord(o) {
+        if (!(score == 0 || score == -1 || score > 0)) throw FatalError{-9, "Edge: score must be 0, -1 or positive"};
+    }
+
     double get_score() const { return score; }
     void set_mismatch(double m) { mismatch_rate = m; }
     double get_mismatch_rate() const { return mismatch_rate; }

@@ -1,17 +1,23 @@
-// EdgeCalculator.cpp — construct_edges / process_overlaps of the reference
-// (src/EdgeCalculator.cpp:389-666) with the OpenMP scoring loop replaced by the HIP path
-// behind include/hcedge.h.  The serial insert (duplicate resolution with the reference's
-// tie-break chain) and the nonedge_overlaps.txt bookkeeping stay on the host.
+// EdgeCalculator.cpp — construct_edges / process_overlaps of the reference (src/EdgeCalculator.cpp:389-666) with the
+// OpenMP scoring loop replaced by the HIP path behind include/hcedge.h, and — into an empty graph, every pipeline call —
+// the serial half (duplicate resolution with the reference's tie-break chain, adjacency lists) by the device's
+// resolution of all admitted candidates at once (hc_graph_resolve).  nonedge_overlaps.txt bookkeeping and the per-edge
+// insert into a graph that already holds edges stay on the host.
 #include "EdgeCalculator.h"
 
+#include <sys/mman.h>
+
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
-#include <sys/mman.h>
 #include <cstring>
-#include <type_traits>
+#include <mutex>
 #include <thread>
+#include <type_traits>
 
 namespace hc {
 
@@ -23,24 +29,56 @@ static void check(int status, const char* where) {
     if (status != HC_OK) throw FatalError{status, std::string(where) + ": " + hc_strerror(status) + " " + hc_last_error()};
 }
 
+// The devices of the stage: HC_DEVICE_LIST ("0,1,1": a test knob — an ordinal may repeat, giving several contexts on
+// one device), else the bits of --device_mask, else --device alone.
+static std::vector<int> device_list(const ProgramSettings& ps) {
+    std::vector<int> d;
+    if (const char* e = getenv("HC_DEVICE_LIST")) {
+        for (const char* p = e; *p;) {
+            char* end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            d.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+        }
+    } else if (ps.device_mask) {
+        for (int b = 0; b < 32; b++)
+            if (ps.device_mask & (1u << b)) d.push_back(b);
+    }
+    if (d.empty()) d.push_back(ps.device);
+    return d;
+}
+
 EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_ptr<OverlapGraph> graph,
                                const ProgramSettings& ps)
     : program_settings(ps), fastq_storage(std::move(fastq)), overlap_graph(std::move(graph)) {
     if (ps.add_duplicates) throw FatalError{HC_ERR_ARG, "--add_duplicates is not supported (the pipelines never set it)"};
     if (const char* m = getenv("HC_INSERT_MODE")) m_serial_insert = std::string(m) == "serial";
+    if (const char* m = getenv("HC_RESOLVE")) m_host_resolve = std::string(m) == "host";
     m_cs = to_hc_settings(ps);
-    check(hc_create(&m_ctx, &m_cs), "hc_create");
     const FastqStorage& f = *fastq_storage;
-    check(hc_set_reads(m_ctx, f.bases().data(), f.quals().data(), f.seq_off().data(), f.read_first_seq().data(),
-                       f.get_readcount()),
-          "hc_set_reads");
+    try {
+        for (int d : device_list(ps)) {  // the read store is replicated: candidates are independent given the reads
+            hc_settings cs = m_cs;
+            cs.device = d;
+            Device dev;
+            check(hc_create(&dev.ctx, &cs), "hc_create");
+            m_dev.push_back(dev);
+            check(hc_set_reads(dev.ctx, f.bases().data(), f.quals().data(), f.seq_off().data(), f.read_first_seq().data(),
+                               f.get_readcount()),
+                  "hc_set_reads");
+        }
+    } catch (...) {
+        for (Device& d : m_dev) hc_destroy(d.ctx);
+        throw;
+    }
+    m_ctx = m_dev[0].ctx;
 }
 
 EdgeCalculator::~EdgeCalculator() {
-    if (m_ctx) {
-        hc_host_free(m_ctx, m_res);
-        hc_host_free(m_ctx, m_idx);
-        hc_destroy(m_ctx);
+    for (Device& d : m_dev) {
+        for (hc_block* b : d.blk) hc_block_destroy(b);
+        hc_destroy(d.ctx);
     }
 }
 
@@ -101,62 +139,71 @@ void EdgeCalculator::collect_read_info() {
     for (auto& x : th) x.join();
 }
 
-// src/EdgeCalculator.cpp:395-414 (+ the Edge construction of compute_overlap): device scoring, then finalise and
-// build on a few host threads; sequence order is kept by concatenating the threads' pieces in order.
-void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) {
-    out.edges.clear();
-    out.nonedge_text.clear();
-    out.nonedges = 0;
-    const size_t n = batch.size();
-    if (n == 0) return;
-    double t0 = now_s();
-    if (n > m_cap) {
-        hc_host_free(m_ctx, m_res);
-        hc_host_free(m_ctx, m_idx);
-        m_res = nullptr;
-        m_idx = nullptr;
-        m_cap = 0;
-        const size_t cap = n + n / 8;
-        check(hc_host_alloc(m_ctx, (void**)&m_res, cap * sizeof(hc_result_rec)), "hc_host_alloc");
-        check(hc_host_alloc(m_ctx, (void**)&m_idx, cap * sizeof(uint32_t)), "hc_host_alloc");
-        m_cap = cap;
+// The Edge as compute_overlap builds it, :219-232 / :254-270 / :292-308 / :353-379 (the device's edge_build_kernel
+// states the same arithmetic for the bulk path).
+Edge edge_from_admit(const hc_admit_rec& o, const ReadInfo* read_info) {
+    const ReadInfo& i1 = read_info[o.read1];
+    const ReadInfo& i2 = read_info[o.read2];
+    if (!i1.vertex_set || !i2.vertex_set) throw FatalError{HC_ERR_STATE, "Read::get_vertex_id: vertex id not set"};  // :180-183 asserts it
+    const bool p1 = i1.paired, p2 = i2.paired;
+    const int pos1 = (int)o.pos1, pos2 = (int)o.pos2;
+    int pos3, pos4 = 0;
+    if (!p1 && !p2) {
+        pos3 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :222
+    } else if (!p1 && p2) {
+        pos3 = (int)i1.len_a - pos2 - (int)i2.len_b;                 // :262
+        pos4 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :263
+    } else if (p1 && !p2) {
+        pos3 = (int)i1.len_b + pos2 - (int)i2.len_a;                 // :300
+        pos4 = (int)i2.len_a + pos1 - (int)i1.len_a;                 // :301
+    } else {
+        pos3 = o.ord == '1' ? (int)i1.len_b - pos2 - (int)i2.len_b   // :363
+                            : (int)i1.len_b + pos2 - (int)i2.len_b;  // :370
+        pos4 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :372
     }
-    // the omp-for of :395-414 on the device, straight from the (page-locked) records the parser wrote; only the
-    // records that are not dropped come back
-    const hc_overlap_rec* m_rec = batch.recs;
-    uint64_t n_kept = 0;
-    check(hc_score_batch_compact(m_ctx, m_rec, n, m_idx, m_res, m_cap, &n_kept), "hc_score_batch_compact");
-    stats.scored += n;
-    const double t_dev = now_s();
-    if (program_settings.verbose) puts("build edges / write overlaps to file");
+    Edge e(o.score, pos1, pos2, o.ori1 != 0, o.ori2 != 0, (char)o.ord, i1.read, i2.read);
+    e.set_vertices(i1.vertex, i2.vertex);  // :180-183
+    e.set_extra_pos(pos3, pos4);
+    e.set_perc((int)o.perc);
+    e.set_len((int)o.len1, (!p1 && !p2) ? 0 : (int)o.len2);  // :227 / :268
+    e.set_mismatch((float)o.mm / (double)o.n);                // :132
+    return e;
+}
 
-    if (m_read_info.size() != fastq_storage->m_read_vec.size()) collect_read_info();
+// src/EdgeCalculator.cpp:404-414 for the records of a block that the device did not drop: the class (host libm for the
+// guard band), exp() of the admitted ones, the lines of the non-edges; sequence order is kept by concatenating the
+// threads' pieces in order.
+void EdgeCalculator::finalize_block(const ParsedBatch& batch, const hc_gather_row* rows, uint64_t n_rows, uint64_t base, BlockOut& out) {
+    out.admitted.clear();
+    out.nonedge_text.clear();
+    out.nonedges = out.ambiguous = 0;
+    if (n_rows == 0) return;
     struct Piece {
-        std::vector<Edge> edges;
+        std::vector<hc_admit_rec> admitted;
         std::string nonedge_text;
         uint64_t nonedges = 0, ambiguous = 0;
         FatalError error{0, ""};
     };
     auto build = [&](uint64_t kb, uint64_t ke, Piece& pc) {
         char linebuf[192];
-        pc.edges.reserve((size_t)(ke - kb));
-        constexpr uint64_t kAhead = 12;  // the two rows of m_read_info are random places in a table of n_reads * 32 bytes
+        pc.admitted.reserve((size_t)(ke - kb));
         for (uint64_t k = kb; k < ke; k++) {
-            if (k + kAhead < ke) {
-                const hc_overlap_rec& a = m_rec[m_idx[k + kAhead]];
-                __builtin_prefetch(&m_read_info[a.read1]);
-                __builtin_prefetch(&m_read_info[a.read2]);
+            const hc_gather_row& row = rows[k];
+            const size_t i = (size_t)(row.index - base);
+            if (row.index < base || i >= batch.size()) {
+                pc.error = FatalError{HC_ERR_STATE, "scored record outside its block"};
+                return;
             }
-            const size_t i = m_idx[k];
-            const hc_result_rec& r = m_res[k];
+            static_assert(sizeof(hc_gather_row) == 32 && sizeof(hc_result_rec) == 24, "a row is an index followed by a result record");
+            const hc_result_rec& r = *(const hc_result_rec*)&row.x1;
             uint32_t cls = HC_RES_CLS(r);
-            if (cls == HC_CLS_DROP) continue;
+            const Overlap& line = batch.lines[i];
             if (cls == HC_CLS_ERROR) {
-                pc.error = FatalError{HC_ERR_DATA, "overlap " + batch.lines[i].get_overlap_line() + " touches an invalid base or quality byte"};
+                pc.error = FatalError{HC_ERR_DATA, "overlap " + line.get_overlap_line() + " touches an invalid base or quality byte"};
                 return;
             }
             if (cls == HC_CLS_NONEDGE) {  // :410-413
-                pc.nonedge_text.append(linebuf, batch.lines[i].write_line(linebuf));
+                pc.nonedge_text.append(linebuf, line.write_line(linebuf));
                 pc.nonedges++;
                 continue;
             }
@@ -169,120 +216,103 @@ void EdgeCalculator::score_and_build(const ParsedBatch& batch, BuiltBlock& out) 
             }
             if (cls == HC_CLS_DROP) continue;
             if (cls == HC_CLS_NONEDGE) {
-                pc.nonedge_text.append(linebuf, batch.lines[i].write_line(linebuf));
+                pc.nonedge_text.append(linebuf, line.write_line(linebuf));
                 pc.nonedges++;
                 continue;
             }
-            // build the Edge as compute_overlap does, :219-232 / :254-270 / :292-308 / :353-379
-            const hc_overlap_rec& o = m_rec[i];
-            const ReadInfo& i1 = m_read_info[o.read1];
-            const ReadInfo& i2 = m_read_info[o.read2];
-            if (!i1.vertex_set || !i2.vertex_set) {
-                pc.error = FatalError{HC_ERR_STATE, "Read::get_vertex_id: vertex id not set"};  // :180-183 asserts it
-                return;
-            }
-            const bool p1 = i1.paired, p2 = i2.paired;
-            const int pos1 = (int)o.pos1, pos2 = (int)o.pos2;
-            int pos3, pos4 = 0;
-            if (!p1 && !p2) {
-                pos3 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :222
-            } else if (!p1 && p2) {
-                pos3 = (int)i1.len_a - pos2 - (int)i2.len_b;                 // :262
-                pos4 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :263
-            } else if (p1 && !p2) {
-                pos3 = (int)i1.len_b + pos2 - (int)i2.len_a;                 // :300
-                pos4 = (int)i2.len_a + pos1 - (int)i1.len_a;                 // :301
-            } else {
-                pos3 = o.ord == '1' ? (int)i1.len_b - pos2 - (int)i2.len_b   // :363
-                                    : (int)i1.len_b + pos2 - (int)i2.len_b;  // :370
-                pos4 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :372
-            }
-            Edge e(score, pos1, pos2, o.ori1 != 0, o.ori2 != 0, std::string(1, (char)o.ord), i1.read, i2.read);
-            e.set_vertices(i1.vertex, i2.vertex);  // :180-183
-            e.set_extra_pos(pos3, pos4);
-            e.set_perc((int)o.perc);
-            e.set_len((int)o.len1, (!p1 && !p2) ? 0 : (int)o.len2);  // :227 / :268
-            e.set_mismatch(mismatch_rate);
-            pc.edges.push_back(e);
+            const hc_cand_rec& c = batch.recs[i];
+            hc_admit_rec a;
+            a.score = score;
+            a.read1 = c.read1;
+            a.read2 = c.read2;
+            a.pos1 = line.m_pos1;
+            a.pos2 = line.m_pos2;
+            a.mm = r.mm;
+            a.n = HC_RES_N(r);
+            a.len1 = line.m_len1;
+            a.len2 = line.m_len2;
+            a.perc = line.get_perc();
+            a.ori1 = line.m_ori1 == '+';
+            a.ori2 = line.m_ori2 == '+';
+            a.ord = (uint8_t)line.m_ord;
+            a.pad = 0;
+            pc.admitted.push_back(a);
         }
     };
     static const unsigned build_cap = getenv("HC_BUILD_THREADS") ? (unsigned)atoi(getenv("HC_BUILD_THREADS")) : 8u;  // experiment knob
     unsigned T = program_settings.n_threads > 1 ? std::min<unsigned>(program_settings.n_threads, std::max(1u, build_cap)) : 1;
-    if (n_kept < 4096) T = 1;
+    if (n_rows < 4096) T = 1;
     std::vector<Piece> pieces(T);
     if (T == 1) {
-        build(0, n_kept, pieces[0]);
+        build(0, n_rows, pieces[0]);
     } else {
         if (!m_build_pool || m_build_pool->workers() + 1 < T) m_build_pool.reset(new WorkerPool(T - 1));
         m_build_pool->run(T, [&](unsigned int t) {
             try {
-                build(n_kept * t / T, n_kept * (t + 1) / T, pieces[t]);
-            } catch (const FatalError& e) {  // Edge's own checks (src/Edge.h:43-57, :211-218); reported in sequence order below
+                build(n_rows * t / T, n_rows * (t + 1) / T, pieces[t]);
+            } catch (const FatalError& e) {
                 pieces[t].error = e;
+            } catch (const std::exception& e) {  // nothing may leave a pool thread
+                pieces[t].error = FatalError{HC_ERR_NOMEM, e.what()};
             }
         });
     }
-    const double t_built = now_s();
-    size_t n_edges = 0;
+    size_t n_adm = 0;
     for (const Piece& pc : pieces) {
         if (pc.error.status) throw pc.error;  // the first one in sequence order
-        n_edges += pc.edges.size();
+        n_adm += pc.admitted.size();
     }
-    out.edges.reserve(n_edges);
+    out.admitted.reserve(n_adm);
     for (Piece& pc : pieces) {
-        out.edges.insert(out.edges.end(), pc.edges.begin(), pc.edges.end());
+        out.admitted.insert(out.admitted.end(), pc.admitted.begin(), pc.admitted.end());
         out.nonedge_text += pc.nonedge_text;
         out.nonedges += pc.nonedges;
-        stats.ambiguous += pc.ambiguous;
-    }
-    const double t1 = now_s();
-    stats.t_score += t1 - t0;
-    if (static const bool detail = getenv("HC_STAGE_TIMING") != nullptr; detail) {  // where the score stage spends its time
-        static double dev = 0, build_s = 0, concat = 0;
-        dev += t_dev - t0, build_s += t_built - t_dev, concat += t1 - t_built;
-        fprintf(stderr, "[hc stage] score stage so far: device %.3f s, build %.3f s, concat %.3f s\n", dev, build_s, concat);
+        out.ambiguous += pc.ambiguous;
     }
 }
 
-// src/EdgeCalculator.cpp:431-555: the serial half
-void EdgeCalculator::insert_block(BuiltBlock& blk) {
+// src/EdgeCalculator.cpp:431-555: the serial half for one block
+void EdgeCalculator::consume_block(BlockOut& blk) {
     const double t1 = now_s();
-    const unsigned int dups_before = dup_count;
-    const uint64_t added_before = stats.edges_added;
     stats.nonedges_written += blk.nonedges;
-    if (m_sorted_insert) {
-        m_admitted.emplace_back(std::move(blk.edges));  // resolved once, after the last block
-        blk.edges = std::vector<Edge>();
+    stats.ambiguous += blk.ambiguous;
+    if (m_collect) {
+        m_admitted.insert(m_admitted.end(), blk.admitted.begin(), blk.admitted.end());  // resolved once, after the last block
     } else {
         // The second read of an edge is a random place in the graph's slot index and in the in-lists: ask for the
         // slot and the list header 2*kAhead edges early, and for the end of the list (its header is in cache by
         // then) kAhead edges early.
+        const unsigned int dups_before = dup_count;
+        const uint64_t added_before = stats.edges_added;
+        std::vector<Edge> edges;
+        edges.reserve(blk.admitted.size());
+        for (const hc_admit_rec& a : blk.admitted) edges.push_back(edge_from_admit(a, m_read_info.data()));
         constexpr size_t kAhead = 8;
-        const size_t m = blk.edges.size();
+        const size_t m = edges.size();
         for (size_t k = 0; k < m; k++) {
             if (k + 2 * kAhead < m) {
-                const Edge& a = blk.edges[k + 2 * kAhead];
+                const Edge& a = edges[k + 2 * kAhead];
                 overlap_graph->prefetch_slot(a.get_vertex(1), a.get_vertex(2), a.get_ori(1) == a.get_ori(2));
                 if (a.get_pos(1) == 0) overlap_graph->prefetch_slot(a.get_vertex(2), a.get_vertex(1), false);  // may be swapped, :443-448
             }
             if (k + kAhead < m) {
-                const Edge& a = blk.edges[k + kAhead];
+                const Edge& a = edges[k + kAhead];
                 overlap_graph->prefetch_in_list(a.get_vertex(2));
                 if (a.get_pos(1) == 0) overlap_graph->prefetch_in_list(a.get_vertex(1));
             }
             InsertCounters ic;
-            insert_edge(*overlap_graph, program_settings, blk.edges[k], ic);
+            insert_edge(*overlap_graph, program_settings, edges[k], ic);
             inclusion_count += ic.inclusion_count;
             dup_count += ic.dup_count;
             stats.edges_added += ic.edges_added;
         }
+        if (program_settings.verbose) {
+            printf("Number of edges found: %lu\n", (unsigned long)(stats.edges_added - added_before));
+            printf("Number of duplicates: %u\n", dup_count - dups_before);
+        }
     }
     const double t2 = now_s();
     stats.t_insert += t2 - t1;
-    if (program_settings.verbose && !m_sorted_insert) {
-        printf("Number of edges found: %lu\n", (unsigned long)(stats.edges_added - added_before));
-        printf("Number of duplicates: %u\n", dup_count - dups_before);
-    }
     // :546-555 (the file is opened in append mode even when nothing is written)
     FILE* fo = fopen((program_settings.output_dir + "nonedge_overlaps.txt").c_str(), "a");
     if (fo) {
@@ -292,145 +322,295 @@ void EdgeCalculator::insert_block(BuiltBlock& blk) {
     stats.t_write += now_s() - t2;
 }
 
-// src/EdgeCalculator.cpp:389-557
-void EdgeCalculator::process_overlaps(const ParsedBatch& batch) {
-    BuiltBlock blk;
-    score_and_build(batch, blk);
-    insert_block(blk);
+// The serial half for the whole file on the device: hc_graph_resolve + hc_graph_fetch, then the
+// lists of the graph simply point into the arrays that came back.
+void EdgeCalculator::resolve_on_device(bool sorted) {
+    const bool timing = getenv("HC_STAGE_TIMING") != nullptr;
+    double tp = now_s();
+    auto lap = [&](const char* what) {
+        if (timing) {
+            const double t = now_s();
+            fprintf(stderr, "[hc stage] device resolve: %s %.3f s\n", what, t - tp);
+            tp = t;
+        }
+    };
+    const size_t V = overlap_graph->adj_out.size();
+    const size_t R = m_read_info.size();
+    std::vector<uint32_t> vtx;  // only when the vertex ids are not the read indices
+    bool identity = true;
+    for (size_t r = 0; r < R && identity; r++) identity = m_read_info[r].vertex_set && m_read_info[r].vertex == r;
+    if (!identity) {
+        vtx.resize(R);
+        for (size_t r = 0; r < R; r++) vtx[r] = m_read_info[r].vertex_set ? (uint32_t)m_read_info[r].vertex : 0xFFFFFFFFu;  // unset: out of range
+    }
+    hc_graph_counts gc;
+    check(hc_graph_resolve(m_ctx, m_admitted.data(), m_admitted.size(), V, identity ? nullptr : vtx.data(),
+                           sorted ? HC_GRAPH_SORTED : HC_GRAPH_INSERTION_ORDER, &gc),
+          "hc_graph_resolve");
+    lap("resolve");
+    if (gc.first_bad >= 0) {  // the record the reference's Edge rejects: say what it says
+        (void)edge_from_admit(m_admitted[(size_t)gc.first_bad], m_read_info.data());
+        throw FatalError{HC_ERR_STATE, "hc_graph_resolve rejected an admitted record the host accepts"};
+    }
+    const size_t E = (size_t)gc.n_edges;
+    std::vector<hc_edge_rec> edges(E);
+    std::vector<uint64_t> out_off(V + 1), in_off(V + 1);
+    std::vector<uint32_t> in_nodes(E), seq, tied;
+    std::vector<uint8_t> incl(V);
+    if (gc.n_tied_lists) {
+        seq.resize(E);
+        tied.resize((size_t)gc.n_tied_lists);
+    }
+    check(hc_graph_fetch(m_ctx, edges.data(), out_off.data(), in_nodes.data(), in_off.data(), seq.empty() ? nullptr : seq.data(), incl.data(),
+                         tied.empty() ? nullptr : tied.data()),
+          "hc_graph_fetch");
+    lap("fetch");
+    std::vector<Read*>& reads = fastq_storage->m_read_vec;
+    overlap_graph->adopt_csr(edges.data(), out_off.data(), in_nodes.data(), in_off.data(), incl.data(), reads.data(), reads.size(),
+                             program_settings.n_threads);
+    lap("adopt");
+    if (!tied.empty()) {
+        // sortEdges order, lists longer than 16 with fully tied edges: std::sort's order of those is a function of
+        // the insertion order — put exactly those lists back into insertion order and let sortEdges' own code sort them
+        std::vector<uint32_t> len(reads.size());
+        for (size_t r = 0; r < len.size(); r++) len[r] = reads[r]->get_len();
+        for (uint32_t v : tied) {
+            ArenaList<Edge>& L = overlap_graph->adj_out[v];
+            const size_t a = (size_t)out_off[v];
+            std::vector<std::pair<uint32_t, Edge>> by_seq;
+            for (size_t k = 0; k < L.size(); k++) by_seq.emplace_back(seq[a + k], L[k]);
+            std::sort(by_seq.begin(), by_seq.end(), [](const std::pair<uint32_t, Edge>& x, const std::pair<uint32_t, Edge>& y) { return x.first < y.first; });
+            for (size_t k = 0; k < L.size(); k++) L[k] = by_seq[k].second;
+            overlap_graph->sort_out_list(v, len.data());
+        }
+        overlap_graph->rebuild_in_lists(program_settings.n_threads);
+        lap("tied lists");
+    }
+    inclusion_count += (unsigned int)gc.inclusion_count;
+    dup_count += (unsigned int)gc.dup_count;
+    stats.edges_added += gc.n_edges;
+    if (program_settings.verbose) {  // totals instead of the reference's per-batch lines
+        printf("Number of edges found: %lu\n", (unsigned long)gc.n_edges);
+        printf("Number of duplicates: %lu\n", (unsigned long)gc.dup_count);
+    }
+}
+
+// The same on host threads (HC_RESOLVE=host, or vertex ids beyond the device's 31 bits).
+void EdgeCalculator::resolve_on_host() {
+    const size_t total = m_admitted.size();
+    InsertCounters ic;
+    static_assert(std::is_trivially_copyable<Edge>::value, "Edge lives in a malloc'd array");
+    Edge* all = nullptr;
+    if (total) {
+        const size_t bytes = (total * sizeof(Edge) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        if (posix_memalign((void**)&all, (size_t)2 << 20, bytes) != 0) throw FatalError{HC_ERR_NOMEM, "construct_edges: out of memory"};
+        madvise(all, bytes, MADV_HUGEPAGE);
+    }
+    try {
+        const unsigned T = total < (1u << 16) ? 1u : std::max(1u, std::min<unsigned>(program_settings.n_threads, 16u));
+        std::vector<FatalError> errs(T, FatalError{0, ""});
+        std::vector<size_t> err_at(T, 0);
+        std::vector<std::thread> th;
+        auto build = [&](unsigned t) {
+            for (size_t k = total * t / T; k < total * (t + 1) / T; k++) {
+                try {
+                    new ((void*)(all + k)) Edge(edge_from_admit(m_admitted[k], m_read_info.data()));
+                } catch (const FatalError& e) {
+                    errs[t] = e;
+                    return;
+                }
+            }
+        };
+        for (unsigned t = 1; t < T; t++) th.emplace_back(build, t);
+        build(0);
+        for (auto& x : th) x.join();
+        for (const FatalError& e : errs)
+            if (e.status) throw e;  // the first one in sequence order
+        resolve_admitted_edges(*overlap_graph, program_settings, all, total, ic);
+    } catch (...) {
+        free(all);
+        throw;
+    }
+    free(all);
+    inclusion_count += ic.inclusion_count;
+    dup_count += ic.dup_count;
+    stats.edges_added += ic.edges_added;
+    if (program_settings.verbose) {
+        printf("Number of edges found: %lu\n", (unsigned long)ic.edges_added);
+        printf("Number of duplicates: %u\n", ic.dup_count);
+    }
 }
 
 // src/EdgeCalculator.cpp:561-666
-void EdgeCalculator::construct_edges() {
+void EdgeCalculator::run_stage(bool then_sort) {
     collect_read_info();  // vertex ids may have been assigned since the last call
-    // An empty graph (every pipeline call) takes the bulk path: admitted edges are collected in sequence order and
-    // resolved + filled in once after the last block (resolve_admitted_edges).  A graph that already holds edges,
-    // or HC_INSERT_MODE=serial, takes the per-edge insert of the reference's serial half.
-    m_sorted_insert = !m_serial_insert && overlap_graph->getEdgeCount() == 0 &&
-                      EdgeSlotIndex::representable(overlap_graph->adj_out.size(), overlap_graph->adj_out.size());
+    stats = Stats();
+    // An empty graph (every pipeline call) takes the bulk path: the admitted candidates are collected in sequence
+    // order and resolved at once after the last block.  A graph that already holds edges, or HC_INSERT_MODE=serial,
+    // takes the per-edge insert of the reference's serial half.
+    m_collect = !m_serial_insert && overlap_graph->getEdgeCount() == 0 &&
+                EdgeSlotIndex::representable(overlap_graph->adj_out.size(), overlap_graph->adj_out.size());
     m_admitted.clear();
     std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
     std::vector<Overlap> rejected;
     OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
     if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
     if (program_settings.verbose) puts("reading overlaps file... ");
-    size_t overlaps_per_vec = 250000;
-    if (const char* e = getenv("HC_STAGE_BLOCK")) overlaps_per_vec = (size_t)strtoull(e, nullptr, 10);  // experiment knob  // the reference batches 1,000,000 (:571); batch boundaries do not influence the result
-    // Three-stage pipeline: block k+1 is tokenised by the parser's worker threads while block k is scored on the
-    // device and its edges are built, while the edges of block k-1 are inserted into the graph.  Every stage
-    // consumes the blocks strictly in file order, so the graph, the counters and nonedge_overlaps.txt are those
-    // of the sequential loop.
-    ParsedBatch::RecStorage pinned;  // the parser writes its records where the device reads them
+    size_t overlaps_per_vec = 250000;  // the reference batches 1,000,000 (:571); batch boundaries do not influence the result
+    if (const char* e = getenv("HC_STAGE_BLOCK")) overlaps_per_vec = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 10));  // experiment knob
+
+    // The pipeline.  The caller's thread tokenises block k (on the parser's worker threads) and submits it to device
+    // k mod N; the collector thread waits for the blocks in file order, finalises what the device kept of them and
+    // runs the serial half.  Every stage consumes the blocks strictly in file order, so the graph, the counters and
+    // nonedge_overlaps.txt are those of the sequential loop.  Up to two blocks per device are in flight.
+    const size_t N = m_dev.size();
+    const size_t R = 2 * N + 1;  // parsed blocks alive at once: two per device in flight + the one being parsed
+    ParsedBatch::RecStorage pinned;  // the parser writes its records where the device's DMA reads them
     pinned.ctx = m_ctx;
-    pinned.alloc = [](void* ctx, size_t n) -> hc_overlap_rec* {
+    pinned.alloc = [](void* ctx, size_t n) -> hc_cand_rec* {
         void* p = nullptr;
-        check(hc_host_alloc((hc_ctx*)ctx, &p, n * sizeof(hc_overlap_rec)), "hc_host_alloc");
-        return (hc_overlap_rec*)p;
+        check(hc_host_alloc((hc_ctx*)ctx, &p, n * sizeof(hc_cand_rec)), "hc_host_alloc");
+        return (hc_cand_rec*)p;
     };
-    pinned.release = [](void* ctx, hc_overlap_rec* p) { hc_host_free((hc_ctx*)ctx, p); };
-    ParsedBatch batch[2] = {ParsedBatch(pinned), ParsedBatch(pinned)};
+    pinned.release = [](void* ctx, hc_cand_rec* p) { hc_host_free((hc_ctx*)ctx, p); };
+    struct Slot {
+        ParsedBatch batch;
+        uint64_t base = 0;
+        hc_block* block = nullptr;  // nullptr: nothing was submitted (an empty block)
+        explicit Slot(const ParsedBatch::RecStorage& st) : batch(st) {}
+    };
+    std::vector<std::unique_ptr<Slot>> ring;
+    for (size_t r = 0; r < R; r++) ring.emplace_back(new Slot(pinned));
     ParseCounters pc;
-    bool more[2] = {false, false};
-    FatalError parse_error{0, ""};
-    bool parse_failed = false;
-    auto parse_into = [&](int slot) {
-        try {
-            more[slot] = parser.next_batch(batch[slot], overlaps_per_vec, rejected, pc, /*print_malformed=*/true);
-        } catch (const FatalError& e) {
-            parse_failed = true;
-            parse_error = e;
-            more[slot] = false;
-        }
-    };
-    BuiltBlock built[2];
-    std::thread inserter;
-    FatalError insert_error{0, ""};
-    auto finish_insert = [&] {
-        if (inserter.joinable()) inserter.join();
-        if (insert_error.status) throw insert_error;
-    };
-    double t0 = now_s();
-    parse_into(0);
-    stats.t_parse += now_s() - t0;
-    int cur = 0, slot = 0;
-    while (more[cur]) {
-        if (parse_failed) {
-            if (inserter.joinable()) inserter.join();
-            throw parse_error;
-        }
-        std::thread ahead(parse_into, cur ^ 1);
-        try {
-            if (!batch[cur].empty()) {  // :636-644
-                score_and_build(batch[cur], built[slot]);
-                finish_insert();  // block k-1 is in the graph
-                BuiltBlock* blk = &built[slot];
-                inserter = std::thread([this, blk, &insert_error] {
-                    try {
-                        insert_block(*blk);
-                    } catch (const FatalError& e) {
-                        insert_error = e;
-                    } catch (const std::exception& e) {
-                        insert_error = FatalError{HC_ERR_STATE, e.what()};
-                    }
-                });
-                slot ^= 1;
+
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t submitted = 0, consumed = 0;  // blocks
+    bool producer_done = false;
+    std::atomic<bool> collector_failed{false};
+    FatalError collector_error{0, ""};
+    double t_collect = 0;
+    std::thread collector([&] {
+        BlockOut out;
+        for (size_t k = 0;; k++) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return submitted > k || producer_done; });
+                if (submitted <= k) return;
             }
-        } catch (...) {
-            ahead.join();
-            if (inserter.joinable()) inserter.join();
-            throw;
+            Slot& sl = *ring[k % R];
+            if (!collector_failed) {
+                try {
+                    const double t0 = now_s();
+                    const hc_gather_row* rows = nullptr;
+                    uint64_t n_rows = 0;
+                    if (sl.block) check(hc_block_wait(sl.block, &rows, &n_rows), "hc_block_wait");
+                    finalize_block(sl.batch, rows, n_rows, sl.base, out);
+                    t_collect += now_s() - t0;
+                    consume_block(out);
+                } catch (const FatalError& e) {
+                    collector_error = e;
+                    collector_failed = true;
+                } catch (const std::exception& e) {
+                    collector_error = FatalError{HC_ERR_NOMEM, e.what()};
+                    collector_failed = true;
+                }
+            } else if (sl.block) {  // drain: the block object must not stay in flight
+                const hc_gather_row* rows = nullptr;
+                uint64_t n_rows = 0;
+                (void)hc_block_wait(sl.block, &rows, &n_rows);
+            }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                consumed = k + 1;
+            }
+            cv.notify_all();
         }
-        const double t2 = now_s();
-        ahead.join();
-        stats.t_parse += now_s() - t2;  // only the part of the parse that was not hidden
-        cur ^= 1;
-    }
-    finish_insert();
-    if (parse_failed) throw parse_error;
-    if (m_sorted_insert) {
-        const double tr = now_s();
-        InsertCounters ic;
-        // one array in sequence order (the blocks are copied side by side by a few threads), resolved and filled in
-        static_assert(std::is_trivially_copyable<Edge>::value, "Edge is copied with memcpy");
-        std::vector<size_t> at(m_admitted.size() + 1, 0);
-        for (size_t b = 0; b < m_admitted.size(); b++) at[b + 1] = at[b] + m_admitted[b].size();
-        const size_t total = at.back();
-        Edge* all = nullptr;
-        if (total) {
-            const size_t bytes = (total * sizeof(Edge) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-            if (posix_memalign((void**)&all, (size_t)2 << 20, bytes) != 0) throw FatalError{HC_ERR_NOMEM, "construct_edges: out of memory"};
-            madvise(all, bytes, MADV_HUGEPAGE);  // a hint: 2 MiB pages where the system grants them (fewer first-touch faults)
-        }
+    });
+    auto stop_collector = [&] {
         {
-            const unsigned T = total < (1u << 16) ? 1u : std::max(1u, std::min<unsigned>(program_settings.n_threads, 16u));
-            std::vector<std::thread> th;
-            auto copy = [&](unsigned t) {
-                for (size_t b = t; b < m_admitted.size(); b += T)
-                    if (!m_admitted[b].empty()) memcpy((void*)(all + at[b]), (const void*)m_admitted[b].data(), m_admitted[b].size() * sizeof(Edge));
-            };
-            for (unsigned t = 1; t < T; t++) th.emplace_back(copy, t);
-            copy(0);
-            for (auto& x : th) x.join();
+            std::lock_guard<std::mutex> g(mu);
+            producer_done = true;
         }
-        if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] admitted edges side by side: %.3f s\n", now_s() - tr);
-        try {
-            resolve_admitted_edges(*overlap_graph, program_settings, all, total, ic);
-        } catch (...) {
-            free(all);
-            throw;
+        cv.notify_all();
+        if (collector.joinable()) collector.join();
+    };
+    uint64_t base = 0;
+    try {
+        for (size_t k = 0;; k++) {
+            {  // the slot's previous block (k - R) has been consumed
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return consumed + R > k; });
+                if (collector_failed) break;
+            }
+            Slot& sl = *ring[k % R];
+            const double t0 = now_s();
+            const bool more = parser.next_batch(sl.batch, overlaps_per_vec, rejected, pc, /*print_malformed=*/true);
+            stats.t_parse += now_s() - t0;
+            if (!more) break;
+            sl.base = base;
+            sl.block = nullptr;
+            const size_t n = sl.batch.size();
+            if (n) {  // :636-644
+                Device& dev = m_dev[k % N];
+                const size_t j = (k / N) % 2;
+                {  // the block object's previous user (block k - 2N) has been waited for
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return consumed + 2 * N > k; });
+                }
+                if (n > m_block_cap) {  // the first block sizes the objects; a later, larger one re-creates them all (never in flight then: see below)
+                    {
+                        std::unique_lock<std::mutex> g(mu);
+                        cv.wait(g, [&] { return consumed == k; });
+                    }
+                    for (Device& d : m_dev)
+                        for (hc_block*& b : d.blk) {
+                            hc_block_destroy(b);
+                            b = nullptr;
+                        }
+                    m_block_cap = n + n / 4;
+                }
+                if (!dev.blk[j]) check(hc_block_create(dev.ctx, m_block_cap, &dev.blk[j]), "hc_block_create");
+                check(hc_block_submit(dev.blk[j], sl.batch.recs, n, base), "hc_block_submit");
+                sl.block = dev.blk[j];
+                stats.scored += n;
+                base += n;
+            }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                submitted = k + 1;
+            }
+            cv.notify_all();
         }
-        free(all);
-        inclusion_count += ic.inclusion_count;
-        dup_count += ic.dup_count;
-        stats.edges_added += ic.edges_added;
-        if (program_settings.verbose) {  // totals instead of the reference's per-batch lines
-            printf("Number of edges found: %lu\n", (unsigned long)ic.edges_added);
-            printf("Number of duplicates: %u\n", ic.dup_count);
+    } catch (...) {
+        stop_collector();
+        throw;
+    }
+    stop_collector();
+    if (collector_failed) throw collector_error;
+    stats.t_score = t_collect;
+    bool sorted_already = false;
+    if (m_collect) {
+        const double tr = now_s();
+        bool on_device = !m_host_resolve;
+        for (const ReadInfo& x : m_read_info)
+            if (x.vertex_set && x.vertex >= ((node_id_t)1 << 31)) on_device = false;
+        if (on_device) {
+            resolve_on_device(then_sort);
+            sorted_already = then_sort;
+        } else {
+            resolve_on_host();
         }
         m_admitted.clear();
         m_admitted.shrink_to_fit();
         if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] resolve total %.3f s\n", now_s() - tr);
-        m_sorted_insert = false;
+        m_collect = false;
         stats.t_insert += now_s() - tr;
+    }
+    if (then_sort && !sorted_already) {  // the serial / host-resolved paths: sortEdges as its own pass
+        std::vector<uint32_t> len(fastq_storage->m_read_vec.size());
+        for (size_t r = 0; r < len.size(); r++) len[r] = fastq_storage->m_read_vec[r]->get_len();
+        overlap_graph->sortEdges(len.data(), program_settings.n_threads);
     }
     stats.lines_read = pc.lines_read;
     stats.malformed = pc.malformed;
@@ -441,7 +621,7 @@ void EdgeCalculator::construct_edges() {
         printf("Number of self-overlapping reads: %u\n", self_overlap_count);
         printf("Number of inclusion edges: %u\n", inclusion_count);
     }
-    t0 = now_s();
+    const double t0 = now_s();
     FILE* fo = fopen((program_settings.output_dir + "nonedge_overlaps.txt").c_str(), "a");  // :654-660
     if (fo) {
         char linebuf[192];

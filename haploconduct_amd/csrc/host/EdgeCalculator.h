@@ -42,6 +42,16 @@ void insert_edge(OverlapGraph& g, const ProgramSettings& ps, Edge& e, InsertCoun
 // The graph must not hold edges yet.  `admitted[0..n)` is consumed (edges are normalised in place).
 void resolve_admitted_edges(OverlapGraph& g, const ProgramSettings& ps, Edge* admitted, size_t n, InsertCounters& c);
 
+// The Edge compute_overlap builds for an admitted candidate (src/EdgeCalculator.cpp:219-232, :254-270, :292-308,
+// :353-379).  What it needs to know about a read comes in one row per read.
+struct ReadInfo {
+    Read* read;
+    node_id_t vertex;       // get_vertex_id(true)
+    uint32_t len_a, len_b;  // get_seq_len(0) of a single-end read; get_seq_len(1), get_seq_len(2) of a pair
+    uint32_t paired, vertex_set;
+};
+Edge edge_from_admit(const hc_admit_rec& a, const ReadInfo* read_info);
+
 class EdgeCalculator {
 public:
     unsigned int self_overlap_count = 0;   // never incremented by the reference either (its counting code is commented out)
@@ -53,12 +63,16 @@ public:
     EdgeCalculator(const EdgeCalculator&) = delete;
     EdgeCalculator& operator=(const EdgeCalculator&) = delete;
 
-    void construct_edges();                                // src/EdgeCalculator.cpp:561-666
+    void construct_edges() { run_stage(false); }           // src/EdgeCalculator.cpp:561-666
+    // construct_edges() followed by OverlapGraph::sortEdges() (src/ViralQuasispecies.cpp:281,297 — what every workflow
+    // does) as one call: the adjacency lists come from the device already in sortEdges order.
+    void construct_edges_sorted() { run_stage(true); }
     // src/EdgeCalculator.cpp:67-139 on arbitrary strings (used by SRBuilder::merge_self_overlap in the
     // reference): scored on the device through a two-read scratch store, finalised with the host libm.
     double overlap_score(const std::string& seq1, const std::string& seq2, const std::string& score1,
                          const std::string& score2, unsigned int pos, double& mismatch_rate);
     double phred_to_prob(int phred) const;                 // src/EdgeCalculator.cpp:59-63
+    unsigned int device_count() const { return (unsigned int)m_dev.size(); }
 
     // statistics of the last construct_edges() (build-owned)
     struct Stats {
@@ -68,39 +82,36 @@ public:
     } stats;
 
 private:
-    // process_overlaps (src/EdgeCalculator.cpp:389-557) in its two halves: the parallel one (:395-414: score on the
-    // device, finalise, build the Edge objects) and the serial one (:431-555: insert in sequence order, append the
-    // non-edge lines).  construct_edges() runs the serial half of block k beside the parallel half of block k+1.
-    struct BuiltBlock {
-        std::vector<Edge> edges;   // admitted edges in sequence order
-        std::string nonedge_text;  // lines for nonedge_overlaps.txt in sequence order
-        uint64_t nonedges = 0;
+    // One device of the stage: a context with its own copy of the read store and the blocks it has in flight.
+    struct Device {
+        hc_ctx* ctx = nullptr;
+        hc_block* blk[2] = {nullptr, nullptr};
     };
-    // What building an Edge needs to know about a read, in one 32-byte row instead of a walk over m_read_vec ->
-    // Read -> FastqStorage's offset arrays (five dependent, cold loads per read otherwise).
-    struct ReadInfo {
-        Read* read;
-        node_id_t vertex;       // get_vertex_id(true)
-        uint32_t len_a, len_b;  // get_seq_len(0) of a single-end read; get_seq_len(1), get_seq_len(2) of a pair
-        uint32_t paired, vertex_set;
+    // What the collector makes of one scored block, in sequence order.
+    struct BlockOut {
+        std::vector<hc_admit_rec> admitted;
+        std::string nonedge_text;
+        uint64_t nonedges = 0, ambiguous = 0;
     };
-    std::vector<ReadInfo> m_read_info;
-    std::unique_ptr<WorkerPool> m_build_pool;  // the Edge build of every block runs on these
+    void run_stage(bool then_sort);
     void collect_read_info();
-    void score_and_build(const ParsedBatch& batch, BuiltBlock& out);
-    void insert_block(BuiltBlock& blk);
-    void process_overlaps(const ParsedBatch& batch);
+    void finalize_block(const ParsedBatch& batch, const hc_gather_row* rows, uint64_t n_rows, uint64_t base, BlockOut& out);
+    void consume_block(BlockOut& out);  // serial half: insert (or collect) + nonedge_overlaps.txt, :431-555
+    void resolve_on_device(bool sorted);
+    void resolve_on_host();
+    std::vector<ReadInfo> m_read_info;
+    std::unique_ptr<WorkerPool> m_build_pool;  // the per-block finalisation runs on these
     ProgramSettings program_settings;
     std::shared_ptr<FastqStorage> fastq_storage;
     std::shared_ptr<OverlapGraph> overlap_graph;
     hc_settings m_cs;
-    hc_ctx* m_ctx = nullptr;
-    hc_result_rec* m_res = nullptr;   // page-locked (hc_host_alloc), grow-only; compacted: records of the non-DROP candidates only
-    uint32_t* m_idx = nullptr;        // their positions in the batch, ascending
-    size_t m_cap = 0;
+    hc_ctx* m_ctx = nullptr;          // = m_dev[0].ctx, the primary device (duplicate resolution runs there)
+    std::vector<Device> m_dev;
+    size_t m_block_cap = 0;           // candidates the hc_block objects were created for
     bool m_serial_insert = false;     // HC_INSERT_MODE=serial: per-edge inserts even into an empty graph
-    bool m_sorted_insert = false;     // this construct_edges() call resolves the admitted edges after the last block
-    std::vector<std::vector<Edge>> m_admitted;  // admitted edges of the whole file, block by block in sequence order
+    bool m_host_resolve = false;      // HC_RESOLVE=host: duplicate resolution on the host threads instead of the device
+    bool m_collect = false;           // this call collects the admitted candidates and resolves them after the last block
+    std::vector<hc_admit_rec> m_admitted;  // admitted candidates of the whole file in sequence order
 };
 
 }  // namespace hc

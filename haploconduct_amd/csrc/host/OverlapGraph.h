@@ -1,11 +1,13 @@
 // OverlapGraph.h — the structure the hot path emits into (reference src/OverlapGraph.h:33-131;
 // only the methods on the edge-calculation path: src/OverlapGraph.cpp:88-101,150-229,285-311).
-// Adjacency "lists" are order-preserving vectors: push_back on insert, erase keeps order, so
+// Adjacency "lists" are order-preserving arrays (ArenaList.h): push_back on insert, erase keeps order, so
 // iteration order equals the reference's std::list order.
 #pragma once
 #include <memory>
 #include <vector>
 
+#include "../../../include/hcedge.h"
+#include "ArenaList.h"
 #include "Edge.h"
 #include "FastqStorage.h"
 #include "Types.h"
@@ -98,7 +100,15 @@ public:
         vertex_count++;
         return vertex_to_read.size() - 1;
     }
+    ~OverlapGraph();
+    OverlapGraph(const OverlapGraph&) = delete;
+    OverlapGraph& operator=(const OverlapGraph&) = delete;
     void addEdge(const Edge& edge);                       // :94-101
+    // The whole graph at once, as the device's duplicate resolution hands it over (hc_graph_fetch): adj_out lists back
+    // to back in vertex order with their offsets, adj_in likewise.  The graph must be empty.  Lists point into two
+    // arenas owned by the graph; the slot index is built on the first call that needs it.  reads[r] = m_read_vec[r].
+    void adopt_csr(const hc_edge_rec* edges, const uint64_t* out_off, const uint32_t* in_nodes, const uint64_t* in_off,
+                   const uint8_t* inclusion_bits, Read* const* reads, size_t n_reads, unsigned n_threads);
     // the addEdge calls of pool[order[0]], pool[order[1]], ... as one parallel fill
     void bulk_add_edges(const Edge* pool, const std::vector<uint32_t>& order, unsigned n_threads);
     // src/OverlapGraph.cpp:722-764, the call that follows construct_edges in every workflow: out-lists sorted by
@@ -106,6 +116,8 @@ public:
     // behaviour), adj_in rebuilt from the sorted out-lists.  len_by_read[r] = Read::get_len() of m_read_vec[r];
     // lists are independent, so vertex ranges are sorted on n_threads threads.
     void sortEdges(const uint32_t* len_by_read, unsigned n_threads = 1);
+    void sort_out_list(node_id_t v, const uint32_t* len_by_read);  // sortEdges' treatment of one out-list (:724-749)
+    void rebuild_in_lists(unsigned n_threads);                     // adj_in from the out-lists, :751-762
     Edge removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations);             // :150-194
     double checkEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) const;      // :198-229
     Edge* getEdgeInfoWithOri(node_id_t v, node_id_t w, bool opposite_orientations, bool reverse_allowed = true);  // :285-306
@@ -113,7 +125,7 @@ public:
     // index and the header of the in-vertex's in-list first; a few edges later, once the header is in cache,
     // the end of that list.
     void prefetch_slot(node_id_t v, node_id_t w, bool opposite_orientations) const {
-        if (EdgeSlotIndex::representable(v, w)) slots.prefetch(EdgeSlotIndex::key(v, w, opposite_orientations));
+        if (slots_valid && EdgeSlotIndex::representable(v, w)) slots.prefetch(EdgeSlotIndex::key(v, w, opposite_orientations));
         if (w < adj_in.size()) __builtin_prefetch(&adj_in[w]);
     }
     void prefetch_in_list(node_id_t w) const {
@@ -123,12 +135,16 @@ public:
     unsigned int getVertexCount() const { return vertex_count; }
 
     std::vector<read_id_t> vertex_to_read;
-    std::vector<std::vector<Edge>> adj_out;
-    std::vector<std::vector<node_id_t>> adj_in;
+    std::vector<ArenaList<Edge>> adj_out;
+    std::vector<ArenaList<node_id_t>> adj_in;
     std::vector<uint8_t> inclusions;                      // boost::dynamic_bitset in the reference
 
 private:
-    EdgeSlotIndex slots;  // kept in step with adj_out by addEdge / removeEdgeWithOri
+    void ensure_slots() const;  // after adopt_csr the index is built lazily
+    mutable EdgeSlotIndex slots;  // kept in step with adj_out by addEdge / removeEdgeWithOri
+    mutable bool slots_valid = true;
+    Edge* out_arena = nullptr;        // storage of the lists adopt_csr made (lists that have grown since own theirs)
+    node_id_t* in_arena = nullptr;
     unsigned int vertex_count = 0;
     unsigned int edge_count = 0;
     std::shared_ptr<FastqStorage> fastq_storage;

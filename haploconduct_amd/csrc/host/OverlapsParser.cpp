@@ -96,7 +96,7 @@ struct OverlapsParser::Segment {
     uint64_t first_line = 0;        // index of its first line in the file
     uint64_t line_limit = 0;        // lines with index >= line_limit are not read (max_overlaps, :581)
     Overlap* out_line = nullptr;        // where this segment's passing candidates go (room for one per line + 1)
-    hc_overlap_rec* out_rec = nullptr;
+    hc_cand_rec* out_rec = nullptr;
     size_t n_pass = 0;
     std::vector<Overlap> rejected;
     std::vector<uint32_t> reject_before;  // rejected[k] precedes pass[reject_before[k]] in file order (unused: order is kept per kind)
@@ -153,18 +153,10 @@ void OverlapsParser::parse_segment(Segment& seg) const {
             if (!pass) continue;
             // id -> index: std::map::at in compute_overlap, :170-171 (throws => the reference aborts)
             seg.out_line[seg.n_pass] = o;
-            hc_overlap_rec& r = seg.out_rec[seg.n_pass];
-            if (!m_ids.find(o.m_id1, r.read1) || !m_ids.find(o.m_id2, r.read2))
+            uint32_t r1, r2;
+            if (!m_ids.find(o.m_id1, r1) || !m_ids.find(o.m_id2, r2))
                 throw FatalError{HC_ERR_BAD_OVERLAP, "overlap refers to a read id that is not in the FASTQ input"};
-            r.pos1 = o.m_pos1;
-            r.pos2 = o.m_pos2;
-            r.ori1 = o.m_ori1 == '+';
-            r.ori2 = o.m_ori2 == '+';
-            r.ord = (uint8_t)o.m_ord;
-            r.flags = (uint8_t)((o.m_type1 == 'p') | ((o.m_type2 == 'p') << 1));
-            r.len1 = o.m_len1;
-            r.len2 = o.m_len2;
-            r.perc = perc;
+            seg.out_rec[seg.n_pass] = make_cand(o, r1, r2);
             seg.n_pass++;
         }
     } catch (const FatalError& e) {
@@ -289,12 +281,12 @@ bool OverlapsParser::next_batch(ParsedBatch& batch, size_t max_batch, std::vecto
                     sc.recs.resize(segs[t].n_pass + segs[t].n_pass / 8);
                 }
                 memcpy((void*)sc.lines.data(), (const void*)segs[t].out_line, segs[t].n_pass * sizeof(Overlap));
-                memcpy((void*)sc.recs.data(), (const void*)segs[t].out_rec, segs[t].n_pass * sizeof(hc_overlap_rec));
+                memcpy((void*)sc.recs.data(), (const void*)segs[t].out_rec, segs[t].n_pass * sizeof(hc_cand_rec));
             });
             run([&](unsigned int t) {
                 if (!moves(t)) return;
                 memcpy((void*)(batch.lines.data() + at[t]), (const void*)m_scratch[t].lines.data(), segs[t].n_pass * sizeof(Overlap));
-                memcpy((void*)(batch.recs + at[t]), (const void*)m_scratch[t].recs.data(), segs[t].n_pass * sizeof(hc_overlap_rec));
+                memcpy((void*)(batch.recs + at[t]), (const void*)m_scratch[t].recs.data(), segs[t].n_pass * sizeof(hc_cand_rec));
             });
         }
         batch.n = at[T];

@@ -15,14 +15,15 @@
 namespace hc {
 
 // One block of candidates, structure of arrays: lines[i] is what get_overlap_line() re-serialises, recs[i] what
-// the device scores (read ids resolved to m_read_vec indices).  The storage only grows (a block reuses the
+// the device scores — the compact record (hc_cand_rec, 16 bytes: read ids resolved to m_read_vec indices, positions,
+// orientations, ord); everything else of the line stays in lines[i] on the host.  The storage only grows (a block reuses the
 // elements of the one before it), and the record array can live in memory the caller provides — page-locked
 // memory in the stage, so that the parser's output is what the device reads, without a copy in between.
 struct ParsedBatch {
     struct RecStorage {  // optional provider of the record array
         void* ctx = nullptr;
-        hc_overlap_rec* (*alloc)(void* ctx, size_t n) = nullptr;
-        void (*release)(void* ctx, hc_overlap_rec* p) = nullptr;
+        hc_cand_rec* (*alloc)(void* ctx, size_t n) = nullptr;
+        void (*release)(void* ctx, hc_cand_rec* p) = nullptr;
     };
     ParsedBatch() = default;
     explicit ParsedBatch(const RecStorage& st) : storage(st) {}
@@ -49,14 +50,43 @@ struct ParsedBatch {
     void clear() { n = 0; }
 
     std::vector<Overlap> lines;
-    hc_overlap_rec* recs = nullptr;
+    hc_cand_rec* recs = nullptr;
     size_t n = 0;  // the first n lines / recs are this block
 
 private:
     RecStorage storage;
-    std::vector<hc_overlap_rec> own;
+    std::vector<hc_cand_rec> own;
     size_t cap = 0;
 };
+
+// the compact record of a line (read ids already resolved)
+inline hc_cand_rec make_cand(const Overlap& o, uint32_t read1, uint32_t read2) {
+    hc_cand_rec r;
+    r.read1 = read1;
+    r.read2 = read2;
+    const uint32_t p1 = o.m_pos1 < HC_CAND_POS_MASK ? o.m_pos1 : HC_CAND_POS_MASK;
+    const uint32_t p2 = o.m_pos2 < HC_CAND_POS_MASK ? o.m_pos2 : HC_CAND_POS_MASK;
+    const uint32_t oc = o.m_ord == '-' ? 0u : (o.m_ord == '1' ? 1u : 2u);  // from_fields admits nothing else
+    r.pos1_bits = p1 | (o.m_ori1 == '+' ? 1u << 28 : 0u) | (o.m_ori2 == '+' ? 1u << 29 : 0u) | (oc << 30);
+    r.pos2_bits = p2;
+    return r;
+}
+// the full record (include/hcedge.h) of a line, as the 32-byte ABI describes it
+inline hc_overlap_rec make_overlap_rec(const Overlap& o, uint32_t read1, uint32_t read2) {
+    hc_overlap_rec r;
+    r.read1 = read1;
+    r.read2 = read2;
+    r.pos1 = o.m_pos1;
+    r.pos2 = o.m_pos2;
+    r.ori1 = o.m_ori1 == '+';
+    r.ori2 = o.m_ori2 == '+';
+    r.ord = (uint8_t)o.m_ord;
+    r.flags = (uint8_t)((o.m_type1 == 'p') | ((o.m_type2 == 'p') << 1));
+    r.len1 = o.m_len1;
+    r.len2 = o.m_len2;
+    r.perc = o.get_perc();
+    return r;
+}
 
 struct ParseCounters {
     uint64_t lines_read = 0, malformed = 0, self_overlaps = 0, prefilter_rejected = 0, silently_dropped = 0;
@@ -114,7 +144,7 @@ private:
     std::unique_ptr<Pool> m_pool;
     struct Scratch {  // where one segment parses to before its place in the block is known; kept between blocks
         std::vector<Overlap> lines;
-        std::vector<hc_overlap_rec> recs;
+        std::vector<hc_cand_rec> recs;
     };
     std::vector<Scratch> m_scratch;
 

@@ -56,6 +56,7 @@ struct ProgramSettings {
     unsigned int branch_PE_c = 0;
     bool careful = true;
     int device = 0;  // build-owned addition: HIP device ordinal
+    unsigned int device_mask = 0;  // build-owned addition: bit d = the stage scores blocks on device d too (0 = `device` alone)
 };
 
 // src/Types.h:99-102: strtoul with base auto-detection ("0x..", leading 0 = octal, junk = 0)

@@ -33,6 +33,7 @@ inline ProgramSettings make_ps(const hc_settings* s, const hc_ec_paths* p) {
     ps.max_overlaps = s->max_overlaps;
     ps.n_threads = s->n_threads ? s->n_threads : 1;
     ps.device = s->device;
+    ps.device_mask = s->device_mask;
     if (p) {
         auto str = [](const char* c) { return std::string(c ? c : ""); };
         ps.singles_file = str(p->singles_file);

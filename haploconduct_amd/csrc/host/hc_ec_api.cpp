@@ -42,6 +42,13 @@ int hc_ec_construct_edges(hc_ec* ec) {
     return guarded("construct_edges", [&] { ec->calc->construct_edges(); });
 }
 
+int hc_ec_construct_edges_sorted(hc_ec* ec) {
+    if (!ec) return set_last_error(HC_ERR_ARG, "hc_ec_construct_edges_sorted: null");
+    return guarded("construct_edges", [&] { ec->calc->construct_edges_sorted(); });
+}
+
+uint32_t hc_ec_device_count(hc_ec* ec) { return ec ? ec->calc->device_count() : 0; }
+
 int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* c) {
     if (!ec || !c) return set_last_error(HC_ERR_ARG, "hc_ec_get_counters: null");
     memset(c, 0, sizeof *c);

@@ -309,7 +309,7 @@ int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* ove
             const bool more = parser.next_batch(batch, 1000000, rejected, pc, false);
             if (!more) break;
             for (size_t i = 0; i < batch.size(); i++) {
-                if (out && n < cap) out[n] = batch.recs[i];
+                if (out && n < cap) out[n] = make_overlap_rec(batch.lines[i], batch.recs[i].read1, batch.recs[i].read2);
                 n++;
             }
         }

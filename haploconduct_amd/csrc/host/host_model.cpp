@@ -459,7 +459,27 @@ std::string Overlap::get_overlap_line() const {
 }
 
 // ------------------------------------------------------------------ OverlapGraph
+OverlapGraph::~OverlapGraph() {
+    adj_out.clear();  // the lists first: the borrowed ones point into the arenas
+    adj_in.clear();
+    free(out_arena);
+    free(in_arena);
+}
+
+void OverlapGraph::ensure_slots() const {
+    if (slots_valid) return;
+    slots_valid = true;
+    std::vector<uint64_t> keys;
+    keys.reserve(edge_count);
+    for (const auto& L : adj_out)
+        for (const Edge& e : L)
+            if (EdgeSlotIndex::representable(e.get_vertex(1), e.get_vertex(2)))
+                keys.push_back(EdgeSlotIndex::key(e.get_vertex(1), e.get_vertex(2), e.get_ori(1) == e.get_ori(2)));
+    slots.bulk_add(keys.data(), keys.size(), std::max(1u, std::min(program_settings.n_threads, 16u)));
+}
+
 void OverlapGraph::addEdge(const Edge& edge) {  // src/OverlapGraph.cpp:94-101
+    ensure_slots();
     const node_id_t v = edge.get_vertex(1), w = edge.get_vertex(2);
     if (adj_out[v].capacity() == 0) adj_out[v].reserve(4);  // skips the 1 -> 2 -> 4 reallocations of nearly every vertex
     if (adj_in[w].capacity() == 0) adj_in[w].reserve(8);
@@ -474,6 +494,7 @@ static inline bool same_ori_class(const Edge& e, bool opposite_orientations) {
 }
 
 Edge OverlapGraph::removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) {  // :150-194
+    ensure_slots();
     auto& L = adj_out.at(v);
     Edge removed;
     bool found = false;
@@ -499,6 +520,7 @@ Edge OverlapGraph::removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_ori
 }
 
 double OverlapGraph::checkEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) const {  // :198-229
+    ensure_slots();
     if (EdgeSlotIndex::representable(v, w) && !slots.contains(EdgeSlotIndex::key(v, w, opposite_orientations))) return -1;
     for (const Edge& e : adj_out.at(v))
         if (e.get_vertex(2) == w && same_ori_class(e, opposite_orientations)) return e.get_score();
@@ -532,6 +554,7 @@ hc_settings to_hc_settings(const ProgramSettings& ps) {
               (ps.allow_spaces ? HC_FLAG_ALLOW_SPACES : 0u) | (ps.verbose ? HC_FLAG_VERBOSE : 0u);
     s.max_overlaps = ps.max_overlaps;
     s.device = ps.device;
+    s.device_mask = ps.device_mask;
     s.n_threads = ps.n_threads;
     return s;
 }
@@ -616,6 +639,7 @@ static void run_workers(unsigned T, F&& body) {
 void OverlapGraph::bulk_add_edges(const Edge* pool, const std::vector<uint32_t>& order, unsigned n_threads) {
     const size_t m = order.size();
     if (m == 0) return;
+    ensure_slots();
     const size_t V = adj_out.size();
     bool indexable = true;
     std::vector<node_id_t> c1(m), c2(m);
@@ -681,39 +705,93 @@ void OverlapGraph::bulk_add_edges(const Edge* pool, const std::vector<uint32_t>&
     edge_count += (unsigned int)m;
 }
 
-void OverlapGraph::sortEdges(const uint32_t* len_by_read, unsigned n_threads) {  // src/OverlapGraph.cpp:722-764
+void OverlapGraph::adopt_csr(const hc_edge_rec* edges, const uint64_t* out_off, const uint32_t* in_nodes, const uint64_t* in_off,
+                             const uint8_t* inclusion_bits, Read* const* reads, size_t n_reads, unsigned n_threads) {
+    if (edge_count != 0 || out_arena || in_arena) throw FatalError{HC_ERR_STATE, "adopt_csr: the graph already holds edges"};
     const size_t V = adj_out.size();
-    const unsigned T = edge_count < (1u << 14) ? 1u : std::max(1u, std::min(n_threads, 32u));
+    const size_t E = (size_t)out_off[V];
+    if ((size_t)in_off[V] != E || E > 0xFFFFFFFFull) throw FatalError{HC_ERR_STATE, "adopt_csr: inconsistent offsets"};
+    if (E == 0) return;
+    static_assert(std::is_trivially_copyable<Edge>::value, "Edge lives in malloc'd arenas");
+    const size_t huge = (size_t)2 << 20;
+    const size_t bytes = (E * sizeof(Edge) + huge - 1) & ~(huge - 1);
+    if (posix_memalign((void**)&out_arena, huge, bytes) != 0) {
+        out_arena = nullptr;
+        throw FatalError{HC_ERR_NOMEM, "adopt_csr: out of memory"};
+    }
+    madvise((void*)out_arena, bytes, MADV_HUGEPAGE);  // a hint: 2 MiB pages where the system grants them (fewer first-touch faults)
+    in_arena = (node_id_t*)malloc(E * sizeof(node_id_t));
+    if (!in_arena) throw FatalError{HC_ERR_NOMEM, "adopt_csr: out of memory"};
+    const unsigned T = E < (1u << 14) ? 1u : std::max(1u, std::min(n_threads, 32u));
+    std::vector<uint8_t> bad(T, 0);
+    run_workers(T, [&](unsigned t) {
+        uint8_t my_bad = 0;
+        try {  // Edge's own checks throw: nothing may leave a worker thread
+        for (size_t v = V * t / T; v < V * (t + 1) / T; v++) {
+            const size_t a = (size_t)out_off[v], b = (size_t)out_off[v + 1];
+            if (b < a || b > E) { my_bad = 1; break; }
+            for (size_t k = a; k < b; k++) {
+                const hc_edge_rec& r = edges[k];
+                if (r.read1 >= n_reads || r.read2 >= n_reads || r.v1 != v || r.v2 >= V) { my_bad = 1; break; }
+                Edge* e = new ((void*)(out_arena + k)) Edge(r.score, r.pos1, r.pos2, r.ori1 != 0, r.ori2 != 0, (char)r.ord, reads[r.read1], reads[r.read2]);
+                e->set_vertices(r.v1, r.v2);
+                e->set_extra_pos(r.pos3, r.pos4);
+                e->set_perc(r.perc);
+                e->set_len(r.len1, r.len2);
+                e->set_mismatch(r.mismatch_rate);
+            }
+            if (my_bad) break;
+            adj_out[v].borrow(out_arena + a, b - a, b - a);
+            const size_t ia = (size_t)in_off[v], ib = (size_t)in_off[v + 1];
+            if (ib < ia || ib > E) { my_bad = 1; break; }
+            for (size_t k = ia; k < ib; k++) in_arena[k] = in_nodes[k];
+            adj_in[v].borrow(in_arena + ia, ib - ia, ib - ia);
+            if (inclusion_bits && inclusion_bits[v]) inclusions[v] = 1;
+        }
+        } catch (...) {
+            my_bad = 1;
+        }
+        bad[t] = my_bad;
+    });
+    for (uint8_t b : bad)
+        if (b) throw FatalError{HC_ERR_STATE, "adopt_csr: malformed adjacency"};
+    edge_count = (unsigned int)E;
+    slots_valid = false;
+}
+
+void OverlapGraph::sort_out_list(node_id_t v, const uint32_t* len_by_read) {  // src/OverlapGraph.cpp:724-749
+    ArenaList<Edge>& L = adj_out[v];
+    if (L.size() < 2) return;
     struct Key {
         unsigned int nonoverlap;  // src/Edge.h:58-63, unsigned arithmetic
         node_id_t v2;
         uint32_t at;
     };
-    run_workers(T, [&](unsigned t) {
-        std::vector<Key> keys;
-        std::vector<Edge> sorted;
-        for (size_t v = V * t / T; v < V * (t + 1) / T; v++) {
-            std::vector<Edge>& L = adj_out[v];
-            if (L.size() < 2) continue;
-            keys.clear();
-            for (size_t k = 0; k < L.size(); k++) {
-                const Edge& e = L[k];
-                keys.push_back(Key{(unsigned int)len_by_read[e.get_read(1)->get_index()] + (unsigned int)len_by_read[e.get_read(2)->get_index()] -
-                                       2u * (unsigned int)e.get_len(0),
-                                   e.get_vertex(2), (uint32_t)k});
-            }
-            // the comparator of :733-742 on the same sequence: std::sort's result depends on the comparisons only
-            std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
-                if (a.nonoverlap == b.nonoverlap) return a.v2 < b.v2;
-                return a.nonoverlap < b.nonoverlap;
-            });
-            sorted.clear();
-            for (const Key& k : keys) sorted.push_back(L[k.at]);
-            std::copy(sorted.begin(), sorted.end(), L.begin());
-        }
+    std::vector<Key> keys;
+    keys.reserve(L.size());
+    for (size_t k = 0; k < L.size(); k++) {
+        const Edge& e = L[k];
+        keys.push_back(Key{(unsigned int)len_by_read[e.get_read(1)->get_index()] + (unsigned int)len_by_read[e.get_read(2)->get_index()] -
+                               2u * (unsigned int)e.get_len(0),
+                           e.get_vertex(2), (uint32_t)k});
+    }
+    // the comparator of :733-742 on the same sequence: std::sort's result depends on the comparisons only
+    std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+        if (a.nonoverlap == b.nonoverlap) return a.v2 < b.v2;
+        return a.nonoverlap < b.nonoverlap;
     });
-    // adj_in, :751-762: for every vertex in order, for every edge of its sorted list, vertex1 appended to the in-list
-    // of vertex2 — by ranges of vertex2, every worker walking the out-lists in that same order
+    std::vector<Edge> sorted;
+    sorted.reserve(L.size());
+    for (const Key& k : keys) sorted.push_back(L[k.at]);
+    std::copy(sorted.begin(), sorted.end(), L.begin());
+}
+
+// adj_in, :751-762: for every vertex in order, for every edge of its out-list, vertex1 appended to the in-list of
+// vertex2 — by ranges of vertex2, every worker walking the out-lists in that same order.  In-degrees do not change, so
+// lists that point into the graph's arena are refilled in place.
+void OverlapGraph::rebuild_in_lists(unsigned n_threads) {
+    const size_t V = adj_out.size();
+    const unsigned T = edge_count < (1u << 14) ? 1u : std::max(1u, std::min(n_threads, 32u));
     run_workers(T, [&](unsigned t) {
         const size_t lo = V * t / T, hi = V * (t + 1) / T;
         for (size_t v = lo; v < hi; v++) adj_in[v].clear();
@@ -723,6 +801,15 @@ void OverlapGraph::sortEdges(const uint32_t* len_by_read, unsigned n_threads) { 
                 if (w >= lo && w < hi) adj_in[w].push_back(e.get_vertex(1));
             }
     });
+}
+
+void OverlapGraph::sortEdges(const uint32_t* len_by_read, unsigned n_threads) {  // src/OverlapGraph.cpp:722-764
+    const size_t V = adj_out.size();
+    const unsigned T = edge_count < (1u << 14) ? 1u : std::max(1u, std::min(n_threads, 32u));
+    run_workers(T, [&](unsigned t) {
+        for (size_t v = V * t / T; v < V * (t + 1) / T; v++) sort_out_list(v, len_by_read);
+    });
+    rebuild_in_lists(n_threads);
 }
 
 void EdgeSlotIndex::bulk_add(const uint64_t* keys, size_t n, unsigned n_threads) {

@@ -47,6 +47,8 @@ class hc_fastq_view(C.Structure):
 _sig = {
     "hc_ec_open": (C.c_int, [C.POINTER(_vp), C.POINTER(N.hc_settings), C.POINTER(hc_ec_paths)]),
     "hc_ec_construct_edges": (C.c_int, [_vp]),
+    "hc_ec_construct_edges_sorted": (C.c_int, [_vp]),
+    "hc_ec_device_count": (C.c_uint32, [_vp]),
     "hc_ec_get_counters": (C.c_int, [_vp, C.POINTER(hc_ec_counters)]),
     "hc_ec_read_count": (C.c_uint64, [_vp]),
     "hc_ec_edge_count": (C.c_uint64, [_vp]),
@@ -250,6 +252,13 @@ class EdgeCalculatorStage:
 
     def construct_edges(self):
         N.check(N.lib.hc_ec_construct_edges(self._h), "hc_ec_construct_edges")
+
+    def construct_edges_sorted(self):
+        """construct_edges() + sortEdges() as one call (the lists arrive from the device in sortEdges order)."""
+        N.check(N.lib.hc_ec_construct_edges_sorted(self._h), "hc_ec_construct_edges_sorted")
+
+    def device_count(self):
+        return int(N.lib.hc_ec_device_count(self._h))
 
     def counters(self):
         c = hc_ec_counters()

@@ -155,9 +155,9 @@ class StreamedGather(PayloadGather):
     side stream; call before_write(results) before overwriting a results tensor that a step may still be reading.
     """
 
-    def __init__(self, scorer, n_local, base_index, cap_rows, group=None, depth=2):
+    def __init__(self, scorer, n_local, base_index, cap_rows, group=None, depth=2, rec_fmt=0):
         super().__init__(cap_rows, group, depth, torch.device("cuda", torch.cuda.current_device()))
-        self.sc, self.n, self.base = scorer, int(n_local), int(base_index)
+        self.sc, self.n, self.base, self.fmt = scorer, int(n_local), int(base_index), int(rec_fmt)  # rec_fmt: records.REC_FULL / REC_COMPACT
         # zero-initialised: entries beyond the count of a batch are stale but always valid indices
         self.idx = torch.zeros(max(self.n, 1), dtype=torch.int32, device=self.device)
         self.count = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -167,7 +167,7 @@ class StreamedGather(PayloadGather):
         """Score this rank's n candidate records (device pointer) into d_results and collect the batch."""
         b = self.next_buffers()
         b["unordered"] = self.sc.score_pack_device(d_in_ptr, self.n, d_results.data_ptr(), self.cap, self.base, b["payload"].data_ptr(),
-                                                   torch.cuda.current_stream().cuda_stream)
+                                                   torch.cuda.current_stream().cuda_stream, self.fmt)
         return self.submit(b)
 
     def before_write(self, d_results):

@@ -16,6 +16,21 @@ OVERLAP_DTYPE = np.dtype(
 )
 assert OVERLAP_DTYPE.itemsize == 32
 
+# hc_cand_rec, 16 bytes: what the device reads of a candidate (the form that crosses PCIe in the stage)
+CAND_DTYPE = np.dtype([("read1", "<u4"), ("read2", "<u4"), ("pos1_bits", "<u4"), ("pos2_bits", "<u4")], align=False)
+assert CAND_DTYPE.itemsize == 16
+REC_FULL, REC_COMPACT = 0, 1
+
+# hc_gather_row, 32 bytes: a non-dropped result record tagged with its candidate index
+ROW_DTYPE = np.dtype([("index", "<u8"), ("x1", "<f8"), ("x2", "<f8"), ("mm", "<u4"), ("n_cls", "<u4")], align=False)
+assert ROW_DTYPE.itemsize == 32
+
+# hc_admit_rec, 48 bytes: an admitted candidate handed to the device's duplicate resolution
+ADMIT_DTYPE = np.dtype([("score", "<f8"), ("read1", "<u4"), ("read2", "<u4"), ("pos1", "<u4"), ("pos2", "<u4"), ("mm", "<u4"), ("n", "<u4"),
+                        ("len1", "<u4"), ("len2", "<u4"), ("perc", "<u4"), ("ori1", "u1"), ("ori2", "u1"), ("ord", "u1"), ("pad", "u1")],
+                       align=False)
+assert ADMIT_DTYPE.itemsize == 48
+
 # hc_result_rec, 24 bytes
 RESULT_DTYPE = np.dtype([("x1", "<f8"), ("x2", "<f8"), ("mm", "<u4"), ("n_cls", "<u4")], align=False)
 assert RESULT_DTYPE.itemsize == 24
@@ -47,11 +62,13 @@ class Settings:
     max_overlaps: int = 100000000
     device: int = 0
     n_threads: int = 1
+    device_mask: int = 0
 
     def to_c(self):
         return hc_settings(
             self.edge_threshold, self.ov_threshold, self.merge_contigs, self.mismatch, self.min_read_len,
             self.min_overlap_len, self.min_overlap_perc, self.flags, self.max_overlaps, self.device, self.n_threads,
+            self.device_mask, 0,
         )
 
 

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from .records import OVERLAP_DTYPE, RESULT_DTYPE, Settings
+from .records import ADMIT_DTYPE, CAND_DTYPE, OVERLAP_DTYPE, REC_COMPACT, REC_FULL, RESULT_DTYPE, ROW_DTYPE, Settings
 
 
 def _ptr(a):
@@ -68,6 +68,82 @@ class EdgeScorer:
         N.check(N.lib.hc_score_batch(self._ctx, _ptr(ov), ov.shape[0], _ptr(out)), "hc_score_batch")
         return out
 
+    @staticmethod
+    def pack_cands(overlaps):
+        """hc_pack_cands: hc_overlap_rec -> hc_cand_rec (16 bytes: what the device reads)."""
+        ov = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE)
+        out = np.empty(ov.shape[0], dtype=CAND_DTYPE)
+        N.lib.hc_pack_cands(_ptr(ov), ov.shape[0], _ptr(out))
+        return out
+
+    def score_cands(self, cands):
+        """Compact records in, result records out (hc_score_cands; host buffers)."""
+        cd = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        out = np.empty(cd.shape[0], dtype=RESULT_DTYPE)
+        N.check(N.lib.hc_score_cands(self._ctx, _ptr(cd), cd.shape[0], _ptr(out)), "hc_score_cands")
+        return out
+
+    def score_cands_device(self, d_in_ptr, n, d_out_ptr, stream=None):
+        N.check(N.lib.hc_score_cands_device(self._ctx, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), C.c_void_p(stream or 0)),
+                "hc_score_cands_device")
+
+    def score_blocks(self, cands, block=250000, in_flight=2):
+        """The stage's device leg on a whole candidate array: hc_block_submit / hc_block_wait over blocks of `block`
+        compact records, `in_flight` block objects; returns the non-dropped rows of all blocks in index order."""
+        cd = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        n = cd.shape[0]
+        blocks = []
+        for _ in range(in_flight):
+            b = C.c_void_p()
+            N.check(N.lib.hc_block_create(self._ctx, max(1, min(block, max(n, 1))), C.byref(b)), "hc_block_create")
+            blocks.append(b)
+        out, pending = [], []
+
+        def wait(b):
+            rows, k = C.c_void_p(), C.c_uint64()
+            N.check(N.lib.hc_block_wait(b, C.byref(rows), C.byref(k)), "hc_block_wait")
+            if k.value:
+                out.append(np.frombuffer((C.c_char * (k.value * 32)).from_address(rows.value), dtype=ROW_DTYPE).copy())
+
+        try:
+            for i, at in enumerate(range(0, n, block)):
+                b = blocks[i % in_flight]
+                if len(pending) == in_flight:
+                    wait(pending.pop(0))
+                m = min(block, n - at)
+                N.check(N.lib.hc_block_submit(b, C.c_void_p(cd.ctypes.data + at * 16), m, at), "hc_block_submit")
+                pending.append(b)
+            while pending:
+                wait(pending.pop(0))
+        finally:
+            for b in blocks:
+                N.lib.hc_block_destroy(b)
+        return np.concatenate(out) if out else np.zeros(0, ROW_DTYPE)
+
+    def graph_resolve(self, admitted, n_vertices, vertex_of_read=None, sorted_order=False):
+        """hc_graph_resolve + hc_graph_fetch: duplicate resolution and adjacency lists on the device.  Returns a dict
+        with counts, edges (EDGE_DTYPE), out_off, in_nodes, in_off, seq, inclusions, tied_vertices."""
+        from .host import EDGE_DTYPE
+
+        adm = np.ascontiguousarray(admitted, dtype=ADMIT_DTYPE)
+        gc = N.hc_graph_counts()
+        vtx = None if vertex_of_read is None else np.ascontiguousarray(vertex_of_read, dtype=np.uint32)
+        N.check(N.lib.hc_graph_resolve(self._ctx, _ptr(adm), adm.shape[0], n_vertices, None if vtx is None else _ptr(vtx),
+                                       1 if sorted_order else 0, C.byref(gc)), "hc_graph_resolve")
+        res = {"counts": {k: getattr(gc, k) for k, _ in gc._fields_}}
+        if gc.first_bad >= 0:
+            return res
+        E = int(gc.n_edges)
+        edges = np.zeros(E, EDGE_DTYPE)
+        out_off, in_off = np.zeros(n_vertices + 1, np.uint64), np.zeros(n_vertices + 1, np.uint64)
+        in_nodes, seq = np.zeros(E, np.uint32), np.zeros(E, np.uint32)
+        incl = np.zeros(n_vertices, np.uint8)
+        tied = np.zeros(int(gc.n_tied_lists), np.uint32)
+        N.check(N.lib.hc_graph_fetch(self._ctx, _ptr(edges), _ptr(out_off), _ptr(in_nodes), _ptr(in_off), _ptr(seq), _ptr(incl),
+                                     _ptr(tied) if tied.size else None), "hc_graph_fetch")
+        res.update(edges=edges, out_off=out_off, in_nodes=in_nodes, in_off=in_off, seq=seq, inclusions=incl, tied_vertices=tied)
+        return res
+
     def score_batch_compact(self, overlaps):
         """hc_score_batch_compact: (indices, records) of the non-DROP candidates only."""
         ov = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE)
@@ -98,12 +174,11 @@ class EdgeScorer:
             N.check(N.lib.hc_find_overlaps(self._ctx, err_rate, min_overlap, flags, out.ctypes.data, out.size, C.byref(n)), "hc_find_overlaps")
         return out[: n.value]
 
-    def score_pack_device(self, d_in_ptr, n, d_out_ptr, cap, base_index, d_payload_ptr, stream=None):
-        """hc_score_pack_device: scoring + the collection payload in one kernel.  Returns True when fused (rows unordered)."""
-        fused = C.c_int()
-        N.check(N.lib.hc_score_pack_device(self._ctx, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), cap, base_index,
-                                           C.c_void_p(d_payload_ptr), C.c_void_p(stream or 0), C.byref(fused)), "hc_score_pack_device")
-        return bool(fused.value)
+    def score_pack_device(self, d_in_ptr, n, d_out_ptr, cap, base_index, d_payload_ptr, stream=None, fmt=REC_FULL):
+        """hc_score_pack_device: scoring + the collection payload in one kernel (rows unordered, count in row 0)."""
+        N.check(N.lib.hc_score_pack_device(self._ctx, fmt, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), cap, base_index,
+                                           C.c_void_p(d_payload_ptr), C.c_void_p(stream or 0)), "hc_score_pack_device")
+        return True
 
     def compact_pack_device(self, d_results_ptr, n, d_indices_ptr, d_count_ptr, cap, base_index, d_payload_ptr, stream=None):
         """hc_compact_pack_device: compaction + pack, the count in row 0 of the (cap + 1)-row payload."""
@@ -123,15 +198,15 @@ class EdgeScorer:
     def synchronize(self):
         N.check(N.lib.hc_synchronize(self._ctx), "hc_synchronize")
 
-    def time_kernel(self, d_in_ptr, n, d_out_ptr, iters):
+    def time_kernel(self, d_in_ptr, n, d_out_ptr, iters, fmt=REC_FULL):
         ms = C.c_float()
-        N.check(N.lib.hc_time_score_kernel(self._ctx, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), iters,
+        N.check(N.lib.hc_time_score_kernel(self._ctx, fmt, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), iters,
                                            C.byref(ms)), "hc_time_score_kernel")
         return float(ms.value)
 
-    def count_positions_device(self, d_in_ptr, n):
+    def count_positions_device(self, d_in_ptr, n, fmt=REC_FULL):
         a, b = C.c_uint64(), C.c_uint64()
-        N.check(N.lib.hc_count_positions_device(self._ctx, C.c_void_p(d_in_ptr), n, C.byref(a), C.byref(b)),
+        N.check(N.lib.hc_count_positions_device(self._ctx, fmt, C.c_void_p(d_in_ptr), n, C.byref(a), C.byref(b)),
                 "hc_count_positions_device")
         return int(a.value), int(b.value)
 

@@ -27,7 +27,11 @@
  * Conventions: plain pointers and sizes only; every function returns HC_OK (0)
  * or a negative hc_status and never calls exit()/abort(); the caller owns all
  * host buffers; one context is used from one thread at a time (the reference
- * has exactly one batch in flight, EdgeCalculator.cpp:636-644).
+ * has exactly one batch in flight, EdgeCalculator.cpp:636-644), and its asynchronous
+ * entry points (the *_device calls) share grow-only scratch owned by the context:
+ * at most ONE stream may have work of a context in flight — pass the same stream to
+ * consecutive calls, or synchronise before switching streams.  hc_block objects
+ * (below) own their buffers and stream and may be in flight side by side.
  */
 #ifndef HCEDGE_H_
 #define HCEDGE_H_
@@ -72,8 +76,11 @@ typedef struct hc_settings {
     uint32_t min_overlap_perc; /* --min_overlap_perc (default 0)   [host prefilter]      */
     uint32_t flags;            /* HC_FLAG_*                                              */
     uint64_t max_overlaps;     /* --max_ov          (default 1e8)  [host parser]         */
-    int32_t device;            /* HIP device ordinal                                     */
+    int32_t device;            /* HIP device ordinal (hc_create; the stage's primary)    */
     uint32_t n_threads;        /* --threads: host-side worker threads (parser)           */
+    uint32_t device_mask;      /* stage only (hc_ec_*): bit d = score blocks on device d too;
+                                  0 = `device` alone.  hc_create always uses `device`.   */
+    uint32_t reserved;         /* 0                                                      */
 } hc_settings;
 
 /* ---- one candidate overlap, as it enters process_overlaps (Overlap.h:20-73) ----
@@ -91,6 +98,21 @@ typedef struct hc_overlap_rec {
     uint32_t len1, len2;
     uint32_t perc;      /* Overlap::get_perc() (Overlap.h:203-210)                        */
 } hc_overlap_rec;       /* 32 bytes */
+
+/* ---- the same candidate, only what the DEVICE reads of it (compute_overlap takes ids, positions, orientations
+ * and ord from the record and everything else from the reads, EdgeCalculator.cpp:143-385): the form that crosses
+ * PCIe in the stage — 16 bytes instead of 32; LEN1/LEN2/PERC stay on the host, where the admitted edges are built.
+ *   pos1_bits: bits 0..27 POS1, bit 28 ORI1 == '+', bit 29 ORI2 == '+', bits 30..31 ORD: 0 = '-', 1 = '1', 2 = '2'
+ *   pos2_bits: bits 0..27 POS2, bits 28..31 zero
+ * Positions saturate at 2^28-1: every stored sequence is shorter than that (hc_set_reads), so `pos >= length`
+ * (EdgeCalculator.cpp:76-79) holds for the saturated value exactly when it holds for the original. */
+#define HC_CAND_POS_MASK 0x0FFFFFFFu
+typedef struct hc_cand_rec {
+    uint32_t read1, read2;
+    uint32_t pos1_bits, pos2_bits;
+} hc_cand_rec;          /* 16 bytes */
+#define HC_REC_FULL 0u    /* hc_overlap_rec */
+#define HC_REC_COMPACT 1u /* hc_cand_rec    */
 
 /* ---- per-candidate result of the device pass --------------------------------
  * x_k = (1.0/total_len) * total_score of sub-overlap k, i.e. the argument of the
@@ -172,6 +194,27 @@ int hc_host_free(hc_ctx* ctx, void* ptr);
 int hc_score_batch_device(hc_ctx* ctx, const void* d_in, uint64_t n, void* d_out, void* hip_stream);
 int hc_synchronize(hc_ctx* ctx);
 
+/* The same two entry points for compact records (hc_cand_rec, 16 bytes): what the stage sends over PCIe. */
+void hc_pack_cands(const hc_overlap_rec* in, uint64_t n, hc_cand_rec* out); /* host, pure: record -> compact record */
+int hc_score_cands(hc_ctx* ctx, const hc_cand_rec* in, uint64_t n, hc_result_rec* out);
+int hc_score_cands_device(hc_ctx* ctx, const void* d_cands, uint64_t n, void* d_out, void* hip_stream);
+
+/* ---- one block of the stage in flight (EdgeCalculator.cpp:636-644: "flush every 1e6 overlaps") -------------------
+ * construct_edges() hands the scoring loop one block of candidates at a time.  An hc_block owns what one block needs
+ * on the device — candidate and result buffers, a stream, an event — plus a page-locked host buffer mapped into the
+ * device's address space, into which the scoring kernel itself writes every record that is NOT dropped (a few per
+ * cent of the block), tagged with its candidate index: nothing is compacted or copied back afterwards.
+ *   hc_block_submit : asynchronous — H2D of the compact records, the scoring kernel, the row count
+ *   hc_block_wait   : blocks until the block has been scored; *rows = the non-dropped records sorted by index
+ *                     (index = base_index + position in the block), valid until the next submit on this block.
+ * Several blocks of one context (or of several contexts on several devices) may be in flight at once. */
+typedef struct hc_gather_row hc_gather_row;
+typedef struct hc_block hc_block;
+int hc_block_create(hc_ctx* ctx, uint64_t max_candidates, hc_block** out);
+int hc_block_submit(hc_block* b, const hc_cand_rec* cands, uint64_t n, uint64_t base_index);
+int hc_block_wait(hc_block* b, const hc_gather_row** rows, uint64_t* n_rows);
+int hc_block_destroy(hc_block* b);
+
 /* Stream compaction of a scored batch: the indices (ascending = sequence order) of the records whose
  * class is not HC_CLS_DROP — admitted edges, non-edges kept for FNO, ambiguous and error records —
  * i.e. everything the host or the multi-GPU gather still has to look at (typically a few per cent).
@@ -183,11 +226,11 @@ int hc_compact_device(hc_ctx* ctx, const void* d_results, uint64_t n, void* d_in
  *   d_rows[k] = { uint64 base_index + d_indices[k]; double x1; double x2; uint32 mm; uint32 n_cls }   (32 bytes)
  * i.e. the compacted records of this rank's shard tagged with their global candidate index, ready for one
  * all-gather.  Rows at and beyond *d_count are left untouched.  Asynchronous on `hip_stream`. */
-typedef struct hc_gather_row {
+struct hc_gather_row {
     uint64_t index;
     double x1, x2;
     uint32_t mm, n_cls;
-} hc_gather_row; /* 32 bytes */
+}; /* 32 bytes */
 int hc_pack_rows_device(hc_ctx* ctx, const void* d_results, const void* d_indices, const void* d_count, uint64_t cap,
                         uint64_t base_index, void* d_rows, void* hip_stream);
 
@@ -229,10 +272,9 @@ int hc_compact_pack_device(hc_ctx* ctx, const void* d_results, uint64_t n, void*
  * appended (tagged with base_index + its position) to d_payload in the layout of hc_compact_pack_device — row 0 counts
  * them — by the scoring kernel itself: no compaction pass over the results.  The rows arrive in no particular order
  * (sort by index if sequence order matters); a count above cap means rows were dropped: rerun with a larger cap.
- * *fused = 1 when the kernel did it, 0 when the read set needs an instantiation without a row-appending twin
- * (length balancing, 16-bit symbols) and the call fell back to scoring + hc_compact_pack_device (ordered rows). */
-int hc_score_pack_device(hc_ctx* ctx, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index, void* d_payload,
-                         void* hip_stream, int* fused);
+ * rec_fmt: HC_REC_FULL (d_in holds hc_overlap_rec) or HC_REC_COMPACT (hc_cand_rec).  Every read set takes this path. */
+int hc_score_pack_device(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index,
+                         void* d_payload, void* hip_stream);
 
 /* hc_score_batch + compaction in one call for host callers: scores `in` on the device and copies back
  * only the non-DROP records: idx_out[k] (ascending) and res_out[k] = result of in[idx_out[k]].
@@ -243,13 +285,13 @@ int hc_score_batch_compact(hc_ctx* ctx, const hc_overlap_rec* in, uint64_t n, ui
 
 /* Times `iters` back-to-back launches of the scoring kernel on the context's own
  * stream with hipEvents recorded on THAT stream; returns the mean milliseconds
- * per launch.  Used for the roofline figure. */
-int hc_time_score_kernel(hc_ctx* ctx, const void* d_in, uint64_t n, void* d_out, int iters, float* ms_per_launch);
+ * per launch.  Used for the roofline figure.  rec_fmt as for hc_score_pack_device. */
+int hc_time_score_kernel(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, uint64_t n, void* d_out, int iters, float* ms_per_launch);
 
 /* Sum over the batch of the overlapped positions sum_sub L_sub,
  * L_sub = min(L1 - pos, L2) (EdgeCalculator.cpp:86-88), computed on the device:
  * the exact multiplier for the algorithmic-bytes figure 32 + 16 + 4*L_sub. */
-int hc_count_positions_device(hc_ctx* ctx, const void* d_in, uint64_t n, uint64_t* total_positions,
+int hc_count_positions_device(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, uint64_t n, uint64_t* total_positions,
                               uint64_t* total_subs);
 
 /* Host finalisation of one record with the host libm exp(): score as the
@@ -261,6 +303,60 @@ int hc_finalize(const hc_settings* s, const hc_result_rec* r, double* score, dou
  * HC_ERR_DATA (after filling everything) if some record has class HC_CLS_ERROR. */
 int hc_finalize_batch(const hc_settings* s, const hc_result_rec* r, uint64_t n, double* score, double* mismatch_rate,
                       uint32_t* cls);
+
+/* ---- duplicate resolution + adjacency on the device -----------------------------------------
+ * The serial half of process_overlaps (EdgeCalculator.cpp:431-545) for a whole overlaps file at once, into an EMPTY
+ * graph: the admitted candidates, in sequence order, become Edges (the tail of compute_overlap: pos3/pos4, lengths,
+ * vertices, :219-232, :254-270, :292-308, :353-379), are normalised (:443-448), grouped by graph slot — unordered
+ * vertex pair + (ori1 == ori2) — with a stable radix sort, and every slot replays the reference's replace / keep
+ * decisions in sequence order (score, then the tie-break chain :470-521); the survivors come back as adjacency
+ * lists, in the order the reference's addEdge calls leave them (HC_GRAPH_INSERTION_ORDER) or as
+ * OverlapGraph::sortEdges (OverlapGraph.cpp:722-764) would re-order them right afterwards (HC_GRAPH_SORTED).
+ * One Edge of OverlapGraph::adj_out (src/Edge.h:21-38), flattened; read1/read2 index m_read_vec. */
+typedef struct hc_edge_rec {
+    double score, mismatch_rate;
+    int32_t pos1, pos2, pos3, pos4;
+    uint8_t ori1, ori2, ord, pad;
+    uint32_t read1, read2;
+    uint64_t v1, v2;
+    int32_t perc, len0, len1, len2;
+} hc_edge_rec; /* 80 bytes */
+
+/* An admitted candidate as the host hands it to the device: the record's own columns (the Edge takes POS, ORI, ORD,
+ * PERC, LEN from the file, not from the geometry) + the host-finalised score (exp() is the host libm's)
+ * + the mismatch ratio of the result record. */
+typedef struct hc_admit_rec {
+    double score;        /* hc_finalize                                       */
+    uint32_t read1, read2;
+    uint32_t pos1, pos2;
+    uint32_t mm, n;      /* mismatch_rate = float(mm) / n, EdgeCalculator.cpp:132 */
+    uint32_t len1, len2; /* LEN1, LEN2 columns                                */
+    uint32_t perc;       /* Overlap::get_perc()                               */
+    uint8_t ori1, ori2, ord, pad;
+} hc_admit_rec; /* 48 bytes */
+
+#define HC_GRAPH_INSERTION_ORDER 0u
+#define HC_GRAPH_SORTED 1u /* as after OverlapGraph::sortEdges */
+typedef struct hc_graph_counts {
+    uint64_t n_admitted, n_edges; /* n_edges = occupied slots = survivors                              */
+    uint64_t inclusion_count;     /* perc == 100 among the admitted, before de-duplication (:449-451)  */
+    uint64_t dup_count;           /* `doubles`, :472,537                                               */
+    uint64_t n_tied_lists;        /* HC_GRAPH_SORTED: out-lists longer than 16 that hold fully tied edges —
+                                     std::sort's order of those depends on the insertion order; hc_graph_fetch
+                                     reports them (tied_vertices) so the host can re-sort exactly those */
+    int64_t first_bad;            /* index of the first admitted record the reference's Edge would reject
+                                     (Edge::set_len, src/Edge.h:211-218), -1 = none                      */
+} hc_graph_counts;
+/* vertex_of_read: n_reads vertex ids (Read::get_vertex_id(true)), NULL = identity; every id < n_vertices < 2^31.
+ * admitted: host memory, sequence order.  Synchronous.  Results stay on the device until hc_graph_fetch. */
+int hc_graph_resolve(hc_ctx* ctx, const hc_admit_rec* admitted, uint64_t n, uint64_t n_vertices, const uint32_t* vertex_of_read,
+                     uint32_t order, hc_graph_counts* counts);
+/* edges: n_edges records, adj_out lists back to back in vertex order; out_off: n_vertices + 1 offsets into them;
+ * in_nodes / in_off: adj_in the same way (vertex1 of every in-edge); seq: for every edge, the index of its admitted
+ * record (its place in the reference's insertion sequence); inclusions: n_vertices bytes (OverlapGraph::inclusions,
+ * only marked with HC_FLAG_IGNORE_INCLUSIONS); tied_vertices: room for counts.n_tied_lists ids.  Any may be NULL. */
+int hc_graph_fetch(hc_ctx* ctx, hc_edge_rec* edges, uint64_t* out_off, uint32_t* in_nodes, uint64_t* in_off, uint32_t* seq,
+                   uint8_t* inclusions, uint32_t* tied_vertices);
 
 /* Introspection used by the tests: quality alphabet size K of the current store,
  * and the x-space guard band [lo, hi] of a threshold (x <= lo fails, x > hi passes). */

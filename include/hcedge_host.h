@@ -27,15 +27,7 @@ typedef struct hc_ec_paths {
     uint64_t max_reads;
 } hc_ec_paths;
 
-/* One Edge of OverlapGraph::adj_out (src/Edge.h:21-38), flattened. read1/read2 index m_read_vec. */
-typedef struct hc_edge_rec {
-    double score, mismatch_rate;
-    int32_t pos1, pos2, pos3, pos4;
-    uint8_t ori1, ori2, ord, pad;
-    uint32_t read1, read2;
-    uint64_t v1, v2;
-    int32_t perc, len0, len1, len2;
-} hc_edge_rec; /* 80 bytes */
+/* hc_edge_rec (one Edge of OverlapGraph::adj_out, flattened): include/hcedge.h */
 
 typedef struct hc_ec_counters {
     uint64_t self_overlap_count, inclusion_count, dup_count; /* src/EdgeCalculator.h:40-42 */
@@ -51,6 +43,11 @@ typedef struct hc_ec hc_ec; /* FastqStorage + OverlapGraph + EdgeCalculator */
 int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* paths);
 /* EdgeCalculator::construct_edges() — src/EdgeCalculator.cpp:561-666 */
 int hc_ec_construct_edges(hc_ec* ec);
+/* construct_edges() + OverlapGraph::sortEdges() (src/ViralQuasispecies.cpp:281,297: what every workflow calls next) as
+ * one call: into an empty graph the adjacency lists come back from the device already in sortEdges order. */
+int hc_ec_construct_edges_sorted(hc_ec* ec);
+/* number of device contexts the stage scores on (hc_settings.device_mask) */
+uint32_t hc_ec_device_count(hc_ec* ec);
 int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* out);
 uint64_t hc_ec_read_count(hc_ec* ec);
 uint64_t hc_ec_edge_count(hc_ec* ec); /* OverlapGraph::getEdgeCount */

@@ -38,6 +38,8 @@ def run_both(oracle, tmp_path, reads, lines, st, tag):
         ec.construct_edges()
         edges, inc, c = ec.edges(), ec.inclusions(), ec.counters()
         assert ec.edge_count() == edges.size
+        ec.sort_edges()
+        sorted_edges, sorted_in = ec.edges(), ec.in_lists()
     want = g.all_edges()
     assert edges.size == want.size, (edges.size, want.size)
     for k in FIELDS:
@@ -46,11 +48,39 @@ def run_both(oracle, tmp_path, reads, lines, st, tag):
             a, b = a.view(np.uint64), b.view(np.uint64)
         assert np.array_equal(a, b), f"edge field {k} differs"
     assert np.array_equal(inc, g.inclusions())
-    assert open(out_dir + "nonedge_overlaps.txt", "rb").read() == open(ref_nonedge, "rb").read()
-    for k in ("inclusion_count", "dup_count", "edges_added", "nonedges_written", "prefilter_rejected", "malformed_lines",
-              "lines_read", "scored"):
+    nonedge = open(out_dir + "nonedge_overlaps.txt", "rb").read()
+    assert nonedge == open(ref_nonedge, "rb").read()
+    COUNTERS = ("inclusion_count", "dup_count", "edges_added", "nonedges_written", "prefilter_rejected", "malformed_lines", "lines_read", "scored")
+    for k in COUNTERS:
         assert c[k] == getattr(oc, k), k
     assert c["self_overlap_count"] == 0
+    # The other routes to the same graph: the device's duplicate resolution is the default above; the host threads'
+    # resolution, the per-edge serial insert, three contexts taking the blocks in turn, and the fused
+    # construct + sortEdges call (against construct_edges followed by sortEdges) must all agree with it.
+    for env, sorted_call in (({"HC_RESOLVE": "host"}, False), ({"HC_INSERT_MODE": "serial"}, False), ({"HC_DEVICE_LIST": "0,0,0"}, False),
+                             ({}, True), ({"HC_RESOLVE": "host"}, True)):
+        os.environ.update(env)
+        try:
+            with host.EdgeCalculatorStage(st, singles=s, paired1=p1, paired2=p2, overlaps=ov, output_dir=out_dir) as ec:
+                if "HC_DEVICE_LIST" in env:
+                    assert ec.device_count() == 3
+                os.remove(out_dir + "nonedge_overlaps.txt")
+                if sorted_call:
+                    ec.construct_edges_sorted()
+                    e2, in2 = ec.edges(), ec.in_lists()
+                    assert e2.tobytes() == sorted_edges.tobytes(), (env, "sorted adjacency differs")
+                    assert np.array_equal(in2[0], sorted_in[0]) and np.array_equal(in2[1], sorted_in[1]), (env, "sorted in-lists differ")
+                else:
+                    ec.construct_edges()
+                    assert ec.edges().tobytes() == edges.tobytes(), (env, "adjacency differs")
+                assert np.array_equal(ec.inclusions(), inc), env
+                c2 = ec.counters()
+                for k in COUNTERS:
+                    assert c2[k] == c[k], (env, k)
+                assert open(out_dir + "nonedge_overlaps.txt", "rb").read() == nonedge, env
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
     return edges, c
 
 

@@ -20,7 +20,7 @@ class S(C.Structure):
     _fields_ = [("edge_threshold", C.c_double), ("ov_threshold", C.c_double), ("merge_contigs", C.c_double),
                 ("mismatch", C.c_double), ("min_read_len", C.c_uint32), ("min_overlap_len", C.c_uint32),
                 ("min_overlap_perc", C.c_uint32), ("flags", C.c_uint32), ("max_overlaps", C.c_uint64),
-                ("device", C.c_int32), ("n_threads", C.c_uint32)]
+                ("device", C.c_int32), ("n_threads", C.c_uint32), ("device_mask", C.c_uint32), ("reserved", C.c_uint32)]
 class P(C.Structure):
     _fields_ = [(k, C.c_char_p) for k in ("singles", "p1", "p2", "ids", "ov", "out")] + [("max_reads", C.c_uint64)]
 class V(C.Structure):

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 rm -rf $R/gpurun_out/traffic_fetch $R/gpurun_out/traffic_write $R/gpurun_out/traffic_l2 $R/gpurun_out/traffic_l1 $R/gpurun_out/traffic_sq $R/gpurun_out/traffic_lds
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline"
+B="python3 $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-stage --also none"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/traffic_fetch -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/traffic_write -- $B > /dev/null 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $R/gpurun_out/traffic_l2 -- $B > /dev/null 2>&1
@@ -27,7 +27,7 @@ for d in sorted(glob.glob("$R/gpurun_out/traffic_*/*/*_counter_collection.csv"))
     for k, v in agg.items():
         out[k] = sum(v) / len(v)
 fetch_kb, write_kb = out.get("FETCH_SIZE", 0.0), out.get("WRITE_SIZE", 0.0)
-res = {"workload": "$W", "order": "sfo", "kernel": "hc::score_kernel", "counters_per_launch": out,
+res = {"workload": "$W", "order": "sfo", "record_bytes": 16, "kernel": "hc::score_kernel", "counters_per_launch": out,
        "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
        "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md HBM section); WRITE_SIZE as read; x1024 B per KB",
        "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0}
