@@ -69,15 +69,22 @@ def roofline_record(workload, order, n, positions, kern_ms):
         r["achieved"] = t["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
         r["frac"] = r["achieved"] / HBM_PEAK_GBS
         busy = {}
-        if c.get("GRBM_GUI_ACTIVE") and c.get("TA_BUSY_avr"):
-            busy["ta_busy"] = c["TA_BUSY_avr"] / (c["GRBM_GUI_ACTIVE"] / 8.0)  # GRBM_GUI_ACTIVE sums the 8 XCDs
-        if c.get("SQ_WAVE_CYCLES"):
-            for k, name in (("SQ_ACTIVE_INST_VALU", "valu_active_of_wave_cycles"), ("SQ_ACTIVE_INST_LDS", "lds_active_of_wave_cycles"),
-                            ("SQ_WAIT_ANY", "waiting_of_wave_cycles")):
-                if c.get(k):
-                    busy[name] = c[k] / c["SQ_WAVE_CYCLES"]
+        if c.get("GRBM_GUI_ACTIVE"):
+            cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
+            n_cu = 256
+            if c.get("TA_BUSY_avr"):
+                busy["ta_busy"] = c["TA_BUSY_avr"] / cycles  # vector-memory front end (address processing of the lane-divergent gathers)
+            if c.get("SQ_ACTIVE_INST_VALU"):
+                busy["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (4 * n_cu * cycles)  # quad-cycles over all SIMDs
+            if c.get("SQ_LDS_IDX_ACTIVE"):
+                busy["lds_busy"] = c["SQ_LDS_IDX_ACTIVE"] / (n_cu * cycles)
+            busy["kernel_cycles"] = cycles
         if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
             busy["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        if c.get("SQ_INSTS_VALU") and c.get("SQ_INSTS_VMEM_RD"):
+            waves = n / 64.0
+            busy["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"] / waves
+            busy["vmem_read_instructions_per_wave"] = c["SQ_INSTS_VMEM_RD"] / waves
         r["issue_bound"] = dict(busy, source=f"profiles/traffic_{workload}.json")
     return r
 

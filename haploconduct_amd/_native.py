@@ -79,6 +79,8 @@ _sig = {
     "hc_block_submit": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
     "hc_block_wait": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64)]),
     "hc_block_destroy": (C.c_int, [_vp]),
+    "hc_graph_begin": (C.c_int, [_vp]),
+    "hc_graph_append": (C.c_int, [_vp, _vp, C.c_uint64]),
     "hc_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, C.POINTER(hc_graph_counts)]),
     "hc_graph_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hc_compact_pack_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp]),

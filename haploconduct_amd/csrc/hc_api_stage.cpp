@@ -116,13 +116,51 @@ int hc_block_wait(hc_block* b, const hc_gather_row** rows, uint64_t* n_rows) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+int hc_graph_begin(hc_ctx* c) {
+    if (!c) return fail(HC_ERR_ARG, "hc_graph_begin: null context");
+    c->graph.n_appended = 0;
+    c->graph.valid = false;
+    return HC_OK;
+}
+
+int hc_graph_append(hc_ctx* c, const hc_admit_rec* admitted, uint64_t n) {
+    if (!c || (n && !admitted)) return fail(HC_ERR_ARG, "hc_graph_append: null argument");
+    if (n == 0) return HC_OK;
+    HC_HIP(hipSetDevice(c->device));
+    hc_ctx::Graph& g = c->graph;
+    g.valid = false;
+    const uint64_t have = g.n_appended, want = have + n;
+    if (want >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_graph_append: more than 2^31-1 records");
+    if (want * sizeof(hc_admit_rec) > g.adm.cap) {  // grow, keeping what is there
+        size_t cap = g.adm.cap ? g.adm.cap : ((size_t)1 << 24);
+        while (cap < want * sizeof(hc_admit_rec)) cap *= 2;
+        void* bigger = nullptr;
+        HC_HIP(hipMalloc(&bigger, cap));
+        if (have) {
+            const hipError_t e = hipMemcpy(bigger, g.adm.p, have * sizeof(hc_admit_rec), hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(bigger);
+                return fail(HC_ERR_HIP, std::string("hc_graph_append: ") + hipGetErrorString(e));
+            }
+        }
+        g.adm.release();
+        g.adm.p = bigger;
+        g.adm.cap = cap;
+    }
+    // its own copy call, not the context's stream: the scoring of other blocks is in flight on theirs
+    HC_HIP(hipMemcpy((char*)g.adm.p + have * sizeof(hc_admit_rec), admitted, n * sizeof(hc_admit_rec), hipMemcpyHostToDevice));
+    g.n_appended = want;
+    return HC_OK;
+}
+
 int hc_graph_resolve(hc_ctx* c, const hc_admit_rec* admitted, uint64_t n, uint64_t n_vertices, const uint32_t* vertex_of_read,
                      uint32_t order, hc_graph_counts* counts) {
     if (!c || !counts) return fail(HC_ERR_ARG, "hc_graph_resolve: null argument");
     memset(counts, 0, sizeof *counts);
     counts->first_bad = -1;
     if (!c->have_reads) return fail(HC_ERR_STATE, "hc_graph_resolve: hc_set_reads has not been called");
-    if (n && !admitted) return fail(HC_ERR_ARG, "hc_graph_resolve: null records");
+    const bool appended = admitted == nullptr && n != 0;
+    if (appended && n != c->graph.n_appended) return fail(HC_ERR_ARG, "hc_graph_resolve: n differs from the number of appended records");
     if (order != HC_GRAPH_INSERTION_ORDER && order != HC_GRAPH_SORTED) return fail(HC_ERR_ARG, "hc_graph_resolve: unknown order");
     if (n >= (1ull << 31) || n_vertices >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_graph_resolve: more than 2^31-1 records or vertices");
     HC_HIP(hipSetDevice(c->device));
@@ -134,7 +172,7 @@ int hc_graph_resolve(hc_ctx* c, const hc_admit_rec* admitted, uint64_t n, uint64
     int rc;
 #define ENS(buf, bytes)                                 \
     if ((rc = g.buf.ensure(bytes)) != HC_OK) return rc
-    ENS(adm, m1 * sizeof(hc_admit_rec));
+    if (!appended) ENS(adm, m1 * sizeof(hc_admit_rec));
     ENS(E, m1 * sizeof(hc_edge_rec));
     ENS(key0, m1 * 8);
     ENS(key1, m1 * 8);
@@ -175,7 +213,10 @@ int hc_graph_resolve(hc_ctx* c, const hc_admit_rec* admitted, uint64_t n, uint64
     HC_HIP(hipMemsetAsync(g.tied.p, 0, (size_t)V + 1, s));
     unsigned long long* d_count = g.counters.as<unsigned long long>() + 5;
     if (m) {
-        HC_HIP(hipMemcpyAsync(g.adm.p, admitted, (size_t)m * sizeof(hc_admit_rec), hipMemcpyHostToDevice, s));
+        if (!appended) {
+            HC_HIP(hipMemcpyAsync(g.adm.p, admitted, (size_t)m * sizeof(hc_admit_rec), hipMemcpyHostToDevice, s));
+            g.n_appended = 0;
+        }
         HC_HIP(hc::graph_build_and_replay(gp, g.adm.as<hc_admit_rec>(), m, g.E.as<hc_edge_rec>(), g.key0.as<uint64_t>(), g.key1.as<uint64_t>(),
                                           g.idx0.as<uint32_t>(), g.idx1.as<uint32_t>(), g.keep.as<uint8_t>(), g.incl.as<uint8_t>(),
                                           g.counters.as<unsigned long long>(), g.surv.as<uint32_t>(), d_count, g.temp.p, g.temp.cap, s));

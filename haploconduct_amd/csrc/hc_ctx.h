@@ -125,6 +125,7 @@ struct hc_ctx {
         hc_scratch adm, E, key0, key1, idx0, idx1, keep, incl, tied, counters, surv, k32a, k32b, k64a, k64b, tmp_idx, o_out, o_in,
             out_off, in_off, edges_out, in_nodes, vtx, temp, tied_list;
         uint64_t n_vertices = 0, n_edges = 0, n_tied = 0;
+        uint64_t n_appended = 0;  // records hc_graph_append has put into adm
         bool valid = false;
     } graph;
 };

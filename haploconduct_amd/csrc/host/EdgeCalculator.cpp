@@ -276,8 +276,10 @@ void EdgeCalculator::consume_block(BlockOut& blk) {
     const double t1 = now_s();
     stats.nonedges_written += blk.nonedges;
     stats.ambiguous += blk.ambiguous;
-    if (m_collect) {
-        m_admitted.insert(m_admitted.end(), blk.admitted.begin(), blk.admitted.end());  // resolved once, after the last block
+    if (m_collect) {  // resolved once, after the last block; the device receives its copy now, behind the scoring of later blocks
+        if (m_device_resolve && !blk.admitted.empty()) check(hc_graph_append(m_ctx, blk.admitted.data(), blk.admitted.size()), "hc_graph_append");
+        m_admitted.emplace_back(std::move(blk.admitted));
+        blk.admitted = std::vector<hc_admit_rec>();
     } else {
         // The second read of an edge is a random place in the graph's slot index and in the in-lists: ask for the
         // slot and the list header 2*kAhead edges early, and for the end of the list (its header is in cache by
@@ -344,12 +346,20 @@ void EdgeCalculator::resolve_on_device(bool sorted) {
         for (size_t r = 0; r < R; r++) vtx[r] = m_read_info[r].vertex_set ? (uint32_t)m_read_info[r].vertex : 0xFFFFFFFFu;  // unset: out of range
     }
     hc_graph_counts gc;
-    check(hc_graph_resolve(m_ctx, m_admitted.data(), m_admitted.size(), V, identity ? nullptr : vtx.data(),
-                           sorted ? HC_GRAPH_SORTED : HC_GRAPH_INSERTION_ORDER, &gc),
+    size_t total = 0;
+    for (const auto& b : m_admitted) total += b.size();
+    check(hc_graph_resolve(m_ctx, nullptr, total, V, identity ? nullptr : vtx.data(), sorted ? HC_GRAPH_SORTED : HC_GRAPH_INSERTION_ORDER, &gc),
           "hc_graph_resolve");
     lap("resolve");
     if (gc.first_bad >= 0) {  // the record the reference's Edge rejects: say what it says
-        (void)edge_from_admit(m_admitted[(size_t)gc.first_bad], m_read_info.data());
+        size_t at = (size_t)gc.first_bad;
+        for (const auto& b : m_admitted) {
+            if (at < b.size()) {
+                (void)edge_from_admit(b[at], m_read_info.data());
+                break;
+            }
+            at -= b.size();
+        }
         throw FatalError{HC_ERR_STATE, "hc_graph_resolve rejected an admitted record the host accepts"};
     }
     const size_t E = (size_t)gc.n_edges;
@@ -397,7 +407,9 @@ void EdgeCalculator::resolve_on_device(bool sorted) {
 
 // The same on host threads (HC_RESOLVE=host, or vertex ids beyond the device's 31 bits).
 void EdgeCalculator::resolve_on_host() {
-    const size_t total = m_admitted.size();
+    std::vector<size_t> at(m_admitted.size() + 1, 0);
+    for (size_t b = 0; b < m_admitted.size(); b++) at[b + 1] = at[b] + m_admitted[b].size();
+    const size_t total = at.back();
     InsertCounters ic;
     static_assert(std::is_trivially_copyable<Edge>::value, "Edge lives in a malloc'd array");
     Edge* all = nullptr;
@@ -409,17 +421,18 @@ void EdgeCalculator::resolve_on_host() {
     try {
         const unsigned T = total < (1u << 16) ? 1u : std::max(1u, std::min<unsigned>(program_settings.n_threads, 16u));
         std::vector<FatalError> errs(T, FatalError{0, ""});
-        std::vector<size_t> err_at(T, 0);
         std::vector<std::thread> th;
-        auto build = [&](unsigned t) {
-            for (size_t k = total * t / T; k < total * (t + 1) / T; k++) {
-                try {
-                    new ((void*)(all + k)) Edge(edge_from_admit(m_admitted[k], m_read_info.data()));
-                } catch (const FatalError& e) {
-                    errs[t] = e;
-                    return;
+        auto build = [&](unsigned t) {  // blocks dealt to the threads in contiguous runs: errors come out in sequence order
+            const size_t nb = m_admitted.size();
+            for (size_t b = nb * t / T; b < nb * (t + 1) / T; b++)
+                for (size_t k = 0; k < m_admitted[b].size(); k++) {
+                    try {
+                        new ((void*)(all + at[b] + k)) Edge(edge_from_admit(m_admitted[b][k], m_read_info.data()));
+                    } catch (const FatalError& e) {
+                        errs[t] = e;
+                        return;
+                    }
                 }
-            }
         };
         for (unsigned t = 1; t < T; t++) th.emplace_back(build, t);
         build(0);
@@ -451,6 +464,10 @@ void EdgeCalculator::run_stage(bool then_sort) {
     m_collect = !m_serial_insert && overlap_graph->getEdgeCount() == 0 &&
                 EdgeSlotIndex::representable(overlap_graph->adj_out.size(), overlap_graph->adj_out.size());
     m_admitted.clear();
+    m_device_resolve = m_collect && !m_host_resolve;
+    for (const ReadInfo& x : m_read_info)
+        if (x.vertex_set && x.vertex >= ((node_id_t)1 << 31)) m_device_resolve = false;
+    if (m_device_resolve) check(hc_graph_begin(m_ctx), "hc_graph_begin");
     std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
     std::vector<Overlap> rejected;
     OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
@@ -592,10 +609,7 @@ void EdgeCalculator::run_stage(bool then_sort) {
     bool sorted_already = false;
     if (m_collect) {
         const double tr = now_s();
-        bool on_device = !m_host_resolve;
-        for (const ReadInfo& x : m_read_info)
-            if (x.vertex_set && x.vertex >= ((node_id_t)1 << 31)) on_device = false;
-        if (on_device) {
+        if (m_device_resolve) {
             resolve_on_device(then_sort);
             sorted_already = then_sort;
         } else {

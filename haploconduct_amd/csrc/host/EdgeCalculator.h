@@ -111,7 +111,8 @@ private:
     bool m_serial_insert = false;     // HC_INSERT_MODE=serial: per-edge inserts even into an empty graph
     bool m_host_resolve = false;      // HC_RESOLVE=host: duplicate resolution on the host threads instead of the device
     bool m_collect = false;           // this call collects the admitted candidates and resolves them after the last block
-    std::vector<hc_admit_rec> m_admitted;  // admitted candidates of the whole file in sequence order
+    bool m_device_resolve = false;    // ... on the device: every block's admitted records are appended there as they come
+    std::vector<std::vector<hc_admit_rec>> m_admitted;  // admitted candidates of the whole file, block by block, in sequence order
 };
 
 }  // namespace hc

@@ -120,15 +120,23 @@ class EdgeScorer:
                 N.lib.hc_block_destroy(b)
         return np.concatenate(out) if out else np.zeros(0, ROW_DTYPE)
 
-    def graph_resolve(self, admitted, n_vertices, vertex_of_read=None, sorted_order=False):
+    def graph_resolve(self, admitted, n_vertices, vertex_of_read=None, sorted_order=False, pieces=0):
         """hc_graph_resolve + hc_graph_fetch: duplicate resolution and adjacency lists on the device.  Returns a dict
-        with counts, edges (EDGE_DTYPE), out_off, in_nodes, in_off, seq, inclusions, tied_vertices."""
+        with counts, edges (EDGE_DTYPE), out_off, in_nodes, in_off, seq, inclusions, tied_vertices.
+        pieces > 0: hand the records over with hc_graph_begin / hc_graph_append in that many pieces first."""
         from .host import EDGE_DTYPE
 
         adm = np.ascontiguousarray(admitted, dtype=ADMIT_DTYPE)
         gc = N.hc_graph_counts()
         vtx = None if vertex_of_read is None else np.ascontiguousarray(vertex_of_read, dtype=np.uint32)
-        N.check(N.lib.hc_graph_resolve(self._ctx, _ptr(adm), adm.shape[0], n_vertices, None if vtx is None else _ptr(vtx),
+        src = _ptr(adm)
+        if pieces > 0:
+            N.check(N.lib.hc_graph_begin(self._ctx), "hc_graph_begin")
+            cuts = [adm.shape[0] * k // pieces for k in range(pieces + 1)]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                N.check(N.lib.hc_graph_append(self._ctx, C.c_void_p(adm.ctypes.data + a * 48), b - a), "hc_graph_append")
+            src = None
+        N.check(N.lib.hc_graph_resolve(self._ctx, src, adm.shape[0], n_vertices, None if vtx is None else _ptr(vtx),
                                        1 if sorted_order else 0, C.byref(gc)), "hc_graph_resolve")
         res = {"counts": {k: getattr(gc, k) for k, _ in gc._fields_}}
         if gc.first_bad >= 0:

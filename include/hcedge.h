@@ -347,8 +347,15 @@ typedef struct hc_graph_counts {
     int64_t first_bad;            /* index of the first admitted record the reference's Edge would reject
                                      (Edge::set_len, src/Edge.h:211-218), -1 = none                      */
 } hc_graph_counts;
+/* The admitted records may also be handed over piecewise while the file is still being scored (the stage does: the
+ * copies hide behind the scoring of later blocks): hc_graph_begin forgets what was appended, hc_graph_append copies n
+ * more records (sequence order = order of the calls) behind them; hc_graph_resolve with admitted == NULL resolves the
+ * appended records (n must equal their number). */
+int hc_graph_begin(hc_ctx* ctx);
+int hc_graph_append(hc_ctx* ctx, const hc_admit_rec* admitted, uint64_t n);
 /* vertex_of_read: n_reads vertex ids (Read::get_vertex_id(true)), NULL = identity; every id < n_vertices < 2^31.
- * admitted: host memory, sequence order.  Synchronous.  Results stay on the device until hc_graph_fetch. */
+ * admitted: host memory, sequence order (or NULL, see above).  Synchronous.  Results stay on the device until
+ * hc_graph_fetch. */
 int hc_graph_resolve(hc_ctx* ctx, const hc_admit_rec* admitted, uint64_t n, uint64_t n_vertices, const uint32_t* vertex_of_read,
                      uint32_t order, hc_graph_counts* counts);
 /* edges: n_edges records, adj_out lists back to back in vertex order; out_off: n_vertices + 1 offsets into them;

@@ -134,6 +134,10 @@ def test_device_resolution_is_the_serial_insert(seed, paired_frac):
         got = sc.graph_resolve(adm, V)
         assert got["counts"]["first_bad"] == -1
         assert got["edges"].tobytes() == want.tobytes()
+        # handed over piecewise (what the stage does while later blocks are still being scored): same graph
+        again = sc.graph_resolve(adm, V, pieces=37)
+        assert again["edges"].tobytes() == want.tobytes() and again["counts"] == got["counts"]
+        assert np.array_equal(again["in_nodes"], got["in_nodes"]) and np.array_equal(again["seq"], got["seq"])
         assert np.array_equal(got["inclusions"], want_inc) and want_inc.sum() > 0
         assert got["counts"]["dup_count"] == wc["dup_count"] > 1000 and got["counts"]["inclusion_count"] == wc["inclusion_count"]
         assert got["counts"]["n_edges"] == want.size == wc["edges_added"]
