@@ -237,9 +237,11 @@ int main(int argc, char** argv) {
         auto fastq = std::make_shared<FastqStorage>(ps);  // :233
         if (ps.verbose) printf("FastqStorage ready! Construction took %g seconds.\n", now_s() - t0);
         t0 = now_s();
-        auto graph = std::make_shared<OverlapGraph>(fastq->get_readcount(), fastq, ps);  // :252-261
+        auto graph = std::make_shared<OverlapGraph>(ps.add_duplicates ? 2 * fastq->get_readcount() : fastq->get_readcount(), fastq, ps);  // :246-261
         if (ps.verbose) puts("Adding vertices...");
-        for (Read* r : fastq->m_read_vec) r->set_vertex_id(true, graph->addVertex(r->get_read_id()));  // :266-271
+        for (Read* r : fastq->m_read_vec) r->set_vertex_id(true, graph->addVertex(r->get_read_id()));  // :259-263
+        if (ps.add_duplicates)  // a vertex for each reverse complementary read, :265-271
+            for (Read* r : fastq->m_read_vec) r->set_vertex_id(false, graph->addVertex(r->get_read_id()));
         if (ps.verbose) {
             printf("Overlap graph ready! Construction took %g seconds.\n", now_s() - t0);
             printf("Number of vertices: %u\n", graph->getVertexCount());

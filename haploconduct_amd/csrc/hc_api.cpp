@@ -93,15 +93,7 @@ int hc_device_count(void) {
     return n;
 }
 
-int hc_create(hc_ctx** out, const hc_settings* settings) {
-    if (!out || !settings) return fail(HC_ERR_ARG, "hc_create: null argument");
-    *out = nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-        return fail(HC_ERR_NO_DEVICE, "hc_create: no HIP device visible");
-    if (settings->device < 0 || settings->device >= n) return fail(HC_ERR_ARG, "hc_create: device ordinal out of range");
-    hc_ctx* c = new (std::nothrow) hc_ctx();
-    if (!c) return fail(HC_ERR_NOMEM, "hc_create: host allocation failed");
+static int create_ctx(hc_ctx* c, const hc_settings* settings) {
     c->settings = *settings;
     c->device = settings->device;
     HC_HIP(hipSetDevice(c->device));
@@ -118,6 +110,26 @@ int hc_create(hc_ctx** out, const hc_settings* settings) {
     c->params.merge_contigs = settings->merge_contigs;
     c->params.min_read_len = settings->min_read_len;
     c->params.flags = (settings->edge_threshold < 0 ? kParamEdgeAlways : 0u) | (settings->ov_threshold < 0 ? kParamOvAlways : 0u);
+    c->params.rec_fmt = HC_REC_FULL;
+    c->params.pad = 0;
+    return HC_OK;
+}
+
+int hc_create(hc_ctx** out, const hc_settings* settings) {
+    if (!out || !settings) return fail(HC_ERR_ARG, "hc_create: null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(HC_ERR_NO_DEVICE, "hc_create: no HIP device visible");
+    if (settings->device < 0 || settings->device >= n) return fail(HC_ERR_ARG, "hc_create: device ordinal out of range");
+    hc_ctx* c = new (std::nothrow) hc_ctx();
+    if (!c) return fail(HC_ERR_NOMEM, "hc_create: host allocation failed");
+    const int rc = create_ctx(c, settings);
+    if (rc != HC_OK) {  // nothing of a half-built context stays behind
+        const std::string why = g_last_error;
+        hc_destroy(c);
+        return fail(rc, why);
+    }
     *out = c;
     return HC_OK;
 }
@@ -251,20 +263,26 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     build_lut(phred, c->settings.mismatch, symbytes, lut);
 
     free_store(c);
-    uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_qmap = nullptr, *d_seq_bad = nullptr;
-    uint64_t *d_raw_off = nullptr, *d_seq_off = nullptr;
-    uint32_t* d_first = nullptr;
+    struct Tmp {  // freed on every return path
+        void* p = nullptr;
+        ~Tmp() {
+            if (p) (void)hipFree(p);
+        }
+    } t_bases, t_quals, t_qmap, t_seq_bad, t_raw_off, t_seq_off, t_first;
     const uint64_t sym_bytes_total = (nsym ? nsym : 1) * symbytes;
     HC_HIP(hipMalloc(&c->d_sym, sym_bytes_total));
     HC_HIP(hipMalloc((void**)&c->d_reads, sizeof(hc::ReadDesc) * (n_reads ? n_reads : 1)));
     HC_HIP(hipMalloc((void**)&c->d_lut, sizeof(double) * lut.size()));
-    HC_HIP(hipMalloc((void**)&d_seq_off, sizeof(uint64_t) * (n_seq ? n_seq : 1)));
-    HC_HIP(hipMalloc((void**)&d_seq_bad, (n_seq ? n_seq : 1)));
-    HC_HIP(hipMalloc((void**)&d_first, sizeof(uint32_t) * (n_reads + 1)));
-    HC_HIP(hipMalloc((void**)&d_bases, total ? total : 1));
-    HC_HIP(hipMalloc((void**)&d_quals, total ? total : 1));
-    HC_HIP(hipMalloc((void**)&d_raw_off, sizeof(uint64_t) * (n_seq + 1)));
-    HC_HIP(hipMalloc((void**)&d_qmap, 256));
+    HC_HIP(hipMalloc(&t_seq_off.p, sizeof(uint64_t) * (n_seq ? n_seq : 1)));
+    HC_HIP(hipMalloc(&t_seq_bad.p, (n_seq ? n_seq : 1)));
+    HC_HIP(hipMalloc(&t_first.p, sizeof(uint32_t) * (n_reads + 1)));
+    HC_HIP(hipMalloc(&t_bases.p, total ? total : 1));
+    HC_HIP(hipMalloc(&t_quals.p, total ? total : 1));
+    HC_HIP(hipMalloc(&t_raw_off.p, sizeof(uint64_t) * (n_seq + 1)));
+    HC_HIP(hipMalloc(&t_qmap.p, 256));
+    uint8_t *d_bases = (uint8_t*)t_bases.p, *d_quals = (uint8_t*)t_quals.p, *d_qmap = (uint8_t*)t_qmap.p, *d_seq_bad = (uint8_t*)t_seq_bad.p;
+    uint64_t *d_raw_off = (uint64_t*)t_raw_off.p, *d_seq_off = (uint64_t*)t_seq_off.p;
+    uint32_t* d_first = (uint32_t*)t_first.p;
     if (total) {
         HC_HIP(hipMemcpyAsync(d_bases, bases, total, hipMemcpyHostToDevice, c->stream));
         HC_HIP(hipMemcpyAsync(d_quals, quals, total, hipMemcpyHostToDevice, c->stream));
@@ -277,13 +295,6 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     HC_HIP(hc::launch_encode(symbytes, d_bases, d_quals, d_raw_off, d_seq_off, d_qmap, n_seq, K, c->d_sym, d_seq_bad,
                              d_first, n_reads, c->d_reads, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_bases);
-    (void)hipFree(d_quals);
-    (void)hipFree(d_raw_off);
-    (void)hipFree(d_qmap);
-    (void)hipFree(d_seq_off);
-    (void)hipFree(d_seq_bad);
-    (void)hipFree(d_first);
 
     {  // SFO ids: singles, then every /1 mate, then every /2 mate (s_p1_p2.fasta, savage.py:643-664)
         uint32_t n_single = 0, n_pairs = 0;

@@ -286,8 +286,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     }
     if (batches.size() > 1) {  // every batch is sorted; one more sort (key, position) + gather for the global order
         if (R >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 overlaps");
-        DevBuf sk0, sk1, si0, si1;
-        void* sorted = nullptr;
+        DevBuf sk0, sk1, si0, si1, dsorted;  // freed on every return path
         HC_HIP(hipMalloc(&sk0.own, R * 8));
         HC_HIP(hipMalloc(&sk1.own, R * 8));
         HC_HIP(hipMalloc(&si0.own, R * 8));
@@ -298,12 +297,13 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         DevBuf stmp;
         HC_HIP(hipMalloc(&stmp.own, b ? b : 16));
         HC_HIP(hc::finder_sort_pairs(stmp.own, b, (uint64_t*)sk0.own, (uint64_t*)sk1.own, (uint64_t*)si0.own, (uint64_t*)si1.own, R, 64, st));
-        HC_HIP(hipMalloc(&sorted, R * sizeof(hc_sfo_rec)));
-        HC_HIP(hc::finder_gather((const hc_sfo_rec*)d_r1.p, (const uint64_t*)si1.own, R, (hc_sfo_rec*)sorted, st));
+        HC_HIP(hipMalloc(&dsorted.own, R * sizeof(hc_sfo_rec)));
+        HC_HIP(hc::finder_gather((const hc_sfo_rec*)d_r1.p, (const uint64_t*)si1.own, R, (hc_sfo_rec*)dsorted.own, st));
         HC_HIP(hipStreamSynchronize(st));
         (void)hipFree(d_r1.own);
-        d_r1.own = sorted;
-        d_r1.p = sorted;
+        d_r1.own = dsorted.own;
+        d_r1.p = dsorted.own;
+        dsorted.own = nullptr;
         lap("global order of the batches");
     }
     *n_out = R;

@@ -52,7 +52,6 @@ static std::vector<int> device_list(const ProgramSettings& ps) {
 EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_ptr<OverlapGraph> graph,
                                const ProgramSettings& ps)
     : program_settings(ps), fastq_storage(std::move(fastq)), overlap_graph(std::move(graph)) {
-    if (ps.add_duplicates) throw FatalError{HC_ERR_ARG, "--add_duplicates is not supported (the pipelines never set it)"};
     if (const char* m = getenv("HC_INSERT_MODE")) m_serial_insert = std::string(m) == "serial";
     if (const char* m = getenv("HC_RESOLVE")) m_host_resolve = std::string(m) == "host";
     m_cs = to_hc_settings(ps);
@@ -126,6 +125,9 @@ void EdgeCalculator::collect_read_info() {
             x.len_b = x.paired ? (uint32_t)(off[q + 2] - off[q + 1]) : 0;
             x.vertex_set = r->has_vertex_id(true);
             x.vertex = x.vertex_set ? r->get_vertex_id(true) : 0;
+            x.vertex_rev_set = r->has_vertex_id(false);
+            x.vertex_rev = x.vertex_rev_set ? r->get_vertex_id(false) : 0;
+            x.pad = 0;
         }
     };
     const unsigned T = n < (1u << 16) ? 1u : std::max(1u, std::min<unsigned>(program_settings.n_threads, 8u));
@@ -141,10 +143,12 @@ void EdgeCalculator::collect_read_info() {
 
 // The Edge as compute_overlap builds it, :219-232 / :254-270 / :292-308 / :353-379 (the device's edge_build_kernel
 // states the same arithmetic for the bulk path).
-Edge edge_from_admit(const hc_admit_rec& o, const ReadInfo* read_info) {
+Edge edge_from_admit(const hc_admit_rec& o, const ReadInfo* read_info, bool add_duplicates) {
     const ReadInfo& i1 = read_info[o.read1];
     const ReadInfo& i2 = read_info[o.read2];
-    if (!i1.vertex_set || !i2.vertex_set) throw FatalError{HC_ERR_STATE, "Read::get_vertex_id: vertex id not set"};  // :180-183 asserts it
+    const bool rev1 = add_duplicates && !o.ori1, rev2 = add_duplicates && !o.ori2;  // :176-183
+    if (!(rev1 ? i1.vertex_rev_set : i1.vertex_set) || !(rev2 ? i2.vertex_rev_set : i2.vertex_set))
+        throw FatalError{HC_ERR_STATE, "Read::get_vertex_id: vertex id not set"};  // Read.h:111-120 asserts it
     const bool p1 = i1.paired, p2 = i2.paired;
     const int pos1 = (int)o.pos1, pos2 = (int)o.pos2;
     int pos3, pos4 = 0;
@@ -162,7 +166,7 @@ Edge edge_from_admit(const hc_admit_rec& o, const ReadInfo* read_info) {
         pos4 = (int)i1.len_a - pos1 - (int)i2.len_a;                 // :372
     }
     Edge e(o.score, pos1, pos2, o.ori1 != 0, o.ori2 != 0, (char)o.ord, i1.read, i2.read);
-    e.set_vertices(i1.vertex, i2.vertex);  // :180-183
+    e.set_vertices(rev1 ? i1.vertex_rev : i1.vertex, rev2 ? i2.vertex_rev : i2.vertex);
     e.set_extra_pos(pos3, pos4);
     e.set_perc((int)o.perc);
     e.set_len((int)o.len1, (!p1 && !p2) ? 0 : (int)o.len2);  // :227 / :268
@@ -288,7 +292,7 @@ void EdgeCalculator::consume_block(BlockOut& blk) {
         const uint64_t added_before = stats.edges_added;
         std::vector<Edge> edges;
         edges.reserve(blk.admitted.size());
-        for (const hc_admit_rec& a : blk.admitted) edges.push_back(edge_from_admit(a, m_read_info.data()));
+        for (const hc_admit_rec& a : blk.admitted) edges.push_back(edge_from_admit(a, m_read_info.data(), program_settings.add_duplicates));
         constexpr size_t kAhead = 8;
         const size_t m = edges.size();
         for (size_t k = 0; k < m; k++) {
@@ -363,21 +367,30 @@ void EdgeCalculator::resolve_on_device(bool sorted) {
         throw FatalError{HC_ERR_STATE, "hc_graph_resolve rejected an admitted record the host accepts"};
     }
     const size_t E = (size_t)gc.n_edges;
-    std::vector<hc_edge_rec> edges(E);
+    // destination of the fetch: plain uninitialised memory (a zero-filled std::vector would touch 300 MB at C3 first)
+    struct Raw {
+        void* p = nullptr;
+        explicit Raw(size_t bytes) {
+            const size_t huge = (size_t)2 << 20, n = (std::max<size_t>(bytes, 1) + huge - 1) & ~(huge - 1);
+            if (posix_memalign(&p, huge, n) != 0) throw FatalError{HC_ERR_NOMEM, "construct_edges: out of memory"};
+            madvise(p, n, MADV_HUGEPAGE);
+        }
+        ~Raw() { free(p); }
+        Raw(const Raw&) = delete;
+        Raw& operator=(const Raw&) = delete;
+    };
+    Raw r_edges(E * sizeof(hc_edge_rec)), r_in(E * sizeof(uint32_t)), r_seq(gc.n_tied_lists ? E * sizeof(uint32_t) : 0);
+    hc_edge_rec* edges = (hc_edge_rec*)r_edges.p;
+    uint32_t* in_nodes = (uint32_t*)r_in.p;
+    uint32_t* seq = gc.n_tied_lists ? (uint32_t*)r_seq.p : nullptr;
     std::vector<uint64_t> out_off(V + 1), in_off(V + 1);
-    std::vector<uint32_t> in_nodes(E), seq, tied;
+    std::vector<uint32_t> tied((size_t)gc.n_tied_lists);
     std::vector<uint8_t> incl(V);
-    if (gc.n_tied_lists) {
-        seq.resize(E);
-        tied.resize((size_t)gc.n_tied_lists);
-    }
-    check(hc_graph_fetch(m_ctx, edges.data(), out_off.data(), in_nodes.data(), in_off.data(), seq.empty() ? nullptr : seq.data(), incl.data(),
-                         tied.empty() ? nullptr : tied.data()),
+    check(hc_graph_fetch(m_ctx, edges, out_off.data(), in_nodes, in_off.data(), seq, incl.data(), tied.empty() ? nullptr : tied.data()),
           "hc_graph_fetch");
     lap("fetch");
     std::vector<Read*>& reads = fastq_storage->m_read_vec;
-    overlap_graph->adopt_csr(edges.data(), out_off.data(), in_nodes.data(), in_off.data(), incl.data(), reads.data(), reads.size(),
-                             program_settings.n_threads);
+    overlap_graph->adopt_csr(edges, out_off.data(), in_nodes, in_off.data(), incl.data(), reads.data(), reads.size(), program_settings.n_threads);
     lap("adopt");
     if (!tied.empty()) {
         // sortEdges order, lists longer than 16 with fully tied edges: std::sort's order of those is a function of
@@ -427,7 +440,7 @@ void EdgeCalculator::resolve_on_host() {
             for (size_t b = nb * t / T; b < nb * (t + 1) / T; b++)
                 for (size_t k = 0; k < m_admitted[b].size(); k++) {
                     try {
-                        new ((void*)(all + at[b] + k)) Edge(edge_from_admit(m_admitted[b][k], m_read_info.data()));
+                        new ((void*)(all + at[b] + k)) Edge(edge_from_admit(m_admitted[b][k], m_read_info.data(), program_settings.add_duplicates));
                     } catch (const FatalError& e) {
                         errs[t] = e;
                         return;
@@ -464,7 +477,7 @@ void EdgeCalculator::run_stage(bool then_sort) {
     m_collect = !m_serial_insert && overlap_graph->getEdgeCount() == 0 &&
                 EdgeSlotIndex::representable(overlap_graph->adj_out.size(), overlap_graph->adj_out.size());
     m_admitted.clear();
-    m_device_resolve = m_collect && !m_host_resolve;
+    m_device_resolve = m_collect && !m_host_resolve && !program_settings.add_duplicates;  // vertices by orientation: host route
     for (const ReadInfo& x : m_read_info)
         if (x.vertex_set && x.vertex >= ((node_id_t)1 << 31)) m_device_resolve = false;
     if (m_device_resolve) check(hc_graph_begin(m_ctx), "hc_graph_begin");
@@ -620,6 +633,14 @@ void EdgeCalculator::run_stage(bool then_sort) {
         if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] resolve total %.3f s\n", now_s() - tr);
         m_collect = false;
         stats.t_insert += now_s() - tr;
+    }
+    if (program_settings.add_duplicates) {  // :650-652
+        unsigned int built = 0, doubles = 0;
+        overlap_graph->addEquivalentEdges(&built, &doubles);
+        if (program_settings.verbose) {
+            printf("Number of equivalent edges built: %u\n", built);
+            printf("Number of duplicates: %u\n", doubles);
+        }
     }
     if (then_sort && !sorted_already) {  // the serial / host-resolved paths: sortEdges as its own pass
         std::vector<uint32_t> len(fastq_storage->m_read_vec.size());

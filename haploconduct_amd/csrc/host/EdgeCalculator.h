@@ -47,10 +47,12 @@ void resolve_admitted_edges(OverlapGraph& g, const ProgramSettings& ps, Edge* ad
 struct ReadInfo {
     Read* read;
     node_id_t vertex;       // get_vertex_id(true)
+    node_id_t vertex_rev;   // get_vertex_id(false): the reverse-complemented read's vertex (--add_duplicates only)
     uint32_t len_a, len_b;  // get_seq_len(0) of a single-end read; get_seq_len(1), get_seq_len(2) of a pair
-    uint32_t paired, vertex_set;
+    uint8_t paired, vertex_set, vertex_rev_set, pad;
 };
-Edge edge_from_admit(const hc_admit_rec& a, const ReadInfo* read_info);
+// add_duplicates: vertices by orientation (src/EdgeCalculator.cpp:176-179) instead of the normal one (:181-182)
+Edge edge_from_admit(const hc_admit_rec& a, const ReadInfo* read_info, bool add_duplicates = false);
 
 class EdgeCalculator {
 public:

@@ -118,6 +118,12 @@ public:
     void sortEdges(const uint32_t* len_by_read, unsigned n_threads = 1);
     void sort_out_list(node_id_t v, const uint32_t* len_by_read);  // sortEdges' treatment of one out-list (:724-749)
     void rebuild_in_lists(unsigned n_threads);                     // adj_in from the out-lists, :751-762
+    Edge removeEdge(node_id_t v, node_id_t w);                                                // :102-146
+    double checkEdge(node_id_t v, node_id_t w, bool reverse_allowed) const;                   // :233-259
+    // :608-719 (--add_duplicates; called at the end of construct_edges, EdgeCalculator.cpp:650-652): every edge once more
+    // between the vertices of the reverse-complemented reads.  The mirrored edges carry no reverse offsets and no
+    // mismatch rate in the reference (uninitialised / -1); here: pos3 = pos4 = 0, mismatch rate -1.
+    void addEquivalentEdges(unsigned int* n_built = nullptr, unsigned int* n_doubles = nullptr);
     Edge removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations);             // :150-194
     double checkEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) const;      // :198-229
     Edge* getEdgeInfoWithOri(node_id_t v, node_id_t w, bool opposite_orientations, bool reverse_allowed = true);  // :285-306

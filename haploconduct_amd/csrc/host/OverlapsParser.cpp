@@ -162,6 +162,9 @@ void OverlapsParser::parse_segment(Segment& seg) const {
     } catch (const FatalError& e) {
         seg.failed = true;
         seg.error = e;
+    } catch (const std::exception& e) {  // vector growth: nothing may leave a pool thread
+        seg.failed = true;
+        seg.error = FatalError{HC_ERR_NOMEM, std::string("overlaps parser: ") + e.what()};
     }
 }
 

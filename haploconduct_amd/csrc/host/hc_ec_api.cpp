@@ -28,8 +28,11 @@ int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* path
     int rc = guarded("hc_ec_open", [&] {
         ec->ps = make_ps(settings, paths);
         ec->fastq = std::make_shared<FastqStorage>(ec->ps);                                   // ViralQuasispecies.cpp:233
-        ec->graph = std::make_shared<OverlapGraph>(ec->fastq->get_readcount(), ec->fastq, ec->ps);  // :252-261
-        for (Read* r : ec->fastq->m_read_vec) r->set_vertex_id(true, ec->graph->addVertex(r->get_read_id()));  // :266-271
+        const unsigned int R = ec->fastq->get_readcount();
+        ec->graph = std::make_shared<OverlapGraph>(ec->ps.add_duplicates ? 2 * R : R, ec->fastq, ec->ps);  // :246-261
+        for (Read* r : ec->fastq->m_read_vec) r->set_vertex_id(true, ec->graph->addVertex(r->get_read_id()));  // :259-263
+        if (ec->ps.add_duplicates)  // a vertex for every reverse-complemented read as well, :265-271
+            for (Read* r : ec->fastq->m_read_vec) r->set_vertex_id(false, ec->graph->addVertex(r->get_read_id()));
         ec->calc.reset(new EdgeCalculator(ec->fastq, ec->graph, ec->ps));                     // :279
     });
     if (rc) return rc;
@@ -72,6 +75,7 @@ int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* c) {
 }
 
 uint64_t hc_ec_read_count(hc_ec* ec) { return ec ? ec->fastq->get_readcount() : 0; }
+uint64_t hc_ec_vertex_count(hc_ec* ec) { return ec ? ec->graph->adj_out.size() : 0; }
 uint64_t hc_ec_edge_count(hc_ec* ec) { return ec ? ec->graph->getEdgeCount() : 0; }
 
 int hc_ec_get_edges(hc_ec* ec, hc_edge_rec* out, uint64_t cap, uint64_t* n_out) {

@@ -519,6 +519,108 @@ Edge OverlapGraph::removeEdgeWithOri(node_id_t v, node_id_t w, bool opposite_ori
     return removed;
 }
 
+Edge OverlapGraph::removeEdge(node_id_t v, node_id_t w) {  // :102-146: the first edge v -> w, the first v in w's in-list
+    ensure_slots();
+    auto& L = adj_out.at(v);
+    Edge removed;
+    bool found = false;
+    for (auto it = L.begin(); it != L.end(); ++it) {
+        if (it->get_vertex(2) == w) {
+            removed = *it;
+            if (EdgeSlotIndex::representable(v, w)) slots.remove(EdgeSlotIndex::key(v, w, it->get_ori(1) == it->get_ori(2)));
+            L.erase(it);
+            edge_count--;
+            found = true;
+            break;
+        }
+    }
+    if (!found) throw FatalError{HC_ERR_STATE, "Edge to be removed not found..."};
+    auto& I = adj_in.at(w);
+    for (auto it = I.begin(); it != I.end(); ++it) {
+        if (*it == v) {
+            I.erase(it);
+            break;
+        }
+    }
+    return removed;
+}
+
+double OverlapGraph::checkEdge(node_id_t v, node_id_t w, bool reverse_allowed) const {  // :233-259
+    for (const Edge& e : adj_out.at(v))
+        if (e.get_vertex(2) == w) return e.get_score();
+    if (reverse_allowed)
+        for (const Edge& e : adj_out.at(w))
+            if (e.get_vertex(2) == v) return e.get_score();
+    return -1;
+}
+
+void OverlapGraph::addEquivalentEdges(unsigned int* n_built, unsigned int* n_doubles) {  // :608-719
+    const size_t V = adj_out.size();
+    std::vector<std::vector<Edge>> extra(V);
+    for (size_t i = 0; i < V; i++) {  // :618-668
+        for (const Edge& it : adj_out[i]) {
+            int pos1 = it.get_extra_pos(1), pos2 = it.get_extra_pos(2);
+            bool ori1, ori2;
+            char ord;
+            Read *read_1, *read_2;
+            const bool no_ord = it.get_ord() == '-' || it.get_ord() == '0';
+            if (pos1 < 0) {
+                read_1 = it.get_read(2);
+                read_2 = it.get_read(1);
+                ori1 = !it.get_ori(2);
+                ori2 = !it.get_ori(1);
+                pos1 = -pos1;
+                if (pos2 < 0) {
+                    ord = '1';
+                    pos2 = -pos2;
+                } else {
+                    ord = no_ord ? '-' : '2';
+                }
+            } else {
+                read_1 = it.get_read(1);
+                read_2 = it.get_read(2);
+                ori1 = !it.get_ori(1);
+                ori2 = !it.get_ori(2);
+                if (pos2 < 0) {
+                    pos2 = -pos2;
+                    ord = '2';
+                } else {
+                    ord = no_ord ? '-' : '1';
+                }
+            }
+            Edge e(it.get_score(), pos1, pos2, ori1, ori2, ord, read_1, read_2);
+            const node_id_t node1 = read_1->get_vertex_id(ori1), node2 = read_2->get_vertex_id(ori2);
+            e.set_vertices(node1, node2);
+            e.set_len(it.get_len(1), it.get_len(2));
+            e.set_perc(it.get_perc());
+            extra.at(node1).push_back(e);
+        }
+    }
+    unsigned int count = 0, doubles = 0;
+    for (size_t i = 0; i < V; i++) {  // :670-709
+        for (Edge it : extra[i]) {
+            node_id_t v1 = it.get_vertex(1), v2 = it.get_vertex(2);
+            if (it.get_pos(1) == 0 && v1 > v2) {  // either direction is possible: small id to large id
+                std::swap(v1, v2);
+                it.swap_reads();
+            }
+            const double score = checkEdge(v1, v2, /*reverse_allowed=*/false);
+            if (score < 0) {
+                addEdge(it);
+                count++;
+            } else if (it.get_score() > score) {
+                removeEdge(v1, v2);
+                addEdge(it);
+                doubles++;
+            } else {
+                doubles++;
+            }
+        }
+    }
+    if (n_built) *n_built = count;
+    if (n_doubles) *n_doubles = doubles;
+}
+
 double OverlapGraph::checkEdgeWithOri(node_id_t v, node_id_t w, bool opposite_orientations) const {  // :198-229
     ensure_slots();
     if (EdgeSlotIndex::representable(v, w) && !slots.contains(EdgeSlotIndex::key(v, w, opposite_orientations))) return -1;

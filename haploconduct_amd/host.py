@@ -51,6 +51,7 @@ _sig = {
     "hc_ec_device_count": (C.c_uint32, [_vp]),
     "hc_ec_get_counters": (C.c_int, [_vp, C.POINTER(hc_ec_counters)]),
     "hc_ec_read_count": (C.c_uint64, [_vp]),
+    "hc_ec_vertex_count": (C.c_uint64, [_vp]),
     "hc_ec_edge_count": (C.c_uint64, [_vp]),
     "hc_ec_get_edges": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_ec_get_inclusions": (C.c_int, [_vp, _vp, C.c_uint64]),
@@ -278,8 +279,11 @@ class EdgeCalculatorStage:
         N.check(N.lib.hc_ec_get_edges(self._h, out.ctypes.data, n.value, C.byref(n)), "hc_ec_get_edges")
         return out
 
+    def vertex_count(self):
+        return int(N.lib.hc_ec_vertex_count(self._h))
+
     def inclusions(self):
-        out = np.zeros(self.read_count(), np.uint8)
+        out = np.zeros(self.vertex_count(), np.uint8)
         N.check(N.lib.hc_ec_get_inclusions(self._h, out.ctypes.data, out.size), "hc_ec_get_inclusions")
         return out
 
@@ -289,7 +293,7 @@ class EdgeCalculatorStage:
 
     def in_lists(self):
         n = self.edge_count()
-        off = np.zeros(self.read_count() + 1, np.uint64)
+        off = np.zeros(self.vertex_count() + 1, np.uint64)
         nodes = np.zeros(max(n, 1), np.uint64)
         N.check(N.lib.hc_ec_get_in_lists(self._h, off.ctypes.data, nodes.ctypes.data, n), "hc_ec_get_in_lists")
         return off, nodes[:n]

@@ -50,6 +50,7 @@ int hc_ec_construct_edges_sorted(hc_ec* ec);
 uint32_t hc_ec_device_count(hc_ec* ec);
 int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* out);
 uint64_t hc_ec_read_count(hc_ec* ec);
+uint64_t hc_ec_vertex_count(hc_ec* ec); /* read count, or twice that with HC_FLAG_ADD_DUPLICATES (src/ViralQuasispecies.cpp:246-251) */
 uint64_t hc_ec_edge_count(hc_ec* ec); /* OverlapGraph::getEdgeCount */
 /* adj_out flattened in vertex order, each list in list order; *n_out = number of edges (may exceed cap). */
 int hc_ec_get_edges(hc_ec* ec, hc_edge_rec* out, uint64_t cap, uint64_t* n_out);
@@ -57,7 +58,12 @@ int hc_ec_get_inclusions(hc_ec* ec, uint8_t* out, uint64_t cap); /* OverlapGraph
 /* OverlapGraph::sortEdges() — src/OverlapGraph.cpp:722-764, called right after construct_edges in every workflow
  * (src/ViralQuasispecies.cpp:297,359,434): every out-list sorted by non-overlap length, then vertex2; adj_in rebuilt. */
 int hc_ec_sort_edges(hc_ec* ec);
-/* adj_in as offsets (read_count + 1) and vertex ids (edge_count), each list in list order. */
+/* adj_in as offsets (vertex_count + 1) and vertex ids (edge_count), each list in list order.  Before hc_ec_sort_edges the
+ * order INSIDE an in-list is that of the surviving edges' place in the insertion sequence; the reference's own order can
+ * differ from it in one case — a vertex pair holding edges of both orientation classes in the same direction, one of
+ * which was replaced later (removeEdgeWithOri erases the first `v` of the list, whichever edge it stood for) — and only
+ * in where the other entries sit between the two equal ids.  sortEdges rebuilds every in-list (OverlapGraph.cpp:751-762),
+ * after which the lists are the reference's in every case. */
 int hc_ec_get_in_lists(hc_ec* ec, uint64_t* in_off, uint64_t* in_nodes, uint64_t cap);
 /* EdgeCalculator::overlap_score on caller strings (src/EdgeCalculator.cpp:67-139), scored on the device. */
 int hc_ec_overlap_score(hc_ec* ec, const char* seq1, const char* seq2, const char* phred1, const char* phred2,

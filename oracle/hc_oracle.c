@@ -516,6 +516,34 @@ static int g_remove(hco_graph* g, uint64_t v, uint64_t w, int opp) {
     return 0;
 }
 
+/* OverlapGraph::checkEdge with reverse_allowed = false, OverlapGraph.cpp:233-259: the first edge v -> w of the list */
+static double g_check_edge(const hco_graph* g, uint64_t v, uint64_t w) {
+    const elist* L = &g->out[v];
+    for (uint64_t i = 0; i < L->n; i++)
+        if (L->e[i].v2 == w) return L->e[i].score;
+    return -1;
+}
+
+/* OverlapGraph::removeEdge, OverlapGraph.cpp:102-146: the first edge v -> w, the first v in w's in-list */
+static int g_remove_edge(hco_graph* g, uint64_t v, uint64_t w) {
+    elist* L = &g->out[v];
+    uint64_t i;
+    for (i = 0; i < L->n; i++)
+        if (L->e[i].v2 == w) break;
+    if (i == L->n) return -1;
+    memmove(&L->e[i], &L->e[i + 1], (L->n - i - 1) * sizeof(hco_gedge));
+    L->n--;
+    g->edge_count--;
+    vlist* I = &g->in[w];
+    for (i = 0; i < I->n; i++)
+        if (I->v[i] == v) {
+            memmove(&I->v[i], &I->v[i + 1], (I->n - i - 1) * sizeof(uint64_t));
+            I->n--;
+            break;
+        }
+    return 0;
+}
+
 /* Edge::swap_reads, Edge.h:74-88 */
 static void edge_swap_reads(hco_gedge* e) {
     uint32_t r = e->read1; e->read1 = e->read2; e->read2 = r;
@@ -582,6 +610,92 @@ int hco_graph_insert(hco_graph* g, const hco_settings* s, hco_gedge* it1, hco_co
     return 0;
 }
 
+/* OverlapGraph::addEquivalentEdges, OverlapGraph.cpp:608-719 (--add_duplicates): every edge once more between the
+ * vertices of the reverse-complemented reads.  Vertex of read r in orientation o: r if o, n_reads + r otherwise
+ * (ViralQuasispecies.cpp:259-271).  The mirrored Edge gets pos1/pos2 from the original's reverse offsets and never has
+ * its own reverse offsets or mismatch rate set (uninitialised / -1 in the reference): pos3 = pos4 = 0, mismatch -1 here. */
+int hco_graph_add_equivalent_edges(hco_graph* g, uint32_t n_reads) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < g->V; i++) total += g->out[i].n;
+    hco_gedge* extra = (hco_gedge*)malloc(sizeof(hco_gedge) * (total ? total : 1));
+    uint64_t* cnt = (uint64_t*)calloc(g->V + 1, sizeof(uint64_t));
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < g->V; i++) /* :618-668 */
+        for (uint64_t k = 0; k < g->out[i].n; k++) {
+            const hco_gedge* it = &g->out[i].e[k];
+            hco_gedge e;
+            memset(&e, 0, sizeof e);
+            int pos1 = it->pos3, pos2 = it->pos4;
+            if (pos1 < 0) {
+                e.read1 = it->read2;
+                e.read2 = it->read1;
+                e.ori1 = !it->ori2;
+                e.ori2 = !it->ori1;
+                pos1 = -pos1;
+                if (pos2 < 0) {
+                    e.ord = '1';
+                    pos2 = -pos2;
+                } else {
+                    e.ord = (it->ord == '-' || it->ord == '0') ? '-' : '2';
+                }
+            } else {
+                e.read1 = it->read1;
+                e.read2 = it->read2;
+                e.ori1 = !it->ori1;
+                e.ori2 = !it->ori2;
+                if (pos2 < 0) {
+                    pos2 = -pos2;
+                    e.ord = '2';
+                } else {
+                    e.ord = (it->ord == '-' || it->ord == '0') ? '-' : '1';
+                }
+            }
+            e.score = it->score;
+            e.pos1 = pos1;
+            e.pos2 = pos2;
+            e.v1 = e.ori1 ? e.read1 : (uint64_t)n_reads + e.read1;
+            e.v2 = e.ori2 ? e.read2 : (uint64_t)n_reads + e.read2;
+            if (e.v1 >= g->V || e.v2 >= g->V) {
+                free(extra);
+                free(cnt);
+                return -21;
+            }
+            e.len1 = it->len1; /* set_len(get_len(1), get_len(2)) */
+            e.len2 = it->len2;
+            e.len0 = it->len1 + it->len2;
+            e.perc = it->perc;
+            e.mismatch_rate = -1;
+            extra[m++] = e;
+            cnt[e.v1 + 1]++;
+        }
+    /* extra_edges.at(node1).push_back(edge): by vertex, in the order they were built */
+    for (uint64_t v = 0; v < g->V; v++) cnt[v + 1] += cnt[v];
+    hco_gedge* by_v = (hco_gedge*)malloc(sizeof(hco_gedge) * (total ? total : 1));
+    uint64_t* at = (uint64_t*)malloc(sizeof(uint64_t) * (g->V + 1));
+    memcpy(at, cnt, sizeof(uint64_t) * (g->V + 1));
+    for (uint64_t k = 0; k < m; k++) by_v[at[extra[k].v1]++] = extra[k];
+    for (uint64_t k = 0; k < m; k++) { /* :670-709 */
+        hco_gedge* it = &by_v[k];
+        uint64_t v1 = it->v1, v2 = it->v2;
+        if (it->pos1 == 0 && v1 > v2) {
+            uint64_t t = v1; v1 = v2; v2 = t;
+            edge_swap_reads(it);
+        }
+        const double score = g_check_edge(g, v1, v2);
+        if (score < 0) {
+            g_add(g, it);
+        } else if (it->score > score) {
+            g_remove_edge(g, v1, v2);
+            g_add(g, it);
+        }
+    }
+    free(extra);
+    free(by_v);
+    free(cnt);
+    free(at);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* id -> index: FastqStorage.h:88-97 builds a std::map by insert(): the first
  * occurrence of an id wins.  Sorted array + binary search here. */
@@ -637,8 +751,13 @@ static int process_batch(const hco_reads* R, const hco_settings* s, pending* bat
             ge.ord = o->ord;
             ge.read1 = o->read1;
             ge.read2 = o->read2;
-            ge.v1 = o->read1; /* get_vertex_id(true), :181-182 */
-            ge.v2 = o->read2;
+            if (s->flags & HCO_FLAG_ADD_DUPLICATES) { /* get_vertex_id(ori), :176-179 */
+                ge.v1 = o->ori1 ? o->read1 : (uint64_t)R->n_reads + o->read1;
+                ge.v2 = o->ori2 ? o->read2 : (uint64_t)R->n_reads + o->read2;
+            } else { /* get_vertex_id(true), :181-182 */
+                ge.v1 = o->read1;
+                ge.v2 = o->read2;
+            }
             ge.perc = (int)o->perc;
             if (e.n_subs == 1) { /* set_len(len1, 0) :227 ; set_len(len1, len2) :268 */
                 ge.len0 = (int)o->len1;
@@ -666,7 +785,6 @@ static int process_batch(const hco_reads* R, const hco_settings* s, pending* bat
 /* EdgeCalculator.cpp:561-666 */
 int hco_construct_edges(const hco_reads* R, const unsigned long* read_ids, const hco_settings* s,
                         const char* overlaps_path, const char* nonedge_path, hco_graph* g, hco_counters* c) {
-    if (s->flags & HCO_FLAG_ADD_DUPLICATES) return -1;
     memset(c, 0, sizeof *c);
     FILE* f = fopen(overlaps_path, "r");
     if (!f) return -30; /* :662-665 */
@@ -749,6 +867,7 @@ int hco_construct_edges(const hco_reads* R, const unsigned long* read_ids, const
         }
     }
     if (!rc && nb > 0) rc = process_batch(R, s, batch, nb, g, c, nonedge); /* :641-644 */
+    if (!rc && (s->flags & HCO_FLAG_ADD_DUPLICATES)) rc = hco_graph_add_equivalent_edges(g, R->n_reads); /* :650-652 */
     if (!rc && nonedge) { /* :654-660 */
         char buf[512];
         for (uint64_t k = 0; k < nrej; k++) {

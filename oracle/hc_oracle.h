@@ -152,11 +152,14 @@ typedef struct hco_counters {
 
 /* Insert one admitted edge exactly as EdgeCalculator.cpp:441-538 does. */
 int hco_graph_insert(hco_graph* g, const hco_settings* s, hco_gedge* e, hco_counters* c);
+/* OverlapGraph::addEquivalentEdges, OverlapGraph.cpp:608-719 */
+int hco_graph_add_equivalent_edges(hco_graph* g, uint32_t n_reads);
 
 /* EdgeCalculator::construct_edges, EdgeCalculator.cpp:561-666, single thread.
  * read_ids[i] is the read id of m_read_vec[i] (id->index as FastqStorage.h:88-97:
  * first occurrence wins); nonedge_path may be NULL (no file written).
- * Vertices are the m_read_vec indices (add_duplicates unsupported: returns -1). */
+ * Vertices are the m_read_vec indices; with HCO_FLAG_ADD_DUPLICATES the graph needs 2 * n_reads vertices (read r
+ * reverse-complemented = vertex n_reads + r) and OverlapGraph::addEquivalentEdges runs at the end (:650-652). */
 int hco_construct_edges(const hco_reads* reads, const unsigned long* read_ids, const hco_settings* s,
                         const char* overlaps_path, const char* nonedge_path, hco_graph* g, hco_counters* c);
 

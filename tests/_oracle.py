@@ -171,7 +171,7 @@ class Graph:
 
 
 def construct_edges(reads, settings, overlaps_path, nonedge_path=None):
-    g = Graph(reads.n_reads)
+    g = Graph(reads.n_reads * (2 if settings.flags & 1 else 1))  # --add_duplicates: a second vertex per read, ViralQuasispecies.cpp:246-251
     c = hco_counters()
     cr, cs = reads_to_c(reads), settings_to_c(settings)
     ids = np.ascontiguousarray(reads.read_ids, dtype=np.uint64)

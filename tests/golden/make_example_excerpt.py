@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Cuts small excerpts out of the reference's example READ DATA (not source) for the C1-style
-parity tests: savage/example/input_fas (merged singles ~400-490 bp + 2x250 pairs, 25 distinct
-quality values, N and Q0 bases) and polyte/example/input (2x250, 35 distinct quality values ->
-exercises the 16-bit-symbol path).  Run in the build container:  python tests/golden/make_example_excerpt.py"""
+"""Copies the reference's example READ DATA (not source) for the C1 parity tests: savage/example/input_fas WHOLE
+(BASELINE config 1: 2 000 merged singles of ~400-490 bp + 200 2x250 pairs, 25 distinct quality values, N and Q0 bases)
+and an excerpt of polyte/example/input (2x250, 35 distinct quality values -> exercises the wide-symbol path), gzipped.
+Run in the build container:  python tests/golden/make_example_excerpt.py"""
 import gzip
 import os
 
@@ -13,14 +13,16 @@ REF = "/root/reference"
 def head(path, n_records):
     with open(path, "rb") as f:
         lines = f.read().split(b"\n")
+    if n_records is None:  # the whole file
+        return b"\n".join(lines).rstrip(b"\n") + b"\n"
     return b"\n".join(lines[: 4 * n_records]) + b"\n"
 
 
 def main():
     out = {
-        "savage_singles.fastq": head(f"{REF}/savage/example/input_fas/singles.fastq", 450),
-        "savage_paired1.fastq": head(f"{REF}/savage/example/input_fas/paired1.fastq", 200),
-        "savage_paired2.fastq": head(f"{REF}/savage/example/input_fas/paired2.fastq", 200),
+        "savage_singles.fastq": head(f"{REF}/savage/example/input_fas/singles.fastq", None),
+        "savage_paired1.fastq": head(f"{REF}/savage/example/input_fas/paired1.fastq", None),
+        "savage_paired2.fastq": head(f"{REF}/savage/example/input_fas/paired2.fastq", None),
         "polyte_forward.fastq": head(f"{REF}/polyte/example/input/forward.fastq", 500),
         "polyte_reverse.fastq": head(f"{REF}/polyte/example/input/reverse.fastq", 500),
     }

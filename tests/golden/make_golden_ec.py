@@ -54,13 +54,14 @@ def run_probe(ref, reads, lines, st):
     fields = [f.encode() for ln in lines for f in ln.split("\t")]
     assert len(fields) == 13 * len(lines)
     L = (C.c_char_p * len(fields))(*fields)
-    cap = len(lines)
+    dup = 1 if st.get("add_duplicates") else 0
+    cap = len(lines) * (2 if dup else 1)
     edges = (FragEdge * cap)()
     n_edges, nb = C.c_uint64(), C.c_uint64()
-    incl = np.zeros(reads.n_reads, np.uint8)
+    incl = np.zeros(reads.n_reads * (2 if dup else 1), np.uint8)  # --add_duplicates: a second vertex per read (reverse complement)
     text = _vp()
     counters = (C.c_uint32 * 2)()
-    fs = FragSettings(st["edge_threshold"], st["ov_threshold"], st["merge_contigs"], st["mismatch"], st["min_read_len"], st["ignore_inclusions"])
+    fs = FragSettings(st["edge_threshold"], st["ov_threshold"], st["merge_contigs"], st["mismatch"], st["min_read_len"], st["ignore_inclusions"] | (2 * dup))
     with tempfile.TemporaryDirectory() as d:
         rc = ref.frag_process_overlaps(C.byref(fs), S, Q, ids.ctypes.data, n_single, n_paired, L, len(lines), d.encode(), edges, cap,
                                        C.byref(n_edges), incl.ctypes.data, C.byref(text), C.byref(nb), counters)
@@ -106,6 +107,18 @@ def scenarios():
                                                       ignore_inclusions=0)
     yield "singles_min_read_len", reads, lines[:700], dict(edge_threshold=0.97, ov_threshold=0.2, merge_contigs=0.0, mismatch=0.0, min_read_len=200,
                                                           ignore_inclusions=0)
+    # 2b. --add_duplicates (never set by the pipelines): vertices by orientation (EdgeCalculator.cpp:176-179), then
+    # OverlapGraph::addEquivalentEdges (OverlapGraph.cpp:608-719) mirrors every edge onto the reverse-complement vertices
+    yield "singles_add_duplicates", reads, lines, dict(edge_threshold=0.995, ov_threshold=0.9, merge_contigs=0.0, mismatch=0.0, min_read_len=0,
+                                                       ignore_inclusions=1, add_duplicates=1)
+    preads, pmeta = synth.make_paired_dataset(90, 700, flip_frac=0.4, seed=35)
+    preads.quals = HQ[np.random.default_rng(2).integers(0, HQ.size, preads.quals.size)]
+    pcand = synth.paired_candidates(pmeta, seed=36)
+    plines = synth.records_to_lines(pcand, preads)
+    for ln in rng.sample(plines, len(plines) // 3):
+        plines.insert(rng.randrange(len(plines)), ln)
+    yield "pairs_add_duplicates", preads, plines, dict(edge_threshold=0.97, ov_threshold=0.5, merge_contigs=0.0, mismatch=0.0, min_read_len=0,
+                                                      ignore_inclusions=0, add_duplicates=1)
     # 3. singles and pairs together: s-p and p-s candidates by geometry, right and wrong orientations
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_parity import _mixed_reads
@@ -140,7 +153,8 @@ def main():
     for name, reads, lines, st in scenarios():
         edges, incl, nonedge, counters = run_probe(ref, reads, lines, st)
         n_single = sum(1 for r in range(reads.n_reads) if not reads.is_paired(r))
-        case = {"source": "fragment probe of src/EdgeCalculator.cpp:26-557 + src/OverlapGraph.cpp:83-101,150-229,285-319 (process_overlaps)",
+        case = {"source": "fragment probe of src/EdgeCalculator.cpp:26-557 + src/OverlapGraph.cpp:83-147,150-229,233-259,285-319,608-719 "
+                          "(process_overlaps; with add_duplicates followed by addEquivalentEdges, whose edges carry no reverse offsets: stored as 0)",
                 "settings": st, "n_single": n_single, "n_paired": reads.n_reads - n_single,
                 "read_ids": [int(x) for x in reads.read_ids],
                 "seqs": [reads.seq(q)[0].decode() for q in range(reads.n_seq)], "quals": [reads.seq(q)[1].decode() for q in range(reads.n_seq)],

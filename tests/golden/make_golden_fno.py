@@ -98,6 +98,58 @@ def main():
     json.dump({"source": "fragment probe of src/FindNextOverlaps.cpp:25-631,816-958 + src/OverlapGraph.cpp:233-259 (findNextOverlaps, optimize = true)",
                "cases": runs}, open(os.path.join(OUT, "fno1_run.json"), "w"), separators=(",", ":"))
 
+    # ---- whole findNextOverlaps() runs WITH the stored non-edges: optimize = false, so the reference's own
+    # reconsiderNonedgeOverlaps (:635-813 minus the Boost trim at :652) reads <dir>/nonedge_overlaps.txt — lines with outer
+    # blanks and tabs among them —, builds its temporary edges, drops those behind an existing edge (checkEdge, :702) and
+    # hands the rest to processOverlaps.  Reads are named by their vertex number in that file (see frag_fno1_run).
+    runs_ne = []
+    for seed in range(8):
+        flags = [F.RESOLVE_ORIENTATIONS, F.RESOLVE_ORIENTATIONS | F.NO_INCLUSIONS, 0][seed % 3]
+        inp = T.fno1_scenario(2500 + seed, n_nodes=40, n_srs=13, n_edges=100, paired_frac=[0.0, 0.4, 1.0, 0.5][seed % 4], flags=flags,
+                              with_extras=True)
+        rng = np.random.default_rng(900 + seed)
+        ne = T.random_edges(rng, inp.nodes, 70, score=0.0)
+        # a third of them behind an existing edge of the graph (either direction): checkEdge must drop those
+        k = len(ne) // 3
+        pick = inp.graph_edges[rng.integers(0, len(inp.graph_edges), k)]
+        flip = rng.random(k) < 0.5
+        ne["v1"][:k] = np.where(flip, pick["v2"], pick["v1"])
+        ne["v2"][:k] = np.where(flip, pick["v1"], pick["v2"])
+        ne = ne[rng.permutation(len(ne))]
+        pp = (inp.nodes["paired"][ne["v1"].astype(int)] != 0) & (inp.nodes["paired"][ne["v2"].astype(int)] != 0)
+        ne["ord"] = np.where(pp, np.where(rng.random(len(ne)) < 0.5, ord("1"), ord("2")), ord("-"))  # Overlap's constructor checks ord against the types
+        ne["len1"] = np.maximum(ne["len1"], 1)  # Edge::set_len asserts len1 > 0
+        lines = []
+        for e in ne:
+            t1 = "p" if inp.nodes[int(e["v1"])]["paired"] else "s"
+            t2 = "p" if inp.nodes[int(e["v2"])]["paired"] else "s"
+            ln = "\t".join(str(x) for x in [int(e["v1"]), int(e["v2"]), int(e["pos1"]), int(e["pos2"]), chr(int(e["ord"])),
+                                            "+" if e["ori1"] else "-", "+" if e["ori2"] else "-", int(e["perc"]), 0, int(e["len1"]), int(e["len2"]), t1, t2])
+            lines.append([ln, " " + ln, ln + "\t ", "\t \t" + ln + "  "][int(rng.integers(4))])
+        inp.nonedges = ne
+        inp.edge_threshold = [0.97, 0.0, 1.0][seed % 3]
+        s = inp.struct()
+        text, n, nl = _vp(), C.c_uint64(), C.c_uint64()
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "nonedge_overlaps.txt"), "w").write("\n".join(lines) + "\n")
+            ref.frag_fno1_run(C.byref(s), d.encode(), C.byref(text), C.byref(n), C.byref(nl))
+        got = C.string_at(text, n.value).decode()
+        ref.frag_fno_free(text)
+        ecols = ["v1", "v2", "score", "pos1", "pos2", "len1", "len2", "perc", "ord", "ori1", "ori2"]
+        runs_ne.append({
+            "flags": flags, "new_read_count": int(inp.new_read_count), "edge_threshold": inp.edge_threshold,
+            "nodes": rec_list(inp.nodes[["id", "len1", "len2", "paired", "visited", "orientation"]]),
+            "srs": rec_list(inp.srs[["id", "len1", "len2", "paired"]]),
+            "clique_off": inp.clique_off.tolist(), "clique_nodes": inp.clique_nodes.tolist(),
+            "subread_off": inp.subread_off.tolist(), "subreads": rec_list(inp.subreads),
+            "graph_edges": rec_list(inp.graph_edges[ecols]), "branching_edges": rec_list(inp.branching_edges[ecols]),
+            "inclusion_off": inp.inclusion_off.tolist(), "inclusion_edges": rec_list(inp.inclusion_edges[ecols]),
+            "nonedge_lines": lines, "text": got, "n_lines": int(nl.value),
+        })
+    json.dump({"source": "fragment probe of src/FindNextOverlaps.cpp:25-631,635-651,653-813,816-958 + src/OverlapGraph.cpp:233-259 "
+                         "(findNextOverlaps with reconsiderNonedgeOverlaps, optimize = false; reads named by vertex number in nonedge_overlaps.txt)",
+               "cases": runs_ne}, open(os.path.join(OUT, "fno1_run_nonedges.json"), "w"), separators=(",", ":"))
+
     # ---- whole findNextOverlaps3() runs.  hc_fno3_input lists the originals of a super-read in the iteration order of
     # its std::unordered_map; the probe is given an insertion order and tells which iteration order results.
     ref.frag_fno3_run.argtypes = [C.POINTER(F.hc_fno3_input), C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

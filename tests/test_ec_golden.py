@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import haploconduct_amd as hc
-from haploconduct_amd.records import FLAG_IGNORE_INCLUSIONS, FLAG_RESOLVE_ORIENTATIONS
+from haploconduct_amd.records import FLAG_ADD_DUPLICATES, FLAG_IGNORE_INCLUSIONS, FLAG_RESOLVE_ORIENTATIONS
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ec")
 CASES = sorted(glob.glob(os.path.join(GOLD, "*.json")))
@@ -27,7 +27,8 @@ def load_case(path):
     s = c["settings"]
     st = hc.Settings(edge_threshold=s["edge_threshold"], ov_threshold=s["ov_threshold"], merge_contigs=s["merge_contigs"], mismatch=s["mismatch"],
                      min_read_len=s["min_read_len"], min_overlap_len=0, min_overlap_perc=0,
-                     flags=FLAG_RESOLVE_ORIENTATIONS | (FLAG_IGNORE_INCLUSIONS if s["ignore_inclusions"] else 0))
+                     flags=(FLAG_ADD_DUPLICATES if s.get("add_duplicates") else FLAG_RESOLVE_ORIENTATIONS) |  # exclusive, ViralQuasispecies.cpp:144-148
+                           (FLAG_IGNORE_INCLUSIONS if s["ignore_inclusions"] else 0))
     want = {k: [e[i] for e in c["edges"]] for i, k in enumerate(c["edge_fields"])}
     for k in ("score", "mismatch_rate"):
         want[k] = np.array([float.fromhex(x) for x in want[k]], np.float64)
@@ -56,7 +57,7 @@ def test_oracle_reproduces_the_references_process_overlaps(oracle, tmp_path, pat
 
 
 def test_the_vectors_cover_the_branches():
-    assert len(CASES) == 7
+    assert len(CASES) == 9
     tot = {"edges": 0, "nonedges": 0, "dups": 0, "incl_bits": 0, "incl_count": 0}
     ords, oris = set(), set()
     for p in CASES:

@@ -87,6 +87,44 @@ def test_golden_whole_find_next_overlaps_runs(olib):
     assert some_induced >= 5
 
 
+def test_golden_whole_runs_with_stored_nonedges(olib):
+    """The reference's own findNextOverlaps() with optimize = false: reconsiderNonedgeOverlaps (src/FindNextOverlaps.cpp:
+    635-813; its one Boost call, the trim at :652, replaced by a build-owned statement in the probe) reads
+    nonedge_overlaps.txt — padded lines among them —, drops the overlaps behind an existing edge (checkEdge, :702) and feeds
+    the rest to processOverlaps.  The product receives the same file through its own line parser
+    (host.parse_overlap -> records -> fno.edges_from_records); oracle and product must write the same overlaps.txt."""
+    from haploconduct_amd import host
+    from haploconduct_amd.records import OVERLAP_DTYPE
+
+    g = json.load(open(os.path.join(GOLD, "fno1_run_nonedges.json")))
+    assert "reconsiderNonedgeOverlaps" in g["source"] and len(g["cases"]) == 8
+    ecols = ["v1", "v2", "score", "pos1", "pos2", "len1", "len2", "perc", "ord", "ori1", "ori2"]
+    matter = 0
+    for c in g["cases"]:
+        nodes = _rec(c["nodes"], F.FNO_READ_DTYPE, ["id", "len1", "len2", "paired", "visited", "orientation"])
+        srs = _rec(c["srs"], F.FNO_READ_DTYPE, ["id", "len1", "len2", "paired"])
+        subs = _rec(c["subreads"], F.FNO_SUBREAD_DTYPE, ["node", "index1", "index2", "startpos1", "startpos2"])
+        co, so, io = c["clique_off"], c["subread_off"], c["inclusion_off"]
+        cliques = [np.array(c["clique_nodes"][co[i]:co[i + 1]], np.uint64) for i in range(len(srs))]
+        subreads = [subs[so[i]:so[i + 1]] for i in range(len(srs))]
+        incl = _rec(c["inclusion_edges"], F.FNO_EDGE_DTYPE, ecols)
+        groups = [incl[io[i]:io[i + 1]] for i in range(len(io) - 1)]
+        recs = np.zeros(len(c["nonedge_lines"]), OVERLAP_DTYPE)
+        for k, ln in enumerate(c["nonedge_lines"]):  # the file as the product's own parser reads it; ids are vertex numbers here
+            rc, o = host.parse_overlap(ln)
+            assert rc == 0
+            recs[k] = (o["id1"], o["id2"], o["pos1"], o["pos2"], o["ori1"] == "+", o["ori2"] == "+", ord(o["ord"]), 0, o["len1"], o["len2"], o["perc"])
+        inp = F.Fno1Input(nodes, srs, cliques, subreads, _rec(c["graph_edges"], F.FNO_EDGE_DTYPE, ecols),
+                          branching_edges=_rec(c["branching_edges"], F.FNO_EDGE_DTYPE, ecols), nonedges=F.edges_from_records(recs),
+                          inclusion_groups=groups, new_read_count=c["new_read_count"], edge_threshold=c["edge_threshold"], flags=c["flags"])
+        want = c["text"].encode()
+        for text, cnt in (T.oracle_fno1(olib, inp), F.find_next_overlaps(inp)):
+            assert text == want and cnt["n_lines"] == c["n_lines"] == want.count(b"\n")
+        inp.nonedges = np.zeros(0, F.FNO_EDGE_DTYPE)  # the stored non-edges matter: without them the file is different
+        matter += F.find_next_overlaps(inp)[0] != want
+    assert matter >= 6
+
+
 def test_golden_whole_find_next_overlaps3_runs(olib):
     """The reference's own findNextOverlaps3() as a whole (original_to_index walk in its unordered_map order, the
     candidate list, deduceOverlap, the file): oracle and product reproduce overlaps.txt byte for byte."""

@@ -360,8 +360,12 @@ def test_fuzz_stage_against_oracle(oracle, tmp_path, seed):
                 lines[k] = "  " + lines[k].replace("\t", " \t", 3) + " "
     from haploconduct_amd.records import FLAG_ALLOW_SPACES
 
-    flags = FLAG_RESOLVE_ORIENTATIONS | (FLAG_IGNORE_INCLUSIONS if rng.integers(0, 2) else 0) | (FLAG_RELAX_PE_EDGES if rng.integers(0, 2) else 0) | \
-        (FLAG_ALLOW_SPACES if allow_spaces else 0)
+    from haploconduct_amd.records import FLAG_ADD_DUPLICATES
+
+    # every fourth scenario with --add_duplicates (vertices by orientation, addEquivalentEdges at the end) instead of its
+    # exclusive twin --resolve_orientations (src/ViralQuasispecies.cpp:144-148)
+    flags = (FLAG_ADD_DUPLICATES if seed % 4 == 3 else FLAG_RESOLVE_ORIENTATIONS) | (FLAG_IGNORE_INCLUSIONS if rng.integers(0, 2) else 0) | \
+        (FLAG_RELAX_PE_EDGES if rng.integers(0, 2) else 0) | (FLAG_ALLOW_SPACES if allow_spaces else 0)
     st = hc.Settings(edge_threshold=float(rng.choice([0.9, 0.97, 0.995, 1.0])), ov_threshold=float(rng.choice([0.0, 0.5, 0.9])),
                      merge_contigs=float(rng.choice([0.0, 0.0, 0.01])), mismatch=float(rng.choice([0.0, 0.0, 0.02])),
                      min_read_len=int(rng.choice([0, 0, 100])), min_overlap_len=int(rng.choice([0, 100, 150, 220])),
