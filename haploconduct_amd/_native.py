@@ -52,6 +52,12 @@ class hc_settings(C.Structure):
     ]
 
 
+class hc_text_result(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_lines", "lines_read", "needs_host", "n_nonplain", "n_unknown_id", "self_overlaps", "silently_dropped",
+                                          "prefilter_rejected", "scored")] + \
+               [("rows", C.c_void_p), ("n_rows", C.c_uint64), ("rejected", C.c_void_p), ("n_rejected", C.c_uint64)]
+
+
 class hc_graph_counts(C.Structure):
     _fields_ = [("n_admitted", C.c_uint64), ("n_edges", C.c_uint64), ("inclusion_count", C.c_uint64), ("dup_count", C.c_uint64),
                 ("n_tied_lists", C.c_uint64), ("first_bad", C.c_int64)]
@@ -79,6 +85,12 @@ _sig = {
     "hc_block_submit": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
     "hc_block_wait": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64)]),
     "hc_block_destroy": (C.c_int, [_vp]),
+    "hc_text_set_ids": (C.c_int, [_vp, _vp, C.c_uint32]),
+    "hc_textblock_create": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    "hc_textblock_buffer": (_vp, [_vp]),
+    "hc_textblock_submit": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "hc_textblock_wait": (C.c_int, [_vp, C.POINTER(hc_text_result)]),
+    "hc_textblock_destroy": (C.c_int, [_vp]),
     "hc_graph_begin": (C.c_int, [_vp]),
     "hc_graph_append": (C.c_int, [_vp, _vp, C.c_uint64]),
     "hc_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, C.POINTER(hc_graph_counts)]),

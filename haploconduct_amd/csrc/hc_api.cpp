@@ -112,6 +112,7 @@ static int create_ctx(hc_ctx* c, const hc_settings* settings) {
     c->params.flags = (settings->edge_threshold < 0 ? kParamEdgeAlways : 0u) | (settings->ov_threshold < 0 ? kParamOvAlways : 0u);
     c->params.rec_fmt = HC_REC_FULL;
     c->params.pad = 0;
+    c->params.n_dev = nullptr;
     return HC_OK;
 }
 
@@ -382,7 +383,8 @@ static int ensure_sort_workspace(hc_ctx* c, uint64_t n) {
 }  // extern "C"
 
 int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, hipStream_t s, bool reorder,
-                 hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index) {
+                 hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index, const unsigned long long* n_dev,
+                 const hc_line_rec* lines_in, hc_line_rec* lines_out) {
     const uint32_t* perm = nullptr;
     if (reorder && n > 1 && n < (1ull << 31)) {
         int rc = ensure_sort_workspace(c, n);
@@ -397,8 +399,9 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
     }
     hc::ScoreParams prm = c->params;
     prm.rec_fmt = fmt;
+    prm.n_dev = n_dev;
     HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->fetch_group, rows, row_count, cap,
-                            base_index, s));
+                            base_index, s, lines_in, lines_out));
     return HC_OK;
 }
 

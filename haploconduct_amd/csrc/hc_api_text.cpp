@@ -1,0 +1,232 @@
+// hc_api_text.cpp — hc_text_* / hc_textblock_* (include/hcedge.h): a block of the overlaps file's text goes to the
+// device, is split into lines, parsed, prefiltered and scored there (kernels: hc_text_kernels.hip + the scoring kernel),
+// and comes back as the few per cent of records the host still has to look at.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hcedge.h"
+#include "hc_ctx.h"
+#include "hc_text.h"
+
+static int fail(int status, const std::string& what) { return hc::set_last_error(status, what); }
+
+struct hc_textblock {
+    hc_ctx* ctx = nullptr;
+    uint64_t max_bytes = 0;
+    uint32_t max_lines = 0;
+    uint32_t row_cap = 0;  // rows / rejects the mapped host buffers hold; a block that needs more goes to the host
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    char* h_text = nullptr;                    // page-locked: the caller reads the file into it
+    char* d_text = nullptr;                    // max_bytes + 64
+    uint32_t *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_line_start = nullptr;
+    hc_cand_rec* d_cands = nullptr;            // max_lines
+    hc_line_rec* d_lines = nullptr;            // max_lines
+    hc_result_rec* d_out = nullptr;            // max_lines
+    unsigned long long* d_counters = nullptr;  // hc::kTextCounters
+    hc_gather_row* h_rows = nullptr;           // page-locked, mapped: written by the scoring kernel
+    hc_line_rec* h_row_lines = nullptr;        // page-locked, mapped: the parsed line of every row
+    hc_text_reject* h_rejects = nullptr;       // page-locked, mapped: written by the parse kernel
+    unsigned long long* h_counters = nullptr;  // page-locked
+    std::vector<hc_text_row> rows;             // what hc_textblock_wait hands out
+    bool in_flight = false;
+};
+
+extern "C" {
+
+// FastqStorage::m_ID_to_index (a std::map built by insert(): the first occurrence of an id wins, FastqStorage.h:83-96) as
+// a table the parse kernel reads: direct when the ids are dense, else open addressing (the host parser's IdIndex, restated)
+int hc_text_set_ids(hc_ctx* c, const uint64_t* read_ids, uint32_t n_reads) {
+    if (!c || (n_reads && !read_ids)) return fail(HC_ERR_ARG, "hc_text_set_ids: null argument");
+    HC_HIP(hipSetDevice(c->device));
+    c->have_ids = false;
+    uint64_t max_id = 0;
+    for (uint32_t i = 0; i < n_reads; i++) max_id = read_ids[i] > max_id ? read_ids[i] : max_id;
+    std::vector<uint32_t> table;
+    std::vector<uint64_t> keys;
+    if (n_reads == 0 || max_id < 8ull * n_reads + 1024) {
+        c->id_direct = 1;
+        table.assign(n_reads ? (size_t)max_id + 1 : 1, 0xFFFFFFFFu);
+        for (uint32_t i = 0; i < n_reads; i++)
+            if (table[read_ids[i]] == 0xFFFFFFFFu) table[read_ids[i]] = i;
+        c->id_size = n_reads ? max_id + 1 : 0;
+        c->id_shift = 0;
+    } else {
+        c->id_direct = 0;
+        size_t cap = 16;
+        int bits = 4;
+        while (cap < 2 * (size_t)n_reads) {
+            cap <<= 1;
+            bits++;
+        }
+        c->id_shift = 64 - bits;
+        c->id_size = cap;
+        table.assign(cap, 0xFFFFFFFFu);
+        keys.assign(cap, 0);
+        for (uint32_t i = 0; i < n_reads; i++) {
+            const uint64_t id = read_ids[i];
+            uint64_t h = (id * 0x9E3779B97F4A7C15ull) >> c->id_shift;
+            while (table[h] != 0xFFFFFFFFu && keys[h] != id) h = (h + 1) & (cap - 1);
+            if (table[h] == 0xFFFFFFFFu) {
+                table[h] = i;
+                keys[h] = id;
+            }
+        }
+    }
+    int rc;
+    if ((rc = c->id_table.ensure(table.size() * 4)) != HC_OK) return rc;
+    HC_HIP(hipMemcpy(c->id_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    if (!keys.empty()) {
+        if ((rc = c->id_keys.ensure(keys.size() * 8)) != HC_OK) return rc;
+        HC_HIP(hipMemcpy(c->id_keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+    }
+    c->have_ids = true;
+    return HC_OK;
+}
+
+int hc_textblock_create(hc_ctx* c, uint64_t max_bytes, hc_textblock** out) {
+    if (!c || !out || max_bytes < 64 || max_bytes >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_textblock_create: bad argument");
+    *out = nullptr;
+    HC_HIP(hipSetDevice(c->device));
+    hc_textblock* b = new (std::nothrow) hc_textblock();
+    if (!b) return fail(HC_ERR_NOMEM, "hc_textblock_create: host allocation failed");
+    b->ctx = c;
+    b->max_bytes = max_bytes;
+    b->max_lines = (uint32_t)(max_bytes / 24 + 16);  // a plain line has at least 26 bytes with its newline; more lines: the host's block
+    const uint32_t n_tiles = (uint32_t)((max_bytes + 4095) / 4096);
+    const size_t L = b->max_lines;
+    b->row_cap = b->max_lines / 8 + 4096;  // a few per cent of the lines survive scoring in real files
+    const size_t RC = b->row_cap;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+    };
+    ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    ok(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    ok(hipHostMalloc((void**)&b->h_text, max_bytes + 64, hipHostMallocDefault));
+    ok(hipMalloc((void**)&b->d_text, max_bytes + 64));
+    ok(hipMalloc((void**)&b->d_tile_cnt, (size_t)(n_tiles + 1) * 4));
+    ok(hipMalloc((void**)&b->d_tile_off, (size_t)(n_tiles + 1) * 4));
+    ok(hipMalloc((void**)&b->d_line_start, (L + 2) * 4));
+    ok(hipMalloc((void**)&b->d_cands, (L + 256) * sizeof(hc_cand_rec)));
+    ok(hipMalloc((void**)&b->d_lines, L * sizeof(hc_line_rec)));
+    ok(hipMalloc((void**)&b->d_out, L * sizeof(hc_result_rec)));
+    ok(hipMalloc((void**)&b->d_counters, hc::kTextCounters * sizeof(unsigned long long)));
+    ok(hipHostMalloc((void**)&b->h_rows, RC * sizeof(hc_gather_row), hipHostMallocMapped));
+    ok(hipHostMalloc((void**)&b->h_row_lines, RC * sizeof(hc_line_rec), hipHostMallocMapped));
+    ok(hipHostMalloc((void**)&b->h_rejects, RC * sizeof(hc_text_reject), hipHostMallocMapped));
+    ok(hipHostMalloc((void**)&b->h_counters, hc::kTextCounters * sizeof(unsigned long long), hipHostMallocDefault));
+    if (e != hipSuccess) {
+        hc_textblock_destroy(b);
+        return fail(HC_ERR_HIP, std::string("hc_textblock_create: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return HC_OK;
+}
+
+char* hc_textblock_buffer(hc_textblock* b) { return b ? b->h_text : nullptr; }
+
+int hc_textblock_destroy(hc_textblock* b) {
+    if (!b) return HC_OK;
+    (void)hipSetDevice(b->ctx->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (void* p : {(void*)b->d_text, (void*)b->d_tile_cnt, (void*)b->d_tile_off, (void*)b->d_line_start, (void*)b->d_cands, (void*)b->d_lines,
+                    (void*)b->d_out, (void*)b->d_counters})
+        if (p) (void)hipFree(p);
+    for (void* p : {(void*)b->h_text, (void*)b->h_rows, (void*)b->h_row_lines, (void*)b->h_rejects, (void*)b->h_counters})
+        if (p) (void)hipHostFree(p);
+    if (b->done) (void)hipEventDestroy(b->done);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return HC_OK;
+}
+
+int hc_textblock_submit(hc_textblock* b, uint64_t n_bytes, uint64_t first_line_no, uint64_t base_index) {
+    if (!b) return fail(HC_ERR_ARG, "hc_textblock_submit: null block");
+    hc_ctx* c = b->ctx;
+    if (!c->have_reads || !c->have_ids) return fail(HC_ERR_STATE, "hc_textblock_submit: hc_set_reads and hc_text_set_ids come first");
+    if (b->in_flight) return fail(HC_ERR_STATE, "hc_textblock_submit: the block is still in flight (hc_textblock_wait first)");
+    if (n_bytes > b->max_bytes) return fail(HC_ERR_ARG, "hc_textblock_submit: more text than the block was created for");
+    HC_HIP(hipSetDevice(c->device));
+    hipStream_t s = b->stream;
+    memset(b->h_text + n_bytes, 0, 64);  // the 16-byte loads of the last tile read past the text: no stray newline there
+    HC_HIP(hipMemsetAsync(b->d_counters, 0, hc::kTextCounters * sizeof(unsigned long long), s));
+    if (n_bytes) {
+        HC_HIP(hipMemcpyAsync(b->d_text, b->h_text, n_bytes + 64, hipMemcpyHostToDevice, s));
+        HC_HIP(hc::launch_text_lines(b->d_text, n_bytes, b->d_tile_cnt, b->d_tile_off, b->max_lines, b->d_line_start, b->d_counters, s));
+        hc::TextParams prm;
+        prm.n_bytes = n_bytes;
+        prm.first_line_no = first_line_no;
+        prm.max_overlaps = c->settings.max_overlaps;
+        prm.max_lines = b->max_lines;
+        prm.min_overlap_len = c->settings.min_overlap_len;
+        prm.min_overlap_perc = c->settings.min_overlap_perc;
+        prm.relax_pe = (c->settings.flags & HC_FLAG_RELAX_PE_EDGES) ? 1u : 0u;
+        prm.reject_cap = b->row_cap;
+        prm.pad = 0;
+        hc::IdTable ids;
+        ids.table = c->id_table.as<uint32_t>();
+        ids.keys = c->id_keys.as<uint64_t>();
+        ids.size = c->id_size;
+        ids.shift = c->id_shift;
+        ids.direct = c->id_direct;
+        void *d_rejects = nullptr, *d_rows = nullptr, *d_row_lines = nullptr;
+        HC_HIP(hipHostGetDevicePointer(&d_rejects, b->h_rejects, 0));
+        HC_HIP(hipHostGetDevicePointer(&d_rows, b->h_rows, 0));
+        HC_HIP(hipHostGetDevicePointer(&d_row_lines, b->h_row_lines, 0));
+        HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, s));
+        // the scoring kernel on the records the parse kernel left behind; how many there are is only known on the device
+        int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_cands, b->max_lines, b->d_out, s, false, (hc_gather_row*)d_rows,
+                              b->d_counters + hc::kTextRows, b->row_cap, base_index, b->d_counters + hc::kTextLines, b->d_lines,
+                              (hc_line_rec*)d_row_lines);
+        if (rc) return rc;
+    }
+    HC_HIP(hipMemcpyAsync(b->h_counters, b->d_counters, hc::kTextCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HC_HIP(hipEventRecord(b->done, s));
+    b->in_flight = true;
+    return HC_OK;
+}
+
+int hc_textblock_wait(hc_textblock* b, hc_text_result* out) {
+    if (!b || !out) return fail(HC_ERR_ARG, "hc_textblock_wait: null argument");
+    memset(out, 0, sizeof *out);
+    if (!b->in_flight) return fail(HC_ERR_STATE, "hc_textblock_wait: nothing was submitted");
+    HC_HIP(hipSetDevice(b->ctx->device));
+    HC_HIP(hipEventSynchronize(b->done));
+    b->in_flight = false;
+    const unsigned long long* k = b->h_counters;
+    out->n_lines = k[hc::kTextLines];
+    out->lines_read = k[hc::kTextRead];
+    out->n_nonplain = k[hc::kTextNonPlain];
+    out->n_unknown_id = k[hc::kTextUnknownId];
+    out->needs_host = (k[hc::kTextOverflow] || k[hc::kTextNonPlain] || k[hc::kTextUnknownId] || k[hc::kTextRows] > b->row_cap ||
+                       k[hc::kTextRejectSlots] > b->row_cap)
+                          ? 1
+                          : 0;
+    if (out->needs_host) return HC_OK;
+    out->self_overlaps = k[hc::kTextSelf];
+    out->silently_dropped = k[hc::kTextSilent];
+    out->prefilter_rejected = k[hc::kTextReject];
+    out->scored = k[hc::kTextPass];
+    const uint64_t n_rows = k[hc::kTextRows], n_rej = k[hc::kTextRejectSlots];
+    // the kernels append in no particular order; the stage consumes in file order
+    b->rows.resize(n_rows);
+    for (uint64_t i = 0; i < n_rows; i++) {
+        b->rows[i].row = b->h_rows[i];
+        b->rows[i].line = b->h_row_lines[i];
+    }
+    std::sort(b->rows.begin(), b->rows.end(), [](const hc_text_row& x, const hc_text_row& y) { return x.row.index < y.row.index; });
+    std::sort(b->h_rejects, b->h_rejects + n_rej, [](const hc_text_reject& x, const hc_text_reject& y) { return x.line_index < y.line_index; });
+    out->rows = b->rows.data();
+    out->n_rows = n_rows;
+    out->rejected = b->h_rejects;
+    out->n_rejected = n_rej;
+    return HC_OK;
+}
+
+}  // extern "C"

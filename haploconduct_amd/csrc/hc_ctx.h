@@ -18,7 +18,8 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
                          hipStream_t stream);
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const void* in, uint64_t n,
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, hc_gather_row* rows,
-                        unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream);
+                        unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
+                        const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr);
 hipError_t set_score_kernel_lds_limit();
 // hc_util_kernels.hip
 size_t compact_temp_bytes(uint32_t n);
@@ -120,6 +121,11 @@ struct hc_ctx {
     uint32_t* d_compact_idx = nullptr;
     hc_result_rec* d_compact_res = nullptr;
     uint64_t compact_cap = 0;
+    // hc_text_set_ids (hc_api_text.cpp): FastqStorage::m_ID_to_index on the device
+    hc_scratch id_table, id_keys;
+    uint64_t id_size = 0;
+    int id_shift = 0, id_direct = 1;
+    bool have_ids = false;
     // hc_graph_resolve / hc_graph_fetch (hc_api_stage.cpp): device-resident result of the last resolve
     struct Graph {
         hc_scratch adm, E, key0, key1, idx0, idx1, keep, incl, tied, counters, surv, k32a, k32b, k64a, k64b, tmp_idx, o_out, o_in,
@@ -131,4 +137,5 @@ struct hc_ctx {
 };
 
 int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, hipStream_t s, bool reorder,
-                 hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index);
+                 hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index,
+                 const unsigned long long* n_dev = nullptr, const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr);

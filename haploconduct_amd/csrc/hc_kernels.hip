@@ -412,12 +412,12 @@ __device__ __forceinline__ hc_result_rec score_candidate(const ScoreParams& prm,
                                                          const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word, int ns,
                                                          const Sub& sub0, const Sub& sub1, uint64_t i,
                                                          hc_result_rec* __restrict__ out) {
-    if (ns == 0) {
+    if (ns <= 0) {  // malformed record: an error; "skip" record (a line dropped before scoring): a dropped result
         hc_result_rec res;
         res.x1 = -__builtin_inf();
         res.x2 = __builtin_nan("");
         res.mm = 1;
-        res.n_cls = 1u | (HC_CLS_ERROR << 28);
+        res.n_cls = 1u | ((ns == 0 ? HC_CLS_ERROR : HC_CLS_DROP) << 28);
         out[i] = res;
         return res;
     }
@@ -443,6 +443,9 @@ struct RowSink {
     unsigned long long* count;
     uint64_t cap;
     uint64_t base_index;
+    // the device parser's stage: the parsed line of every appended row travels with it (lines_out[pos] = lines_in[i])
+    const hc_line_rec* lines_in;
+    hc_line_rec* lines_out;
 };
 
 // Called by ALL lanes of the workgroup (uniform control flow; `valid` = this lane scored candidate i).
@@ -476,6 +479,13 @@ __device__ __forceinline__ void append_rows_block(const RowSink& sink, bool vali
             r.mm = res.mm;
             r.n_cls = res.n_cls;
             sink.rows[pos] = r;
+            if (sink.lines_in) {  // 48 bytes as three 16-byte pieces
+                const uint4* a = (const uint4*)(sink.lines_in + i);
+                uint4* b = (uint4*)(sink.lines_out + pos);
+                b[0] = a[0];
+                b[1] = a[1];
+                b[2] = a[2];
+            }
         }
     }
     __syncthreads();  // lds4 is reused by the next iteration
@@ -488,6 +498,10 @@ template <typename SymT, int G, int LG, bool BAL>
 __device__ __forceinline__ void score_kernel_body(const StoreView& st, const ScoreParams& prm, const double* __restrict__ lut_g,
                                                   const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
                                                   const uint32_t* __restrict__ perm, const RowSink& sink) {
+    if (prm.n_dev) {  // the number of records is only known on the device (lines of a block of text): at most n of them
+        const uint64_t nd = *prm.n_dev;
+        n = nd < n ? nd : n;
+    }
     extern __shared__ __attribute__((aligned(16))) double lut_s[];
     const uint32_t lut_n = st.lut_bytes >> 3;
     for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
@@ -680,7 +694,8 @@ void launch_lg(int group, const ScoreLaunch& a) {
 // rows (RowSink above).
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const void* in, uint64_t n,
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, hc_gather_row* rows,
-                        unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream) {
+                        unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
+                        const hc_line_rec* lines_in, hc_line_rec* lines_out) {
     if (n == 0) return hipSuccess;
     const size_t lds = st.lut_bytes + (17 * (st.symbytes == 1 ? 4 : 8) + 392) * sizeof(uint32_t);
     const uint32_t lg = lut_lg(st.K);
@@ -694,7 +709,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     uint64_t blocks = (n + wg - 1) / wg;
     const uint64_t grid_cap = (uint64_t)n_cu * blocks_per_cu * 4;  // grid-stride beyond this
     if (blocks > grid_cap) blocks = grid_cap;
-    const ScoreLaunch a{st, prm, lut_g, in, n, out, perm, RowSink{rows, row_count, cap, base_index}, (uint32_t)blocks, wg, lds, stream};
+    const ScoreLaunch a{st, prm, lut_g, in, n, out, perm, RowSink{rows, row_count, cap, base_index, lines_in, lines_out}, (uint32_t)blocks, wg, lds, stream};
     if (st.symbytes == 2) launch_lg<uint16_t, 5>(fetch_group, a);
     else if (lg == 3) launch_lg<uint8_t, 3>(fetch_group, a);
     else if (lg == 4) launch_lg<uint8_t, 4>(fetch_group, a);

@@ -16,6 +16,7 @@ struct Cand {
     uint32_t read1, read2, pos1, pos2;
     uint32_t ori1, ori2;  // 1 = "+"
     uint32_t ord;         // '-', '1', '2'; anything else is malformed for a p-p overlap
+    uint32_t skip;        // compact records only: not a candidate (a line the device parser dropped before scoring)
 };
 
 // fmt: HC_REC_FULL (hc_overlap_rec) or HC_REC_COMPACT (hc_cand_rec); wave-uniform
@@ -27,6 +28,7 @@ __device__ __forceinline__ Cand load_cand(const void* __restrict__ in, uint64_t 
         c.read2 = a.y;
         c.pos1 = a.z & HC_CAND_POS_MASK;
         c.pos2 = a.w & HC_CAND_POS_MASK;
+        c.skip = a.w & HC_CAND_SKIP;
         c.ori1 = (a.z >> 28) & 1u;
         c.ori2 = (a.z >> 29) & 1u;
         const uint32_t oc = a.z >> 30;
@@ -41,6 +43,7 @@ __device__ __forceinline__ Cand load_cand(const void* __restrict__ in, uint64_t 
         c.ori1 = (w & 0xFFu) ? 1u : 0u;
         c.ori2 = ((w >> 8) & 0xFFu) ? 1u : 0u;
         c.ord = (w >> 16) & 0xFFu;
+        c.skip = 0;
     }
     return c;
 }
@@ -93,9 +96,10 @@ __device__ __forceinline__ Sub make_sub(const View& A, const View& B, uint32_t p
     return s;
 }
 
-// Returns the number of sub-overlaps (1 or 2); 0 = malformed record.
+// Returns the number of sub-overlaps (1 or 2); 0 = malformed record; -1 = a "skip" record (nothing to score).
 template <int SB>
 __device__ __forceinline__ int resolve(const StoreView& st, const Cand& r, Sub& s0, Sub& s1) {
+    if (r.skip) return -1;
     if (r.read1 >= st.n_reads || r.read2 >= st.n_reads || r.read1 == r.read2) return 0;
     const ReadDesc d1 = load_desc(st.reads + r.read1);
     const ReadDesc d2 = load_desc(st.reads + r.read2);

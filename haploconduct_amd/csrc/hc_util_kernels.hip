@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void count_positions_kernel(StoreView st, uint
         const int ns = st.symbytes == 1 ? resolve<1>(st, rec, s0, s1) : resolve<2>(st, rec, s0, s1);
         if (ns >= 1) pos += sub_positions(s0, min_read_len);
         if (ns == 2) pos += sub_positions(s1, min_read_len);
-        subs += (unsigned long long)ns;
+        if (ns > 0) subs += (unsigned long long)ns;
     }
     for (int off = 32; off > 0; off >>= 1) {
         pos += __shfl_down(pos, off, 64);

@@ -54,6 +54,8 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
     : program_settings(ps), fastq_storage(std::move(fastq)), overlap_graph(std::move(graph)) {
     if (const char* m = getenv("HC_INSERT_MODE")) m_serial_insert = std::string(m) == "serial";
     if (const char* m = getenv("HC_RESOLVE")) m_host_resolve = std::string(m) == "host";
+    if (const char* m = getenv("HC_PARSE")) m_host_parse = std::string(m) == "host";
+    if (const char* m = getenv("HC_TEXT_BLOCK")) m_text_block = std::max<size_t>(4096, (size_t)strtoull(m, nullptr, 10));
     m_cs = to_hc_settings(ps);
     const FastqStorage& f = *fastq_storage;
     try {
@@ -66,6 +68,11 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
             check(hc_set_reads(dev.ctx, f.bases().data(), f.quals().data(), f.seq_off().data(), f.read_first_seq().data(),
                                f.get_readcount()),
                   "hc_set_reads");
+            if (!m_host_parse) {  // the device's text parser looks read ids up itself
+                std::vector<uint64_t> ids(f.m_read_vec.size());
+                for (size_t r = 0; r < ids.size(); r++) ids[r] = f.m_read_vec[r]->get_read_id();
+                check(hc_text_set_ids(dev.ctx, ids.data(), (uint32_t)ids.size()), "hc_text_set_ids");
+            }
         }
     } catch (...) {
         for (Device& d : m_dev) hc_destroy(d.ctx);
@@ -77,6 +84,7 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
 EdgeCalculator::~EdgeCalculator() {
     for (Device& d : m_dev) {
         for (hc_block* b : d.blk) hc_block_destroy(b);
+        for (hc_textblock* b : d.tblk) hc_textblock_destroy(b);
         hc_destroy(d.ctx);
     }
 }
@@ -467,28 +475,304 @@ void EdgeCalculator::resolve_on_host() {
     }
 }
 
-// src/EdgeCalculator.cpp:561-666
-void EdgeCalculator::run_stage(bool then_sort) {
-    collect_read_info();  // vertex ids may have been assigned since the last call
-    stats = Stats();
-    // An empty graph (every pipeline call) takes the bulk path: the admitted candidates are collected in sequence
-    // order and resolved at once after the last block.  A graph that already holds edges, or HC_INSERT_MODE=serial,
-    // takes the per-edge insert of the reference's serial half.
-    m_collect = !m_serial_insert && overlap_graph->getEdgeCount() == 0 &&
-                EdgeSlotIndex::representable(overlap_graph->adj_out.size(), overlap_graph->adj_out.size());
-    m_admitted.clear();
-    m_device_resolve = m_collect && !m_host_resolve && !program_settings.add_duplicates;  // vertices by orientation: host route
-    for (const ReadInfo& x : m_read_info)
-        if (x.vertex_set && x.vertex >= ((node_id_t)1 << 31)) m_device_resolve = false;
-    if (m_device_resolve) check(hc_graph_begin(m_ctx), "hc_graph_begin");
-    std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
-    std::vector<Overlap> rejected;
-    OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
-    if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
-    if (program_settings.verbose) puts("reading overlaps file... ");
+static Overlap overlap_of(const hc_line_rec& l) {
+    Overlap o;
+    o.m_id1 = l.id1;
+    o.m_id2 = l.id2;
+    o.m_pos1 = l.pos1;
+    o.m_pos2 = l.pos2;
+    o.m_perc1 = l.perc1;
+    o.m_perc2 = l.perc2;
+    o.m_len1 = l.len1;
+    o.m_len2 = l.len2;
+    o.m_ord = (char)l.ord;
+    o.m_ori1 = (char)l.ori1;
+    o.m_ori2 = (char)l.ori2;
+    o.m_type1 = (char)l.type1;
+    o.m_type2 = (char)l.type2;
+    return o;
+}
+
+// finalize_block for a block the device parsed: every row carries the parsed line it came from
+void EdgeCalculator::finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out) {
+    out.admitted.clear();
+    out.nonedge_text.clear();
+    out.nonedges = out.ambiguous = 0;
+    if (n_rows == 0) return;
+    struct Piece {
+        std::vector<hc_admit_rec> admitted;
+        std::string nonedge_text;
+        uint64_t nonedges = 0, ambiguous = 0;
+        FatalError error{0, ""};
+    };
+    auto build = [&](uint64_t kb, uint64_t ke, Piece& pc) {
+        char linebuf[192];
+        pc.admitted.reserve((size_t)(ke - kb));
+        for (uint64_t k = kb; k < ke; k++) {
+            const hc_result_rec& r = *(const hc_result_rec*)&rows[k].row.x1;
+            const hc_line_rec& l = rows[k].line;
+            uint32_t cls = HC_RES_CLS(r);
+            if (cls == HC_CLS_ERROR) {
+                pc.error = FatalError{HC_ERR_DATA, "overlap " + overlap_of(l).get_overlap_line() + " touches an invalid base or quality byte"};
+                return;
+            }
+            if (cls == HC_CLS_NONEDGE) {  // :410-413
+                pc.nonedge_text.append(linebuf, overlap_of(l).write_line(linebuf));
+                pc.nonedges++;
+                continue;
+            }
+            double score, mismatch_rate;
+            if (cls == HC_CLS_AMBIG) pc.ambiguous++;
+            const int st = hc_finalize(&m_cs, &r, &score, &mismatch_rate, &cls);  // exp() with the host libm
+            if (st != HC_OK) {
+                pc.error = FatalError{st, "hc_finalize"};
+                return;
+            }
+            if (cls == HC_CLS_DROP) continue;
+            if (cls == HC_CLS_NONEDGE) {
+                pc.nonedge_text.append(linebuf, overlap_of(l).write_line(linebuf));
+                pc.nonedges++;
+                continue;
+            }
+            hc_admit_rec a;
+            if (!ids.find(l.id1, a.read1) || !ids.find(l.id2, a.read2)) {  // the device found them
+                pc.error = FatalError{HC_ERR_STATE, "device-parsed line names an unknown read"};
+                return;
+            }
+            a.score = score;
+            a.pos1 = l.pos1;
+            a.pos2 = l.pos2;
+            a.mm = r.mm;
+            a.n = HC_RES_N(r);
+            a.len1 = l.len1;
+            a.len2 = l.len2;
+            a.perc = l.perc2 > 0 ? (uint32_t)(0.5 * (l.perc1 + l.perc2)) : l.perc1;  // Overlap::get_perc, src/Overlap.h:203-210
+            a.ori1 = l.ori1 == '+';
+            a.ori2 = l.ori2 == '+';
+            a.ord = l.ord;
+            a.pad = 0;
+            pc.admitted.push_back(a);
+        }
+    };
+    static const unsigned build_cap = getenv("HC_BUILD_THREADS") ? (unsigned)atoi(getenv("HC_BUILD_THREADS")) : 8u;  // experiment knob
+    unsigned T = program_settings.n_threads > 1 ? std::min<unsigned>(program_settings.n_threads, std::max(1u, build_cap)) : 1;
+    if (n_rows < 4096) T = 1;
+    std::vector<Piece> pieces(T);
+    if (T == 1) {
+        build(0, n_rows, pieces[0]);
+    } else {
+        if (!m_build_pool || m_build_pool->workers() + 1 < T) m_build_pool.reset(new WorkerPool(T - 1));
+        m_build_pool->run(T, [&](unsigned int t) {
+            try {
+                build(n_rows * t / T, n_rows * (t + 1) / T, pieces[t]);
+            } catch (const FatalError& e) {
+                pieces[t].error = e;
+            } catch (const std::exception& e) {  // nothing may leave a pool thread
+                pieces[t].error = FatalError{HC_ERR_NOMEM, e.what()};
+            }
+        });
+    }
+    size_t n_adm = 0;
+    for (const Piece& pc : pieces) {
+        if (pc.error.status) throw pc.error;  // the first one in sequence order
+        n_adm += pc.admitted.size();
+    }
+    out.admitted.reserve(n_adm);
+    for (Piece& pc : pieces) {
+        out.admitted.insert(out.admitted.end(), pc.admitted.begin(), pc.admitted.end());
+        out.nonedge_text += pc.nonedge_text;
+        out.nonedges += pc.nonedges;
+        out.ambiguous += pc.ambiguous;
+    }
+}
+
+// The file's TEXT sent to the device block by block: the caller's thread copies the next stretch of
+// the file — cut behind a newline — into the page-locked buffer of a text block and submits it (split into lines,
+// parse, --max_ov, prefilter, id lookup and scoring all happen on the device, hc_textblock_*); the collector thread
+// waits for the blocks in file order and runs the serial half on what survived.  A block the device reports as
+// unusual (a line that is not plain, an id that is not in the FASTQ input, ...) is tokenised by the host parser and
+// scored as a block of records, synchronously, at its place in the order: every error and every malformed-line message
+// comes out as from the host-parsed pipeline.
+void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc) {
+    const size_t N = m_dev.size();
+    const size_t R = 2 * N + 1;
+    const size_t B = m_text_block;
+    for (Device& d : m_dev)
+        for (hc_textblock*& b : d.tblk)
+            if (!b) check(hc_textblock_create(d.ctx, B, &b), "hc_textblock_create");
+    struct Slot {
+        hc_textblock* tb = nullptr;  // nullptr: the host's block (nothing was submitted)
+        size_t begin = 0, end = 0;
+        uint64_t first_line = 0, n_lines = 0;
+    };
+    std::vector<Slot> ring(R);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t submitted = 0, consumed = 0;
+    bool producer_done = false;
+    std::atomic<bool> collector_failed{false};
+    FatalError collector_error{0, ""};
+    double t_collect = 0;
+    uint64_t n_host_blocks = 0;
+    std::thread collector([&] {
+        BlockOut out;
+        ParsedBatch::RecStorage pinned;
+        pinned.ctx = m_ctx;
+        pinned.alloc = [](void* ctx, size_t n) -> hc_cand_rec* {
+            void* p = nullptr;
+            check(hc_host_alloc((hc_ctx*)ctx, &p, n * sizeof(hc_cand_rec)), "hc_host_alloc");
+            return (hc_cand_rec*)p;
+        };
+        pinned.release = [](void* ctx, hc_cand_rec* p) { hc_host_free((hc_ctx*)ctx, p); };
+        ParsedBatch host_batch(pinned);
+        for (size_t k = 0;; k++) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return submitted > k || producer_done; });
+                if (submitted <= k) return;
+            }
+            const Slot sl = ring[k % R];
+            if (!collector_failed) {
+                try {
+                    const double t0 = now_s();
+                    hc_text_result tr;
+                    memset(&tr, 0, sizeof tr);
+                    tr.needs_host = 1;
+                    if (sl.tb) check(hc_textblock_wait(sl.tb, &tr), "hc_textblock_wait");
+                    if (tr.needs_host) {  // the host's tokeniser + Overlap constructor own this block
+                        n_host_blocks++;
+                        parser.parse_range(sl.begin, sl.end, sl.first_line, host_batch, rejected, pc, /*print_malformed=*/true);
+                        const size_t n = host_batch.size();
+                        const hc_gather_row* rows = nullptr;
+                        uint64_t n_rows = 0;
+                        if (n) {
+                            Device& dev = m_dev[0];
+                            if (n > m_block_cap || !dev.blk[0]) {
+                                hc_block_destroy(dev.blk[0]);
+                                dev.blk[0] = nullptr;
+                                m_block_cap = std::max(m_block_cap, n + n / 4);
+                                check(hc_block_create(dev.ctx, m_block_cap, &dev.blk[0]), "hc_block_create");
+                            }
+                            check(hc_block_submit(dev.blk[0], host_batch.recs, n, 0), "hc_block_submit");
+                            check(hc_block_wait(dev.blk[0], &rows, &n_rows), "hc_block_wait");
+                            stats.scored += n;
+                        }
+                        finalize_block(host_batch, rows, n_rows, 0, out);
+                    } else {
+                        pc.lines_read += tr.lines_read;
+                        pc.self_overlaps += tr.self_overlaps;
+                        pc.silently_dropped += tr.silently_dropped;
+                        pc.prefilter_rejected += tr.prefilter_rejected;
+                        stats.scored += tr.scored;
+                        for (uint64_t j = 0; j < tr.n_rejected; j++) rejected.push_back(overlap_of(tr.rejected[j].line));
+                        finalize_text_block(parser.ids(), tr.rows, tr.n_rows, out);
+                    }
+                    t_collect += now_s() - t0;
+                    consume_block(out);
+                } catch (const FatalError& e) {
+                    collector_error = e;
+                    collector_failed = true;
+                } catch (const std::exception& e) {
+                    collector_error = FatalError{HC_ERR_NOMEM, e.what()};
+                    collector_failed = true;
+                }
+            } else if (sl.tb) {  // drain: the block object must not stay in flight
+                hc_text_result tr;
+                (void)hc_textblock_wait(sl.tb, &tr);
+            }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                consumed = k + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    auto stop_collector = [&] {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            producer_done = true;
+        }
+        cv.notify_all();
+        if (collector.joinable()) collector.join();
+    };
+    try {
+        size_t pos = 0;
+        uint64_t line_no = 0;
+        const size_t size = parser.size();
+        for (size_t k = 0; pos < size && line_no < program_settings.max_overlaps; k++) {  // `&& i < max_overlaps`, :581
+            {  // the block object's previous user (block k - 2N) has been consumed
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return consumed + 2 * N > k; });
+                if (collector_failed) break;
+            }
+            Slot sl;
+            sl.begin = pos;
+            sl.first_line = line_no;
+            Device& dev = m_dev[k % N];
+            hc_textblock* tb = dev.tblk[(k / N) % 2];
+            const double t0 = now_s();
+            size_t end = std::min(size, pos + B);
+            uint64_t newlines = 0;
+            parser.copy_range(hc_textblock_buffer(tb), pos, end, newlines);
+            if (end < size) {  // cut behind the last newline of the stretch
+                const char* buf = hc_textblock_buffer(tb);
+                size_t cut = end - pos;
+                while (cut > 0 && buf[cut - 1] != '\n') cut--;
+                if (cut == 0) {  // one line longer than a block: the host's (its parser has no such limit)
+                    sl.end = parser.line_end_at(end);
+                    sl.tb = nullptr;
+                    // its line count is only known once parsed: everything up to its end goes to the host in one piece,
+                    // and with it the rest of the file, so that line numbers stay exact
+                    sl.end = size;
+                    stats.t_parse += now_s() - t0;
+                    ring[k % R] = sl;
+                    pos = size;
+                    {
+                        std::lock_guard<std::mutex> g(mu);
+                        submitted = k + 1;
+                    }
+                    cv.notify_all();
+                    break;
+                }
+                end = pos + cut;  // the bytes behind the cut are copied again with the next block
+            }
+            sl.end = end;
+            sl.n_lines = newlines;  // of the whole stretch; corrected below when it was cut
+            if (end < std::min(size, pos + B)) {
+                const char* buf = hc_textblock_buffer(tb);
+                sl.n_lines -= (uint64_t)std::count(buf + (end - pos), buf + (std::min(size, pos + B) - pos), '\n');
+            }
+            if (end == size) {  // a last piece without a newline is a line too (std::getline)
+                const char* buf = hc_textblock_buffer(tb);
+                if (end > pos && buf[end - pos - 1] != '\n') sl.n_lines++;
+            }
+            stats.t_parse += now_s() - t0;
+            check(hc_textblock_submit(tb, end - pos, line_no, 0), "hc_textblock_submit");
+            sl.tb = tb;
+            ring[k % R] = sl;
+            pos = end;
+            line_no += sl.n_lines;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                submitted = k + 1;
+            }
+            cv.notify_all();
+        }
+    } catch (...) {
+        stop_collector();
+        throw;
+    }
+    stop_collector();
+    if (collector_failed) throw collector_error;
+    stats.t_score = t_collect;
+    if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] device-parsed pipeline: %lu block(s) went to the host parser\n", (unsigned long)n_host_blocks);
+}
+
+// The file tokenised on the host's threads (HC_PARSE=host; also what a block the device's parser does not read goes
+// through).
+void EdgeCalculator::score_host_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc) {
     size_t overlaps_per_vec = 250000;  // the reference batches 1,000,000 (:571); batch boundaries do not influence the result
     if (const char* e = getenv("HC_STAGE_BLOCK")) overlaps_per_vec = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 10));  // experiment knob
-
     // The pipeline.  The caller's thread tokenises block k (on the parser's worker threads) and submits it to device
     // k mod N; the collector thread waits for the blocks in file order, finalises what the device kept of them and
     // runs the serial half.  Every stage consumes the blocks strictly in file order, so the graph, the counters and
@@ -511,7 +795,6 @@ void EdgeCalculator::run_stage(bool then_sort) {
     };
     std::vector<std::unique_ptr<Slot>> ring;
     for (size_t r = 0; r < R; r++) ring.emplace_back(new Slot(pinned));
-    ParseCounters pc;
 
     std::mutex mu;
     std::condition_variable cv;
@@ -619,6 +902,30 @@ void EdgeCalculator::run_stage(bool then_sort) {
     stop_collector();
     if (collector_failed) throw collector_error;
     stats.t_score = t_collect;
+}
+
+// src/EdgeCalculator.cpp:561-666
+void EdgeCalculator::run_stage(bool then_sort) {
+    collect_read_info();  // vertex ids may have been assigned since the last call
+    stats = Stats();
+    // An empty graph (every pipeline call) takes the bulk path: the admitted candidates are collected in sequence
+    // order and resolved at once after the last block.  A graph that already holds edges, or HC_INSERT_MODE=serial,
+    // takes the per-edge insert of the reference's serial half.
+    m_collect = !m_serial_insert && overlap_graph->getEdgeCount() == 0 &&
+                EdgeSlotIndex::representable(overlap_graph->adj_out.size(), overlap_graph->adj_out.size());
+    m_admitted.clear();
+    m_device_resolve = m_collect && !m_host_resolve && !program_settings.add_duplicates;  // vertices by orientation: host route
+    for (const ReadInfo& x : m_read_info)
+        if (x.vertex_set && x.vertex >= ((node_id_t)1 << 31)) m_device_resolve = false;
+    if (m_device_resolve) check(hc_graph_begin(m_ctx), "hc_graph_begin");
+    std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
+    std::vector<Overlap> rejected;
+    OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
+    if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
+    if (program_settings.verbose) puts("reading overlaps file... ");
+    ParseCounters pc;
+    if (m_host_parse) score_host_parsed(parser, rejected, pc);
+    else score_device_parsed(parser, rejected, pc);
     bool sorted_already = false;
     if (m_collect) {
         const double tr = now_s();

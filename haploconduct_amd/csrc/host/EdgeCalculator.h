@@ -87,7 +87,8 @@ private:
     // One device of the stage: a context with its own copy of the read store and the blocks it has in flight.
     struct Device {
         hc_ctx* ctx = nullptr;
-        hc_block* blk[2] = {nullptr, nullptr};
+        hc_block* blk[2] = {nullptr, nullptr};       // blocks of host-parsed records
+        hc_textblock* tblk[2] = {nullptr, nullptr};  // blocks of the file's text (the device parses)
     };
     // What the collector makes of one scored block, in sequence order.
     struct BlockOut {
@@ -96,6 +97,9 @@ private:
         uint64_t nonedges = 0, ambiguous = 0;
     };
     void run_stage(bool then_sort);
+    void score_host_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc);   // the file tokenised on host threads
+    void score_device_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc); // the file's text sent to the device
+    void finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out);
     void collect_read_info();
     void finalize_block(const ParsedBatch& batch, const hc_gather_row* rows, uint64_t n_rows, uint64_t base, BlockOut& out);
     void consume_block(BlockOut& out);  // serial half: insert (or collect) + nonedge_overlaps.txt, :431-555
@@ -112,6 +116,8 @@ private:
     size_t m_block_cap = 0;           // candidates the hc_block objects were created for
     bool m_serial_insert = false;     // HC_INSERT_MODE=serial: per-edge inserts even into an empty graph
     bool m_host_resolve = false;      // HC_RESOLVE=host: duplicate resolution on the host threads instead of the device
+    bool m_host_parse = false;        // HC_PARSE=host: the overlaps file is tokenised on the host threads instead of the device
+    size_t m_text_block = 16u << 20;  // bytes of text per device-parsed block (HC_TEXT_BLOCK)
     bool m_collect = false;           // this call collects the admitted candidates and resolves them after the last block
     bool m_device_resolve = false;    // ... on the device: every block's admitted records are appended there as they come
     std::vector<std::vector<hc_admit_rec>> m_admitted;  // admitted candidates of the whole file, block by block, in sequence order

@@ -213,10 +213,62 @@ bool OverlapsParser::next_batch(ParsedBatch& batch, size_t max_batch, std::vecto
     // block = up to max_batch * 40 bytes of text (a line is >= ~26 bytes), ending at a line end
     size_t block_end = m_pos + max_batch * 40;
     if (block_end >= m_size) block_end = m_size;
-    else {
-        const char* nl = (const char*)memchr(m_data + block_end, '\n', m_size - block_end);
-        block_end = nl ? (size_t)(nl - m_data) + 1 : m_size;
+    else block_end = line_end_at(block_end);
+    m_line_no += parse_range(m_pos, block_end, m_line_no, batch, rejected, c, print_malformed);
+    m_pos = block_end;
+    if (m_pos >= m_size || !(m_line_no < m_ps.max_overlaps)) m_done = true;
+    return true;
+}
+
+size_t OverlapsParser::line_end_at(size_t at) const {
+    if (at >= m_size) return m_size;
+    const char* nl = (const char*)memchr(m_data + at, '\n', m_size - at);
+    return nl ? (size_t)(nl - m_data) + 1 : m_size;
+}
+
+void OverlapsParser::copy_range(char* dst, size_t begin, size_t end, uint64_t& newlines) const {
+    std::lock_guard<std::mutex> pool_guard(m_pool_mu);
+    const size_t bytes = end - begin;
+    unsigned int T = m_threads;
+    if (bytes < (size_t)T * (1u << 18)) T = (unsigned int)(bytes >> 18) + 1;
+    std::vector<uint64_t> nl(T, 0);
+    std::vector<uint8_t> bad(T, 0);
+    auto body = [&](unsigned int t) {
+        const size_t a = begin + bytes * t / T, b = begin + bytes * (t + 1) / T;
+        size_t at = a;
+        while (at < b) {  // pread: the kernel copies out of the page cache, no page of a mapping is faulted in
+            const ssize_t k = pread(m_fd, dst + (at - begin), b - at, (off_t)at);
+            if (k <= 0) {
+                bad[t] = 1;
+                return;
+            }
+            at += (size_t)k;
+        }
+        nl[t] = (uint64_t)std::count(dst + (a - begin), dst + (b - begin), '\n');
+    };
+    if (T == 1 || !m_pool) {
+        for (unsigned int t = 0; t < T; t++) body(t);
+    } else {
+        m_pool->run(T, body);
     }
+    newlines = 0;
+    for (unsigned int t = 0; t < T; t++) {
+        if (bad[t]) throw FatalError{HC_ERR_IO, "Unable to read the overlaps file"};
+        newlines += nl[t];
+    }
+}
+
+// Parses bytes [m_pos, block_end) of the file with m_threads threads: the block is cut into segments at line
+// starts, the lines of each segment are numbered from a parallel newline count (so that the
+// max_overlaps line limit is honoured exactly), segments are parsed concurrently and concatenated in
+// file order.
+uint64_t OverlapsParser::parse_range(size_t range_begin, size_t block_end, uint64_t first_line, ParsedBatch& batch, std::vector<Overlap>& rejected,
+                                     ParseCounters& c, bool print_malformed) {
+    std::lock_guard<std::mutex> pool_guard(m_pool_mu);
+    batch.clear();
+    const size_t m_pos = range_begin;  // (the body below was written against the sequential reader's members)
+    const uint64_t m_line_no = first_line;
+    if (block_end <= m_pos) return 0;
     const size_t bytes = block_end - m_pos;
     unsigned int T = m_threads;
     if (bytes < (size_t)T * 65536) T = (unsigned int)(bytes / 65536) + 1;
@@ -308,10 +360,7 @@ bool OverlapsParser::next_batch(ParsedBatch& batch, size_t max_batch, std::vecto
         }
         rejected.insert(rejected.end(), sg.rejected.begin(), sg.rejected.end());
     }
-    m_pos = block_end;
-    m_line_no = line;
-    if (m_pos >= m_size || !(m_line_no < m_ps.max_overlaps)) m_done = true;
-    return true;
+    return line - m_line_no;
 }
 
 }  // namespace hc

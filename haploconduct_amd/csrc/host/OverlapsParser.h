@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <string>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../../include/hcedge.h"
@@ -136,12 +137,25 @@ public:
     // nonedge_overlaps.txt at the end, :654-660).  Returns false when the input is exhausted
     // (or max_overlaps lines have been read, :581).
     bool next_batch(ParsedBatch& batch, size_t max_batch, std::vector<Overlap>& rejected, ParseCounters& c, bool print_malformed);
+    // The same for the bytes [begin, end) of the file (begin at a line start, end behind a newline or at the end of the
+    // file), whose first line is line number first_line of the file; returns the number of lines in the range.  The
+    // device-parsing stage hands the blocks its kernels do not read (a line that is not plain) to this.
+    uint64_t parse_range(size_t begin, size_t end, uint64_t first_line, ParsedBatch& batch, std::vector<Overlap>& rejected, ParseCounters& c,
+                         bool print_malformed);
+    // The device-parsing stage reads the file itself: its size, the bytes [begin, end) copied to dst on the parser's
+    // threads (pread: no page of the mapping is touched) with the number of newlines among them, the end of the line
+    // that holds byte `at` (offset behind its newline, or the size of the file), and the id table.
+    size_t size() const { return m_size; }
+    void copy_range(char* dst, size_t begin, size_t end, uint64_t& newlines) const;
+    size_t line_end_at(size_t at) const;
+    const IdIndex& ids() const { return m_ids; }
 
 private:
     struct Segment;
     void parse_segment(Segment& seg) const;
     class Pool;  // the parser's worker threads, started once
     std::unique_ptr<Pool> m_pool;
+    mutable std::mutex m_pool_mu;  // copy_range and parse_range may be called from two threads: one phase of the pool at a time
     struct Scratch {  // where one segment parses to before its place in the block is known; kept between blocks
         std::vector<Overlap> lines;
         std::vector<hc_cand_rec> recs;

@@ -25,6 +25,15 @@ REC_FULL, REC_COMPACT = 0, 1
 ROW_DTYPE = np.dtype([("index", "<u8"), ("x1", "<f8"), ("x2", "<f8"), ("mm", "<u4"), ("n_cls", "<u4")], align=False)
 assert ROW_DTYPE.itemsize == 32
 
+# hc_line_rec, 48 bytes: one parsed line of the overlaps file; hc_text_row = row + line; hc_text_reject = line number + line
+LINE_DTYPE = np.dtype([("id1", "<u8"), ("id2", "<u8"), ("pos1", "<u4"), ("pos2", "<u4"), ("perc1", "<u4"), ("perc2", "<u4"), ("len1", "<u4"),
+                       ("len2", "<u4"), ("ord", "u1"), ("ori1", "u1"), ("ori2", "u1"), ("type1", "u1"), ("type2", "u1"), ("pad", "u1", (3,))], align=False)
+assert LINE_DTYPE.itemsize == 48
+TEXT_ROW_DTYPE = np.dtype([("row", ROW_DTYPE), ("line", LINE_DTYPE)], align=False)
+assert TEXT_ROW_DTYPE.itemsize == 80
+TEXT_REJECT_DTYPE = np.dtype([("line_index", "<u4"), ("pad", "<u4"), ("line", LINE_DTYPE)], align=False)
+assert TEXT_REJECT_DTYPE.itemsize == 56
+
 # hc_admit_rec, 48 bytes: an admitted candidate handed to the device's duplicate resolution
 ADMIT_DTYPE = np.dtype([("score", "<f8"), ("read1", "<u4"), ("read2", "<u4"), ("pos1", "<u4"), ("pos2", "<u4"), ("mm", "<u4"), ("n", "<u4"),
                         ("len1", "<u4"), ("len2", "<u4"), ("perc", "<u4"), ("ori1", "u1"), ("ori2", "u1"), ("ord", "u1"), ("pad", "u1")],

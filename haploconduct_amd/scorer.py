@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from .records import ADMIT_DTYPE, CAND_DTYPE, OVERLAP_DTYPE, REC_COMPACT, REC_FULL, RESULT_DTYPE, ROW_DTYPE, Settings
+from .records import ADMIT_DTYPE, CAND_DTYPE, OVERLAP_DTYPE, REC_COMPACT, REC_FULL, RESULT_DTYPE, ROW_DTYPE, TEXT_REJECT_DTYPE, TEXT_ROW_DTYPE, Settings
 
 
 def _ptr(a):
@@ -119,6 +119,44 @@ class EdgeScorer:
             for b in blocks:
                 N.lib.hc_block_destroy(b)
         return np.concatenate(out) if out else np.zeros(0, ROW_DTYPE)
+
+    def set_ids(self, read_ids):
+        """hc_text_set_ids: the id -> read index table of the device's text parser."""
+        ids = np.ascontiguousarray(read_ids, dtype=np.uint64)
+        N.check(N.lib.hc_text_set_ids(self._ctx, _ptr(ids), ids.shape[0]), "hc_text_set_ids")
+
+    def score_text(self, text, block_bytes=1 << 20, first_line_no=0):
+        """The overlaps file's TEXT through hc_textblock_submit / hc_textblock_wait, block by block (cut at line ends).
+        Returns a list with one dict per block: the hc_text_result fields, rows / rejected as numpy copies."""
+        raw = text if isinstance(text, bytes) else text.encode()
+        b = C.c_void_p()
+        N.check(N.lib.hc_textblock_create(self._ctx, max(block_bytes, 64), C.byref(b)), "hc_textblock_create")
+        out, at, line_no, base = [], 0, first_line_no, 0
+        try:
+            buf = N.lib.hc_textblock_buffer(b)
+            while at < len(raw):
+                end = min(len(raw), at + block_bytes)
+                if end < len(raw):
+                    nl = raw.rfind(b"\n", at, end)
+                    if nl < 0:
+                        raise ValueError("a line longer than the block")
+                    end = nl + 1
+                C.memmove(buf, raw[at:end], end - at)
+                N.check(N.lib.hc_textblock_submit(b, end - at, line_no, base), "hc_textblock_submit")
+                r = N.hc_text_result()
+                N.check(N.lib.hc_textblock_wait(b, C.byref(r)), "hc_textblock_wait")
+                d = {k: getattr(r, k) for k, _ in r._fields_ if k not in ("rows", "rejected")}
+                d["rows"] = np.frombuffer((C.c_char * (r.n_rows * 80)).from_address(r.rows), dtype=TEXT_ROW_DTYPE).copy() if r.n_rows else np.zeros(0, TEXT_ROW_DTYPE)
+                d["rejected"] = (np.frombuffer((C.c_char * (r.n_rejected * 56)).from_address(r.rejected), dtype=TEXT_REJECT_DTYPE).copy()
+                                 if r.n_rejected else np.zeros(0, TEXT_REJECT_DTYPE))
+                d["base"], d["bytes"] = base, (at, end)
+                out.append(d)
+                line_no += r.n_lines
+                base += r.n_lines
+                at = end
+        finally:
+            N.lib.hc_textblock_destroy(b)
+        return out
 
     def graph_resolve(self, admitted, n_vertices, vertex_of_read=None, sorted_order=False, pieces=0):
         """hc_graph_resolve + hc_graph_fetch: duplicate resolution and adjacency lists on the device.  Returns a dict

@@ -103,10 +103,13 @@ typedef struct hc_overlap_rec {
  * and ord from the record and everything else from the reads, EdgeCalculator.cpp:143-385): the form that crosses
  * PCIe in the stage — 16 bytes instead of 32; LEN1/LEN2/PERC stay on the host, where the admitted edges are built.
  *   pos1_bits: bits 0..27 POS1, bit 28 ORI1 == '+', bit 29 ORI2 == '+', bits 30..31 ORD: 0 = '-', 1 = '1', 2 = '2'
- *   pos2_bits: bits 0..27 POS2, bits 28..31 zero
+ *   pos2_bits: bits 0..27 POS2, bits 28..30 zero, bit 31 (HC_CAND_SKIP): not a candidate — the scoring kernel writes a
+ *              dropped result and reads nothing else of the record (the device's text parser marks the lines it
+ *              dropped this way instead of compacting the block)
  * Positions saturate at 2^28-1: every stored sequence is shorter than that (hc_set_reads), so `pos >= length`
  * (EdgeCalculator.cpp:76-79) holds for the saturated value exactly when it holds for the original. */
 #define HC_CAND_POS_MASK 0x0FFFFFFFu
+#define HC_CAND_SKIP 0x80000000u
 typedef struct hc_cand_rec {
     uint32_t read1, read2;
     uint32_t pos1_bits, pos2_bits;
@@ -208,7 +211,11 @@ int hc_score_cands_device(hc_ctx* ctx, const void* d_cands, uint64_t n, void* d_
  *   hc_block_wait   : blocks until the block has been scored; *rows = the non-dropped records sorted by index
  *                     (index = base_index + position in the block), valid until the next submit on this block.
  * Several blocks of one context (or of several contexts on several devices) may be in flight at once. */
-typedef struct hc_gather_row hc_gather_row;
+typedef struct hc_gather_row { /* a non-dropped result record tagged with its candidate index */
+    uint64_t index;
+    double x1, x2;
+    uint32_t mm, n_cls;
+} hc_gather_row; /* 32 bytes */
 typedef struct hc_block hc_block;
 int hc_block_create(hc_ctx* ctx, uint64_t max_candidates, hc_block** out);
 int hc_block_submit(hc_block* b, const hc_cand_rec* cands, uint64_t n, uint64_t base_index);
@@ -226,11 +233,7 @@ int hc_compact_device(hc_ctx* ctx, const void* d_results, uint64_t n, void* d_in
  *   d_rows[k] = { uint64 base_index + d_indices[k]; double x1; double x2; uint32 mm; uint32 n_cls }   (32 bytes)
  * i.e. the compacted records of this rank's shard tagged with their global candidate index, ready for one
  * all-gather.  Rows at and beyond *d_count are left untouched.  Asynchronous on `hip_stream`. */
-struct hc_gather_row {
-    uint64_t index;
-    double x1, x2;
-    uint32_t mm, n_cls;
-}; /* 32 bytes */
+/* (hc_gather_row: defined with hc_block above) */
 int hc_pack_rows_device(hc_ctx* ctx, const void* d_results, const void* d_indices, const void* d_count, uint64_t cap,
                         uint64_t base_index, void* d_rows, void* hip_stream);
 
@@ -303,6 +306,55 @@ int hc_finalize(const hc_settings* s, const hc_result_rec* r, double* score, dou
  * HC_ERR_DATA (after filling everything) if some record has class HC_CLS_ERROR. */
 int hc_finalize_batch(const hc_settings* s, const hc_result_rec* r, uint64_t n, double* score, double* mismatch_rate,
                       uint32_t* cls);
+
+/* ---- the overlaps file read on the device ("mmap + SIMD/GPU tokenizer") ----------------------
+ * construct_edges spends its time in the serial text parser (EdgeCalculator.cpp:581-604: getline + stringstream + 13
+ * strings per line); here a block of the file's TEXT goes to the device as it is and three byte kernels do what the
+ * reference does with every line before process_overlaps: split it at its newlines, read the 13 fields of a PLAIN
+ * line (single tabs, decimal numbers or "-", valid one-character fields: what scripts/sfo2overlaps.py and FNO write),
+ * honour --max_ov, drop self overlaps (:605-607), apply the prefilter (:612-635), look the two ids up
+ * (m_ID_to_index, :164-171) — and the scoring kernel runs on the result in the same stream.  What comes back is what
+ * an hc_block returns, each row together with the parsed line it came from (the host needs LEN / PERC / the text of a
+ * non-edge), plus the prefilter's rejects and the line counters.  A block holding a line that is not plain (padded,
+ * malformed, hexadecimal ids, an id that is not in the FASTQ input, ...) is REPORTED, not guessed: the host then takes
+ * that block through its own tokeniser and Overlap constructor, which own every error the reference can raise. */
+typedef struct hc_line_rec { /* one parsed line: Overlap (src/Overlap.h:20-73) */
+    uint64_t id1, id2;
+    uint32_t pos1, pos2, perc1, perc2, len1, len2;
+    uint8_t ord, ori1, ori2, type1, type2, pad[3]; /* the characters of the file: '1' '2' '-', '+' '-', 's' 'p' */
+} hc_line_rec; /* 48 bytes */
+typedef struct hc_text_row {
+    hc_gather_row row; /* index = base_index + number of the line in the block */
+    hc_line_rec line;
+} hc_text_row; /* 80 bytes */
+typedef struct hc_text_reject {
+    uint32_t line_index, pad; /* number of the line in the block */
+    hc_line_rec line;
+} hc_text_reject; /* 56 bytes */
+typedef struct hc_text_result {
+    uint64_t n_lines;          /* lines in the block (a last piece without a newline is a line)              */
+    uint64_t lines_read;       /* of them below --max_ov                                                      */
+    uint64_t needs_host;       /* != 0: lines the device does not read (n_nonplain), an unknown id, more lines than the
+                                  block has room for, or more surviving records / rejects than its host buffers
+                                  hold (an eighth of the lines): nothing else of this result may be used     */
+    uint64_t n_nonplain, n_unknown_id;
+    uint64_t self_overlaps, silently_dropped, prefilter_rejected, scored; /* the counters of construct_edges  */
+    const hc_text_row* rows;   /* non-dropped records, sorted by index                                        */
+    uint64_t n_rows;
+    const hc_text_reject* rejected; /* sorted by line_index (the order they are written to nonedge_overlaps.txt) */
+    uint64_t n_rejected;
+} hc_text_result;
+typedef struct hc_textblock hc_textblock;
+/* read_ids[r] = id of m_read_vec[r]; the first occurrence of an id wins (std::map::insert, FastqStorage.h:88-97). */
+int hc_text_set_ids(hc_ctx* ctx, const uint64_t* read_ids, uint32_t n_reads);
+int hc_textblock_create(hc_ctx* ctx, uint64_t max_bytes, hc_textblock** out);
+/* The block's page-locked text buffer (max_bytes): the caller reads the file straight into it. */
+char* hc_textblock_buffer(hc_textblock* b);
+/* Asynchronous.  The first n_bytes of the buffer are one block of the file starting at a line start; first_line_no =
+ * number of that line in the file; --max_ov, the prefilter settings and the flags come from the context's settings. */
+int hc_textblock_submit(hc_textblock* b, uint64_t n_bytes, uint64_t first_line_no, uint64_t base_index);
+int hc_textblock_wait(hc_textblock* b, hc_text_result* out); /* valid until the next submit on this block */
+int hc_textblock_destroy(hc_textblock* b);
 
 /* ---- duplicate resolution + adjacency on the device -----------------------------------------
  * The serial half of process_overlaps (EdgeCalculator.cpp:431-545) for a whole overlaps file at once, into an EMPTY

@@ -42,13 +42,14 @@ def test_record_layouts(tmp_path):
     import subprocess
 
     from haploconduct_amd.host import EDGE_DTYPE
-    from haploconduct_amd.records import ADMIT_DTYPE, CAND_DTYPE, ROW_DTYPE, SFO_DTYPE
+    from haploconduct_amd.records import ADMIT_DTYPE, CAND_DTYPE, LINE_DTYPE, ROW_DTYPE, SFO_DTYPE, TEXT_REJECT_DTYPE, TEXT_ROW_DTYPE
 
     assert OVERLAP_DTYPE.itemsize == 32 and RESULT_DTYPE.itemsize == 24
     assert OVERLAP_DTYPE.fields["ord"][1] == 18 and OVERLAP_DTYPE.fields["perc"][1] == 28
     assert RESULT_DTYPE.fields["n_cls"][1] == 20
     views = {"hc_overlap_rec": OVERLAP_DTYPE, "hc_cand_rec": CAND_DTYPE, "hc_result_rec": RESULT_DTYPE, "hc_gather_row": ROW_DTYPE,
-             "hc_admit_rec": ADMIT_DTYPE, "hc_edge_rec": EDGE_DTYPE, "hc_sfo_rec": SFO_DTYPE}
+             "hc_admit_rec": ADMIT_DTYPE, "hc_edge_rec": EDGE_DTYPE, "hc_sfo_rec": SFO_DTYPE, "hc_line_rec": LINE_DTYPE,
+             "hc_text_row": TEXT_ROW_DTYPE, "hc_text_reject": TEXT_REJECT_DTYPE}
     probes = []
     for name, dt in views.items():
         tag = "struct hc_gather_row" if name == "hc_gather_row" else name
@@ -56,7 +57,8 @@ def test_record_layouts(tmp_path):
         for f in dt.names:
             if not f.startswith("_"):
                 probes.append(f'printf("{name}.{f} %zu\\n", offsetof({tag}, {f}));')
-    for name, st in (("hc_settings", N.hc_settings), ("hc_graph_counts", N.hc_graph_counts)):
+    structs = (("hc_settings", N.hc_settings), ("hc_graph_counts", N.hc_graph_counts), ("hc_text_result", N.hc_text_result))
+    for name, st in structs:
         probes.append(f'printf("{name} %zu\\n", sizeof({name}));')
         for f, _ in st._fields_:
             probes.append(f'printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
@@ -70,7 +72,7 @@ def test_record_layouts(tmp_path):
         for f in dt.names:
             if not f.startswith("_"):
                 assert int(got[f"{name}.{f}"]) == dt.fields[f][1], (name, f)
-    for name, st in (("hc_settings", N.hc_settings), ("hc_graph_counts", N.hc_graph_counts)):
+    for name, st in structs:
         assert int(got[name]) == C.sizeof(st), name
         for f, _ in st._fields_:
             assert int(got[f"{name}.{f}"]) == getattr(st, f).offset, (name, f)

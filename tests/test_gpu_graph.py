@@ -218,3 +218,103 @@ def test_stage_fused_sort_with_fully_tied_edges_in_long_lists(oracle, tmp_path):
         got, got_in = ec.edges(), ec.in_lists()
     assert got.tobytes() == want.tobytes()
     assert np.array_equal(got_in[0], want_in[0]) and np.array_equal(got_in[1], want_in[1])
+
+
+def _text_case(seed):
+    reads, meta = synth.make_paired_dataset(900, 2200, flip_frac=0.3, seed=seed)
+    cand = synth.paired_candidates(meta, n_candidates=15000, seed=seed + 1)
+    sreads_lines = synth.records_to_lines(cand, reads)
+    return reads, cand, sreads_lines
+
+
+@pytest.mark.parametrize("block_bytes", [1 << 20, 40000, 3000])
+def test_device_text_parser_is_the_host_parser(block_bytes, tmp_path):
+    """hc_textblock_*: the overlaps file's text split, parsed, prefiltered and scored on the device against the host
+    parser (pinned by the reference's own prefilter lines, tests/test_prefilter_golden.py) followed by hc_score_cands: same
+    non-dropped records with the same parsed lines, same rejects in file order, same counters — through --max_ov, self
+    overlaps, "-" columns, percentages below --min_overlap_perc, a last line without a newline."""
+    from haploconduct_amd.records import FLAG_RELAX_PE_EDGES, LINE_DTYPE
+
+    reads, cand, lines = _text_case(41)
+    rng = random.Random(3)
+    ids = reads.read_ids
+    # shorter overlaps (prefilter rejects / relaxed passes), self overlaps, low percentages
+    for k in rng.sample(range(len(lines)), 600):
+        f = lines[k].split("\t")
+        f[9] = str(rng.choice([10, 70, 74, 75, 76, 149, 150]))
+        f[10] = str(rng.choice([10, 70, 74, 75, 76, 149, 150]))
+        f[7] = str(rng.choice([0, 59, 60, 61, 100]))
+        lines[k] = "\t".join(f)
+    for k in rng.sample(range(len(lines)), 30):
+        f = lines[k].split("\t")
+        f[1] = f[0]
+        lines[k] = "\t".join(f)
+    text = "\n".join(lines)  # no trailing newline: the last piece is a line too
+    path = str(tmp_path / "ov.txt")
+    open(path, "w").write(text)
+    reads.write_fastq(None, str(tmp_path / "p1.fastq"), str(tmp_path / "p2.fastq"))
+    fq = host.Fastq(paired1=str(tmp_path / "p1.fastq"), paired2=str(tmp_path / "p2.fastq"))
+    for st in (hc.Settings(edge_threshold=0.97, min_overlap_len=150, min_overlap_perc=60),
+               hc.Settings(edge_threshold=0.97, min_overlap_len=151, flags=FLAG_RESOLVE_ORIENTATIONS | FLAG_RELAX_PE_EDGES, max_overlaps=9000)):
+        want_recs, wc = fq.parse_file(st, path)
+        with hc.EdgeScorer(st) as sc:
+            sc.set_reads(reads)
+            sc.set_ids(ids)
+            want_res = sc.score_batch(want_recs)
+            blocks = sc.score_text(text, block_bytes=block_bytes)
+        assert all(b["needs_host"] == 0 for b in blocks)
+        assert sum(b["lines_read"] for b in blocks) == wc["lines_read"] and sum(b["scored"] for b in blocks) == wc["scored"] == want_recs.size
+        assert sum(b["prefilter_rejected"] for b in blocks) == wc["prefilter_rejected"] > 50
+        assert sum(b["silently_dropped"] for b in blocks) == wc["silently_dropped"]
+        assert sum(b["self_overlaps"] for b in blocks) > 0
+        rows = np.concatenate([b["rows"] for b in blocks])
+        assert (np.diff(rows["row"]["index"].astype(np.int64)) > 0).all()
+        kept = np.nonzero(result_cls(want_res) != 0)[0]
+        assert rows.size == kept.size > 300
+        for k in ("x1", "x2"):
+            assert np.array_equal(rows["row"][k].view(np.uint64), want_res[k][kept].view(np.uint64))
+        assert np.array_equal(rows["row"]["mm"], want_res["mm"][kept]) and np.array_equal(rows["row"]["n_cls"], want_res["n_cls"][kept])
+        # the parsed line travelling with every row is the host parser's record of that candidate
+        ln, wr = rows["line"], want_recs[kept]
+        assert np.array_equal(ln["id1"], ids[wr["read1"]]) and np.array_equal(ln["id2"], ids[wr["read2"]])
+        assert np.array_equal(ln["pos1"], wr["pos1"]) and np.array_equal(ln["pos2"], wr["pos2"])
+        assert np.array_equal(ln["len1"], wr["len1"]) and np.array_equal(ln["len2"], wr["len2"])
+        assert np.array_equal(ln["ord"], wr["ord"]) and np.array_equal(ln["ori1"] == ord("+"), wr["ori1"] != 0)
+        perc = np.where(ln["perc2"] > 0, (ln["perc1"] + ln["perc2"]) // 2, ln["perc1"])
+        assert np.array_equal(perc, wr["perc"])
+        # rejects: in file order, with the line number inside their block
+        n_rej = sum(b["rejected"].size for b in blocks)
+        assert n_rej == wc["prefilter_rejected"]
+        for b in blocks:
+            assert (np.diff(b["rejected"]["line_index"].astype(np.int64)) > 0).all()
+
+
+def test_device_text_parser_hands_unusual_blocks_to_the_host():
+    reads, cand, lines = _text_case(43)
+    good = "\n".join(lines[:2000]) + "\n"
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        sc.set_ids(reads.read_ids)
+        assert sc.score_text(good)[0]["needs_host"] == 0
+        for bad in (lines[5] + " ", "  " + lines[5], "1\t2\t3", "", lines[5].replace("\t", " \t", 1), "0x10" + lines[5][lines[5].index("\t"):],
+                    "007" + lines[5][lines[5].index("\t"):], lines[5] + "\tz", lines[5][:-1] + "q"):
+            b = sc.score_text(good + bad + "\n" + good)[0]
+            assert b["needs_host"] == 1 and b["n_nonplain"] == 1, bad
+        unknown = lines[5].split("\t")
+        unknown[1] = "99999999"
+        b = sc.score_text(good + "\t".join(unknown) + "\n")[0]
+        assert b["needs_host"] == 1 and b["n_unknown_id"] == 1 and b["n_nonplain"] == 0
+        assert sc.score_text("\n" * 100000, block_bytes=1 << 20)[0]["needs_host"] == 1  # more lines than a block of plain lines can hold
+        # sparse ids: the open-addressing table
+        sparse = reads.read_ids * 1000003 + 17
+        sc.set_ids(sparse)
+        relabelled = []
+        for ln in lines[:3000]:
+            f = ln.split("\t")
+            f[0], f[1] = str(int(f[0]) * 1000003 + 17), str(int(f[1]) * 1000003 + 17)
+            relabelled.append("\t".join(f))
+        sc.set_ids(reads.read_ids)
+        a = sc.score_text("\n".join(lines[:3000]) + "\n")[0]
+        sc.set_ids(sparse)
+        b = sc.score_text("\n".join(relabelled) + "\n")[0]
+        assert b["needs_host"] == 0 and a["rows"]["row"].tobytes() == b["rows"]["row"].tobytes()

@@ -54,11 +54,13 @@ def run_both(oracle, tmp_path, reads, lines, st, tag):
     for k in COUNTERS:
         assert c[k] == getattr(oc, k), k
     assert c["self_overlap_count"] == 0
-    # The other routes to the same graph: the device's duplicate resolution is the default above; the host threads'
-    # resolution, the per-edge serial insert, three contexts taking the blocks in turn, and the fused
-    # construct + sortEdges call (against construct_edges followed by sortEdges) must all agree with it.
+    # The other routes to the same graph: above, the device read the file's text itself and resolved the duplicates;
+    # the host threads' resolution, the per-edge serial insert, three contexts taking the blocks in turn, the host's
+    # tokeniser instead of the device's (HC_PARSE=host), tiny text blocks, and the fused construct + sortEdges call
+    # (against construct_edges followed by sortEdges) must all agree with it.
     for env, sorted_call in (({"HC_RESOLVE": "host"}, False), ({"HC_INSERT_MODE": "serial"}, False), ({"HC_DEVICE_LIST": "0,0,0"}, False),
-                             ({}, True), ({"HC_RESOLVE": "host"}, True)):
+                             ({"HC_PARSE": "host"}, False), ({"HC_PARSE": "host", "HC_DEVICE_LIST": "0,0,0"}, False),
+                             ({"HC_TEXT_BLOCK": "4096"}, False), ({}, True), ({"HC_RESOLVE": "host"}, True)):
         os.environ.update(env)
         try:
             with host.EdgeCalculatorStage(st, singles=s, paired1=p1, paired2=p2, overlaps=ov, output_dir=out_dir) as ec:
@@ -372,6 +374,7 @@ def test_fuzz_stage_against_oracle(oracle, tmp_path, seed):
                      min_overlap_perc=int(rng.choice([0, 0, 60])), flags=flags, max_overlaps=int(rng.choice([10 ** 8, 10 ** 8, len(lines) // 2])))
     st.n_threads = int(rng.choice([1, 3, 8]))
     os.environ["HC_STAGE_BLOCK"] = str(int(rng.choice([700, 5000, 250000])))
+    os.environ["HC_TEXT_BLOCK"] = str(int(rng.choice([4096, 60000, 16 << 20])))
     try:
         edges, c = run_both(oracle, tmp_path, reads, lines, st, f"fz{seed}")
         if os.environ.get("HC_FUZZ_REPORT"):  # coverage of the soak: what the scenarios actually exercised
@@ -380,6 +383,7 @@ def test_fuzz_stage_against_oracle(oracle, tmp_path, seed):
                     "scored", "dup_count", "inclusion_count", "nonedges_written", "prefilter_rejected", "malformed_lines")) + "\n")
     finally:
         os.environ.pop("HC_STAGE_BLOCK", None)
+        os.environ.pop("HC_TEXT_BLOCK", None)
 
 
 def test_edge_invariant_violation_in_a_threaded_build_is_an_error_not_a_crash(tmp_path):
