@@ -34,6 +34,7 @@ struct hc_textblock {
     hc_text_reject* h_rejects = nullptr;       // page-locked, mapped: written by the parse kernel
     unsigned long long* h_counters = nullptr;  // page-locked
     std::vector<hc_text_row> rows;             // what hc_textblock_wait hands out
+    std::vector<uint64_t> keys;                // (index, slot) of the appended rows, for putting them in order
     bool in_flight = false;
 };
 
@@ -215,12 +216,16 @@ int hc_textblock_wait(hc_textblock* b, hc_text_result* out) {
     out->scored = k[hc::kTextPass];
     const uint64_t n_rows = k[hc::kTextRows], n_rej = k[hc::kTextRejectSlots];
     // the kernels append in no particular order; the stage consumes in file order
+    // (sorting 8-byte keys and gathering once, not 80-byte records)
+    b->keys.resize(n_rows);
+    for (uint64_t i = 0; i < n_rows; i++) b->keys[i] = (b->h_rows[i].index << 24) | i;  // index < 2^31 lines + base; slot < 2^24
+    std::sort(b->keys.begin(), b->keys.end());
     b->rows.resize(n_rows);
     for (uint64_t i = 0; i < n_rows; i++) {
-        b->rows[i].row = b->h_rows[i];
-        b->rows[i].line = b->h_row_lines[i];
+        const uint64_t at = b->keys[i] & 0xFFFFFFu;
+        b->rows[i].row = b->h_rows[at];
+        b->rows[i].line = b->h_row_lines[at];
     }
-    std::sort(b->rows.begin(), b->rows.end(), [](const hc_text_row& x, const hc_text_row& y) { return x.row.index < y.row.index; });
     std::sort(b->h_rejects, b->h_rejects + n_rej, [](const hc_text_reject& x, const hc_text_reject& y) { return x.line_index < y.line_index; });
     out->rows = b->rows.data();
     out->n_rows = n_rows;

@@ -56,6 +56,7 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
     if (const char* m = getenv("HC_RESOLVE")) m_host_resolve = std::string(m) == "host";
     if (const char* m = getenv("HC_PARSE")) m_host_parse = std::string(m) == "host";
     if (const char* m = getenv("HC_TEXT_BLOCK")) m_text_block = std::max<size_t>(4096, (size_t)strtoull(m, nullptr, 10));
+    if (const char* m = getenv("HC_TEXT_DEPTH")) m_text_depth = std::max<size_t>(1, (size_t)atoi(m));
     m_cs = to_hc_settings(ps);
     const FastqStorage& f = *fastq_storage;
     try {
@@ -494,7 +495,7 @@ static Overlap overlap_of(const hc_line_rec& l) {
 }
 
 // finalize_block for a block the device parsed: every row carries the parsed line it came from
-void EdgeCalculator::finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out) {
+void EdgeCalculator::finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out, unsigned threads) {
     out.admitted.clear();
     out.nonedge_text.clear();
     out.nonedges = out.ambiguous = 0;
@@ -557,6 +558,7 @@ void EdgeCalculator::finalize_text_block(const IdIndex& ids, const hc_text_row* 
     static const unsigned build_cap = getenv("HC_BUILD_THREADS") ? (unsigned)atoi(getenv("HC_BUILD_THREADS")) : 8u;  // experiment knob
     unsigned T = program_settings.n_threads > 1 ? std::min<unsigned>(program_settings.n_threads, std::max(1u, build_cap)) : 1;
     if (n_rows < 4096) T = 1;
+    if (threads) T = std::min(T, threads);  // several collectors call this side by side: each on its own thread (the pool is one)
     std::vector<Piece> pieces(T);
     if (T == 1) {
         build(0, n_rows, pieces[0]);
@@ -595,17 +597,21 @@ void EdgeCalculator::finalize_text_block(const IdIndex& ids, const hc_text_row* 
 // comes out as from the host-parsed pipeline.
 void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc) {
     const size_t N = m_dev.size();
-    const size_t R = 2 * N + 1;
+    const size_t D = m_text_depth;  // text blocks per device
+    const size_t R = D * N + 1;
     const size_t B = m_text_block;
-    for (Device& d : m_dev)
+    for (Device& d : m_dev) {
+        d.tblk.resize(D, nullptr);
         for (hc_textblock*& b : d.tblk)
             if (!b) check(hc_textblock_create(d.ctx, B, &b), "hc_textblock_create");
+    }
     struct Slot {
         hc_textblock* tb = nullptr;  // nullptr: the host's block (nothing was submitted)
         size_t begin = 0, end = 0;
         uint64_t first_line = 0, n_lines = 0;
     };
     std::vector<Slot> ring(R);
+    std::vector<BlockOut> outs(R);
     std::mutex mu;
     std::condition_variable cv;
     size_t submitted = 0, consumed = 0;
@@ -614,8 +620,14 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     FatalError collector_error{0, ""};
     double t_collect = 0;
     uint64_t n_host_blocks = 0;
-    std::thread collector([&] {
-        BlockOut out;
+    double tm_wait = 0, tm_final = 0, tm_turn = 0, tm_consume = 0, tm_slot = 0, tm_copy = 0, tm_submit = 0;  // HC_STAGE_TIMING
+    // Several collectors: collector c takes the blocks k = c, c + C, ...; waiting for the device, putting the rows in
+    // order and finalising them (exp() of the admitted ones, the lines of the non-edges) happens side by side for
+    // different blocks, the serial half (and everything that touches shared state) strictly in block order.
+    unsigned C = std::max(1u, std::min<unsigned>(4u, program_settings.n_threads));
+    if (const char* e = getenv("HC_COLLECTORS")) C = std::max(1, atoi(e));
+    C = (unsigned)std::min<size_t>(C, D * N);  // at most D * N blocks are in flight
+    auto collect = [&](unsigned c) {
         ParsedBatch::RecStorage pinned;
         pinned.ctx = m_ctx;
         pinned.alloc = [](void* ctx, size_t n) -> hc_cand_rec* {
@@ -625,20 +637,38 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
         };
         pinned.release = [](void* ctx, hc_cand_rec* p) { hc_host_free((hc_ctx*)ctx, p); };
         ParsedBatch host_batch(pinned);
-        for (size_t k = 0;; k++) {
+        for (size_t k = c;; k += C) {
             {
                 std::unique_lock<std::mutex> g(mu);
                 cv.wait(g, [&] { return submitted > k || producer_done; });
                 if (submitted <= k) return;
             }
             const Slot sl = ring[k % R];
+            BlockOut& out = outs[k % R];
+            hc_text_result tr;
+            memset(&tr, 0, sizeof tr);
+            tr.needs_host = 1;
+            FatalError mine{0, ""};
+            const double t0 = now_s();
+            double t_w = t0;
+            try {  // side by side with the other collectors
+                if (sl.tb) check(hc_textblock_wait(sl.tb, &tr), "hc_textblock_wait");
+                t_w = now_s();
+                if (!tr.needs_host && !collector_failed) finalize_text_block(parser.ids(), tr.rows, tr.n_rows, out, /*threads=*/1);
+            } catch (const FatalError& e) {
+                mine = e;
+            } catch (const std::exception& e) {
+                mine = FatalError{HC_ERR_NOMEM, e.what()};
+            }
+            const double t1 = now_s();
+            {  // in block order from here
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return consumed == k; });
+            }
+            const double t2 = now_s();
             if (!collector_failed) {
                 try {
-                    const double t0 = now_s();
-                    hc_text_result tr;
-                    memset(&tr, 0, sizeof tr);
-                    tr.needs_host = 1;
-                    if (sl.tb) check(hc_textblock_wait(sl.tb, &tr), "hc_textblock_wait");
+                    if (mine.status) throw mine;
                     if (tr.needs_host) {  // the host's tokeniser + Overlap constructor own this block
                         n_host_blocks++;
                         parser.parse_range(sl.begin, sl.end, sl.first_line, host_batch, rejected, pc, /*print_malformed=*/true);
@@ -665,9 +695,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                         pc.prefilter_rejected += tr.prefilter_rejected;
                         stats.scored += tr.scored;
                         for (uint64_t j = 0; j < tr.n_rejected; j++) rejected.push_back(overlap_of(tr.rejected[j].line));
-                        finalize_text_block(parser.ids(), tr.rows, tr.n_rows, out);
                     }
-                    t_collect += now_s() - t0;
                     consume_block(out);
                 } catch (const FatalError& e) {
                     collector_error = e;
@@ -676,40 +704,45 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                     collector_error = FatalError{HC_ERR_NOMEM, e.what()};
                     collector_failed = true;
                 }
-            } else if (sl.tb) {  // drain: the block object must not stay in flight
-                hc_text_result tr;
-                (void)hc_textblock_wait(sl.tb, &tr);
             }
             {
                 std::lock_guard<std::mutex> g(mu);
+                const double t3 = now_s();
+                t_collect += (t1 - t0) / C + (t3 - t2);
+                tm_wait += t_w - t0, tm_final += t1 - t_w, tm_turn += t2 - t1, tm_consume += t3 - t2;
                 consumed = k + 1;
             }
             cv.notify_all();
         }
-    });
+    };
+    std::vector<std::thread> collectors;
+    for (unsigned c = 0; c < C; c++) collectors.emplace_back(collect, c);
     auto stop_collector = [&] {
         {
             std::lock_guard<std::mutex> g(mu);
             producer_done = true;
         }
         cv.notify_all();
-        if (collector.joinable()) collector.join();
+        for (auto& t : collectors)
+            if (t.joinable()) t.join();
     };
     try {
         size_t pos = 0;
         uint64_t line_no = 0;
         const size_t size = parser.size();
         for (size_t k = 0; pos < size && line_no < program_settings.max_overlaps; k++) {  // `&& i < max_overlaps`, :581
-            {  // the block object's previous user (block k - 2N) has been consumed
+            const double ts = now_s();
+            {  // the block object's previous user (block k - D * N) has been consumed
                 std::unique_lock<std::mutex> g(mu);
-                cv.wait(g, [&] { return consumed + 2 * N > k; });
+                cv.wait(g, [&] { return consumed + D * N > k; });
                 if (collector_failed) break;
             }
+            tm_slot += now_s() - ts;
             Slot sl;
             sl.begin = pos;
             sl.first_line = line_no;
             Device& dev = m_dev[k % N];
-            hc_textblock* tb = dev.tblk[(k / N) % 2];
+            hc_textblock* tb = dev.tblk[(k / N) % D];
             const double t0 = now_s();
             size_t end = std::min(size, pos + B);
             uint64_t newlines = 0;
@@ -746,8 +779,11 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                 const char* buf = hc_textblock_buffer(tb);
                 if (end > pos && buf[end - pos - 1] != '\n') sl.n_lines++;
             }
-            stats.t_parse += now_s() - t0;
+            const double tc = now_s();
+            stats.t_parse += tc - t0;
+            tm_copy += tc - t0;
             check(hc_textblock_submit(tb, end - pos, line_no, 0), "hc_textblock_submit");
+            tm_submit += now_s() - tc;
             sl.tb = tb;
             ring[k % R] = sl;
             pos = end;
@@ -765,7 +801,11 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     stop_collector();
     if (collector_failed) throw collector_error;
     stats.t_score = t_collect;
-    if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] device-parsed pipeline: %lu block(s) went to the host parser\n", (unsigned long)n_host_blocks);
+    if (getenv("HC_STAGE_TIMING"))
+        fprintf(stderr, "[hc stage] device-parsed pipeline: %lu block(s) went to the host parser; producer: waiting for a block object %.3f s, "
+                        "copy %.3f s, submit %.3f s; %u collector(s), summed: waiting for the device + ordering rows %.3f s, finalise %.3f s, "
+                        "waiting for their turn %.3f s, serial half %.3f s\n",
+                (unsigned long)n_host_blocks, tm_slot, tm_copy, tm_submit, C, tm_wait, tm_final, tm_turn, tm_consume);
 }
 
 // The file tokenised on the host's threads (HC_PARSE=host; also what a block the device's parser does not read goes

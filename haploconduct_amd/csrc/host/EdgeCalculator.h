@@ -88,7 +88,7 @@ private:
     struct Device {
         hc_ctx* ctx = nullptr;
         hc_block* blk[2] = {nullptr, nullptr};       // blocks of host-parsed records
-        hc_textblock* tblk[2] = {nullptr, nullptr};  // blocks of the file's text (the device parses)
+        std::vector<hc_textblock*> tblk;             // blocks of the file's text (the device parses): m_text_depth per device
     };
     // What the collector makes of one scored block, in sequence order.
     struct BlockOut {
@@ -99,7 +99,7 @@ private:
     void run_stage(bool then_sort);
     void score_host_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc);   // the file tokenised on host threads
     void score_device_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc); // the file's text sent to the device
-    void finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out);
+    void finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out, unsigned threads = 0);
     void collect_read_info();
     void finalize_block(const ParsedBatch& batch, const hc_gather_row* rows, uint64_t n_rows, uint64_t base, BlockOut& out);
     void consume_block(BlockOut& out);  // serial half: insert (or collect) + nonedge_overlaps.txt, :431-555
@@ -118,6 +118,7 @@ private:
     bool m_host_resolve = false;      // HC_RESOLVE=host: duplicate resolution on the host threads instead of the device
     bool m_host_parse = false;        // HC_PARSE=host: the overlaps file is tokenised on the host threads instead of the device
     size_t m_text_block = 16u << 20;  // bytes of text per device-parsed block (HC_TEXT_BLOCK)
+    size_t m_text_depth = 6;          // text blocks in flight per device (HC_TEXT_DEPTH): copy of block k+2.. beside the device's work on k, k+1
     bool m_collect = false;           // this call collects the admitted candidates and resolves them after the last block
     bool m_device_resolve = false;    // ... on the device: every block's admitted records are appended there as they come
     std::vector<std::vector<hc_admit_rec>> m_admitted;  // admitted candidates of the whole file, block by block, in sequence order

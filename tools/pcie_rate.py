@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""The PCIe-inclusive scoring rate (never bench.py's `value`): hc_score_batch on host buffers —
-H2D of the candidate records, kernel, D2H of the result records — with page-locked (hc_host_alloc) and with pageable
-memory, on the bench workload."""
+"""The PCIe-inclusive scoring rate (never bench.py's `value`): candidate records start in page-locked HOST
+memory and what the host needs of the results ends there —
+  blocks : hc_block_submit / hc_block_wait, the stage's device leg: 16-byte records over PCIe, the scoring kernel
+           writing the non-dropped rows straight into host memory, several blocks in flight;
+  full   : hc_score_cands / hc_score_batch, one synchronous call: records in, all 24-byte result records out."""
 import ctypes as C
 import json
 import os
@@ -18,29 +20,62 @@ def main():
     import haploconduct_amd as hc
     from haploconduct_amd import _native as N
 
-    reads, cand, cfg, st = bench.build_workload("c2", 0)
+    workload = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    reads, cand, cfg, st = bench.build_workload(workload, 0)
     n = int(cand.size)
+    res = {}
     with hc.EdgeScorer(st) as sc:
         sc.set_reads(reads)
-        pin_in, pin_out = C.c_void_p(), C.c_void_p()
-        N.check(N.lib.hc_host_alloc(sc._ctx, C.byref(pin_in), n * 32), "hc_host_alloc")
-        N.check(N.lib.hc_host_alloc(sc._ctx, C.byref(pin_out), n * 24), "hc_host_alloc")
-        C.memmove(pin_in, cand.ctypes.data, n * 32)
-        out_pageable = np.zeros(n * 24, np.uint8)
-        res = {}
-        for name, pi, po in (("page_locked", pin_in, pin_out), ("pageable", C.c_void_p(cand.ctypes.data), C.c_void_p(out_pageable.ctypes.data))):
-            for _ in range(3):
-                N.check(N.lib.hc_score_batch(sc._ctx, pi, n, po), "hc_score_batch")
+        cd = sc.pack_cands(cand)
+        pin = C.c_void_p()
+        N.check(N.lib.hc_host_alloc(sc._ctx, C.byref(pin), n * 16), "hc_host_alloc")
+        C.memmove(pin, cd.ctypes.data, n * 16)
+        for block, depth in ((1 << 20, 4), (250000, 4), (1 << 22, 3)):
+            blocks = []
+            for _ in range(depth):
+                b = C.c_void_p()
+                N.check(N.lib.hc_block_create(sc._ctx, block, C.byref(b)), "hc_block_create")
+                blocks.append(b)
+            rows, k = C.c_void_p(), C.c_uint64()
+
+            def run():
+                pending, kept = [], 0
+                for i, at in enumerate(range(0, n, block)):
+                    if len(pending) == depth:
+                        N.check(N.lib.hc_block_wait(pending.pop(0), C.byref(rows), C.byref(k)), "hc_block_wait")
+                        kept += k.value
+                    b = blocks[i % depth]
+                    N.check(N.lib.hc_block_submit(b, C.c_void_p(pin.value + at * 16), min(block, n - at), at), "hc_block_submit")
+                    pending.append(b)
+                while pending:
+                    N.check(N.lib.hc_block_wait(pending.pop(0), C.byref(rows), C.byref(k)), "hc_block_wait")
+                    kept += k.value
+                return kept
+
+            run()
+            reps = 5 if n > 10000000 else 30
             t0 = time.perf_counter()
-            reps = 20
             for _ in range(reps):
-                N.check(N.lib.hc_score_batch(sc._ctx, pi, n, po), "hc_score_batch")
+                kept = run()
             dt = (time.perf_counter() - t0) / reps
-            res[name] = {"ms_per_batch": round(dt * 1e3, 3), "candidates_per_s": round(n / dt), "pcie_GB_per_s": round(n * 56 / dt / 1e9, 1)}
-        same = bytes((C.c_char * (n * 24)).from_address(pin_out.value)) == out_pageable.tobytes()
-        N.lib.hc_host_free(sc._ctx, pin_in)
-        N.lib.hc_host_free(sc._ctx, pin_out)
-    print(json.dumps({"workload": cfg["workload"], "candidates": n, "bytes_over_pcie_per_candidate": 56, "identical_results": same, **res}))
+            res[f"blocks_{block}_x{depth}"] = {"ms": round(dt * 1e3, 3), "candidates_per_s": round(n / dt), "rows_back": kept,
+                                               "pcie_GB_per_s": round((n * 16 + kept * 32) / dt / 1e9, 1)}
+            for b in blocks:
+                N.lib.hc_block_destroy(b)
+        if n <= 20000000:
+            pin_out = C.c_void_p()
+            N.check(N.lib.hc_host_alloc(sc._ctx, C.byref(pin_out), n * 24), "hc_host_alloc")
+            for name, fn, rb in (("full_cands16", N.lib.hc_score_cands, 16),):
+                for _ in range(3):
+                    N.check(fn(sc._ctx, pin, n, pin_out), name)
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    N.check(fn(sc._ctx, pin, n, pin_out), name)
+                dt = (time.perf_counter() - t0) / 20
+                res[name] = {"ms": round(dt * 1e3, 3), "candidates_per_s": round(n / dt), "pcie_GB_per_s": round(n * (rb + 24) / dt / 1e9, 1)}
+            N.lib.hc_host_free(sc._ctx, pin_out)
+        N.lib.hc_host_free(sc._ctx, pin)
+    print(json.dumps({"workload": cfg["workload"], "candidates": n, **res}))
 
 
 if __name__ == "__main__":
