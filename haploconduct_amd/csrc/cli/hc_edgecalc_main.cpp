@@ -124,6 +124,7 @@ int main(int argc, char** argv) {
     B("careful_diploid", 0, &ps.careful, "more careful merging by avoiding neighboring components");
     B("verbose", 'v', &ps.verbose, "output additional information during assembly");
     NUM("device", 0, ps.device, "[hc-edgecalc] HIP device ordinal");
+    NUM("device_mask", 0, ps.device_mask, "[hc-edgecalc] bit d set: score blocks on HIP device d too (0 = --device alone)");
 
     auto usage = [&]() {
         puts("Program options:");

@@ -179,14 +179,15 @@ int hc_destroy(hc_ctx* c) {
 // (EdgeCalculator.cpp:41,44,52,60) so that every term the device adds is bit-identical to the
 // reference's log(p).  Dimension Kp = K + 2: index K is the N row/column (0.0: the position is
 // skipped, :35-39), index K+1 the invalid-symbol row/column (NaN poison).  Layouts: hc_device.h.
-static void build_lut(const std::vector<int>& phred, double mismatch_setting, uint32_t symbytes, std::vector<double>& lut) {
+static bool build_lut(const std::vector<int>& phred, double mismatch_setting, uint32_t symbytes, std::vector<double>& lut) {
     const size_t K = phred.size(), Kp = K + 2;
     const double inf = std::numeric_limits<double>::infinity();
     const double nan = std::numeric_limits<double>::quiet_NaN();
     const uint32_t lg = hc::lut_lg((uint32_t)K);
     const bool wide = symbytes == 1 && lg == 6;
     const size_t dim = symbytes == 1 ? ((size_t)1 << lg) : Kp;  // rows / columns that can be addressed
-    lut.assign(symbytes == 1 ? (size_t)2 << (2 * lg) : Kp * Kp * 2, nan);
+    lut.assign(symbytes == 1 ? (size_t)2 << (2 * lg) : (size_t)hc::lut_tri((uint32_t)Kp) * 2, nan);
+    bool symmetric = true;  // the 16-bit layout keeps one triangle: every (a, b) must equal (b, a) bit for bit
     for (size_t a = 0; a < dim; a++) {
         for (size_t b = 0; b < dim; b++) {
             // which index means N / invalid depends on the encoding (hc_device.h)
@@ -211,11 +212,15 @@ static void build_lut(const std::vector<int>& phred, double mismatch_setting, ui
                 lut[hc::lut_addr_u8(lg, (uint32_t)a, (uint32_t)b, 0) / 8] = vm;
                 lut[hc::lut_addr_u8(lg, (uint32_t)a, (uint32_t)b, 1) / 8] = vx;
             } else {
-                lut[hc::lut_addr_u16((uint32_t)Kp, (uint32_t)a, (uint32_t)b, 0) / 8] = vm;
-                lut[hc::lut_addr_u16((uint32_t)Kp, (uint32_t)a, (uint32_t)b, 1) / 8] = vx;
+                double& sm = lut[hc::lut_addr_u16((uint32_t)Kp, (uint32_t)a, (uint32_t)b, 0) / 8];
+                double& sx = lut[hc::lut_addr_u16((uint32_t)Kp, (uint32_t)a, (uint32_t)b, 1) / 8];
+                if (a > b && (memcmp(&sm, &vm, 8) != 0 || memcmp(&sx, &vx, 8) != 0)) symmetric = false;  // (b, a) was stored first
+                sm = vm;
+                sx = vx;
             }
         }
     }
+    return symmetric;
 }
 
 int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const uint64_t* seq_off,
@@ -261,7 +266,8 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         nsym += 2 * hc::slot_stride(seq_len[q], symbytes);
     }
     std::vector<double> lut;
-    build_lut(phred, c->settings.mismatch, symbytes, lut);
+    if (!build_lut(phred, c->settings.mismatch, symbytes, lut))  // (never seen: the reference's expressions commute for every Phred pair)
+        return fail(HC_ERR_STATE, "hc_set_reads: the log-probability table is not symmetric in its two qualities (--mismatch within one ulp of a term?)");
 
     free_store(c);
     struct Tmp {  // freed on every return path
@@ -345,7 +351,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         // 64-symbol fetch groups for short-read sets, 32-symbol groups when the
         // sequences are long (contigs): measured on BASELINE configs 2-5, see DESIGN.md
         const uint64_t mean_len = n_seq ? total / n_seq : 0;
-        c->fetch_group = mean_len > 600 ? 2 : 4;
+        c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 4;
     }
     return HC_OK;
 }

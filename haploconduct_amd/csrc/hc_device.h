@@ -68,14 +68,19 @@ struct StoreView {
 //                   pre-masked symbol bytes (no shift, no multiply); the XOR of the column with the row
 //                   spreads the few hot (qa, qb) pairs over the LDS banks (rows of a power-of-two table
 //                   would otherwise alias bank for bank).
-//   uint16 symbols: two dense planes of Kp x Kp entries: byte address = (m*Kp*Kp + qa*Kp + qb) * 8
-//                   (entry index < 2*97*97 fits 16 bits: two positions per packed-16-bit VALU op)
+//   uint16 symbols: two planes (match, mismatch) holding the LOWER TRIANGLE of the Kp x Kp table — log p(Q1, Q2) is
+//                   symmetric in the two qualities (hc_set_reads checks the table it built, entry by entry) —:
+//                   byte address = (m*T + hi*(hi+1)/2 + lo) * 8, hi/lo = larger/smaller of (qa, qb), T = Kp*(Kp+1)/2
+//                   (entry index < 2*4753 fits 16 bits: two positions per packed-16-bit VALU op).  Half the LDS of
+//                   the square layout: 31 KiB for 60 quality values, 74 KiB for the full Phred range.
 constexpr uint32_t kWideN = 48, kWideBadQual = 49, kWideBadBase = 50;  // reserved qidx of the wide 8-bit encoding
 // LG: log2 of the 8-bit-symbol table dimension; 6 selects the wide encoding.
 __host__ __device__ inline uint32_t lut_lg(uint32_t K) { return K + 2 <= 8 ? 3u : (K + 2 <= 16 ? 4u : (K + 2 <= 32 ? 5u : 6u)); }
 __host__ __device__ inline uint32_t sym_bytes_for(uint32_t K) { return K <= kWideN ? 1u : 2u; }
+__host__ __device__ inline uint32_t lut_tri(uint32_t Kp) { return Kp * (Kp + 1u) / 2u; }
 __host__ __device__ inline uint32_t lut_addr_u16(uint32_t Kp, uint32_t qa, uint32_t qb, uint32_t m) {
-    return (m * Kp * Kp + qa * Kp + qb) * 8u;
+    const uint32_t hi = qa > qb ? qa : qb, lo = qa > qb ? qb : qa;
+    return (m * lut_tri(Kp) + hi * (hi + 1u) / 2u + lo) * 8u;
 }
 __host__ __device__ inline uint32_t lut_addr_u8(uint32_t lg, uint32_t qa, uint32_t qb, uint32_t m) {
     return m * (8u << (2 * lg)) + qa * (8u << lg) + ((qb ^ qa) & ((1u << lg) - 1u)) * 8u;

@@ -269,14 +269,16 @@ __device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint3
             for (int k = 0; k < 4; ++k)
                 t[jj * 4 + k] = lds_f64(lut, __builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
         } else {
-            // two positions per packed 16-bit op: entry = m*Kp*Kp + qa*Kp + qb (< 2*97*97, fits 16 bits)
+            // two positions per packed 16-bit op: entry = m*T + hi*(hi+1)/2 + lo of the triangular planes (hc_device.h;
+            // < 2*4753, fits 16 bits; hi*(hi+1) <= 96*97 does too)
             typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
             const u16x2 qa2 = __builtin_bit_cast(u16x2, aw) >> (unsigned short)3;  // the code bits fall off each lane
             const u16x2 qb2 = __builtin_bit_cast(u16x2, bw) >> (unsigned short)3;
             const u16x2 m2 = __builtin_bit_cast(u16x2, mk >> 2);                    // 0 / 1 per lane
-            const u16x2 kp2 = {(unsigned short)Kp, (unsigned short)Kp};
-            const u16x2 pl2 = {(unsigned short)(Kp * Kp), (unsigned short)(Kp * Kp)};
-            const uint32_t e2 = __builtin_bit_cast(uint32_t, (u16x2)(m2 * pl2 + (qa2 * kp2 + qb2)));
+            const u16x2 hi2 = __builtin_elementwise_max(qa2, qb2), lo2 = __builtin_elementwise_min(qa2, qb2);
+            const u16x2 one2 = {1, 1};
+            const u16x2 tri2 = {(unsigned short)lut_tri(Kp), (unsigned short)lut_tri(Kp)};
+            const uint32_t e2 = __builtin_bit_cast(uint32_t, (u16x2)(m2 * tri2 + (((hi2 * (hi2 + one2)) >> (unsigned short)1) + lo2)));
             t[jj * 2 + 0] = lds_f64(lut, (e2 << 3) & 0x7FFF8u);
             t[jj * 2 + 1] = lds_f64(lut, (e2 >> 13) & 0x7FFF8u);
         }
@@ -606,8 +608,10 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
     }
 }
 
+// (second launch bound: at least 4 waves per SIMD, i.e. at most 128 registers — at 130 the kernel drops to 3 waves per SIMD
+// and loses a quarter of the loads in flight; the 16-bit-symbol instantiations need 132 registers: 3 waves per SIMD — 4 with spills measured slower)
 template <typename SymT, int G, int LG, bool BAL>
-__global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+__global__ __launch_bounds__(256, sizeof(SymT) == 1 ? 4 : 3) void score_kernel(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                     const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
                                                     const uint32_t* __restrict__ perm, RowSink sink) {
     score_kernel_body<SymT, G, LG, BAL>(st, prm, lut_g, in, n, out, perm, sink);
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(256) void score_kernel(StoreView st, ScoreParams pr
 // wide 8-bit symbols), and with one table per 256-lane workgroup only 2 workgroups fit a CU: 8 waves, too few to hide
 // the gather latency.  One table shared by 512 lanes restores 16 waves per CU (see launch_score).
 template <typename SymT, int G, int LG>
-__global__ __launch_bounds__(512) void score_kernel_wide_wg(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+__global__ __launch_bounds__(512, 4) void score_kernel_wide_wg(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                             const void* __restrict__ in, uint64_t n,
                                                             hc_result_rec* __restrict__ out, const uint32_t* __restrict__ perm,
                                                             RowSink sink) {
@@ -684,8 +688,12 @@ void launch_one(const ScoreLaunch& a) {
 
 template <typename SymT, int LG>
 void launch_lg(int group, const ScoreLaunch& a) {
-    if (group == 2) launch_one<SymT, 2, LG>(a);
-    else launch_one<SymT, 4, LG>(a);
+    if constexpr (sizeof(SymT) == 2) {  // 16-bit symbols: 32-symbol fetch groups only (64-symbol groups need 196 registers)
+        launch_one<SymT, 2, LG>(a);
+    } else {
+        if (group == 2) launch_one<SymT, 2, LG>(a);
+        else launch_one<SymT, 4, LG>(a);
+    }
 }
 }  // namespace
 
@@ -723,8 +731,10 @@ template <typename SymT, int LG>
 hipError_t set_lds_limit_lg() {
     const int kMax = 160 * 1024;  // allow the full 160 KiB of LDS for large quality alphabets
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 4, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 4, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if constexpr (sizeof(SymT) == 1) {
+        if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 4, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 4, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    }
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 2, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 2, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if constexpr (sizeof(SymT) == 1 && LG == 6) {

@@ -1,7 +1,8 @@
-"""World-size-2 test of the multi-GPU path on CPU (gloo): contiguous candidate shards, one
-all-gather-v of the admitted records, same admitted set as the single-process run.  The scoring
-itself is stood in for by the oracle here (no GPU in this container); on the GPU box the same
-functions run over RCCL from bench.py --gpus N."""
+"""World-size-2 test of the multi-GPU path on CPU (gloo): ONE candidate set split into contiguous, order-preserving
+shards (parallel.shard_range — what `bench.py --gpus N --scaling strong` does with the 1e8 candidates; an odd count, so
+the shards differ in size), one all-gather-v of the admitted records, same admitted set as the single-process run.
+The scoring itself is stood in for by the oracle here (no GPU in this container); on the GPU box the same functions
+run over RCCL from bench.py --gpus N."""
 import os
 import subprocess
 import sys
@@ -86,7 +87,11 @@ def test_two_rank_gather_equals_single_process(oracle):
     with tempfile.TemporaryDirectory() as d:
         script = os.path.join(d, "worker.py")
         open(script, "w").write(WORKER)
-        port = str(29500 + os.getpid() % 2000)
+        import socket
+
+        with socket.socket() as sk:  # a port nobody holds right now (not derived from the pid: parallel CI runs collide)
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
         procs = []
         for r in range(2):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", HC_PORT=port, HC_ROOT=ROOT, HC_OUT=d,

@@ -491,3 +491,37 @@ def test_prefilter_rejecting_half_of_the_lines_over_many_blocks(oracle, tmp_path
     finally:
         os.environ.pop("HC_STAGE_BLOCK", None)
     assert c["prefilter_rejected"] > 50000 and c["scored"] > 30000 and c["malformed_lines"] > 100 and edges.size > 1000
+
+
+def test_stage_device_mask(tmp_path):
+    """hc_settings.device_mask: the stage deals its blocks to every device of the mask in turn (replicated read store, one
+    context per device, results consumed in block order).  With one GPU visible the mask names it alone; with two or more,
+    the first two: the reference's own process_overlaps vectors must come out either way."""
+    from tests.test_ec_golden import compare_edges, load_case
+
+    n_dev = hc.device_count()
+    path = [p for p in _ec_golden_cases() if "pairs_dups" in p][0]
+    c, reads, st, want = load_case(path)
+    (tmp_path / "overlaps.txt").write_text("\n".join(c["lines"]) + "\n")
+    reads.write_fastq(None, str(tmp_path / "p1.fastq"), str(tmp_path / "p2.fastq"))
+    st.n_threads = 4
+    os.environ["HC_TEXT_BLOCK"] = "8192"  # many blocks, so that every device gets some
+    try:
+        for mask in ([0b1] if n_dev < 2 else [0b1, 0b11, 0b10]):
+            st.device_mask = mask
+            out = tmp_path / f"out{mask}"
+            out.mkdir()
+            with host.EdgeCalculatorStage(st, paired1=str(tmp_path / "p1.fastq"), paired2=str(tmp_path / "p2.fastq"),
+                                          overlaps=str(tmp_path / "overlaps.txt"), output_dir=str(out) + "/") as ec:
+                assert ec.device_count() == bin(mask).count("1")
+                ec.construct_edges()
+                compare_edges(ec.edges(), want, f"HIP stage, device mask {mask:#b}")
+                assert ec.inclusions().tolist() == c["inclusions"]
+            assert (out / "nonedge_overlaps.txt").read_text() == c["nonedge_overlaps"]
+        if n_dev < 2:
+            st.device_mask = 0b10  # a device that is not there: an error, not a silent fallback
+            with pytest.raises(hc.HcError):
+                host.EdgeCalculatorStage(st, paired1=str(tmp_path / "p1.fastq"), paired2=str(tmp_path / "p2.fastq"),
+                                         overlaps=str(tmp_path / "overlaps.txt"), output_dir=str(tmp_path) + "/")
+    finally:
+        os.environ.pop("HC_TEXT_BLOCK", None)
