@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/hcedge.h"
 #include "hc_ctx.h"
@@ -23,9 +24,11 @@ struct hc_block {
     void* d_in = nullptr;                  // cap hc_cand_rec
     void* d_out = nullptr;                 // cap hc_result_rec
     unsigned long long* d_count = nullptr; // rows appended by the kernel
-    hc_gather_row* h_rows = nullptr;       // page-locked, mapped: cap rows, written by the kernel
+    hc_gather_row* d_rows = nullptr;       // cap rows: the non-dropped records in sequence order (launch_kept_rows)
+    uint32_t* d_tiles = nullptr;           // its scratch: two arrays of cap / 1024 + 2 counters
+    hc_gather_row* h_rows = nullptr;       // page-locked, mapped: the rows, streamed out by a copy kernel behind it
     unsigned long long* h_count = nullptr; // page-locked
-    uint64_t n = 0;
+    uint64_t n = 0, base_index = 0;
     bool in_flight = false;
 };
 
@@ -49,6 +52,8 @@ int hc_block_create(hc_ctx* c, uint64_t max_candidates, hc_block** out) {
     if ((e = hipMalloc(&b->d_in, max_candidates * sizeof(hc_cand_rec))) != hipSuccess) return cleanup(e, "candidates");
     if ((e = hipMalloc(&b->d_out, max_candidates * sizeof(hc_result_rec))) != hipSuccess) return cleanup(e, "results");
     if ((e = hipMalloc((void**)&b->d_count, sizeof(unsigned long long))) != hipSuccess) return cleanup(e, "count");
+    if ((e = hipMalloc((void**)&b->d_rows, max_candidates * sizeof(hc_gather_row))) != hipSuccess) return cleanup(e, "rows");
+    if ((e = hipMalloc((void**)&b->d_tiles, 2 * (max_candidates / 1024 + 2) * sizeof(uint32_t))) != hipSuccess) return cleanup(e, "tiles");
     if ((e = hipHostMalloc((void**)&b->h_rows, max_candidates * sizeof(hc_gather_row), hipHostMallocMapped)) != hipSuccess)
         return cleanup(e, "row buffer");
     if ((e = hipHostMalloc((void**)&b->h_count, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return cleanup(e, "count buffer");
@@ -63,6 +68,8 @@ int hc_block_destroy(hc_block* b) {
     if (b->d_in) (void)hipFree(b->d_in);
     if (b->d_out) (void)hipFree(b->d_out);
     if (b->d_count) (void)hipFree(b->d_count);
+    if (b->d_rows) (void)hipFree(b->d_rows);
+    if (b->d_tiles) (void)hipFree(b->d_tiles);
     if (b->h_rows) (void)hipHostFree(b->h_rows);
     if (b->h_count) (void)hipHostFree(b->h_count);
     if (b->done) (void)hipEventDestroy(b->done);
@@ -80,17 +87,19 @@ int hc_block_submit(hc_block* b, const hc_cand_rec* cands, uint64_t n, uint64_t 
     if (n && !cands) return fail(HC_ERR_ARG, "hc_block_submit: null records");
     HC_HIP(hipSetDevice(c->device));
     b->n = n;
+    b->base_index = base_index;
     *b->h_count = 0;
     if (n) {
         void* d_rows = nullptr;
         HC_HIP(hipHostGetDevicePointer(&d_rows, b->h_rows, 0));
         HC_HIP(hipMemcpyAsync(b->d_in, cands, n * sizeof(hc_cand_rec), hipMemcpyHostToDevice, b->stream));
-        HC_HIP(hipMemsetAsync(b->d_count, 0, sizeof(unsigned long long), b->stream));
         // as given: the stage's blocks come from files in sfo2overlaps / FNO order; an unordered file still scores
         // correctly, only slower (hc_set_reorder(HC_REORDER_ALWAYS) sorts every block first)
-        int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_in, n, b->d_out, b->stream, false, (hc_gather_row*)d_rows, b->d_count, b->cap,
-                              base_index);
+        int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_in, n, b->d_out, b->stream, false, nullptr, nullptr, 0, 0);
         if (rc) return rc;
+        HC_HIP(hc::launch_kept_rows((const hc_result_rec*)b->d_out, n, nullptr, base_index, b->d_tiles, b->d_tiles + (b->cap / 1024 + 2), b->d_rows,
+                                    b->cap, b->d_count, nullptr, nullptr, b->stream));
+        HC_HIP(hc::launch_flush_rows(b->d_rows, d_rows, b->d_count, b->cap, sizeof(hc_gather_row), c->n_cu, b->stream));
         HC_HIP(hipMemcpyAsync(b->h_count, b->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
     }
     HC_HIP(hipEventRecord(b->done, b->stream));
@@ -108,9 +117,7 @@ int hc_block_wait(hc_block* b, const hc_gather_row** rows, uint64_t* n_rows) {
     b->in_flight = false;
     const uint64_t k = *b->h_count;
     if (k > b->cap) return fail(HC_ERR_STATE, "hc_block_wait: row count beyond the block's capacity");
-    // the kernel appends in no particular order; the stage consumes in sequence order
-    std::sort(b->h_rows, b->h_rows + k, [](const hc_gather_row& x, const hc_gather_row& y) { return x.index < y.index; });
-    *rows = b->h_rows;
+    *rows = b->h_rows;  // in sequence order as they are (launch_kept_rows)
     *n_rows = k;
     return HC_OK;
 }

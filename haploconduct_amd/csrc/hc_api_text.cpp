@@ -29,12 +29,14 @@ struct hc_textblock {
     hc_line_rec* d_lines = nullptr;            // max_lines
     hc_result_rec* d_out = nullptr;            // max_lines
     unsigned long long* d_counters = nullptr;  // hc::kTextCounters
-    hc_gather_row* h_rows = nullptr;           // page-locked, mapped: written by the scoring kernel
-    hc_line_rec* h_row_lines = nullptr;        // page-locked, mapped: the parsed line of every row
+    uint32_t* d_kept_tiles = nullptr;          // scratch of launch_kept_rows
+    hc_gather_row* d_rows = nullptr;           // row_cap rows: the non-dropped records in file order ...
+    hc_line_rec* d_row_lines = nullptr;        // ... each with the parsed line it came from
+    hc_gather_row* h_rows = nullptr;           // page-locked, mapped: both streamed out by copy kernels behind the scoring kernel
+    hc_line_rec* h_row_lines = nullptr;
     hc_text_reject* h_rejects = nullptr;       // page-locked, mapped: written by the parse kernel
     unsigned long long* h_counters = nullptr;  // page-locked
     std::vector<hc_text_row> rows;             // what hc_textblock_wait hands out
-    std::vector<uint64_t> keys;                // (index, slot) of the appended rows, for putting them in order
     bool in_flight = false;
 };
 
@@ -118,6 +120,9 @@ int hc_textblock_create(hc_ctx* c, uint64_t max_bytes, hc_textblock** out) {
     ok(hipMalloc((void**)&b->d_lines, L * sizeof(hc_line_rec)));
     ok(hipMalloc((void**)&b->d_out, L * sizeof(hc_result_rec)));
     ok(hipMalloc((void**)&b->d_counters, hc::kTextCounters * sizeof(unsigned long long)));
+    ok(hipMalloc((void**)&b->d_kept_tiles, 2 * (L / 1024 + 2) * sizeof(uint32_t)));
+    ok(hipMalloc((void**)&b->d_rows, RC * sizeof(hc_gather_row)));
+    ok(hipMalloc((void**)&b->d_row_lines, RC * sizeof(hc_line_rec)));
     ok(hipHostMalloc((void**)&b->h_rows, RC * sizeof(hc_gather_row), hipHostMallocMapped));
     ok(hipHostMalloc((void**)&b->h_row_lines, RC * sizeof(hc_line_rec), hipHostMallocMapped));
     ok(hipHostMalloc((void**)&b->h_rejects, RC * sizeof(hc_text_reject), hipHostMallocMapped));
@@ -137,7 +142,7 @@ int hc_textblock_destroy(hc_textblock* b) {
     (void)hipSetDevice(b->ctx->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void* p : {(void*)b->d_text, (void*)b->d_tile_cnt, (void*)b->d_tile_off, (void*)b->d_line_start, (void*)b->d_cands, (void*)b->d_lines,
-                    (void*)b->d_out, (void*)b->d_counters})
+                    (void*)b->d_out, (void*)b->d_counters, (void*)b->d_rows, (void*)b->d_row_lines, (void*)b->d_kept_tiles})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)b->h_text, (void*)b->h_rows, (void*)b->h_row_lines, (void*)b->h_rejects, (void*)b->h_counters})
         if (p) (void)hipHostFree(p);
@@ -182,10 +187,14 @@ int hc_textblock_submit(hc_textblock* b, uint64_t n_bytes, uint64_t first_line_n
         HC_HIP(hipHostGetDevicePointer(&d_row_lines, b->h_row_lines, 0));
         HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, s));
         // the scoring kernel on the records the parse kernel left behind; how many there are is only known on the device
-        int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_cands, b->max_lines, b->d_out, s, false, (hc_gather_row*)d_rows,
-                              b->d_counters + hc::kTextRows, b->row_cap, base_index, b->d_counters + hc::kTextLines, b->d_lines,
-                              (hc_line_rec*)d_row_lines);
+        int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_cands, b->max_lines, b->d_out, s, false, nullptr, nullptr, 0, 0,
+                              b->d_counters + hc::kTextLines);
         if (rc) return rc;
+        HC_HIP(hc::launch_kept_rows(b->d_out, b->max_lines, b->d_counters + hc::kTextLines, base_index, b->d_kept_tiles,
+                                    b->d_kept_tiles + (b->max_lines / 1024 + 2), b->d_rows, b->row_cap, b->d_counters + hc::kTextRows, b->d_lines,
+                                    b->d_row_lines, s));
+        HC_HIP(hc::launch_flush_rows(b->d_rows, d_rows, b->d_counters + hc::kTextRows, b->row_cap, sizeof(hc_gather_row), c->n_cu, s));
+        HC_HIP(hc::launch_flush_rows(b->d_row_lines, d_row_lines, b->d_counters + hc::kTextRows, b->row_cap, sizeof(hc_line_rec), c->n_cu, s));
     }
     HC_HIP(hipMemcpyAsync(b->h_counters, b->d_counters, hc::kTextCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HC_HIP(hipEventRecord(b->done, s));
@@ -215,16 +224,11 @@ int hc_textblock_wait(hc_textblock* b, hc_text_result* out) {
     out->prefilter_rejected = k[hc::kTextReject];
     out->scored = k[hc::kTextPass];
     const uint64_t n_rows = k[hc::kTextRows], n_rej = k[hc::kTextRejectSlots];
-    // the kernels append in no particular order; the stage consumes in file order
-    // (sorting 8-byte keys and gathering once, not 80-byte records)
-    b->keys.resize(n_rows);
-    for (uint64_t i = 0; i < n_rows; i++) b->keys[i] = (b->h_rows[i].index << 24) | i;  // index < 2^31 lines + base; slot < 2^24
-    std::sort(b->keys.begin(), b->keys.end());
+    // rows: in file order as they are (launch_kept_rows); the parse kernel's rejects are appended in no particular order
     b->rows.resize(n_rows);
     for (uint64_t i = 0; i < n_rows; i++) {
-        const uint64_t at = b->keys[i] & 0xFFFFFFu;
-        b->rows[i].row = b->h_rows[at];
-        b->rows[i].line = b->h_row_lines[at];
+        b->rows[i].row = b->h_rows[i];
+        b->rows[i].line = b->h_row_lines[i];
     }
     std::sort(b->h_rejects, b->h_rejects + n_rej, [](const hc_text_reject& x, const hc_text_reject& y) { return x.line_index < y.line_index; });
     out->rows = b->rows.data();

@@ -35,6 +35,11 @@ hipError_t launch_reorder(uint32_t n_reads, uint32_t fmt, const void* in, uint32
                           uint32_t* idx_in, uint32_t* perm_out, void* temp, size_t temp_bytes, hipStream_t stream);
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, uint32_t fmt, const void* in, uint64_t n,
                                   unsigned long long* totals, hipStream_t stream);
+hipError_t launch_kept_rows(const hc_result_rec* res, uint64_t n, const unsigned long long* n_dev, uint64_t base_index, uint32_t* tile_cnt,
+                            uint32_t* tile_off, hc_gather_row* rows, uint64_t cap, unsigned long long* count, const hc_line_rec* lines_in,
+                            hc_line_rec* lines_out, hipStream_t stream);
+hipError_t launch_flush_rows(const void* src, void* dst_mapped, const unsigned long long* count, uint64_t cap, uint32_t row_bytes, uint32_t n_cu,
+                             hipStream_t stream);
 
 int set_last_error(int status, const std::string& what);  // thread-local text behind hc_last_error()
 }  // namespace hc

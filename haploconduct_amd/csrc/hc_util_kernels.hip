@@ -146,6 +146,144 @@ hipError_t launch_pack_rows(const hc_result_rec* res, const uint32_t* idx, const
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// The non-dropped records of a scored block IN SEQUENCE ORDER, as rows tagged with their index — what the stage consumes.
+// (The scoring kernel's own row append is unordered: fine for the multi-GPU payload, whose consumer sorts once per
+// batch; the stage would sort every block on a host thread, which costs several times the block's PCIe time.)
+// Three small passes over the 24-byte result records, which the scoring kernel has just written (L2 / Infinity Cache):
+// non-dropped records per 1 024-record tile, exclusive scan of the tile counts, ordered scatter.
+constexpr uint32_t kKeptTile = 1024;
+
+__device__ __forceinline__ uint64_t records_of(uint64_t n, const unsigned long long* n_dev) {
+    if (!n_dev) return n;
+    const uint64_t nd = *n_dev;
+    return nd < n ? nd : n;
+}
+
+__global__ __launch_bounds__(256) void kept_count_kernel(const hc_result_rec* __restrict__ res, uint64_t n,
+                                                         const unsigned long long* __restrict__ n_dev, uint32_t* __restrict__ tile_cnt) {
+    n = records_of(n, n_dev);
+    const uint64_t i0 = (uint64_t)blockIdx.x * kKeptTile + threadIdx.x * 4u;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (i0 + j < n) c += (res[i0 + j].n_cls >> 28) != HC_CLS_DROP;
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_down((int)c, o, 64);
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// tile_off[t] = sum of tile_cnt[0..t); *total = the sum of all.  One workgroup.
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t* __restrict__ tile_cnt, uint32_t n_tiles, uint32_t* __restrict__ tile_off,
+                                                          unsigned long long* __restrict__ total) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_tiles ? tile_cnt[i] : 0u;
+        uint32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+            if ((int)(threadIdx.x & 63u) >= o) incl += up;
+        }
+        if ((threadIdx.x & 63u) == 63u) wave_sum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wave_sum[w];
+        if (i < n_tiles) tile_off[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void kept_scatter_kernel(const hc_result_rec* __restrict__ res, uint64_t n,
+                                                           const unsigned long long* __restrict__ n_dev, const uint32_t* __restrict__ tile_off,
+                                                           uint64_t base_index, hc_gather_row* __restrict__ rows, uint64_t cap,
+                                                           const hc_line_rec* __restrict__ lines_in, hc_line_rec* __restrict__ lines_out) {
+    n = records_of(n, n_dev);
+    const uint64_t i0 = (uint64_t)blockIdx.x * kKeptTile + threadIdx.x * 4u;
+    hc_result_rec r[4];
+    uint32_t keep[4], c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        keep[j] = 0;
+        if (i0 + j < n) {
+            r[j] = res[i0 + j];
+            keep[j] = (r[j].n_cls >> 28) != HC_CLS_DROP;
+        }
+        c += keep[j];
+    }
+    uint32_t incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if ((int)(threadIdx.x & 63u) >= o) incl += up;
+    }
+    __shared__ uint32_t wave_sum[4];
+    if ((threadIdx.x & 63u) == 63u) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t at = (uint64_t)tile_off[blockIdx.x] + incl - c;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) at += wave_sum[w];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (keep[j]) {
+            if (at < cap) {
+                hc_gather_row o;
+                o.index = base_index + i0 + j;
+                o.x1 = r[j].x1;
+                o.x2 = r[j].x2;
+                o.mm = r[j].mm;
+                o.n_cls = r[j].n_cls;
+                rows[at] = o;
+                if (lines_in) {
+                    const uint4* a = (const uint4*)(lines_in + i0 + j);
+                    uint4* b = (uint4*)(lines_out + at);
+                    b[0] = a[0];
+                    b[1] = a[1];
+                    b[2] = a[2];
+                }
+            }
+            at++;
+        }
+}
+
+// rows / lines_out: device buffers of cap records; *count = number of non-dropped records (may exceed cap).
+// tile_cnt / tile_off: scratch of (n + 1023) / 1024 + 1 entries each.
+hipError_t launch_kept_rows(const hc_result_rec* res, uint64_t n, const unsigned long long* n_dev, uint64_t base_index, uint32_t* tile_cnt,
+                            uint32_t* tile_off, hc_gather_row* rows, uint64_t cap, unsigned long long* count, const hc_line_rec* lines_in,
+                            hc_line_rec* lines_out, hipStream_t stream) {
+    const uint32_t n_tiles = (uint32_t)((n + kKeptTile - 1) / kKeptTile);
+    if (n_tiles == 0) return hipMemsetAsync(count, 0, sizeof(unsigned long long), stream);
+    hipLaunchKernelGGL(kept_count_kernel, dim3(n_tiles), dim3(256), 0, stream, res, n, n_dev, tile_cnt);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, tile_cnt, n_tiles, tile_off, count);
+    hipLaunchKernelGGL(kept_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, res, n, n_dev, tile_off, base_index, rows, cap, lines_in, lines_out);
+    return hipGetLastError();
+}
+
+// Rows in a DEVICE buffer -> page-locked host memory mapped into the device's address
+// space, as one coalesced stream of 16-byte pieces (consecutive lanes write consecutive pieces: full-size PCIe writes;
+// scattered 32-byte stores cross PCIe at a fraction of the rate).
+__global__ __launch_bounds__(256) void flush_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                         const unsigned long long* __restrict__ count, unsigned long long cap,
+                                                         uint32_t pieces_per_row) {
+    unsigned long long k = *count;
+    k = (k < cap ? k : cap) * pieces_per_row;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += (unsigned long long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+hipError_t launch_flush_rows(const void* src, void* dst_mapped, const unsigned long long* count, uint64_t cap, uint32_t row_bytes, uint32_t n_cu,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(flush_rows_kernel, dim3(n_cu), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst_mapped, count,
+                       (unsigned long long)cap, row_bytes / 16u);
+    return hipGetLastError();
+}
+
 hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, uint32_t fmt, const void* in, uint64_t n,
                                   unsigned long long* totals, hipStream_t stream) {
     if (n == 0) return hipSuccess;

@@ -38,27 +38,37 @@ def main():
                 blocks.append(b)
             rows, k = C.c_void_p(), C.c_uint64()
 
+            spent = {"submit": 0.0, "wait": 0.0}
+
             def run():
                 pending, kept = [], 0
                 for i, at in enumerate(range(0, n, block)):
                     if len(pending) == depth:
+                        t = time.perf_counter()
                         N.check(N.lib.hc_block_wait(pending.pop(0), C.byref(rows), C.byref(k)), "hc_block_wait")
+                        spent["wait"] += time.perf_counter() - t
                         kept += k.value
                     b = blocks[i % depth]
+                    t = time.perf_counter()
                     N.check(N.lib.hc_block_submit(b, C.c_void_p(pin.value + at * 16), min(block, n - at), at), "hc_block_submit")
+                    spent["submit"] += time.perf_counter() - t
                     pending.append(b)
                 while pending:
+                    t = time.perf_counter()
                     N.check(N.lib.hc_block_wait(pending.pop(0), C.byref(rows), C.byref(k)), "hc_block_wait")
+                    spent["wait"] += time.perf_counter() - t
                     kept += k.value
                 return kept
 
             run()
             reps = 5 if n > 10000000 else 30
+            spent["submit"] = spent["wait"] = 0.0
             t0 = time.perf_counter()
             for _ in range(reps):
                 kept = run()
             dt = (time.perf_counter() - t0) / reps
             res[f"blocks_{block}_x{depth}"] = {"ms": round(dt * 1e3, 3), "candidates_per_s": round(n / dt), "rows_back": kept,
+                                               "in_submit_ms": round(spent["submit"] / reps * 1e3, 3), "in_wait_ms": round(spent["wait"] / reps * 1e3, 3),
                                                "pcie_GB_per_s": round((n * 16 + kept * 32) / dt / 1e9, 1)}
             for b in blocks:
                 N.lib.hc_block_destroy(b)
