@@ -186,7 +186,7 @@ static bool build_lut(const std::vector<int>& phred, double mismatch_setting, ui
     const uint32_t lg = hc::lut_lg((uint32_t)K);
     const bool wide = symbytes == 1 && lg == 6;
     const size_t dim = symbytes == 1 ? ((size_t)1 << lg) : Kp;  // rows / columns that can be addressed
-    lut.assign(symbytes == 1 ? (size_t)2 << (2 * lg) : (size_t)hc::lut_tri((uint32_t)Kp) * 2, nan);
+    lut.assign(symbytes == 1 ? (size_t)hc::lut_doubles_u8(lg) : (size_t)hc::lut_tri((uint32_t)Kp) * 2, nan);
     bool symmetric = true;  // the 16-bit layout keeps one triangle: every (a, b) must equal (b, a) bit for bit
     for (size_t a = 0; a < dim; a++) {
         for (size_t b = 0; b < dim; b++) {
@@ -335,6 +335,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     c->view.symbytes = symbytes;
     c->view.lut_bytes = (uint32_t)(lut.size() * sizeof(double));
     c->store_bytes = sym_bytes_total;
+    c->view.store_bytes = sym_bytes_total;
     c->have_reads = true;
     {
         uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
@@ -346,12 +347,12 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         if (const char* b = getenv("HC_BALANCE")) c->view.balance = atoi(b) != 0;
     }
     if (const char* v = getenv("HC_FETCH_GROUP")) {
-        c->fetch_group = atoi(v) == 2 ? 2 : 4;
+        c->fetch_group = !strcmp(v, "coop") ? 0 : (atoi(v) == 2 ? 2 : 4);
     } else {
         // 64-symbol fetch groups for short-read sets, 32-symbol groups when the
         // sequences are long (contigs): measured on BASELINE configs 2-5, see DESIGN.md
         const uint64_t mean_len = n_seq ? total / n_seq : 0;
-        c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 4;
+        c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 0;  // 0: cooperative fetch where the kernel has it (launch_score), else 4
     }
     return HC_OK;
 }

@@ -83,8 +83,9 @@ struct hc_ctx {
     hc_settings settings;
     int device = 0;
     uint32_t n_cu = 256;
-    int fetch_group = 4;  // 16-symbol chunks per fetch group of the scoring kernel: 4 (short reads) or 2 (contigs);
-                          // chosen per read set in hc_set_reads (HC_FETCH_GROUP overrides: a tuning knob only)
+    int fetch_group = 4;  // how the scoring kernel fetches symbols: 0 = cooperatively (quads fetch 64-byte rows, short reads),
+                          // 4 / 2 = per lane in groups of 4 / 2 16-symbol chunks (2: contigs); chosen per read set in
+                          // hc_set_reads (HC_FETCH_GROUP=coop|4|2 overrides: a tuning knob only)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // read store

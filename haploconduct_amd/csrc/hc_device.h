@@ -14,7 +14,8 @@
 //          invalid symbol gets qidx = K+1 (the NaN row: poisons the sum, the lane then
 //          re-scans the overlap position by position to report exactly what the reference
 //          would do).  Table dimension Kp = K + 2.
-//   K <= 30 -> uint8 symbols as above (5-bit qidx, 3-bit code);
+//   K <= 30 -> uint8 symbols as above (5-bit qidx, 3-bit code); with K <= 6 (3-bit qidx) bits 6-7 of the symbol repeat
+//          the low two bits of qidx (they are address bits of the K <= 6 log table as they stand, see below);
 //   31 <= K <= 48 -> "wide" uint8 symbols  sym = (qidx << 2) | base2  (6-bit qidx, A,C,G,T = 0..3) with the
 //          reserved indices 48 = N, 49 = invalid quality, 50 = invalid base (recognisable by the two top bits);
 //   K > 48 -> uint16 symbols  (qidx << 3) | code.
@@ -59,10 +60,17 @@ struct StoreView {
     uint32_t symbytes;  // 1 or 2
     uint32_t lut_bytes; // bytes of the log table as laid out for this symbol width
     uint32_t balance;   // 1: sequence lengths differ widely -> block-local length balancing in the scoring kernel
+    uint64_t store_bytes;  // bytes of the symbol store (the cooperative fetch addresses it through a buffer descriptor)
 };
 
 // Log table layouts (doubles):
-//   uint8 symbols : two dense planes (match, mismatch) of 2^LG x 2^LG entries, LG = ceil(log2(Kp)) in {3,4,5}:
+//   uint8 symbols, LG = 3 (Kp <= 8): SPARSE, 16 KiB of address space for 128 entries:
+//                   byte address = qa << 11 | m << 10 | (qa & 3) << 6 | ((qb ^ qa) & 7) << 3
+//                   — every field sits where the symbol byte (qidx << 3 | code, low index bits repeated in bits 6-7),
+//                   the XOR of the two symbol bytes and the mismatch flag (bit 2) already have it: two AND-ORs per four
+//                   positions build the four addresses' bytes, no shifts.  The (qa & 3) and XOR fields select the LDS
+//                   bank, as in the dense layouts.
+//   uint8 symbols, LG in {4,5}: two dense planes (match, mismatch) of 2^LG x 2^LG entries, LG = ceil(log2(Kp)):
 //                   byte address = m * (8 << 2LG) + qa * (8 << LG) + ((qb ^ qa) & (2^LG - 1)) * 8.
 //                   The address of a position is exactly the 16-bit value one v_perm_b32 assembles from two
 //                   pre-masked symbol bytes (no shift, no multiply); the XOR of the column with the row
@@ -82,7 +90,10 @@ __host__ __device__ inline uint32_t lut_addr_u16(uint32_t Kp, uint32_t qa, uint3
     const uint32_t hi = qa > qb ? qa : qb, lo = qa > qb ? qb : qa;
     return (m * lut_tri(Kp) + hi * (hi + 1u) / 2u + lo) * 8u;
 }
+// doubles of the 8-bit-symbol table as laid out in LDS
+__host__ __device__ inline uint32_t lut_doubles_u8(uint32_t lg) { return lg == 3 ? 2048u : (2u << (2 * lg)); }
 __host__ __device__ inline uint32_t lut_addr_u8(uint32_t lg, uint32_t qa, uint32_t qb, uint32_t m) {
+    if (lg == 3) return (qa << 11) | (m << 10) | ((qa & 3u) << 6) | (((qb ^ qa) & 7u) << 3);
     return m * (8u << (2 * lg)) + qa * (8u << lg) + ((qb ^ qa) & ((1u << lg) - 1u)) * 8u;
 }
 

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    const SymT nsym = WIDE ? (SymT)(kWideN << 2) : (SymT)((K << 3) | kCodeN);
+    // smallest 8-bit table (lut_lg == 3): the index's low two bits once more in bits 6-7 of the symbol (hc_device.h)
+    const bool dup = sizeof(SymT) == 1 && !WIDE && lut_lg(K) == 3;
+    const SymT nsym = WIDE ? (SymT)(kWideN << 2) : (SymT)((K << 3) | kCodeN | (dup ? (K & 3u) << 6 : 0u));
     for (uint32_t q = wave; q < n_seq; q += n_waves) {
         const uint64_t r0 = raw_off[q];
         const uint32_t len = (uint32_t)(raw_off[q + 1] - r0);
@@ -84,8 +86,9 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                         qx = K + 1;
                     }
                     const uint32_t rcode = code < 4 ? 3 - code : code;
-                    sym[f0 + i] = (SymT)((qx << 3) | code);
-                    sym[f0 + stride + (len - 1 - i)] = (SymT)((qx << 3) | rcode);
+                    const uint32_t qbits = (qx << 3) | (dup ? (qx & 3u) << 6 : 0u);
+                    sym[f0 + i] = (SymT)(qbits | code);
+                    sym[f0 + stride + (len - 1 - i)] = (SymT)(qbits | rcode);
                 }
             } else {
                 sym[f0 + i] = nsym;
@@ -148,16 +151,18 @@ struct Tr<uint16_t> {
     static constexpr int kSymBits = 16;
 };
 
-__device__ __forceinline__ double lds_f64(const char* lut, uint32_t byte_addr) {
-    return *(const double*)(lut + byte_addr);
+// The log table starts at LDS address 0 (the kernel has no other LDS than its one dynamic array; checked at entry), so a
+// table byte address IS the LDS address: no per-position base add in front of the ds_read_b64.
+typedef const __attribute__((address_space(3))) double lds_cdouble;
+__device__ __forceinline__ double lds_f64(uint32_t byte_addr) {
+    return *(lds_cdouble*)(uintptr_t)byte_addr;
 }
 
 // Exact per-position re-scan (rare: only when the fast sum came out NaN, i.e. the window
 // holds an invalid base / quality byte).  Mirrors the reference's order of checks:
 // all quality bytes of the window first (:92-101), then position by position (:106-128).
 template <typename SymT>
-__device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, const SymT* __restrict__ b, uint32_t L,
-                                                const char* lut, uint32_t Kp) {
+__device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, const SymT* __restrict__ b, uint32_t L, uint32_t Kp) {
     const uint32_t lg = lut_lg(Kp - 2u);
     SubScore r;
     r.x = -__builtin_inf();
@@ -190,9 +195,11 @@ __device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, cons
         }
         if (ka == 1u || kb == 1u) continue;  // N: :35-39, :122-124
         const uint32_t m = wide ? ((sa & 3u) != (sb & 3u)) : ((sa & 7u) != (sb & 7u));
-        const uint32_t qa = wide ? sa >> 2 : sa >> 3, qb = wide ? sb >> 2 : sb >> 3;
+        // 8-bit symbols of the smallest table carry a copy of the index's low bits above it (hc_device.h)
+        const uint32_t qmask = sizeof(SymT) == 1 ? (1u << lg) - 1u : 0xFFFFu;
+        const uint32_t qa = wide ? sa >> 2 : (sa >> 3) & qmask, qb = wide ? sb >> 2 : (sb >> 3) & qmask;
         const uint32_t addr = sizeof(SymT) == 1 ? lut_addr_u8(lg, qa, qb, m) : lut_addr_u16(Kp, qa, qb, m);
-        const double t = lds_f64(lut, addr);
+        const double t = lds_f64(addr);
         if (t == __builtin_inf()) return r;  // :125-127
         S += t;
         cn += 1;
@@ -205,30 +212,19 @@ __device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, cons
     return r;
 }
 
-// Tail masks: kMaskTab[r][j] keeps the first r symbols of a 16-symbol chunk, as four (uint8) or
-// eight (uint16) 32-bit words.  Lives in LDS right behind the log table (one ds_read_b128 per
-// chunk instead of ~35 VALU instructions of shift/compare/select).
-template <typename SymT>
-__device__ __forceinline__ void fill_mask_table(uint32_t* tab /* 17 * kWords */, uint32_t tid, uint32_t nthreads) {
-    using T = Tr<SymT>;
-    for (uint32_t i = tid; i < 17u * T::kWords; i += nthreads) {
-        const int r = (int)(i / T::kWords), j = (int)(i % T::kWords);
-        const int left = r - j * T::kSymsPerWord;
-        tab[i] = left >= T::kSymsPerWord ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << (left * T::kSymBits)) - 1u));
-    }
-}
-
-// The table reads of one half-chunk (8 positions): packed-byte N / mismatch masks and counters, then
-// one LDS address per position.  aw/bw/keep point at the half's 32-bit words.
+// The table reads of one half-chunk (8 positions): packed-byte N / mismatch masks and counters, then one LDS address per
+// position.  wa/wb point at the half's 32-bit words.  Symbols at or beyond the end of the overlap need no masking: there
+// at least one of the two streams is in the N padding behind its sequence (L = min(lenA - pos, lenB); every slot is
+// padded with N symbols to a multiple of 16 plus 32 bytes), and a position with an N adds 0.0 and counts as skipped.
+// cn4 / cm4: per-byte counters in steps of 4 (the flag sits at bit 2 of its byte); the caller folds them at least every
+// 63 words.  The wide encoding keeps plain popcounts (its flags sit at bit 7).
 template <typename SymT, int LG>
-__device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint32_t* wb, const uint32_t* keep,
-                                                 uint32_t nsym_word, const char* lut, uint32_t Kp, double (&t)[8],
-                                                 uint32_t& skipped, uint32_t& cm) {
+__device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint32_t* wb, uint32_t Kp, double (&t)[8], uint32_t& cn4,
+                                                 uint32_t& cm4) {
     using T = Tr<SymT>;
 #pragma unroll
     for (int jj = 0; jj < T::kWords / 2; ++jj) {
-        // symbols at or beyond L become N: they add 0.0 and count as skipped
-        const uint32_t aw = (wa[jj] & keep[jj]) | (nsym_word & ~keep[jj]);
+        const uint32_t aw = wa[jj];
         const uint32_t bw = wb[jj];
         const uint32_t e = aw ^ bw;
         if (sizeof(SymT) == 1 && LG == 6) {
@@ -236,23 +232,22 @@ __device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint3
             // address = m << 15 | qa << 9 | ((qb ^ qa) & 63) << 3
             const uint32_t nm = ((aw & (aw << 1)) | (bw & (bw << 1))) & 0x80808080u;
             const uint32_t mk = ((e << 7) | (e << 6)) & 0x80808080u & ~nm;  // base bits differ, neither is N
-            skipped += __builtin_popcount(nm);
-            cm += __builtin_popcount(mk);
+            cn4 += __builtin_popcount(nm);
+            cm4 += __builtin_popcount(mk);
             const uint32_t lo = (e << 1) & 0xF8F8F8F8u;
             const uint32_t hi = ((e >> 7) & 0x01010101u) | ((aw >> 1) & 0x7E7E7E7Eu) | mk;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                t[jj * 4 + k] = lds_f64(lut, __builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
+                t[jj * 4 + k] = lds_f64(__builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
             continue;
         }
         const uint32_t x = aw | bw;
         const uint32_t nm = x & (T::kLow1 << 2);                             // code bit 2 on either side: N (or invalid)
         const uint32_t mk = ((e << 1) | (e << 2)) & (T::kLow1 << 2) & ~x;  // bases differ, neither is N
-        skipped += __builtin_popcount(nm);
-        cm += __builtin_popcount(mk);
+        cn4 += nm;
+        cm4 += mk;
         if (sizeof(SymT) == 1) {
-            // Two bytes per position whose concatenation IS the table's byte address
-            //   m * (8 << 2LG) + qa * (8 << LG) + (qb ^ qa) * 8        (hc_device.h)
+            // Two bytes per position whose concatenation IS the table's byte address (hc_device.h: lut_addr_u8);
             // symbol byte = qidx << 3 | code, mk holds the mismatch flag at bit 2 of each byte, e = aw ^ bw.
             uint32_t lo, hi;
             if (LG == 5) {         // bits 3-7: qb^qa | bits 8-12: qa, bit 13: m
@@ -261,13 +256,14 @@ __device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint3
             } else if (LG == 4) {  // bits 3-6: qb^qa, bit 7: qa0 | bits 8-10: qa>>1, bit 11: m
                 lo = (e & 0x78787878u) | ((aw << 4) & 0x80808080u);
                 hi = ((aw >> 4) & 0x07070707u) | (mk << 1);
-            } else {               // bits 3-5: qb^qa, bits 6-7: qa&3 | bit 8: qa>>2, bit 9: m
-                lo = (e & 0x38383838u) | ((aw << 3) & 0xC0C0C0C0u);
-                hi = ((aw >> 5) & 0x01010101u) | (mk >> 1);
+            } else {               // sparse layout, nothing to shift: bits 3-5: qb^qa, bits 6-7: qa&3 (the symbol's own
+                                   // bits 6-7) | bit 10: m, bits 11-13: qa
+                lo = (e & 0x38383838u) | (aw & 0xC0C0C0C0u);
+                hi = (aw & 0x38383838u) | mk;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                t[jj * 4 + k] = lds_f64(lut, __builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
+                t[jj * 4 + k] = lds_f64(__builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
         } else {
             // two positions per packed 16-bit op: entry = m*T + hi*(hi+1)/2 + lo of the triangular planes (hc_device.h;
             // < 2*4753, fits 16 bits; hi*(hi+1) <= 96*97 does too)
@@ -279,75 +275,79 @@ __device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint3
             const u16x2 one2 = {1, 1};
             const u16x2 tri2 = {(unsigned short)lut_tri(Kp), (unsigned short)lut_tri(Kp)};
             const uint32_t e2 = __builtin_bit_cast(uint32_t, (u16x2)(m2 * tri2 + (((hi2 * (hi2 + one2)) >> (unsigned short)1) + lo2)));
-            t[jj * 2 + 0] = lds_f64(lut, (e2 << 3) & 0x7FFF8u);
-            t[jj * 2 + 1] = lds_f64(lut, (e2 >> 13) & 0x7FFF8u);
+            t[jj * 2 + 0] = lds_f64((e2 << 3) & 0x7FFF8u);
+            t[jj * 2 + 1] = lds_f64((e2 >> 13) & 0x7FFF8u);
         }
     }
 }
 
-// One sub-overlap with 64-symbol fetch groups: a lane pulls four consecutive 16-byte pieces of each
-// stream back to back (one whole 64-byte line of an aligned stream), so a line is fetched into L1 once
-// and consumed at once instead of being re-requested by four separate loop iterations that other
-// waves' lines evict in between.  The next group is prefetched while the current one is scored.
+// One sub-overlap with 64-symbol fetch groups: a lane pulls four consecutive 16-byte pieces of each stream back to back
+// (one whole 64-byte line of an aligned stream), so a line is fetched into L1 once and consumed at once instead of being
+// re-requested by four separate loop iterations that other waves' lines evict in between.  The next group is in flight
+// while the current one is scored.
 template <typename SymT, int LG, int G /* 16-symbol chunks per group */>
-__device__ __forceinline__ void score_sub_wide(const SymT* __restrict__ sym, const Sub& s, const char* lut,
-                                               const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word,
-                                               uint32_t min_read_len, SubScore& out) {
+__device__ __forceinline__ void score_sub_wide(const SymT* __restrict__ a, const SymT* __restrict__ b, uint32_t L, uint32_t fatal,
+                                               uint32_t Kp, SubScore& out) {
     using T = Tr<SymT>;
+    constexpr bool kPacked = !(sizeof(SymT) == 1 && LG == 6);  // per-byte counters (half_chunk_terms)
     out.x = -__builtin_inf();
     out.mm = 1;
     out.n = 1;
-    out.err = s.fatal;
-    const uint32_t L = sub_positions(s, min_read_len);
+    out.err = fatal;
     if (L == 0) return;
     const uint32_t nch = (L + 15u) >> 4;
-    const SymT* a = sym + s.offA + s.pos;
-    const SymT* b = sym + s.offB;
     double S = 0.0;
     uint32_t skipped = 0, cm = 0;
-    uint32_t na[G][T::kWords] = {}, nb[G][T::kWords] = {};
-#pragma unroll
-    for (int q = 0; q < G; ++q)
-        if ((uint32_t)q < nch) {
-            __builtin_memcpy(na[q], a + 16u * q, sizeof(na[q]));
-            __builtin_memcpy(nb[q], b + 16u * q, sizeof(nb[q]));
-        }
-    for (uint32_t c0 = 0; c0 < nch; c0 += G) {
-        uint32_t ca[G][T::kWords], cb[G][T::kWords];
-#pragma unroll
-        for (int q = 0; q < G; ++q) {
-#pragma unroll
-            for (int w = 0; w < T::kWords; ++w) {
-                ca[q][w] = na[q][w];
-                cb[q][w] = nb[q][w];
-            }
-        }
+    // two register sets (x / y) take turns: while one group is scored the next one is in flight into the other set
+    uint32_t xa[G][T::kWords], xb[G][T::kWords], ya[G][T::kWords], yb[G][T::kWords];
+    auto fetch = [&](uint32_t (&ra)[G][T::kWords], uint32_t (&rb)[G][T::kWords], uint32_t cbase) {
 #pragma unroll
         for (int q = 0; q < G; ++q)
-            if (c0 + G + q < nch) {
-                __builtin_memcpy(na[q], a + 16u * (c0 + G + q), sizeof(na[q]));
-                __builtin_memcpy(nb[q], b + 16u * (c0 + G + q), sizeof(nb[q]));
+            if (cbase + q < nch) {
+                __builtin_memcpy(ra[q], a + 16u * (cbase + q), sizeof(ra[q]));
+                __builtin_memcpy(rb[q], b + 16u * (cbase + q), sizeof(rb[q]));
             }
+    };
+    auto score_group = [&](const uint32_t (&ra)[G][T::kWords], const uint32_t (&rb)[G][T::kWords], uint32_t cbase) {
+        uint32_t cn4 = 0, cm4 = 0;
 #pragma unroll
-        for (int q = 0; q < G; ++q) {
-            const uint32_t c = c0 + q;
-            if (c < nch) {
-                uint32_t keep[T::kWords];
-                const uint32_t rem = L - 16u * c;
-                __builtin_memcpy(keep, masktab + (rem >= 16u ? 16u : rem) * T::kWords, sizeof(keep));
+        for (int q = 0; q < G; ++q)
+            if (cbase + q < nch) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     double t[8];
-                    half_chunk_terms<SymT, LG>(ca[q] + h * (T::kWords / 2), cb[q] + h * (T::kWords / 2), keep + h * (T::kWords / 2),
-                                               nsym_word, lut, Kp, t, skipped, cm);
+                    half_chunk_terms<SymT, LG>(ra[q] + h * (T::kWords / 2), rb[q] + h * (T::kWords / 2), Kp, t, cn4, cm4);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) S += t[k];  // :119, strictly in position order
                 }
             }
+        if (kPacked) {  // a byte (16-bit lane) of cn4 / cm4 holds at most 4 * 4 * G <= 64 here
+            skipped = __builtin_amdgcn_sad_u8(cn4, 0u, skipped);
+            cm = __builtin_amdgcn_sad_u8(cm4, 0u, cm);
+        } else {
+            skipped += cn4;
+            cm += cm4;
         }
+    };
+    // `arrived`: loads complete in order, so a (pretended) use of the set's last register makes the compiler wait for the
+    // set HERE, before the other set's loads are issued — otherwise it waits at the first real use, behind those loads,
+    // and (the loads being conditional) for them too.
+    auto arrived = [](uint32_t (&rb)[G][T::kWords]) { asm volatile("" : "+v"(rb[G - 1][T::kWords - 1])); };
+    fetch(xa, xb, 0);
+    for (uint32_t c0 = 0; c0 < nch; c0 += 2 * G) {
+        arrived(xb);
+        fetch(ya, yb, c0 + G);
+        score_group(xa, xb, c0);
+        arrived(yb);
+        fetch(xa, xb, c0 + 2 * G);
+        score_group(ya, yb, c0 + G);
     }
-    if (S != S) {  // an invalid symbol inside the window
-        const SubScore e = score_sub_slow<SymT>(a, b, L, lut, Kp);
+    if (kPacked) {
+        skipped >>= 2;
+        cm >>= 2;
+    }
+    if (S != S) {  // an invalid symbol inside the window (or next to it, in the last chunk)
+        const SubScore e = score_sub_slow<SymT>(a, b, L, Kp);
         out.x = e.x;
         out.mm = e.mm;
         out.n = e.n;
@@ -356,6 +356,139 @@ __device__ __forceinline__ void score_sub_wide(const SymT* __restrict__ sym, con
     }
     if (S == __builtin_inf()) return;
     const uint32_t cn = 16u * nch - skipped;
+    if (cn == 0) return;
+    out.x = (1.0 / (double)cn) * S;
+    out.mm = cm;
+    out.n = cn;
+}
+
+// ---------------------------------------------------------------------------
+// Cooperative fetch (the memory side of the kernel, measured alone: tools/experiments/gather_shapes.hip — one lane
+// fetching its own candidate's windows 16 bytes at a time is bound by the L1's tag look-ups, one per lane and load; four
+// lanes fetching ONE candidate's 64 contiguous bytes need a quarter of them: 1.67x the candidates per second).
+//
+// The 64 candidates of a wave advance together in 64-byte rows (64 symbols of 8 bits, 32 of 16).  Lane l OWNS candidate
+// l (it adds that candidate's terms, in position order, as before) and is also a LOADER: in load j (0..3) it fetches
+// the 16-byte piece (l & 3) ^ ((l >> 4) & 3) of the current row of candidate 16 j + (l >> 2), so a quad reads one
+// candidate's 64 contiguous bytes.  The pieces go through a per-wave LDS image of 64 rows x 64 bytes — written lane-linear
+// (1 KiB per instruction), read by the owner one row per lane; the XOR of the piece number with (row >> 2) & 3 puts the 16
+// rows a 128-bit LDS read serves in one pass into 16 different bank groups.  The A rows and then the B rows of a step pass
+// through the same image (the owner keeps its A row in registers); the next step's pieces are in flight into registers
+// meanwhile.  Loads go through a buffer descriptor of the store: a piece that is not needed (beyond the candidate's
+// window) gets an out-of-range offset, which the range check drops without a memory access — no divergent control flow
+// around the loads, so the compiler counts them exactly (s_waitcnt vmcnt(N)).  Wave-synchronous: no workgroup barrier;
+// LDS executes one wave's instructions in order.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+__device__ __forceinline__ void lds_store128(uint32_t addr, u32x4 v) { *(lds_u32x4*)(uintptr_t)addr = v; }
+__device__ __forceinline__ u32x4 lds_load128(uint32_t addr) { return *(const lds_u32x4*)(uintptr_t)addr; }
+__device__ __forceinline__ void wave_lds_order() {  // keeps the compiler from reordering the image's stores and loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr uint32_t kStageBytesPerWave = 64u * 64u;
+
+// One sub-overlap of each of the wave's 64 candidates.  Called by all 64 lanes; a lane without one passes L = 0.
+// offA / offB: byte offsets of the window starts in the store; L: positions (sub_positions()).
+template <typename SymT, int LG>
+__device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, const SymT* __restrict__ sym, uint32_t stage, uint32_t offA,
+                                               uint32_t offB, uint32_t L, uint32_t fatal, uint32_t Kp, SubScore& out) {
+    using T = Tr<SymT>;
+    constexpr uint32_t kSymB = sizeof(SymT);
+    constexpr int kChunks = 4 / kSymB;            // 16-symbol chunks per 64-byte row
+    constexpr uint32_t kChunkB = 16u * kSymB;     // bytes per chunk
+    constexpr bool kPacked = !(sizeof(SymT) == 1 && LG == 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t piece = (lane & 3u) ^ ((lane >> 4) & 3u);   // of the row, as a loader
+    const uint32_t Lb = L * kSymB;
+    uint32_t la[4], lb[4], lim[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int src = 16 * j + (int)(lane >> 2);
+        la[j] = (uint32_t)__shfl((int)offA, src, 64) + 16u * piece;
+        lb[j] = (uint32_t)__shfl((int)offB, src, 64) + 16u * piece;
+        // a piece is wanted while the chunk it belongs to starts inside the window
+        const uint32_t end = (uint32_t)__shfl((int)Lb, src, 64), cs = (16u * piece) & ~(kChunkB - 1u);
+        lim[j] = end > cs ? end - cs : 0u;
+    }
+    const uint32_t wr = stage + lane * 16u;                                  // + j KiB: lane-linear
+    const uint32_t rd = stage + lane * 64u + (((lane >> 2) & 3u) << 4);    // ^ piece << 4
+    u32x4 nA[4], nB[4];
+    auto fetch = [&](uint32_t at) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = at < lim[j];
+            nA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] + at : 0xFFFFFFFFu, 0, 0);
+            nB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] + at : 0xFFFFFFFFu, 0, 0);
+        }
+    };
+    fetch(0);
+    double S = 0.0;
+    uint32_t skipped = 0, cm = 0;
+    for (uint32_t at = 0; __ballot(at < Lb) != 0ull; at += 64u) {  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_store128(wr + 1024u * j, nA[j]);
+        wave_lds_order();
+        u32x4 xa[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) xa[p] = lds_load128(rd ^ ((uint32_t)p << 4));
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_store128(wr + 1024u * j, nB[j]);
+        wave_lds_order();
+        fetch(at + 64u);
+        uint32_t cn4 = 0, cm4 = 0;
+#pragma unroll
+        for (int q = 0; q < kChunks; ++q)
+            if (at + kChunkB * q < Lb) {
+                uint32_t wa[T::kWords], wb[T::kWords];
+#pragma unroll
+                for (int s = 0; s < (int)kSymB; ++s) {
+                    const int p = q * (int)kSymB + s;
+                    const u32x4 vb = lds_load128(rd ^ ((uint32_t)p << 4));
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        wa[4 * s + w] = xa[p][w];
+                        wb[4 * s + w] = vb[w];
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double t[8];
+                    half_chunk_terms<SymT, LG>(wa + h * (T::kWords / 2), wb + h * (T::kWords / 2), Kp, t, cn4, cm4);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) S += t[k];  // :119, strictly in position order
+                }
+            }
+        if (kPacked) {
+            skipped = __builtin_amdgcn_sad_u8(cn4, 0u, skipped);
+            cm = __builtin_amdgcn_sad_u8(cm4, 0u, cm);
+        } else {
+            skipped += cn4;
+            cm += cm4;
+        }
+        wave_lds_order();  // the owners' reads of this step's B rows stay in front of the next step's stores
+    }
+    out.x = -__builtin_inf();
+    out.mm = 1;
+    out.n = 1;
+    out.err = fatal;
+    if (L == 0) return;
+    if (kPacked) {
+        skipped >>= 2;
+        cm >>= 2;
+    }
+    if (S != S) {  // an invalid symbol inside the window (or next to it, in the last chunk)
+        const SubScore e = score_sub_slow<SymT>((const SymT*)((const char*)sym + offA), (const SymT*)((const char*)sym + offB), L, Kp);
+        out.x = e.x;
+        out.mm = e.mm;
+        out.n = e.n;
+        out.err |= e.err;
+        return;
+    }
+    if (S == __builtin_inf()) return;
+    const uint32_t cn = 16u * ((L + 15u) >> 4) - skipped;
     if (cn == 0) return;
     out.x = (1.0 / (double)cn) * S;
     out.mm = cm;
@@ -410,8 +543,7 @@ __device__ __forceinline__ hc_result_rec classify_and_store(const ScoreParams& p
 // One candidate, one lane: score its sub-overlaps and write the result record.
 // G = 16-symbol chunks per fetch group (4: 64-symbol groups for short reads; 2: 32-symbol groups for contigs).
 template <typename SymT, int G, int LG>
-__device__ __forceinline__ hc_result_rec score_candidate(const ScoreParams& prm, const SymT* __restrict__ sym, const char* lut,
-                                                         const uint32_t* masktab, uint32_t Kp, uint32_t nsym_word, int ns,
+__device__ __forceinline__ hc_result_rec score_candidate(const ScoreParams& prm, const SymT* __restrict__ sym, uint32_t Kp, int ns,
                                                          const Sub& sub0, const Sub& sub1, uint64_t i,
                                                          hc_result_rec* __restrict__ out) {
     if (ns <= 0) {  // malformed record: an error; "skip" record (a line dropped before scoring): a dropped result
@@ -428,8 +560,12 @@ __device__ __forceinline__ hc_result_rec score_candidate(const ScoreParams& prm,
     s2.mm = 0;
     s2.n = 1;
     s2.err = 0;
-    score_sub_wide<SymT, LG, G>(sym, sub0, lut, masktab, Kp, nsym_word, prm.min_read_len, s1);
-    if (ns == 2) score_sub_wide<SymT, LG, G>(sym, sub1, lut, masktab, Kp, nsym_word, prm.min_read_len, s2);
+    // the second sub-overlap waits as two pointers and a length while the first is scored
+    const SymT* a1 = sym + sub1.offA + sub1.pos;
+    const SymT* b1 = sym + sub1.offB;
+    const uint32_t L1 = ns == 2 ? sub_positions(sub1, prm.min_read_len) | (sub1.fatal << 31) : 0u;
+    score_sub_wide<SymT, LG, G>(sym + sub0.offA + sub0.pos, sym + sub0.offB, sub_positions(sub0, prm.min_read_len), sub0.fatal, Kp, s1);
+    if (ns == 2) score_sub_wide<SymT, LG, G>(a1, b1, L1 & 0x7FFFFFFFu, L1 >> 31, Kp, s2);
     return classify_and_store(prm, ns, s1, s2, i, out);
 }
 
@@ -505,21 +641,17 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
         n = nd < n ? nd : n;
     }
     extern __shared__ __attribute__((aligned(16))) double lut_s[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lut_s != 0u) __builtin_trap();  // lds_f64 relies on it
     const uint32_t lut_n = st.lut_bytes >> 3;
     for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
-    uint32_t* masktab = (uint32_t*)(lut_s + lut_n);
-    fill_mask_table<SymT>(masktab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const char* lut = (const char*)lut_s;
 
     const SymT* sym = (const SymT*)st.sym;
     const uint32_t Kp = st.K + 2u;
-    const uint32_t nsym = (sizeof(SymT) == 1 && LG == 6) ? (kWideN << 2) : ((st.K << 3) | kCodeN);
-    const uint32_t nsym_word = sizeof(SymT) == 1 ? nsym * 0x01010101u : nsym * 0x00010001u;
     const uint32_t fmt = prm.rec_fmt;
-    // scratch behind the mask table: [0..127] class histogram / offsets, [128..383] order, [384..391] reduce (BAL);
+    // scratch behind the table: [0..127] class histogram / offsets, [128..383] order, [384..391] reduce (BAL);
     // [0..17] wave offsets of the row append (the two never overlap in time: barriers in between)
-    uint32_t* bal = masktab + 17 * Tr<SymT>::kWords;
+    uint32_t* bal = (uint32_t*)(lut_s + lut_n);
     const uint32_t tid = threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     // with a permutation, slot s scores candidate perm[s] (neighbouring lanes share reads) and writes its
@@ -600,11 +732,74 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
         if (slot < n) {
             i = perm ? (uint64_t)perm[slot] : slot;
             const Cand rec = load_cand(in, i, fmt);
-            Sub sub0, sub1;
+            Sub sub0{}, sub1{};
             const int ns = resolve<(int)sizeof(SymT)>(st, rec, sub0, sub1);
-            res = score_candidate<SymT, G, LG>(prm, sym, lut, masktab, Kp, nsym_word, ns, sub0, sub1, i, out);
+            res = score_candidate<SymT, G, LG>(prm, sym, Kp, ns, sub0, sub1, i, out);
         }
         if (sink.rows) append_rows_block(sink, slot < n, res, i, bal);  // kernel-argument-uniform branch
+    }
+}
+
+// The scoring kernel with the cooperative fetch (score_sub_coop): 8-bit symbols of the dense / sparse tables, stores
+// below 4 GiB (32-bit byte offsets), no length balancing.  Same results, records and row sink as score_kernel.
+template <typename SymT, int LG>
+__global__ __launch_bounds__(256, 4) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+                                                            const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
+                                                            const uint32_t* __restrict__ perm, RowSink sink) {
+    if (prm.n_dev) {
+        const uint64_t nd = *prm.n_dev;
+        n = nd < n ? nd : n;
+    }
+    extern __shared__ __attribute__((aligned(16))) double lut_s[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lut_s != 0u) __builtin_trap();  // lds_f64 relies on it
+    const uint32_t lut_n = st.lut_bytes >> 3;
+    for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
+    __syncthreads();
+    uint32_t* scratch = (uint32_t*)(lut_s + lut_n);                                   // 32 words: row append
+    const uint32_t stage = st.lut_bytes + 128u + (threadIdx.x >> 6) * kStageBytesPerWave;  // this wave's image (LDS byte address)
+    const SymT* sym = (const SymT*)st.sym;
+    const uint32_t Kp = st.K + 2u;
+    const uint32_t fmt = prm.rec_fmt;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.sym, 0, (uint32_t)st.store_bytes, 0x00020000);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t block_base = (uint64_t)blockIdx.x * blockDim.x; block_base < n; block_base += stride) {
+        const uint64_t slot = block_base + threadIdx.x;
+        uint64_t i = 0;
+        int ns = -2;  // no candidate in this lane
+        Sub sub0{}, sub1{};
+        if (slot < n) {
+            i = perm ? (uint64_t)perm[slot] : slot;
+            ns = resolve<(int)sizeof(SymT)>(st, load_cand(in, i, fmt), sub0, sub1);
+        }
+        const uint32_t L0 = ns >= 1 ? sub_positions(sub0, prm.min_read_len) : 0u;
+        const uint32_t L1 = ns == 2 ? sub_positions(sub1, prm.min_read_len) : 0u;
+        SubScore s1, s2;
+        s2.x = __builtin_nan("");
+        s2.mm = 0;
+        s2.n = 1;
+        s2.err = 0;
+        score_sub_coop<SymT, LG>(rsrc, sym, stage, (uint32_t)((sub0.offA + sub0.pos) * sizeof(SymT)), (uint32_t)(sub0.offB * sizeof(SymT)), L0,
+                                 sub0.fatal, Kp, s1);
+        if (__ballot(ns == 2) != 0ull) {
+            SubScore t2;
+            score_sub_coop<SymT, LG>(rsrc, sym, stage, (uint32_t)((sub1.offA + sub1.pos) * sizeof(SymT)), (uint32_t)(sub1.offB * sizeof(SymT)),
+                                     L1, sub1.fatal, Kp, t2);
+            if (ns == 2) s2 = t2;
+        }
+        hc_result_rec res;
+        res.n_cls = 0;
+        if (slot < n) {
+            if (ns <= 0) {  // malformed record: an error; "skip" record: a dropped result
+                res.x1 = -__builtin_inf();
+                res.x2 = __builtin_nan("");
+                res.mm = 1;
+                res.n_cls = 1u | ((ns == 0 ? HC_CLS_ERROR : HC_CLS_DROP) << 28);
+                out[i] = res;
+            } else {
+                res = classify_and_store(prm, ns, s1, s2, i, out);
+            }
+        }
+        if (sink.rows) append_rows_block(sink, slot < n, res, i, scratch);  // kernel-argument-uniform branch
     }
 }
 
@@ -705,8 +900,29 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in, hc_line_rec* lines_out) {
     if (n == 0) return hipSuccess;
-    const size_t lds = st.lut_bytes + (17 * (st.symbytes == 1 ? 4 : 8) + 392) * sizeof(uint32_t);
     const uint32_t lg = lut_lg(st.K);
+    if (fetch_group == 0) {
+        const bool coop = st.symbytes == 1 && lg <= 5 && !st.balance && st.store_bytes < 0xFFFF0000ull;
+        if (coop) {
+            const size_t lds_c = st.lut_bytes + 128 + 4 * kStageBytesPerWave;
+            uint32_t per_cu = (uint32_t)((160 * 1024) / lds_c);
+            per_cu = per_cu > 8 ? 8 : per_cu;
+            uint64_t blocks_c = (n + 255) / 256;
+            const uint64_t cap_c = (uint64_t)n_cu * per_cu * 4;
+            if (blocks_c > cap_c) blocks_c = cap_c;
+            const RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out};
+#define HC_COOP(LG_)                                                                                                                  \
+    hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, prm, lut_g, in, n, out, \
+                       perm, sink)
+            if (lg == 3) HC_COOP(3);
+            else if (lg == 4) HC_COOP(4);
+            else HC_COOP(5);
+#undef HC_COOP
+            return hipGetLastError();
+        }
+        fetch_group = 4;
+    }
+    const size_t lds = st.lut_bytes + 392 * sizeof(uint32_t);
     // Fill the chip: enough 256-thread blocks for 8 waves per SIMD, bounded by LDS.
     uint32_t blocks_per_cu = 8;
     const uint32_t by_lds = (uint32_t)((160 * 1024) / lds);
@@ -747,6 +963,10 @@ hipError_t set_lds_limit_lg() {
 
 hipError_t set_score_kernel_lds_limit() {
     hipError_t e;
+    const int kMax = 160 * 1024;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 3>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 4>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 5>()) != hipSuccess) return e;

@@ -330,13 +330,32 @@ int hc_host_graph_new(hc_host_graph** out, uint64_t n_vertices, const hc_setting
     std::unique_ptr<hc_host_graph> g(new hc_host_graph());
     g->ps = make_ps(settings, nullptr);
     g->graph.reset(new OverlapGraph((unsigned int)n_vertices, nullptr, g->ps));
-    g->reads.reserve(n_vertices);
-    for (uint64_t i = 0; i < n_vertices; i++) {
+    // --add_duplicates: the second half of the vertices are the reverse-complemented reads (ViralQuasispecies.cpp:246-271)
+    const uint64_t n_reads = g->ps.add_duplicates ? n_vertices / 2 : n_vertices;
+    g->reads.reserve(n_reads);
+    for (uint64_t i = 0; i < n_reads; i++) {
         g->reads.emplace_back(nullptr, (unsigned int)i, false, (read_id_t)i);
-        g->graph->addVertex(i);
+        g->reads.back().set_vertex_id(true, g->graph->addVertex(i));
     }
+    if (g->ps.add_duplicates)
+        for (uint64_t i = 0; i < n_reads; i++) g->reads[i].set_vertex_id(false, g->graph->addVertex(i));
     *out = g.release();
     return HC_OK;
+}
+
+int hc_host_graph_adopt(hc_host_graph* g, const hc_edge_rec* edges, const uint64_t* out_off, const uint32_t* in_nodes, const uint64_t* in_off,
+                        const uint8_t* inclusions) {
+    if (!g || !out_off || !in_off) return set_last_error(HC_ERR_ARG, "hc_host_graph_adopt: null");
+    return guarded("adopt_csr", [&] {
+        std::vector<Read*> reads(g->reads.size());
+        for (size_t i = 0; i < reads.size(); i++) reads[i] = &g->reads[i];
+        g->graph->adopt_csr(edges, out_off, in_nodes, in_off, inclusions, reads.data(), reads.size(), g->ps.n_threads);
+    });
+}
+
+int hc_host_graph_add_equivalent_edges(hc_host_graph* g) {
+    if (!g) return set_last_error(HC_ERR_ARG, "hc_host_graph_add_equivalent_edges: null");
+    return guarded("addEquivalentEdges", [&] { g->graph->addEquivalentEdges(); });
 }
 
 int hc_host_graph_insert(hc_host_graph* g, const hc_edge_rec* r) {

@@ -71,6 +71,8 @@ _sig = {
     "hc_host_graph_new": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.POINTER(N.hc_settings)]),
     "hc_host_graph_insert": (C.c_int, [_vp, _vp]),
     "hc_host_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "hc_host_graph_adopt": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "hc_host_graph_add_equivalent_edges": (C.c_int, [_vp]),
     "hc_host_graph_sort_edges": (C.c_int, [_vp, _vp, C.c_uint64]),
     "hc_host_graph_get_in_lists": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "hc_ec_sort_edges": (C.c_int, [_vp]),
@@ -211,6 +213,17 @@ class HostGraph:
     def resolve(self, edge_recs):
         e = np.ascontiguousarray(edge_recs, dtype=EDGE_DTYPE)
         return N.lib.hc_host_graph_resolve(self._h, e.ctypes.data, e.shape[0])
+
+    def adopt(self, edges, out_off, in_nodes, in_off, inclusions=None):
+        """OverlapGraph::adopt_csr: the CSR form hc_graph_fetch returns, into this (empty) graph."""
+        e = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+        oo, io = np.ascontiguousarray(out_off, np.uint64), np.ascontiguousarray(in_off, np.uint64)
+        inn = np.ascontiguousarray(in_nodes, np.uint32)
+        inc = None if inclusions is None else np.ascontiguousarray(inclusions, np.uint8)
+        return N.lib.hc_host_graph_adopt(self._h, e.ctypes.data, oo.ctypes.data, inn.ctypes.data, io.ctypes.data, None if inc is None else inc.ctypes.data)
+
+    def add_equivalent_edges(self):
+        return N.lib.hc_host_graph_add_equivalent_edges(self._h)
 
     def sort_edges(self, len_by_read):
         """OverlapGraph::sortEdges (src/OverlapGraph.cpp:722-764); len_by_read[r] = total length of read r."""

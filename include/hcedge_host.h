@@ -135,6 +135,13 @@ int hc_host_graph_insert(hc_host_graph* g, const hc_edge_rec* edge);
 /* The sort-based equivalent on an EMPTY graph: resolves n edges given in sequence
  * order in one call; must leave the graph exactly as n hc_host_graph_insert calls would. */
 int hc_host_graph_resolve(hc_host_graph* g, const hc_edge_rec* edges, uint64_t n);
+/* The graph as the device's duplicate resolution hands it over (hc_graph_fetch: CSR of hc_edge_rec + in-lists), into an
+ * EMPTY graph: the lists become views into two arrays owned by the graph (OverlapGraph::adopt_csr). */
+int hc_host_graph_adopt(hc_host_graph* g, const hc_edge_rec* edges, const uint64_t* out_off, const uint32_t* in_nodes, const uint64_t* in_off,
+                        const uint8_t* inclusions);
+/* OverlapGraph::addEquivalentEdges (src/OverlapGraph.cpp:608-719); the graph must have been created with
+ * HC_FLAG_ADD_DUPLICATES and twice the number of reads as vertices. */
+int hc_host_graph_add_equivalent_edges(hc_host_graph* g);
 int hc_host_graph_get(hc_host_graph* g, hc_edge_rec* out, uint64_t cap, uint64_t* n_out, uint8_t* inclusions,
                       hc_ec_counters* counters);
 /* OverlapGraph::sortEdges on the bare graph; len_by_read[r] = Read::get_len() of read r (n_reads = n_vertices). */

@@ -164,6 +164,9 @@ class Graph:
     def inclusions(self):
         return np.array([lib.hco_graph_inclusion(self.g, v) for v in range(self.V)], dtype=np.uint8)
 
+    def add_equivalent_edges(self, n_reads):
+        return lib.hco_graph_add_equivalent_edges(self.g, n_reads)
+
     def insert(self, settings, gedge, counters):
         e = np.array([gedge], dtype=GEDGE_DTYPE) if not isinstance(gedge, np.ndarray) else gedge
         cs = settings_to_c(settings)

@@ -321,3 +321,77 @@ def test_id_lookup_sparse_and_duplicate_ids(tmp_path):
         bad = _write(tmp_path / f"bad{big}.txt", f"7\t{big + 1}\t3\t-\t-\t+\t+\t70\t-\t7\t-\ts\ts\n")
         with pytest.raises(hc.HcError):
             f.parse_file(hc.Settings(min_overlap_len=0), bad)
+
+
+def _csr_of(g, V):
+    """The graph in the form hc_graph_fetch hands over: edges by v1 (list order kept), offsets, in-lists."""
+    edges, inc, _ = g.get()
+    out_off = np.zeros(V + 1, np.uint64)
+    np.add.at(out_off, edges["v1"].astype(np.int64) + 1, 1)
+    out_off = np.cumsum(out_off).astype(np.uint64)
+    in_off, in_nodes = g.in_lists(edges.size)
+    return edges, out_off, in_nodes, in_off, inc
+
+
+def test_adopted_csr_graph_behaves_like_an_owned_one():
+    """OverlapGraph::adopt_csr makes every adjacency list a view into one array; later inserts (the tie-break chain may
+    remove, swap and append), sortEdges and the read-out must behave exactly as on a graph built edge by edge."""
+    rng = random.Random(23)
+    for flags, V, n_threads in ((hc.records.FLAG_RESOLVE_ORIENTATIONS, 60, 1),
+                                (hc.records.FLAG_RESOLVE_ORIENTATIONS | hc.records.FLAG_IGNORE_INCLUSIONS, 700, 4)):
+        st = hc.Settings(flags=flags, n_threads=n_threads)
+        stream = _random_edge_stream(rng, V, 6000)
+        later = _random_edge_stream(rng, V, 1500)
+        g = host.HostGraph(V, st)
+        for e in stream:
+            assert g.insert(e.copy()) == 0
+        edges, out_off, in_nodes, in_off, inc = _csr_of(g, V)
+        assert int(out_off[-1]) == edges.size == int(in_off[-1])
+        g2 = host.HostGraph(V, st)
+        assert g2.adopt(edges, out_off, in_nodes, in_off, inc) == 0
+        edges2, out_off2, in_nodes2, in_off2, inc2 = _csr_of(g2, V)
+        assert edges2.tobytes() == edges.tobytes() and np.array_equal(inc2, inc)
+        assert np.array_equal(in_nodes2, in_nodes) and np.array_equal(in_off2, in_off)
+        for e in later:  # grows some lists past their borrowed capacity, removes from others
+            assert g.insert(e.copy()) == 0 and g2.insert(e.copy()) == 0
+        a, b = _csr_of(g, V), _csr_of(g2, V)
+        assert a[0].tobytes() == b[0].tobytes()
+        for x, y in zip(a[1:], b[1:]):
+            assert np.array_equal(x, y)
+        lens = np.full(V, 150, np.uint32)
+        g.sort_edges(lens)
+        g2.sort_edges(lens)
+        assert g.get()[0].tobytes() == g2.get()[0].tobytes()
+        # adopting into a graph that already holds edges is refused, not merged
+        assert g2.adopt(edges, out_off, in_nodes, in_off, inc) != 0
+
+
+def test_add_equivalent_edges_matches_oracle(oracle):
+    """--add_duplicates: OverlapGraph::addEquivalentEdges (src/OverlapGraph.cpp:608-719) on an owned and on an adopted graph."""
+    rng = random.Random(3)
+    R = 40
+    flags = hc.records.FLAG_RESOLVE_ORIENTATIONS | hc.records.FLAG_ADD_DUPLICATES
+    st = hc.Settings(flags=flags)
+    stream = _random_edge_stream(rng, R, 1200)
+    stream["v1"] = np.where(stream["ori1"] != 0, stream["read1"], R + stream["read1"].astype(np.int64))
+    stream["v2"] = np.where(stream["ori2"] != 0, stream["read2"], R + stream["read2"].astype(np.int64))
+    g = host.HostGraph(2 * R, st)
+    og = oracle.Graph(2 * R)
+    oc = oracle.hco_counters()
+    for e in stream:
+        assert g.insert(e.copy()) == 0
+        assert og.insert(st, np.array([e], dtype=oracle.GEDGE_DTYPE), oc) == 0
+    csr = _csr_of(g, 2 * R)
+    g2 = host.HostGraph(2 * R, st)
+    assert g2.adopt(*csr) == 0
+    assert g.add_equivalent_edges() == 0 and g2.add_equivalent_edges() == 0
+    assert og.add_equivalent_edges(R) == 0
+    want = og.all_edges()
+    for got in (g.get()[0], g2.get()[0]):
+        assert got.size == want.size > csr[0].size
+        for k in ("score", "pos1", "pos2", "ori1", "ori2", "ord", "read1", "read2", "v1", "v2"):
+            assert np.array_equal(got[k], want[k]), k
+    assert g.get()[0].tobytes() == g2.get()[0].tobytes()
+    a, b = _csr_of(g, 2 * R), _csr_of(g2, 2 * R)
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)

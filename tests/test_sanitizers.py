@@ -100,6 +100,46 @@ assert host.hc_host_graph_sort_edges(g, lens, 400) == 0
 assert host.hc_host_graph_sort_edges(g, lens, 399) != 0
 host.hc_host_graph_free(g)
 
+# 3a'. the device's hand-over (CSR -> list views into one array), inserts on top of the views, addEquivalentEdges, sortEdges
+import numpy as np
+R = 150; V2 = 2 * R
+st = S(0.97, 0.9, 0, 0, 0, 10, 0, 2 | 1, 10**8, 0, 3)
+def rec2():
+    a, b = rng.sample(range(R), 2); o1, o2 = rng.randrange(2), rng.randrange(2)
+    return struct.pack("<ddiiiiBBBBIIIQQiiii", rng.choice([0.97, 0.98, 1.0]), rng.choice([0.0, 0.1]), rng.choice([0, 3]), rng.choice([0, 2]), rng.choice([-2, 0, 2]),
+                       rng.choice([-1, 0, 1]), o1, o2, ord(rng.choice("-12")), 0, a, b, 0, a if o1 else R + a, b if o2 else R + b, rng.choice([100, 50]), 100, 100, 0)
+ga = C.c_void_p(); gb = C.c_void_p()
+assert host.hc_host_graph_new(C.byref(ga), V2, C.byref(st)) == 0 and host.hc_host_graph_new(C.byref(gb), V2, C.byref(st)) == 0
+for _ in range(5000):
+    assert host.hc_host_graph_insert(ga, rec2()) == 0
+host.hc_host_graph_get.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+host.hc_host_graph_get_in_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+host.hc_host_graph_adopt.argtypes = [C.c_void_p] * 6
+def dump(g):
+    ne = C.c_uint64()
+    assert host.hc_host_graph_get(g, None, 0, C.byref(ne), None, None) == 0
+    e = np.zeros((ne.value, 80), np.uint8); inc = np.zeros(V2, np.uint8)
+    assert host.hc_host_graph_get(g, e.ctypes.data, ne.value, C.byref(ne), inc.ctypes.data, None) == 0
+    io = np.zeros(V2 + 1, np.uint64); inn = np.zeros(max(ne.value, 1), np.uint64)
+    assert host.hc_host_graph_get_in_lists(g, io.ctypes.data, inn.ctypes.data, ne.value) == 0
+    return e, inc, io, inn[:ne.value]
+e, inc, io, inn = dump(ga)
+v1 = e[:, 48:56].copy().view(np.uint64).ravel()
+oo = np.zeros(V2 + 1, np.uint64); np.add.at(oo, v1.astype(np.int64) + 1, 1); oo = np.cumsum(oo).astype(np.uint64)
+inn32 = inn.astype(np.uint32)
+assert host.hc_host_graph_adopt(gb, e.ctypes.data, oo.ctypes.data, inn32.ctypes.data, io.ctypes.data, inc.ctypes.data) == 0
+assert host.hc_host_graph_adopt(gb, e.ctypes.data, oo.ctypes.data, inn32.ctypes.data, io.ctypes.data, inc.ctypes.data) != 0  # not empty any more
+del e, inn32, oo  # the graph owns copies; nothing may point into the caller's arrays
+for _ in range(3000):
+    r = rec2()
+    assert host.hc_host_graph_insert(ga, r) == 0 and host.hc_host_graph_insert(gb, r) == 0
+assert host.hc_host_graph_add_equivalent_edges(ga) == 0 and host.hc_host_graph_add_equivalent_edges(gb) == 0
+lens2 = (C.c_uint32 * R)(*[rng.choice([100, 150, 400]) for _ in range(R)])
+assert host.hc_host_graph_sort_edges(ga, lens2, R) == 0 and host.hc_host_graph_sort_edges(gb, lens2, R) == 0
+da, db = dump(ga), dump(gb)
+assert all(np.array_equal(x, y) for x, y in zip(da, db)) and da[0].shape[0] > 1000
+host.hc_host_graph_free(ga); host.hc_host_graph_free(gb)
+
 # 3b. SFO ingest on plausible and hostile files
 host.hc_sfo2overlaps.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p]
 sfo = []
