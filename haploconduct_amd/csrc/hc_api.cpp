@@ -245,8 +245,14 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         seq_len[q] = (uint32_t)len;
     }
     // dense quality alphabet over the bytes the reference accepts: Q = byte-33 >= 0 as a signed char
-    uint64_t hist[256] = {0};
-    for (uint64_t i = 0; i < total; i++) hist[quals[i]]++;
+    uint64_t hist[256] = {0}, base_hist[256] = {0};
+    for (uint64_t i = 0; i < total; i++) {
+        hist[quals[i]]++;
+        base_hist[bases[i]]++;
+    }
+    bool any_bad_base = false;  // a base outside ACGTN somewhere (the encoder flags the sequence; the store is then not "regular")
+    for (int b = 0; b < 256; b++)
+        if (base_hist[b] && b != 'A' && b != 'C' && b != 'G' && b != 'T' && b != 'N') any_bad_base = true;
     std::vector<int> phred;
     uint8_t qmap[256];
     memset(qmap, 255, sizeof qmap);
@@ -336,6 +342,17 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     c->view.lut_bytes = (uint32_t)(lut.size() * sizeof(double));
     c->store_bytes = sym_bytes_total;
     c->view.store_bytes = sym_bytes_total;
+    {  // regular store (hc_device.h): descriptors by arithmetic
+        bool same_len = n_seq > 0;
+        for (uint32_t q = 1; q < n_seq && same_len; q++) same_len = seq_len[q] == seq_len[0];
+        uint32_t n_single = 0;
+        for (uint32_t r = 0; r < n_reads; r++) n_single += read_first_seq[r + 1] - read_first_seq[r] == 1;
+        c->view.regular = (same_len && c->singles_first && !any_bad_base) ? 1u : 0u;
+        if (const char* v = getenv("HC_REGULAR_STORE")) c->view.regular = c->view.regular && atoi(v) != 0;  // test / tuning knob: 0 forces look-ups
+        c->view.ulen = same_len ? seq_len[0] : 0u;
+        c->view.n_single = n_single;
+        c->view.seq_syms = same_len ? (uint32_t)(2 * hc::slot_stride(seq_len[0], symbytes)) : 0u;
+    }
     c->have_reads = true;
     {
         uint32_t lmin = 0xFFFFFFFFu, lmax = 0;

@@ -61,6 +61,14 @@ struct StoreView {
     uint32_t lut_bytes; // bytes of the log table as laid out for this symbol width
     uint32_t balance;   // 1: sequence lengths differ widely -> block-local length balancing in the scoring kernel
     uint64_t store_bytes;  // bytes of the symbol store (the cooperative fetch addresses it through a buffer descriptor)
+    // "Regular" store: every sequence has the same length, the single-end reads come before the paired-end ones and no
+    // sequence holds a base outside ACGTN.  A read's descriptor is then arithmetic (hc_resolve.h: regular_desc) and the
+    // scoring kernel does not look it up — the dependent, random 32-byte read per candidate costs a quarter of the
+    // kernel's memory-side rate (tools/experiments/gather_shapes.hip).  0: descriptors are read from `reads`.
+    uint32_t regular;
+    uint32_t ulen;      // the common sequence length
+    uint32_t n_single;  // reads [0, n_single) own one sequence, the others two
+    uint32_t seq_syms;  // symbols per sequence in the store: 2 * slot_stride(ulen)
 };
 
 // Log table layouts (doubles):

@@ -67,6 +67,20 @@ __device__ __forceinline__ ReadDesc load_desc(const ReadDesc* p) {
     return d;
 }
 
+// the descriptor of read r in a regular store (StoreView::regular): sequences are laid out back to back
+__device__ __forceinline__ ReadDesc regular_desc(const StoreView& st, uint32_t r) {
+    const bool paired = r >= st.n_single;
+    const uint32_t seq = paired ? st.n_single + 2u * (r - st.n_single) : r;
+    ReadDesc d;
+    d.off1 = (uint64_t)seq * st.seq_syms;
+    d.off2 = paired ? d.off1 + st.seq_syms : 0u;
+    d.len1 = st.ulen;
+    d.len2 = paired ? st.ulen : 0u;
+    d.flags = paired ? kReadPaired : 0u;
+    d.pad = 0;
+    return d;
+}
+
 // mate: 0 = /1 (or the single sequence), 1 = /2
 template <int SB>
 __device__ __forceinline__ View make_view(const ReadDesc& d, uint32_t mate, uint32_t fwd) {
@@ -101,8 +115,8 @@ template <int SB>
 __device__ __forceinline__ int resolve(const StoreView& st, const Cand& r, Sub& s0, Sub& s1) {
     if (r.skip) return -1;
     if (r.read1 >= st.n_reads || r.read2 >= st.n_reads || r.read1 == r.read2) return 0;
-    const ReadDesc d1 = load_desc(st.reads + r.read1);
-    const ReadDesc d2 = load_desc(st.reads + r.read2);
+    const ReadDesc d1 = st.regular ? regular_desc(st, r.read1) : load_desc(st.reads + r.read1);
+    const ReadDesc d2 = st.regular ? regular_desc(st, r.read2) : load_desc(st.reads + r.read2);
     const uint32_t p1 = d1.flags & kReadPaired, p2 = d2.flags & kReadPaired;
     const uint32_t o1 = r.ori1, o2 = r.ori2;
     // single: S(R,o); paired: F(R,o) = o ? /1 : rc(/2) ("front"), K(R,o) = o ? /2 : rc(/1) ("back")

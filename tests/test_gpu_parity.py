@@ -399,6 +399,57 @@ def test_fuzz_random_read_sets_settings_and_geometry(oracle, seed):
     check_parity(oracle, reads, st, cand)
 
 
+@pytest.mark.parametrize("fetch", ["coop", "4", "2"])
+@pytest.mark.parametrize("regular", ["1", "0"])
+@pytest.mark.parametrize("n_quals", [5, 12, 25])  # the three dense / sparse 8-bit tables
+def test_fetch_and_descriptor_paths_agree(oracle, monkeypatch, fetch, regular, n_quals):
+    """A store of equal-length sequences, singles first ("regular": read descriptors by arithmetic) scored with the
+    cooperative fetch and with both per-lane fetch groups, each with and without descriptor look-ups: every combination
+    must reproduce the oracle.  Singles, pairs, all four type combinations, window lengths 1..150, random orientations."""
+    monkeypatch.setenv("HC_FETCH_GROUP", fetch)
+    monkeypatch.setenv("HC_REGULAR_STORE", regular)
+    rng = np.random.default_rng(77 + n_quals)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rng.integers(0, 4, 4000)]
+    alphabet = rng.choice(np.arange(33, 127), size=n_quals, replace=False).astype(np.uint8)
+    L = 150
+
+    def piece(s):
+        seg = genome[s:s + L].copy()
+        k = rng.random(L) < 0.004
+        seg[k] = acgt[rng.integers(0, 4, int(k.sum()))]
+        seg[rng.random(L) < 0.003] = ord("N")
+        return seg.tobytes(), alphabet[rng.integers(0, n_quals, L)].tobytes()
+
+    n_s, n_p = 150, 250
+    starts = rng.integers(0, 4000 - 600, n_s + n_p)
+    ins = rng.integers(300, 600, n_s + n_p)
+    singles = [piece(int(starts[i])) for i in range(n_s)]
+    pairs = [(piece(int(starts[i])), piece(int(starts[i] + ins[i] - L))) for i in range(n_s, n_s + n_p)]
+    reads = hc.ReadSet.from_lists(singles, pairs)
+    n, m = reads.n_reads, 6000
+    cand = np.zeros(m, OVERLAP_DTYPE)
+    a = rng.integers(0, n, m)
+    b = (a + 1 + rng.integers(0, n - 1, m)) % n
+    cand["read1"], cand["read2"] = a, b
+    pa, pb = a >= n_s, b >= n_s
+    true_geo = rng.random(m) < 0.7
+    d1 = starts[b] - starts[a]
+    d2 = (starts[b] + ins[b]) - (starts[a] + ins[a])
+    cand["pos1"] = np.where(true_geo & (d1 >= 0) & (d1 < L), d1, rng.integers(0, L + 10, m))
+    cand["pos2"] = np.where(pa | pb, np.where(true_geo & (d2 >= 0) & (d2 < L), d2, rng.integers(0, L + 10, m)), 0)
+    cand["ori1"] = np.where(true_geo, 1, rng.integers(0, 2, m))
+    cand["ori2"] = np.where(true_geo, 1, rng.integers(0, 2, m))
+    cand["ord"] = np.where(pa & pb, np.where(rng.random(m) < 0.5, ord("1"), ord("2")), ord("-"))
+    cand["flags"] = pa.astype(np.uint8) | (pb.astype(np.uint8) << 1)
+    cand["len1"], cand["len2"], cand["perc"] = 100, 100, 90
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.5, min_read_len=0)
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        assert sc.info()["qual_alphabet"] == n_quals
+    check_parity(oracle, reads, st, cand)
+
+
 @pytest.mark.gpu
 def test_unordered_batches_of_growing_size_through_the_compact_path():
     """Regression: an unordered batch takes the device re-ordering (its scratch grows with the batch) inside

@@ -75,20 +75,35 @@ __global__ __launch_bounds__(256, 4) void gather_v1(const uint8_t* __restrict__ 
 
 // v2: quads fetch one candidate's 64-byte group; LDS hands the pieces to the owner lane
 constexpr uint32_t kRow = 80;  // 64 + 16: rows of 16 consecutive lanes fall into 16 different 16-byte bank groups
+template <int DESC>
 __global__ __launch_bounds__(256, 4) void gather_v2(const uint8_t* __restrict__ sym, uint32_t stride, const Cand* __restrict__ cands,
-                                                   uint64_t n, uint32_t* __restrict__ out) {
+                                                   uint64_t n, uint32_t* __restrict__ out, const uint4* __restrict__ desc32,
+                                                   const uint2* __restrict__ desc8) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[4][64 * kRow];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint8_t* buf = stage[wave];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     Cand c = {0, 0, 0, 0};
     if (i < n) c = cands[i];
+    // where a read's sequences start: computed (fixed stride), or looked up per read as the scoring kernel does
+    uint64_t baseA = (uint64_t)c.seqA * 2u * stride, baseB = (uint64_t)c.seqB * 2u * stride;
+    if (DESC == 1 && i < n) {
+        const uint4 a0 = desc32[(c.seqA >> 1) * 2], a1 = desc32[(c.seqA >> 1) * 2 + 1];
+        const uint4 b0 = desc32[(c.seqB >> 1) * 2], b1 = desc32[(c.seqB >> 1) * 2 + 1];
+        baseA = (((uint64_t)a0.y << 32) | a0.x) + (a1.z & 0u);
+        baseB = (((uint64_t)b0.y << 32) | b0.x) + (b1.z & 0u);
+    }
+    if (DESC == 2 && i < n) {
+        const uint2 a = desc8[c.seqA >> 1], b = desc8[c.seqB >> 1];
+        baseA = (uint64_t)a.x * 16u + (a.y & 0u);
+        baseB = (uint64_t)b.x * 16u + (b.y & 0u);
+    }
     const uint32_t quad = lane >> 2, piece = lane & 3u;
     uint32_t acc = 0;
     for (int sub = 0; sub < 2; sub++) {
         const uint32_t pos = sub ? c.pos2 : c.pos1;
-        const uint64_t offA = (uint64_t)(c.seqA + sub) * 2u * stride + pos;
-        const uint64_t offB = (uint64_t)(c.seqB + sub) * 2u * stride;
+        const uint64_t offA = baseA + (uint64_t)sub * 2u * stride + pos;
+        const uint64_t offB = baseB + (uint64_t)sub * 2u * stride;
         const uint32_t L = i < n ? kLen - pos : 0u;
         // what the loader lanes need of the four candidates they fetch for
         uint64_t la[4], lb[4];
@@ -179,13 +194,30 @@ int main(int argc, char** argv) {
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
         const int grid = (int)((n + 255) / 256);
-        for (int variant = 0; variant < 3; variant++) {
+        // descriptors of the reads (pairs): 32 bytes as the kernel's ReadDesc, or 8 bytes (offset in 16-byte units, lengths)
+        std::vector<uint4> hd32((size_t)n_reads * 2);
+        std::vector<uint2> hd8(n_reads);
+        for (uint32_t r = 0; r < n_reads; r++) {
+            const uint64_t off = (uint64_t)r * 4u * stride;
+            hd32[2 * r] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), (uint32_t)(off + 2u * stride), (uint32_t)((off + 2u * stride) >> 32));
+            hd32[2 * r + 1] = make_uint4(kLen, kLen, 1, 0);
+            hd8[r] = make_uint2((uint32_t)(off / 16u), kLen | (kLen << 16));
+        }
+        uint4* d_d32;
+        uint2* d_d8;
+        CK(hipMalloc(&d_d32, hd32.size() * sizeof(uint4)));
+        CK(hipMalloc(&d_d8, hd8.size() * sizeof(uint2)));
+        CK(hipMemcpy(d_d32, hd32.data(), hd32.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_d8, hd8.data(), hd8.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        for (int variant = 0; variant < 5; variant++) {
             float best = 1e9f;
             for (int rep = 0; rep < 6; rep++) {
                 CK(hipEventRecord(e0));
                 if (variant == 0) gather_v1<4><<<grid, 256>>>(d_s, stride, d_c, n, d_out);
                 else if (variant == 1) gather_v1<2><<<grid, 256>>>(d_s, stride, d_c, n, d_out);
-                else gather_v2<<<grid, 256>>>(d_s, stride, d_c, n, d_out);
+                else if (variant == 2) gather_v2<0><<<grid, 256>>>(d_s, stride, d_c, n, d_out, d_d32, d_d8);
+                else if (variant == 3) gather_v2<1><<<grid, 256>>>(d_s, stride, d_c, n, d_out, d_d32, d_d8);
+                else gather_v2<2><<<grid, 256>>>(d_s, stride, d_c, n, d_out, d_d32, d_d8);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 float ms;
@@ -196,10 +228,16 @@ int main(int argc, char** argv) {
             if (variant == 0) ref = got;
             const bool same = ref == got;
             printf("{\"slot_stride\": %u, \"variant\": \"%s\", \"ms\": %.4f, \"cand_per_s\": %.3e, \"same_result\": %s}\n", stride,
-                   variant == 0 ? "v1 lane-per-candidate G=4" : (variant == 1 ? "v1 lane-per-candidate G=2" : "v2 quad fetch via LDS"), best,
+                   variant == 0 ? "v1 lane-per-candidate G=4"
+                                : (variant == 1 ? "v1 lane-per-candidate G=2"
+                                                : (variant == 2 ? "v2 quad fetch via LDS, offsets computed"
+                                                                : (variant == 3 ? "v2 + 32-byte read descriptors" : "v2 + 8-byte read descriptors"))),
+                   best,
                    (double)n / (best * 1e-3), same ? "true" : "false");
         }
         CK(hipFree(d_s));
+        CK(hipFree(d_d32));
+        CK(hipFree(d_d8));
     }
     return 0;
 }
