@@ -363,13 +363,18 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         c->view.balance = (n_seq && lmax > 2u * lmin) ? 1u : 0u;  // mixed-length read set (contigs + reads)
         if (const char* b = getenv("HC_BALANCE")) c->view.balance = atoi(b) != 0;
     }
+    c->coop_fetch = true;
     if (const char* v = getenv("HC_FETCH_GROUP")) {
-        c->fetch_group = !strcmp(v, "coop") ? 0 : (atoi(v) == 2 ? 2 : 4);
+        c->coop_fetch = !strcmp(v, "coop");
+        c->fetch_group = atoi(v) == 2 ? 2 : 4;
     } else {
         // 64-symbol fetch groups for short-read sets, 32-symbol groups when the
         // sequences are long (contigs): measured on BASELINE configs 2-5, see DESIGN.md
         const uint64_t mean_len = n_seq ? total / n_seq : 0;
-        c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 0;  // 0: cooperative fetch where the kernel has it (launch_score), else 4
+        c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 4;
+        // contig-length sequences: a lane streams its own long rows well enough, and the waves of a cooperative step would
+        // wait for their longest candidate row by row (C5: 0.95 ms per lane, 0.98 ms cooperative)
+        c->coop_fetch = mean_len <= 600;
     }
     return HC_OK;
 }
@@ -424,7 +429,7 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
     hc::ScoreParams prm = c->params;
     prm.rec_fmt = fmt;
     prm.n_dev = n_dev;
-    HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->fetch_group, rows, row_count, cap,
+    HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group, rows, row_count, cap,
                             base_index, s, lines_in, lines_out));
     return HC_OK;
 }

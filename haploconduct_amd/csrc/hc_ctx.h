@@ -17,7 +17,7 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
                          uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
                          hipStream_t stream);
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const void* in, uint64_t n,
-                        hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, hc_gather_row* rows,
+                        hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr);
 hipError_t set_score_kernel_lds_limit();
@@ -83,9 +83,9 @@ struct hc_ctx {
     hc_settings settings;
     int device = 0;
     uint32_t n_cu = 256;
-    int fetch_group = 4;  // how the scoring kernel fetches symbols: 0 = cooperatively (quads fetch 64-byte rows, short reads),
-                          // 4 / 2 = per lane in groups of 4 / 2 16-symbol chunks (2: contigs); chosen per read set in
-                          // hc_set_reads (HC_FETCH_GROUP=coop|4|2 overrides: a tuning knob only)
+    bool coop_fetch = true;  // the scoring kernel fetches symbols cooperatively (quads read 64-byte rows; stores below 4 GiB)
+    int fetch_group = 4;     // otherwise per lane, in groups of 4 (short reads) or 2 (contigs, 16-bit symbols) 16-symbol chunks;
+                             // chosen per read set in hc_set_reads (HC_FETCH_GROUP=coop|4|2 overrides: a tuning knob only)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // read store

@@ -375,7 +375,7 @@ __device__ __forceinline__ void score_sub_wide(const SymT* __restrict__ a, const
 // rows a 128-bit LDS read serves in one pass into 16 different bank groups.  The A rows and then the B rows of a step pass
 // through the same image (the owner keeps its A row in registers); the next step's pieces are in flight into registers
 // meanwhile.  Loads go through a buffer descriptor of the store: a piece that is not needed (beyond the candidate's
-// window) gets an out-of-range offset, which the range check drops without a memory access — no divergent control flow
+// window) gets the first out-of-range offset, which the range check drops without a memory access — no divergent control flow
 // around the loads, so the compiler counts them exactly (s_waitcnt vmcnt(N)).  Wave-synchronous: no workgroup barrier;
 // LDS executes one wave's instructions in order.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -388,11 +388,13 @@ __device__ __forceinline__ void wave_lds_order() {  // keeps the compiler from r
 }
 
 constexpr uint32_t kStageBytesPerWave = 64u * 64u;
+// LDS of the cooperative kernel: [table][scratch: 128 + WG + 32 words][pad to 1 KiB][one image per wave]
+__host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t wg) { return (lut_bytes + (128u + wg + 32u) * 4u + 1023u) & ~1023u; }
 
 // One sub-overlap of each of the wave's 64 candidates.  Called by all 64 lanes; a lane without one passes L = 0.
 // offA / offB: byte offsets of the window starts in the store; L: positions (sub_positions()).
 template <typename SymT, int LG>
-__device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, const SymT* __restrict__ sym, uint32_t stage, uint32_t offA,
+__device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint32_t oob, const SymT* __restrict__ sym, uint32_t stage, uint32_t offA,
                                                uint32_t offB, uint32_t L, uint32_t fatal, uint32_t Kp, SubScore& out) {
     using T = Tr<SymT>;
     constexpr uint32_t kSymB = sizeof(SymT);
@@ -419,8 +421,8 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool on = at < lim[j];
-            nA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] + at : 0xFFFFFFFFu, 0, 0);
-            nB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] + at : 0xFFFFFFFFu, 0, 0);
+            nA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] + at : oob, 0, 0);
+            nB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] + at : oob, 0, 0);
         }
     };
     fetch(0);
@@ -629,6 +631,86 @@ __device__ __forceinline__ void append_rows_block(const RowSink& sink, bool vali
     __syncthreads();  // lds4 is reused by the next iteration
 }
 
+// Block-local length balancing (read sets with mixed sequence lengths): returns the slot this lane scores in the
+// workgroup's iteration that starts at block_base.  Called by every lane of the workgroup (barriers inside).
+// bal: 128 + blockDim.x + 32 words of LDS scratch ([0..127] class histogram / offsets, then the order array, then 2 x 16 words
+// of reduction).
+template <typename SymT>
+__device__ __forceinline__ uint64_t balanced_slot(const StoreView& st, const ScoreParams& prm, const void* __restrict__ in, uint64_t n,
+                                                  const uint32_t* __restrict__ perm, uint32_t fmt, uint64_t block_base, uint32_t* bal) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t red = 128u + blockDim.x;  // behind the order array
+    uint64_t slot = block_base + tid;
+    {
+        // Block-local length balancing (read sets with mixed sequence lengths).  A wave runs as long as its
+        // longest lane; with mixed-length contigs (BASELINE config 5) the mean lane is busy 29 % of that time.
+        // When the overlap lengths of the candidates of this workgroup differ widely, they are redistributed over
+        // the lanes by length (LDS counting sort over quarter-octave length classes, longest first), so every
+        // wave gets similar work; the candidates stay inside their workgroup, which keeps the read-sharing
+        // locality (reordering over larger windows measured slower).
+        // phase 1: the length class of the candidate in this lane's own slot (its state is dead before phase 2)
+        uint32_t chunks = 0;
+        if (slot < n) {
+            const Cand rec = load_cand(in, perm ? (uint64_t)perm[slot] : slot, fmt);
+            Sub s0, s1;
+            const int ns = resolve<(int)sizeof(SymT)>(st, rec, s0, s1);
+            if (ns >= 1) chunks = (sub_positions(s0, prm.min_read_len) + 15u) >> 4;
+            if (ns == 2) {
+                const uint32_t c1 = (sub_positions(s1, prm.min_read_len) + 15u) >> 4;
+                chunks = c1 > chunks ? c1 : chunks;
+            }
+        }
+        uint32_t wmax = chunks, wsum = chunks;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t m = (uint32_t)__shfl_xor((int)wmax, o, 64);
+            wmax = m > wmax ? m : wmax;
+            wsum += (uint32_t)__shfl_xor((int)wsum, o, 64);
+        }
+        if ((tid & 63u) == 0) {
+            bal[red + (tid >> 6)] = wmax;
+            bal[red + 16 + (tid >> 6)] = wsum;
+        }
+        if (tid < 128) bal[tid] = 0;
+        __syncthreads();
+        uint32_t bmax = 0, bsum = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+            bmax = bal[red + w] > bmax ? bal[red + w] : bmax;
+            bsum += bal[red + 16 + w];
+        }
+        // worth it when the longest overlap is at least twice the block's mean and there is real work to balance
+        if (bmax >= 16u && (uint64_t)bmax * blockDim.x > 2ull * bsum) {
+            uint32_t cls = 0;  // quarter-octave class of the chunk count
+            if (chunks > 1) {
+                const uint32_t lg = 31u - (uint32_t)__builtin_clz(chunks);
+                cls = lg * 4u + (lg >= 2 ? (chunks >> (lg - 2)) & 3u : 0u);
+            }
+            cls = cls > 127u ? 127u : cls;
+            atomicAdd(&bal[cls], 1u);
+            __syncthreads();
+            if (tid < 64) {  // exclusive scan over the classes, longest class first
+                const uint32_t c0 = bal[127 - 2 * tid], c1 = bal[126 - 2 * tid];
+                uint32_t incl = c0 + c1;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+                    if ((int)tid >= o) incl += up;
+                }
+                const uint32_t excl = incl - (c0 + c1);
+                bal[127 - 2 * tid] = excl;
+                bal[126 - 2 * tid] = excl + c0;
+            }
+            __syncthreads();
+            const uint32_t at = atomicAdd(&bal[cls], 1u);
+            bal[128 + at] = tid;
+            __syncthreads();
+            slot = block_base + bal[128 + tid];
+        }
+        __syncthreads();  // bal is reused below and by the next iteration
+    }
+    return slot;
+}
+
 // The scoring kernel.  LG: log2 of the 8-bit-symbol table dimension (3..6; ignored for 16-bit symbols).  BAL:
 // block-local length balancing (below).  Workgroup-uniform loop: iteration k of a workgroup handles the candidates
 // [block_base, block_base + blockDim.x).
@@ -649,8 +731,8 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
     const SymT* sym = (const SymT*)st.sym;
     const uint32_t Kp = st.K + 2u;
     const uint32_t fmt = prm.rec_fmt;
-    // scratch behind the table: [0..127] class histogram / offsets, [128..383] order, [384..391] reduce (BAL);
-    // [0..17] wave offsets of the row append (the two never overlap in time: barriers in between)
+    // scratch behind the table: length balancing (balanced_slot) / [0..17] wave offsets of the row append (the two never
+    // overlap in time: barriers in between)
     uint32_t* bal = (uint32_t*)(lut_s + lut_n);
     const uint32_t tid = threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -658,73 +740,7 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
     // record back to the candidate's own position: out[i] <-> in[i] always holds
     for (uint64_t block_base = (uint64_t)blockIdx.x * blockDim.x; block_base < n; block_base += stride) {
         uint64_t slot = block_base + tid;
-        if (BAL) {
-            // Block-local length balancing (read sets with mixed sequence lengths).  A wave runs as long as its
-            // longest lane; with mixed-length contigs (BASELINE config 5) the mean lane is busy 29 % of that time.
-            // When the overlap lengths of the candidates of this workgroup differ widely, they are redistributed over
-            // the lanes by length (LDS counting sort over quarter-octave length classes, longest first), so every
-            // wave gets similar work; the candidates stay inside their workgroup, which keeps the read-sharing
-            // locality (reordering over larger windows measured slower).
-            // phase 1: the length class of the candidate in this lane's own slot (its state is dead before phase 2)
-            uint32_t chunks = 0;
-            if (slot < n) {
-                const Cand rec = load_cand(in, perm ? (uint64_t)perm[slot] : slot, fmt);
-                Sub s0, s1;
-                const int ns = resolve<(int)sizeof(SymT)>(st, rec, s0, s1);
-                if (ns >= 1) chunks = (sub_positions(s0, prm.min_read_len) + 15u) >> 4;
-                if (ns == 2) {
-                    const uint32_t c1 = (sub_positions(s1, prm.min_read_len) + 15u) >> 4;
-                    chunks = c1 > chunks ? c1 : chunks;
-                }
-            }
-            uint32_t wmax = chunks, wsum = chunks;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t m = (uint32_t)__shfl_xor((int)wmax, o, 64);
-                wmax = m > wmax ? m : wmax;
-                wsum += (uint32_t)__shfl_xor((int)wsum, o, 64);
-            }
-            if ((tid & 63u) == 0) {
-                bal[384 + (tid >> 6)] = wmax;
-                bal[388 + (tid >> 6)] = wsum;
-            }
-            if (tid < 128) bal[tid] = 0;
-            __syncthreads();
-            uint32_t bmax = 0, bsum = 0;
-            for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
-                bmax = bal[384 + w] > bmax ? bal[384 + w] : bmax;
-                bsum += bal[388 + w];
-            }
-            // worth it when the longest overlap is at least twice the block's mean and there is real work to balance
-            if (bmax >= 16u && (uint64_t)bmax * blockDim.x > 2ull * bsum) {
-                uint32_t cls = 0;  // quarter-octave class of the chunk count
-                if (chunks > 1) {
-                    const uint32_t lg = 31u - (uint32_t)__builtin_clz(chunks);
-                    cls = lg * 4u + (lg >= 2 ? (chunks >> (lg - 2)) & 3u : 0u);
-                }
-                cls = cls > 127u ? 127u : cls;
-                atomicAdd(&bal[cls], 1u);
-                __syncthreads();
-                if (tid < 64) {  // exclusive scan over the classes, longest class first
-                    const uint32_t c0 = bal[127 - 2 * tid], c1 = bal[126 - 2 * tid];
-                    uint32_t incl = c0 + c1;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-                        if ((int)tid >= o) incl += up;
-                    }
-                    const uint32_t excl = incl - (c0 + c1);
-                    bal[127 - 2 * tid] = excl;
-                    bal[126 - 2 * tid] = excl + c0;
-                }
-                __syncthreads();
-                const uint32_t at = atomicAdd(&bal[cls], 1u);
-                bal[128 + at] = tid;
-                __syncthreads();
-                slot = block_base + bal[128 + tid];
-            }
-            __syncthreads();  // bal is reused below and by the next iteration
-        }
+        if (BAL) slot = balanced_slot<SymT>(st, prm, in, n, perm, fmt, block_base, bal);
         // score the candidate of the (possibly reassigned) slot
         hc_result_rec res;
         res.n_cls = 0;
@@ -740,10 +756,12 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
     }
 }
 
-// The scoring kernel with the cooperative fetch (score_sub_coop): 8-bit symbols of the dense / sparse tables, stores
-// below 4 GiB (32-bit byte offsets), no length balancing.  Same results, records and row sink as score_kernel.
-template <typename SymT, int LG>
-__global__ __launch_bounds__(256, 4) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+// The scoring kernel with the cooperative fetch (score_sub_coop), for stores below 4 GiB (32-bit byte offsets).  Same
+// results, records and row sink as score_kernel.  WG: lanes per workgroup — one log table per workgroup, so a large table
+// (wide 8-bit symbols: 64 KiB; 16-bit symbols: up to 74 KiB) is shared by 1 024 lanes to keep 16 waves on a CU.
+// LDS: coop_stage_base().
+template <typename SymT, int LG, int WG, bool BAL>
+__global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                             const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
                                                             const uint32_t* __restrict__ perm, RowSink sink) {
     if (prm.n_dev) {
@@ -753,17 +771,20 @@ __global__ __launch_bounds__(256, 4) void score_kernel_coop(StoreView st, ScoreP
     extern __shared__ __attribute__((aligned(16))) double lut_s[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lut_s != 0u) __builtin_trap();  // lds_f64 relies on it
     const uint32_t lut_n = st.lut_bytes >> 3;
-    for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
+    for (uint32_t i = threadIdx.x; i < lut_n; i += WG) lut_s[i] = lut_g[i];
     __syncthreads();
-    uint32_t* scratch = (uint32_t*)(lut_s + lut_n);                                   // 32 words: row append
-    const uint32_t stage = st.lut_bytes + 128u + (threadIdx.x >> 6) * kStageBytesPerWave;  // this wave's image (LDS byte address)
+    uint32_t* scratch = (uint32_t*)(lut_s + lut_n);
+    // this wave's image (LDS byte address); the images start at a multiple of 1 KiB (the XOR swizzle needs whole 64-byte rows)
+    const uint32_t stage = coop_stage_base(st.lut_bytes, WG) + (threadIdx.x >> 6) * kStageBytesPerWave;
     const SymT* sym = (const SymT*)st.sym;
     const uint32_t Kp = st.K + 2u;
     const uint32_t fmt = prm.rec_fmt;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.sym, 0, (uint32_t)st.store_bytes, 0x00020000);
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t block_base = (uint64_t)blockIdx.x * blockDim.x; block_base < n; block_base += stride) {
-        const uint64_t slot = block_base + threadIdx.x;
+    const uint32_t oob = (uint32_t)st.store_bytes;  // the first offset the descriptor's range check rejects (no wrap-around at +16)
+    const uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (uint64_t block_base = (uint64_t)blockIdx.x * WG; block_base < n; block_base += stride) {
+        uint64_t slot = block_base + threadIdx.x;
+        if (BAL) slot = balanced_slot<SymT>(st, prm, in, n, perm, fmt, block_base, scratch);
         uint64_t i = 0;
         int ns = -2;  // no candidate in this lane
         Sub sub0{}, sub1{};
@@ -778,11 +799,11 @@ __global__ __launch_bounds__(256, 4) void score_kernel_coop(StoreView st, ScoreP
         s2.mm = 0;
         s2.n = 1;
         s2.err = 0;
-        score_sub_coop<SymT, LG>(rsrc, sym, stage, (uint32_t)((sub0.offA + sub0.pos) * sizeof(SymT)), (uint32_t)(sub0.offB * sizeof(SymT)), L0,
+        score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, (uint32_t)((sub0.offA + sub0.pos) * sizeof(SymT)), (uint32_t)(sub0.offB * sizeof(SymT)), L0,
                                  sub0.fatal, Kp, s1);
         if (__ballot(ns == 2) != 0ull) {
             SubScore t2;
-            score_sub_coop<SymT, LG>(rsrc, sym, stage, (uint32_t)((sub1.offA + sub1.pos) * sizeof(SymT)), (uint32_t)(sub1.offB * sizeof(SymT)),
+            score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, (uint32_t)((sub1.offA + sub1.pos) * sizeof(SymT)), (uint32_t)(sub1.offB * sizeof(SymT)),
                                      L1, sub1.fatal, Kp, t2);
             if (ns == 2) s2 = t2;
         }
@@ -892,37 +913,56 @@ void launch_lg(int group, const ScoreLaunch& a) {
 }
 }  // namespace
 
-// fetch_group: 4 = 64-symbol fetch groups (short reads), 2 = 32-symbol groups (contig-length sequences); chosen per
+// fetch_group: 0 = cooperative fetch (falls back to lane_fetch_group for stores of 4 GiB and more); per lane: 4 = 64-symbol
+// fetch groups (short reads), 2 = 32-symbol groups (contig-length sequences); chosen per
 // read set by hc_set_reads.  rows == nullptr: plain scoring; otherwise every non-dropped record is also appended to
 // rows (RowSink above).
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const void* in, uint64_t n,
-                        hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, hc_gather_row* rows,
+                        hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in, hc_line_rec* lines_out) {
     if (n == 0) return hipSuccess;
     const uint32_t lg = lut_lg(st.K);
     if (fetch_group == 0) {
-        const bool coop = st.symbytes == 1 && lg <= 5 && !st.balance && st.store_bytes < 0xFFFF0000ull;
-        if (coop) {
-            const size_t lds_c = st.lut_bytes + 128 + 4 * kStageBytesPerWave;
+        // a 4 KiB image per wave next to the table: 256-lane workgroups while four of them fit a CU, else one table for 1 024 lanes
+        const bool coop = st.store_bytes < 0xFFFF0000ull;
+        const size_t lds_256 = coop_stage_base(st.lut_bytes, 256) + 4 * kStageBytesPerWave;
+        const uint32_t wg_c = 4 * lds_256 <= 160 * 1024 ? 256u : 1024u;
+        const size_t lds_c = coop_stage_base(st.lut_bytes, wg_c) + (wg_c / 64) * kStageBytesPerWave;
+        if (coop && lds_c <= 160 * 1024) {
             uint32_t per_cu = (uint32_t)((160 * 1024) / lds_c);
-            per_cu = per_cu > 8 ? 8 : per_cu;
-            uint64_t blocks_c = (n + 255) / 256;
+            per_cu = per_cu * (wg_c / 64) > 32 ? 32 / (wg_c / 64) : per_cu;
+            uint64_t blocks_c = (n + wg_c - 1) / wg_c;
             const uint64_t cap_c = (uint64_t)n_cu * per_cu * 4;
             if (blocks_c > cap_c) blocks_c = cap_c;
             const RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out};
-#define HC_COOP(LG_)                                                                                                                  \
-    hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, prm, lut_g, in, n, out, \
-                       perm, sink)
-            if (lg == 3) HC_COOP(3);
-            else if (lg == 4) HC_COOP(4);
-            else HC_COOP(5);
+#define HC_COOP(T_, LG_)                                                                                                              \
+    do {                                                                                                                              \
+        if (wg_c == 256 && st.balance)                                                                                                \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, prm,  \
+                               lut_g, in, n, out, perm, sink);                                                                        \
+        else if (wg_c == 256)                                                                                                         \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, false>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, prm, \
+                               lut_g, in, n, out, perm, sink);                                                                        \
+        else if (st.balance)                                                                                                          \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream, st,     \
+                               prm, lut_g, in, n, out, perm, sink);                                                                   \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream, st,    \
+                               prm, lut_g, in, n, out, perm, sink);                                                                   \
+    } while (0)
+            if (st.symbytes == 2) HC_COOP(uint16_t, 5);
+            else if (lg == 3) HC_COOP(uint8_t, 3);
+            else if (lg == 4) HC_COOP(uint8_t, 4);
+            else if (lg == 5) HC_COOP(uint8_t, 5);
+            else HC_COOP(uint8_t, 6);
 #undef HC_COOP
             return hipGetLastError();
         }
-        fetch_group = 4;
+        fetch_group = lane_fetch_group;
     }
-    const size_t lds = st.lut_bytes + 392 * sizeof(uint32_t);
+    const uint32_t wg_max = 512;
+    const size_t lds = st.lut_bytes + (128 + wg_max + 32) * sizeof(uint32_t);
     // Fill the chip: enough 256-thread blocks for 8 waves per SIMD, bounded by LDS.
     uint32_t blocks_per_cu = 8;
     const uint32_t by_lds = (uint32_t)((160 * 1024) / lds);
@@ -964,9 +1004,17 @@ hipError_t set_lds_limit_lg() {
 hipError_t set_score_kernel_lds_limit() {
     hipError_t e;
     const int kMax = 160 * 1024;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+#define HC_COOP_ATTR(T_, LG_)                                                                                                                             \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;  \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;   \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    HC_COOP_ATTR(uint8_t, 3)
+    HC_COOP_ATTR(uint8_t, 4)
+    HC_COOP_ATTR(uint8_t, 5)
+    HC_COOP_ATTR(uint8_t, 6)
+    HC_COOP_ATTR(uint16_t, 5)
+#undef HC_COOP_ATTR
     if ((e = set_lds_limit_lg<uint8_t, 3>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 4>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 5>()) != hipSuccess) return e;
