@@ -428,6 +428,7 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
     }
     hc::ScoreParams prm = c->params;
     prm.rec_fmt = fmt;
+    { static const bool no_sort = getenv("HC_COOP_SORT") && atoi(getenv("HC_COOP_SORT")) == 0; prm.pad = no_sort ? 1u : 0u; }
     prm.n_dev = n_dev;
     HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group, rows, row_count, cap,
                             base_index, s, lines_in, lines_out));

@@ -388,8 +388,8 @@ __device__ __forceinline__ void wave_lds_order() {  // keeps the compiler from r
 }
 
 constexpr uint32_t kStageBytesPerWave = 64u * 64u;
-// LDS of the cooperative kernel: [table][scratch: 128 + WG + 32 words][pad to 1 KiB][one image per wave]
-__host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t wg) { return (lut_bytes + (128u + wg + 32u) * 4u + 1023u) & ~1023u; }
+// LDS of the cooperative kernel: [table][scratch: 32 words][pad to 1 KiB][one image per wave]
+__host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t /*wg*/) { return (lut_bytes + 128u + 1023u) & ~1023u; }
 
 // One sub-overlap of each of the wave's 64 candidates.  Called by all 64 lanes; a lane without one passes L = 0.
 // offA / offB: byte offsets of the window starts in the store; L: positions (sub_positions()).
@@ -760,7 +760,20 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
 // results, records and row sink as score_kernel.  WG: lanes per workgroup — one log table per workgroup, so a large table
 // (wide 8-bit symbols: 64 KiB; 16-bit symbols: up to 74 KiB) is shared by 1 024 lanes to keep 16 waves on a CU.
 // LDS: coop_stage_base().
-template <typename SymT, int LG, int WG, bool BAL>
+// SORT: the 128 sub-overlaps of a wave's 64 candidates (two per candidate at most) are dealt to its lanes by length —
+// ranks from one pair of ballots per length class, longest first; lane t scores rank t and then rank 127 - t — so the 64
+// sub-overlaps the wave steps through together are the longer half, then the shorter half: a wave runs as long as its
+// longest lane, and with windows of 75..150 symbols next to each other a lane is busy 76 % of that time; sorted, the second
+// pass usually needs one 64-byte step less.  Parameters and results change lanes through the wave's own image space: no
+// workgroup barrier (a workgroup-wide sort saved more work and lost it again waiting at its seven barriers).
+__device__ __forceinline__ uint32_t length_class(uint32_t chunks) {  // 0..15 exact, then quarter octaves; < 128
+    if (chunks < 16u) return chunks;
+    const uint32_t lg = 31u - (uint32_t)__builtin_clz(chunks);
+    const uint32_t c = 16u + (lg - 4u) * 4u + ((chunks >> (lg - 2u)) & 3u);
+    return c > 127u ? 127u : c;
+}
+
+template <typename SymT, int LG, int WG, bool SORT>
 __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                             const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
                                                             const uint32_t* __restrict__ perm, RowSink sink) {
@@ -773,18 +786,19 @@ __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score
     const uint32_t lut_n = st.lut_bytes >> 3;
     for (uint32_t i = threadIdx.x; i < lut_n; i += WG) lut_s[i] = lut_g[i];
     __syncthreads();
-    uint32_t* scratch = (uint32_t*)(lut_s + lut_n);
+    uint32_t* scratch = (uint32_t*)(lut_s + lut_n);  // row append: [0..17]
     // this wave's image (LDS byte address); the images start at a multiple of 1 KiB (the XOR swizzle needs whole 64-byte rows)
-    const uint32_t stage = coop_stage_base(st.lut_bytes, WG) + (threadIdx.x >> 6) * kStageBytesPerWave;
+    const uint32_t stage_base = coop_stage_base(st.lut_bytes, WG);
+    const uint32_t stage = stage_base + (threadIdx.x >> 6) * kStageBytesPerWave;
     const SymT* sym = (const SymT*)st.sym;
     const uint32_t Kp = st.K + 2u;
     const uint32_t fmt = prm.rec_fmt;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.sym, 0, (uint32_t)st.store_bytes, 0x00020000);
     const uint32_t oob = (uint32_t)st.store_bytes;  // the first offset the descriptor's range check rejects (no wrap-around at +16)
+    const uint32_t tid = threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * WG;
     for (uint64_t block_base = (uint64_t)blockIdx.x * WG; block_base < n; block_base += stride) {
-        uint64_t slot = block_base + threadIdx.x;
-        if (BAL) slot = balanced_slot<SymT>(st, prm, in, n, perm, fmt, block_base, scratch);
+        const uint64_t slot = block_base + tid;
         uint64_t i = 0;
         int ns = -2;  // no candidate in this lane
         Sub sub0{}, sub1{};
@@ -794,18 +808,68 @@ __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score
         }
         const uint32_t L0 = ns >= 1 ? sub_positions(sub0, prm.min_read_len) : 0u;
         const uint32_t L1 = ns == 2 ? sub_positions(sub1, prm.min_read_len) : 0u;
+        // a sub-overlap as it travels: window starts as byte offsets into the store, positions | fatal << 31
+        uint32_t a0 = (uint32_t)((sub0.offA + sub0.pos) * sizeof(SymT)), b0 = (uint32_t)(sub0.offB * sizeof(SymT)), l0 = L0 | (sub0.fatal << 31);
+        uint32_t a1 = (uint32_t)((sub1.offA + sub1.pos) * sizeof(SymT)), b1 = (uint32_t)(sub1.offB * sizeof(SymT)), l1 = L1 | (sub1.fatal << 31);
         SubScore s1, s2;
-        s2.x = __builtin_nan("");
-        s2.mm = 0;
-        s2.n = 1;
-        s2.err = 0;
-        score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, (uint32_t)((sub0.offA + sub0.pos) * sizeof(SymT)), (uint32_t)(sub0.offB * sizeof(SymT)), L0,
-                                 sub0.fatal, Kp, s1);
-        if (__ballot(ns == 2) != 0ull) {
-            SubScore t2;
-            score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, (uint32_t)((sub1.offA + sub1.pos) * sizeof(SymT)), (uint32_t)(sub1.offB * sizeof(SymT)),
-                                     L1, sub1.fatal, Kp, t2);
-            if (ns == 2) s2 = t2;
+        if (SORT) {
+            // rank of the wave's sub-overlap 2 lane + s, longest class first: one pair of ballots per class that occurs
+            const uint32_t lane = tid & 63u;
+            const uint32_t c0 = length_class((L0 + 15u) >> 4), c1 = length_class((L1 + 15u) >> 4);
+            uint32_t cmax = c0 > c1 ? c0 : c1, cmin = c0 < c1 ? c0 : c1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t hi = (uint32_t)__shfl_xor((int)cmax, o, 64), lo = (uint32_t)__shfl_xor((int)cmin, o, 64);
+                cmax = hi > cmax ? hi : cmax;
+                cmin = lo < cmin ? lo : cmin;
+            }
+            const uint64_t below = (1ull << lane) - 1ull;
+            uint32_t base = 0, r0 = 0, r1 = 0;
+            for (int c = (int)cmax; c >= (int)cmin; --c) {  // wave-uniform
+                const uint64_t m0 = __ballot(c0 == (uint32_t)c), m1 = __ballot(c1 == (uint32_t)c);
+                const uint32_t n0 = (uint32_t)__popcll(m0);
+                if (c0 == (uint32_t)c) r0 = base + (uint32_t)__popcll(m0 & below);
+                if (c1 == (uint32_t)c) r1 = base + n0 + (uint32_t)__popcll(m1 & below);
+                base += n0 + (uint32_t)__popcll(m1);
+            }
+            // through the wave's own image space (wave-synchronous): what to score, and where its result belongs
+            const uint32_t x = stage;  // LDS byte address; 16 bytes per rank
+            lds_store128(x + 16u * r0, u32x4{a0, b0, l0, 2u * lane});
+            lds_store128(x + 16u * r1, u32x4{a1, b1, l1, 2u * lane + 1u});
+            wave_lds_order();
+            const u32x4 p0 = lds_load128(x + 16u * lane), p1 = lds_load128(x + 16u * (127u - lane));  // rank `lane`, then the other half mirrored
+            wave_lds_order();
+            SubScore r[2];
+            score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, p0[0], p0[1], p0[2] & 0x7FFFFFFFu, p0[2] >> 31, Kp, r[0]);
+            r[1].x = -__builtin_inf();
+            r[1].mm = 1;
+            r[1].n = 1;
+            r[1].err = p1[2] >> 31;
+            if (__ballot((p1[2] & 0x7FFFFFFFu) != 0u) != 0ull)
+                score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, p1[0], p1[1], p1[2] & 0x7FFFFFFFu, p1[2] >> 31, Kp, r[1]);
+            wave_lds_order();
+            lds_store128(x + 16u * p0[3], u32x4{(uint32_t)__double2loint(r[0].x), (uint32_t)__double2hiint(r[0].x), r[0].mm, r[0].n | (r[0].err << 31)});
+            lds_store128(x + 16u * p1[3], u32x4{(uint32_t)__double2loint(r[1].x), (uint32_t)__double2hiint(r[1].x), r[1].mm, r[1].n | (r[1].err << 31)});
+            wave_lds_order();
+            const u32x4 q0 = lds_load128(x + 32u * lane), q1 = lds_load128(x + 32u * lane + 16u);
+            wave_lds_order();
+            s1.x = __hiloint2double((int)q0[1], (int)q0[0]);
+            s1.mm = q0[2];
+            s1.n = q0[3] & 0x7FFFFFFFu;
+            s1.err = q0[3] >> 31;
+            s2.x = __hiloint2double((int)q1[1], (int)q1[0]);
+            s2.mm = q1[2];
+            s2.n = q1[3] & 0x7FFFFFFFu;
+            s2.err = q1[3] >> 31;
+        } else {
+            score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, a0, b0, L0, sub0.fatal, Kp, s1);
+            if (__ballot(ns == 2) != 0ull) score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, a1, b1, L1, sub1.fatal, Kp, s2);
+        }
+        if (ns != 2) {  // what a candidate without a second sub-overlap reports (compute_overlap, s-s)
+            s2.x = __builtin_nan("");
+            s2.mm = 0;
+            s2.n = 1;
+            s2.err = 0;
         }
         hc_result_rec res;
         res.n_cls = 0;
@@ -936,15 +1000,16 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             const uint64_t cap_c = (uint64_t)n_cu * per_cu * 4;
             if (blocks_c > cap_c) blocks_c = cap_c;
             const RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out};
+            const bool sort_subs = !(prm.pad & 1u);
 #define HC_COOP(T_, LG_)                                                                                                              \
     do {                                                                                                                              \
-        if (wg_c == 256 && st.balance)                                                                                                \
+        if (wg_c == 256 && sort_subs)                                                                                                 \
             hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, prm,  \
                                lut_g, in, n, out, perm, sink);                                                                        \
         else if (wg_c == 256)                                                                                                         \
             hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, false>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, prm, \
                                lut_g, in, n, out, perm, sink);                                                                        \
-        else if (st.balance)                                                                                                          \
+        else if (sort_subs)                                                                                                           \
             hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream, st,     \
                                prm, lut_g, in, n, out, perm, sink);                                                                   \
         else                                                                                                                          \
