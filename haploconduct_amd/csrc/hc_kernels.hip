@@ -497,6 +497,15 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
     out.n = cn;
 }
 
+// Result records are written once and read by nobody on the device: streamed past the caches, so they do not push the
+// read store out of L2 / the Infinity Cache (the candidate records are read the same way, hc_resolve.h).
+__device__ __forceinline__ void store_result(hc_result_rec* __restrict__ out, uint64_t i, const hc_result_rec& r) {
+    unsigned long long* p = (unsigned long long*)(out + i);
+    __builtin_nontemporal_store((unsigned long long)__double_as_longlong(r.x1), p);
+    __builtin_nontemporal_store((unsigned long long)__double_as_longlong(r.x2), p + 1);
+    __builtin_nontemporal_store(((unsigned long long)r.n_cls << 32) | r.mm, p + 2);
+}
+
 // exp(x) > T  in x-space: 1 pass, 0 fail, 2 ambiguous
 __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return x > b.hi ? 1u : (x <= b.lo ? 0u : 2u); }
 
@@ -538,7 +547,7 @@ __device__ __forceinline__ hc_result_rec classify_and_store(const ScoreParams& p
     res.x2 = s2.x;
     res.mm = mm;
     res.n_cls = (nn & 0x0FFFFFFFu) | (cls << 28);
-    out[i] = res;
+    store_result(out, i, res);
     return res;
 }
 
@@ -554,7 +563,7 @@ __device__ __forceinline__ hc_result_rec score_candidate(const ScoreParams& prm,
         res.x2 = __builtin_nan("");
         res.mm = 1;
         res.n_cls = 1u | ((ns == 0 ? HC_CLS_ERROR : HC_CLS_DROP) << 28);
-        out[i] = res;
+        store_result(out, i, res);
         return res;
     }
     SubScore s1, s2;
@@ -879,7 +888,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score
                 res.x2 = __builtin_nan("");
                 res.mm = 1;
                 res.n_cls = 1u | ((ns == 0 ? HC_CLS_ERROR : HC_CLS_DROP) << 28);
-                out[i] = res;
+                store_result(out, i, res);
             } else {
                 res = classify_and_store(prm, ns, s1, s2, i, out);
             }

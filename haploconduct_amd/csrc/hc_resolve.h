@@ -22,8 +22,9 @@ struct Cand {
 // fmt: HC_REC_FULL (hc_overlap_rec) or HC_REC_COMPACT (hc_cand_rec); wave-uniform
 __device__ __forceinline__ Cand load_cand(const void* __restrict__ in, uint64_t i, uint32_t fmt) {
     Cand c;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     if (fmt == HC_REC_COMPACT) {
-        const uint4 a = ((const uint4*)in)[i];
+        const u32x4_t a = __builtin_nontemporal_load((const u32x4_t*)in + i);  // read once: streamed
         c.read1 = a.x;
         c.read2 = a.y;
         c.pos1 = a.z & HC_CAND_POS_MASK;
@@ -34,7 +35,7 @@ __device__ __forceinline__ Cand load_cand(const void* __restrict__ in, uint64_t 
         const uint32_t oc = a.z >> 30;
         c.ord = oc == 1u ? (uint32_t)'1' : (oc == 2u ? (uint32_t)'2' : (oc == 0u ? (uint32_t)'-' : 0u));
     } else {
-        const uint4 a = ((const uint4*)in)[2 * i];  // the second half (len1, len2, perc) is host-only
+        const u32x4_t a = __builtin_nontemporal_load((const u32x4_t*)in + 2 * i);  // the second half (len1, len2, perc) is host-only
         c.read1 = a.x;
         c.read2 = a.y;
         c.pos1 = a.z;
@@ -88,7 +89,8 @@ __device__ __forceinline__ View make_view(const ReadDesc& d, uint32_t mate, uint
     const uint64_t off = mate ? d.off2 : d.off1;
     v.len = mate ? d.len2 : d.len1;
     // slot_stride() with a compile-time symbol size (no 64-bit division)
-    const uint32_t stride = SB == 1 ? (((v.len + 15u) & ~15u) + 32u) : ((((2u * v.len + 15u) & ~15u) + 32u) >> 1);
+    const uint32_t bytes = ((((uint32_t)SB * v.len + 15u) & ~15u) + 32u + kSlotAlign - 1u) & ~(kSlotAlign - 1u);
+    const uint32_t stride = SB == 1 ? bytes : bytes >> 1;
     v.off = off + (fwd ? 0u : stride);
     v.fatal = (!fwd && (d.flags & (mate ? kReadBadBase2 : kReadBadBase1))) ? 1u : 0u;
     return v;
