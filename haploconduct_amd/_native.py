@@ -89,6 +89,9 @@ _sig = {
     "hc_textblock_create": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
     "hc_textblock_buffer": (_vp, [_vp]),
     "hc_textblock_submit": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "hc_textblock_submit_from": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64]),
+    "hc_linechain_create": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    "hc_linechain_destroy": (C.c_int, [_vp]),
     "hc_textblock_wait": (C.c_int, [_vp, C.POINTER(hc_text_result)]),
     "hc_textblock_destroy": (C.c_int, [_vp]),
     "hc_graph_begin": (C.c_int, [_vp]),

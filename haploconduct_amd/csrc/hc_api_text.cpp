@@ -22,7 +22,8 @@ struct hc_textblock {
     uint32_t row_cap = 0;  // rows / rejects the mapped host buffers hold; a block that needs more goes to the host
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    char* h_text = nullptr;                    // page-locked: the caller reads the file into it
+    hipEvent_t lines_known = nullptr;          // chained submits: this block's entry of the line chain is written
+    char* h_text = nullptr;                    // page-locked, allocated on first use (hc_textblock_buffer): the caller reads the file into it
     char* d_text = nullptr;                    // max_bytes + 64
     uint32_t *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_line_start = nullptr;
     hc_cand_rec* d_cands = nullptr;            // max_lines
@@ -111,7 +112,7 @@ int hc_textblock_create(hc_ctx* c, uint64_t max_bytes, hc_textblock** out) {
     };
     ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     ok(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
-    ok(hipHostMalloc((void**)&b->h_text, max_bytes + 64, hipHostMallocDefault));
+    ok(hipEventCreateWithFlags(&b->lines_known, hipEventDisableTiming));
     ok(hipMalloc((void**)&b->d_text, max_bytes + 64));
     ok(hipMalloc((void**)&b->d_tile_cnt, (size_t)(n_tiles + 1) * 4));
     ok(hipMalloc((void**)&b->d_tile_off, (size_t)(n_tiles + 1) * 4));
@@ -135,7 +136,44 @@ int hc_textblock_create(hc_ctx* c, uint64_t max_bytes, hc_textblock** out) {
     return HC_OK;
 }
 
-char* hc_textblock_buffer(hc_textblock* b) { return b ? b->h_text : nullptr; }
+char* hc_textblock_buffer(hc_textblock* b) {
+    if (!b) return nullptr;
+    if (!b->h_text) {  // only callers that fill the block themselves pay for the page-locked buffer
+        (void)hipSetDevice(b->ctx->device);
+        if (hipHostMalloc((void**)&b->h_text, b->max_bytes + 64, hipHostMallocDefault) != hipSuccess) b->h_text = nullptr;
+    }
+    return b->h_text;
+}
+
+// A chain of line counts shared by the blocks of one file, in page-locked memory every device and the host can read:
+// entry k = lines in front of block k.
+struct hc_linechain {
+    unsigned long long* h = nullptr;
+    uint64_t n = 0;
+};
+
+int hc_linechain_create(hc_ctx* c, uint64_t n_blocks, hc_linechain** out) {
+    if (!c || !out) return fail(HC_ERR_ARG, "hc_linechain_create: null argument");
+    HC_HIP(hipSetDevice(c->device));
+    hc_linechain* ch = new (std::nothrow) hc_linechain();
+    if (!ch) return fail(HC_ERR_NOMEM, "hc_linechain_create: host allocation failed");
+    ch->n = n_blocks + 2;
+    hipError_t e = hipHostMalloc((void**)&ch->h, ch->n * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) {
+        delete ch;
+        return fail(HC_ERR_HIP, std::string("hc_linechain_create: ") + hipGetErrorString(e));
+    }
+    memset(ch->h, 0, ch->n * sizeof(unsigned long long));
+    *out = ch;
+    return HC_OK;
+}
+
+int hc_linechain_destroy(hc_linechain* ch) {
+    if (!ch) return HC_OK;
+    if (ch->h) (void)hipHostFree(ch->h);
+    delete ch;
+    return HC_OK;
+}
 
 int hc_textblock_destroy(hc_textblock* b) {
     if (!b) return HC_OK;
@@ -147,27 +185,56 @@ int hc_textblock_destroy(hc_textblock* b) {
     for (void* p : {(void*)b->h_text, (void*)b->h_rows, (void*)b->h_row_lines, (void*)b->h_rejects, (void*)b->h_counters})
         if (p) (void)hipHostFree(p);
     if (b->done) (void)hipEventDestroy(b->done);
+    if (b->lines_known) (void)hipEventDestroy(b->lines_known);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return HC_OK;
 }
 
+static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, uint64_t first_line_no, hc_linechain* chain, uint64_t k,
+                            hc_textblock* prev, uint64_t base_index);
+
 int hc_textblock_submit(hc_textblock* b, uint64_t n_bytes, uint64_t first_line_no, uint64_t base_index) {
     if (!b) return fail(HC_ERR_ARG, "hc_textblock_submit: null block");
+    if (!b->h_text) return fail(HC_ERR_STATE, "hc_textblock_submit: hc_textblock_buffer was never filled");
+    return textblock_submit(b, b->h_text, n_bytes, first_line_no, nullptr, 0, nullptr, base_index);
+}
+
+int hc_textblock_submit_from(hc_textblock* b, const void* text, uint64_t n_bytes, hc_linechain* chain, uint64_t k, hc_textblock* prev,
+                             uint64_t base_index) {
+    if (!b || (n_bytes && !text) || !chain) return fail(HC_ERR_ARG, "hc_textblock_submit_from: null argument");
+    if (k + 1 >= chain->n) return fail(HC_ERR_ARG, "hc_textblock_submit_from: the line chain is shorter than that");
+    return textblock_submit(b, text, n_bytes, 0, chain, k, prev, base_index);
+}
+
+static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, uint64_t first_line_no, hc_linechain* chain, uint64_t k,
+                            hc_textblock* prev, uint64_t base_index) {
     hc_ctx* c = b->ctx;
     if (!c->have_reads || !c->have_ids) return fail(HC_ERR_STATE, "hc_textblock_submit: hc_set_reads and hc_text_set_ids come first");
     if (b->in_flight) return fail(HC_ERR_STATE, "hc_textblock_submit: the block is still in flight (hc_textblock_wait first)");
     if (n_bytes > b->max_bytes) return fail(HC_ERR_ARG, "hc_textblock_submit: more text than the block was created for");
     HC_HIP(hipSetDevice(c->device));
     hipStream_t s = b->stream;
-    memset(b->h_text + n_bytes, 0, 64);  // the 16-byte loads of the last tile read past the text: no stray newline there
     HC_HIP(hipMemsetAsync(b->d_counters, 0, hc::kTextCounters * sizeof(unsigned long long), s));
+    unsigned long long* d_chain = nullptr;
+    if (chain) HC_HIP(hipHostGetDevicePointer((void**)&d_chain, chain->h, 0));
     if (n_bytes) {
-        HC_HIP(hipMemcpyAsync(b->d_text, b->h_text, n_bytes + 64, hipMemcpyHostToDevice, s));
+        // the text as it is (page-locked or pageable: a file mapping goes to the device without a copy by the caller), and
+        // 64 zero bytes behind it: the 16-byte loads of the last tile read past the text, no stray newline there
+        HC_HIP(hipMemcpyAsync(b->d_text, src, n_bytes, hipMemcpyHostToDevice, s));
+        HC_HIP(hipMemsetAsync(b->d_text + n_bytes, 0, 64, s));
         HC_HIP(hc::launch_text_lines(b->d_text, n_bytes, b->d_tile_cnt, b->d_tile_off, b->max_lines, b->d_line_start, b->d_counters, s));
+    }
+    if (chain) {  // entry k is written by block k - 1's sequence (another stream, maybe another device)
+        if (prev) HC_HIP(hipStreamWaitEvent(s, prev->lines_known, 0));
+        HC_HIP(hc::launch_text_chain(d_chain + k, b->d_counters, d_chain + k + 1, s));
+        HC_HIP(hipEventRecord(b->lines_known, s));
+    }
+    if (n_bytes) {
         hc::TextParams prm;
         prm.n_bytes = n_bytes;
         prm.first_line_no = first_line_no;
+        prm.first_line_ptr = chain ? d_chain + k : nullptr;
         prm.max_overlaps = c->settings.max_overlaps;
         prm.max_lines = b->max_lines;
         prm.min_overlap_len = c->settings.min_overlap_len;

@@ -17,7 +17,8 @@ struct IdTable {  // FastqStorage::m_ID_to_index on the device: direct table whe
 
 struct TextParams {
     uint64_t n_bytes;
-    uint64_t first_line_no;  // number of the block's first line in the file
+    uint64_t first_line_no;  // number of the block's first line in the file ...
+    const unsigned long long* first_line_ptr;  // ... plus *first_line_ptr when set (a line chain, hc_linechain)
     uint64_t max_overlaps;   // --max_ov: lines numbered >= this are not read (EdgeCalculator.cpp:581)
     uint32_t max_lines;      // room in the line arrays; more newlines than that: the block goes to the host
     uint32_t min_overlap_len, min_overlap_perc, relax_pe;
@@ -43,6 +44,8 @@ enum {
 
 hipError_t launch_text_lines(const char* text, uint64_t n_bytes, uint32_t* tile_cnt, uint32_t* tile_off, uint32_t max_lines,
                              uint32_t* line_start, unsigned long long* counters, hipStream_t s);
+hipError_t launch_text_chain(const unsigned long long* lines_before, const unsigned long long* counters, unsigned long long* lines_before_next,
+                             hipStream_t s);
 hipError_t launch_text_parse(const TextParams& prm, const char* text, const uint32_t* line_start, const IdTable& ids, hc_cand_rec* cands,
                              hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, hipStream_t s);
 

@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const c
     }
     const uint32_t i = first + threadIdx.x;
     uint32_t n_read = 0, n_nonplain = 0, n_self = 0, n_silent = 0, n_reject = 0, n_pass = 0, n_unknown = 0;
-    if (i < n && prm.first_line_no + i < prm.max_overlaps) {  // `&& i < max_overlaps`, :581
+    const uint64_t first_line = prm.first_line_no + (prm.first_line_ptr ? *prm.first_line_ptr : 0ull);
+    if (i < n && first_line + i < prm.max_overlaps) {  // `&& i < max_overlaps`, :581
         n_read = 1;
         const uint32_t b = line_start[i];
         uint32_t e = line_start[i + 1] - 1u;  // the newline (or the virtual one behind a last line without)
@@ -319,6 +320,17 @@ hipError_t launch_text_lines(const char* text, uint64_t n_bytes, uint32_t* tile_
     hipLaunchKernelGGL(text_count_kernel, dim3(n_tiles), dim3(256), 0, s, text, n_bytes, tile_cnt);
     hipLaunchKernelGGL(text_scan_kernel, dim3(1), dim3(1024), 0, s, text, n_bytes, tile_cnt, n_tiles, max_lines, tile_off, line_start, counters);
     hipLaunchKernelGGL(text_lines_kernel, dim3(n_tiles), dim3(256), 0, s, text, n_bytes, tile_off, max_lines, line_start);
+    return hipGetLastError();
+}
+
+// Line numbers across blocks without the host counting newlines: lines_before_next = lines_before + this block's lines
+__global__ void text_chain_kernel(const unsigned long long* __restrict__ lines_before, const unsigned long long* __restrict__ counters,
+                                  unsigned long long* __restrict__ lines_before_next) {
+    *lines_before_next = *lines_before + counters[kTextLines];
+}
+hipError_t launch_text_chain(const unsigned long long* lines_before, const unsigned long long* counters, unsigned long long* lines_before_next,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(text_chain_kernel, dim3(1), dim3(1), 0, s, lines_before, counters, lines_before_next);
     return hipGetLastError();
 }
 

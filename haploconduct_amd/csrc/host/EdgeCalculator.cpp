@@ -600,11 +600,13 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     const size_t D = m_text_depth;  // text blocks per device
     const size_t R = D * N + 1;
     const size_t B = m_text_block;
+    const double t_setup0 = now_s();
     for (Device& d : m_dev) {
         d.tblk.resize(D, nullptr);
         for (hc_textblock*& b : d.tblk)
             if (!b) check(hc_textblock_create(d.ctx, B, &b), "hc_textblock_create");
     }
+    if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] text blocks ready after %.3f s\n", now_s() - t_setup0);
     struct Slot {
         hc_textblock* tb = nullptr;  // nullptr: the host's block (nothing was submitted)
         size_t begin = 0, end = 0;
@@ -621,6 +623,18 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     double t_collect = 0;
     uint64_t n_host_blocks = 0;
     double tm_wait = 0, tm_final = 0, tm_turn = 0, tm_consume = 0, tm_slot = 0, tm_copy = 0, tm_submit = 0;  // HC_STAGE_TIMING
+    // Where the text comes from: the page-locked buffer of the block, filled by pread on the pool (default), or,
+    // HC_TEXT_SOURCE=map, the file's mapping as it is — no copy and no newline count by the host: the runtime moves the
+    // pageable text, the blocks number their lines through a chain of counters on the device side (hc_linechain).  Measured
+    // equal at C3 (0.25 s both; the runtime's pageable copy reaches 25 GB/s beside the collectors' HIP calls, 40-50 GB/s
+    // alone: tools/experiments/register_cost.cpp), so the default stays the path whose speed is in this code's hands.
+    const bool from_map = getenv("HC_TEXT_SOURCE") && !strcmp(getenv("HC_TEXT_SOURCE"), "map");
+    struct ChainGuard {
+        hc_linechain* p = nullptr;
+        ~ChainGuard() { hc_linechain_destroy(p); }
+    } chain;
+    if (from_map) check(hc_linechain_create(m_ctx, parser.size() / std::max<size_t>(B / 2, 1) + 4, &chain.p), "hc_linechain_create");
+    std::atomic<uint64_t> lines_consumed{0};  // from_map: what the collectors have seen (the device applies --max_ov exactly)
     // Several collectors: collector c takes the blocks k = c, c + C, ...; waiting for the device, putting the rows in
     // order and finalising them (exp() of the admitted ones, the lines of the non-edges) happens side by side for
     // different blocks, the serial half (and everything that touches shared state) strictly in block order.
@@ -671,7 +685,8 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                     if (mine.status) throw mine;
                     if (tr.needs_host) {  // the host's tokeniser + Overlap constructor own this block
                         n_host_blocks++;
-                        parser.parse_range(sl.begin, sl.end, sl.first_line, host_batch, rejected, pc, /*print_malformed=*/true);
+                        parser.parse_range(sl.begin, sl.end, from_map ? lines_consumed.load() : sl.first_line, host_batch, rejected, pc,
+                                           /*print_malformed=*/true);
                         const size_t n = host_batch.size();
                         const hc_gather_row* rows = nullptr;
                         uint64_t n_rows = 0;
@@ -697,6 +712,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                         for (uint64_t j = 0; j < tr.n_rejected; j++) rejected.push_back(overlap_of(tr.rejected[j].line));
                     }
                     consume_block(out);
+                    if (sl.tb) lines_consumed += tr.n_lines;  // (a block that never went to the device is the file's last)
                 } catch (const FatalError& e) {
                     collector_error = e;
                     collector_failed = true;
@@ -730,7 +746,9 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
         size_t pos = 0;
         uint64_t line_no = 0;
         const size_t size = parser.size();
-        for (size_t k = 0; pos < size && line_no < program_settings.max_overlaps; k++) {  // `&& i < max_overlaps`, :581
+        hc_textblock* prev_tb = nullptr;
+        size_t chain_k = 0;
+        for (size_t k = 0; pos < size && line_no < program_settings.max_overlaps && lines_consumed.load() < program_settings.max_overlaps; k++) {  // `&& i < max_overlaps`, :581
             const double ts = now_s();
             {  // the block object's previous user (block k - D * N) has been consumed
                 std::unique_lock<std::mutex> g(mu);
@@ -746,9 +764,13 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
             const double t0 = now_s();
             size_t end = std::min(size, pos + B);
             uint64_t newlines = 0;
-            parser.copy_range(hc_textblock_buffer(tb), pos, end, newlines);
+            if (!from_map) {
+                char* dst = hc_textblock_buffer(tb);
+                if (!dst) throw FatalError{HC_ERR_NOMEM, "construct_edges: no page-locked buffer for a block of text"};
+                parser.copy_range(dst, pos, end, newlines);
+            }
             if (end < size) {  // cut behind the last newline of the stretch
-                const char* buf = hc_textblock_buffer(tb);
+                const char* buf = from_map ? parser.data() + pos : hc_textblock_buffer(tb);
                 size_t cut = end - pos;
                 while (cut > 0 && buf[cut - 1] != '\n') cut--;
                 if (cut == 0) {  // one line longer than a block: the host's (its parser has no such limit)
@@ -770,19 +792,27 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                 end = pos + cut;  // the bytes behind the cut are copied again with the next block
             }
             sl.end = end;
-            sl.n_lines = newlines;  // of the whole stretch; corrected below when it was cut
-            if (end < std::min(size, pos + B)) {
-                const char* buf = hc_textblock_buffer(tb);
-                sl.n_lines -= (uint64_t)std::count(buf + (end - pos), buf + (std::min(size, pos + B) - pos), '\n');
-            }
-            if (end == size) {  // a last piece without a newline is a line too (std::getline)
-                const char* buf = hc_textblock_buffer(tb);
-                if (end > pos && buf[end - pos - 1] != '\n') sl.n_lines++;
+            if (!from_map) {
+                sl.n_lines = newlines;  // of the whole stretch; corrected below when it was cut
+                if (end < std::min(size, pos + B)) {
+                    const char* buf = hc_textblock_buffer(tb);
+                    sl.n_lines -= (uint64_t)std::count(buf + (end - pos), buf + (std::min(size, pos + B) - pos), '\n');
+                }
+                if (end == size) {  // a last piece without a newline is a line too (std::getline)
+                    const char* buf = hc_textblock_buffer(tb);
+                    if (end > pos && buf[end - pos - 1] != '\n') sl.n_lines++;
+                }
             }
             const double tc = now_s();
             stats.t_parse += tc - t0;
             tm_copy += tc - t0;
-            check(hc_textblock_submit(tb, end - pos, line_no, 0), "hc_textblock_submit");
+            if (from_map) {
+                check(hc_textblock_submit_from(tb, parser.data() + pos, end - pos, chain.p, chain_k, prev_tb, 0), "hc_textblock_submit_from");
+                prev_tb = tb;
+                chain_k++;
+            } else {
+                check(hc_textblock_submit(tb, end - pos, line_no, 0), "hc_textblock_submit");
+            }
             tm_submit += now_s() - tc;
             sl.tb = tb;
             ring[k % R] = sl;
@@ -960,12 +990,18 @@ void EdgeCalculator::run_stage(bool then_sort) {
     if (m_device_resolve) check(hc_graph_begin(m_ctx), "hc_graph_begin");
     std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
     std::vector<Overlap> rejected;
+    const double t_stage0 = now_s();
+    auto stage_lap = [&](const char* what) {
+        if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] %s at %.3f s\n", what, now_s() - t_stage0);
+    };
     OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
+    stage_lap("overlaps file open");
     if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
     if (program_settings.verbose) puts("reading overlaps file... ");
     ParseCounters pc;
     if (m_host_parse) score_host_parsed(parser, rejected, pc);
     else score_device_parsed(parser, rejected, pc);
+    stage_lap("all blocks scored and consumed");
     bool sorted_already = false;
     if (m_collect) {
         const double tr = now_s();
@@ -978,6 +1014,7 @@ void EdgeCalculator::run_stage(bool then_sort) {
         m_admitted.clear();
         m_admitted.shrink_to_fit();
         if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] resolve total %.3f s\n", now_s() - tr);
+        stage_lap("graph resolved");
         m_collect = false;
         stats.t_insert += now_s() - tr;
     }

@@ -146,6 +146,7 @@ public:
     // threads (pread: no page of the mapping is touched) with the number of newlines among them, the end of the line
     // that holds byte `at` (offset behind its newline, or the size of the file), and the id table.
     size_t size() const { return m_size; }
+    const char* data() const { return m_data; }  // the file's mapping (PROT_READ, MAP_PRIVATE)
     void copy_range(char* dst, size_t begin, size_t end, uint64_t& newlines) const;
     size_t line_end_at(size_t at) const;
     const IdIndex& ids() const { return m_ids; }

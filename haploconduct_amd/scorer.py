@@ -125,10 +125,14 @@ class EdgeScorer:
         ids = np.ascontiguousarray(read_ids, dtype=np.uint64)
         N.check(N.lib.hc_text_set_ids(self._ctx, _ptr(ids), ids.shape[0]), "hc_text_set_ids")
 
-    def score_text(self, text, block_bytes=1 << 20, first_line_no=0):
+    def score_text(self, text, block_bytes=1 << 20, first_line_no=0, chained=False):
         """The overlaps file's TEXT through hc_textblock_submit / hc_textblock_wait, block by block (cut at line ends).
-        Returns a list with one dict per block: the hc_text_result fields, rows / rejected as numpy copies."""
+        Returns a list with one dict per block: the hc_text_result fields, rows / rejected as numpy copies.
+        chained: hc_textblock_submit_from — the text goes to the device straight from `text`, two blocks in flight, line
+        numbers through an hc_linechain (first_line_no must be 0)."""
         raw = text if isinstance(text, bytes) else text.encode()
+        if chained:
+            return self._score_text_chained(raw, block_bytes)
         b = C.c_void_p()
         N.check(N.lib.hc_textblock_create(self._ctx, max(block_bytes, 64), C.byref(b)), "hc_textblock_create")
         out, at, line_no, base = [], 0, first_line_no, 0
@@ -156,6 +160,51 @@ class EdgeScorer:
                 at = end
         finally:
             N.lib.hc_textblock_destroy(b)
+        return out
+
+    def _score_text_chained(self, raw, block_bytes):
+        cuts, at = [], 0
+        while at < len(raw):
+            end = min(len(raw), at + block_bytes)
+            if end < len(raw):
+                nl = raw.rfind(b"\n", at, end)
+                if nl < 0:
+                    raise ValueError("a line longer than the block")
+                end = nl + 1
+            cuts.append((at, end))
+            at = end
+        src = np.frombuffer(raw, np.uint8)  # pageable host memory, read in place
+        blocks = [C.c_void_p(), C.c_void_p()]
+        chain = C.c_void_p()
+        for b in blocks:
+            N.check(N.lib.hc_textblock_create(self._ctx, max(block_bytes, 64), C.byref(b)), "hc_textblock_create")
+        N.check(N.lib.hc_linechain_create(self._ctx, len(cuts), C.byref(chain)), "hc_linechain_create")
+        out, base = [], 0
+
+        def collect(k):
+            nonlocal base
+            r = N.hc_text_result()
+            N.check(N.lib.hc_textblock_wait(blocks[k % 2], C.byref(r)), "hc_textblock_wait")
+            d = {f: getattr(r, f) for f, _ in r._fields_ if f not in ("rows", "rejected")}
+            d["rows"] = np.frombuffer((C.c_char * (r.n_rows * 80)).from_address(r.rows), dtype=TEXT_ROW_DTYPE).copy() if r.n_rows else np.zeros(0, TEXT_ROW_DTYPE)
+            d["rejected"] = (np.frombuffer((C.c_char * (r.n_rejected * 56)).from_address(r.rejected), dtype=TEXT_REJECT_DTYPE).copy()
+                             if r.n_rejected else np.zeros(0, TEXT_REJECT_DTYPE))
+            d["base"], d["bytes"] = base, cuts[k]
+            base += r.n_lines
+            out.append(d)
+
+        try:
+            for k, (a, e) in enumerate(cuts):
+                if k >= 2:
+                    collect(k - 2)
+                N.check(N.lib.hc_textblock_submit_from(blocks[k % 2], src.ctypes.data + a, e - a, chain, k, blocks[(k - 1) % 2] if k else None, 0),
+                        "hc_textblock_submit_from")
+            for k in range(max(0, len(cuts) - 2), len(cuts)):
+                collect(k)
+        finally:
+            for b in blocks:
+                N.lib.hc_textblock_destroy(b)
+            N.lib.hc_linechain_destroy(chain)
         return out
 
     def graph_resolve(self, admitted, n_vertices, vertex_of_read=None, sorted_order=False, pieces=0):

@@ -353,6 +353,16 @@ char* hc_textblock_buffer(hc_textblock* b);
 /* Asynchronous.  The first n_bytes of the buffer are one block of the file starting at a line start; first_line_no =
  * number of that line in the file; --max_ov, the prefilter settings and the flags come from the context's settings. */
 int hc_textblock_submit(hc_textblock* b, uint64_t n_bytes, uint64_t first_line_no, uint64_t base_index);
+/* The same without the caller copying or counting anything: `text` is host memory as it is — a mapping of the overlaps
+ * file will do, page-locked or not — and the number of the block's first line comes from a chain of counters the blocks of
+ * one file share: block k (0, 1, 2 ... in file order, one submit each) reads entry k, which block k - 1's launch sequence
+ * wrote, and writes entry k + 1.  `prev` = the block object block k - 1 was submitted on (NULL for k == 0); it may belong
+ * to another context / device.  hc_text_result.n_lines of every block tells the host the same numbers afterwards. */
+typedef struct hc_linechain hc_linechain;
+int hc_linechain_create(hc_ctx* ctx, uint64_t n_blocks, hc_linechain** out);
+int hc_linechain_destroy(hc_linechain* chain);
+int hc_textblock_submit_from(hc_textblock* b, const void* text, uint64_t n_bytes, hc_linechain* chain, uint64_t k, hc_textblock* prev,
+                             uint64_t base_index);
 int hc_textblock_wait(hc_textblock* b, hc_text_result* out); /* valid until the next submit on this block */
 int hc_textblock_destroy(hc_textblock* b);
 

@@ -262,6 +262,19 @@ def test_device_text_parser_is_the_host_parser(block_bytes, tmp_path):
             sc.set_ids(ids)
             want_res = sc.score_batch(want_recs)
             blocks = sc.score_text(text, block_bytes=block_bytes)
+            # the same text read in place by the device, two blocks in flight, line numbers (--max_ov) through the line chain
+            chained = sc.score_text(text, block_bytes=block_bytes, chained=True)
+        assert len(chained) == len(blocks)
+        for x, y in zip(blocks, chained):
+            for k in x:
+                if k == "rows":  # the chained submit numbers a block's rows from 0 (the host learns the line counts afterwards)
+                    yr = y[k].copy()
+                    yr["row"]["index"] += y["base"]
+                    assert x[k].tobytes() == yr.tobytes(), k
+                elif k == "rejected":
+                    assert x[k].tobytes() == y[k].tobytes(), k
+                else:
+                    assert x[k] == y[k], k
         assert all(b["needs_host"] == 0 for b in blocks)
         assert sum(b["lines_read"] for b in blocks) == wc["lines_read"] and sum(b["scored"] for b in blocks) == wc["scored"] == want_recs.size
         assert sum(b["prefilter_rejected"] for b in blocks) == wc["prefilter_rejected"] > 50
