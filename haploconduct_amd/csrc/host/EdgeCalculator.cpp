@@ -73,21 +73,42 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
                 std::vector<uint64_t> ids(f.m_read_vec.size());
                 for (size_t r = 0; r < ids.size(); r++) ids[r] = f.m_read_vec[r]->get_read_id();
                 check(hc_text_set_ids(dev.ctx, ids.data(), (uint32_t)ids.size()), "hc_text_set_ids");
+                // the blocks of text construct_edges streams the overlaps file through, with their page-locked buffers:
+                // device memory and page-locking belong to setting the stage up, like the read store
+                Device& dv = m_dev.back();
+                dv.tblk.resize(m_text_depth, nullptr);
+                for (hc_textblock*& b : dv.tblk) {
+                    check(hc_textblock_create(dv.ctx, m_text_block, &b), "hc_textblock_create");
+                    if (!hc_textblock_buffer(b)) throw FatalError{HC_ERR_NOMEM, "EdgeCalculator: no page-locked buffer for a block of text"};
+                }
             }
         }
     } catch (...) {
-        for (Device& d : m_dev) hc_destroy(d.ctx);
+        for (Device& d : m_dev) {
+            for (hc_textblock* b : d.tblk) hc_textblock_destroy(b);
+            hc_destroy(d.ctx);
+        }
         throw;
     }
     m_ctx = m_dev[0].ctx;
 }
 
 EdgeCalculator::~EdgeCalculator() {
+    if (m_cleanup.joinable()) m_cleanup.join();
     for (Device& d : m_dev) {
         for (hc_block* b : d.blk) hc_block_destroy(b);
         for (hc_textblock* b : d.tblk) hc_textblock_destroy(b);
         hc_destroy(d.ctx);
     }
+}
+
+// Work that only gives memory back: run behind the caller's back, one piece after the other
+void EdgeCalculator::defer_cleanup(std::function<void()> work) {
+    std::thread prev = std::move(m_cleanup);
+    m_cleanup = std::thread([p = std::make_shared<std::thread>(std::move(prev)), w = std::move(work)]() mutable {
+        if (p->joinable()) p->join();
+        w();
+    });
 }
 
 double EdgeCalculator::phred_to_prob(int phred) const { return pow(10, -phred / 10.0); }  // :59-63
@@ -388,10 +409,20 @@ void EdgeCalculator::resolve_on_device(bool sorted) {
         Raw(const Raw&) = delete;
         Raw& operator=(const Raw&) = delete;
     };
-    Raw r_edges(E * sizeof(hc_edge_rec)), r_in(E * sizeof(uint32_t)), r_seq(gc.n_tied_lists ? E * sizeof(uint32_t) : 0);
-    hc_edge_rec* edges = (hc_edge_rec*)r_edges.p;
-    uint32_t* in_nodes = (uint32_t*)r_in.p;
-    uint32_t* seq = gc.n_tied_lists ? (uint32_t*)r_seq.p : nullptr;
+    // (freed by the clean-up thread, off the caller's clock: unmapping 300 MB takes as long as the fetch's copy)
+    struct Fetched {
+        Raw edges, in, seq;
+        Fetched(size_t a, size_t b, size_t c) : edges(a), in(b), seq(c) {}
+    };
+    std::unique_ptr<Fetched> fetched(new Fetched(E * sizeof(hc_edge_rec), E * sizeof(uint32_t), gc.n_tied_lists ? E * sizeof(uint32_t) : 0));
+    struct HandOver {
+        std::unique_ptr<Fetched>& f;
+        EdgeCalculator* self;
+        ~HandOver() { self->defer_cleanup([p = f.release()] { delete p; }); }
+    } hand_over{fetched, this};
+    hc_edge_rec* edges = (hc_edge_rec*)fetched->edges.p;
+    uint32_t* in_nodes = (uint32_t*)fetched->in.p;
+    uint32_t* seq = gc.n_tied_lists ? (uint32_t*)fetched->seq.p : nullptr;
     std::vector<uint64_t> out_off(V + 1), in_off(V + 1);
     std::vector<uint32_t> tied((size_t)gc.n_tied_lists);
     std::vector<uint8_t> incl(V);
@@ -1011,8 +1042,11 @@ void EdgeCalculator::run_stage(bool then_sort) {
         } else {
             resolve_on_host();
         }
-        m_admitted.clear();
-        m_admitted.shrink_to_fit();
+        {  // 180 MB of admitted records at C3: freed off the caller's clock
+            auto* old = new std::vector<std::vector<hc_admit_rec>>(std::move(m_admitted));
+            m_admitted.clear();
+            defer_cleanup([old] { delete old; });
+        }
         if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] resolve total %.3f s\n", now_s() - tr);
         stage_lap("graph resolved");
         m_collect = false;

@@ -2,7 +2,9 @@
 // (reference src/EdgeCalculator.h:25-64).  Same constructor, same public methods and counters;
 // the OpenMP loop of process_overlaps is replaced by hc_score_batch on the MI355X.
 #pragma once
+#include <functional>
 #include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -117,6 +119,8 @@ private:
     bool m_serial_insert = false;     // HC_INSERT_MODE=serial: per-edge inserts even into an empty graph
     bool m_host_resolve = false;      // HC_RESOLVE=host: duplicate resolution on the host threads instead of the device
     bool m_host_parse = false;        // HC_PARSE=host: the overlaps file is tokenised on the host threads instead of the device
+    std::thread m_cleanup;            // frees of large buffers, off the caller's clock (defer_cleanup)
+    void defer_cleanup(std::function<void()> work);
     size_t m_text_block = 16u << 20;  // bytes of text per device-parsed block (HC_TEXT_BLOCK)
     size_t m_text_depth = 6;          // text blocks in flight per device (HC_TEXT_DEPTH): copy of block k+2.. beside the device's work on k, k+1
     bool m_collect = false;           // this call collects the admitted candidates and resolves them after the last block
