@@ -265,11 +265,24 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     const uint32_t K = (uint32_t)phred.size();
     const uint32_t symbytes = hc::sym_bytes_for(K);
 
+    // store layout (hc_device.h): a single read [fwd][rc]; a pair [/1 fwd][/2 fwd][/1 rc][/2 rc]
     std::vector<uint64_t> sym_off(n_seq ? n_seq : 1);
+    std::vector<uint32_t> rc_delta(n_seq ? n_seq : 1);
     uint64_t nsym = 0;
-    for (uint32_t q = 0; q < n_seq; q++) {
-        sym_off[q] = nsym;
-        nsym += 2 * hc::slot_stride(seq_len[q], symbytes);
+    for (uint32_t r = 0; r < n_reads; r++) {
+        const uint32_t q = read_first_seq[r];
+        const uint64_t s1 = hc::slot_stride(seq_len[q], symbytes);
+        if (read_first_seq[r + 1] - q == 2) {
+            const uint64_t s2 = hc::slot_stride(seq_len[q + 1], symbytes);
+            sym_off[q] = nsym;
+            sym_off[q + 1] = nsym + s1;
+            rc_delta[q] = rc_delta[q + 1] = (uint32_t)(s1 + s2);
+            nsym += 2 * (s1 + s2);
+        } else {
+            sym_off[q] = nsym;
+            rc_delta[q] = (uint32_t)s1;
+            nsym += 2 * s1;
+        }
     }
     std::vector<double> lut;
     if (!build_lut(phred, c->settings.mismatch, symbytes, lut))  // (never seen: the reference's expressions commute for every Phred pair)
@@ -281,7 +294,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         ~Tmp() {
             if (p) (void)hipFree(p);
         }
-    } t_bases, t_quals, t_qmap, t_seq_bad, t_raw_off, t_seq_off, t_first;
+    } t_bases, t_quals, t_qmap, t_seq_bad, t_raw_off, t_seq_off, t_first, t_rc_delta;
     const uint64_t sym_bytes_total = (nsym ? nsym : 1) * symbytes;
     HC_HIP(hipMalloc(&c->d_sym, sym_bytes_total));
     HC_HIP(hipMalloc((void**)&c->d_reads, sizeof(hc::ReadDesc) * (n_reads ? n_reads : 1)));
@@ -293,6 +306,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     HC_HIP(hipMalloc(&t_quals.p, total ? total : 1));
     HC_HIP(hipMalloc(&t_raw_off.p, sizeof(uint64_t) * (n_seq + 1)));
     HC_HIP(hipMalloc(&t_qmap.p, 256));
+    HC_HIP(hipMalloc(&t_rc_delta.p, sizeof(uint32_t) * (n_seq ? n_seq : 1)));
     uint8_t *d_bases = (uint8_t*)t_bases.p, *d_quals = (uint8_t*)t_quals.p, *d_qmap = (uint8_t*)t_qmap.p, *d_seq_bad = (uint8_t*)t_seq_bad.p;
     uint64_t *d_raw_off = (uint64_t*)t_raw_off.p, *d_seq_off = (uint64_t*)t_seq_off.p;
     uint32_t* d_first = (uint32_t*)t_first.p;
@@ -303,9 +317,10 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     HC_HIP(hipMemcpyAsync(d_raw_off, seq_off, sizeof(uint64_t) * (n_seq + 1), hipMemcpyHostToDevice, c->stream));
     HC_HIP(hipMemcpyAsync(d_qmap, qmap, 256, hipMemcpyHostToDevice, c->stream));
     HC_HIP(hipMemcpyAsync(d_seq_off, sym_off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, c->stream));
+    HC_HIP(hipMemcpyAsync(t_rc_delta.p, rc_delta.data(), sizeof(uint32_t) * n_seq, hipMemcpyHostToDevice, c->stream));
     HC_HIP(hipMemcpyAsync(d_first, read_first_seq, sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, c->stream));
     HC_HIP(hipMemcpyAsync(c->d_lut, lut.data(), sizeof(double) * lut.size(), hipMemcpyHostToDevice, c->stream));
-    HC_HIP(hc::launch_encode(symbytes, d_bases, d_quals, d_raw_off, d_seq_off, d_qmap, n_seq, K, c->d_sym, d_seq_bad,
+    HC_HIP(hc::launch_encode(symbytes, d_bases, d_quals, d_raw_off, d_seq_off, (const uint32_t*)t_rc_delta.p, d_qmap, n_seq, K, c->d_sym, d_seq_bad,
                              d_first, n_reads, c->d_reads, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
 
@@ -320,16 +335,16 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
                 n_single++;
             }
         }
-        c->seq_refs.assign(n_seq, hc::SeqRef{0, 0, 0});
+        c->seq_refs.assign(n_seq, hc::SeqRef{0, 0, 0, 0, 0});
         uint32_t pair_no = 0;
         for (uint32_t r = 0; r < n_reads; r++) {
             const uint32_t q = read_first_seq[r];
             if (read_first_seq[r + 1] - q == 2) {
-                c->seq_refs[q] = hc::SeqRef{sym_off[q], seq_len[q], n_single + pair_no};
-                c->seq_refs[q + 1] = hc::SeqRef{sym_off[q + 1], seq_len[q + 1], n_single + n_pairs + pair_no};
+                c->seq_refs[q] = hc::SeqRef{sym_off[q], seq_len[q], n_single + pair_no, rc_delta[q], 0};
+                c->seq_refs[q + 1] = hc::SeqRef{sym_off[q + 1], seq_len[q + 1], n_single + n_pairs + pair_no, rc_delta[q + 1], 0};
                 pair_no++;
             } else {
-                c->seq_refs[q] = hc::SeqRef{sym_off[q], seq_len[q], r};
+                c->seq_refs[q] = hc::SeqRef{sym_off[q], seq_len[q], r, rc_delta[q], 0};
             }
         }
     }

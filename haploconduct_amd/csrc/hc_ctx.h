@@ -13,7 +13,7 @@
 namespace hc {
 // hc_kernels.hip
 hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
-                         const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
+                         const uint64_t* seq_off, const uint32_t* rc_delta, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
                          uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
                          hipStream_t stream);
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const void* in, uint64_t n,

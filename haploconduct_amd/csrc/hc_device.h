@@ -2,7 +2,11 @@
 //
 // Read store in HBM (built once per hc_set_reads, see DESIGN.md "Data layout"):
 //   every stored sequence q (a single read, or mate /1 or /2 of a pair) owns two
-//   SLOTS of symbols: forward at off, reverse-complement at off + slot_stride(len).
+//   SLOTS of symbols, forward and reverse-complement, each slot_stride(len) symbols long.  A single read:
+//   [fwd][rc].  A pair: [/1 fwd][/2 fwd][/1 rc][/2 rc] — the two windows a paired candidate reads of one read are the
+//   same orientation of both mates, and next to each other they share a 128-byte line more often (3.0 instead of 3.3
+//   lines per candidate on 2 x 150 bp reads; every miss moves a whole line).  rc slot = fwd slot + rc_delta
+//   (ReadDesc / SeqRef), rc_delta = the slot(s) in between.
 //   One symbol per base:
 //       sym = (qidx << 3) | code
 //   code = 0..3 for A,C,G,T (complement = 3 - code), 4 = N,
@@ -54,7 +58,7 @@ struct ReadDesc {
     uint64_t off1, off2;  // forward-slot offsets (symbols) of /1 (or the single sequence) and /2
     uint32_t len1, len2;
     uint32_t flags;
-    uint32_t pad;
+    uint32_t rc_delta;  // symbols from a forward slot of this read to the reverse-complement slot of the same mate
 };
 
 struct StoreView {
@@ -74,7 +78,7 @@ struct StoreView {
     uint32_t regular;
     uint32_t ulen;      // the common sequence length
     uint32_t n_single;  // reads [0, n_single) own one sequence, the others two
-    uint32_t seq_syms;  // symbols per sequence in the store: 2 * slot_stride(ulen)
+    uint32_t seq_syms;  // symbols per sequence in the store (both orientations): 2 * slot_stride(ulen)
 };
 
 // Log table layouts (doubles):

@@ -33,7 +33,7 @@ __device__ __forceinline__ ReadDesc g_load_desc(const ReadDesc* p) {
     d.len1 = b.x;
     d.len2 = b.y;
     d.flags = b.z;
-    d.pad = 0;
+    d.rc_delta = b.w;
     return d;
 }
 

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                                                            const uint8_t* __restrict__ quals,
                                                            const uint64_t* __restrict__ raw_off,  // [n_seq+1]
                                                            const uint64_t* __restrict__ seq_off,  // [n_seq] symbols
+                                                           const uint32_t* __restrict__ rc_delta,  // [n_seq] fwd slot -> rc slot
                                                            const uint8_t* __restrict__ qmap,  // [256] byte -> qidx, 255 = invalid
                                                            uint32_t n_seq, uint32_t K, SymT* __restrict__ sym,
                                                            uint8_t* __restrict__ seq_bad) {
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
         const uint64_t r0 = raw_off[q];
         const uint32_t len = (uint32_t)(raw_off[q + 1] - r0);
         const uint64_t f0 = seq_off[q];
-        const uint64_t stride = slot_stride(len, sizeof(SymT));
+        const uint64_t stride = slot_stride(len, sizeof(SymT));  // symbols of one slot (sequence + N padding)
+        const uint64_t rc0 = f0 + rc_delta[q];
         uint32_t bad = 0;
         for (uint32_t i = lane; i < (uint32_t)stride; i += 64) {
             if (i < len) {
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                     if (qi == 255) { qx = kWideBadQual; b2 = 0; }  // quality outside [33,127]: always fatal inside an overlap
                     const uint32_t rb2 = qx < kWideN ? 3u - b2 : 0u;
                     sym[f0 + i] = (SymT)((qx << 2) | b2);
-                    sym[f0 + stride + (len - 1 - i)] = (SymT)((qx << 2) | rb2);
+                    sym[rc0 + (len - 1 - i)] = (SymT)((qx << 2) | rb2);
                 } else {
                     if (code == kCodeN) qx = K;            // zero row of the log table
                     if (code == kCodeBadBase) qx = K + 1;  // NaN row
@@ -88,11 +90,11 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                     const uint32_t rcode = code < 4 ? 3 - code : code;
                     const uint32_t qbits = (qx << 3) | (dup ? (qx & 3u) << 6 : 0u);
                     sym[f0 + i] = (SymT)(qbits | code);
-                    sym[f0 + stride + (len - 1 - i)] = (SymT)(qbits | rcode);
+                    sym[rc0 + (len - 1 - i)] = (SymT)(qbits | rcode);
                 }
             } else {
                 sym[f0 + i] = nsym;
-                sym[f0 + stride + i] = nsym;
+                sym[rc0 + i] = nsym;
             }
         }
         const unsigned long long any_bad = __ballot(bad != 0);
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
 __global__ __launch_bounds__(256) void build_read_desc_kernel(const uint32_t* __restrict__ read_first_seq,
                                                               const uint64_t* __restrict__ seq_off,
                                                               const uint64_t* __restrict__ raw_off,
-                                                              const uint8_t* __restrict__ seq_bad, uint32_t n_reads,
-                                                              ReadDesc* __restrict__ out) {
+                                                              const uint8_t* __restrict__ seq_bad, const uint32_t* __restrict__ rc_delta,
+                                                              uint32_t n_reads, ReadDesc* __restrict__ out) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const uint32_t f = read_first_seq[r];
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void build_read_desc_kernel(const uint32_t* __
         d.len2 = (uint32_t)(raw_off[f + 2] - raw_off[f + 1]);
         d.flags |= seq_bad[f + 1] ? kReadBadBase2 : 0u;
     }
-    d.pad = 0;
+    d.rc_delta = rc_delta[f];
     out[r] = d;
 }
 
@@ -920,7 +922,7 @@ __global__ __launch_bounds__(512, 4) void score_kernel_wide_wg(StoreView st, Sco
 // ---------------------------------------------------------------------------
 // Launch wrappers (called from hc_api.cpp).
 hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
-                         const uint64_t* seq_off, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
+                         const uint64_t* seq_off, const uint32_t* rc_delta, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
                          uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
                          hipStream_t stream) {
     if (n_seq == 0) return hipSuccess;
@@ -929,18 +931,18 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
     if (blocks > 65536) blocks = 65536;
     if (symbytes == 1 && lut_lg(K) == 6)
         hipLaunchKernelGGL((encode_store_kernel<uint8_t, true>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
-                           seq_off, qmap, n_seq, K, (uint8_t*)sym, seq_bad);
+                           seq_off, rc_delta, qmap, n_seq, K, (uint8_t*)sym, seq_bad);
     else if (symbytes == 1)
         hipLaunchKernelGGL((encode_store_kernel<uint8_t, false>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
-                           seq_off, qmap, n_seq, K, (uint8_t*)sym, seq_bad);
+                           seq_off, rc_delta, qmap, n_seq, K, (uint8_t*)sym, seq_bad);
     else
         hipLaunchKernelGGL((encode_store_kernel<uint16_t, false>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
-                           seq_off, qmap, n_seq, K, (uint16_t*)sym, seq_bad);
+                           seq_off, rc_delta, qmap, n_seq, K, (uint16_t*)sym, seq_bad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (n_reads)
         hipLaunchKernelGGL(build_read_desc_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, read_first_seq,
-                           seq_off, raw_off, seq_bad, n_reads, descs);
+                           seq_off, raw_off, seq_bad, rc_delta, n_reads, descs);
     return hipGetLastError();
 }
 

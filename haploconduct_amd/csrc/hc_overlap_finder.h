@@ -11,9 +11,11 @@ namespace hc {
 // One stored sequence: forward slot (symbols), length, and its id in the SFO numbering
 // (singles, then all /1 mates, then all /2 mates: the s_p1_p2.fasta the pipelines feed to rust-overlaps).
 struct SeqRef {
-    uint64_t off;
+    uint64_t off;       // forward slot
     uint32_t len;
     uint32_t sfo_id;
+    uint32_t rc_delta;  // reverse-complement slot = off + rc_delta (hc_device.h: store layout)
+    uint32_t pad;
 };
 
 hipError_t finder_index(const void* sym, uint32_t symbytes, bool wide, const SeqRef* seqs, const uint64_t* pos_start, uint32_t n_seq,

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void finder_seed_kernel(const void* __restrict
         const SeqRef r = seqs[q];
         if (r.len < k) continue;
         const uint32_t nt = (r.len - k) / s + 1;
-        const uint64_t rc_off = r.off + slot_stride(r.len, symbytes);
+        const uint64_t rc_off = r.off + r.rc_delta;
         for (uint32_t j = lane; j < nt * n_ori; j += 64u) {
             const uint32_t o = j / nt, t = j - o * nt;
             const uint64_t code = kmer_at<SB, WIDE>(sym, (o ? rc_off : r.off) + (uint64_t)t * s, k);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void finder_verify_kernel(const void* __restri
             const bool inclusion = (d >= 0 && d + lb <= la) || (d <= 0 && d + lb >= la);
             if (L >= (int)min_overlap && (!inclusion || (flags & HC_FIND_INCLUSIONS))) {
                 const uint32_t kmax = (uint32_t)(err_rate * (double)L);
-                const uint64_t offb = o ? B.off + slot_stride(B.len, symbytes) : B.off;
+                const uint64_t offb = o ? B.off + B.rc_delta : B.off;
                 if (SB == 1) {  // 8 symbols per step (slots are padded: reading a few bytes past the end is safe)
                     const uint8_t* pa = (const uint8_t*)sym + A.off + (uint64_t)start;
                     const uint8_t* pb = (const uint8_t*)sym + offb + (uint64_t)(start - d);

@@ -64,7 +64,7 @@ __device__ __forceinline__ ReadDesc load_desc(const ReadDesc* p) {
     d.len1 = b.x;
     d.len2 = b.y;
     d.flags = b.z;
-    d.pad = 0;
+    d.rc_delta = b.w;
     return d;
 }
 
@@ -73,12 +73,13 @@ __device__ __forceinline__ ReadDesc regular_desc(const StoreView& st, uint32_t r
     const bool paired = r >= st.n_single;
     const uint32_t seq = paired ? st.n_single + 2u * (r - st.n_single) : r;
     ReadDesc d;
+    const uint32_t slot = st.seq_syms >> 1;
     d.off1 = (uint64_t)seq * st.seq_syms;
-    d.off2 = paired ? d.off1 + st.seq_syms : 0u;
+    d.off2 = paired ? d.off1 + slot : 0u;  // [/1 fwd][/2 fwd][/1 rc][/2 rc]
     d.len1 = st.ulen;
     d.len2 = paired ? st.ulen : 0u;
     d.flags = paired ? kReadPaired : 0u;
-    d.pad = 0;
+    d.rc_delta = paired ? 2u * slot : slot;
     return d;
 }
 
@@ -88,10 +89,7 @@ __device__ __forceinline__ View make_view(const ReadDesc& d, uint32_t mate, uint
     View v;
     const uint64_t off = mate ? d.off2 : d.off1;
     v.len = mate ? d.len2 : d.len1;
-    // slot_stride() with a compile-time symbol size (no 64-bit division)
-    const uint32_t bytes = ((((uint32_t)SB * v.len + 15u) & ~15u) + 32u + kSlotAlign - 1u) & ~(kSlotAlign - 1u);
-    const uint32_t stride = SB == 1 ? bytes : bytes >> 1;
-    v.off = off + (fwd ? 0u : stride);
+    v.off = off + (fwd ? 0u : d.rc_delta);
     v.fatal = (!fwd && (d.flags & (mate ? kReadBadBase2 : kReadBadBase1))) ? 1u : 0u;
     return v;
 }
