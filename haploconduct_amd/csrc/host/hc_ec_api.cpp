@@ -1,5 +1,6 @@
 // hc_ec_api.cpp — extern "C" face (include/hcedge_host.h) of the host-side stage.
 #include <cstring>
+#include <chrono>
 #include <memory>
 
 #include "../../../include/hcedge_host.h"
@@ -26,14 +27,20 @@ int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* path
     *out = nullptr;
     std::unique_ptr<hc_ec> ec(new hc_ec());
     int rc = guarded("hc_ec_open", [&] {
+        const bool timing = getenv("HC_STAGE_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
         ec->ps = make_ps(settings, paths);
         ec->fastq = std::make_shared<FastqStorage>(ec->ps);                                   // ViralQuasispecies.cpp:233
+        const double t1 = now();
         const unsigned int R = ec->fastq->get_readcount();
         ec->graph = std::make_shared<OverlapGraph>(ec->ps.add_duplicates ? 2 * R : R, ec->fastq, ec->ps);  // :246-261
         for (Read* r : ec->fastq->m_read_vec) r->set_vertex_id(true, ec->graph->addVertex(r->get_read_id()));  // :259-263
         if (ec->ps.add_duplicates)  // a vertex for every reverse-complemented read as well, :265-271
             for (Read* r : ec->fastq->m_read_vec) r->set_vertex_id(false, ec->graph->addVertex(r->get_read_id()));
+        const double t2 = now();
         ec->calc.reset(new EdgeCalculator(ec->fastq, ec->graph, ec->ps));                     // :279
+        if (timing) fprintf(stderr, "[hc stage] open: FASTQ -> FastqStorage %.3f s, graph vertices %.3f s, device contexts + store + text blocks %.3f s\n", t1 - t0, t2 - t1, now() - t2);
     });
     if (rc) return rc;
     *out = ec.release();
