@@ -179,15 +179,22 @@ void FastqStorage::read_new_ids(const std::string& path) {  // src/FastqStorage.
     if (!f.is_open()) throw FatalError{HC_ERR_IO, "Unable to open read-to-overlapID file"};
     std::string line;
     unsigned int max_id = 0;
+    // The reference pushes every line into ONE stringstream and takes two tab-delimited fields out of it (:69-71); what a
+    // line holds beyond its second field stays in the stream and is read in front of the next line's first field (:79-80
+    // clear the flags, not the contents).  `pending` is that remainder.
+    std::string pending;
     while (std::getline(f, line)) {
-        const size_t t1 = line.find('\t');
-        std::string new_id = line.substr(0, t1);
+        const std::string s = pending + line;
+        pending.clear();
+        const size_t t1 = s.find('\t');
+        const std::string new_id = s.substr(0, t1);  // getline(ss, new_read_ID, '\t')
         std::string old_id;
         if (t1 != std::string::npos) {
-            const size_t t2 = line.find('\t', t1 + 1);
-            old_id = line.substr(t1 + 1, t2 == std::string::npos ? std::string::npos : t2 - t1 - 1);
+            const size_t t2 = s.find('\t', t1 + 1);
+            old_id = s.substr(t1 + 1, t2 == std::string::npos ? std::string::npos : t2 - t1 - 1);
+            if (t2 != std::string::npos) pending = s.substr(t2 + 1);
         }
-        if (old_id.empty()) throw FatalError{HC_ERR_FORMAT, "--IDs line without an old id"};  // .at(0) throws in the reference
+        if (old_id.empty()) throw FatalError{HC_ERR_FORMAT, "--IDs line without an old id"};  // .at(0) throws in the reference (:72)
         if (old_id[0] == '>') old_id = old_id.substr(1);
         const read_id_t nid = str_to_read_id(new_id);
         if (nid > max_id) max_id = (unsigned int)nid;
