@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <array>
 #include <limits>
 #include <new>
 #include <string>
@@ -246,9 +248,27 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     }
     // dense quality alphabet over the bytes the reference accepts: Q = byte-33 >= 0 as a signed char
     uint64_t hist[256] = {0}, base_hist[256] = {0};
-    for (uint64_t i = 0; i < total; i++) {
-        hist[quals[i]]++;
-        base_hist[bases[i]]++;
+    {  // byte histograms of the two arrays (300 MB each at C3): a few threads, one partial pair each
+        const unsigned T = total < (1u << 22) ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::array<uint64_t, 512>> part(T);
+        auto work = [&](unsigned t) {
+            std::array<uint64_t, 512>& h = part[t];
+            h.fill(0);
+            const uint64_t a = total * t / T, b = total * (t + 1) / T;
+            for (uint64_t i = a; i < b; i++) {
+                h[quals[i]]++;
+                h[256 + bases[i]]++;
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        for (unsigned t = 0; t < T; t++)
+            for (int b = 0; b < 256; b++) {
+                hist[b] += part[t][(size_t)b];
+                base_hist[b] += part[t][256 + (size_t)b];
+            }
     }
     bool any_bad_base = false;  // a base outside ACGTN somewhere (the encoder flags the sequence; the store is then not "regular")
     for (int b = 0; b < 256; b++)
