@@ -17,11 +17,11 @@
 //     host through the host libm (guard band => HC_CLS_AMBIG, host decides).
 // No MFMA: this is byte gathering + table lookup + a serial fp64 add chain.
 //
-// Mapping (DESIGN.md "Kernel"): one lane = one candidate.  Per 16 positions a lane
-// loads 16 symbols of each read (16 B per load for 8-bit symbols), derives N / mismatch
-// masks and counts with packed-byte integer ops (4 positions per VALU op), builds the 16
-// LDS addresses of the log table with one v_perm_b32 + one shift each, issues the 16
-// ds_read_b64 back to back, and only then runs the 16 dependent v_add_f64.
+// Mapping: one lane OWNS one candidate — it derives N / mismatch masks and counts with packed-byte
+// integer ops (4 positions per VALU op), builds the 16 LDS addresses of the log table of a 16-position chunk with one
+// v_perm_b32 each, issues the 16 ds_read_b64 back to back and runs the 16 dependent v_add_f64 — and the lanes of a wave
+// FETCH together: quads read 64-byte rows that reach the owner through a per-wave LDS image (score_kernel_coop).  The
+// one-lane-one-fetch kernel (score_kernel) remains for contig-length read sets and stores of 4 GiB and more.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -141,7 +141,6 @@ struct Tr<uint8_t> {
     static constexpr int kSymsPerWord = 4;
     static constexpr int kWords = 4;  // per 16-symbol chunk
     static constexpr uint32_t kLow1 = 0x01010101u;
-    static constexpr uint32_t kQMask = 0xF8F8F8F8u;
     static constexpr int kSymBits = 8;
 };
 template <>
@@ -149,7 +148,6 @@ struct Tr<uint16_t> {
     static constexpr int kSymsPerWord = 2;
     static constexpr int kWords = 8;
     static constexpr uint32_t kLow1 = 0x00010001u;
-    static constexpr uint32_t kQMask = 0xFFF8FFF8u;
     static constexpr int kSymBits = 16;
 };
 
