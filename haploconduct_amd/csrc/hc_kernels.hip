@@ -640,89 +640,102 @@ __device__ __forceinline__ void append_rows_block(const RowSink& sink, bool vali
     __syncthreads();  // lds4 is reused by the next iteration
 }
 
-// Block-local length balancing (read sets with mixed sequence lengths): returns the slot this lane scores in the
-// workgroup's iteration that starts at block_base.  Called by every lane of the workgroup (barriers inside).
-// bal: 128 + blockDim.x + 32 words of LDS scratch ([0..127] class histogram / offsets, then the order array, then 2 x 16 words
-// of reduction).
+// Block-local length balancing (read sets with mixed sequence lengths: contigs next to reads).  A wave runs as long as
+// its longest lane, a workgroup iteration as long as its longest wave; with the log-uniform 150..6 000 bp contigs of
+// BASELINE config 5 the mean lane is busy 29 % of that time.  One iteration of a workgroup takes kBalItems x blockDim.x
+// candidates, ranks them by overlap length (LDS counting sort over quarter-octave classes, longest first) and deals them
+// like cards, there and back: lane t gets ranks t, 2W-1-t, 2W+t, ... (W = blockDim.x) and scores them one after the
+// other.  Neighbouring lanes then hold overlaps of neighbouring rank at any moment (little divergence inside a wave); with
+// several items per lane every lane's items also add up to about the same length — but the wider window costs more in
+// lost read sharing than the even finish gains (kBalItems below), so it is one item per lane: the candidates stay inside
+// their 256-candidate block.
+// Called by every lane of the workgroup (barriers inside).  bal: 128 + kBalItems * blockDim.x + 32 words of LDS scratch
+// ([0..127] class histogram / offsets, then the order array, then 2 x 16 words of reduction).
+constexpr int kBalItems = 1;  // measured on C5 (2 M contig overlaps): 1 -> 0.975 ms, 2 -> 1.036, 4 -> 1.167: the wider the window, the less neighbouring lanes share reads
 template <typename SymT>
-__device__ __forceinline__ uint64_t balanced_slot(const StoreView& st, const ScoreParams& prm, const void* __restrict__ in, uint64_t n,
-                                                  const uint32_t* __restrict__ perm, uint32_t fmt, uint64_t block_base, uint32_t* bal) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t red = 128u + blockDim.x;  // behind the order array
-    uint64_t slot = block_base + tid;
-    {
-        // Block-local length balancing (read sets with mixed sequence lengths).  A wave runs as long as its
-        // longest lane; with mixed-length contigs (BASELINE config 5) the mean lane is busy 29 % of that time.
-        // When the overlap lengths of the candidates of this workgroup differ widely, they are redistributed over
-        // the lanes by length (LDS counting sort over quarter-octave length classes, longest first), so every
-        // wave gets similar work; the candidates stay inside their workgroup, which keeps the read-sharing
-        // locality (reordering over larger windows measured slower).
-        // phase 1: the length class of the candidate in this lane's own slot (its state is dead before phase 2)
-        uint32_t chunks = 0;
+__device__ __forceinline__ void balanced_slots(const StoreView& st, const ScoreParams& prm, const void* __restrict__ in, uint64_t n,
+                                               const uint32_t* __restrict__ perm, uint32_t fmt, uint64_t block_base, uint32_t* bal,
+                                               uint64_t (&slots)[kBalItems]) {
+    const uint32_t tid = threadIdx.x, W = blockDim.x;
+    const uint32_t red = 128u + kBalItems * W;  // behind the order array
+    // phase 1: the length classes of the candidates in this lane's own slots (their state is dead before phase 2)
+    uint32_t chunks[kBalItems];
+    uint32_t wmax = 0, wsum = 0;
+#pragma unroll
+    for (int k = 0; k < kBalItems; ++k) {
+        const uint64_t slot = block_base + (uint64_t)k * W + tid;
+        slots[k] = slot;
+        uint32_t c = 0;
         if (slot < n) {
             const Cand rec = load_cand(in, perm ? (uint64_t)perm[slot] : slot, fmt);
             Sub s0, s1;
             const int ns = resolve<(int)sizeof(SymT)>(st, rec, s0, s1);
-            if (ns >= 1) chunks = (sub_positions(s0, prm.min_read_len) + 15u) >> 4;
-            if (ns == 2) {
-                const uint32_t c1 = (sub_positions(s1, prm.min_read_len) + 15u) >> 4;
-                chunks = c1 > chunks ? c1 : chunks;
-            }
+            if (ns >= 1) c = (sub_positions(s0, prm.min_read_len) + 15u) >> 4;
+            if (ns == 2) c += (sub_positions(s1, prm.min_read_len) + 15u) >> 4;  // the lane scores both, one after the other
         }
-        uint32_t wmax = chunks, wsum = chunks;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t m = (uint32_t)__shfl_xor((int)wmax, o, 64);
-            wmax = m > wmax ? m : wmax;
-            wsum += (uint32_t)__shfl_xor((int)wsum, o, 64);
-        }
-        if ((tid & 63u) == 0) {
-            bal[red + (tid >> 6)] = wmax;
-            bal[red + 16 + (tid >> 6)] = wsum;
-        }
-        if (tid < 128) bal[tid] = 0;
-        __syncthreads();
-        uint32_t bmax = 0, bsum = 0;
-        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
-            bmax = bal[red + w] > bmax ? bal[red + w] : bmax;
-            bsum += bal[red + 16 + w];
-        }
-        // worth it when the longest overlap is at least twice the block's mean and there is real work to balance
-        if (bmax >= 16u && (uint64_t)bmax * blockDim.x > 2ull * bsum) {
-            uint32_t cls = 0;  // quarter-octave class of the chunk count
-            if (chunks > 1) {
-                const uint32_t lg = 31u - (uint32_t)__builtin_clz(chunks);
-                cls = lg * 4u + (lg >= 2 ? (chunks >> (lg - 2)) & 3u : 0u);
-            }
-            cls = cls > 127u ? 127u : cls;
-            atomicAdd(&bal[cls], 1u);
-            __syncthreads();
-            if (tid < 64) {  // exclusive scan over the classes, longest class first
-                const uint32_t c0 = bal[127 - 2 * tid], c1 = bal[126 - 2 * tid];
-                uint32_t incl = c0 + c1;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-                    if ((int)tid >= o) incl += up;
-                }
-                const uint32_t excl = incl - (c0 + c1);
-                bal[127 - 2 * tid] = excl;
-                bal[126 - 2 * tid] = excl + c0;
-            }
-            __syncthreads();
-            const uint32_t at = atomicAdd(&bal[cls], 1u);
-            bal[128 + at] = tid;
-            __syncthreads();
-            slot = block_base + bal[128 + tid];
-        }
-        __syncthreads();  // bal is reused below and by the next iteration
+        chunks[k] = c;
+        wmax = c > wmax ? c : wmax;
+        wsum += c;
     }
-    return slot;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t m = (uint32_t)__shfl_xor((int)wmax, o, 64);
+        wmax = m > wmax ? m : wmax;
+        wsum += (uint32_t)__shfl_xor((int)wsum, o, 64);
+    }
+    if ((tid & 63u) == 0) {
+        bal[red + (tid >> 6)] = wmax;
+        bal[red + 16 + (tid >> 6)] = wsum;
+    }
+    if (tid < 128) bal[tid] = 0;
+    __syncthreads();
+    uint32_t bmax = 0, bsum = 0;
+    for (uint32_t w = 0; w < (W >> 6); ++w) {
+        bmax = bal[red + w] > bmax ? bal[red + w] : bmax;
+        bsum += bal[red + 16 + w];
+    }
+    // worth it when the longest overlap is at least twice the block's mean and there is real work to balance
+    if (bmax >= 16u && (uint64_t)bmax * kBalItems * W > 2ull * bsum) {
+        uint32_t cls[kBalItems];
+#pragma unroll
+        for (int k = 0; k < kBalItems; ++k) {
+            uint32_t c = 0;  // quarter-octave class of the chunk count
+            if (chunks[k] > 1) {
+                const uint32_t lg = 31u - (uint32_t)__builtin_clz(chunks[k]);
+                c = lg * 4u + (lg >= 2 ? (chunks[k] >> (lg - 2)) & 3u : 0u);
+            }
+            cls[k] = c > 127u ? 127u : c;
+            atomicAdd(&bal[cls[k]], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {  // exclusive scan over the classes, longest class first
+            const uint32_t c0 = bal[127 - 2 * tid], c1 = bal[126 - 2 * tid];
+            uint32_t incl = c0 + c1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+                if ((int)tid >= o) incl += up;
+            }
+            const uint32_t excl = incl - (c0 + c1);
+            bal[127 - 2 * tid] = excl;
+            bal[126 - 2 * tid] = excl + c0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kBalItems; ++k) bal[128 + atomicAdd(&bal[cls[k]], 1u)] = (uint32_t)k * W + tid;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kBalItems; ++k) {
+            const uint32_t rank = (k & 1) ? (uint32_t)(k + 1) * W - 1u - tid : (uint32_t)k * W + tid;  // there and back
+            slots[k] = block_base + bal[128 + rank];
+        }
+    }
+    __syncthreads();  // bal is reused below and by the next iteration
 }
 
 // The scoring kernel.  LG: log2 of the 8-bit-symbol table dimension (3..6; ignored for 16-bit symbols).  BAL:
-// block-local length balancing (below).  Workgroup-uniform loop: iteration k of a workgroup handles the candidates
-// [block_base, block_base + blockDim.x).
+// block-local length balancing (balanced_slots).  Workgroup-uniform loop: an iteration of a workgroup handles the
+// candidates [block_base, block_base + blockDim.x) — kBalItems times as many with BAL.
 template <typename SymT, int G, int LG, bool BAL>
 __device__ __forceinline__ void score_kernel_body(const StoreView& st, const ScoreParams& prm, const double* __restrict__ lut_g,
                                                   const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
@@ -747,21 +760,27 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     // with a permutation, slot s scores candidate perm[s] (neighbouring lanes share reads) and writes its
     // record back to the candidate's own position: out[i] <-> in[i] always holds
-    for (uint64_t block_base = (uint64_t)blockIdx.x * blockDim.x; block_base < n; block_base += stride) {
-        uint64_t slot = block_base + tid;
-        if (BAL) slot = balanced_slot<SymT>(st, prm, in, n, perm, fmt, block_base, bal);
-        // score the candidate of the (possibly reassigned) slot
-        hc_result_rec res;
-        res.n_cls = 0;
-        uint64_t i = 0;
-        if (slot < n) {
-            i = perm ? (uint64_t)perm[slot] : slot;
-            const Cand rec = load_cand(in, i, fmt);
-            Sub sub0{}, sub1{};
-            const int ns = resolve<(int)sizeof(SymT)>(st, rec, sub0, sub1);
-            res = score_candidate<SymT, G, LG>(prm, sym, Kp, ns, sub0, sub1, i, out);
+    constexpr int kItems = BAL ? kBalItems : 1;  // candidates per lane and iteration
+    for (uint64_t block_base = (uint64_t)blockIdx.x * blockDim.x * kItems; block_base < n; block_base += stride * kItems) {
+        uint64_t slots[kBalItems];
+        slots[0] = block_base + tid;
+        if (BAL) balanced_slots<SymT>(st, prm, in, n, perm, fmt, block_base, bal, slots);
+#pragma unroll 1
+        for (int k = 0; k < kItems; ++k) {
+            const uint64_t slot = slots[k];
+            // score the candidate of the (possibly reassigned) slot
+            hc_result_rec res;
+            res.n_cls = 0;
+            uint64_t i = 0;
+            if (slot < n) {
+                i = perm ? (uint64_t)perm[slot] : slot;
+                const Cand rec = load_cand(in, i, fmt);
+                Sub sub0{}, sub1{};
+                const int ns = resolve<(int)sizeof(SymT)>(st, rec, sub0, sub1);
+                res = score_candidate<SymT, G, LG>(prm, sym, Kp, ns, sub0, sub1, i, out);
+            }
+            if (sink.rows) append_rows_block(sink, slot < n, res, i, bal);  // kernel-argument-uniform branch
         }
-        if (sink.rows) append_rows_block(sink, slot < n, res, i, bal);  // kernel-argument-uniform branch
     }
 }
 
@@ -1035,16 +1054,17 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
         }
         fetch_group = lane_fetch_group;
     }
-    const uint32_t wg_max = 512;
-    const size_t lds = st.lut_bytes + (128 + wg_max + 32) * sizeof(uint32_t);
+    auto lds_for = [&](uint32_t lanes) { return st.lut_bytes + (128 + (st.balance ? kBalItems : 1) * lanes + 32) * sizeof(uint32_t); };
     // Fill the chip: enough 256-thread blocks for 8 waves per SIMD, bounded by LDS.
     uint32_t blocks_per_cu = 8;
-    const uint32_t by_lds = (uint32_t)((160 * 1024) / lds);
+    const uint32_t by_lds = (uint32_t)((160 * 1024) / lds_for(256));
     if (by_lds < blocks_per_cu) blocks_per_cu = by_lds < 1 ? 1 : by_lds;
     // large table, few workgroups per CU: let 512 lanes share each table (measured, C4, 35 quality values, 64 KiB
     // table: 256 lanes 0.169 ms, 512 lanes 0.152 ms, 1 024 lanes 0.174 ms)
     const uint32_t wg = (!st.balance && st.symbytes == 1 && lg == 6 && blocks_per_cu <= 2) ? 512u : 256u;
-    uint64_t blocks = (n + wg - 1) / wg;
+    const size_t lds = lds_for(wg);
+    const uint64_t per_wg = (uint64_t)wg * (st.balance ? kBalItems : 1);  // candidates per workgroup iteration
+    uint64_t blocks = (n + per_wg - 1) / per_wg;
     const uint64_t grid_cap = (uint64_t)n_cu * blocks_per_cu * 4;  // grid-stride beyond this
     if (blocks > grid_cap) blocks = grid_cap;
     const ScoreLaunch a{st, prm, lut_g, in, n, out, perm, RowSink{rows, row_count, cap, base_index, lines_in, lines_out}, (uint32_t)blocks, wg, lds, stream};
