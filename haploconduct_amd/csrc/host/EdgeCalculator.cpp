@@ -654,17 +654,26 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     double t_collect = 0;
     uint64_t n_host_blocks = 0;
     double tm_wait = 0, tm_final = 0, tm_turn = 0, tm_consume = 0, tm_slot = 0, tm_copy = 0, tm_submit = 0;  // HC_STAGE_TIMING
-    // Where the text comes from: the page-locked buffer of the block, filled by pread on the pool (default), or,
-    // HC_TEXT_SOURCE=map, the file's mapping as it is — no copy and no newline count by the host: the runtime moves the
-    // pageable text, the blocks number their lines through a chain of counters on the device side (hc_linechain).  Measured
-    // equal at C3 (0.25 s both; the runtime's pageable copy reaches 25 GB/s beside the collectors' HIP calls, 40-50 GB/s
-    // alone: tools/experiments/register_cost.cpp), so the default stays the path whose speed is in this code's hands.
-    const bool from_map = getenv("HC_TEXT_SOURCE") && !strcmp(getenv("HC_TEXT_SOURCE"), "map");
+    // Where the text comes from and who numbers the lines (HC_TEXT_SOURCE):
+    //   pread-chain (default): pread on the pool into the block's page-locked buffer, which the host then never looks at —
+    //       the cut is found in the file's mapping, and the blocks number their lines through a chain of counters on the
+    //       device side (hc_linechain).  Counting the newlines of what it had just copied took the host as long as the copy:
+    //       C3 copy 0.16 -> 0.075 s, stage 0.26 -> 0.20 s.
+    //   pread: the same copy with the host's newline count and explicit line numbers (round-2 form, kept as a route).
+    //   map: no copy at all — the runtime moves the pageable mapping (hc_textblock_submit_from on the mapping): 0.25 s,
+    //       the runtime's pageable copy reaches 25 GB/s beside the collectors' HIP calls (40-50 alone:
+    //       tools/experiments/register_cost.cpp).
+    // HC_TEXT_BUFFER=wc makes the blocks' buffers write-combined (pread fills those 1.4x as fast in isolation,
+    // tools/experiments/pread_targets.cpp; no gain in the stage, where the producer then waits for the device).
+    const char* text_source = getenv("HC_TEXT_SOURCE");
+    const bool from_map = text_source && !strcmp(text_source, "map");
+    const bool pread_chain = !text_source || !strcmp(text_source, "pread-chain");
+    const bool chained = from_map || pread_chain;
     struct ChainGuard {
         hc_linechain* p = nullptr;
         ~ChainGuard() { hc_linechain_destroy(p); }
     } chain;
-    if (from_map) check(hc_linechain_create(m_ctx, parser.size() / std::max<size_t>(B / 2, 1) + 4, &chain.p), "hc_linechain_create");
+    if (chained) check(hc_linechain_create(m_ctx, parser.size() / std::max<size_t>(B / 2, 1) + 4, &chain.p), "hc_linechain_create");
     std::atomic<uint64_t> lines_consumed{0};  // from_map: what the collectors have seen (the device applies --max_ov exactly)
     // Several collectors: collector c takes the blocks k = c, c + C, ...; waiting for the device, putting the rows in
     // order and finalising them (exp() of the admitted ones, the lines of the non-edges) happens side by side for
@@ -716,7 +725,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                     if (mine.status) throw mine;
                     if (tr.needs_host) {  // the host's tokeniser + Overlap constructor own this block
                         n_host_blocks++;
-                        parser.parse_range(sl.begin, sl.end, from_map ? lines_consumed.load() : sl.first_line, host_batch, rejected, pc,
+                        parser.parse_range(sl.begin, sl.end, chained ? lines_consumed.load() : sl.first_line, host_batch, rejected, pc,
                                            /*print_malformed=*/true);
                         const size_t n = host_batch.size();
                         const hc_gather_row* rows = nullptr;
@@ -798,10 +807,10 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
             if (!from_map) {
                 char* dst = hc_textblock_buffer(tb);
                 if (!dst) throw FatalError{HC_ERR_NOMEM, "construct_edges: no page-locked buffer for a block of text"};
-                parser.copy_range(dst, pos, end, newlines);
+                parser.copy_range(dst, pos, end, newlines, /*count_newlines=*/!pread_chain);
             }
             if (end < size) {  // cut behind the last newline of the stretch
-                const char* buf = from_map ? parser.data() + pos : hc_textblock_buffer(tb);
+                const char* buf = chained ? parser.data() + pos : hc_textblock_buffer(tb);
                 size_t cut = end - pos;
                 while (cut > 0 && buf[cut - 1] != '\n') cut--;
                 if (cut == 0) {  // one line longer than a block: the host's (its parser has no such limit)
@@ -823,7 +832,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                 end = pos + cut;  // the bytes behind the cut are copied again with the next block
             }
             sl.end = end;
-            if (!from_map) {
+            if (!chained) {
                 sl.n_lines = newlines;  // of the whole stretch; corrected below when it was cut
                 if (end < std::min(size, pos + B)) {
                     const char* buf = hc_textblock_buffer(tb);
@@ -837,8 +846,9 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
             const double tc = now_s();
             stats.t_parse += tc - t0;
             tm_copy += tc - t0;
-            if (from_map) {
-                check(hc_textblock_submit_from(tb, parser.data() + pos, end - pos, chain.p, chain_k, prev_tb, 0), "hc_textblock_submit_from");
+            if (chained) {
+                check(hc_textblock_submit_from(tb, from_map ? parser.data() + pos : hc_textblock_buffer(tb), end - pos, chain.p, chain_k, prev_tb, 0),
+                      "hc_textblock_submit_from");
                 prev_tb = tb;
                 chain_k++;
             } else {

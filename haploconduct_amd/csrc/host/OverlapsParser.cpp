@@ -226,7 +226,7 @@ size_t OverlapsParser::line_end_at(size_t at) const {
     return nl ? (size_t)(nl - m_data) + 1 : m_size;
 }
 
-void OverlapsParser::copy_range(char* dst, size_t begin, size_t end, uint64_t& newlines) const {
+void OverlapsParser::copy_range(char* dst, size_t begin, size_t end, uint64_t& newlines, bool count_newlines) const {
     std::lock_guard<std::mutex> pool_guard(m_pool_mu);
     const size_t bytes = end - begin;
     unsigned int T = m_threads;
@@ -244,7 +244,7 @@ void OverlapsParser::copy_range(char* dst, size_t begin, size_t end, uint64_t& n
             }
             at += (size_t)k;
         }
-        nl[t] = (uint64_t)std::count(dst + (a - begin), dst + (b - begin), '\n');
+        if (count_newlines) nl[t] = (uint64_t)std::count(dst + (a - begin), dst + (b - begin), '\n');
     };
     if (T == 1 || !m_pool) {
         for (unsigned int t = 0; t < T; t++) body(t);

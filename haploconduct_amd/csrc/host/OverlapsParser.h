@@ -147,7 +147,7 @@ public:
     // that holds byte `at` (offset behind its newline, or the size of the file), and the id table.
     size_t size() const { return m_size; }
     const char* data() const { return m_data; }  // the file's mapping (PROT_READ, MAP_PRIVATE)
-    void copy_range(char* dst, size_t begin, size_t end, uint64_t& newlines) const;
+    void copy_range(char* dst, size_t begin, size_t end, uint64_t& newlines, bool count_newlines = true) const;  // false: dst is never read
     size_t line_end_at(size_t at) const;
     const IdIndex& ids() const { return m_ids; }
 

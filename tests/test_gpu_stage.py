@@ -57,11 +57,12 @@ def run_both(oracle, tmp_path, reads, lines, st, tag):
     # The other routes to the same graph: above, the device read the file's text itself and resolved the duplicates;
     # the host threads' resolution, the per-edge serial insert, three contexts taking the blocks in turn, the host's
     # tokeniser instead of the device's (HC_PARSE=host), tiny text blocks, the text read in place from the file's mapping
-    # with device-side line numbering (HC_TEXT_SOURCE=map), and the fused construct + sortEdges call
+    # (HC_TEXT_SOURCE=map), the host counting the lines itself (HC_TEXT_SOURCE=pread), write-combined text buffers, and the fused construct + sortEdges call
     # (against construct_edges followed by sortEdges) must all agree with it.
     for env, sorted_call in (({"HC_RESOLVE": "host"}, False), ({"HC_INSERT_MODE": "serial"}, False), ({"HC_DEVICE_LIST": "0,0,0"}, False),
                              ({"HC_PARSE": "host"}, False), ({"HC_PARSE": "host", "HC_DEVICE_LIST": "0,0,0"}, False),
-                             ({"HC_TEXT_BLOCK": "4096"}, False), ({"HC_TEXT_SOURCE": "map"}, False),
+                             ({"HC_TEXT_BLOCK": "4096"}, False), ({"HC_TEXT_SOURCE": "map"}, False), ({"HC_TEXT_SOURCE": "pread"}, False), ({"HC_TEXT_BUFFER": "wc"}, False),
+                             ({"HC_TEXT_SOURCE": "pread", "HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False),
                              ({"HC_TEXT_SOURCE": "map", "HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False),
                              ({"HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False), ({}, True), ({"HC_RESOLVE": "host"}, True)):
         os.environ.update(env)
