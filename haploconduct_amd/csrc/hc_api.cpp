@@ -172,6 +172,10 @@ int hc_destroy(hc_ctx* c) {
     if (c->d_compact_res) (void)hipFree(c->d_compact_res);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int t = 0; t < 2; t++) {
+        if (c->graph.h_stage[t]) (void)hipHostFree(c->graph.h_stage[t]);
+        if (c->graph.stage_free[t]) (void)hipEventDestroy(c->graph.stage_free[t]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return HC_OK;

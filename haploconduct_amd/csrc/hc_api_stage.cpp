@@ -142,6 +142,7 @@ int hc_graph_append(hc_ctx* c, const hc_admit_rec* admitted, uint64_t n) {
         size_t cap = g.adm.cap ? g.adm.cap : ((size_t)1 << 24);
         while (cap < want * sizeof(hc_admit_rec)) cap *= 2;
         void* bigger = nullptr;
+        HC_HIP(hipStreamSynchronize(c->stream));  // appends in flight land in the old buffer first
         HC_HIP(hipMalloc(&bigger, cap));
         if (have) {
             const hipError_t e = hipMemcpy(bigger, g.adm.p, have * sizeof(hc_admit_rec), hipMemcpyDeviceToDevice);
@@ -154,8 +155,25 @@ int hc_graph_append(hc_ctx* c, const hc_admit_rec* admitted, uint64_t n) {
         g.adm.p = bigger;
         g.adm.cap = cap;
     }
-    // its own copy call, not the context's stream: the scoring of other blocks is in flight on theirs
-    HC_HIP(hipMemcpy((char*)g.adm.p + have * sizeof(hc_admit_rec), admitted, n * sizeof(hc_admit_rec), hipMemcpyHostToDevice));
+    // through a page-locked buffer, asynchronously on the context's stream (the blocks score on their own streams;
+    // hc_graph_resolve runs on this one, behind the copies): the caller — the stage's in-order half — does not wait
+    const int t = g.stage_turn;
+    g.stage_turn ^= 1;
+    const size_t bytes = n * sizeof(hc_admit_rec);
+    if (!g.stage_free[t]) HC_HIP(hipEventCreateWithFlags(&g.stage_free[t], hipEventDisableTiming));
+    else HC_HIP(hipEventSynchronize(g.stage_free[t]));  // its previous copy (two appends ago) has left the buffer
+    if (g.stage_cap[t] < bytes) {
+        if (g.h_stage[t]) (void)hipHostFree(g.h_stage[t]);
+        g.h_stage[t] = nullptr;
+        g.stage_cap[t] = 0;
+        size_t cap = (size_t)1 << 20;
+        while (cap < bytes) cap *= 2;
+        HC_HIP(hipHostMalloc(&g.h_stage[t], cap, hipHostMallocDefault));
+        g.stage_cap[t] = cap;
+    }
+    memcpy(g.h_stage[t], admitted, bytes);
+    HC_HIP(hipMemcpyAsync((char*)g.adm.p + have * sizeof(hc_admit_rec), g.h_stage[t], bytes, hipMemcpyHostToDevice, c->stream));
+    HC_HIP(hipEventRecord(g.stage_free[t], c->stream));
     g.n_appended = want;
     return HC_OK;
 }

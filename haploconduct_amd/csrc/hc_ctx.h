@@ -139,6 +139,11 @@ struct hc_ctx {
         uint64_t n_vertices = 0, n_edges = 0, n_tied = 0;
         uint64_t n_appended = 0;  // records hc_graph_append has put into adm
         bool valid = false;
+        // hc_graph_append copies through two page-locked buffers on the context's stream and does not wait for the copy
+        void* h_stage[2] = {nullptr, nullptr};
+        size_t stage_cap[2] = {0, 0};
+        hipEvent_t stage_free[2] = {nullptr, nullptr};
+        int stage_turn = 0;
     } graph;
 };
 
