@@ -42,6 +42,10 @@ private:
     void read_singles(const std::string& path, unsigned long max_reads);
     void read_pairs(const std::string& p1, const std::string& p2, unsigned long max_reads);
     void push_sequence(const char* s, size_t ns, const char* q, size_t nq, bool upper);
+    // the same records from read-only mappings of the files, on several threads (regular files of some size); false: not
+    // applicable, nothing was touched, the sequential readers take over
+    bool read_mapped(const std::string& p1, const std::string* p2, unsigned long max_reads, unsigned threads);
+    unsigned m_threads = 1;
     read_id_t resolve_id(const std::string& token) const;
     read_id_t resolve_id(const char* token, size_t n) const;
 

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <functional>
 #include <thread>
 
 #include "../../../include/hcedge.h"
@@ -220,7 +221,215 @@ void FastqStorage::push_sequence(const char* s, size_t ns, const char* q, size_t
     m_seq_off.push_back(o + ns);
 }
 
+// ---- the files on several threads ------------------------------------------------------------------------------------
+// A read-only mapping of one FASTQ file and the start of every record the sequential reader (LineFile::next4) would
+// return: lines as std::getline yields them, at most max_lines of them, four per record, an incomplete last record ignored.
+namespace {
+struct MappedFastq {
+    int fd = -1;
+    const char* p = nullptr;
+    size_t size = 0;
+    std::vector<size_t> rec;  // rec[r] = offset of record r's header line; rec[n] = where the line after the last record starts (or size)
+    size_t n = 0;
+    ~MappedFastq() {
+        if (p) munmap((void*)p, size);
+        if (fd >= 0) close(fd);
+    }
+    // false: not a regular file (the caller falls back to LineFile, which also reads pipes)
+    bool open_and_index(const std::string& path, uint64_t max_lines, unsigned T, bool& exists) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        exists = fd >= 0;
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+        size = (size_t)st.st_size;
+        if (size == 0) {
+            rec.assign(1, 0);
+            return true;
+        }
+        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = (const char*)m;
+        T = std::max(1u, std::min<unsigned>(T, (unsigned)(size >> (getenv("HC_FASTQ_GRAIN") ? 4 : 20)) + 1));
+        std::vector<uint64_t> nl(T + 1, 0);
+        auto chunk = [&](unsigned t, size_t& a, size_t& b) {
+            a = size * t / T;
+            b = size * (t + 1) / T;
+        };
+        auto run = [&](const std::function<void(unsigned)>& f) {
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; t++) th.emplace_back(f, t);
+            f(0);
+            for (auto& x : th) x.join();
+        };
+        run([&](unsigned t) {
+            size_t a, b;
+            chunk(t, a, b);
+            nl[t + 1] = (uint64_t)std::count(p + a, p + b, '\n');
+        });
+        for (unsigned t = 0; t < T; t++) nl[t + 1] += nl[t];  // nl[t] = newlines in front of chunk t = index of the line its first byte is in
+        const uint64_t total_lines = nl[T] + (p[size - 1] != '\n' ? 1u : 0u);
+        const uint64_t used = std::min<uint64_t>(total_lines, max_lines);
+        n = (size_t)(used / 4);
+        rec.assign(n + 1, size);
+        rec[0] = 0;
+        run([&](unsigned t) {
+            size_t a, b;
+            chunk(t, a, b);
+            uint64_t line = nl[t];  // of the byte at a
+            const char* q = p + a;
+            const char* const e = p + b;
+            while ((q = (const char*)memchr(q, '\n', (size_t)(e - q))) != nullptr) {
+                line++;  // the line that starts behind this newline
+                q++;
+                if ((line & 3u) == 0 && line / 4 <= n) rec[(size_t)(line / 4)] = (size_t)(q - p);
+            }
+        });
+        return true;
+    }
+    // the four lines of record r
+    void lines(size_t r, const char* l[4], size_t len[4]) const {
+        const char* q = p + rec[r];
+        const char* const e = p + size;
+        for (int k = 0; k < 4; k++) {
+            const char* nlp = q < e ? (const char*)memchr(q, '\n', (size_t)(e - q)) : nullptr;
+            l[k] = q;
+            len[k] = nlp ? (size_t)(nlp - q) : (size_t)(e - q);
+            q = nlp ? nlp + 1 : e;
+        }
+    }
+};
+}  // namespace
+
+bool FastqStorage::read_mapped(const std::string& path1, const std::string* path2, unsigned long max_reads, unsigned threads) {
+    const bool paired = path2 != nullptr;
+    const uint64_t max_lines = 4ull * (unsigned int)max_reads;
+    MappedFastq f1, f2;
+    bool e1 = false, e2 = false;
+    if (!f1.open_and_index(path1, max_lines, threads, e1)) {
+        if (!e1) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + path1};
+        return false;
+    }
+    if (paired && !f2.open_and_index(*path2, max_lines, threads, e2)) {
+        if (!e2) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + *path2};
+        return false;
+    }
+    const double tm0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    auto tlap = [&](const char* what) {
+        if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] fastq %s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tm0);
+    };
+    const size_t n = paired ? std::min(f1.n, f2.n) : f1.n;  // records up to the shorter file, :170
+    // small input: the sequential reader is as fast (HC_FASTQ_PARALLEL_MIN / HC_FASTQ_GRAIN: test knobs — bytes from which
+    // this path is taken, records per thread at least)
+    size_t min_bytes = (size_t)4 << 20, grain = 4096;
+    if (const char* e = getenv("HC_FASTQ_PARALLEL_MIN")) min_bytes = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("HC_FASTQ_GRAIN")) grain = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 10));
+    if (f1.size + f2.size < min_bytes) return false;
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / grain + 1));
+    const size_t per = paired ? 2 : 1;
+    // pass A: every check of the sequential reader in its order, the ids, the lengths
+    std::vector<read_id_t> ids(n);
+    std::vector<uint32_t> len(n * per);
+    struct Err {
+        size_t at = (size_t)-1;
+        FatalError e{0, ""};
+    };
+    std::vector<Err> err(T);
+    std::vector<uint64_t> bytes(T + 1, 0);
+    auto run = [&](const std::function<void(unsigned)>& f) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++) th.emplace_back(f, t);
+        f(0);
+        for (auto& x : th) x.join();
+    };
+    run([&](unsigned t) {
+        uint64_t sum = 0;
+        for (size_t r = n * t / T; r < n * (t + 1) / T; r++) {
+            try {
+                const char *l1[4], *l2[4];
+                size_t n1[4], n2[4] = {0, 0, 0, 0};
+                f1.lines(r, l1, n1);
+                if (paired) f2.lines(r, l2, n2);
+                if (n1[0] == 0 || l1[0][0] != '@')
+                    throw FatalError{HC_ERR_FORMAT, paired ? "Read ID does not start with @. Exiting read_pairs." : "Read ID does not start with @. Exiting read_singles."};
+                const char *t1, *t2;
+                size_t tn1, tn2;
+                first_token(l1[0], n1[0], t1, tn1);
+                if (paired) {
+                    first_token(l2[0], n2[0], t2, tn2);
+                    if (tn1 != tn2 || memcmp(t1, t2, tn1) != 0) throw FatalError{HC_ERR_FORMAT, "Fastq files /1 /2 are not ordered identically. Exiting read_pairs."};
+                }
+                const read_id_t id = resolve_id(t1, tn1);
+                ids[r] = id;
+                if (paired) {
+                    if (n1[1] == 0 || n2[1] == 0)
+                        throw FatalError{HC_ERR_BAD_READ, "paired read with ID " + std::to_string(id) + " has an empty sequence... exiting."};
+                } else if (n1[1] == 0) {
+                    throw FatalError{HC_ERR_BAD_READ, "single read with ID " + std::to_string(id) + " has an empty sequence... exiting."};
+                }
+                if (n1[1] != n1[3] || (paired && n2[1] != n2[3]))
+                    throw FatalError{HC_ERR_BAD_READ, "FASTQ record with sequence and quality strings of different length"};
+                len[r * per] = (uint32_t)n1[1];
+                sum += n1[1];
+                if (paired) {
+                    len[r * per + 1] = (uint32_t)n2[1];
+                    sum += n2[1];
+                }
+            } catch (const FatalError& e) {
+                err[t].at = r;
+                err[t].e = e;
+                break;
+            }
+        }
+        bytes[t + 1] = sum;
+    });
+    for (unsigned t = 0; t < T; t++)
+        if (err[t].at != (size_t)-1) throw err[t].e;  // the first bad record in file order: threads own ascending ranges
+    for (unsigned t = 0; t < T; t++) bytes[t + 1] += bytes[t];
+    tlap("pass A done");
+    // pass B: the bytes, each thread behind its predecessors'
+    const size_t base_bytes = m_bases.size(), base_seq = m_seq_off.size() - 1;
+    m_bases.resize(base_bytes + bytes[T]);
+    m_quals.resize(base_bytes + bytes[T]);
+    m_seq_off.resize(base_seq + 1 + n * per);
+    tlap("arrays sized");
+    static const std::array<uint8_t, 256> up = [] {
+        std::array<uint8_t, 256> t{};
+        for (int c = 0; c < 256; c++) t[(size_t)c] = (uint8_t)toupper(c);
+        return t;
+    }();
+    run([&](unsigned t) {
+        uint64_t o = base_bytes + bytes[t];
+        for (size_t r = n * t / T; r < n * (t + 1) / T; r++) {
+            const char* l[4];
+            size_t ln[4];
+            for (size_t m = 0; m < per; m++) {
+                (m ? f2 : f1).lines(r, l, ln);
+                const size_t k = ln[1];
+                if (!paired) {  // boost::to_upper_copy, :122 — pairs are NOT upper-cased, :197-198
+                    for (size_t i = 0; i < k; i++) m_bases[o + i] = up[(uint8_t)l[1][i]];
+                } else {
+                    memcpy(&m_bases[o], l[1], k);
+                }
+                memcpy(&m_quals[o], l[3], k);
+                o += k;
+                m_seq_off[base_seq + 1 + r * per + m] = o;
+            }
+        }
+    });
+    tlap("pass B done");
+    std::vector<Read>& vec = paired ? m_paired_vec : m_singles_vec;
+    vec.reserve(vec.size() + n);
+    m_first.reserve(m_first.size() + n);
+    for (size_t r = 0; r < n; r++) {
+        m_first.push_back(m_first.back() + (uint32_t)per);
+        vec.emplace_back(this, 0u, paired, ids[r]);
+    }
+    return true;
+}
+
 void FastqStorage::read_singles(const std::string& path, unsigned long max_reads) {  // src/FastqStorage.cpp:92-152
+    if (m_threads > 1 && read_mapped(path, nullptr, max_reads, m_threads)) return;
     LineFile f(path, 4ull * (unsigned int)max_reads);
     if (!f.is_open()) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + path};
     m_bases.reserve(m_bases.size() + f.bytes() / 2);
@@ -241,6 +450,7 @@ void FastqStorage::read_singles(const std::string& path, unsigned long max_reads
 }
 
 void FastqStorage::read_pairs(const std::string& p1, const std::string& p2, unsigned long max_reads) {  // :154-235
+    if (m_threads > 1 && read_mapped(p1, &p2, max_reads, m_threads)) return;
     LineFile f1(p1, 4ull * (unsigned int)max_reads);
     if (!f1.is_open()) throw FatalError{HC_ERR_IO, "Unable to open fastq file " + p1};
     LineFile f2(p2, 4ull * (unsigned int)max_reads);
@@ -267,11 +477,25 @@ void FastqStorage::read_pairs(const std::string& p1, const std::string& p2, unsi
 }
 
 FastqStorage::FastqStorage(const ProgramSettings& ps) {  // src/FastqStorage.h:58-98
+    const bool timing = getenv("HC_STAGE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    m_threads = std::max(1u, std::min(16u, (unsigned)ps.n_threads));
+    if (const char* e = getenv("HC_FASTQ_THREADS")) m_threads = (unsigned)std::max(1, atoi(e));
     if (!ps.id_correspondence.empty()) read_new_ids(ps.id_correspondence);
     if (!ps.singles_file.empty() && ps.singles_file != "None") read_singles(ps.singles_file, ps.max_reads);
     m_readcount_single = (unsigned int)m_singles_vec.size();
     if (!ps.paired1_file.empty() && ps.paired1_file != "None") read_pairs(ps.paired1_file, ps.paired2_file, ps.max_reads);
     m_readcount_paired = (unsigned int)m_paired_vec.size();
+    const double t1 = now();
+    struct Lap {
+        bool on;
+        double t1, t0;
+        std::function<double()> now;
+        ~Lap() {
+            if (on) fprintf(stderr, "[hc stage] FastqStorage: files %.3f s, read vector + id index %.3f s\n", t1 - t0, now() - t1);
+        }
+    } lap{timing, t1, t0, now};
     if (ps.verbose) {
         printf("Singles: %u\n", m_readcount_single);
         printf("Pairs: %u\n", m_readcount_paired);

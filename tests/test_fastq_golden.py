@@ -13,8 +13,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "fastq_pairs.json")))["cases"]
 
 
+@pytest.mark.parametrize("parallel", [False, True], ids=["sequential", "threads"])
 @pytest.mark.parametrize("case", GOLD, ids=[c["name"] for c in GOLD])
-def test_paired_fastq_reader_matches_reference_vectors(case, tmp_path):
+def test_paired_fastq_reader_matches_reference_vectors(case, parallel, tmp_path, monkeypatch):
+    if parallel:  # the mapped, multi-threaded reader on the same tiny inputs: three threads, one record each at least
+        monkeypatch.setenv("HC_FASTQ_THREADS", "3")
+        monkeypatch.setenv("HC_FASTQ_PARALLEL_MIN", "0")
+        monkeypatch.setenv("HC_FASTQ_GRAIN", "1")
+    else:
+        monkeypatch.setenv("HC_FASTQ_THREADS", "1")
     p1, p2, ids = str(tmp_path / "p1.fastq"), str(tmp_path / "p2.fastq"), str(tmp_path / "ids.txt")
     open(p1, "w", newline="").write(case["p1"])
     if case.get("p2") is not None:

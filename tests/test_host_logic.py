@@ -395,3 +395,46 @@ def test_add_equivalent_edges_matches_oracle(oracle):
     a, b = _csr_of(g, 2 * R), _csr_of(g2, 2 * R)
     for x, y in zip(a[1:], b[1:]):
         assert np.array_equal(x, y)
+
+
+def test_threaded_fastq_reader_equals_the_sequential_one(tmp_path, monkeypatch):
+    """Random single- and paired-end files (mixed case, CR-LF, lengths 1..300, header comments, a missing final newline, an
+    incomplete last record, --max_reads in the middle): the mapped reader on five threads must leave exactly the arrays
+    the sequential line reader leaves."""
+    rng = random.Random(17)
+
+    def rec(i, n, crlf):
+        eol = "\r\n" if crlf else "\n"
+        seq = "".join(rng.choice("ACGTNacgtn") for _ in range(n))
+        qual = "".join(chr(rng.randrange(33, 110)) for _ in range(n))
+        return f"@{i} c{rng.randrange(9)}{eol}{seq}{eol}+{eol}{qual}{eol}"
+
+    for trial in range(6):
+        crlf = trial == 2
+        n_s, n_p = rng.randrange(50, 400), rng.randrange(50, 400)
+        s = "".join(rec(i, rng.randrange(1, 300), crlf) for i in range(n_s))
+        p1 = "".join(rec(1000 + i, rng.randrange(1, 300), crlf) for i in range(n_p))
+        p2 = "".join(rec(1000 + i, rng.randrange(1, 300), crlf) for i in range(n_p))
+        if trial == 3:
+            s, p1 = s[:-1], p1[:-1]  # no final newline
+        if trial == 4:
+            s += "@77\nACGT\n+\n"  # incomplete record
+            p2 += "@5000\nAC\n"
+        paths = [str(tmp_path / f"{k}{trial}.fastq") for k in ("s", "p1", "p2")]
+        for path, text in zip(paths, (s, p1, p2)):
+            open(path, "w", newline="").write(text)
+        for max_reads in (0, 73):
+            got = []
+            for threads, grain in (("1", None), ("5", "1")):
+                monkeypatch.setenv("HC_FASTQ_THREADS", threads)
+                monkeypatch.setenv("HC_FASTQ_PARALLEL_MIN", "0")
+                if grain:
+                    monkeypatch.setenv("HC_FASTQ_GRAIN", grain)
+                else:
+                    monkeypatch.delenv("HC_FASTQ_GRAIN", raising=False)
+                f = host.Fastq(singles=paths[0], paired1=paths[1], paired2=paths[2], max_reads=max_reads)
+                got.append((f.n_single, f.n_paired, f.bases.tobytes(), f.quals.tobytes(), f.seq_off.tobytes(), f.read_first_seq.tobytes(),
+                            f.read_ids.tobytes()))
+                f.close()
+            assert got[0] == got[1], (trial, max_reads)
+            assert got[0][0] > 0 and got[0][1] > 0
