@@ -40,15 +40,22 @@ for _ in range(20000):
 good = b"7\t9\t12\t30\t1\t+\t-\t80\t70\t120\t105\tp\tp"
 assert host.hc_host_parse_overlap(good, len(good), 0, out, text) == 0
 
-# 2. FASTQ reader on hostile files, then parser + prefilter with many threads
+# 2. FASTQ reader on hostile files (both the sequential line reader and the mapped multi-threaded one), then parser + prefilter with many threads
 def w(name, data):
     open(d + name, "wb").write(data); return (d + name).encode()
 fq = b"".join(b"@%d\nACGTNACGTN%s\n+\nIIIIIIIIII%s\n" % (i, b"ACGT" * (i % 7), b"5555" * (i % 7)) for i in range(300))
 s = w("s.fastq", fq)
-for bad in (b"", b"@1\n", b"@1\nACGT\n+\nII\n", b"x\nACGT\n+\nIIII\n", b"@1\n\n+\n\n", b"@1\nACGT\n+\nIIII", b"\n\n\n\n"):
-    h = C.c_void_p(); v = V(); p = P(w("bad.fastq", bad), None, None, None, None, None, 0)
-    rc = host.hc_host_fastq_load(C.byref(h), C.byref(p), C.byref(v))
-    if rc == 0: host.hc_host_fastq_free(h)
+for mode in (0, 1):
+    if mode:  # the mapped reader on tiny inputs: three threads, one record each at least
+        os.environ.update(HC_FASTQ_THREADS="3", HC_FASTQ_PARALLEL_MIN="0", HC_FASTQ_GRAIN="1")
+    for bad in (b"", b"@1\n", b"@1\nACGT\n+\nII\n", b"x\nACGT\n+\nIIII\n", b"@1\n\n+\n\n", b"@1\nACGT\n+\nIIII", b"\n\n\n\n",
+                b"@1\nAC\n+\nII\n@2\nACG\n+\nIII\n@3\nA\n+\nI\n@4\nAC\n+\nI", b"@1\r\nAC\r\n+\r\nII\r\n" * 7):
+        h = C.c_void_p(); v = V(); p = P(w("bad.fastq", bad), None, None, None, None, None, 0)
+        rc = host.hc_host_fastq_load(C.byref(h), C.byref(p), C.byref(v))
+        if rc == 0: host.hc_host_fastq_free(h)
+        h = C.c_void_p(); v = V(); p = P(None, w("bad1.fastq", bad), w("bad2.fastq", bad[: len(bad) // 2 * 2]), None, None, None, 0)
+        rc = host.hc_host_fastq_load(C.byref(h), C.byref(p), C.byref(v))
+        if rc == 0: host.hc_host_fastq_free(h)
 h = C.c_void_p(); v = V(); p = P(s, None, None, None, None, None, 0)
 assert host.hc_host_fastq_load(C.byref(h), C.byref(p), C.byref(v)) == 0 and v.n_reads == 300
 lines = []
