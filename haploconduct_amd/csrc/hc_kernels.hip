@@ -514,14 +514,16 @@ __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return 
 __device__ __forceinline__ hc_result_rec classify_and_store(const ScoreParams& prm, int ns, const SubScore& s1, const SubScore& s2,
                                                             uint64_t i, hc_result_rec* __restrict__ out) {
     hc_result_rec res;
-    // mismatch_rate = float(mismatch_count)/total_len (:132); std::max over the two (:254)
-    const double m1 = (double)(float)s1.mm / (double)s1.n;
+    // mismatch_rate = float(mismatch_count)/total_len (:132); std::max over the two (:254): the sub-overlap with the larger
+    // rate supplies (mm, n).  Which one that is needs no division: for mm < 2^24 (exact as a float) and n < 2^26 two
+    // different fractions mm/n <= 1 lie more than 2^-52 apart — two ulps at least — so their correctly rounded quotients
+    // compare as the fractions do, i.e. as the cross products; equal fractions give equal quotients.
     uint32_t mm = s1.mm, nn = s1.n;
-    double mrate = m1;
     if (ns == 2) {
-        const double m2 = (double)(float)s2.mm / (double)s2.n;
-        if (m1 < m2) {
-            mrate = m2;
+        bool second;
+        if ((s1.mm | s2.mm) < (1u << 24) && (s1.n | s2.n) < (1u << 26)) second = (uint64_t)s1.mm * s2.n < (uint64_t)s2.mm * s1.n;
+        else second = (double)(float)s1.mm / (double)s1.n < (double)(float)s2.mm / (double)s2.n;
+        if (second) {
             mm = s2.mm;
             nn = s2.n;
         }
@@ -539,7 +541,8 @@ __device__ __forceinline__ hc_result_rec classify_and_store(const ScoreParams& p
     if (s1.err | s2.err) cls = HC_CLS_ERROR;
     else if (e == 1) cls = HC_CLS_EDGE;
     else if (e == 2) cls = HC_CLS_AMBIG;
-    else if (mrate <= prm.merge_contigs) cls = HC_CLS_EDGE_MC;
+    // mismatch_rate <= --merge_contigs; against the default 0 that is "no mismatch" (the rate is never negative)
+    else if (prm.merge_contigs == 0.0 ? mm == 0u : (double)(float)mm / (double)nn <= prm.merge_contigs) cls = HC_CLS_EDGE_MC;
     else if (o == 1) cls = HC_CLS_NONEDGE;
     else if (o == 2) cls = HC_CLS_AMBIG;
     else cls = HC_CLS_DROP;
