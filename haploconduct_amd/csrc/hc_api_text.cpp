@@ -26,6 +26,7 @@ struct hc_textblock {
     char* h_text = nullptr;                    // page-locked, allocated on first use (hc_textblock_buffer): the caller reads the file into it
     char* d_text = nullptr;                    // max_bytes + 64
     uint32_t *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_line_start = nullptr;
+    uint32_t* d_tally = nullptr;               // the parse kernel's per-workgroup tallies
     hc_cand_rec* d_cands = nullptr;            // max_lines
     hc_line_rec* d_lines = nullptr;            // max_lines
     hc_result_rec* d_out = nullptr;            // max_lines
@@ -116,6 +117,7 @@ int hc_textblock_create(hc_ctx* c, uint64_t max_bytes, hc_textblock** out) {
     ok(hipMalloc((void**)&b->d_text, max_bytes + 64));
     ok(hipMalloc((void**)&b->d_tile_cnt, (size_t)(n_tiles + 1) * 4));
     ok(hipMalloc((void**)&b->d_tile_off, (size_t)(n_tiles + 1) * 4));
+    ok(hipMalloc((void**)&b->d_tally, ((size_t)b->max_lines / 256 + 2) * 8 * 4));
     ok(hipMalloc((void**)&b->d_line_start, (L + 2) * 4));
     ok(hipMalloc((void**)&b->d_cands, (L + 256) * sizeof(hc_cand_rec)));
     ok(hipMalloc((void**)&b->d_lines, L * sizeof(hc_line_rec)));
@@ -183,7 +185,7 @@ int hc_textblock_destroy(hc_textblock* b) {
     if (!b) return HC_OK;
     (void)hipSetDevice(b->ctx->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    for (void* p : {(void*)b->d_text, (void*)b->d_tile_cnt, (void*)b->d_tile_off, (void*)b->d_line_start, (void*)b->d_cands, (void*)b->d_lines,
+    for (void* p : {(void*)b->d_tally, (void*)b->d_text, (void*)b->d_tile_cnt, (void*)b->d_tile_off, (void*)b->d_line_start, (void*)b->d_cands, (void*)b->d_lines,
                     (void*)b->d_out, (void*)b->d_counters, (void*)b->d_rows, (void*)b->d_row_lines, (void*)b->d_kept_tiles})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)b->h_text, (void*)b->h_rows, (void*)b->h_row_lines, (void*)b->h_rejects, (void*)b->h_counters})
@@ -256,7 +258,7 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
         HC_HIP(hipHostGetDevicePointer(&d_rejects, b->h_rejects, 0));
         HC_HIP(hipHostGetDevicePointer(&d_rows, b->h_rows, 0));
         HC_HIP(hipHostGetDevicePointer(&d_row_lines, b->h_row_lines, 0));
-        HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, s));
+        HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, b->d_tally, s));
         // the scoring kernel on the records the parse kernel left behind; how many there are is only known on the device
         int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_cands, b->max_lines, b->d_out, s, false, nullptr, nullptr, 0, 0,
                               b->d_counters + hc::kTextLines);

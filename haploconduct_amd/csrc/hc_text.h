@@ -47,6 +47,7 @@ hipError_t launch_text_lines(const char* text, uint64_t n_bytes, uint32_t* tile_
 hipError_t launch_text_chain(const unsigned long long* lines_before, const unsigned long long* counters, unsigned long long* lines_before_next,
                              hipStream_t s);
 hipError_t launch_text_parse(const TextParams& prm, const char* text, const uint32_t* line_start, const IdTable& ids, hc_cand_rec* cands,
-                             hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, hipStream_t s);
+                             hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, uint32_t* tally /* [(max_lines + 255) / 256][8] */,
+                             hipStream_t s);
 
 }  // namespace hc

@@ -139,42 +139,70 @@ __device__ __forceinline__ bool id_lookup(const IdTable& t, uint64_t id, uint32_
     }
 }
 
+// The characters of a line through a 4-byte window: one aligned word read per four characters instead of one dependent
+// byte read each (the line sits in LDS or in the block's text: either way a read is ~100 cycles of latency in the lane's
+// serial walk; text_parse_kernel is bound by exactly that walk).  Reads stay inside [line & ~3, (end + 3) & ~3): the
+// staged text and the block's text both have room on either side.
+typedef const __attribute__((address_space(3))) char* lds_text;      // the workgroup's stretch of text staged in LDS
+typedef const __attribute__((address_space(3))) uint32_t* lds_words;
+template <bool LDS>
 struct Cursor {
-    const char* p;
-    const char* e;
+    uint32_t at, e;     // byte offsets from `base`
+    uint32_t w;         // the aligned word `at` points into
+    const char* base;   // global text (LDS: unused, offsets are LDS addresses)
+    __device__ __forceinline__ uint32_t word(uint32_t off) const {
+        if (LDS) return *(lds_words)(uintptr_t)off;
+        return *(const uint32_t*)(base + off);
+    }
+    __device__ __forceinline__ void load() { w = word(at & ~3u); }
+    __device__ __forceinline__ uint32_t cur() const { return (w >> (8u * (at & 3u))) & 0xFFu; }
+    __device__ __forceinline__ void next() {
+        at++;
+        if ((at & 3u) == 0) w = word(at);
+    }
 };
 
 // digits (at most max_digits) followed by a tab; dash_ok: a lone "-" reads as 0 (atoi("-"))
-__device__ __forceinline__ bool take_number(Cursor& c, unsigned max_digits, bool dash_ok, uint64_t& v, bool& dash) {
+template <bool LDS>
+__device__ __forceinline__ bool take_number(Cursor<LDS>& c, unsigned max_digits, bool dash_ok, uint64_t& v, bool& dash) {
     dash = false;
     v = 0;
-    if (dash_ok && c.p < c.e && *c.p == '-') {
+    if (dash_ok && c.at < c.e && c.cur() == '-') {
         dash = true;
-        c.p++;
+        c.next();
     } else {
-        const char* b = c.p;
-        while (c.p < c.e && (unsigned)(*c.p - '0') <= 9u) v = v * 10 + (uint64_t)(*c.p++ - '0');
-        const unsigned d = (unsigned)(c.p - b);
+        const uint32_t b = c.at;
+        const uint32_t first = c.at < c.e ? c.cur() : 0u;
+        while (c.at < c.e && (c.cur() - '0') <= 9u) {
+            v = v * 10 + (uint64_t)(c.cur() - '0');
+            c.next();
+        }
+        const unsigned d = c.at - b;
         if (d == 0 || d > max_digits) return false;
-        if (!dash_ok && b[0] == '0' && d > 1) return false;  // strtoul(.., 0) reads a leading 0 as octal: not plain
+        if (!dash_ok && first == '0' && d > 1) return false;  // strtoul(.., 0) reads a leading 0 as octal: not plain
     }
-    if (c.p >= c.e || *c.p != '\t') return false;
-    c.p++;
+    if (c.at >= c.e || c.cur() != '\t') return false;
+    c.next();
     return true;
 }
 
-__device__ __forceinline__ bool take_char(Cursor& c, char& ch, bool last) {
-    if (c.p >= c.e) return false;
-    ch = *c.p++;
-    if (last) return c.p == c.e;
-    if (c.p >= c.e || *c.p != '\t') return false;
-    c.p++;
+template <bool LDS>
+__device__ __forceinline__ bool take_char(Cursor<LDS>& c, char& ch, bool last) {
+    if (c.at >= c.e) return false;
+    ch = (char)c.cur();
+    c.next();
+    if (last) return c.at == c.e;
+    if (c.at >= c.e || c.cur() != '\t') return false;
+    c.next();
     return true;
 }
 
 // Overlap::from_plain_line (host_model.cpp) on the device: the same acceptance rules, the same values.
-__device__ __forceinline__ bool parse_plain_line(const char* s, uint32_t n, hc_line_rec& o) {
-    Cursor c{s, s + n};
+// LDS: `begin` is the LDS byte address of the line; else its offset in `text`.
+template <bool LDS>
+__device__ __forceinline__ bool parse_plain_line(const char* text, uint32_t begin, uint32_t n, hc_line_rec& o) {
+    Cursor<LDS> c{begin, begin + n, 0u, text};
+    c.load();
     uint64_t id1, id2, pos1, pos2, perc1, perc2, len1, len2;
     bool dash, dash_pos2;
     char ord, ori1, ori2, type1, type2;
@@ -210,8 +238,10 @@ constexpr uint32_t kStageBytes = 32 * 1024;  // text of the 256 lines of a workg
 // counters: the enum of hc_text.h
 __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const char* __restrict__ text, const uint32_t* __restrict__ line_start,
                                                          IdTable ids, hc_cand_rec* __restrict__ cands, hc_line_rec* __restrict__ lines,
-                                                         hc_text_reject* __restrict__ rejects, unsigned long long* __restrict__ counters) {
+                                                         hc_text_reject* __restrict__ rejects, unsigned long long* __restrict__ counters,
+                                                         uint32_t* __restrict__ tally /* [workgroups][8] */) {
     __shared__ __attribute__((aligned(16))) char stage[kStageBytes + 32];  // + the 16-byte pieces at both ends
+    __shared__ uint32_t wave_tally[4][8];
     if (counters[kTextOverflow]) return;  // more lines than room: nothing is parsed here, the host takes the block
     const uint32_t n = (uint32_t)counters[kTextLines];
     const uint32_t first = blockIdx.x * 256u;
@@ -241,13 +271,14 @@ __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const c
         n_read = 1;
         const uint32_t b = line_start[i];
         uint32_t e = line_start[i + 1] - 1u;  // the newline (or the virtual one behind a last line without)
-        const char* src = staged ? stage + (b - (lo & ~15u)) : text + b;
+        // the line: in the staged copy (an LDS address) or in the block's text (an offset)
+        const uint32_t stage_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)stage + (b - (lo & ~15u));
         hc_cand_rec cd;
         cd.read1 = cd.read2 = 0;
         cd.pos1_bits = 0;
         cd.pos2_bits = HC_CAND_SKIP;
         hc_line_rec o;
-        if (!parse_plain_line(src, e - b, o)) {
+        if (!(staged ? parse_plain_line<true>(text, stage_at, e - b, o) : parse_plain_line<false>(text, b, e - b, o))) {
             n_nonplain = 1;
         } else {
             lines[i] = o;
@@ -303,13 +334,35 @@ __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const c
         cd.pos2_bits = HC_CAND_SKIP;
         cands[i] = cd;
     }
-    // tallies: one atomic per counter and wave
+    // tallies: summed over the workgroup and written to its own slot — no atomics (every wave adding to the same seven
+    // counters of one cache line serialised there: the kernel then took as long as those ~40 000 atomics, 160 us a block)
     const uint32_t vals[7] = {n_read, n_nonplain, n_self, n_silent, n_reject, n_pass, n_unknown};
 #pragma unroll
     for (int k = 0; k < 7; k++) {
-        const unsigned long long c = __popcll(__ballot(vals[k] != 0));
-        if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&counters[k], c);
+        const uint32_t c = (uint32_t)__popcll(__ballot(vals[k] != 0));
+        if ((threadIdx.x & 63u) == 0) wave_tally[threadIdx.x >> 6][k] = c;
     }
+    __syncthreads();
+    if (threadIdx.x < 7) tally[blockIdx.x * 8u + threadIdx.x] = wave_tally[0][threadIdx.x] + wave_tally[1][threadIdx.x] + wave_tally[2][threadIdx.x] + wave_tally[3][threadIdx.x];
+}
+
+// counters[0..6] += the workgroups' tallies (one workgroup; the parse kernel's workgroups that had lines)
+__global__ __launch_bounds__(256) void text_tally_kernel(const uint32_t* __restrict__ tally, unsigned long long* __restrict__ counters) {
+    if (counters[kTextOverflow]) return;
+    const uint32_t n_wg = (uint32_t)((counters[kTextLines] + 255u) / 256u);
+    __shared__ unsigned long long part[4][8];
+    unsigned long long sum[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t g = threadIdx.x; g < n_wg; g += 256u)
+#pragma unroll
+        for (int k = 0; k < 7; k++) sum[k] += tally[g * 8u + k];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum[k] += (unsigned long long)__shfl_xor((long long)sum[k], o, 64);
+        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6][k] = sum[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) counters[threadIdx.x] += part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -335,10 +388,11 @@ hipError_t launch_text_chain(const unsigned long long* lines_before, const unsig
 }
 
 hipError_t launch_text_parse(const TextParams& prm, const char* text, const uint32_t* line_start, const IdTable& ids, hc_cand_rec* cands,
-                             hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, hipStream_t s) {
+                             hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, uint32_t* tally, hipStream_t s) {
     if (prm.max_lines == 0) return hipSuccess;
     hipLaunchKernelGGL(text_parse_kernel, dim3((prm.max_lines + 255) / 256), dim3(256), 0, s, prm, text, line_start, ids, cands, lines, rejects,
-                       counters);
+                       counters, tally);
+    hipLaunchKernelGGL(text_tally_kernel, dim3(1), dim3(256), 0, s, tally, counters);
     return hipGetLastError();
 }
 
