@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <type_traits>
@@ -782,6 +783,67 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
         for (auto& t : collectors)
             if (t.joinable()) t.join();
     };
+    // The HIP calls of a block (a dozen launches, copies and events: 0.1 ms) are issued by a thread of their own, so that
+    // the caller's thread can go on copying the next block meanwhile; blocks are submitted and published strictly in order.
+    struct Pending {
+        size_t k = 0;
+        hc_textblock* tb = nullptr;  // nullptr: nothing to submit (the host's block), only publish
+        const char* src = nullptr;
+        size_t bytes = 0;
+        uint64_t line_no = 0;
+        size_t chain_k = 0;
+        hc_textblock* prev = nullptr;
+    };
+    std::deque<Pending> pending;
+    std::mutex smu;
+    std::condition_variable scv;
+    bool no_more = false;
+    std::thread submitter([&] {
+        for (;;) {
+            Pending p;
+            {
+                std::unique_lock<std::mutex> g(smu);
+                scv.wait(g, [&] { return !pending.empty() || no_more; });
+                if (pending.empty()) return;
+                p = pending.front();
+                pending.pop_front();
+            }
+            if (p.tb && !collector_failed) {
+                const double t0 = now_s();
+                try {
+                    if (chained) check(hc_textblock_submit_from(p.tb, p.src, p.bytes, chain.p, p.chain_k, p.prev, 0), "hc_textblock_submit_from");
+                    else check(hc_textblock_submit(p.tb, p.bytes, p.line_no, 0), "hc_textblock_submit");
+                } catch (const FatalError& e) {
+                    std::lock_guard<std::mutex> g(mu);
+                    if (!collector_failed) {
+                        collector_error = e;
+                        collector_failed = true;
+                    }
+                }
+                tm_submit += now_s() - t0;
+            }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                submitted = p.k + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    auto hand_over = [&](const Pending& p) {
+        {
+            std::lock_guard<std::mutex> g(smu);
+            pending.push_back(p);
+        }
+        scv.notify_one();
+    };
+    auto stop_submitter = [&] {
+        {
+            std::lock_guard<std::mutex> g(smu);
+            no_more = true;
+        }
+        scv.notify_one();
+        if (submitter.joinable()) submitter.join();
+    };
     try {
         size_t pos = 0;
         uint64_t line_no = 0;
@@ -822,11 +884,9 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                     stats.t_parse += now_s() - t0;
                     ring[k % R] = sl;
                     pos = size;
-                    {
-                        std::lock_guard<std::mutex> g(mu);
-                        submitted = k + 1;
-                    }
-                    cv.notify_all();
+                    Pending p;
+                    p.k = k;
+                    hand_over(p);
                     break;
                 }
                 end = pos + cut;  // the bytes behind the cut are copied again with the next block
@@ -846,29 +906,30 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
             const double tc = now_s();
             stats.t_parse += tc - t0;
             tm_copy += tc - t0;
+            sl.tb = tb;
+            ring[k % R] = sl;  // (read by the collectors only once the submitter has published block k)
+            Pending p;
+            p.k = k;
+            p.tb = tb;
+            p.src = from_map ? parser.data() + pos : hc_textblock_buffer(tb);
+            p.bytes = end - pos;
+            p.line_no = line_no;
+            p.chain_k = chain_k;
+            p.prev = prev_tb;
+            hand_over(p);
             if (chained) {
-                check(hc_textblock_submit_from(tb, from_map ? parser.data() + pos : hc_textblock_buffer(tb), end - pos, chain.p, chain_k, prev_tb, 0),
-                      "hc_textblock_submit_from");
                 prev_tb = tb;
                 chain_k++;
-            } else {
-                check(hc_textblock_submit(tb, end - pos, line_no, 0), "hc_textblock_submit");
             }
-            tm_submit += now_s() - tc;
-            sl.tb = tb;
-            ring[k % R] = sl;
             pos = end;
             line_no += sl.n_lines;
-            {
-                std::lock_guard<std::mutex> g(mu);
-                submitted = k + 1;
-            }
-            cv.notify_all();
         }
     } catch (...) {
+        stop_submitter();
         stop_collector();
         throw;
     }
+    stop_submitter();
     stop_collector();
     if (collector_failed) throw collector_error;
     stats.t_score = t_collect;
