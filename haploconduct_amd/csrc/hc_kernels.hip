@@ -643,6 +643,20 @@ __device__ __forceinline__ void append_rows_block(const RowSink& sink, bool vali
     __syncthreads();  // lds4 is reused by the next iteration
 }
 
+// The log table into LDS.  The sparse layout of the smallest table (hc_device.h) has 128 live entries in 16 KiB of address
+// space: only those are copied (a workgroup that scores one block of 256 candidates would otherwise move 16 KiB for them).
+template <typename SymT, int LG>
+__device__ __forceinline__ void load_log_table(double* lut_s, const double* __restrict__ lut_g, uint32_t lut_n, uint32_t tid, uint32_t n_threads) {
+    if (sizeof(SymT) == 1 && LG == 3) {
+        for (uint32_t e = tid; e < 128u; e += n_threads) {
+            const uint32_t at = lut_addr_u8(3, e >> 4, (e >> 1) & 7u, e & 1u) >> 3;
+            lut_s[at] = lut_g[at];
+        }
+    } else {
+        for (uint32_t i = tid; i < lut_n; i += n_threads) lut_s[i] = lut_g[i];
+    }
+}
+
 // Block-local length balancing (read sets with mixed sequence lengths: contigs next to reads).  A wave runs as long as
 // its longest lane, a workgroup iteration as long as its longest wave; with the log-uniform 150..6 000 bp contigs of
 // BASELINE config 5 the mean lane is busy 29 % of that time.  One iteration of a workgroup takes kBalItems x blockDim.x
@@ -750,7 +764,7 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
     extern __shared__ __attribute__((aligned(16))) double lut_s[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lut_s != 0u) __builtin_trap();  // lds_f64 relies on it
     const uint32_t lut_n = st.lut_bytes >> 3;
-    for (uint32_t i = threadIdx.x; i < lut_n; i += blockDim.x) lut_s[i] = lut_g[i];
+    load_log_table<SymT, LG>(lut_s, lut_g, lut_n, threadIdx.x, blockDim.x);
     __syncthreads();
 
     const SymT* sym = (const SymT*)st.sym;
@@ -815,7 +829,7 @@ __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score
     extern __shared__ __attribute__((aligned(16))) double lut_s[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lut_s != 0u) __builtin_trap();  // lds_f64 relies on it
     const uint32_t lut_n = st.lut_bytes >> 3;
-    for (uint32_t i = threadIdx.x; i < lut_n; i += WG) lut_s[i] = lut_g[i];
+    load_log_table<SymT, LG>(lut_s, lut_g, lut_n, threadIdx.x, WG);
     __syncthreads();
     uint32_t* scratch = (uint32_t*)(lut_s + lut_n);  // row append: [0..17]
     // this wave's image (LDS byte address); the images start at a multiple of 1 KiB (the XOR swizzle needs whole 64-byte rows)
