@@ -26,6 +26,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "../../include/hcedge.h"
 #include "hc_device.h"
 #include "hc_resolve.h"
@@ -1042,7 +1044,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             uint32_t per_cu = (uint32_t)((160 * 1024) / lds_c);
             per_cu = per_cu * (wg_c / 64) > 32 ? 32 / (wg_c / 64) : per_cu;
             uint64_t blocks_c = (n + wg_c - 1) / wg_c;
-            const uint64_t cap_c = (uint64_t)n_cu * per_cu * 4;
+            static const int grid_mult = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 4;  // experiment knob
+            const uint64_t cap_c = (uint64_t)n_cu * per_cu * grid_mult;
             if (blocks_c > cap_c) blocks_c = cap_c;
             const RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out};
             const bool sort_subs = !(prm.pad & 1u);
