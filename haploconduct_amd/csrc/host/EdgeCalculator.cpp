@@ -59,6 +59,7 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
     if (const char* m = getenv("HC_TEXT_BLOCK")) m_text_block = std::max<size_t>(4096, (size_t)strtoull(m, nullptr, 10));
     if (const char* m = getenv("HC_TEXT_DEPTH")) m_text_depth = std::max<size_t>(1, (size_t)atoi(m));
     m_cs = to_hc_settings(ps);
+    if (ps.n_threads > 1) m_pool.reset(new WorkerPool(ps.n_threads - 1));
     const FastqStorage& f = *fastq_storage;
     try {
         for (int d : device_list(ps)) {  // the read store is replicated: candidates are independent given the reads
@@ -1078,7 +1079,12 @@ void EdgeCalculator::score_host_parsed(OverlapsParser& parser, std::vector<Overl
 
 // src/EdgeCalculator.cpp:561-666
 void EdgeCalculator::run_stage(bool then_sort) {
+    const double t_stage0 = now_s();
+    auto stage_lap = [&](const char* what) {
+        if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] %s at %.3f s\n", what, now_s() - t_stage0);
+    };
     collect_read_info();  // vertex ids may have been assigned since the last call
+    stage_lap("read info collected");
     stats = Stats();
     // An empty graph (every pipeline call) takes the bulk path: the admitted candidates are collected in sequence
     // order and resolved at once after the last block.  A graph that already holds edges, or HC_INSERT_MODE=serial,
@@ -1092,11 +1098,14 @@ void EdgeCalculator::run_stage(bool then_sort) {
     if (m_device_resolve) check(hc_graph_begin(m_ctx), "hc_graph_begin");
     std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
     std::vector<Overlap> rejected;
-    const double t_stage0 = now_s();
-    auto stage_lap = [&](const char* what) {
-        if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] %s at %.3f s\n", what, now_s() - t_stage0);
-    };
-    OverlapsParser parser(program_settings.overlaps_file, program_settings, *fastq_storage);
+    // (closed by the clean-up thread: unmapping the 4 GB file with the worker threads alive takes 20 ms)
+    std::unique_ptr<OverlapsParser> parser_owner(new OverlapsParser(program_settings.overlaps_file, program_settings, *fastq_storage, m_pool.get()));
+    struct CloseLater {
+        std::unique_ptr<OverlapsParser>& p;
+        EdgeCalculator* self;
+        ~CloseLater() { self->defer_cleanup([q = p.release()] { delete q; }); }
+    } close_later{parser_owner, this};
+    OverlapsParser& parser = *parser_owner;
     stage_lap("overlaps file open");
     if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
     if (program_settings.verbose) puts("reading overlaps file... ");
@@ -1155,6 +1164,7 @@ void EdgeCalculator::run_stage(bool then_sort) {
         fclose(fo);
     }
     stats.t_write += now_s() - t0;
+    stage_lap("construct_edges body done (destructors follow)");
 }
 
 }  // namespace hc

@@ -119,6 +119,8 @@ private:
     bool m_serial_insert = false;     // HC_INSERT_MODE=serial: per-edge inserts even into an empty graph
     bool m_host_resolve = false;      // HC_RESOLVE=host: duplicate resolution on the host threads instead of the device
     bool m_host_parse = false;        // HC_PARSE=host: the overlaps file is tokenised on the host threads instead of the device
+    std::unique_ptr<WorkerPool> m_pool;  // the stage's worker threads (lent to the overlaps parser of every call: starting and
+                                         // joining 31 threads per file cost 25 ms)
     std::thread m_cleanup;            // frees of large buffers, off the caller's clock (defer_cleanup)
     void defer_cleanup(std::function<void()> work);
     size_t m_text_block = 16u << 20;  // bytes of text per device-parsed block (HC_TEXT_BLOCK)

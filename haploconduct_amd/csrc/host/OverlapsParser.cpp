@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <condition_variable>
 #include <functional>
@@ -168,13 +169,7 @@ void OverlapsParser::parse_segment(Segment& seg) const {
     }
 }
 
-// The parser's worker threads, started once (WorkerPool.h).
-class OverlapsParser::Pool : public WorkerPool {
-public:
-    using WorkerPool::WorkerPool;
-};
-
-OverlapsParser::OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq)
+OverlapsParser::OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq, WorkerPool* shared_pool)
     : m_ps(ps), m_fastq(fastq), m_ids(fastq), m_threads(ps.n_threads ? ps.n_threads : 1) {
     m_fd = open(path.c_str(), O_RDONLY);
     if (m_fd < 0) return;
@@ -188,13 +183,27 @@ OverlapsParser::OverlapsParser(const std::string& path, const ProgramSettings& p
         m_data = (const char*)p;
     }
     m_open = true;
-    if (m_threads > 1) m_pool.reset(new Pool(m_threads - 1));
+    if (m_threads > 1) {
+        if (shared_pool && shared_pool->workers() + 1 >= m_threads) {
+            m_pool = shared_pool;
+        } else {
+            m_own_pool.reset(new WorkerPool(m_threads - 1));
+            m_pool = m_own_pool.get();
+        }
+    }
 }
 
 OverlapsParser::~OverlapsParser() {
-    m_pool.reset();
+    const bool timing = getenv("HC_STAGE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    m_pool = nullptr;
+    m_own_pool.reset();
+    const double t1 = now();
     if (m_data) munmap((void*)m_data, m_size);
+    const double t2 = now();
     if (m_fd >= 0) close(m_fd);
+    if (timing) fprintf(stderr, "[hc stage] overlaps parser closed: pool %.3f s, munmap %.3f s, close %.3f s\n", t1 - t0, t2 - t1, now() - t2);
 }
 
 // Parses the next block of the file with m_threads threads: the block is cut into segments at line

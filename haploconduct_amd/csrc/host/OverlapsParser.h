@@ -12,6 +12,7 @@
 #include "FastqStorage.h"
 #include "Overlap.h"
 #include "Types.h"
+#include "WorkerPool.h"
 
 namespace hc {
 
@@ -129,7 +130,8 @@ private:
 
 class OverlapsParser {
 public:
-    OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq);
+    // shared_pool: worker threads of the caller (at least ps.n_threads - 1), used instead of starting and joining a pool per file
+    OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq, WorkerPool* shared_pool = nullptr);
     ~OverlapsParser();
     bool is_open() const { return m_open; }
     // Fills `batch` with up to `max_batch` candidates that pass the prefilter (:612-635), in file
@@ -154,8 +156,8 @@ public:
 private:
     struct Segment;
     void parse_segment(Segment& seg) const;
-    class Pool;  // the parser's worker threads, started once
-    std::unique_ptr<Pool> m_pool;
+    std::unique_ptr<WorkerPool> m_own_pool;  // the parser's worker threads, started once — unless the caller lends its pool
+    WorkerPool* m_pool = nullptr;
     mutable std::mutex m_pool_mu;  // copy_range and parse_range may be called from two threads: one phase of the pool at a time
     struct Scratch {  // where one segment parses to before its place in the block is known; kept between blocks
         std::vector<Overlap> lines;

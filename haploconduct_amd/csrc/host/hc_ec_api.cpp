@@ -54,7 +54,11 @@ int hc_ec_construct_edges(hc_ec* ec) {
 
 int hc_ec_construct_edges_sorted(hc_ec* ec) {
     if (!ec) return set_last_error(HC_ERR_ARG, "hc_ec_construct_edges_sorted: null");
-    return guarded("construct_edges", [&] { ec->calc->construct_edges_sorted(); });
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    const int rc = guarded("construct_edges", [&] { ec->calc->construct_edges_sorted(); });
+    if (getenv("HC_STAGE_TIMING"))
+        fprintf(stderr, "[hc stage] hc_ec_construct_edges_sorted took %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
+    return rc;
 }
 
 uint32_t hc_ec_device_count(hc_ec* ec) { return ec ? ec->calc->device_count() : 0; }
