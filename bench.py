@@ -356,9 +356,11 @@ def stage_end_to_end(reads, cand, settings, threads, reps=2):
         best = min(runs, key=lambda r: r["construct_edges_sorted_s"])
         return {"value": best["scored"] / best["construct_edges_sorted_s"], "unit": "candidate overlaps/s", "threads": threads,
                 "text_bytes": os.path.getsize(d + "overlaps.txt"), "files_written_s": t_files, "best": best, "runs": runs,
-                "what": "hc_ec_construct_edges_sorted: overlaps text file -> parse -> H2D of 16-byte records -> scoring kernel -> non-dropped rows "
-                        "-> host exp() -> device duplicate resolution + adjacency in sortEdges order -> OverlapGraph; FASTQ load + store "
-                        "upload (open_s) not included, as in the reference's own timing (src/ViralQuasispecies.cpp:280-283)"}
+                "what": "hc_ec_construct_edges_sorted: the overlaps file's text -> H2D in 16 MiB blocks -> device: lines, parse, prefilter, "
+                        "scoring kernel, non-dropped rows in file order -> host exp() of the admitted -> device duplicate resolution + "
+                        "adjacency in sortEdges order -> OverlapGraph; `best` of the runs (a process's first call is the slower one); "
+                        "FASTQ load + store upload (open_s) not included, as in the reference's own timing "
+                        "(src/ViralQuasispecies.cpp:280-283)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
