@@ -45,6 +45,20 @@ struct DevBuf {
         (buf).p = sl__.p;                                                                     \
     } while (0)
 
+// the temporary storage of the library calls: the slot keeps what earlier calls grew it to
+#define HC_GROW_TMP(bytes)                                        \
+    do {                                                          \
+        if ((bytes) > d_tmp.slot->cap) {                          \
+            HC_HIP(hipStreamSynchronize(st));                     \
+            (void)hipFree(d_tmp.slot->p);                         \
+            d_tmp.slot->p = nullptr;                              \
+            d_tmp.slot->cap = 0;                                  \
+            HC_HIP(hipMalloc(&d_tmp.slot->p, (bytes)));           \
+            d_tmp.slot->cap = (bytes);                            \
+            d_tmp.p = d_tmp.slot->p;                              \
+        }                                                         \
+        tmp_bytes = d_tmp.slot->cap;                              \
+    } while (0)
 
 extern "C" {
 
@@ -143,6 +157,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     size_t tmp_bytes = 0;
     HC_HIP(hc::finder_sort_pairs(nullptr, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
     HC_ALLOC(d_tmp, tmp_bytes);
+    tmp_bytes = d_tmp.slot->cap;
     HC_HIP(hc::finder_sort_pairs(d_tmp.p, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), P, 64, st));
     lap("index + sort");
     // 2. seeds: range of every seed k-mer in the index
@@ -161,16 +176,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     {
         size_t b = 0;
         HC_HIP(hc::finder_scan(nullptr, b, d_val.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
-        if (b > tmp_bytes) {
-            HC_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_tmp.slot->p);
-            d_tmp.slot->p = nullptr;
-            d_tmp.slot->cap = 0;
-            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
-            d_tmp.slot->cap = b;
-            d_tmp.p = d_tmp.slot->p;
-            tmp_bytes = b;
-        }
+        HC_GROW_TMP(b);
         HC_HIP(hc::finder_scan(d_tmp.p, b, d_val.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
     }
     uint64_t H = 0;  // number of candidate hits = last element of the exclusive scan over S + 1 counts (the extra one is 0)
@@ -227,17 +233,10 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         HC_HIP(hc::finder_scan32(nullptr, b3, d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), Hmax + 1, st));
         b = b2 > b ? b2 : b;
         b = b3 > b ? b3 : b;
-        if (b > tmp_bytes) {
-            HC_HIP(hipStreamSynchronize(st));
-            (void)hipFree(d_tmp.slot->p);
-            d_tmp.slot->p = nullptr;
-            d_tmp.slot->cap = 0;
-            HC_HIP(hipMalloc(&d_tmp.slot->p, b));
-            d_tmp.slot->cap = b;
-            d_tmp.p = d_tmp.slot->p;
-            tmp_bytes = b;
-        }
+        HC_GROW_TMP(b);
     }
+    HC_HIP(hipStreamSynchronize(st));
+    lap("scratch for the batches");
     unsigned long long R = 0;
     size_t res_cap = 0;  // records; the result buffer grows by doubling (it outlives the call: not a scratch slot)
     for (const Batch& bt : batches) {

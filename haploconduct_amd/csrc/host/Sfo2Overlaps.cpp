@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -515,6 +516,39 @@ inline SfoRec to_sfo(const BRec& r) {
     return o;
 }
 
+// Sorts one bucket by brec_less.  The order is decided by (id0, id1) for all but the few records of one pair of reads, so
+// what is sorted are 16-byte (key, index) entries — one integer comparison, the full one only between records of the same
+// pair — and the 48-byte records are moved once, at the end.
+struct SortEntry {
+    uint64_t key;
+    uint32_t idx, s0;
+};
+struct SortScratch {  // one per worker thread, grown to its largest bucket: no allocation (and no page faults) per bucket
+    std::vector<SortEntry> entries;
+    std::vector<BRec> records;
+};
+void sort_bucket(BRec* r, size_t n, SortScratch& scratch) {
+    if (n < 2) return;
+    if (n >= (1ull << 32)) {
+        std::sort(r, r + n, brec_less);
+        return;
+    }
+    if (scratch.entries.size() < n) {
+        scratch.entries.resize(n);
+        scratch.records.resize(n);
+    }
+    SortEntry* e = scratch.entries.data();
+    for (size_t i = 0; i < n; i++) e[i] = SortEntry{(uint64_t)r[i].id0 << 32 | r[i].id1, (uint32_t)i, r[i].s0};
+    std::sort(e, e + n, [r](const SortEntry& x, const SortEntry& y) {
+        if (x.key != y.key) return x.key < y.key;
+        if (x.s0 != y.s0) return x.s0 < y.s0;
+        return brec_less(r[x.idx], r[y.idx]);
+    });
+    BRec* tmp = scratch.records.data();
+    for (size_t i = 0; i < n; i++) tmp[i] = r[e[i].idx];
+    memcpy(r, tmp, n * sizeof(BRec));
+}
+
 struct RecArray {  // n records, not initialised: the workers touch (and so place) their own stretches first
     BRec* p = nullptr;
     explicit RecArray(size_t n) {
@@ -594,9 +628,12 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
     const auto t0 = std::chrono::steady_clock::now();
     unsigned T = std::thread::hardware_concurrency();
     if (T == 0) T = 1;
-    if (T > 32) T = 32;
-    if (n / 20000 + 1 < T) T = (unsigned)(n / 20000 + 1);
-    if (const char* e = getenv("HC_SFO_BUCKETS")) T = (unsigned)std::max(1, atoi(e));  // test knob: many buckets on small inputs
+    if (T > 64) T = 64;
+    // buckets: several per thread (short sorts that stay in the caches, an even finish), none below 20 000 records
+    uint64_t NB = std::min<uint64_t>((uint64_t)T * 8, n / 20000 + 1);
+    if (const char* e = getenv("HC_SFO_BUCKETS")) NB = (uint64_t)std::max(1, atoi(e));  // test knob: many buckets on small inputs
+    if (NB > 4096) NB = 4096;
+    if (NB < T) T = (unsigned)NB;
     auto workers = [&](unsigned count, const std::function<void(unsigned)>& body) {
         if (count <= 1) {
             body(0);
@@ -607,56 +644,55 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
         body(0);
         for (auto& x : th) x.join();
     };
-    // 1. the flip of :112-122 (smaller original id first)
-    RecArray flipped_mem(n);
-    BRec* flipped = flipped_mem.p;
+    // the flip of :112-122 (smaller original id first); id0_of = the id it puts first
+    auto id0_of = [&](const hc_sfo_rec& r) {
+        const long na = original_id((long)r.idA, ns, np), nb = original_id((long)r.idB, ns, np);
+        return (uint32_t)(na > nb ? nb : na);
+    };
+    auto flip_into = [&](const hc_sfo_rec& r, BRec& o) {
+        const long na = original_id((long)r.idA, ns, np), nb = original_id((long)r.idB, ns, np);
+        o.ori = r.inverted ? 'I' : 'N';
+        o.k = r.K;
+        if (na > nb) {
+            o.id0 = (uint32_t)nb; o.id1 = (uint32_t)na;
+            o.s0 = r.idB; o.s1 = r.idA;
+            if (r.inverted) { o.oha = r.OHB; o.ohb = r.OHA; }
+            else { o.oha = -(int64_t)r.OHA; o.ohb = -(int64_t)r.OHB; }
+            o.ola = r.OLB; o.olb = r.OLA;
+        } else {
+            o.id0 = (uint32_t)na; o.id1 = (uint32_t)nb;
+            o.s0 = r.idA; o.s1 = r.idB;
+            o.oha = r.OHA; o.ohb = r.OHB;
+            o.ola = r.OLA; o.olb = r.OLB;
+        }
+    };
+    // 1. buckets of id0 ranges: splitters from a sample, a counting pass that notes every record's bucket
     std::vector<FatalError> errs(T, FatalError{0, ""});
+    std::vector<uint32_t> split;  // bucket b holds id0 in [split[b-1], split[b])
+    if (NB > 1) {
+        std::vector<uint32_t> sample;
+        const uint64_t step = std::max<uint64_t>(1, n / (NB * 64));
+        for (uint64_t i = 0; i < n; i += step) sample.push_back(id0_of(recs[i]));
+        std::sort(sample.begin(), sample.end());
+        for (uint64_t b = 1; b < NB; b++) {
+            const uint32_t v = sample[sample.size() * b / NB];
+            if (split.empty() || v > split.back()) split.push_back(v);
+        }
+    }
+    const unsigned B = (unsigned)split.size() + 1;
+    auto bucket_of = [&](uint32_t id0) { return (uint16_t)(std::upper_bound(split.begin(), split.end(), id0) - split.begin()); };
+    std::vector<std::vector<uint64_t>> counts(T, std::vector<uint64_t>(B, 0));
+    std::unique_ptr<uint16_t[]> bucket(new uint16_t[n ? n : 1]);  // not initialised: written by the thread that reads it back
     workers(T, [&](unsigned t) {
         try {
-            for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) {
-                const hc_sfo_rec& r = recs[i];
-                const long na = original_id((long)r.idA, ns, np), nb = original_id((long)r.idB, ns, np);
-                BRec& o = flipped[i];
-                o.ori = r.inverted ? 'I' : 'N';
-                o.k = r.K;
-                if (na > nb) {
-                    o.id0 = (uint32_t)nb; o.id1 = (uint32_t)na;
-                    o.s0 = r.idB; o.s1 = r.idA;
-                    if (r.inverted) { o.oha = r.OHB; o.ohb = r.OHA; }
-                    else { o.oha = -(int64_t)r.OHA; o.ohb = -(int64_t)r.OHB; }
-                    o.ola = r.OLB; o.olb = r.OLA;
-                } else {
-                    o.id0 = (uint32_t)na; o.id1 = (uint32_t)nb;
-                    o.s0 = r.idA; o.s1 = r.idB;
-                    o.oha = r.OHA; o.ohb = r.OHB;
-                    o.ola = r.OLA; o.olb = r.OLB;
-                }
-            }
+            std::vector<uint64_t>& c = counts[t];
+            for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) c[bucket[i] = bucket_of(id0_of(recs[i]))]++;
         } catch (const FatalError& e) {
             errs[t] = e;
         }
     });
     for (const FatalError& e : errs)
         if (e.status) throw e;
-    // 2. buckets of id0 ranges: splitters from a sample, a counting pass, a scatter pass
-    std::vector<uint32_t> split;  // bucket b holds id0 in [split[b-1], split[b])
-    if (T > 1) {
-        std::vector<uint32_t> sample;
-        const uint64_t step = std::max<uint64_t>(1, n / ((uint64_t)T * 256));
-        for (uint64_t i = 0; i < n; i += step) sample.push_back(flipped[i].id0);
-        std::sort(sample.begin(), sample.end());
-        for (unsigned b = 1; b < T; b++) {
-            const uint32_t v = sample[sample.size() * b / T];
-            if (split.empty() || v > split.back()) split.push_back(v);
-        }
-    }
-    const unsigned B = (unsigned)split.size() + 1;
-    auto bucket_of = [&](uint32_t id0) { return (unsigned)(std::upper_bound(split.begin(), split.end(), id0) - split.begin()); };
-    std::vector<std::vector<uint64_t>> counts(T, std::vector<uint64_t>(B, 0));
-    workers(T, [&](unsigned t) {
-        std::vector<uint64_t>& c = counts[t];
-        for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) c[bucket_of(flipped[i].id0)]++;
-    });
     std::vector<uint64_t> start(B + 1, 0);
     for (unsigned b = 0; b < B; b++) {
         uint64_t m = 0;
@@ -667,29 +703,36 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
         }
         start[b + 1] = start[b] + m;
     }
+    // 2. flip + scatter in one pass: the flipped form of a record is written once, into its bucket
     RecArray sorted_mem(n);
     BRec* sorted = sorted_mem.p;
     workers(T, [&](unsigned t) {
         std::vector<uint64_t> at = counts[t];
-        for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) sorted[at[bucket_of(flipped[i].id0)]++] = flipped[i];
+        for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) flip_into(recs[i], sorted[at[bucket[i]]++]);
     });
-    flipped_mem.release();
+    bucket.reset();
     const auto t1 = std::chrono::steady_clock::now();
     // 3. sort and match every bucket on its own
     std::vector<BucketResult> res(B);
+    std::atomic<uint64_t> sort_ns{0}, match_ns{0};  // summed over the threads (HC_SFO_TIMING)
     {
         std::vector<unsigned> order(B);  // largest buckets first: they bound the makespan
         for (unsigned b = 0; b < B; b++) order[b] = b;
         std::sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return start[x + 1] - start[x] > start[y + 1] - start[y]; });
         std::atomic<unsigned> next{0};
         workers(std::min(T, B), [&](unsigned) {
+            SortScratch scratch;
             for (;;) {
                 const unsigned k = next.fetch_add(1);
                 if (k >= B) return;
                 const unsigned b = order[k];
                 try {
-                    std::sort(sorted + start[b], sorted + start[b + 1], brec_less);
+                    const auto ta = std::chrono::steady_clock::now();
+                    sort_bucket(sorted + start[b], start[b + 1] - start[b], scratch);
+                    const auto tb = std::chrono::steady_clock::now();
                     match_bucket(sorted + start[b], start[b + 1] - start[b], ns, np, res[b]);
+                    sort_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(tb - ta).count();
+                    match_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tb).count();
                 } catch (const FatalError& e) {
                     res[b].error = e;
                 }
@@ -704,6 +747,7 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
         for (const BucketResult& r : res) bytes += r.before.text.size() + r.after.text.size();
         out.reserve(bytes + bytes / 16);
     }
+    const auto t2 = std::chrono::steady_clock::now();
     std::vector<BRec> open;
     for (BucketResult& r : res) {
         if (r.error.status) throw r.error;
@@ -720,8 +764,9 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
         n_lines += r.after.n_lines;
     }  // the group open at the very end is never matched (:63-103)
     if (getenv("HC_SFO_TIMING"))
-        fprintf(stderr, "sfo_records_to_overlaps: flip + partition %.3f s, sort + match + stitch %.3f s (%u buckets)\n",
-                std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), B);
+        fprintf(stderr, "sfo_records_to_overlaps: flip + partition %.3f s, sort + match %.3f s (thread-seconds: sort %.3f, match %.3f), stitch %.3f s (%u buckets, %u threads)\n",
+                std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(), sort_ns.load() * 1e-9, match_ns.load() * 1e-9,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count(), B, T);
     return out;
 }
 
