@@ -5,13 +5,37 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <memory>
+#include <new>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "Read.h"
 #include "Types.h"
 
 namespace hc {
+
+// The flat base / quality arrays: bytes that resize() adds are left uninitialised (every one of them is written by the
+// reader right after — zero-filling 300 MB first costs 50 ms on one thread and places every page on its node).
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+        ::new ((void*)p) U;
+    }
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+using ByteVec = std::vector<uint8_t, DefaultInitAllocator<uint8_t>>;
 
 class FastqStorage {
 public:
@@ -29,8 +53,8 @@ public:
     unsigned int get_readcount() const { return (unsigned int)m_read_vec.size(); }
 
     // flat layout (hc_set_reads arguments)
-    const std::vector<uint8_t>& bases() const { return m_bases; }
-    const std::vector<uint8_t>& quals() const { return m_quals; }
+    const ByteVec& bases() const { return m_bases; }
+    const ByteVec& quals() const { return m_quals; }
     const std::vector<uint64_t>& seq_off() const { return m_seq_off; }
     const std::vector<uint32_t>& read_first_seq() const { return m_first; }
     // sequence index of mate i (0 = single, 1 = /1, 2 = /2) of read `index`
@@ -51,7 +75,7 @@ private:
 
     std::map<std::string, std::string> m_new_readIDs;    // fastq id -> overlaps-file id (--IDs)
     bool m_have_new_ids = false;
-    std::vector<uint8_t> m_bases, m_quals;
+    ByteVec m_bases, m_quals;
     std::vector<uint64_t> m_seq_off{0};
     std::vector<uint32_t> m_first{0};
 };

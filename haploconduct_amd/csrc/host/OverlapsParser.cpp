@@ -170,7 +170,7 @@ void OverlapsParser::parse_segment(Segment& seg) const {
 }
 
 OverlapsParser::OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq, WorkerPool* shared_pool)
-    : m_ps(ps), m_fastq(fastq), m_ids(fastq), m_threads(ps.n_threads ? ps.n_threads : 1) {
+    : m_ps(ps), m_ids(fastq), m_threads(ps.n_threads ? ps.n_threads : 1) {
     m_fd = open(path.c_str(), O_RDONLY);
     if (m_fd < 0) return;
     struct stat st;

@@ -166,7 +166,6 @@ private:
     std::vector<Scratch> m_scratch;
 
     const ProgramSettings& m_ps;
-    const FastqStorage& m_fastq;
     IdIndex m_ids;
     unsigned int m_threads = 1;
     bool m_open = false;
