@@ -5,6 +5,7 @@
 // insert into a graph that already holds edges stay on the host.
 #include "EdgeCalculator.h"
 
+#include <sys/stat.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -57,8 +58,17 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
     if (const char* m = getenv("HC_RESOLVE")) m_host_resolve = std::string(m) == "host";
     if (const char* m = getenv("HC_PARSE")) m_host_parse = std::string(m) == "host";
     if (const char* m = getenv("HC_TEXT_BLOCK")) m_text_block = std::max<size_t>(4096, (size_t)strtoull(m, nullptr, 10));
-    if (const char* m = getenv("HC_TEXT_DEPTH")) m_text_depth = std::max<size_t>(1, (size_t)atoi(m));
     m_cs = to_hc_settings(ps);
+    if (const char* m = getenv("HC_TEXT_DEPTH")) {
+        m_text_depth = std::max<size_t>(1, (size_t)atoi(m));
+    } else {  // as deep as the overlaps file has blocks for one device, between 2 and 10: a small file does not pay for buffers it never fills
+        struct stat sb;
+        const size_t n_dev = std::max<size_t>(1, device_list(ps).size());
+        if (stat(ps.overlaps_file.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) {
+            const size_t blocks = ((size_t)sb.st_size + m_text_block - 1) / m_text_block;
+            m_text_depth = std::min<size_t>(m_text_depth, std::max<size_t>(2, (blocks + n_dev - 1) / n_dev));
+        }
+    }
     if (ps.n_threads > 1) m_pool.reset(new WorkerPool(ps.n_threads - 1));
     const FastqStorage& f = *fastq_storage;
     try {

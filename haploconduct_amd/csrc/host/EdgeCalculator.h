@@ -124,7 +124,7 @@ private:
     std::thread m_cleanup;            // frees of large buffers, off the caller's clock (defer_cleanup)
     void defer_cleanup(std::function<void()> work);
     size_t m_text_block = 16u << 20;  // bytes of text per device-parsed block (HC_TEXT_BLOCK)
-    size_t m_text_depth = 6;          // text blocks in flight per device (HC_TEXT_DEPTH): copy of block k+2.. beside the device's work on k, k+1
+    size_t m_text_depth = 10;         // text blocks in flight per device at most (HC_TEXT_DEPTH; fewer for a short file): copies of later blocks beside the device's work on k, k+1
     bool m_collect = false;           // this call collects the admitted candidates and resolves them after the last block
     bool m_device_resolve = false;    // ... on the device: every block's admitted records are appended there as they come
     std::vector<std::vector<hc_admit_rec>> m_admitted;  // admitted candidates of the whole file, block by block, in sequence order

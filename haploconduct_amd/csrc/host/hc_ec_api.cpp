@@ -29,7 +29,7 @@ extern "C" {
 // the graph kernels and their sorts — as long again as a whole C2-sized stage.  hc_ec_open runs the stage's device
 // sequence once on two dummy reads, in a thread beside its FASTQ parsing (which is host work): the code is then in place
 // when construct_edges wants it, and opening takes no longer.  Best effort: errors end the warm-up, not the open.
-static void warm_device_code(hc_settings cs) {
+static void warm_device_code(hc_settings cs) noexcept try {
     hc_ctx* c = nullptr;
     if (hc_create(&c, &cs) != HC_OK) return;
     hc_textblock* tb = nullptr;
@@ -71,6 +71,7 @@ static void warm_device_code(hc_settings cs) {
     hc_linechain_destroy(chain);
     hc_textblock_destroy(tb);
     hc_destroy(c);
+} catch (...) {  // a thread body: nothing may leave it
 }
 
 int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* paths) {

@@ -61,7 +61,8 @@ def run_both(oracle, tmp_path, reads, lines, st, tag):
     # (against construct_edges followed by sortEdges) must all agree with it.
     for env, sorted_call in (({"HC_RESOLVE": "host"}, False), ({"HC_INSERT_MODE": "serial"}, False), ({"HC_DEVICE_LIST": "0,0,0"}, False),
                              ({"HC_PARSE": "host"}, False), ({"HC_PARSE": "host", "HC_DEVICE_LIST": "0,0,0"}, False),
-                             ({"HC_TEXT_BLOCK": "4096"}, False), ({"HC_TEXT_SOURCE": "map"}, False), ({"HC_TEXT_SOURCE": "pread"}, False), ({"HC_TEXT_BUFFER": "wc"}, False),
+                             ({"HC_TEXT_BLOCK": "4096"}, False), ({"HC_TEXT_BLOCK": "4096", "HC_TEXT_DEPTH": "1"}, False),
+                             ({"HC_TEXT_BLOCK": "8192", "HC_TEXT_DEPTH": "3", "HC_COLLECTORS": "2"}, False), ({"HC_TEXT_SOURCE": "map"}, False), ({"HC_TEXT_SOURCE": "pread"}, False), ({"HC_TEXT_BUFFER": "wc"}, False),
                              ({"HC_TEXT_SOURCE": "pread", "HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False),
                              ({"HC_TEXT_SOURCE": "map", "HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False),
                              ({"HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False), ({}, True), ({"HC_RESOLVE": "host"}, True)):
