@@ -1,0 +1,35 @@
+// hc_fno_device.h — the device form of find-next-overlaps' second half: computeOverlapData
+// (src/FindNextOverlaps.cpp:351-565) for a batch of (edge, super-read, super-read) combinations, then a radix sort +
+// unique in place of the reference's std::set<std::string> (:937-948), then the text of the surviving lines.
+// The order of a std::set<std::string> of 13-column lines is the order of the column tuples with every number compared
+// as its DECIMAL TEXT (a tab ends the shorter text and sorts below '-' and every digit), so each column maps to an
+// order-preserving integer and the line to one 256-bit key; equal keys <=> equal lines.
+#ifndef HC_FNO_DEVICE_H_
+#define HC_FNO_DEVICE_H_
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "hc_fno_items.h"
+
+namespace hc {
+
+enum : unsigned long long {
+    kFnoStatusRequire = 1,  // an assert / .at() of the reference would fire: the host path reports which
+    kFnoStatusRange = 2     // a number outside what the keys hold (id >= 10^10, perc > 999): the host path takes over
+};
+// counters: [0..3] lines per kind before the unique (hc_fno_counters), [4] status bits, [5] lines after the unique
+constexpr int kFnoCounters = 6;
+
+hipError_t fno_deduce(const FnoItem* items, uint64_t n, uint32_t no_inclusions, FnoRec* rec, uint64_t* k0, uint64_t* k1, uint64_t* k2,
+                      uint64_t* k3, uint32_t* iota, unsigned long long* counters, hipStream_t s);
+hipError_t fno_gather_keys(const uint64_t* key, const uint32_t* perm, uint64_t n, uint64_t* out, hipStream_t s);
+// len[i] = bytes (with the newline) of the line at sorted place i if it is the first of its run of equal lines, else 0; len[n] = 0
+hipError_t fno_mark_lines(const FnoRec* rec, const uint32_t* perm, uint64_t n, uint64_t* len, unsigned long long* counters, hipStream_t s);
+hipError_t fno_format(const FnoRec* rec, const uint32_t* perm, const uint64_t* len, const uint64_t* off, uint64_t n, char* text, hipStream_t s);
+// stable radix sort of (64-bit key, 32-bit value) pairs (hc_graph_kernels.hip owns the instantiation)
+hipError_t sort_pairs_u64_u32(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint32_t* v_in, uint32_t* v_out,
+                              uint32_t n, int end_bit, hipStream_t s);
+
+}  // namespace hc
+#endif

@@ -1,0 +1,38 @@
+// hc_fno_items.h — the records find-next-overlaps hands to its device form (hc_fno_device.h) and the host-side entry
+// points of that form (hc_api_fno.cpp).  Plain C++: the host code that fills the records builds without HIP.
+#ifndef HC_FNO_ITEMS_H_
+#define HC_FNO_ITEMS_H_
+#include <cstdint>
+#include <functional>
+
+namespace hc {
+
+// One combination, everything the arithmetic needs already looked up (host: ids, lengths, findCliqueIndex offsets).
+//   kind 0 (copied, :44-68):  v = { pos1, pos2, perc, len1, len2 } of the edge
+//   kind 1..3:                v = { e.pos1, e.pos2, i1l, i1r, i2l, i2r, a.len1, a.len2, b.len1, b.len2 }
+struct FnoItem {
+    uint64_t ida, idb;
+    int32_t v[10];
+    uint8_t kind, a_paired, b_paired, e_ord, ori1, ori2, pad[2];
+};
+static_assert(sizeof(FnoItem) == 64, "FnoItem is 64 bytes");
+
+struct FnoRec {  // the 13 columns of one line (perc2 is always "0")
+    uint64_t id1, id2;
+    int32_t pos1, pos2, perc, len1, len2;
+    uint8_t ord2, ori1, ori2, type1, type2, kind, valid, pad;
+};
+static_assert(sizeof(FnoRec) == 48, "FnoRec is 48 bytes");
+
+// HC_FNO=host | device; by default the device takes batches of 200 000 combinations and more when there is one.
+// Throws FatalError{HC_ERR_NO_DEVICE} for HC_FNO=device without a device.
+bool fno_device_wanted(uint64_t n_items);
+// computeOverlapData per item, the std::set<std::string> order and unique, the text: `text_of(bytes)` returns where the
+// text goes; counters[0..3] lines per kind before the unique, counters[4] lines of the text.  false: the device met
+// something the host path has to report (a stop of the reference) or to handle (numbers beyond the keys' range);
+// text_of was not called.  seconds[0..1] (may be null): copy + deduce + sorts + unique + scan, text.
+bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of,
+                         uint64_t counters[5], double* seconds);
+
+}  // namespace hc
+#endif

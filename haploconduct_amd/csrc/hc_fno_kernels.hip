@@ -1,0 +1,318 @@
+// hc_fno_kernels.hip — find-next-overlaps on the device (hc_fno_device.h): one lane per combination deduces its line's
+// columns (computeOverlapData, src/FindNextOverlaps.cpp:351-565) and the line's 256-bit sort key; after four stable
+// radix sorts (least significant 64 bits first) one lane per sorted place drops repeated lines and measures the text;
+// after a scan one lane per line writes it.  Integer work, one float division per percentage (correctly rounded on
+// both sides, -ffp-contract=off).
+#include "hc_fno_device.h"
+
+namespace hc {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// (int)floor(std::max(ov/float(la), ov/float(lb))*100), src/FindNextOverlaps.cpp:375,429,487,549
+__device__ __forceinline__ int perc_max(int ov, int la, int lb) {
+    const float a = (float)ov / (float)la, b = (float)ov / (float)lb;
+    const float m = (a < b ? b : a) * 100.0f;
+    return (int)floorf(m);
+}
+
+struct Induced {
+    int pos1, pos2, perc, len1, len2;
+    uint8_t ord1, ord2, type1, type2;
+};
+
+// 0 = a line, 1 = no line ("failure": trimmed away / should have been merged), 2 = the reference would stop
+__device__ int induced_overlap(const FnoItem& it, Induced& o) {
+    const int e_pos1 = it.v[0], e_pos2 = it.v[1], i1l = it.v[2], i1r = it.v[3], i2l = it.v[4], i2r = it.v[5];
+    const int a1 = it.v[6], a2 = it.v[7], b1 = it.v[8], b2 = it.v[9];
+    const bool ap = it.a_paired != 0, bp = it.b_paired != 0;
+    const int shift1 = (e_pos1 + i1l) - i2l;
+    o.ord1 = shift1 < 0 ? '2' : '1';
+    o.pos1 = shift1 < 0 ? -shift1 : shift1;
+    o.type1 = ap ? 'p' : 's';
+    o.type2 = bp ? 'p' : 's';
+    if (!ap && !bp) {  // :358-385
+        if (!(a1 > 0 && b1 > 0)) return 2;
+        const int len = shift1 < 0 ? b1 : a1;
+        o.len1 = imin(imin(len - o.pos1, a1), b1);
+        o.len2 = 0;
+        o.perc = perc_max(o.len1, a1, b1);
+        o.ord2 = '-';
+        o.pos2 = 0;
+        if (o.pos1 >= len) return 1;
+    } else if (ap != bp) {  // P-S :387-440, S-P :442-486
+        const int P1 = ap ? a1 : b1, P2 = ap ? a2 : b2, S1 = ap ? b1 : a1;
+        if (!(P1 + P2 > 0 && S1 > 0)) return 2;
+        const bool starts_in_pair = ap ? (shift1 >= 0) : (shift1 < 0);
+        if (o.pos1 >= (starts_in_pair ? P1 : S1)) return 1;
+        o.len1 = starts_in_pair ? P1 - o.pos1 : P1;
+        if (ap) o.pos2 = it.e_ord == '1' ? i2r - (i1r + e_pos2) : (e_pos2 + i2r) - i1r;
+        else o.pos2 = it.e_ord == '2' ? i1r - (e_pos2 + i2r) : i1r + e_pos2 - i2r;
+        if (o.pos2 >= S1 || o.pos2 < 0) return 1;
+        o.ord2 = '-';
+        o.len2 = imin(S1 - o.pos2, P2);
+        const int total = o.len1 + o.len2;
+        o.perc = imin(ap ? perc_max(total, P1 + P2, S1) : perc_max(total, S1, P1 + P2), 100);
+    } else {  // P-P :488-547
+        if (o.pos1 >= (shift1 < 0 ? b1 : a1)) return 1;
+        o.len1 = shift1 < 0 ? imin(a1, b1 - o.pos1) : imin(a1 - o.pos1, b1);
+        const int shift2 = it.e_ord == '1' ? (e_pos2 + i1r) - i2r : i1r - (e_pos2 + i2r);
+        if (shift2 < 0) {
+            o.ord2 = o.ord1 == '1' ? '2' : '1';
+            o.pos2 = -shift2;
+            if (o.pos2 >= b2) return 1;
+            o.len2 = imin(a2, b2 - o.pos2);
+        } else {
+            o.ord2 = o.ord1 == '1' ? '1' : '2';
+            o.pos2 = shift2;
+            if (o.pos2 >= a2) return 1;
+            o.len2 = imin(a2 - o.pos2, b2);
+        }
+        o.perc = imin(perc_max(o.len1 + o.len2, a1 + a2, b1 + b2), 100);
+    }
+    if (!(o.perc >= 0 && o.perc <= 100)) return 2;  // :562
+    return 0;
+}
+
+// ---- decimal text <-> order-preserving integers ----------------------------------------------------------------
+// the text of v followed by a tab, read as a number in base 11 with D places: digit d -> d + 1, nothing -> 0
+template <int D>
+__device__ __forceinline__ uint64_t dec_key_unsigned(uint64_t v) {
+    uint8_t dg[20];
+    int nd = 0;
+    do {
+        dg[nd++] = (uint8_t)(v % 10);
+        v /= 10;
+    } while (v);
+    uint64_t key = 0;
+#pragma unroll
+    for (int i = 0; i < D; i++) key = key * 11 + (i < nd ? (uint64_t)dg[nd - 1 - i] + 1 : 0);
+    return key;
+}
+// the same with a sign: base 12, '-' -> 1, digit d -> d + 2, 11 places ("-2147483648")
+__device__ __forceinline__ uint64_t dec_key_signed(int32_t x) {
+    uint8_t ch[11];
+    int n = 0;
+    uint32_t v = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
+    uint8_t dg[10];
+    int nd = 0;
+    do {
+        dg[nd++] = (uint8_t)(v % 10);
+        v /= 10;
+    } while (v);
+    if (x < 0) ch[n++] = 1;
+    for (int i = nd - 1; i >= 0; i--) ch[n++] = (uint8_t)(dg[i] + 2);
+    uint64_t key = 0;
+#pragma unroll
+    for (int i = 0; i < 11; i++) key = key * 12 + (i < n ? ch[i] : 0);
+    return key;
+}
+__device__ __forceinline__ uint32_t digits_u64(uint64_t v) {
+    uint32_t n = 1;
+    while (v >= 10) {
+        v /= 10;
+        n++;
+    }
+    return n;
+}
+__device__ __forceinline__ uint32_t chars_i32(int32_t x) {
+    const uint32_t v = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
+    return digits_u64(v) + (x < 0 ? 1u : 0u);
+}
+__device__ __forceinline__ char* put_u64(char* p, uint64_t v) {
+    char tmp[20];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+__device__ __forceinline__ char* put_i32(char* p, int32_t x) {  // std::to_string(int)
+    if (x < 0) *p++ = '-';
+    return put_u64(p, x < 0 ? 0u - (uint32_t)x : (uint32_t)x);
+}
+
+__global__ __launch_bounds__(kBlock) void fno_deduce_kernel(const FnoItem* __restrict__ items, uint64_t n, uint32_t no_inclusions,
+                                                            FnoRec* __restrict__ rec, uint64_t* __restrict__ k0, uint64_t* __restrict__ k1,
+                                                            uint64_t* __restrict__ k2, uint64_t* __restrict__ k3, uint32_t* __restrict__ iota,
+                                                            unsigned long long* __restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    __shared__ unsigned int tally[4];
+    __shared__ unsigned int status;
+    if (threadIdx.x < 4) tally[threadIdx.x] = 0;
+    if (threadIdx.x == 4) status = 0;
+    __syncthreads();
+    if (i < n) {
+        const FnoItem it = items[i];
+        FnoRec r;
+        r.pad = 0;
+        r.kind = it.kind;
+        r.ori1 = it.ori1;
+        r.ori2 = it.ori2;
+        unsigned bad = 0;
+        bool line = true;
+        if (it.kind == 0) {  // :44-68
+            r.id1 = it.ida;
+            r.id2 = it.idb;
+            r.pos1 = it.v[0];
+            r.pos2 = it.v[1];
+            r.perc = it.v[2];
+            r.len1 = it.v[3];
+            r.len2 = it.v[4];
+            r.ord2 = it.e_ord;
+            r.type1 = it.a_paired ? 'p' : 's';
+            r.type2 = it.b_paired ? 'p' : 's';
+        } else {
+            Induced o;
+            const int what = induced_overlap(it, o);
+            if (what == 2) bad |= (unsigned)kFnoStatusRequire;
+            line = what == 0;
+            const bool fwd = o.ord1 == '1';
+            r.id1 = fwd ? it.ida : it.idb;
+            r.id2 = fwd ? it.idb : it.ida;
+            r.type1 = fwd ? o.type1 : o.type2;
+            r.type2 = fwd ? o.type2 : o.type1;
+            r.pos1 = o.pos1;
+            r.pos2 = o.pos2;
+            r.perc = o.perc;
+            r.len1 = o.len1;
+            r.len2 = o.len2;
+            r.ord2 = o.ord2;
+        }
+        if (line && !(r.ord2 == '-' || r.ord2 == '1' || r.ord2 == '2')) bad |= (unsigned)kFnoStatusRequire;
+        if (line && no_inclusions && r.perc == 100) line = false;
+        if (line && (r.id1 >= 10000000000ull || r.id2 >= 10000000000ull || r.perc < 0 || r.perc > 999)) bad |= (unsigned)kFnoStatusRange;
+        if (bad) line = false;
+        r.valid = line ? 1 : 0;
+        rec[i] = r;
+        iota[i] = (uint32_t)i;
+        if (line) {
+            atomicAdd(&tally[it.kind & 3], 1u);
+            const uint64_t kid1 = dec_key_unsigned<10>(r.id1), kid2 = dec_key_unsigned<10>(r.id2);  // 35 bits each
+            const uint64_t kp1 = dec_key_signed(r.pos1), kp2 = dec_key_signed(r.pos2);             // 40 bits each
+            const uint64_t kl1 = dec_key_signed(r.len1), kl2 = dec_key_signed(r.len2);
+            const uint64_t kpc = dec_key_unsigned<3>((uint64_t)r.perc);                            // 11 bits
+            const uint64_t ord = r.ord2 == '-' ? 0 : (r.ord2 == '1' ? 1 : 2);                       // '-' < '1' < '2'
+            const uint64_t o1 = r.ori1 == '+' ? 0 : 1, o2 = r.ori2 == '+' ? 0 : 1;                  // '+' < '-'
+            const uint64_t t1 = r.type1 == 'p' ? 0 : 1, t2 = r.type2 == 'p' ? 0 : 1;                // 'p' < 's'
+            k3[i] = kid1 << 29 | kid2 >> 6;
+            k2[i] = (kid2 & 63) << 58 | kp1 << 18 | kp2 >> 22;
+            k1[i] = (kp2 & ((1ull << 22) - 1)) << 42 | ord << 40 | o1 << 39 | o2 << 38 | kpc << 27 | kl1 >> 13;
+            k0[i] = (kl1 & 8191) << 51 | kl2 << 11 | t1 << 10 | t2 << 9;
+        } else {  // behind every line
+            k3[i] = ~0ull;
+            k2[i] = ~0ull;
+            k1[i] = ~0ull;
+            k0[i] = ~0ull;
+            if (bad) atomicOr(&status, bad);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && tally[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+    if (threadIdx.x == 4 && status) atomicOr(&counters[4], (unsigned long long)status);
+}
+
+__global__ __launch_bounds__(kBlock) void fno_gather_kernel(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm, uint64_t n,
+                                                            uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = key[perm[i]];
+}
+
+__device__ __forceinline__ bool same_line(const FnoRec& a, const FnoRec& b) {
+    return a.id1 == b.id1 && a.id2 == b.id2 && a.pos1 == b.pos1 && a.pos2 == b.pos2 && a.perc == b.perc && a.len1 == b.len1 && a.len2 == b.len2 &&
+           a.ord2 == b.ord2 && a.ori1 == b.ori1 && a.ori2 == b.ori2 && a.type1 == b.type1 && a.type2 == b.type2;
+}
+
+__global__ __launch_bounds__(kBlock) void fno_mark_kernel(const FnoRec* __restrict__ rec, const uint32_t* __restrict__ perm, uint64_t n,
+                                                          uint64_t* __restrict__ len, unsigned long long* __restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    __shared__ unsigned int lines;
+    if (threadIdx.x == 0) lines = 0;
+    __syncthreads();
+    if (i <= n) {
+        uint64_t bytes = 0;
+        if (i < n) {
+            const FnoRec r = rec[perm[i]];
+            if (r.valid && (i == 0 || !same_line(r, rec[perm[i - 1]]))) {
+                // 12 tabs + newline + ord2, ori1, ori2, "0", type1, type2
+                bytes = 19 + digits_u64(r.id1) + digits_u64(r.id2) + chars_i32(r.pos1) + chars_i32(r.pos2) + chars_i32(r.perc) + chars_i32(r.len1) +
+                        chars_i32(r.len2);
+                atomicAdd(&lines, 1u);
+            }
+        }
+        len[i] = bytes;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && lines) atomicAdd(&counters[5], (unsigned long long)lines);
+}
+
+__global__ __launch_bounds__(kBlock) void fno_format_kernel(const FnoRec* __restrict__ rec, const uint32_t* __restrict__ perm,
+                                                            const uint64_t* __restrict__ len, const uint64_t* __restrict__ off, uint64_t n,
+                                                            char* __restrict__ text) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n || len[i] == 0) return;
+    const FnoRec r = rec[perm[i]];
+    char line[96];  // 2 x 20 + 5 x 11 would be 95 + 19: ids are below 10^10 here, so 2 x 10 + 5 x 11 + 19 = 94
+    char* p = line;
+    p = put_u64(p, r.id1);
+    *p++ = '\t';
+    p = put_u64(p, r.id2);
+    *p++ = '\t';
+    p = put_i32(p, r.pos1);
+    *p++ = '\t';
+    p = put_i32(p, r.pos2);
+    *p++ = '\t';
+    *p++ = (char)r.ord2;
+    *p++ = '\t';
+    *p++ = (char)r.ori1;
+    *p++ = '\t';
+    *p++ = (char)r.ori2;
+    *p++ = '\t';
+    p = put_i32(p, r.perc);
+    *p++ = '\t';
+    *p++ = '0';
+    *p++ = '\t';
+    p = put_i32(p, r.len1);
+    *p++ = '\t';
+    p = put_i32(p, r.len2);
+    *p++ = '\t';
+    *p++ = (char)r.type1;
+    *p++ = '\t';
+    *p++ = (char)r.type2;
+    *p++ = '\n';
+    char* dst = text + off[i];
+    const int m = (int)(p - line);
+    for (int k = 0; k < m; k++) dst[k] = line[k];
+}
+
+inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+}  // namespace
+
+hipError_t fno_deduce(const FnoItem* items, uint64_t n, uint32_t no_inclusions, FnoRec* rec, uint64_t* k0, uint64_t* k1, uint64_t* k2,
+                      uint64_t* k3, uint32_t* iota, unsigned long long* counters, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fno_deduce_kernel, grid_for(n), dim3(kBlock), 0, s, items, n, no_inclusions, rec, k0, k1, k2, k3, iota, counters);
+    return hipGetLastError();
+}
+hipError_t fno_gather_keys(const uint64_t* key, const uint32_t* perm, uint64_t n, uint64_t* out, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fno_gather_kernel, grid_for(n), dim3(kBlock), 0, s, key, perm, n, out);
+    return hipGetLastError();
+}
+hipError_t fno_mark_lines(const FnoRec* rec, const uint32_t* perm, uint64_t n, uint64_t* len, unsigned long long* counters, hipStream_t s) {
+    hipLaunchKernelGGL(fno_mark_kernel, grid_for(n + 1), dim3(kBlock), 0, s, rec, perm, n, len, counters);
+    return hipGetLastError();
+}
+hipError_t fno_format(const FnoRec* rec, const uint32_t* perm, const uint64_t* len, const uint64_t* off, uint64_t n, char* text, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fno_format_kernel, grid_for(n), dim3(kBlock), 0, s, rec, perm, len, off, n, text);
+    return hipGetLastError();
+}
+
+}  // namespace hc

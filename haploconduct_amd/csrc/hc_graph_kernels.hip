@@ -21,6 +21,7 @@
 #include "../../include/hcedge.h"
 #include "hc_device.h"
 #include "hc_graph.h"
+#include "hc_fno_device.h"
 
 namespace hc {
 
@@ -249,6 +250,12 @@ struct IsSet {
     __device__ __forceinline__ bool operator()(const uint32_t& i) const { return f[i] != 0; }
 };
 }  // namespace
+
+// the (64-bit key, 32-bit value) radix sort for other translation units (find-next-overlaps): one instantiation in the library
+hipError_t sort_pairs_u64_u32(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint32_t* v_in, uint32_t* v_out,
+                              uint32_t n, int end_bit, hipStream_t s) {
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, s);
+}
 
 size_t graph_temp_bytes(uint32_t m, uint32_t V) {
     size_t best = 0, b = 0;

@@ -12,29 +12,13 @@
 #include <utility>
 #include <vector>
 
+#include "DefaultInit.h"
 #include "Read.h"
 #include "Types.h"
 
 namespace hc {
 
-// The flat base / quality arrays: bytes that resize() adds are left uninitialised (every one of them is written by the
-// reader right after — zero-filling 300 MB first costs 50 ms on one thread and places every page on its node).
-template <class T>
-struct DefaultInitAllocator : std::allocator<T> {
-    template <class U>
-    struct rebind {
-        using other = DefaultInitAllocator<U>;
-    };
-    using std::allocator<T>::allocator;
-    template <class U>
-    void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
-        ::new ((void*)p) U;
-    }
-    template <class U, class... A>
-    void construct(U* p, A&&... a) {
-        ::new ((void*)p) U(std::forward<A>(a)...);
-    }
-};
+// The flat base / quality arrays: bytes that resize() adds are left uninitialised (DefaultInit.h)
 using ByteVec = std::vector<uint8_t, DefaultInitAllocator<uint8_t>>;
 
 class FastqStorage {

@@ -26,6 +26,8 @@
 #include <vector>
 
 #include "../../../include/hcfno.h"
+#include "../hc_fno_items.h"
+#include "DefaultInit.h"
 #include "Types.h"
 
 namespace hc {
@@ -33,8 +35,9 @@ int set_last_error(int status, const std::string& what);
 }
 
 struct hc_fno_output {
-    std::string text;
+    std::vector<char, hc::DefaultInitAllocator<char>> text;  // sized, then written in full: not zero-filled first
     hc_fno_counters counters;
+    bool on_device = false;
 };
 
 namespace {
@@ -613,6 +616,87 @@ private:
         return p;
     }
 
+    // ---- the device form --------------------------------------------------------------------
+    // The look-ups of deduce() — ids, lengths, findCliqueIndex offsets, orientation signs — stay with the host threads
+    // (they chase the caller's arrays); the arithmetic, the ordering, the unique and the text are the device's.
+    void build_item(const Item& it, hc::FnoItem& o) const {
+        const hc_fno_edge& e = *it.edge;
+        const hc_fno_read &n1 = in_.nodes[e.v1], &n2 = in_.nodes[e.v2];
+        memset(&o, 0, sizeof o);
+        o.ori1 = o.ori2 = '+';
+        if ((in_.flags & HC_FNO_RESOLVE_ORIENTATIONS) && it.nonedge) {  // :35-38
+            o.ori1 = ((e.ori1 != 0) == (n1.orientation != 0)) ? '+' : '-';
+            o.ori2 = ((e.ori2 != 0) == (n2.orientation != 0)) ? '+' : '-';
+        }
+        o.kind = (uint8_t)it.kind;
+        o.e_ord = (uint8_t)e.ord;
+        if (it.kind == kCopied) {  // :44-68
+            FNO_REQUIRE(e.perc >= 0);
+            o.ida = n1.id;
+            o.idb = n2.id;
+            o.v[0] = e.pos1; o.v[1] = e.pos2; o.v[2] = e.perc; o.v[3] = e.len1; o.v[4] = e.len2;
+            o.a_paired = n1.paired != 0;
+            o.b_paired = n2.paired != 0;
+            return;
+        }
+        int i1l = 0, i1r = 0, i2l = 0, i2r = 0;
+        ReadFacts a, b;
+        if (it.kind == kU2SR) {
+            a = facts(n1);
+            o.ida = n1.id;
+        } else {
+            a = facts(in_.srs[it.sr1]);
+            o.ida = in_.srs[it.sr1].id;
+            clique_indices(e.v1, it.sr1, n1.paired, i1l, i1r);
+        }
+        if (it.kind == kV2SR) {
+            b = facts(n2);
+            o.idb = n2.id;
+        } else {
+            b = facts(in_.srs[it.sr2]);
+            o.idb = in_.srs[it.sr2].id;
+            clique_indices(e.v2, it.sr2, n2.paired, i2l, i2r);
+        }
+        o.v[0] = e.pos1; o.v[1] = e.pos2;
+        o.v[2] = i1l; o.v[3] = i1r; o.v[4] = i2l; o.v[5] = i2r;
+        o.v[6] = a.len1; o.v[7] = a.len2; o.v[8] = b.len1; o.v[9] = b.len2;
+        o.a_paired = a.paired;
+        o.b_paired = b.paired;
+    }
+
+    // false: the device met something the host path has to report (a stop of the reference) or to handle (numbers
+    // beyond the keys' range); nothing was written
+    bool deduce_on_device(hc_fno_output& out) {
+        const uint64_t n = items_.size();
+        if (n == 0 || n >= 0x7FFFFFF0ull) return false;
+        const bool timing = getenv("HC_FNO_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        const auto t0 = now();
+        std::unique_ptr<hc::FnoItem[]> h_items(new hc::FnoItem[n]);
+        parallel_chunks(n, threads_, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t i = b; i < e; ++i) build_item(items_[i], h_items[i]);
+        });
+        const auto t1 = now();
+        uint64_t counters[5] = {0, 0, 0, 0, 0};
+        double seconds[2] = {0, 0};
+        auto text_of = [&](uint64_t bytes) {
+            out.text.resize(bytes);
+            return out.text.data();
+        };
+        if (!hc::fno_lines_on_device(h_items.get(), n, (in_.flags & HC_FNO_NO_INCLUSIONS) != 0, text_of, counters, seconds)) return false;
+        memset(&out.counters, 0, sizeof out.counters);
+        out.counters.copied = counters[kCopied];
+        out.counters.u2sr = counters[kU2SR];
+        out.counters.v2sr = counters[kV2SR];
+        out.counters.sr2sr = counters[kSR2SR];
+        out.counters.n_lines = counters[4];
+        out.on_device = true;
+        if (timing)
+            fprintf(stderr, "hc_fno1_run (device): look-ups on the host %.3f s, copy + deduce + 4 sorts + unique + scan %.3f s, text %.3f s\n",
+                    std::chrono::duration<double>(t1 - t0).count(), seconds[0], seconds[1]);
+        return true;
+    }
+
     struct Line {
         const char* p;
         uint32_t n;
@@ -625,6 +709,7 @@ private:
     void deduce_and_emit(hc_fno_output& out) {
         constexpr size_t kMaxLine = 160;  // 2 x 20 digits + 6 x 11 + separators
         const uint64_t n = items_.size();
+        if (hc::fno_device_wanted(n) && deduce_on_device(out)) return;
         const unsigned T = (unsigned)std::min<uint64_t>(threads_, n ? n : 1);
         std::vector<std::unique_ptr<char[]>> arena(T);  // new char[]: not zero-filled, only the bytes written get touched
         std::vector<std::vector<Line>> lines(T);
@@ -896,7 +981,7 @@ private:
         out.text.reserve(total);
         memset(&out.counters, 0, sizeof out.counters);
         for (unsigned t = 0; t < T; ++t) {
-            out.text.append(arena[t].get(), used[t]);
+            out.text.insert(out.text.end(), arena[t].get(), arena[t].get() + used[t]);
             out.counters.n_lines += nlines[t];
         }
         out.counters.candidates = n;
@@ -965,6 +1050,7 @@ int hc_fno_output_write(const hc_fno_output* o, const char* path) {
 }
 
 void hc_fno_output_free(hc_fno_output* o) { delete o; }
+int hc_fno_output_on_device(const hc_fno_output* o) { return o && o->on_device ? 1 : 0; }
 
 int hc_fno_compute_overlap_data(const hc_fno_read* sr1, const hc_fno_read* sr2, const int32_t idx[4], const hc_fno_edge* edge, int32_t* ok,
                                 int32_t out9[9]) {

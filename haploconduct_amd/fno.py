@@ -67,6 +67,7 @@ for _name, (_res, _args) in {
     "hc_fno_output_counters": (C.c_int, [_vp, C.POINTER(hc_fno_counters)]),
     "hc_fno_output_write": (C.c_int, [_vp, C.c_char_p]),
     "hc_fno_output_free": (None, [_vp]),
+    "hc_fno_output_on_device": (C.c_int, [_vp]),
     "hc_fno_compute_overlap_data": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp]),
 }.items():
     _f = getattr(N.lib, _name)
@@ -148,8 +149,13 @@ class Fno3Input:
         return s
 
 
+last_on_device = False  # whether the latest output collected here came from the device form (hc_fno_output_on_device)
+
+
 def _collect(h, out_path):
+    global last_on_device
     try:
+        last_on_device = bool(N.lib.hc_fno_output_on_device(h))
         text, n = _vp(), C.c_uint64()
         N.check(N.lib.hc_fno_output_text(h, C.byref(text), C.byref(n)), "hc_fno_output_text")
         data = C.string_at(text, n.value) if n.value else b""

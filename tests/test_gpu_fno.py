@@ -1,0 +1,93 @@
+"""Find-next-overlaps with its second half on the device (csrc/hc_fno_kernels.hip): computeOverlapData
+per combination, four radix sorts over the lines' 256-bit text-order keys, unique, text.  Must write what the host form
+writes — which tests/test_fno.py pins to the reference's own findNextOverlaps() (fragment-probe goldens) — byte for byte,
+report the same counters, and leave the reference's stops to the host form's diagnosis."""
+import os
+
+import numpy as np
+import pytest
+
+from haploconduct_amd import HcError
+from haploconduct_amd import fno as F
+from tests import _fno as T
+from tests import test_fno as host_tests
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def olib():
+    return T.load_oracle()
+
+
+@pytest.fixture()
+def on_device():
+    os.environ["HC_FNO"] = "device"
+    yield
+    os.environ.pop("HC_FNO", None)
+
+
+def test_goldens_of_the_reference_through_the_device(olib, on_device):
+    # the same golden files, the same assertions, the other route
+    host_tests.test_golden_update_overlap_oracle_and_product(olib)
+    assert F.last_on_device
+    host_tests.test_golden_whole_find_next_overlaps_runs(olib)
+    assert F.last_on_device
+    host_tests.test_golden_whole_runs_with_stored_nonedges(olib)
+    assert F.last_on_device
+    host_tests.test_fno1_sections_contribute(olib)
+    host_tests.test_fno1_first_edge_wins_per_superread_pair(olib)
+    host_tests.test_fno1_nonedge_behind_existing_edge_is_skipped(olib)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_device_matches_oracle_on_random_scenarios(olib, on_device, seed):
+    host_tests.test_fno1_product_matches_oracle(olib, seed)
+    assert F.last_on_device
+
+
+def test_stops_of_the_reference_are_reported_as_by_the_host_form(olib, on_device):
+    host_tests.test_fno1_aborts_where_the_reference_does(olib)
+
+
+def _big(n_nodes, n_srs, n_edges, seed, flags):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fno_bench
+    inp = fno_bench.big_fno1(n_nodes, n_srs, n_edges, seed=seed)
+    inp.flags = flags
+    return inp
+
+
+@pytest.mark.parametrize("seed,flags", [(1, F.RESOLVE_ORIENTATIONS), (2, F.RESOLVE_ORIENTATIONS | F.NO_INCLUSIONS), (3, 0)])
+def test_large_iteration_device_equals_host(seed, flags):
+    """3·10^5 vertices, 7.5·10^4 super-reads, 1.2·10^6 edges and stored non-edges: millions of combinations, repeated lines
+    among them; default routing must pick the device, HC_FNO=host the host threads, and both write the same file."""
+    inp = _big(300000, 75000, 1200000, seed, flags)
+    os.environ["HC_FNO"] = "host"
+    try:
+        want, wc = F.find_next_overlaps(inp)
+        assert not F.last_on_device
+    finally:
+        os.environ.pop("HC_FNO", None)
+    got, gc = F.find_next_overlaps(inp)
+    assert F.last_on_device, "a batch of this size goes to the device by default"
+    assert gc == wc
+    assert got == want
+    assert wc["n_lines"] > 10 ** 6
+    lines = got.split(b"\n")[:-1]
+    assert len(lines) == gc["n_lines"] and all(a < b for a, b in zip(lines[:200000], lines[1:200001]))
+
+
+def test_numbers_beyond_the_keys_fall_to_the_host_form(on_device):
+    """ids of eleven digits and a four-digit percentage of a copied edge do not fit the device's keys: the call still
+    succeeds, on the host threads, with the lines the host form writes."""
+    nodes = np.zeros(3, F.FNO_READ_DTYPE)
+    nodes["id"] = [20000000000, 5, 7]
+    nodes["len1"] = 100
+    edges = np.zeros(2, F.FNO_EDGE_DTYPE)
+    edges["v1"], edges["v2"], edges["score"], edges["pos1"], edges["len1"], edges["perc"], edges["ord"] = [0, 1], [1, 2], 1.0, 10, 90, [90, 1234], ord("-")
+    inp = F.Fno1Input(nodes, np.zeros(0, F.FNO_READ_DTYPE), [], [], edges, new_read_count=30000000000)
+    got, cnt = F.find_next_overlaps(inp)
+    assert not F.last_on_device
+    assert got == b"20000000000\t5\t10\t0\t-\t+\t+\t90\t0\t90\t0\ts\ts\n5\t7\t10\t0\t-\t+\t+\t1234\t0\t90\t0\ts\ts\n" and cnt["copied"] == 2

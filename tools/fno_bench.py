@@ -92,6 +92,7 @@ def main():
     inp = big_fno1(a.nodes, a.srs, a.edges)
     res = {"mode": "fno1", "nodes": a.nodes, "super_reads": a.srs, "graph_edges": a.edges, "nonedges": a.edges // 2, "product_s": {}}
     ref_text = None
+    os.environ["HC_FNO"] = "host"  # the host threads' form at several thread counts ...
     for th in a.threads:
         inp.n_threads = th
         t = time.perf_counter()
@@ -99,7 +100,19 @@ def main():
         res["product_s"][str(th or os.cpu_count())] = round(time.perf_counter() - t, 3)
         assert ref_text is None or text == ref_text
         ref_text = text
+    os.environ.pop("HC_FNO", None)
     res["lines"], res["bytes"] = cnt["n_lines"], len(ref_text)
+    inp.n_threads = 0  # ... and the default routing: the device takes the second half when there is one
+    runs = []
+    for _ in range(3):
+        t = time.perf_counter()
+        text, dcnt = F.find_next_overlaps(inp)
+        runs.append(round(time.perf_counter() - t, 3))
+        if not F.last_on_device:
+            break
+        assert text == ref_text and dcnt == cnt
+    if F.last_on_device:
+        res["device_form_s"] = runs
     if not a.no_oracle:
         from tests import _fno as T
         lib = T.load_oracle()
