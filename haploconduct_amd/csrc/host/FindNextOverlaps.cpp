@@ -271,7 +271,7 @@ private:
     std::vector<uint64_t> n2s_off_;           // nodes_to_SR as CSR
     std::vector<uint32_t> n2s_;
     std::vector<const hc_fno_edge*> work_;  // every edge updateOverlap is called on, in the reference's order
-    std::vector<Item> items_;
+    std::vector<Item, hc::DefaultInitAllocator<Item>> items_;  // sized once, filled by the threads: not zero-filled first
     std::vector<hc_fno_edge> induced_;  // inclusion-induced edges (owned)
     std::vector<uint64_t> adj_off_;     // OverlapGraph::adj_out as CSR over graph_edges (stable by v1)
     std::vector<uint32_t> adj_;
@@ -450,7 +450,17 @@ private:
     // pair of new ids, the first combination it meets (overlaps_found); here every combination is stamped with its
     // place in that order and each hash partition keeps the earliest one per pair.
     void walk() {
+        const bool timing = getenv("HC_FNO_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto lap = [&](const char* what, std::chrono::steady_clock::time_point& since) {
+            if (!timing) return;
+            const auto t = now();
+            fprintf(stderr, "hc_fno1_run: walk: %s %.3f s\n", what, std::chrono::duration<double>(t - since).count());
+            since = t;
+        };
+        auto tw = now();
         collect_work();
+        lap("edges in walk order", tw);
         const uint64_t E = work_.size();
         const unsigned T = (unsigned)std::min<uint64_t>(threads_, E ? E : 1);
         const unsigned P = T;  // partitions
@@ -499,6 +509,7 @@ private:
                 }
             }
         });
+        lap("combinations dealt by pair", tw);
         // per partition: the earliest combination of every pair
         std::vector<std::vector<Item>> winners(P);
         parallel_chunks(P, P, [&](uint64_t pb, uint64_t pe, unsigned) {
@@ -532,12 +543,21 @@ private:
                     if (c) winners[p].push_back(Item{work_[c->edge], c->sr1, c->sr2, c->kind, (uint8_t)(work_[c->edge]->score == 0)});
             }
         });
+        lap("earliest combination per pair", tw);
         size_t total = 0;
         for (auto& d : direct) total += d.size();
         for (auto& w : winners) total += w.size();
-        items_.reserve(total);
-        for (auto& d : direct) items_.insert(items_.end(), d.begin(), d.end());
-        for (auto& w : winners) items_.insert(items_.end(), w.begin(), w.end());
+        items_.resize(total);  // leaves the items uninitialised; every source list is copied to its place by some thread
+        std::vector<const std::vector<Item>*> lists;
+        for (auto& d : direct) lists.push_back(&d);
+        for (auto& w : winners) lists.push_back(&w);
+        std::vector<size_t> at(lists.size() + 1, 0);
+        for (size_t k = 0; k < lists.size(); ++k) at[k + 1] = at[k] + lists[k]->size();
+        parallel_chunks(lists.size(), threads_, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t k = b; k < e; ++k)
+                if (!lists[k]->empty()) memcpy(items_.data() + at[k], lists[k]->data(), lists[k]->size() * sizeof(Item));
+        });
+        lap("one list", tw);
     }
 
     // one line of overlaps.txt (without the newline) into p; returns the end, or nullptr if no line results
@@ -693,7 +713,12 @@ private:
             out.text.resize(bytes);
             return out.text.data();
         };
-        if (!hc::fno_lines_on_device(h_items.get(), n, (in_.flags & HC_FNO_NO_INCLUSIONS) != 0, text_of, counters, seconds)) return false;
+        try {
+            if (!hc::fno_lines_on_device(h_items.get(), n, (in_.flags & HC_FNO_NO_INCLUSIONS) != 0, text_of, counters, seconds)) return false;
+        } catch (const FatalError& e) {
+            if (e.status != HC_ERR_NOMEM) throw;
+            return false;  // a batch beyond the device's memory: the host threads take it
+        }
         memset(&out.counters, 0, sizeof out.counters);
         out.counters.copied = counters[kCopied];
         out.counters.u2sr = counters[kU2SR];
