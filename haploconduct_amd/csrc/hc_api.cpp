@@ -143,6 +143,11 @@ static void free_store(hc_ctx* c) {
         sl.p = nullptr;
         sl.cap = 0;
     }
+    for (auto& sl : c->ingest_scratch) {
+        if (sl.p) (void)hipFree(sl.p);
+        sl.p = nullptr;
+        sl.cap = 0;
+    }
     if (c->d_found) (void)hipFree(c->d_found);
     c->d_found = nullptr;
     c->n_found = 0;
@@ -174,6 +179,7 @@ int hc_destroy(hc_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int t = 0; t < 2; t++) {
         if (c->graph.h_stage[t]) (void)hipHostFree(c->graph.h_stage[t]);
+        if (c->h_ingest[t]) (void)hipHostFree(c->h_ingest[t]);
         if (c->graph.stage_free[t]) (void)hipEventDestroy(c->graph.stage_free[t]);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -7,10 +7,19 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hcedge.h"
 #include "hc_ctx.h"
+#include "hc_fno_device.h"
+#include "hc_sfo_device.h"
+#include "host/Types.h"
+
+namespace hc {
+std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns, long np, uint64_t& n_lines);
+std::string sfo_sorted_to_overlaps(const SfoFlipped* recs, uint64_t n, long ns, long np, uint64_t& n_lines);
+}  // namespace hc
 
 static int fail(int status, const std::string& what) { return hc::set_last_error(status, what); }
 
@@ -312,6 +321,143 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     remember((hc_sfo_rec*)d_r1.p, R);  // the context owns the records now
     d_r1.own = nullptr;
     return HC_OK;
+}
+
+// ---- the SFO ingest straight from the records of hc_find_overlaps ------------------------------------------------------
+int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines) {
+    if (!c || !out_path) return fail(HC_ERR_ARG, "hc_found_to_overlaps: null argument");
+    if (!c->found_valid) return fail(HC_ERR_STATE, "hc_found_to_overlaps: hc_find_overlaps has not been called on this read set");
+    const uint64_t n = c->n_found;
+    const bool timing = getenv("HC_SFO_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    struct Freed {
+        std::vector<void*> dev;
+        void* host = nullptr;
+        ~Freed() {
+            for (void* p : dev) (void)hipFree(p);
+            free(host);
+        }
+    } mem;
+    // Device blocks: the finder's grow-only scratch is idle now and large enough for most of what is needed here; what
+    // it cannot serve comes from a second grow-only set.  (Allocating and freeing 8 GB per call costs ten times the sorts.)
+    std::vector<hc_ctx::Scratch*> idle;
+    for (auto& sl : c->finder_scratch)
+        if (sl.p) idle.push_back(&sl);
+    for (auto& sl : c->ingest_scratch)
+        if (sl.p) idle.push_back(&sl);
+    unsigned n_own = 0;
+    auto dmalloc = [&](size_t bytes, void** p) {
+        const size_t need = bytes ? bytes : 16;
+        int best = -1;
+        for (size_t i = 0; i < idle.size(); i++)
+            if (idle[i] && idle[i]->cap >= need && (best < 0 || idle[i]->cap < idle[(size_t)best]->cap)) best = (int)i;
+        if (best >= 0) {
+            *p = idle[(size_t)best]->p;
+            idle[(size_t)best] = nullptr;
+            return hipSuccess;
+        }
+        while (n_own < 12 && c->ingest_scratch[n_own].p) n_own++;  // an empty slot of the second set
+        if (n_own >= 12) return hipErrorOutOfMemory;
+        hc_ctx::Scratch& sl = c->ingest_scratch[n_own];
+        const hipError_t e = hipMalloc(&sl.p, need);
+        if (e != hipSuccess) {
+            sl.p = nullptr;
+            return e;
+        }
+        sl.cap = need;
+        *p = sl.p;
+        return hipSuccess;
+    };
+    try {
+        HC_HIP(hipSetDevice(c->device));
+        hipStream_t st = c->stream;
+        uint64_t k = 0;
+        std::string text;
+        const double t0 = now();
+        bool sorted_on_device = false;
+        if (n && n < 0x7FFFFFF0ull) {
+            hc::SfoFlipped *d_flip = nullptr, *d_sorted = nullptr;
+            uint64_t *d_k[3] = {nullptr, nullptr, nullptr}, *d_ka = nullptr, *d_kb = nullptr;
+            uint32_t *d_pa = nullptr, *d_pb = nullptr;
+            unsigned long long* d_status = nullptr;
+            void* d_tmp = nullptr;
+            HC_HIP(dmalloc(n * sizeof(hc::SfoFlipped), (void**)&d_flip));
+            HC_HIP(dmalloc(n * sizeof(hc::SfoFlipped), (void**)&d_sorted));
+            for (auto& kk : d_k) HC_HIP(dmalloc(n * 8, (void**)&kk));
+            HC_HIP(dmalloc(n * 8, (void**)&d_ka));
+            HC_HIP(dmalloc(n * 8, (void**)&d_kb));
+            HC_HIP(dmalloc(n * 4, (void**)&d_pa));
+            HC_HIP(dmalloc(n * 4, (void**)&d_pb));
+            HC_HIP(dmalloc(8, (void**)&d_status));
+            size_t tmp_bytes = 0;
+            HC_HIP(hc::sort_pairs_u64_u32(nullptr, tmp_bytes, d_ka, d_kb, d_pa, d_pb, (uint32_t)n, 64, st));
+            HC_HIP(dmalloc(tmp_bytes, &d_tmp));
+            HC_HIP(hipMemsetAsync(d_status, 0, 8, st));
+            HC_HIP(hipStreamSynchronize(st));
+            const double t_alloc = now();
+            HC_HIP(hc::sfo_flip(c->d_found, n, num_singles, num_pairs, d_flip, d_k[0], d_k[1], d_k[2], d_pa, d_status, st));
+            uint32_t *perm = d_pa, *perm_next = d_pb;
+            for (int ch = 0; ch < 3; ch++) {  // least significant 64 bits first; every sort is stable
+                const uint64_t* keys = d_k[ch];
+                if (ch) {
+                    HC_HIP(hc::fno_gather_keys(d_k[ch], perm, n, d_ka, st));
+                    keys = d_ka;
+                }
+                size_t b = tmp_bytes;
+                HC_HIP(hc::sort_pairs_u64_u32(d_tmp, b, keys, d_kb, perm, perm_next, (uint32_t)n, 64, st));
+                std::swap(perm, perm_next);
+            }
+            HC_HIP(hc::sfo_gather(d_flip, perm, n, d_sorted, st));
+            unsigned long long status = 0;
+            HC_HIP(hipMemcpyAsync(&status, d_status, 8, hipMemcpyDeviceToHost, st));
+            // the page-locked ring the sorted records come back through (kept with the context)
+            const uint64_t ring = 2u << 20;  // records per buffer of the ring: 64 MiB
+            uint64_t chunk = ring;            // records per copy (HC_SFO_CHUNK: test knob, small chunks on small inputs)
+            if (const char* e = getenv("HC_SFO_CHUNK")) chunk = std::min<uint64_t>(ring, std::max<uint64_t>(1, strtoull(e, nullptr, 10)));
+            if (!c->h_ingest[0]) {
+                for (int t = 0; t < 2; t++) HC_HIP(hipHostMalloc(&c->h_ingest[t], ring * sizeof(hc::SfoFlipped), hipHostMallocDefault));
+                c->h_ingest_cap = ring * sizeof(hc::SfoFlipped);
+            }
+            HC_HIP(hipStreamSynchronize(st));
+            const double t1 = now();
+            if (!status) {
+                // copy of chunk j + 1 beside the matching of chunk j
+                hc::SfoSortedMatcher matcher((long)num_singles, (long)num_pairs);
+                const uint64_t n_chunks = (n + chunk - 1) / chunk;
+                auto count_of = [&](uint64_t j) { return std::min(chunk, n - j * chunk); };
+                HC_HIP(hipMemcpyAsync(c->h_ingest[0], d_sorted, count_of(0) * sizeof(hc::SfoFlipped), hipMemcpyDeviceToHost, st));
+                for (uint64_t j = 0; j < n_chunks; j++) {
+                    HC_HIP(hipStreamSynchronize(st));  // chunk j has arrived
+                    if (j + 1 < n_chunks)
+                        HC_HIP(hipMemcpyAsync(c->h_ingest[(j + 1) & 1], d_sorted + (j + 1) * chunk, count_of(j + 1) * sizeof(hc::SfoFlipped),
+                                              hipMemcpyDeviceToHost, st));
+                    matcher.feed((const hc::SfoFlipped*)c->h_ingest[j & 1], count_of(j));
+                }
+                const double t2 = now();
+                text = matcher.finish(k);
+                sorted_on_device = true;
+                if (timing)
+                    fprintf(stderr, "hc_found_to_overlaps: device blocks %.3f s, flip + 3 sorts + gather on the device %.3f s, copy + match %.3f s, stitch %.3f s\n",
+                            t_alloc - t0, t1 - t_alloc, t2 - t1, now() - t2);
+            }
+        }
+        if (!sorted_on_device) {  // nothing found, an id or a number the device's keys do not hold: the host path sorts, and reports
+            mem.host = malloc(n ? n * sizeof(hc_sfo_rec) : 16);
+            if (!mem.host) return fail(HC_ERR_NOMEM, "hc_found_to_overlaps: out of host memory");
+            if (n) HC_HIP(hipMemcpy(mem.host, c->d_found, n * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
+            text = hc::sfo_records_to_overlaps((const hc_sfo_rec*)mem.host, n, (long)num_singles, (long)num_pairs, k);
+        }
+        FILE* o = fopen(out_path, "wb");
+        if (!o) return fail(HC_ERR_IO, std::string("cannot write ") + out_path);
+        const size_t w = text.empty() ? 0 : fwrite(text.data(), 1, text.size(), o);
+        if (fclose(o) != 0 || w != text.size()) return fail(HC_ERR_IO, std::string("short write to ") + out_path);
+        if (n_lines) *n_lines = k;
+        return HC_OK;
+    } catch (const hc::FatalError& e) {
+        return fail(e.status, e.what);
+    } catch (const std::bad_alloc&) {
+        return fail(HC_ERR_NOMEM, "hc_found_to_overlaps: out of host memory");
+    }
 }
 
 }  // extern "C"

@@ -1,0 +1,24 @@
+// hc_sfo_device.h — the SFO ingest's flip + sort on the device: the records of hc_find_overlaps are already there, and the
+// script's `sort` (four numeric keys, then the rest of the line bytewise, LC_ALL=C) is a radix sort over a 192-bit key
+// once every later column is mapped to the integer that orders like its decimal text.
+#ifndef HC_SFO_DEVICE_H_
+#define HC_SFO_DEVICE_H_
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/hcedge.h"
+#include "hc_sfo_items.h"
+
+namespace hc {
+
+enum : unsigned long long {
+    kSfoStatusId = 1,    // an SFO id outside --num_singles / --num_pairs: the host path reports it
+    kSfoStatusRange = 2  // a number the keys do not hold (|overhang| or overlap length >= 10^7, K >= 10^4): the host path sorts
+};
+hipError_t sfo_flip(const hc_sfo_rec* in, uint64_t n, uint64_t ns, uint64_t np, SfoFlipped* out, uint64_t* k0, uint64_t* k1, uint64_t* k2,
+                    uint32_t* iota, unsigned long long* status, hipStream_t s);
+hipError_t sfo_gather(const SfoFlipped* in, const uint32_t* perm, uint64_t n, SfoFlipped* out, hipStream_t s);
+
+}  // namespace hc
+#endif

@@ -23,6 +23,7 @@
 #include <sys/mman.h>
 
 #include "../../../include/hcedge_host.h"
+#include "../hc_sfo_items.h"
 #include "Types.h"
 
 namespace hc {
@@ -594,16 +595,21 @@ struct BucketResult {
     FatalError error{0, ""};
 };
 
-void match_bucket(const BRec* r, size_t n, long ns, long np, BucketResult& out) {
+template <typename Get>  // get(i): the i-th record of the bucket, in sorted order
+void match_bucket(Get get, size_t n, long ns, long np, BucketResult& out) {
     std::vector<BRec> cands;
     Emitter* em = &out.before;
+    BRec prev{};
     for (size_t i = 0; i < n; i++) {
-        if (i && brec_same(r[i], r[i - 1])) continue;  // uniq
-        if (r[i].id0 == r[i].id1) continue;             // self-overlap, :69-70
-        const bool pa = is_paired(r[i].id0, ns, np), pb = is_paired(r[i].id1, ns, np);
+        const BRec r = get(i);
+        const bool repeated = i && brec_same(r, prev);
+        prev = r;
+        if (repeated) continue;       // uniq
+        if (r.id0 == r.id1) continue;  // self-overlap, :69-70
+        const bool pa = is_paired(r.id0, ns, np), pb = is_paired(r.id1, ns, np);
         if (!pa && !pb) {  // :79-85
             em->cur.clear();
-            put_ss(em->cur, s_s_overlap(to_sfo(r[i])));
+            put_ss(em->cur, s_s_overlap(to_sfo(r)));
             em->line(em->cur);
             continue;
         }
@@ -613,13 +619,51 @@ void match_bucket(const BRec* r, size_t n, long ns, long np, BucketResult& out) 
             out.pb = pb;
             em = &out.after;
         }
-        if (!cands.empty() && (cands[0].id0 != r[i].id0 || cands[0].id1 != r[i].id1)) {
+        if (!cands.empty() && (cands[0].id0 != r.id0 || cands[0].id1 != r.id1)) {
             em->match_group(cands, pa, pb);
             cands.clear();
         }
-        cands.push_back(r[i]);
+        cands.push_back(r);
     }
     out.open.swap(cands);
+}
+
+// the open group of a bucket travels to the next bucket that holds a non-single record and is matched there
+std::string stitch(std::vector<BucketResult>& res, uint64_t& n_lines) {
+    std::string out;
+    n_lines = 0;
+    {
+        size_t bytes = 0;
+        for (const BucketResult& r : res) bytes += r.before.text.size() + r.after.text.size();
+        out.reserve(bytes + bytes / 16);
+    }
+    std::vector<BRec> open;
+    for (BucketResult& r : res) {
+        if (r.error.status) throw r.error;
+        out += r.before.text;
+        n_lines += r.before.n_lines;
+        if (r.has_paired) {
+            Emitter em;
+            em.match_group(open, r.pa, r.pb);
+            out += em.text;
+            n_lines += em.n_lines;
+            open.swap(r.open);
+        }
+        out += r.after.text;
+        n_lines += r.after.n_lines;
+    }  // the group open at the very end is never matched (:63-103)
+    return out;
+}
+
+void run_workers(unsigned count, const std::function<void(unsigned)>& body) {
+    if (count <= 1) {
+        body(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < count; t++) th.emplace_back(body, t);
+    body(0);
+    for (auto& x : th) x.join();
 }
 
 }  // namespace
@@ -730,7 +774,10 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
                     const auto ta = std::chrono::steady_clock::now();
                     sort_bucket(sorted + start[b], start[b + 1] - start[b], scratch);
                     const auto tb = std::chrono::steady_clock::now();
-                    match_bucket(sorted + start[b], start[b + 1] - start[b], ns, np, res[b]);
+                    {
+                        const BRec* base = sorted + start[b];
+                        match_bucket([base](size_t i) -> const BRec& { return base[i]; }, start[b + 1] - start[b], ns, np, res[b]);
+                    }
                     sort_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(tb - ta).count();
                     match_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tb).count();
                 } catch (const FatalError& e) {
@@ -740,34 +787,118 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
         });
     }
     // 4. stitch: the open group travels to the next bucket that holds a non-single record and is matched there
-    std::string out;
-    n_lines = 0;
-    {
-        size_t bytes = 0;
-        for (const BucketResult& r : res) bytes += r.before.text.size() + r.after.text.size();
-        out.reserve(bytes + bytes / 16);
-    }
     const auto t2 = std::chrono::steady_clock::now();
-    std::vector<BRec> open;
-    for (BucketResult& r : res) {
-        if (r.error.status) throw r.error;
-        out += r.before.text;
-        n_lines += r.before.n_lines;
-        if (r.has_paired) {
-            Emitter em;
-            em.match_group(open, r.pa, r.pb);
-            out += em.text;
-            n_lines += em.n_lines;
-            open.swap(r.open);
-        }
-        out += r.after.text;
-        n_lines += r.after.n_lines;
-    }  // the group open at the very end is never matched (:63-103)
+    std::string out = stitch(res, n_lines);
     if (getenv("HC_SFO_TIMING"))
         fprintf(stderr, "sfo_records_to_overlaps: flip + partition %.3f s, sort + match %.3f s (thread-seconds: sort %.3f, match %.3f), stitch %.3f s (%u buckets, %u threads)\n",
                 std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(), sort_ns.load() * 1e-9, match_ns.load() * 1e-9,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count(), B, T);
     return out;
+}
+
+// The same from records the device has flipped and sorted already (hc_found_to_overlaps): only the matching is left.
+// The sorted run arrives in chunks; a chunk (behind what the previous one left over) is cut where the pair (id0, id1)
+// changes — a group of paired candidates and a run of repeated records never straddle a cut —, the pieces are matched on
+// their own by the threads, and the results are stitched at the end as above.  What follows a chunk's last cut waits for
+// the next chunk.
+struct SfoSortedMatcher::Impl {
+    long ns, np;
+    unsigned threads;
+    std::vector<SfoFlipped> carry;
+    std::vector<BucketResult> res;
+    double match_s = 0;
+
+    BRec brec(const SfoFlipped& f) const {
+        BRec r;
+        r.id0 = (uint32_t)original_id((long)f.s0, ns, np);
+        r.id1 = (uint32_t)original_id((long)f.s1, ns, np);
+        r.s0 = f.s0; r.s1 = f.s1;
+        r.oha = f.oha; r.ohb = f.ohb;
+        r.ola = f.ola; r.olb = f.olb; r.k = f.k;
+        r.ori = f.inverted ? 'I' : 'N';
+        return r;
+    }
+    bool same_pair(const SfoFlipped& x, const SfoFlipped& y) const {
+        return original_id((long)x.s0, ns, np) == original_id((long)y.s0, ns, np) && original_id((long)x.s1, ns, np) == original_id((long)y.s1, ns, np);
+    }
+    // the records [0, total) of carry followed by recs, cut into pieces and matched
+    void match(const SfoFlipped* recs, uint64_t total) {
+        if (!total) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        const uint64_t nc = carry.size();
+        auto at = [&](uint64_t i) -> const SfoFlipped& { return i < nc ? carry[i] : recs[i - nc]; };
+        uint64_t P = std::min<uint64_t>((uint64_t)threads * 4, total / 20000 + 1);
+        if (const char* e = getenv("HC_SFO_BUCKETS")) P = (uint64_t)std::max(1, atoi(e));
+        if (P > 4096) P = 4096;
+        std::vector<uint64_t> start(P + 1, total);
+        start[0] = 0;
+        for (uint64_t b = 1; b < P; b++) {
+            uint64_t cut = std::max(total * b / P, start[b - 1]);
+            while (cut > 0 && cut < total && same_pair(at(cut), at(cut - 1))) cut++;
+            start[b] = cut;
+        }
+        const size_t first = res.size();
+        res.resize(first + P);
+        std::atomic<uint64_t> next{0};
+        run_workers((unsigned)std::min<uint64_t>(threads, P), [&](unsigned) {
+            for (;;) {
+                const uint64_t b = next.fetch_add(1);
+                if (b >= P) return;
+                try {
+                    const uint64_t base = start[b];
+                    match_bucket([&, base](size_t i) { return brec(at(base + i)); }, start[b + 1] - start[b], ns, np, res[first + b]);
+                } catch (const FatalError& e) {
+                    res[first + b].error = e;
+                }
+            }
+        });
+        match_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+SfoSortedMatcher::SfoSortedMatcher(long num_singles, long num_pairs) : impl_(new Impl) {
+    impl_->ns = num_singles;
+    impl_->np = num_pairs;
+    unsigned T = std::thread::hardware_concurrency();
+    if (T == 0) T = 1;
+    if (T > 32) T = 32;
+    impl_->threads = T;
+}
+SfoSortedMatcher::~SfoSortedMatcher() = default;
+
+void SfoSortedMatcher::feed(const SfoFlipped* recs, uint64_t n) {
+    Impl& m = *impl_;
+    if (!n) return;
+    // the last cut of this chunk: everything behind it belongs to a pair the next chunk may continue
+    uint64_t e = n;
+    while (e > 0 && m.same_pair(recs[e - 1], recs[n - 1])) e--;
+    if (e == 0 && !m.carry.empty() && !m.same_pair(m.carry.back(), recs[0])) {
+        m.match(recs, m.carry.size());  // the carry ends where this chunk starts a new pair
+        m.carry.clear();
+    }
+    if (e > 0) {
+        m.match(recs, m.carry.size() + e);
+        m.carry.clear();
+    }
+    m.carry.insert(m.carry.end(), recs + e, recs + n);
+}
+
+std::string SfoSortedMatcher::finish(uint64_t& n_lines) {
+    Impl& m = *impl_;
+    m.match(nullptr, m.carry.size());
+    m.carry.clear();
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string out = stitch(m.res, n_lines);
+    if (getenv("HC_SFO_TIMING"))
+        fprintf(stderr, "sorted SFO records: matching %.3f s (%zu pieces, %u threads), stitch %.3f s\n", m.match_s, m.res.size(), m.threads,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return out;
+}
+
+std::string sfo_sorted_to_overlaps(const SfoFlipped* recs, uint64_t n, long ns, long np, uint64_t& n_lines) {
+    SfoSortedMatcher m(ns, np);
+    m.feed(recs, n);
+    return m.finish(n_lines);
 }
 
 }  // namespace hc

@@ -269,6 +269,13 @@ class EdgeScorer:
             N.check(N.lib.hc_find_overlaps(self._ctx, err_rate, min_overlap, flags, out.ctypes.data, out.size, C.byref(n)), "hc_find_overlaps")
         return out[: n.value]
 
+    def found_to_overlaps(self, out_path, num_singles, num_pairs):
+        """hc_found_to_overlaps: the SFO ingest (scripts/sfo2overlaps.py) straight from the records the last find_overlaps
+        left on the device — flip and sort there, matching on the host threads.  Returns the number of overlap lines."""
+        n = C.c_uint64()
+        N.check(N.lib.hc_found_to_overlaps(self._ctx, str(out_path).encode(), int(num_singles), int(num_pairs), C.byref(n)), "hc_found_to_overlaps")
+        return int(n.value)
+
     def score_pack_device(self, d_in_ptr, n, d_out_ptr, cap, base_index, d_payload_ptr, stream=None, fmt=REC_FULL):
         """hc_score_pack_device: scoring + the collection payload in one kernel (rows unordered, count in row 0)."""
         N.check(N.lib.hc_score_pack_device(self._ctx, fmt, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), cap, base_index,

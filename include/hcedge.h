@@ -264,6 +264,12 @@ typedef struct hc_sfo_rec {
  * fetching with a second, identical call computes once. */
 int hc_find_overlaps(hc_ctx* ctx, double err_rate, uint32_t min_overlap, uint32_t flags, hc_sfo_rec* out, uint64_t cap,
                      uint64_t* n_out);
+/* The SFO ingest (scripts/sfo2overlaps.py --in --out --num_singles --num_pairs; hcedge_host.h: hc_sfo_records_to_overlaps)
+ * straight from the records the last hc_find_overlaps left on the device: the script's flip (:112-122) and its
+ * `sort -k1,1n -k2,2n -k3,3n -k4,4n` (whole line as last resort, LC_ALL=C) run there as three radix sorts over a 192-bit
+ * key, the sorted records come back once, the host threads match the paired candidates and write the 13-column overlaps
+ * file.  Same bytes as hc_host_write_sfo + hc_sfo2overlaps on those records.  *n_lines = overlap lines written. */
+int hc_found_to_overlaps(hc_ctx* ctx, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines);
 
 /* hc_compact_device + hc_pack_rows_device in one call, with the count travelling inside the payload: d_payload is
  * (cap + 1) rows; row 0 = { index = *d_count, x1 = x2 = 0, mm = 0, n_cls = 0 }, rows 1.. as hc_pack_rows_device writes

@@ -244,3 +244,54 @@ def test_real_reads_to_graph(oracle, tmp_path):
     compare_edges(got, want, "HIP stage vs the reference's own code on real reads")
     assert (out / "nonedge_overlaps.txt").read_text() == rnonedge
     assert cnt["inclusion_count"] == rcounters[0] and cnt["dup_count"] == rcounters[1] and len(redges) > 200
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_ingest_from_the_device_records_writes_the_same_file(tmp_path, case):
+    """hc_found_to_overlaps (flip + the script's sort on the device, matching on the host) against hc_sfo_records_to_overlaps
+    on the fetched records (which tests/test_sfo_ingest.py pins to the reference's own scripts/sfo2overlaps.py): singles,
+    pairs and both, reversals, mismatches, repeats; one, a few and many pieces of the sorted run."""
+    kw = [dict(n_single=0, n_pair=700, glen=2500, lo=120, hi=150, err=0.0),
+          dict(n_single=900, n_pair=0, glen=2500, lo=100, hi=300, err=0.01),
+          dict(n_single=300, n_pair=500, glen=2500, lo=100, hi=200, err=0.01),
+          dict(n_single=200, n_pair=600, glen=1500, lo=100, hi=160, err=0.02, repeat=True),
+          dict(n_single=50, n_pair=900, glen=3000, lo=140, hi=150, err=0.0, rc_frac=0.0),
+          dict(n_single=400, n_pair=400, glen=2000, lo=90, hi=250, err=0.02, n_rate=0.002)][case]
+    reads = make_reads(100 + case, **kw)
+    n_single, n_pairs = kw["n_single"], kw["n_pair"]
+    err, t = (0.0, 60) if kw["err"] == 0.0 else (0.03, 70)
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        recs = sc.find_overlaps(err, t)
+        assert recs.size > 500
+        want_n = host.sfo_records_to_overlaps(recs, str(tmp_path / "want.txt"), n_single, n_pairs)
+        want = (tmp_path / "want.txt").read_bytes()
+        assert want_n == want.count(b"\n") and want_n > 50
+        # pieces per chunk of the sorted run, records per chunk (the default takes these inputs in one chunk; 1 and 3: nearly
+        # every group of paired candidates straddles a chunk border and waits in the carry)
+        for pieces, chunk in ((None, None), ("1", None), ("7", None), ("200", None), (None, "1"), (None, "3"), ("3", "1000"), (None, "4096")):
+            if pieces:
+                os.environ["HC_SFO_BUCKETS"] = pieces
+            if chunk:
+                os.environ["HC_SFO_CHUNK"] = chunk
+            try:
+                got_n = sc.found_to_overlaps(tmp_path / "got.txt", n_single, n_pairs)
+            finally:
+                os.environ.pop("HC_SFO_BUCKETS", None)
+                os.environ.pop("HC_SFO_CHUNK", None)
+            assert got_n == want_n and (tmp_path / "got.txt").read_bytes() == want, (pieces, chunk)
+        # ids that do not fit --num_singles / --num_pairs: the host path's diagnosis
+        if n_pairs:
+            with pytest.raises(hc.HcError) as ei:
+                sc.found_to_overlaps(tmp_path / "bad.txt", n_single, n_pairs // 2)
+            with pytest.raises(hc.HcError) as ej:
+                host.sfo_records_to_overlaps(recs, str(tmp_path / "bad2.txt"), n_single, n_pairs // 2)
+            assert ei.value.status == ej.value.status
+
+
+def test_ingest_from_the_device_needs_found_records():
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(make_reads(7, n_single=50, n_pair=0, glen=600, lo=100, hi=150, err=0.0))
+        with pytest.raises(hc.HcError):
+            sc.found_to_overlaps("/tmp/never_written.txt", 50, 0)
+

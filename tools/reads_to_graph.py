@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--err", type=float, default=0.0)
     ap.add_argument("--min-overlap", type=int, default=90)
     ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--host-ingest", action="store_true", help="fetch the SFO records and run the whole ingest on the host threads")
     a = ap.parse_args()
     import bench
     import haploconduct_amd as hc
@@ -37,11 +38,19 @@ def main():
         sc.set_reads(reads)
         t["store"] = time.perf_counter() - t0
         t0 = time.perf_counter()
-        recs = sc.find_overlaps(a.err, a.min_overlap)
-        t["find_overlaps"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    n_lines = host.sfo_records_to_overlaps(recs, d + "overlaps.txt", n_single, n_pairs)  # == write_sfo + sfo2overlaps
-    t["sfo_records_to_overlaps"] = time.perf_counter() - t0
+        if a.host_ingest:  # the records fetched, flipped and sorted by the host threads
+            recs = sc.find_overlaps(a.err, a.min_overlap)
+            n_recs = recs.size
+            t["find_overlaps"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            n_lines = host.sfo_records_to_overlaps(recs, d + "overlaps.txt", n_single, n_pairs)  # == write_sfo + sfo2overlaps
+            t["sfo_records_to_overlaps"] = time.perf_counter() - t0
+        else:  # the records stay on the device: flip + sort there, the sorted records come back once for the matching
+            n_recs = sc.find_overlaps(a.err, a.min_overlap, count_only=True)
+            t["find_overlaps"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            n_lines = sc.found_to_overlaps(d + "overlaps.txt", n_single, n_pairs)
+            t["found_to_overlaps"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     kw = dict(singles=None if paired else d + "singles.fastq", paired1=d + "p1.fastq" if paired else None,
               paired2=d + "p2.fastq" if paired else None, overlaps=d + "overlaps.txt", output_dir=d)
@@ -51,7 +60,7 @@ def main():
         ec.construct_edges()
         t["construct_edges"] = time.perf_counter() - t0
         edges = ec.edge_count()
-    print(json.dumps({"workload": cfg.get("workload", a.workload), "sequences": int(reads.n_seq), "sfo_records": int(recs.size),
+    print(json.dumps({"workload": cfg.get("workload", a.workload), "sequences": int(reads.n_seq), "sfo_records": int(n_recs),
                       "overlap_lines": int(n_lines), "edges": int(edges), "seconds": {k: round(v, 4) for k, v in t.items()},
                       "total_s": round(sum(t.values()), 3)}))
     import shutil
