@@ -322,7 +322,7 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
     return rec, reads, cand, settings
 
 
-def stage_end_to_end(reads, cand, settings, threads, reps=2):
+def stage_end_to_end(reads, cand, settings, threads, reps=4):
     """text overlaps file + FASTQ in -> populated OverlapGraph in sortEdges order + nonedge_overlaps.txt
     out, through the host mirror (hc_ec_open, hc_ec_construct_edges_sorted) on this box; files in a scratch directory."""
     import shutil
