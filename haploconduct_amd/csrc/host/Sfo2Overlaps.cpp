@@ -757,6 +757,10 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
     bucket.reset();
     const auto t1 = std::chrono::steady_clock::now();
     // 3. sort and match every bucket on its own
+    // (HC_SFO_VIA_MATCHER=<records per chunk>, test knob: only sort here, then hand the sorted run to the chunk-fed matcher
+    // of hc_found_to_overlaps, which otherwise needs a device to be reached)
+    const char* via_env = getenv("HC_SFO_VIA_MATCHER");
+    const bool via_matcher = via_env != nullptr;
     std::vector<BucketResult> res(B);
     std::atomic<uint64_t> sort_ns{0}, match_ns{0};  // summed over the threads (HC_SFO_TIMING)
     {
@@ -774,7 +778,7 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
                     const auto ta = std::chrono::steady_clock::now();
                     sort_bucket(sorted + start[b], start[b + 1] - start[b], scratch);
                     const auto tb = std::chrono::steady_clock::now();
-                    {
+                    if (!via_matcher) {
                         const BRec* base = sorted + start[b];
                         match_bucket([base](size_t i) -> const BRec& { return base[i]; }, start[b + 1] - start[b], ns, np, res[b]);
                     }
@@ -785,6 +789,23 @@ std::string sfo_records_to_overlaps(const hc_sfo_rec* recs, uint64_t n, long ns,
                 }
             }
         });
+    }
+    if (via_matcher) {
+        for (const BucketResult& r : res)
+            if (r.error.status) throw r.error;
+        const uint64_t chunk = std::max<uint64_t>(1, strtoull(via_env, nullptr, 10));
+        SfoSortedMatcher m(ns, np);
+        std::vector<SfoFlipped> buf;
+        for (uint64_t at = 0; at < n; at += chunk) {
+            const uint64_t c = std::min(chunk, n - at);
+            buf.resize(c);
+            for (uint64_t i = 0; i < c; i++) {
+                const BRec& r = sorted[at + i];
+                buf[i] = SfoFlipped{r.s0, r.s1, (int32_t)r.oha, (int32_t)r.ohb, r.ola, r.olb, r.k, r.ori == 'I' ? 1u : 0u};
+            }
+            m.feed(buf.data(), c);
+        }
+        return m.finish(n_lines);
     }
     // 4. stitch: the open group travels to the next bucket that holds a non-single record and is matched there
     const auto t2 = std::chrono::steady_clock::now();

@@ -165,6 +165,13 @@ raw = b"".join(struct.pack("<IIiiIIII", rng.randrange(120), rng.randrange(120), 
 nl = C.c_uint64()
 host.hc_sfo_records_to_overlaps(raw, 30000, (d + "c.out").encode(), 40, 40, C.byref(nl))
 assert host.hc_sfo_records_to_overlaps(raw, 30000, (d + "c.out").encode(), 10, 10, C.byref(nl)) != 0  # ids out of range: an error
+# ... and the chunk-fed matcher behind a sorted run (what hc_found_to_overlaps uses after the device's sort): same file
+want_c = open(d + "c.out", "rb").read() if host.hc_sfo_records_to_overlaps(raw, 30000, (d + "c.out").encode(), 40, 40, C.byref(nl)) == 0 else None
+for chunk in ("1", "5", "4096"):
+    os.environ["HC_SFO_VIA_MATCHER"] = chunk
+    assert host.hc_sfo_records_to_overlaps(raw, 30000, (d + "c2.out").encode(), 40, 40, C.byref(nl)) == 0
+    assert want_c is not None and open(d + "c2.out", "rb").read() == want_c
+del os.environ["HC_SFO_VIA_MATCHER"]
 del os.environ["HC_SFO_BUCKETS"]
 
 # 3c. find-next-overlaps on the scenarios the parent process saved (well-formed and hostile ones)

@@ -18,13 +18,16 @@ from sfo2overlaps_oracle import sfo2overlaps as oracle_sfo2overlaps  # noqa: E40
 CASES = sorted(glob.glob(os.path.join(HERE, "golden", "sfo", "*.sfo")))
 
 
-@pytest.fixture(autouse=True, params=["auto", "general"])
+@pytest.fixture(autouse=True, params=["auto", "general", "matcher 1", "matcher 7", "matcher 1000"])
 def ingest_route(request, monkeypatch):
     """Files of the plain shape (eight fields, single tabs, canonical numbers) are parsed into records and run through
     the partitioned records path; every other file — and every file under HC_SFO_TEXT_GENERAL — through the line-keeping
-    general path.  Every test below runs both ways."""
+    general path.  "matcher k": the records path only sorts and hands the sorted run, k records at a time, to the chunk-fed
+    matcher hc_found_to_overlaps uses behind the device's sort (HC_SFO_VIA_MATCHER).  Every test below runs all ways."""
     if request.param == "general":
         monkeypatch.setenv("HC_SFO_TEXT_GENERAL", "1")
+    if request.param.startswith("matcher"):
+        monkeypatch.setenv("HC_SFO_VIA_MATCHER", request.param.split()[1])
     monkeypatch.setenv("HC_SFO_BUCKETS", "5")  # several buckets even on the small fixtures
     return request.param
 
