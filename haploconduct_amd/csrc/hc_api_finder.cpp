@@ -84,7 +84,16 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     uint32_t max_len = 0;
     for (const hc::SeqRef& r : c->seq_refs) max_len = r.len > max_len ? r.len : max_len;
     if (max_len >= (1u << 14)) return fail(HC_ERR_ARG, "hc_find_overlaps: sequences of 16384 symbols or more are not supported");
-    if (n_seq < 2 || max_len < min_overlap) return HC_OK;
+    if (n_seq < 2 || max_len < min_overlap) {  // nothing can overlap: an empty result, remembered like any other
+        if (c->d_found) (void)hipFree(c->d_found);
+        c->d_found = nullptr;
+        c->n_found = 0;
+        c->found_err = err_rate;
+        c->found_min = min_overlap;
+        c->found_flags = flags & ~HC_FIND_RECOMPUTE;
+        c->found_valid = true;
+        return HC_OK;
+    }
     HC_HIP(hipSetDevice(c->device));
     const bool timing = getenv("HC_FIND_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

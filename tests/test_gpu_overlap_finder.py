@@ -295,3 +295,16 @@ def test_ingest_from_the_device_needs_found_records():
         with pytest.raises(hc.HcError):
             sc.found_to_overlaps("/tmp/never_written.txt", 50, 0)
 
+
+def test_ingest_from_the_device_with_nothing_found(tmp_path):
+    rng = np.random.default_rng(5)
+    n = 6
+    bases = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n * 120)
+    reads = hc.ReadSet(bases, np.full(bases.size, ord("I"), np.uint8), np.arange(n + 1, dtype=np.uint64) * 120, np.arange(n + 1, dtype=np.uint32),
+                       np.arange(n, dtype=np.uint64))
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        assert sc.find_overlaps(0.0, 60, count_only=True) == 0
+        assert sc.found_to_overlaps(tmp_path / "none.txt", n, 0) == 0
+    assert (tmp_path / "none.txt").read_bytes() == b""
+
