@@ -32,6 +32,14 @@
 #include "hc_device.h"
 #include "hc_resolve.h"
 
+// cache policy bits of the cooperative fetch's row loads (experiment: 2 = non-temporal)
+#ifndef HC_COOP_AUX_A
+#define HC_COOP_AUX_A 0
+#endif
+#ifndef HC_COOP_AUX_B
+#define HC_COOP_AUX_B 0
+#endif
+
 namespace hc {
 
 // ---------------------------------------------------------------------------
@@ -423,8 +431,8 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool on = at < lim[j];
-            nA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] + at : oob, 0, 0);
-            nB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] + at : oob, 0, 0);
+            nA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] + at : oob, 0, HC_COOP_AUX_A);
+            nB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] + at : oob, 0, HC_COOP_AUX_B);
         }
     };
     fetch(0);
