@@ -727,8 +727,9 @@ private:
         out.counters.n_lines = counters[4];
         out.on_device = true;
         if (timing)
-            fprintf(stderr, "hc_fno1_run (device): look-ups on the host %.3f s, copy + deduce + 4 sorts + unique + scan %.3f s, text %.3f s\n",
-                    std::chrono::duration<double>(t1 - t0).count(), seconds[0], seconds[1]);
+            fprintf(stderr, "hc_fno1_run (device): look-ups on the host %.3f s, copy + deduce + 4 sorts + unique + scan %.3f s, text %.3f s, device blocks released %.3f s\n",
+                    std::chrono::duration<double>(t1 - t0).count(), seconds[0], seconds[1],
+                    std::chrono::duration<double>(now() - t1).count() - seconds[0] - seconds[1]);
         return true;
     }
 
