@@ -125,7 +125,8 @@ int hc_fno_output_counters(const hc_fno_output* o, hc_fno_counters* c);
 int hc_fno_output_write(const hc_fno_output* o, const char* path); /* what the reference leaves in overlaps.txt */
 void hc_fno_output_free(hc_fno_output* o);
 /* 1 if the arithmetic, the ordering and the text of this output were the device's (FNO=1 batches of 200 000 combinations
- * and more when a HIP device is present; HC_FNO=host / HC_FNO=device force either), 0 if the host threads'. */
+ * and more when a HIP device is present; HC_FNO=host / HC_FNO=device force either), 0 if the host threads'.  The device is
+ * the calling thread's current HIP device (hipSetDevice; device 0 unless the caller chose another). */
 int hc_fno_output_on_device(const hc_fno_output* o);
 
 /* computeOverlapData (:351-565) on its own: the overlap of two (super-)reads induced by one edge.
