@@ -774,6 +774,13 @@ int hc_finalize_batch(const hc_settings* s, const hc_result_rec* r, uint64_t n, 
     return HC_OK;
 }
 
+int hc_device_bus_id(int32_t device, char* bus_id, uint32_t cap) {
+    if (!bus_id || cap < 16) return fail(HC_ERR_ARG, "hc_device_bus_id: null or short buffer");
+    bus_id[0] = 0;
+    HC_HIP(hipDeviceGetPCIBusId(bus_id, (int)cap, device));
+    return HC_OK;
+}
+
 int hc_get_info(hc_ctx* c, uint32_t* qual_alphabet, uint64_t* store_bytes, double* x_edge_lo, double* x_edge_hi,
                 double* x_ov_lo, double* x_ov_hi) {
     if (!c) return fail(HC_ERR_ARG, "hc_get_info: null context");

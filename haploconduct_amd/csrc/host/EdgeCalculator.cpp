@@ -5,6 +5,7 @@
 // insert into a graph that already holds edges stay on the host.
 #include "EdgeCalculator.h"
 
+#include <sched.h>
 #include <sys/stat.h>
 #include <sys/mman.h>
 
@@ -51,6 +52,52 @@ static std::vector<int> device_list(const ProgramSettings& ps) {
     return d;
 }
 
+// The CPUs of the NUMA node a device is attached to: /sys/bus/pci/devices/<bus id>/numa_node -> node<k>/cpulist.
+// Empty when the machine has one node, the node is unknown, or HC_NUMA=0.
+static std::vector<int> cpus_near_device(int device) {
+    std::vector<int> cpus;
+    if (const char* e = getenv("HC_NUMA"))
+        if (atoi(e) == 0) return cpus;
+    char bus[64] = {0};
+    if (hc_device_bus_id(device, bus, (uint32_t)sizeof bus) != HC_OK) return cpus;
+    for (char* c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);
+    auto slurp = [](const std::string& path) {
+        std::string text;
+        if (FILE* f = fopen(path.c_str(), "r")) {
+            char buf[4096];
+            const size_t n = fread(buf, 1, sizeof buf - 1, f);
+            fclose(f);
+            text.assign(buf, n);
+        }
+        return text;
+    };
+    const std::string node = slurp(std::string("/sys/bus/pci/devices/") + bus + "/numa_node");
+    if (node.empty() || atoi(node.c_str()) < 0) return cpus;
+    if (slurp("/sys/devices/system/node/online").find_first_of(",-") == std::string::npos) return cpus;  // a single node
+    const std::string list = slurp("/sys/devices/system/node/node" + std::to_string(atoi(node.c_str())) + "/cpulist");
+    for (size_t i = 0; i < list.size();) {  // "64-127,192-255"
+        if (!isdigit((unsigned char)list[i])) {
+            i++;
+            continue;
+        }
+        char* end = nullptr;
+        const long a = strtol(list.c_str() + i, &end, 10);
+        long b = a;
+        if (*end == '-') b = strtol(end + 1, &end, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) cpus.push_back((int)c);
+        i = (size_t)(end - list.c_str());
+    }
+    return cpus;
+}
+
+void EdgeCalculator::bind_here() const {
+    if (m_node_cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : m_node_cpus) CPU_SET(c, &set);
+    (void)sched_setaffinity(0, sizeof set, &set);  // best effort: a cgroup may not grant these CPUs
+}
+
 EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_ptr<OverlapGraph> graph,
                                const ProgramSettings& ps)
     : program_settings(ps), fastq_storage(std::move(fastq)), overlap_graph(std::move(graph)) {
@@ -69,7 +116,8 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
             m_text_depth = std::min<size_t>(m_text_depth, std::max<size_t>(2, (blocks + n_dev - 1) / n_dev));
         }
     }
-    if (ps.n_threads > 1) m_pool.reset(new WorkerPool(ps.n_threads - 1));
+    m_node_cpus = cpus_near_device(m_cs.device);
+    if (ps.n_threads > 1) m_pool.reset(new WorkerPool(ps.n_threads - 1, [this] { bind_here(); }));
     const FastqStorage& f = *fastq_storage;
     try {
         for (int d : device_list(ps)) {  // the read store is replicated: candidates are independent given the reads
@@ -644,6 +692,17 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     const size_t R = D * N + 1;
     const size_t B = m_text_block;
     const double t_setup0 = now_s();
+    // the calling thread copies text too: next to the device for the length of the call, then back where it was allowed before
+    cpu_set_t cpus_before;
+    CPU_ZERO(&cpus_before);
+    struct RestoreCpus {
+        cpu_set_t* set;
+        bool on;
+        ~RestoreCpus() {
+            if (on) (void)sched_setaffinity(0, sizeof *set, set);
+        }
+    } restore_cpus{&cpus_before, !m_node_cpus.empty() && sched_getaffinity(0, sizeof cpus_before, &cpus_before) == 0};
+    bind_here();
     for (Device& d : m_dev) {
         d.tblk.resize(D, nullptr);
         for (hc_textblock*& b : d.tblk)
@@ -784,7 +843,11 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
         }
     };
     std::vector<std::thread> collectors;
-    for (unsigned c = 0; c < C; c++) collectors.emplace_back(collect, c);
+    for (unsigned c = 0; c < C; c++)
+        collectors.emplace_back([&, c] {
+            bind_here();
+            collect(c);
+        });
     auto stop_collector = [&] {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -810,6 +873,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     std::condition_variable scv;
     bool no_more = false;
     std::thread submitter([&] {
+        bind_here();
         for (;;) {
             Pending p;
             {

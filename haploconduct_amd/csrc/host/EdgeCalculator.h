@@ -119,6 +119,10 @@ private:
     bool m_serial_insert = false;     // HC_INSERT_MODE=serial: per-edge inserts even into an empty graph
     bool m_host_resolve = false;      // HC_RESOLVE=host: duplicate resolution on the host threads instead of the device
     bool m_host_parse = false;        // HC_PARSE=host: the overlaps file is tokenised on the host threads instead of the device
+    // CPUs of the NUMA node the primary device hangs on (empty: one node, unknown, or HC_NUMA=0): the stage's threads copy
+    // the file's text into page-locked buffers next to that device, so they run there
+    std::vector<int> m_node_cpus;
+    void bind_here() const;  // the calling thread -> m_node_cpus
     std::unique_ptr<WorkerPool> m_pool;  // the stage's worker threads (lent to the overlaps parser of every call: starting and
                                          // joining 31 threads per file cost 25 ms)
     std::thread m_cleanup;            // frees of large buffers, off the caller's clock (defer_cleanup)

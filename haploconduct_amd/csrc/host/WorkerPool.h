@@ -15,8 +15,13 @@ class WorkerPool {
 public:
     WorkerPool(const WorkerPool&) = delete;
     WorkerPool& operator=(const WorkerPool&) = delete;
-    explicit WorkerPool(unsigned int workers) {
-        for (unsigned int w = 0; w < workers; w++) m_threads.emplace_back([this, w] { loop(w + 1); });
+    // on_start: run by every worker before it waits for work (the stage binds its threads to the device's NUMA node)
+    explicit WorkerPool(unsigned int workers, std::function<void()> on_start = nullptr) {
+        for (unsigned int w = 0; w < workers; w++)
+            m_threads.emplace_back([this, w, on_start] {
+                if (on_start) on_start();
+                loop(w + 1);
+            });
     }
     ~WorkerPool() {
         {

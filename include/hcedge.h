@@ -433,6 +433,10 @@ int hc_graph_resolve(hc_ctx* ctx, const hc_admit_rec* admitted, uint64_t n, uint
 int hc_graph_fetch(hc_ctx* ctx, hc_edge_rec* edges, uint64_t* out_off, uint32_t* in_nodes, uint64_t* in_off, uint32_t* seq,
                    uint8_t* inclusions, uint32_t* tied_vertices);
 
+/* PCI bus id of a device ("0000:c1:00.0"), for callers that place the host threads feeding it on its NUMA node
+ * (/sys/bus/pci/devices/<id>/numa_node); the stage does (HC_NUMA=0 turns that off). */
+int hc_device_bus_id(int32_t device, char* bus_id, uint32_t cap);
+
 /* Introspection used by the tests: quality alphabet size K of the current store,
  * and the x-space guard band [lo, hi] of a threshold (x <= lo fails, x > hi passes). */
 int hc_get_info(hc_ctx* ctx, uint32_t* qual_alphabet, uint64_t* store_bytes, double* x_edge_lo,
