@@ -4,6 +4,7 @@
 // resolution of all admitted candidates at once (hc_graph_resolve).  nonedge_overlaps.txt bookkeeping and the per-edge
 // insert into a graph that already holds edges stay on the host.
 #include "EdgeCalculator.h"
+#include "NumaBind.h"
 
 #include <sched.h>
 #include <sys/stat.h>
@@ -52,51 +53,7 @@ static std::vector<int> device_list(const ProgramSettings& ps) {
     return d;
 }
 
-// The CPUs of the NUMA node a device is attached to: /sys/bus/pci/devices/<bus id>/numa_node -> node<k>/cpulist.
-// Empty when the machine has one node, the node is unknown, or HC_NUMA=0.
-static std::vector<int> cpus_near_device(int device) {
-    std::vector<int> cpus;
-    if (const char* e = getenv("HC_NUMA"))
-        if (atoi(e) == 0) return cpus;
-    char bus[64] = {0};
-    if (hc_device_bus_id(device, bus, (uint32_t)sizeof bus) != HC_OK) return cpus;
-    for (char* c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);
-    auto slurp = [](const std::string& path) {
-        std::string text;
-        if (FILE* f = fopen(path.c_str(), "r")) {
-            char buf[4096];
-            const size_t n = fread(buf, 1, sizeof buf - 1, f);
-            fclose(f);
-            text.assign(buf, n);
-        }
-        return text;
-    };
-    const std::string node = slurp(std::string("/sys/bus/pci/devices/") + bus + "/numa_node");
-    if (node.empty() || atoi(node.c_str()) < 0) return cpus;
-    if (slurp("/sys/devices/system/node/online").find_first_of(",-") == std::string::npos) return cpus;  // a single node
-    const std::string list = slurp("/sys/devices/system/node/node" + std::to_string(atoi(node.c_str())) + "/cpulist");
-    for (size_t i = 0; i < list.size();) {  // "64-127,192-255"
-        if (!isdigit((unsigned char)list[i])) {
-            i++;
-            continue;
-        }
-        char* end = nullptr;
-        const long a = strtol(list.c_str() + i, &end, 10);
-        long b = a;
-        if (*end == '-') b = strtol(end + 1, &end, 10);
-        for (long c = a; c <= b && c < CPU_SETSIZE; c++) cpus.push_back((int)c);
-        i = (size_t)(end - list.c_str());
-    }
-    return cpus;
-}
-
-void EdgeCalculator::bind_here() const {
-    if (m_node_cpus.empty()) return;
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    for (int c : m_node_cpus) CPU_SET(c, &set);
-    (void)sched_setaffinity(0, sizeof set, &set);  // best effort: a cgroup may not grant these CPUs
-}
+void EdgeCalculator::bind_here() const { bind_thread_to(m_node_cpus); }
 
 EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_ptr<OverlapGraph> graph,
                                const ProgramSettings& ps)
@@ -693,16 +650,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     const size_t B = m_text_block;
     const double t_setup0 = now_s();
     // the calling thread copies text too: next to the device for the length of the call, then back where it was allowed before
-    cpu_set_t cpus_before;
-    CPU_ZERO(&cpus_before);
-    struct RestoreCpus {
-        cpu_set_t* set;
-        bool on;
-        ~RestoreCpus() {
-            if (on) (void)sched_setaffinity(0, sizeof *set, set);
-        }
-    } restore_cpus{&cpus_before, !m_node_cpus.empty() && sched_getaffinity(0, sizeof cpus_before, &cpus_before) == 0};
-    bind_here();
+    BoundForNow bound(m_node_cpus);
     for (Device& d : m_dev) {
         d.tblk.resize(D, nullptr);
         for (hc_textblock*& b : d.tblk)

@@ -8,6 +8,7 @@
 
 #include "../../../include/hcedge_host.h"
 #include "EdgeCalculator.h"
+#include "NumaBind.h"
 #include "api_helpers.h"
 
 namespace hc {
@@ -82,6 +83,8 @@ int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* path
         const bool timing = getenv("HC_STAGE_TIMING") != nullptr;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t0 = now();
+        // the FASTQ reader's threads (they inherit this thread's CPUs) fill the arrays the read store is uploaded from: next to the device
+        hc::BoundForNow bound(hc::cpus_near_device(settings->device));
         std::thread warm;  // once per process and device
         static std::atomic<uint64_t> warmed{0};
         const uint64_t dev_bit = 1ull << ((uint32_t)settings->device & 63u);
