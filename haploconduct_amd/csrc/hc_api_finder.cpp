@@ -14,6 +14,7 @@
 #include "hc_ctx.h"
 #include "hc_fno_device.h"
 #include "hc_sfo_device.h"
+#include "host/NumaBind.h"
 #include "host/Types.h"
 
 namespace hc {
@@ -379,6 +380,7 @@ int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, 
     };
     try {
         HC_HIP(hipSetDevice(c->device));
+        hc::BoundForNow bound(hc::cpus_near_device(c->device));  // the matching threads read the page-locked ring: next to the device
         hipStream_t st = c->stream;
         uint64_t k = 0;
         std::string text;
