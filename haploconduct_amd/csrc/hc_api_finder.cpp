@@ -257,7 +257,11 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     HC_HIP(hipStreamSynchronize(st));
     lap("scratch for the batches");
     unsigned long long R = 0;
-    size_t res_cap = 0;  // records; the result buffer grows by doubling (it outlives the call: not a scratch slot)
+    // the records of the batches collect in one more grow-only slot (growing keeps what is in it); the result that
+    // outlives the call is allocated once, at the end, at its size: one hipMalloc and (for the previous result) one hipFree
+    // per call — allocating and freeing gigabytes per batch and for the final sort cost more than the kernels on some hosts
+    hc_ctx::Scratch& acc = c->finder_scratch[n_slots++];
+    size_t res_cap = acc.cap / sizeof(hc_sfo_rec);  // records
     for (const Batch& bt : batches) {
         const uint64_t Hb = bt.hits;
         HC_HIP(hc::finder_expand(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), bt.q0, bt.q1, bt.base, k, s, n_ori, d_v1.as<uint64_t>(),
@@ -285,15 +289,15 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
             if (batches.size() == 1) want = Rb;
             void* bigger = nullptr;
             HC_HIP(hipMalloc(&bigger, want * sizeof(hc_sfo_rec)));
-            if (R) HC_HIP(hipMemcpyAsync(bigger, d_r1.own, R * sizeof(hc_sfo_rec), hipMemcpyDeviceToDevice, st));
+            if (R) HC_HIP(hipMemcpyAsync(bigger, acc.p, R * sizeof(hc_sfo_rec), hipMemcpyDeviceToDevice, st));
             HC_HIP(hipStreamSynchronize(st));
-            if (d_r1.own) (void)hipFree(d_r1.own);
-            d_r1.own = bigger;
-            d_r1.p = bigger;
+            if (acc.p) (void)hipFree(acc.p);
+            acc.p = bigger;
+            acc.cap = want * sizeof(hc_sfo_rec);
             res_cap = want;
         }
         HC_HIP(hc::finder_emit(d_by_sfo.as<hc::SeqRef>(), d_h0.as<uint64_t>(), d_kout.as<uint32_t>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), M,
-                               (hc_sfo_rec*)d_r1.p + R, st));
+                               (hc_sfo_rec*)acc.p + R, st));
         R += Rb;
     }
     HC_HIP(hipStreamSynchronize(st));
@@ -302,27 +306,37 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         remember(nullptr, 0);
         return HC_OK;
     }
+    if (R >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 overlaps");
+    HC_HIP(hipMalloc(&d_r1.own, R * sizeof(hc_sfo_rec)));  // the result: the context's until the next call
+    d_r1.p = d_r1.own;
     if (batches.size() > 1) {  // every batch is sorted; one more sort (key, position) + gather for the global order
-        if (R >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 overlaps");
-        DevBuf sk0, sk1, si0, si1, dsorted;  // freed on every return path
-        HC_HIP(hipMalloc(&sk0.own, R * 8));
-        HC_HIP(hipMalloc(&sk1.own, R * 8));
-        HC_HIP(hipMalloc(&si0.own, R * 8));
-        HC_HIP(hipMalloc(&si1.own, R * 8));
-        HC_HIP(hc::finder_rekey((const hc_sfo_rec*)d_r1.p, R, (uint64_t*)sk0.own, (uint64_t*)si0.own, st));
+        // the batches' buffers are idle now: they hold the keys and positions of this sort when they are large enough
+        DevBuf own[5];  // what they cannot hold; freed on every return path
+        auto room = [&](const DevBuf& idle, size_t bytes, DevBuf& fallback, void** p) -> hipError_t {
+            if (idle.slot && idle.slot->cap >= bytes) {
+                *p = idle.slot->p;
+                return hipSuccess;
+            }
+            const hipError_t e = hipMalloc(&fallback.own, bytes ? bytes : 16);
+            *p = fallback.own;
+            return e;
+        };
+        void *sk0 = nullptr, *sk1 = nullptr, *si0 = nullptr, *si1 = nullptr, *stmp = nullptr;
+        HC_HIP(room(d_h0, R * 8, own[0], &sk0));
+        HC_HIP(room(d_h1, R * 8, own[1], &sk1));
+        HC_HIP(room(d_kout, R * 8, own[2], &si0));
+        HC_HIP(room(d_flag, R * 8, own[3], &si1));
+        HC_HIP(hc::finder_rekey((const hc_sfo_rec*)acc.p, R, (uint64_t*)sk0, (uint64_t*)si0, st));
         size_t b = 0;
-        HC_HIP(hc::finder_sort_pairs(nullptr, b, (uint64_t*)sk0.own, (uint64_t*)sk1.own, (uint64_t*)si0.own, (uint64_t*)si1.own, R, 64, st));
-        DevBuf stmp;
-        HC_HIP(hipMalloc(&stmp.own, b ? b : 16));
-        HC_HIP(hc::finder_sort_pairs(stmp.own, b, (uint64_t*)sk0.own, (uint64_t*)sk1.own, (uint64_t*)si0.own, (uint64_t*)si1.own, R, 64, st));
-        HC_HIP(hipMalloc(&dsorted.own, R * sizeof(hc_sfo_rec)));
-        HC_HIP(hc::finder_gather((const hc_sfo_rec*)d_r1.p, (const uint64_t*)si1.own, R, (hc_sfo_rec*)dsorted.own, st));
+        HC_HIP(hc::finder_sort_pairs(nullptr, b, (uint64_t*)sk0, (uint64_t*)sk1, (uint64_t*)si0, (uint64_t*)si1, R, 64, st));
+        HC_HIP(room(d_pos, b, own[4], &stmp));
+        HC_HIP(hc::finder_sort_pairs(stmp, b, (uint64_t*)sk0, (uint64_t*)sk1, (uint64_t*)si0, (uint64_t*)si1, R, 64, st));
+        HC_HIP(hc::finder_gather((const hc_sfo_rec*)acc.p, (const uint64_t*)si1, R, (hc_sfo_rec*)d_r1.p, st));
         HC_HIP(hipStreamSynchronize(st));
-        (void)hipFree(d_r1.own);
-        d_r1.own = dsorted.own;
-        d_r1.p = dsorted.own;
-        dsorted.own = nullptr;
         lap("global order of the batches");
+    } else {
+        HC_HIP(hipMemcpyAsync(d_r1.p, acc.p, R * sizeof(hc_sfo_rec), hipMemcpyDeviceToDevice, st));
+        HC_HIP(hipStreamSynchronize(st));
     }
     *n_out = R;
     const uint64_t take = R < cap ? R : cap;

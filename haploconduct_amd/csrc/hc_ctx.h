@@ -104,7 +104,7 @@ struct hc_ctx {
     struct Scratch {  // grow-only device scratch of the finder, one slot per buffer, freed with the store
         void* p = nullptr;
         size_t cap = 0;
-    } finder_scratch[20], ingest_scratch[12];  // the second set: hc_found_to_overlaps
+    } finder_scratch[24], ingest_scratch[12];  // the second set: hc_found_to_overlaps
     void* h_ingest[2] = {nullptr, nullptr};  // page-locked ring hc_found_to_overlaps copies the sorted records through
     size_t h_ingest_cap = 0;                  // bytes of each
     hc_sfo_rec* d_found = nullptr;
