@@ -355,12 +355,8 @@ int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, 
     const bool timing = getenv("HC_SFO_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     struct Freed {
-        std::vector<void*> dev;
         void* host = nullptr;
-        ~Freed() {
-            for (void* p : dev) (void)hipFree(p);
-            free(host);
-        }
+        ~Freed() { free(host); }
     } mem;
     // Device blocks: the finder's grow-only scratch is idle now and large enough for most of what is needed here; what
     // it cannot serve comes from a second grow-only set.  (Allocating and freeing 8 GB per call costs ten times the sorts.)
