@@ -81,11 +81,14 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
             hc_settings cs = m_cs;
             cs.device = d;
             Device dev;
+            const double tc0 = now_s();
             check(hc_create(&dev.ctx, &cs), "hc_create");
             m_dev.push_back(dev);
+            const double tc1 = now_s();
             check(hc_set_reads(dev.ctx, f.bases().data(), f.quals().data(), f.seq_off().data(), f.read_first_seq().data(),
                                f.get_readcount()),
                   "hc_set_reads");
+            const double tc2 = now_s();
             if (!m_host_parse) {  // the device's text parser looks read ids up itself
                 std::vector<uint64_t> ids(f.m_read_vec.size());
                 for (size_t r = 0; r < ids.size(); r++) ids[r] = f.m_read_vec[r]->get_read_id();
@@ -94,10 +97,14 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
                 // device memory and page-locking belong to setting the stage up, like the read store
                 Device& dv = m_dev.back();
                 dv.tblk.resize(m_text_depth, nullptr);
+                const double tc3 = now_s();
                 for (hc_textblock*& b : dv.tblk) {
                     check(hc_textblock_create(dv.ctx, m_text_block, &b), "hc_textblock_create");
                     if (!hc_textblock_buffer(b)) throw FatalError{HC_ERR_NOMEM, "EdgeCalculator: no page-locked buffer for a block of text"};
                 }
+                if (getenv("HC_STAGE_TIMING"))
+                    fprintf(stderr, "[hc stage] device %d: context %.3f s, read store %.3f s, id table %.3f s, %zu text blocks %.3f s\n", d, tc1 - tc0, tc2 - tc1,
+                            tc3 - tc2, dv.tblk.size(), now_s() - tc3);
             }
         }
     } catch (...) {
