@@ -83,18 +83,21 @@ int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* path
         const bool timing = getenv("HC_STAGE_TIMING") != nullptr;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t0 = now();
-        // the FASTQ reader's threads (they inherit this thread's CPUs) fill the arrays the read store is uploaded from: next to the device
-        hc::BoundForNow bound(hc::cpus_near_device(settings->device));
         std::thread warm;  // once per process and device
         static std::atomic<uint64_t> warmed{0};
         const uint64_t dev_bit = 1ull << ((uint32_t)settings->device & 63u);
-        if (!(getenv("HC_WARM") && atoi(getenv("HC_WARM")) == 0) && !(warmed.fetch_or(dev_bit) & dev_bit)) warm = std::thread(warm_device_code, *settings);
+        const bool first_open = !(warmed.fetch_or(dev_bit) & dev_bit);
+        if (first_open && !(getenv("HC_WARM") && atoi(getenv("HC_WARM")) == 0)) warm = std::thread(warm_device_code, *settings);
         struct Join {
             std::thread& t;
             ~Join() {
                 if (t.joinable()) t.join();
             }
         } join_warm{warm};
+        // The FASTQ reader's threads (they inherit this thread's CPUs) fill the arrays the read store is uploaded from: next to
+        // the device.  Not on a process's first open: asking where the device sits starts the HIP runtime, which that open
+        // leaves to the warm-up thread beside the parsing (the stage's own threads find their place once it is up).
+        hc::BoundForNow bound(first_open ? std::vector<int>() : hc::cpus_near_device(settings->device));
         ec->ps = make_ps(settings, paths);
         ec->fastq = std::make_shared<FastqStorage>(ec->ps);                                   // ViralQuasispecies.cpp:233
         const double t1 = now();
