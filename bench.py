@@ -13,15 +13,23 @@ the replicated read store) or strong (the 1e8 candidates are split over the rank
 rank are collected on every rank with one RCCL all-gather per step.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline":     the scoring kernel's mean launch time (hipEvents on the launch stream) against 8 TB/s HBM:
-                  `achieved` / `frac` from the memory-side bytes the PMC counters measured for this workload
-                  (profiles/traffic_<workload>.json: a bound that cannot be exceeded), `algorithmic_GBps` /
-                  `frac_algorithmic` from SURVEY.md §8(d)'s 32 + 16 + 4*L_sub bytes per candidate (no credit for cache
-                  reuse: exceeds the peak when the read store is served from the caches), `issue_bound` = the busy
-                  fractions of the units that actually bound the kernel (vector-memory front end, VALU, LDS)
-  "stage_end_to_end": text overlaps file + FASTQ -> populated, sorted OverlapGraph (hc_ec_construct_edges_sorted)
+  "roofline":     everything measured in THIS run unless said otherwise: `kernel` (the symbol the library picked,
+                  hc_get_kernel_info) and `kernel_ms` (mean launch time, hipEvents on the launch stream);
+                  `frac_encoded` = the bytes the kernel must touch in the store's own encoding with no reuse —
+                  16 B record + 24 B result + 2 symbols per overlapped position — / kernel_ms / 8 TB/s;
+                  `frac_8d` = SURVEY.md 8(d)'s 32 + 16 + 4 B per position (ASCII base + quality of both reads) the
+                  same way: NOT A BOUND, it exceeds 1 because the store holds one fused symbol byte per position;
+                  `achieved` / `frac` / `traffic` = memory-side bytes per launch from the committed PMC passes
+                  (profiles/traffic_<workload>.json: FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included — fabric
+                  traffic, not DRAM traffic) / kernel_ms / 8 TB/s — null unless that file was collected on the kernel
+                  sources of this run (hash), names the kernel this run launched, and its duration is within 5 % of
+                  this run's; `bound` = the busiest unit by the same file's counters ("valu": the kernel is
+                  issue-bound), with the busy fractions under `busy`
+  "stage_end_to_end": text overlaps file + FASTQ -> populated, sorted OverlapGraph (hc_ec_construct_edges_sorted):
+                  median and best of the runs, open + construct totals
   "cpu_baseline": the reference's own process_overlaps (fragment probe) / the CPU oracle timed on this box's host cores
   "also":         the same measurements on configs[1] "c2" (2M candidates), the round-1 headline
+N > 1 adds "ranks": per rank kernel_ms, step_ms, gather_wait_ms, and `n_ranks_seen` = the world size RCCL reported.
 """
 import argparse
 import json
@@ -38,61 +46,96 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 STREAMED_READ_GBS = 6030.0  # a 4 GiB lane-linear read on this chip (profiles/r02_fetch_calibration.jsonl; the guide: ~6.3 TB/s achievable)
 
 
-def pmc_profile(workload, order):
+KERNEL_SOURCES = ("hc_kernels.hip", "hc_device.h", "hc_resolve.h")
+
+
+def kernel_source_sha():
+    """Hash of the sources the scoring kernel is compiled from: a PMC file collected on other sources is stale."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "haploconduct_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(workload, order, kernel_symbol, kern_ms):
     """The committed rocprofv3 PMC passes of the scoring kernel on this workload (profiles/traffic_<workload>.json,
     produced by tools/collect_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md §HBM prescribes for gfx950), or None."""
+    MI355X_MICROARCH.md §HBM prescribes for gfx950) — only if it describes what this run measures: collected on the same
+    kernel sources, the same kernel symbol, a duration within 5 % of this run's.  Returns (profile or None, why not)."""
     path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("order") == order and t.get("record_bytes", 32) == 16:
-            return t
     except Exception:
-        pass
-    return None
+        return None, f"no profiles/traffic_{workload}.json"
+    if t.get("order") != order or t.get("record_bytes", 32) != 16:
+        return None, "the PMC file is for another candidate order / record format"
+    if t.get("kernel_source_sha") != kernel_source_sha():
+        return None, f"stale: the PMC file was collected on kernel sources {t.get('kernel_source_sha')}, this run has {kernel_source_sha()}"
+    sym = (t.get("kernel") or "").split("(")[0].replace("void ", "").strip()
+    if sym != kernel_symbol:
+        return None, f"the PMC file measured {sym!r}, this run launched {kernel_symbol!r}"
+    ref_ms = t.get("kernel_ms_hipevents_under_rocprof") or t.get("kernel_ms_rocprof_avg")
+    if not ref_ms or abs(ref_ms - kern_ms) > 0.05 * kern_ms:
+        return None, f"the PMC file's kernel took {ref_ms} ms, this run's {kern_ms:.4f} ms: more than 5 % apart"
+    return t, None
 
 
-def roofline_record(workload, order, n, positions, kern_ms):
-    """See the module docstring.  Memory-side bytes come from the PMC pass of the same workload and record format."""
-    alg_bytes = 48 * n + 4 * positions  # SURVEY.md §8(d): 32 B record + 16 B result + 4 B per overlapped position
-    alg = alg_bytes / (kern_ms * 1e-3) / 1e9
-    r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-         "kernel": "hc::score_kernel_coop (hc::score_kernel for contig-length read sets)", "kernel_ms": kern_ms, "kernel_candidates_per_s": n / (kern_ms * 1e-3),
-         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg, "frac_algorithmic": alg / HBM_PEAK_GBS,
-         "note": "achieved/frac: memory-side bytes of the PMC pass (FETCH_SIZE x2 + WRITE_SIZE; every request is a 128-byte line, the "
-                 "factor checked on known byte counts for this access shape: profiles/r02_fetch_calibration.jsonl; Infinity-Cache hits "
-                 "included) over the live kernel time, against the 8 TB/s spec peak; a streamed read of 4 GiB reaches 6.0 TB/s on this "
-                 "chip (same file; the guide: ~6.3 achievable), frac_of_streamed_read relates the kernel to that; frac_algorithmic: "
-                 "SURVEY 8(d) bytes without cache-reuse credit, not a bound (the shared read of neighbouring candidates comes out of "
-                 "L1/L2); issue_bound: busy fractions of the vector-memory front end, the VALUs and the LDS from the same PMC pass"}
-    t = pmc_profile(workload, order)
-    if t:
-        c = t.get("counters_per_launch", {})
-        r["traffic"] = t["hbm_bytes_per_launch"]
-        r["achieved"] = t["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
-        r["frac"] = r["achieved"] / HBM_PEAK_GBS
-        r["frac_of_streamed_read"] = r["achieved"] / STREAMED_READ_GBS
-        busy = {}
-        if c.get("GRBM_GUI_ACTIVE"):
-            cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
-            n_cu = 256
-            if c.get("TA_BUSY_avr"):
-                busy["ta_busy"] = c["TA_BUSY_avr"] / cycles  # vector-memory front end (address processing of the lane-divergent gathers)
-            if c.get("SQ_ACTIVE_INST_VALU"):
-                busy["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (4 * n_cu * cycles)  # quad-cycles over all SIMDs
-            if c.get("SQ_LDS_IDX_ACTIVE"):
-                busy["lds_busy"] = c["SQ_LDS_IDX_ACTIVE"] / (n_cu * cycles)
-                if c.get("SQ_LDS_BANK_CONFLICT") is not None:
-                    busy["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
-            busy["kernel_cycles"] = cycles
-        if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
-            busy["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
-        if c.get("SQ_INSTS_VALU") and c.get("SQ_INSTS_VMEM_RD"):
-            waves = n / 64.0
-            busy["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"] / waves
-            busy["vmem_read_instructions_per_wave"] = c["SQ_INSTS_VMEM_RD"] / waves
-        r["issue_bound"] = dict(busy, source=f"profiles/traffic_{workload}.json")
+def roofline_record(workload, order, n, positions, kern_ms, kernel_info, symbytes):
+    """See the module docstring."""
+    kernel_symbol = kernel_info.split(" encoding=")[0]
+    t_s = kern_ms * 1e-3
+    bytes_8d = 48 * n + 4 * positions                   # SURVEY.md §8(d): 32 B record + 16 B result + 4 B per overlapped position
+    bytes_enc = (16 + 24) * n + 2 * symbytes * positions  # hc_cand_rec + hc_result_rec + one symbol of each read per position
+    r = {"bound": "unmeasured (no matching PMC file)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+         "kernel": kernel_symbol, "kernel_info": kernel_info, "kernel_ms": kern_ms, "kernel_candidates_per_s": n / t_s,
+         "kernel_positions_per_s": positions / t_s, "kernel_source_sha": kernel_source_sha(),
+         "encoded_bytes_per_launch": bytes_enc, "encoded_GBps": bytes_enc / t_s / 1e9, "frac_encoded": bytes_enc / t_s / 1e9 / HBM_PEAK_GBS,
+         "bytes_8d_per_launch": bytes_8d, "GBps_8d": bytes_8d / t_s / 1e9, "frac_8d": bytes_8d / t_s / 1e9 / HBM_PEAK_GBS,
+         "frac_8d_note": "not a bound: SURVEY 8(d) counts an ASCII base and a quality byte per read and position; the store holds one fused symbol",
+         "note": "frac_encoded: compulsory bytes in the store's encoding without cache-reuse credit (neighbouring candidates share a read: part of it "
+                 "comes out of L1/L2); achieved/frac/traffic: memory-side (fabric) bytes of the PMC passes, FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache "
+                 "hits included (factor checked on known byte counts: profiles/r02_fetch_calibration.jsonl) — only when the PMC file matches this "
+                 "run's kernel sources, kernel symbol and duration; bound: the busiest unit of that file's counters"}
+    t, why = pmc_profile(workload, order, kernel_symbol, kern_ms)
+    if not t:
+        r["traffic_note"] = why
+        return r
+    c = t.get("counters_per_launch", {})
+    r["traffic"] = t["hbm_bytes_per_launch"]
+    r["achieved"] = t["hbm_bytes_per_launch"] / t_s / 1e9
+    r["frac"] = r["achieved"] / HBM_PEAK_GBS
+    r["frac_of_streamed_read"] = r["achieved"] / STREAMED_READ_GBS
+    r["traffic_source"] = {"file": f"profiles/traffic_{workload}.json", "git_sha": t.get("git_sha"), "kernel_source_sha": t.get("kernel_source_sha"),
+                           "kernel_ms_rocprof_avg": t.get("kernel_ms_rocprof_avg"), "kernel_ms_hipevents_under_rocprof": t.get("kernel_ms_hipevents_under_rocprof")}
+    busy = {}
+    if c.get("GRBM_GUI_ACTIVE"):
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
+        n_cu = 256
+        busy["hbm_fabric"] = r["frac"]
+        if c.get("TA_BUSY_avr"):
+            busy["ta"] = c["TA_BUSY_avr"] / cycles  # vector-memory front end (address processing of the gathers)
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            busy["valu"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (4 * n_cu * cycles)  # quad-cycles over all SIMDs
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            busy["lds"] = c["SQ_LDS_IDX_ACTIVE"] / (n_cu * cycles)
+        r["bound"] = max(busy, key=busy.get)
+        if r["bound"] == "hbm_fabric":
+            r["bound"] = "hbm"
+        busy["kernel_cycles"] = cycles
+        if c.get("SQ_LDS_BANK_CONFLICT") is not None and c.get("SQ_LDS_IDX_ACTIVE"):
+            busy["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
+        busy["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if c.get("SQ_INSTS_VALU") and c.get("SQ_INSTS_VMEM_RD"):
+        per_wave = c["SQ_INSTS_VALU"] / (n / 64.0)  # what every lane, i.e. every candidate, executes
+        busy["valu_instructions_per_candidate"] = per_wave
+        busy["valu_instructions_per_position"] = per_wave / (positions / max(n, 1))
+        busy["vmem_read_instructions_per_wave"] = c["SQ_INSTS_VMEM_RD"] / (n / 64.0)
+    r["busy"] = busy
     return r
 
 
@@ -291,10 +334,14 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    sc.synchronize()
+    launch_stream.synchronize()
+    t_scored = time.perf_counter()
     if gather:
         gather.finish()  # every all-gather of the timed steps has completed
-    sc.synchronize()
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    gather_wait_ms = (time.perf_counter() - t_scored) * 1e3  # what the collection still needed once this rank's kernels were done
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -307,6 +354,16 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
         dt = float(t.item())
     # kernel-only: hipEvents on the stream the kernel is launched on
     kern_ms = sc.time_kernel(d_in.data_ptr(), n, d_out.data_ptr(), max(5, min(args.steps, 200)), REC_COMPACT)
+    kinfo = sc.kernel_info()
+    symbytes = 2 if "encoding=u16" in kinfo else 1
+    per_rank = None
+    if dist:  # what every rank saw, gathered outside the timed region
+        mine = torch.tensor([kern_ms, dt_local / args.steps * 1e3, gather_wait_ms / max(args.steps, 1), float(dist.get_world_size()), float(n)],
+                            device="cuda", dtype=torch.float64)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank = [{"rank": r, "kernel_ms": float(v[0]), "step_ms": float(v[1]), "gather_wait_ms_per_step": float(v[2]),
+                     "n_ranks_seen": int(v[3]), "candidates": int(v[4])} for r, v in enumerate(everyone)]
     rec = {
         "value": n_job * args.steps / dt,
         "ms_per_step": dt / args.steps * 1e3,
@@ -314,8 +371,14 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
                        parallelism=f"candidate shards x{world}, replicated read store" +
                                    (", one all-gather of the non-dropped records per step" if gather else ""),
                        edge_threshold=settings.edge_threshold, mean_positions_per_candidate=positions / max(n, 1)),
-        "roofline": roofline_record(workload, order, n, positions, kern_ms),
+        "roofline": roofline_record(workload, order, n, positions, kern_ms, kinfo, symbytes),
     }
+    if per_rank:
+        # overlap: the share of the all-gather's time hidden behind the scoring kernel = 1 - (step - kernel) / gather alone is not
+        # observable without a second run; what is: a step costs step_ms against a kernel of kernel_ms, the difference is what the
+        # collection adds on the critical path
+        rec["ranks"] = {"n_ranks_seen": per_rank[0]["n_ranks_seen"], "per_rank": per_rank,
+                        "collection_on_critical_path_ms": max(0.0, rec["ms_per_step"] - max(p["kernel_ms"] for p in per_rank))}
     sc.close()
     del d_in, d_out
     torch.cuda.empty_cache()
@@ -353,14 +416,18 @@ def stage_end_to_end(reads, cand, settings, threads, reps=4):
             runs.append({"open_s": t1 - t0, "construct_edges_sorted_s": t2 - t1, "edges": ec.edge_count(), "scored": c["scored"],
                          "parse_s": c["t_parse"], "collect_s": c["t_score"], "resolve_s": c["t_insert"], "write_s": c["t_write"]})
             ec.close()
-        best = min(runs, key=lambda r: r["construct_edges_sorted_s"])
-        return {"value": best["scored"] / best["construct_edges_sorted_s"], "unit": "candidate overlaps/s", "threads": threads,
-                "text_bytes": os.path.getsize(d + "overlaps.txt"), "files_written_s": t_files, "best": best, "runs": runs,
+        by_time = sorted(runs, key=lambda r: r["construct_edges_sorted_s"])
+        best, median = by_time[0], by_time[(len(by_time) - 1) // 2]  # lower median: never better than half of the runs
+        by_total = sorted(r["open_s"] + r["construct_edges_sorted_s"] for r in runs)
+        return {"value": median["scored"] / median["construct_edges_sorted_s"], "unit": "candidate overlaps/s", "threads": threads,
+                "value_is": "median run", "best_value": best["scored"] / best["construct_edges_sorted_s"],
+                "open_plus_construct_s": {"median": by_total[(len(by_total) - 1) // 2], "best": by_total[0]},
+                "text_bytes": os.path.getsize(d + "overlaps.txt"), "files_written_s": t_files, "median": median, "best": best, "runs": runs,
                 "what": "hc_ec_construct_edges_sorted: the overlaps file's text -> H2D in 16 MiB blocks -> device: lines, parse, prefilter, "
                         "scoring kernel, non-dropped rows in file order -> host exp() of the admitted -> device duplicate resolution + "
-                        "adjacency in sortEdges order -> OverlapGraph; `best` of the runs (a process's first call is the slower one); "
-                        "FASTQ load + store upload (open_s) not included, as in the reference's own timing "
-                        "(src/ViralQuasispecies.cpp:280-283)"}
+                        "adjacency in sortEdges order -> OverlapGraph; `value` is the MEDIAN of the runs (a process's first call is the "
+                        "slowest); FASTQ load + store upload + device warm-up + block allocation (open_s) are not part of it, as in the "
+                        "reference's own timing (src/ViralQuasispecies.cpp:280-283) — open_plus_construct_s has them"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -415,7 +482,7 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "candidate overlaps scored/sec (edge-calc stage)",
+            "metric": "candidate overlaps scored/sec (edge-calc scoring pass: compute_overlap + overlap_score + admission class, candidates resident in HBM; the whole stage from the overlaps text: stage_end_to_end)",
             "value": main_rec["value"],
             "unit": "candidate overlaps/s",
             "n_gpus": world,

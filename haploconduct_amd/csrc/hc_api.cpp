@@ -416,10 +416,10 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         // 64-symbol fetch groups for short-read sets, 32-symbol groups when the
         // sequences are long (contigs): measured on BASELINE configs 2-5, see DESIGN.md
         const uint64_t mean_len = n_seq ? total / n_seq : 0;
-        c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 4;
-        // contig-length sequences: a lane streams its own long rows well enough, and the waves of a cooperative step would
-        // wait for their longest candidate row by row (C5: 0.95 ms per lane, 0.98 ms cooperative)
-        c->coop_fetch = mean_len <= 600;
+        c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 4;  // the per-lane kernel's, should the store reach 4 GiB
+        // every read set takes the cooperative fetch; sets of mixed sequence length (view.balance: contigs next to reads)
+        // with their candidates bucketed by length first (hc::bucket_perm_kernel)
+        c->coop_fetch = true;
     }
     return HC_OK;
 }
@@ -458,7 +458,7 @@ static int ensure_sort_workspace(hc_ctx* c, uint64_t n) {
 
 int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, hipStream_t s, bool reorder,
                  hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index, const unsigned long long* n_dev,
-                 const hc_line_rec* lines_in, hc_line_rec* lines_out) {
+                 const hc_line_rec* lines_in, hc_line_rec* lines_out, hc_bucket_ws* bucket) {
     const uint32_t* perm = nullptr;
     if (reorder && n > 1 && n < (1ull << 31)) {
         int rc = ensure_sort_workspace(c, n);
@@ -475,8 +475,16 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
     prm.rec_fmt = fmt;
     { static const bool no_sort = getenv("HC_COOP_SORT") && atoi(getenv("HC_COOP_SORT")) == 0; prm.pad = no_sort ? 1u : 0u; }
     prm.n_dev = n_dev;
+    uint32_t *bperm = nullptr, *bqueue = nullptr;
+    if (c->view.balance && c->coop_fetch && n < (1ull << 32)) {  // mixed sequence lengths: the launch buckets its candidates by length first
+        hc_bucket_ws* ws = bucket ? bucket : &c->bucket;
+        int rc = ws->ensure(n);
+        if (rc) return rc;
+        bperm = ws->perm();
+        bqueue = ws->queue();
+    }
     HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group, rows, row_count, cap,
-                            base_index, s, lines_in, lines_out));
+                            base_index, s, lines_in, lines_out, bperm, bqueue));
     return HC_OK;
 }
 
@@ -790,6 +798,15 @@ int hc_get_info(hc_ctx* c, uint32_t* qual_alphabet, uint64_t* store_bytes, doubl
     if (x_edge_hi) *x_edge_hi = c->params.edge.hi;
     if (x_ov_lo) *x_ov_lo = c->params.ov.lo;
     if (x_ov_hi) *x_ov_hi = c->params.ov.hi;
+    return HC_OK;
+}
+
+int hc_get_kernel_info(hc_ctx* c, char* buf, uint32_t cap) {
+    if (!c || !buf || cap == 0) return fail(HC_ERR_ARG, "hc_get_kernel_info: null argument");
+    buf[0] = 0;
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_get_kernel_info: hc_set_reads has not been called");
+    const std::string d = hc::describe_score_kernel(c->view, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group);
+    snprintf(buf, cap, "%s", d.c_str());
     return HC_OK;
 }
 

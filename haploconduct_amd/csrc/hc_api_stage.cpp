@@ -29,6 +29,7 @@ struct hc_block {
     hc_gather_row* h_rows = nullptr;       // page-locked, mapped: the rows, streamed out by a copy kernel behind it
     unsigned long long* h_count = nullptr; // page-locked
     uint64_t n = 0, base_index = 0;
+    hc_bucket_ws bucket;                   // scratch of a length-bucketed scoring launch (read sets of mixed sequence length)
     bool in_flight = false;
 };
 
@@ -95,7 +96,7 @@ int hc_block_submit(hc_block* b, const hc_cand_rec* cands, uint64_t n, uint64_t 
         HC_HIP(hipMemcpyAsync(b->d_in, cands, n * sizeof(hc_cand_rec), hipMemcpyHostToDevice, b->stream));
         // as given: the stage's blocks come from files in sfo2overlaps / FNO order; an unordered file still scores
         // correctly, only slower (hc_set_reorder(HC_REORDER_ALWAYS) sorts every block first)
-        int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_in, n, b->d_out, b->stream, false, nullptr, nullptr, 0, 0);
+        int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_in, n, b->d_out, b->stream, false, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, &b->bucket);
         if (rc) return rc;
         HC_HIP(hc::launch_kept_rows((const hc_result_rec*)b->d_out, n, nullptr, base_index, b->d_tiles, b->d_tiles + (b->cap / 1024 + 2), b->d_rows,
                                     b->cap, b->d_count, nullptr, nullptr, b->stream));

@@ -39,6 +39,7 @@ struct hc_textblock {
     hc_text_reject* h_rejects = nullptr;       // page-locked, mapped: written by the parse kernel
     unsigned long long* h_counters = nullptr;  // page-locked
     std::vector<hc_text_row> rows;             // what hc_textblock_wait hands out
+    hc_bucket_ws bucket;                       // scratch of a length-bucketed scoring launch (read sets of mixed sequence length)
     bool in_flight = false;
 };
 
@@ -261,7 +262,7 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
         HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, b->d_tally, s));
         // the scoring kernel on the records the parse kernel left behind; how many there are is only known on the device
         int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_cands, b->max_lines, b->d_out, s, false, nullptr, nullptr, 0, 0,
-                              b->d_counters + hc::kTextLines);
+                              b->d_counters + hc::kTextLines, nullptr, nullptr, &b->bucket);
         if (rc) return rc;
         HC_HIP(hc::launch_kept_rows(b->d_out, b->max_lines, b->d_counters + hc::kTextLines, base_index, b->d_kept_tiles,
                                     b->d_kept_tiles + (b->max_lines / 1024 + 2), b->d_rows, b->row_cap, b->d_counters + hc::kTextRows, b->d_lines,

@@ -19,8 +19,12 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const void* in, uint64_t n,
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
-                        const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr);
+                        const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr, uint32_t* bucket_perm = nullptr,
+                        uint32_t* bucket_queue = nullptr);
+// bucket_perm (n uint32) / bucket_queue (one uint32): scratch of the length-bucketed launch (read sets of mixed sequence
+// length, StoreView::balance): without them such a set is scored in the order given
 hipError_t set_score_kernel_lds_limit();
+std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane_fetch_group);
 // hc_util_kernels.hip
 size_t compact_temp_bytes(uint32_t n);
 hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_out, unsigned long long* count_out, void* temp,
@@ -79,6 +83,15 @@ struct hc_scratch {
     ~hc_scratch() { release(); }
 };
 
+// Scratch of one length-bucketed scoring launch (hc::bucket_perm_kernel): the queue counter, then the permutation.  One per
+// thing that launches on its own stream (the context, every hc_block / hc_textblock); grow-only.
+struct hc_bucket_ws {
+    hc_scratch mem;
+    int ensure(uint64_t n) { return mem.ensure((n + 16) * sizeof(uint32_t)); }
+    uint32_t* queue() const { return mem.as<uint32_t>(); }
+    uint32_t* perm() const { return mem.as<uint32_t>() + 16; }
+};
+
 struct hc_ctx {
     hc_settings settings;
     int device = 0;
@@ -123,6 +136,7 @@ struct hc_ctx {
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint64_t sort_cap = 0;
+    hc_bucket_ws bucket;  // length-bucketed launches on the context's own entry points
     // compaction scratch, grow-only
     void* d_compact_tmp = nullptr;
     size_t compact_tmp_bytes = 0;
@@ -151,4 +165,5 @@ struct hc_ctx {
 
 int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, hipStream_t s, bool reorder,
                  hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index,
-                 const unsigned long long* n_dev = nullptr, const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr);
+                 const unsigned long long* n_dev = nullptr, const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr,
+                 hc_bucket_ws* bucket = nullptr);  // bucket: the caller's own scratch (launches beside the context's stream), else the context's

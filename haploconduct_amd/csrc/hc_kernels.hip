@@ -27,6 +27,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <string>
 
 #include "../../include/hcedge.h"
 #include "hc_device.h"
@@ -811,6 +813,111 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
     }
 }
 
+// The row append of ONE wave (the length-bucketed launch: its waves take their work from a queue, each at its own pace, so
+// there is no workgroup-wide moment to share an atomic).  Called by all 64 lanes.
+__device__ __forceinline__ void append_rows_wave(const RowSink& sink, bool valid, const hc_result_rec& res, uint64_t i) {
+    const bool keep = valid && (res.n_cls >> 28) != HC_CLS_DROP;
+    const uint64_t m = __ballot(keep);
+    if (m == 0ull) return;  // wave-uniform
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(sink.count, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (keep) {
+        const uint64_t pos = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < sink.cap) {
+            hc_gather_row r;
+            r.index = sink.base_index + i;
+            r.x1 = res.x1;
+            r.x2 = res.x2;
+            r.mm = res.mm;
+            r.n_cls = res.n_cls;
+            sink.rows[pos] = r;
+            if (sink.lines_in) {
+                const uint4* a = (const uint4*)(sink.lines_in + i);
+                uint4* b = (uint4*)(sink.lines_out + pos);
+                b[0] = a[0];
+                b[1] = a[1];
+                b[2] = a[2];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t length_class(uint32_t chunks) {  // 0..15 exact, then quarter octaves; < 128
+    if (chunks < 16u) return chunks;
+    const uint32_t lg = 31u - (uint32_t)__builtin_clz(chunks);
+    const uint32_t c = 16u + (lg - 4u) * 4u + ((chunks >> (lg - 2u)) & 3u);
+    return c > 127u ? 127u : c;
+}
+
+// ---------------------------------------------------------------------------
+// Length bucketing (read sets of mixed sequence length: contigs next to reads, BASELINE config 5).  A wave advances its 64
+// candidates row by row and runs as long as its longest one: with overlaps of log-uniform length 100..6 000 the mean lane
+// is busy 28 % of that time.  Candidates are therefore bucketed by (tile, length class): inside every tile of kBucketTile
+// consecutive candidates — consecutive candidates share reads, so a tile keeps the file's locality — this kernel ranks the
+// candidates by the length class of their overlap (LDS counting sort, longest first) and writes the ranking as a
+// permutation; the scoring kernel then takes GROUPS of 64 consecutive ranks (one wave each: lengths within a quarter octave of each other, lane efficiency 0.95 on
+// config 5) from a queue, group g of every tile before group g + 1 of any — the longest groups first, so the waves that
+// finish last are finishing short ones.  Results go back to the candidate's own place (out[i] <-> in[i]).
+// One 1 024-lane workgroup per tile, 4 slots per lane.  perm_in: an earlier permutation to compose with (hc_set_reorder) or nullptr.
+constexpr uint32_t kBucketTile = 4096;
+constexpr uint32_t kGroupsPerTile = kBucketTile / 64;
+template <int SB>
+__global__ __launch_bounds__(1024) void bucket_perm_kernel(StoreView st, uint32_t min_read_len, uint32_t fmt, const void* __restrict__ in, uint64_t n,
+                                                           const unsigned long long* __restrict__ n_dev, const uint32_t* __restrict__ perm_in,
+                                                           uint32_t* __restrict__ perm_out, uint32_t* __restrict__ queue) {
+    if (n_dev) {
+        const uint64_t nd = *n_dev;
+        n = nd < n ? nd : n;
+    }
+    __shared__ uint32_t hist[129];  // class + 1 of a candidate (1..128); 0 = no candidate in the slot (those rank last)
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) *queue = 0;  // the scoring kernel behind this one in the stream starts its queue at 0
+    if (tid < 129) hist[tid] = 0;
+    __syncthreads();
+    const uint64_t tile_base = (uint64_t)blockIdx.x * kBucketTile;
+    uint32_t cls[4], idx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t slot = tile_base + (uint32_t)k * 1024u + tid;
+        cls[k] = 0;
+        idx[k] = 0;
+        if (slot < n) {
+            idx[k] = perm_in ? perm_in[slot] : (uint32_t)slot;
+            const Cand rec = load_cand(in, idx[k], fmt);
+            Sub s0, s1;
+            const int ns = resolve<SB>(st, rec, s0, s1);
+            uint32_t c = 0;
+            if (ns >= 1) c = (sub_positions(s0, min_read_len) + 15u) >> 4;
+            if (ns == 2) c += (sub_positions(s1, min_read_len) + 15u) >> 4;
+            cls[k] = length_class(c) + 1u;
+        }
+        atomicAdd(&hist[cls[k]], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan, longest class first: lane t owns classes 128 - 2t and 127 - 2t; class 0 follows them all
+        const uint32_t hi = 128u - 2u * tid, lo = hi - 1u;
+        const uint32_t c0 = hist[hi], c1 = hist[lo];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+            if ((int)tid >= o) incl += up;
+        }
+        const uint32_t excl = incl - (c0 + c1);
+        hist[hi] = excl;
+        hist[lo] = excl + c0;
+        if (tid == 63) hist[0] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t rank = atomicAdd(&hist[cls[k]], 1u);
+        if (cls[k]) perm_out[tile_base + rank] = idx[k];  // ranks of the candidates are < the number of candidates in the tile
+    }
+}
+
 // The scoring kernel with the cooperative fetch (score_sub_coop), for stores below 4 GiB (32-bit byte offsets).  Same
 // results, records and row sink as score_kernel.  WG: lanes per workgroup — one log table per workgroup, so a large table
 // (wide 8-bit symbols: 64 KiB; 16-bit symbols: up to 74 KiB) is shared by 1 024 lanes to keep 16 waves on a CU.
@@ -821,17 +928,13 @@ __device__ __forceinline__ void score_kernel_body(const StoreView& st, const Sco
 // longest lane, and with windows of 75..150 symbols next to each other a lane is busy 76 % of that time; sorted, the second
 // pass usually needs one 64-byte step less.  Parameters and results change lanes through the wave's own image space: no
 // workgroup barrier (a workgroup-wide sort saved more work and lost it again waiting at its seven barriers).
-__device__ __forceinline__ uint32_t length_class(uint32_t chunks) {  // 0..15 exact, then quarter octaves; < 128
-    if (chunks < 16u) return chunks;
-    const uint32_t lg = 31u - (uint32_t)__builtin_clz(chunks);
-    const uint32_t c = 16u + (lg - 4u) * 4u + ((chunks >> (lg - 2u)) & 3u);
-    return c > 127u ? 127u : c;
-}
-
-template <typename SymT, int LG, int WG, bool SORT>
+template <typename SymT, int LG, int WG, bool SORT, bool DYN>
 __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                             const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
-                                                            const uint32_t* __restrict__ perm, RowSink sink) {
+                                                            const uint32_t* __restrict__ perm, RowSink sink, uint32_t* __restrict__ queue) {
+    // DYN (length-bucketed launches, bucket_perm_kernel): the waves take groups of 64 ranks from `queue`, each wave at its
+    // own pace; n_hint = the launch's n, which the queue's geometry was laid out for (the device may know fewer records)
+    const uint64_t n_hint = n;
     if (prm.n_dev) {
         const uint64_t nd = *prm.n_dev;
         n = nd < n ? nd : n;
@@ -852,8 +955,26 @@ __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score
     const uint32_t oob = (uint32_t)st.store_bytes;  // the first offset the descriptor's range check rejects (no wrap-around at +16)
     const uint32_t tid = threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * WG;
-    for (uint64_t block_base = (uint64_t)blockIdx.x * WG; block_base < n; block_base += stride) {
-        const uint64_t slot = block_base + tid;
+    // DYN: queue entry q = group (q / n_tiles) of tile (q % n_tiles): group g of every tile before group g + 1 of any, i.e.
+    // the longest groups of the launch first.  The next entry is asked for before the current one is scored (one atomic per
+    // 64 candidates, its latency behind the group's work).
+    const uint32_t n_tiles = DYN ? (uint32_t)((n_hint + kBucketTile - 1) / kBucketTile) : 0u;
+    const uint32_t n_groups = n_tiles * kGroupsPerTile;
+    uint32_t q_next = 0;
+    if (DYN && (tid & 63u) == 0) q_next = atomicAdd(queue, 1u);
+    for (uint64_t block_base = (uint64_t)blockIdx.x * WG;; block_base += stride) {
+        uint64_t slot;
+        if (DYN) {
+            const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_next);
+            if (q >= n_groups) break;
+            if ((tid & 63u) == 0) q_next = atomicAdd(queue, 1u);
+            const uint32_t grp = q / n_tiles, tile = q - grp * n_tiles;
+            slot = (uint64_t)tile * kBucketTile + grp * 64u + (tid & 63u);
+            if (slot - (tid & 63u) >= n) continue;  // wave-uniform: a group behind the end of the last tile
+        } else {
+            if (block_base >= n) break;
+            slot = block_base + tid;
+        }
         uint64_t i = 0;
         int ns = -2;  // no candidate in this lane
         Sub sub0{}, sub1{};
@@ -939,7 +1060,10 @@ __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score
                 res = classify_and_store(prm, ns, s1, s2, i, out);
             }
         }
-        if (sink.rows) append_rows_block(sink, slot < n, res, i, scratch);  // kernel-argument-uniform branch
+        if (sink.rows) {  // kernel-argument-uniform branch
+            if (DYN) append_rows_wave(sink, slot < n, res, i);
+            else append_rows_block(sink, slot < n, res, i, scratch);
+        }
     }
 }
 
@@ -1039,7 +1163,7 @@ void launch_lg(int group, const ScoreLaunch& a) {
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const void* in, uint64_t n,
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
-                        const hc_line_rec* lines_in, hc_line_rec* lines_out) {
+                        const hc_line_rec* lines_in, hc_line_rec* lines_out, uint32_t* bucket_perm, uint32_t* bucket_queue) {
     if (n == 0) return hipSuccess;
     const uint32_t lg = lut_lg(st.K);
     if (fetch_group == 0) {
@@ -1051,26 +1175,45 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
         if (coop && lds_c <= 160 * 1024) {
             uint32_t per_cu = (uint32_t)((160 * 1024) / lds_c);
             per_cu = per_cu * (wg_c / 64) > 32 ? 32 / (wg_c / 64) : per_cu;
+            // mixed sequence lengths: bucket the candidates by (tile, length class) first; the waves then take groups of 64
+            // ranks from a queue (bucket_perm_kernel)
+            const bool bucketed = st.balance && bucket_perm && bucket_queue && n < (1ull << 32);
             uint64_t blocks_c = (n + wg_c - 1) / wg_c;
             static const int grid_mult = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 4;  // experiment knob
-            const uint64_t cap_c = (uint64_t)n_cu * per_cu * grid_mult;
+            const uint64_t cap_c = (uint64_t)n_cu * per_cu * (bucketed ? 1 : grid_mult);  // a queue needs resident workgroups only
             if (blocks_c > cap_c) blocks_c = cap_c;
             const RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out};
-            const bool sort_subs = !(prm.pad & 1u);
+            const bool sort_subs = bucketed || !(prm.pad & 1u);
+            if (bucketed) {
+                const uint32_t tiles = (uint32_t)((n + kBucketTile - 1) / kBucketTile);
+                if (st.symbytes == 2)
+                    hipLaunchKernelGGL((bucket_perm_kernel<2>), dim3(tiles), dim3(1024), 0, stream, st, prm.min_read_len, prm.rec_fmt, in, n, prm.n_dev,
+                                       perm, bucket_perm, bucket_queue);
+                else
+                    hipLaunchKernelGGL((bucket_perm_kernel<1>), dim3(tiles), dim3(1024), 0, stream, st, prm.min_read_len, prm.rec_fmt, in, n, prm.n_dev,
+                                       perm, bucket_perm, bucket_queue);
+                perm = bucket_perm;
+            }
 #define HC_COOP(T_, LG_)                                                                                                              \
     do {                                                                                                                              \
-        if (wg_c == 256 && sort_subs)                                                                                                 \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, prm,  \
-                               lut_g, in, n, out, perm, sink);                                                                        \
+        if (wg_c == 256 && bucketed)                                                                                                  \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, \
+                               prm, lut_g, in, n, out, perm, sink, bucket_queue);                                                     \
+        else if (bucketed)                                                                                                            \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true, true>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream,   \
+                               st, prm, lut_g, in, n, out, perm, sink, bucket_queue);                                                 \
+        else if (wg_c == 256 && sort_subs)                                                                                            \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, false>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, \
+                               prm, lut_g, in, n, out, perm, sink, nullptr);                                                          \
         else if (wg_c == 256)                                                                                                         \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, false>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, prm, \
-                               lut_g, in, n, out, perm, sink);                                                                        \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, false, false>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream,   \
+                               st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
         else if (sort_subs)                                                                                                           \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream, st,     \
-                               prm, lut_g, in, n, out, perm, sink);                                                                   \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream,  \
+                               st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
         else                                                                                                                          \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream, st,    \
-                               prm, lut_g, in, n, out, perm, sink);                                                                   \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, false, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream, \
+                               st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
     } while (0)
             if (st.symbytes == 2) HC_COOP(uint16_t, 5);
             else if (lg == 3) HC_COOP(uint8_t, 3);
@@ -1104,6 +1247,31 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     return hipGetLastError();
 }
 
+// Which kernel launch_score picks for this store, as text (hc_get_kernel_info: tests and bench.py name the measured kernel with it).
+std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane_fetch_group) {
+    const uint32_t lg = lut_lg(st.K);
+    const std::string sym = st.symbytes == 2 ? "uint16_t" : "uint8_t";
+    const std::string enc = st.symbytes == 2 ? "u16" : (lg == 6 ? "wide8" : "packed8");
+    char buf[256];
+    if (fetch_group == 0) {
+        const bool coop = st.store_bytes < 0xFFFF0000ull;
+        const size_t lds_256 = coop_stage_base(st.lut_bytes, 256) + 4 * kStageBytesPerWave;
+        const uint32_t wg_c = 4 * lds_256 <= 160 * 1024 ? 256u : 1024u;
+        const size_t lds_c = coop_stage_base(st.lut_bytes, wg_c) + (wg_c / 64) * kStageBytesPerWave;
+        if (coop && lds_c <= 160 * 1024) {
+            snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, %u, true, %s> encoding=%s table_bytes=%u lds_bytes=%zu%s", sym.c_str(),
+                     st.symbytes == 2 ? 5u : lg, wg_c, st.balance ? "true" : "false", enc.c_str(), st.lut_bytes, lds_c,
+                     st.balance ? " length-bucketed (hc::bucket_perm_kernel, wave queue)" : "");
+            return buf;
+        }
+        fetch_group = lane_fetch_group;
+    }
+    const int g = st.symbytes == 2 ? 2 : (fetch_group == 2 ? 2 : 4);
+    snprintf(buf, sizeof buf, "hc::score_kernel<%s, %d, %u, %s> encoding=%s table_bytes=%u (one lane, one fetch)", sym.c_str(), g, st.symbytes == 2 ? 5u : lg,
+             st.balance ? "true" : "false", enc.c_str(), st.lut_bytes);
+    return buf;
+}
+
 namespace {
 template <typename SymT, int LG>
 hipError_t set_lds_limit_lg() {
@@ -1127,10 +1295,12 @@ hipError_t set_score_kernel_lds_limit() {
     hipError_t e;
     const int kMax = 160 * 1024;
 #define HC_COOP_ATTR(T_, LG_)                                                                                                                             \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;  \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;   \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;  \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;   \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;    \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;  \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     HC_COOP_ATTR(uint8_t, 3)
     HC_COOP_ATTR(uint8_t, 4)
     HC_COOP_ATTR(uint8_t, 5)

@@ -56,6 +56,12 @@ class EdgeScorer:
         return {"qual_alphabet": k.value, "store_bytes": sb.value, "x_edge": (d[0].value, d[1].value),
                 "x_ov": (d[2].value, d[3].value)}
 
+    def kernel_info(self):
+        """hc_get_kernel_info: the scoring kernel chosen for the read set, as text."""
+        buf = C.create_string_buffer(512)
+        N.check(N.lib.hc_get_kernel_info(self._ctx, buf, 512), "hc_get_kernel_info")
+        return buf.value.decode()
+
     def set_reorder(self, mode):
         """0 never, 1 always, 2 auto (hc_set_reorder)."""
         N.check(N.lib.hc_set_reorder(self._ctx, int(mode)), "hc_set_reorder")

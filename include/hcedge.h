@@ -303,6 +303,11 @@ int hc_time_score_kernel(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, uint64
 int hc_count_positions_device(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, uint64_t n, uint64_t* total_positions,
                               uint64_t* total_subs);
 
+/* The scoring kernel hc_set_reads chose for the read set, as text: the kernel's symbol (template arguments included: what
+ * rocprofv3's kernel trace lists), the symbol encoding, the log table's size and whether launches bucket their candidates
+ * by length first (read sets of mixed sequence length).  Diagnostics: tests and bench.py name what they measured with it. */
+int hc_get_kernel_info(hc_ctx* ctx, char* buf, uint32_t cap);
+
 /* Host finalisation of one record with the host libm exp(): score as the
  * reference returns it (EdgeCalculator.cpp:137-138, 254-261), mismatch_rate
  * (EdgeCalculator.cpp:132) and the class, AMBIG resolved. Pure function. */
