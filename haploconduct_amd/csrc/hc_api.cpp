@@ -421,6 +421,8 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         // with their candidates bucketed by length first (hc::bucket_perm_kernel)
         c->coop_fetch = true;
     }
+    c->view.long_rows = (n_seq && total / n_seq > 600) ? 1u : 0u;
+    if (const char* v = getenv("HC_LONG_ROWS")) c->view.long_rows = atoi(v) != 0;  // tuning knob
     return HC_OK;
 }
 

@@ -79,6 +79,13 @@ struct StoreView {
     uint32_t ulen;      // the common sequence length
     uint32_t n_single;  // reads [0, n_single) own one sequence, the others two
     uint32_t seq_syms;  // symbols per sequence in the store (both orientations): 2 * slot_stride(ulen)
+    // Contig-length sequences (mean length > 600): a candidate streams its two windows through dozens of 64-byte steps, and a
+    // 128-byte line fetched for one step is wanted again by the next.  With 16 waves on every CU the lines in use exceed an
+    // XCD's 4 MB L2 (32 CUs x 16 waves x 64 candidates x 2 windows x 128 B = 8.4 MB) and half of them are fetched twice; the
+    // launch therefore keeps 8 waves per CU (BASELINE config 5: 0.97 -> 0.75 ms; 12 waves 0.90, 4 waves 0.86;
+    // profiles/r03_occupancy.txt).  Short-read sets want all 16 (10^8 x 2 x 150 bp: 8 waves cost +27 %).
+    uint32_t long_rows;
+    uint32_t pad_;
 };
 
 // Log table layouts (doubles):

@@ -1175,6 +1175,13 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
         if (coop && lds_c <= 160 * 1024) {
             uint32_t per_cu = (uint32_t)((160 * 1024) / lds_c);
             per_cu = per_cu * (wg_c / 64) > 32 ? 32 / (wg_c / 64) : per_cu;
+            size_t lds_launch = lds_c;
+            static const int wg_per_cu = getenv("HC_COOP_WG_PER_CU") ? atoi(getenv("HC_COOP_WG_PER_CU")) : 0;  // experiment knob: fewer resident workgroups
+            const uint32_t want_per_cu = wg_per_cu > 0 ? (uint32_t)wg_per_cu : (st.long_rows && wg_c == 256 ? 2u : 0u);  // StoreView::long_rows
+            if (want_per_cu > 0 && want_per_cu < per_cu) {
+                per_cu = want_per_cu;
+                lds_launch = std::max(lds_c, (size_t)(160 * 1024) / (per_cu + 1) + 1024);  // LDS no other workgroup fits beside
+            }
             // mixed sequence lengths: bucket the candidates by (tile, length class) first; the waves then take groups of 64
             // ranks from a queue (bucket_perm_kernel)
             const bool bucketed = st.balance && bucket_perm && bucket_queue && n < (1ull << 32);
@@ -1197,22 +1204,22 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
 #define HC_COOP(T_, LG_)                                                                                                              \
     do {                                                                                                                              \
         if (wg_c == 256 && bucketed)                                                                                                  \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, \
                                prm, lut_g, in, n, out, perm, sink, bucket_queue);                                                     \
         else if (bucketed)                                                                                                            \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true, true>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream,   \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true, true>), dim3((uint32_t)blocks_c), dim3(1024), lds_launch, stream,   \
                                st, prm, lut_g, in, n, out, perm, sink, bucket_queue);                                                 \
         else if (wg_c == 256 && sort_subs)                                                                                            \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, false>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream, st, \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, false>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, \
                                prm, lut_g, in, n, out, perm, sink, nullptr);                                                          \
         else if (wg_c == 256)                                                                                                         \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, false, false>), dim3((uint32_t)blocks_c), dim3(256), lds_c, stream,   \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, false, false>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream,   \
                                st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
         else if (sort_subs)                                                                                                           \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream,  \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_launch, stream,  \
                                st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
         else                                                                                                                          \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, false, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_c, stream, \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, false, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_launch, stream, \
                                st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
     } while (0)
             if (st.symbytes == 2) HC_COOP(uint16_t, 5);
@@ -1259,8 +1266,11 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
         const uint32_t wg_c = 4 * lds_256 <= 160 * 1024 ? 256u : 1024u;
         const size_t lds_c = coop_stage_base(st.lut_bytes, wg_c) + (wg_c / 64) * kStageBytesPerWave;
         if (coop && lds_c <= 160 * 1024) {
-            snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, %u, true, %s> encoding=%s table_bytes=%u lds_bytes=%zu%s", sym.c_str(),
-                     st.symbytes == 2 ? 5u : lg, wg_c, st.balance ? "true" : "false", enc.c_str(), st.lut_bytes, lds_c,
+            uint32_t per_cu = (uint32_t)((160 * 1024) / lds_c);
+            per_cu = per_cu * (wg_c / 64) > 32 ? 32 / (wg_c / 64) : per_cu;
+            if (st.long_rows && wg_c == 256 && per_cu > 2) per_cu = 2;
+            snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, %u, true, %s> encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=%u%s", sym.c_str(),
+                     st.symbytes == 2 ? 5u : lg, wg_c, st.balance ? "true" : "false", enc.c_str(), st.lut_bytes, lds_c, per_cu * (wg_c / 64),
                      st.balance ? " length-bucketed (hc::bucket_perm_kernel, wave queue)" : "");
             return buf;
         }
