@@ -221,6 +221,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     uint64_t batch_hits = 1ull << 29;
     if (const char* e = getenv("HC_FIND_BATCH_HITS")) batch_hits = strtoull(e, nullptr, 10);
     if (batch_hits < 1024) batch_hits = 1024;
+    if (batch_hits > (1ull << 31)) batch_hits = 1ull << 31;  // the sorts (hc_prims.hip) index with 32 bits
     struct Batch {
         uint32_t q0, q1;
         uint64_t base, hits;

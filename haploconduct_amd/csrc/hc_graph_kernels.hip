@@ -11,16 +11,17 @@
 //                               OverlapGraph::inclusions from the record inserted FIRST (:459-468)
 //     -> select + stable sorts  survivors in sequence order -> adjacency lists (CSR) in the order the reference's
 //                               addEdge calls leave them, or in the order sortEdges() would re-order them to
-// All of it is HBM-bound integer work on a few per cent of the candidates: hipCUB's radix sort / select are used as
-// utilities, the record logic is hand-written.
+// All of it is HBM-bound integer work on a few per cent of the candidates; the radix sorts and selections are
+// hc_prims.hip's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <hipcub/hipcub.hpp>
+#include <algorithm>
 
 #include "../../include/hcedge.h"
 #include "hc_device.h"
 #include "hc_graph.h"
+#include "hc_prims.h"
 #include "hc_fno_device.h"
 
 namespace hc {
@@ -242,32 +243,22 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(const hc_edge_rec* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// host-side launchers (hc_api.cpp owns the buffers)
-namespace {
-template <typename T>
-struct IsSet {
-    const T* f;
-    __device__ __forceinline__ bool operator()(const uint32_t& i) const { return f[i] != 0; }
-};
-}  // namespace
+// host-side launchers (hc_api.cpp owns the buffers); sorting and selection: hc_prims.hip
 
-// the (64-bit key, 32-bit value) radix sort for other translation units (find-next-overlaps): one instantiation in the library
+// the (64-bit key, 32-bit value) radix sort for other translation units (find-next-overlaps); temp == nullptr: the scratch size
 hipError_t sort_pairs_u64_u32(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint32_t* v_in, uint32_t* v_out,
                               uint32_t n, int end_bit, hipStream_t s) {
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, s);
+    if (!temp) {
+        temp_bytes = prims::sort_temp_bytes(n, sizeof(uint64_t), sizeof(uint32_t));
+        return hipSuccess;
+    }
+    return prims::sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, end_bit, s);
 }
 
 size_t graph_temp_bytes(uint32_t m, uint32_t V) {
-    size_t best = 0, b = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
-                                             (uint32_t*)nullptr, (int)m);
-    best = b > best ? b : best;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                             (uint32_t*)nullptr, (int)m);
-    best = b > best ? b : best;
-    hipcub::CountingInputIterator<uint32_t> it(0);
-    (void)hipcub::DeviceSelect::If(nullptr, b, it, (uint32_t*)nullptr, (unsigned long long*)nullptr, (int)(m > V ? m : V), IsSet<uint8_t>{nullptr});
-    best = b > best ? b : best;
+    size_t best = prims::sort_temp_bytes(m, sizeof(uint64_t), sizeof(uint32_t));
+    best = std::max(best, prims::sort_temp_bytes(m, sizeof(uint32_t), sizeof(uint32_t)));
+    best = std::max(best, prims::select_temp_bytes(m > V ? m : V));
     return best;
 }
 
@@ -280,11 +271,10 @@ hipError_t graph_build_and_replay(const GraphParams& gp, const hc_admit_rec* A, 
     hipLaunchKernelGGL(edge_build_kernel, grid, block, 0, s, gp, A, m, E, key0, idx0, counters);
     int vbits = 1;
     while (vbits < 31 && (gp.n_vertices >> vbits)) vbits++;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key0, key1, idx0, idx1, (int)m, 0, 33 + vbits, s);
+    hipError_t e = prims::sort_pairs(temp, temp_bytes, key0, key1, idx0, idx1, m, 0, 33 + vbits, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(slot_replay_kernel, grid, block, 0, s, gp, E, key1, idx1, m, keep, inclusions, counters);
-    hipcub::CountingInputIterator<uint32_t> it(0);
-    return hipcub::DeviceSelect::If(temp, temp_bytes, it, survivors, d_count, (int)m, IsSet<uint8_t>{keep}, s);
+    return prims::select_flagged(temp, temp_bytes, keep, m, survivors, d_count, s);
 }
 
 // survivors (sequence order, n of them) -> O_out (CSR order of adj_out), out_off, O_in (CSR order of adj_in), in_off
@@ -307,31 +297,30 @@ hipError_t graph_orders(const GraphParams& gp, const hc_edge_rec* E, const uint3
         // adj_out[v]: survivors with vertex1 == v in sequence order; adj_in[w]: vertex1 of survivors with vertex2 == w
         // in sequence order (addEdge appends to both lists, OverlapGraph.cpp:94-101)
         hipLaunchKernelGGL(order_keys_kernel, grid, block, 0, s, gp, E, survivors, n, 0, k32a, (uint64_t*)nullptr);
-        if ((e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k32a, k32b, survivors, O_out, (int)n, 0, vbits, s)) != hipSuccess) return e;
+        if ((e = prims::sort_pairs(temp, temp_bytes, k32a, k32b, survivors, O_out, n, 0, vbits, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(offsets_kernel<uint32_t>, vgrid, block, 0, s, k32b, n, 0, V, out_off);
         hipLaunchKernelGGL(order_keys_kernel, grid, block, 0, s, gp, E, survivors, n, 1, k32a, (uint64_t*)nullptr);
-        if ((e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k32a, k32b, survivors, O_in, (int)n, 0, vbits, s)) != hipSuccess) return e;
+        if ((e = prims::sort_pairs(temp, temp_bytes, k32a, k32b, survivors, O_in, n, 0, vbits, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(offsets_kernel<uint32_t>, vgrid, block, 0, s, k32b, n, 0, V, in_off);
         return hipGetLastError();
     }
     // sortEdges: out-lists by (non-overlap length, vertex2), ties in sequence order (two stable LSD passes); adj_in
     // rebuilt by walking the sorted out-lists in vertex order (:751-762) = a stable sort of that order by vertex2
     hipLaunchKernelGGL(order_keys_kernel, grid, block, 0, s, gp, E, survivors, n, 1, k32a, (uint64_t*)nullptr);
-    if ((e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k32a, k32b, survivors, tmp_idx, (int)n, 0, vbits, s)) != hipSuccess) return e;
+    if ((e = prims::sort_pairs(temp, temp_bytes, k32a, k32b, survivors, tmp_idx, n, 0, vbits, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(order_keys_kernel, grid, block, 0, s, gp, E, tmp_idx, n, 2, (uint32_t*)nullptr, k64a);
-    if ((e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k64a, k64b, tmp_idx, O_out, (int)n, 0, 32 + vbits, s)) != hipSuccess) return e;
+    if ((e = prims::sort_pairs(temp, temp_bytes, k64a, k64b, tmp_idx, O_out, n, 0, 32 + vbits, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(offsets_kernel<uint64_t>, vgrid, block, 0, s, k64b, n, 32, V, out_off);
     hipLaunchKernelGGL(gather_u32_kernel, grid, block, 0, s, E, O_out, n, k32a);  // vertex2 in sorted out-order
     hipLaunchKernelGGL(tied_lists_kernel, grid, block, 0, s, k64b, k32a, n, out_off, tied);
-    if ((e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k32a, k32b, O_out, O_in, (int)n, 0, vbits, s)) != hipSuccess) return e;
+    if ((e = prims::sort_pairs(temp, temp_bytes, k32a, k32b, O_out, O_in, n, 0, vbits, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(offsets_kernel<uint32_t>, vgrid, block, 0, s, k32b, n, 0, V, in_off);
     return hipGetLastError();
 }
 
 hipError_t graph_select_tied(const uint8_t* tied, uint32_t V, uint32_t* out, unsigned long long* d_count, void* temp, size_t temp_bytes,
                              hipStream_t s) {
-    hipcub::CountingInputIterator<uint32_t> it(0);
-    return hipcub::DeviceSelect::If(temp, temp_bytes, it, out, d_count, (int)V, IsSet<uint8_t>{tied}, s);
+    return prims::select_flagged(temp, temp_bytes, tied, V, out, d_count, s);
 }
 
 hipError_t graph_gather(const hc_edge_rec* E, const uint32_t* O_out, const uint32_t* O_in, uint32_t n, hc_edge_rec* edges_out,

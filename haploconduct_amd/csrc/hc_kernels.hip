@@ -405,7 +405,7 @@ __host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t
 
 // One sub-overlap of each of the wave's 64 candidates.  Called by all 64 lanes; a lane without one passes L = 0.
 // offA / offB: byte offsets of the window starts in the store; L: positions (sub_positions()).
-template <typename SymT, int LG>
+template <typename SymT, int LG, int DEPTH = 1>
 __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint32_t oob, const SymT* __restrict__ sym, uint32_t stage, uint32_t offA,
                                                uint32_t offB, uint32_t L, uint32_t fatal, uint32_t Kp, SubScore& out) {
     using T = Tr<SymT>;
@@ -428,30 +428,31 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
     }
     const uint32_t wr = stage + lane * 16u;                                  // + j KiB: lane-linear
     const uint32_t rd = stage + lane * 64u + (((lane >> 2) & 3u) << 4);    // ^ piece << 4
-    u32x4 nA[4], nB[4];
-    auto fetch = [&](uint32_t at) {
+    // DEPTH register sets of pieces in flight: set s holds the pieces of the step it is consumed in and is refilled, right
+    // after its pieces went to LDS, with those of DEPTH steps further on
+    u32x4 nA[DEPTH][4], nB[DEPTH][4];
+    auto fetch = [&](u32x4 (&sA)[4], u32x4 (&sB)[4], uint32_t at) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool on = at < lim[j];
-            nA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] + at : oob, 0, HC_COOP_AUX_A);
-            nB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] + at : oob, 0, HC_COOP_AUX_B);
+            sA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] + at : oob, 0, HC_COOP_AUX_A);
+            sB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] + at : oob, 0, HC_COOP_AUX_B);
         }
     };
-    fetch(0);
     double S = 0.0;
     uint32_t skipped = 0, cm = 0;
-    for (uint32_t at = 0; __ballot(at < Lb) != 0ull; at += 64u) {  // wave-uniform
+    auto step = [&](u32x4 (&sA)[4], u32x4 (&sB)[4], uint32_t at) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_store128(wr + 1024u * j, nA[j]);
+        for (int j = 0; j < 4; ++j) lds_store128(wr + 1024u * j, sA[j]);
         wave_lds_order();
         u32x4 xa[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) xa[p] = lds_load128(rd ^ ((uint32_t)p << 4));
         wave_lds_order();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_store128(wr + 1024u * j, nB[j]);
+        for (int j = 0; j < 4; ++j) lds_store128(wr + 1024u * j, sB[j]);
         wave_lds_order();
-        fetch(at + 64u);
+        fetch(sA, sB, at + 64u * DEPTH);
         uint32_t cn4 = 0, cm4 = 0;
 #pragma unroll
         for (int q = 0; q < kChunks; ++q)
@@ -483,6 +484,15 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
             cm += cm4;
         }
         wave_lds_order();  // the owners' reads of this step's B rows stay in front of the next step's stores
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(nA[d], nB[d], 64u * d);
+    for (uint32_t at = 0; __ballot(at < Lb) != 0ull; at += 64u * DEPTH) {  // wave-uniform
+        step(nA[0], nB[0], at);
+        if (DEPTH == 2) {
+            if (__ballot(at + 64u < Lb) == 0ull) break;
+            step(nA[DEPTH - 1], nB[DEPTH - 1], at + 64u);
+        }
     }
     out.x = -__builtin_inf();
     out.mm = 1;
@@ -928,8 +938,10 @@ __global__ __launch_bounds__(1024) void bucket_perm_kernel(StoreView st, uint32_
 // longest lane, and with windows of 75..150 symbols next to each other a lane is busy 76 % of that time; sorted, the second
 // pass usually needs one 64-byte step less.  Parameters and results change lanes through the wave's own image space: no
 // workgroup barrier (a workgroup-wide sort saved more work and lost it again waiting at its seven barriers).
-template <typename SymT, int LG, int WG, bool SORT, bool DYN>
-__global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
+// DEPTH: steps of pieces in flight (2: the launch for contig-length read sets, which keeps 8 waves per CU and so has the
+// registers for a second set, StoreView::long_rows).
+template <typename SymT, int LG, int WG, bool SORT, bool DYN, int DEPTH = 1>
+__global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 2 : 1))) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                             const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
                                                             const uint32_t* __restrict__ perm, RowSink sink, uint32_t* __restrict__ queue) {
     // DYN (length-bucketed launches, bucket_perm_kernel): the waves take groups of 64 ranks from `queue`, each wave at its
@@ -1016,13 +1028,13 @@ __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score
             const u32x4 p0 = lds_load128(x + 16u * lane), p1 = lds_load128(x + 16u * (127u - lane));  // rank `lane`, then the other half mirrored
             wave_lds_order();
             SubScore r[2];
-            score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, p0[0], p0[1], p0[2] & 0x7FFFFFFFu, p0[2] >> 31, Kp, r[0]);
+            score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, p0[0], p0[1], p0[2] & 0x7FFFFFFFu, p0[2] >> 31, Kp, r[0]);
             r[1].x = -__builtin_inf();
             r[1].mm = 1;
             r[1].n = 1;
             r[1].err = p1[2] >> 31;
             if (__ballot((p1[2] & 0x7FFFFFFFu) != 0u) != 0ull)
-                score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, p1[0], p1[1], p1[2] & 0x7FFFFFFFu, p1[2] >> 31, Kp, r[1]);
+                score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, p1[0], p1[1], p1[2] & 0x7FFFFFFFu, p1[2] >> 31, Kp, r[1]);
             wave_lds_order();
             lds_store128(x + 16u * p0[3], u32x4{(uint32_t)__double2loint(r[0].x), (uint32_t)__double2hiint(r[0].x), r[0].mm, r[0].n | (r[0].err << 31)});
             lds_store128(x + 16u * p1[3], u32x4{(uint32_t)__double2loint(r[1].x), (uint32_t)__double2hiint(r[1].x), r[1].mm, r[1].n | (r[1].err << 31)});
@@ -1038,8 +1050,8 @@ __global__ __launch_bounds__(WG, WG == 256 ? 4 : (WG == 512 ? 2 : 1)) void score
             s2.n = q1[3] & 0x7FFFFFFFu;
             s2.err = q1[3] >> 31;
         } else {
-            score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, a0, b0, L0, sub0.fatal, Kp, s1);
-            if (__ballot(ns == 2) != 0ull) score_sub_coop<SymT, LG>(rsrc, oob, sym, stage, a1, b1, L1, sub1.fatal, Kp, s2);
+            score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, a0, b0, L0, sub0.fatal, Kp, s1);
+            if (__ballot(ns == 2) != 0ull) score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, a1, b1, L1, sub1.fatal, Kp, s2);
         }
         if (ns != 2) {  // what a candidate without a second sub-overlap reports (compute_overlap, s-s)
             s2.x = __builtin_nan("");
@@ -1191,6 +1203,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             if (blocks_c > cap_c) blocks_c = cap_c;
             const RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out};
             const bool sort_subs = bucketed || !(prm.pad & 1u);
+            static const int deep_env = getenv("HC_COOP_DEPTH") ? atoi(getenv("HC_COOP_DEPTH")) : 0;  // experiment knob: 1 = one step in flight always
+            const bool deep = bucketed && per_cu <= 2 && wg_c == 256 && deep_env != 1;
             if (bucketed) {
                 const uint32_t tiles = (uint32_t)((n + kBucketTile - 1) / kBucketTile);
                 if (st.symbytes == 2)
@@ -1203,7 +1217,10 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             }
 #define HC_COOP(T_, LG_)                                                                                                              \
     do {                                                                                                                              \
-        if (wg_c == 256 && bucketed)                                                                                                  \
+        if (wg_c == 256 && bucketed && deep)                                                                                          \
+            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true, 2>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, \
+                               st, prm, lut_g, in, n, out, perm, sink, bucket_queue);                                                 \
+        else if (wg_c == 256 && bucketed)                                                                                             \
             hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, \
                                prm, lut_g, in, n, out, perm, sink, bucket_queue);                                                     \
         else if (bucketed)                                                                                                            \
@@ -1269,8 +1286,9 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
             uint32_t per_cu = (uint32_t)((160 * 1024) / lds_c);
             per_cu = per_cu * (wg_c / 64) > 32 ? 32 / (wg_c / 64) : per_cu;
             if (st.long_rows && wg_c == 256 && per_cu > 2) per_cu = 2;
-            snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, %u, true, %s> encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=%u%s", sym.c_str(),
-                     st.symbytes == 2 ? 5u : lg, wg_c, st.balance ? "true" : "false", enc.c_str(), st.lut_bytes, lds_c, per_cu * (wg_c / 64),
+            const bool deep = st.balance && per_cu <= 2 && wg_c == 256;
+            snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, %u, true, %s%s> encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=%u%s", sym.c_str(),
+                     st.symbytes == 2 ? 5u : lg, wg_c, st.balance ? "true" : "false", deep ? ", 2" : "", enc.c_str(), st.lut_bytes, lds_c, per_cu * (wg_c / 64),
                      st.balance ? " length-bucketed (hc::bucket_perm_kernel, wave queue)" : "");
             return buf;
         }
@@ -1308,6 +1326,7 @@ hipError_t set_score_kernel_lds_limit() {
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;  \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;   \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;    \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;  \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;

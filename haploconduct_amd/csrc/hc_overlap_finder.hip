@@ -8,23 +8,23 @@
 // symbols taken at every s-th position of a sequence, k + s - 1 <= w guarantees that one seed lies inside that
 // window.  So:
 //   index    every k-mer of every forward sequence (2 bits per base, a k-mer with a non-ACGT symbol never
-//            matches) -> radix sort by k-mer                                             [hipCUB]
+//            matches) -> radix sort by k-mer                                             [hc_prims]
 //   seeds    k-mers at positions 0, s, 2s, ... of every sequence B, forward and (with reversals) reverse
 //            complement — the store holds both orientations — binary-searched in the index
 //   expand   every hit (A, q) with id(A) < id(B) gives a diagonal d = q - p: key (A, B, orientation, d); done in
 //            batches of seed sequences so that the number of hits in flight stays bounded whatever the coverage
-//   unique   radix sort + unique of the keys (many seeds find the same diagonal)          [hipCUB]
+//   unique   radix sort + unique of the keys (many seeds find the same diagonal)          [hc_prims]
 //   verify   one lane per candidate: overlap region, length >= T, mismatches <= floor(e*L) (N matches nothing);
 //            writes 8 bytes per candidate (mismatch count, flag), not a record
-//   emit     exclusive scan of the flags [hipCUB], then the records of the verified candidates in key order
+//   emit     exclusive scan of the flags [hc_prims], then the records of the verified candidates in key order
 // Every unordered pair is examined once (the lower id is the indexed side), so no record appears twice.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <hipcub/hipcub.hpp>
 
 #include "../../include/hcedge.h"
 #include "hc_device.h"
+#include "hc_prims.h"
 #include "hc_overlap_finder.h"
 
 namespace hc {
@@ -392,23 +392,43 @@ hipError_t finder_gather(const hc_sfo_rec* recs, const uint64_t* idx, uint64_t n
     return hipGetLastError();
 }
 
-// hipCUB steps; temp == nullptr returns the scratch size in *temp_bytes
+// sorting, scans and unique (hc_prims.hip); temp == nullptr returns the scratch size in temp_bytes
 hipError_t finder_sort_pairs(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint64_t* v_in, uint64_t* v_out,
                              uint64_t n, int end_bit, hipStream_t stream) {
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (int64_t)n, 0, end_bit, stream);
+    if (!temp) {
+        temp_bytes = prims::sort_temp_bytes(n, sizeof(uint64_t), sizeof(uint64_t));
+        return hipSuccess;
+    }
+    return prims::sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, n, 0, end_bit, stream);
 }
 hipError_t finder_sort_keys(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, uint64_t n, hipStream_t stream) {
-    return hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, k_in, k_out, (int64_t)n, 0, 64, stream);
+    if (!temp) {
+        temp_bytes = prims::sort_temp_bytes(n, sizeof(uint64_t), 0);
+        return hipSuccess;
+    }
+    return prims::sort_keys(temp, temp_bytes, k_in, k_out, n, 0, 64, stream);
 }
 hipError_t finder_scan(void* temp, size_t& temp_bytes, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t stream) {
-    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int64_t)n, stream);
+    if (!temp) {
+        temp_bytes = prims::scan_temp_bytes(n, sizeof(uint64_t));
+        return hipSuccess;
+    }
+    return prims::exclusive_sum(temp, temp_bytes, in, out, n, stream);
 }
 hipError_t finder_unique(void* temp, size_t& temp_bytes, const uint64_t* in, uint64_t* out, unsigned long long* n_out, uint64_t n,
                          hipStream_t stream) {
-    return hipcub::DeviceSelect::Unique(temp, temp_bytes, in, out, n_out, (int64_t)n, stream);
+    if (!temp) {
+        temp_bytes = prims::select_temp_bytes(n);
+        return hipSuccess;
+    }
+    return prims::unique(temp, temp_bytes, in, out, n_out, n, stream);
 }
 hipError_t finder_scan32(void* temp, size_t& temp_bytes, const uint32_t* in, uint32_t* out, uint64_t n, hipStream_t stream) {
-    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int64_t)n, stream);
+    if (!temp) {
+        temp_bytes = prims::scan_temp_bytes(n, sizeof(uint32_t));
+        return hipSuccess;
+    }
+    return prims::exclusive_sum(temp, temp_bytes, in, out, n, stream);
 }
 
 }  // namespace hc

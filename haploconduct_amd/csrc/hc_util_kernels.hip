@@ -1,14 +1,12 @@
 // hc_util_kernels.hip — the small kernels around the scoring kernel (gfx950): position counting for the
 // algorithmic-bytes figure, the optional candidate reorder, ordered stream compaction of the non-dropped records
-// and the packing of multi-GPU collection rows.  hipCUB (radix sort, select) is used as a utility here; the hot op
-// is the hand-written kernel in hc_kernels.hip.
+// and the packing of multi-GPU collection rows.  Sorting and selection: hc_prims.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <hipcub/hipcub.hpp>
-
 #include "../../include/hcedge.h"
 #include "hc_device.h"
+#include "hc_prims.h"
 #include "hc_resolve.h"
 
 namespace hc {
@@ -40,8 +38,7 @@ __global__ __launch_bounds__(256) void count_positions_kernel(StoreView st, uint
 // ---------------------------------------------------------------------------
 // Candidate reorder for locality: key = the smaller read index of the pair (the grouping real
 // overlap files have, scripts/sfo2overlaps.py:53); a stable LSD radix sort of (key, index) pairs
-// gives the permutation the scoring kernel walks.  hipCUB is used as a utility here; the hot op
-// stays the hand-written kernel above.
+// gives the permutation the scoring kernel walks.
 __global__ __launch_bounds__(256) void make_keys_kernel(uint32_t fmt, const void* __restrict__ in, uint32_t n,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,12 +48,7 @@ __global__ __launch_bounds__(256) void make_keys_kernel(uint32_t fmt, const void
     idx[i] = i;
 }
 
-size_t reorder_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    return bytes;
-}
+size_t reorder_temp_bytes(uint32_t n) { return prims::sort_temp_bytes(n, sizeof(uint32_t), sizeof(uint32_t)); }
 
 // keys_in/idx_in are scratch (n each); perm_out receives the permutation.
 hipError_t launch_reorder(uint32_t n_reads, uint32_t fmt, const void* in, uint32_t n, uint32_t* keys_in, uint32_t* keys_out,
@@ -65,28 +57,16 @@ hipError_t launch_reorder(uint32_t n_reads, uint32_t fmt, const void* in, uint32
     hipLaunchKernelGGL(make_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fmt, in, n, keys_in, idx_in);
     int end_bit = 1;
     while (end_bit < 32 && (n_reads >> end_bit)) end_bit++;  // keys < n_reads; a malformed record's key may exceed that: the result is a permutation either way
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm_out, (int)n, 0, end_bit, stream);
+    return prims::sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm_out, n, 0, end_bit, stream);
 }
 
 // ---------------------------------------------------------------------------
 // Compaction of the records the host / the gather still need (class != DROP), in sequence order.
-struct NotDropped {
-    const hc_result_rec* res;
-    __device__ __forceinline__ bool operator()(const uint32_t& i) const { return (res[i].n_cls >> 28) != HC_CLS_DROP; }
-};
-
-size_t compact_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
-    hipcub::CountingInputIterator<uint32_t> it(0);
-    (void)hipcub::DeviceSelect::If(nullptr, bytes, it, (uint32_t*)nullptr, (unsigned long long*)nullptr, (int)n,
-                                   NotDropped{nullptr});
-    return bytes;
-}
+size_t compact_temp_bytes(uint32_t n) { return prims::select_temp_bytes(n); }
 
 hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_out, unsigned long long* count_out, void* temp,
                           size_t temp_bytes, hipStream_t stream) {
-    hipcub::CountingInputIterator<uint32_t> it(0);
-    return hipcub::DeviceSelect::If(temp, temp_bytes, it, idx_out, count_out, (int)n, NotDropped{res}, stream);
+    return prims::select_not_dropped(temp, temp_bytes, res, n, idx_out, count_out, stream);
 }
 
 __global__ __launch_bounds__(256) void gather_results_kernel(const hc_result_rec* __restrict__ res,

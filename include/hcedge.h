@@ -308,6 +308,17 @@ int hc_count_positions_device(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, u
  * by length first (read sets of mixed sequence length).  Diagnostics: tests and bench.py name what they measured with it. */
 int hc_get_kernel_info(hc_ctx* ctx, char* buf, uint32_t cap);
 
+/* ---- device primitives (csrc/hc_prims.hip), behind host-buffer entry points for their unit tests ------------------
+ * The stage's device side sorts and compacts with its own kernels: a stable LSD radix sort (8 bits a pass; keys of 4 bytes
+ * with 4-byte values, keys of 8 bytes with values of 4, 8 or 0 bytes), an exclusive prefix sum (elements of 4 or 8
+ * bytes), the indices of the set flags in ascending order, and the first element of every run of equal neighbours.
+ * Synchronous, host buffers in and out, n < 2^32; the sort orders by bits [begin_bit, end_bit) of the key. */
+int hc_dev_radix_sort(uint32_t key_bytes, uint32_t val_bytes, const void* keys, const void* vals, void* keys_out, void* vals_out, uint64_t n,
+                      int begin_bit, int end_bit);
+int hc_dev_exclusive_sum(uint32_t elem_bytes, const void* in, void* out, uint64_t n);
+int hc_dev_select_flagged(const uint8_t* flags, uint64_t n, uint32_t* idx_out, uint64_t* count);
+int hc_dev_unique_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* count);
+
 /* Host finalisation of one record with the host libm exp(): score as the
  * reference returns it (EdgeCalculator.cpp:137-138, 254-261), mismatch_rate
  * (EdgeCalculator.cpp:132) and the class, AMBIG resolved. Pure function. */

@@ -132,7 +132,7 @@ def _slice_against_the_reference(reads, cand, st, tmp_path, lo, n_lines):
 
 def test_full_size_c5_bucketed_kernel_properties_and_oracle_sample(oracle, c5):
     reads, cand, st = c5
-    cls = _properties_and_oracle_sample(oracle, reads, cand, st, ["score_kernel_coop<uint8_t", "length-bucketed", "true, true>"], 6000)
+    cls = _properties_and_oracle_sample(oracle, reads, cand, st, ["score_kernel_coop<uint8_t", "length-bucketed", "true, true", "waves_per_cu=8"], 6000)
     assert 10000 < int(((cls == 2) | (cls == 3)).sum()) < cand.size
 
 
