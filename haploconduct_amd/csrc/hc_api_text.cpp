@@ -40,6 +40,10 @@ struct hc_textblock {
     unsigned long long* h_counters = nullptr;  // page-locked
     std::vector<hc_text_row> rows;             // what hc_textblock_wait hands out
     hc_bucket_ws bucket;                       // scratch of a length-bucketed scoring launch (read sets of mixed sequence length)
+    // the last submit, kept so that hc_textblock_wait can redo its device half with larger row buffers
+    uint64_t sub_bytes = 0, sub_first_line = 0, sub_base_index = 0;
+    const unsigned long long* sub_first_line_ptr = nullptr;
+    uint64_t n_regrown = 0;                    // how often that happened
     bool in_flight = false;
 };
 
@@ -198,6 +202,82 @@ int hc_textblock_destroy(hc_textblock* b) {
     return HC_OK;
 }
 
+// Parse -> score -> surviving rows in file order -> the mapped host buffers, on the block's stream: everything of a submit
+// behind the line starts.  Reads the block's text, line starts and counters[kTextLines / kTextOverflow] as they are on the device.
+static int textblock_device_half(hc_textblock* b) {
+    hc_ctx* c = b->ctx;
+    hipStream_t s = b->stream;
+    hc::TextParams prm;
+    prm.n_bytes = b->sub_bytes;
+    prm.first_line_no = b->sub_first_line;
+    prm.first_line_ptr = b->sub_first_line_ptr;
+    prm.max_overlaps = c->settings.max_overlaps;
+    prm.max_lines = b->max_lines;
+    prm.min_overlap_len = c->settings.min_overlap_len;
+    prm.min_overlap_perc = c->settings.min_overlap_perc;
+    prm.relax_pe = (c->settings.flags & HC_FLAG_RELAX_PE_EDGES) ? 1u : 0u;
+    prm.reject_cap = b->row_cap;
+    prm.pad = 0;
+    hc::IdTable ids;
+    ids.table = c->id_table.as<uint32_t>();
+    ids.keys = c->id_keys.as<uint64_t>();
+    ids.size = c->id_size;
+    ids.shift = c->id_shift;
+    ids.direct = c->id_direct;
+    void *d_rejects = nullptr, *d_rows = nullptr, *d_row_lines = nullptr;
+    HC_HIP(hipHostGetDevicePointer(&d_rejects, b->h_rejects, 0));
+    HC_HIP(hipHostGetDevicePointer(&d_rows, b->h_rows, 0));
+    HC_HIP(hipHostGetDevicePointer(&d_row_lines, b->h_row_lines, 0));
+    HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, b->d_tally, s));
+    // the scoring kernel on the records the parse kernel left behind; how many there are is only known on the device
+    int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_cands, b->max_lines, b->d_out, s, false, nullptr, nullptr, 0, 0,
+                          b->d_counters + hc::kTextLines, nullptr, nullptr, &b->bucket);
+    if (rc) return rc;
+    HC_HIP(hc::launch_kept_rows(b->d_out, b->max_lines, b->d_counters + hc::kTextLines, b->sub_base_index, b->d_kept_tiles,
+                                b->d_kept_tiles + (b->max_lines / 1024 + 2), b->d_rows, b->row_cap, b->d_counters + hc::kTextRows, b->d_lines,
+                                b->d_row_lines, s));
+    HC_HIP(hc::launch_flush_rows(b->d_rows, d_rows, b->d_counters + hc::kTextRows, b->row_cap, sizeof(hc_gather_row), c->n_cu, s));
+    HC_HIP(hc::launch_flush_rows(b->d_row_lines, d_row_lines, b->d_counters + hc::kTextRows, b->row_cap, sizeof(hc_line_rec), c->n_cu, s));
+    return HC_OK;
+}
+
+// More surviving rows (or prefilter rejects) than the block's row buffers hold: real files can keep more than the eighth
+// of the lines the buffers start with (overlaps found at a low error rate; later iterations).  The text, its line starts and
+// the line count are still on the device and the device's parse is good: the buffers grow to what this block needs (and stay
+// that size) and the device half runs again — the block does not fall back to the host's tokeniser.
+static int textblock_regrow(hc_textblock* b, uint64_t need) {
+    hc_ctx* c = b->ctx;
+    uint64_t cap = need + need / 8 + 1024;
+    if (cap > b->max_lines) cap = b->max_lines;
+    if (cap < need) return fail(HC_ERR_STATE, "hc_textblock_wait: more rows than lines");
+    HC_HIP(hipStreamSynchronize(b->stream));
+    for (void* p : {(void*)b->d_rows, (void*)b->d_row_lines})
+        if (p) (void)hipFree(p);
+    for (void* p : {(void*)b->h_rows, (void*)b->h_row_lines, (void*)b->h_rejects})
+        if (p) (void)hipHostFree(p);
+    b->d_rows = nullptr;
+    b->d_row_lines = nullptr;
+    b->h_rows = nullptr;
+    b->h_row_lines = nullptr;
+    b->h_rejects = nullptr;
+    b->row_cap = (uint32_t)cap;
+    HC_HIP(hipMalloc((void**)&b->d_rows, cap * sizeof(hc_gather_row)));
+    HC_HIP(hipMalloc((void**)&b->d_row_lines, cap * sizeof(hc_line_rec)));
+    HC_HIP(hipHostMalloc((void**)&b->h_rows, cap * sizeof(hc_gather_row), hipHostMallocMapped));
+    HC_HIP(hipHostMalloc((void**)&b->h_row_lines, cap * sizeof(hc_line_rec), hipHostMallocMapped));
+    HC_HIP(hipHostMalloc((void**)&b->h_rejects, cap * sizeof(hc_text_reject), hipHostMallocMapped));
+    // what the device half adds to: the parse kernel's tallies and slots, the row count (lines / overflow stay)
+    HC_HIP(hipMemsetAsync(b->d_counters, 0, hc::kTextLines * sizeof(unsigned long long), b->stream));
+    HC_HIP(hipMemsetAsync(b->d_counters + hc::kTextRows, 0, (hc::kTextCounters - hc::kTextRows) * sizeof(unsigned long long), b->stream));
+    int rc = textblock_device_half(b);
+    if (rc) return rc;
+    HC_HIP(hipMemcpyAsync(b->h_counters, b->d_counters, hc::kTextCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    HC_HIP(hipStreamSynchronize(b->stream));
+    b->n_regrown++;
+    (void)c;
+    return HC_OK;
+}
+
 static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, uint64_t first_line_no, hc_linechain* chain, uint64_t k,
                             hc_textblock* prev, uint64_t base_index);
 
@@ -237,44 +317,21 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
         HC_HIP(hc::launch_text_chain(d_chain + k, b->d_counters, d_chain + k + 1, s));
         HC_HIP(hipEventRecord(b->lines_known, s));
     }
+    b->sub_bytes = n_bytes;
+    b->sub_first_line = first_line_no;
+    b->sub_first_line_ptr = chain ? d_chain + k : nullptr;
+    b->sub_base_index = base_index;
     if (n_bytes) {
-        hc::TextParams prm;
-        prm.n_bytes = n_bytes;
-        prm.first_line_no = first_line_no;
-        prm.first_line_ptr = chain ? d_chain + k : nullptr;
-        prm.max_overlaps = c->settings.max_overlaps;
-        prm.max_lines = b->max_lines;
-        prm.min_overlap_len = c->settings.min_overlap_len;
-        prm.min_overlap_perc = c->settings.min_overlap_perc;
-        prm.relax_pe = (c->settings.flags & HC_FLAG_RELAX_PE_EDGES) ? 1u : 0u;
-        prm.reject_cap = b->row_cap;
-        prm.pad = 0;
-        hc::IdTable ids;
-        ids.table = c->id_table.as<uint32_t>();
-        ids.keys = c->id_keys.as<uint64_t>();
-        ids.size = c->id_size;
-        ids.shift = c->id_shift;
-        ids.direct = c->id_direct;
-        void *d_rejects = nullptr, *d_rows = nullptr, *d_row_lines = nullptr;
-        HC_HIP(hipHostGetDevicePointer(&d_rejects, b->h_rejects, 0));
-        HC_HIP(hipHostGetDevicePointer(&d_rows, b->h_rows, 0));
-        HC_HIP(hipHostGetDevicePointer(&d_row_lines, b->h_row_lines, 0));
-        HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, b->d_tally, s));
-        // the scoring kernel on the records the parse kernel left behind; how many there are is only known on the device
-        int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_cands, b->max_lines, b->d_out, s, false, nullptr, nullptr, 0, 0,
-                              b->d_counters + hc::kTextLines, nullptr, nullptr, &b->bucket);
+        int rc = textblock_device_half(b);
         if (rc) return rc;
-        HC_HIP(hc::launch_kept_rows(b->d_out, b->max_lines, b->d_counters + hc::kTextLines, base_index, b->d_kept_tiles,
-                                    b->d_kept_tiles + (b->max_lines / 1024 + 2), b->d_rows, b->row_cap, b->d_counters + hc::kTextRows, b->d_lines,
-                                    b->d_row_lines, s));
-        HC_HIP(hc::launch_flush_rows(b->d_rows, d_rows, b->d_counters + hc::kTextRows, b->row_cap, sizeof(hc_gather_row), c->n_cu, s));
-        HC_HIP(hc::launch_flush_rows(b->d_row_lines, d_row_lines, b->d_counters + hc::kTextRows, b->row_cap, sizeof(hc_line_rec), c->n_cu, s));
     }
     HC_HIP(hipMemcpyAsync(b->h_counters, b->d_counters, hc::kTextCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HC_HIP(hipEventRecord(b->done, s));
     b->in_flight = true;
     return HC_OK;
 }
+
+uint64_t hc_textblock_regrown(hc_textblock* b) { return b ? b->n_regrown : 0; }
 
 int hc_textblock_wait(hc_textblock* b, hc_text_result* out) {
     if (!b || !out) return fail(HC_ERR_ARG, "hc_textblock_wait: null argument");
@@ -284,6 +341,13 @@ int hc_textblock_wait(hc_textblock* b, hc_text_result* out) {
     HC_HIP(hipEventSynchronize(b->done));
     b->in_flight = false;
     const unsigned long long* k = b->h_counters;
+    if (!(k[hc::kTextOverflow] || k[hc::kTextNonPlain] || k[hc::kTextUnknownId]) &&
+        (k[hc::kTextRows] > b->row_cap || k[hc::kTextRejectSlots] > b->row_cap)) {
+        const uint64_t need = k[hc::kTextRows] > k[hc::kTextRejectSlots] ? k[hc::kTextRows] : k[hc::kTextRejectSlots];
+        int rc = textblock_regrow(b, need);
+        if (rc) return rc;
+        k = b->h_counters;
+    }
     out->n_lines = k[hc::kTextLines];
     out->lines_read = k[hc::kTextRead];
     out->n_nonplain = k[hc::kTextNonPlain];

@@ -3,13 +3,17 @@
 // (hc_graph_kernels.hip), the overlap finder, the SFO ingest and find-next-overlaps — all HBM-bound integer work.
 //
 // Radix sort, one pass (8 bits) = three launches, no spinning between workgroups (nothing here can hang):
-//   upsweep    workgroup b counts the digits of its contiguous range of tiles  -> counts[digit][b]
-//   spine      one workgroup: exclusive scan of counts in (digit, b) order     -> where (digit, b) starts in the output
-//   downsweep  workgroup b walks its tiles in order; per tile: every wave ranks its items by digit with eight ballots
-//              (lanes holding the same digit find each other; the lowest of them bumps the wave's digit counter in LDS
-//              once for all), a 256-lane scan over the digits places the tile in LDS sorted by digit, and the tile leaves
-//              as runs of consecutive addresses.  Items keep their order within a digit (stable): wave-striped
-//              loads make index order = (wave, item, lane) order, which is the order the ranks are dealt in.
+//   upsweep    workgroup b counts the digits of its contiguous range of tiles   -> counts[b][digit]
+//   groups     one workgroup per 32 consecutive ranges: counts[b][digit] becomes the prefix inside the group, the group's
+//              sums go to sums[group][digit] (no single workgroup walks the whole table: with 1 024 ranges that took
+//              0.4 ms a pass, five times the pass itself for 10^7 items)
+//   downsweep  workgroup b first adds up what is in front of it — the digit's total over all groups below the digit, the
+//              sums of the groups in front of its own, its prefix inside the group: at most 32 + 1 rows of 1 KiB — then
+//              walks its tiles in order; per tile: every wave ranks its items by digit with eight ballots (lanes holding the
+//              same digit find each other; the lowest of them bumps the wave's digit counter in LDS once for all), a
+//              256-lane scan over the digits places the tile in LDS sorted by digit, and the tile leaves as runs of
+//              consecutive addresses.  Items keep their order within a digit (stable): wave-striped loads make index
+//              order = (wave, item, lane) order, which is the order the ranks are dealt in.
 // Bytes per item and pass: key read twice, written once; value read and written once.
 #include "hc_prims.h"
 
@@ -87,13 +91,29 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep_kernel(const K* __rest
     }
     for (; i < hi; i += kThreads) atomicAdd(&h[wave][(uint32_t)(keys[i] >> shift) & mask], 1u);
     __syncthreads();
-    counts[(uint64_t)tid * G + blockIdx.x] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    counts[(uint64_t)blockIdx.x * 256 + tid] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+}
+
+constexpr uint32_t kGroup = 32;  // ranges per group of the offset table
+__global__ __launch_bounds__(256) void radix_groups_kernel(uint32_t* __restrict__ counts, uint32_t G, uint32_t* __restrict__ sums) {
+    const uint32_t d = threadIdx.x, b0 = blockIdx.x * kGroup;
+    uint32_t v[kGroup];
+#pragma unroll
+    for (uint32_t j = 0; j < kGroup; ++j) v[j] = b0 + j < G ? counts[(uint64_t)(b0 + j) * 256 + d] : 0u;
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kGroup; ++j) {
+        if (b0 + j < G) counts[(uint64_t)(b0 + j) * 256 + d] = run;
+        run += v[j];
+    }
+    sums[(uint64_t)blockIdx.x * 256 + d] = run;
 }
 
 template <typename K, typename V, bool HAS_V>
 __global__ __launch_bounds__(kThreads) void radix_downsweep_kernel(const K* __restrict__ k_in, K* __restrict__ k_out, const V* __restrict__ v_in,
                                                                    V* __restrict__ v_out, uint64_t n, int shift, uint32_t mask, uint32_t tiles_per_block,
-                                                                   uint32_t G, const uint32_t* __restrict__ offsets) {
+                                                                   uint32_t G, const uint32_t* __restrict__ offsets /* prefix inside the group */,
+                                                                   const uint32_t* __restrict__ sums /* [groups][256] */) {
     __shared__ K skeys[kTile];
     __shared__ V svals[HAS_V ? kTile : 1];
     __shared__ uint32_t wcount[4][256];  // per wave: running count of a digit while ranking, then the wave's offset inside the digit
@@ -102,7 +122,22 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep_kernel(const K* __re
     __shared__ uint32_t gbase[256];      // global position of this workgroup's next item of a digit
     __shared__ uint32_t wsum[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    gbase[tid] = offsets[(uint64_t)tid * G + blockIdx.x];
+    {  // where this workgroup's first item of digit tid goes
+        const uint32_t groups = (G + kGroup - 1) / kGroup, mine = blockIdx.x / kGroup;
+        uint32_t total = 0, before = 0;
+        for (uint32_t g = 0; g < groups; ++g) {
+            const uint32_t v = sums[(uint64_t)g * 256 + tid];
+            total += v;
+            before += g < mine ? v : 0u;
+        }
+        const uint32_t incl = wave_incl_scan(total, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t lower = incl - total;  // items of smaller digits
+        for (uint32_t w = 0; w < wave; ++w) lower += wsum[w];
+        gbase[tid] = lower + before + offsets[(uint64_t)blockIdx.x * 256 + tid];
+        __syncthreads();  // wsum is used again per tile
+    }
     const uint64_t lo = (uint64_t)blockIdx.x * tiles_per_block * kTile;
     uint64_t hi = lo + (uint64_t)tiles_per_block * kTile;
     hi = hi < n ? hi : n;
@@ -186,7 +221,7 @@ SortPlan plan_sort(uint64_t n, size_t kb, size_t vb) {
     const uint64_t tiles = (n + kTile - 1) / kTile;
     p.tiles_per_block = (uint32_t)std::max<uint64_t>(1, (tiles + kMaxBlocks - 1) / kMaxBlocks);
     p.G = (uint32_t)std::max<uint64_t>(1, (tiles + p.tiles_per_block - 1) / p.tiles_per_block);
-    p.counts_bytes = (((size_t)256 * p.G * sizeof(uint32_t)) + 255) & ~(size_t)255;
+    p.counts_bytes = (((size_t)256 * (p.G + (p.G + kGroup - 1) / kGroup) * sizeof(uint32_t)) + 255) & ~(size_t)255;  // counts, then the groups' sums
     p.keys_off = p.counts_bytes;
     p.vals_off = p.keys_off + ((n * kb + 255) & ~(size_t)255);
     p.total = p.vals_off + ((n * vb + 255) & ~(size_t)255);
@@ -208,6 +243,7 @@ hipError_t radix_sort(void* temp, size_t temp_bytes, const K* k_in, K* k_out, co
         return hipSuccess;
     }
     uint32_t* counts = (uint32_t*)temp;
+    uint32_t* sums = counts + (size_t)256 * p.G;
     K* tk = (K*)((char*)temp + p.keys_off);
     V* tv = (V*)((char*)temp + p.vals_off);
     const K* sk = k_in;
@@ -220,9 +256,9 @@ hipError_t radix_sort(void* temp, size_t temp_bytes, const K* k_in, K* k_out, co
         K* dk = to_out ? k_out : tk;
         V* dv = to_out ? v_out : tv;
         hipLaunchKernelGGL((radix_upsweep_kernel<K>), dim3(p.G), dim3(kThreads), 0, s, sk, n, shift, mask, p.tiles_per_block, p.G, counts);
-        hipLaunchKernelGGL((spine_scan_kernel<uint32_t>), dim3(1), dim3(1024), 0, s, counts, (uint64_t)256 * p.G, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(radix_groups_kernel, dim3((p.G + kGroup - 1) / kGroup), dim3(256), 0, s, counts, p.G, sums);
         hipLaunchKernelGGL((radix_downsweep_kernel<K, V, HAS_V>), dim3(p.G), dim3(kThreads), 0, s, sk, dk, sv, dv, n, shift, mask, p.tiles_per_block,
-                           p.G, counts);
+                           p.G, (const uint32_t*)counts, (const uint32_t*)sums);
         sk = dk;
         sv = dv;
     }
@@ -274,14 +310,35 @@ __global__ __launch_bounds__(kThreads) void scan_apply_kernel(const T* __restric
     }
 }
 
+// In-place exclusive scan of M entries (tile sums / tile counts), *total = their sum: one workgroup while that is quick
+// (M <= 8 192: eight entries per lane), else the three-launch form once more with its own small table behind `spare`.
+constexpr uint64_t kSpineMax = 8192;
+template <typename T>
+size_t spine_spare_bytes(uint64_t M) { return M > kSpineMax ? ((M + kTile - 1) / kTile + 1) * sizeof(T) : 0; }
+template <typename T>
+hipError_t scan_inplace(T* data, uint64_t M, unsigned long long* total, void* spare, hipStream_t s) {
+    if (M <= kSpineMax) {
+        hipLaunchKernelGGL((spine_scan_kernel<T>), dim3(1), dim3(1024), 0, s, data, M, total);
+        return hipGetLastError();
+    }
+    const uint64_t tiles = (M + kTile - 1) / kTile;
+    if (tiles > kSpineMax) return hipErrorInvalidValue;
+    T* tile = (T*)spare;
+    hipLaunchKernelGGL((scan_tile_sums_kernel<T>), dim3((uint32_t)tiles), dim3(kThreads), 0, s, (const T*)data, M, tile);
+    hipLaunchKernelGGL((spine_scan_kernel<T>), dim3(1), dim3(1024), 0, s, tile, tiles, total);
+    hipLaunchKernelGGL((scan_apply_kernel<T>), dim3((uint32_t)tiles), dim3(kThreads), 0, s, (const T*)data, data, M, (const T*)tile);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t exclusive_sum_t(void* temp, size_t temp_bytes, const T* in, T* out, uint64_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint64_t tiles = (n + kTile - 1) / kTile;
-    if (tiles >= (1ull << 31) || !temp || temp_bytes < tiles * sizeof(T)) return hipErrorInvalidValue;
+    if (tiles >= (1ull << 31) || !temp || temp_bytes < tiles * sizeof(T) + spine_spare_bytes<T>(tiles)) return hipErrorInvalidValue;
     T* tile = (T*)temp;
     hipLaunchKernelGGL((scan_tile_sums_kernel<T>), dim3((uint32_t)tiles), dim3(kThreads), 0, s, in, n, tile);
-    hipLaunchKernelGGL((spine_scan_kernel<T>), dim3(1), dim3(1024), 0, s, tile, tiles, (unsigned long long*)nullptr);
+    hipError_t e = scan_inplace<T>(tile, tiles, nullptr, tile + tiles, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((scan_apply_kernel<T>), dim3((uint32_t)tiles), dim3(kThreads), 0, s, in, out, n, (const T*)tile);
     return hipGetLastError();
 }
@@ -350,10 +407,11 @@ template <typename Pred, typename Emit>
 hipError_t select_t(void* temp, size_t temp_bytes, Pred pred, Emit emit, uint64_t n, unsigned long long* count, hipStream_t s) {
     if (n == 0) return hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
     const uint64_t tiles = (n + kTile - 1) / kTile;
-    if (n >= (1ull << 32) || !temp || temp_bytes < tiles * sizeof(uint32_t)) return hipErrorInvalidValue;
+    if (n >= (1ull << 32) || !temp || temp_bytes < tiles * sizeof(uint32_t) + spine_spare_bytes<uint32_t>(tiles)) return hipErrorInvalidValue;
     uint32_t* tile = (uint32_t*)temp;
     hipLaunchKernelGGL((select_count_kernel<Pred>), dim3((uint32_t)tiles), dim3(kThreads), 0, s, pred, n, tile);
-    hipLaunchKernelGGL((spine_scan_kernel<uint32_t>), dim3(1), dim3(1024), 0, s, tile, tiles, count);
+    hipError_t e = scan_inplace<uint32_t>(tile, tiles, count, tile + tiles, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((select_scatter_kernel<Pred, Emit>), dim3((uint32_t)tiles), dim3(kThreads), 0, s, pred, emit, n, (const uint32_t*)tile);
     return hipGetLastError();
 }
@@ -380,7 +438,10 @@ hipError_t sort_keys(void* temp, size_t temp_bytes, const uint64_t* k_in, uint64
                                                  stream);
 }
 
-size_t scan_temp_bytes(uint64_t n, size_t elem_bytes) { return ((n + kTile - 1) / kTile + 1) * elem_bytes; }
+size_t scan_temp_bytes(uint64_t n, size_t elem_bytes) {
+    const uint64_t tiles = (n + kTile - 1) / kTile + 1;
+    return (tiles + (tiles + kTile - 1) / kTile + 2) * elem_bytes;
+}
 hipError_t exclusive_sum(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint64_t n, hipStream_t stream) {
     return exclusive_sum_t<uint32_t>(temp, temp_bytes, in, out, n, stream);
 }
@@ -388,7 +449,7 @@ hipError_t exclusive_sum(void* temp, size_t temp_bytes, const uint64_t* in, uint
     return exclusive_sum_t<uint64_t>(temp, temp_bytes, in, out, n, stream);
 }
 
-size_t select_temp_bytes(uint64_t n) { return ((n + kTile - 1) / kTile + 1) * sizeof(uint32_t); }
+size_t select_temp_bytes(uint64_t n) { return scan_temp_bytes(n, sizeof(uint32_t)); }
 hipError_t select_flagged(void* temp, size_t temp_bytes, const uint8_t* flags, uint64_t n, uint32_t* idx_out, unsigned long long* count,
                           hipStream_t stream) {
     return select_t(temp, temp_bytes, FlagPred{flags}, EmitIndex{idx_out}, n, count, stream);

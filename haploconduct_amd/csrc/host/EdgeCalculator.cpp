@@ -751,6 +751,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                     if (mine.status) throw mine;
                     if (tr.needs_host) {  // the host's tokeniser + Overlap constructor own this block
                         n_host_blocks++;
+                        stats.host_blocks++;
                         parser.parse_range(sl.begin, sl.end, chained ? lines_consumed.load() : sl.first_line, host_batch, rejected, pc,
                                            /*print_malformed=*/true);
                         const size_t n = host_batch.size();
@@ -770,6 +771,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                         }
                         finalize_block(host_batch, rows, n_rows, 0, out);
                     } else {
+                        stats.device_blocks++;
                         pc.lines_read += tr.lines_read;
                         pc.self_overlaps += tr.self_overlaps;
                         pc.silently_dropped += tr.silently_dropped;
@@ -779,12 +781,18 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                     }
                     consume_block(out);
                     if (sl.tb) lines_consumed += tr.n_lines;  // (a block that never went to the device is the file's last)
-                } catch (const FatalError& e) {
-                    collector_error = e;
-                    collector_failed = true;
+                } catch (const FatalError& e) {  // the submitter may be reporting a failure of its own: under mu, the first error wins
+                    std::lock_guard<std::mutex> g(mu);
+                    if (!collector_failed) {
+                        collector_error = e;
+                        collector_failed = true;
+                    }
                 } catch (const std::exception& e) {
-                    collector_error = FatalError{HC_ERR_NOMEM, e.what()};
-                    collector_failed = true;
+                    std::lock_guard<std::mutex> g(mu);
+                    if (!collector_failed) {
+                        collector_error = FatalError{HC_ERR_NOMEM, e.what()};
+                        collector_failed = true;
+                    }
                 }
             }
             {
@@ -963,6 +971,8 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     stop_collector();
     if (collector_failed) throw collector_error;
     stats.t_score = t_collect;
+    for (Device& dev : m_dev)
+        for (hc_textblock* tb : dev.tblk) stats.regrown_blocks += hc_textblock_regrown(tb);
     if (getenv("HC_STAGE_TIMING"))
         fprintf(stderr, "[hc stage] device-parsed pipeline: %lu block(s) went to the host parser; producer: waiting for a block object %.3f s, "
                         "copy %.3f s, submit %.3f s; %u collector(s), summed: waiting for the device + ordering rows %.3f s, finalise %.3f s, "
@@ -1024,11 +1034,17 @@ void EdgeCalculator::score_host_parsed(OverlapsParser& parser, std::vector<Overl
                     t_collect += now_s() - t0;
                     consume_block(out);
                 } catch (const FatalError& e) {
-                    collector_error = e;
-                    collector_failed = true;
+                    std::lock_guard<std::mutex> g(mu);
+                    if (!collector_failed) {
+                        collector_error = e;
+                        collector_failed = true;
+                    }
                 } catch (const std::exception& e) {
-                    collector_error = FatalError{HC_ERR_NOMEM, e.what()};
-                    collector_failed = true;
+                    std::lock_guard<std::mutex> g(mu);
+                    if (!collector_failed) {
+                        collector_error = FatalError{HC_ERR_NOMEM, e.what()};
+                        collector_failed = true;
+                    }
                 }
             } else if (sl.block) {  // drain: the block object must not stay in flight
                 const hc_gather_row* rows = nullptr;

@@ -83,6 +83,9 @@ public:
         uint64_t lines_read = 0, malformed = 0, self_overlaps = 0, prefilter_rejected = 0, scored = 0, edges_added = 0,
                  nonedges_written = 0, ambiguous = 0, silently_dropped = 0;
         double t_parse = 0, t_score = 0, t_insert = 0, t_write = 0;
+        // blocks of the overlaps file's text: parsed on the device / taken over by the host's tokeniser (a line that is not
+        // plain, an unknown id, more lines than room) / device blocks that ran twice because their row buffers had to grow
+        uint64_t device_blocks = 0, host_blocks = 0, regrown_blocks = 0;
     } stats;
 
 private:

@@ -150,6 +150,9 @@ int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* c) {
     c->t_score = s.t_score;
     c->t_insert = s.t_insert;
     c->t_write = s.t_write;
+    c->device_blocks = s.device_blocks;
+    c->host_blocks = s.host_blocks;
+    c->regrown_blocks = s.regrown_blocks;
     return HC_OK;
 }
 

@@ -386,6 +386,9 @@ int hc_linechain_destroy(hc_linechain* chain);
 int hc_textblock_submit_from(hc_textblock* b, const void* text, uint64_t n_bytes, hc_linechain* chain, uint64_t k, hc_textblock* prev,
                              uint64_t base_index);
 int hc_textblock_wait(hc_textblock* b, hc_text_result* out); /* valid until the next submit on this block */
+/* A block starts with row buffers for an eighth of its lines; a block with more surviving records (or prefilter rejects)
+ * grows them inside hc_textblock_wait and runs its device half again — it does not go to the host.  How often so far: */
+uint64_t hc_textblock_regrown(hc_textblock* b);
 int hc_textblock_destroy(hc_textblock* b);
 
 /* ---- duplicate resolution + adjacency on the device -----------------------------------------

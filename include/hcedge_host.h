@@ -34,6 +34,10 @@ typedef struct hc_ec_counters {
     uint64_t edges_added, nonedges_written, prefilter_rejected, malformed_lines, lines_read, scored;
     uint64_t ambiguous, silently_dropped;
     double t_parse, t_score, t_insert, t_write; /* seconds, build-owned breakdown */
+    /* blocks of the overlaps file's text: parsed on the device; taken over by the host's tokeniser (a line that is not
+     * plain, an id that is not in the FASTQ input, more lines than a block has room for); device blocks whose row buffers
+     * had to grow, so that their device half ran twice (more than an eighth of the lines survived scoring) */
+    uint64_t device_blocks, host_blocks, regrown_blocks;
 } hc_ec_counters;
 
 typedef struct hc_ec hc_ec; /* FastqStorage + OverlapGraph + EdgeCalculator */

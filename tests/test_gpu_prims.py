@@ -49,7 +49,7 @@ def test_radix_sort_is_numpys_stable_sort(kdt, vdt, n):
 
 
 @pytest.mark.parametrize("dt", [np.uint32, np.uint64])
-@pytest.mark.parametrize("n", SIZES + [2048 * 1024 * 3 + 1])
+@pytest.mark.parametrize("n", SIZES + [2048 * 1024 * 3 + 1, 2048 * 8192 + 5])
 def test_exclusive_sum(dt, n):
     rng = np.random.default_rng(n)
     a = rng.integers(0, 50 if dt == np.uint32 else 1 << 40, n).astype(dt)
@@ -59,7 +59,7 @@ def test_exclusive_sum(dt, n):
     assert np.array_equal(out, want)
 
 
-@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("n", SIZES + [2048 * 8192 + 5])
 @pytest.mark.parametrize("density", [0.0, 0.03, 0.5, 1.0])
 def test_select_flagged(n, density):
     rng = np.random.default_rng(n + int(density * 100))

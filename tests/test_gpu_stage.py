@@ -530,3 +530,43 @@ def test_stage_device_mask(tmp_path):
                                          overlaps=str(tmp_path / "overlaps.txt"), output_dir=str(tmp_path) + "/")
     finally:
         os.environ.pop("HC_TEXT_BLOCK", None)
+
+
+@pytest.mark.parametrize("what", ["survivors", "rejects"])
+def test_blocks_where_most_lines_survive_stay_on_the_device(oracle, tmp_path, monkeypatch, what):
+    """A text block starts with row buffers for an eighth of its lines (real files keep a few per cent).  Error-free reads:
+    EVERY overlap is admitted (survivors), or a prefilter that rejects most lines into nonedge_overlaps.txt (rejects): the
+    blocks must grow their buffers and run their device half again, not fall back to the host's tokeniser
+    (hc_ec_counters.host_blocks == 0), and leave the oracle's graph, non-edge file and counters."""
+    monkeypatch.setenv("HC_TEXT_BLOCK", str(1 << 20))
+    reads, meta = synth.make_paired_dataset(2500, 1500, n_strains=1, divergence=0.0, err=0.0, n_rate=0.0, seed=77)
+    cand = synth.paired_candidates(meta, n_candidates=120000, seed=78)
+    lines = synth.records_to_lines(cand, reads)
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.9, min_overlap_len=150 if what == "survivors" else 260, n_threads=4)
+    d = tmp_path
+    ov = str(d / "overlaps.txt")
+    open(ov, "w").write("\n".join(lines) + "\n")
+    reads.write_fastq(None, str(d / "p1.fastq"), str(d / "p2.fastq"))
+    rc, g, oc = oracle.construct_edges(reads, st, ov, str(d / "ref_nonedge.txt"))
+    assert rc == 0
+    out = d / "out"
+    out.mkdir()
+    with host.EdgeCalculatorStage(st, paired1=str(d / "p1.fastq"), paired2=str(d / "p2.fastq"), overlaps=ov, output_dir=str(out) + "/") as ec:
+        ec.construct_edges()
+        edges, c = ec.edges(), ec.counters()
+    assert c["host_blocks"] == 0 and c["device_blocks"] >= 4, c
+    assert c["regrown_blocks"] >= 1, "the test is meant to overflow the blocks' first row buffers"
+    if what == "survivors":
+        assert c["edges_added"] + c["dup_count"] > 0.5 * len(lines)
+    else:
+        assert c["prefilter_rejected"] > 0.5 * len(lines)
+    want = g.all_edges()
+    assert edges.size == want.size
+    for k in FIELDS:
+        a, b = edges[k], want[k]
+        if a.dtype.kind == "f":
+            a, b = a.view(np.uint64), b.view(np.uint64)
+        assert np.array_equal(a, b), k
+    assert (out / "nonedge_overlaps.txt").read_bytes() == (d / "ref_nonedge.txt").read_bytes()
+    for k in ("inclusion_count", "dup_count", "edges_added", "nonedges_written", "prefilter_rejected", "lines_read", "scored"):
+        assert c[k] == getattr(oc, k), k
