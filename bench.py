@@ -348,6 +348,8 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
     if gather:  # outside the timed region: the collected set is what it should be
         rows, counts = gather.collect(last)
         assert len(counts) == world and rows.shape[0] == sum(counts) and bool((rows[1:, 0] > rows[:-1, 0]).all()), "gathered rows out of order"
+        if args.dump_rows and rank == 0:  # tests: the collected rows of the last step, as every rank holds them
+            np.save(args.dump_rows, rows.cpu().numpy())
     if dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -442,6 +444,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank scores its own candidate set of the workload's size; strong = the one set is split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-rows", default=None, help="N > 1 (or HC_BENCH_FORCE_GATHER=1): rank 0 writes the rows collected in the last step to this .npy file")
     ap.add_argument("--no-stage", action="store_true", help="skip the stage end-to-end measurement")
     ap.add_argument("--stage-threads", type=int, default=0, help="--threads of the stage (0 = min(32, hardware threads))")
     ap.add_argument("--order", default="sfo", choices=["sfo", "grouped", "shuffled"],
@@ -497,6 +500,8 @@ def main():
             "config": main_rec["config"],
             "roofline": main_rec["roofline"],
         }
+        if "ranks" in main_rec:
+            out["ranks"] = main_rec["ranks"]
     if dist:
         dist.barrier()
     if rank == 0 and world == 1:

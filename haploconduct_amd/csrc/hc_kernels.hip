@@ -394,6 +394,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 __device__ __forceinline__ void lds_store128(uint32_t addr, u32x4 v) { *(lds_u32x4*)(uintptr_t)addr = v; }
 __device__ __forceinline__ u32x4 lds_load128(uint32_t addr) { return *(const lds_u32x4*)(uintptr_t)addr; }
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+__device__ __forceinline__ void lds_store64(uint32_t addr, uint32_t a, uint32_t b) { *(lds_u32x2*)(uintptr_t)addr = u32x2{a, b}; }
+__device__ __forceinline__ void lds_load64(uint32_t addr, uint32_t& a, uint32_t& b) {
+    const u32x2 v = *(const lds_u32x2*)(uintptr_t)addr;
+    a = v[0];
+    b = v[1];
+}
+__device__ __forceinline__ uint32_t lds_load32(uint32_t addr) { return *(const lds_u32*)(uintptr_t)addr; }
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t addr, uint32_t v) {  // ds_add_rtn_u32
+    return __hip_atomic_fetch_add((lds_u32*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void wave_lds_order() {  // keeps the compiler from reordering the image's stores and loads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1001,25 +1014,37 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
         uint32_t a1 = (uint32_t)((sub1.offA + sub1.pos) * sizeof(SymT)), b1 = (uint32_t)(sub1.offB * sizeof(SymT)), l1 = L1 | (sub1.fatal << 31);
         SubScore s1, s2;
         if (SORT) {
-            // rank of the wave's sub-overlap 2 lane + s, longest class first: one pair of ballots per class that occurs
+            // rank of the wave's sub-overlap 2 lane + s, longest class first, by a counting sort over the 128 length classes in the
+            // upper half of the wave's own image: every sub-overlap takes a ticket in its class (ds_add_rtn: the tickets of a class
+            // are its members in some order), a 64-lane scan over the bins turns the counts into class starts.  (Round 2 ranked
+            // with one pair of ballots per class between the wave's longest and shortest: 24 VALU instructions per class, 150 - 200
+            // per candidate on 2 x 150 bp reads, more on mixed lengths; this is 40 whatever the lengths.)
             const uint32_t lane = tid & 63u;
             const uint32_t c0 = length_class((L0 + 15u) >> 4), c1 = length_class((L1 + 15u) >> 4);
-            uint32_t cmax = c0 > c1 ? c0 : c1, cmin = c0 < c1 ? c0 : c1;
+            const uint32_t hb = stage + 2048u;  // 128 bins of 4 bytes; bin 127 - c holds class c
+            lds_store64(hb + 8u * lane, 0u, 0u);
+            wave_lds_order();
+            const uint32_t bin0 = hb + 4u * (127u - c0), bin1 = hb + 4u * (127u - c1);
+            uint32_t r0 = lds_add_rtn(bin0, 1u);
+            uint32_t r1 = lds_add_rtn(bin1, 1u);
+            wave_lds_order();
+            {
+                uint32_t h0, h1;
+                lds_load64(hb + 8u * lane, h0, h1);
+                uint32_t incl = h0 + h1;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t hi = (uint32_t)__shfl_xor((int)cmax, o, 64), lo = (uint32_t)__shfl_xor((int)cmin, o, 64);
-                cmax = hi > cmax ? hi : cmax;
-                cmin = lo < cmin ? lo : cmin;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+                    if ((int)lane >= o) incl += up;
+                }
+                const uint32_t excl = incl - (h0 + h1);
+                wave_lds_order();
+                lds_store64(hb + 8u * lane, excl, excl + h0);
             }
-            const uint64_t below = (1ull << lane) - 1ull;
-            uint32_t base = 0, r0 = 0, r1 = 0;
-            for (int c = (int)cmax; c >= (int)cmin; --c) {  // wave-uniform
-                const uint64_t m0 = __ballot(c0 == (uint32_t)c), m1 = __ballot(c1 == (uint32_t)c);
-                const uint32_t n0 = (uint32_t)__popcll(m0);
-                if (c0 == (uint32_t)c) r0 = base + (uint32_t)__popcll(m0 & below);
-                if (c1 == (uint32_t)c) r1 = base + n0 + (uint32_t)__popcll(m1 & below);
-                base += n0 + (uint32_t)__popcll(m1);
-            }
+            wave_lds_order();
+            r0 += lds_load32(bin0);
+            r1 += lds_load32(bin1);
+            wave_lds_order();
             // through the wave's own image space (wave-synchronous): what to score, and where its result belongs
             const uint32_t x = stage;  // LDS byte address; 16 bytes per rank
             lds_store128(x + 16u * r0, u32x4{a0, b0, l0, 2u * lane});

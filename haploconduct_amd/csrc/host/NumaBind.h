@@ -52,11 +52,21 @@ inline std::vector<int> cpus_near_device(int device) {
     return cpus;
 }
 
-inline void bind_thread_to(const std::vector<int>& cpus) {  // the calling thread
+// The calling thread onto those of `cpus` it is ALLOWED on: the mask the process was started with (taskset, numactl, a
+// scheduler that pins by affinity) is never widened — when none of the node's CPUs is in it, nothing changes.
+inline void bind_thread_to(const std::vector<int>& cpus) {
     if (cpus.empty()) return;
-    cpu_set_t set;
+    cpu_set_t allowed, set;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
     CPU_ZERO(&set);
-    for (int c : cpus) CPU_SET(c, &set);
+    int n = 0;
+    for (int c : cpus)
+        if (CPU_ISSET(c, &allowed)) {
+            CPU_SET(c, &set);
+            n++;
+        }
+    if (n == 0) return;
     (void)sched_setaffinity(0, sizeof set, &set);  // best effort: a cgroup may not grant these CPUs
 }
 

@@ -1077,7 +1077,11 @@ void OverlapGraph::adopt_csr(const hc_edge_rec* edges, const uint64_t* out_off, 
             adj_out[v].borrow(out_arena + a, b - a, b - a);
             const size_t ia = (size_t)in_off[v], ib = (size_t)in_off[v + 1];
             if (ib < ia || ib > E) { my_bad = 1; break; }
-            for (size_t k = ia; k < ib; k++) in_arena[k] = in_nodes[k];
+            for (size_t k = ia; k < ib; k++) {
+                if (in_nodes[k] >= V) { my_bad = 1; break; }
+                in_arena[k] = in_nodes[k];
+            }
+            if (my_bad) break;
             adj_in[v].borrow(in_arena + ia, ib - ia, ib - ia);
             if (inclusion_bits && inclusion_bits[v]) inclusions[v] = 1;
         }
@@ -1087,7 +1091,18 @@ void OverlapGraph::adopt_csr(const hc_edge_rec* edges, const uint64_t* out_off, 
         bad[t] = my_bad;
     });
     for (uint8_t b : bad)
-        if (b) throw FatalError{HC_ERR_STATE, "adopt_csr: malformed adjacency"};
+        if (b) {  // leave the graph as it was found: empty, and fit for another adopt
+            for (size_t v = 0; v < V; v++) {
+                adj_out[v].borrow(nullptr, 0, 0);
+                adj_in[v].borrow(nullptr, 0, 0);
+                inclusions[v] = 0;
+            }
+            free((void*)out_arena);
+            free((void*)in_arena);
+            out_arena = nullptr;
+            in_arena = nullptr;
+            throw FatalError{HC_ERR_STATE, "adopt_csr: malformed adjacency"};
+        }
     edge_count = (unsigned int)E;
     slots_valid = false;
 }

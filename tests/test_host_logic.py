@@ -364,6 +364,18 @@ def test_adopted_csr_graph_behaves_like_an_owned_one():
         assert g.get()[0].tobytes() == g2.get()[0].tobytes()
         # adopting into a graph that already holds edges is refused, not merged
         assert g2.adopt(edges, out_off, in_nodes, in_off, inc) != 0
+        # caller-supplied arrays are checked: an in-list entry that is no vertex, an edge filed under the wrong vertex; a
+        # refused adopt leaves the graph empty and fit for the next one
+        g3 = host.HostGraph(V, st)
+        bad_nodes = in_nodes.copy()
+        bad_nodes[bad_nodes.size // 2] = V
+        assert g3.adopt(edges, out_off, bad_nodes, in_off, inc) != 0
+        assert g3.get()[0].size == 0 and not g3.get()[1].any()
+        bad_edges = edges.copy()
+        bad_edges["v1"][edges.size // 3] += 1
+        assert g3.adopt(bad_edges, out_off, in_nodes, in_off, inc) != 0
+        assert g3.adopt(edges, out_off, in_nodes, in_off, inc) == 0
+        assert g3.get()[0].tobytes() == edges.tobytes()
 
 
 def test_add_equivalent_edges_matches_oracle(oracle):
