@@ -349,8 +349,12 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
 }
 
 // ---- the SFO ingest straight from the records of hc_find_overlaps ------------------------------------------------------
-int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines) {
-    if (!c || !out_path) return fail(HC_ERR_ARG, "hc_found_to_overlaps: null argument");
+}  // extern "C"
+
+// The ingest's result as text in memory (hc_ctx.h): what hc_found_to_overlaps writes to its file, and what the stage's
+// reads -> graph call hands to its own text blocks without a file in between.
+int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs, std::string& text, uint64_t* n_lines) {
+    if (!c) return fail(HC_ERR_ARG, "hc_found_to_overlaps: null argument");
     if (!c->found_valid) return fail(HC_ERR_STATE, "hc_found_to_overlaps: hc_find_overlaps has not been called on this read set");
     const uint64_t n = c->n_found;
     const bool timing = getenv("HC_SFO_TIMING") != nullptr;
@@ -394,7 +398,7 @@ int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, 
         hc::BoundForNow bound(hc::cpus_near_device(c->device));  // the matching threads read the page-locked ring: next to the device
         hipStream_t st = c->stream;
         uint64_t k = 0;
-        std::string text;
+        text.clear();
         const double t0 = now();
         bool sorted_on_device = false;
         if (n && n < 0x7FFFFFF0ull) {
@@ -469,10 +473,6 @@ int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, 
             if (n) HC_HIP(hipMemcpy(mem.host, c->d_found, n * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
             text = hc::sfo_records_to_overlaps((const hc_sfo_rec*)mem.host, n, (long)num_singles, (long)num_pairs, k);
         }
-        FILE* o = fopen(out_path, "wb");
-        if (!o) return fail(HC_ERR_IO, std::string("cannot write ") + out_path);
-        const size_t w = text.empty() ? 0 : fwrite(text.data(), 1, text.size(), o);
-        if (fclose(o) != 0 || w != text.size()) return fail(HC_ERR_IO, std::string("short write to ") + out_path);
         if (n_lines) *n_lines = k;
         return HC_OK;
     } catch (const hc::FatalError& e) {
@@ -480,6 +480,20 @@ int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, 
     } catch (const std::bad_alloc&) {
         return fail(HC_ERR_NOMEM, "hc_found_to_overlaps: out of host memory");
     }
+}
+
+extern "C" {
+
+int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines) {
+    if (!c || !out_path) return fail(HC_ERR_ARG, "hc_found_to_overlaps: null argument");
+    std::string text;
+    const int rc = hc_found_to_overlaps_text(c, num_singles, num_pairs, text, n_lines);
+    if (rc) return rc;
+    FILE* o = fopen(out_path, "wb");
+    if (!o) return fail(HC_ERR_IO, std::string("cannot write ") + out_path);
+    const size_t w = text.empty() ? 0 : fwrite(text.data(), 1, text.size(), o);
+    if (fclose(o) != 0 || w != text.size()) return fail(HC_ERR_IO, std::string("short write to ") + out_path);
+    return HC_OK;
 }
 
 }  // extern "C"

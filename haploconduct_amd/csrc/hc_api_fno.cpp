@@ -108,4 +108,40 @@ bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, c
     return true;
 }
 
+bool fno3_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of, uint64_t* n_lines,
+                          double* seconds) {
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
+    hipStream_t st = nullptr;
+    DeviceBuffers d;
+    FnoItem* d_items = d.get<FnoItem>(n);
+    Fno3Rec* d_rec = d.get<Fno3Rec>(n);
+    uint64_t *d_len = d.get<uint64_t>(n + 1), *d_off = d.get<uint64_t>(n + 1);
+    unsigned long long* d_counters = d.get<unsigned long long>(kFnoCounters);
+    size_t scan_bytes = 0;
+    hip_check(finder_scan(nullptr, scan_bytes, d_len, d_off, n + 1, st), "scan size");
+    void* d_tmp = d.get<char>(scan_bytes);
+    hip_check(hipMemcpyAsync(d_items, items, n * sizeof(FnoItem), hipMemcpyHostToDevice, st), "copy of the candidate pairs");
+    hip_check(hipMemsetAsync(d_counters, 0, kFnoCounters * sizeof(unsigned long long), st), "memset");
+    hip_check(fno3_deduce(d_items, n, no_inclusions ? 1u : 0u, d_rec, d_len, d_counters, st), "deduce");
+    hip_check(finder_scan(d_tmp, scan_bytes, d_len, d_off, n + 1, st), "scan");
+    unsigned long long h_counters[kFnoCounters];
+    uint64_t total_bytes = 0;
+    hip_check(hipMemcpyAsync(h_counters, d_counters, sizeof h_counters, hipMemcpyDeviceToHost, st), "counters");
+    hip_check(hipMemcpyAsync(&total_bytes, d_off + n, 8, hipMemcpyDeviceToHost, st), "size of the text");
+    hip_check(hipStreamSynchronize(st), "synchronize");
+    if (h_counters[4]) return false;
+    const auto t1 = now();
+    char* d_text = d.get<char>(total_bytes);
+    hip_check(fno3_format(d_rec, d_len, d_off, n, d_text, st), "format");
+    char* h_text = text_of(total_bytes);
+    if (total_bytes) hip_check(hipMemcpy(h_text, d_text, total_bytes, hipMemcpyDeviceToHost), "copy of the text");
+    if (n_lines) *n_lines = h_counters[5];
+    if (seconds) {
+        seconds[0] = std::chrono::duration<double>(t1 - t0).count();
+        seconds[1] = std::chrono::duration<double>(now() - t1).count();
+    }
+    return true;
+}
+
 }  // namespace hc

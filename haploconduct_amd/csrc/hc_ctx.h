@@ -167,3 +167,6 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
                  hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index,
                  const unsigned long long* n_dev = nullptr, const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr,
                  hc_bucket_ws* bucket = nullptr);  // bucket: the caller's own scratch (launches beside the context's stream), else the context's
+
+// hc_found_to_overlaps with the overlaps file's text left in memory (hc_api_finder.cpp)
+int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs, std::string& text, uint64_t* n_lines);

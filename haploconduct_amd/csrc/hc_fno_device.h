@@ -27,6 +27,16 @@ hipError_t fno_gather_keys(const uint64_t* key, const uint32_t* perm, uint64_t n
 // len[i] = bytes (with the newline) of the line at sorted place i if it is the first of its run of equal lines, else 0; len[n] = 0
 hipError_t fno_mark_lines(const FnoRec* rec, const uint32_t* perm, uint64_t n, uint64_t* len, unsigned long long* counters, hipStream_t s);
 hipError_t fno_format(const FnoRec* rec, const uint32_t* perm, const uint64_t* len, const uint64_t* off, uint64_t n, char* text, hipStream_t s);
+// FNO=3: deduceOverlap per candidate pair (in walk order); len[i] = bytes of its line (0: no line), len[n] = 0; counters[4] status
+// bits, counters[5] lines.  Then the text at off[i] (the exclusive scan of len).
+struct Fno3Rec {
+    uint64_t id1, id2;
+    int32_t pos1, pos2, perc1, perc2, len1, len2;
+    uint8_t ord, type1, type2, pad[5];
+};
+static_assert(sizeof(Fno3Rec) == 48, "Fno3Rec is 48 bytes");
+hipError_t fno3_deduce(const FnoItem* items, uint64_t n, uint32_t no_inclusions, Fno3Rec* rec, uint64_t* len, unsigned long long* counters, hipStream_t s);
+hipError_t fno3_format(const Fno3Rec* rec, const uint64_t* len, const uint64_t* off, uint64_t n, char* text, hipStream_t s);
 // stable radix sort of (64-bit key, 32-bit value) pairs (hc_graph_kernels.hip owns the instantiation)
 hipError_t sort_pairs_u64_u32(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint32_t* v_in, uint32_t* v_out,
                               uint32_t n, int end_bit, hipStream_t s);

@@ -34,5 +34,14 @@ bool fno_device_wanted(uint64_t n_items);
 bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of,
                          uint64_t counters[5], double* seconds);
 
+// FNO=3 (src/FindNextOverlaps3.cpp:176-406, deduceOverlap): one candidate pair of super-reads that share an original read,
+// everything looked up on the host —
+//   kind 4: ida / idb = the super-reads' ids, a_paired / b_paired, v = { index1 of the original in A, index2 in A, index1 in B,
+//           index2 in B, A.len1, A.len2, B.len1, B.len2 }
+// — deduced on the device in the order given (the walk's), the lines' text written in that order.  false: the device met
+// something the reference would stop at; the host form then runs and reports.  *n_lines: lines written.
+bool fno3_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of, uint64_t* n_lines,
+                          double* seconds);
+
 }  // namespace hc
 #endif

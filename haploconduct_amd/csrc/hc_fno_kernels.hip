@@ -290,6 +290,141 @@ __global__ __launch_bounds__(kBlock) void fno_format_kernel(const FnoRec* __rest
     for (int k = 0; k < m; k++) dst[k] = line[k];
 }
 
+// ---- FNO=3 ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ratio100(int a, int b) { return (int)floorf((float)a / (float)b * 100.0f); }  // FindNextOverlaps3.cpp:259
+
+// deduceOverlap, src/FindNextOverlaps3.cpp:180-406, and the two tests of :149-157 — statement for statement the host form
+// (host/FindNextOverlaps.cpp, Fno3::deduce).  0 = a line, 1 = no line, 2 = the reference would stop.
+__device__ int deduce3(const FnoItem& it, uint32_t no_inclusions, Fno3Rec& o) {
+    const int a_l = it.v[0], a_r = it.v[1], b_l = it.v[2], b_r = it.v[3];
+    const int A1 = it.v[4], A2 = it.v[5], B1 = it.v[6], B2 = it.v[7];
+    const bool ap = it.a_paired != 0, bp = it.b_paired != 0;
+    const bool a_first = a_l - b_l >= 0;
+    o.id1 = a_first ? it.ida : it.idb;
+    o.id2 = a_first ? it.idb : it.ida;
+    int pos1 = a_first ? a_l - b_l : b_l - a_l, pos2 = 0, len1, len2 = 0;
+    int perc1, perc2 = 0;
+    uint8_t ord = '-', t1, t2;
+    if (!ap && !bp) {  // :204-237
+        if (A1 <= 0 || B1 <= 0) return 2;  // a division by zero in the reference
+        if (pos1 > (a_first ? A1 : B1)) return 1;
+        len1 = a_first ? imin(A1 - pos1, B1) : imin(A1, B1 - pos1);
+        perc1 = perc_max(len1, A1, B1);
+        t1 = t2 = 's';
+    } else if (ap != bp) {  // :238-281 (P-S), :282-324 (S-P)
+        const int P1 = ap ? A1 : B1, P2 = ap ? A2 : B2, S = ap ? B1 : A1;
+        const bool pair_first = ap == a_first;
+        len1 = pair_first ? P1 - pos1 : imin(P1, S - pos1);
+        if (len1 <= 0) return 1;
+        t1 = pair_first ? 'p' : 's';
+        t2 = pair_first ? 's' : 'p';
+        if (P1 <= 0) return 2;
+        perc1 = ratio100(len1, P1);
+        pos2 = ap ? b_r - a_r : a_r - b_r;
+        len2 = imin(P2, S - pos2);
+        if (len2 <= 0 || pos2 < 0) return 1;
+        if (P2 <= 0) return 2;
+        perc2 = ratio100(len2, P2);
+    } else {  // :325-399
+        len1 = a_first ? imin(A1 - pos1, B1) : imin(A1, B1 - pos1);
+        const bool back = a_r - b_r >= 0;
+        pos2 = back ? a_r - b_r : b_r - a_r;
+        len2 = back ? imin(A2 - pos2, B2) : imin(A2, B2 - pos2);
+        if (len1 <= 0 || len2 <= 0) return 1;
+        if (A1 <= 0 || B1 <= 0 || A2 <= 0 || B2 <= 0) return 2;
+        perc1 = perc_max(len1, A1, B1);
+        perc2 = perc_max(len2, A2, B2);
+        if (!((unsigned)perc1 <= 100u && (unsigned)perc2 <= 100u)) return 2;
+        ord = a_first == back ? '1' : '2';
+        t1 = t2 = 'p';
+    }
+    if (perc1 < 0 || perc1 > 100 || perc2 < 0 || perc2 > 100) return 2;  // the Overlap constructor's checks, src/Overlap.h:88-102
+    if (len1 < 0 || len2 < 0) return 2;
+    const unsigned perc = perc2 > 0 ? (unsigned)(0.5 * (double)(perc1 + perc2)) : (unsigned)perc1;  // Overlap::get_perc
+    if (no_inclusions && perc == 100u) return 1;
+    if (len1 <= 0) return 1;
+    o.pos1 = pos1;
+    o.pos2 = pos2;
+    o.perc1 = perc1;
+    o.perc2 = perc2;
+    o.len1 = len1;
+    o.len2 = len2;
+    o.ord = ord;
+    o.type1 = t1;
+    o.type2 = t2;
+    return 0;
+}
+
+__global__ __launch_bounds__(kBlock) void fno3_deduce_kernel(const FnoItem* __restrict__ items, uint64_t n, uint32_t no_inclusions, Fno3Rec* __restrict__ rec,
+                                                             uint64_t* __restrict__ len, unsigned long long* __restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    __shared__ unsigned int lines, status;
+    if (threadIdx.x == 0) {
+        lines = 0;
+        status = 0;
+    }
+    __syncthreads();
+    if (i <= n) {
+        uint64_t bytes = 0;
+        if (i < n) {
+            Fno3Rec r;
+            const FnoItem it = items[i];
+            const int what = it.ida >= 10000000000ull || it.idb >= 10000000000ull ? 3 : deduce3(it, no_inclusions, r);
+            if (what == 0) {
+                // 12 tabs + newline + ord, "+", "+", type1, type2
+                bytes = 18 + digits_u64(r.id1) + digits_u64(r.id2) + chars_i32(r.pos1) + chars_i32(r.pos2) + chars_i32(r.perc1) + chars_i32(r.perc2) +
+                        chars_i32(r.len1) + chars_i32(r.len2);
+                rec[i] = r;
+                atomicAdd(&lines, 1u);
+            } else if (what >= 2) {
+                atomicOr(&status, what == 2 ? (unsigned)kFnoStatusRequire : (unsigned)kFnoStatusRange);
+            }
+        }
+        len[i] = bytes;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && lines) atomicAdd(&counters[5], (unsigned long long)lines);
+    if (threadIdx.x == 0 && status) atomicOr(&counters[4], (unsigned long long)status);
+}
+
+__global__ __launch_bounds__(kBlock) void fno3_format_kernel(const Fno3Rec* __restrict__ rec, const uint64_t* __restrict__ len, const uint64_t* __restrict__ off,
+                                                             uint64_t n, char* __restrict__ text) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n || len[i] == 0) return;
+    const Fno3Rec r = rec[i];
+    char line[104];  // 2 x 10 + 6 x 11 + 18
+    char* p = line;
+    p = put_u64(p, r.id1);
+    *p++ = '\t';
+    p = put_u64(p, r.id2);
+    *p++ = '\t';
+    p = put_i32(p, r.pos1);
+    *p++ = '\t';
+    p = put_i32(p, r.pos2);
+    *p++ = '\t';
+    *p++ = (char)r.ord;
+    *p++ = '\t';
+    *p++ = '+';
+    *p++ = '\t';
+    *p++ = '+';
+    *p++ = '\t';
+    p = put_i32(p, r.perc1);
+    *p++ = '\t';
+    p = put_i32(p, r.perc2);
+    *p++ = '\t';
+    p = put_i32(p, r.len1);
+    *p++ = '\t';
+    p = put_i32(p, r.len2);
+    *p++ = '\t';
+    *p++ = (char)r.type1;
+    *p++ = '\t';
+    *p++ = (char)r.type2;
+    *p++ = '\n';
+    char* dst = text + off[i];
+    const int m = (int)(p - line);
+    for (int k = 0; k < m; k++) dst[k] = line[k];
+}
+
 inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 }  // namespace
@@ -312,6 +447,16 @@ hipError_t fno_mark_lines(const FnoRec* rec, const uint32_t* perm, uint64_t n, u
 hipError_t fno_format(const FnoRec* rec, const uint32_t* perm, const uint64_t* len, const uint64_t* off, uint64_t n, char* text, hipStream_t s) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(fno_format_kernel, grid_for(n), dim3(kBlock), 0, s, rec, perm, len, off, n, text);
+    return hipGetLastError();
+}
+
+hipError_t fno3_deduce(const FnoItem* items, uint64_t n, uint32_t no_inclusions, Fno3Rec* rec, uint64_t* len, unsigned long long* counters, hipStream_t s) {
+    hipLaunchKernelGGL(fno3_deduce_kernel, grid_for(n + 1), dim3(kBlock), 0, s, items, n, no_inclusions, rec, len, counters);
+    return hipGetLastError();
+}
+hipError_t fno3_format(const Fno3Rec* rec, const uint64_t* len, const uint64_t* off, uint64_t n, char* text, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fno3_format_kernel, grid_for(n), dim3(kBlock), 0, s, rec, len, off, n, text);
     return hipGetLastError();
 }
 

@@ -23,6 +23,9 @@
 #include <thread>
 #include <type_traits>
 
+struct hc_ctx;
+int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs, std::string& text, uint64_t* n_lines);  // hc_api_finder.cpp
+
 namespace hc {
 
 static double now_s() {
@@ -1144,7 +1147,9 @@ void EdgeCalculator::run_stage(bool then_sort) {
     std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
     std::vector<Overlap> rejected;
     // (closed by the clean-up thread: unmapping the 4 GB file with the worker threads alive takes 20 ms)
-    std::unique_ptr<OverlapsParser> parser_owner(new OverlapsParser(program_settings.overlaps_file, program_settings, *fastq_storage, m_pool.get()));
+    std::unique_ptr<OverlapsParser> parser_owner(m_text_override
+                                                     ? new OverlapsParser(m_text_override, program_settings, *fastq_storage, m_pool.get())
+                                                     : new OverlapsParser(program_settings.overlaps_file, program_settings, *fastq_storage, m_pool.get()));
     struct CloseLater {
         std::unique_ptr<OverlapsParser>& p;
         EdgeCalculator* self;
@@ -1210,6 +1215,29 @@ void EdgeCalculator::run_stage(bool then_sort) {
     }
     stats.t_write += now_s() - t0;
     stage_lap("construct_edges body done (destructors follow)");
+}
+
+void EdgeCalculator::construct_edges_from_reads(double err_rate, uint32_t min_overlap, uint32_t find_flags, bool then_sort, uint64_t* n_found,
+                                                uint64_t* n_lines) {
+    const double t0 = now_s();
+    uint64_t found = 0, lines = 0;
+    check(hc_find_overlaps(m_ctx, err_rate, min_overlap, find_flags, nullptr, 0, &found), "hc_find_overlaps");
+    const double t1 = now_s();
+    auto text = std::make_shared<std::string>();
+    check(hc_found_to_overlaps_text(m_ctx, fastq_storage->m_readcount_single, fastq_storage->m_readcount_paired, *text, &lines),
+          "hc_found_to_overlaps");
+    const double t2 = now_s();
+    if (n_found) *n_found = found;
+    if (n_lines) *n_lines = lines;
+    struct Reset {
+        std::shared_ptr<const std::string>& p;
+        ~Reset() { p.reset(); }
+    } reset{m_text_override};
+    m_text_override = text;
+    run_stage(then_sort);
+    if (getenv("HC_STAGE_TIMING"))
+        fprintf(stderr, "[hc stage] reads -> graph: find %.3f s (%lu SFO records), ingest %.3f s (%lu lines, %zu bytes of text in memory), construct %.3f s\n",
+                t1 - t0, (unsigned long)found, t2 - t1, (unsigned long)lines, text->size(), now_s() - t2);
 }
 
 }  // namespace hc

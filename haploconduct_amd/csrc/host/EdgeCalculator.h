@@ -71,6 +71,13 @@ public:
     // construct_edges() followed by OverlapGraph::sortEdges() (src/ViralQuasispecies.cpp:281,297 — what every workflow
     // does) as one call: the adjacency lists come from the device already in sortEdges order.
     void construct_edges_sorted() { run_stage(true); }
+    // Reads -> graph with no overlaps file in between (what savage.py:664,713 does with rust-overlaps, scripts/sfo2overlaps.py
+    // and an overlaps.txt): the candidates are found on the device among the reads of this stage's own store
+    // (hc_find_overlaps: err_rate, min_overlap, HC_FIND_* flags), the SFO ingest runs on the records where they are
+    // (hc_found_to_overlaps' sort + matching), and the overlaps file's text goes from memory into the stage's text blocks.
+    // Same graph as writing that file and calling construct_edges[_sorted] on it.  *n_found / *n_lines: SFO records, overlap lines.
+    void construct_edges_from_reads(double err_rate, uint32_t min_overlap, uint32_t find_flags, bool then_sort, uint64_t* n_found,
+                                    uint64_t* n_lines);
     // src/EdgeCalculator.cpp:67-139 on arbitrary strings (used by SRBuilder::merge_self_overlap in the
     // reference): scored on the device through a two-read scratch store, finalised with the host libm.
     double overlap_score(const std::string& seq1, const std::string& seq2, const std::string& score1,
@@ -102,6 +109,7 @@ private:
         uint64_t nonedges = 0, ambiguous = 0;
     };
     void run_stage(bool then_sort);
+    std::shared_ptr<const std::string> m_text_override;  // construct_edges_from_reads: the overlaps file's text, in memory
     void score_host_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc);   // the file tokenised on host threads
     void score_device_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc); // the file's text sent to the device
     void finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out, unsigned threads = 0);

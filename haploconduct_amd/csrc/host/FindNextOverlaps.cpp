@@ -19,6 +19,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -992,9 +993,80 @@ private:
         return p;
     }
 
+    // The device form: the walk above stays on the host — its order is the iteration order of a
+    // std::unordered_map, a property of the reference's libstdc++ — and hands over one 64-byte record per candidate pair with
+    // the look-ups done (ids, lengths, where the shared original sits in both super-reads); deduceOverlap, the lines' lengths,
+    // their places (a scan) and their text run on the device, in walk order.  Whatever the reference would stop at makes the
+    // device report instead of write; the host form below then runs and diagnoses.
+    bool emit_on_device(hc_fno_output& out) {
+        const uint64_t n = cands_.size();
+        if (n == 0 || n >= 0x7FFFFFF0ull) return false;
+        const bool timing = getenv("HC_FNO_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        const auto t0 = now();
+        std::unique_ptr<hc::FnoItem[]> items(new hc::FnoItem[n]);
+        std::atomic<bool> missing{false};
+        parallel_chunks(n, threads_, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t i = b; i < e; ++i) {
+                const Cand& c = cands_[i];
+                const hc_fno_read &A = in_.srs[c.a], &B = in_.srs[c.b];
+                const hc_fno_original *oa = find_original(c.a, c.original_id), *ob = find_original(c.b, c.original_id);
+                hc::FnoItem& it = items[i];
+                memset(&it, 0, sizeof it);
+                if (!oa || !ob) {  // originals.at(original_id) would throw: the host form reports
+                    missing = true;
+                    continue;
+                }
+                it.ida = A.id;
+                it.idb = B.id;
+                it.v[0] = (int32_t)oa->index1;
+                it.v[1] = (int32_t)oa->index2;
+                it.v[2] = (int32_t)ob->index1;
+                it.v[3] = (int32_t)ob->index2;
+                it.v[4] = (int32_t)A.len1;
+                it.v[5] = (int32_t)A.len2;
+                it.v[6] = (int32_t)B.len1;
+                it.v[7] = (int32_t)B.len2;
+                it.kind = 4;
+                it.a_paired = A.paired != 0;
+                it.b_paired = B.paired != 0;
+            }
+        });
+        if (missing) return false;
+        const auto t1 = now();
+        uint64_t n_lines = 0;
+        double seconds[2] = {0, 0};
+        auto text_of = [&](uint64_t bytes) {
+            out.text.resize(bytes);
+            return out.text.data();
+        };
+        try {
+            if (!hc::fno3_lines_on_device(items.get(), n, (in_.flags & HC_FNO_NO_INCLUSIONS) != 0, text_of, &n_lines, seconds)) return false;
+        } catch (const FatalError& e) {
+            if (e.status != HC_ERR_NOMEM) throw;
+            return false;
+        }
+        memset(&out.counters, 0, sizeof out.counters);
+        out.counters.n_lines = n_lines;
+        out.counters.candidates = n;
+        out.on_device = true;
+        if (timing)
+            fprintf(stderr, "hc_fno3_run (device): look-ups on the host %.3f s, copy + deduceOverlap + scan %.3f s, text %.3f s\n",
+                    std::chrono::duration<double>(t1 - t0).count(), seconds[0], seconds[1]);
+        return true;
+    }
+
+    const hc_fno_original* find_original(uint32_t sr, uint64_t id) const {
+        const hc_fno_original* b = by_id_.data() + in_.orig_off[sr];
+        const hc_fno_original* e = by_id_.data() + in_.orig_off[sr + 1];
+        const hc_fno_original* it = std::lower_bound(b, e, id, [](const hc_fno_original& x, uint64_t v) { return x.original_id < v; });
+        return (it == e || it->original_id != id) ? nullptr : it;
+    }
+
     void emit(hc_fno_output& out) {
         constexpr size_t kMaxLine = 160;
         const uint64_t n = cands_.size();
+        if (hc::fno_device_wanted(n) && emit_on_device(out)) return;
         const unsigned T = (unsigned)std::min<uint64_t>(threads_, n ? n : 1);
         std::vector<std::unique_ptr<char[]>> arena(T);
         std::vector<size_t> used(T, 0), nlines(T, 0);

@@ -193,6 +193,22 @@ OverlapsParser::OverlapsParser(const std::string& path, const ProgramSettings& p
     }
 }
 
+OverlapsParser::OverlapsParser(std::shared_ptr<const std::string> text, const ProgramSettings& ps, const FastqStorage& fastq, WorkerPool* shared_pool)
+    : m_ps(ps), m_ids(fastq), m_threads(ps.n_threads ? ps.n_threads : 1), m_text(std::move(text)) {
+    if (!m_text) return;
+    m_size = m_text->size();
+    m_data = m_size ? m_text->data() : nullptr;
+    m_open = true;
+    if (m_threads > 1) {
+        if (shared_pool && shared_pool->workers() + 1 >= m_threads) {
+            m_pool = shared_pool;
+        } else {
+            m_own_pool.reset(new WorkerPool(m_threads - 1));
+            m_pool = m_own_pool.get();
+        }
+    }
+}
+
 OverlapsParser::~OverlapsParser() {
     const bool timing = getenv("HC_STAGE_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -200,7 +216,7 @@ OverlapsParser::~OverlapsParser() {
     m_pool = nullptr;
     m_own_pool.reset();
     const double t1 = now();
-    if (m_data) munmap((void*)m_data, m_size);
+    if (m_data && !m_text) munmap((void*)m_data, m_size);
     const double t2 = now();
     if (m_fd >= 0) close(m_fd);
     if (timing) fprintf(stderr, "[hc stage] overlaps parser closed: pool %.3f s, munmap %.3f s, close %.3f s\n", t1 - t0, t2 - t1, now() - t2);
@@ -245,6 +261,10 @@ void OverlapsParser::copy_range(char* dst, size_t begin, size_t end, uint64_t& n
     auto body = [&](unsigned int t) {
         const size_t a = begin + bytes * t / T, b = begin + bytes * (t + 1) / T;
         size_t at = a;
+        if (m_fd < 0) {  // text in memory
+            memcpy(dst + (a - begin), m_data + a, b - a);
+            at = b;
+        }
         while (at < b) {  // pread: the kernel copies out of the page cache, no page of a mapping is faulted in
             const ssize_t k = pread(m_fd, dst + (at - begin), b - at, (off_t)at);
             if (k <= 0) {

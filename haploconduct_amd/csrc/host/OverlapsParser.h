@@ -132,6 +132,9 @@ class OverlapsParser {
 public:
     // shared_pool: worker threads of the caller (at least ps.n_threads - 1), used instead of starting and joining a pool per file
     OverlapsParser(const std::string& path, const ProgramSettings& ps, const FastqStorage& fastq, WorkerPool* shared_pool = nullptr);
+    // The same over the overlaps file's text in memory (kept alive by the parser): the reads -> graph call, whose
+    // overlaps never become a file.
+    OverlapsParser(std::shared_ptr<const std::string> text, const ProgramSettings& ps, const FastqStorage& fastq, WorkerPool* shared_pool = nullptr);
     ~OverlapsParser();
     bool is_open() const { return m_open; }
     // Fills `batch` with up to `max_batch` candidates that pass the prefilter (:612-635), in file
@@ -170,6 +173,7 @@ private:
     unsigned int m_threads = 1;
     bool m_open = false;
     int m_fd = -1;
+    std::shared_ptr<const std::string> m_text;  // the memory-backed form: m_data points into it, there is no file
     const char* m_data = nullptr;
     size_t m_size = 0, m_pos = 0;
     uint64_t m_line_no = 0;

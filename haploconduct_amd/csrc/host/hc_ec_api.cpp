@@ -129,6 +129,12 @@ int hc_ec_construct_edges_sorted(hc_ec* ec) {
     return rc;
 }
 
+int hc_ec_construct_edges_from_reads(hc_ec* ec, double err_rate, uint32_t min_overlap, uint32_t find_flags, int sorted, uint64_t* n_found,
+                                     uint64_t* n_lines) {
+    if (!ec) return set_last_error(HC_ERR_ARG, "hc_ec_construct_edges_from_reads: null");
+    return guarded("construct_edges", [&] { ec->calc->construct_edges_from_reads(err_rate, min_overlap, find_flags, sorted != 0, n_found, n_lines); });
+}
+
 uint32_t hc_ec_device_count(hc_ec* ec) { return ec ? ec->calc->device_count() : 0; }
 
 int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* c) {

@@ -49,6 +49,7 @@ _sig = {
     "hc_ec_open": (C.c_int, [C.POINTER(_vp), C.POINTER(N.hc_settings), C.POINTER(hc_ec_paths)]),
     "hc_ec_construct_edges": (C.c_int, [_vp]),
     "hc_ec_construct_edges_sorted": (C.c_int, [_vp]),
+    "hc_ec_construct_edges_from_reads": (C.c_int, [_vp, C.c_double, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "hc_ec_device_count": (C.c_uint32, [_vp]),
     "hc_ec_get_counters": (C.c_int, [_vp, C.POINTER(hc_ec_counters)]),
     "hc_ec_read_count": (C.c_uint64, [_vp]),
@@ -271,6 +272,15 @@ class EdgeCalculatorStage:
     def construct_edges_sorted(self):
         """construct_edges() + sortEdges() as one call (the lists arrive from the device in sortEdges order)."""
         N.check(N.lib.hc_ec_construct_edges_sorted(self._h), "hc_ec_construct_edges_sorted")
+
+    def construct_edges_from_reads(self, err_rate, min_overlap, reversals=True, inclusions=True, sorted_order=True):
+        """hc_ec_construct_edges_from_reads: candidates found on the device, ingested and scored without an overlaps file.
+        Returns (SFO records found, overlap lines)."""
+        nf, nl = C.c_uint64(), C.c_uint64()
+        flags = (1 if reversals else 0) | (2 if inclusions else 0)
+        N.check(N.lib.hc_ec_construct_edges_from_reads(self._h, float(err_rate), int(min_overlap), flags, 1 if sorted_order else 0,
+                                                       C.byref(nf), C.byref(nl)), "hc_ec_construct_edges_from_reads")
+        return nf.value, nl.value
 
     def device_count(self):
         return int(N.lib.hc_ec_device_count(self._h))

@@ -50,6 +50,15 @@ int hc_ec_construct_edges(hc_ec* ec);
 /* construct_edges() + OverlapGraph::sortEdges() (src/ViralQuasispecies.cpp:281,297: what every workflow calls next) as
  * one call: into an empty graph the adjacency lists come back from the device already in sortEdges order. */
 int hc_ec_construct_edges_sorted(hc_ec* ec);
+/* Reads -> graph with no files in between — the front of SAVAGE stage a (savage.py:643-717: rust-overlaps -> SFO file ->
+ * scripts/sfo2overlaps.py -> overlaps.txt -> ViralQuasispecies) as one call on an open stage: hc_find_overlaps on the
+ * stage's own read store (err_rate, min_overlap, HC_FIND_* flags as for rust-overlaps), the SFO ingest on the records where
+ * they are (the script's flip and sort on the device, the matching on the host threads), the overlaps file's text from
+ * memory into the device's text blocks, construct_edges (sorted != 0: + sortEdges).  The graph, nonedge_overlaps.txt and
+ * the counters are those of writing the overlaps file (hc_found_to_overlaps) and calling hc_ec_construct_edges[_sorted]
+ * on it; hc_paths.overlaps_file is not read.  *n_found: SFO records, *n_lines: overlap lines (either may be NULL). */
+int hc_ec_construct_edges_from_reads(hc_ec* ec, double err_rate, uint32_t min_overlap, uint32_t find_flags, int sorted, uint64_t* n_found,
+                                     uint64_t* n_lines);
 /* number of device contexts the stage scores on (hc_settings.device_mask) */
 uint32_t hc_ec_device_count(hc_ec* ec);
 int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* out);

@@ -91,3 +91,43 @@ def test_numbers_beyond_the_keys_fall_to_the_host_form(on_device):
     got, cnt = F.find_next_overlaps(inp)
     assert not F.last_on_device
     assert got == b"20000000000\t5\t10\t0\t-\t+\t+\t90\t0\t90\t0\ts\ts\n5\t7\t10\t0\t-\t+\t+\t1234\t0\t90\t0\ts\ts\n" and cnt["copied"] == 2
+
+
+# ---- FNO=3 on the device (deduceOverlap per candidate pair of the host's walk, the lines' places by a scan, their text) ----
+def test_fno3_goldens_of_the_reference_through_the_device(olib, on_device):
+    host_tests.test_golden_whole_find_next_overlaps3_runs(olib)
+    assert F.last_on_device
+    for flags in (0, F.NO_INCLUSIONS):  # the 800 deduceOverlap calls of the reference, one device launch each
+        host_tests.test_golden_deduce_overlap(olib, flags)
+        assert F.last_on_device
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fno3_device_matches_oracle_on_random_scenarios(olib, on_device, seed):
+    host_tests.test_fno3_product_matches_oracle(olib, seed)
+    assert F.last_on_device
+
+
+def test_fno3_stops_of_the_reference_are_reported_as_by_the_host_form(olib, on_device):
+    host_tests.test_fno3_aborts_where_the_reference_does(olib)
+
+
+@pytest.mark.parametrize("flags", [0, F.NO_INCLUSIONS])
+def test_fno3_large_iteration_device_equals_host(flags):
+    """2.5·10^5 super-reads over 10^6 originals: hundreds of thousands of candidate pairs; the default routing picks the device
+    for a batch of this size, HC_FNO=host the host threads, and both write the same file in the same (walk) order."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fno_bench
+    inp = fno_bench.big_fno3(250000, 1000000)
+    inp.flags = flags
+    os.environ["HC_FNO"] = "host"
+    try:
+        want, wc = F.find_next_overlaps3(inp)
+        assert not F.last_on_device
+    finally:
+        os.environ.pop("HC_FNO", None)
+    got, gc = F.find_next_overlaps3(inp)
+    assert wc["candidates"] >= 200000, "the test means to exceed the device threshold"
+    assert F.last_on_device
+    assert gc == wc and got == want and wc["n_lines"] > 100000

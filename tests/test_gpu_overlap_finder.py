@@ -308,3 +308,46 @@ def test_ingest_from_the_device_with_nothing_found(tmp_path):
         assert sc.found_to_overlaps(tmp_path / "none.txt", n, 0) == 0
     assert (tmp_path / "none.txt").read_bytes() == b""
 
+
+
+@pytest.mark.parametrize("workload", ["c2", "mixed"])
+def test_reads_to_graph_in_one_call_equals_the_file_route(tmp_path, workload):
+    """hc_ec_construct_edges_from_reads — candidates found on the device, ingested where they are, the overlaps file's text
+    from memory into the text blocks — against the route with files in between (hc_find_overlaps + hc_found_to_overlaps ->
+    overlaps.txt -> hc_ec_construct_edges_sorted on a second stage): the same sorted graph, in-lists, inclusions,
+    nonedge_overlaps.txt and counters.  C2 (50 000 read pairs of 2 x 150) and a small set of singles and pairs with
+    reversals and mismatches."""
+    if workload == "c2":
+        import bench
+
+        reads, cand, cfg, st = bench.build_workload("c2", 0)
+        del cand
+        n_single, n_pairs, err, t = 0, reads.n_reads, 0.0, 90
+    else:
+        kw = dict(n_single=300, n_pair=500, glen=2500, lo=100, hi=200, err=0.01)
+        reads = make_reads(321, **kw)
+        n_single, n_pairs, err, t = kw["n_single"], kw["n_pair"], 0.03, 70
+        st = hc.Settings(edge_threshold=0.9, ov_threshold=0.5, min_overlap_len=0)
+    st.n_threads = 8
+    d = str(tmp_path) + "/"
+    fq = dict(singles=d + "s.fastq" if n_single else None, paired1=d + "p1.fastq" if n_pairs else None, paired2=d + "p2.fastq" if n_pairs else None)
+    reads.write_fastq(fq["singles"], fq["paired1"], fq["paired2"])
+    out_a, out_b = tmp_path / "a", tmp_path / "b"
+    out_a.mkdir()
+    out_b.mkdir()
+    with host.EdgeCalculatorStage(st, output_dir=str(out_a) + "/", **fq) as ec:  # no overlaps file at all
+        n_found, n_lines = ec.construct_edges_from_reads(err, t)
+        a = (ec.edges(), ec.in_lists(), ec.inclusions(), ec.counters())
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        assert sc.find_overlaps(err, t, count_only=True) == n_found
+        assert sc.found_to_overlaps(d + "overlaps.txt", n_single, n_pairs) == n_lines
+    with host.EdgeCalculatorStage(st, overlaps=d + "overlaps.txt", output_dir=str(out_b) + "/", **fq) as ec:
+        ec.construct_edges_sorted()
+        b = (ec.edges(), ec.in_lists(), ec.inclusions(), ec.counters())
+    assert n_lines > 1000 and a[0].size == b[0].size > 500
+    assert a[0].tobytes() == b[0].tobytes()
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])
+    for k in ("inclusion_count", "dup_count", "edges_added", "nonedges_written", "prefilter_rejected", "lines_read", "scored", "self_overlap_count"):
+        assert a[3][k] == b[3][k], k
+    assert (out_a / "nonedge_overlaps.txt").read_bytes() == (out_b / "nonedge_overlaps.txt").read_bytes()
