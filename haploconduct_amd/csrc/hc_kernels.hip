@@ -42,6 +42,14 @@
 #define HC_COOP_AUX_B 0
 #endif
 
+// Experiment builds only (tools/experiments/ablate.sh): HC_ABLATE is a bit mask of parts of the cooperative kernel that are
+// cut out to see what the others cost — results are garbage.  1: no table reads (the LDS look-up of every position becomes a
+// register move), 2: no row loads from memory, 4: no passage of the rows through the LDS image.  The shipped library is
+// built without it.
+#ifndef HC_ABLATE
+#define HC_ABLATE 0
+#endif
+
 namespace hc {
 
 // ---------------------------------------------------------------------------
@@ -167,7 +175,11 @@ struct Tr<uint16_t> {
 // table byte address IS the LDS address: no per-position base add in front of the ds_read_b64.
 typedef const __attribute__((address_space(3))) double lds_cdouble;
 __device__ __forceinline__ double lds_f64(uint32_t byte_addr) {
+#if HC_ABLATE & 1
+    return __hiloint2double(0x3C000000 | (int)(byte_addr & 0xFFFFu), (int)byte_addr);  // a tiny positive number made from the address
+#else
     return *(lds_cdouble*)(uintptr_t)byte_addr;
+#endif
 }
 
 // Exact per-position re-scan (rare: only when the fast sum came out NaN, i.e. the window
@@ -448,23 +460,37 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool on = at < lim[j];
+#if HC_ABLATE & 2
+            sA[j] = u32x4{0x01010101u + (on ? (la[j] + at) & 0x02020202u : 0u), 0x01010101u, 0x09090909u, 0x11111111u};  // valid symbols only
+            sB[j] = u32x4{0x09090909u + (on ? (lb[j] + at) & 0x02020202u : 0u), 0x09090909u, 0x01010101u, 0x11111111u};
+#else
             sA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] + at : oob, 0, HC_COOP_AUX_A);
             sB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] + at : oob, 0, HC_COOP_AUX_B);
+#endif
         }
     };
     double S = 0.0;
     uint32_t skipped = 0, cm = 0;
     auto step = [&](u32x4 (&sA)[4], u32x4 (&sB)[4], uint32_t at) {
+        u32x4 xa[4];
+#if HC_ABLATE & 4
+        u32x4 xb_[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            xa[p] = sA[p];
+            xb_[p] = sB[p];
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds_store128(wr + 1024u * j, sA[j]);
         wave_lds_order();
-        u32x4 xa[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) xa[p] = lds_load128(rd ^ ((uint32_t)p << 4));
         wave_lds_order();
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds_store128(wr + 1024u * j, sB[j]);
         wave_lds_order();
+#endif
         fetch(sA, sB, at + 64u * DEPTH);
         uint32_t cn4 = 0, cm4 = 0;
 #pragma unroll
@@ -474,7 +500,11 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
 #pragma unroll
                 for (int s = 0; s < (int)kSymB; ++s) {
                     const int p = q * (int)kSymB + s;
+#if HC_ABLATE & 4
+                    const u32x4 vb = xb_[p];
+#else
                     const u32x4 vb = lds_load128(rd ^ ((uint32_t)p << 4));
+#endif
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         wa[4 * s + w] = xa[p][w];
