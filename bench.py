@@ -75,7 +75,7 @@ def pmc_profile(workload, order, kernel_symbol, kern_ms):
         return None, "the PMC file is for another candidate order / record format"
     if t.get("kernel_source_sha") != kernel_source_sha():
         return None, f"stale: the PMC file was collected on kernel sources {t.get('kernel_source_sha')}, this run has {kernel_source_sha()}"
-    sym = (t.get("kernel") or "").split("(")[0].replace("void ", "").strip()
+    sym = (t.get("kernel") or "").split("(")[0].replace("void ", "").replace("unsigned char", "uint8_t").replace("unsigned short", "uint16_t").strip()
     if sym != kernel_symbol:
         return None, f"the PMC file measured {sym!r}, this run launched {kernel_symbol!r}"
     ref_ms = t.get("kernel_ms_hipevents_under_rocprof") or t.get("kernel_ms_rocprof_avg")

@@ -428,6 +428,36 @@ constexpr uint32_t kStageBytesPerWave = 64u * 64u;
 // LDS of the cooperative kernel: [table][scratch: 32 words][pad to 1 KiB][one image per wave]
 __host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t /*wg*/) { return (lut_bytes + 128u + 1023u) & ~1023u; }
 
+// What a sub-overlap's walk leaves behind -> its result (x = (1/n) S, mismatches, n), or the exact re-scan when the sum came
+// out NaN (an invalid symbol inside the window, or next to it in the last chunk).
+template <typename SymT>
+__device__ __forceinline__ void finish_sub(const SymT* __restrict__ sym, uint32_t offA, uint32_t offB, uint32_t L, uint32_t fatal, uint32_t Kp, double S,
+                                           uint32_t skipped, uint32_t cm, bool packed, SubScore& out) {
+    out.x = -__builtin_inf();
+    out.mm = 1;
+    out.n = 1;
+    out.err = fatal;
+    if (L == 0) return;
+    if (packed) {
+        skipped >>= 2;
+        cm >>= 2;
+    }
+    if (S != S) {
+        const SubScore e = score_sub_slow<SymT>((const SymT*)((const char*)sym + offA), (const SymT*)((const char*)sym + offB), L, Kp);
+        out.x = e.x;
+        out.mm = e.mm;
+        out.n = e.n;
+        out.err |= e.err;
+        return;
+    }
+    if (S == __builtin_inf()) return;
+    const uint32_t cn = 16u * ((L + 15u) >> 4) - skipped;
+    if (cn == 0) return;
+    out.x = (1.0 / (double)cn) * S;
+    out.mm = cm;
+    out.n = cn;
+}
+
 // One sub-overlap of each of the wave's 64 candidates.  Called by all 64 lanes; a lane without one passes L = 0.
 // offA / offB: byte offsets of the window starts in the store; L: positions (sub_positions()).
 template <typename SymT, int LG, int DEPTH = 1>
@@ -453,9 +483,79 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
     }
     const uint32_t wr = stage + lane * 16u;                                  // + j KiB: lane-linear
     const uint32_t rd = stage + lane * 64u + (((lane >> 2) & 3u) << 4);    // ^ piece << 4
+    if constexpr (DEPTH == 0) {
+        // LDS-DMA form (buffer_load_dwordx4 ... lds, gfx950): the pieces go from memory straight into the wave's image — A rows
+        // into its first 4 KiB, B rows into the second — with no destination registers and no ds_write_b128; the image is
+        // lane-linear per instruction (M0 = wave-uniform base, lane l writes 16 bytes at base + 16 l), the XOR swizzle sits on
+        // the SOURCE side (which piece a lane fetches), exactly as in the register-staged form.  A step: wait for its pieces,
+        // every owner copies its two rows into registers, the next step's pieces are requested into the same image, the rows
+        // are scored from the registers.
+        double S = 0.0;
+        uint32_t skipped = 0, cm = 0;
+        const uint32_t rdA = stage + lane * 64u + (((lane >> 2) & 3u) << 4), rdB = rdA + 4096u;
+        auto fetch_dma = [&](uint32_t at) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = at < lim[j];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(stage + 1024u * j), 16,
+                                                         on ? la[j] + at : oob, 0, 0, HC_COOP_AUX_A);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(stage + 4096u + 1024u * j), 16,
+                                                         on ? lb[j] + at : oob, 0, 0, HC_COOP_AUX_B);
+            }
+        };
+        if (__ballot(Lb != 0u) != 0ull) {  // wave-uniform
+            fetch_dma(0);
+            for (uint32_t at = 0;; at += 64u) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's pieces have landed
+                wave_lds_order();
+                u32x4 xa[4], xb[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    xa[p] = lds_load128(rdA ^ ((uint32_t)p << 4));
+                    xb[p] = lds_load128(rdB ^ ((uint32_t)p << 4));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
+                wave_lds_order();
+                const bool more = __ballot(at + 64u < Lb) != 0ull;
+                if (more) fetch_dma(at + 64u);  // into the image every owner has just emptied
+                uint32_t cn4 = 0, cm4 = 0;
+#pragma unroll
+                for (int q = 0; q < kChunks; ++q)
+                    if (at + kChunkB * q < Lb) {
+                        uint32_t wa[T::kWords], wb[T::kWords];
+#pragma unroll
+                        for (int sw = 0; sw < (int)kSymB; ++sw) {
+                            const int p = q * (int)kSymB + sw;
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                wa[4 * sw + w] = xa[p][w];
+                                wb[4 * sw + w] = xb[p][w];
+                            }
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            double t[8];
+                            half_chunk_terms<SymT, LG>(wa + h * (T::kWords / 2), wb + h * (T::kWords / 2), Kp, t, cn4, cm4);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) S += t[k];  // :119, strictly in position order
+                        }
+                    }
+                if (kPacked) {
+                    skipped = __builtin_amdgcn_sad_u8(cn4, 0u, skipped);
+                    cm = __builtin_amdgcn_sad_u8(cm4, 0u, cm);
+                } else {
+                    skipped += cn4;
+                    cm += cm4;
+                }
+                if (!more) break;
+            }
+        }
+        finish_sub<SymT>(sym, offA, offB, L, fatal, Kp, S, skipped, cm, kPacked, out);
+        return;
+    }
     // DEPTH register sets of pieces in flight: set s holds the pieces of the step it is consumed in and is refilled, right
     // after its pieces went to LDS, with those of DEPTH steps further on
-    u32x4 nA[DEPTH][4], nB[DEPTH][4];
+    u32x4 nA[DEPTH == 0 ? 1 : DEPTH][4], nB[DEPTH == 0 ? 1 : DEPTH][4];
     auto fetch = [&](u32x4 (&sA)[4], u32x4 (&sB)[4], uint32_t at) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -537,29 +637,7 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
             step(nA[DEPTH - 1], nB[DEPTH - 1], at + 64u);
         }
     }
-    out.x = -__builtin_inf();
-    out.mm = 1;
-    out.n = 1;
-    out.err = fatal;
-    if (L == 0) return;
-    if (kPacked) {
-        skipped >>= 2;
-        cm >>= 2;
-    }
-    if (S != S) {  // an invalid symbol inside the window (or next to it, in the last chunk)
-        const SubScore e = score_sub_slow<SymT>((const SymT*)((const char*)sym + offA), (const SymT*)((const char*)sym + offB), L, Kp);
-        out.x = e.x;
-        out.mm = e.mm;
-        out.n = e.n;
-        out.err |= e.err;
-        return;
-    }
-    if (S == __builtin_inf()) return;
-    const uint32_t cn = 16u * ((L + 15u) >> 4) - skipped;
-    if (cn == 0) return;
-    out.x = (1.0 / (double)cn) * S;
-    out.mm = cm;
-    out.n = cn;
+    finish_sub<SymT>(sym, offA, offB, L, fatal, Kp, S, skipped, cm, kPacked, out);
 }
 
 // Result records are written once and read by nobody on the device: streamed past the caches, so they do not push the
@@ -1002,7 +1080,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     uint32_t* scratch = (uint32_t*)(lut_s + lut_n);  // row append: [0..17]
     // this wave's image (LDS byte address); the images start at a multiple of 1 KiB (the XOR swizzle needs whole 64-byte rows)
     const uint32_t stage_base = coop_stage_base(st.lut_bytes, WG);
-    const uint32_t stage = stage_base + (threadIdx.x >> 6) * kStageBytesPerWave;
+    const uint32_t stage = stage_base + (threadIdx.x >> 6) * (DEPTH == 0 ? 2u * kStageBytesPerWave : kStageBytesPerWave);  // DEPTH 0: LDS-DMA, A and B images
     const SymT* sym = (const SymT*)st.sym;
     const uint32_t Kp = st.K + 2u;
     const uint32_t fmt = prm.rec_fmt;
@@ -1223,6 +1301,15 @@ void launch_lg(int group, const ScoreLaunch& a) {
 }
 }  // namespace
 
+// The LDS-DMA form of the cooperative fetch (score_sub_coop, DEPTH = 0) runs 1 024-lane workgroups, one per CU: launches of
+// fewer candidates than this keep the 256-lane register-staged form, which fills the chip with four times as many workgroups.
+// C3 (10^8 candidates) 7.50 -> 7.10 ms, C2 (2 * 10^6) 0.190 -> 0.180 ms.  HC_COOP_DMA=0 turns it off (a tuning knob).
+constexpr uint64_t kDmaMinCandidates = 500000;
+static bool coop_dma_wanted() {
+    static const bool on = !(getenv("HC_COOP_DMA") && atoi(getenv("HC_COOP_DMA")) == 0);
+    return on;
+}
+
 // fetch_group: 0 = cooperative fetch (falls back to lane_fetch_group for stores of 4 GiB and more); per lane: 4 = 64-symbol
 // fetch groups (short reads), 2 = 32-symbol groups (contig-length sequences); chosen per
 // read set by hc_set_reads.  rows == nullptr: plain scoring; otherwise every non-dropped record is also appended to
@@ -1269,6 +1356,25 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                     hipLaunchKernelGGL((bucket_perm_kernel<1>), dim3(tiles), dim3(1024), 0, stream, st, prm.min_read_len, prm.rec_fmt, in, n, prm.n_dev,
                                        perm, bucket_perm, bucket_queue);
                 perm = bucket_perm;
+            }
+            // LDS-DMA form (score_sub_coop, DEPTH = 0): 8 KiB of image per wave, so one 1 024-lane workgroup with one table per CU;
+            // 8-bit symbols with a table of at most 16 KiB
+            const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
+            if (coop_dma_wanted() && n >= kDmaMinCandidates && !bucketed && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024) {
+                uint64_t blocks_d = (n + 1023) / 1024;
+                // one workgroup is resident per CU; 16 queued per CU even out what the CUs finish at different times (C3: 1 per CU 7.32 ms,
+                // 4: 7.10, 16: 6.92, 64: 6.88, 256: 7.32, one per 1 024 candidates 7.63; profiles/r03_dma_grid.txt)
+                static const int grid_mult_d = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 16;
+                const uint64_t cap_d = (uint64_t)n_cu * grid_mult_d;
+                if (blocks_d > cap_d) blocks_d = cap_d;
+#define HC_COOP_DMA_LAUNCH(LG_)                                                                                                       \
+    hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_, 1024, true, false, 0>), dim3((uint32_t)blocks_d), dim3(1024), lds_dma, stream, st, prm, \
+                       lut_g, in, n, out, perm, sink, nullptr)
+                if (lg == 3) HC_COOP_DMA_LAUNCH(3);
+                else if (lg == 4) HC_COOP_DMA_LAUNCH(4);
+                else HC_COOP_DMA_LAUNCH(5);
+#undef HC_COOP_DMA_LAUNCH
+                return hipGetLastError();
             }
 #define HC_COOP(T_, LG_)                                                                                                              \
     do {                                                                                                                              \
@@ -1342,9 +1448,18 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
             per_cu = per_cu * (wg_c / 64) > 32 ? 32 / (wg_c / 64) : per_cu;
             if (st.long_rows && wg_c == 256 && per_cu > 2) per_cu = 2;
             const bool deep = st.balance && per_cu <= 2 && wg_c == 256;
-            snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, %u, true, %s%s> encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=%u%s", sym.c_str(),
-                     st.symbytes == 2 ? 5u : lg, wg_c, st.balance ? "true" : "false", deep ? ", 2" : "", enc.c_str(), st.lut_bytes, lds_c, per_cu * (wg_c / 64),
-                     st.balance ? " length-bucketed (hc::bucket_perm_kernel, wave queue)" : "");
+            const uint32_t lgt = st.symbytes == 2 ? 5u : lg;
+            char small[128];
+            snprintf(small, sizeof small, "hc::score_kernel_coop<%s, %u, %u, true, %s, %d>", sym.c_str(), lgt, wg_c, st.balance ? "true" : "false", deep ? 2 : 1);
+            const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
+            const bool dma = !st.balance && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024 && coop_dma_wanted();
+            if (dma)
+                snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, 1024, true, false, 0> encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=16 "
+                                          "LDS-DMA fetch for launches of %llu candidates and more; smaller launches: %s",
+                         sym.c_str(), lgt, enc.c_str(), st.lut_bytes, lds_dma, (unsigned long long)kDmaMinCandidates, small);
+            else
+                snprintf(buf, sizeof buf, "%s encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=%u%s", small, enc.c_str(), st.lut_bytes, lds_c,
+                         per_cu * (wg_c / 64), st.balance ? " length-bucketed (hc::bucket_perm_kernel, wave queue)" : "");
             return buf;
         }
         fetch_group = lane_fetch_group;
@@ -1385,6 +1500,9 @@ hipError_t set_score_kernel_lds_limit() {
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;  \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 3, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 4, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 5, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     HC_COOP_ATTR(uint8_t, 3)
     HC_COOP_ATTR(uint8_t, 4)
     HC_COOP_ATTR(uint8_t, 5)
