@@ -78,9 +78,11 @@ def pmc_profile(workload, order, kernel_symbol, kern_ms):
     sym = (t.get("kernel") or "").split("(")[0].replace("void ", "").replace("unsigned char", "uint8_t").replace("unsigned short", "uint16_t").strip()
     if sym != kernel_symbol:
         return None, f"the PMC file measured {sym!r}, this run launched {kernel_symbol!r}"
-    ref_ms = t.get("kernel_ms_hipevents_under_rocprof") or t.get("kernel_ms_rocprof_avg")
-    if not ref_ms or abs(ref_ms - kern_ms) > 0.05 * kern_ms:
-        return None, f"the PMC file's kernel took {ref_ms} ms, this run's {kern_ms:.4f} ms: more than 5 % apart"
+    # the file's two clocks: rocprofv3's kernel trace (average duration) and hipEvents in the same, profiled run (inflated for launches of
+    # a fraction of a millisecond); one of them within 5 % of this run's
+    refs = [x for x in (t.get("kernel_ms_rocprof_avg"), t.get("kernel_ms_hipevents_under_rocprof")) if x]
+    if not any(abs(x - kern_ms) <= 0.05 * kern_ms for x in refs):
+        return None, f"the PMC file's kernel took {refs} ms (rocprofv3 average, hipEvents under rocprofv3), this run's {kern_ms:.4f} ms: more than 5 % apart"
     return t, None
 
 
