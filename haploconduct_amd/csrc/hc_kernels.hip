@@ -1309,6 +1309,10 @@ static bool coop_dma_wanted() {
     static const bool on = !(getenv("HC_COOP_DMA") && atoi(getenv("HC_COOP_DMA")) == 0);
     return on;
 }
+static uint64_t coop_dma_min() {  // HC_COOP_DMA_MIN: test knob — the LDS-DMA form for launches of that many candidates and more
+    const char* e = getenv("HC_COOP_DMA_MIN");
+    return e ? strtoull(e, nullptr, 10) : kDmaMinCandidates;
+}
 
 // fetch_group: 0 = cooperative fetch (falls back to lane_fetch_group for stores of 4 GiB and more); per lane: 4 = 64-symbol
 // fetch groups (short reads), 2 = 32-symbol groups (contig-length sequences); chosen per
@@ -1360,7 +1364,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             // LDS-DMA form (score_sub_coop, DEPTH = 0): 8 KiB of image per wave, so one 1 024-lane workgroup with one table per CU;
             // 8-bit symbols with a table of at most 16 KiB
             const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
-            if (coop_dma_wanted() && n >= kDmaMinCandidates && !bucketed && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024) {
+            if (coop_dma_wanted() && n >= coop_dma_min() && !bucketed && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024) {
                 uint64_t blocks_d = (n + 1023) / 1024;
                 // one workgroup is resident per CU; 16 queued per CU even out what the CUs finish at different times (C3: 1 per CU 7.32 ms,
                 // 4: 7.10, 16: 6.92, 64: 6.88, 256: 7.32, one per 1 024 candidates 7.63; profiles/r03_dma_grid.txt)

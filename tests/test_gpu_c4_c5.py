@@ -228,6 +228,16 @@ def test_fuzz_bucketed_launch_random_shapes(oracle, seed):
             assert np.array_equal(res["mm"], ref["mm"]) and np.array_equal(result_n(res), ref["n"])
             score, mrate, cls = sc.finalize(res)
             assert np.array_equal(cls, ref["cls"]) and np.array_equal(score.view(np.uint64), ref["score"].view(np.uint64))
+        # the per-lane kernel with block-local balancing (what a store of 4 GiB and more takes) on the same shapes
+        for fetch in ("2", "4"):
+            os.environ["HC_FETCH_GROUP"] = fetch
+            try:
+                with hc.EdgeScorer(st) as lane:
+                    lane.set_reads(reads)
+                    assert "hc::score_kernel<" in lane.kernel_info()
+                    assert lane.score_batch(cand).tobytes() == res.tobytes(), (seed, fetch)
+            finally:
+                os.environ.pop("HC_FETCH_GROUP", None)
         # the launch that also collects its rows (the multi-GPU payload): the same records, whatever their order
         kept = np.nonzero(result_cls(res) != 0)[0]
         rows = sc.score_blocks(sc.pack_cands(cand), block=5000, in_flight=2)

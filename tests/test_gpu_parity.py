@@ -399,9 +399,18 @@ def test_fuzz_random_read_sets_settings_and_geometry(oracle, seed):
     check_parity(oracle, reads, st, cand)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 4, 7, 10, 13, 16, 22, 31, 37])
+def test_fuzz_through_the_lds_dma_form(oracle, monkeypatch, seed):
+    """The LDS-DMA form of the cooperative fetch serves launches of 5 * 10^5 candidates and more; here it is made to take
+    the fuzz scenarios' 1 500 (read sets of equal-length sequences only: mixed lengths take the bucketed launch)."""
+    monkeypatch.setenv("HC_COOP_DMA_MIN", "1")
+    monkeypatch.setenv("HC_BALANCE", "0")  # every read set through the plain launch, whatever its lengths
+    test_fuzz_random_read_sets_settings_and_geometry(oracle, seed)
+
+
 @pytest.mark.parametrize("fetch", ["coop", "4", "2"])
 @pytest.mark.parametrize("regular", ["1", "0"])
-@pytest.mark.parametrize("n_quals", [5, 12, 25])  # the three dense / sparse 8-bit tables
+@pytest.mark.parametrize("n_quals", [5, 12, 25, 40, 60])  # the three dense / sparse 8-bit tables, the wide 8-bit encoding (per lane: 512-lane workgroups), 16-bit symbols
 def test_fetch_and_descriptor_paths_agree(oracle, monkeypatch, fetch, regular, n_quals):
     """A store of equal-length sequences, singles first ("regular": read descriptors by arithmetic) scored with the
     cooperative fetch and with both per-lane fetch groups, each with and without descriptor look-ups: every combination
