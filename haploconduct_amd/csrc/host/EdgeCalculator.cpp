@@ -409,8 +409,56 @@ void EdgeCalculator::resolve_on_device(bool sorted) {
     hc_graph_counts gc;
     size_t total = 0;
     for (const auto& b : m_admitted) total += b.size();
+    // destination of the fetch: plain uninitialised memory (a zero-filled std::vector would touch 300 MB at C3 first), sized for the
+    // upper bound (every admitted record an edge) BEFORE the device resolves, so that a few threads can fault its pages in while it
+    // does: the copy into fresh pages ran at 15 GB/s, into touched ones it runs at the runtime's pageable-copy rate
+    struct Raw {
+        void* p = nullptr;
+        size_t bytes = 0;
+        explicit Raw(size_t want) {
+            const size_t huge = (size_t)2 << 20;
+            bytes = (std::max<size_t>(want, 1) + huge - 1) & ~(huge - 1);
+            if (posix_memalign(&p, huge, bytes) != 0) throw FatalError{HC_ERR_NOMEM, "construct_edges: out of memory"};
+            madvise(p, bytes, MADV_HUGEPAGE);
+        }
+        ~Raw() { free(p); }
+        Raw(const Raw&) = delete;
+        Raw& operator=(const Raw&) = delete;
+    };
+    // (freed by the clean-up thread, off the caller's clock: unmapping 300 MB takes as long as the fetch's copy)
+    struct Fetched {
+        Raw edges, in, seq;
+        Fetched(size_t a, size_t b, size_t c) : edges(a), in(b), seq(c) {}
+    };
+    std::unique_ptr<Fetched> fetched(new Fetched(total * sizeof(hc_edge_rec), total * sizeof(uint32_t), total * sizeof(uint32_t)));
+    struct HandOver {
+        std::unique_ptr<Fetched>& f;
+        EdgeCalculator* self;
+        ~HandOver() { self->defer_cleanup([p = f.release()] { delete p; }); }
+    } hand_over{fetched, this};
+    std::vector<std::thread> touchers;
+    struct JoinAll {
+        std::vector<std::thread>& t;
+        ~JoinAll() {
+            for (auto& x : t)
+                if (x.joinable()) x.join();
+        }
+    } join_all{touchers};
+    {
+        const unsigned T = total * sizeof(hc_edge_rec) < ((size_t)64 << 20) ? 0u : std::max(1u, std::min(8u, program_settings.n_threads));
+        for (unsigned t = 0; t < T; t++)
+            touchers.emplace_back([&, t, T] {
+                bind_here();
+                for (Raw* r : {&fetched->edges, &fetched->in}) {
+                    volatile char* q = (volatile char*)r->p;
+                    for (size_t at = r->bytes * t / T & ~(size_t)4095; at < r->bytes * (t + 1) / T; at += 4096) q[at] = 0;
+                }
+            });
+    }
     check(hc_graph_resolve(m_ctx, nullptr, total, V, identity ? nullptr : vtx.data(), sorted ? HC_GRAPH_SORTED : HC_GRAPH_INSERTION_ORDER, &gc),
           "hc_graph_resolve");
+    for (auto& x : touchers) x.join();
+    touchers.clear();
     lap("resolve");
     if (gc.first_bad >= 0) {  // the record the reference's Edge rejects: say what it says
         size_t at = (size_t)gc.first_bad;
@@ -424,29 +472,7 @@ void EdgeCalculator::resolve_on_device(bool sorted) {
         throw FatalError{HC_ERR_STATE, "hc_graph_resolve rejected an admitted record the host accepts"};
     }
     const size_t E = (size_t)gc.n_edges;
-    // destination of the fetch: plain uninitialised memory (a zero-filled std::vector would touch 300 MB at C3 first)
-    struct Raw {
-        void* p = nullptr;
-        explicit Raw(size_t bytes) {
-            const size_t huge = (size_t)2 << 20, n = (std::max<size_t>(bytes, 1) + huge - 1) & ~(huge - 1);
-            if (posix_memalign(&p, huge, n) != 0) throw FatalError{HC_ERR_NOMEM, "construct_edges: out of memory"};
-            madvise(p, n, MADV_HUGEPAGE);
-        }
-        ~Raw() { free(p); }
-        Raw(const Raw&) = delete;
-        Raw& operator=(const Raw&) = delete;
-    };
-    // (freed by the clean-up thread, off the caller's clock: unmapping 300 MB takes as long as the fetch's copy)
-    struct Fetched {
-        Raw edges, in, seq;
-        Fetched(size_t a, size_t b, size_t c) : edges(a), in(b), seq(c) {}
-    };
-    std::unique_ptr<Fetched> fetched(new Fetched(E * sizeof(hc_edge_rec), E * sizeof(uint32_t), gc.n_tied_lists ? E * sizeof(uint32_t) : 0));
-    struct HandOver {
-        std::unique_ptr<Fetched>& f;
-        EdgeCalculator* self;
-        ~HandOver() { self->defer_cleanup([p = f.release()] { delete p; }); }
-    } hand_over{fetched, this};
+    if (E > total) throw FatalError{HC_ERR_STATE, "hc_graph_resolve returned more edges than admitted records"};
     hc_edge_rec* edges = (hc_edge_rec*)fetched->edges.p;
     uint32_t* in_nodes = (uint32_t*)fetched->in.p;
     uint32_t* seq = gc.n_tied_lists ? (uint32_t*)fetched->seq.p : nullptr;
