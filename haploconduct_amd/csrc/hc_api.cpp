@@ -485,8 +485,20 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
         bperm = ws->perm();
         bqueue = ws->queue();
     }
+    hc_gather_row* seg_buf = nullptr;
+    uint32_t* seg_count = nullptr;
+    uint64_t seg_total = 0;
+    if (rows && !lines_in && c->coop_fetch && !bperm) {  // the plain cooperative launch collects its rows in per-workgroup segments
+        constexpr uint64_t kMaxGroups = 4096;        // the largest grid launch_score uses for it (n_cu x 16)
+        seg_total = 2 * cap + kMaxGroups * 512;      // twice the expected share per workgroup, and room for the small ones
+        int rc = c->sink_rows.ensure(seg_total * sizeof(hc_gather_row));
+        if (rc) return rc;
+        if ((rc = c->sink_counts.ensure(kMaxGroups * sizeof(uint32_t))) != HC_OK) return rc;
+        seg_buf = c->sink_rows.as<hc_gather_row>();
+        seg_count = c->sink_counts.as<uint32_t>();
+    }
     HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group, rows, row_count, cap,
-                            base_index, s, lines_in, lines_out, bperm, bqueue));
+                            base_index, s, lines_in, lines_out, bperm, bqueue, seg_buf, seg_count, seg_total));
     return HC_OK;
 }
 

@@ -20,7 +20,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr, uint32_t* bucket_perm = nullptr,
-                        uint32_t* bucket_queue = nullptr);
+                        uint32_t* bucket_queue = nullptr, hc_gather_row* seg_buf = nullptr, uint32_t* seg_count = nullptr, uint64_t seg_total_rows = 0);
+// seg_buf (seg_total_rows rows) / seg_count (4 096 counters): scratch of a launch that collects its rows in per-workgroup segments
 // bucket_perm (n uint32) / bucket_queue (one uint32): scratch of the length-bucketed launch (read sets of mixed sequence
 // length, StoreView::balance): without them such a set is scored in the order given
 hipError_t set_score_kernel_lds_limit();
@@ -137,6 +138,7 @@ struct hc_ctx {
     size_t sort_tmp_bytes = 0;
     uint64_t sort_cap = 0;
     hc_bucket_ws bucket;  // length-bucketed launches on the context's own entry points
+    hc_scratch sink_rows, sink_counts;  // hc_score_pack_device: the row sink's per-workgroup segments (hc_kernels.hip: RowSink)
     // compaction scratch, grow-only
     void* d_compact_tmp = nullptr;
     size_t compact_tmp_bytes = 0;

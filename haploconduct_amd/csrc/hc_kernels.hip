@@ -741,6 +741,15 @@ struct RowSink {
     // the device parser's stage: the parsed line of every appended row travels with it (lines_out[pos] = lines_in[i])
     const hc_line_rec* lines_in;
     hc_line_rec* lines_out;
+    // Segment mode (the cooperative kernel's plain launches; hc_score_pack_device): every workgroup appends into a segment of its
+    // own — seg_rows rows at seg_buf + blockIdx.x * seg_rows, its place taken from a counter in LDS, so the waves neither meet at a
+    // barrier nor share a global atomic — and leaves its count in seg_count[blockIdx.x]; sink_compact_kernel then moves the
+    // segments into `rows` back to back and writes *count.  nullptr: rows are appended directly (one global atomic per workgroup
+    // and iteration behind two barriers, or one per wave in the bucketed launch).
+    hc_gather_row* seg_buf;
+    uint32_t* seg_count;
+    uint32_t seg_rows;
+    uint32_t pad_;
 };
 
 // Called by ALL lanes of the workgroup (uniform control flow; `valid` = this lane scored candidate i).
@@ -975,6 +984,69 @@ __device__ __forceinline__ void append_rows_wave(const RowSink& sink, bool valid
     }
 }
 
+// Segment mode of the row sink: called by all 64 lanes of a wave, at its own pace.  lds_counter: LDS byte address of the
+// workgroup's row counter.
+__device__ __forceinline__ void append_rows_segment(const RowSink& sink, bool valid, const hc_result_rec& res, uint64_t i, uint32_t lds_counter) {
+    const bool keep = valid && (res.n_cls >> 28) != HC_CLS_DROP;
+    const uint64_t m = __ballot(keep);
+    if (m == 0ull) return;  // wave-uniform
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) base = lds_add_rtn(lds_counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    if (keep) {
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < sink.seg_rows) {
+            hc_gather_row r;
+            r.index = sink.base_index + i;
+            r.x1 = res.x1;
+            r.x2 = res.x2;
+            r.mm = res.mm;
+            r.n_cls = res.n_cls;
+            sink.seg_buf[(uint64_t)blockIdx.x * sink.seg_rows + pos] = r;
+        }
+    }
+}
+
+// The segments of a launch back to back into the payload: workgroup g adds up the counts in front of it (at most 4 096 of them),
+// copies its rows as 16-byte pieces, and the last one writes the total — pushed beyond `cap` when a segment overflowed, so that
+// the caller sees rows were lost (hc_score_pack_device's contract).
+__global__ __launch_bounds__(256) void sink_compact_kernel(const hc_gather_row* __restrict__ seg_buf, const uint32_t* __restrict__ seg_count, uint32_t seg_rows,
+                                                           uint32_t G, hc_gather_row* __restrict__ rows, unsigned long long cap,
+                                                           unsigned long long* __restrict__ count) {
+    __shared__ unsigned long long part[4];
+    __shared__ uint32_t lost[4];
+    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    unsigned long long before = 0;
+    uint32_t over = 0;
+    for (uint32_t k = tid; k < G; k += 256) {
+        const uint32_t c = seg_count[k];
+        if (k < g) before += c < seg_rows ? c : seg_rows;
+        over |= c > seg_rows ? 1u : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        before += __shfl_down(before, o, 64);
+        over |= (uint32_t)__shfl_down((int)over, o, 64);
+    }
+    if ((tid & 63u) == 0) {
+        part[tid >> 6] = before;
+        lost[tid >> 6] = over;
+    }
+    __syncthreads();
+    before = part[0] + part[1] + part[2] + part[3];
+    over = lost[0] | lost[1] | lost[2] | lost[3];
+    const uint32_t mine = seg_count[g] < seg_rows ? seg_count[g] : seg_rows;
+    const uint4* src = (const uint4*)(seg_buf + (uint64_t)g * seg_rows);
+    uint4* dst = (uint4*)(rows + before);
+    const unsigned long long room = before < cap ? cap - before : 0ull;
+    const uint32_t n_copy = mine < room ? mine : (uint32_t)room;
+    for (uint32_t k = tid; k < 2u * n_copy; k += 256) dst[k] = src[k];  // 32-byte rows as two 16-byte pieces
+    if (g == G - 1 && tid == 0) {
+        const unsigned long long total = before + mine;
+        *count = over ? (total > cap ? total : cap + 1ull) : total;
+    }
+}
+
 __device__ __forceinline__ uint32_t length_class(uint32_t chunks) {  // 0..15 exact, then quarter octaves; < 128
     if (chunks < 16u) return chunks;
     const uint32_t lg = 31u - (uint32_t)__builtin_clz(chunks);
@@ -1076,8 +1148,10 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lut_s != 0u) __builtin_trap();  // lds_f64 relies on it
     const uint32_t lut_n = st.lut_bytes >> 3;
     load_log_table<SymT, LG>(lut_s, lut_g, lut_n, threadIdx.x, WG);
+    uint32_t* scratch = (uint32_t*)(lut_s + lut_n);  // row append: [0..17]; segment mode: [24] the workgroup's row counter
+    const uint32_t seg_counter = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(scratch + 24);
+    if (threadIdx.x == 0) scratch[24] = 0;
     __syncthreads();
-    uint32_t* scratch = (uint32_t*)(lut_s + lut_n);  // row append: [0..17]
     // this wave's image (LDS byte address); the images start at a multiple of 1 KiB (the XOR swizzle needs whole 64-byte rows)
     const uint32_t stage_base = coop_stage_base(st.lut_bytes, WG);
     const uint32_t stage = stage_base + (threadIdx.x >> 6) * (DEPTH == 0 ? 2u * kStageBytesPerWave : kStageBytesPerWave);  // DEPTH 0: LDS-DMA, A and B images
@@ -1207,8 +1281,13 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
         }
         if (sink.rows) {  // kernel-argument-uniform branch
             if (DYN) append_rows_wave(sink, slot < n, res, i);
+            else if (sink.seg_count) append_rows_segment(sink, slot < n, res, i, seg_counter);
             else append_rows_block(sink, slot < n, res, i, scratch);
         }
+    }
+    if (!DYN && sink.rows && sink.seg_count) {  // kernel-argument-uniform: every wave of the workgroup leaves its loop and arrives here
+        __syncthreads();
+        if (threadIdx.x == 0) sink.seg_count[blockIdx.x] = scratch[24];
     }
 }
 
@@ -1321,7 +1400,8 @@ static uint64_t coop_dma_min() {  // HC_COOP_DMA_MIN: test knob — the LDS-DMA 
 hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const double* lut_g, const void* in, uint64_t n,
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
-                        const hc_line_rec* lines_in, hc_line_rec* lines_out, uint32_t* bucket_perm, uint32_t* bucket_queue) {
+                        const hc_line_rec* lines_in, hc_line_rec* lines_out, uint32_t* bucket_perm, uint32_t* bucket_queue, hc_gather_row* seg_buf,
+                        uint32_t* seg_count, uint64_t seg_total_rows) {
     if (n == 0) return hipSuccess;
     const uint32_t lg = lut_lg(st.K);
     if (fetch_group == 0) {
@@ -1347,7 +1427,23 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             static const int grid_mult = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 4;  // experiment knob
             const uint64_t cap_c = (uint64_t)n_cu * per_cu * (bucketed ? 1 : grid_mult);  // a queue needs resident workgroups only
             if (blocks_c > cap_c) blocks_c = cap_c;
-            const RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out};
+            RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u};
+            // the plain launches collect their rows in per-workgroup segments (RowSink); G = the launch's workgroups
+            const bool segmented = rows && seg_buf && seg_count && !bucketed && !lines_in;
+            bool seg_on = false;
+            auto use_segments = [&](uint64_t G) {
+                seg_on = segmented && G <= 4096;  // seg_count holds 4 096 counters (a larger grid only under HC_GRID_MULT)
+                if (!seg_on) return;
+                const uint64_t per = seg_total_rows / G;
+                sink.seg_buf = seg_buf;
+                sink.seg_count = seg_count;
+                sink.seg_rows = (uint32_t)std::min<uint64_t>(per, 0xFFFFFFFFull);
+            };
+            auto compact_segments = [&](uint64_t G) {
+                if (seg_on)
+                    hipLaunchKernelGGL(sink_compact_kernel, dim3((uint32_t)G), dim3(256), 0, stream, (const hc_gather_row*)seg_buf, (const uint32_t*)seg_count,
+                                       sink.seg_rows, (uint32_t)G, rows, (unsigned long long)cap, row_count);
+            };
             const bool sort_subs = bucketed || !(prm.pad & 1u);
             static const int deep_env = getenv("HC_COOP_DEPTH") ? atoi(getenv("HC_COOP_DEPTH")) : 0;  // experiment knob: 1 = one step in flight always
             const bool deep = bucketed && per_cu <= 2 && wg_c == 256 && deep_env != 1;
@@ -1371,6 +1467,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 static const int grid_mult_d = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 16;
                 const uint64_t cap_d = (uint64_t)n_cu * grid_mult_d;
                 if (blocks_d > cap_d) blocks_d = cap_d;
+                use_segments(blocks_d);
 #define HC_COOP_DMA_LAUNCH(LG_)                                                                                                       \
     hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_, 1024, true, false, 0>), dim3((uint32_t)blocks_d), dim3(1024), lds_dma, stream, st, prm, \
                        lut_g, in, n, out, perm, sink, nullptr)
@@ -1378,6 +1475,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 else if (lg == 4) HC_COOP_DMA_LAUNCH(4);
                 else HC_COOP_DMA_LAUNCH(5);
 #undef HC_COOP_DMA_LAUNCH
+                compact_segments(blocks_d);
                 return hipGetLastError();
             }
 #define HC_COOP(T_, LG_)                                                                                                              \
@@ -1404,12 +1502,14 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, false, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_launch, stream, \
                                st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
     } while (0)
+            use_segments(blocks_c);
             if (st.symbytes == 2) HC_COOP(uint16_t, 5);
             else if (lg == 3) HC_COOP(uint8_t, 3);
             else if (lg == 4) HC_COOP(uint8_t, 4);
             else if (lg == 5) HC_COOP(uint8_t, 5);
             else HC_COOP(uint8_t, 6);
 #undef HC_COOP
+            compact_segments(blocks_c);
             return hipGetLastError();
         }
         fetch_group = lane_fetch_group;
@@ -1427,7 +1527,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     uint64_t blocks = (n + per_wg - 1) / per_wg;
     const uint64_t grid_cap = (uint64_t)n_cu * blocks_per_cu * 4;  // grid-stride beyond this
     if (blocks > grid_cap) blocks = grid_cap;
-    const ScoreLaunch a{st, prm, lut_g, in, n, out, perm, RowSink{rows, row_count, cap, base_index, lines_in, lines_out}, (uint32_t)blocks, wg, lds, stream};
+    const ScoreLaunch a{st, prm, lut_g, in, n, out, perm, RowSink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u}, (uint32_t)blocks, wg, lds, stream};
     if (st.symbytes == 2) launch_lg<uint16_t, 5>(fetch_group, a);
     else if (lg == 3) launch_lg<uint8_t, 3>(fetch_group, a);
     else if (lg == 4) launch_lg<uint8_t, 4>(fetch_group, a);

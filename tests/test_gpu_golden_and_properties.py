@@ -179,6 +179,8 @@ def test_rccl_gather_path_single_rank():
             small = parallel.StreamedGather(sc, cand.size, base_index=0, cap_rows=max(1, kept.size // 2))
             with pytest.raises(OverflowError):
                 small.collect(small.step(d_out))
+            with pytest.raises(OverflowError):  # the fused form (per-workgroup segments moved into a payload that is too small)
+                small.collect(small.score_step(d_in.data_ptr(), d_out))
             small.finish()
         cls = result_cls(host)
         want = np.nonzero((cls >= 2) & (cls <= 4))[0]
