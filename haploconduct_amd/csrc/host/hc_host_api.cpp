@@ -292,14 +292,29 @@ int hc_host_fastq_free(hc_fastq* f) {
     return HC_OK;
 }
 
+static int parse_with(const hc_settings* settings, hc_fastq* f, const char* overlaps_path, std::shared_ptr<const std::string> text, hc_overlap_rec* out,
+                      uint64_t cap, uint64_t* n_out, hc_ec_counters* counters);
+
 int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* overlaps_path, hc_overlap_rec* out,
                        uint64_t cap, uint64_t* n_out, hc_ec_counters* counters) {
     if (!settings || !f || !overlaps_path || !n_out) return set_last_error(HC_ERR_ARG, "hc_host_parse_file: null");
+    return parse_with(settings, f, overlaps_path, nullptr, out, cap, n_out, counters);
+}
+
+int hc_host_parse_text(const hc_settings* settings, hc_fastq* f, const char* text, uint64_t n_bytes, hc_overlap_rec* out, uint64_t cap,
+                       uint64_t* n_out, hc_ec_counters* counters) {
+    if (!settings || !f || (n_bytes && !text) || !n_out) return set_last_error(HC_ERR_ARG, "hc_host_parse_text: null");
+    return parse_with(settings, f, nullptr, std::make_shared<const std::string>(text ? text : "", (size_t)n_bytes), out, cap, n_out, counters);
+}
+
+static int parse_with(const hc_settings* settings, hc_fastq* f, const char* overlaps_path, std::shared_ptr<const std::string> text, hc_overlap_rec* out,
+                      uint64_t cap, uint64_t* n_out, hc_ec_counters* counters) {
     *n_out = 0;
     return guarded("parse", [&] {
         ProgramSettings ps = make_ps(settings, nullptr);
-        ps.overlaps_file = overlaps_path;
-        OverlapsParser parser(ps.overlaps_file, ps, *f->fastq);
+        if (overlaps_path) ps.overlaps_file = overlaps_path;
+        std::unique_ptr<OverlapsParser> owner(text ? new OverlapsParser(text, ps, *f->fastq) : new OverlapsParser(ps.overlaps_file, ps, *f->fastq));
+        OverlapsParser& parser = *owner;
         if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};
         ParsedBatch batch;
         std::vector<Overlap> rejected;

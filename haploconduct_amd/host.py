@@ -66,6 +66,8 @@ _sig = {
     "hc_host_fastq_free": (C.c_int, [_vp]),
     "hc_host_parse_file": (C.c_int, [C.POINTER(N.hc_settings), _vp, C.c_char_p, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                      C.POINTER(hc_ec_counters)]),
+    "hc_host_parse_text": (C.c_int, [C.POINTER(N.hc_settings), _vp, C.c_char_p, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64),
+                                     C.POINTER(hc_ec_counters)]),
     "hc_sfo2overlaps": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_sfo_records_to_overlaps": (C.c_int, [_vp, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_host_write_sfo": (C.c_int, [C.c_char_p, _vp, C.c_uint64]),
@@ -185,6 +187,17 @@ class Fastq:
         out = np.zeros(n.value, dtype=OVERLAP_DTYPE)
         N.check(N.lib.hc_host_parse_file(C.byref(cs), self._h, _b(overlaps_path), out.ctypes.data, n.value, C.byref(n),
                                          C.byref(c)), "hc_host_parse_file")
+        return out, c.as_dict()
+
+    def parse_text(self, settings: Settings, text):
+        """hc_host_parse_text: the overlaps file's text in memory through the same parser."""
+        raw = text if isinstance(text, bytes) else text.encode()
+        cs = settings.to_c()
+        n = C.c_uint64()
+        c = hc_ec_counters()
+        N.check(N.lib.hc_host_parse_text(C.byref(cs), self._h, raw, len(raw), None, 0, C.byref(n), C.byref(c)), "hc_host_parse_text")
+        out = np.zeros(n.value, dtype=OVERLAP_DTYPE)
+        N.check(N.lib.hc_host_parse_text(C.byref(cs), self._h, raw, len(raw), out.ctypes.data, n.value, C.byref(n), C.byref(c)), "hc_host_parse_text")
         return out, c.as_dict()
 
     def close(self):

@@ -120,6 +120,10 @@ int hc_host_fastq_free(hc_fastq* f);
  * candidates that would enter process_overlaps, in order.  *n_out may exceed cap. */
 int hc_host_parse_file(const hc_settings* settings, hc_fastq* f, const char* overlaps_path, hc_overlap_rec* out,
                        uint64_t cap, uint64_t* n_out, hc_ec_counters* counters);
+/* The same over the overlaps file's text in memory (what hc_ec_construct_edges_from_reads hands to the stage): identical
+ * records, counters and errors as for a file holding those bytes. */
+int hc_host_parse_text(const hc_settings* settings, hc_fastq* f, const char* text, uint64_t n_bytes, hc_overlap_rec* out, uint64_t cap,
+                       uint64_t* n_out, hc_ec_counters* counters);
 
 /* The inverse of the parser: n candidate records as 13-column overlaps-file lines (SURVEY.md Appendix A;
  * Overlap::get_overlap_line, src/Overlap.h:234-237, with "-" in the POS2/PERC2/LEN2 columns of a

@@ -49,6 +49,9 @@ def test_product_parser_takes_the_references_decisions(k, reads, tmp_path):
         want = [(int(t.split("\t")[0]), int(t.split("\t")[1])) for t, vv in zip(b["text"], b["verdict"]) if vv == 1]
         got = [(int(rs.read_ids[r["read1"]]), int(rs.read_ids[r["read2"]])) for r in recs]
         assert got == want
+        # the same bytes in memory instead of a file (what hc_ec_construct_edges_from_reads hands to the parser): same records, same counters
+        recs_m, c_m = f.parse_text(_settings(b, threads), "\n".join(b["lines"]) + "\n")
+        assert recs_m.tobytes() == recs.tobytes() and c_m == c
     # the text the kept lines re-serialise to, both reader routes
     for ln, vv, t in zip(b["lines"], b["verdict"], b["text"]):
         for general in (False, True):

@@ -76,6 +76,9 @@ for threads in (1, 3, 16):
 ov2 = w("ov2.txt", b"0\t9999\t0\t-\t-\t+\t+\t100\t-\t30\t-\ts\ts\n")
 st = S(0.97, 0.9, 0, 0, 0, 10, 0, 2, 10**8, 0, 4)
 assert host.hc_host_parse_file(C.byref(st), h, ov2, None, 0, C.byref(n), None) != 0
+host.hc_host_parse_text.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+for raw in (b"", b"\n", open(ov, "rb").read(), open(ov, "rb").read()[:-7], b"\t\t\n" * 5000):  # the memory-backed parser on the same hostile bytes
+    host.hc_host_parse_text(C.byref(st), h, raw, len(raw), None, 0, C.byref(n), None)
 host.hc_host_fastq_free(h)
 
 # 3. serial insert under duplicates
