@@ -405,7 +405,12 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
             lmin = seq_len[q] < lmin ? seq_len[q] : lmin;
             lmax = seq_len[q] > lmax ? seq_len[q] : lmax;
         }
-        c->view.balance = (n_seq && lmax > 2u * lmin) ? 1u : 0u;  // mixed-length read set (contigs + reads)
+        // mixed-length read set of contig-length sequences (contigs + reads): the launches bucket their candidates by length.
+        // Mixed but short sequences keep the plain launch, whose waves deal their sub-overlaps by length themselves: the
+        // bucketing's queue, gathered records and scattered results cost more than the idle lanes there (2 * 10^6 overlaps of
+        // reads of 100..400 bp: plain 0.19 ms, bucketed 0.45; 150..1 500 bp: 0.45 / 0.50; 150..6 000 bp: 1.36 / 0.72;
+        // profiles/r03_bucket_dispatch.txt)
+        c->view.balance = (n_seq && lmax > 2u * lmin && total / n_seq > 600) ? 1u : 0u;
         if (const char* b = getenv("HC_BALANCE")) c->view.balance = atoi(b) != 0;
     }
     c->coop_fetch = true;
