@@ -176,6 +176,14 @@ def build_workload(workload, rank):
         st = dict(edge_threshold=0.995, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=100)
         desc = f"c5: {n_reads} synthetic singles of log-uniform length 150..6000 bp, {cand.size} s-s candidates"
         cfg = {"reads": n_reads, "genome_len": glen}
+    elif workload == "c6":
+        # tuning workload: contig-length sequences of ONE length (no bucketing): which occupancy / fetch form long rows want
+        n_reads, glen = 40000, 300000
+        reads, meta = synth.make_single_dataset(n_reads, glen, len_lo=2000, len_hi=2000, n_strains=3, divergence=0.01, flip_frac=0.5, seed=7)
+        cand = synth.single_candidates(meta, min_overlap=100, n_candidates=1500000)
+        st = dict(edge_threshold=0.995, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=100)
+        desc = f"c6: {n_reads} synthetic singles of 2000 bp, {cand.size} s-s candidates"
+        cfg = {"reads": n_reads, "genome_len": glen}
     elif workload in ("c5s", "c5m"):
         # tuning workloads for the dispatch between the plain and the length-bucketed launch: reads of mixed but short / medium length
         lo, hi = (100, 400) if workload == "c5s" else (150, 1500)
