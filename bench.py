@@ -184,9 +184,9 @@ def build_workload(workload, rank):
         st = dict(edge_threshold=0.995, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=100)
         desc = f"c6: {n_reads} synthetic singles of 2000 bp, {cand.size} s-s candidates"
         cfg = {"reads": n_reads, "genome_len": glen}
-    elif workload in ("c5s", "c5m"):
+    elif workload in ("c5s", "c5m", "c5t"):
         # tuning workloads for the dispatch between the plain and the length-bucketed launch: reads of mixed but short / medium length
-        lo, hi = (100, 400) if workload == "c5s" else (150, 1500)
+        lo, hi = {"c5s": (100, 400), "c5m": (150, 1500), "c5t": (120, 900)}[workload]
         n_reads, glen = 120000, 300000
         reads, meta = synth.make_single_dataset(n_reads, glen, len_lo=lo, len_hi=hi, n_strains=3, divergence=0.01, flip_frac=0.5, seed=6, log_uniform=True)
         cand = synth.single_candidates(meta, min_overlap=60, n_candidates=2000000)

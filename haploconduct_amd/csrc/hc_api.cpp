@@ -405,12 +405,12 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
             lmin = seq_len[q] < lmin ? seq_len[q] : lmin;
             lmax = seq_len[q] > lmax ? seq_len[q] : lmax;
         }
-        // mixed-length read set of contig-length sequences (contigs + reads): the launches bucket their candidates by length.
-        // Mixed but short sequences keep the plain launch, whose waves deal their sub-overlaps by length themselves: the
-        // bucketing's queue, gathered records and scattered results cost more than the idle lanes there (2 * 10^6 overlaps of
-        // reads of 100..400 bp: plain 0.19 ms, bucketed 0.45; 150..1 500 bp: 0.45 / 0.50; 150..6 000 bp: 1.36 / 0.72;
-        // profiles/r03_bucket_dispatch.txt)
-        c->view.balance = (n_seq && lmax > 2u * lmin && total / n_seq > 600) ? 1u : 0u;
+        // mixed-length read set (contigs + reads) of sequences that are not short: the launches bucket their candidates by length.
+        // Mixed but short sequences keep the plain launch, whose waves deal their sub-overlaps by length themselves: the bucketing's
+        // gathered records and scattered results cost more than the idle lanes there.  2 * 10^6 s-s overlaps, plain / bucketed:
+        // reads of 100..400 bp (mean 216) 0.196 / 0.234 ms, 120..900 bp (mean 387) 0.307 / 0.289, 150..1 500 bp (mean 586)
+        // 0.441 / 0.348, 150..6 000 bp (mean 1 586) 1.35 / 0.63 (profiles/r03_bucket_dispatch.txt)
+        c->view.balance = (n_seq && lmax > 2u * lmin && total / n_seq > 350) ? 1u : 0u;
         if (const char* b = getenv("HC_BALANCE")) c->view.balance = atoi(b) != 0;
     }
     c->coop_fetch = true;
@@ -493,7 +493,7 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
     hc_gather_row* seg_buf = nullptr;
     uint32_t* seg_count = nullptr;
     uint64_t seg_total = 0;
-    if (rows && !lines_in && c->coop_fetch && !bperm) {  // the plain cooperative launch collects its rows in per-workgroup segments
+    if (rows && !lines_in && c->coop_fetch) {  // the cooperative launches collect their rows in per-workgroup segments
         constexpr uint64_t kMaxGroups = 4096;        // the largest grid launch_score uses for it (n_cu x 16)
         seg_total = 2 * cap + kMaxGroups * 512;      // twice the expected share per workgroup, and room for the small ones
         int rc = c->sink_rows.ensure(seg_total * sizeof(hc_gather_row));

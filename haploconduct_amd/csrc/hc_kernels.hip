@@ -642,11 +642,20 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
 
 // Result records are written once and read by nobody on the device: streamed past the caches, so they do not push the
 // read store out of L2 / the Infinity Cache (the candidate records are read the same way, hc_resolve.h).
+// (STREAM = false: the bucketed launch writes a tile's records in rank order, i.e. scattered over the tile's 96 KiB — plain stores
+// let the L2 put the lines together before they leave)
+template <bool STREAM = true>
 __device__ __forceinline__ void store_result(hc_result_rec* __restrict__ out, uint64_t i, const hc_result_rec& r) {
     unsigned long long* p = (unsigned long long*)(out + i);
-    __builtin_nontemporal_store((unsigned long long)__double_as_longlong(r.x1), p);
-    __builtin_nontemporal_store((unsigned long long)__double_as_longlong(r.x2), p + 1);
-    __builtin_nontemporal_store(((unsigned long long)r.n_cls << 32) | r.mm, p + 2);
+    if (STREAM) {
+        __builtin_nontemporal_store((unsigned long long)__double_as_longlong(r.x1), p);
+        __builtin_nontemporal_store((unsigned long long)__double_as_longlong(r.x2), p + 1);
+        __builtin_nontemporal_store(((unsigned long long)r.n_cls << 32) | r.mm, p + 2);
+    } else {
+        p[0] = (unsigned long long)__double_as_longlong(r.x1);
+        p[1] = (unsigned long long)__double_as_longlong(r.x2);
+        p[2] = ((unsigned long long)r.n_cls << 32) | r.mm;
+    }
 }
 
 // exp(x) > T  in x-space: 1 pass, 0 fail, 2 ambiguous
@@ -654,6 +663,7 @@ __device__ __forceinline__ uint32_t band_test(double x, const Band& b) { return 
 
 // The tail of compute_overlap + the 3-way class of process_overlaps for one candidate whose sub-overlap
 // results are known: mismatch_rate = max of the two (:254), class in x-space (:404-413), result record.
+template <bool STREAM = true>
 __device__ __forceinline__ hc_result_rec classify_and_store(const ScoreParams& prm, int ns, const SubScore& s1, const SubScore& s2,
                                                             uint64_t i, hc_result_rec* __restrict__ out) {
     hc_result_rec res;
@@ -693,7 +703,7 @@ __device__ __forceinline__ hc_result_rec classify_and_store(const ScoreParams& p
     res.x2 = s2.x;
     res.mm = mm;
     res.n_cls = (nn & 0x0FFFFFFFu) | (cls << 28);
-    store_result(out, i, res);
+    store_result<STREAM>(out, i, res);
     return res;
 }
 
@@ -1065,7 +1075,6 @@ __device__ __forceinline__ uint32_t length_class(uint32_t chunks) {  // 0..15 ex
 // finish last are finishing short ones.  Results go back to the candidate's own place (out[i] <-> in[i]).
 // One 1 024-lane workgroup per tile, 4 slots per lane.  perm_in: an earlier permutation to compose with (hc_set_reorder) or nullptr.
 constexpr uint32_t kBucketTile = 4096;
-constexpr uint32_t kGroupsPerTile = kBucketTile / 64;
 template <int SB>
 __global__ __launch_bounds__(1024) void bucket_perm_kernel(StoreView st, uint32_t min_read_len, uint32_t fmt, const void* __restrict__ in, uint64_t n,
                                                            const unsigned long long* __restrict__ n_dev, const uint32_t* __restrict__ perm_in,
@@ -1137,8 +1146,8 @@ template <typename SymT, int LG, int WG, bool SORT, bool DYN, int DEPTH = 1>
 __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 2 : 1))) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                             const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
                                                             const uint32_t* __restrict__ perm, RowSink sink, uint32_t* __restrict__ queue) {
-    // DYN (length-bucketed launches, bucket_perm_kernel): the waves take groups of 64 ranks from `queue`, each wave at its
-    // own pace; n_hint = the launch's n, which the queue's geometry was laid out for (the device may know fewer records)
+    // DYN (length-bucketed launches, bucket_perm_kernel): the workgroup takes WG consecutive ranks of a tile from `queue`;
+    // n_hint = the launch's n, which the queue's geometry was laid out for (the device may know fewer records)
     const uint64_t n_hint = n;
     if (prm.n_dev) {
         const uint64_t nd = *prm.n_dev;
@@ -1150,7 +1159,10 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     load_log_table<SymT, LG>(lut_s, lut_g, lut_n, threadIdx.x, WG);
     uint32_t* scratch = (uint32_t*)(lut_s + lut_n);  // row append: [0..17]; segment mode: [24] the workgroup's row counter
     const uint32_t seg_counter = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(scratch + 24);
-    if (threadIdx.x == 0) scratch[24] = 0;
+    if (threadIdx.x == 0) {
+        scratch[24] = 0;
+        if (DYN) scratch[26] = atomicAdd(queue, 1u);  // the workgroup's first queue entry; [26], [27]: this iteration's and the next one's
+    }
     __syncthreads();
     // this wave's image (LDS byte address); the images start at a multiple of 1 KiB (the XOR swizzle needs whole 64-byte rows)
     const uint32_t stage_base = coop_stage_base(st.lut_bytes, WG);
@@ -1162,22 +1174,23 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     const uint32_t oob = (uint32_t)st.store_bytes;  // the first offset the descriptor's range check rejects (no wrap-around at +16)
     const uint32_t tid = threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * WG;
-    // DYN: queue entry q = group (q / n_tiles) of tile (q % n_tiles): group g of every tile before group g + 1 of any, i.e.
-    // the longest groups of the launch first.  The next entry is asked for before the current one is scored (one atomic per
-    // 64 candidates, its latency behind the group's work).
+    // DYN: queue entry q = piece (q / n_tiles) of tile (q % n_tiles), a piece being WG consecutive ranks — WG / 64 groups of
+    // neighbouring length, one per wave: piece p of every tile before piece p + 1 of any, i.e. the longest candidates of the launch
+    // first.  One atomic per workgroup and iteration, asked for before the current piece is scored and published in LDS behind it;
+    // the barrier that orders the two is the only one of the loop, and the waves reach it together because their groups are alike.
+    // (Round 3's first form queued groups per wave: 1.6 * 10^6 atomics on one address at C3's size, 2.5 x the plain launch on reads of
+    // 100..400 bp.)
     const uint32_t n_tiles = DYN ? (uint32_t)((n_hint + kBucketTile - 1) / kBucketTile) : 0u;
-    const uint32_t n_groups = n_tiles * kGroupsPerTile;
-    uint32_t q_next = 0;
-    if (DYN && (tid & 63u) == 0) q_next = atomicAdd(queue, 1u);
-    for (uint64_t block_base = (uint64_t)blockIdx.x * WG;; block_base += stride) {
+    const uint32_t n_pieces = n_tiles * (kBucketTile / WG);
+    uint32_t q_ahead = 0, iter = 0;
+    for (uint64_t block_base = (uint64_t)blockIdx.x * WG;; block_base += stride, ++iter) {
         uint64_t slot;
         if (DYN) {
-            const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_next);
-            if (q >= n_groups) break;
-            if ((tid & 63u) == 0) q_next = atomicAdd(queue, 1u);
-            const uint32_t grp = q / n_tiles, tile = q - grp * n_tiles;
-            slot = (uint64_t)tile * kBucketTile + grp * 64u + (tid & 63u);
-            if (slot - (tid & 63u) >= n) continue;  // wave-uniform: a group behind the end of the last tile
+            const uint32_t q = scratch[26 + (iter & 1u)];
+            if (q >= n_pieces) break;  // workgroup-uniform
+            if (tid == 0) q_ahead = atomicAdd(queue, 1u);
+            const uint32_t piece = q / n_tiles, tile = q - piece * n_tiles;
+            slot = (uint64_t)tile * kBucketTile + piece * WG + tid;  // (behind the end of the last tile: lanes without a candidate)
         } else {
             if (block_base >= n) break;
             slot = block_base + tid;
@@ -1274,18 +1287,22 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
                 res.x2 = __builtin_nan("");
                 res.mm = 1;
                 res.n_cls = 1u | ((ns == 0 ? HC_CLS_ERROR : HC_CLS_DROP) << 28);
-                store_result(out, i, res);
+                store_result<!DYN>(out, i, res);
             } else {
-                res = classify_and_store(prm, ns, s1, s2, i, out);
+                res = classify_and_store<!DYN>(prm, ns, s1, s2, i, out);
             }
         }
         if (sink.rows) {  // kernel-argument-uniform branch
-            if (DYN) append_rows_wave(sink, slot < n, res, i);
-            else if (sink.seg_count) append_rows_segment(sink, slot < n, res, i, seg_counter);
+            if (sink.seg_count) append_rows_segment(sink, slot < n, res, i, seg_counter);
+            else if (DYN) append_rows_wave(sink, slot < n, res, i);
             else append_rows_block(sink, slot < n, res, i, scratch);
         }
+        if (DYN) {
+            if (tid == 0) scratch[26 + ((iter + 1u) & 1u)] = q_ahead;
+            __syncthreads();
+        }
     }
-    if (!DYN && sink.rows && sink.seg_count) {  // kernel-argument-uniform: every wave of the workgroup leaves its loop and arrives here
+    if (sink.rows && sink.seg_count) {  // kernel-argument-uniform: every wave of the workgroup leaves its loop and arrives here
         __syncthreads();
         if (threadIdx.x == 0) sink.seg_count[blockIdx.x] = scratch[24];
     }
@@ -1415,7 +1432,9 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             per_cu = per_cu * (wg_c / 64) > 32 ? 32 / (wg_c / 64) : per_cu;
             size_t lds_launch = lds_c;
             static const int wg_per_cu = getenv("HC_COOP_WG_PER_CU") ? atoi(getenv("HC_COOP_WG_PER_CU")) : 0;  // experiment knob: fewer resident workgroups
-            const uint32_t want_per_cu = wg_per_cu > 0 ? (uint32_t)wg_per_cu : (st.long_rows && wg_c == 256 ? 2u : 0u);  // StoreView::long_rows
+            // 8 waves per CU: contig-length sequences (StoreView::long_rows) and every length-bucketed launch (measured on reads of
+            // 100..400, 150..1 500 and 150..6 000 bp: 0.233 / 0.348 / 0.629 ms against 0.260 / 0.435 / 0.841 with 16)
+            const uint32_t want_per_cu = wg_per_cu > 0 ? (uint32_t)wg_per_cu : ((st.long_rows || st.balance) && wg_c == 256 ? 2u : 0u);
             if (want_per_cu > 0 && want_per_cu < per_cu) {
                 per_cu = want_per_cu;
                 lds_launch = std::max(lds_c, (size_t)(160 * 1024) / (per_cu + 1) + 1024);  // LDS no other workgroup fits beside
@@ -1429,7 +1448,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             if (blocks_c > cap_c) blocks_c = cap_c;
             RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u};
             // the plain launches collect their rows in per-workgroup segments (RowSink); G = the launch's workgroups
-            const bool segmented = rows && seg_buf && seg_count && !bucketed && !lines_in;
+            const bool segmented = rows && seg_buf && seg_count && !lines_in;
             bool seg_on = false;
             auto use_segments = [&](uint64_t G) {
                 seg_on = segmented && G <= 4096;  // seg_count holds 4 096 counters (a larger grid only under HC_GRID_MULT)
@@ -1550,7 +1569,7 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
         if (coop && lds_c <= 160 * 1024) {
             uint32_t per_cu = (uint32_t)((160 * 1024) / lds_c);
             per_cu = per_cu * (wg_c / 64) > 32 ? 32 / (wg_c / 64) : per_cu;
-            if (st.long_rows && wg_c == 256 && per_cu > 2) per_cu = 2;
+            if ((st.long_rows || st.balance) && wg_c == 256 && per_cu > 2) per_cu = 2;
             const bool deep = st.balance && per_cu <= 2 && wg_c == 256;
             const uint32_t lgt = st.symbytes == 2 ? 5u : lg;
             char small[128];
