@@ -298,12 +298,23 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     // store layout (hc_device.h): a single read [fwd][rc]; a pair [/1 fwd][/2 fwd][/1 rc][/2 rc]
     std::vector<uint64_t> sym_off(n_seq ? n_seq : 1);
     std::vector<uint32_t> rc_delta(n_seq ? n_seq : 1);
+    // slots on 128-byte lines while the store stays inside the Infinity Cache (256 MB), else packed (hc_device.h: slot_stride)
+    uint32_t slot_align = 128;
+    {
+        uint64_t aligned_bytes = 0;
+        for (uint32_t q = 0; q < n_seq; q++) aligned_bytes += 2 * hc::slot_stride(seq_len[q], symbytes, 128) * symbytes;
+        if (aligned_bytes > (256ull << 20)) slot_align = 16;
+        if (const char* v = getenv("HC_SLOT_ALIGN")) {  // tuning knob: 16, 32, 64, 128, 256
+            const int a = atoi(v);
+            if (a >= 16 && a <= 4096 && (a & (a - 1)) == 0) slot_align = (uint32_t)a;
+        }
+    }
     uint64_t nsym = 0;
     for (uint32_t r = 0; r < n_reads; r++) {
         const uint32_t q = read_first_seq[r];
-        const uint64_t s1 = hc::slot_stride(seq_len[q], symbytes);
+        const uint64_t s1 = hc::slot_stride(seq_len[q], symbytes, slot_align);
         if (read_first_seq[r + 1] - q == 2) {
-            const uint64_t s2 = hc::slot_stride(seq_len[q + 1], symbytes);
+            const uint64_t s2 = hc::slot_stride(seq_len[q + 1], symbytes, slot_align);
             sym_off[q] = nsym;
             sym_off[q + 1] = nsym + s1;
             rc_delta[q] = rc_delta[q + 1] = (uint32_t)(s1 + s2);
@@ -351,7 +362,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     HC_HIP(hipMemcpyAsync(d_first, read_first_seq, sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, c->stream));
     HC_HIP(hipMemcpyAsync(c->d_lut, lut.data(), sizeof(double) * lut.size(), hipMemcpyHostToDevice, c->stream));
     HC_HIP(hc::launch_encode(symbytes, d_bases, d_quals, d_raw_off, d_seq_off, (const uint32_t*)t_rc_delta.p, d_qmap, n_seq, K, c->d_sym, d_seq_bad,
-                             d_first, n_reads, c->d_reads, c->stream));
+                             d_first, n_reads, c->d_reads, slot_align, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
 
     {  // SFO ids: singles, then every /1 mate, then every /2 mate (s_p1_p2.fasta, savage.py:643-664)
@@ -396,7 +407,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         if (const char* v = getenv("HC_REGULAR_STORE")) c->view.regular = c->view.regular && atoi(v) != 0;  // test / tuning knob: 0 forces look-ups
         c->view.ulen = same_len ? seq_len[0] : 0u;
         c->view.n_single = n_single;
-        c->view.seq_syms = same_len ? (uint32_t)(2 * hc::slot_stride(seq_len[0], symbytes)) : 0u;
+        c->view.seq_syms = same_len ? (uint32_t)(2 * hc::slot_stride(seq_len[0], symbytes, slot_align)) : 0u;
     }
     c->have_reads = true;
     {

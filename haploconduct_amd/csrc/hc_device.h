@@ -40,15 +40,14 @@ constexpr uint32_t kReadBadBase1 = 2u;  // sequence /1 (or the single) holds a b
 constexpr uint32_t kReadBadBase2 = 4u;  // build_rev_comp exits when it is reverse-complemented (Types.h:124-127)
 
 // slot stride in SYMBOLS for a sequence of `len` symbols of `symbytes` bytes each: the symbols, N padding to a multiple
-// of 16 bytes plus 32 bytes, rounded up to kSlotAlign bytes
-#ifndef HC_SLOT_ALIGN
-#define HC_SLOT_ALIGN 16
-#endif
-constexpr uint32_t kSlotAlign = HC_SLOT_ALIGN;
-__host__ __device__ inline uint64_t slot_stride(uint32_t len, uint32_t symbytes) {
+// of 16 bytes plus 32 bytes, rounded up to `align` bytes (a power of two >= 16; chosen per read set by hc_set_reads:
+// slots that start on a 128-byte line put a partner read's window — the slot's first L symbols — into the fewest lines,
+// worth 3 - 4 % on sets whose store stays inside the Infinity Cache; the 10^8-candidate set with its 384 MB store loses
+// 9 % to the third more memory)
+__host__ __device__ inline uint64_t slot_stride(uint32_t len, uint32_t symbytes, uint32_t align) {
     uint64_t bytes = (uint64_t)len * symbytes;
     bytes = ((bytes + 15) & ~(uint64_t)15) + 32;
-    bytes = (bytes + kSlotAlign - 1) & ~(uint64_t)(kSlotAlign - 1);
+    bytes = (bytes + align - 1) & ~(uint64_t)(align - 1);
     return bytes / symbytes;
 }
 

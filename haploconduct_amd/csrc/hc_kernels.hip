@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                                                            const uint32_t* __restrict__ rc_delta,  // [n_seq] fwd slot -> rc slot
                                                            const uint8_t* __restrict__ qmap,  // [256] byte -> qidx, 255 = invalid
                                                            uint32_t n_seq, uint32_t K, SymT* __restrict__ sym,
-                                                           uint8_t* __restrict__ seq_bad) {
+                                                           uint8_t* __restrict__ seq_bad, uint32_t slot_align) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
         const uint64_t r0 = raw_off[q];
         const uint32_t len = (uint32_t)(raw_off[q + 1] - r0);
         const uint64_t f0 = seq_off[q];
-        const uint64_t stride = slot_stride(len, sizeof(SymT));  // symbols of one slot (sequence + N padding)
+        const uint64_t stride = slot_stride(len, sizeof(SymT), slot_align);  // symbols of one slot (sequence + N padding)
         const uint64_t rc0 = f0 + rc_delta[q];
         uint32_t bad = 0;
         for (uint32_t i = lane; i < (uint32_t)stride; i += 64) {
@@ -1166,7 +1166,9 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     __syncthreads();
     // this wave's image (LDS byte address); the images start at a multiple of 1 KiB (the XOR swizzle needs whole 64-byte rows)
     const uint32_t stage_base = coop_stage_base(st.lut_bytes, WG);
-    const uint32_t stage = stage_base + (threadIdx.x >> 6) * (DEPTH == 0 ? 2u * kStageBytesPerWave : kStageBytesPerWave);  // DEPTH 0: LDS-DMA, A and B images
+    // (wave-uniform, and told so: the LDS-DMA form's M0 values and every image address + constant are then scalar work)
+    const uint32_t stage = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(stage_base + (threadIdx.x >> 6) * (DEPTH == 0 ? 2u * kStageBytesPerWave : kStageBytesPerWave)));  // DEPTH 0: LDS-DMA, A and B images
     const SymT* sym = (const SymT*)st.sym;
     const uint32_t Kp = st.K + 2u;
     const uint32_t fmt = prm.rec_fmt;
@@ -1332,7 +1334,7 @@ __global__ __launch_bounds__(512, 4) void score_kernel_wide_wg(StoreView st, Sco
 // Launch wrappers (called from hc_api.cpp).
 hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t* quals, const uint64_t* raw_off,
                          const uint64_t* seq_off, const uint32_t* rc_delta, const uint8_t* qmap, uint32_t n_seq, uint32_t K, void* sym,
-                         uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs,
+                         uint8_t* seq_bad, const uint32_t* read_first_seq, uint32_t n_reads, ReadDesc* descs, uint32_t slot_align,
                          hipStream_t stream) {
     if (n_seq == 0) return hipSuccess;
     const uint32_t waves_per_block = 4;
@@ -1340,13 +1342,13 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
     if (blocks > 65536) blocks = 65536;
     if (symbytes == 1 && lut_lg(K) == 6)
         hipLaunchKernelGGL((encode_store_kernel<uint8_t, true>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
-                           seq_off, rc_delta, qmap, n_seq, K, (uint8_t*)sym, seq_bad);
+                           seq_off, rc_delta, qmap, n_seq, K, (uint8_t*)sym, seq_bad, slot_align);
     else if (symbytes == 1)
         hipLaunchKernelGGL((encode_store_kernel<uint8_t, false>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
-                           seq_off, rc_delta, qmap, n_seq, K, (uint8_t*)sym, seq_bad);
+                           seq_off, rc_delta, qmap, n_seq, K, (uint8_t*)sym, seq_bad, slot_align);
     else
         hipLaunchKernelGGL((encode_store_kernel<uint16_t, false>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
-                           seq_off, rc_delta, qmap, n_seq, K, (uint16_t*)sym, seq_bad);
+                           seq_off, rc_delta, qmap, n_seq, K, (uint16_t*)sym, seq_bad, slot_align);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (n_reads)
