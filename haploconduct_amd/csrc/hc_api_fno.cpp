@@ -7,11 +7,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/hcedge.h"
 #include "hc_fno_device.h"
 #include "hc_overlap_finder.h"
+#include "hc_prims.h"
 #include "host/Types.h"
 
 namespace hc {
@@ -20,7 +22,17 @@ namespace {
 struct DeviceBuffers {  // freed on every way out
     std::vector<void*> all;
     ~DeviceBuffers() {
-        for (void* p : all) (void)hipFree(p);
+        for (void* p : all)
+            if (p) (void)hipFree(p);
+    }
+    void release(void* p) {  // early, for buffers that are spent
+        if (!p) return;
+        for (void*& q : all)
+            if (q == p) {
+                (void)hipFree(p);
+                q = nullptr;
+                return;
+            }
     }
     template <typename T>
     T* get(uint64_t count) {
@@ -50,13 +62,13 @@ bool fno_device_wanted(uint64_t n_items) {
     return forced || n_items >= 200000;
 }
 
-bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of,
-                         uint64_t counters[5], double* seconds) {
+namespace {
+
+// the second half from items that already sit on the device: computeOverlapData, the four stable sorts, unique, scan, text
+bool lines_from_device_items(DeviceBuffers& d, const FnoItem* d_items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of,
+                             uint64_t counters[5], double* seconds, std::chrono::steady_clock::time_point t0) {
     auto now = [] { return std::chrono::steady_clock::now(); };
-    const auto t0 = now();
     hipStream_t st = nullptr;  // the default stream of the calling thread's device
-    DeviceBuffers d;
-    FnoItem* d_items = d.get<FnoItem>(n);
     FnoRec* d_rec = d.get<FnoRec>(n);
     uint64_t* d_k[4];
     for (auto& k : d_k) k = d.get<uint64_t>(n);
@@ -68,7 +80,6 @@ bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, c
     hip_check(finder_scan(nullptr, scan_bytes, d_ka, d_kb, n + 1, st), "scan size");
     tmp_bytes = std::max(tmp_bytes, scan_bytes);
     void* d_tmp = d.get<char>(tmp_bytes);
-    hip_check(hipMemcpyAsync(d_items, items, n * sizeof(FnoItem), hipMemcpyHostToDevice, st), "copy of the combinations");
     hip_check(hipMemsetAsync(d_counters, 0, kFnoCounters * sizeof(unsigned long long), st), "memset");
     hip_check(fno_deduce(d_items, n, no_inclusions ? 1u : 0u, d_rec, d_k[0], d_k[1], d_k[2], d_k[3], d_pa, d_counters, st), "deduce");
     // least significant 64 bits first; every sort is stable
@@ -95,6 +106,7 @@ bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, c
     hip_check(hipStreamSynchronize(st), "synchronize");
     if (h_counters[4]) return false;
     const auto t1 = now();
+    for (auto& k : d_k) d.release(k);  // the keys are spent: room for the text
     char* d_text = d.get<char>(total_bytes);
     hip_check(fno_format(d_rec, perm, d_ka, d_kb, n, d_text, st), "format");
     char* h_text = text_of(total_bytes);
@@ -106,6 +118,137 @@ bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, c
         seconds[1] = std::chrono::duration<double>(now() - t1).count();
     }
     return true;
+}
+
+}  // namespace
+
+bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of,
+                         uint64_t counters[5], double* seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    DeviceBuffers d;
+    FnoItem* d_items = d.get<FnoItem>(n);
+    hip_check(hipMemcpyAsync(d_items, items, n * sizeof(FnoItem), hipMemcpyHostToDevice, nullptr), "copy of the combinations");
+    return lines_from_device_items(d, d_items, n, no_inclusions, text_of, counters, seconds, t0);
+}
+
+// FNO=1 whole: the walk (updateOverlap's case analysis, the first combination per pair of new ids), the look-ups, then the second
+// half above.  false: the device met something the host path has to report or to handle; nothing was written.
+bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_t)>& text_of, uint64_t counters[5], uint64_t* n_items_out,
+                         double* seconds) {
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
+    hipStream_t st = nullptr;
+    uint64_t E = 0;
+    for (uint32_t k = 0; k < h.n_spans; k++) E += h.spans[k].n;
+    if (E == 0 || E >= 0x7FFFFFF0ull || h.n_srs >= 0xFFFFFFFFull) return false;
+    uint32_t id_bits = 1;
+    while (id_bits < 64 && (h.new_read_count - 1) >> id_bits) id_bits++;
+    if (h.new_read_count == 0 || 2 * id_bits > 62) return false;
+    DeviceBuffers d;
+    FnoWalkInput w{};
+    {
+        hc_fno_edge* d_edges = d.get<hc_fno_edge>(E);
+        uint64_t at = 0;
+        for (uint32_t k = 0; k < h.n_spans; k++) {
+            if (h.spans[k].n) hip_check(hipMemcpyAsync(d_edges + at, h.spans[k].p, h.spans[k].n * sizeof(hc_fno_edge), hipMemcpyHostToDevice, st), "copy of the edges");
+            at += h.spans[k].n;
+        }
+        w.edges = d_edges;
+        w.n_edges = E;
+    }
+    auto upload = [&](auto* dst_tag, const void* src, uint64_t count, const char* what) {
+        using T = std::remove_pointer_t<decltype(dst_tag)>;
+        T* p = d.get<T>(count);
+        if (count) hip_check(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st), what);
+        return (const T*)p;
+    };
+    w.nodes = upload((hc_fno_read*)nullptr, h.nodes, h.n_nodes, "copy of the vertices");
+    w.n_nodes = h.n_nodes;
+    w.srs = upload((hc_fno_read*)nullptr, h.srs, h.n_srs, "copy of the super-reads");
+    w.n_srs = h.n_srs;
+    w.n2s_off = upload((uint64_t*)nullptr, h.n2s_off, h.n_nodes + 1, "copy of nodes_to_SR");
+    w.n2s = upload((uint32_t*)nullptr, h.n2s, h.n2s_off[h.n_nodes], "copy of nodes_to_SR");
+    w.subread_off = upload((uint64_t*)nullptr, h.subread_off, h.n_srs + 1, "copy of the subread maps");
+    w.subreads = upload((hc_fno_subread*)nullptr, h.subreads, h.n_srs ? h.subread_off[h.n_srs] : 0, "copy of the subread maps");
+    w.new_read_count = h.new_read_count;
+    w.id_bits = id_bits;
+    w.resolve_orientations = h.resolve_orientations ? 1u : 0u;
+
+    unsigned long long* d_status = d.get<unsigned long long>(kFnoCounters);
+    hip_check(hipMemsetAsync(d_status, 0, kFnoCounters * sizeof(unsigned long long), st), "memset");
+    uint64_t *d_off_comb = d.get<uint64_t>(E + 1), *d_off_direct = d.get<uint64_t>(E + 1);
+    hip_check(fno_walk_count(w, d_off_comb, d_off_direct, d_status, st), "count");
+    size_t scan_bytes = 0;
+    hip_check(finder_scan(nullptr, scan_bytes, d_off_comb, d_off_comb, E + 1, st), "scan size");
+    void* d_scan_tmp = d.get<char>(scan_bytes);
+    {
+        size_t b = scan_bytes;
+        hip_check(finder_scan(d_scan_tmp, b, d_off_comb, d_off_comb, E + 1, st), "scan");
+        b = scan_bytes;
+        hip_check(finder_scan(d_scan_tmp, b, d_off_direct, d_off_direct, E + 1, st), "scan");
+    }
+    uint64_t n_comb = 0, n_direct = 0;
+    unsigned long long h_status[kFnoCounters];
+    hip_check(hipMemcpyAsync(&n_comb, d_off_comb + E, 8, hipMemcpyDeviceToHost, st), "count of the combinations");
+    hip_check(hipMemcpyAsync(&n_direct, d_off_direct + E, 8, hipMemcpyDeviceToHost, st), "count of the copied edges");
+    hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
+    hip_check(hipStreamSynchronize(st), "synchronize");
+    if (h_status[4] || n_comb >= 0x7FFFFFF0ull || n_direct + n_comb >= 0x7FFFFFF0ull) return false;
+
+    uint32_t* d_val_sorted = nullptr;
+    uint32_t* d_head_pos = nullptr;
+    uint64_t n_heads = 0;
+    if (n_comb) {
+        uint64_t *d_key = d.get<uint64_t>(n_comb), *d_key_sorted = d.get<uint64_t>(n_comb);
+        uint32_t* d_iota = d.get<uint32_t>(n_comb);
+        d_val_sorted = d.get<uint32_t>(n_comb);
+        hip_check(fno_walk_expand(w, d_off_comb, n_comb, d_key, d_iota, d_status, st), "expand");
+        size_t sort_bytes = 0;
+        hip_check(sort_pairs_u64_u32(nullptr, sort_bytes, d_key, d_key_sorted, d_iota, d_val_sorted, (uint32_t)n_comb, 64, st), "sort size");
+        const size_t sel_bytes = prims::select_temp_bytes(n_comb);
+        void* d_tmp = d.get<char>(std::max(sort_bytes, sel_bytes));
+        size_t b = sort_bytes;
+        hip_check(sort_pairs_u64_u32(d_tmp, b, d_key, d_key_sorted, d_iota, d_val_sorted, (uint32_t)n_comb, (int)(2 * id_bits), st), "sort");
+        uint8_t* d_flag = d.get<uint8_t>(n_comb);
+        hip_check(fno_walk_heads(d_key_sorted, n_comb, d_flag, st), "heads");
+        d_head_pos = d.get<uint32_t>(n_comb);
+        hip_check(prims::select_flagged(d_tmp, sel_bytes, d_flag, n_comb, d_head_pos, d_status + 5, st), "select");
+        hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
+        hip_check(hipStreamSynchronize(st), "synchronize");
+        if (h_status[4]) return false;
+        n_heads = h_status[5];
+        d.release(d_key);
+        d.release(d_key_sorted);
+        d.release(d_iota);
+        d.release(d_flag);
+        d.release(d_tmp);
+    }
+    const uint64_t n_items = n_direct + n_heads;
+    if (n_items == 0) return false;  // (nothing to write: the host form says so in its own way)
+    uint32_t* d_direct_edge = d.get<uint32_t>(n_direct);
+    hip_check(fno_walk_direct(d_off_direct, E, d_direct_edge, st), "copied edges");
+    FnoItem* d_items = d.get<FnoItem>(n_items);
+    hip_check(fno_walk_items(w, d_off_comb, d_direct_edge, n_direct, d_val_sorted, d_head_pos, n_heads, d_items, d_status, st), "items");
+    hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
+    hip_check(hipStreamSynchronize(st), "synchronize");
+    if (h_status[4]) return false;
+    // the walk's inputs are spent
+    d.release((void*)w.edges);
+    d.release(d_off_comb);
+    d.release(d_off_direct);
+    d.release(d_val_sorted);
+    d.release(d_head_pos);
+    d.release(d_direct_edge);
+    if (n_items_out) *n_items_out = n_items;
+    const auto t1 = now();
+    double sec2[2] = {0, 0};
+    const bool ok = lines_from_device_items(d, d_items, n_items, h.no_inclusions, text_of, counters, sec2, t1);
+    if (seconds) {
+        seconds[0] = std::chrono::duration<double>(t1 - t0).count();
+        seconds[1] = sec2[0];
+        seconds[2] = sec2[1];
+    }
+    return ok;
 }
 
 bool fno3_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of, uint64_t* n_lines,

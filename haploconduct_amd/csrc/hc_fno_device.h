@@ -10,6 +10,7 @@
 
 #include <cstdint>
 
+#include "../../include/hcfno.h"
 #include "hc_fno_items.h"
 
 namespace hc {
@@ -27,6 +28,32 @@ hipError_t fno_gather_keys(const uint64_t* key, const uint32_t* perm, uint64_t n
 // len[i] = bytes (with the newline) of the line at sorted place i if it is the first of its run of equal lines, else 0; len[n] = 0
 hipError_t fno_mark_lines(const FnoRec* rec, const uint32_t* perm, uint64_t n, uint64_t* len, unsigned long long* counters, hipStream_t s);
 hipError_t fno_format(const FnoRec* rec, const uint32_t* perm, const uint64_t* len, const uint64_t* off, uint64_t n, char* text, hipStream_t s);
+// ---- the walk of FNO=1 on the device (hc_fno_kernels.hip) ---------------------------------------------------------------------
+struct FnoWalkInput {  // device pointers
+    const hc_fno_edge* edges;  // every edge updateOverlap is called on, in the reference's order
+    uint64_t n_edges;
+    const hc_fno_read* nodes;
+    uint64_t n_nodes;
+    const hc_fno_read* srs;
+    uint64_t n_srs;
+    const uint64_t* n2s_off;  // nodes_to_SR as CSR (:893-906)
+    const uint32_t* n2s;
+    const uint64_t* subread_off;
+    const hc_fno_subread* subreads;  // of every super-read, sorted by node
+    uint64_t new_read_count;
+    uint32_t id_bits;  // ids < new_read_count < 2^id_bits; a pair's key is lo << id_bits | hi
+    uint32_t resolve_orientations;
+};
+// cnt_*[i], i <= n_edges ([n_edges] = 0): combinations / copied items of edge i
+hipError_t fno_walk_count(const FnoWalkInput& w, uint64_t* cnt_comb, uint64_t* cnt_direct, unsigned long long* counters, hipStream_t s);
+// key[c] = the unordered pair of new ids of combination c (walk order), ~0 for a skipped one; iota[c] = c
+hipError_t fno_walk_expand(const FnoWalkInput& w, const uint64_t* off_comb, uint64_t n_comb, uint64_t* key, uint32_t* iota, unsigned long long* counters,
+                           hipStream_t s);
+hipError_t fno_walk_heads(const uint64_t* key_sorted, uint64_t n_comb, uint8_t* flag, hipStream_t s);  // first of every run of equal pairs
+hipError_t fno_walk_direct(const uint64_t* off_direct, uint64_t n_edges, uint32_t* direct_edge, hipStream_t s);
+hipError_t fno_walk_items(const FnoWalkInput& w, const uint64_t* off_comb, const uint32_t* direct_edge, uint64_t n_direct, const uint32_t* val_sorted,
+                          const uint32_t* head_pos, uint64_t n_heads, FnoItem* items, unsigned long long* counters, hipStream_t s);
+
 // FNO=3: deduceOverlap per candidate pair (in walk order); len[i] = bytes of its line (0: no line), len[n] = 0; counters[4] status
 // bits, counters[5] lines.  Then the text at off[i] (the exclusive scan of len).
 struct Fno3Rec {

@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <functional>
 
+#include "../../include/hcfno.h"
+
 namespace hc {
 
 // One combination, everything the arithmetic needs already looked up (host: ids, lengths, findCliqueIndex offsets).
@@ -33,6 +35,31 @@ bool fno_device_wanted(uint64_t n_items);
 // text_of was not called.  seconds[0..1] (may be null): copy + deduce + sorts + unique + scan, text.
 bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of,
                          uint64_t counters[5], double* seconds);
+
+// FNO=1 whole on the device.  The edges updateOverlap is called on, in the reference's order, as spans of host memory (adj_out,
+// branching_edges, the kept non-edges, the inclusion-induced edges); nodes_to_SR as CSR; every super-read's subreads sorted by node.
+struct FnoEdgeSpan {
+    const hc_fno_edge* p;
+    uint64_t n;
+};
+struct FnoWalkHost {
+    const FnoEdgeSpan* spans;
+    uint32_t n_spans;
+    const hc_fno_read* nodes;
+    uint64_t n_nodes;
+    const hc_fno_read* srs;
+    uint64_t n_srs;
+    const uint64_t* n2s_off;
+    const uint32_t* n2s;
+    const uint64_t* subread_off;
+    const hc_fno_subread* subreads;
+    uint64_t new_read_count;
+    bool resolve_orientations, no_inclusions;
+};
+// counters as fno_lines_on_device; *n_items: combinations kept (copied edges + first combination per pair); seconds[0..2] (may be
+// null): copies + walk + look-ups, deduce + sorts + unique + scan, text.  false: something the host form has to report or handle.
+bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_t)>& text_of, uint64_t counters[5], uint64_t* n_items,
+                         double* seconds);
 
 // FNO=3 (src/FindNextOverlaps3.cpp:176-406, deduceOverlap): one candidate pair of super-reads that share an original read,
 // everything looked up on the host —

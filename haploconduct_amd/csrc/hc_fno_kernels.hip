@@ -425,6 +425,205 @@ __global__ __launch_bounds__(kBlock) void fno3_format_kernel(const Fno3Rec* __re
     for (int k = 0; k < m; k++) dst[k] = line[k];
 }
 
+// ---- the walk of FNO=1 (src/FindNextOverlaps.cpp:25-349, 612-630, 891-935) -----------------------------------------------------
+// updateOverlap's case analysis per edge in walk order: an edge between two unmerged vertices is copied (one "direct" item); an
+// edge with a merged end stands for one combination per super-read holding that end (both ends merged: per pair of super-reads),
+// and of the combinations of one unordered pair of new ids the reference keeps the FIRST it meets (overlaps_found).  Here:
+// count per edge, scan, one lane per combination writes the pair as a sort key — combinations are numbered in walk order, so a
+// STABLE sort by pair puts the first met in front of its run — the heads of the runs are the kept ones.
+__device__ __forceinline__ uint64_t n2s_count(const FnoWalkInput& w, uint64_t v) { return w.n2s_off[v + 1] - w.n2s_off[v]; }
+
+__global__ __launch_bounds__(kBlock) void fno_walk_count_kernel(FnoWalkInput w, uint64_t* __restrict__ cnt_comb, uint64_t* __restrict__ cnt_direct,
+                                                                unsigned long long* __restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i > w.n_edges) return;
+    uint64_t comb = 0, direct = 0;
+    if (i < w.n_edges) {
+        const uint64_t u = w.edges[i].v1, v = w.edges[i].v2;
+        if (u >= w.n_nodes || v >= w.n_nodes) {
+            atomicOr(&counters[4], (unsigned long long)kFnoStatusRequire);  // "edge vertex out of range"
+        } else {
+            const bool vu = w.nodes[u].visited != 0, vv = w.nodes[v].visited != 0;
+            if (!vu && !vv) direct = 1;
+            else if (!vu) comb = n2s_count(w, v);
+            else if (!vv) comb = n2s_count(w, u);
+            else {
+                comb = n2s_count(w, u) * n2s_count(w, v);
+                if (comb >= 0xFFFFFFFFull) {  // the host path's "too many super-reads share one vertex"
+                    atomicOr(&counters[4], (unsigned long long)kFnoStatusRange);
+                    comb = 0;
+                }
+            }
+        }
+    }
+    cnt_comb[i] = comb;  // [n_edges] = 0: the scans' totals
+    cnt_direct[i] = direct;
+}
+
+// the edge a combination belongs to: the last i with off[i] <= c (off is the exclusive scan of the counts, off[n] = total)
+__device__ __forceinline__ uint64_t edge_of(const uint64_t* __restrict__ off, uint64_t n, uint64_t c) {
+    uint64_t lo = 0, hi = n;  // off[lo] <= c < off[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= c) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+struct Combination {
+    uint64_t edge;
+    uint32_t sr1, sr2;
+    uint64_t id1, id2;
+    uint8_t kind;  // 1 u2sr, 2 v2sr, 3 sr2sr
+};
+__device__ __forceinline__ Combination combination(const FnoWalkInput& w, const uint64_t* __restrict__ off_comb, uint64_t c) {
+    Combination k;
+    k.edge = edge_of(off_comb, w.n_edges, c);
+    const uint64_t nth = c - off_comb[k.edge];
+    const uint64_t u = w.edges[k.edge].v1, v = w.edges[k.edge].v2;
+    const bool vu = w.nodes[u].visited != 0;
+    const bool vv = w.nodes[v].visited != 0;
+    k.sr1 = k.sr2 = 0;
+    if (!vu) {  // :69-150
+        k.kind = 1;
+        k.sr2 = w.n2s[w.n2s_off[v] + nth];
+        k.id1 = w.nodes[u].id;
+        k.id2 = w.srs[k.sr2].id;
+    } else if (!vv) {  // :151-230
+        k.kind = 2;
+        k.sr1 = w.n2s[w.n2s_off[u] + nth];
+        k.id1 = w.nodes[v].id;
+        k.id2 = w.srs[k.sr1].id;
+    } else {  // :231-349
+        k.kind = 3;
+        const uint64_t n2 = n2s_count(w, v);
+        k.sr1 = w.n2s[w.n2s_off[u] + nth / n2];
+        k.sr2 = w.n2s[w.n2s_off[v] + nth % n2];
+        k.id1 = w.srs[k.sr1].id;
+        k.id2 = w.srs[k.sr2].id;
+    }
+    return k;
+}
+
+__global__ __launch_bounds__(kBlock) void fno_walk_expand_kernel(FnoWalkInput w, const uint64_t* __restrict__ off_comb, uint64_t n_comb,
+                                                                 uint64_t* __restrict__ key, uint32_t* __restrict__ iota,
+                                                                 unsigned long long* __restrict__ counters) {
+    const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= n_comb) return;
+    const Combination k = combination(w, off_comb, c);
+    uint64_t out = ~0ull;  // sr2sr of one super-read with itself: skipped (:246), sorts behind every pair
+    if (k.id1 == k.id2) {
+        if (k.kind != 3) atomicOr(&counters[4], (unsigned long long)kFnoStatusRequire);  // assert(id1 != id2)
+    } else {
+        const uint64_t lo = k.id1 < k.id2 ? k.id1 : k.id2, hi = k.id1 < k.id2 ? k.id2 : k.id1;
+        if (hi >= w.new_read_count) atomicOr(&counters[4], (unsigned long long)kFnoStatusRequire);  // overlaps_found.at(id)
+        else out = lo << w.id_bits | hi;
+    }
+    key[c] = out;
+    iota[c] = (uint32_t)c;
+}
+
+__global__ __launch_bounds__(kBlock) void fno_walk_heads_kernel(const uint64_t* __restrict__ key_sorted, uint64_t n_comb, uint8_t* __restrict__ flag) {
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_comb) return;
+    const uint64_t k = key_sorted[j];
+    flag[j] = (k != ~0ull && (j == 0 || key_sorted[j - 1] != k)) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void fno_walk_direct_kernel(const uint64_t* __restrict__ off_direct, uint64_t n_edges, uint32_t* __restrict__ direct_edge) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_edges) return;
+    if (off_direct[i + 1] != off_direct[i]) direct_edge[off_direct[i]] = (uint32_t)i;
+}
+
+// the pair of findCliqueIndex calls of :95-109 etc.: start offsets of `node` inside super-read `sr` (its subreads sorted by node)
+__device__ __forceinline__ bool clique_indices(const FnoWalkInput& w, uint64_t node, uint32_t sr, bool read_paired, int& left, int& right) {
+    uint64_t lo = w.subread_off[sr], hi = w.subread_off[sr + 1];
+    if (lo == hi) return false;  // assert(!subreadMap.empty())
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (w.subreads[mid].node <= node) lo = mid;
+        else hi = mid;
+    }
+    const hc_fno_subread s = w.subreads[lo];
+    if (s.node != node) return false;  // subreadMap.at(node)
+    if (!(s.index1 >= 0 && s.startpos1 >= 0) || (s.index1 > 0 && s.startpos1 > 0)) return false;
+    left = s.index1 - s.startpos1;
+    const bool sr_paired = w.srs[sr].paired != 0;
+    if (!sr_paired && !read_paired) {
+        right = left;
+        return true;
+    }
+    if (!(s.index2 >= 0 && s.startpos2 >= 0)) return false;
+    if (sr_paired && s.index2 > 0 && s.startpos2 > 0) return false;
+    right = s.index2 - s.startpos2;
+    return true;
+}
+
+// One item per kept combination, everything computeOverlapData needs looked up (the host form's build_item):
+// items [0, n_direct) are the copied edges, the others the heads of the sorted runs.
+__global__ __launch_bounds__(kBlock) void fno_walk_items_kernel(FnoWalkInput w, const uint64_t* __restrict__ off_comb, const uint32_t* __restrict__ direct_edge,
+                                                                uint64_t n_direct, const uint32_t* __restrict__ val_sorted,
+                                                                const uint32_t* __restrict__ head_pos, uint64_t n_heads, FnoItem* __restrict__ items,
+                                                                unsigned long long* __restrict__ counters) {
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_direct + n_heads) return;
+    FnoItem o;
+    for (int k = 0; k < 10; ++k) o.v[k] = 0;
+    o.pad[0] = o.pad[1] = 0;
+    bool ok = true;
+    Combination c;
+    if (t < n_direct) {
+        c.edge = direct_edge[t];
+        c.kind = 0;
+        c.sr1 = c.sr2 = 0;
+    } else {
+        c = combination(w, off_comb, val_sorted[head_pos[t - n_direct]]);
+    }
+    const hc_fno_edge e = w.edges[c.edge];
+    const hc_fno_read n1 = w.nodes[e.v1], n2 = w.nodes[e.v2];
+    o.ori1 = o.ori2 = '+';
+    if (w.resolve_orientations && e.score == 0) {  // :35-38
+        o.ori1 = ((e.ori1 != 0) == (n1.orientation != 0)) ? '+' : '-';
+        o.ori2 = ((e.ori2 != 0) == (n2.orientation != 0)) ? '+' : '-';
+    }
+    o.kind = c.kind;
+    o.e_ord = e.ord;
+    if (c.kind == 0) {  // :44-68
+        ok = e.perc >= 0;
+        o.ida = n1.id;
+        o.idb = n2.id;
+        o.v[0] = e.pos1; o.v[1] = e.pos2; o.v[2] = e.perc; o.v[3] = e.len1; o.v[4] = e.len2;
+        o.a_paired = n1.paired != 0;
+        o.b_paired = n2.paired != 0;
+    } else {
+        int i1l = 0, i1r = 0, i2l = 0, i2r = 0;
+        hc_fno_read a, b;
+        if (c.kind == 1) {
+            a = n1;
+        } else {
+            a = w.srs[c.sr1];
+            ok = clique_indices(w, e.v1, c.sr1, n1.paired != 0, i1l, i1r) && ok;
+        }
+        if (c.kind == 2) {
+            b = n2;
+        } else {
+            b = w.srs[c.sr2];
+            ok = clique_indices(w, e.v2, c.sr2, n2.paired != 0, i2l, i2r) && ok;
+        }
+        o.ida = a.id;
+        o.idb = b.id;
+        o.v[0] = e.pos1; o.v[1] = e.pos2;
+        o.v[2] = i1l; o.v[3] = i1r; o.v[4] = i2l; o.v[5] = i2r;
+        o.v[6] = (int)a.len1; o.v[7] = (int)a.len2; o.v[8] = (int)b.len1; o.v[9] = (int)b.len2;
+        o.a_paired = a.paired != 0;
+        o.b_paired = b.paired != 0;
+    }
+    if (!ok) atomicOr(&counters[4], (unsigned long long)kFnoStatusRequire);
+    items[t] = o;
+}
+
 inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 }  // namespace
@@ -447,6 +646,34 @@ hipError_t fno_mark_lines(const FnoRec* rec, const uint32_t* perm, uint64_t n, u
 hipError_t fno_format(const FnoRec* rec, const uint32_t* perm, const uint64_t* len, const uint64_t* off, uint64_t n, char* text, hipStream_t s) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(fno_format_kernel, grid_for(n), dim3(kBlock), 0, s, rec, perm, len, off, n, text);
+    return hipGetLastError();
+}
+
+hipError_t fno_walk_count(const FnoWalkInput& w, uint64_t* cnt_comb, uint64_t* cnt_direct, unsigned long long* counters, hipStream_t s) {
+    hipLaunchKernelGGL(fno_walk_count_kernel, grid_for(w.n_edges + 1), dim3(kBlock), 0, s, w, cnt_comb, cnt_direct, counters);
+    return hipGetLastError();
+}
+hipError_t fno_walk_expand(const FnoWalkInput& w, const uint64_t* off_comb, uint64_t n_comb, uint64_t* key, uint32_t* iota, unsigned long long* counters,
+                           hipStream_t s) {
+    if (!n_comb) return hipSuccess;
+    hipLaunchKernelGGL(fno_walk_expand_kernel, grid_for(n_comb), dim3(kBlock), 0, s, w, off_comb, n_comb, key, iota, counters);
+    return hipGetLastError();
+}
+hipError_t fno_walk_heads(const uint64_t* key_sorted, uint64_t n_comb, uint8_t* flag, hipStream_t s) {
+    if (!n_comb) return hipSuccess;
+    hipLaunchKernelGGL(fno_walk_heads_kernel, grid_for(n_comb), dim3(kBlock), 0, s, key_sorted, n_comb, flag);
+    return hipGetLastError();
+}
+hipError_t fno_walk_direct(const uint64_t* off_direct, uint64_t n_edges, uint32_t* direct_edge, hipStream_t s) {
+    if (!n_edges) return hipSuccess;
+    hipLaunchKernelGGL(fno_walk_direct_kernel, grid_for(n_edges), dim3(kBlock), 0, s, off_direct, n_edges, direct_edge);
+    return hipGetLastError();
+}
+hipError_t fno_walk_items(const FnoWalkInput& w, const uint64_t* off_comb, const uint32_t* direct_edge, uint64_t n_direct, const uint32_t* val_sorted,
+                          const uint32_t* head_pos, uint64_t n_heads, FnoItem* items, unsigned long long* counters, hipStream_t s) {
+    if (!(n_direct + n_heads)) return hipSuccess;
+    hipLaunchKernelGGL(fno_walk_items_kernel, grid_for(n_direct + n_heads), dim3(kBlock), 0, s, w, off_comb, direct_edge, n_direct, val_sorted, head_pos,
+                       n_heads, items, counters);
     return hipGetLastError();
 }
 

@@ -39,7 +39,8 @@ int set_last_error(int status, const std::string& what);
 struct hc_fno_output {
     std::vector<char, hc::DefaultInitAllocator<char>> text;  // sized, then written in full: not zero-filled first
     hc_fno_counters counters;
-    bool on_device = false;
+    bool on_device = false;       // the arithmetic, the ordering and the text were the device's
+    bool walk_on_device = false;  // ... and the walk and the look-ups too (FNO=1)
 };
 
 namespace {
@@ -50,6 +51,15 @@ using hc::FatalError;
     do {               \
         if (!(c)) ref_abort(#c); \
     } while (0)
+
+// the output's text sized for the device's copy: fresh pages, 2 MiB ones where the system grants them (the copy of 0.4 GB into
+// untouched 4 KiB pages runs at 12 GB/s, a tenth of the pages' faults is most of that)
+char* sized_text(hc_fno_output& out, uint64_t bytes) {
+    out.text.resize(bytes);
+    const uintptr_t huge = (uintptr_t)2 << 20, b = ((uintptr_t)out.text.data() + huge - 1) & ~(huge - 1), e = ((uintptr_t)out.text.data() + bytes) & ~(huge - 1);
+    if (e > b) (void)madvise((void*)b, e - b, MADV_HUGEPAGE);
+    return out.text.data();
+}
 
 unsigned thread_count(uint32_t asked) {
     unsigned n = asked ? asked : std::thread::hardware_concurrency();
@@ -247,6 +257,13 @@ public:
         index_subreads();
         build_nodes_to_sr();
         auto t1 = now();
+        collect_work();
+        if (walk_on_device(out)) {
+            if (timing)
+                fprintf(stderr, "hc_fno1_run: index %.3f s, edges in walk order + the whole rest on the device %.3f s\n",
+                        std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(now() - t1).count());
+            return;
+        }
         walk();
         auto t2 = now();
         deduce_and_emit(out);
@@ -271,9 +288,21 @@ private:
     std::vector<hc_fno_subread> sub_sorted_;  // subreads of every super-read, sorted by node within the super-read
     std::vector<uint64_t> n2s_off_;           // nodes_to_SR as CSR
     std::vector<uint32_t> n2s_;
-    std::vector<const hc_fno_edge*> work_;  // every edge updateOverlap is called on, in the reference's order
+    // every edge updateOverlap is called on, in the reference's order: four runs of edges — adj_out and branching_edges where
+    // the caller keeps them, the stored non-edges that pass :702 (copied together), the inclusion-induced edges
+    hc::FnoEdgeSpan work_[4] = {{nullptr, 0}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}};
+    uint64_t n_work_ = 0;
+    std::vector<hc_fno_edge, hc::DefaultInitAllocator<hc_fno_edge>> kept_nonedges_;
+    const hc_fno_edge* work_at(uint64_t i) const {
+        for (int k = 0; k < 3; ++k) {
+            if (i < work_[k].n) return work_[k].p + i;
+            i -= work_[k].n;
+        }
+        return work_[3].p + i;
+    }
     std::vector<Item, hc::DefaultInitAllocator<Item>> items_;  // sized once, filled by the threads: not zero-filled first
     std::vector<hc_fno_edge> induced_;  // inclusion-induced edges (owned)
+    bool adj_identity_ = false;         // graph_edges lie vertex by vertex already (the documented order): adj_ is not built
     std::vector<uint64_t> adj_off_;     // OverlapGraph::adj_out as CSR over graph_edges (stable by v1)
     std::vector<uint32_t> adj_;
 
@@ -343,22 +372,41 @@ private:
     }
 
     void build_adjacency() {  // only what checkEdge needs
+        const uint64_t G = in_.n_graph_edges;
+        const hc_fno_edge* ge = in_.graph_edges;
         adj_off_.assign(in_.n_nodes + 1, 0);
-        for (uint64_t i = 0; i < in_.n_graph_edges; ++i) {
-            if (in_.graph_edges[i].v1 >= in_.n_nodes || in_.graph_edges[i].v2 >= in_.n_nodes) ref_abort("edge vertex out of range");
-            ++adj_off_[in_.graph_edges[i].v1 + 1];
+        // adj_out "vertex by vertex" (hcfno.h) is sorted by v1: every thread checks its stretch and, where v1 steps up, writes the
+        // offsets of the vertices in between; anything else takes the counting sort
+        std::atomic<bool> sorted{true};
+        parallel_chunks(G, threads_, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t i = b; i < e; ++i) {
+                if (ge[i].v1 >= in_.n_nodes || ge[i].v2 >= in_.n_nodes) ref_abort("edge vertex out of range");
+                if (i && ge[i - 1].v1 > ge[i].v1) sorted.store(false, std::memory_order_relaxed);
+            }
+        });
+        adj_identity_ = sorted.load();
+        if (adj_identity_) {
+            parallel_chunks(G + 1, threads_, [&](uint64_t b, uint64_t e, unsigned) {
+                for (uint64_t i = b; i < e; ++i) {  // offsets of the vertices in (v1[i - 1], v1[i]], i = G: up to n_nodes
+                    const uint64_t from = i ? ge[i - 1].v1 + 1 : 0, to = i < G ? ge[i].v1 : in_.n_nodes;
+                    for (uint64_t v = from; v <= to; ++v) adj_off_[v] = i;
+                }
+            });
+            return;
         }
+        for (uint64_t i = 0; i < G; ++i) ++adj_off_[ge[i].v1 + 1];
         for (uint64_t v = 0; v < in_.n_nodes; ++v) adj_off_[v + 1] += adj_off_[v];
-        adj_.resize(in_.n_graph_edges);
+        adj_.resize(G);
         std::vector<uint64_t> cur(adj_off_.begin(), adj_off_.end() - 1);
-        for (uint64_t i = 0; i < in_.n_graph_edges; ++i) adj_[cur[in_.graph_edges[i].v1]++] = (uint32_t)i;
+        for (uint64_t i = 0; i < G; ++i) adj_[cur[ge[i].v1]++] = (uint32_t)i;
     }
 
+    const hc_fno_edge& adj_edge(uint64_t k) const { return in_.graph_edges[adj_identity_ ? k : adj_[k]]; }
     double check_edge(uint64_t v, uint64_t w) const {  // OverlapGraph::checkEdge(v, w, true), src/OverlapGraph.cpp:233-259
         for (uint64_t k = adj_off_[v]; k < adj_off_[v + 1]; ++k)
-            if (in_.graph_edges[adj_[k]].v2 == w) return in_.graph_edges[adj_[k]].score;
+            if (adj_edge(k).v2 == w) return adj_edge(k).score;
         for (uint64_t k = adj_off_[w]; k < adj_off_[w + 1]; ++k)
-            if (in_.graph_edges[adj_[k]].v2 == v) return in_.graph_edges[adj_[k]].score;
+            if (adj_edge(k).v2 == v) return adj_edge(k).score;
         return -1.0;
     }
 
@@ -366,15 +414,14 @@ private:
     // inclusion-induced edges (:612-630, :635-813, :816-887)
     void collect_work() {
         if (in_.n_graph_edges + in_.n_branching_edges + in_.n_nonedges >= 0xFFFFFFF0ull) throw FatalError{HC_ERR_ARG, "too many edges"};
-        work_.reserve(in_.n_graph_edges + in_.n_branching_edges);
-        for (uint64_t i = 0; i < in_.n_graph_edges; ++i) work_.push_back(in_.graph_edges + i);
-        for (uint64_t i = 0; i < in_.n_branching_edges; ++i) work_.push_back(in_.branching_edges + i);
+        work_[0] = {in_.graph_edges, in_.n_graph_edges};
+        work_[1] = {in_.branching_edges, in_.n_branching_edges};
         const bool use_nonedges = !(in_.flags & HC_FNO_OPTIMIZE) && in_.n_nonedges;  // :914
         if (use_nonedges || in_.n_inclusion_groups) build_adjacency();
         if (use_nonedges) {
             if (!in_.nonedges) throw FatalError{HC_ERR_ARG, "null array"};
             const unsigned T = (unsigned)std::min<uint64_t>(threads_, in_.n_nonedges);
-            std::vector<std::vector<const hc_fno_edge*>> kept(T);
+            std::vector<std::vector<uint32_t>> kept(T);  // indices into nonedges
             parallel_chunks(in_.n_nonedges, T, [&](uint64_t b, uint64_t e, unsigned t) {
                 for (uint64_t i = b; i < e; ++i) {
                     const hc_fno_edge* ed = in_.nonedges + i;
@@ -382,10 +429,17 @@ private:
                     FNO_REQUIRE(ed->len1 > 0 && ed->len2 >= 0);  // Edge::set_len, src/Edge.h:212-214
                     if (ed->v1 >= in_.n_nodes || ed->v2 >= in_.n_nodes) ref_abort("edge vertex out of range");
                     if (check_edge(ed->v1, ed->v2) > 0) continue;  // :702
-                    kept[t].push_back(ed);
+                    kept[t].push_back((uint32_t)i);
                 }
             });
-            for (auto& k : kept) work_.insert(work_.end(), k.begin(), k.end());
+            std::vector<uint64_t> at(T + 1, 0);
+            for (unsigned t = 0; t < T; ++t) at[t + 1] = at[t] + kept[t].size();
+            kept_nonedges_.resize(at[T]);
+            parallel_chunks(T, T, [&](uint64_t tb, uint64_t te, unsigned) {
+                for (uint64_t t = tb; t < te; ++t)
+                    for (size_t k = 0; k < kept[t].size(); ++k) kept_nonedges_[at[t] + k] = in_.nonedges[kept[t][k]];
+            });
+            work_[2] = {kept_nonedges_.data(), kept_nonedges_.size()};
         }
         // findInclusionOverlaps: u->w and w->v both inclusions  =>  try u->v
         uint64_t n_induced = 0;
@@ -435,8 +489,9 @@ private:
                     if (check_edge(ne.v1, ne.v2) == -1) induced_.push_back(ne);
                 }
         }
-        for (const hc_fno_edge& e : induced_) work_.push_back(&e);
-        if (work_.size() >= 0xFFFFFFFFull) throw FatalError{HC_ERR_ARG, "too many edges"};
+        work_[3] = {induced_.data(), induced_.size()};
+        n_work_ = work_[0].n + work_[1].n + work_[2].n + work_[3].n;
+        if (n_work_ >= 0xFFFFFFFFull) throw FatalError{HC_ERR_ARG, "too many edges"};
     }
 
     static uint64_t pair_hash(uint64_t a, uint64_t b) {
@@ -460,9 +515,7 @@ private:
             since = t;
         };
         auto tw = now();
-        collect_work();
-        lap("edges in walk order", tw);
-        const uint64_t E = work_.size();
+        const uint64_t E = n_work_;
         const unsigned T = (unsigned)std::min<uint64_t>(threads_, E ? E : 1);
         const unsigned P = T;  // partitions
         std::vector<std::vector<std::vector<Combo>>> scattered(T, std::vector<std::vector<Combo>>(P));
@@ -476,7 +529,7 @@ private:
                 parts[pair_hash(c.lo, c.hi) % P].push_back(c);
             };
             for (uint64_t i = b; i < e_end; ++i) {
-                const hc_fno_edge* e = work_[i];
+                const hc_fno_edge* e = work_at(i);
                 if (e->v1 >= in_.n_nodes || e->v2 >= in_.n_nodes) ref_abort("edge vertex out of range");
                 const uint64_t u = e->v1, v = e->v2;
                 const bool vu = in_.nodes[u].visited, vv = in_.nodes[v].visited;
@@ -541,7 +594,7 @@ private:
                     }
                 winners[p].reserve(distinct);
                 for (const Combo* c : table)
-                    if (c) winners[p].push_back(Item{work_[c->edge], c->sr1, c->sr2, c->kind, (uint8_t)(work_[c->edge]->score == 0)});
+                    if (c) winners[p].push_back(Item{work_at(c->edge), c->sr1, c->sr2, c->kind, (uint8_t)(work_at(c->edge)->score == 0)});
             }
         });
         lap("earliest combination per pair", tw);
@@ -710,10 +763,7 @@ private:
         const auto t1 = now();
         uint64_t counters[5] = {0, 0, 0, 0, 0};
         double seconds[2] = {0, 0};
-        auto text_of = [&](uint64_t bytes) {
-            out.text.resize(bytes);
-            return out.text.data();
-        };
+        auto text_of = [&](uint64_t bytes) { return sized_text(out, bytes); };
         try {
             if (!hc::fno_lines_on_device(h_items.get(), n, (in_.flags & HC_FNO_NO_INCLUSIONS) != 0, text_of, counters, seconds)) return false;
         } catch (const FatalError& e) {
@@ -731,6 +781,53 @@ private:
             fprintf(stderr, "hc_fno1_run (device): look-ups on the host %.3f s, copy + deduce + 4 sorts + unique + scan %.3f s, text %.3f s, device blocks released %.3f s\n",
                     std::chrono::duration<double>(t1 - t0).count(), seconds[0], seconds[1],
                     std::chrono::duration<double>(now() - t1).count() - seconds[0] - seconds[1]);
+        return true;
+    }
+
+    // FNO=1 whole on the device (hc_fno_items.h: fno1_walk_on_device): the edges in walk order go over as they lie in the caller's
+    // arrays (the kept non-edges gathered first), with nodes_to_SR and the sorted subread maps; false = the host form runs.
+    bool walk_on_device(hc_fno_output& out) {
+        if (const char* e = getenv("HC_FNO_WALK"))
+            if (strcmp(e, "host") == 0) return false;
+        const uint64_t E = n_work_;
+        if (!hc::fno_device_wanted(E)) return false;
+        const bool timing = getenv("HC_FNO_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        hc::FnoWalkHost h{};
+        h.spans = work_;
+        h.n_spans = 4;
+        h.nodes = in_.nodes;
+        h.n_nodes = in_.n_nodes;
+        h.srs = in_.srs;
+        h.n_srs = in_.n_srs;
+        h.n2s_off = n2s_off_.data();
+        h.n2s = n2s_.data();
+        h.subread_off = in_.subread_off;
+        h.subreads = sub_sorted_.data();
+        h.new_read_count = in_.new_read_count;
+        h.resolve_orientations = (in_.flags & HC_FNO_RESOLVE_ORIENTATIONS) != 0;
+        h.no_inclusions = (in_.flags & HC_FNO_NO_INCLUSIONS) != 0;
+        uint64_t counters[5] = {0, 0, 0, 0, 0}, n_items = 0;
+        double seconds[3] = {0, 0, 0};
+        auto text_of = [&](uint64_t bytes) { return sized_text(out, bytes); };
+        try {
+            if (!hc::fno1_walk_on_device(h, text_of, counters, &n_items, seconds)) return false;
+        } catch (const FatalError& e) {
+            if (e.status != HC_ERR_NOMEM) throw;
+            return false;  // beyond the device's memory: the host threads take it
+        }
+        memset(&out.counters, 0, sizeof out.counters);
+        out.counters.copied = counters[kCopied];
+        out.counters.u2sr = counters[kU2SR];
+        out.counters.v2sr = counters[kV2SR];
+        out.counters.sr2sr = counters[kSR2SR];
+        out.counters.n_lines = counters[4];
+        out.on_device = true;
+        out.walk_on_device = true;
+        if (timing)
+            fprintf(stderr, "hc_fno1_run (device walk): copies + walk + look-ups %.3f s (%llu items), deduce + 4 sorts + unique + scan %.3f s, text %.3f s, buffers released %.3f s\n",
+                    seconds[0], (unsigned long long)n_items, seconds[1], seconds[2],
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - seconds[0] - seconds[1] - seconds[2]);
         return true;
     }
 
@@ -1036,10 +1133,7 @@ private:
         const auto t1 = now();
         uint64_t n_lines = 0;
         double seconds[2] = {0, 0};
-        auto text_of = [&](uint64_t bytes) {
-            out.text.resize(bytes);
-            return out.text.data();
-        };
+        auto text_of = [&](uint64_t bytes) { return sized_text(out, bytes); };
         try {
             if (!hc::fno3_lines_on_device(items.get(), n, (in_.flags & HC_FNO_NO_INCLUSIONS) != 0, text_of, &n_lines, seconds)) return false;
         } catch (const FatalError& e) {
@@ -1158,7 +1252,7 @@ int hc_fno_output_write(const hc_fno_output* o, const char* path) {
 }
 
 void hc_fno_output_free(hc_fno_output* o) { delete o; }
-int hc_fno_output_on_device(const hc_fno_output* o) { return o && o->on_device ? 1 : 0; }
+int hc_fno_output_on_device(const hc_fno_output* o) { return o && o->on_device ? (o->walk_on_device ? 2 : 1) : 0; }
 
 int hc_fno_compute_overlap_data(const hc_fno_read* sr1, const hc_fno_read* sr2, const int32_t idx[4], const hc_fno_edge* edge, int32_t* ok,
                                 int32_t out9[9]) {

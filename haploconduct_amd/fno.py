@@ -5,6 +5,7 @@ SRBuilder::findNextOverlaps3 (src/FindNextOverlaps3.cpp:20-88) on flat numpy rec
 The input builders here are shared with the tests, which feed the same structures to
 the oracle (oracle/fno_oracle.cpp) — the structures are plain data, not the oracle.
 """
+import time
 import ctypes as C
 
 import numpy as np
@@ -150,12 +151,15 @@ class Fno3Input:
 
 
 last_on_device = False  # whether the latest output collected here came from the device form (hc_fno_output_on_device)
+last_device_level = 0   # 0 host threads, 1 second half on the device, 2 the walk and the look-ups too (FNO=1)
+last_run_s = 0.0        # seconds inside hc_fno1_run / hc_fno3_run alone (without this module's copy of the text into bytes)
 
 
 def _collect(h, out_path):
-    global last_on_device
+    global last_on_device, last_device_level
     try:
-        last_on_device = bool(N.lib.hc_fno_output_on_device(h))
+        last_device_level = int(N.lib.hc_fno_output_on_device(h))
+        last_on_device = last_device_level > 0
         text, n = _vp(), C.c_uint64()
         N.check(N.lib.hc_fno_output_text(h, C.byref(text), C.byref(n)), "hc_fno_output_text")
         data = C.string_at(text, n.value) if n.value else b""
@@ -170,15 +174,21 @@ def _collect(h, out_path):
 
 def find_next_overlaps(inp, out_path=None):
     """FNO=1.  Returns (text of overlaps.txt as bytes, counters dict); writes out_path when given."""
+    global last_run_s
     s, h = inp.struct(), _vp()
+    t0 = time.perf_counter()
     N.check(N.lib.hc_fno1_run(C.byref(s), C.byref(h)), "hc_fno1_run")
+    last_run_s = time.perf_counter() - t0
     return _collect(h, out_path)
 
 
 def find_next_overlaps3(inp, out_path=None):
     """FNO=3.  Returns (text of overlaps.txt as bytes, counters dict)."""
+    global last_run_s
     s, h = inp.struct(), _vp()
+    t0 = time.perf_counter()
     N.check(N.lib.hc_fno3_run(C.byref(s), C.byref(h)), "hc_fno3_run")
+    last_run_s = time.perf_counter() - t0
     return _collect(h, out_path)
 
 

@@ -124,9 +124,11 @@ int hc_fno_output_text(const hc_fno_output* o, const char** text, uint64_t* n_by
 int hc_fno_output_counters(const hc_fno_output* o, hc_fno_counters* c);
 int hc_fno_output_write(const hc_fno_output* o, const char* path); /* what the reference leaves in overlaps.txt */
 void hc_fno_output_free(hc_fno_output* o);
-/* 1 if the arithmetic, the ordering and the text of this output were the device's (FNO=1 batches of 200 000 combinations
- * and more when a HIP device is present; HC_FNO=host / HC_FNO=device force either), 0 if the host threads'.  The device is
- * the calling thread's current HIP device (hipSetDevice; device 0 unless the caller chose another). */
+/* 0: the host threads wrote this output.  1: the arithmetic, the ordering and the text were the device's, the walk and the
+ * look-ups the host threads'.  2 (FNO=1): the walk — updateOverlap's case analysis, the first combination per pair of new ids
+ * (:25-349) — and the look-ups were the device's too.  The device takes batches of 200 000 edges / combinations and more when a
+ * HIP device is present; HC_FNO=host / HC_FNO=device force either, HC_FNO_WALK=host keeps the walk on the host threads.  The
+ * device is the calling thread's current HIP device (hipSetDevice; device 0 unless the caller chose another). */
 int hc_fno_output_on_device(const hc_fno_output* o);
 
 /* computeOverlapData (:351-565) on its own: the overlap of two (super-)reads induced by one edge.

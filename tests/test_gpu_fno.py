@@ -20,21 +20,26 @@ def olib():
     return T.load_oracle()
 
 
-@pytest.fixture()
-def on_device():
+@pytest.fixture(params=["walk on the device", "walk on the host threads"])
+def on_device(request):
+    """Both device routes of FNO=1: everything behind the edge list on the device (level 2), or the walk and the look-ups with
+    the host threads and the second half on the device (level 1, HC_FNO_WALK=host).  FNO=3 has the one device route."""
     os.environ["HC_FNO"] = "device"
-    yield
+    if request.param.endswith("host threads"):
+        os.environ["HC_FNO_WALK"] = "host"
+    yield 1 if request.param.endswith("host threads") else 2
     os.environ.pop("HC_FNO", None)
+    os.environ.pop("HC_FNO_WALK", None)
 
 
 def test_goldens_of_the_reference_through_the_device(olib, on_device):
     # the same golden files, the same assertions, the other route
     host_tests.test_golden_update_overlap_oracle_and_product(olib)
-    assert F.last_on_device
+    assert F.last_device_level == on_device
     host_tests.test_golden_whole_find_next_overlaps_runs(olib)
-    assert F.last_on_device
+    assert F.last_device_level == on_device
     host_tests.test_golden_whole_runs_with_stored_nonedges(olib)
-    assert F.last_on_device
+    assert F.last_device_level == on_device
     host_tests.test_fno1_sections_contribute(olib)
     host_tests.test_fno1_first_edge_wins_per_superread_pair(olib)
     host_tests.test_fno1_nonedge_behind_existing_edge_is_skipped(olib)
@@ -43,7 +48,7 @@ def test_goldens_of_the_reference_through_the_device(olib, on_device):
 @pytest.mark.parametrize("seed", range(24))
 def test_device_matches_oracle_on_random_scenarios(olib, on_device, seed):
     host_tests.test_fno1_product_matches_oracle(olib, seed)
-    assert F.last_on_device
+    assert F.last_device_level == on_device
 
 
 def test_stops_of_the_reference_are_reported_as_by_the_host_form(olib, on_device):
@@ -71,9 +76,16 @@ def test_large_iteration_device_equals_host(seed, flags):
     finally:
         os.environ.pop("HC_FNO", None)
     got, gc = F.find_next_overlaps(inp)
-    assert F.last_on_device, "a batch of this size goes to the device by default"
+    assert F.last_device_level == 2, "a batch of this size goes to the device by default, walk and all"
     assert gc == wc
     assert got == want
+    os.environ["HC_FNO_WALK"] = "host"
+    try:
+        got1, gc1 = F.find_next_overlaps(inp)
+        assert F.last_device_level == 1
+    finally:
+        os.environ.pop("HC_FNO_WALK", None)
+    assert gc1 == wc and got1 == want
     assert wc["n_lines"] > 10 ** 6
     lines = got.split(b"\n")[:-1]
     assert len(lines) == gc["n_lines"] and all(a < b for a, b in zip(lines[:200000], lines[1:200001]))

@@ -277,7 +277,8 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
                           'namespace hc { int set_last_error(int s, const std::string&) { return s; }\n'
                           'struct FnoItem; bool fno_device_wanted(uint64_t) { return false; }\n'
                           'bool fno_lines_on_device(const FnoItem*, uint64_t, bool, const std::function<char*(uint64_t)>&, uint64_t*, double*) { return false; }\n'
-                          'bool fno3_lines_on_device(const FnoItem*, uint64_t, bool, const std::function<char*(uint64_t)>&, uint64_t*, double*) { return false; } }\n'
+                          'bool fno3_lines_on_device(const FnoItem*, uint64_t, bool, const std::function<char*(uint64_t)>&, uint64_t*, double*) { return false; }\n'
+                          'struct FnoWalkHost; bool fno1_walk_on_device(const FnoWalkHost&, const std::function<char*(uint64_t)>&, uint64_t*, uint64_t*, double*) { return false; } }\n'
                           'extern "C" { const char* hc_strerror(int) { return ""; } const char* hc_last_error(void) { return ""; } }\n')
     san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-fPIC", "-shared"]
     r = subprocess.run(["g++", "-std=c++17", *san, "-pthread", "-o", host_so, os.path.join(hd, "host_model.cpp"),

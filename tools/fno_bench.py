@@ -103,16 +103,23 @@ def main():
     os.environ.pop("HC_FNO", None)
     res["lines"], res["bytes"] = cnt["n_lines"], len(ref_text)
     inp.n_threads = 0  # ... and the default routing: the device takes the second half when there is one
-    runs = []
+    runs, lib_runs = [], []
     for _ in range(3):
         t = time.perf_counter()
         text, dcnt = F.find_next_overlaps(inp)
         runs.append(round(time.perf_counter() - t, 3))
+        lib_runs.append(round(F.last_run_s, 3))
         if not F.last_on_device:
             break
         assert text == ref_text and dcnt == cnt
     if F.last_on_device:
-        res["device_form_s"] = runs
+        res["device_form_s"] = runs                  # with this harness's copy of the text into a bytes object
+        res["device_form_library_s"] = lib_runs      # hc_fno1_run alone
+        res["device_level"] = F.last_device_level    # 2: walk and look-ups on the device too
+        os.environ["HC_FNO_WALK"] = "host"           # round 2's split: walk and look-ups with the host threads
+        F.find_next_overlaps(inp)
+        res["walk_on_host_library_s"] = round(F.last_run_s, 3)
+        os.environ.pop("HC_FNO_WALK", None)
     if not a.no_oracle:
         from tests import _fno as T
         lib = T.load_oracle()
@@ -144,7 +151,7 @@ def main():
             tr = time.perf_counter() - t
         same = C.string_at(text, nb.value) == ptext
         ref.frag_fno_free(text)
-        res["without_nonedges"] = {"lines": pcnt["n_lines"], "product_s": round(tp, 3), "reference_own_code_s": round(tr, 3),
+        res["without_nonedges"] = {"lines": pcnt["n_lines"], "product_s": round(tp, 3), "product_library_s": round(F.last_run_s, 3), "reference_own_code_s": round(tr, 3),
                                    "identical_to_reference": bool(same)}
         inp.nonedges = saved
         inp.flags &= ~F.OPTIMIZE
