@@ -96,6 +96,7 @@ _sig = {
     "hc_textblock_wait": (C.c_int, [_vp, C.POINTER(hc_text_result)]),
     "hc_textblock_destroy": (C.c_int, [_vp]),
     "hc_textblock_regrown": (C.c_uint64, [_vp]),
+    "hc_textblock_reserve_rows": (C.c_int, [_vp, C.c_uint64]),
     "hc_graph_begin": (C.c_int, [_vp]),
     "hc_graph_append": (C.c_int, [_vp, _vp, C.c_uint64]),
     "hc_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, C.POINTER(hc_graph_counts)]),

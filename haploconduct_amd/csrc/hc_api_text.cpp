@@ -44,6 +44,7 @@ struct hc_textblock {
     uint64_t sub_bytes = 0, sub_first_line = 0, sub_base_index = 0;
     const unsigned long long* sub_first_line_ptr = nullptr;
     uint64_t n_regrown = 0;                    // how often that happened
+    std::vector<void*> old_device, old_host;   // row buffers hc_textblock_reserve_rows replaced: freed with the block (a free waits for the device)
     bool in_flight = false;
 };
 
@@ -195,6 +196,8 @@ int hc_textblock_destroy(hc_textblock* b) {
         if (p) (void)hipFree(p);
     for (void* p : {(void*)b->h_text, (void*)b->h_rows, (void*)b->h_row_lines, (void*)b->h_rejects, (void*)b->h_counters})
         if (p) (void)hipHostFree(p);
+    for (void* p : b->old_device) (void)hipFree(p);
+    for (void* p : b->old_host) (void)hipHostFree(p);
     if (b->done) (void)hipEventDestroy(b->done);
     if (b->lines_known) (void)hipEventDestroy(b->lines_known);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -245,16 +248,19 @@ static int textblock_device_half(hc_textblock* b) {
 // of the lines the buffers start with (overlaps found at a low error rate; later iterations).  The text, its line starts and
 // the line count are still on the device and the device's parse is good: the buffers grow to what this block needs (and stay
 // that size) and the device half runs again — the block does not fall back to the host's tokeniser.
-static int textblock_regrow(hc_textblock* b, uint64_t need) {
-    hc_ctx* c = b->ctx;
-    uint64_t cap = need + need / 8 + 1024;
-    if (cap > b->max_lines) cap = b->max_lines;
-    if (cap < need) return fail(HC_ERR_STATE, "hc_textblock_wait: more rows than lines");
-    HC_HIP(hipStreamSynchronize(b->stream));
+// the row buffers (device rows, their mapped host twins, the rejects) for `cap` rows; defer_free: the old ones are kept for
+// hc_textblock_destroy instead of being freed now (hipFree / hipHostFree wait for the device: not next to another launch sequence)
+static int textblock_row_buffers(hc_textblock* b, uint64_t cap, bool defer_free) {
     for (void* p : {(void*)b->d_rows, (void*)b->d_row_lines})
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (defer_free) b->old_device.push_back(p);
+            else (void)hipFree(p);
+        }
     for (void* p : {(void*)b->h_rows, (void*)b->h_row_lines, (void*)b->h_rejects})
-        if (p) (void)hipHostFree(p);
+        if (p) {
+            if (defer_free) b->old_host.push_back(p);
+            else (void)hipHostFree(p);
+        }
     b->d_rows = nullptr;
     b->d_row_lines = nullptr;
     b->h_rows = nullptr;
@@ -266,6 +272,19 @@ static int textblock_regrow(hc_textblock* b, uint64_t need) {
     HC_HIP(hipHostMalloc((void**)&b->h_rows, cap * sizeof(hc_gather_row), hipHostMallocMapped));
     HC_HIP(hipHostMalloc((void**)&b->h_row_lines, cap * sizeof(hc_line_rec), hipHostMallocMapped));
     HC_HIP(hipHostMalloc((void**)&b->h_rejects, cap * sizeof(hc_text_reject), hipHostMallocMapped));
+    return HC_OK;
+}
+
+static int textblock_regrow(hc_textblock* b, uint64_t need) {
+    hc_ctx* c = b->ctx;
+    uint64_t cap = need + need / 8 + 1024;
+    if (cap > b->max_lines) cap = b->max_lines;
+    if (cap < need) return fail(HC_ERR_STATE, "hc_textblock_wait: more rows than lines");
+    HC_HIP(hipStreamSynchronize(b->stream));
+    {
+        const int rc = textblock_row_buffers(b, cap, false);
+        if (rc) return rc;
+    }
     // what the device half adds to: the parse kernel's tallies and slots, the row count (lines / overflow stay)
     HC_HIP(hipMemsetAsync(b->d_counters, 0, hc::kTextLines * sizeof(unsigned long long), b->stream));
     HC_HIP(hipMemsetAsync(b->d_counters + hc::kTextRows, 0, (hc::kTextCounters - hc::kTextRows) * sizeof(unsigned long long), b->stream));
@@ -332,6 +351,14 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
 }
 
 uint64_t hc_textblock_regrown(hc_textblock* b) { return b ? b->n_regrown : 0; }
+
+int hc_textblock_reserve_rows(hc_textblock* b, uint64_t rows) {
+    if (!b) return fail(HC_ERR_ARG, "hc_textblock_reserve_rows: null block");
+    if (rows > b->max_lines) rows = b->max_lines;
+    if (rows <= b->row_cap) return HC_OK;
+    HC_HIP(hipSetDevice(b->ctx->device));
+    return textblock_row_buffers(b, rows, true);
+}
 
 int hc_textblock_wait(hc_textblock* b, hc_text_result* out) {
     if (!b || !out) return fail(HC_ERR_ARG, "hc_textblock_wait: null argument");

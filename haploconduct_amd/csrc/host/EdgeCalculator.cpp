@@ -1247,7 +1247,25 @@ void EdgeCalculator::construct_edges_from_reads(double err_rate, uint32_t min_ov
                                                 uint64_t* n_lines) {
     const double t0 = now_s();
     uint64_t found = 0, lines = 0;
+    // Overlaps that come straight from the finder mostly survive the scoring (all of them at err_rate 0): the first text blocks get
+    // row buffers for lines of 32 bytes now, beside the finder's kernels, instead of each growing its own inside its first wait
+    // (page-locking 68 MB a block; a block with still more rows, and the later blocks of a long text, grow on demand as ever)
+    int grow_rc = HC_OK;
+    std::thread grower([&] {
+        bind_here();
+        for (Device& d : m_dev)
+            for (size_t k = 0; k < d.tblk.size() && k < 6; k++)
+                if (d.tblk[k] && grow_rc == HC_OK) grow_rc = hc_textblock_reserve_rows(d.tblk[k], m_text_block / 32);
+    });
+    struct Join {
+        std::thread& t;
+        ~Join() {
+            if (t.joinable()) t.join();
+        }
+    } join_grower{grower};
     check(hc_find_overlaps(m_ctx, err_rate, min_overlap, find_flags, nullptr, 0, &found), "hc_find_overlaps");
+    grower.join();
+    check(grow_rc, "hc_textblock_reserve_rows");
     const double t1 = now_s();
     auto text = std::make_shared<std::string>();
     check(hc_found_to_overlaps_text(m_ctx, fastq_storage->m_readcount_single, fastq_storage->m_readcount_paired, *text, &lines),

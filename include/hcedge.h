@@ -389,6 +389,10 @@ int hc_textblock_wait(hc_textblock* b, hc_text_result* out); /* valid until the 
 /* A block starts with row buffers for an eighth of its lines; a block with more surviving records (or prefilter rejects)
  * grows them inside hc_textblock_wait and runs its device half again — it does not go to the host.  How often so far: */
 uint64_t hc_textblock_regrown(hc_textblock* b);
+/* Row buffers for at least `rows` rows (at most the block's lines) ahead of a submit, for a caller that expects most lines to survive
+ * (overlaps straight from hc_find_overlaps: the one-call route grows its blocks while the finder runs).  Not while the block is in
+ * flight.  The buffers it replaces are freed with the block. */
+int hc_textblock_reserve_rows(hc_textblock* b, uint64_t rows);
 int hc_textblock_destroy(hc_textblock* b);
 
 /* ---- duplicate resolution + adjacency on the device -----------------------------------------

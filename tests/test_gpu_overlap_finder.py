@@ -351,3 +351,6 @@ def test_reads_to_graph_in_one_call_equals_the_file_route(tmp_path, workload):
     for k in ("inclusion_count", "dup_count", "edges_added", "nonedges_written", "prefilter_rejected", "lines_read", "scored", "self_overlap_count"):
         assert a[3][k] == b[3][k], k
     assert (out_a / "nonedge_overlaps.txt").read_bytes() == (out_b / "nonedge_overlaps.txt").read_bytes()
+    # the one-call route gave its first text blocks row buffers for lines of 32 bytes while the finder ran (hc_textblock_reserve_rows):
+    # even where every overlap is admitted no block had to grow inside its wait; the file route's blocks start with an eighth
+    assert a[3]["host_blocks"] == 0 and a[3]["regrown_blocks"] == 0, a[3]
