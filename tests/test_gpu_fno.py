@@ -45,7 +45,7 @@ def test_goldens_of_the_reference_through_the_device(olib, on_device):
     host_tests.test_fno1_nonedge_behind_existing_edge_is_skipped(olib)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HC_FUZZ_FNO_SEEDS", "24"))))  # soak: HC_FUZZ_FNO_SEEDS=400
 def test_device_matches_oracle_on_random_scenarios(olib, on_device, seed):
     host_tests.test_fno1_product_matches_oracle(olib, seed)
     assert F.last_device_level == on_device
