@@ -88,26 +88,53 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
             check(hc_create(&dev.ctx, &cs), "hc_create");
             m_dev.push_back(dev);
             const double tc1 = now_s();
+            // the blocks of text construct_edges streams the overlaps file through, with their page-locked buffers (device memory
+            // and page-locking belong to setting the stage up, like the read store), are made by a second thread while this one
+            // uploads the reads: page-locking is the driver's work on the host, the upload is the copy engine's
+            Device& dv = m_dev.back();
+            std::string blocks_error;
+            int blocks_rc = HC_OK;
+            double blocks_s = 0;
+            std::thread blocks;
+            struct Join {
+                std::thread& t;
+                ~Join() {
+                    if (t.joinable()) t.join();
+                }
+            } join_blocks{blocks};
+            if (!m_host_parse) {
+                dv.tblk.resize(m_text_depth, nullptr);
+                blocks = std::thread([&] {
+                    bind_here();
+                    const double tb = now_s();
+                    for (hc_textblock*& b : dv.tblk) {
+                        blocks_rc = hc_textblock_create(dv.ctx, m_text_block, &b);
+                        if (blocks_rc == HC_OK && !hc_textblock_buffer(b)) {
+                            blocks_rc = HC_ERR_NOMEM;
+                            blocks_error = "EdgeCalculator: no page-locked buffer for a block of text";
+                        } else if (blocks_rc != HC_OK) {
+                            blocks_error = std::string("hc_textblock_create: ") + hc_strerror(blocks_rc) + " " + hc_last_error();
+                        }
+                        if (blocks_rc != HC_OK) break;
+                    }
+                    blocks_s = now_s() - tb;
+                });
+            }
             check(hc_set_reads(dev.ctx, f.bases().data(), f.quals().data(), f.seq_off().data(), f.read_first_seq().data(),
                                f.get_readcount()),
                   "hc_set_reads");
             const double tc2 = now_s();
+            double tc3 = tc2;
             if (!m_host_parse) {  // the device's text parser looks read ids up itself
                 std::vector<uint64_t> ids(f.m_read_vec.size());
                 for (size_t r = 0; r < ids.size(); r++) ids[r] = f.m_read_vec[r]->get_read_id();
                 check(hc_text_set_ids(dev.ctx, ids.data(), (uint32_t)ids.size()), "hc_text_set_ids");
-                // the blocks of text construct_edges streams the overlaps file through, with their page-locked buffers:
-                // device memory and page-locking belong to setting the stage up, like the read store
-                Device& dv = m_dev.back();
-                dv.tblk.resize(m_text_depth, nullptr);
-                const double tc3 = now_s();
-                for (hc_textblock*& b : dv.tblk) {
-                    check(hc_textblock_create(dv.ctx, m_text_block, &b), "hc_textblock_create");
-                    if (!hc_textblock_buffer(b)) throw FatalError{HC_ERR_NOMEM, "EdgeCalculator: no page-locked buffer for a block of text"};
-                }
+                tc3 = now_s();
+                blocks.join();
+                if (blocks_rc != HC_OK) throw FatalError{blocks_rc, blocks_error};
                 if (getenv("HC_STAGE_TIMING"))
-                    fprintf(stderr, "[hc stage] device %d: context %.3f s, read store %.3f s, id table %.3f s, %zu text blocks %.3f s\n", d, tc1 - tc0, tc2 - tc1,
-                            tc3 - tc2, dv.tblk.size(), now_s() - tc3);
+                    fprintf(stderr, "[hc stage] device %d: context %.3f s, read store %.3f s, id table %.3f s, %zu text blocks %.3f s beside them (+ %.3f s)\n", d, tc1 - tc0,
+                            tc2 - tc1, tc3 - tc2, dv.tblk.size(), blocks_s, now_s() - tc3);
             }
         }
     } catch (...) {
