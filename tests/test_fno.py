@@ -197,6 +197,21 @@ def test_fno1_product_matches_oracle(olib, seed):
         assert all(l.split(b"\t")[7] != b"100" for l in lines)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_fno1_graph_edges_in_any_order(olib, seed):
+    """hcfno.h asks for adj_out vertex by vertex, and checkEdge then uses the array as it lies; an array in any other order still
+    has to give what the oracle gives for it (the counting-sort adjacency behind the fast path), stored non-edges and
+    inclusion-induced edges — the users of checkEdge — included."""
+    inp = T.fno1_scenario(100 + seed, n_nodes=60, n_srs=20, n_edges=300, with_extras=True, flags=[F.RESOLVE_ORIENTATIONS, 0][seed % 2],
+                          paired_frac=[0.0, 0.4, 1.0][seed % 3], n_threads=[1, 0, 3][seed % 3])
+    rng = np.random.default_rng(seed)
+    inp.graph_edges = inp.graph_edges[rng.permutation(inp.graph_edges.size)]
+    assert (np.diff(inp.graph_edges["v1"].astype(np.int64)) < 0).any()
+    want, wc = T.oracle_fno1(olib, inp)
+    got, gc = F.find_next_overlaps(inp)
+    assert got == want and gc == wc
+
+
 def test_fno1_sections_contribute(olib):
     """Branching edges, stored non-edges and inclusion-induced edges each add lines (so the walk over them is exercised)."""
     base = T.fno1_scenario(5, n_nodes=60, n_srs=20, n_edges=200, with_extras=True)

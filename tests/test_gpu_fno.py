@@ -51,6 +51,12 @@ def test_device_matches_oracle_on_random_scenarios(olib, on_device, seed):
     assert F.last_device_level == on_device
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_device_takes_graph_edges_in_any_order(olib, on_device, seed):
+    host_tests.test_fno1_graph_edges_in_any_order(olib, seed)
+    assert F.last_device_level == on_device
+
+
 def test_stops_of_the_reference_are_reported_as_by_the_host_form(olib, on_device):
     host_tests.test_fno1_aborts_where_the_reference_does(olib)
 
