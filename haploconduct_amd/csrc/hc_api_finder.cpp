@@ -13,6 +13,7 @@
 #include "../../include/hcedge.h"
 #include "hc_ctx.h"
 #include "hc_fno_device.h"
+#include "hc_prims.h"
 #include "hc_sfo_device.h"
 #include "host/NumaBind.h"
 #include "host/Types.h"
@@ -434,6 +435,32 @@ int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pair
                 std::swap(perm, perm_next);
             }
             HC_HIP(hc::sfo_gather(d_flip, perm, n, d_sorted, st));
+            // Only the records the matching can see anything of leave the device (hc_sfo_kernels.hip: lines between unpaired reads,
+            // groups of two lines and more, the lines that close them): d_flip, spent, takes them; the keys' buffers the flags
+            // and the places.  HC_SFO_FILTER=0: all of them, as before.
+            uint64_t n_out = n;
+            const hc::SfoFlipped* d_send = d_sorted;
+            const bool filter = !(getenv("HC_SFO_FILTER") && atoi(getenv("HC_SFO_FILTER")) == 0);
+            if (filter) {
+                uint8_t *d_grouped = (uint8_t*)d_k[0], *d_keep = (uint8_t*)d_k[1];
+                uint32_t* d_idx = (uint32_t*)d_k[2];
+                unsigned long long* d_cnt = (unsigned long long*)d_ka;  // [0] grouped records, [1] kept records
+                const size_t sel_bytes = hc::prims::select_temp_bytes(n);
+                if (sel_bytes > tmp_bytes) return fail(HC_ERR_STATE, "hc_found_to_overlaps: scratch smaller than the selection needs");
+                HC_HIP(hc::sfo_classify(d_sorted, n, num_singles, num_pairs, d_grouped, d_keep, st));
+                HC_HIP(hc::prims::select_flagged(d_tmp, tmp_bytes, d_grouped, n, d_idx, d_cnt, st));
+                unsigned long long m = 0;
+                HC_HIP(hipMemcpyAsync(&m, d_cnt, 8, hipMemcpyDeviceToHost, st));
+                HC_HIP(hipStreamSynchronize(st));
+                HC_HIP(hc::sfo_groups(d_sorted, d_idx, m, num_singles, num_pairs, d_keep, st));
+                HC_HIP(hc::prims::select_flagged(d_tmp, tmp_bytes, d_keep, n, d_idx, d_cnt + 1, st));
+                unsigned long long kept = 0;
+                HC_HIP(hipMemcpyAsync(&kept, d_cnt + 1, 8, hipMemcpyDeviceToHost, st));
+                HC_HIP(hipStreamSynchronize(st));
+                HC_HIP(hc::sfo_gather_kept(d_sorted, d_idx, kept, d_flip, st));
+                n_out = kept;
+                d_send = d_flip;
+            }
             unsigned long long status = 0;
             HC_HIP(hipMemcpyAsync(&status, d_status, 8, hipMemcpyDeviceToHost, st));
             // the page-locked ring the sorted records come back through (kept with the context)
@@ -449,13 +476,13 @@ int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pair
             if (!status) {
                 // copy of chunk j + 1 beside the matching of chunk j
                 hc::SfoSortedMatcher matcher((long)num_singles, (long)num_pairs);
-                const uint64_t n_chunks = (n + chunk - 1) / chunk;
-                auto count_of = [&](uint64_t j) { return std::min(chunk, n - j * chunk); };
-                HC_HIP(hipMemcpyAsync(c->h_ingest[0], d_sorted, count_of(0) * sizeof(hc::SfoFlipped), hipMemcpyDeviceToHost, st));
+                const uint64_t n_chunks = (n_out + chunk - 1) / chunk;
+                auto count_of = [&](uint64_t j) { return std::min(chunk, n_out - j * chunk); };
+                if (n_out) HC_HIP(hipMemcpyAsync(c->h_ingest[0], d_send, count_of(0) * sizeof(hc::SfoFlipped), hipMemcpyDeviceToHost, st));
                 for (uint64_t j = 0; j < n_chunks; j++) {
                     HC_HIP(hipStreamSynchronize(st));  // chunk j has arrived
                     if (j + 1 < n_chunks)
-                        HC_HIP(hipMemcpyAsync(c->h_ingest[(j + 1) & 1], d_sorted + (j + 1) * chunk, count_of(j + 1) * sizeof(hc::SfoFlipped),
+                        HC_HIP(hipMemcpyAsync(c->h_ingest[(j + 1) & 1], d_send + (j + 1) * chunk, count_of(j + 1) * sizeof(hc::SfoFlipped),
                                               hipMemcpyDeviceToHost, st));
                     matcher.feed((const hc::SfoFlipped*)c->h_ingest[j & 1], count_of(j));
                 }
@@ -463,8 +490,8 @@ int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pair
                 text = matcher.finish(k);
                 sorted_on_device = true;
                 if (timing)
-                    fprintf(stderr, "hc_found_to_overlaps: device blocks %.3f s, flip + 3 sorts + gather on the device %.3f s, copy + match %.3f s, stitch %.3f s\n",
-                            t_alloc - t0, t1 - t_alloc, t2 - t1, now() - t2);
+                    fprintf(stderr, "hc_found_to_overlaps: device blocks %.3f s, flip + 3 sorts + gather + filter on the device %.3f s (%llu of %llu records leave it), copy + match %.3f s, stitch %.3f s\n",
+                            t_alloc - t0, t1 - t_alloc, (unsigned long long)n_out, (unsigned long long)n, t2 - t1, now() - t2);
             }
         }
         if (!sorted_on_device) {  // nothing found, an id or a number the device's keys do not hold: the host path sorts, and reports

@@ -19,6 +19,12 @@ enum : unsigned long long {
 hipError_t sfo_flip(const hc_sfo_rec* in, uint64_t n, uint64_t ns, uint64_t np, SfoFlipped* out, uint64_t* k0, uint64_t* k1, uint64_t* k2,
                     uint32_t* iota, unsigned long long* status, hipStream_t s);
 hipError_t sfo_gather(const SfoFlipped* in, const uint32_t* perm, uint64_t n, SfoFlipped* out, hipStream_t s);
+// Of the sorted records, those the script's matching can see anything of (hc_sfo_kernels.hip): grouped[i] = a line that joins a
+// group of one pair of reads, keep[i] = an output line by itself; then, for the grouped ones in order (idx), keep = its group has
+// two lines or more, or it closes such a group; then the kept ones in order.
+hipError_t sfo_classify(const SfoFlipped* sorted, uint64_t n, uint64_t ns, uint64_t np, uint8_t* grouped, uint8_t* keep, hipStream_t s);
+hipError_t sfo_groups(const SfoFlipped* sorted, const uint32_t* idx, uint64_t m, uint64_t ns, uint64_t np, uint8_t* keep, hipStream_t s);
+hipError_t sfo_gather_kept(const SfoFlipped* sorted, const uint32_t* idx, uint64_t k, SfoFlipped* out, hipStream_t s);
 
 }  // namespace hc
 #endif

@@ -103,6 +103,55 @@ __global__ __launch_bounds__(kBlock) void sfo_gather_kernel(const SfoFlipped* __
     dst[0] = src[0];
     dst[1] = src[1];
 }
+// ---- which sorted records the matching can see -------------------------------------------------------------------------------
+// scripts/sfo2overlaps.py:63-103 after its `uniq`: a line whose two original ids are equal is skipped; a line between two
+// unpaired reads is an output line; the others collect in groups of one pair of reads, and a group is matched (every two of
+// its lines, :221-310) when the NEXT such line arrives, with that line's read types (:94).  A group of one line yields nothing
+// whoever closes it, so of the grouped lines only those of groups of two and more, and the line that closes such a group, have
+// to reach the host's matcher: on overlaps of paired reads at one error rate that is a few per cent of the records.
+__device__ __forceinline__ uint32_t sfo_original(uint32_t sfo, uint64_t ns, uint64_t np) {  // :136-147
+    return (np == 0 || sfo < ns + np) ? sfo : (uint32_t)(sfo - np);
+}
+__device__ __forceinline__ bool sfo_same_pair(const SfoFlipped& a, const SfoFlipped& b, uint64_t ns, uint64_t np) {
+    return sfo_original(a.s0, ns, np) == sfo_original(b.s0, ns, np) && sfo_original(a.s1, ns, np) == sfo_original(b.s1, ns, np);
+}
+
+__global__ __launch_bounds__(kBlock) void sfo_classify_kernel(const SfoFlipped* __restrict__ sorted, uint64_t n, uint64_t ns, uint64_t np,
+                                                              uint8_t* __restrict__ grouped, uint8_t* __restrict__ keep) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const SfoFlipped r = sorted[i];
+    bool dup = false;  // `uniq`: equal to the line in front of it
+    if (i) {
+        const SfoFlipped p = sorted[i - 1];
+        dup = p.s0 == r.s0 && p.s1 == r.s1 && p.oha == r.oha && p.ohb == r.ohb && p.ola == r.ola && p.olb == r.olb && p.k == r.k &&
+              p.inverted == r.inverted;
+    }
+    const uint32_t id0 = sfo_original(r.s0, ns, np), id1 = sfo_original(r.s1, ns, np);
+    const bool seen = !dup && id0 != id1;                                  // :66-67
+    const bool single = np == 0 || (id0 < ns && id1 < ns);                // is_paired, :124-134
+    grouped[i] = seen && !single;
+    keep[i] = seen && single;  // an output line by itself; the grouped ones are decided below
+}
+
+// j-th grouped record (idx[j] = its place among the sorted ones): kept when its group has two lines or more, or when it closes one
+__global__ __launch_bounds__(kBlock) void sfo_groups_kernel(const SfoFlipped* __restrict__ sorted, const uint32_t* __restrict__ idx, uint64_t m,
+                                                            uint64_t ns, uint64_t np, uint8_t* __restrict__ keep) {
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= m) return;
+    const SfoFlipped r = sorted[idx[j]];
+    const bool same_prev = j > 0 && sfo_same_pair(sorted[idx[j - 1]], r, ns, np);
+    const bool same_next = j + 1 < m && sfo_same_pair(r, sorted[idx[j + 1]], ns, np);
+    bool closes = false;  // the group in front of it has two lines or more
+    if (j > 1 && !same_prev) closes = sfo_same_pair(sorted[idx[j - 2]], sorted[idx[j - 1]], ns, np);
+    keep[idx[j]] = (same_prev || same_next || closes) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void sfo_gather_kept_kernel(const SfoFlipped* __restrict__ sorted, const uint32_t* __restrict__ idx, uint64_t k,
+                                                                 SfoFlipped* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < k) out[i] = sorted[idx[i]];
+}
 }  // namespace
 
 hipError_t sfo_flip(const hc_sfo_rec* in, uint64_t n, uint64_t ns, uint64_t np, SfoFlipped* out, uint64_t* k0, uint64_t* k1, uint64_t* k2,
@@ -114,6 +163,22 @@ hipError_t sfo_flip(const hc_sfo_rec* in, uint64_t n, uint64_t ns, uint64_t np, 
 hipError_t sfo_gather(const SfoFlipped* in, const uint32_t* perm, uint64_t n, SfoFlipped* out, hipStream_t s) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(sfo_gather_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, in, perm, n, out);
+    return hipGetLastError();
+}
+
+hipError_t sfo_classify(const SfoFlipped* sorted, uint64_t n, uint64_t ns, uint64_t np, uint8_t* grouped, uint8_t* keep, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(sfo_classify_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, sorted, n, ns, np, grouped, keep);
+    return hipGetLastError();
+}
+hipError_t sfo_groups(const SfoFlipped* sorted, const uint32_t* idx, uint64_t m, uint64_t ns, uint64_t np, uint8_t* keep, hipStream_t s) {
+    if (!m) return hipSuccess;
+    hipLaunchKernelGGL(sfo_groups_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, sorted, idx, m, ns, np, keep);
+    return hipGetLastError();
+}
+hipError_t sfo_gather_kept(const SfoFlipped* sorted, const uint32_t* idx, uint64_t k, SfoFlipped* out, hipStream_t s) {
+    if (!k) return hipSuccess;
+    hipLaunchKernelGGL(sfo_gather_kept_kernel, dim3((unsigned)((k + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, sorted, idx, k, out);
     return hipGetLastError();
 }
 

@@ -269,17 +269,19 @@ def test_ingest_from_the_device_records_writes_the_same_file(tmp_path, case):
         assert want_n == want.count(b"\n") and want_n > 50
         # pieces per chunk of the sorted run, records per chunk (the default takes these inputs in one chunk; 1 and 3: nearly
         # every group of paired candidates straddles a chunk border and waits in the carry)
-        for pieces, chunk in ((None, None), ("1", None), ("7", None), ("200", None), (None, "1"), (None, "3"), ("3", "1000"), (None, "4096")):
-            if pieces:
-                os.environ["HC_SFO_BUCKETS"] = pieces
-            if chunk:
-                os.environ["HC_SFO_CHUNK"] = chunk
+        # ... and with / without the device's choice of the records the matching can see anything of (lines between unpaired reads,
+        # groups of two lines and more, the lines that close them; HC_SFO_FILTER=0: every sorted record goes to the host)
+        for pieces, chunk, filt in ((None, None, None), ("1", None, None), ("7", None, None), ("200", None, "0"), (None, "1", None), (None, "3", None),
+                                    ("3", "1000", "0"), (None, "4096", None), (None, None, "0"), (None, "2", "0")):
+            for k, v in (("HC_SFO_BUCKETS", pieces), ("HC_SFO_CHUNK", chunk), ("HC_SFO_FILTER", filt)):
+                if v:
+                    os.environ[k] = v
             try:
                 got_n = sc.found_to_overlaps(tmp_path / "got.txt", n_single, n_pairs)
             finally:
-                os.environ.pop("HC_SFO_BUCKETS", None)
-                os.environ.pop("HC_SFO_CHUNK", None)
-            assert got_n == want_n and (tmp_path / "got.txt").read_bytes() == want, (pieces, chunk)
+                for k in ("HC_SFO_BUCKETS", "HC_SFO_CHUNK", "HC_SFO_FILTER"):
+                    os.environ.pop(k, None)
+            assert got_n == want_n and (tmp_path / "got.txt").read_bytes() == want, (pieces, chunk, filt)
         # ids that do not fit --num_singles / --num_pairs: the host path's diagnosis
         if n_pairs:
             with pytest.raises(hc.HcError) as ei:
