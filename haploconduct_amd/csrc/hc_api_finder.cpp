@@ -192,7 +192,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     HC_ALLOC(d_val, (S + 1) * 8);
     HC_HIP(hipMemsetAsync(d_val.p, 0, (S + 1) * 8, st));
     HC_HIP(hc::finder_count_valid(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori, d_v1.as<uint64_t>(),
-                                  d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_val.as<uint64_t>(), st));
+                                  d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), min_overlap, flags, d_val.as<uint64_t>(), st));
     {
         size_t b = 0;
         HC_HIP(hc::finder_scan(nullptr, b, d_val.as<uint64_t>(), d_off.as<uint64_t>(), S + 1, st));
@@ -267,7 +267,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     for (const Batch& bt : batches) {
         const uint64_t Hb = bt.hits;
         HC_HIP(hc::finder_expand(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), bt.q0, bt.q1, bt.base, k, s, n_ori, d_v1.as<uint64_t>(),
-                                 d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), d_h0.as<uint64_t>(), st));
+                                 d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), min_overlap, flags, d_h0.as<uint64_t>(), st));
         size_t bs = tmp_bytes;
         HC_HIP(hc::finder_sort_keys(d_tmp.p, bs, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), Hb, st));
         bs = tmp_bytes;

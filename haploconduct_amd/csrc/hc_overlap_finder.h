@@ -24,10 +24,11 @@ hipError_t finder_seeds(const void* sym, uint32_t symbytes, bool wide, const Seq
                         uint32_t k, uint32_t s, uint32_t n_ori, const uint64_t* keys, uint64_t n_keys, uint64_t* seed_lo,
                         uint64_t* seed_cnt, hipStream_t stream);
 hipError_t finder_count_valid(const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
-                              const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, uint64_t* seed_valid, hipStream_t stream);
+                              const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, uint32_t min_overlap, uint32_t flags,
+                              uint64_t* seed_valid, hipStream_t stream);
 hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_t q_begin, uint32_t q_end, uint64_t out_base, uint32_t k,
                          uint32_t s, uint32_t n_ori, const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt,
-                         const uint64_t* seed_out, uint64_t* out_keys, hipStream_t stream);
+                         const uint64_t* seed_out, uint32_t min_overlap, uint32_t flags, uint64_t* out_keys, hipStream_t stream);
 hipError_t finder_verify(const void* sym, uint32_t symbytes, bool wide, const SeqRef* by_sfo, const uint64_t* keys, uint64_t n,
                          double err_rate, uint32_t min_overlap, uint32_t flags, uint32_t* kout, uint32_t* flag, hipStream_t stream);
 hipError_t finder_emit(const SeqRef* by_sfo, const uint64_t* keys, const uint32_t* kout, const uint32_t* flag, const uint32_t* pos, uint64_t n,

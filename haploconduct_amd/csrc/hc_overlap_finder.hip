@@ -121,12 +121,22 @@ __device__ __forceinline__ uint64_t pack_key(uint32_t idA, uint32_t idB, uint32_
 
 constexpr uint64_t kFewHits = 24;  // up to this many hits a seed is handled by one lane, above by a whole wave
 
+// Whether a diagonal can be reported at all — a function of the two lengths alone, asked of every seed hit BEFORE it becomes a
+// key (a third of the hits at 150 bp and T = 90 lie on diagonals of shorter overlaps) and again by the verification:
+// B[0] aligns with A[d]; the overlap is [max(0, d), min(la, d + lb)).
+__device__ __forceinline__ bool diagonal_wanted(int d, int la, int lb, uint32_t min_overlap, uint32_t flags) {
+    const int start = d > 0 ? d : 0, end = la < d + lb ? la : d + lb;
+    const bool inclusion = (d >= 0 && d + lb <= la) || (d <= 0 && d + lb >= la);
+    return end - start >= (int)min_overlap && (!inclusion || (flags & HC_FIND_INCLUSIONS));
+}
+
 // Number of hits of every seed that will become a candidate: the indexed sequence has the lower id (every unordered pair
-// once).  Replaces the raw hit counts before the scan, so that only those keys are written and sorted.
+// once) and the diagonal can be reported.  Replaces the raw hit counts before the scan, so that only those keys are written and sorted.
 __global__ __launch_bounds__(256) void finder_count_valid_kernel(const SeqRef* __restrict__ seqs, const uint64_t* __restrict__ seed_start,
                                                                  uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
                                                                  const uint64_t* __restrict__ vals, const uint64_t* __restrict__ seed_lo,
-                                                                 const uint64_t* __restrict__ seed_cnt, uint64_t* __restrict__ seed_valid) {
+                                                                 const uint64_t* __restrict__ seed_cnt, uint32_t min_overlap, uint32_t flags,
+                                                                 uint64_t* __restrict__ seed_valid) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -139,16 +149,26 @@ __global__ __launch_bounds__(256) void finder_count_valid_kernel(const SeqRef* _
             const uint64_t sid = seed_start[q] + j;
             const uint64_t cnt = seed_cnt[sid], lo = seed_lo[sid];
             if (cnt > kFewHits) continue;
+            const int p = (int)((j % nt) * s);
             uint32_t mine = 0;
-            for (uint64_t h = 0; h < cnt; h++) mine += seqs[(uint32_t)(vals[lo + h] >> 32)].sfo_id < r.sfo_id;
+            for (uint64_t h = 0; h < cnt; h++) {
+                const uint64_t v = vals[lo + h];
+                const SeqRef a = seqs[(uint32_t)(v >> 32)];
+                mine += a.sfo_id < r.sfo_id && diagonal_wanted((int)(uint32_t)v - p, (int)a.len, (int)r.len, min_overlap, flags);
+            }
             seed_valid[sid] = mine;
         }
         for (uint32_t j = 0; j < nt * n_ori; j++) {
             const uint64_t sid = seed_start[q] + j;
             const uint64_t cnt = seed_cnt[sid], lo = seed_lo[sid];
             if (cnt <= kFewHits) continue;
+            const int p = (int)((j % nt) * s);
             uint32_t mine = 0;
-            for (uint64_t h = lane; h < cnt; h += 64u) mine += seqs[(uint32_t)(vals[lo + h] >> 32)].sfo_id < r.sfo_id;
+            for (uint64_t h = lane; h < cnt; h += 64u) {
+                const uint64_t v = vals[lo + h];
+                const SeqRef a = seqs[(uint32_t)(v >> 32)];
+                mine += a.sfo_id < r.sfo_id && diagonal_wanted((int)(uint32_t)v - p, (int)a.len, (int)r.len, min_overlap, flags);
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor((int)mine, o, 64);
             if (lane == 0) seed_valid[sid] = mine;
@@ -161,7 +181,8 @@ __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __rest
                                                             uint32_t n_ori,
                                                             const uint64_t* __restrict__ vals, const uint64_t* __restrict__ seed_lo,
                                                             const uint64_t* __restrict__ seed_cnt,
-                                                            const uint64_t* __restrict__ seed_out, uint64_t* __restrict__ out_keys) {
+                                                            const uint64_t* __restrict__ seed_out, uint32_t min_overlap, uint32_t flags,
+                                                            uint64_t* __restrict__ out_keys) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -180,8 +201,9 @@ __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __rest
             uint64_t at = seed_out[sid] - out_base;
             for (uint64_t h = 0; h < cnt; h++) {
                 const uint64_t v = vals[lo + h];
-                const uint32_t ida = seqs[(uint32_t)(v >> 32)].sfo_id;
-                if (ida < r.sfo_id) out_keys[at++] = pack_key(ida, r.sfo_id, o, (int)(uint32_t)v - p);
+                const SeqRef a = seqs[(uint32_t)(v >> 32)];
+                const int d = (int)(uint32_t)v - p;
+                if (a.sfo_id < r.sfo_id && diagonal_wanted(d, (int)a.len, (int)r.len, min_overlap, flags)) out_keys[at++] = pack_key(a.sfo_id, r.sfo_id, o, d);
             }
         }
         // repeat-rich seeds: the hits of one seed are spread over the lanes, so that it does not stall a single lane
@@ -198,8 +220,9 @@ __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __rest
                 uint64_t key = kNoKey;
                 if (h < cnt) {
                     const uint64_t v = vals[lo + h];
-                    const uint32_t ida = seqs[(uint32_t)(v >> 32)].sfo_id;
-                    if (ida < r.sfo_id) key = pack_key(ida, r.sfo_id, o, (int)(uint32_t)v - p);
+                    const SeqRef a = seqs[(uint32_t)(v >> 32)];
+                    const int d = (int)(uint32_t)v - p;
+                    if (a.sfo_id < r.sfo_id && diagonal_wanted(d, (int)a.len, (int)r.len, min_overlap, flags)) key = pack_key(a.sfo_id, r.sfo_id, o, d);
                 }
                 const uint64_t m = __ballot(key != kNoKey);
                 if (key != kNoKey) out_keys[at + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
@@ -240,8 +263,7 @@ __global__ __launch_bounds__(256) void finder_verify_kernel(const void* __restri
             const int la = (int)A.len, lb = (int)B.len;
             const int start = d > 0 ? d : 0, end = la < d + lb ? la : d + lb;
             const int L = end - start;
-            const bool inclusion = (d >= 0 && d + lb <= la) || (d <= 0 && d + lb >= la);
-            if (L >= (int)min_overlap && (!inclusion || (flags & HC_FIND_INCLUSIONS))) {
+            if (diagonal_wanted(d, la, lb, min_overlap, flags)) {
                 const uint32_t kmax = (uint32_t)(err_rate * (double)L);
                 const uint64_t offb = o ? B.off + B.rc_delta : B.off;
                 if (SB == 1) {  // 8 symbols per step (slots are padded: reading a few bytes past the end is safe)
@@ -341,17 +363,18 @@ hipError_t finder_seeds(const void* sym, uint32_t symbytes, bool wide, const Seq
 }
 
 hipError_t finder_count_valid(const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
-                              const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, uint64_t* seed_valid, hipStream_t stream) {
+                              const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, uint32_t min_overlap, uint32_t flags,
+                              uint64_t* seed_valid, hipStream_t stream) {
     hipLaunchKernelGGL(finder_count_valid_kernel, dim3(wave_grid(n_seq)), dim3(256), 0, stream, seqs, seed_start, n_seq, k, s, n_ori, vals,
-                       seed_lo, seed_cnt, seed_valid);
+                       seed_lo, seed_cnt, min_overlap, flags, seed_valid);
     return hipGetLastError();
 }
 
 hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_t q_begin, uint32_t q_end, uint64_t out_base, uint32_t k,
                          uint32_t s, uint32_t n_ori, const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt,
-                         const uint64_t* seed_out, uint64_t* out_keys, hipStream_t stream) {
+                         const uint64_t* seed_out, uint32_t min_overlap, uint32_t flags, uint64_t* out_keys, hipStream_t stream) {
     hipLaunchKernelGGL(finder_expand_kernel, dim3(wave_grid(q_end - q_begin)), dim3(256), 0, stream, seqs, seed_start, q_begin, q_end,
-                       out_base, k, s, n_ori, vals, seed_lo, seed_cnt, seed_out, out_keys);
+                       out_base, k, s, n_ori, vals, seed_lo, seed_cnt, seed_out, min_overlap, flags, out_keys);
     return hipGetLastError();
 }
 
