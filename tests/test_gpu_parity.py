@@ -408,6 +408,16 @@ def test_fuzz_through_the_lds_dma_form(oracle, monkeypatch, seed):
     test_fuzz_random_read_sets_settings_and_geometry(oracle, seed)
 
 
+@pytest.mark.parametrize("align", ["16", "64", "256"])
+@pytest.mark.parametrize("seed", [1, 2, 3, 7, 10])
+def test_slot_alignment_of_the_store_changes_nothing(oracle, monkeypatch, align, seed):
+    """hc_set_reads starts every read slot on a 128-byte line while the store stays inside the Infinity Cache and packs the slots
+    (16 bytes) beyond that; HC_SLOT_ALIGN forces a stride.  The fuzz scenarios (regular and irregular stores, all three encodings)
+    under the packed layout the 10^8-candidate set gets, and under two more."""
+    monkeypatch.setenv("HC_SLOT_ALIGN", align)
+    test_fuzz_random_read_sets_settings_and_geometry(oracle, seed)
+
+
 @pytest.mark.parametrize("fetch", ["coop", "4", "2"])
 @pytest.mark.parametrize("regular", ["1", "0"])
 @pytest.mark.parametrize("n_quals", [5, 12, 25, 40, 60])  # the three dense / sparse 8-bit tables, the wide 8-bit encoding (per lane: 512-lane workgroups), 16-bit symbols
