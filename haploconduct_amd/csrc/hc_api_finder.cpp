@@ -156,14 +156,18 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     const uint64_t P = pos_start[n_seq], S = seed_start[n_seq];
     if (P >= (1ull << 31) || S >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: read set too large for one call (2^31 positions)");
 
-    DevBuf d_seqs, d_by_sfo, d_pos_start, d_seed_start, d_k0, d_k1, d_v0, d_v1, d_tmp, d_lo, d_cnt, d_off, d_count;
+    DevBuf d_idlen, d_seqs, d_by_sfo, d_pos_start, d_seed_start, d_k0, d_k1, d_v0, d_v1, d_tmp, d_lo, d_cnt, d_off, d_count;
     HC_ALLOC(d_seqs, n_seq * sizeof(hc::SeqRef));
     HC_ALLOC(d_by_sfo, n_seq * sizeof(hc::SeqRef));
+    HC_ALLOC(d_idlen, n_seq * sizeof(uint2));
     HC_ALLOC(d_pos_start, (n_seq + 1) * sizeof(uint64_t));
     HC_ALLOC(d_seed_start, (n_seq + 1) * sizeof(uint64_t));
     HC_ALLOC(d_count, sizeof(unsigned long long));
     HC_HIP(hipMemcpyAsync(d_seqs.p, c->seq_refs.data(), n_seq * sizeof(hc::SeqRef), hipMemcpyHostToDevice, st));
     HC_HIP(hipMemcpyAsync(d_by_sfo.p, by_sfo.data(), n_seq * sizeof(hc::SeqRef), hipMemcpyHostToDevice, st));
+    std::vector<uint2> idlen(n_seq);  // what a seed hit asks of the indexed sequence: 8 bytes instead of a SeqRef
+    for (uint32_t q = 0; q < n_seq; q++) idlen[q] = make_uint2(c->seq_refs[q].sfo_id, c->seq_refs[q].len);
+    HC_HIP(hipMemcpyAsync(d_idlen.p, idlen.data(), n_seq * sizeof(uint2), hipMemcpyHostToDevice, st));
     HC_HIP(hipMemcpyAsync(d_pos_start.p, pos_start.data(), (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     HC_HIP(hipMemcpyAsync(d_seed_start.p, seed_start.data(), (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
 
@@ -191,7 +195,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     DevBuf d_val;
     HC_ALLOC(d_val, (S + 1) * 8);
     HC_HIP(hipMemsetAsync(d_val.p, 0, (S + 1) * 8, st));
-    HC_HIP(hc::finder_count_valid(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori, d_v1.as<uint64_t>(),
+    HC_HIP(hc::finder_count_valid(d_seqs.as<hc::SeqRef>(), d_idlen.as<uint2>(), d_seed_start.as<uint64_t>(), n_seq, k, s, n_ori, d_v1.as<uint64_t>(),
                                   d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), min_overlap, flags, d_val.as<uint64_t>(), st));
     {
         size_t b = 0;
@@ -266,7 +270,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     size_t res_cap = acc.cap / sizeof(hc_sfo_rec);  // records
     for (const Batch& bt : batches) {
         const uint64_t Hb = bt.hits;
-        HC_HIP(hc::finder_expand(d_seqs.as<hc::SeqRef>(), d_seed_start.as<uint64_t>(), bt.q0, bt.q1, bt.base, k, s, n_ori, d_v1.as<uint64_t>(),
+        HC_HIP(hc::finder_expand(d_seqs.as<hc::SeqRef>(), d_idlen.as<uint2>(), d_seed_start.as<uint64_t>(), bt.q0, bt.q1, bt.base, k, s, n_ori, d_v1.as<uint64_t>(),
                                  d_lo.as<uint64_t>(), d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), min_overlap, flags, d_h0.as<uint64_t>(), st));
         size_t bs = tmp_bytes;
         HC_HIP(hc::finder_sort_keys(d_tmp.p, bs, d_h0.as<uint64_t>(), d_h1.as<uint64_t>(), Hb, st));

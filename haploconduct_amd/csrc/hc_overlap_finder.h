@@ -23,10 +23,10 @@ hipError_t finder_index(const void* sym, uint32_t symbytes, bool wide, const Seq
 hipError_t finder_seeds(const void* sym, uint32_t symbytes, bool wide, const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq,
                         uint32_t k, uint32_t s, uint32_t n_ori, const uint64_t* keys, uint64_t n_keys, uint64_t* seed_lo,
                         uint64_t* seed_cnt, hipStream_t stream);
-hipError_t finder_count_valid(const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
+hipError_t finder_count_valid(const SeqRef* seqs, const uint2* idlen /* (sfo id, length) per sequence */, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
                               const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, uint32_t min_overlap, uint32_t flags,
                               uint64_t* seed_valid, hipStream_t stream);
-hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_t q_begin, uint32_t q_end, uint64_t out_base, uint32_t k,
+hipError_t finder_expand(const SeqRef* seqs, const uint2* idlen, const uint64_t* seed_start, uint32_t q_begin, uint32_t q_end, uint64_t out_base, uint32_t k,
                          uint32_t s, uint32_t n_ori, const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt,
                          const uint64_t* seed_out, uint32_t min_overlap, uint32_t flags, uint64_t* out_keys, hipStream_t stream);
 hipError_t finder_verify(const void* sym, uint32_t symbytes, bool wide, const SeqRef* by_sfo, const uint64_t* keys, uint64_t n,

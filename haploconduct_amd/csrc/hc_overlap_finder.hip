@@ -132,7 +132,8 @@ __device__ __forceinline__ bool diagonal_wanted(int d, int la, int lb, uint32_t 
 
 // Number of hits of every seed that will become a candidate: the indexed sequence has the lower id (every unordered pair
 // once) and the diagonal can be reported.  Replaces the raw hit counts before the scan, so that only those keys are written and sorted.
-__global__ __launch_bounds__(256) void finder_count_valid_kernel(const SeqRef* __restrict__ seqs, const uint64_t* __restrict__ seed_start,
+__global__ __launch_bounds__(256) void finder_count_valid_kernel(const SeqRef* __restrict__ seqs, const uint2* __restrict__ idlen,
+                                                                 const uint64_t* __restrict__ seed_start,
                                                                  uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
                                                                  const uint64_t* __restrict__ vals, const uint64_t* __restrict__ seed_lo,
                                                                  const uint64_t* __restrict__ seed_cnt, uint32_t min_overlap, uint32_t flags,
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(256) void finder_count_valid_kernel(const SeqRef* _
             uint32_t mine = 0;
             for (uint64_t h = 0; h < cnt; h++) {
                 const uint64_t v = vals[lo + h];
-                const SeqRef a = seqs[(uint32_t)(v >> 32)];
-                mine += a.sfo_id < r.sfo_id && diagonal_wanted((int)(uint32_t)v - p, (int)a.len, (int)r.len, min_overlap, flags);
+                const uint2 a = idlen[(uint32_t)(v >> 32)];  // (sfo id, length) of the indexed sequence: 8 bytes a hit, not a 24-byte SeqRef
+                mine += a.x < r.sfo_id && diagonal_wanted((int)(uint32_t)v - p, (int)a.y, (int)r.len, min_overlap, flags);
             }
             seed_valid[sid] = mine;
         }
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(256) void finder_count_valid_kernel(const SeqRef* _
             uint32_t mine = 0;
             for (uint64_t h = lane; h < cnt; h += 64u) {
                 const uint64_t v = vals[lo + h];
-                const SeqRef a = seqs[(uint32_t)(v >> 32)];
-                mine += a.sfo_id < r.sfo_id && diagonal_wanted((int)(uint32_t)v - p, (int)a.len, (int)r.len, min_overlap, flags);
+                const uint2 a = idlen[(uint32_t)(v >> 32)];  // (sfo id, length) of the indexed sequence: 8 bytes a hit, not a 24-byte SeqRef
+                mine += a.x < r.sfo_id && diagonal_wanted((int)(uint32_t)v - p, (int)a.y, (int)r.len, min_overlap, flags);
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor((int)mine, o, 64);
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(256) void finder_count_valid_kernel(const SeqRef* _
     }
 }
 
-__global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __restrict__ seqs, const uint64_t* __restrict__ seed_start,
+__global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __restrict__ seqs, const uint2* __restrict__ idlen,
+                                                            const uint64_t* __restrict__ seed_start,
                                                             uint32_t q_begin, uint32_t n_seq, uint64_t out_base, uint32_t k, uint32_t s,
                                                             uint32_t n_ori,
                                                             const uint64_t* __restrict__ vals, const uint64_t* __restrict__ seed_lo,
@@ -201,9 +203,9 @@ __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __rest
             uint64_t at = seed_out[sid] - out_base;
             for (uint64_t h = 0; h < cnt; h++) {
                 const uint64_t v = vals[lo + h];
-                const SeqRef a = seqs[(uint32_t)(v >> 32)];
+                const uint2 a = idlen[(uint32_t)(v >> 32)];  // (sfo id, length) of the indexed sequence: 8 bytes a hit, not a 24-byte SeqRef
                 const int d = (int)(uint32_t)v - p;
-                if (a.sfo_id < r.sfo_id && diagonal_wanted(d, (int)a.len, (int)r.len, min_overlap, flags)) out_keys[at++] = pack_key(a.sfo_id, r.sfo_id, o, d);
+                if (a.x < r.sfo_id && diagonal_wanted(d, (int)a.y, (int)r.len, min_overlap, flags)) out_keys[at++] = pack_key(a.x, r.sfo_id, o, d);
             }
         }
         // repeat-rich seeds: the hits of one seed are spread over the lanes, so that it does not stall a single lane
@@ -220,9 +222,9 @@ __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __rest
                 uint64_t key = kNoKey;
                 if (h < cnt) {
                     const uint64_t v = vals[lo + h];
-                    const SeqRef a = seqs[(uint32_t)(v >> 32)];
+                    const uint2 a = idlen[(uint32_t)(v >> 32)];  // (sfo id, length) of the indexed sequence: 8 bytes a hit, not a 24-byte SeqRef
                     const int d = (int)(uint32_t)v - p;
-                    if (a.sfo_id < r.sfo_id && diagonal_wanted(d, (int)a.len, (int)r.len, min_overlap, flags)) key = pack_key(a.sfo_id, r.sfo_id, o, d);
+                    if (a.x < r.sfo_id && diagonal_wanted(d, (int)a.y, (int)r.len, min_overlap, flags)) key = pack_key(a.x, r.sfo_id, o, d);
                 }
                 const uint64_t m = __ballot(key != kNoKey);
                 if (key != kNoKey) out_keys[at + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
@@ -266,14 +268,20 @@ __global__ __launch_bounds__(256) void finder_verify_kernel(const void* __restri
             if (diagonal_wanted(d, la, lb, min_overlap, flags)) {
                 const uint32_t kmax = (uint32_t)(err_rate * (double)L);
                 const uint64_t offb = o ? B.off + B.rc_delta : B.off;
-                if (SB == 1) {  // 8 symbols per step (slots are padded: reading a few bytes past the end is safe)
+                if (SB == 1) {  // 32 symbols per step, all eight loads issued before the first is looked at: the give-up test between
+                                // steps makes every step a round trip to memory, and a window of 150 symbols now takes 5 of them, not 19
+                                // (slots are padded by 32 bytes and more: reading past the end of the window is safe)
                     const uint8_t* pa = (const uint8_t*)sym + A.off + (uint64_t)start;
                     const uint8_t* pb = (const uint8_t*)sym + offb + (uint64_t)(start - d);
-                    for (int x = 0; x < L && mm <= kmax; x += 8) {
-                        uint64_t a, b;
-                        __builtin_memcpy(&a, pa + x, 8);
-                        __builtin_memcpy(&b, pb + x, 8);
-                        mm += mismatches8<WIDE>(a, b, L - x < 8 ? L - x : 8);
+                    for (int x = 0; x < L && mm <= kmax; x += 32) {
+                        uint64_t a[4], b[4];
+                        __builtin_memcpy(a, pa + x, 32);
+                        __builtin_memcpy(b, pb + x, 32);
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const int nb = L - x - 8 * w;
+                            if (nb > 0) mm += mismatches8<WIDE>(a[w], b[w], nb < 8 ? nb : 8);
+                        }
                     }
                 } else {
                     for (int x = start; x < end && mm <= kmax; x++) {
@@ -362,18 +370,18 @@ hipError_t finder_seeds(const void* sym, uint32_t symbytes, bool wide, const Seq
     return hipGetLastError();
 }
 
-hipError_t finder_count_valid(const SeqRef* seqs, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
+hipError_t finder_count_valid(const SeqRef* seqs, const uint2* idlen, const uint64_t* seed_start, uint32_t n_seq, uint32_t k, uint32_t s, uint32_t n_ori,
                               const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt, uint32_t min_overlap, uint32_t flags,
                               uint64_t* seed_valid, hipStream_t stream) {
-    hipLaunchKernelGGL(finder_count_valid_kernel, dim3(wave_grid(n_seq)), dim3(256), 0, stream, seqs, seed_start, n_seq, k, s, n_ori, vals,
+    hipLaunchKernelGGL(finder_count_valid_kernel, dim3(wave_grid(n_seq)), dim3(256), 0, stream, seqs, idlen, seed_start, n_seq, k, s, n_ori, vals,
                        seed_lo, seed_cnt, min_overlap, flags, seed_valid);
     return hipGetLastError();
 }
 
-hipError_t finder_expand(const SeqRef* seqs, const uint64_t* seed_start, uint32_t q_begin, uint32_t q_end, uint64_t out_base, uint32_t k,
+hipError_t finder_expand(const SeqRef* seqs, const uint2* idlen, const uint64_t* seed_start, uint32_t q_begin, uint32_t q_end, uint64_t out_base, uint32_t k,
                          uint32_t s, uint32_t n_ori, const uint64_t* vals, const uint64_t* seed_lo, const uint64_t* seed_cnt,
                          const uint64_t* seed_out, uint32_t min_overlap, uint32_t flags, uint64_t* out_keys, hipStream_t stream) {
-    hipLaunchKernelGGL(finder_expand_kernel, dim3(wave_grid(q_end - q_begin)), dim3(256), 0, stream, seqs, seed_start, q_begin, q_end,
+    hipLaunchKernelGGL(finder_expand_kernel, dim3(wave_grid(q_end - q_begin)), dim3(256), 0, stream, seqs, idlen, seed_start, q_begin, q_end,
                        out_base, k, s, n_ori, vals, seed_lo, seed_cnt, seed_out, min_overlap, flags, out_keys);
     return hipGetLastError();
 }
