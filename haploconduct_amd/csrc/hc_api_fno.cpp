@@ -138,44 +138,103 @@ bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_
     auto now = [] { return std::chrono::steady_clock::now(); };
     const auto t0 = now();
     hipStream_t st = nullptr;
-    uint64_t E = 0;
-    for (uint32_t k = 0; k < h.n_spans; k++) E += h.spans[k].n;
-    if (E == 0 || E >= 0x7FFFFFF0ull || h.n_srs >= 0xFFFFFFFFull) return false;
+    const bool debug = getenv("HC_FNO_DEBUG") != nullptr;
+    auto left = [&](const char* where, unsigned long long status) {  // why the host form takes over (HC_FNO_DEBUG)
+        if (debug) fprintf(stderr, "[hc fno] the device route ends at %s, status %llu\n", where, status);
+        return false;
+    };
+    const uint64_t G = h.graph.n, B = h.branching.n, N = h.nonedges.n, I = h.induced.n;
+    if (G + B + N + I == 0 || G + B + N + I >= 0x7FFFFFF0ull || h.n_srs >= 0xFFFFFFFFull || h.n_nodes >= 0xFFFFFFFFull) return false;
     uint32_t id_bits = 1;
     while (id_bits < 64 && (h.new_read_count - 1) >> id_bits) id_bits++;
     if (h.new_read_count == 0 || 2 * id_bits > 62) return false;
     DeviceBuffers d;
     FnoWalkInput w{};
-    {
-        hc_fno_edge* d_edges = d.get<hc_fno_edge>(E);
-        uint64_t at = 0;
-        for (uint32_t k = 0; k < h.n_spans; k++) {
-            if (h.spans[k].n) hip_check(hipMemcpyAsync(d_edges + at, h.spans[k].p, h.spans[k].n * sizeof(hc_fno_edge), hipMemcpyHostToDevice, st), "copy of the edges");
-            at += h.spans[k].n;
-        }
-        w.edges = d_edges;
-        w.n_edges = E;
-    }
+    unsigned long long* d_status = d.get<unsigned long long>(kFnoCounters);
+    hip_check(hipMemsetAsync(d_status, 0, kFnoCounters * sizeof(unsigned long long), st), "memset");
+    unsigned long long h_status[kFnoCounters];
     auto upload = [&](auto* dst_tag, const void* src, uint64_t count, const char* what) {
         using T = std::remove_pointer_t<decltype(dst_tag)>;
         T* p = d.get<T>(count);
         if (count) hip_check(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st), what);
         return (const T*)p;
     };
+    // the edges in walk order: [adj_out][branching][stored non-edges that pass :702][inclusion-induced]
+    hc_fno_edge* d_edges = d.get<hc_fno_edge>(G + B + N + I);
+    if (G) hip_check(hipMemcpyAsync(d_edges, h.graph.p, G * sizeof(hc_fno_edge), hipMemcpyHostToDevice, st), "copy of the edges");
+    if (B) hip_check(hipMemcpyAsync(d_edges + G, h.branching.p, B * sizeof(hc_fno_edge), hipMemcpyHostToDevice, st), "copy of the edges");
+    uint64_t kept = 0;
+    if (N) {
+        const hc_fno_edge* d_non = upload((hc_fno_edge*)nullptr, h.nonedges.p, N, "copy of the stored non-edges");
+        uint64_t* d_adj = d.get<uint64_t>(h.n_nodes + 1);
+        uint8_t* d_keep = d.get<uint8_t>(N);
+        uint32_t* d_idx = d.get<uint32_t>(N);
+        const size_t sel_bytes = prims::select_temp_bytes(N);
+        void* d_sel = d.get<char>(sel_bytes);
+        hip_check(fno_adj_offsets(d_edges, G, h.n_nodes, d_adj, d_status, st), "adj_out");
+        hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
+        hip_check(hipStreamSynchronize(st), "synchronize");
+        if (h_status[4]) return left("adj_out", h_status[4]);  // unsorted or out of range: the host form
+        hip_check(fno_nonedge_filter(d_non, N, d_edges, d_adj, h.n_nodes, d_keep, d_status, st), "stored non-edges");
+        hip_check(prims::select_flagged(d_sel, sel_bytes, d_keep, N, d_idx, d_status + 5, st), "select");
+        hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
+        hip_check(hipStreamSynchronize(st), "synchronize");
+        if (h_status[4]) return left("the stored non-edges", h_status[4]);
+        kept = h_status[5];
+        hip_check(fno_gather_edges(d_non, d_idx, kept, d_edges + G + B, st), "gather");
+        hip_check(hipStreamSynchronize(st), "synchronize");
+        d.release((void*)d_non);
+        d.release(d_adj);
+        d.release(d_keep);
+        d.release(d_idx);
+        d.release(d_sel);
+    }
+    if (I) hip_check(hipMemcpyAsync(d_edges + G + B + kept, h.induced.p, I * sizeof(hc_fno_edge), hipMemcpyHostToDevice, st), "copy of the edges");
+    const uint64_t E = G + B + kept + I;
+    if (E == 0) return false;
+    w.edges = d_edges;
+    w.n_edges = E;
     w.nodes = upload((hc_fno_read*)nullptr, h.nodes, h.n_nodes, "copy of the vertices");
     w.n_nodes = h.n_nodes;
     w.srs = upload((hc_fno_read*)nullptr, h.srs, h.n_srs, "copy of the super-reads");
     w.n_srs = h.n_srs;
-    w.n2s_off = upload((uint64_t*)nullptr, h.n2s_off, h.n_nodes + 1, "copy of nodes_to_SR");
-    w.n2s = upload((uint32_t*)nullptr, h.n2s, h.n2s_off[h.n_nodes], "copy of nodes_to_SR");
+    {  // nodes_to_SR: (vertex, super-read) per clique member, a stable sort by vertex, the offsets
+        const uint64_t total = h.n_srs ? h.clique_off[h.n_srs] : 0;
+        if (total >= 0x7FFFFFF0ull) return false;
+        const uint64_t* d_cn = upload((uint64_t*)nullptr, h.clique_nodes, total, "copy of the cliques");
+        const uint64_t* d_co = upload((uint64_t*)nullptr, h.clique_off, h.n_srs + 1, "copy of the cliques");
+        uint64_t *d_key = d.get<uint64_t>(total), *d_key_sorted = d.get<uint64_t>(total);
+        uint32_t *d_sr = d.get<uint32_t>(total), *d_n2s = d.get<uint32_t>(total);
+        uint64_t* d_n2s_off = d.get<uint64_t>(h.n_nodes + 1);
+        hip_check(fno_clique_pairs(d_cn, d_co, h.n_srs, total, h.n_nodes, d_key, d_sr, d_status, st), "nodes_to_SR");
+        if (total) {
+            size_t sort_bytes = 0;
+            hip_check(sort_pairs_u64_u32(nullptr, sort_bytes, d_key, d_key_sorted, d_sr, d_n2s, (uint32_t)total, 64, st), "sort size");
+            void* d_tmp = d.get<char>(sort_bytes);
+            uint32_t node_bits = 1;
+            while (node_bits < 64 && (h.n_nodes - 1) >> node_bits) node_bits++;
+            hip_check(sort_pairs_u64_u32(d_tmp, sort_bytes, d_key, d_key_sorted, d_sr, d_n2s, (uint32_t)total, (int)node_bits, st), "sort");
+            hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
+            hip_check(hipStreamSynchronize(st), "synchronize");
+            if (h_status[4]) return left("nodes_to_SR", h_status[4]);  // a clique names a vertex the graph does not have
+            d.release(d_tmp);
+        }
+        hip_check(fno_offsets(d_key_sorted, total, h.n_nodes, d_n2s_off, st), "nodes_to_SR offsets");
+        hip_check(hipStreamSynchronize(st), "synchronize");
+        d.release((void*)d_cn);
+        d.release((void*)d_co);
+        d.release(d_key);
+        d.release(d_key_sorted);
+        d.release(d_sr);
+        w.n2s = d_n2s;
+        w.n2s_off = d_n2s_off;
+    }
     w.subread_off = upload((uint64_t*)nullptr, h.subread_off, h.n_srs + 1, "copy of the subread maps");
     w.subreads = upload((hc_fno_subread*)nullptr, h.subreads, h.n_srs ? h.subread_off[h.n_srs] : 0, "copy of the subread maps");
     w.new_read_count = h.new_read_count;
     w.id_bits = id_bits;
     w.resolve_orientations = h.resolve_orientations ? 1u : 0u;
 
-    unsigned long long* d_status = d.get<unsigned long long>(kFnoCounters);
-    hip_check(hipMemsetAsync(d_status, 0, kFnoCounters * sizeof(unsigned long long), st), "memset");
     uint64_t *d_off_comb = d.get<uint64_t>(E + 1), *d_off_direct = d.get<uint64_t>(E + 1);
     hip_check(fno_walk_count(w, d_off_comb, d_off_direct, d_status, st), "count");
     size_t scan_bytes = 0;
@@ -188,12 +247,11 @@ bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_
         hip_check(finder_scan(d_scan_tmp, b, d_off_direct, d_off_direct, E + 1, st), "scan");
     }
     uint64_t n_comb = 0, n_direct = 0;
-    unsigned long long h_status[kFnoCounters];
     hip_check(hipMemcpyAsync(&n_comb, d_off_comb + E, 8, hipMemcpyDeviceToHost, st), "count of the combinations");
     hip_check(hipMemcpyAsync(&n_direct, d_off_direct + E, 8, hipMemcpyDeviceToHost, st), "count of the copied edges");
     hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
     hip_check(hipStreamSynchronize(st), "synchronize");
-    if (h_status[4] || n_comb >= 0x7FFFFFF0ull || n_direct + n_comb >= 0x7FFFFFF0ull) return false;
+    if (h_status[4] || n_comb >= 0x7FFFFFF0ull || n_direct + n_comb >= 0x7FFFFFF0ull) return left("the count of the combinations", h_status[4]);
 
     uint32_t* d_val_sorted = nullptr;
     uint32_t* d_head_pos = nullptr;
@@ -215,7 +273,7 @@ bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_
         hip_check(prims::select_flagged(d_tmp, sel_bytes, d_flag, n_comb, d_head_pos, d_status + 5, st), "select");
         hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
         hip_check(hipStreamSynchronize(st), "synchronize");
-        if (h_status[4]) return false;
+        if (h_status[4]) return left("the pairs of new ids", h_status[4]);
         n_heads = h_status[5];
         d.release(d_key);
         d.release(d_key_sorted);
@@ -224,14 +282,14 @@ bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_
         d.release(d_tmp);
     }
     const uint64_t n_items = n_direct + n_heads;
-    if (n_items == 0) return false;  // (nothing to write: the host form says so in its own way)
+    if (n_items == 0) return left("no combination kept", 0);  // (nothing to write: the host form says so in its own way)
     uint32_t* d_direct_edge = d.get<uint32_t>(n_direct);
     hip_check(fno_walk_direct(d_off_direct, E, d_direct_edge, st), "copied edges");
     FnoItem* d_items = d.get<FnoItem>(n_items);
     hip_check(fno_walk_items(w, d_off_comb, d_direct_edge, n_direct, d_val_sorted, d_head_pos, n_heads, d_items, d_status, st), "items");
     hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
     hip_check(hipStreamSynchronize(st), "synchronize");
-    if (h_status[4]) return false;
+    if (h_status[4]) return left("the look-ups", h_status[4]);
     // the walk's inputs are spent
     d.release((void*)w.edges);
     d.release(d_off_comb);
@@ -243,6 +301,7 @@ bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_
     const auto t1 = now();
     double sec2[2] = {0, 0};
     const bool ok = lines_from_device_items(d, d_items, n_items, h.no_inclusions, text_of, counters, sec2, t1);
+    if (!ok) left("computeOverlapData", 0);
     if (seconds) {
         seconds[0] = std::chrono::duration<double>(t1 - t0).count();
         seconds[1] = sec2[0];

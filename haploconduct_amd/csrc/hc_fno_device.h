@@ -17,7 +17,8 @@ namespace hc {
 
 enum : unsigned long long {
     kFnoStatusRequire = 1,  // an assert / .at() of the reference would fire: the host path reports which
-    kFnoStatusRange = 2     // a number outside what the keys hold (id >= 10^10, perc > 999): the host path takes over
+    kFnoStatusRange = 2,    // a number outside what the keys hold (id >= 10^10, perc > 999): the host path takes over
+    kFnoStatusUnsorted = 4  // graph_edges do not come vertex by vertex: the host form builds adj_out by counting
 };
 // counters: [0..3] lines per kind before the unique (hc_fno_counters), [4] status bits, [5] lines after the unique
 constexpr int kFnoCounters = 6;
@@ -44,6 +45,14 @@ struct FnoWalkInput {  // device pointers
     uint32_t id_bits;  // ids < new_read_count < 2^id_bits; a pair's key is lo << id_bits | hi
     uint32_t resolve_orientations;
 };
+// what the walk needs first: adj_out's offsets from the sorted graph_edges, the stored non-edges that pass :702, nodes_to_SR from the cliques
+hipError_t fno_adj_offsets(const hc_fno_edge* ge, uint64_t G, uint64_t n_nodes, uint64_t* off, unsigned long long* counters, hipStream_t s);
+hipError_t fno_nonedge_filter(const hc_fno_edge* nonedges, uint64_t n, const hc_fno_edge* ge, const uint64_t* off, uint64_t n_nodes, uint8_t* keep,
+                              unsigned long long* counters, hipStream_t s);
+hipError_t fno_gather_edges(const hc_fno_edge* in, const uint32_t* idx, uint64_t n, hc_fno_edge* out, hipStream_t s);
+hipError_t fno_clique_pairs(const uint64_t* clique_nodes, const uint64_t* clique_off, uint64_t n_srs, uint64_t total, uint64_t n_nodes, uint64_t* key,
+                            uint32_t* sr, unsigned long long* counters, hipStream_t s);
+hipError_t fno_offsets(const uint64_t* sorted, uint64_t n, uint64_t n_nodes, uint64_t* off, hipStream_t s);
 // cnt_*[i], i <= n_edges ([n_edges] = 0): combinations / copied items of edge i
 hipError_t fno_walk_count(const FnoWalkInput& w, uint64_t* cnt_comb, uint64_t* cnt_direct, unsigned long long* counters, hipStream_t s);
 // key[c] = the unordered pair of new ids of combination c (walk order), ~0 for a skipped one; iota[c] = c

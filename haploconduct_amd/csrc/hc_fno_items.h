@@ -36,21 +36,22 @@ bool fno_device_wanted(uint64_t n_items);
 bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, const std::function<char*(uint64_t)>& text_of,
                          uint64_t counters[5], double* seconds);
 
-// FNO=1 whole on the device.  The edges updateOverlap is called on, in the reference's order, as spans of host memory (adj_out,
-// branching_edges, the kept non-edges, the inclusion-induced edges); nodes_to_SR as CSR; every super-read's subreads sorted by node.
+// FNO=1 whole on the device.  The edges updateOverlap is called on, in the reference's order: adj_out (graph_edges, vertex by
+// vertex — anything else makes the call return false), branching_edges, the stored non-edges (ALL of them when use_nonedges: which
+// pass :702 is decided on the device against adj_out), the inclusion-induced edges (the host's: few); the cliques nodes_to_SR is
+// made of (:893-906); every super-read's subreads sorted by node.
 struct FnoEdgeSpan {
     const hc_fno_edge* p;
     uint64_t n;
 };
 struct FnoWalkHost {
-    const FnoEdgeSpan* spans;
-    uint32_t n_spans;
+    FnoEdgeSpan graph, branching, nonedges, induced;
     const hc_fno_read* nodes;
     uint64_t n_nodes;
     const hc_fno_read* srs;
     uint64_t n_srs;
-    const uint64_t* n2s_off;
-    const uint32_t* n2s;
+    const uint64_t* clique_off;
+    const uint64_t* clique_nodes;
     const uint64_t* subread_off;
     const hc_fno_subread* subreads;
     uint64_t new_read_count;

@@ -471,6 +471,74 @@ __device__ __forceinline__ uint64_t edge_of(const uint64_t* __restrict__ off, ui
     return lo;
 }
 
+// ---- what the walk needs first, built where the walk runs ---------------------------------------------------------------------
+// OverlapGraph::adj_out as offsets into graph_edges, which the caller hands over vertex by vertex (sorted by v1): lane i writes the
+// offsets of the vertices in (v1[i - 1], v1[i]]; lane G those up to n_nodes.  Unsorted edges are the host form's business.
+__global__ __launch_bounds__(kBlock) void fno_adj_offsets_kernel(const hc_fno_edge* __restrict__ ge, uint64_t G, uint64_t n_nodes, uint64_t* __restrict__ off,
+                                                                 unsigned long long* __restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i > G) return;
+    if (i < G && (ge[i].v1 >= n_nodes || ge[i].v2 >= n_nodes)) {
+        atomicOr(&counters[4], (unsigned long long)kFnoStatusRequire);  // "edge vertex out of range"
+        return;
+    }
+    if (i && i < G && ge[i - 1].v1 > ge[i].v1) {
+        atomicOr(&counters[4], (unsigned long long)kFnoStatusUnsorted);
+        return;
+    }
+    const uint64_t from = i ? ge[i - 1].v1 + 1 : 0, to = i < G ? ge[i].v1 : n_nodes;
+    if (i && ge[i - 1].v1 >= n_nodes) return;  // reported by lane i - 1
+    for (uint64_t v = from; v <= to; ++v) off[v] = i;
+}
+
+// OverlapGraph::checkEdge(v, w, true), src/OverlapGraph.cpp:233-259: the score of the first edge v -> w, else of the first w -> v, else -1
+__device__ __forceinline__ double check_edge(const hc_fno_edge* __restrict__ ge, const uint64_t* __restrict__ off, uint64_t v, uint64_t w) {
+    for (uint64_t k = off[v]; k < off[v + 1]; ++k)
+        if (ge[k].v2 == w) return ge[k].score;
+    for (uint64_t k = off[w]; k < off[w + 1]; ++k)
+        if (ge[k].v2 == v) return ge[k].score;
+    return -1.0;
+}
+
+// the stored non-edges updateOverlap is called on (:635-813): those no edge of the graph stands for already (:702)
+__global__ __launch_bounds__(kBlock) void fno_nonedge_filter_kernel(const hc_fno_edge* __restrict__ nonedges, uint64_t n, const hc_fno_edge* __restrict__ ge,
+                                                                    const uint64_t* __restrict__ off, uint64_t n_nodes, uint8_t* __restrict__ keep,
+                                                                    unsigned long long* __restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const hc_fno_edge e = nonedges[i];
+    uint8_t k = 0;
+    if (e.score != 0) atomicOr(&counters[4], (unsigned long long)kFnoStatusRange);  // not a stored non-edge: the host form says so
+    else if (!(e.len1 > 0 && e.len2 >= 0) || e.v1 >= n_nodes || e.v2 >= n_nodes) atomicOr(&counters[4], (unsigned long long)kFnoStatusRequire);
+    else k = check_edge(ge, off, e.v1, e.v2) > 0 ? 0 : 1;
+    keep[i] = k;
+}
+__global__ __launch_bounds__(kBlock) void fno_gather_edges_kernel(const hc_fno_edge* __restrict__ in, const uint32_t* __restrict__ idx, uint64_t n,
+                                                                  hc_fno_edge* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+
+// nodes_to_SR (:893-906): (vertex, super-read) for every member of every clique, in super-read order — a stable sort by vertex
+// leaves every vertex's super-reads in the order the reference pushes them — then the offsets as for adj_out
+__global__ __launch_bounds__(kBlock) void fno_clique_pairs_kernel(const uint64_t* __restrict__ clique_nodes, const uint64_t* __restrict__ clique_off,
+                                                                  uint64_t n_srs, uint64_t total, uint64_t n_nodes, uint64_t* __restrict__ key,
+                                                                  uint32_t* __restrict__ sr, unsigned long long* __restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t node = clique_nodes[i];
+    if (node >= n_nodes) atomicOr(&counters[4], (unsigned long long)kFnoStatusRequire);  // nodes_to_SR.at(node)
+    key[i] = node;
+    sr[i] = (uint32_t)edge_of(clique_off, n_srs, i);  // the super-read entry i belongs to
+}
+__global__ __launch_bounds__(kBlock) void fno_offsets_kernel(const uint64_t* __restrict__ sorted, uint64_t n, uint64_t n_nodes, uint64_t* __restrict__ off) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i > n) return;
+    const uint64_t from = i ? sorted[i - 1] + 1 : 0, to = i < n ? sorted[i] : n_nodes;
+    if ((i && sorted[i - 1] >= n_nodes) || (i < n && sorted[i] >= n_nodes)) return;  // reported by fno_clique_pairs_kernel
+    for (uint64_t v = from; v <= to; ++v) off[v] = i;
+}
+
 struct Combination {
     uint64_t edge;
     uint32_t sr1, sr2;
@@ -649,6 +717,31 @@ hipError_t fno_format(const FnoRec* rec, const uint32_t* perm, const uint64_t* l
     return hipGetLastError();
 }
 
+hipError_t fno_adj_offsets(const hc_fno_edge* ge, uint64_t G, uint64_t n_nodes, uint64_t* off, unsigned long long* counters, hipStream_t s) {
+    hipLaunchKernelGGL(fno_adj_offsets_kernel, grid_for(G + 1), dim3(kBlock), 0, s, ge, G, n_nodes, off, counters);
+    return hipGetLastError();
+}
+hipError_t fno_nonedge_filter(const hc_fno_edge* nonedges, uint64_t n, const hc_fno_edge* ge, const uint64_t* off, uint64_t n_nodes, uint8_t* keep,
+                              unsigned long long* counters, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fno_nonedge_filter_kernel, grid_for(n), dim3(kBlock), 0, s, nonedges, n, ge, off, n_nodes, keep, counters);
+    return hipGetLastError();
+}
+hipError_t fno_gather_edges(const hc_fno_edge* in, const uint32_t* idx, uint64_t n, hc_fno_edge* out, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fno_gather_edges_kernel, grid_for(n), dim3(kBlock), 0, s, in, idx, n, out);
+    return hipGetLastError();
+}
+hipError_t fno_clique_pairs(const uint64_t* clique_nodes, const uint64_t* clique_off, uint64_t n_srs, uint64_t total, uint64_t n_nodes, uint64_t* key,
+                            uint32_t* sr, unsigned long long* counters, hipStream_t s) {
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(fno_clique_pairs_kernel, grid_for(total), dim3(kBlock), 0, s, clique_nodes, clique_off, n_srs, total, n_nodes, key, sr, counters);
+    return hipGetLastError();
+}
+hipError_t fno_offsets(const uint64_t* sorted, uint64_t n, uint64_t n_nodes, uint64_t* off, hipStream_t s) {
+    hipLaunchKernelGGL(fno_offsets_kernel, grid_for(n + 1), dim3(kBlock), 0, s, sorted, n, n_nodes, off);
+    return hipGetLastError();
+}
 hipError_t fno_walk_count(const FnoWalkInput& w, uint64_t* cnt_comb, uint64_t* cnt_direct, unsigned long long* counters, hipStream_t s) {
     hipLaunchKernelGGL(fno_walk_count_kernel, grid_for(w.n_edges + 1), dim3(kBlock), 0, s, w, cnt_comb, cnt_direct, counters);
     return hipGetLastError();

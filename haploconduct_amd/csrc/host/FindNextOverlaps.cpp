@@ -71,6 +71,7 @@ template <typename F>
 void parallel_chunks(uint64_t n, unsigned threads, F&& f) {  // f(begin, end, thread_index)
     if (n == 0) return;
     if (threads > n) threads = (unsigned)n;
+    if (n >= 65536 && threads > n / 8192 + 1) threads = (unsigned)(n / 8192 + 1);  // item loops (task lists are short): starting a thread costs as much as a few thousand items
     if (threads <= 1) {
         f((uint64_t)0, n, 0u);
         return;
@@ -255,15 +256,19 @@ public:
         auto t0 = now();
         check_input();
         index_subreads();
-        build_nodes_to_sr();
-        auto t1 = now();
-        collect_work();
-        if (walk_on_device(out)) {
+        auto t0b = now();
+        if (walk_on_device(out)) {  // takes the caller's arrays as they are: nodes_to_SR, adj_out and the non-edge test happen there
             if (timing)
-                fprintf(stderr, "hc_fno1_run: index %.3f s, edges in walk order + the whole rest on the device %.3f s\n",
-                        std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(now() - t1).count());
+                fprintf(stderr, "hc_fno1_run: subread maps sorted %.3f s, the whole rest on the device %.3f s\n", std::chrono::duration<double>(t0b - t0).count(),
+                        std::chrono::duration<double>(now() - t0b).count());
             return;
         }
+        build_nodes_to_sr();
+        auto t1 = now();
+        if (timing)
+            fprintf(stderr, "hc_fno1_run: index: subread maps sorted %.3f s, nodes_to_SR %.3f s\n", std::chrono::duration<double>(t0b - t0).count(),
+                    std::chrono::duration<double>(t1 - t0b).count());
+        collect_work();
         walk();
         auto t2 = now();
         deduce_and_emit(out);
@@ -410,38 +415,10 @@ private:
         return -1.0;
     }
 
-    // the edges updateOverlap sees, in order: adj_out, branching_edges, the stored non-edges that pass :702, the
-    // inclusion-induced edges (:612-630, :635-813, :816-887)
-    void collect_work() {
-        if (in_.n_graph_edges + in_.n_branching_edges + in_.n_nonedges >= 0xFFFFFFF0ull) throw FatalError{HC_ERR_ARG, "too many edges"};
-        work_[0] = {in_.graph_edges, in_.n_graph_edges};
-        work_[1] = {in_.branching_edges, in_.n_branching_edges};
-        const bool use_nonedges = !(in_.flags & HC_FNO_OPTIMIZE) && in_.n_nonedges;  // :914
-        if (use_nonedges || in_.n_inclusion_groups) build_adjacency();
-        if (use_nonedges) {
-            if (!in_.nonedges) throw FatalError{HC_ERR_ARG, "null array"};
-            const unsigned T = (unsigned)std::min<uint64_t>(threads_, in_.n_nonedges);
-            std::vector<std::vector<uint32_t>> kept(T);  // indices into nonedges
-            parallel_chunks(in_.n_nonedges, T, [&](uint64_t b, uint64_t e, unsigned t) {
-                for (uint64_t i = b; i < e; ++i) {
-                    const hc_fno_edge* ed = in_.nonedges + i;
-                    if (ed->score != 0) throw FatalError{HC_ERR_ARG, "a stored non-edge must carry score 0"};
-                    FNO_REQUIRE(ed->len1 > 0 && ed->len2 >= 0);  // Edge::set_len, src/Edge.h:212-214
-                    if (ed->v1 >= in_.n_nodes || ed->v2 >= in_.n_nodes) ref_abort("edge vertex out of range");
-                    if (check_edge(ed->v1, ed->v2) > 0) continue;  // :702
-                    kept[t].push_back((uint32_t)i);
-                }
-            });
-            std::vector<uint64_t> at(T + 1, 0);
-            for (unsigned t = 0; t < T; ++t) at[t + 1] = at[t] + kept[t].size();
-            kept_nonedges_.resize(at[T]);
-            parallel_chunks(T, T, [&](uint64_t tb, uint64_t te, unsigned) {
-                for (uint64_t t = tb; t < te; ++t)
-                    for (size_t k = 0; k < kept[t].size(); ++k) kept_nonedges_[at[t] + k] = in_.nonedges[kept[t][k]];
-            });
-            work_[2] = {kept_nonedges_.data(), kept_nonedges_.size()};
-        }
-        // findInclusionOverlaps: u->w and w->v both inclusions  =>  try u->v
+    // findInclusionOverlaps (:816-887): the inclusion-induced edges, checked against adj_out (build_adjacency must have run if there are groups)
+    void collect_induced() {
+        induced_.clear();
+        // u->w and w->v both inclusions  =>  try u->v
         uint64_t n_induced = 0;
         for (uint64_t g = 0; g < in_.n_inclusion_groups; ++g) {
             const uint64_t l = in_.inclusion_off[g + 1] - in_.inclusion_off[g];
@@ -489,7 +466,52 @@ private:
                     if (check_edge(ne.v1, ne.v2) == -1) induced_.push_back(ne);
                 }
         }
+    }
+
+    // the edges updateOverlap sees, in order: adj_out, branching_edges, the stored non-edges that pass :702, the
+    // inclusion-induced edges (:612-630, :635-813, :816-887)
+    void collect_work() {
+        if (in_.n_graph_edges + in_.n_branching_edges + in_.n_nonedges >= 0xFFFFFFF0ull) throw FatalError{HC_ERR_ARG, "too many edges"};
+        const bool timing = getenv("HC_FNO_TIMING") != nullptr;
+        auto tl = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            const auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "hc_fno1_run: edges in walk order: %s %.3f s\n", what, std::chrono::duration<double>(t - tl).count());
+            tl = t;
+        };
+        work_[0] = {in_.graph_edges, in_.n_graph_edges};
+        work_[1] = {in_.branching_edges, in_.n_branching_edges};
+        const bool use_nonedges = !(in_.flags & HC_FNO_OPTIMIZE) && in_.n_nonedges;  // :914
+        if (use_nonedges || in_.n_inclusion_groups) build_adjacency();
+        lap("adjacency");
+        if (use_nonedges) {
+            if (!in_.nonedges) throw FatalError{HC_ERR_ARG, "null array"};
+            const unsigned T = (unsigned)std::min<uint64_t>(threads_, in_.n_nonedges);
+            std::vector<std::vector<uint32_t>> kept(T);  // indices into nonedges
+            parallel_chunks(in_.n_nonedges, T, [&](uint64_t b, uint64_t e, unsigned t) {
+                for (uint64_t i = b; i < e; ++i) {
+                    const hc_fno_edge* ed = in_.nonedges + i;
+                    if (ed->score != 0) throw FatalError{HC_ERR_ARG, "a stored non-edge must carry score 0"};
+                    FNO_REQUIRE(ed->len1 > 0 && ed->len2 >= 0);  // Edge::set_len, src/Edge.h:212-214
+                    if (ed->v1 >= in_.n_nodes || ed->v2 >= in_.n_nodes) ref_abort("edge vertex out of range");
+                    if (check_edge(ed->v1, ed->v2) > 0) continue;  // :702
+                    kept[t].push_back((uint32_t)i);
+                }
+            });
+            std::vector<uint64_t> at(T + 1, 0);
+            for (unsigned t = 0; t < T; ++t) at[t + 1] = at[t] + kept[t].size();
+            kept_nonedges_.resize(at[T]);
+            parallel_chunks(T, T, [&](uint64_t tb, uint64_t te, unsigned) {
+                for (uint64_t t = tb; t < te; ++t)
+                    for (size_t k = 0; k < kept[t].size(); ++k) kept_nonedges_[at[t] + k] = in_.nonedges[kept[t][k]];
+            });
+            work_[2] = {kept_nonedges_.data(), kept_nonedges_.size()};
+        }
+        lap("stored non-edges");
+        collect_induced();
         work_[3] = {induced_.data(), induced_.size()};
+        lap("inclusion-induced edges");
         n_work_ = work_[0].n + work_[1].n + work_[2].n + work_[3].n;
         if (n_work_ >= 0xFFFFFFFFull) throw FatalError{HC_ERR_ARG, "too many edges"};
     }
@@ -789,19 +811,28 @@ private:
     bool walk_on_device(hc_fno_output& out) {
         if (const char* e = getenv("HC_FNO_WALK"))
             if (strcmp(e, "host") == 0) return false;
-        const uint64_t E = n_work_;
+        const bool use_nonedges = !(in_.flags & HC_FNO_OPTIMIZE) && in_.n_nonedges;  // :914
+        const uint64_t E = in_.n_graph_edges + in_.n_branching_edges + (use_nonedges ? in_.n_nonedges : 0);
         if (!hc::fno_device_wanted(E)) return false;
+        if (use_nonedges && !in_.nonedges) throw FatalError{HC_ERR_ARG, "null array"};
         const bool timing = getenv("HC_FNO_TIMING") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
+        for (uint64_t i = 0; i < in_.n_srs; ++i) FNO_REQUIRE(in_.clique_off[i + 1] > in_.clique_off[i]);  // get_sorted_clique asserts size() > 0
+        if (in_.n_inclusion_groups) {  // few edges, on the host: they need checkEdge, i.e. adj_out here as well
+            build_adjacency();
+            collect_induced();
+        }
         hc::FnoWalkHost h{};
-        h.spans = work_;
-        h.n_spans = 4;
+        h.graph = {in_.graph_edges, in_.n_graph_edges};
+        h.branching = {in_.branching_edges, in_.n_branching_edges};
+        h.nonedges = {in_.nonedges, use_nonedges ? in_.n_nonedges : 0};
+        h.induced = {induced_.data(), induced_.size()};
         h.nodes = in_.nodes;
         h.n_nodes = in_.n_nodes;
         h.srs = in_.srs;
         h.n_srs = in_.n_srs;
-        h.n2s_off = n2s_off_.data();
-        h.n2s = n2s_.data();
+        h.clique_off = in_.clique_off;
+        h.clique_nodes = in_.clique_nodes;
         h.subread_off = in_.subread_off;
         h.subreads = sub_sorted_.data();
         h.new_read_count = in_.new_read_count;
