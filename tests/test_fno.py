@@ -285,13 +285,26 @@ def test_fno1_aborts_where_the_reference_does(olib):
     bad3 = T.fno1_scenario(3)
     bad3.subreads["index1"] = 5
     bad3.subreads["startpos1"] = 5
+    # an edge, a stored non-edge and a clique that name a vertex the graph does not have: visited.at / nodes_to_SR.at throw
+    bad4 = T.fno1_scenario(3)
+    bad4.graph_edges["v2"][0] = 10 ** 6
+    bad5 = T.fno1_scenario(3, with_extras=True)
+    bad5.nonedges["v1"][0] = 10 ** 6
+    bad6 = T.fno1_scenario(3)
+    bad6.clique_nodes[0] = 10 ** 6
     assert F.find_next_overlaps(good)[0] == T.oracle_fno1(olib, good)[0]
-    for b in (bad, bad2, bad3):
+    for b in (bad, bad2, bad3, bad4, bad5, bad6):
         with pytest.raises(T.OracleAbort):
             T.oracle_fno1(olib, b)
         with pytest.raises(HcError) as ei:
             F.find_next_overlaps(b)
         assert ei.value.status == -9 and "reference stops here" in str(ei.value)
+    # build-owned: a "stored non-edge" that carries a score is an argument error, not a line of nonedge_overlaps.txt
+    bad7 = T.fno1_scenario(3, with_extras=True)
+    bad7.nonedges["score"][0] = 0.5
+    with pytest.raises(HcError) as ei:
+        F.find_next_overlaps(bad7)
+    assert ei.value.status == -1 and "score 0" in str(ei.value)
 
 
 @pytest.mark.parametrize("seed", range(16))
