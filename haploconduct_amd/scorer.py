@@ -131,11 +131,12 @@ class EdgeScorer:
         ids = np.ascontiguousarray(read_ids, dtype=np.uint64)
         N.check(N.lib.hc_text_set_ids(self._ctx, _ptr(ids), ids.shape[0]), "hc_text_set_ids")
 
-    def score_text(self, text, block_bytes=1 << 20, first_line_no=0, chained=False):
+    def score_text(self, text, block_bytes=1 << 20, first_line_no=0, chained=False, reserve_rows=0):
         """The overlaps file's TEXT through hc_textblock_submit / hc_textblock_wait, block by block (cut at line ends).
         Returns a list with one dict per block: the hc_text_result fields, rows / rejected as numpy copies.
         chained: hc_textblock_submit_from — the text goes to the device straight from `text`, two blocks in flight, line
-        numbers through an hc_linechain (first_line_no must be 0)."""
+        numbers through an hc_linechain (first_line_no must be 0).  reserve_rows: hc_textblock_reserve_rows before the first submit;
+        every dict carries "regrown" = hc_textblock_regrown of the block so far."""
         raw = text if isinstance(text, bytes) else text.encode()
         if chained:
             return self._score_text_chained(raw, block_bytes)
@@ -143,6 +144,8 @@ class EdgeScorer:
         N.check(N.lib.hc_textblock_create(self._ctx, max(block_bytes, 64), C.byref(b)), "hc_textblock_create")
         out, at, line_no, base = [], 0, first_line_no, 0
         try:
+            if reserve_rows:
+                N.check(N.lib.hc_textblock_reserve_rows(b, reserve_rows), "hc_textblock_reserve_rows")
             buf = N.lib.hc_textblock_buffer(b)
             while at < len(raw):
                 end = min(len(raw), at + block_bytes)
@@ -160,6 +163,7 @@ class EdgeScorer:
                 d["rejected"] = (np.frombuffer((C.c_char * (r.n_rejected * 56)).from_address(r.rejected), dtype=TEXT_REJECT_DTYPE).copy()
                                  if r.n_rejected else np.zeros(0, TEXT_REJECT_DTYPE))
                 d["base"], d["bytes"] = base, (at, end)
+                d["regrown"] = int(N.lib.hc_textblock_regrown(b))
                 out.append(d)
                 line_no += r.n_lines
                 base += r.n_lines

@@ -331,3 +331,23 @@ def test_device_text_parser_hands_unusual_blocks_to_the_host():
         sc.set_ids(sparse)
         b = sc.score_text("\n".join(relabelled) + "\n")[0]
         assert b["needs_host"] == 0 and a["rows"]["row"].tobytes() == b["rows"]["row"].tobytes()
+
+
+def test_reserved_row_buffers_spare_the_block_its_second_run():
+    """hc_textblock_reserve_rows (the one-call reads -> graph route grows its blocks while the finder runs): a block whose lines all
+    survive grows its row buffers inside hc_textblock_wait and runs its device half again — unless they were reserved; same rows
+    either way."""
+    reads, meta = synth.make_paired_dataset(1500, 1200, n_strains=1, divergence=0.0, err=0.0, n_rate=0.0, seed=5)
+    cand = synth.paired_candidates(meta, n_candidates=60000, seed=6)
+    text = "\n".join(synth.records_to_lines(cand, reads)) + "\n"
+    st = hc.Settings(edge_threshold=0.97, ov_threshold=0.9, min_overlap_len=150)
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        sc.set_ids(reads.read_ids)
+        grown = sc.score_text(text, block_bytes=1 << 20)
+        reserved = sc.score_text(text, block_bytes=1 << 20, reserve_rows=1 << 20)
+    assert len(grown) == len(reserved) >= 2
+    assert grown[0]["regrown"] >= 1, "every line survives: the first block is meant to overflow an eighth of its lines"
+    assert all(b["regrown"] == 0 and b["needs_host"] == 0 for b in reserved)
+    for x, y in zip(grown, reserved):
+        assert x["rows"].tobytes() == y["rows"].tobytes() and x["n_rows"] == y["n_rows"] > 0.9 * x["n_lines"]
