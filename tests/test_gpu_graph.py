@@ -267,6 +267,8 @@ def test_device_text_parser_is_the_host_parser(block_bytes, tmp_path):
         assert len(chained) == len(blocks)
         for x, y in zip(blocks, chained):
             for k in x:
+                if k == "regrown":  # a count of the block object, not of the text
+                    continue
                 if k == "rows":  # the chained submit numbers a block's rows from 0 (the host learns the line counts afterwards)
                     yr = y[k].copy()
                     yr["row"]["index"] += y["base"]
