@@ -223,7 +223,9 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         HC_HIP(hipMemcpyAsync(h_bound.data(), d_bound.p, (n_seq + 1) * 8, hipMemcpyDeviceToHost, st));
         HC_HIP(hipStreamSynchronize(st));
     }
-    uint64_t batch_hits = 1ull << 29;
+    // 2^27 seed hits in flight (28 bytes of scratch each): with 2^29 the first call of a context allocated 15 GB for the batches alone,
+    // which costs 0.2 - 0.9 s on some hosts (the call itself takes 0.12 s); four batches instead of one cost 6 % once the scratch exists
+    uint64_t batch_hits = 1ull << 27;
     if (const char* e = getenv("HC_FIND_BATCH_HITS")) batch_hits = strtoull(e, nullptr, 10);
     if (batch_hits < 1024) batch_hits = 1024;
     if (batch_hits > (1ull << 31)) batch_hits = 1ull << 31;  // the sorts (hc_prims.hip) index with 32 bits

@@ -669,10 +669,37 @@ void EdgeCalculator::finalize_text_block(const IdIndex& ids, const hc_text_row* 
     static const unsigned build_cap = getenv("HC_BUILD_THREADS") ? (unsigned)atoi(getenv("HC_BUILD_THREADS")) : 8u;  // experiment knob
     unsigned T = program_settings.n_threads > 1 ? std::min<unsigned>(program_settings.n_threads, std::max(1u, build_cap)) : 1;
     if (n_rows < 4096) T = 1;
-    if (threads) T = std::min(T, threads);  // several collectors call this side by side: each on its own thread (the pool is one)
+    // several collectors call this side by side (threads = 1: the pool is one): a block nearly all of whose lines survive — overlaps
+    // straight from the finder — then spends 12 ms in one thread's exp(); such a block gets a few threads of its own
+    bool own_threads = false;
+    if (threads) {
+        const unsigned want = n_rows >= 100000 ? std::min(4u, std::max(1u, program_settings.n_threads / 4)) : 1u;
+        own_threads = threads == 1 && want > 1;
+        T = own_threads ? want : std::min(T, threads);
+    }
     std::vector<Piece> pieces(T);
     if (T == 1) {
         build(0, n_rows, pieces[0]);
+    } else if (own_threads) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++)
+            th.emplace_back([&, t] {
+                try {
+                    build(n_rows * t / T, n_rows * (t + 1) / T, pieces[t]);
+                } catch (const FatalError& e) {
+                    pieces[t].error = e;
+                } catch (const std::exception& e) {
+                    pieces[t].error = FatalError{HC_ERR_NOMEM, e.what()};
+                }
+            });
+        try {
+            build(0, n_rows / T, pieces[0]);
+        } catch (const FatalError& e) {
+            pieces[0].error = e;
+        } catch (const std::exception& e) {
+            pieces[0].error = FatalError{HC_ERR_NOMEM, e.what()};
+        }
+        for (auto& x : th) x.join();
     } else {
         if (!m_build_pool || m_build_pool->workers() + 1 < T) m_build_pool.reset(new WorkerPool(T - 1));
         m_build_pool->run(T, [&](unsigned int t) {
