@@ -918,6 +918,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     std::mutex smu;
     std::condition_variable scv;
     bool no_more = false;
+    const bool submit_trace = getenv("HC_STAGE_TIMING") && getenv("HC_SUBMIT_TRACE");
     std::thread submitter([&] {
         bind_here();
         for (;;) {
@@ -941,7 +942,9 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                         collector_failed = true;
                     }
                 }
-                tm_submit += now_s() - t0;
+                const double dt = now_s() - t0;
+                tm_submit += dt;
+                if (submit_trace && p.k < 24) fprintf(stderr, "[hc stage] submit of block %llu: %.1f ms\n", (unsigned long long)p.k, dt * 1e3);
             }
             {
                 std::lock_guard<std::mutex> g(mu);
