@@ -182,6 +182,8 @@ int hc_destroy(hc_ctx* c) {
         if (c->h_ingest[t]) (void)hipHostFree(c->h_ingest[t]);
         if (c->graph.stage_free[t]) (void)hipEventDestroy(c->graph.stage_free[t]);
     }
+    for (hipStream_t s : c->text_copy_stream)
+        if (s) (void)hipStreamDestroy(s);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return HC_OK;

@@ -23,6 +23,7 @@ struct hc_textblock {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     hipEvent_t lines_known = nullptr;          // chained submits: this block's entry of the line chain is written
+    hipEvent_t copied = nullptr;               // the text has arrived (the copies of all blocks share the context's copy stream)
     char* h_text = nullptr;                    // page-locked, allocated on first use (hc_textblock_buffer): the caller reads the file into it
     char* d_text = nullptr;                    // max_bytes + 64
     uint32_t *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_line_start = nullptr;
@@ -120,6 +121,7 @@ int hc_textblock_create(hc_ctx* c, uint64_t max_bytes, hc_textblock** out) {
     ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     ok(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
     ok(hipEventCreateWithFlags(&b->lines_known, hipEventDisableTiming));
+    ok(hipEventCreateWithFlags(&b->copied, hipEventDisableTiming));
     ok(hipMalloc((void**)&b->d_text, max_bytes + 64));
     ok(hipMalloc((void**)&b->d_tile_cnt, (size_t)(n_tiles + 1) * 4));
     ok(hipMalloc((void**)&b->d_tile_off, (size_t)(n_tiles + 1) * 4));
@@ -200,6 +202,7 @@ int hc_textblock_destroy(hc_textblock* b) {
     for (void* p : b->old_host) (void)hipHostFree(p);
     if (b->done) (void)hipEventDestroy(b->done);
     if (b->lines_known) (void)hipEventDestroy(b->lines_known);
+    if (b->copied) (void)hipEventDestroy(b->copied);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return HC_OK;
@@ -327,7 +330,21 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
     if (n_bytes) {
         // the text as it is (page-locked or pageable: a file mapping goes to the device without a copy by the caller), and
         // 64 zero bytes behind it: the 16-byte loads of the last tile read past the text, no stray newline there
-        HC_HIP(hipMemcpyAsync(b->d_text, src, n_bytes, hipMemcpyHostToDevice, s));
+        // The blocks' copies take turns on TWO streams of the context and a block's own stream waits for its copy.  On the ten
+        // blocks' own streams the runtime opened a further copy queue whenever a copy met others in flight: 7 - 8 ms inside
+        // hipMemcpyAsync, five or six times during the first file of a process (HC_SUBMIT_TRACE) — C3's first construct_edges of a
+        // process 0.18 - 0.20 s against 0.13 - 0.14 s with two; one stream alone does not keep the link busy (later files 0.13 - 0.17 s
+        // against 0.12).  HC_TEXT_COPY_STREAMS = 0 (the blocks' own) .. 4.
+        static const int copy_streams = getenv("HC_TEXT_COPY_STREAMS") ? std::max(0, std::min(4, atoi(getenv("HC_TEXT_COPY_STREAMS")))) : 2;
+        if (copy_streams) {
+            hipStream_t& cs = c->text_copy_stream[c->text_copy_next++ % (uint32_t)copy_streams];
+            if (!cs) HC_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            HC_HIP(hipMemcpyAsync(b->d_text, src, n_bytes, hipMemcpyHostToDevice, cs));
+            HC_HIP(hipEventRecord(b->copied, cs));
+            HC_HIP(hipStreamWaitEvent(s, b->copied, 0));
+        } else {
+            HC_HIP(hipMemcpyAsync(b->d_text, src, n_bytes, hipMemcpyHostToDevice, s));
+        }
         HC_HIP(hipMemsetAsync(b->d_text + n_bytes, 0, 64, s));
         HC_HIP(hc::launch_text_lines(b->d_text, n_bytes, b->d_tile_cnt, b->d_tile_off, b->max_lines, b->d_line_start, b->d_counters, s));
     }

@@ -101,6 +101,8 @@ struct hc_ctx {
     int fetch_group = 4;     // otherwise per lane, in groups of 4 (short reads) or 2 (contigs, 16-bit symbols) 16-symbol chunks;
                              // chosen per read set in hc_set_reads (HC_FETCH_GROUP=coop|4|2 overrides: a tuning knob only)
     hipStream_t stream = nullptr;
+    hipStream_t text_copy_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // the text blocks' host-to-device copies, in turn (hc_api_text.cpp)
+    uint32_t text_copy_next = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // read store
     bool have_reads = false;
