@@ -13,6 +13,7 @@
 #include "../../include/hcedge.h"
 #include "hc_ctx.h"
 #include "hc_fno_device.h"
+#include "hc_hostcopy.h"
 #include "hc_prims.h"
 #include "hc_sfo_device.h"
 #include "host/NumaBind.h"
@@ -348,7 +349,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     }
     *n_out = R;
     const uint64_t take = R < cap ? R : cap;
-    if (take) HC_HIP(hipMemcpy(out, d_r1.p, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
+    if (take) HC_HIP(hc::copy_to_pageable_host(out, d_r1.p, take * sizeof(hc_sfo_rec)));
     lap("copy to host");
     remember((hc_sfo_rec*)d_r1.p, R);  // the context owns the records now
     d_r1.own = nullptr;

@@ -14,6 +14,7 @@
 
 #include "../../include/hcedge.h"
 #include "hc_fno_device.h"
+#include "hc_hostcopy.h"
 #include "hc_overlap_finder.h"
 #include "hc_prims.h"
 #include "host/Types.h"
@@ -50,37 +51,6 @@ void hip_check(hipError_t e, const char* what) {
 }
 
 
-// The text's way back: into fresh pageable memory the runtime's copy runs at 13 - 16 GB/s, most of it the first touch of the
-// pages; a few threads touch the destination one stretch ahead of the copy, which then runs at what pageable memory allows.
-void copy_text_to_host(char* h_text, const char* d_text, uint64_t bytes) {
-    const uint64_t chunk = (uint64_t)32 << 20;
-    if (bytes < 2 * chunk) {
-        hip_check(hipMemcpy(h_text, d_text, bytes, hipMemcpyDeviceToHost), "copy of the text");
-        return;
-    }
-    const uint64_t n_chunks = (bytes + chunk - 1) / chunk;
-    std::atomic<uint64_t> touched{0};  // chunks whose pages exist
-    unsigned T = std::thread::hardware_concurrency();
-    T = T > 8 ? 8 : (T ? T : 1);
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; t++)
-        th.emplace_back([&, t] {
-            for (uint64_t k = 0; k < n_chunks; k++) {
-                const uint64_t b = k * chunk, e = std::min(bytes, b + chunk), len = e - b;
-                volatile char* p = h_text + b;
-                for (uint64_t at = len * t / T & ~(uint64_t)4095; at < len * (t + 1) / T; at += 4096) p[at] = 0;
-                touched.fetch_add(1, std::memory_order_release);  // T increments per chunk
-            }
-        });
-    hipError_t err = hipSuccess;
-    for (uint64_t k = 0; k < n_chunks && err == hipSuccess; k++) {
-        while (touched.load(std::memory_order_acquire) < (uint64_t)T * (k + 1)) std::this_thread::yield();
-        const uint64_t b = k * chunk, e = std::min(bytes, b + chunk);
-        err = hipMemcpy(h_text + b, d_text + b, e - b, hipMemcpyDeviceToHost);
-    }
-    for (auto& x : th) x.join();
-    hip_check(err, "copy of the text");
-}
 }  // namespace
 
 bool fno_device_wanted(uint64_t n_items) {
@@ -144,7 +114,7 @@ bool lines_from_device_items(DeviceBuffers& d, const FnoItem* d_items, uint64_t 
     char* d_text = d.get<char>(total_bytes);
     hip_check(fno_format(d_rec, perm, d_ka, d_kb, n, d_text, st), "format");
     char* h_text = text_of(total_bytes);
-    if (total_bytes) copy_text_to_host(h_text, d_text, total_bytes);
+    if (total_bytes) hip_check(copy_to_pageable_host(h_text, d_text, total_bytes), "copy of the text");
     for (int k = 0; k < 4; k++) counters[k] = h_counters[k];
     counters[4] = h_counters[5];
     if (seconds) {
@@ -371,7 +341,7 @@ bool fno3_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, 
     char* d_text = d.get<char>(total_bytes);
     hip_check(fno3_format(d_rec, d_len, d_off, n, d_text, st), "format");
     char* h_text = text_of(total_bytes);
-    if (total_bytes) copy_text_to_host(h_text, d_text, total_bytes);
+    if (total_bytes) hip_check(copy_to_pageable_host(h_text, d_text, total_bytes), "copy of the text");
     if (n_lines) *n_lines = h_counters[5];
     if (seconds) {
         seconds[0] = std::chrono::duration<double>(t1 - t0).count();
