@@ -1014,6 +1014,14 @@ private:
     void walk() {
         // :26-76.  The walk order of :100 is the iteration order of this very container type in the reference;
         // it is kept as is so that the order (a property of the host's libstdc++) is the reference's.
+        const bool timing = getenv("HC_FNO_TIMING") != nullptr;
+        auto tl = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            const auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "hc_fno3_run: walk: %s %.3f s\n", what, std::chrono::duration<double>(t - tl).count());
+            tl = t;
+        };
         std::unordered_map<unsigned long, unsigned long> original_to_index;
         std::vector<uint64_t> count;  // super-reads per original, by index
         std::vector<uint64_t> slot_of(n_ ? in_.orig_off[n_] : 0);
@@ -1027,6 +1035,7 @@ private:
                 slot_of[k] = ins.first->second;
                 ++count[ins.first->second];
             }
+        lap("originals numbered in order of appearance (the reference's unordered_map)");
         std::vector<uint64_t> off(count.size() + 1, 0);
         for (size_t i = 0; i < count.size(); ++i) off[i + 1] = off[i] + count[i];
         std::vector<uint32_t> members(off.back());
@@ -1035,6 +1044,7 @@ private:
             for (uint64_t i = 0; i < n_; ++i)
                 for (uint64_t k = in_.orig_off[i]; k < in_.orig_off[i + 1]; ++k) members[cur[slot_of[k]]++] = (uint32_t)i;
         }
+        lap("super-reads per original");
         // nodeDictApproach :100-132
         for (const auto& kv : original_to_index) {
             const uint32_t* m = members.data() + off[kv.second];
@@ -1043,6 +1053,7 @@ private:
                 for (uint64_t j = i + 1; j < cnt; ++j)
                     if (!found_.test_and_set(in_.srs[m[i]].id, in_.srs[m[j]].id)) cands_.push_back(Cand{m[i], m[j], kv.first});
         }
+        lap("pairs in the map's order, first met kept");
     }
 
     // deduceOverlap :180-406 and the two tests of :149-157; returns the end of the line or nullptr
