@@ -177,6 +177,7 @@ int hc_destroy(hc_ctx* c) {
     if (c->d_compact_res) (void)hipFree(c->d_compact_res);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
     for (int t = 0; t < 2; t++) {
         if (c->graph.h_stage[t]) (void)hipHostFree(c->graph.h_stage[t]);
         if (c->h_ingest[t]) (void)hipHostFree(c->h_ingest[t]);
@@ -479,8 +480,18 @@ static int ensure_sort_workspace(hc_ctx* c, uint64_t n) {
 int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, hipStream_t s, bool reorder,
                  hc_gather_row* rows, unsigned long long* row_count, uint64_t cap, uint64_t base_index, const unsigned long long* n_dev,
                  const hc_line_rec* lines_in, hc_line_rec* lines_out, hc_bucket_ws* bucket) {
+    // Which of the context's own scratch this launch will use (blocks bring their own and take none of it)
+    const bool want_perm = reorder && n > 1 && n < (1ull << 31);
+    const bool want_bucket = c->view.balance && c->coop_fetch && n < (1ull << 32);
+    const bool want_segments = rows && !lines_in && c->coop_fetch;
+    const bool ctx_scratch = want_perm || (want_bucket && !bucket) || want_segments;
+    if (ctx_scratch) {
+        // one launch at a time on that scratch: a launch on another stream than the last one waits for it on the device
+        if (!c->scratch_done) HC_HIP(hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming));
+        if (c->scratch_used && c->scratch_stream != s) HC_HIP(hipStreamWaitEvent(s, c->scratch_done, 0));
+    }
     const uint32_t* perm = nullptr;
-    if (reorder && n > 1 && n < (1ull << 31)) {
+    if (want_perm) {
         int rc = ensure_sort_workspace(c, n);
         if (rc) return rc;
         uint32_t* keys_in = c->d_sort;
@@ -496,7 +507,7 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
     { static const bool no_sort = getenv("HC_COOP_SORT") && atoi(getenv("HC_COOP_SORT")) == 0; prm.pad = no_sort ? 1u : 0u; }
     prm.n_dev = n_dev;
     uint32_t *bperm = nullptr, *bqueue = nullptr;
-    if (c->view.balance && c->coop_fetch && n < (1ull << 32)) {  // mixed sequence lengths: the launch buckets its candidates by length first
+    if (want_bucket) {  // mixed sequence lengths: the launch buckets its candidates by length first
         hc_bucket_ws* ws = bucket ? bucket : &c->bucket;
         int rc = ws->ensure(n);
         if (rc) return rc;
@@ -506,17 +517,27 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
     hc_gather_row* seg_buf = nullptr;
     uint32_t* seg_count = nullptr;
     uint64_t seg_total = 0;
-    if (rows && !lines_in && c->coop_fetch) {  // the cooperative launches collect their rows in per-workgroup segments
-        constexpr uint64_t kMaxGroups = 4096;        // the largest grid launch_score uses for it (n_cu x 16)
-        seg_total = 2 * cap + kMaxGroups * 512;      // twice the expected share per workgroup, and room for the small ones
+    if (want_segments) {  // the cooperative launches collect their rows in per-workgroup segments, spilling into `cap` rows behind them
+        seg_total = 2 * cap + hc::kSinkMaxGroups * 512;  // the expected share per workgroup and room for the small ones, then the spill area
+        // (a grown buffer is a new one: the launches in flight on the old one are behind scratch_done, which this stream has waited for
+        // or is itself ordered behind — but the runtime frees at once, so wait for them on the host before letting go of it)
+        if (seg_total * sizeof(hc_gather_row) > c->sink_rows.cap && c->scratch_used) HC_HIP(hipEventSynchronize(c->scratch_done));
         int rc = c->sink_rows.ensure(seg_total * sizeof(hc_gather_row));
         if (rc) return rc;
-        if ((rc = c->sink_counts.ensure(kMaxGroups * sizeof(uint32_t))) != HC_OK) return rc;
+        if (!c->sink_counts.p) {
+            if ((rc = c->sink_counts.ensure((hc::kSinkMaxGroups + 2) * sizeof(uint32_t))) != HC_OK) return rc;
+            HC_HIP(hipMemsetAsync(c->sink_counts.p, 0, (hc::kSinkMaxGroups + 2) * sizeof(uint32_t), s));  // the spill counters start at zero
+        }
         seg_buf = c->sink_rows.as<hc_gather_row>();
         seg_count = c->sink_counts.as<uint32_t>();
     }
     HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group, rows, row_count, cap,
-                            base_index, s, lines_in, lines_out, bperm, bqueue, seg_buf, seg_count, seg_total));
+                            base_index, s, lines_in, lines_out, bperm, bqueue, seg_buf, seg_count, seg_total, &c->sink_turn));
+    if (ctx_scratch) {
+        HC_HIP(hipEventRecord(c->scratch_done, s));
+        c->scratch_stream = s;
+        c->scratch_used = true;
+    }
     return HC_OK;
 }
 

@@ -371,6 +371,7 @@ uint64_t hc_textblock_regrown(hc_textblock* b) { return b ? b->n_regrown : 0; }
 
 int hc_textblock_reserve_rows(hc_textblock* b, uint64_t rows) {
     if (!b) return fail(HC_ERR_ARG, "hc_textblock_reserve_rows: null block");
+    if (b->in_flight) return fail(HC_ERR_STATE, "hc_textblock_reserve_rows: the block is still in flight (hc_textblock_wait first)");
     if (rows > b->max_lines) rows = b->max_lines;
     if (rows <= b->row_cap) return HC_OK;
     HC_HIP(hipSetDevice(b->ctx->device));

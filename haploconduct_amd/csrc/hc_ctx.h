@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -20,8 +21,11 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr, uint32_t* bucket_perm = nullptr,
-                        uint32_t* bucket_queue = nullptr, hc_gather_row* seg_buf = nullptr, uint32_t* seg_count = nullptr, uint64_t seg_total_rows = 0);
-// seg_buf (seg_total_rows rows) / seg_count (4 096 counters): scratch of a launch that collects its rows in per-workgroup segments
+                        uint32_t* bucket_queue = nullptr, hc_gather_row* seg_buf = nullptr, uint32_t* seg_count = nullptr, uint64_t seg_total_rows = 0,
+                        uint32_t* spill_turn = nullptr);
+// seg_buf (seg_total_rows rows: segments, then `cap` rows of spill area) / seg_count (kSinkMaxGroups counters + 2 spill counters, all
+// zero before the first launch) / spill_turn (host: which spill counter the next launch uses; advanced by a launch that used segments):
+// scratch of a launch that collects its rows in per-workgroup segments
 // bucket_perm (n uint32) / bucket_queue (one uint32): scratch of the length-bucketed launch (read sets of mixed sequence
 // length, StoreView::balance): without them such a set is scored in the order given
 hipError_t set_score_kernel_lds_limit();
@@ -102,7 +106,7 @@ struct hc_ctx {
                              // chosen per read set in hc_set_reads (HC_FETCH_GROUP=coop|4|2 overrides: a tuning knob only)
     hipStream_t stream = nullptr;
     hipStream_t text_copy_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // the text blocks' host-to-device copies, in turn (hc_api_text.cpp)
-    uint32_t text_copy_next = 0;
+    std::atomic<uint32_t> text_copy_next{0};  // (the streams themselves are created by the one thread that submits: hcedge.h)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // read store
     bool have_reads = false;
@@ -141,6 +145,12 @@ struct hc_ctx {
     uint64_t sort_cap = 0;
     hc_bucket_ws bucket;  // length-bucketed launches on the context's own entry points
     hc_scratch sink_rows, sink_counts;  // hc_score_pack_device: the row sink's per-workgroup segments (hc_kernels.hip: RowSink)
+    uint32_t sink_turn = 0;             // which of the two spill counters the next segmented launch uses
+    // The context's own scratch (reorder workspace, `bucket`, the sink's segments) serves one launch at a time: a launch that uses
+    // any of it on another stream than the last such launch waits for that one (hc_ctx_score)
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
     // compaction scratch, grow-only
     void* d_compact_tmp = nullptr;
     size_t compact_tmp_bytes = 0;

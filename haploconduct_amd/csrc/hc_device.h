@@ -30,6 +30,7 @@
 
 namespace hc {
 
+constexpr uint64_t kSinkMaxGroups = 4096;  // the largest grid that collects its rows in per-workgroup segments (n_cu x 16; hc_kernels.hip: RowSink)
 constexpr uint32_t kCodeN = 4;
 constexpr uint32_t kCodeBadQual = 6;
 constexpr uint32_t kCodeBadBase = 7;

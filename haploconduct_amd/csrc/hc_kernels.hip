@@ -756,10 +756,17 @@ struct RowSink {
     // barrier nor share a global atomic — and leaves its count in seg_count[blockIdx.x]; sink_compact_kernel then moves the
     // segments into `rows` back to back and writes *count.  nullptr: rows are appended directly (one global atomic per workgroup
     // and iteration behind two barriers, or one per wave in the bucketed launch).
+    // A row that finds its workgroup's segment full is not lost (round 4, ADVICE: one workgroup's share of the kept rows is not bounded
+    // by any multiple of the mean — bucketed launches pull pieces at their own pace, and a file may keep all its rows in one stretch):
+    // it goes to the SPILL area behind the segments (spill_cap rows, its place from one global counter per wave — the slow path, taken
+    // by skewed launches only), and sink_compact_kernel appends the spilled rows behind the segments' rows.  *count is then exactly
+    // the number of kept rows, above cap only when there were more kept rows than cap.
     hc_gather_row* seg_buf;
     uint32_t* seg_count;
     uint32_t seg_rows;
-    uint32_t pad_;
+    uint32_t spill_cap;
+    hc_gather_row* spill_buf;
+    uint32_t* spill_count;  // zero when the launch starts (sink_compact_kernel re-arms the counter of the launch after the next)
 };
 
 // Called by ALL lanes of the workgroup (uniform control flow; `valid` = this lane scored candidate i).
@@ -1016,44 +1023,73 @@ __device__ __forceinline__ void append_rows_segment(const RowSink& sink, bool va
             sink.seg_buf[(uint64_t)blockIdx.x * sink.seg_rows + pos] = r;
         }
     }
+    if (base + (uint32_t)__popcll(m) > sink.seg_rows) {  // wave-uniform: some of this wave's rows found the segment full
+        const bool over = keep && base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) >= sink.seg_rows;
+        const uint64_t mo = __ballot(over);
+        uint32_t sbase = 0;
+        if (lane == 0) sbase = atomicAdd(sink.spill_count, (uint32_t)__popcll(mo));
+        sbase = (uint32_t)__shfl((int)sbase, 0, 64);
+        if (over) {
+            const uint32_t pos = sbase + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
+            if (pos < sink.spill_cap) {
+                hc_gather_row r;
+                r.index = sink.base_index + i;
+                r.x1 = res.x1;
+                r.x2 = res.x2;
+                r.mm = res.mm;
+                r.n_cls = res.n_cls;
+                sink.spill_buf[pos] = r;
+            }
+        }
+    }
 }
 
-// The segments of a launch back to back into the payload: workgroup g adds up the counts in front of it (at most 4 096 of them),
-// copies its rows as 16-byte pieces, and the last one writes the total — pushed beyond `cap` when a segment overflowed, so that
-// the caller sees rows were lost (hc_score_pack_device's contract).
+// The segments of a launch back to back into the payload, the spilled rows behind them: workgroup g adds up the counts in front of
+// it and all of them (at most 4 096), copies its rows as 16-byte pieces and a share of the spilled ones, and the last one writes the
+// total = the number of kept rows (nothing is written beyond `cap`; a total above cap tells the caller rows were lost:
+// hc_score_pack_device's contract).  spill_next: the counter the launch after this one spills through, zeroed here.
 __global__ __launch_bounds__(256) void sink_compact_kernel(const hc_gather_row* __restrict__ seg_buf, const uint32_t* __restrict__ seg_count, uint32_t seg_rows,
                                                            uint32_t G, hc_gather_row* __restrict__ rows, unsigned long long cap,
-                                                           unsigned long long* __restrict__ count) {
-    __shared__ unsigned long long part[4];
-    __shared__ uint32_t lost[4];
+                                                           unsigned long long* __restrict__ count, const hc_gather_row* __restrict__ spill_buf,
+                                                           const uint32_t* __restrict__ spill_count, uint32_t spill_cap, uint32_t* __restrict__ spill_next) {
+    __shared__ unsigned long long part[8];
     const uint32_t g = blockIdx.x, tid = threadIdx.x;
-    unsigned long long before = 0;
-    uint32_t over = 0;
+    unsigned long long before = 0, all = 0;
     for (uint32_t k = tid; k < G; k += 256) {
-        const uint32_t c = seg_count[k];
-        if (k < g) before += c < seg_rows ? c : seg_rows;
-        over |= c > seg_rows ? 1u : 0u;
+        const uint32_t c = seg_count[k] < seg_rows ? seg_count[k] : seg_rows;
+        if (k < g) before += c;
+        all += c;
     }
     for (int o = 32; o > 0; o >>= 1) {
         before += __shfl_down(before, o, 64);
-        over |= (uint32_t)__shfl_down((int)over, o, 64);
+        all += __shfl_down(all, o, 64);
     }
     if ((tid & 63u) == 0) {
         part[tid >> 6] = before;
-        lost[tid >> 6] = over;
+        part[4 + (tid >> 6)] = all;
     }
     __syncthreads();
     before = part[0] + part[1] + part[2] + part[3];
-    over = lost[0] | lost[1] | lost[2] | lost[3];
+    all = part[4] + part[5] + part[6] + part[7];
     const uint32_t mine = seg_count[g] < seg_rows ? seg_count[g] : seg_rows;
     const uint4* src = (const uint4*)(seg_buf + (uint64_t)g * seg_rows);
     uint4* dst = (uint4*)(rows + before);
     const unsigned long long room = before < cap ? cap - before : 0ull;
     const uint32_t n_copy = mine < room ? mine : (uint32_t)room;
     for (uint32_t k = tid; k < 2u * n_copy; k += 256) dst[k] = src[k];  // 32-byte rows as two 16-byte pieces
+    const uint32_t spilled = *spill_count;
+    if (spilled) {  // the slow path's rows, dealt to the workgroups row by row
+        const uint32_t have = spilled < spill_cap ? spilled : spill_cap;
+        for (uint64_t k = (uint64_t)g * 256 + tid; k < have; k += (uint64_t)G * 256) {
+            if (all + k < cap) {
+                ((uint4*)(rows + all + k))[0] = ((const uint4*)(spill_buf + k))[0];
+                ((uint4*)(rows + all + k))[1] = ((const uint4*)(spill_buf + k))[1];
+            }
+        }
+    }
     if (g == G - 1 && tid == 0) {
-        const unsigned long long total = before + mine;
-        *count = over ? (total > cap ? total : cap + 1ull) : total;
+        *count = all + spilled;
+        *spill_next = 0;
     }
 }
 
@@ -1420,7 +1456,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in, hc_line_rec* lines_out, uint32_t* bucket_perm, uint32_t* bucket_queue, hc_gather_row* seg_buf,
-                        uint32_t* seg_count, uint64_t seg_total_rows) {
+                        uint32_t* seg_count, uint64_t seg_total_rows, uint32_t* spill_turn) {
     if (n == 0) return hipSuccess;
     const uint32_t lg = lut_lg(st.K);
     if (fetch_group == 0) {
@@ -1448,22 +1484,28 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             static const int grid_mult = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 4;  // experiment knob
             const uint64_t cap_c = (uint64_t)n_cu * per_cu * (bucketed ? 1 : grid_mult);  // a queue needs resident workgroups only
             if (blocks_c > cap_c) blocks_c = cap_c;
-            RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u};
-            // the plain launches collect their rows in per-workgroup segments (RowSink); G = the launch's workgroups
-            const bool segmented = rows && seg_buf && seg_count && !lines_in;
+            RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u, nullptr, nullptr};
+            // the cooperative launches collect their rows in per-workgroup segments (RowSink); G = the launch's workgroups.  Of the
+            // seg_total_rows rows of scratch the last `cap` are the spill area, the others are dealt to the workgroups.
+            const bool segmented = rows && seg_buf && seg_count && spill_turn && !lines_in && cap < 0xFFFFFFFFull && seg_total_rows > cap;
             bool seg_on = false;
             auto use_segments = [&](uint64_t G) {
-                seg_on = segmented && G <= 4096;  // seg_count holds 4 096 counters (a larger grid only under HC_GRID_MULT)
+                seg_on = segmented && G <= kSinkMaxGroups;  // seg_count holds that many counters (a larger grid only under HC_GRID_MULT)
                 if (!seg_on) return;
-                const uint64_t per = seg_total_rows / G;
+                const uint64_t per = (seg_total_rows - cap) / G;
                 sink.seg_buf = seg_buf;
                 sink.seg_count = seg_count;
                 sink.seg_rows = (uint32_t)std::min<uint64_t>(per, 0xFFFFFFFFull);
+                sink.spill_buf = seg_buf + (seg_total_rows - cap);
+                sink.spill_cap = (uint32_t)cap;
+                sink.spill_count = seg_count + kSinkMaxGroups + (*spill_turn & 1u);
             };
             auto compact_segments = [&](uint64_t G) {
                 if (seg_on)
                     hipLaunchKernelGGL(sink_compact_kernel, dim3((uint32_t)G), dim3(256), 0, stream, (const hc_gather_row*)seg_buf, (const uint32_t*)seg_count,
-                                       sink.seg_rows, (uint32_t)G, rows, (unsigned long long)cap, row_count);
+                                       sink.seg_rows, (uint32_t)G, rows, (unsigned long long)cap, row_count, (const hc_gather_row*)sink.spill_buf,
+                                       (const uint32_t*)sink.spill_count, sink.spill_cap, seg_count + kSinkMaxGroups + ((*spill_turn + 1u) & 1u));
+                if (seg_on) ++*spill_turn;  // the next segmented launch spills through the counter this one has just zeroed
             };
             const bool sort_subs = bucketed || !(prm.pad & 1u);
             static const int deep_env = getenv("HC_COOP_DEPTH") ? atoi(getenv("HC_COOP_DEPTH")) : 0;  // experiment knob: 1 = one step in flight always
@@ -1548,7 +1590,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     uint64_t blocks = (n + per_wg - 1) / per_wg;
     const uint64_t grid_cap = (uint64_t)n_cu * blocks_per_cu * 4;  // grid-stride beyond this
     if (blocks > grid_cap) blocks = grid_cap;
-    const ScoreLaunch a{st, prm, lut_g, in, n, out, perm, RowSink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u}, (uint32_t)blocks, wg, lds, stream};
+    const ScoreLaunch a{st, prm, lut_g, in, n, out, perm, RowSink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u, nullptr, nullptr}, (uint32_t)blocks, wg, lds, stream};
     if (st.symbytes == 2) launch_lg<uint16_t, 5>(fetch_group, a);
     else if (lg == 3) launch_lg<uint8_t, 3>(fetch_group, a);
     else if (lg == 4) launch_lg<uint8_t, 4>(fetch_group, a);

@@ -280,8 +280,13 @@ int hc_compact_pack_device(hc_ctx* ctx, const void* d_results, uint64_t n, void*
 /* Scoring and collection payload in ONE kernel: like hc_score_batch_device, and every record that is not dropped is also
  * appended (tagged with base_index + its position) to d_payload in the layout of hc_compact_pack_device — row 0 counts
  * them — by the scoring kernel itself: no compaction pass over the results.  The rows arrive in no particular order
- * (sort by index if sequence order matters); a count above cap means rows were dropped: rerun with a larger cap.
- * rec_fmt: HC_REC_FULL (d_in holds hc_overlap_rec) or HC_REC_COMPACT (hc_cand_rec).  Every read set takes this path. */
+ * (sort by index if sequence order matters); the count is the number of kept rows exactly, so a count above cap means —
+ * and only means — that there were more kept rows than cap and the surplus was dropped: rerun with a larger cap.
+ * rec_fmt: HC_REC_FULL (d_in holds hc_overlap_rec) or HC_REC_COMPACT (hc_cand_rec).  Every read set takes this path.
+ * Streams: the device entry points (this one, hc_score_batch_device, hc_score_cands_device, hc_score_compact_device) may be given
+ * different streams on one context; launches that need the context's scratch (row collection, hc_set_reorder, length-bucketed
+ * read sets) are then ordered behind one another on the device, others run side by side.  Calls on one context come from
+ * one host thread at a time. */
 int hc_score_pack_device(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index,
                          void* d_payload, void* hip_stream);
 
@@ -369,6 +374,10 @@ typedef struct hc_text_result {
 typedef struct hc_textblock hc_textblock;
 /* read_ids[r] = id of m_read_vec[r]; the first occurrence of an id wins (std::map::insert, FastqStorage.h:88-97). */
 int hc_text_set_ids(hc_ctx* ctx, const uint64_t* read_ids, uint32_t n_reads);
+/* hc_textblock_create reads nothing of the context but its device number and changes nothing of it (streams, events and
+ * allocations of the block's own; errors go to the calling thread's hc_last_error): it may run on a second host thread beside
+ * hc_set_reads / hc_text_set_ids on the same context (the stage's constructor does).  hc_textblock_submit hands the copy streams
+ * of the context round: submits on one context come from one host thread at a time. */
 int hc_textblock_create(hc_ctx* ctx, uint64_t max_bytes, hc_textblock** out);
 /* The block's page-locked text buffer (max_bytes): the caller reads the file straight into it. */
 char* hc_textblock_buffer(hc_textblock* b);
