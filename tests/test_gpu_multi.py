@@ -28,17 +28,17 @@ def _n_devices():
     return torch.cuda.device_count()
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
-def test_two_ranks_over_rccl_collect_what_one_device_computes(tmp_path, scaling):
+def test_ranks_over_rccl_collect_what_one_device_computes(tmp_path, scaling, world):
     n_dev = _n_devices()
-    if n_dev < 2:
-        pytest.skip(f"{n_dev} GPU(s) visible: the N > 1 path needs two")
-    world = 2
+    if n_dev < world:
+        pytest.skip(f"{n_dev} GPU(s) visible: this case needs {world}")
     rows_file = str(tmp_path / "rows.npy")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-           "--workload", "c2", "--scaling", scaling, "--no-stage", "--no-cpu-baseline", "--also", "none", "--dump-rows", rows_file]
+           "--workload", "c2", "--scaling", scaling, "--one-mode", "--no-stage", "--no-cpu-baseline", "--also", "none", "--dump-rows", rows_file]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -71,3 +71,50 @@ def test_two_ranks_over_rccl_collect_what_one_device_computes(tmp_path, scaling)
     assert rows.shape == want.shape and np.array_equal(rows, want), "the gathered rows are not the one-device result"
     expected_total = sum(c.size for c in per_rank) if scaling == "weak" else per_rank[0].size
     assert sum(p["candidates"] for p in ranks["per_rank"]) == expected_total
+
+
+def test_one_pass_yields_both_curves():
+    """The driver's command line (no --scaling, no --one-mode) at N = 2: the headline is the weak figure, the strong split of the one
+    candidate set rides along under "strong" with its own per-rank record, and both passed their in-run parity checks."""
+    n_dev = _n_devices()
+    if n_dev < 2:
+        pytest.skip(f"{n_dev} GPU(s) visible: the N > 1 path needs two")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "c2", "--no-stage", "--no-cpu-baseline", "--also", "none"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "weak" and line["config"]["candidates_per_step"] == 2 * line["config"]["candidates_per_gpu"]
+    st = line["strong"]
+    assert st["scaling"] == "strong" and st["candidates_per_step"] == line["config"]["candidates_per_gpu"]
+    assert st["ranks"]["n_ranks_seen"] == 2 and sum(p["candidates"] for p in st["ranks"]["per_rank"]) == st["candidates_per_step"]
+    assert st["parity"]["digest_matches_untimed_launch"] and line["parity"]["parity_checked_records"] > 0
+
+
+def test_hc_edgecalc_device_mask_over_real_devices(tmp_path):
+    """The process boundary on more than one GPU: hc-edgecalc --device_mask 3 deals the blocks of the overlaps file to two devices;
+    graph and non-edge file equal the one-device run's."""
+    n_dev = _n_devices()
+    if n_dev < 2:
+        pytest.skip(f"{n_dev} GPU(s) visible: --device_mask 3 needs two")
+    from haploconduct_amd import host, synth
+
+    reads, meta = synth.make_paired_dataset(4000, 6000, flip_frac=0.25, seed=21)
+    cand = synth.paired_candidates(meta, n_candidates=600000, seed=22)
+    d = str(tmp_path) + "/"
+    host.write_overlaps(d + "overlaps.txt", cand, reads)
+    reads.write_fastq(None, d + "p1.fastq", d + "p2.fastq")
+    exe = os.path.join(ROOT, "haploconduct_amd", "csrc", "hc-edgecalc")
+    outs = {}
+    for name, mask in (("one", "1"), ("two", "3")):
+        o = d + name + "/"
+        os.mkdir(o)
+        r = subprocess.run([exe, "--paired1", d + "p1.fastq", "--paired2", d + "p2.fastq", "--overlaps", d + "overlaps.txt", "--output", o,
+                            "--edge_threshold", "0.97", "--min_overlap_len", "150", "--threads", "8", "--device_mask", mask, "--graph_only", "true",
+                            "--original_readcount", str(reads.n_reads)],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[name] = {f: open(o + f, "rb").read() for f in sorted(os.listdir(o)) if f in ("edges.tsv", "edges_sorted.tsv", "nonedge_overlaps.txt", "edgecalc_stats.txt")}
+    assert len(outs["one"]) == 4 and len(outs["one"]["edges_sorted.tsv"]) > 10000 and outs["one"] == outs["two"]

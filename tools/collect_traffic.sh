@@ -17,7 +17,11 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-stage --also none"
 pass() { d=$1; shift; rocprofv3 "$@" --kernel-trace --output-format csv -d $O/$d -- $B > $O/$d.out 2> $O/$d.err || echo "pass $d failed" >&2; }
+# the duration pass traces >= 30 launches of the kernel and the file keeps their MEDIAN (round 3 kept the mean of nine, one of them an outlier)
+B_COUNTERS=$B
+B="python3 $R/bench.py --workload $W --steps 30 --warmup 2 --no-cpu-baseline --no-stage --also none"
 pass stats --stats
+B=$B_COUNTERS
 pass fetch --pmc FETCH_SIZE
 pass write --pmc WRITE_SIZE
 pass l2 --pmc TCC_HIT_sum TCC_MISS_sum
@@ -51,6 +55,7 @@ fetch_kb, write_kb = out.get("FETCH_SIZE", 0.0), out.get("WRITE_SIZE", 0.0)
 sha = open("$R/.build_sha").read().strip() if os.path.exists("$R/.build_sha") else None
 res = {"workload": "$W", "order": "sfo", "record_bytes": 16,
        "kernel": names.most_common(1)[0][0] if names else None,
+       "kernel_ms_rocprof_median": sorted(dur)[len(dur) // 2] if dur else None, "kernel_ms_rocprof_min": min(dur) if dur else None,
        "kernel_ms_rocprof_avg": sum(dur) / len(dur) if dur else None, "kernel_launches_traced": len(dur),
        "other_kernels_ms_avg": {k.split("(")[0]: sum(v) / len(v) for k, v in others.items() if "bucket_perm" in k},
        "kernel_ms_hipevents_under_rocprof": (bench_line.get("roofline") or {}).get("kernel_ms"),
