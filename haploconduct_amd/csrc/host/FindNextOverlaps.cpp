@@ -1250,9 +1250,19 @@ int guarded_fno(const char* where, F&& f) {
 
 extern "C" {
 
+// (--add_duplicates and flags this build does not know: refused by name, hcfno.h)
+static int refuse_unbuilt_flags(const char* who, uint32_t flags) {
+    if (flags & HC_FNO_ADD_DUPLICATES)
+        return hc::set_last_error(HC_ERR_ARG, std::string(who) + ": HC_FNO_ADD_DUPLICATES (--add_duplicates) is not built: the reference's branches "
+                                              "src/FindNextOverlaps.cpp:672-675,699-793 have no counterpart here; no workflow sets the flag");
+    if (flags & ~HC_FNO_KNOWN_FLAGS) return hc::set_last_error(HC_ERR_ARG, std::string(who) + ": unknown bit in flags");
+    return HC_OK;
+}
+
 int hc_fno1_run(const hc_fno1_input* in, hc_fno_output** out) {
     if (!in || !out) return hc::set_last_error(HC_ERR_ARG, "hc_fno1_run: null argument");
     *out = nullptr;
+    if (int rc = refuse_unbuilt_flags("hc_fno1_run", in->flags)) return rc;
     return guarded_fno("hc_fno1_run", [&] {
         std::unique_ptr<hc_fno_output> o(new hc_fno_output());
         Fno1(*in).run(*o);
@@ -1263,6 +1273,7 @@ int hc_fno1_run(const hc_fno1_input* in, hc_fno_output** out) {
 int hc_fno3_run(const hc_fno3_input* in, hc_fno_output** out) {
     if (!in || !out) return hc::set_last_error(HC_ERR_ARG, "hc_fno3_run: null argument");
     *out = nullptr;
+    if (int rc = refuse_unbuilt_flags("hc_fno3_run", in->flags)) return rc;
     return guarded_fno("hc_fno3_run", [&] {
         std::unique_ptr<hc_fno_output> o(new hc_fno_output());
         Fno3(*in).run(*o);

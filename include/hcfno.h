@@ -68,6 +68,12 @@ typedef struct hc_fno_original {
 #define HC_FNO_RESOLVE_ORIENTATIONS 0x1u /* program_settings.resolve_orientations */
 #define HC_FNO_NO_INCLUSIONS        0x2u /* program_settings.no_inclusions */
 #define HC_FNO_OPTIMIZE             0x4u /* program_settings.optimize: skip the stored non-edges (:914) */
+/* program_settings.add_duplicates: the reference's FNO=1 then takes a vertex per read AND strand and adds every stored non-edge a
+ * second time, mirrored (src/FindNextOverlaps.cpp:672-675, 699-793).  NOT BUILT (no workflow of the reference sets the flag:
+ * savage.py / polyte.py / pipeline_per_stage.py never pass --add_duplicates): hc_fno1_run and hc_fno3_run refuse an input that
+ * carries this bit — or any bit they do not know — with HC_ERR_ARG and a message naming it, instead of computing something else. */
+#define HC_FNO_ADD_DUPLICATES       0x8u
+#define HC_FNO_KNOWN_FLAGS          (HC_FNO_RESOLVE_ORIENTATIONS | HC_FNO_NO_INCLUSIONS | HC_FNO_OPTIMIZE)
 
 typedef struct hc_fno1_input {
     /* vertices of the overlap graph, index = vertex id */

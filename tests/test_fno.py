@@ -363,3 +363,28 @@ def test_super_read_order_is_part_of_the_contract(olib):
     assert ei.value.status == -1 and "single-end first" in str(ei.value)
     with pytest.raises(T.OracleAbort):
         T.oracle_fno1(olib, inp)
+
+
+def test_add_duplicates_is_refused_by_name():
+    """FNO's --add_duplicates branches (src/FindNextOverlaps.cpp:672-675,699-793) are not built: the entry points say so instead of
+    computing the run without them (no workflow of the reference sets the flag)."""
+    from haploconduct_amd import _native as N
+
+    inp = T.fno1_scenario(3, n_nodes=30, n_srs=10, n_edges=80, with_extras=True, flags=F.RESOLVE_ORIENTATIONS | F.ADD_DUPLICATES)
+    with pytest.raises(N.HcError) as e:
+        F.find_next_overlaps(inp)
+    assert "HC_FNO_ADD_DUPLICATES" in str(e.value) and "not built" in str(e.value)
+    inp.flags = 0x40  # a bit nobody defined
+    with pytest.raises(N.HcError) as e:
+        F.find_next_overlaps(inp)
+    assert "unknown bit" in str(e.value)
+    srs = np.array([T.make_read(0, 100, 0, 0), T.make_read(1, 100, 0, 0)], F.FNO_READ_DTYPE)
+    origs = []
+    for idx in (0, 5):
+        a = np.zeros(1, F.FNO_ORIGINAL_DTYPE)
+        a["original_id"], a["index1"], a["index2"] = 5, idx, 0
+        origs.append(a)
+    inp3 = F.Fno3Input(srs, 0, 0, 2, origs, new_read_count=2000, original_readcount=1, flags=F.ADD_DUPLICATES)
+    with pytest.raises(N.HcError) as e:
+        F.find_next_overlaps3(inp3)
+    assert "HC_FNO_ADD_DUPLICATES" in str(e.value)

@@ -1,0 +1,104 @@
+"""INTEGRATION.md level A, compiled and run: the REFERENCE'S OWN src/EdgeCalculator.cpp:26-557 with the seven pieces of
+integration/reference_patch/ inserted at the lines INTEGRATION.md names — the class members and constructor lines, the short cut
+at the head of overlap_score, the three insertions in process_overlaps, the two new member functions — compiled against
+include/hcedge.h and linked to libhcedge.so (oracle/Makefile: _ref/libhcref_edgecalc_patched.so, built in the build container,
+shipped with the repository).  So here the reference's own Overlap / Read / Edge types, its compute_overlap (sequence choice,
+sub-overlap combination, reverse offsets), its 3-way class, its serial insert with the tie-break chain and its OverlapGraph run
+around scores that come from the MI355X.  The nine scenarios of tests/golden/ec/ (outputs of the UNPATCHED reference lines) must
+come out byte for byte: edges in list order with score and mismatch rate as bit patterns, inclusions, nonedge_overlaps.txt,
+inclusion_count, dup_count."""
+import ctypes as C
+import glob
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_ec_golden import CASES, load_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc_patched.so")
+
+
+@pytest.fixture(scope="module")
+def patched():
+    if not os.path.exists(LIB):
+        pytest.skip("oracle/_ref/libhcref_edgecalc_patched.so is built only where /root/reference exists")
+    spec = importlib.util.spec_from_file_location("make_golden_ec", os.path.join(ROOT, "tests", "golden", "make_golden_ec.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    ref = C.CDLL(LIB)
+    vp = C.c_void_p
+    ref.frag_process_overlaps.restype = C.c_int
+    ref.frag_process_overlaps.argtypes = [C.POINTER(mg.FragSettings), vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, C.c_char_p, vp,
+                                          C.c_uint64, C.POINTER(C.c_uint64), vp, C.POINTER(vp), C.POINTER(C.c_uint64), vp]
+    ref.frag_ec_free.argtypes = [vp]
+    return mg, ref
+
+
+def test_the_patch_files_are_what_integration_md_quotes():
+    """Every line of every piece under integration/reference_patch/ appears in INTEGRATION.md, in order."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    pieces = sorted(glob.glob(os.path.join(ROOT, "integration", "reference_patch", "*.inc")))
+    assert len(pieces) == 7
+    for p in pieces:
+        text = open(p).read().rstrip("\n")
+        assert text in doc, f"INTEGRATION.md does not quote {os.path.basename(p)} verbatim"
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
+def test_reference_code_with_hip_scoring_reproduces_the_reference(patched, path):
+    mg, ref = patched
+    c, reads, st, want = load_case(path)
+    edges, incl, nonedge, counters = mg.run_probe(ref, reads, c["lines"], c["settings"])
+    assert len(edges) == len(c["edges"]), f"{len(edges)} edges, the unpatched reference built {len(c['edges'])}"
+    assert edges == c["edges"], "an Edge differs (scores and mismatch rates compared as hex floats)"
+    assert incl == c["inclusions"]
+    assert nonedge == c["nonedge_overlaps"]
+    assert counters == [c["inclusion_count"], c["dup_count"]]
+
+
+def test_patched_construct_edges_on_a_file(patched, tmp_path):
+    """The reference's own construct_edges (parser, prefilter, batches) over the patched process_overlaps, against the unpatched
+    probe on the same file: 60 000 lines of 2x150 pairs, two OpenMP threads on the patched side (the thread-local hand-over)."""
+    from haploconduct_amd import host, synth
+
+    mg, ref = patched
+    plain_path = os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so")
+    if not os.path.exists(plain_path):
+        pytest.skip("no unpatched probe")
+    plain = C.CDLL(plain_path)
+    reads, meta = synth.make_paired_dataset(3000, 4000, flip_frac=0.25, seed=41)
+    cand = synth.paired_candidates(meta, n_candidates=60000, seed=42)
+    path = str(tmp_path / "overlaps.txt")
+    host.write_overlaps(path, cand, reads)
+    seqs, quals = zip(*(reads.seq(q) for q in range(reads.n_seq)))
+    S, Q = (C.c_char_p * len(seqs))(*seqs), (C.c_char_p * len(quals))(*quals)
+    ids = np.ascontiguousarray(reads.read_ids, dtype=np.uint64)
+    fs = mg.FragSettings(0.97, 0.9, 0.0, 0.0, 0, 0)
+    pre = (C.c_uint32 * 3)(150, 0, 0)
+    vp = C.c_void_p
+    out = {}
+    for name, lib in (("plain", plain), ("patched", ref)):
+        lib.frag_construct_edges.restype = C.c_int
+        lib.frag_construct_edges.argtypes = [C.POINTER(mg.FragSettings), vp, C.c_uint64, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, vp,
+                                             C.c_uint64, C.POINTER(C.c_uint64), vp, C.POINTER(vp), C.POINTER(C.c_uint64), vp]
+        lib.frag_ec_free.argtypes = [vp]
+        cap = cand.size
+        edges = (mg.FragEdge * cap)()
+        n_edges, nb = C.c_uint64(), C.c_uint64()
+        incl = np.zeros(reads.n_reads, np.uint8)
+        text = vp()
+        counters = (C.c_uint32 * 3)()
+        d = tmp_path / name
+        d.mkdir()
+        rc = lib.frag_construct_edges(C.byref(fs), pre, 10 ** 8, S, Q, ids.ctypes.data, 0, reads.n_reads, path.encode(), str(d).encode(), edges, cap,
+                                      C.byref(n_edges), incl.ctypes.data, C.byref(text), C.byref(nb), counters)
+        assert rc == 0
+        out[name] = (bytes(C.string_at(C.addressof(edges), int(n_edges.value) * C.sizeof(mg.FragEdge))), incl.tobytes(),
+                     C.string_at(text, nb.value), list(counters))
+        lib.frag_ec_free(text)
+    assert len(out["plain"][0]) > 1000 * 80
+    assert out["plain"] == out["patched"]

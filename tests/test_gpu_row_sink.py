@@ -93,7 +93,7 @@ def test_launches_on_two_streams_of_one_context():
     """Collecting launches given different streams share the context's segments: the library orders them on the device."""
     import torch
 
-    reads, meta = synth.make_paired_dataset(3000, 4500, flip_frac=0.25, seed=77)
+    reads, meta = synth.make_paired_dataset(10000, 8000, flip_frac=0.25, seed=77)
     a = synth.paired_candidates(meta, n_candidates=400000, seed=78)
     b = synth.paired_candidates(meta, n_candidates=250000, seed=79)
     st = hc.Settings(edge_threshold=0.97)

@@ -1,0 +1,80 @@
+"""RESTATEMENT ONLY — the three statements of the path that nothing reference-side executes in this repository, because they are
+Boost calls and the image has no Boost (the pinning table):
+
+  src/EdgeCalculator.cpp:584   boost::trim_if(tupleline, boost::is_any_of("\\t "))
+  src/EdgeCalculator.cpp:587   boost::split(tokens, tupleline, boost::is_any_of("\\t "), boost::token_compress_on)   (--allow_spaced_overlaps)
+  src/FastqStorage.cpp:123     boost::to_upper_copy(line)                                                               (read_singles)
+
+The product and the oracle both restate them from Boost's documented behaviour; the tests below hold the product to an
+independent model of that documented behaviour written here in Python.  They do NOT pin anything against reference code — every
+test name says so."""
+import random
+import re
+
+import numpy as np
+import pytest
+
+from haploconduct_amd import host
+
+
+def _lines(seed, n=2000):
+    rng = random.Random(seed)
+    alphabet = ["\t", "\t", " ", " ", "a", "12", "-", "+", "s", "p", "", "0x1F", "\t\t", "  "]
+    out = ["", " ", "\t", " \t ", "a", "a\tb", "a\t\tb", " a \t b ", "\ta\tb\t", "a b\tc", "1\t2\t3\t-\t-\t+\t+\t9\t-\t8\t-\ts\ts",
+           " 1 2 3 - - + + 9 - 8 - s s ", "1  2\t \t3"]
+    for _ in range(n):
+        out.append("".join(rng.choice(alphabet) for _ in range(rng.randrange(0, 30))))
+    return out
+
+
+def test_restatement_only_line_trim_then_tab_split_without_compression():
+    """:584 then :590-596: both ends lose every tab and space; fields are cut at every single tab (empty fields stay)."""
+    for ln in _lines(1):
+        trimmed = ln.strip("\t ")
+        want = trimmed.split("\t")  # str.split with a separator keeps empty fields; "" -> [""]: one empty token, as the reference's loop
+        n, got = host.split_line(ln, False, max_fields=64)
+        assert n == len(want) and got == want[:64], repr(ln)
+
+
+def test_restatement_only_allow_spaced_overlaps_split_compresses_runs():
+    """:587 with token_compress_on: runs of tabs and spaces are ONE separator; the trimmed empty line is one empty token."""
+    for ln in _lines(2):
+        trimmed = ln.strip("\t ")
+        want = re.split(r"[\t ]+", trimmed)
+        n, got = host.split_line(ln, True, max_fields=64)
+        assert n == len(want) and got == want[:64], repr(ln)
+
+
+def test_restatement_only_spaced_line_parses_like_its_tabbed_twin():
+    """A 13-field line written with spaces (and runs of them) is the same Overlap under --allow_spaced_overlaps as its tabbed form
+    without the flag; without the flag the spaced form does not have 13 fields."""
+    rng = random.Random(3)
+    for _ in range(300):
+        f = [str(rng.randrange(1, 10 ** 6)), str(rng.randrange(1, 10 ** 6)), str(rng.randrange(0, 200)), "-", "-", rng.choice("+-"), rng.choice("+-"),
+             str(rng.randrange(0, 101)), "-", str(rng.randrange(1, 300)), "-", "s", "s"]
+        tabbed = "\t".join(f)
+        spaced = "".join(x + rng.choice([" ", "  ", "\t", " \t", "\t "]) for x in f).rstrip("\t ")
+        rc_t, a = host.parse_overlap(tabbed, allow_spaces=False)
+        rc_s, b = host.parse_overlap(spaced, allow_spaces=True)
+        assert rc_t == 0 and rc_s == 0 and a == b
+        if " " in spaced:
+            rc_n, _ = host.parse_overlap(spaced, allow_spaces=False)
+            assert rc_n != 0 or host.split_line(spaced, False)[0] == 13
+
+
+def test_restatement_only_lower_case_singles_are_upper_cased_pairs_are_not(tmp_path):
+    """:123 (read_singles) upper-cases the sequence line of a single-end read — ASCII letters only, every other byte as it is;
+    read_pairs has no such call (src/FastqStorage.cpp:197-198)."""
+    rng = np.random.default_rng(4)
+    pool = np.frombuffer(b"ACGTNacgtnRYKMrykm*.-xX", np.uint8)
+    seqs = [bytes(pool[rng.integers(0, pool.size, rng.integers(1, 60))]) for _ in range(200)]
+    s = tmp_path / "s.fastq"
+    s.write_bytes(b"".join(b"@%d\n%s\n+\n%s\n" % (i, q, b"I" * len(q)) for i, q in enumerate(seqs)))
+    p1, p2 = tmp_path / "p1.fastq", tmp_path / "p2.fastq"
+    p1.write_bytes(b"".join(b"@%d\n%s\n+\n%s\n" % (1000 + i, q, b"I" * len(q)) for i, q in enumerate(seqs)))
+    p2.write_bytes(b"".join(b"@%d\n%s\n+\n%s\n" % (1000 + i, q[::-1], b"5" * len(q)) for i, q in enumerate(seqs)))
+    f = host.Fastq(singles=str(s), paired1=str(p1), paired2=str(p2))
+    rs = f.readset()
+    for i, q in enumerate(seqs):
+        assert rs.seq(i)[0] == q.upper(), "singles: upper-cased"
+        assert rs.seq(len(seqs) + 2 * i)[0] == q and rs.seq(len(seqs) + 2 * i + 1)[0] == q[::-1], "pairs: as in the file"
