@@ -212,6 +212,15 @@ def build_workload(workload, rank):
         st = dict(edge_threshold=0.995, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=100)
         desc = f"c6: {n_reads} synthetic singles of 2000 bp, {cand.size} s-s candidates"
         cfg = {"reads": n_reads, "genome_len": glen}
+    elif workload == "c1s":
+        # the SAVAGE-example shape at timing size: merged single-end reads of 400..500 bp (savage/example/input_fas/singles.fastq: 2 000
+        # of them beside 200 pairs), s-s candidates, stage-a settings (savage.py:384: --edge_threshold 0.97, M = 200)
+        n_reads, glen = 100000, 300000
+        reads, meta = synth.make_single_dataset(n_reads, glen, len_lo=400, len_hi=500, n_strains=3, divergence=0.01, flip_frac=0.5, seed=8)
+        cand = synth.single_candidates(meta, min_overlap=200, n_candidates=2000000)
+        st = dict(edge_threshold=0.97, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=200)
+        desc = f"c1s: {n_reads} synthetic singles of 400..500 bp (the SAVAGE example's merged reads), {cand.size} s-s candidates"
+        cfg = {"reads": n_reads, "genome_len": glen}
     elif workload in ("c5s", "c5m", "c5t"):
         # tuning workloads for the dispatch between the plain and the length-bucketed launch: reads of mixed but short / medium length
         lo, hi = {"c5s": (100, 400), "c5m": (150, 1500), "c5t": (120, 900)}[workload]
