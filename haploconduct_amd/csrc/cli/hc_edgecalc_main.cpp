@@ -65,6 +65,7 @@ static double now_s() {
 }
 
 int main(int argc, char** argv) {
+    const double t_main = now_s();
     ProgramSettings ps;
     std::vector<Opt> opts;
     std::map<std::string, int> seen;
@@ -247,7 +248,16 @@ int main(int argc, char** argv) {
             printf("Overlap graph ready! Construction took %g seconds.\n", now_s() - t0);
             printf("Number of vertices: %u\n", graph->getVertexCount());
         }
+        // where a short run's time goes (verbose): the HIP runtime's start is paid by the first HIP call of a process
+        t0 = now_s();
+        const int n_devices = hc_device_count();
+        const double t_hip = now_s() - t0;
+        t0 = now_s();
         EdgeCalculator calc(fastq, graph, ps);  // :279
+        const double t_ctor = now_s() - t0;
+        if (ps.verbose)
+            printf("[hc-edgecalc] HIP runtime start %.3f s (%d device(s)), EdgeCalculator (contexts, read store, text blocks) %.3f s\n", t_hip, n_devices,
+                   t_ctor);
         t0 = now_s();
         calc.construct_edges();  // :281
         const double dt = now_s() - t0;
@@ -286,6 +296,7 @@ int main(int argc, char** argv) {
                     graph->getVertexCount(), graph->getEdgeCount(), calc.inclusion_count, calc.dup_count, calc.self_overlap_count);
             fclose(sf);
         }
+        if (ps.verbose) printf("[hc-edgecalc] %.3f s since main() started\n", now_s() - t_main);
     } catch (const FatalError& e) {  // every exit(1) / assert of the reference on this path
         fprintf(stderr, "%s\n", e.what.c_str());
         return 1;

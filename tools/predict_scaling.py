@@ -90,6 +90,8 @@ def main():
                           "measured by the builder"}
     dist.destroy_process_group()
     sys.stdout.flush()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)  # RCCL's banner sits in C stdio: it goes to stderr with the rest
     os.dup2(real_stdout, 1)
     print(json.dumps(out, indent=1))
 
