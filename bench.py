@@ -212,6 +212,14 @@ def build_workload(workload, rank):
         st = dict(edge_threshold=0.995, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=100)
         desc = f"c6: {n_reads} synthetic singles of 2000 bp, {cand.size} s-s candidates"
         cfg = {"reads": n_reads, "genome_len": glen}
+    elif workload == "c2t":
+        # tuning workload: quality-trimmed pairs — mates of 60..150 bp (mixed sequence lengths in a PAIRED set), p-p candidates
+        reads, meta = synth.make_paired_dataset(50000, 45000, seed=1, trim_lo=60)
+        cand = synth.paired_candidates(meta, n_candidates=None, min_len=50, seed=2)
+        cand = cand[:2000000]
+        st = dict(edge_threshold=0.97, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=100)
+        desc = f"c2t: 50000 synthetic pairs trimmed to 60..150 bp per mate, {cand.size} p-p candidates"
+        cfg = {"read_pairs": 50000, "genome_len": 45000}
     elif workload == "c1s":
         # the SAVAGE-example shape at timing size: merged single-end reads of 400..500 bp (savage/example/input_fas/singles.fastq: 2 000
         # of them beside 200 pairs), s-s candidates, stage-a settings (savage.py:384: --edge_threshold 0.97, M = 200)

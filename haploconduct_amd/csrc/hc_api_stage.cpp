@@ -302,4 +302,17 @@ int hc_graph_fetch(hc_ctx* c, hc_edge_rec* edges, uint64_t* out_off, uint32_t* i
     return HC_OK;
 }
 
+int hc_graph_fetch_edges(hc_ctx* c, uint64_t first, uint64_t count, hc_edge_rec* dst) {
+    if (!c) return fail(HC_ERR_ARG, "hc_graph_fetch_edges: null context");
+    hc_ctx::Graph& g = c->graph;
+    if (!g.valid) return fail(HC_ERR_STATE, "hc_graph_fetch_edges: no resolved graph on the device");
+    if (first > g.n_edges || count > g.n_edges - first) return fail(HC_ERR_ARG, "hc_graph_fetch_edges: range beyond the edges");
+    if (count == 0) return HC_OK;
+    if (!dst) return fail(HC_ERR_ARG, "hc_graph_fetch_edges: null destination");
+    HC_HIP(hipSetDevice(c->device));
+    HC_HIP(hipMemcpyAsync(dst, g.edges_out.as<hc_edge_rec>() + first, count * sizeof(hc_edge_rec), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    return HC_OK;
+}
+
 }  // extern "C"

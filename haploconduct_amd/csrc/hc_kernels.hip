@@ -1178,7 +1178,12 @@ __global__ __launch_bounds__(1024) void bucket_perm_kernel(StoreView st, uint32_
 // workgroup barrier (a workgroup-wide sort saved more work and lost it again waiting at its seven barriers).
 // DEPTH: steps of pieces in flight (2: the launch for contig-length read sets, which keeps 8 waves per CU and so has the
 // registers for a second set, StoreView::long_rows).
-template <typename SymT, int LG, int WG, bool SORT, bool DYN, int DEPTH = 1>
+// WQ (round 4, the LDS-DMA form's plain launches): every WAVE takes its work from a queue — items of 64..512 consecutive candidates,
+// handed out by one of (at most) eight counters, counter c serving the workgroups with blockIdx % 8 == c (one XCD under round-robin
+// placement: speed only) from the c-th contiguous eighth of the items — in a grid of one resident workgroup per CU.  The next item is
+// asked for before the current one is scored.  No wave waits for another at a workgroup's end, no CU for another at the launch's end
+// beyond one item.  The last wave to leave zeroes the counters for the launch after this one (queue[8] counts the leavers).
+template <typename SymT, int LG, int WG, bool SORT, bool DYN, int DEPTH = 1, bool WQ = false>
 __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 2 : 1))) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                             const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
                                                             const uint32_t* __restrict__ perm, RowSink sink, uint32_t* __restrict__ queue) {
@@ -1197,6 +1202,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     const uint32_t seg_counter = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(scratch + 24);
     if (threadIdx.x == 0) {
         scratch[24] = 0;
+        scratch[28] = 0;  // WQ: waves of this workgroup that have left
         if (DYN) scratch[26] = atomicAdd(queue, 1u);  // the workgroup's first queue entry; [26], [27]: this iteration's and the next one's
     }
     __syncthreads();
@@ -1221,9 +1227,38 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     const uint32_t n_tiles = DYN ? (uint32_t)((n_hint + kBucketTile - 1) / kBucketTile) : 0u;
     const uint32_t n_pieces = n_tiles * (kBucketTile / WG);
     uint32_t q_ahead = 0, iter = 0;
+    // WQ: this wave's item, the one it has asked for already, where it stands inside the item
+    const uint32_t wq_steps = WQ ? (prm.pad >> 8) : 0u;                 // 64-candidate steps per item (1..8)
+    const uint32_t wq_items = WQ ? (uint32_t)((n + 64ull * wq_steps - 1) / (64ull * wq_steps)) : 0u;
+    const uint32_t wq_shards = gridDim.x < 8u ? gridDim.x : 8u, wq_shard = blockIdx.x % wq_shards;
+    const uint32_t wq_per = WQ ? (wq_items + wq_shards - 1) / wq_shards : 0u;
+    const uint32_t wq_first = wq_shard * wq_per, wq_end = wq_first + wq_per < wq_items ? wq_first + wq_per : wq_items;
+    // The first item of a wave is its rank among the waves that share its counter (no atomic, nothing to wait for); the counter hands out
+    // what lies behind those.  A pull's answer is left in its register until the item is entered (the loop's own vmcnt waits cover it).
+    const uint32_t wq_rank = (blockIdx.x / wq_shards) * (WG / 64) + (tid >> 6);
+    const uint32_t wq_waves = ((gridDim.x - wq_shard + wq_shards - 1) / wq_shards) * (WG / 64);  // waves that pull from this counter
+    uint32_t wq_item = 0, wq_next_raw = 0, wq_k = 0;
+    auto wq_pull = [&]() -> uint32_t {  // issued by lane 0; the other lanes hold 0 and take lane 0's answer when it is used
+        uint32_t t = 0;
+        if ((tid & 63u) == 0) t = atomicAdd(queue + wq_shard, 1u);
+        return t;
+    };
+    if (WQ) {
+        wq_item = wq_first + wq_rank;
+        if (wq_item < wq_end) wq_next_raw = wq_pull();
+    }
     for (uint64_t block_base = (uint64_t)blockIdx.x * WG;; block_base += stride, ++iter) {
         uint64_t slot;
-        if (DYN) {
+        if (WQ) {
+            if (wq_k == wq_steps) {
+                wq_item = wq_first + wq_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_next_raw);
+                wq_k = 0;
+                if (wq_item < wq_end) wq_next_raw = wq_pull();
+            }
+            if (wq_item >= wq_end) break;  // wave-uniform
+            slot = ((uint64_t)wq_item * wq_steps + wq_k) * 64u + (tid & 63u);
+            ++wq_k;
+        } else if (DYN) {
             const uint32_t q = scratch[26 + (iter & 1u)];
             if (q >= n_pieces) break;  // workgroup-uniform
             if (tid == 0) q_ahead = atomicAdd(queue, 1u);
@@ -1344,6 +1379,16 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
         __syncthreads();
         if (threadIdx.x == 0) sink.seg_count[blockIdx.x] = scratch[24];
     }
+    if (WQ && (tid & 63u) == 0) {
+        // the last wave of the launch to leave re-arms the queue (no wave pulls after it has left): the waves of a workgroup count in
+        // LDS, the last of them counts for the workgroup (one global atomic per workgroup, not per wave: 4 096 of them on one word took 50 us)
+        if (lds_add_rtn(seg_counter + 16u, 1u) == WG / 64 - 1u) {
+            if (atomicAdd(queue + 8, 1u) == gridDim.x - 1u) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) __hip_atomic_store(queue + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // (second launch bound: at least 4 waves per SIMD, i.e. at most 128 registers — at 130 the kernel drops to 3 waves per SIMD
@@ -1456,7 +1501,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in, hc_line_rec* lines_out, uint32_t* bucket_perm, uint32_t* bucket_queue, hc_gather_row* seg_buf,
-                        uint32_t* seg_count, uint64_t seg_total_rows, uint32_t* spill_turn) {
+                        uint32_t* seg_count, uint64_t seg_total_rows, uint32_t* spill_turn, uint32_t* wave_queue) {
     if (n == 0) return hipSuccess;
     const uint32_t lg = lut_lg(st.K);
     if (fetch_group == 0) {
@@ -1530,6 +1575,30 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 static const int grid_mult_d = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 16;
                 const uint64_t cap_d = (uint64_t)n_cu * grid_mult_d;
                 if (blocks_d > cap_d) blocks_d = cap_d;
+                // The wave queue pays from ~64 steps of 64 candidates per wave on (2 * 10^7 candidates: level; 10^8: 4 % ahead); below that its
+                // atomics cost more than the even finish gains (2 * 10^6: 0.27 against 0.19 ms) and the static grid stays.
+                // HC_WAVE_QUEUE=0: never; =2: always (experiments and tests); HC_WAVE_QUEUE_STEPS: steps per item
+                static const int wave_queue_mode = getenv("HC_WAVE_QUEUE") ? atoi(getenv("HC_WAVE_QUEUE")) : 1;
+                const uint64_t wq_blocks = std::min<uint64_t>((n + 1023) / 1024, n_cu);
+                const uint64_t per_wave = n / (wq_blocks * 16 * 64);  // 64-candidate steps a wave gets on average
+                if (wave_queue && (wave_queue_mode == 2 || (wave_queue_mode == 1 && per_wave >= 64))) {
+                    // one resident workgroup per CU, the waves pull items of eight 64-candidate steps
+                    blocks_d = wq_blocks;
+                    uint32_t steps = per_wave >= 64 ? 8u : (per_wave >= 32 ? 4u : (per_wave >= 16 ? 2u : 1u));
+                    if (const char* e = getenv("HC_WAVE_QUEUE_STEPS")) steps = (uint32_t)std::min(8, std::max(1, atoi(e)));
+                    ScoreParams pq = prm;
+                    pq.pad = (prm.pad & 0xFFu) | (steps << 8);
+                    use_segments(blocks_d);
+#define HC_COOP_WQ_LAUNCH(LG_)                                                                                                                  \
+    hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_, 1024, true, false, 0, true>), dim3((uint32_t)blocks_d), dim3(1024), lds_dma, stream, st, \
+                       pq, lut_g, in, n, out, perm, sink, wave_queue)
+                    if (lg == 3) HC_COOP_WQ_LAUNCH(3);
+                    else if (lg == 4) HC_COOP_WQ_LAUNCH(4);
+                    else HC_COOP_WQ_LAUNCH(5);
+#undef HC_COOP_WQ_LAUNCH
+                    compact_segments(blocks_d);
+                    return hipGetLastError();
+                }
                 use_segments(blocks_d);
 #define HC_COOP_DMA_LAUNCH(LG_)                                                                                                       \
     hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_, 1024, true, false, 0>), dim3((uint32_t)blocks_d), dim3(1024), lds_dma, stream, st, prm, \
@@ -1670,6 +1739,9 @@ hipError_t set_score_kernel_lds_limit() {
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 3, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 4, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 5, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 3, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 4, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 5, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     HC_COOP_ATTR(uint8_t, 3)
     HC_COOP_ATTR(uint8_t, 4)
     HC_COOP_ATTR(uint8_t, 5)

@@ -506,12 +506,58 @@ void EdgeCalculator::resolve_on_device(bool sorted) {
     std::vector<uint64_t> out_off(V + 1), in_off(V + 1);
     std::vector<uint32_t> tied((size_t)gc.n_tied_lists);
     std::vector<uint8_t> incl(V);
-    check(hc_graph_fetch(m_ctx, edges, out_off.data(), in_nodes, in_off.data(), seq, incl.data(), tied.empty() ? nullptr : tied.data()),
-          "hc_graph_fetch");
-    lap("fetch");
     std::vector<Read*>& reads = fastq_storage->m_read_vec;
-    overlap_graph->adopt_csr(edges, out_off.data(), in_nodes, in_off.data(), incl.data(), reads.data(), reads.size(), program_settings.n_threads);
-    lap("adopt");
+    // HC_FETCH_PIECE_BYTES: bytes of edges per piece (default 32 MiB; 0: the whole graph in one fetch, then adopt — round 3's order; tests
+    // set a few KiB to run small graphs through the pieces)
+    const size_t piece_bytes = getenv("HC_FETCH_PIECE_BYTES") ? (size_t)strtoull(getenv("HC_FETCH_PIECE_BYTES"), nullptr, 10) : ((size_t)32 << 20);
+    if (piece_bytes == 0 || E * sizeof(hc_edge_rec) <= piece_bytes) {
+        check(hc_graph_fetch(m_ctx, edges, out_off.data(), in_nodes, in_off.data(), seq, incl.data(), tied.empty() ? nullptr : tied.data()),
+              "hc_graph_fetch");
+        lap("fetch");
+        overlap_graph->adopt_csr(edges, out_off.data(), in_nodes, in_off.data(), incl.data(), reads.data(), reads.size(), program_settings.n_threads);
+        lap("adopt");
+    } else {
+        // The small arrays first (offsets, in-lists, inclusions: 20 MB at C3), then the 300 MB of edges in pieces of 32 MiB while the host
+        // threads turn what has arrived into the graph's lists (round 3: fetch 7 ms, then adopt 5 - 7 ms, one after the other)
+        check(hc_graph_fetch(m_ctx, nullptr, out_off.data(), in_nodes, in_off.data(), seq, incl.data(), tied.empty() ? nullptr : tied.data()),
+              "hc_graph_fetch");
+        lap("fetch of the offsets and in-lists");
+        std::atomic<size_t> arrived{0};
+        std::atomic<bool> abandon{false};
+        int fetch_rc = HC_OK;
+        std::string fetch_err;
+        std::thread fetcher([&] {
+            bind_here();
+            const size_t piece = std::max<size_t>(1, piece_bytes / sizeof(hc_edge_rec));
+            for (size_t at = 0; at < E; at += piece) {
+                const size_t k = std::min(piece, E - at);
+                fetch_rc = hc_graph_fetch_edges(m_ctx, at, k, edges + at);
+                if (fetch_rc != HC_OK) {
+                    fetch_err = hc_last_error();
+                    abandon.store(true, std::memory_order_release);
+                    return;
+                }
+                arrived.store(at + k, std::memory_order_release);
+            }
+        });
+        struct JoinFetcher {
+            std::thread& t;
+            std::atomic<bool>& stop;
+            ~JoinFetcher() {
+                if (t.joinable()) t.join();
+            }
+        } join_fetcher{fetcher, abandon};
+        try {
+            overlap_graph->adopt_csr(edges, out_off.data(), in_nodes, in_off.data(), incl.data(), reads.data(), reads.size(), program_settings.n_threads,
+                                     &arrived, &abandon);
+        } catch (...) {
+            fetcher.join();
+            if (fetch_rc != HC_OK) throw FatalError{fetch_rc, "hc_graph_fetch_edges: " + fetch_err};
+            throw;
+        }
+        fetcher.join();
+        lap("fetch of the edges in pieces + adopt behind it");
+    }
     if (!tied.empty()) {
         // sortEdges order, lists longer than 16 with fully tied edges: std::sort's order of those is a function of
         // the insertion order — put exactly those lists back into insertion order and let sortEdges' own code sort them

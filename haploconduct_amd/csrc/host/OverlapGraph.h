@@ -3,6 +3,7 @@
 // Adjacency "lists" are order-preserving arrays (ArenaList.h): push_back on insert, erase keeps order, so
 // iteration order equals the reference's std::list order.
 #pragma once
+#include <atomic>
 #include <memory>
 #include <vector>
 
@@ -107,8 +108,12 @@ public:
     // The whole graph at once, as the device's duplicate resolution hands it over (hc_graph_fetch): adj_out lists back
     // to back in vertex order with their offsets, adj_in likewise.  The graph must be empty.  Lists point into two
     // arenas owned by the graph; the slot index is built on the first call that needs it.  reads[r] = m_read_vec[r].
+    // edges_arrived (optional): the edge array is still being filled from its front — records [0, *edges_arrived) are there; a worker
+    // waits for its vertices' records (the stage fetches the edges in pieces and adopts behind the copy).  *abandon set by the filler
+    // (its copy failed): the workers stop waiting and the call throws.
     void adopt_csr(const hc_edge_rec* edges, const uint64_t* out_off, const uint32_t* in_nodes, const uint64_t* in_off,
-                   const uint8_t* inclusion_bits, Read* const* reads, size_t n_reads, unsigned n_threads);
+                   const uint8_t* inclusion_bits, Read* const* reads, size_t n_reads, unsigned n_threads,
+                   const std::atomic<size_t>* edges_arrived = nullptr, const std::atomic<bool>* abandon = nullptr);
     // the addEdge calls of pool[order[0]], pool[order[1]], ... as one parallel fill
     void bulk_add_edges(const Edge* pool, const std::vector<uint32_t>& order, unsigned n_threads);
     // src/OverlapGraph.cpp:722-764, the call that follows construct_edges in every workflow: out-lists sorted by

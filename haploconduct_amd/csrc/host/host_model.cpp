@@ -1039,7 +1039,8 @@ void OverlapGraph::bulk_add_edges(const Edge* pool, const std::vector<uint32_t>&
 }
 
 void OverlapGraph::adopt_csr(const hc_edge_rec* edges, const uint64_t* out_off, const uint32_t* in_nodes, const uint64_t* in_off,
-                             const uint8_t* inclusion_bits, Read* const* reads, size_t n_reads, unsigned n_threads) {
+                             const uint8_t* inclusion_bits, Read* const* reads, size_t n_reads, unsigned n_threads,
+                             const std::atomic<size_t>* edges_arrived, const std::atomic<bool>* abandon) {
     if (edge_count != 0 || out_arena || in_arena) throw FatalError{HC_ERR_STATE, "adopt_csr: the graph already holds edges"};
     const size_t V = adj_out.size();
     const size_t E = (size_t)out_off[V];
@@ -1057,12 +1058,28 @@ void OverlapGraph::adopt_csr(const hc_edge_rec* edges, const uint64_t* out_off, 
     if (!in_arena) throw FatalError{HC_ERR_NOMEM, "adopt_csr: out of memory"};
     const unsigned T = E < (1u << 14) ? 1u : std::max(1u, std::min(n_threads, 32u));
     std::vector<uint8_t> bad(T, 0);
+    // Behind a copy that is still running, the vertices are dealt in stretches of 4 096 taken in turn, so that every thread works near the
+    // copy's front; otherwise in T contiguous ranges
+    std::atomic<size_t> next_stretch{0};
+    const size_t stretch = edges_arrived ? 4096 : (V + T - 1) / T;
     run_workers(T, [&](unsigned t) {
         uint8_t my_bad = 0;
         try {  // Edge's own checks throw: nothing may leave a worker thread
-        for (size_t v = V * t / T; v < V * (t + 1) / T; v++) {
+        size_t have = edges_arrived ? 0 : E;
+        for (;;) {
+        const size_t v0 = edges_arrived ? next_stretch.fetch_add(stretch) : stretch * t;
+        if (v0 >= V || my_bad) break;
+        const size_t v1 = std::min(V, v0 + stretch);
+        for (size_t v = v0; v < v1; v++) {
             const size_t a = (size_t)out_off[v], b = (size_t)out_off[v + 1];
             if (b < a || b > E) { my_bad = 1; break; }
+            while (have < b) {  // the copy has not reached this vertex's records yet
+                have = edges_arrived->load(std::memory_order_acquire);
+                if (have >= b) break;
+                if (abandon && abandon->load(std::memory_order_acquire)) { my_bad = 2; break; }
+                std::this_thread::yield();
+            }
+            if (my_bad) break;
             for (size_t k = a; k < b; k++) {
                 const hc_edge_rec& r = edges[k];
                 if (r.read1 >= n_reads || r.read2 >= n_reads || r.v1 != v || r.v2 >= V) { my_bad = 1; break; }
@@ -1084,6 +1101,8 @@ void OverlapGraph::adopt_csr(const hc_edge_rec* edges, const uint64_t* out_off, 
             if (my_bad) break;
             adj_in[v].borrow(in_arena + ia, ib - ia, ib - ia);
             if (inclusion_bits && inclusion_bits[v]) inclusions[v] = 1;
+        }
+        if (!edges_arrived) break;  // one contiguous range per thread
         }
         } catch (...) {
             my_bad = 1;

@@ -38,8 +38,10 @@ def _mutate(rng, seq, rate):
 
 
 def make_paired_dataset(n_pairs, genome_len, n_strains=3, divergence=0.01, read_len=150, ins_lo=350, ins_hi=600,
-                        err=0.005, n_rate=0.001, flip_frac=0.0, seed=1):
-    """Returns (ReadSet, meta) where meta has frag start `s`, /2 start `e`, `flipped` per pair."""
+                        err=0.005, n_rate=0.001, flip_frac=0.0, seed=1, trim_lo=None):
+    """Returns (ReadSet, meta) where meta has frag start `s`, /2 start `e`, `flipped` per pair.
+    trim_lo: every mate keeps only its first U[trim_lo, read_len] bases (quality-trimmed reads: sequences of mixed length; needs
+    flip_frac == 0); meta then also has the mates' lengths `l1`, `l2`."""
     rng = np.random.default_rng(seed)
     base = _ACGT[rng.integers(0, 4, genome_len)]
     strains = [_mutate(rng, base, divergence) for _ in range(n_strains)]
@@ -77,8 +79,17 @@ def make_paired_dataset(n_pairs, genome_len, n_strains=3, divergence=0.01, read_
     quals = np.empty((n_pairs, 2, read_len), np.uint8)
     bases[:, 0], bases[:, 1] = r1, r2
     quals[:, 0], quals[:, 1] = q1, q2
-    seq_off = np.arange(2 * n_pairs + 1, dtype=np.uint64) * read_len
     first = np.arange(n_pairs + 1, dtype=np.uint32) * 2
+    if trim_lo is not None:
+        assert flip_frac == 0.0, "trimmed pairs are generated unflipped"
+        lens = rng.integers(trim_lo, read_len + 1, (n_pairs, 2))
+        keep = (np.arange(read_len)[None, None, :] < lens[:, :, None])
+        seq_off = np.zeros(2 * n_pairs + 1, dtype=np.uint64)
+        seq_off[1:] = np.cumsum(lens.reshape(-1))
+        reads = ReadSet(bases[keep], quals[keep], seq_off, first, np.arange(n_pairs, dtype=np.uint64))
+        return reads, {"s": s, "e": e, "flipped": flipped, "read_len": read_len, "strain": strain, "l1": lens[:, 0].astype(np.int32),
+                       "l2": lens[:, 1].astype(np.int32)}
+    seq_off = np.arange(2 * n_pairs + 1, dtype=np.uint64) * read_len
     reads = ReadSet(bases.reshape(-1), quals.reshape(-1), seq_off, first, np.arange(n_pairs, dtype=np.uint64))
     return reads, {"s": s, "e": e, "flipped": flipped, "read_len": read_len, "strain": strain}
 
@@ -137,6 +148,15 @@ def paired_candidates(meta, n_candidates=None, min_len=75, seed=2, max_window=10
     rec["len2"] = rl - np.abs(d2)
     rec["perc"] = (0.5 * (np.floor(100.0 * rec["len1"] / rl) + np.floor(100.0 * rec["len2"] / rl))).astype(np.uint32)
     rec["flags"] = 3
+    if "l1" in meta:  # trimmed mates: the overlap of a suffix of one mate with the other's prefix, from their own lengths; short ones go
+        l1, l2 = meta["l1"], meta["l2"]
+        a1 = np.minimum(l1[i] - p1, l1[j])
+        ord1 = d2 >= 0
+        a2 = np.where(ord1, np.minimum(l2[i] - np.abs(d2), l2[j]), np.minimum(l2[j] - np.abs(d2), l2[i]))
+        ok = (a1 >= min_len) & (a2 >= min_len)
+        rec["len1"], rec["len2"] = np.maximum(a1, 0), np.maximum(a2, 0)
+        rec["perc"] = (0.5 * (np.floor(100.0 * np.maximum(a1, 0) / np.minimum(l1[i], l1[j])) + np.floor(100.0 * np.maximum(a2, 0) / np.minimum(l2[i], l2[j])))).astype(np.uint32)
+        rec = rec[ok]
     return rec
 
 

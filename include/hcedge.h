@@ -464,6 +464,10 @@ int hc_graph_resolve(hc_ctx* ctx, const hc_admit_rec* admitted, uint64_t n, uint
  * only marked with HC_FLAG_IGNORE_INCLUSIONS); tied_vertices: room for counts.n_tied_lists ids.  Any may be NULL. */
 int hc_graph_fetch(hc_ctx* ctx, hc_edge_rec* edges, uint64_t* out_off, uint32_t* in_nodes, uint64_t* in_off, uint32_t* seq,
                    uint8_t* inclusions, uint32_t* tied_vertices);
+/* The edges of hc_graph_fetch in pieces: records [first, first + count) of the resolved graph's edge array into dst.  Synchronous.
+ * The stage fetches the small arrays first (hc_graph_fetch with edges == NULL) and then the edges piece by piece, while its host
+ * threads turn the pieces that have arrived into the graph's lists. */
+int hc_graph_fetch_edges(hc_ctx* ctx, uint64_t first, uint64_t count, hc_edge_rec* dst);
 
 /* PCI bus id of a device ("0000:c1:00.0"), for callers that place the host threads feeding it on its NUMA node
  * (/sys/bus/pci/devices/<id>/numa_node); the stage does (HC_NUMA=0 turns that off). */

@@ -57,15 +57,17 @@ def run_both(oracle, tmp_path, reads, lines, st, tag):
     # The other routes to the same graph: above, the device read the file's text itself and resolved the duplicates;
     # the host threads' resolution, the per-edge serial insert, three contexts taking the blocks in turn, the host's
     # tokeniser instead of the device's (HC_PARSE=host), tiny text blocks, the text read in place from the file's mapping
-    # (HC_TEXT_SOURCE=map), the host counting the lines itself (HC_TEXT_SOURCE=pread), write-combined text buffers, and the fused construct + sortEdges call
-    # (against construct_edges followed by sortEdges) must all agree with it.
+    # (HC_TEXT_SOURCE=map), the host counting the lines itself (HC_TEXT_SOURCE=pread), write-combined text buffers, the fused construct + sortEdges call
+    # (against construct_edges followed by sortEdges), and the resolved graph fetched in pieces with the host adopting behind the copy
+    # (HC_FETCH_PIECE_BYTES: pieces of 50 and of 10 edges, and none) must all agree with it.
     for env, sorted_call in (({"HC_RESOLVE": "host"}, False), ({"HC_INSERT_MODE": "serial"}, False), ({"HC_DEVICE_LIST": "0,0,0"}, False),
                              ({"HC_PARSE": "host"}, False), ({"HC_PARSE": "host", "HC_DEVICE_LIST": "0,0,0"}, False),
                              ({"HC_TEXT_BLOCK": "4096"}, False), ({"HC_TEXT_BLOCK": "4096", "HC_TEXT_DEPTH": "1"}, False),
                              ({"HC_TEXT_BLOCK": "8192", "HC_TEXT_DEPTH": "3", "HC_COLLECTORS": "2"}, False), ({"HC_TEXT_SOURCE": "map"}, False), ({"HC_TEXT_SOURCE": "pread"}, False), ({"HC_TEXT_BUFFER": "wc"}, False),
                              ({"HC_TEXT_SOURCE": "pread", "HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False),
                              ({"HC_TEXT_SOURCE": "map", "HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False),
-                             ({"HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False), ({}, True), ({"HC_RESOLVE": "host"}, True)):
+                             ({"HC_TEXT_BLOCK": "4096", "HC_DEVICE_LIST": "0,0,0"}, False), ({}, True), ({"HC_RESOLVE": "host"}, True),
+                             ({"HC_FETCH_PIECE_BYTES": "4000"}, False), ({"HC_FETCH_PIECE_BYTES": "800"}, True), ({"HC_FETCH_PIECE_BYTES": "0"}, True)):
         os.environ.update(env)
         try:
             with host.EdgeCalculatorStage(st, singles=s, paired1=p1, paired2=p2, overlaps=ov, output_dir=out_dir) as ec:
