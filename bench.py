@@ -565,7 +565,7 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
     parity = parity_record(torch, sc, reads, settings, cand, d_out, n, device_digest(torch, d_out, n), digest_untimed)
     # kernel-only: hipEvents on the stream the kernel is launched on
     kern_ms = sc.time_kernel(d_in.data_ptr(), n, d_out.data_ptr(), max(5, min(args.steps, 200)), REC_COMPACT)
-    kinfo = sc.kernel_info()
+    kinfo = sc.kernel_info(n)  # the form a launch of this size takes
     symbytes = 2 if "encoding=u16" in kinfo else 1
     per_rank = None
     if dist:  # what every rank saw, gathered outside the timed region

@@ -113,6 +113,7 @@ _sig = {
     "hc_finalize_batch": (C.c_int, [C.POINTER(hc_settings), _vp, C.c_uint64, _vp, _vp, _vp]),
     "hc_get_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)] + [C.POINTER(C.c_double)] * 4),
     "hc_get_kernel_info": (C.c_int, [_vp, C.c_char_p, C.c_uint32]),
+    "hc_get_kernel_info_for": (C.c_int, [_vp, C.c_uint64, C.c_char_p, C.c_uint32]),
     "hc_dev_radix_sort": (C.c_int, [C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int]),
     "hc_dev_exclusive_sum": (C.c_int, [C.c_uint32, _vp, _vp, C.c_uint64]),
     "hc_dev_select_flagged": (C.c_int, [_vp, C.c_uint64, _vp, C.POINTER(C.c_uint64)]),

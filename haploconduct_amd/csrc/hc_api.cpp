@@ -432,13 +432,28 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         c->coop_fetch = !strcmp(v, "coop");
         c->fetch_group = atoi(v) == 2 ? 2 : 4;
     } else {
-        // 64-symbol fetch groups for short-read sets, 32-symbol groups when the
-        // sequences are long (contigs): measured on BASELINE configs 2-5, see DESIGN.md
+        // Which kernel a read set takes, by its shape (2 * 10^6 candidates each, kernel ms; profiles/r04_dispatch.txt, r04_dispatch_pairs.txt):
+        //   pairs 2 x 150 (C2)                        cooperative 0.186        per lane 0.25            -> cooperative (LDS-DMA rows)
+        //   pairs trimmed to 60..150 per mate         cooperative 0.098        per lane 0.097           -> cooperative
+        //   singles 400..500 (the SAVAGE example)     cooperative 0.265        per lane 0.304           -> cooperative
+        //   singles 250, 35 quality values (C4)       cooperative 0.147        per lane 0.139 - 0.147   -> cooperative (within the noise)
+        //   singles 100..400, mean 216                cooperative 0.186        per lane (G = 2) 0.169   -> PER LANE: a wave's step pays the
+        //                                                                        row exchange for its longest lane while most lanes are done
+        //   singles 120..900, mean 387                bucketed 0.288           per lane 0.284 - 0.287   -> bucketed cooperative (level)
+        //   singles 150..1 500, mean 586              bucketed 0.347           per lane 0.388           -> bucketed cooperative
+        // 64-symbol fetch groups for short-read sets, 32-symbol groups when the sequences are long (contigs) or the symbols 16 bits wide:
+        // the per-lane kernel's, for the sets that take it (below) and for stores of 4 GiB and more
         const uint64_t mean_len = n_seq ? total / n_seq : 0;
-        c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 4;  // the per-lane kernel's, should the store reach 4 GiB
-        // every read set takes the cooperative fetch; sets of mixed sequence length (view.balance: contigs next to reads)
-        // with their candidates bucketed by length first (hc::bucket_perm_kernel)
-        c->coop_fetch = true;
+        c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 4;
+        uint32_t lmin = 0xFFFFFFFFu, lmax = 0, n_pairs = 0;
+        for (uint32_t q = 0; q < n_seq; q++) {
+            lmin = seq_len[q] < lmin ? seq_len[q] : lmin;
+            lmax = seq_len[q] > lmax ? seq_len[q] : lmax;
+        }
+        for (uint32_t r = 0; r < n_reads; r++) n_pairs += read_first_seq[r + 1] - read_first_seq[r] == 2;
+        const bool short_mixed_singles = n_seq && n_pairs == 0 && lmax > 2u * lmin && mean_len <= 300;
+        c->coop_fetch = !short_mixed_singles;
+        if (short_mixed_singles) c->fetch_group = 2;
     }
     c->view.long_rows = (n_seq && total / n_seq > 600) ? 1u : 0u;
     if (const char* v = getenv("HC_LONG_ROWS")) c->view.long_rows = atoi(v) != 0;  // tuning knob
@@ -504,7 +519,7 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
     }
     hc::ScoreParams prm = c->params;
     prm.rec_fmt = fmt;
-    { static const bool no_sort = getenv("HC_COOP_SORT") && atoi(getenv("HC_COOP_SORT")) == 0; prm.pad = no_sort ? 1u : 0u; }
+    prm.pad = 0;
     prm.n_dev = n_dev;
     uint32_t *bperm = nullptr, *bqueue = nullptr;
     if (want_bucket) {  // mixed sequence lengths: the launch buckets its candidates by length first
@@ -863,13 +878,15 @@ int hc_get_info(hc_ctx* c, uint32_t* qual_alphabet, uint64_t* store_bytes, doubl
     return HC_OK;
 }
 
-int hc_get_kernel_info(hc_ctx* c, char* buf, uint32_t cap) {
+int hc_get_kernel_info_for(hc_ctx* c, uint64_t n, char* buf, uint32_t cap) {
     if (!c || !buf || cap == 0) return fail(HC_ERR_ARG, "hc_get_kernel_info: null argument");
     buf[0] = 0;
     if (!c->have_reads) return fail(HC_ERR_STATE, "hc_get_kernel_info: hc_set_reads has not been called");
-    const std::string d = hc::describe_score_kernel(c->view, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group);
+    const std::string d = hc::describe_score_kernel(c->view, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group, c->n_cu, n);
     snprintf(buf, cap, "%s", d.c_str());
     return HC_OK;
 }
+
+int hc_get_kernel_info(hc_ctx* c, char* buf, uint32_t cap) { return hc_get_kernel_info_for(c, 0, buf, cap); }
 
 }  // extern "C"

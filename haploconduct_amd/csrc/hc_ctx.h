@@ -31,7 +31,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
 // bucket_perm (n uint32) / bucket_queue (one uint32): scratch of the length-bucketed launch (read sets of mixed sequence
 // length, StoreView::balance): without them such a set is scored in the order given
 hipError_t set_score_kernel_lds_limit();
-std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane_fetch_group);
+std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane_fetch_group, uint32_t n_cu = 256, uint64_t n = 0);  // n: the form a launch of n candidates takes (0: in general)
 // hc_util_kernels.hip
 size_t compact_temp_bytes(uint32_t n);
 hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_out, unsigned long long* count_out, void* temp,

@@ -134,7 +134,7 @@ struct ScoreParams {
     uint32_t min_read_len;
     uint32_t flags;  // bit0: edge_threshold < 0 (every score passes), bit1: ov_threshold < 0
     uint32_t rec_fmt;  // HC_REC_FULL / HC_REC_COMPACT: layout of the candidate records of this launch
-    uint32_t pad;      // bit 0: the cooperative kernel does not sort the sub-overlaps by length (HC_COOP_SORT=0: a tuning knob)
+    uint32_t pad;      // bits 8..11: 64-candidate steps per item of the wave queue (hc_kernels.hip: WQ), set by launch_score
     const unsigned long long* n_dev;  // nullptr, or where the device holds the number of records (<= the launch's n)
 };
 

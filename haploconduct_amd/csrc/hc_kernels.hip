@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <string>
 
@@ -1488,6 +1489,18 @@ static bool coop_dma_wanted() {
     static const bool on = !(getenv("HC_COOP_DMA") && atoi(getenv("HC_COOP_DMA")) == 0);
     return on;
 }
+// The wave queue pays from ~64 steps of 64 candidates per wave on (2 * 10^7 candidates: level with the static grid; 10^8: 4 % ahead);
+// below that its atomics cost more than the even finish gains (2 * 10^6: 0.27 against 0.19 ms) and the static grid stays.
+// HC_WAVE_QUEUE=0: never; =2: always (experiments and tests); HC_WAVE_QUEUE_STEPS: steps per item
+static bool wave_queue_for(uint64_t n, uint32_t n_cu, uint32_t* steps_out) {
+    static const int mode = getenv("HC_WAVE_QUEUE") ? atoi(getenv("HC_WAVE_QUEUE")) : 1;
+    const uint64_t wq_blocks = std::min<uint64_t>((n + 1023) / 1024, n_cu ? n_cu : 1);
+    const uint64_t per_wave = n / (wq_blocks * 16 * 64);  // 64-candidate steps a wave gets on average
+    uint32_t steps = per_wave >= 64 ? 8u : (per_wave >= 32 ? 4u : (per_wave >= 16 ? 2u : 1u));
+    if (const char* e = getenv("HC_WAVE_QUEUE_STEPS")) steps = (uint32_t)std::min(8, std::max(1, atoi(e)));
+    if (steps_out) *steps_out = steps;
+    return mode == 2 || (mode == 1 && per_wave >= 64);
+}
 static uint64_t coop_dma_min() {  // HC_COOP_DMA_MIN: test knob — the LDS-DMA form for launches of that many candidates and more
     const char* e = getenv("HC_COOP_DMA_MIN");
     return e ? strtoull(e, nullptr, 10) : kDmaMinCandidates;
@@ -1552,7 +1565,6 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                                        (const uint32_t*)sink.spill_count, sink.spill_cap, seg_count + kSinkMaxGroups + ((*spill_turn + 1u) & 1u));
                 if (seg_on) ++*spill_turn;  // the next segmented launch spills through the counter this one has just zeroed
             };
-            const bool sort_subs = bucketed || !(prm.pad & 1u);
             static const int deep_env = getenv("HC_COOP_DEPTH") ? atoi(getenv("HC_COOP_DEPTH")) : 0;  // experiment knob: 1 = one step in flight always
             const bool deep = bucketed && per_cu <= 2 && wg_c == 256 && deep_env != 1;
             if (bucketed) {
@@ -1575,17 +1587,10 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 static const int grid_mult_d = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 16;
                 const uint64_t cap_d = (uint64_t)n_cu * grid_mult_d;
                 if (blocks_d > cap_d) blocks_d = cap_d;
-                // The wave queue pays from ~64 steps of 64 candidates per wave on (2 * 10^7 candidates: level; 10^8: 4 % ahead); below that its
-                // atomics cost more than the even finish gains (2 * 10^6: 0.27 against 0.19 ms) and the static grid stays.
-                // HC_WAVE_QUEUE=0: never; =2: always (experiments and tests); HC_WAVE_QUEUE_STEPS: steps per item
-                static const int wave_queue_mode = getenv("HC_WAVE_QUEUE") ? atoi(getenv("HC_WAVE_QUEUE")) : 1;
-                const uint64_t wq_blocks = std::min<uint64_t>((n + 1023) / 1024, n_cu);
-                const uint64_t per_wave = n / (wq_blocks * 16 * 64);  // 64-candidate steps a wave gets on average
-                if (wave_queue && (wave_queue_mode == 2 || (wave_queue_mode == 1 && per_wave >= 64))) {
-                    // one resident workgroup per CU, the waves pull items of eight 64-candidate steps
-                    blocks_d = wq_blocks;
-                    uint32_t steps = per_wave >= 64 ? 8u : (per_wave >= 32 ? 4u : (per_wave >= 16 ? 2u : 1u));
-                    if (const char* e = getenv("HC_WAVE_QUEUE_STEPS")) steps = (uint32_t)std::min(8, std::max(1, atoi(e)));
+                uint32_t steps = 8;
+                if (wave_queue && wave_queue_for(n, n_cu, &steps)) {
+                    // one resident workgroup per CU, the waves pull items of `steps` 64-candidate steps
+                    blocks_d = std::min<uint64_t>((n + 1023) / 1024, n_cu);
                     ScoreParams pq = prm;
                     pq.pad = (prm.pad & 0xFFu) | (steps << 8);
                     use_segments(blocks_d);
@@ -1610,37 +1615,40 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 compact_segments(blocks_d);
                 return hipGetLastError();
             }
-#define HC_COOP(T_, LG_)                                                                                                              \
-    do {                                                                                                                              \
-        if (wg_c == 256 && bucketed && deep)                                                                                          \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true, 2>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, \
-                               st, prm, lut_g, in, n, out, perm, sink, bucket_queue);                                                 \
-        else if (wg_c == 256 && bucketed)                                                                                             \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, \
-                               prm, lut_g, in, n, out, perm, sink, bucket_queue);                                                     \
-        else if (bucketed)                                                                                                            \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true, true>), dim3((uint32_t)blocks_c), dim3(1024), lds_launch, stream,   \
-                               st, prm, lut_g, in, n, out, perm, sink, bucket_queue);                                                 \
-        else if (wg_c == 256 && sort_subs)                                                                                            \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, false>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, \
-                               prm, lut_g, in, n, out, perm, sink, nullptr);                                                          \
-        else if (wg_c == 256)                                                                                                         \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, false, false>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream,   \
-                               st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
-        else if (sort_subs)                                                                                                           \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_launch, stream,  \
-                               st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, false, false>), dim3((uint32_t)blocks_c), dim3(1024), lds_launch, stream, \
-                               st, prm, lut_g, in, n, out, perm, sink, nullptr);                                                      \
-    } while (0)
+            // The instantiations a read set can reach: 8-bit symbols with a table of at most 16 KiB (LG 3..5) always fit four 256-lane
+            // workgroups per CU; the wide 8-bit encoding (64 KiB table) always shares one table among 1 024 lanes; 16-bit symbols take
+            // either, by table size.  Nothing else is compiled (round 3 carried 45 scoring kernels, a third of them unreachable).
+            auto launch_coop = [&](auto sym_tag, auto lg_tag, auto wg_tag) {
+                using T_ = decltype(sym_tag);
+                constexpr int LG_ = decltype(lg_tag)::value;
+                constexpr int WG_ = decltype(wg_tag)::value;
+                if (bucketed && deep) {
+                    if constexpr (WG_ == 256)
+                        hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true, 2>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, prm,
+                                           lut_g, in, n, out, perm, sink, bucket_queue);
+                } else if (bucketed) {
+                    hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, prm, lut_g,
+                                       in, n, out, perm, sink, bucket_queue);
+                } else {
+                    hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, false>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, prm, lut_g,
+                                       in, n, out, perm, sink, nullptr);
+                }
+            };
+            using W256 = std::integral_constant<int, 256>;
+            using W1024 = std::integral_constant<int, 1024>;
             use_segments(blocks_c);
-            if (st.symbytes == 2) HC_COOP(uint16_t, 5);
-            else if (lg == 3) HC_COOP(uint8_t, 3);
-            else if (lg == 4) HC_COOP(uint8_t, 4);
-            else if (lg == 5) HC_COOP(uint8_t, 5);
-            else HC_COOP(uint8_t, 6);
-#undef HC_COOP
+            if (st.symbytes == 2) {
+                if (wg_c == 256) launch_coop(uint16_t{}, std::integral_constant<int, 5>{}, W256{});
+                else launch_coop(uint16_t{}, std::integral_constant<int, 5>{}, W1024{});
+            } else if (lg == 6) {
+                if (wg_c != 1024) return hipErrorInvalidConfiguration;  // (a 64 KiB table never leaves room for four workgroups)
+                launch_coop(uint8_t{}, std::integral_constant<int, 6>{}, W1024{});
+            } else {
+                if (wg_c != 256) return hipErrorInvalidConfiguration;   // (tables of at most 16 KiB always do)
+                if (lg == 3) launch_coop(uint8_t{}, std::integral_constant<int, 3>{}, W256{});
+                else if (lg == 4) launch_coop(uint8_t{}, std::integral_constant<int, 4>{}, W256{});
+                else launch_coop(uint8_t{}, std::integral_constant<int, 5>{}, W256{});
+            }
             compact_segments(blocks_c);
             return hipGetLastError();
         }
@@ -1669,11 +1677,11 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
 }
 
 // Which kernel launch_score picks for this store, as text (hc_get_kernel_info: tests and bench.py name the measured kernel with it).
-std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane_fetch_group) {
+std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane_fetch_group, uint32_t n_cu, uint64_t n) {
     const uint32_t lg = lut_lg(st.K);
     const std::string sym = st.symbytes == 2 ? "uint16_t" : "uint8_t";
     const std::string enc = st.symbytes == 2 ? "u16" : (lg == 6 ? "wide8" : "packed8");
-    char buf[256];
+    char buf[640];
     if (fetch_group == 0) {
         const bool coop = st.store_bytes < 0xFFFF0000ull;
         const size_t lds_256 = coop_stage_base(st.lut_bytes, 256) + 4 * kStageBytesPerWave;
@@ -1689,11 +1697,14 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
             snprintf(small, sizeof small, "hc::score_kernel_coop<%s, %u, %u, true, %s, %d>", sym.c_str(), lgt, wg_c, st.balance ? "true" : "false", deep ? 2 : 1);
             const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
             const bool dma = !st.balance && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024 && coop_dma_wanted();
-            if (dma)
-                snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, 1024, true, false, 0> encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=16 "
-                                          "LDS-DMA fetch for launches of %llu candidates and more; smaller launches: %s",
-                         sym.c_str(), lgt, enc.c_str(), st.lut_bytes, lds_dma, (unsigned long long)kDmaMinCandidates, small);
-            else
+            // n != 0: the form a launch of n candidates takes; n == 0: the read set's forms in general
+            if (dma && (n == 0 || n >= coop_dma_min())) {
+                const bool wq = n != 0 && wave_queue_for(n, n_cu, nullptr);
+                snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, 1024, true, false, 0%s> encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=16 "
+                                          "LDS-DMA fetch for launches of %llu candidates and more (the waves pull their items from a queue — template "
+                                          "argument WQ = true — where a wave gets 64 steps and more); smaller launches: %s",
+                         sym.c_str(), lgt, wq ? ", true" : "", enc.c_str(), st.lut_bytes, lds_dma, (unsigned long long)coop_dma_min(), small);
+            } else
                 snprintf(buf, sizeof buf, "%s encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=%u%s", small, enc.c_str(), st.lut_bytes, lds_c,
                          per_cu * (wg_c / 64), st.balance ? " length-bucketed (hc::bucket_perm_kernel, wave queue)" : "");
             return buf;
@@ -1728,26 +1739,30 @@ hipError_t set_lds_limit_lg() {
 hipError_t set_score_kernel_lds_limit() {
     hipError_t e;
     const int kMax = 160 * 1024;
-#define HC_COOP_ATTR(T_, LG_)                                                                                                                             \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;  \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;   \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;    \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;  \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 1024, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 3, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 4, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 5, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 3, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 4, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 5, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    HC_COOP_ATTR(uint8_t, 3)
-    HC_COOP_ATTR(uint8_t, 4)
-    HC_COOP_ATTR(uint8_t, 5)
-    HC_COOP_ATTR(uint8_t, 6)
-    HC_COOP_ATTR(uint16_t, 5)
+#define HC_COOP_ATTR(T_, LG_, WG_)                                                                                                                         \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+#define HC_COOP_ATTR_DEEP(T_, LG_) \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+#define HC_COOP_ATTR_DMA(LG_)                                                                                                                                          \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, LG_, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, LG_, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    HC_COOP_ATTR_DMA(3)
+    HC_COOP_ATTR_DMA(4)
+    HC_COOP_ATTR_DMA(5)
+    HC_COOP_ATTR(uint8_t, 3, 256)
+    HC_COOP_ATTR(uint8_t, 4, 256)
+    HC_COOP_ATTR(uint8_t, 5, 256)
+    HC_COOP_ATTR(uint8_t, 6, 1024)
+    HC_COOP_ATTR(uint16_t, 5, 256)
+    HC_COOP_ATTR(uint16_t, 5, 1024)
+    HC_COOP_ATTR_DEEP(uint8_t, 3)
+    HC_COOP_ATTR_DEEP(uint8_t, 4)
+    HC_COOP_ATTR_DEEP(uint8_t, 5)
+    HC_COOP_ATTR_DEEP(uint16_t, 5)
 #undef HC_COOP_ATTR
+#undef HC_COOP_ATTR_DEEP
+#undef HC_COOP_ATTR_DMA
     if ((e = set_lds_limit_lg<uint8_t, 3>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 4>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 5>()) != hipSuccess) return e;

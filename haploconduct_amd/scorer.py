@@ -56,10 +56,10 @@ class EdgeScorer:
         return {"qual_alphabet": k.value, "store_bytes": sb.value, "x_edge": (d[0].value, d[1].value),
                 "x_ov": (d[2].value, d[3].value)}
 
-    def kernel_info(self):
-        """hc_get_kernel_info: the scoring kernel chosen for the read set, as text."""
-        buf = C.create_string_buffer(512)
-        N.check(N.lib.hc_get_kernel_info(self._ctx, buf, 512), "hc_get_kernel_info")
+    def kernel_info(self, n=0):
+        """hc_get_kernel_info[_for]: the scoring kernel chosen for the read set (n > 0: for a launch of n candidates), as text."""
+        buf = C.create_string_buffer(768)
+        N.check(N.lib.hc_get_kernel_info_for(self._ctx, int(n), buf, 768), "hc_get_kernel_info_for")
         return buf.value.decode()
 
     def set_reorder(self, mode):

@@ -312,6 +312,9 @@ int hc_count_positions_device(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, u
  * rocprofv3's kernel trace lists), the symbol encoding, the log table's size and whether launches bucket their candidates
  * by length first (read sets of mixed sequence length).  Diagnostics: tests and bench.py name what they measured with it. */
 int hc_get_kernel_info(hc_ctx* ctx, char* buf, uint32_t cap);
+/* The same for a launch of n candidates: the library picks the kernel's form by the launch's size too (register-staged rows for
+ * small launches, LDS-DMA rows from 5 * 10^5 candidates on, the waves' work queue where every wave gets 64 steps and more). */
+int hc_get_kernel_info_for(hc_ctx* ctx, uint64_t n, char* buf, uint32_t cap);
 
 /* ---- device primitives (csrc/hc_prims.hip), behind host-buffer entry points for their unit tests ------------------
  * The stage's device side sorts and compacts with its own kernels: a stable LSD radix sort (8 bits a pass; keys of 4 bytes
