@@ -42,7 +42,7 @@ def test_the_patch_files_are_what_integration_md_quotes():
     """Every line of every piece under integration/reference_patch/ appears in INTEGRATION.md, in order."""
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     pieces = sorted(glob.glob(os.path.join(ROOT, "integration", "reference_patch", "*.inc")))
-    assert len(pieces) == 7
+    assert len(pieces) == 8  # seven pieces of level A, one of level B
     for p in pieces:
         text = open(p).read().rstrip("\n")
         assert text in doc, f"INTEGRATION.md does not quote {os.path.basename(p)} verbatim"
@@ -102,3 +102,78 @@ def test_patched_construct_edges_on_a_file(patched, tmp_path):
         lib.frag_ec_free(text)
     assert len(out["plain"][0]) > 1000 * 80
     assert out["plain"] == out["patched"]
+
+
+def _stage(lib, name, mg, fs, pre, S, Q, ids, n_single, n_paired, fastq, ov_path, out_dir, cap, n_vertices):
+    vp = C.c_void_p
+    fn = getattr(lib, name)
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(mg.FragSettings), vp, C.c_uint64, vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_char_p, C.c_char_p, vp, C.c_uint64,
+                   C.POINTER(C.c_uint64), vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_uint64), vp]
+    edges = (mg.FragEdge * cap)()
+    n_edges, nb = C.c_uint64(), C.c_uint64()
+    in_off = np.zeros(n_vertices + 1, np.uint64)
+    in_nodes = np.zeros(cap, np.uint64)
+    incl = np.zeros(n_vertices, np.uint8)
+    text = vp()
+    counters = (C.c_uint32 * 3)()
+    F = (C.c_char_p * 3)(*[f.encode() for f in fastq])
+    rc = fn(C.byref(fs), pre, 10 ** 8, S, Q, ids.ctypes.data, n_single, n_paired, F, ov_path.encode(), out_dir.encode(), edges, cap, C.byref(n_edges),
+            in_off.ctypes.data, in_nodes.ctypes.data, incl.ctypes.data, C.byref(text), C.byref(nb), counters)
+    assert rc == 0, f"{name} returned {rc}"
+    n = int(n_edges.value)
+    out = (bytes(C.string_at(C.addressof(edges), n * C.sizeof(mg.FragEdge))), in_off.tobytes(), in_nodes[:n].tobytes(), incl.tobytes(),
+           C.string_at(text, nb.value), list(counters))
+    lib.frag_ec_free.argtypes = [vp]
+    lib.frag_ec_free(text)
+    return n, out
+
+
+@pytest.mark.parametrize("what", ["pairs", "savage_example"])
+def test_level_b_adapter_fills_the_references_graph(patched, tmp_path, what):
+    """INTEGRATION.md level B, compiled (integration/reference_patch/ViralQuasispecies.cpp.level_b.inc inside the patched probe): the whole
+    stage inside libhcedge.so, its edges copied into the REFERENCE'S OWN OverlapGraph with the reference's Edge and addEdge — against the
+    reference's own construct_edges + sortEdges on the same files: adj_out in list order (scores and mismatch rates as bits), adj_in,
+    inclusions, nonedge_overlaps.txt, the three counters main() logs."""
+    import gzip
+
+    from haploconduct_amd import host, synth
+    import haploconduct_amd as hc
+
+    mg, ref = patched
+    d = str(tmp_path) + "/"
+    if what == "pairs":
+        reads, meta = synth.make_paired_dataset(3000, 4000, flip_frac=0.25, seed=41)
+        cand = synth.paired_candidates(meta, n_candidates=60000, seed=42)
+        host.write_overlaps(d + "overlaps.txt", cand, reads)
+        reads.write_fastq(None, d + "p1.fastq", d + "p2.fastq")
+        fastq = ["None", d + "p1.fastq", d + "p2.fastq"]
+        fs, pre = mg.FragSettings(0.97, 0.9, 0.0, 0.0, 0, 0), (C.c_uint32 * 3)(150, 0, 0)
+    else:  # the reference's example reads, SAVAGE stage b/c settings (ignore_inclusions, merge_contigs)
+        fastq = []
+        for name in ("savage_singles", "savage_paired1", "savage_paired2"):
+            fastq.append(d + name + ".fastq")
+            with gzip.open(os.path.join(ROOT, "tests", "golden", name + ".fastq.gz"), "rb") as f, open(fastq[-1], "wb") as o:
+                o.write(f.read())
+        f = host.Fastq(singles=fastq[0], paired1=fastq[1], paired2=fastq[2])
+        reads = f.readset()
+        with hc.EdgeScorer(hc.Settings()) as sc:
+            sc.set_reads(reads)
+            sfo = sc.find_overlaps(0.02, 100)
+        host.sfo_records_to_overlaps(sfo, d + "overlaps.txt", f.n_single, f.n_paired)
+        fs, pre = mg.FragSettings(0.995, 0.9, 0.01, 0.0, 0, 1), (C.c_uint32 * 3)(100, 0, 0)
+    seqs, quals = zip(*(reads.seq(q) for q in range(reads.n_seq)))
+    S, Q = (C.c_char_p * len(seqs))(*seqs), (C.c_char_p * len(quals))(*quals)
+    ids = np.ascontiguousarray(reads.read_ids, dtype=np.uint64)
+    n_single = sum(1 for r in range(reads.n_reads) if not reads.is_paired(r))
+    n_lines = sum(1 for _ in open(d + "overlaps.txt"))
+    got = {}
+    for name in ("frag_stage_sorted", "frag_stage_level_b"):
+        o = d + name
+        os.mkdir(o)
+        got[name] = _stage(ref, name, mg, fs, pre, S, Q, ids, n_single, reads.n_reads - n_single, fastq, d + "overlaps.txt", o, n_lines, reads.n_reads)
+    n_ref, a = got["frag_stage_sorted"]
+    n_b, b = got["frag_stage_level_b"]
+    assert n_ref == n_b > 1000
+    for k, part in enumerate(("adj_out", "in_off", "in_nodes", "inclusions", "nonedge_overlaps.txt", "counters")):
+        assert a[k] == b[k], f"{part} differs between the reference's stage and the level-B adapter"
