@@ -62,7 +62,7 @@ def test_reference_code_with_hip_scoring_reproduces_the_reference(patched, path)
 
 def test_patched_construct_edges_on_a_file(patched, tmp_path):
     """The reference's own construct_edges (parser, prefilter, batches) over the patched process_overlaps, against the unpatched
-    probe on the same file: 60 000 lines of 2x150 pairs, two OpenMP threads on the patched side (the thread-local hand-over)."""
+    probe on the same file: 60 000 lines of 2x150 pairs."""
     from haploconduct_amd import host, synth
 
     mg, ref = patched
@@ -167,11 +167,15 @@ def test_level_b_adapter_fills_the_references_graph(patched, tmp_path, what):
     ids = np.ascontiguousarray(reads.read_ids, dtype=np.uint64)
     n_single = sum(1 for r in range(reads.n_reads) if not reads.is_paired(r))
     n_lines = sum(1 for _ in open(d + "overlaps.txt"))
+    plain_path = os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so")
+    if not os.path.exists(plain_path):
+        pytest.skip("no unpatched probe")
+    plain = C.CDLL(plain_path)  # the reference's stage from the UNPATCHED probe: nothing of this build inside it
     got = {}
-    for name in ("frag_stage_sorted", "frag_stage_level_b"):
+    for name, lib in (("frag_stage_sorted", plain), ("frag_stage_level_b", ref)):
         o = d + name
         os.mkdir(o)
-        got[name] = _stage(ref, name, mg, fs, pre, S, Q, ids, n_single, reads.n_reads - n_single, fastq, d + "overlaps.txt", o, n_lines, reads.n_reads)
+        got[name] = _stage(lib, name, mg, fs, pre, S, Q, ids, n_single, reads.n_reads - n_single, fastq, d + "overlaps.txt", o, n_lines, reads.n_reads)
     n_ref, a = got["frag_stage_sorted"]
     n_b, b = got["frag_stage_level_b"]
     assert n_ref == n_b > 1000
