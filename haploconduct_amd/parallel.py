@@ -151,7 +151,7 @@ class StreamedGather(PayloadGather):
 
     score_step: `hc_score_pack_device` — the scoring kernel's row-appending twin writes the payload itself (rows
     unordered), then the all-gather on a side stream, overlapping the scoring kernel of the next batch.
-    step: for results that exist already: `hc_compact_pack_device` (hipCUB select + pack kernel, rows ordered) on the
+    step: for results that exist already: `hc_compact_pack_device` (the library's own ordered selection + pack kernel, rows ordered) on the
     side stream; call before_write(results) before overwriting a results tensor that a step may still be reading.
     """
 

@@ -12,7 +12,8 @@
  * The reference reads its inputs out of SRBuilder / OverlapGraph / Read objects; this ABI takes the same
  * facts as flat arrays (what each getter would return), so that any owner of super-reads can call it.
  * What the reference writes to <output>/overlaps.txt comes back as one text buffer, byte for byte, plus the
- * counters the reference prints.  Host code (C++), no device work: see DESIGN.md "FNO".
+ * counters the reference prints.  With a HIP device present, inputs of 2 * 10^5 edges and more run on it (FNO=1 whole; FNO=3's
+ * deduceOverlap and text); smaller ones and HC_FNO=host on host threads — same bytes either way.
  *
  * Conventions as in hcedge.h: plain pointers and sizes, HC_OK or a negative hc_status, hc_last_error() has
  * the text.  Wherever the reference would assert/exit/throw (a node missing from a map, a percentage above
