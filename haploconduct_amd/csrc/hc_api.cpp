@@ -451,7 +451,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
             lmax = seq_len[q] > lmax ? seq_len[q] : lmax;
         }
         for (uint32_t r = 0; r < n_reads; r++) n_pairs += read_first_seq[r + 1] - read_first_seq[r] == 2;
-        const bool short_mixed_singles = n_seq && n_pairs == 0 && lmax > 2u * lmin && mean_len <= 300;
+        const bool short_mixed_singles = n_seq && n_pairs == 0 && lmax > 2u * lmin && mean_len <= 300 && !c->view.balance;  // (HC_BALANCE=1 forces the bucketed launch)
         c->coop_fetch = !short_mixed_singles;
         if (short_mixed_singles) c->fetch_group = 2;
     }

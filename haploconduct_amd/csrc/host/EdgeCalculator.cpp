@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <type_traits>
@@ -522,12 +523,23 @@ void EdgeCalculator::resolve_on_device(bool sorted) {
         check(hc_graph_fetch(m_ctx, nullptr, out_off.data(), in_nodes, in_off.data(), seq, incl.data(), tied.empty() ? nullptr : tied.data()),
               "hc_graph_fetch");
         lap("fetch of the offsets and in-lists");
+        // The CALLING thread copies (it holds the HIP runtime's per-thread state: a fresh thread's first copy cost 20 - 50 ms on a process's
+        // first file), a helper thread runs the adoption, whose workers wait for the copy's front.
         std::atomic<size_t> arrived{0};
         std::atomic<bool> abandon{false};
+        std::exception_ptr adopt_error;
+        std::thread adopter([&] {
+            bind_here();
+            try {
+                overlap_graph->adopt_csr(edges, out_off.data(), in_nodes, in_off.data(), incl.data(), reads.data(), reads.size(), program_settings.n_threads,
+                                         &arrived, &abandon);
+            } catch (...) {
+                adopt_error = std::current_exception();
+            }
+        });
         int fetch_rc = HC_OK;
         std::string fetch_err;
-        std::thread fetcher([&] {
-            bind_here();
+        {
             const size_t piece = std::max<size_t>(1, piece_bytes / sizeof(hc_edge_rec));
             for (size_t at = 0; at < E; at += piece) {
                 const size_t k = std::min(piece, E - at);
@@ -535,27 +547,14 @@ void EdgeCalculator::resolve_on_device(bool sorted) {
                 if (fetch_rc != HC_OK) {
                     fetch_err = hc_last_error();
                     abandon.store(true, std::memory_order_release);
-                    return;
+                    break;
                 }
                 arrived.store(at + k, std::memory_order_release);
             }
-        });
-        struct JoinFetcher {
-            std::thread& t;
-            std::atomic<bool>& stop;
-            ~JoinFetcher() {
-                if (t.joinable()) t.join();
-            }
-        } join_fetcher{fetcher, abandon};
-        try {
-            overlap_graph->adopt_csr(edges, out_off.data(), in_nodes, in_off.data(), incl.data(), reads.data(), reads.size(), program_settings.n_threads,
-                                     &arrived, &abandon);
-        } catch (...) {
-            fetcher.join();
-            if (fetch_rc != HC_OK) throw FatalError{fetch_rc, "hc_graph_fetch_edges: " + fetch_err};
-            throw;
         }
-        fetcher.join();
+        adopter.join();
+        if (fetch_rc != HC_OK) throw FatalError{fetch_rc, "hc_graph_fetch_edges: " + fetch_err};
+        if (adopt_error) std::rethrow_exception(adopt_error);
         lap("fetch of the edges in pieces + adopt behind it");
     }
     if (!tied.empty()) {

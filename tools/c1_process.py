@@ -128,7 +128,10 @@ def main():
 
         stages = {"stage_a": ((0.97, 200, 0.0, "false"), {"edge_threshold": 0.97}, (200, 0, 0)),
                   "stage_bc": ((0.995, 100, 0.01, "true"), {"edge_threshold": 0.995, "merge_contigs": 0.01, "ignore_inclusions": 1}, (100, 0, 0))}
-        out = {"workload": f"savage/example/input_fas whole: {f.n_single} singles + {f.n_paired} pairs, {n_lines} overlap lines "
+        help_walls, _ = run_cli([exe, "--help"], 5)  # loads every library the program links (the HIP runtime's among them) and leaves: no HIP call
+        out = {"process_start_and_exit_s": {"median": sorted(help_walls)[2], "min": min(help_walls),
+                                            "what": "`hc-edgecalc --help`: exec + dynamic loading of libhcedge.so and the HIP runtime's libraries + exit, no HIP call"},
+               "workload": f"savage/example/input_fas whole: {f.n_single} singles + {f.n_paired} pairs, {n_lines} overlap lines "
                            f"({os.path.getsize(d + 'overlaps.txt')} bytes) from the library's own finder + SFO ingest",
                "host": f"{os.cpu_count()} hardware threads", "reps": args.reps, "stages": {}}
         for name, (vals, rs, pre) in stages.items():
