@@ -427,9 +427,7 @@ __device__ __forceinline__ void wave_lds_order() {  // keeps the compiler from r
 
 constexpr uint32_t kStageBytesPerWave = 64u * 64u;
 // LDS of the cooperative kernel: [table][scratch: 32 words][pad to 1 KiB][one image per wave]
-// (256 bytes behind the table: 128 of scratch words, then the classification thresholds — re-read from LDS by every step instead of living in
-// scalar registers the kernel does not have: it ran with 68 of them spilled into vector lanes, ~130 v_readlane / v_writelane per step)
-__host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t /*wg*/) { return (lut_bytes + 256u + 1023u) & ~1023u; }
+__host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t /*wg*/) { return (lut_bytes + 128u + 1023u) & ~1023u; }
 
 // What a sub-overlap's walk leaves behind -> its result (x = (1/n) S, mismatches, n), or the exact re-scan when the sum came
 // out NaN (an invalid symbol inside the window, or next to it in the last chunk).
@@ -1203,15 +1201,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     load_log_table<SymT, LG>(lut_s, lut_g, lut_n, threadIdx.x, WG);
     uint32_t* scratch = (uint32_t*)(lut_s + lut_n);  // row append: [0..17]; segment mode: [24] the workgroup's row counter
     const uint32_t seg_counter = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(scratch + 24);
-    double* cls_lds = (double*)(scratch + 32);  // [0..4]: edge.lo, edge.hi, ov.lo, ov.hi, merge_contigs; [5]: flags
-    const uint32_t cls_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)cls_lds;
     if (threadIdx.x == 0) {
-        cls_lds[0] = prm.edge.lo;
-        cls_lds[1] = prm.edge.hi;
-        cls_lds[2] = prm.ov.lo;
-        cls_lds[3] = prm.ov.hi;
-        cls_lds[4] = prm.merge_contigs;
-        ((uint32_t*)cls_lds)[10] = prm.flags;
         scratch[24] = 0;
         scratch[28] = 0;  // WQ: waves of this workgroup that have left
         if (DYN) scratch[26] = atomicAdd(queue, 1u);  // the workgroup's first queue entry; [26], [27]: this iteration's and the next one's
@@ -1373,19 +1363,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
                 res.n_cls = 1u | ((ns == 0 ? HC_CLS_ERROR : HC_CLS_DROP) << 28);
                 store_result<!DYN>(out, i, res);
             } else {
-#ifdef HC_CLS_SGPR  // experiment build: the thresholds stay kernel arguments (round 3's form)
-                const ScoreParams& pc = prm;
-                (void)cls_addr;
-#else
-                ScoreParams pc;  // the thresholds, from LDS (see coop_stage_base)
-                pc.edge.lo = lds_f64(cls_addr);
-                pc.edge.hi = lds_f64(cls_addr + 8u);
-                pc.ov.lo = lds_f64(cls_addr + 16u);
-                pc.ov.hi = lds_f64(cls_addr + 24u);
-                pc.merge_contigs = lds_f64(cls_addr + 32u);
-                pc.flags = lds_load32(cls_addr + 40u);
-#endif
-                res = classify_and_store<!DYN>(pc, ns, s1, s2, i, out);
+                res = classify_and_store<!DYN>(prm, ns, s1, s2, i, out);
             }
         }
         if (sink.rows) {  // kernel-argument-uniform branch
