@@ -517,7 +517,8 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
     if with_gather:
         sc.score_cands_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
         torch.cuda.synchronize()
-        kept = torch.tensor([int((((d_out.view(torch.int64).view(-1, 3)[:, 2] >> 60) & 0xF) != 0).sum().item())], device="cuda")
+        coll = "cuda" if dist.get_backend() == "nccl" else "cpu"  # small tensors of the bookkeeping collectives (gloo: test runs only)
+        kept = torch.tensor([int((((d_out.view(torch.int64).view(-1, 3)[:, 2] >> 60) & 0xF) != 0).sum().item())], device=coll)
         dist.all_reduce(kept, op=dist.ReduceOp.MAX)  # one capacity for all ranks
         gather = parallel.StreamedGather(sc, n, base_index=base_index, cap_rows=int(kept.item()) * 5 // 4 + 1024, rec_fmt=REC_COMPACT)
     last = None
@@ -558,7 +559,8 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
         if args.dump_rows and rank == 0:  # tests: the collected rows of the last step, as every rank holds them
             np.save(args.dump_rows, rows.cpu().numpy())
     if dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        coll = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([dt], device=coll, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # parity, timed half: the digest of what the last timed step left, and stretches of it against the CPU oracle
@@ -570,7 +572,7 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
     per_rank = None
     if dist:  # what every rank saw, gathered outside the timed region
         mine = torch.tensor([kern_ms, dt_local / args.steps * 1e3, gather_wait_ms / max(args.steps, 1), float(dist.get_world_size()), float(n)],
-                            device="cuda", dtype=torch.float64)
+                            device=coll, dtype=torch.float64)
         everyone = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine)
         per_rank = [{"rank": r, "kernel_ms": float(v[0]), "step_ms": float(v[1]), "gather_wait_ms_per_step": float(v[2]),
@@ -678,6 +680,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libhcedge has no CPU fallback")
+    # HC_BENCH_BACKEND=gloo HC_BENCH_ONE_DEVICE=1 (tests on a one-GPU box: every rank on device 0, the all-gather staged through the host): the
+    # N-rank code path — shards, both scaling modes, per-rank records, parity — without N GPUs.  Never set by the driver; the line says so.
+    backend = os.environ.get("HC_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("HC_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     # HC_BENCH_FORCE_GATHER=1: run the N > 1 step (payload + all-gather) on a single rank too, to time and test that
@@ -686,7 +694,9 @@ def main():
     if with_gather:
         import torch.distributed as dist
 
-        if world > 1:
+        if world > 1 and backend != "nccl":
+            dist.init_process_group(backend)
+        elif world > 1:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1,
@@ -708,7 +718,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": main_rec["config"],
+            "config": dict(main_rec["config"], **({"test_run": f"backend {backend}, every rank on one device: NOT a multi-GPU measurement"}
+                                                  if (backend != "nccl" or one_device) else {})),
             "roofline": main_rec["roofline"],
             "parity": main_rec["parity"],
             "parity_checked_records": main_rec["parity"]["parity_checked_records"],

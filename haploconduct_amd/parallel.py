@@ -74,6 +74,13 @@ def pack_payload(results, base_index, cap_rows, shuffle_seed=None):
     return torch.from_numpy(out)
 
 
+class _DoneWork:
+    """Stand-in for an async work handle whose collective has already completed (the staged gloo path below)."""
+
+    def wait(self):
+        return True
+
+
 class PayloadGather:
     """The all-gather-v of the collection payloads as ONE all-gather per batch, on any backend (nccl = RCCL, gloo):
     every rank contributes a fixed-capacity payload whose row 0 is its count; `depth` buffer sets in turn, the
@@ -93,6 +100,19 @@ class PayloadGather:
                       "work": None, "unordered": False} for _ in range(depth)]
         self.i = 0
 
+    def _all_gather(self, b):
+        """One all-gather of b["payload"] into b["all"].  nccl (= RCCL): asynchronous, device to device.  gloo has no all-gather of
+        device tensors: the payload is staged through host memory, synchronously (how a one-GPU box runs the N-rank bench path: every
+        rank on the same device, tests/test_gpu_multi.py; never the driver's path)."""
+        if self.cuda and dist.get_backend(self.group) == "gloo":
+            torch.cuda.current_stream().synchronize()
+            host_all = torch.empty(b["all"].shape, dtype=b["all"].dtype)
+            dist.all_gather_into_tensor(host_all, b["payload"].cpu(), group=self.group)
+            b["all"].copy_(host_all)
+            torch.cuda.current_stream().synchronize()
+            return _DoneWork()
+        return dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
+
     def next_buffers(self):
         """The buffer set of the next batch; its payload may be written once the all-gather that last used it is done
         (on CUDA the current stream is made to wait for it, on CPU the call blocks)."""
@@ -109,9 +129,9 @@ class PayloadGather:
             b["scored"].record(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 self.side.wait_event(b["scored"])
-                b["work"] = dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
+                b["work"] = self._all_gather(b)
         else:
-            b["work"] = dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
+            b["work"] = self._all_gather(b)
         return b
 
     def collect(self, b):
@@ -188,5 +208,5 @@ class StreamedGather(PayloadGather):
                                         b["payload"].data_ptr(), self.side.cuda_stream)
             b["packed"].record(self.side)
             self.packed[d_results.data_ptr()] = b["packed"]
-            b["work"] = dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
+            b["work"] = self._all_gather(b)
         return b

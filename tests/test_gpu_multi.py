@@ -118,3 +118,46 @@ def test_hc_edgecalc_device_mask_over_real_devices(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[name] = {f: open(o + f, "rb").read() for f in sorted(os.listdir(o)) if f in ("edges.tsv", "edges_sorted.tsv", "nonedge_overlaps.txt", "edgecalc_stats.txt")}
     assert len(outs["one"]) == 4 and len(outs["one"]["edges_sorted.tsv"]) > 10000 and outs["one"] == outs["two"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_n_rank_bench_path_on_one_gpu_over_gloo(tmp_path, world):
+    """The N-rank path of bench.py WITHOUT N GPUs: every rank on device 0, the all-gather staged through the host over gloo
+    (HC_BENCH_BACKEND=gloo HC_BENCH_ONE_DEVICE=1; the line says "test_run").  Everything but RCCL itself is the driver's path: torch.distributed.run,
+    the shards, both scaling modes in one line, the per-rank records, the in-run parity of every rank, the gathered rows.  Runs on a one-GPU box."""
+    if _n_devices() < 1:
+        pytest.skip("no GPU")
+    env = dict(os.environ, HC_BENCH_BACKEND="gloo", HC_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1"]
+    tail = ["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "c2", "--no-stage", "--no-cpu-baseline", "--also", "none"]
+    # (1) the driver's command line: both curves in one line
+    r = subprocess.run(base + ["--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + tail, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "test_run" in line["config"] and line["n_gpus"] == world and line["scaling"] == "weak"
+    assert line["config"]["candidates_per_step"] == world * line["config"]["candidates_per_gpu"]
+    assert line["ranks"]["n_ranks_seen"] == world and len(line["ranks"]["per_rank"]) == world
+    st = line["strong"]
+    assert st["candidates_per_step"] == line["config"]["candidates_per_gpu"] and st["ranks"]["n_ranks_seen"] == world
+    assert sum(p["candidates"] for p in st["ranks"]["per_rank"]) == st["candidates_per_step"]
+    assert line["parity"]["digest_matches_untimed_launch"] and st["parity"]["digest_matches_untimed_launch"]
+    assert line["value"] > 0 and st["value"] > 0
+    # (2) the strong split's gathered rows are the one-device result
+    rows_file = str(tmp_path / "rows.npy")
+    r = subprocess.run(base + ["--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + tail +
+                       ["--scaling", "strong", "--one-mode", "--dump-rows", rows_file], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = np.load(rows_file)
+    import bench
+    import haploconduct_amd as hc
+    from haploconduct_amd.records import result_cls
+
+    reads, cand, cfg, stt = bench.build_workload("c2", 0)
+    with hc.EdgeScorer(stt) as sc:
+        sc.set_reads(reads)
+        res = sc.score_cands(sc.pack_cands(cand))
+    kept = np.nonzero(result_cls(res) != 0)[0]
+    want = np.stack([kept.astype(np.int64), res["x1"][kept].view(np.int64), res["x2"][kept].view(np.int64),
+                     res["mm"][kept].astype(np.int64) | (res["n_cls"][kept].astype(np.int64) << 32)], axis=1)
+    assert rows.shape == want.shape and np.array_equal(rows, want)
