@@ -1204,6 +1204,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     if (threadIdx.x == 0) {
         scratch[24] = 0;
         scratch[28] = 0;  // WQ: waves of this workgroup that have left
+        scratch[29] = 0;  // WQ, local form: the workgroup's ticket counter
         if (DYN) scratch[26] = atomicAdd(queue, 1u);  // the workgroup's first queue entry; [26], [27]: this iteration's and the next one's
     }
     __syncthreads();
@@ -1229,19 +1230,22 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     const uint32_t n_pieces = n_tiles * (kBucketTile / WG);
     uint32_t q_ahead = 0, iter = 0;
     // WQ: this wave's item, the one it has asked for already, where it stands inside the item
-    const uint32_t wq_steps = WQ ? (prm.pad >> 8) : 0u;                 // 64-candidate steps per item (1..8)
+    const uint32_t wq_steps = WQ ? ((prm.pad >> 8) & 0xFu) : 0u;        // 64-candidate steps per item (1..8)
+    // LOCAL form (prm.pad bit 12; small launches): the items are dealt to the workgroups in equal contiguous ranges and the waves of a
+    // workgroup take theirs from a ticket counter in LDS — no global atomic at all; the waves of a CU finish within one item of each other
+    const bool wq_local = WQ && (prm.pad & 0x1000u);
     const uint32_t wq_items = WQ ? (uint32_t)((n + 64ull * wq_steps - 1) / (64ull * wq_steps)) : 0u;
     const uint32_t wq_shards = gridDim.x < 8u ? gridDim.x : 8u, wq_shard = blockIdx.x % wq_shards;
-    const uint32_t wq_per = WQ ? (wq_items + wq_shards - 1) / wq_shards : 0u;
-    const uint32_t wq_first = wq_shard * wq_per, wq_end = wq_first + wq_per < wq_items ? wq_first + wq_per : wq_items;
+    const uint32_t wq_per = WQ ? (wq_local ? (wq_items + gridDim.x - 1) / gridDim.x : (wq_items + wq_shards - 1) / wq_shards) : 0u;
+    const uint32_t wq_first = (wq_local ? blockIdx.x : wq_shard) * wq_per, wq_end = wq_first + wq_per < wq_items ? wq_first + wq_per : wq_items;
     // The first item of a wave is its rank among the waves that share its counter (no atomic, nothing to wait for); the counter hands out
-    // what lies behind those.  A pull's answer is left in its register until the item is entered (the loop's own vmcnt waits cover it).
-    const uint32_t wq_rank = (blockIdx.x / wq_shards) * (WG / 64) + (tid >> 6);
-    const uint32_t wq_waves = ((gridDim.x - wq_shard + wq_shards - 1) / wq_shards) * (WG / 64);  // waves that pull from this counter
+    // what lies behind those.  A pull's answer is left in its register until the item is entered (the loop's own waits cover it).
+    const uint32_t wq_rank = wq_local ? (tid >> 6) : (blockIdx.x / wq_shards) * (WG / 64) + (tid >> 6);
+    const uint32_t wq_waves = wq_local ? (uint32_t)(WG / 64) : ((gridDim.x - wq_shard + wq_shards - 1) / wq_shards) * (WG / 64);  // waves that pull from this counter
     uint32_t wq_item = 0, wq_next_raw = 0, wq_k = 0;
     auto wq_pull = [&]() -> uint32_t {  // issued by lane 0; the other lanes hold 0 and take lane 0's answer when it is used
         uint32_t t = 0;
-        if ((tid & 63u) == 0) t = atomicAdd(queue + wq_shard, 1u);
+        if ((tid & 63u) == 0) t = wq_local ? lds_add_rtn(seg_counter + 20u, 1u) : atomicAdd(queue + wq_shard, 1u);
         return t;
     };
     if (WQ) {
@@ -1383,7 +1387,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     if (WQ && (tid & 63u) == 0) {
         // the last wave of the launch to leave re-arms the queue (no wave pulls after it has left): the waves of a workgroup count in
         // LDS, the last of them counts for the workgroup (one global atomic per workgroup, not per wave: 4 096 of them on one word took 50 us)
-        if (lds_add_rtn(seg_counter + 16u, 1u) == WG / 64 - 1u) {
+        if (!wq_local && lds_add_rtn(seg_counter + 16u, 1u) == WG / 64 - 1u) {
             if (atomicAdd(queue + 8, 1u) == gridDim.x - 1u) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) __hip_atomic_store(queue + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1492,14 +1496,18 @@ static bool coop_dma_wanted() {
 // The wave queue pays from ~64 steps of 64 candidates per wave on (2 * 10^7 candidates: level with the static grid; 10^8: 4 % ahead);
 // below that its atomics cost more than the even finish gains (2 * 10^6: 0.27 against 0.19 ms) and the static grid stays.
 // HC_WAVE_QUEUE=0: never; =2: always (experiments and tests); HC_WAVE_QUEUE_STEPS: steps per item
-static bool wave_queue_for(uint64_t n, uint32_t n_cu, uint32_t* steps_out) {
+static int wave_queue_mode() {
     static const int mode = getenv("HC_WAVE_QUEUE") ? atoi(getenv("HC_WAVE_QUEUE")) : 1;
+    return mode;
+}
+static bool wave_queue_for(uint64_t n, uint32_t n_cu, uint32_t* steps_out) {
+    const int mode = wave_queue_mode();
     const uint64_t wq_blocks = std::min<uint64_t>((n + 1023) / 1024, n_cu ? n_cu : 1);
     const uint64_t per_wave = n / (wq_blocks * 16 * 64);  // 64-candidate steps a wave gets on average
     uint32_t steps = per_wave >= 64 ? 8u : (per_wave >= 32 ? 4u : (per_wave >= 16 ? 2u : 1u));
     if (const char* e = getenv("HC_WAVE_QUEUE_STEPS")) steps = (uint32_t)std::min(8, std::max(1, atoi(e)));
     if (steps_out) *steps_out = steps;
-    return mode == 2 || (mode == 1 && per_wave >= 64);
+    return mode == 2 || mode == 3 || (mode == 1 && per_wave >= 64);
 }
 static uint64_t coop_dma_min() {  // HC_COOP_DMA_MIN: test knob — the LDS-DMA form for launches of that many candidates and more
     const char* e = getenv("HC_COOP_DMA_MIN");
@@ -1592,7 +1600,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                     // one resident workgroup per CU, the waves pull items of `steps` 64-candidate steps
                     blocks_d = std::min<uint64_t>((n + 1023) / 1024, n_cu);
                     ScoreParams pq = prm;
-                    pq.pad = (prm.pad & 0xFFu) | (steps << 8);
+                    pq.pad = (prm.pad & 0xFFu) | (steps << 8) | (wave_queue_mode() == 3 ? 0x1000u : 0u);  // (3: experiment — tickets in LDS)
                     use_segments(blocks_d);
 #define HC_COOP_WQ_LAUNCH(LG_)                                                                                                                  \
     hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_, 1024, true, false, 0, true>), dim3((uint32_t)blocks_d), dim3(1024), lds_dma, stream, st, \
