@@ -175,8 +175,8 @@ def build_workload(workload, rank):
     import haploconduct_amd as hc
 
     st = dict(edge_threshold=0.97, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=150)
-    if workload in ("c2", "c2-small", "c3", "c3-lite"):
-        n_pairs, glen, n_cand = {"c2": (50000, 45000, 2000000), "c2-small": (5000, 1800, 200000),
+    if workload in ("c2", "c2-small", "c2-mid", "c2-100k", "c3", "c3-lite"):
+        n_pairs, glen, n_cand = {"c2": (50000, 45000, 2000000), "c2-small": (5000, 1800, 200000), "c2-mid": (50000, 45000, 400000), "c2-100k": (50000, 45000, 100000),
                                  "c3": (500000, 90000, 100000000), "c3-lite": (500000, 90000, 20000000)}[workload]
         reads, meta = synth.make_paired_dataset(n_pairs, glen, seed=1)
         cand = synth.paired_candidates(meta, n_candidates=n_cand, seed=2 + rank)

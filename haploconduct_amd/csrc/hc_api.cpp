@@ -546,17 +546,8 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
         seg_buf = c->sink_rows.as<hc_gather_row>();
         seg_count = c->sink_counts.as<uint32_t>();
     }
-    uint32_t* wave_queue = nullptr;
-    if (c->coop_fetch && !want_bucket) {  // the queue words of this launch (used by the LDS-DMA form only)
-        if (!c->wave_queues.p) {
-            int rc = c->wave_queues.ensure((size_t)kWaveQueueSlots * 16 * sizeof(uint32_t));
-            if (rc) return rc;
-            HC_HIP(hipMemset(c->wave_queues.p, 0, (size_t)kWaveQueueSlots * 16 * sizeof(uint32_t)));
-        }
-        wave_queue = c->wave_queues.as<uint32_t>() + 16u * (c->wave_queue_turn.fetch_add(1) % kWaveQueueSlots);
-    }
     HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group, rows, row_count, cap,
-                            base_index, s, lines_in, lines_out, bperm, bqueue, seg_buf, seg_count, seg_total, &c->sink_turn, wave_queue));
+                            base_index, s, lines_in, lines_out, bperm, bqueue, seg_buf, seg_count, seg_total, &c->sink_turn));
     if (ctx_scratch) {
         HC_HIP(hipEventRecord(c->scratch_done, s));
         c->scratch_stream = s;

@@ -22,9 +22,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr, uint32_t* bucket_perm = nullptr,
                         uint32_t* bucket_queue = nullptr, hc_gather_row* seg_buf = nullptr, uint32_t* seg_count = nullptr, uint64_t seg_total_rows = 0,
-                        uint32_t* spill_turn = nullptr, uint32_t* wave_queue = nullptr);
-// wave_queue: 16 zeroed uint32 of device memory no other launch in flight uses (8 item counters, one count of the waves that have left, spare):
-// the LDS-DMA form then runs as one resident workgroup per CU whose waves pull their items; the launch leaves the words zero
+                        uint32_t* spill_turn = nullptr);
 // seg_buf (seg_total_rows rows: segments, then `cap` rows of spill area) / seg_count (kSinkMaxGroups counters + 2 spill counters, all
 // zero before the first launch) / spill_turn (host: which spill counter the next launch uses; advanced by a launch that used segments):
 // scratch of a launch that collects its rows in per-workgroup segments
@@ -99,8 +97,6 @@ struct hc_bucket_ws {
     uint32_t* perm() const { return mem.as<uint32_t>() + 16; }
 };
 
-constexpr uint32_t kWaveQueueSlots = 256;
-
 struct hc_ctx {
     hc_settings settings;
     int device = 0;
@@ -150,10 +146,7 @@ struct hc_ctx {
     hc_bucket_ws bucket;  // length-bucketed launches on the context's own entry points
     hc_scratch sink_rows, sink_counts;  // hc_score_pack_device: the row sink's per-workgroup segments (hc_kernels.hip: RowSink)
     uint32_t sink_turn = 0;             // which of the two spill counters the next segmented launch uses
-    // wave queues of the LDS-DMA launches (hc_kernels.hip: WQ): a ring of kWaveQueueSlots x 16 words, zero at rest; consecutive launches take
-    // consecutive slots (any stream, blocks included), so a slot comes round again only kWaveQueueSlots launches later
-    hc_scratch wave_queues;
-    std::atomic<uint32_t> wave_queue_turn{0};
+
     // The context's own scratch (reorder workspace, `bucket`, the sink's segments) serves one launch at a time: a launch that uses
     // any of it on another stream than the last such launch waits for that one (hc_ctx_score)
     hipEvent_t scratch_done = nullptr;

@@ -266,9 +266,11 @@ __device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint3
                 t[jj * 4 + k] = lds_f64(__builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
             continue;
         }
-        const uint32_t x = aw | bw;
-        const uint32_t nm = x & (T::kLow1 << 2);                             // code bit 2 on either side: N (or invalid)
-        const uint32_t mk = ((e << 1) | (e << 2)) & (T::kLow1 << 2) & ~x;  // bases differ, neither is N
+        // N flag of either symbol; mismatch flag = (e0 | e1) moved to bit 2 and cleared where the N flag is set.  Two three-input bit ops
+        // (v_bitop3_b32, written out: left to itself the compiler forms aw | bw as a value of its own — one more VALU op per four positions)
+        constexpr uint32_t kFlag = T::kLow1 << 2;
+        const uint32_t nm = __builtin_amdgcn_bitop3_b32(aw, kFlag, bw, 0xC8);                        // (aw | bw) & kFlag
+        const uint32_t mk = __builtin_amdgcn_bitop3_b32((e << 1) | (e << 2), kFlag, nm, 0x40);      // u & kFlag & ~nm
         cn4 += nm;
         cm4 += mk;
         if (sizeof(SymT) == 1) {
@@ -1179,11 +1181,12 @@ __global__ __launch_bounds__(1024) void bucket_perm_kernel(StoreView st, uint32_
 // workgroup barrier (a workgroup-wide sort saved more work and lost it again waiting at its seven barriers).
 // DEPTH: steps of pieces in flight (2: the launch for contig-length read sets, which keeps 8 waves per CU and so has the
 // registers for a second set, StoreView::long_rows).
-// WQ (round 4, the LDS-DMA form's plain launches): every WAVE takes its work from a queue — items of 64..512 consecutive candidates,
-// handed out by one of (at most) eight counters, counter c serving the workgroups with blockIdx % 8 == c (one XCD under round-robin
-// placement: speed only) from the c-th contiguous eighth of the items — in a grid of one resident workgroup per CU.  The next item is
-// asked for before the current one is scored.  No wave waits for another at a workgroup's end, no CU for another at the launch's end
-// beyond one item.  The last wave to leave zeroes the counters for the launch after this one (queue[8] counts the leavers).
+// WQ (round 4, the LDS-DMA form): one resident workgroup per CU; the candidates are dealt to the workgroups in equal contiguous ranges and
+// every WAVE takes its items — 64 consecutive candidates each — from a ticket counter in LDS (ds_add_rtn; the first item is the wave's own
+// number, the next ticket is asked for before the current item is scored).  The waves of a CU then finish within one item of each other,
+// and no global atomic is involved.  Measured against the static grid (a wave strides over its workgroup's iterations) and against a
+// global queue (eight counters in memory, items of 512 candidates): C2 0.191 / 0.210 / 0.165 ms, C3-lite 1.525 / 1.531 / 1.482, C3
+// 7.04 / 6.67 / 6.55 (profiles/r04_wave_queue.txt, r04_wq_local.txt); the CUs hold 15.3 of their 16 waves on average instead of 12.7.
 template <typename SymT, int LG, int WG, bool SORT, bool DYN, int DEPTH = 1, bool WQ = false>
 __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 2 : 1))) void score_kernel_coop(StoreView st, ScoreParams prm, const double* __restrict__ lut_g,
                                                             const void* __restrict__ in, uint64_t n, hc_result_rec* __restrict__ out,
@@ -1203,8 +1206,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     const uint32_t seg_counter = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(scratch + 24);
     if (threadIdx.x == 0) {
         scratch[24] = 0;
-        scratch[28] = 0;  // WQ: waves of this workgroup that have left
-        scratch[29] = 0;  // WQ, local form: the workgroup's ticket counter
+        scratch[29] = 0;  // WQ: the workgroup's ticket counter
         if (DYN) scratch[26] = atomicAdd(queue, 1u);  // the workgroup's first queue entry; [26], [27]: this iteration's and the next one's
     }
     __syncthreads();
@@ -1230,33 +1232,25 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     const uint32_t n_pieces = n_tiles * (kBucketTile / WG);
     uint32_t q_ahead = 0, iter = 0;
     // WQ: this wave's item, the one it has asked for already, where it stands inside the item
-    const uint32_t wq_steps = WQ ? ((prm.pad >> 8) & 0xFu) : 0u;        // 64-candidate steps per item (1..8)
-    // LOCAL form (prm.pad bit 12; small launches): the items are dealt to the workgroups in equal contiguous ranges and the waves of a
-    // workgroup take theirs from a ticket counter in LDS — no global atomic at all; the waves of a CU finish within one item of each other
-    const bool wq_local = WQ && (prm.pad & 0x1000u);
+    const uint32_t wq_steps = WQ ? ((prm.pad >> 8) & 0xFu) : 0u;        // 64-candidate steps per item (1 unless HC_WAVE_QUEUE_STEPS says otherwise)
     const uint32_t wq_items = WQ ? (uint32_t)((n + 64ull * wq_steps - 1) / (64ull * wq_steps)) : 0u;
-    const uint32_t wq_shards = gridDim.x < 8u ? gridDim.x : 8u, wq_shard = blockIdx.x % wq_shards;
-    const uint32_t wq_per = WQ ? (wq_local ? (wq_items + gridDim.x - 1) / gridDim.x : (wq_items + wq_shards - 1) / wq_shards) : 0u;
-    const uint32_t wq_first = (wq_local ? blockIdx.x : wq_shard) * wq_per, wq_end = wq_first + wq_per < wq_items ? wq_first + wq_per : wq_items;
-    // The first item of a wave is its rank among the waves that share its counter (no atomic, nothing to wait for); the counter hands out
-    // what lies behind those.  A pull's answer is left in its register until the item is entered (the loop's own waits cover it).
-    const uint32_t wq_rank = wq_local ? (tid >> 6) : (blockIdx.x / wq_shards) * (WG / 64) + (tid >> 6);
-    const uint32_t wq_waves = wq_local ? (uint32_t)(WG / 64) : ((gridDim.x - wq_shard + wq_shards - 1) / wq_shards) * (WG / 64);  // waves that pull from this counter
+    const uint32_t wq_per = WQ ? (wq_items + gridDim.x - 1) / gridDim.x : 0u;  // items of this workgroup: [wq_first, wq_end)
+    const uint32_t wq_first = blockIdx.x * wq_per, wq_end = wq_first + wq_per < wq_items ? wq_first + wq_per : wq_items;
     uint32_t wq_item = 0, wq_next_raw = 0, wq_k = 0;
-    auto wq_pull = [&]() -> uint32_t {  // issued by lane 0; the other lanes hold 0 and take lane 0's answer when it is used
+    auto wq_pull = [&]() -> uint32_t {  // issued by lane 0 (the other lanes hold 0); the answer is taken when the item is entered
         uint32_t t = 0;
-        if ((tid & 63u) == 0) t = wq_local ? lds_add_rtn(seg_counter + 20u, 1u) : atomicAdd(queue + wq_shard, 1u);
+        if ((tid & 63u) == 0) t = lds_add_rtn(seg_counter + 20u, 1u);
         return t;
     };
     if (WQ) {
-        wq_item = wq_first + wq_rank;
+        wq_item = wq_first + (tid >> 6);  // the first item of a wave: its own number (the tickets start behind the WG / 64 of them)
         if (wq_item < wq_end) wq_next_raw = wq_pull();
     }
     for (uint64_t block_base = (uint64_t)blockIdx.x * WG;; block_base += stride, ++iter) {
         uint64_t slot;
         if (WQ) {
             if (wq_k == wq_steps) {
-                wq_item = wq_first + wq_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_next_raw);
+                wq_item = wq_first + (uint32_t)(WG / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_next_raw);
                 wq_k = 0;
                 if (wq_item < wq_end) wq_next_raw = wq_pull();
             }
@@ -1384,16 +1378,6 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
         __syncthreads();
         if (threadIdx.x == 0) sink.seg_count[blockIdx.x] = scratch[24];
     }
-    if (WQ && (tid & 63u) == 0) {
-        // the last wave of the launch to leave re-arms the queue (no wave pulls after it has left): the waves of a workgroup count in
-        // LDS, the last of them counts for the workgroup (one global atomic per workgroup, not per wave: 4 096 of them on one word took 50 us)
-        if (!wq_local && lds_add_rtn(seg_counter + 16u, 1u) == WG / 64 - 1u) {
-            if (atomicAdd(queue + 8, 1u) == gridDim.x - 1u) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) __hip_atomic_store(queue + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
 }
 
 // (second launch bound: at least 4 waves per SIMD, i.e. at most 128 registers — at 130 the kernel drops to 3 waves per SIMD
@@ -1493,21 +1477,12 @@ static bool coop_dma_wanted() {
     static const bool on = !(getenv("HC_COOP_DMA") && atoi(getenv("HC_COOP_DMA")) == 0);
     return on;
 }
-// The wave queue pays from ~64 steps of 64 candidates per wave on (2 * 10^7 candidates: level with the static grid; 10^8: 4 % ahead);
-// below that its atomics cost more than the even finish gains (2 * 10^6: 0.27 against 0.19 ms) and the static grid stays.
-// HC_WAVE_QUEUE=0: never; =2: always (experiments and tests); HC_WAVE_QUEUE_STEPS: steps per item
-static int wave_queue_mode() {
-    static const int mode = getenv("HC_WAVE_QUEUE") ? atoi(getenv("HC_WAVE_QUEUE")) : 1;
-    return mode;
-}
-static bool wave_queue_for(uint64_t n, uint32_t n_cu, uint32_t* steps_out) {
-    const int mode = wave_queue_mode();
-    const uint64_t wq_blocks = std::min<uint64_t>((n + 1023) / 1024, n_cu ? n_cu : 1);
-    const uint64_t per_wave = n / (wq_blocks * 16 * 64);  // 64-candidate steps a wave gets on average
-    uint32_t steps = per_wave >= 64 ? 8u : (per_wave >= 32 ? 4u : (per_wave >= 16 ? 2u : 1u));
-    if (const char* e = getenv("HC_WAVE_QUEUE_STEPS")) steps = (uint32_t)std::min(8, std::max(1, atoi(e)));
+// HC_WAVE_QUEUE=0: the LDS-DMA form on the static grid (round 3's launch; an A/B knob); HC_WAVE_QUEUE_STEPS: 64-candidate steps per item (1)
+static bool wave_queue_on(uint32_t* steps_out) {
+    static const bool on = !(getenv("HC_WAVE_QUEUE") && atoi(getenv("HC_WAVE_QUEUE")) == 0);
+    static const uint32_t steps = getenv("HC_WAVE_QUEUE_STEPS") ? (uint32_t)std::min(8, std::max(1, atoi(getenv("HC_WAVE_QUEUE_STEPS")))) : 1u;
     if (steps_out) *steps_out = steps;
-    return mode == 2 || mode == 3 || (mode == 1 && per_wave >= 64);
+    return on;
 }
 static uint64_t coop_dma_min() {  // HC_COOP_DMA_MIN: test knob — the LDS-DMA form for launches of that many candidates and more
     const char* e = getenv("HC_COOP_DMA_MIN");
@@ -1522,7 +1497,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in, hc_line_rec* lines_out, uint32_t* bucket_perm, uint32_t* bucket_queue, hc_gather_row* seg_buf,
-                        uint32_t* seg_count, uint64_t seg_total_rows, uint32_t* spill_turn, uint32_t* wave_queue) {
+                        uint32_t* seg_count, uint64_t seg_total_rows, uint32_t* spill_turn) {
     if (n == 0) return hipSuccess;
     const uint32_t lg = lut_lg(st.K);
     if (fetch_group == 0) {
@@ -1595,16 +1570,16 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 static const int grid_mult_d = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 16;
                 const uint64_t cap_d = (uint64_t)n_cu * grid_mult_d;
                 if (blocks_d > cap_d) blocks_d = cap_d;
-                uint32_t steps = 8;
-                if (wave_queue && wave_queue_for(n, n_cu, &steps)) {
-                    // one resident workgroup per CU, the waves pull items of `steps` 64-candidate steps
+                uint32_t steps = 1;
+                if (wave_queue_on(&steps)) {
+                    // one resident workgroup per CU; its waves take their items from a ticket counter in LDS (score_kernel_coop: WQ)
                     blocks_d = std::min<uint64_t>((n + 1023) / 1024, n_cu);
                     ScoreParams pq = prm;
-                    pq.pad = (prm.pad & 0xFFu) | (steps << 8) | (wave_queue_mode() == 3 ? 0x1000u : 0u);  // (3: experiment — tickets in LDS)
+                    pq.pad = (prm.pad & 0xFFu) | (steps << 8);
                     use_segments(blocks_d);
 #define HC_COOP_WQ_LAUNCH(LG_)                                                                                                                  \
     hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_, 1024, true, false, 0, true>), dim3((uint32_t)blocks_d), dim3(1024), lds_dma, stream, st, \
-                       pq, lut_g, in, n, out, perm, sink, wave_queue)
+                       pq, lut_g, in, n, out, perm, sink, nullptr)
                     if (lg == 3) HC_COOP_WQ_LAUNCH(3);
                     else if (lg == 4) HC_COOP_WQ_LAUNCH(4);
                     else HC_COOP_WQ_LAUNCH(5);
@@ -1707,10 +1682,11 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
             const bool dma = !st.balance && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024 && coop_dma_wanted();
             // n != 0: the form a launch of n candidates takes; n == 0: the read set's forms in general
             if (dma && (n == 0 || n >= coop_dma_min())) {
-                const bool wq = n != 0 && wave_queue_for(n, n_cu, nullptr);
+                const bool wq = wave_queue_on(nullptr);
+                (void)n_cu;
                 snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, 1024, true, false, 0%s> encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=16 "
-                                          "LDS-DMA fetch for launches of %llu candidates and more (the waves pull their items from a queue — template "
-                                          "argument WQ = true — where a wave gets 64 steps and more); smaller launches: %s",
+                                          "LDS-DMA fetch for launches of %llu candidates and more (one workgroup per CU, the waves take their items from a "
+                                          "ticket counter in LDS); smaller launches: %s",
                          sym.c_str(), lgt, wq ? ", true" : "", enc.c_str(), st.lut_bytes, lds_dma, (unsigned long long)coop_dma_min(), small);
             } else
                 snprintf(buf, sizeof buf, "%s encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=%u%s", small, enc.c_str(), st.lut_bytes, lds_c,
