@@ -1598,6 +1598,16 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 compact_segments(blocks_d);
                 return hipGetLastError();
             }
+            using W256 = std::integral_constant<int, 256>;
+            using W1024 = std::integral_constant<int, 1024>;
+            // the plain register-staged launches take their items by ticket too (WQ): as many workgroups as are resident, equal ranges
+            uint32_t steps_c = 1;
+            const bool tickets = !bucketed && wave_queue_on(&steps_c);
+            ScoreParams pq = prm;
+            if (tickets) {
+                pq.pad = (prm.pad & 0xFFu) | (steps_c << 8);
+                blocks_c = std::min<uint64_t>((n + wg_c - 1) / wg_c, (uint64_t)n_cu * per_cu);
+            }
             // The instantiations a read set can reach: 8-bit symbols with a table of at most 16 KiB (LG 3..5) always fit four 256-lane
             // workgroups per CU; the wide 8-bit encoding (64 KiB table) always shares one table among 1 024 lanes; 16-bit symbols take
             // either, by table size.  Nothing else is compiled (round 3 carried 45 scoring kernels, a third of them unreachable).
@@ -1612,13 +1622,14 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 } else if (bucketed) {
                     hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, prm, lut_g,
                                        in, n, out, perm, sink, bucket_queue);
+                } else if (tickets) {
+                    hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, false, 1, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, pq,
+                                       lut_g, in, n, out, perm, sink, nullptr);
                 } else {
                     hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, false>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, prm, lut_g,
                                        in, n, out, perm, sink, nullptr);
                 }
             };
-            using W256 = std::integral_constant<int, 256>;
-            using W1024 = std::integral_constant<int, 1024>;
             use_segments(blocks_c);
             if (st.symbytes == 2) {
                 if (wg_c == 256) launch_coop(uint16_t{}, std::integral_constant<int, 5>{}, W256{});
@@ -1677,7 +1688,8 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
             const bool deep = st.balance && per_cu <= 2 && wg_c == 256;
             const uint32_t lgt = st.symbytes == 2 ? 5u : lg;
             char small[128];
-            snprintf(small, sizeof small, "hc::score_kernel_coop<%s, %u, %u, true, %s, %d>", sym.c_str(), lgt, wg_c, st.balance ? "true" : "false", deep ? 2 : 1);
+            snprintf(small, sizeof small, "hc::score_kernel_coop<%s, %u, %u, true, %s, %d%s>", sym.c_str(), lgt, wg_c, st.balance ? "true" : "false", deep ? 2 : 1,
+                     (!st.balance && wave_queue_on(nullptr)) ? ", true" : "");
             const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
             const bool dma = !st.balance && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024 && coop_dma_wanted();
             // n != 0: the form a launch of n candidates takes; n == 0: the read set's forms in general
@@ -1725,6 +1737,7 @@ hipError_t set_score_kernel_lds_limit() {
     const int kMax = 160 * 1024;
 #define HC_COOP_ATTR(T_, LG_, WG_)                                                                                                                         \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
 #define HC_COOP_ATTR_DEEP(T_, LG_) \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
