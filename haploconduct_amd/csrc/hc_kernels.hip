@@ -1469,10 +1469,11 @@ void launch_lg(int group, const ScoreLaunch& a) {
 }
 }  // namespace
 
-// The LDS-DMA form of the cooperative fetch (score_sub_coop, DEPTH = 0) runs 1 024-lane workgroups, one per CU: launches of
-// fewer candidates than this keep the 256-lane register-staged form, which fills the chip with four times as many workgroups.
-// C3 (10^8 candidates) 7.50 -> 7.10 ms, C2 (2 * 10^6) 0.190 -> 0.180 ms.  HC_COOP_DMA=0 turns it off (a tuning knob).
-constexpr uint64_t kDmaMinCandidates = 500000;
+// The LDS-DMA form of the cooperative fetch (score_sub_coop, DEPTH = 0) runs 1 024-lane workgroups, one per CU, whose waves take their items
+// by ticket: launches of fewer candidates than this keep the 256-lane register-staged form, which fills the chip with four times as many
+// workgroups.  2 * 10^5 candidates: 0.0224 against 0.0253 ms, 4 * 10^5: 0.0441 / 0.0482, 10^5: 0.0251 / 0.0198 (profiles/r04_tickets_reg.txt;
+// round 3, static grid: from 5 * 10^5 on).  HC_COOP_DMA=0 turns it off (a tuning knob).
+constexpr uint64_t kDmaMinCandidates = 150000;
 static bool coop_dma_wanted() {
     static const bool on = !(getenv("HC_COOP_DMA") && atoi(getenv("HC_COOP_DMA")) == 0);
     return on;
@@ -1571,7 +1572,9 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 const uint64_t cap_d = (uint64_t)n_cu * grid_mult_d;
                 if (blocks_d > cap_d) blocks_d = cap_d;
                 uint32_t steps = 1;
-                if (wave_queue_on(&steps)) {
+                // (rows collected without segments — a payload of 2^32 rows and more — go through append_rows_block, whose barriers need every
+                // wave of a workgroup in the same iteration: that launch keeps the static grid)
+                if (wave_queue_on(&steps) && !(rows && !segmented)) {
                     // one resident workgroup per CU; its waves take their items from a ticket counter in LDS (score_kernel_coop: WQ)
                     blocks_d = std::min<uint64_t>((n + 1023) / 1024, n_cu);
                     ScoreParams pq = prm;
@@ -1600,9 +1603,12 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             }
             using W256 = std::integral_constant<int, 256>;
             using W1024 = std::integral_constant<int, 1024>;
-            // the plain register-staged launches take their items by ticket too (WQ): as many workgroups as are resident, equal ranges
+            // the plain register-staged launches of 1 024-lane workgroups (wide 8-bit and 16-bit symbol tables: one workgroup per CU) take their
+            // items by ticket too (WQ): C4 with 35 quality values 0.153 -> 0.122 ms, with 60 (16-bit symbols) 0.208 -> 0.179; 256-lane workgroups
+            // (four per CU, four waves each) gain nothing by it (0.0195 / 0.0198, 0.0505 / 0.0482 ms) and keep the static grid
+            // (profiles/r04_tickets_reg.txt)
             uint32_t steps_c = 1;
-            const bool tickets = !bucketed && wave_queue_on(&steps_c);
+            const bool tickets = !bucketed && wg_c == 1024 && wave_queue_on(&steps_c) && !(rows && !segmented);  // (append_rows_block has barriers)
             ScoreParams pq = prm;
             if (tickets) {
                 pq.pad = (prm.pad & 0xFFu) | (steps_c << 8);
@@ -1623,8 +1629,9 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                     hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, prm, lut_g,
                                        in, n, out, perm, sink, bucket_queue);
                 } else if (tickets) {
-                    hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, false, 1, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, pq,
-                                       lut_g, in, n, out, perm, sink, nullptr);
+                    if constexpr (WG_ == 1024)
+                        hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 1024, true, false, 1, true>), dim3((uint32_t)blocks_c), dim3(1024), lds_launch, stream, st,
+                                           pq, lut_g, in, n, out, perm, sink, nullptr);
                 } else {
                     hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, false>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, prm, lut_g,
                                        in, n, out, perm, sink, nullptr);
@@ -1689,7 +1696,7 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
             const uint32_t lgt = st.symbytes == 2 ? 5u : lg;
             char small[128];
             snprintf(small, sizeof small, "hc::score_kernel_coop<%s, %u, %u, true, %s, %d%s>", sym.c_str(), lgt, wg_c, st.balance ? "true" : "false", deep ? 2 : 1,
-                     (!st.balance && wave_queue_on(nullptr)) ? ", true" : "");
+                     (!st.balance && wg_c == 1024 && wave_queue_on(nullptr)) ? ", true" : "");
             const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
             const bool dma = !st.balance && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024 && coop_dma_wanted();
             // n != 0: the form a launch of n candidates takes; n == 0: the read set's forms in general
@@ -1737,7 +1744,6 @@ hipError_t set_score_kernel_lds_limit() {
     const int kMax = 160 * 1024;
 #define HC_COOP_ATTR(T_, LG_, WG_)                                                                                                                         \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
 #define HC_COOP_ATTR_DEEP(T_, LG_) \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
@@ -1753,6 +1759,8 @@ hipError_t set_score_kernel_lds_limit() {
     HC_COOP_ATTR(uint8_t, 6, 1024)
     HC_COOP_ATTR(uint16_t, 5, 256)
     HC_COOP_ATTR(uint16_t, 5, 1024)
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 6, 1024, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint16_t, 5, 1024, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     HC_COOP_ATTR_DEEP(uint8_t, 3)
     HC_COOP_ATTR_DEEP(uint8_t, 4)
     HC_COOP_ATTR_DEEP(uint8_t, 5)

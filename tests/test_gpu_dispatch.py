@@ -42,9 +42,13 @@ def test_savage_example_shape_takes_the_cooperative_kernel(oracle, monkeypatch):
     reads, meta = synth.make_single_dataset(20000, 60000, len_lo=400, len_hi=500, n_strains=3, divergence=0.01, flip_frac=0.5, seed=8)
     cand = synth.single_candidates(meta, min_overlap=200, n_candidates=300000)
     st = hc.Settings(edge_threshold=0.97, min_overlap_len=200)
-    small, large = _check(oracle, reads, cand, st, ["hc::score_kernel_coop<uint8_t, 3, 256, true, false, 1>"], monkeypatch, {"HC_FETCH_GROUP": "2"})
-    assert "score_kernel_coop<uint8_t, 3, 1024, true, false, 0, true>" in large  # a 10^8-candidate launch: LDS-DMA rows, the waves' work queue
+    small, large = _check(oracle, reads, cand, st, ["hc::score_kernel_coop<uint8_t, 3, 1024, true, false, 0, true>"], monkeypatch, {"HC_FETCH_GROUP": "2"})
+    # 300 000 candidates and 10^8 alike: LDS-DMA rows, one workgroup per CU, the waves take their items by ticket; below 150 000: 256-lane workgroups
+    assert small.split(" encoding=")[0] == large.split(" encoding=")[0] == "hc::score_kernel_coop<uint8_t, 3, 1024, true, false, 0, true>"
     assert "length-bucketed" not in small
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        assert sc.kernel_info(100000).startswith("hc::score_kernel_coop<uint8_t, 3, 256, true, false, 1>")
 
 
 def test_the_savage_example_reads_themselves_take_the_cooperative_kernel(tmp_path):
@@ -73,7 +77,7 @@ def test_trimmed_pairs_take_the_cooperative_kernel(oracle, monkeypatch):
     cand = synth.paired_candidates(meta, min_len=50, seed=2)[:300000]
     assert cand.size > 100000
     st = hc.Settings(edge_threshold=0.97, min_overlap_len=100)
-    _check(oracle, reads, cand, st, ["hc::score_kernel_coop<uint8_t, 3, 256, true, false, 1>"], monkeypatch, {"HC_FETCH_GROUP": "4"})
+    _check(oracle, reads, cand, st, ["hc::score_kernel_coop<uint8_t, 3, 1024, true, false, 0, true>"], monkeypatch, {"HC_FETCH_GROUP": "4"})
 
 
 def test_contig_length_mixed_singles_take_the_bucketed_launch(oracle, monkeypatch):
