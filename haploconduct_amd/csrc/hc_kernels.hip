@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     if (threadIdx.x == 0) {
         scratch[24] = 0;
         scratch[29] = 0;  // WQ: the workgroup's ticket counter
-        if (DYN) scratch[26] = atomicAdd(queue, 1u);  // the workgroup's first queue entry; [26], [27]: this iteration's and the next one's
+        if (DYN && !WQ) scratch[26] = atomicAdd(queue, 1u);  // the workgroup's first queue entry; [26], [27]: this iteration's and the next one's
     }
     __syncthreads();
     // this wave's image (LDS byte address); the images start at a multiple of 1 KiB (the XOR swizzle needs whole 64-byte rows)
@@ -1233,9 +1233,12 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     uint32_t q_ahead = 0, iter = 0;
     // WQ: this wave's item, the one it has asked for already, where it stands inside the item
     const uint32_t wq_steps = WQ ? ((prm.pad >> 8) & 0xFu) : 0u;        // 64-candidate steps per item (1 unless HC_WAVE_QUEUE_STEPS says otherwise)
-    const uint32_t wq_items = WQ ? (uint32_t)((n + 64ull * wq_steps - 1) / (64ull * wq_steps)) : 0u;
-    const uint32_t wq_per = WQ ? (wq_items + gridDim.x - 1) / gridDim.x : 0u;  // items of this workgroup: [wq_first, wq_end)
-    const uint32_t wq_first = blockIdx.x * wq_per, wq_end = wq_first + wq_per < wq_items ? wq_first + wq_per : wq_items;
+    // DYN with WQ (bucketed launches by ticket): the workgroup owns the pieces q = blockIdx, blockIdx + G, ... of the queue's order (every
+    // workgroup a like mix of long and short ones) and its waves take (piece, group of 64 ranks) pairs by ticket: no global atomic, no barrier
+    const uint32_t dq_pieces = (DYN && WQ && blockIdx.x < n_pieces) ? (n_pieces - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+    const uint32_t wq_items = !WQ ? 0u : (DYN ? dq_pieces * (uint32_t)(WG / 64) : (uint32_t)((n + 64ull * wq_steps - 1) / (64ull * wq_steps)));
+    const uint32_t wq_per = !WQ ? 0u : (DYN ? wq_items : (wq_items + gridDim.x - 1) / gridDim.x);  // items of this workgroup: [wq_first, wq_end)
+    const uint32_t wq_first = DYN ? 0u : blockIdx.x * wq_per, wq_end = wq_first + wq_per < wq_items ? wq_first + wq_per : wq_items;
     uint32_t wq_item = 0, wq_next_raw = 0, wq_k = 0;
     auto wq_pull = [&]() -> uint32_t {  // issued by lane 0 (the other lanes hold 0); the answer is taken when the item is entered
         uint32_t t = 0;
@@ -1255,7 +1258,14 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
                 if (wq_item < wq_end) wq_next_raw = wq_pull();
             }
             if (wq_item >= wq_end) break;  // wave-uniform
-            slot = ((uint64_t)wq_item * wq_steps + wq_k) * 64u + (tid & 63u);
+            if (DYN) {
+                const uint32_t k = wq_item / (uint32_t)(WG / 64), w = wq_item - k * (uint32_t)(WG / 64);
+                const uint32_t q = blockIdx.x + k * gridDim.x;
+                const uint32_t piece = q / n_tiles, tile = q - piece * n_tiles;
+                slot = (uint64_t)tile * kBucketTile + piece * WG + w * 64u + (tid & 63u);
+            } else {
+                slot = ((uint64_t)wq_item * wq_steps + wq_k) * 64u + (tid & 63u);
+            }
             ++wq_k;
         } else if (DYN) {
             const uint32_t q = scratch[26 + (iter & 1u)];
@@ -1369,7 +1379,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
             else if (DYN) append_rows_wave(sink, slot < n, res, i);
             else append_rows_block(sink, slot < n, res, i, scratch);
         }
-        if (DYN) {
+        if (DYN && !WQ) {
             if (tid == 0) scratch[26 + ((iter + 1u) & 1u)] = q_ahead;
             __syncthreads();
         }
@@ -1614,6 +1624,9 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 pq.pad = (prm.pad & 0xFFu) | (steps_c << 8);
                 blocks_c = std::min<uint64_t>((n + wg_c - 1) / wg_c, (uint64_t)n_cu * per_cu);
             }
+            static const bool bucket_tickets_env = getenv("HC_BUCKET_TICKETS") && atoi(getenv("HC_BUCKET_TICKETS")) != 0;  // experiment
+            const bool bucket_tickets = bucketed && bucket_tickets_env && !(rows && !segmented);
+            if (bucket_tickets) pq.pad = (prm.pad & 0xFFu) | (1u << 8);
             // The instantiations a read set can reach: 8-bit symbols with a table of at most 16 KiB (LG 3..5) always fit four 256-lane
             // workgroups per CU; the wide 8-bit encoding (64 KiB table) always shares one table among 1 024 lanes; 16-bit symbols take
             // either, by table size.  Nothing else is compiled (round 3 carried 45 scoring kernels, a third of them unreachable).
@@ -1621,10 +1634,17 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 using T_ = decltype(sym_tag);
                 constexpr int LG_ = decltype(lg_tag)::value;
                 constexpr int WG_ = decltype(wg_tag)::value;
-                if (bucketed && deep) {
+                if (bucketed && deep && bucket_tickets) {
+                    if constexpr (WG_ == 256)
+                        hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true, 2, true>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, pq,
+                                           lut_g, in, n, out, perm, sink, bucket_queue);
+                } else if (bucketed && deep) {
                     if constexpr (WG_ == 256)
                         hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true, 2>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, prm,
                                            lut_g, in, n, out, perm, sink, bucket_queue);
+                } else if (bucketed && bucket_tickets) {
+                    hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, true, 1, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, pq, lut_g,
+                                       in, n, out, perm, sink, bucket_queue);
                 } else if (bucketed) {
                     hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, prm, lut_g,
                                        in, n, out, perm, sink, bucket_queue);
@@ -1744,9 +1764,11 @@ hipError_t set_score_kernel_lds_limit() {
     const int kMax = 160 * 1024;
 #define HC_COOP_ATTR(T_, LG_, WG_)                                                                                                                         \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
 #define HC_COOP_ATTR_DEEP(T_, LG_) \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
 #define HC_COOP_ATTR_DMA(LG_)                                                                                                                                          \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, LG_, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, LG_, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;

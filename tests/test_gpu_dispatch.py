@@ -46,6 +46,7 @@ def test_savage_example_shape_takes_the_cooperative_kernel(oracle, monkeypatch):
     # 300 000 candidates and 10^8 alike: LDS-DMA rows, one workgroup per CU, the waves take their items by ticket; below 150 000: 256-lane workgroups
     assert small.split(" encoding=")[0] == large.split(" encoding=")[0] == "hc::score_kernel_coop<uint8_t, 3, 1024, true, false, 0, true>"
     assert "length-bucketed" not in small
+    monkeypatch.delenv("HC_FETCH_GROUP")  # (_check left it set for its second scorer)
     with hc.EdgeScorer(st) as sc:
         sc.set_reads(reads)
         assert sc.kernel_info(100000).startswith("hc::score_kernel_coop<uint8_t, 3, 256, true, false, 1>")
