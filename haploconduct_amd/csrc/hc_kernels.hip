@@ -1624,9 +1624,10 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 pq.pad = (prm.pad & 0xFFu) | (steps_c << 8);
                 blocks_c = std::min<uint64_t>((n + wg_c - 1) / wg_c, (uint64_t)n_cu * per_cu);
             }
-            static const bool bucket_tickets_env = getenv("HC_BUCKET_TICKETS") && atoi(getenv("HC_BUCKET_TICKETS")) != 0;  // experiment
-            const bool bucket_tickets = bucketed && bucket_tickets_env && !(rows && !segmented);
-            if (bucket_tickets) pq.pad = (prm.pad & 0xFFu) | (1u << 8);
+            // bucketed launches go by ticket as well: the workgroup owns the pieces blockIdx, blockIdx + G, ... of the longest-first order and
+            // its waves take (piece, group of 64 ranks) pairs from the LDS counter — no global queue atomic, no barrier per piece (round 3's
+            // workgroup queue: C5 0.627 -> 0.620 ms, singles of 150..1 500 bp 0.342 -> 0.324, 120..900 bp 0.283 -> 0.268; profiles/r04_bucket_tickets.txt)
+            if (bucketed) pq.pad = (prm.pad & 0xFFu) | (1u << 8);
             // The instantiations a read set can reach: 8-bit symbols with a table of at most 16 KiB (LG 3..5) always fit four 256-lane
             // workgroups per CU; the wide 8-bit encoding (64 KiB table) always shares one table among 1 024 lanes; 16-bit symbols take
             // either, by table size.  Nothing else is compiled (round 3 carried 45 scoring kernels, a third of them unreachable).
@@ -1634,19 +1635,12 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 using T_ = decltype(sym_tag);
                 constexpr int LG_ = decltype(lg_tag)::value;
                 constexpr int WG_ = decltype(wg_tag)::value;
-                if (bucketed && deep && bucket_tickets) {
+                if (bucketed && deep) {
                     if constexpr (WG_ == 256)
                         hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true, 2, true>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, pq,
                                            lut_g, in, n, out, perm, sink, bucket_queue);
-                } else if (bucketed && deep) {
-                    if constexpr (WG_ == 256)
-                        hipLaunchKernelGGL((score_kernel_coop<T_, LG_, 256, true, true, 2>), dim3((uint32_t)blocks_c), dim3(256), lds_launch, stream, st, prm,
-                                           lut_g, in, n, out, perm, sink, bucket_queue);
-                } else if (bucketed && bucket_tickets) {
-                    hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, true, 1, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, pq, lut_g,
-                                       in, n, out, perm, sink, bucket_queue);
                 } else if (bucketed) {
-                    hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, prm, lut_g,
+                    hipLaunchKernelGGL((score_kernel_coop<T_, LG_, WG_, true, true, 1, true>), dim3((uint32_t)blocks_c), dim3(WG_), lds_launch, stream, st, pq, lut_g,
                                        in, n, out, perm, sink, bucket_queue);
                 } else if (tickets) {
                     if constexpr (WG_ == 1024)
@@ -1716,7 +1710,7 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
             const uint32_t lgt = st.symbytes == 2 ? 5u : lg;
             char small[128];
             snprintf(small, sizeof small, "hc::score_kernel_coop<%s, %u, %u, true, %s, %d%s>", sym.c_str(), lgt, wg_c, st.balance ? "true" : "false", deep ? 2 : 1,
-                     (!st.balance && wg_c == 1024 && wave_queue_on(nullptr)) ? ", true" : "");
+                     (st.balance || (wg_c == 1024 && wave_queue_on(nullptr))) ? ", true" : "");
             const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
             const bool dma = !st.balance && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024 && coop_dma_wanted();
             // n != 0: the form a launch of n candidates takes; n == 0: the read set's forms in general
@@ -1729,7 +1723,7 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
                          sym.c_str(), lgt, wq ? ", true" : "", enc.c_str(), st.lut_bytes, lds_dma, (unsigned long long)coop_dma_min(), small);
             } else
                 snprintf(buf, sizeof buf, "%s encoding=%s table_bytes=%u lds_bytes=%zu waves_per_cu=%u%s", small, enc.c_str(), st.lut_bytes, lds_c,
-                         per_cu * (wg_c / 64), st.balance ? " length-bucketed (hc::bucket_perm_kernel, wave queue)" : "");
+                         per_cu * (wg_c / 64), st.balance ? " length-bucketed (hc::bucket_perm_kernel, items by ticket)" : "");
             return buf;
         }
         fetch_group = lane_fetch_group;
@@ -1764,10 +1758,8 @@ hipError_t set_score_kernel_lds_limit() {
     const int kMax = 160 * 1024;
 #define HC_COOP_ATTR(T_, LG_, WG_)                                                                                                                         \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, WG_, true, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
 #define HC_COOP_ATTR_DEEP(T_, LG_) \
-    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<T_, LG_, 256, true, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
 #define HC_COOP_ATTR_DMA(LG_)                                                                                                                                          \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, LG_, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \

@@ -85,4 +85,4 @@ def test_contig_length_mixed_singles_take_the_bucketed_launch(oracle, monkeypatc
     reads, meta = synth.make_single_dataset(8000, 60000, len_lo=150, len_hi=3000, n_strains=3, divergence=0.01, flip_frac=0.5, seed=5, log_uniform=True)
     cand = synth.single_candidates(meta, min_overlap=100, n_candidates=200000)
     st = hc.Settings(edge_threshold=0.995, min_overlap_len=100)
-    small, _ = _check(oracle, reads, cand, st, ["hc::score_kernel_coop<uint8_t, 3, 256, true, true, 2>", "length-bucketed"], monkeypatch, {"HC_BALANCE": "0"})
+    small, _ = _check(oracle, reads, cand, st, ["hc::score_kernel_coop<uint8_t, 3, 256, true, true, 2, true>", "length-bucketed"], monkeypatch, {"HC_BALANCE": "0"})
