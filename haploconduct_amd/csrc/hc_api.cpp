@@ -456,7 +456,6 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         if (short_mixed_singles) c->fetch_group = 2;
     }
     c->view.long_rows = (n_seq && total / n_seq > 600) ? 1u : 0u;
-    if (const char* v = getenv("HC_LONG_ROWS")) c->view.long_rows = atoi(v) != 0;  // tuning knob
     return HC_OK;
 }
 

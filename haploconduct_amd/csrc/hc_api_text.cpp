@@ -334,16 +334,13 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
         // blocks' own streams the runtime opened a further copy queue whenever a copy met others in flight: 7 - 8 ms inside
         // hipMemcpyAsync, five or six times during the first file of a process (HC_SUBMIT_TRACE) — C3's first construct_edges of a
         // process 0.18 - 0.20 s against 0.13 - 0.14 s with two; one stream alone does not keep the link busy (later files 0.13 - 0.17 s
-        // against 0.12).  HC_TEXT_COPY_STREAMS = 0 (the blocks' own) .. 4.
-        static const int copy_streams = getenv("HC_TEXT_COPY_STREAMS") ? std::max(0, std::min(4, atoi(getenv("HC_TEXT_COPY_STREAMS")))) : 2;
-        if (copy_streams) {
-            hipStream_t& cs = c->text_copy_stream[c->text_copy_next++ % (uint32_t)copy_streams];
+        // against 0.12; a round-3 knob, gone: the measurement stands).
+        {
+            hipStream_t& cs = c->text_copy_stream[c->text_copy_next++ % 2u];
             if (!cs) HC_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             HC_HIP(hipMemcpyAsync(b->d_text, src, n_bytes, hipMemcpyHostToDevice, cs));
             HC_HIP(hipEventRecord(b->copied, cs));
             HC_HIP(hipStreamWaitEvent(s, b->copied, 0));
-        } else {
-            HC_HIP(hipMemcpyAsync(b->d_text, src, n_bytes, hipMemcpyHostToDevice, s));
         }
         HC_HIP(hipMemsetAsync(b->d_text + n_bytes, 0, 64, s));
         HC_HIP(hc::launch_text_lines(b->d_text, n_bytes, b->d_tile_cnt, b->d_tile_off, b->max_lines, b->d_line_start, b->d_counters, s));
