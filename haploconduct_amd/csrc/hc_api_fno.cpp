@@ -148,7 +148,8 @@ bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_
         return false;
     };
     const uint64_t G = h.graph.n, B = h.branching.n, N = h.nonedges.n, I = h.induced.n;
-    if (G + B + N + I == 0 || G + B + N + I >= 0x7FFFFFF0ull || h.n_srs >= 0xFFFFFFFFull || h.n_nodes >= 0xFFFFFFFFull) return false;
+    const uint64_t per_nonedge = h.dup_half ? 2 : 1;  // --add_duplicates: every kept stored non-edge and its opposite
+    if (G + B + N + I == 0 || G + B + per_nonedge * N + I >= 0x7FFFFFF0ull || h.n_srs >= 0xFFFFFFFFull || h.n_nodes >= 0xFFFFFFFFull) return false;
     uint32_t id_bits = 1;
     while (id_bits < 64 && (h.new_read_count - 1) >> id_bits) id_bits++;
     if (h.new_read_count == 0 || 2 * id_bits > 62) return false;
@@ -164,7 +165,9 @@ bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_
         return (const T*)p;
     };
     // the edges in walk order: [adj_out][branching][stored non-edges that pass :702][inclusion-induced]
-    hc_fno_edge* d_edges = d.get<hc_fno_edge>(G + B + N + I);
+    hc_fno_edge* d_edges = d.get<hc_fno_edge>(G + B + per_nonedge * N + I);
+    w.nodes = upload((hc_fno_read*)nullptr, h.nodes, h.n_nodes, "copy of the vertices");
+    w.n_nodes = h.n_nodes;
     if (G) hip_check(hipMemcpyAsync(d_edges, h.graph.p, G * sizeof(hc_fno_edge), hipMemcpyHostToDevice, st), "copy of the edges");
     if (B) hip_check(hipMemcpyAsync(d_edges + G, h.branching.p, B * sizeof(hc_fno_edge), hipMemcpyHostToDevice, st), "copy of the edges");
     uint64_t kept = 0;
@@ -185,8 +188,16 @@ bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_
         hip_check(hipStreamSynchronize(st), "synchronize");
         if (h_status[4]) return left("the stored non-edges", h_status[4]);
         kept = h_status[5];
-        hip_check(fno_gather_edges(d_non, d_idx, kept, d_edges + G + B, st), "gather");
-        hip_check(hipStreamSynchronize(st), "synchronize");
+        if (h.dup_half) {
+            hip_check(fno_gather_mirrored(d_non, d_idx, kept, w.nodes, h.dup_half, d_edges + G + B, d_status, st), "gather");
+            hip_check(hipMemcpyAsync(h_status, d_status, sizeof h_status, hipMemcpyDeviceToHost, st), "status");
+            hip_check(hipStreamSynchronize(st), "synchronize");
+            if (h_status[4]) return left("the opposite overlaps of the stored non-edges", h_status[4]);
+            kept *= 2;
+        } else {
+            hip_check(fno_gather_edges(d_non, d_idx, kept, d_edges + G + B, st), "gather");
+            hip_check(hipStreamSynchronize(st), "synchronize");
+        }
         d.release((void*)d_non);
         d.release(d_adj);
         d.release(d_keep);
@@ -198,8 +209,6 @@ bool fno1_walk_on_device(const FnoWalkHost& h, const std::function<char*(uint64_
     if (E == 0) return false;
     w.edges = d_edges;
     w.n_edges = E;
-    w.nodes = upload((hc_fno_read*)nullptr, h.nodes, h.n_nodes, "copy of the vertices");
-    w.n_nodes = h.n_nodes;
     w.srs = upload((hc_fno_read*)nullptr, h.srs, h.n_srs, "copy of the super-reads");
     w.n_srs = h.n_srs;
     {  // nodes_to_SR: (vertex, super-read) per clique member, a stable sort by vertex, the offsets

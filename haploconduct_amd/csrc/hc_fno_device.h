@@ -50,6 +50,9 @@ hipError_t fno_adj_offsets(const hc_fno_edge* ge, uint64_t G, uint64_t n_nodes, 
 hipError_t fno_nonedge_filter(const hc_fno_edge* nonedges, uint64_t n, const hc_fno_edge* ge, const uint64_t* off, uint64_t n_nodes, uint8_t* keep,
                               unsigned long long* counters, hipStream_t s);
 hipError_t fno_gather_edges(const hc_fno_edge* in, const uint32_t* idx, uint64_t n, hc_fno_edge* out, hipStream_t s);
+// --add_duplicates: out[2 i] = in[idx[i]], out[2 i + 1] = its opposite (fno_mirror_nonedge); a record the host form has to report sets the status
+hipError_t fno_gather_mirrored(const hc_fno_edge* in, const uint32_t* idx, uint64_t n, const hc_fno_read* nodes, uint64_t half, hc_fno_edge* out,
+                               unsigned long long* counters, hipStream_t s);
 hipError_t fno_clique_pairs(const uint64_t* clique_nodes, const uint64_t* clique_off, uint64_t n_srs, uint64_t total, uint64_t n_nodes, uint64_t* key,
                             uint32_t* sr, unsigned long long* counters, hipStream_t s);
 hipError_t fno_offsets(const uint64_t* sorted, uint64_t n, uint64_t n_nodes, uint64_t* off, hipStream_t s);

@@ -40,6 +40,63 @@ bool fno_lines_on_device(const FnoItem* items, uint64_t n, bool no_inclusions, c
 // vertex — anything else makes the call return false), branching_edges, the stored non-edges (ALL of them when use_nonedges: which
 // pass :702 is decided on the device against adj_out), the inclusion-induced edges (the host's: few); the cliques nodes_to_SR is
 // made of (:893-906); every super-read's subreads sorted by node.
+#if defined(__HIPCC__)
+#define HC_FNO_HD __host__ __device__
+#else
+#define HC_FNO_HD
+#endif
+// --add_duplicates (program_settings.add_duplicates; HC_FNO_ADD_DUPLICATES): the graph has a vertex per read AND strand — vertex r for
+// read r as it is, r + half for its reverse complement (src/ViralQuasispecies.cpp:246-270) — and reconsiderNonedgeOverlaps adds every
+// stored non-edge that passes :702 a second time, seen from the other strand (src/FindNextOverlaps.cpp:699-793).  `e` is the line's
+// own edge (vertices by orientation, :672-675), r1 / r2 its two reads; *o receives the opposite edge.  The reference computes the
+// positions as `size_t - int - size_t` assigned to an int: exact arithmetic modulo 2^32.
+// Returns 0; 1 where the reference's assert at :755 fires (two paired reads, ord neither "1" nor "2"); 2 when a vertex does not lie
+// on the strand the line's orientation names (not a record reconsiderNonedgeOverlaps could have built).
+HC_FNO_HD inline int fno_mirror_nonedge(const hc_fno_edge& e, const hc_fno_read& r1, const hc_fno_read& r2, uint64_t half, hc_fno_edge* o) {
+    if ((e.v1 < half) != (e.ori1 != 0) || (e.v2 < half) != (e.ori2 != 0)) return 2;
+    const uint64_t w1 = e.v1 < half ? e.v1 + half : e.v1 - half;  // get_vertex_id(!ori1), :700-701
+    const uint64_t w2 = e.v2 < half ? e.v2 + half : e.v2 - half;
+    const uint32_t p1 = (uint32_t)e.pos1, p2 = (uint32_t)e.pos2;
+    uint32_t q1, q2 = 0;
+    bool both_paired = false;
+    if (!r1.paired && !r2.paired) {  // S-S, :702-717
+        q1 = r1.len1 - p1 - r2.len1;
+    } else if (r1.paired && !r2.paired) {  // P-S, :718-735
+        q1 = r1.len2 + p2 - r2.len1;
+        q2 = r2.len1 + p1 - r1.len1;
+    } else if (!r1.paired && r2.paired) {  // S-P, :736-753
+        q1 = r1.len1 - p2 - r2.len2;
+        q2 = r1.len1 - p1 - r2.len1;
+    } else {  // P-P, :754-792
+        if (e.ord == '1') q1 = r1.len2 - p2 - r2.len2;
+        else if (e.ord == '2') q1 = r1.len2 + p2 - r2.len2;
+        else return 1;
+        q2 = r1.len1 - p1 - r2.len1;
+        both_paired = true;
+    }
+    int32_t pos1 = (int32_t)q1, pos2 = (int32_t)q2;
+    const bool turned = pos1 < 0;  // the opposite overlap starts in read2: it leaves from read2's vertex
+    uint8_t ord = e.ord;
+    if (both_paired) {
+        if (pos2 < 0) {
+            pos2 = (int32_t)(0u - (uint32_t)pos2);
+            ord = turned ? '1' : '2';
+        } else {
+            ord = turned ? '2' : '1';
+        }
+    }
+    *o = e;
+    o->score = 0;
+    o->pos1 = turned ? (int32_t)(0u - (uint32_t)pos1) : pos1;
+    o->pos2 = pos2;
+    o->ord = ord;
+    o->v1 = turned ? w2 : w1;
+    o->v2 = turned ? w1 : w2;
+    o->ori1 = turned ? !e.ori2 : !e.ori1;
+    o->ori2 = turned ? !e.ori1 : !e.ori2;
+    return 0;
+}
+
 struct FnoEdgeSpan {
     const hc_fno_edge* p;
     uint64_t n;
@@ -56,6 +113,7 @@ struct FnoWalkHost {
     const hc_fno_subread* subreads;
     uint64_t new_read_count;
     bool resolve_orientations, no_inclusions;
+    uint64_t dup_half;  // --add_duplicates: n_nodes / 2 (every kept stored non-edge is followed by its opposite, fno_mirror_nonedge); else 0
 };
 // counters as fno_lines_on_device; *n_items: combinations kept (copied edges + first combination per pair); seconds[0..2] (may be
 // null): copies + walk + look-ups, deduce + sorts + unique + scan, text.  false: something the host form has to report or handle.

@@ -518,6 +518,20 @@ __global__ __launch_bounds__(kBlock) void fno_gather_edges_kernel(const hc_fno_e
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] = in[idx[i]];
 }
+__global__ __launch_bounds__(kBlock) void fno_gather_mirrored_kernel(const hc_fno_edge* __restrict__ in, const uint32_t* __restrict__ idx, uint64_t n,
+                                                                     const hc_fno_read* __restrict__ nodes, uint64_t half, hc_fno_edge* __restrict__ out,
+                                                                     unsigned long long* __restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const hc_fno_edge e = in[idx[i]];  // (its vertices are below 2 * half: the filter looked them up)
+    hc_fno_edge o;
+    if (fno_mirror_nonedge(e, nodes[e.v1], nodes[e.v2], half, &o) != 0) {
+        atomicOr(&counters[4], (unsigned long long)kFnoStatusRequire);
+        o = e;
+    }
+    out[2 * i] = e;
+    out[2 * i + 1] = o;
+}
 
 // nodes_to_SR (:893-906): (vertex, super-read) for every member of every clique, in super-read order — a stable sort by vertex
 // leaves every vertex's super-reads in the order the reference pushes them — then the offsets as for adj_out
@@ -730,6 +744,12 @@ hipError_t fno_nonedge_filter(const hc_fno_edge* nonedges, uint64_t n, const hc_
 hipError_t fno_gather_edges(const hc_fno_edge* in, const uint32_t* idx, uint64_t n, hc_fno_edge* out, hipStream_t s) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(fno_gather_edges_kernel, grid_for(n), dim3(kBlock), 0, s, in, idx, n, out);
+    return hipGetLastError();
+}
+hipError_t fno_gather_mirrored(const hc_fno_edge* in, const uint32_t* idx, uint64_t n, const hc_fno_read* nodes, uint64_t half, hc_fno_edge* out,
+                               unsigned long long* counters, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fno_gather_mirrored_kernel, grid_for(n), dim3(kBlock), 0, s, in, idx, n, nodes, half, out, counters);
     return hipGetLastError();
 }
 hipError_t fno_clique_pairs(const uint64_t* clique_nodes, const uint64_t* clique_off, uint64_t n_srs, uint64_t total, uint64_t n_nodes, uint64_t* key,

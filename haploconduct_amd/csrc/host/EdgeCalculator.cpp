@@ -59,6 +59,50 @@ static std::vector<int> device_list(const ProgramSettings& ps) {
 
 void EdgeCalculator::bind_here() const { bind_thread_to(m_node_cpus); }
 
+struct EdgeCalculator::Appender {
+    hc_ctx* ctx;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<const hc_admit_rec*, size_t>> q;
+    bool no_more = false;
+    FatalError error{0, ""};
+    Appender(hc_ctx* c, std::function<void()> on_start) : ctx(c) {
+        th = std::thread([this, on_start] {
+            on_start();
+            for (;;) {
+                std::pair<const hc_admit_rec*, size_t> job;
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return !q.empty() || no_more; });
+                    if (q.empty()) return;
+                    job = q.front();
+                    q.pop_front();
+                }
+                if (error.status) continue;  // drain
+                const int rc = hc_graph_append(ctx, job.first, job.second);
+                if (rc != HC_OK) error = FatalError{rc, std::string("hc_graph_append: ") + hc_strerror(rc) + " " + hc_last_error()};
+            }
+        });
+    }
+    void push(const hc_admit_rec* p, size_t n) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            q.emplace_back(p, n);
+        }
+        cv.notify_one();
+    }
+    void finish() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            no_more = true;
+        }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+    }
+    ~Appender() { finish(); }
+};
+
 EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_ptr<OverlapGraph> graph,
                                const ProgramSettings& ps)
     : program_settings(ps), fastq_storage(std::move(fastq)), overlap_graph(std::move(graph)) {
@@ -366,8 +410,14 @@ void EdgeCalculator::consume_block(BlockOut& blk) {
     stats.nonedges_written += blk.nonedges;
     stats.ambiguous += blk.ambiguous;
     if (m_collect) {  // resolved once, after the last block; the device receives its copy now, behind the scoring of later blocks
-        if (m_device_resolve && !blk.admitted.empty()) check(hc_graph_append(m_ctx, blk.admitted.data(), blk.admitted.size()), "hc_graph_append");
+        // (the records stay where they are until the graph is resolved: m_admitted owns the buffer from here on)
+        const hc_admit_rec* recs = blk.admitted.data();
+        const size_t n_recs = blk.admitted.size();
         m_admitted.emplace_back(std::move(blk.admitted));
+        if (m_device_resolve && n_recs) {
+            if (m_appender) m_appender->push(recs, n_recs);
+            else check(hc_graph_append(m_ctx, recs, n_recs), "hc_graph_append");
+        }
         blk.admitted = std::vector<hc_admit_rec>();
     } else {
         // The second read of an edge is a random place in the graph's slot index and in the in-lists: ask for the
@@ -411,6 +461,20 @@ void EdgeCalculator::consume_block(BlockOut& blk) {
         fclose(fo);
     }
     stats.t_write += now_s() - t2;
+}
+
+void EdgeCalculator::start_appender() {
+    finish_appender(false);
+    if (getenv("HC_APPEND_INLINE")) return;  // experiment knob: the appends from the collectors' in-order half, as before
+    m_appender.reset(new Appender(m_ctx, [this] { bind_here(); }));
+}
+
+void EdgeCalculator::finish_appender(bool rethrow) {
+    if (!m_appender) return;
+    m_appender->finish();
+    const FatalError e = m_appender->error;
+    m_appender.reset();
+    if (rethrow && e.status) throw e;
 }
 
 // The serial half for the whole file on the device: hc_graph_resolve + hc_graph_fetch, then the
@@ -1272,6 +1336,11 @@ void EdgeCalculator::run_stage(bool then_sort) {
     for (const ReadInfo& x : m_read_info)
         if (x.vertex_set && x.vertex >= ((node_id_t)1 << 31)) m_device_resolve = false;
     if (m_device_resolve) check(hc_graph_begin(m_ctx), "hc_graph_begin");
+    struct AppenderGuard {  // (an exception on the way: the thread is joined before m_admitted goes)
+        EdgeCalculator* self;
+        ~AppenderGuard() { self->finish_appender(false); }
+    } appender_guard{this};
+    if (m_device_resolve) start_appender();
     std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
     std::vector<Overlap> rejected;
     // (closed by the clean-up thread: unmapping the 4 GB file with the worker threads alive takes 20 ms)
@@ -1290,6 +1359,7 @@ void EdgeCalculator::run_stage(bool then_sort) {
     ParseCounters pc;
     if (m_host_parse) score_host_parsed(parser, rejected, pc);
     else score_device_parsed(parser, rejected, pc);
+    finish_appender(true);
     stage_lap("all blocks scored and consumed");
     bool sorted_already = false;
     if (m_collect) {

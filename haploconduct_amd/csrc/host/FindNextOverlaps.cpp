@@ -289,6 +289,7 @@ private:
         bool before(const Combo& o) const { return edge != o.edge ? edge < o.edge : nth < o.nth; }
     };
     const hc_fno1_input& in_;
+    uint64_t dup_half_ = 0;  // --add_duplicates: n_nodes / 2, else 0
     unsigned threads_ = 1;
     std::vector<hc_fno_subread> sub_sorted_;  // subreads of every super-read, sorted by node within the super-read
     std::vector<uint64_t> n2s_off_;           // nodes_to_SR as CSR
@@ -324,6 +325,23 @@ private:
         if ((in_.n_graph_edges && !in_.graph_edges) || (in_.n_branching_edges && !in_.branching_edges) ||
             (in_.n_inclusion_groups && (!in_.inclusion_off || !in_.inclusion_edges)))
             throw FatalError{HC_ERR_ARG, "null array"};
+        if (in_.flags & HC_FNO_ADD_DUPLICATES) {  // a vertex per read and strand: r and r + n_nodes / 2 are one Read (src/ViralQuasispecies.cpp:246-270)
+            if (in_.n_nodes & 1) throw FatalError{HC_ERR_ARG, "HC_FNO_ADD_DUPLICATES: an even number of vertices (every read on both strands) is expected"};
+            dup_half_ = in_.n_nodes / 2;
+            for (uint64_t r = 0; r < dup_half_; ++r) {
+                const hc_fno_read &a = in_.nodes[r], &b = in_.nodes[r + dup_half_];
+                if (a.len1 != b.len1 || a.len2 != b.len2 || (a.paired != 0) != (b.paired != 0))
+                    throw FatalError{HC_ERR_ARG, "HC_FNO_ADD_DUPLICATES: vertices r and r + n_nodes / 2 must describe the same read (lengths, paired)"};
+            }
+            if (!(in_.flags & HC_FNO_OPTIMIZE) && in_.n_nonedges && in_.nonedges)  // :672-675: a line's vertices are taken by its orientations
+                parallel_chunks(in_.n_nonedges, threads_, [&](uint64_t b, uint64_t e, unsigned) {
+                    for (uint64_t i = b; i < e; ++i) {
+                        const hc_fno_edge& x = in_.nonedges[i];
+                        if ((x.v1 < dup_half_) != (x.ori1 != 0) || (x.v2 < dup_half_) != (x.ori2 != 0))
+                            throw FatalError{HC_ERR_ARG, "HC_FNO_ADD_DUPLICATES: a stored non-edge's vertex is not on the strand its orientation names"};
+                    }
+                });
+        }
     }
 
     void index_subreads() {
@@ -501,11 +519,27 @@ private:
             });
             std::vector<uint64_t> at(T + 1, 0);
             for (unsigned t = 0; t < T; ++t) at[t + 1] = at[t] + kept[t].size();
-            kept_nonedges_.resize(at[T]);
-            parallel_chunks(T, T, [&](uint64_t tb, uint64_t te, unsigned) {
-                for (uint64_t t = tb; t < te; ++t)
-                    for (size_t k = 0; k < kept[t].size(); ++k) kept_nonedges_[at[t] + k] = in_.nonedges[kept[t][k]];
-            });
+            if (dup_half_) {  // every kept line twice: itself, then the same overlap seen from the other strand (:699-793)
+                if (2 * at[T] + in_.n_graph_edges + in_.n_branching_edges >= 0xFFFFFFF0ull) throw FatalError{HC_ERR_ARG, "too many edges"};
+                kept_nonedges_.resize(2 * at[T]);
+                parallel_chunks(T, T, [&](uint64_t tb, uint64_t te, unsigned) {
+                    for (uint64_t t = tb; t < te; ++t)
+                        for (size_t k = 0; k < kept[t].size(); ++k) {
+                            const hc_fno_edge& e = in_.nonedges[kept[t][k]];
+                            hc_fno_edge& o = kept_nonedges_[2 * (at[t] + k) + 1];
+                            kept_nonedges_[2 * (at[t] + k)] = e;
+                            const int rc = hc::fno_mirror_nonedge(e, in_.nodes[e.v1], in_.nodes[e.v2], dup_half_, &o);
+                            if (rc == 2) throw FatalError{HC_ERR_ARG, "HC_FNO_ADD_DUPLICATES: a stored non-edge's vertex is not on the strand its orientation names"};
+                            if (rc) ref_abort("overlap.get_ord() == \"2\" (two paired reads, --add_duplicates)");
+                        }
+                });
+            } else {
+                kept_nonedges_.resize(at[T]);
+                parallel_chunks(T, T, [&](uint64_t tb, uint64_t te, unsigned) {
+                    for (uint64_t t = tb; t < te; ++t)
+                        for (size_t k = 0; k < kept[t].size(); ++k) kept_nonedges_[at[t] + k] = in_.nonedges[kept[t][k]];
+                });
+            }
             work_[2] = {kept_nonedges_.data(), kept_nonedges_.size()};
         }
         lap("stored non-edges");
@@ -838,6 +872,7 @@ private:
         h.new_read_count = in_.new_read_count;
         h.resolve_orientations = (in_.flags & HC_FNO_RESOLVE_ORIENTATIONS) != 0;
         h.no_inclusions = (in_.flags & HC_FNO_NO_INCLUSIONS) != 0;
+        h.dup_half = use_nonedges ? dup_half_ : 0;
         uint64_t counters[5] = {0, 0, 0, 0, 0}, n_items = 0;
         double seconds[3] = {0, 0, 0};
         auto text_of = [&](uint64_t bytes) { return sized_text(out, bytes); };
@@ -1250,11 +1285,8 @@ int guarded_fno(const char* where, F&& f) {
 
 extern "C" {
 
-// (--add_duplicates and flags this build does not know: refused by name, hcfno.h)
+// (flags this build does not know: refused, hcfno.h)
 static int refuse_unbuilt_flags(const char* who, uint32_t flags) {
-    if (flags & HC_FNO_ADD_DUPLICATES)
-        return hc::set_last_error(HC_ERR_ARG, std::string(who) + ": HC_FNO_ADD_DUPLICATES (--add_duplicates) is not built: the reference's branches "
-                                              "src/FindNextOverlaps.cpp:672-675,699-793 have no counterpart here; no workflow sets the flag");
     if (flags & ~HC_FNO_KNOWN_FLAGS) return hc::set_last_error(HC_ERR_ARG, std::string(who) + ": unknown bit in flags");
     return HC_OK;
 }

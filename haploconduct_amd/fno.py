@@ -25,7 +25,7 @@ assert FNO_READ_DTYPE.itemsize == 24 and FNO_EDGE_DTYPE.itemsize == 48
 assert FNO_SUBREAD_DTYPE.itemsize == 24 and FNO_ORIGINAL_DTYPE.itemsize == 24
 
 RESOLVE_ORIENTATIONS, NO_INCLUSIONS, OPTIMIZE = 1, 2, 4
-ADD_DUPLICATES = 8  # not built: hc_fno1_run / hc_fno3_run refuse it by name (include/hcfno.h)
+ADD_DUPLICATES = 8  # program_settings.add_duplicates: a vertex per read and strand (include/hcfno.h)
 
 _vp = C.c_void_p
 

@@ -4,7 +4,8 @@
  *
  *   FNO=1  SRBuilder::findNextOverlaps   src/FindNextOverlaps.cpp:890-958
  *            updateOverlap :25-327, findCliqueIndex :331-347, computeOverlapData :351-565,
- *            reconsiderEdgeOverlaps :605-631, reconsiderNonedgeOverlaps :635-813 (the checkEdge filter :702),
+ *            reconsiderEdgeOverlaps :605-631, reconsiderNonedgeOverlaps :635-813 (the checkEdge filter :702, the
+ *            opposite overlaps of --add_duplicates :699-793),
  *            findInclusionOverlaps :816-887
  *   FNO=3  SRBuilder::findNextOverlaps3  src/FindNextOverlaps3.cpp:20-88, nodeDictApproach :90-173,
  *            deduceOverlap :176-406
@@ -69,15 +70,19 @@ typedef struct hc_fno_original {
 #define HC_FNO_RESOLVE_ORIENTATIONS 0x1u /* program_settings.resolve_orientations */
 #define HC_FNO_NO_INCLUSIONS        0x2u /* program_settings.no_inclusions */
 #define HC_FNO_OPTIMIZE             0x4u /* program_settings.optimize: skip the stored non-edges (:914) */
-/* program_settings.add_duplicates: the reference's FNO=1 then takes a vertex per read AND strand and adds every stored non-edge a
- * second time, mirrored (src/FindNextOverlaps.cpp:672-675, 699-793).  NOT BUILT (no workflow of the reference sets the flag:
- * savage.py / polyte.py / pipeline_per_stage.py never pass --add_duplicates): hc_fno1_run and hc_fno3_run refuse an input that
- * carries this bit — or any bit they do not know — with HC_ERR_ARG and a message naming it, instead of computing something else. */
+/* program_settings.add_duplicates (src/FindNextOverlaps.cpp:672-675, 699-793): the overlap graph has a vertex per read AND strand —
+ * `nodes` then lists every read twice, vertex r as it is and vertex r + n_nodes / 2 as its reverse complement
+ * (src/ViralQuasispecies.cpp:246-270: same lengths and type, each with its own id / visited / orientation) — and
+ * reconsiderNonedgeOverlaps takes the vertices of a stored non-edge by the line's orientations (`nonedges[i].v1` = read1's vertex on
+ * strand ori1, likewise v2: anything else is HC_ERR_ARG) and, for every line that passes :702, adds the SAME overlap a second time as
+ * seen from the other strand (positions from the read lengths, :703-792).  hc_fno1_run builds that second edge itself: `nonedges`
+ * stays one record per line.  FNO=3 never reads the setting: hc_fno3_run accepts the bit and ignores it.
+ * Bits nobody defined are refused with HC_ERR_ARG. */
 #define HC_FNO_ADD_DUPLICATES       0x8u
-#define HC_FNO_KNOWN_FLAGS          (HC_FNO_RESOLVE_ORIENTATIONS | HC_FNO_NO_INCLUSIONS | HC_FNO_OPTIMIZE)
+#define HC_FNO_KNOWN_FLAGS          (HC_FNO_RESOLVE_ORIENTATIONS | HC_FNO_NO_INCLUSIONS | HC_FNO_OPTIMIZE | HC_FNO_ADD_DUPLICATES)
 
 typedef struct hc_fno1_input {
-    /* vertices of the overlap graph, index = vertex id */
+    /* vertices of the overlap graph, index = vertex id (HC_FNO_ADD_DUPLICATES: 2 x reads, see above) */
     const hc_fno_read* nodes;
     uint64_t n_nodes;
     /* super-reads: single_SR_vec followed by paired_SR_vec (:893-906) */

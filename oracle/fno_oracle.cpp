@@ -13,9 +13,10 @@
 // processOverlaps, reconsiderEdgeOverlaps, findInclusionOverlaps, findNextOverlaps), OverlapGraph.cpp:233-259 (checkEdge)
 // and FindNextOverlaps3.cpp:20-406 (the whole of FNO=3).  This file is checked against it on the committed vectors
 // tests/golden/fno/*.json: whole findNextOverlaps() and findNextOverlaps3() runs (the files they write), updateOverlap
-// sequences, computeOverlapData and deduceOverlap calls.  The one part without a reference execution is
-// reconsiderNonedgeOverlaps (FindNextOverlaps.cpp:635-813: boost::trim_if): reading the stored non-edges and the
-// checkEdge filter in front of them (:702) are restated here — "parity unpinned" for that branch only.
+// sequences, computeOverlapData and deduceOverlap calls.  reconsiderNonedgeOverlaps (FindNextOverlaps.cpp:635-813) is in the
+// probe as well, around its one Boost call (boost::trim_if at :652, replaced by a build-owned statement): the stored non-edges,
+// the checkEdge filter in front of them (:702) and the opposite overlaps of --add_duplicates (:699-793) are pinned by
+// fno1_run_nonedges.json and fno1_run_add_duplicates.json.
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -389,15 +390,72 @@ struct Fno1 {
         // reconsiderEdgeOverlaps :605-631
         for (uint64_t i = 0; i < in->n_graph_edges; ++i) update_overlap(ed_of(in->graph_edges[i]));
         for (uint64_t i = 0; i < in->n_branching_edges; ++i) update_overlap(ed_of(in->branching_edges[i]));
-        // reconsiderNonedgeOverlaps :635-813 (without --add_duplicates)
+        // reconsiderNonedgeOverlaps :635-813.  With --add_duplicates the graph has a vertex per read and strand (vertex r: read r,
+        // vertex r + n_nodes / 2: its reverse complement, src/ViralQuasispecies.cpp:246-270), the line's vertices are taken by its
+        // orientations (:672-675) and every line that passes :702 is followed by the same overlap seen from the other strand (:699-793).
         if (!(in->flags & HC_FNO_OPTIMIZE)) {
+            const bool dup = (in->flags & HC_FNO_ADD_DUPLICATES) != 0;
+            const unsigned long half = in->n_nodes / 2;
+            if (dup) {
+                if (in->n_nodes % 2) throw RefAbort{"input contract: --add_duplicates needs every read on both strands"};
+                for (unsigned long r = 0; r < half; ++r)
+                    if (nodes[r].len1 != nodes[r + half].len1 || nodes[r].len2 != nodes[r + half].len2 || nodes[r].paired != nodes[r + half].paired)
+                        throw RefAbort{"input contract: vertices r and r + n_nodes / 2 are one read"};
+            }
+            auto other_strand = [&](unsigned long v) { return v < half ? v + half : v - half; };  // Read::get_vertex_id(!ori)
             for (uint64_t i = 0; i < in->n_nonedges; ++i) {
                 Ed e = ed_of(in->nonedges[i]);
                 e.score = 0;
                 REF_ASSERT(e.len1 > 0);   // Edge::set_len
                 REF_ASSERT(e.len2 >= 0);
+                if (dup && ((e.v1 < half) != e.ori1 || (e.v2 < half) != e.ori2))
+                    throw RefAbort{"input contract: under --add_duplicates a line's vertex is its read's vertex on the strand the orientation names (:672-675)"};
                 if (check_edge(e.v1, e.v2, true) > 0) continue;
                 update_overlap(e);
+                if (!dup) continue;
+                const Rd &read1 = nodes.at(e.v1), &read2 = nodes.at(e.v2);
+                const unsigned long v1 = other_strand(e.v1), v2 = other_strand(e.v2);  // :700-701
+                // the reference's `int pos = size() - get_pos() - size()`: size_t arithmetic, then the conversion to int
+                const size_t a1 = (size_t)read1.len1, a2 = (size_t)read1.len2, b1 = (size_t)read2.len1, b2 = (size_t)read2.len2;
+                const size_t p1 = (size_t)(long)e.pos1, p2 = (size_t)(long)e.pos2;
+                int pos1, pos2 = 0;
+                char ord = e.ord;
+                if (!read1.paired && !read2.paired) {  // S-S :702-717
+                    pos1 = (int)(a1 - p1 - b1);
+                } else if (read1.paired && !read2.paired) {  // P-S :718-735
+                    pos1 = (int)(a2 + p2 - b1);
+                    pos2 = (int)(b1 + p1 - a1);
+                } else if (!read1.paired && read2.paired) {  // S-P :736-753
+                    pos1 = (int)(a1 - p2 - b2);
+                    pos2 = (int)(a1 - p1 - b1);
+                } else {  // P-P :754-792
+                    if (e.ord == '1') {
+                        pos1 = (int)(a2 - p2 - b2);
+                    } else {
+                        REF_ASSERT(e.ord == '2');
+                        pos1 = (int)(a2 + p2 - b2);
+                    }
+                    pos2 = (int)(a1 - p1 - b1);
+                    if (pos1 < 0) {
+                        if (pos2 < 0) {
+                            pos2 = -pos2;
+                            ord = '1';
+                        } else {
+                            ord = '2';
+                        }
+                    } else {
+                        if (pos2 < 0) {
+                            pos2 = -pos2;
+                            ord = '2';
+                        } else {
+                            ord = '1';
+                        }
+                    }
+                }
+                Ed opp;
+                if (pos1 < 0) opp = Ed{v2, v1, 0.0, -pos1, pos2, e.len1, e.len2, e.perc, ord, !e.ori2, !e.ori1};
+                else opp = Ed{v1, v2, 0.0, pos1, pos2, e.len1, e.len2, e.perc, ord, !e.ori1, !e.ori2};
+                update_overlap(opp);
             }
         }
         // findInclusionOverlaps :816-883

@@ -92,10 +92,15 @@ def random_edges(rng, nodes, n, score=None, perc100=0.1):
 
 
 def fno1_scenario(seed, n_nodes=40, n_srs=14, n_edges=120, paired_frac=0.4, flags=F.RESOLVE_ORIENTATIONS, with_extras=False,
-                  trimmed_frac=0.3, n_threads=0):
-    """A random but well-formed FNO=1 input: every precondition the reference asserts holds."""
+                  trimmed_frac=0.3, n_threads=0, dup=False):
+    """A random but well-formed FNO=1 input: every precondition the reference asserts holds.  dup: the vertices of --add_duplicates —
+    n_nodes / 2 reads, vertex r and vertex r + n_nodes / 2 the two strands of read r (same lengths and type); the stored non-edges of
+    such a scenario come from dup_nonedges below."""
     rng = np.random.default_rng(seed)
     paired = rng.random(n_nodes) < paired_frac
+    if dup:
+        assert n_nodes % 2 == 0
+        paired[n_nodes // 2:] = paired[:n_nodes // 2]
     cliques, sr_paired = [], []
     for _ in range(n_srs):
         p = bool(rng.random() < paired_frac)
@@ -117,6 +122,9 @@ def fno1_scenario(seed, n_nodes=40, n_srs=14, n_edges=120, paired_frac=0.4, flag
         if not visited[u]:
             nodes[u]["id"] = next_id
             next_id += 1
+    if dup:
+        for f in ("len1", "len2"):
+            nodes[f][n_nodes // 2:] = nodes[f][:n_nodes // 2]
     srs = np.zeros(n_srs, F.FNO_READ_DTYPE)
     subreads = []
     for i in range(n_srs):
@@ -148,6 +156,37 @@ def fno1_scenario(seed, n_nodes=40, n_srs=14, n_edges=120, paired_frac=0.4, flag
             groups.append(np.array(star, F.FNO_EDGE_DTYPE))
         kw["inclusion_groups"] = groups
     return F.Fno1Input(nodes, srs, cliques, subreads, graph_edges, new_read_count=next_id, flags=flags, n_threads=n_threads, **kw)
+
+
+def dup_nonedges(rng, inp, n, behind_edge_frac=0.33):
+    """Stored non-edges of an --add_duplicates scenario as reconsiderNonedgeOverlaps builds them (src/FindNextOverlaps.cpp:672-675): one
+    record per line of nonedge_overlaps.txt, each vertex the read's vertex on the strand the line's orientation names; about a third of
+    them between vertices the graph already joins (checkEdge drops the line AND its opposite).  Returns (records, lines): the lines name
+    the reads by their number r < n_nodes / 2."""
+    half = len(inp.nodes) // 2
+    ne = random_edges(rng, inp.nodes, n, score=0.0)
+    k = int(len(ne) * behind_edge_frac)
+    if k and len(inp.graph_edges):
+        pick = inp.graph_edges[rng.integers(0, len(inp.graph_edges), k)]
+        flip = rng.random(k) < 0.5
+        ne["v1"][:k] = np.where(flip, pick["v2"], pick["v1"])
+        ne["v2"][:k] = np.where(flip, pick["v1"], pick["v2"])
+    ne = ne[(ne["v1"] % half) != (ne["v2"] % half)]
+    ne = ne[rng.permutation(len(ne))]
+    ne["ori1"] = ne["v1"] < half
+    ne["ori2"] = ne["v2"] < half
+    p1, p2 = inp.nodes["paired"][ne["v1"].astype(int)] != 0, inp.nodes["paired"][ne["v2"].astype(int)] != 0
+    ne["ord"] = np.where(p1 & p2, np.where(rng.random(len(ne)) < 0.5, ord("1"), ord("2")), ord("-"))  # Overlap's constructor checks ord against the types
+    ne["pos2"] = np.where(p1 | p2, ne["pos2"], 0)
+    ne["len1"] = np.maximum(ne["len1"], 1)  # Edge::set_len asserts len1 > 0
+    ne["len2"] = np.where(p1 | p2, ne["len2"], 0)
+    lines = []
+    for e in ne:
+        t1 = "p" if inp.nodes[int(e["v1"])]["paired"] else "s"
+        t2 = "p" if inp.nodes[int(e["v2"])]["paired"] else "s"
+        lines.append("\t".join(str(x) for x in [int(e["v1"]) % half, int(e["v2"]) % half, int(e["pos1"]), int(e["pos2"]), chr(int(e["ord"])),
+                                                "+" if e["ori1"] else "-", "+" if e["ori2"] else "-", int(e["perc"]), 0, int(e["len1"]), int(e["len2"]), t1, t2]))
+    return ne, lines
 
 
 def fno3_scenario(seed, n_single=12, n_paired=8, n_trivial=10, n_originals=60, flags=0, n_threads=0):

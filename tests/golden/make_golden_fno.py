@@ -150,6 +150,41 @@ def main():
                          "(findNextOverlaps with reconsiderNonedgeOverlaps, optimize = false; reads named by vertex number in nonedge_overlaps.txt)",
                "cases": runs_ne}, open(os.path.join(OUT, "fno1_run_nonedges.json"), "w"), separators=(",", ":"))
 
+    # ---- whole findNextOverlaps() runs under --add_duplicates (program_settings.add_duplicates = true): a vertex per read and strand,
+    # the stored non-edges' vertices by orientation (:672-675) and, behind every line that passes checkEdge, the same overlap seen from
+    # the other strand (:699-793, all four type combinations, both signs of the new position).
+    runs_dup = []
+    for seed in range(10):
+        flags = [F.RESOLVE_ORIENTATIONS, F.RESOLVE_ORIENTATIONS | F.NO_INCLUSIONS, 0][seed % 3] | F.ADD_DUPLICATES
+        inp = T.fno1_scenario(2700 + seed, n_nodes=48, n_srs=13, n_edges=100, paired_frac=[0.0, 0.4, 1.0, 0.5, 0.3][seed % 5], flags=flags,
+                              with_extras=True, dup=True)
+        rng = np.random.default_rng(1900 + seed)
+        ne, lines = T.dup_nonedges(rng, inp, 90)
+        inp.nonedges = ne
+        inp.edge_threshold = [0.97, 0.0, 1.0][seed % 3]
+        s = inp.struct()
+        text, n, nl = _vp(), C.c_uint64(), C.c_uint64()
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "nonedge_overlaps.txt"), "w").write("\n".join(lines) + "\n")
+            ref.frag_fno1_run(C.byref(s), d.encode(), C.byref(text), C.byref(n), C.byref(nl))
+        got = C.string_at(text, n.value).decode()
+        ref.frag_fno_free(text)
+        ecols = ["v1", "v2", "score", "pos1", "pos2", "len1", "len2", "perc", "ord", "ori1", "ori2"]
+        runs_dup.append({
+            "flags": flags, "new_read_count": int(inp.new_read_count), "edge_threshold": inp.edge_threshold,
+            "nodes": rec_list(inp.nodes[["id", "len1", "len2", "paired", "visited", "orientation"]]),
+            "srs": rec_list(inp.srs[["id", "len1", "len2", "paired"]]),
+            "clique_off": inp.clique_off.tolist(), "clique_nodes": inp.clique_nodes.tolist(),
+            "subread_off": inp.subread_off.tolist(), "subreads": rec_list(inp.subreads),
+            "graph_edges": rec_list(inp.graph_edges[ecols]), "branching_edges": rec_list(inp.branching_edges[ecols]),
+            "inclusion_off": inp.inclusion_off.tolist(), "inclusion_edges": rec_list(inp.inclusion_edges[ecols]),
+            "nonedge_lines": lines, "text": got, "n_lines": int(nl.value),
+        })
+    json.dump({"source": "fragment probe of src/FindNextOverlaps.cpp:25-631,635-651,653-813,816-958 + src/OverlapGraph.cpp:233-259 "
+                         "(findNextOverlaps with reconsiderNonedgeOverlaps, add_duplicates = true, optimize = false; n_nodes / 2 reads, read r with "
+                         "vertices r and r + n_nodes / 2 as src/ViralQuasispecies.cpp:246-270 assigns them; reads named by r in nonedge_overlaps.txt)",
+               "cases": runs_dup}, open(os.path.join(OUT, "fno1_run_add_duplicates.json"), "w"), separators=(",", ":"))
+
     # ---- whole findNextOverlaps3() runs.  hc_fno3_input lists the originals of a super-read in the iteration order of
     # its std::unordered_map; the probe is given an insertion order and tells which iteration order results.
     ref.frag_fno3_run.argtypes = [C.POINTER(F.hc_fno3_input), C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

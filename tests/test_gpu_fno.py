@@ -40,6 +40,8 @@ def test_goldens_of_the_reference_through_the_device(olib, on_device):
     assert F.last_device_level == on_device
     host_tests.test_golden_whole_runs_with_stored_nonedges(olib)
     assert F.last_device_level == on_device
+    host_tests.test_golden_whole_runs_under_add_duplicates(olib)  # --add_duplicates: the opposite overlaps are the device's (level 2) too
+    assert F.last_device_level == on_device
     host_tests.test_fno1_sections_contribute(olib)
     host_tests.test_fno1_first_edge_wins_per_superread_pair(olib)
     host_tests.test_fno1_nonedge_behind_existing_edge_is_skipped(olib)
@@ -49,6 +51,35 @@ def test_goldens_of_the_reference_through_the_device(olib, on_device):
 def test_device_matches_oracle_on_random_scenarios(olib, on_device, seed):
     host_tests.test_fno1_product_matches_oracle(olib, seed)
     assert F.last_device_level == on_device
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_device_matches_oracle_under_add_duplicates(olib, on_device, seed):
+    host_tests.test_fno1_add_duplicates_product_matches_oracle(olib, seed)
+    assert F.last_device_level == on_device
+
+
+def test_add_duplicates_contract_through_the_device(olib, on_device):
+    host_tests.test_add_duplicates_contract(olib)
+
+
+def test_large_iteration_under_add_duplicates_device_equals_host():
+    """2 x 10^5 reads on both strands, 8 x 10^5 edges and 4 x 10^5 stored non-edges with their opposites: default routing picks the
+    device for the walk, HC_FNO=host the host threads; one file."""
+    inp = _big(400000, 90000, 800000, 5, F.RESOLVE_ORIENTATIONS | F.ADD_DUPLICATES, dup=True)
+    assert len(inp.nonedges) > 390000
+    os.environ["HC_FNO"] = "host"
+    try:
+        want, wc = F.find_next_overlaps(inp)
+        assert not F.last_on_device
+    finally:
+        os.environ.pop("HC_FNO", None)
+    got, gc = F.find_next_overlaps(inp)
+    assert F.last_device_level == 2
+    assert gc == wc and got == want
+    inp.flags = F.RESOLVE_ORIENTATIONS
+    other, oc = F.find_next_overlaps(inp)
+    assert oc["n_lines"] < wc["n_lines"], "the opposite overlaps add lines"
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -63,11 +94,11 @@ def test_stops_of_the_reference_are_reported_as_by_the_host_form(olib, on_device
     host_tests.test_fno1_aborts_where_the_reference_does(olib)
 
 
-def _big(n_nodes, n_srs, n_edges, seed, flags):
+def _big(n_nodes, n_srs, n_edges, seed, flags, dup=False):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fno_bench
-    inp = fno_bench.big_fno1(n_nodes, n_srs, n_edges, seed=seed)
+    inp = fno_bench.big_fno1(n_nodes, n_srs, n_edges, seed=seed, dup=dup)
     inp.flags = flags
     return inp
 

@@ -15,9 +15,13 @@ sys.path.insert(0, ROOT)
 from haploconduct_amd import fno as F  # noqa: E402
 
 
-def big_fno1(n_nodes, n_srs, n_edges, seed=1):
+def big_fno1(n_nodes, n_srs, n_edges, seed=1, dup=False):
+    """dup: the vertices of --add_duplicates (vertex r and r + n_nodes / 2 are the two strands of read r; the stored non-edges carry
+    the orientation of the strand their vertices lie on); the caller sets F.ADD_DUPLICATES in flags."""
     rng = np.random.default_rng(seed)
     paired = rng.random(n_nodes) < 0.4
+    if dup:
+        paired[n_nodes // 2:] = paired[:n_nodes // 2]
     k = 4
     base = rng.integers(0, n_nodes, size=n_srs)
     cl = (base[:, None] + np.arange(k)[None, :] * 7919) % n_nodes  # k distinct vertices per super-read
@@ -25,6 +29,9 @@ def big_fno1(n_nodes, n_srs, n_edges, seed=1):
     visited[cl.ravel()] = True
     nodes = np.zeros(n_nodes, F.FNO_READ_DTYPE)
     nodes["len1"], nodes["len2"] = rng.integers(100, 300, n_nodes), np.where(paired, rng.integers(100, 300, n_nodes), 0)
+    if dup:
+        for f in ("len1", "len2"):
+            nodes[f][n_nodes // 2:] = nodes[f][:n_nodes // 2]
     nodes["paired"], nodes["visited"], nodes["orientation"] = paired, visited, rng.integers(0, 2, n_nodes)
     nodes["id"] = np.where(visited, 0, np.cumsum(~visited) - 1)
     n_unvisited = int((~visited).sum())
@@ -57,6 +64,11 @@ def big_fno1(n_nodes, n_srs, n_edges, seed=1):
     inp.clique_off, inp.clique_nodes = (np.arange(n_srs + 1) * k).astype(np.uint64), cl.ravel().astype(np.uint64)
     inp.subread_off, inp.subreads = (np.arange(n_srs + 1) * k).astype(np.uint64), sub
     inp.graph_edges, inp.branching_edges, inp.nonedges = edges(n_edges, 0.99), edges(n_edges // 20, 1.0), edges(n_edges // 2, 0.0)
+    if dup:
+        ne, half = inp.nonedges, n_nodes // 2
+        ne = ne[(ne["v1"] % half) != (ne["v2"] % half)]
+        ne["ori1"], ne["ori2"] = ne["v1"] < half, ne["v2"] < half
+        inp.nonedges = ne
     inp.inclusion_off, inp.inclusion_edges, inp.n_inclusion_groups = np.zeros(1, np.uint64), np.zeros(0, F.FNO_EDGE_DTYPE), 0
     inp.new_read_count, inp.edge_threshold, inp.flags, inp.n_threads = n_unvisited + n_srs, 0.97, F.RESOLVE_ORIENTATIONS, 0
     return inp
