@@ -137,7 +137,7 @@ int hc_textblock_create(hc_ctx* c, uint64_t max_bytes, hc_textblock** out) {
     ok(hipHostMalloc((void**)&b->h_rows, RC * sizeof(hc_gather_row), hipHostMallocMapped));
     ok(hipHostMalloc((void**)&b->h_row_lines, RC * sizeof(hc_line_rec), hipHostMallocMapped));
     ok(hipHostMalloc((void**)&b->h_rejects, RC * sizeof(hc_text_reject), hipHostMallocMapped));
-    ok(hipHostMalloc((void**)&b->h_counters, hc::kTextCounters * sizeof(unsigned long long), hipHostMallocDefault));
+    ok(hipHostMalloc((void**)&b->h_counters, hc::kTextCounters * sizeof(unsigned long long), hipHostMallocMapped));  // the last launch of a block writes them
     if (e != hipSuccess) {
         hc_textblock_destroy(b);
         return fail(HC_ERR_HIP, std::string("hc_textblock_create: ") + hipGetErrorString(e));
@@ -241,9 +241,12 @@ static int textblock_device_half(hc_textblock* b) {
     if (rc) return rc;
     HC_HIP(hc::launch_kept_rows(b->d_out, b->max_lines, b->d_counters + hc::kTextLines, b->sub_base_index, b->d_kept_tiles,
                                 b->d_kept_tiles + (b->max_lines / 1024 + 2), b->d_rows, b->row_cap, b->d_counters + hc::kTextRows, b->d_lines,
-                                b->d_row_lines, s));
-    HC_HIP(hc::launch_flush_rows(b->d_rows, d_rows, b->d_counters + hc::kTextRows, b->row_cap, sizeof(hc_gather_row), c->n_cu, s));
-    HC_HIP(hc::launch_flush_rows(b->d_row_lines, d_row_lines, b->d_counters + hc::kTextRows, b->row_cap, sizeof(hc_line_rec), c->n_cu, s));
+                                b->d_row_lines, s, b->d_tally, b->d_counters));
+    // both row arrays and the counters -> the block's page-locked words, one launch
+    void* d_counters_host = nullptr;
+    HC_HIP(hipHostGetDevicePointer(&d_counters_host, b->h_counters, 0));
+    HC_HIP(hc::launch_flush_text_rows(b->d_rows, d_rows, b->d_row_lines, d_row_lines, b->d_counters + hc::kTextRows, b->row_cap, b->d_counters,
+                                      (unsigned long long*)d_counters_host, c->n_cu, s));
     return HC_OK;
 }
 
@@ -291,9 +294,8 @@ static int textblock_regrow(hc_textblock* b, uint64_t need) {
     // what the device half adds to: the parse kernel's tallies and slots, the row count (lines / overflow stay)
     HC_HIP(hipMemsetAsync(b->d_counters, 0, hc::kTextLines * sizeof(unsigned long long), b->stream));
     HC_HIP(hipMemsetAsync(b->d_counters + hc::kTextRows, 0, (hc::kTextCounters - hc::kTextRows) * sizeof(unsigned long long), b->stream));
-    int rc = textblock_device_half(b);
+    int rc = textblock_device_half(b);  // (its last launch leaves the counters in h_counters)
     if (rc) return rc;
-    HC_HIP(hipMemcpyAsync(b->h_counters, b->d_counters, hc::kTextCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
     HC_HIP(hipStreamSynchronize(b->stream));
     b->n_regrown++;
     (void)c;
@@ -324,12 +326,11 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
     if (n_bytes > b->max_bytes) return fail(HC_ERR_ARG, "hc_textblock_submit: more text than the block was created for");
     HC_HIP(hipSetDevice(c->device));
     hipStream_t s = b->stream;
-    HC_HIP(hipMemsetAsync(b->d_counters, 0, hc::kTextCounters * sizeof(unsigned long long), s));
     unsigned long long* d_chain = nullptr;
     if (chain) HC_HIP(hipHostGetDevicePointer((void**)&d_chain, chain->h, 0));
     if (n_bytes) {
-        // the text as it is (page-locked or pageable: a file mapping goes to the device without a copy by the caller), and
-        // 64 zero bytes behind it: the 16-byte loads of the last tile read past the text, no stray newline there
+        // the text as it is (page-locked or pageable: a file mapping goes to the device without a copy by the caller).  The 16-byte
+        // pieces of the last tile reach past the text: the kernels that look for newlines ignore what lies there.
         // The blocks' copies take turns on TWO streams of the context and a block's own stream waits for its copy.  On the ten
         // blocks' own streams the runtime opened a further copy queue whenever a copy met others in flight: 7 - 8 ms inside
         // hipMemcpyAsync, five or six times during the first file of a process (HC_SUBMIT_TRACE) — C3's first construct_edges of a
@@ -342,23 +343,25 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
             HC_HIP(hipEventRecord(b->copied, cs));
             HC_HIP(hipStreamWaitEvent(s, b->copied, 0));
         }
-        HC_HIP(hipMemsetAsync(b->d_text + n_bytes, 0, 64, s));
-        HC_HIP(hc::launch_text_lines(b->d_text, n_bytes, b->d_tile_cnt, b->d_tile_off, b->max_lines, b->d_line_start, b->d_counters, s));
+        HC_HIP(hc::launch_text_count(b->d_text, n_bytes, b->d_tile_cnt, s));
     }
-    if (chain) {  // entry k is written by block k - 1's sequence (another stream, maybe another device)
-        if (prev) HC_HIP(hipStreamWaitEvent(s, prev->lines_known, 0));
-        HC_HIP(hc::launch_text_chain(d_chain + k, b->d_counters, d_chain + k + 1, s));
-        HC_HIP(hipEventRecord(b->lines_known, s));
-    }
+    // The one-workgroup scan zeroes the block's counters, sets the line count and hands it down the chain: entry k is written by
+    // block k - 1's scan (another stream, maybe another device), entry k + 1 by this one.  An empty block runs it too (over no tiles).
+    if (chain && prev) HC_HIP(hipStreamWaitEvent(s, prev->lines_known, 0));
+    HC_HIP(hc::launch_text_scan(b->d_text, n_bytes, b->d_tile_cnt, b->d_tile_off, b->max_lines, b->d_line_start, b->d_counters,
+                                chain ? d_chain + k : nullptr, chain ? d_chain + k + 1 : nullptr, s));
+    if (chain) HC_HIP(hipEventRecord(b->lines_known, s));
+    if (n_bytes) HC_HIP(hc::launch_text_line_starts(b->d_text, n_bytes, b->d_tile_off, b->max_lines, b->d_line_start, s));
     b->sub_bytes = n_bytes;
     b->sub_first_line = first_line_no;
     b->sub_first_line_ptr = chain ? d_chain + k : nullptr;
     b->sub_base_index = base_index;
     if (n_bytes) {
-        int rc = textblock_device_half(b);
+        int rc = textblock_device_half(b);  // (its last launch leaves the counters in h_counters)
         if (rc) return rc;
+    } else {
+        HC_HIP(hipMemcpyAsync(b->h_counters, b->d_counters, hc::kTextCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     }
-    HC_HIP(hipMemcpyAsync(b->h_counters, b->d_counters, hc::kTextCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HC_HIP(hipEventRecord(b->done, s));
     b->in_flight = true;
     return HC_OK;

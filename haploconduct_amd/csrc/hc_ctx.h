@@ -46,7 +46,11 @@ hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, ui
                                   unsigned long long* totals, hipStream_t stream);
 hipError_t launch_kept_rows(const hc_result_rec* res, uint64_t n, const unsigned long long* n_dev, uint64_t base_index, uint32_t* tile_cnt,
                             uint32_t* tile_off, hc_gather_row* rows, uint64_t cap, unsigned long long* count, const hc_line_rec* lines_in,
-                            hc_line_rec* lines_out, hipStream_t stream);
+                            hc_line_rec* lines_out, hipStream_t stream, const uint32_t* text_tally = nullptr,
+                            unsigned long long* text_counters = nullptr);  // (a text block: the parse kernel's tallies are summed on the way)
+hipError_t launch_flush_text_rows(const void* rows, void* rows_mapped, const void* lines, void* lines_mapped, const unsigned long long* count,
+                                  uint64_t cap, const unsigned long long* counters, unsigned long long* counters_mapped, uint32_t n_cu,
+                                  hipStream_t stream);
 hipError_t launch_flush_rows(const void* src, void* dst_mapped, const unsigned long long* count, uint64_t cap, uint32_t row_bytes, uint32_t n_cu,
                              hipStream_t stream);
 

@@ -42,10 +42,14 @@ enum {
     kTextCounters = 16
 };
 
-hipError_t launch_text_lines(const char* text, uint64_t n_bytes, uint32_t* tile_cnt, uint32_t* tile_off, uint32_t max_lines,
-                             uint32_t* line_start, unsigned long long* counters, hipStream_t s);
-hipError_t launch_text_chain(const unsigned long long* lines_before, const unsigned long long* counters, unsigned long long* lines_before_next,
-                             hipStream_t s);
+// the line starts of a block in three launches: newlines per 4 KiB tile; the one-workgroup scan, which also ZEROES the block's
+// counters before it sets kTextLines / kTextOverflow and, with a chain, writes *lines_before_next = *lines_before + lines; the starts
+hipError_t launch_text_count(const char* text, uint64_t n_bytes, uint32_t* tile_cnt, hipStream_t s);
+hipError_t launch_text_scan(const char* text, uint64_t n_bytes, const uint32_t* tile_cnt, uint32_t* tile_off, uint32_t max_lines, uint32_t* line_start,
+                            unsigned long long* counters, const unsigned long long* lines_before, unsigned long long* lines_before_next,
+                            hipStream_t s);
+hipError_t launch_text_line_starts(const char* text, uint64_t n_bytes, const uint32_t* tile_off, uint32_t max_lines, uint32_t* line_start, hipStream_t s);
+// (counters[0..6] are the sums of the workgroups' tallies: launch_kept_rows_flushed adds them up)
 hipError_t launch_text_parse(const TextParams& prm, const char* text, const uint32_t* line_start, const IdTable& ids, hc_cand_rec* cands,
                              hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, uint32_t* tally /* [(max_lines + 255) / 256][8] */,
                              hipStream_t s);

@@ -25,19 +25,32 @@ __device__ __forceinline__ uint32_t newline_mask(uint32_t w) {
     return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
 }
 
-__device__ __forceinline__ uint4 load16(const char* text, uint64_t n_bytes, uint64_t at) {
-    // the buffer is padded to a multiple of 16 bytes; bytes at and beyond n_bytes are not newlines (the host zero-fills the pad)
-    (void)n_bytes;
-    return *(const uint4*)(text + at);
+// newline masks of the 16 bytes at `at` (< n_bytes).  The last piece of a block reaches past the text: what lies there — an earlier,
+// longer block's bytes — is not part of it and counts for nothing (the buffer has room for the read; until round 4 a memset of 64
+// bytes behind every block's text made sure instead: three fill kernels per block for an unaligned end).
+__device__ __forceinline__ void newline_masks16(const char* text, uint64_t n_bytes, uint64_t at, uint32_t m[4]) {
+    const uint4 v = *(const uint4*)(text + at);
+    m[0] = newline_mask(v.x);
+    m[1] = newline_mask(v.y);
+    m[2] = newline_mask(v.z);
+    m[3] = newline_mask(v.w);
+    if (at + 16 > n_bytes) {
+        const uint32_t valid = (uint32_t)(n_bytes - at);  // 1 .. 15 bytes of text in this piece
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) {
+            const uint32_t have = valid > 4u * w ? valid - 4u * w : 0u;  // bytes of word w that are text
+            if (have < 4u) m[w] &= have ? (1u << (8u * have)) - 1u : 0u;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void text_count_kernel(const char* __restrict__ text, uint64_t n_bytes, uint32_t* __restrict__ tile_cnt) {
     const uint64_t at = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
     uint32_t c = 0;
     if (at < n_bytes) {
-        const uint4 v = load16(text, n_bytes, at);
-        c = __builtin_popcount(newline_mask(v.x)) + __builtin_popcount(newline_mask(v.y)) + __builtin_popcount(newline_mask(v.z)) +
-            __builtin_popcount(newline_mask(v.w));
+        uint32_t m[4];
+        newline_masks16(text, n_bytes, at, m);
+        c = __builtin_popcount(m[0]) + __builtin_popcount(m[1]) + __builtin_popcount(m[2]) + __builtin_popcount(m[3]);
     }
     for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_down((int)c, o, 64);
     __shared__ uint32_t part[4];
@@ -46,13 +59,18 @@ __global__ __launch_bounds__(256) void text_count_kernel(const char* __restrict_
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-// tile_off[t] = newlines before tile t; tile_off[n_tiles] = all of them.  One workgroup of 1 024 lanes.
+// tile_off[t] = newlines before tile t; tile_off[n_tiles] = all of them.  One workgroup of 1 024 lanes.  It is the first kernel of
+// a block that touches the block's counters: it zeroes them (instead of a memset per block), and with a line chain it passes the
+// count on: *lines_before_next = *lines_before + this block's lines (line numbers across blocks without the host counting newlines).
 __global__ __launch_bounds__(1024) void text_scan_kernel(const char* __restrict__ text, uint64_t n_bytes, const uint32_t* __restrict__ tile_cnt,
                                                          uint32_t n_tiles, uint32_t max_lines, uint32_t* __restrict__ tile_off,
-                                                         uint32_t* __restrict__ line_start, unsigned long long* __restrict__ counters) {
+                                                         uint32_t* __restrict__ line_start, unsigned long long* __restrict__ counters,
+                                                         const unsigned long long* __restrict__ lines_before,
+                                                         unsigned long long* __restrict__ lines_before_next) {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
+    if (threadIdx.x < kTextCounters) counters[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t base = 0; base < n_tiles; base += 1024) {
         const uint32_t i = base + threadIdx.x;
@@ -79,6 +97,7 @@ __global__ __launch_bounds__(1024) void text_scan_kernel(const char* __restrict_
         counters[kTextLines] = n_lines;
         counters[kTextOverflow] = n_lines > max_lines ? 1 : 0;
         if (open_end && n_lines <= max_lines) line_start[n_lines] = (uint32_t)(n_bytes + 1);
+        if (lines_before_next) *lines_before_next = *lines_before + n_lines;
     }
 }
 
@@ -88,13 +107,7 @@ __global__ __launch_bounds__(256) void text_lines_kernel(const char* __restrict_
                                                          uint32_t max_lines, uint32_t* __restrict__ line_start) {
     const uint64_t at = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
     uint32_t m[4] = {0, 0, 0, 0};
-    if (at < n_bytes) {
-        const uint4 v = load16(text, n_bytes, at);
-        m[0] = newline_mask(v.x);
-        m[1] = newline_mask(v.y);
-        m[2] = newline_mask(v.z);
-        m[3] = newline_mask(v.w);
-    }
+    if (at < n_bytes) newline_masks16(text, n_bytes, at, m);
     const uint32_t c = __builtin_popcount(m[0]) + __builtin_popcount(m[1]) + __builtin_popcount(m[2]) + __builtin_popcount(m[3]);
     uint32_t incl = c;
     for (int o = 1; o < 64; o <<= 1) {
@@ -346,44 +359,25 @@ __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const c
     if (threadIdx.x < 7) tally[blockIdx.x * 8u + threadIdx.x] = wave_tally[0][threadIdx.x] + wave_tally[1][threadIdx.x] + wave_tally[2][threadIdx.x] + wave_tally[3][threadIdx.x];
 }
 
-// counters[0..6] += the workgroups' tallies (one workgroup; the parse kernel's workgroups that had lines)
-__global__ __launch_bounds__(256) void text_tally_kernel(const uint32_t* __restrict__ tally, unsigned long long* __restrict__ counters) {
-    if (counters[kTextOverflow]) return;
-    const uint32_t n_wg = (uint32_t)((counters[kTextLines] + 255u) / 256u);
-    __shared__ unsigned long long part[4][8];
-    unsigned long long sum[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t g = threadIdx.x; g < n_wg; g += 256u)
-#pragma unroll
-        for (int k = 0; k < 7; k++) sum[k] += tally[g * 8u + k];
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum[k] += (unsigned long long)__shfl_xor((long long)sum[k], o, 64);
-        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6][k] = sum[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 7) counters[threadIdx.x] += part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-hipError_t launch_text_lines(const char* text, uint64_t n_bytes, uint32_t* tile_cnt, uint32_t* tile_off, uint32_t max_lines,
-                             uint32_t* line_start, unsigned long long* counters, hipStream_t s) {
+hipError_t launch_text_count(const char* text, uint64_t n_bytes, uint32_t* tile_cnt, hipStream_t s) {
     const uint32_t n_tiles = (uint32_t)((n_bytes + 4095) / 4096);
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(text_count_kernel, dim3(n_tiles), dim3(256), 0, s, text, n_bytes, tile_cnt);
-    hipLaunchKernelGGL(text_scan_kernel, dim3(1), dim3(1024), 0, s, text, n_bytes, tile_cnt, n_tiles, max_lines, tile_off, line_start, counters);
-    hipLaunchKernelGGL(text_lines_kernel, dim3(n_tiles), dim3(256), 0, s, text, n_bytes, tile_off, max_lines, line_start);
     return hipGetLastError();
 }
-
-// Line numbers across blocks without the host counting newlines: lines_before_next = lines_before + this block's lines
-__global__ void text_chain_kernel(const unsigned long long* __restrict__ lines_before, const unsigned long long* __restrict__ counters,
-                                  unsigned long long* __restrict__ lines_before_next) {
-    *lines_before_next = *lines_before + counters[kTextLines];
+hipError_t launch_text_scan(const char* text, uint64_t n_bytes, const uint32_t* tile_cnt, uint32_t* tile_off, uint32_t max_lines, uint32_t* line_start,
+                            unsigned long long* counters, const unsigned long long* lines_before, unsigned long long* lines_before_next,
+                            hipStream_t s) {
+    const uint32_t n_tiles = (uint32_t)((n_bytes + 4095) / 4096);
+    hipLaunchKernelGGL(text_scan_kernel, dim3(1), dim3(1024), 0, s, text, n_bytes, tile_cnt, n_tiles, max_lines, tile_off, line_start, counters,
+                       lines_before, lines_before_next);
+    return hipGetLastError();
 }
-hipError_t launch_text_chain(const unsigned long long* lines_before, const unsigned long long* counters, unsigned long long* lines_before_next,
-                             hipStream_t s) {
-    hipLaunchKernelGGL(text_chain_kernel, dim3(1), dim3(1), 0, s, lines_before, counters, lines_before_next);
+hipError_t launch_text_line_starts(const char* text, uint64_t n_bytes, const uint32_t* tile_off, uint32_t max_lines, uint32_t* line_start, hipStream_t s) {
+    const uint32_t n_tiles = (uint32_t)((n_bytes + 4095) / 4096);
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(text_lines_kernel, dim3(n_tiles), dim3(256), 0, s, text, n_bytes, tile_off, max_lines, line_start);
     return hipGetLastError();
 }
 
@@ -392,8 +386,7 @@ hipError_t launch_text_parse(const TextParams& prm, const char* text, const uint
     if (prm.max_lines == 0) return hipSuccess;
     hipLaunchKernelGGL(text_parse_kernel, dim3((prm.max_lines + 255) / 256), dim3(256), 0, s, prm, text, line_start, ids, cands, lines, rejects,
                        counters, tally);
-    hipLaunchKernelGGL(text_tally_kernel, dim3(1), dim3(256), 0, s, tally, counters);
-    return hipGetLastError();
+    return hipGetLastError();  // (the workgroups' tallies are summed by the one-workgroup scan of launch_kept_rows_flushed)
 }
 
 }  // namespace hc

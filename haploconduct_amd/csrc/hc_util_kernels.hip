@@ -8,6 +8,7 @@
 #include "hc_device.h"
 #include "hc_prims.h"
 #include "hc_resolve.h"
+#include "hc_text.h"
 
 namespace hc {
 
@@ -155,10 +156,33 @@ __global__ __launch_bounds__(256) void kept_count_kernel(const hc_result_rec* __
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-// tile_off[t] = sum of tile_cnt[0..t); *total = the sum of all.  One workgroup.
+// tile_off[t] = sum of tile_cnt[0..t); *total = the sum of all.  One workgroup.  For a text block it also adds up what the parse
+// kernel's workgroups tallied (text_counters[0..6] += sum over the workgroups that had lines of tally[g][0..6]): a kernel of its own
+// until round 4, one more launch per block for seven sums.
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t* __restrict__ tile_cnt, uint32_t n_tiles, uint32_t* __restrict__ tile_off,
-                                                          unsigned long long* __restrict__ total) {
+                                                          unsigned long long* __restrict__ total, const uint32_t* __restrict__ tally,
+                                                          unsigned long long* __restrict__ text_counters) {
     __shared__ uint32_t wave_sum[16];
+    __shared__ unsigned long long tally_part[16][8];
+    if (tally && !text_counters[kTextOverflow]) {
+        const uint32_t n_wg = (uint32_t)((text_counters[kTextLines] + 255u) / 256u);
+        unsigned long long sum[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t g = threadIdx.x; g < n_wg; g += 1024u)
+#pragma unroll
+            for (int k = 0; k < 7; k++) sum[k] += tally[g * 8u + k];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum[k] += (unsigned long long)__shfl_xor((long long)sum[k], o, 64);
+            if ((threadIdx.x & 63u) == 0) tally_part[threadIdx.x >> 6][k] = sum[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            unsigned long long t = 0;
+            for (int w = 0; w < 16; w++) t += tally_part[w][threadIdx.x];
+            text_counters[threadIdx.x] += t;
+        }
+    }
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -236,11 +260,11 @@ __global__ __launch_bounds__(256) void kept_scatter_kernel(const hc_result_rec* 
 // tile_cnt / tile_off: scratch of (n + 1023) / 1024 + 1 entries each.
 hipError_t launch_kept_rows(const hc_result_rec* res, uint64_t n, const unsigned long long* n_dev, uint64_t base_index, uint32_t* tile_cnt,
                             uint32_t* tile_off, hc_gather_row* rows, uint64_t cap, unsigned long long* count, const hc_line_rec* lines_in,
-                            hc_line_rec* lines_out, hipStream_t stream) {
+                            hc_line_rec* lines_out, hipStream_t stream, const uint32_t* text_tally, unsigned long long* text_counters) {
     const uint32_t n_tiles = (uint32_t)((n + kKeptTile - 1) / kKeptTile);
     if (n_tiles == 0) return hipMemsetAsync(count, 0, sizeof(unsigned long long), stream);
     hipLaunchKernelGGL(kept_count_kernel, dim3(n_tiles), dim3(256), 0, stream, res, n, n_dev, tile_cnt);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, tile_cnt, n_tiles, tile_off, count);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, tile_cnt, n_tiles, tile_off, count, text_tally, text_counters);
     hipLaunchKernelGGL(kept_scatter_kernel, dim3(n_tiles), dim3(256), 0, stream, res, n, n_dev, tile_off, base_index, rows, cap, lines_in, lines_out);
     return hipGetLastError();
 }
@@ -261,6 +285,30 @@ hipError_t launch_flush_rows(const void* src, void* dst_mapped, const unsigned l
                              hipStream_t stream) {
     hipLaunchKernelGGL(flush_rows_kernel, dim3(n_cu), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst_mapped, count,
                        (unsigned long long)cap, row_bytes / 16u);
+    return hipGetLastError();
+}
+
+// A text block's two row arrays in one launch, and its counters with them: the first workgroup copies the 16 counters — final by
+// now — into the block's page-locked words (a hipMemcpyAsync of 128 bytes per block until round 4).
+__global__ __launch_bounds__(256) void flush_text_rows_kernel(const uint4* __restrict__ src_a, uint4* __restrict__ dst_a, uint32_t pieces_a,
+                                                              const uint4* __restrict__ src_b, uint4* __restrict__ dst_b, uint32_t pieces_b,
+                                                              const unsigned long long* __restrict__ count, unsigned long long cap,
+                                                              const unsigned long long* __restrict__ counters,
+                                                              unsigned long long* __restrict__ counters_host) {
+    unsigned long long k = *count;
+    k = k < cap ? k : cap;
+    const unsigned long long ka = k * pieces_a, kb = k * pieces_b, stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < ka; i += stride) dst_a[i] = src_a[i];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < kb; i += stride) dst_b[i] = src_b[i];
+    if (blockIdx.x == 0 && threadIdx.x < kTextCounters) counters_host[threadIdx.x] = counters[threadIdx.x];
+}
+
+hipError_t launch_flush_text_rows(const void* rows, void* rows_mapped, const void* lines, void* lines_mapped, const unsigned long long* count,
+                                  uint64_t cap, const unsigned long long* counters, unsigned long long* counters_mapped, uint32_t n_cu,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(flush_text_rows_kernel, dim3(n_cu), dim3(256), 0, stream, (const uint4*)rows, (uint4*)rows_mapped,
+                       (uint32_t)(sizeof(hc_gather_row) / 16u), (const uint4*)lines, (uint4*)lines_mapped, (uint32_t)(sizeof(hc_line_rec) / 16u), count,
+                       (unsigned long long)cap, counters, counters_mapped);
     return hipGetLastError();
 }
 
