@@ -333,7 +333,7 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
         // pieces of the last tile reach past the text: the kernels that look for newlines ignore what lies there.
         // The blocks' copies take turns on TWO streams of the context and a block's own stream waits for its copy.  On the ten
         // blocks' own streams the runtime opened a further copy queue whenever a copy met others in flight: 7 - 8 ms inside
-        // hipMemcpyAsync, five or six times during the first file of a process (HC_SUBMIT_TRACE) — C3's first construct_edges of a
+        // hipMemcpyAsync, five or six times during the first file of a process (a per-block trace of the submits, round 3) — C3's first construct_edges of a
         // process 0.18 - 0.20 s against 0.13 - 0.14 s with two; one stream alone does not keep the link busy (later files 0.13 - 0.17 s
         // against 0.12; a round-3 knob, gone: the measurement stands).
         {

@@ -372,7 +372,7 @@ void EdgeCalculator::finalize_block(const ParsedBatch& batch, const hc_gather_ro
             pc.admitted.push_back(a);
         }
     };
-    static const unsigned build_cap = getenv("HC_BUILD_THREADS") ? (unsigned)atoi(getenv("HC_BUILD_THREADS")) : 8u;  // experiment knob
+    constexpr unsigned build_cap = 8u;  // more threads per block bought nothing (a round-2 knob, gone)
     unsigned T = program_settings.n_threads > 1 ? std::min<unsigned>(program_settings.n_threads, std::max(1u, build_cap)) : 1;
     if (n_rows < 4096) T = 1;
     std::vector<Piece> pieces(T);
@@ -465,7 +465,6 @@ void EdgeCalculator::consume_block(BlockOut& blk) {
 
 void EdgeCalculator::start_appender() {
     finish_appender(false);
-    if (getenv("HC_APPEND_INLINE")) return;  // experiment knob: the appends from the collectors' in-order half, as before
     m_appender.reset(new Appender(m_ctx, [this] { bind_here(); }));
 }
 
@@ -775,7 +774,7 @@ void EdgeCalculator::finalize_text_block(const IdIndex& ids, const hc_text_row* 
             pc.admitted.push_back(a);
         }
     };
-    static const unsigned build_cap = getenv("HC_BUILD_THREADS") ? (unsigned)atoi(getenv("HC_BUILD_THREADS")) : 8u;  // experiment knob
+    constexpr unsigned build_cap = 8u;  // more threads per block bought nothing (a round-2 knob, gone)
     unsigned T = program_settings.n_threads > 1 ? std::min<unsigned>(program_settings.n_threads, std::max(1u, build_cap)) : 1;
     if (n_rows < 4096) T = 1;
     // several collectors call this side by side (threads = 1: the pool is one): a block nearly all of whose lines survive — overlaps
@@ -1027,7 +1026,6 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     std::mutex smu;
     std::condition_variable scv;
     bool no_more = false;
-    const bool submit_trace = getenv("HC_STAGE_TIMING") && getenv("HC_SUBMIT_TRACE");
     std::thread submitter([&] {
         bind_here();
         for (;;) {
@@ -1053,7 +1051,6 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                 }
                 const double dt = now_s() - t0;
                 tm_submit += dt;
-                if (submit_trace && p.k < 24) fprintf(stderr, "[hc stage] submit of block %llu: %.1f ms\n", (unsigned long long)p.k, dt * 1e3);
             }
             {
                 std::lock_guard<std::mutex> g(mu);

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The device's copy of a block's admitted records: queued to a thread of its own (default) against issued from the collectors' in-order
-# half (HC_APPEND_INLINE=1, the form until round 4).  C3 stage, four runs each, twice.  Writes gpurun_out/r04_appender.txt.
+# half (HC_APPEND_INLINE=1, the form until round 4; the knob lived from commit 'find-next-overlaps under --add_duplicates ...' until the
+# clean-up after this measurement: check that commit out to run the A side again).  C3 stage, four runs each, twice.  Writes gpurun_out/r04_appender.txt.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 O=gpurun_out
 mkdir -p $O
