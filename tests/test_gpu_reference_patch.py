@@ -104,7 +104,7 @@ def test_patched_construct_edges_on_a_file(patched, tmp_path):
     assert out["plain"] == out["patched"]
 
 
-def _stage(lib, name, mg, fs, pre, S, Q, ids, n_single, n_paired, fastq, ov_path, out_dir, cap, n_vertices):
+def _stage(lib, name, mg, fs, pre, S, Q, ids, n_single, n_paired, fastq, ov_path, out_dir, cap, n_vertices, max_overlaps=10 ** 8):
     vp = C.c_void_p
     fn = getattr(lib, name)
     fn.restype = C.c_int
@@ -118,7 +118,7 @@ def _stage(lib, name, mg, fs, pre, S, Q, ids, n_single, n_paired, fastq, ov_path
     text = vp()
     counters = (C.c_uint32 * 3)()
     F = (C.c_char_p * 3)(*[f.encode() for f in fastq])
-    rc = fn(C.byref(fs), pre, 10 ** 8, S, Q, ids.ctypes.data, n_single, n_paired, F, ov_path.encode(), out_dir.encode(), edges, cap, C.byref(n_edges),
+    rc = fn(C.byref(fs), pre, max_overlaps, S, Q, ids.ctypes.data, n_single, n_paired, F, ov_path.encode(), out_dir.encode(), edges, cap, C.byref(n_edges),
             in_off.ctypes.data, in_nodes.ctypes.data, incl.ctypes.data, C.byref(text), C.byref(nb), counters)
     assert rc == 0, f"{name} returned {rc}"
     n = int(n_edges.value)

@@ -145,6 +145,9 @@ def main():
                    "median_run": med, "runs": runs,
                    "outside_main_s": med["process_wall_s"] - med.get("main_total_s", 0.0),
                    "reference_construct_edges_probe": reference_probe(reads, d + "overlaps.txt", rs, pre, (1, 8, 32))}
+            # one more run with the stage's own lap prints (stderr): what the constructor and construct_edges spend their time on
+            tr = subprocess.run(argv(o, *vals), capture_output=True, text=True, env=dict(os.environ, HC_STAGE_TIMING="1"))
+            rec["stage_timing_lines"] = [ln for ln in tr.stderr.splitlines() if ln.startswith("[hc stage]")][:40]
             ctor = med.get("edge_calculator_ctor_s", 0.0) + med.get("hip_runtime_start_s", 0.0)
             rec["what_a_resident_context_would_save_s"] = ctor
             rec["note"] = ("a process per call pays the HIP runtime's start and the context / store / text-block set-up (hip_runtime_start_s + "
