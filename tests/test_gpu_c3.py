@@ -77,53 +77,16 @@ def test_full_size_c3_properties_and_every_record_against_the_oracle(oracle, c3)
 
 
 def _the_file_against_the_references_own_stage(reads, st, d):
-    """ALL 10^8 lines of config 3 (HC_C3_REFERENCE_LINES: fewer, through --max_ov on the same file): the REFERENCE'S OWN construct_edges +
-    sortEdges (fragment probe frag_stage_sorted: its parser, its `i < max_overlaps` bound at src/EdgeCalculator.cpp:581, prefilter, OpenMP
-    loop on 32 threads, serial insert with the tie-break chain, sortEdges; two to three minutes) against hc_ec_construct_edges_sorted:
-    out-lists in list order (scores and mismatch rates as bits), in-lists, inclusions, nonedge_overlaps.txt, counters."""
-    import ctypes as C
-    import importlib.util
-
-    lib_path = os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc_omp.so")
-    if not os.path.exists(lib_path):
-        return  # (built only where /root/reference exists)
-    spec = importlib.util.spec_from_file_location("make_golden_ec", os.path.join(ROOT, "tests", "golden", "make_golden_ec.py"))
-    mg = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mg)
-    from tests.test_gpu_reference_patch import _stage
+    """ALL 10^8 lines of config 3 (HC_C3_REFERENCE_LINES: fewer, through --max_ov on the same file) through the REFERENCE'S OWN
+    construct_edges + sortEdges (32 OpenMP threads: a minute and a half) and through hc_ec_construct_edges_sorted: one graph
+    (tests/_refstage.py)."""
+    from tests._refstage import whole_file_against_the_references_own_stage
 
     n_lines = int(os.environ.get("HC_C3_REFERENCE_LINES", str(10 ** 8)))
-    os.environ["HCREF_THREADS"] = str(min(32, os.cpu_count() or 1))
-    seqs, quals = zip(*(reads.seq(q) for q in range(reads.n_seq)))
-    S, Q = (C.c_char_p * len(seqs))(*seqs), (C.c_char_p * len(quals))(*quals)
-    ids = np.ascontiguousarray(reads.read_ids, dtype=np.uint64)
-    fs = mg.FragSettings(st.edge_threshold, st.ov_threshold, st.merge_contigs, st.mismatch, st.min_read_len, 0)
-    pre = (C.c_uint32 * 3)(st.min_overlap_len, st.min_overlap_perc, 0)
-    os.mkdir(d + "ref")
-    lib = C.CDLL(lib_path)
-    n_ref, want = _stage(lib, "frag_stage_sorted", mg, fs, pre, S, Q, ids, 0, reads.n_reads, ["None", d + "p1.fastq", d + "p2.fastq"], d + "overlaps.txt",
-                         d + "ref", n_lines // 8, reads.n_reads, max_overlaps=n_lines)
-    assert n_lines * 0.03 < n_ref < n_lines // 8
-    fe = np.dtype({"names": ["score", "mismatch_rate", "pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"],
-                   "formats": ["<f8", "<f8", "<i4", "<i4", "<i4", "<i4", "u1", "u1", "u1", "<u8", "<u8", "<i4", "<i4", "<i4", "<i4"],
-                   "offsets": [0, 8, 16, 20, 24, 28, 32, 33, 34, 40, 48, 56, 60, 64, 68], "itemsize": C.sizeof(mg.FragEdge)})
-    ref_edges = np.frombuffer(want[0], fe)
-    os.mkdir(d + "cut")
-    import copy
-    st2 = copy.copy(st)
-    st2.max_overlaps = n_lines
-    with host.EdgeCalculatorStage(st2, paired1=d + "p1.fastq", paired2=d + "p2.fastq", overlaps=d + "overlaps.txt", output_dir=d + "cut/") as ec:
-        ec.construct_edges_sorted()
-        got, (in_off, in_nodes), incl, cnt = ec.edges(), ec.in_lists(), ec.inclusions(), ec.counters()
-    assert cnt["scored"] == n_lines and got.size == n_ref
-    for k in ("score", "mismatch_rate"):
-        assert np.array_equal(np.ascontiguousarray(got[k]).view(np.uint64), np.ascontiguousarray(ref_edges[k]).view(np.uint64)), f"{k} not bit-identical"
-    for k in ("pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"):
-        assert np.array_equal(np.asarray(got[k]).astype(np.int64), ref_edges[k].astype(np.int64)), f"{k} differs"
-    assert in_off.tobytes() == want[1] and in_nodes.tobytes() == want[2], "in-lists differ"
-    assert incl.tobytes() == want[3]
-    assert open(d + "cut/nonedge_overlaps.txt", "rb").read() == want[4]
-    assert [cnt["inclusion_count"], cnt["dup_count"], cnt["self_overlap_count"]] == want[5]
+    n = whole_file_against_the_references_own_stage(reads, st, d, d + "overlaps.txt", n_lines, n_lines // 8, dict(paired1=d + "p1.fastq", paired2=d + "p2.fastq"),
+                                                    min_edges=n_lines * 0.03)
+    if n_lines == 10 ** 8:
+        assert n == 3750623
 
 
 def test_c3_stage_both_resolution_routes_and_a_slice_against_the_references_own_code(c3, tmp_path):

@@ -153,6 +153,19 @@ def test_c4_slice_against_the_references_own_code(c4, tmp_path):
     _slice_against_the_reference(reads, cand, st, tmp_path, 500000, 150000)
 
 
+@pytest.mark.parametrize("which", ["c4", "c5"])
+def test_whole_file_against_the_references_own_construct_edges_and_sort_edges(which, c4, c5, tmp_path):
+    """Config 4 (1.26 * 10^6 lines, 35 quality values, --edge_threshold 1) and config 5 (2 * 10^6 lines, lengths 150..6 000) WHOLE through the
+    REFERENCE'S OWN construct_edges + sortEdges and through hc_ec_construct_edges_sorted: one graph (tests/_refstage.py)."""
+    from tests._refstage import whole_file_against_the_references_own_stage
+
+    reads, cand, st = c4 if which == "c4" else c5
+    d = str(tmp_path) + "/"
+    host.write_overlaps(d + "overlaps.txt", cand, reads)
+    reads.write_fastq(d + "singles.fastq", None, None)
+    whole_file_against_the_references_own_stage(reads, st, d, d + "overlaps.txt", int(cand.size), int(cand.size), dict(singles=d + "singles.fastq"), min_edges=10000)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("HC_FUZZ_BUCKET_SEEDS", "10"))))
 def test_fuzz_bucketed_launch_random_shapes(oracle, monkeypatch, seed):
     """The length-bucketed launch under random shapes: sequences of 30..6 000 symbols (log-uniform), singles, pairs or

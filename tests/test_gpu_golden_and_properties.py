@@ -317,23 +317,10 @@ def test_mixed_read_types_against_the_references_own_code(tmp_path):
 
 
 def test_full_size_c2_stage_against_the_references_own_construct_edges_and_sort_edges(tmp_path):
-    """BASELINE config 2 WHOLE (50 000 pairs, all 2 * 10^6 overlap lines): the REFERENCE'S OWN construct_edges + sortEdges
-    (src/EdgeCalculator.cpp:561-666 with its parser, prefilter, OpenMP loop and serial insert, src/OverlapGraph.cpp:722-764; the fragment
-    probe's frag_stage_sorted, nothing of this build inside it) against hc_ec_construct_edges_sorted on the same files: every out-list
-    in list order with scores and mismatch rates as bit patterns, every in-list, inclusions, nonedge_overlaps.txt, the counters."""
-    import ctypes as C
-    import importlib.util
-
-    lib_path = os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc_omp.so")
-    if not os.path.exists(lib_path):
-        lib_path = os.path.join(ROOT, "oracle", "_ref", "libhcref_edgecalc.so")
-    if not os.path.exists(lib_path):
-        pytest.skip("oracle/_ref/libhcref_edgecalc*.so is built only where /root/reference exists")
-    spec = importlib.util.spec_from_file_location("make_golden_ec", os.path.join(ROOT, "tests", "golden", "make_golden_ec.py"))
-    mg = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mg)
+    """BASELINE config 2 WHOLE (50 000 pairs, all 2 * 10^6 overlap lines) through the REFERENCE'S OWN construct_edges + sortEdges and
+    through hc_ec_construct_edges_sorted: one graph (tests/_refstage.py)."""
     from haploconduct_amd import host
-    from tests.test_gpu_reference_patch import _stage
+    from tests._refstage import whole_file_against_the_references_own_stage
 
     import bench
 
@@ -342,30 +329,5 @@ def test_full_size_c2_stage_against_the_references_own_construct_edges_and_sort_
     d = str(tmp_path) + "/"
     host.write_overlaps(d + "overlaps.txt", cand, reads)
     reads.write_fastq(None, d + "p1.fastq", d + "p2.fastq")
-    seqs, quals = zip(*(reads.seq(q) for q in range(reads.n_seq)))
-    S, Q = (C.c_char_p * len(seqs))(*seqs), (C.c_char_p * len(quals))(*quals)
-    ids = np.ascontiguousarray(reads.read_ids, dtype=np.uint64)
-    fs = mg.FragSettings(st.edge_threshold, st.ov_threshold, st.merge_contigs, st.mismatch, st.min_read_len, 0)
-    pre = (C.c_uint32 * 3)(st.min_overlap_len, st.min_overlap_perc, 0)
-    os.mkdir(d + "ref")
-    n_ref, want = _stage(C.CDLL(lib_path), "frag_stage_sorted", mg, fs, pre, S, Q, ids, 0, reads.n_reads, ["None", d + "p1.fastq", d + "p2.fastq"],
-                         d + "overlaps.txt", d + "ref", int(cand.size), reads.n_reads)
-    assert n_ref > 50000
-    fe = np.dtype({"names": ["score", "mismatch_rate", "pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"],
-                   "formats": ["<f8", "<f8", "<i4", "<i4", "<i4", "<i4", "u1", "u1", "u1", "<u8", "<u8", "<i4", "<i4", "<i4", "<i4"],
-                   "offsets": [0, 8, 16, 20, 24, 28, 32, 33, 34, 40, 48, 56, 60, 64, 68], "itemsize": C.sizeof(mg.FragEdge)})
-    ref_edges = np.frombuffer(want[0], fe)
-    os.mkdir(d + "out")
-    st.n_threads = min(32, os.cpu_count() or 1)
-    with host.EdgeCalculatorStage(st, paired1=d + "p1.fastq", paired2=d + "p2.fastq", overlaps=d + "overlaps.txt", output_dir=d + "out/") as ec:
-        ec.construct_edges_sorted()
-        got, (in_off, in_nodes), incl, cnt = ec.edges(), ec.in_lists(), ec.inclusions(), ec.counters()
-    assert got.size == n_ref
-    for k in ("score", "mismatch_rate"):
-        assert np.array_equal(np.ascontiguousarray(got[k]).view(np.uint64), np.ascontiguousarray(ref_edges[k]).view(np.uint64)), f"{k} not bit-identical"
-    for k in ("pos1", "pos2", "pos3", "pos4", "ori1", "ori2", "ord", "v1", "v2", "perc", "len0", "len1", "len2"):
-        assert np.array_equal(np.asarray(got[k]).astype(np.int64), ref_edges[k].astype(np.int64)), f"{k} differs"
-    assert in_off.tobytes() == want[1] and in_nodes.tobytes() == want[2], "in-lists differ"
-    assert incl.tobytes() == want[3]
-    assert open(d + "out/nonedge_overlaps.txt", "rb").read() == want[4]
-    assert [cnt["inclusion_count"], cnt["dup_count"], cnt["self_overlap_count"]] == want[5]
+    whole_file_against_the_references_own_stage(reads, st, d, d + "overlaps.txt", int(cand.size), int(cand.size), dict(paired1=d + "p1.fastq", paired2=d + "p2.fastq"),
+                                                min_edges=50000)
