@@ -182,3 +182,39 @@ def test_fno3_large_iteration_device_equals_host(flags):
     assert wc["candidates"] >= 200000, "the test means to exceed the device threshold"
     assert F.last_on_device
     assert gc == wc and got == want and wc["n_lines"] > 100000
+
+
+@pytest.mark.parametrize("dup", [False, True], ids=["plain", "add_duplicates"])
+def test_large_iteration_against_the_references_own_find_next_overlaps(dup, tmp_path):
+    """3 * 10^5 vertices, 7.5 * 10^4 super-reads, 1.2 * 10^6 edges and 6 * 10^5 stored non-edges through the REFERENCE'S OWN
+    findNextOverlaps() (fragment probe: updateOverlap, computeOverlapData, reconsiderNonedgeOverlaps reading nonedge_overlaps.txt, its
+    checkEdge, the std::set<std::string>; single thread as SRBuilder forces it) and through hc_fno1_run on the device: the same
+    overlaps.txt, byte for byte — also under --add_duplicates (vertices by orientation, every kept line followed by its opposite)."""
+    import ctypes as C
+
+    import numpy as np
+
+    ref_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libhcref_fno.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref/libhcref_fno.so is built only where /root/reference exists")
+    inp = _big(300000, 75000, 1200000, 11, F.RESOLVE_ORIENTATIONS | (F.ADD_DUPLICATES if dup else 0), dup=dup)
+    ne, nodes = inp.nonedges, inp.nodes
+    half = len(nodes) // 2 if dup else len(nodes)
+    t = np.where(nodes["paired"] != 0, "p", "s")
+    with open(tmp_path / "nonedge_overlaps.txt", "w") as f:  # reads named by their number (the probe's convention)
+        for e in ne:
+            v1, v2 = int(e["v1"]), int(e["v2"])
+            f.write(f"{v1 % half}\t{v2 % half}\t{e['pos1']}\t{e['pos2']}\t{chr(e['ord'])}\t{'+' if e['ori1'] else '-'}\t{'+' if e['ori2'] else '-'}\t"
+                    f"{e['perc']}\t0\t{e['len1']}\t{e['len2']}\t{t[v1]}\t{t[v2]}\n")
+    got, gc = F.find_next_overlaps(inp)
+    assert F.last_device_level == 2
+    ref = C.CDLL(ref_path)
+    vp = C.c_void_p
+    ref.frag_fno1_run.argtypes = [C.POINTER(F.hc_fno1_input), C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    ref.frag_fno_free.argtypes = [vp]
+    s_, text, nb, nl = inp.struct(), vp(), C.c_uint64(), C.c_uint64()
+    ref.frag_fno1_run(C.byref(s_), str(tmp_path).encode(), C.byref(text), C.byref(nb), C.byref(nl))
+    want = C.string_at(text, nb.value)
+    ref.frag_fno_free(text)
+    assert nl.value == gc["n_lines"] > 10 ** 6
+    assert got == want, "overlaps.txt differs from the reference's own"
