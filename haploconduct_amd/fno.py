@@ -205,11 +205,16 @@ def compute_overlap_data(sr1, sr2, idx, edge):
     return int(ok.value), [int(x) for x in out]
 
 
-def edges_from_records(recs):
+def edges_from_records(recs, add_duplicates_reads=None):
     """hc_overlap_rec records (e.g. the lines of nonedge_overlaps.txt parsed by host.parse) -> FNO_EDGE_DTYPE
-    with score 0: vertex = read index (Read::get_vertex_id(true) without --add_duplicates), perc = Overlap::get_perc."""
+    with score 0: vertex = read index (Read::get_vertex_id(true) without --add_duplicates), perc = Overlap::get_perc.
+    add_duplicates_reads = the number of reads: the vertices of --add_duplicates (src/FindNextOverlaps.cpp:672-675) — a read's own vertex
+    for a '+' orientation, read index + number of reads for '-' (src/ViralQuasispecies.cpp:246-270)."""
     e = np.zeros(len(recs), FNO_EDGE_DTYPE)
     e["v1"], e["v2"] = recs["read1"], recs["read2"]
+    if add_duplicates_reads is not None:
+        e["v1"] += np.where(recs["ori1"] != 0, 0, add_duplicates_reads).astype(np.uint64)
+        e["v2"] += np.where(recs["ori2"] != 0, 0, add_duplicates_reads).astype(np.uint64)
     e["pos1"], e["pos2"] = recs["pos1"], recs["pos2"]
     e["len1"], e["len2"], e["perc"] = recs["len1"], recs["len2"], recs["perc"]
     e["ori1"], e["ori2"] = recs["ori1"], recs["ori2"]

@@ -391,10 +391,7 @@ def _dup_records_from_lines(lines, half):
         rc, o = host.parse_overlap(ln)
         assert rc == 0
         recs[k] = (o["id1"], o["id2"], o["pos1"], o["pos2"], o["ori1"] == "+", o["ori2"] == "+", ord(o["ord"]), 0, o["len1"], o["len2"], o["perc"])
-    ne = F.edges_from_records(recs)
-    ne["v1"] += np.where(ne["ori1"] != 0, 0, half).astype(np.uint64)
-    ne["v2"] += np.where(ne["ori2"] != 0, 0, half).astype(np.uint64)
-    return ne
+    return F.edges_from_records(recs, add_duplicates_reads=half)
 
 
 def test_golden_whole_runs_under_add_duplicates(olib):
