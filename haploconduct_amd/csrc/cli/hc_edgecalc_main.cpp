@@ -7,6 +7,8 @@
 // viralquasispecies.log (settings block, :160-218), edges.tsv — the admitted edges in adjacency-list order as
 // construct_edges leaves them, one line per Edge with %.17g score / mismatch rate — and edges_sorted.tsv, the same
 // after overlap_graph->sortEdges() (:297), the order every later stage of the reference sees.
+#include <algorithm>
+#include <charconv>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -15,6 +17,7 @@
 #include <memory>
 #include <string>
 #include <sys/time.h>
+#include <thread>
 #include <unistd.h>
 #include <vector>
 
@@ -272,16 +275,62 @@ int main(int argc, char** argv) {
                    calc.stats.t_parse, calc.stats.t_score, calc.stats.t_insert, calc.stats.t_write,
                    (unsigned long)calc.stats.scored);
         }
+        // The graph as text, one edge per line in list order.  Formatted by --threads threads, each its stretch of vertices into its own
+        // buffer (fprintf with two %.17g per line took 40 ms of the SAVAGE example's 0.19 s process: a fifth of it); the doubles in their
+        // shortest form that reads back to the same bits (std::to_chars).
         auto write_edges = [&](const char* name) {
             FILE* ef = fopen((ps.output_dir + name).c_str(), "w");
             if (!ef) return;
-            for (const auto& L : graph->adj_out)
-                for (const Edge& e : L)
-                    fprintf(ef, "%lu\t%lu\t%lu\t%lu\t%d\t%d\t%d\t%d\t%c\t%c\t%c\t%d\t%d\t%d\t%d\t%.17g\t%.17g\n", e.get_vertex(1),
-                            e.get_vertex(2), e.get_read(1)->get_read_id(), e.get_read(2)->get_read_id(), e.get_pos(1),
-                            e.get_pos(2), e.get_extra_pos(1), e.get_extra_pos(2), e.get_ori(1) ? '+' : '-',
-                            e.get_ori(2) ? '+' : '-', e.get_ord() ? e.get_ord() : '-', e.get_perc(), e.get_len(0), e.get_len(1),
-                            e.get_len(2), e.get_score(), e.get_mismatch_rate());
+            const size_t V = graph->adj_out.size();
+            const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(1u, ps.n_threads), (size_t)16, graph->getEdgeCount() / 4096 + 1}));
+            std::vector<std::string> part(T);
+            auto format = [&](unsigned t) {
+                std::string& buf = part[t];
+                char tmp[40];
+                auto num = [&](long long v, char end) {
+                    auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
+                    buf.append(tmp, r.ptr);
+                    buf.push_back(end);
+                };
+                auto unum = [&](unsigned long long v) {
+                    auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
+                    buf.append(tmp, r.ptr);
+                    buf.push_back('\t');
+                };
+                auto dbl = [&](double v, char end) {
+                    auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
+                    buf.append(tmp, r.ptr);
+                    buf.push_back(end);
+                };
+                for (size_t v = V * t / T; v < V * (t + 1) / T; v++)
+                    for (const Edge& e : graph->adj_out[v]) {
+                        unum(e.get_vertex(1));
+                        unum(e.get_vertex(2));
+                        unum(e.get_read(1)->get_read_id());
+                        unum(e.get_read(2)->get_read_id());
+                        num(e.get_pos(1), '\t');
+                        num(e.get_pos(2), '\t');
+                        num(e.get_extra_pos(1), '\t');
+                        num(e.get_extra_pos(2), '\t');
+                        buf.push_back(e.get_ori(1) ? '+' : '-');
+                        buf.push_back('\t');
+                        buf.push_back(e.get_ori(2) ? '+' : '-');
+                        buf.push_back('\t');
+                        buf.push_back(e.get_ord() ? e.get_ord() : '-');
+                        buf.push_back('\t');
+                        num(e.get_perc(), '\t');
+                        num(e.get_len(0), '\t');
+                        num(e.get_len(1), '\t');
+                        num(e.get_len(2), '\t');
+                        dbl(e.get_score(), '\t');
+                        dbl(e.get_mismatch_rate(), '\n');
+                    }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; t++) th.emplace_back(format, t);
+            format(0);
+            for (auto& x : th) x.join();
+            for (const std::string& b : part) fwrite(b.data(), 1, b.size(), ef);
             fclose(ef);
         };
         write_edges("edges.tsv");

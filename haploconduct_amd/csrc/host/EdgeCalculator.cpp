@@ -117,6 +117,10 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
         struct stat sb;
         const size_t n_dev = std::max<size_t>(1, device_list(ps).size());
         if (stat(ps.overlaps_file.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) {
+            // a file shorter than one block: the blocks are made for ITS size (page-locking and device buffers for 16 MiB took 38 ms of
+            // the SAVAGE example's process, whose file has 3 MB); a longer text on a later call is cut into more blocks of this size
+            if (!getenv("HC_TEXT_BLOCK") && (size_t)sb.st_size < m_text_block)
+                m_text_block = std::max<size_t>((size_t)64 << 10, (((size_t)sb.st_size + 4096) + 65535) & ~(size_t)65535);
             const size_t blocks = ((size_t)sb.st_size + m_text_block - 1) / m_text_block;
             m_text_depth = std::min<size_t>(m_text_depth, std::max<size_t>(2, (blocks + n_dev - 1) / n_dev));
         }
