@@ -25,6 +25,8 @@ struct hc_textblock {
     hipEvent_t lines_known = nullptr;          // chained submits: this block's entry of the line chain is written
     hipEvent_t copied = nullptr;               // the text has arrived (the copies of all blocks share the context's copy stream)
     char* h_text = nullptr;                    // page-locked, allocated on first use (hc_textblock_buffer): the caller reads the file into it
+    char* d_slab = nullptr;                    // ONE device allocation holding d_text ... d_kept_tiles
+    char *d_rowslab = nullptr, *h_rowslab = nullptr;  // the row buffers (they may grow): d_rows + d_row_lines; h_rows + h_row_lines + h_rejects, page-locked and mapped
     char* d_text = nullptr;                    // max_bytes + 64
     uint32_t *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_line_start = nullptr;
     uint32_t* d_tally = nullptr;               // the parse kernel's per-workgroup tallies
@@ -101,6 +103,8 @@ int hc_text_set_ids(hc_ctx* c, const uint64_t* read_ids, uint32_t n_reads) {
     return HC_OK;
 }
 
+static int textblock_row_buffers(hc_textblock* b, uint64_t cap, bool defer_free);
+
 int hc_textblock_create(hc_ctx* c, uint64_t max_bytes, hc_textblock** out) {
     if (!c || !out || max_bytes < 64 || max_bytes >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_textblock_create: bad argument");
     *out = nullptr;
@@ -122,25 +126,42 @@ int hc_textblock_create(hc_ctx* c, uint64_t max_bytes, hc_textblock** out) {
     ok(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
     ok(hipEventCreateWithFlags(&b->lines_known, hipEventDisableTiming));
     ok(hipEventCreateWithFlags(&b->copied, hipEventDisableTiming));
-    ok(hipMalloc((void**)&b->d_text, max_bytes + 64));
-    ok(hipMalloc((void**)&b->d_tile_cnt, (size_t)(n_tiles + 1) * 4));
-    ok(hipMalloc((void**)&b->d_tile_off, (size_t)(n_tiles + 1) * 4));
-    ok(hipMalloc((void**)&b->d_tally, ((size_t)b->max_lines / 256 + 2) * 8 * 4));
-    ok(hipMalloc((void**)&b->d_line_start, (L + 2) * 4));
-    ok(hipMalloc((void**)&b->d_cands, (L + 256) * sizeof(hc_cand_rec)));
-    ok(hipMalloc((void**)&b->d_lines, L * sizeof(hc_line_rec)));
-    ok(hipMalloc((void**)&b->d_out, L * sizeof(hc_result_rec)));
-    ok(hipMalloc((void**)&b->d_counters, hc::kTextCounters * sizeof(unsigned long long)));
-    ok(hipMalloc((void**)&b->d_kept_tiles, 2 * (L / 1024 + 2) * sizeof(uint32_t)));
-    ok(hipMalloc((void**)&b->d_rows, RC * sizeof(hc_gather_row)));
-    ok(hipMalloc((void**)&b->d_row_lines, RC * sizeof(hc_line_rec)));
-    ok(hipHostMalloc((void**)&b->h_rows, RC * sizeof(hc_gather_row), hipHostMallocMapped));
-    ok(hipHostMalloc((void**)&b->h_row_lines, RC * sizeof(hc_line_rec), hipHostMallocMapped));
-    ok(hipHostMalloc((void**)&b->h_rejects, RC * sizeof(hc_text_reject), hipHostMallocMapped));
+    // the arrays of fixed size in ONE device allocation (ten of them took 1 ms each: a block cost 17 ms to make, the stage's ten 35 ms
+    // beside the read store's upload, the SAVAGE example's process a sixth of its constructor); the row buffers, which may grow, apart
+    {
+        size_t at = 0;
+        auto place = [&](size_t bytes) {
+            const size_t here = at;
+            at += (bytes + 255) & ~(size_t)255;
+            return here;
+        };
+        const size_t o_text = place(max_bytes + 64), o_tile_cnt = place((size_t)(n_tiles + 1) * 4), o_tile_off = place((size_t)(n_tiles + 1) * 4),
+                     o_tally = place(((size_t)b->max_lines / 256 + 2) * 8 * 4), o_line_start = place((L + 2) * 4),
+                     o_cands = place((L + 256) * sizeof(hc_cand_rec)), o_lines = place(L * sizeof(hc_line_rec)), o_out = place(L * sizeof(hc_result_rec)),
+                     o_counters = place(hc::kTextCounters * sizeof(unsigned long long)), o_kept = place(2 * (L / 1024 + 2) * sizeof(uint32_t));
+        ok(hipMalloc((void**)&b->d_slab, at));
+        if (b->d_slab) {
+            b->d_text = b->d_slab + o_text;
+            b->d_tile_cnt = (uint32_t*)(b->d_slab + o_tile_cnt);
+            b->d_tile_off = (uint32_t*)(b->d_slab + o_tile_off);
+            b->d_tally = (uint32_t*)(b->d_slab + o_tally);
+            b->d_line_start = (uint32_t*)(b->d_slab + o_line_start);
+            b->d_cands = (hc_cand_rec*)(b->d_slab + o_cands);
+            b->d_lines = (hc_line_rec*)(b->d_slab + o_lines);
+            b->d_out = (hc_result_rec*)(b->d_slab + o_out);
+            b->d_counters = (unsigned long long*)(b->d_slab + o_counters);
+            b->d_kept_tiles = (uint32_t*)(b->d_slab + o_kept);
+        }
+    }
     ok(hipHostMalloc((void**)&b->h_counters, hc::kTextCounters * sizeof(unsigned long long), hipHostMallocMapped));  // the last launch of a block writes them
     if (e != hipSuccess) {
         hc_textblock_destroy(b);
         return fail(HC_ERR_HIP, std::string("hc_textblock_create: ") + hipGetErrorString(e));
+    }
+    if (const int rc = textblock_row_buffers(b, RC, false)) {  // the row buffers: one device and one page-locked allocation
+        const std::string why = hc_last_error();
+        hc_textblock_destroy(b);
+        return fail(rc, why);
     }
     *out = b;
     return HC_OK;
@@ -193,10 +214,9 @@ int hc_textblock_destroy(hc_textblock* b) {
     if (!b) return HC_OK;
     (void)hipSetDevice(b->ctx->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    for (void* p : {(void*)b->d_tally, (void*)b->d_text, (void*)b->d_tile_cnt, (void*)b->d_tile_off, (void*)b->d_line_start, (void*)b->d_cands, (void*)b->d_lines,
-                    (void*)b->d_out, (void*)b->d_counters, (void*)b->d_rows, (void*)b->d_row_lines, (void*)b->d_kept_tiles})
+    for (void* p : {(void*)b->d_slab, (void*)b->d_rowslab})  // (d_text ... d_kept_tiles lie in the slab, d_rows / d_row_lines in the row slab)
         if (p) (void)hipFree(p);
-    for (void* p : {(void*)b->h_text, (void*)b->h_rows, (void*)b->h_row_lines, (void*)b->h_rejects, (void*)b->h_counters})
+    for (void* p : {(void*)b->h_text, (void*)b->h_rowslab, (void*)b->h_counters})
         if (p) (void)hipHostFree(p);
     for (void* p : b->old_device) (void)hipFree(p);
     for (void* p : b->old_host) (void)hipHostFree(p);
@@ -257,27 +277,30 @@ static int textblock_device_half(hc_textblock* b) {
 // the row buffers (device rows, their mapped host twins, the rejects) for `cap` rows; defer_free: the old ones are kept for
 // hc_textblock_destroy instead of being freed now (hipFree / hipHostFree wait for the device: not next to another launch sequence)
 static int textblock_row_buffers(hc_textblock* b, uint64_t cap, bool defer_free) {
-    for (void* p : {(void*)b->d_rows, (void*)b->d_row_lines})
-        if (p) {
-            if (defer_free) b->old_device.push_back(p);
-            else (void)hipFree(p);
-        }
-    for (void* p : {(void*)b->h_rows, (void*)b->h_row_lines, (void*)b->h_rejects})
-        if (p) {
-            if (defer_free) b->old_host.push_back(p);
-            else (void)hipHostFree(p);
-        }
+    if (b->d_rowslab) {
+        if (defer_free) b->old_device.push_back(b->d_rowslab);
+        else (void)hipFree(b->d_rowslab);
+    }
+    if (b->h_rowslab) {
+        if (defer_free) b->old_host.push_back(b->h_rowslab);
+        else (void)hipHostFree(b->h_rowslab);
+    }
+    b->d_rowslab = b->h_rowslab = nullptr;
     b->d_rows = nullptr;
     b->d_row_lines = nullptr;
     b->h_rows = nullptr;
     b->h_row_lines = nullptr;
     b->h_rejects = nullptr;
     b->row_cap = (uint32_t)cap;
-    HC_HIP(hipMalloc((void**)&b->d_rows, cap * sizeof(hc_gather_row)));
-    HC_HIP(hipMalloc((void**)&b->d_row_lines, cap * sizeof(hc_line_rec)));
-    HC_HIP(hipHostMalloc((void**)&b->h_rows, cap * sizeof(hc_gather_row), hipHostMallocMapped));
-    HC_HIP(hipHostMalloc((void**)&b->h_row_lines, cap * sizeof(hc_line_rec), hipHostMallocMapped));
-    HC_HIP(hipHostMalloc((void**)&b->h_rejects, cap * sizeof(hc_text_reject), hipHostMallocMapped));
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t rows_b = up(cap * sizeof(hc_gather_row)), lines_b = up(cap * sizeof(hc_line_rec)), rej_b = up(cap * sizeof(hc_text_reject));
+    HC_HIP(hipMalloc((void**)&b->d_rowslab, rows_b + lines_b));
+    HC_HIP(hipHostMalloc((void**)&b->h_rowslab, rows_b + lines_b + rej_b, hipHostMallocMapped));
+    b->d_rows = (hc_gather_row*)b->d_rowslab;
+    b->d_row_lines = (hc_line_rec*)(b->d_rowslab + rows_b);
+    b->h_rows = (hc_gather_row*)b->h_rowslab;
+    b->h_row_lines = (hc_line_rec*)(b->h_rowslab + rows_b);
+    b->h_rejects = (hc_text_reject*)(b->h_rowslab + rows_b + lines_b);
     return HC_OK;
 }
 
