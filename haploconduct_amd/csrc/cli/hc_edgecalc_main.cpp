@@ -240,6 +240,16 @@ int main(int argc, char** argv) {
     }
     try {
         double t0 = now_s();
+        // the HIP runtime's start and the kernels' load (0.1 s of a process's first HIP calls) happen beside the FASTQ parsing when that lasts
+        // long enough to hide them (64 MiB of FASTQ and more), as in hc_ec_open
+        std::thread warm;
+        struct JoinWarm {
+            std::thread& t;
+            ~JoinWarm() {
+                if (t.joinable()) t.join();
+            }
+        } join_warm{warm};
+        if (hc::warm_up_pays(ps)) warm = std::thread(hc::warm_device_code, hc::to_hc_settings(ps));
         auto fastq = std::make_shared<FastqStorage>(ps);  // :233
         if (ps.verbose) printf("FastqStorage ready! Construction took %g seconds.\n", now_s() - t0);
         t0 = now_s();
@@ -252,8 +262,10 @@ int main(int argc, char** argv) {
             printf("Overlap graph ready! Construction took %g seconds.\n", now_s() - t0);
             printf("Number of vertices: %u\n", graph->getVertexCount());
         }
-        // where a short run's time goes (verbose): the HIP runtime's start is paid by the first HIP call of a process
+        // where a short run's time goes (verbose): the HIP runtime's start is paid by the first HIP call of a process — here what is
+        // left of it once the reads are in memory
         t0 = now_s();
+        if (warm.joinable()) warm.join();
         const int n_devices = hc_device_count();
         const double t_hip = now_s() - t0;
         t0 = now_s();

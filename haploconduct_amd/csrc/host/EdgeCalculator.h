@@ -20,6 +20,10 @@
 namespace hc {
 
 hc_settings to_hc_settings(const ProgramSettings& ps);
+// The stage's device sequence once on two dummy reads (hc_ec_api.cpp): starts the HIP runtime and loads the kernels, best effort; meant for
+// a thread beside the caller's FASTQ parsing on a process's first use of a device.
+void warm_device_code(hc_settings cs) noexcept;
+bool warm_up_pays(const ProgramSettings& ps);  // FASTQ files of 64 MiB and more (HC_WARM=0 / 1 overrides)
 
 // The serial insert of process_overlaps (src/EdgeCalculator.cpp:441-538) as a free function so
 // that it can be exercised without a device context.

@@ -8,6 +8,8 @@
 
 #include "../../../include/hcedge_host.h"
 #include "EdgeCalculator.h"
+
+#include <sys/stat.h>
 #include "NumaBind.h"
 #include "api_helpers.h"
 
@@ -24,13 +26,23 @@ struct hc_ec {
     std::unique_ptr<EdgeCalculator> calc;
 };
 
-extern "C" {
-
 // The runtime loads a kernel's code at its first launch in a process: 12 ms in the text blocks' launch sequence, 11 ms in
 // the graph kernels and their sorts — as long again as a whole C2-sized stage.  hc_ec_open runs the stage's device
 // sequence once on two dummy reads, in a thread beside its FASTQ parsing (which is host work): the code is then in place
 // when construct_edges wants it, and opening takes no longer.  Best effort: errors end the warm-up, not the open.
-static void warm_device_code(hc_settings cs) noexcept try {
+// Worth it when the FASTQ parsing beside it lasts longer than the extra work costs: on the SAVAGE example (2 ms of parsing) a process
+// with the warm-up took 0.178 s, without 0.163; with 0.3 GB of FASTQ it saves 0.05 s.
+bool hc::warm_up_pays(const ProgramSettings& ps) {
+    if (const char* w = getenv("HC_WARM")) return atoi(w) != 0;
+    uint64_t bytes = 0;
+    for (const std::string* f : {&ps.singles_file, &ps.paired1_file, &ps.paired2_file}) {
+        struct stat sb;
+        if (!f->empty() && *f != "None" && stat(f->c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) bytes += (uint64_t)sb.st_size;
+    }
+    return bytes >= ((uint64_t)64 << 20);
+}
+
+void hc::warm_device_code(hc_settings cs) noexcept try {
     hc_ctx* c = nullptr;
     if (hc_create(&c, &cs) != HC_OK) return;
     hc_textblock* tb = nullptr;
@@ -75,6 +87,8 @@ static void warm_device_code(hc_settings cs) noexcept try {
 } catch (...) {  // a thread body: nothing may leave it
 }
 
+extern "C" {
+
 int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* paths) {
     if (!out || !settings || !paths) return set_last_error(HC_ERR_ARG, "hc_ec_open: null argument");
     *out = nullptr;
@@ -87,7 +101,8 @@ int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* path
         static std::atomic<uint64_t> warmed{0};
         const uint64_t dev_bit = 1ull << ((uint32_t)settings->device & 63u);
         const bool first_open = !(warmed.fetch_or(dev_bit) & dev_bit);
-        if (first_open && !(getenv("HC_WARM") && atoi(getenv("HC_WARM")) == 0)) warm = std::thread(warm_device_code, *settings);
+        ec->ps = make_ps(settings, paths);
+        if (first_open && hc::warm_up_pays(ec->ps)) warm = std::thread(hc::warm_device_code, *settings);
         struct Join {
             std::thread& t;
             ~Join() {
@@ -98,7 +113,6 @@ int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* path
         // the device.  Not on a process's first open: asking where the device sits starts the HIP runtime, which that open
         // leaves to the warm-up thread beside the parsing (the stage's own threads find their place once it is up).
         hc::BoundForNow bound(first_open ? std::vector<int>() : hc::cpus_near_device(settings->device));
-        ec->ps = make_ps(settings, paths);
         ec->fastq = std::make_shared<FastqStorage>(ec->ps);                                   // ViralQuasispecies.cpp:233
         const double t1 = now();
         const unsigned int R = ec->fastq->get_readcount();
