@@ -43,7 +43,9 @@ typedef struct hc_ec_counters {
 typedef struct hc_ec hc_ec; /* FastqStorage + OverlapGraph + EdgeCalculator */
 
 /* new FastqStorage(ps); new OverlapGraph(readcount, ...); addVertex + set_vertex_id per read;
- * EdgeCalculator(fastq, graph, ps)  — src/ViralQuasispecies.cpp:233-279.  Needs a HIP device. */
+ * EdgeCalculator(fastq, graph, ps)  — src/ViralQuasispecies.cpp:233-279.  Needs a HIP device.
+ * A process's first open of a device with 64 MiB of FASTQ and more starts the HIP runtime and loads the kernels on a thread beside
+ * the FASTQ parsing (HC_WARM=0 / 1: never / always). */
 int hc_ec_open(hc_ec** out, const hc_settings* settings, const hc_ec_paths* paths);
 /* EdgeCalculator::construct_edges() — src/EdgeCalculator.cpp:561-666 */
 int hc_ec_construct_edges(hc_ec* ec);
