@@ -2,7 +2,8 @@
 // before process_overlaps sees it (reference src/EdgeCalculator.cpp:581-635; Overlap's constructor, src/Overlap.h:39-73),
 // as three HBM-bound byte kernels over a block of the file's text:
 //   text_count_kernel   newlines per 4 KiB tile (16 bytes per lane, one coalesced load)
-//   text_scan_kernel    exclusive scan of the tile counts (one workgroup; a block has a few thousand tiles)
+//   text_scan_kernel    exclusive scan of the tile counts (one workgroup; a block has a few thousand tiles); it also zeroes the
+//                       block's counters, sets the line count and passes it down the chain of line counters across blocks
 //   text_lines_kernel   start offset of every line
 //   text_parse_kernel   one lane per line: the 13 fields of a PLAIN line (single tabs, decimal numbers or "-", valid
 //                       one-character fields — what sfo2overlaps.py and FNO write), --max_ov, the self-overlap test, the
