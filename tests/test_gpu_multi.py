@@ -120,7 +120,7 @@ def test_hc_edgecalc_device_mask_over_real_devices(tmp_path):
     assert len(outs["one"]) == 4 and len(outs["one"]["edges_sorted.tsv"]) > 10000 and outs["one"] == outs["two"]
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_n_rank_bench_path_on_one_gpu_over_gloo(tmp_path, world):
     """The N-rank path of bench.py WITHOUT N GPUs: every rank on device 0, the all-gather staged through the host over gloo
     (HC_BENCH_BACKEND=gloo HC_BENCH_ONE_DEVICE=1; the line says "test_run").  Everything but RCCL itself is the driver's path: torch.distributed.run,
