@@ -170,6 +170,7 @@ int hc_destroy(hc_ctx* c) {
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_totals) (void)hipFree(c->d_totals);
+    if (c->d_started) (void)hipFree(c->d_started);
     if (c->d_sort) (void)hipFree(c->d_sort);
     if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
     if (c->d_compact_tmp) (void)hipFree(c->d_compact_tmp);
@@ -545,8 +546,22 @@ int hc_ctx_score(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_
         seg_buf = c->sink_rows.as<hc_gather_row>();
         seg_count = c->sink_counts.as<uint32_t>();
     }
-    HC_HIP(hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, c->n_cu, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group, rows, row_count, cap,
-                            base_index, s, lines_in, lines_out, bperm, bqueue, seg_buf, seg_count, seg_total, &c->sink_turn));
+    if (want_segments && c->sink_dirty) {  // a segmented launch failed at enqueue: whatever it left in the spill counters goes
+        HC_HIP(hipMemsetAsync(c->sink_counts.as<uint32_t>() + hc::kSinkMaxGroups, 0, 2 * sizeof(uint32_t), s));
+        c->sink_dirty = false;
+    }
+    // the multi-GPU step: CUs left to the collective library (hc_set_comm_reserve), workgroup starts counted for hc_comm_gate_device
+    const uint32_t cus = c->comm_reserve && c->comm_reserve < c->n_cu ? c->n_cu - c->comm_reserve : c->n_cu;
+    unsigned long long* started = (rows && !lines_in) ? c->d_started : nullptr;
+    uint32_t started_groups = 0;
+    const hipError_t le = hc::launch_score(c->view, prm, c->d_lut, d_in, n, (hc_result_rec*)d_out, perm, cus, c->coop_fetch ? 0 : c->fetch_group, c->fetch_group, rows,
+                                           row_count, cap, base_index, s, lines_in, lines_out, bperm, bqueue, seg_buf, seg_count, seg_total, &c->sink_turn, started,
+                                           &started_groups);
+    if (le != hipSuccess) {
+        if (want_segments) c->sink_dirty = true;
+        return hc::set_last_error(HC_ERR_HIP, std::string("launch_score: ") + hipGetErrorString(le));
+    }
+    if (started) c->started_target += started_groups;
     if (ctx_scratch) {
         HC_HIP(hipEventRecord(c->scratch_done, s));
         c->scratch_stream = s;
@@ -676,6 +691,27 @@ static int ensure_compact_workspace(hc_ctx* c, uint64_t n, bool with_buffers) {
         HC_HIP(hipMalloc((void**)&c->d_compact_res, n * sizeof(hc_result_rec)));
         c->compact_cap = n;
     }
+    return HC_OK;
+}
+
+int hc_set_comm_reserve(hc_ctx* c, uint32_t cus) {
+    if (!c) return fail(HC_ERR_ARG, "hc_set_comm_reserve: null context");
+    if (cus >= c->n_cu) return fail(HC_ERR_ARG, "hc_set_comm_reserve: more CUs than the device has");
+    HC_HIP(hipSetDevice(c->device));
+    if (cus && !c->d_started) {
+        HC_HIP(hipMalloc((void**)&c->d_started, sizeof(unsigned long long)));
+        HC_HIP(hipMemset(c->d_started, 0, sizeof(unsigned long long)));
+        c->started_target = 0;
+    }
+    c->comm_reserve = cus;
+    return HC_OK;
+}
+
+int hc_comm_gate_device(hc_ctx* c, void* hip_stream, uint32_t timeout_us) {
+    if (!c) return fail(HC_ERR_ARG, "hc_comm_gate_device: null context");
+    if (!c->d_started) return HC_OK;  // nothing is counted: nothing to wait for
+    HC_HIP(hipSetDevice(c->device));
+    HC_HIP(hc::launch_comm_gate(c->d_started, c->started_target, timeout_us ? timeout_us : 2000u, hip_stream ? (hipStream_t)hip_stream : c->stream));
     return HC_OK;
 }
 

@@ -22,7 +22,9 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in = nullptr, hc_line_rec* lines_out = nullptr, uint32_t* bucket_perm = nullptr,
                         uint32_t* bucket_queue = nullptr, hc_gather_row* seg_buf = nullptr, uint32_t* seg_count = nullptr, uint64_t seg_total_rows = 0,
-                        uint32_t* spill_turn = nullptr);
+                        uint32_t* spill_turn = nullptr, unsigned long long* started = nullptr, uint32_t* started_groups = nullptr);
+// started / started_groups: hc_comm_gate_device — the cooperative launch's workgroups add one each to *started as they start;
+// *started_groups = how many will (0: the launch took a kernel that does not count)
 // seg_buf (seg_total_rows rows: segments, then `cap` rows of spill area) / seg_count (kSinkMaxGroups counters + 2 spill counters, all
 // zero before the first launch) / spill_turn (host: which spill counter the next launch uses; advanced by a launch that used segments):
 // scratch of a launch that collects its rows in per-workgroup segments
@@ -51,6 +53,7 @@ hipError_t launch_kept_rows(const hc_result_rec* res, uint64_t n, const unsigned
 hipError_t launch_flush_text_rows(const void* rows, void* rows_mapped, const void* lines, void* lines_mapped, const unsigned long long* count,
                                   uint64_t cap, const unsigned long long* counters, unsigned long long* counters_mapped, uint32_t n_cu,
                                   hipStream_t stream);
+hipError_t launch_comm_gate(const unsigned long long* started, unsigned long long target, uint32_t timeout_us, hipStream_t stream);
 hipError_t launch_flush_rows(const void* src, void* dst_mapped, const unsigned long long* count, uint64_t cap, uint32_t row_bytes, uint32_t n_cu,
                              hipStream_t stream);
 
@@ -150,6 +153,12 @@ struct hc_ctx {
     hc_bucket_ws bucket;  // length-bucketed launches on the context's own entry points
     hc_scratch sink_rows, sink_counts;  // hc_score_pack_device: the row sink's per-workgroup segments (hc_kernels.hip: RowSink)
     uint32_t sink_turn = 0;             // which of the two spill counters the next segmented launch uses
+    bool sink_dirty = false;            // a segmented launch failed at enqueue: the spill counters are re-zeroed before the next one
+    // the multi-GPU step (hc_set_comm_reserve / hc_comm_gate_device): CUs left free for the collective library's kernels, and the
+    // count of workgroups that have started, which the gate kernel on the exchange's stream waits for
+    uint32_t comm_reserve = 0;
+    unsigned long long* d_started = nullptr;
+    unsigned long long started_target = 0;  // workgroups launched so far with the counter (host side)
 
     // The context's own scratch (reorder workspace, `bucket`, the sink's segments) serves one launch at a time: a launch that uses
     // any of it on another stream than the last such launch waits for that one (hc_ctx_score)

@@ -770,6 +770,9 @@ struct RowSink {
     uint32_t spill_cap;
     hc_gather_row* spill_buf;
     uint32_t* spill_count;  // zero when the launch starts (sink_compact_kernel re-arms the counter of the launch after the next)
+    // hc_comm_gate_device (the multi-GPU step): every workgroup of a cooperative launch adds one here when it starts, so that a gate
+    // kernel on the exchange's stream can hold the collective back until this launch's workgroups sit on their CUs.  nullptr: not counted.
+    unsigned long long* started;
 };
 
 // Called by ALL lanes of the workgroup (uniform control flow; `valid` = this lane scored candidate i).
@@ -1208,6 +1211,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
         scratch[24] = 0;
         scratch[29] = 0;  // WQ: the workgroup's ticket counter
         if (DYN && !WQ) scratch[26] = atomicAdd(queue, 1u);  // the workgroup's first queue entry; [26], [27]: this iteration's and the next one's
+        if (sink.started) atomicAdd(sink.started, 1ull);     // kernel-argument-uniform branch
     }
     __syncthreads();
     // this wave's image (LDS byte address); the images start at a multiple of 1 KiB (the XOR swizzle needs whole 64-byte rows)
@@ -1508,7 +1512,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         hc_result_rec* out, const uint32_t* perm, uint32_t n_cu, int fetch_group, int lane_fetch_group, hc_gather_row* rows,
                         unsigned long long* row_count, uint64_t cap, uint64_t base_index, hipStream_t stream,
                         const hc_line_rec* lines_in, hc_line_rec* lines_out, uint32_t* bucket_perm, uint32_t* bucket_queue, hc_gather_row* seg_buf,
-                        uint32_t* seg_count, uint64_t seg_total_rows, uint32_t* spill_turn) {
+                        uint32_t* seg_count, uint64_t seg_total_rows, uint32_t* spill_turn, unsigned long long* started, uint32_t* started_groups) {
+    if (started_groups) *started_groups = 0;
     if (n == 0) return hipSuccess;
     const uint32_t lg = lut_lg(st.K);
     if (fetch_group == 0) {
@@ -1536,7 +1541,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             static const int grid_mult = getenv("HC_GRID_MULT") ? std::max(1, atoi(getenv("HC_GRID_MULT"))) : 4;  // experiment knob
             const uint64_t cap_c = (uint64_t)n_cu * per_cu * (bucketed ? 1 : grid_mult);  // a queue needs resident workgroups only
             if (blocks_c > cap_c) blocks_c = cap_c;
-            RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u, nullptr, nullptr};
+            RowSink sink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u, nullptr, nullptr, started};
             // the cooperative launches collect their rows in per-workgroup segments (RowSink); G = the launch's workgroups.  Of the
             // seg_total_rows rows of scratch the last `cap` are the spill area, the others are dealt to the workgroups.
             const bool segmented = rows && seg_buf && seg_count && spill_turn && !lines_in && cap < 0xFFFFFFFFull && seg_total_rows > cap;
@@ -1598,6 +1603,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                     else HC_COOP_WQ_LAUNCH(5);
 #undef HC_COOP_WQ_LAUNCH
                     compact_segments(blocks_d);
+                    if (started_groups) *started_groups = (uint32_t)blocks_d;
                     return hipGetLastError();
                 }
                 use_segments(blocks_d);
@@ -1609,6 +1615,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 else HC_COOP_DMA_LAUNCH(5);
 #undef HC_COOP_DMA_LAUNCH
                 compact_segments(blocks_d);
+                if (started_groups) *started_groups = (uint32_t)blocks_d;
                 return hipGetLastError();
             }
             using W256 = std::integral_constant<int, 256>;
@@ -1665,6 +1672,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 else launch_coop(uint8_t{}, std::integral_constant<int, 5>{}, W256{});
             }
             compact_segments(blocks_c);
+            if (started_groups) *started_groups = (uint32_t)blocks_c;
             return hipGetLastError();
         }
         fetch_group = lane_fetch_group;

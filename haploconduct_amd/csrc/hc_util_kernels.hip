@@ -321,4 +321,28 @@ hipError_t launch_count_positions(const StoreView& st, uint32_t min_read_len, ui
     return hipGetLastError();
 }
 
+// hc_comm_gate_device: one lane that leaves when `target` workgroups of the context's cooperative scoring launches have started (or
+// after timeout_us).  Put in front of a collective on the exchange's stream, it makes the collective library's kernels arrive when the
+// scoring kernel that runs beside them already sits on its CUs (all but the hc_set_comm_reserve'd ones), so they take the free ones —
+// arriving first, their workgroups would be spread over CUs the scoring kernel's one-per-CU workgroups then cannot share.  A few
+// registers, no LDS: fits on any CU beside anything.  The timeout makes a wait for a launch that never comes end (the exchange is
+// then simply not gated).
+__global__ __launch_bounds__(64) void comm_gate_kernel(const unsigned long long* __restrict__ started, unsigned long long target, unsigned long long timeout_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(64);
+        if (wall_clock64() - t0 > timeout_ticks) break;
+    }
+}
+
+hipError_t launch_comm_gate(const unsigned long long* started, unsigned long long target, uint32_t timeout_us, hipStream_t stream) {
+    int khz = 100000;  // wall_clock64(): the constant-rate counter, 100 MHz on gfx9
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+    if (khz <= 0) khz = 100000;
+    hipLaunchKernelGGL(comm_gate_kernel, dim3(1), dim3(64), 0, stream, started, target, (unsigned long long)timeout_us * (unsigned long long)khz / 1000ull);
+    return hipGetLastError();
+}
+
 }  // namespace hc

@@ -74,110 +74,248 @@ def pack_payload(results, base_index, cap_rows, shuffle_seed=None):
     return torch.from_numpy(out)
 
 
-class _DoneWork:
-    """Stand-in for an async work handle whose collective has already completed (the staged gloo path below)."""
-
-    def wait(self):
-        return True
+GATHER_MODES = ("ring", "direct")
 
 
 class PayloadGather:
-    """The all-gather-v of the collection payloads as ONE all-gather per batch, on any backend (nccl = RCCL, gloo):
-    every rank contributes a fixed-capacity payload whose row 0 is its count; `depth` buffer sets in turn, the
-    all-gather asynchronous; `collect` (host side) waits, checks the capacity, trims by the counts, and sorts the
-    rows by global index when their producer wrote them in no particular order."""
+    """The all-gather-v of the collection payloads, on any backend (nccl = RCCL, gloo).  Every rank contributes a payload whose row 0 is
+    its count; `depth` buffer sets in turn; everything asynchronous on a side stream; `collect` (host side) waits, checks the capacity,
+    trims by the counts, and sorts the rows by global index when their producer wrote them in no particular order.  Two forms of the
+    exchange, selected by `mode`, bit-identical in what every rank ends up with:
 
-    def __init__(self, cap_rows, group=None, depth=2, device=None):
-        self.cap, self.group, self.depth = int(cap_rows), group, depth
+      "ring"    ONE all-gather of the fixed-capacity payload (cap + 1 rows per rank whatever the counts): the library's own ring / tree
+                over the links; nothing of it ever waits for the host.
+      "direct"  the all-gather-V proper: the counts by one small all-gather, then the payload by grouped per-peer send / recv of exactly
+                1 + count rows (batch_isend_irecv = one ncclGroup: every pair of ranks uses its own xGMI link, nothing is forwarded).
+                The sizes of the send / recv calls must be known on the host: the host waits for the counts.  With lag = True (what
+                StreamedGather.score_step does) the exchange of batch i is issued right behind the launch of batch i + 1's kernel, so
+                the host reads the counts of batch i while the device runs batch i + 1: no bubble on the device.
+
+    Timing: every batch's collective(s) are bracketed by events on the side stream (`gather_ms()`: mean duration since `reset_timings()`)."""
+
+    def __init__(self, cap_rows, group=None, depth=2, device=None, mode="ring", lag=False):
+        if mode not in GATHER_MODES:
+            raise ValueError(f"gather mode {mode!r}: one of {GATHER_MODES}")
+        self.cap, self.group, self.depth, self.mode, self.lag = int(cap_rows), group, depth, mode, lag
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         self.device = device if device is not None else torch.device("cpu")
         self.cuda = self.device.type == "cuda"
+        self.staged = self.cuda and dist.get_backend(group) == "gloo"  # test runs on a one-GPU box: collectives staged through the host
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
         rows = self.cap + 1
+        ev = (lambda: torch.cuda.Event()) if self.cuda else (lambda: None)
         self.bufs = [{"payload": torch.zeros((rows, 4), dtype=torch.int64, device=self.device),
                       "all": torch.zeros((self.world * rows, 4), dtype=torch.int64, device=self.device),
-                      "scored": torch.cuda.Event() if self.cuda else None, "packed": torch.cuda.Event() if self.cuda else None,
-                      "work": None, "unordered": False} for _ in range(depth)]
+                      "counts_dev": torch.zeros(self.world, dtype=torch.int64, device=self.device),
+                      "counts_host": torch.zeros(self.world, dtype=torch.int64, pin_memory=self.cuda),
+                      "scored": ev(), "packed": ev(), "counted": ev(), "done": ev(),
+                      "busy": False, "pending": False, "works": [], "unordered": False} for _ in range(depth)]
         self.i = 0
+        self._pending = []   # submitted batches whose exchange has not been issued yet (lag mode: until the next flush())
+        self._timed = []     # (start event, end event) pairs on the side stream / (seconds,) on CPU
+        self.steps_timed = 0
 
-    def _all_gather(self, b):
-        """One all-gather of b["payload"] into b["all"].  nccl (= RCCL): asynchronous, device to device.  gloo has no all-gather of
-        device tensors: the payload is staged through host memory, synchronously (how a one-GPU box runs the N-rank bench path: every
-        rank on the same device, tests/test_gpu_multi.py; never the driver's path)."""
-        if self.cuda and dist.get_backend(self.group) == "gloo":
+    # -- timing ---------------------------------------------------------------------------------------------------------------------
+    def reset_timings(self):
+        self._timed = []
+
+    def _bracket(self):
+        if self.cuda:
+            return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        return None, None
+
+    def gather_ms(self):
+        """Mean duration of a batch's collective(s) since reset_timings(), in ms (events on the side stream; call after finish())."""
+        per_batch = {}
+        for key, a, b in self._timed[-4096:]:
+            per_batch[key] = per_batch.get(key, 0.0) + (a.elapsed_time(b) if self.cuda else (b - a) * 1e3)
+        return sum(per_batch.values()) / len(per_batch) if per_batch else 0.0
+
+    # -- the two forms of the exchange ----------------------------------------------------------------------------------------------
+    def _peer(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _ring(self, b):
+        """One all-gather of b["payload"] into b["all"] (current stream = the side stream on CUDA)."""
+        if self.staged:
             torch.cuda.current_stream().synchronize()
             host_all = torch.empty(b["all"].shape, dtype=b["all"].dtype)
             dist.all_gather_into_tensor(host_all, b["payload"].cpu(), group=self.group)
             b["all"].copy_(host_all)
-            torch.cuda.current_stream().synchronize()
-            return _DoneWork()
-        return dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)
+            return []
+        return [dist.all_gather_into_tensor(b["all"], b["payload"], group=self.group, async_op=True)]
 
+    def _counts(self, b):
+        """direct, first half: every rank's count (row 0 of its payload) to every rank, and on to the host (which waits for them)."""
+        mine = b["payload"][0, :1]
+        if self.staged:
+            torch.cuda.current_stream().synchronize()
+            dist.all_gather_into_tensor(b["counts_host"], mine.cpu(), group=self.group)
+        elif not self.cuda:
+            dist.all_gather_into_tensor(b["counts_host"], mine.contiguous(), group=self.group)
+        else:
+            w = dist.all_gather_into_tensor(b["counts_dev"], mine, group=self.group, async_op=True)
+            w.wait()  # the side stream waits, not the host
+            b["counts_host"].copy_(b["counts_dev"], non_blocking=True)
+            b["counted"].record(torch.cuda.current_stream())
+            b["counted"].synchronize()  # the host needs the sizes of the send / recv calls
+        b["counts"] = [int(c) for c in b["counts_host"].tolist()]
+        return []
+
+    def _exchange(self, b):
+        """direct, second half: 1 + count rows to and from every peer, each pair of ranks on its own."""
+        counts = b["counts"]
+        if max(counts) > self.cap:  # every rank sees the same counts: every rank stops here, nothing has been posted
+            b["overflow"] = max(counts)
+            return []
+        rows = self.cap + 1
+        mine = 1 + counts[self.rank]
+        src = b["payload"][:mine]
+        if self.staged or not self.cuda:
+            host_src = src.cpu() if self.cuda else src
+            host_all = torch.zeros(b["all"].shape, dtype=b["all"].dtype) if self.cuda else b["all"]
+            host_all[self.rank * rows: self.rank * rows + mine] = host_src
+            ops = []
+            for p in range(self.world):
+                if p != self.rank:
+                    ops.append(dist.P2POp(dist.isend, host_src, self._peer(p), self.group))
+                    ops.append(dist.P2POp(dist.irecv, host_all[p * rows: p * rows + 1 + counts[p]], self._peer(p), self.group))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            if self.cuda:
+                b["all"].copy_(host_all)
+            return []
+        b["all"][self.rank * rows: self.rank * rows + mine].copy_(src, non_blocking=True)
+        ops = []
+        for p in range(self.world):
+            if p != self.rank:
+                ops.append(dist.P2POp(dist.isend, src, self._peer(p), self.group))
+                ops.append(dist.P2POp(dist.irecv, b["all"][p * rows: p * rows + 1 + counts[p]], self._peer(p), self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _run_timed(self, b, key, fn):
+        """fn(b) on the side stream between two events; the side stream waits for the works fn returns."""
+        if self.cuda:
+            with torch.cuda.stream(self.side):
+                t0, t1 = self._bracket()
+                t0.record(self.side)
+                for w in fn(b) or []:
+                    w.wait()
+                t1.record(self.side)
+            self._timed.append((key, t0, t1))
+        else:
+            import time
+
+            t0 = time.perf_counter()
+            for w in fn(b) or []:
+                w.wait()
+            self._timed.append((key, t0, time.perf_counter()))
+
+    def _issue(self, b, gate=None):
+        """The exchange of one submitted batch: on the side stream, behind the work that wrote its payload.  gate: called with the side
+        stream current in front of the collective(s) (StreamedGather: hc_comm_gate_device)."""
+        key, on_side = b["key"], b.pop("on_side", None)
+        if self.cuda:
+            self.side.wait_event(b["scored"])
+            with torch.cuda.stream(self.side):
+                if on_side:
+                    on_side()
+                if gate:
+                    gate()
+        elif on_side:
+            on_side()
+        if self.mode == "ring":
+            self._run_timed(b, key, self._ring)
+        else:
+            self._run_timed(b, key, self._counts)
+            self._run_timed(b, key, self._exchange)
+        if self.cuda:
+            b["done"].record(self.side)
+        b["pending"] = False
+
+    def flush(self, gate=None):
+        """lag mode: the exchanges of the batches submitted so far.  StreamedGather calls it right behind the NEXT batch's kernel launch (with
+        the gate that waits for that kernel's workgroups to have started); collect / finish / a buffer set's reuse call it without one."""
+        while self._pending:
+            self._issue(self._pending.pop(0), gate)
+
+    # -- the batch protocol ---------------------------------------------------------------------------------------------------------
     def next_buffers(self):
-        """The buffer set of the next batch; its payload may be written once the all-gather that last used it is done
-        (on CUDA the current stream is made to wait for it, on CPU the call blocks)."""
+        """The buffer set of the next batch; its payload may be written once the exchange that last used it is done
+        (on CUDA the current stream is made to wait for it, on CPU it has completed already)."""
         b = self.bufs[self.i % self.depth]
         self.i += 1
-        if b["work"] is not None:
-            b["work"].wait()
-            b["work"] = None
+        if b["pending"]:
+            self.flush()
+        if b["busy"]:
+            if self.cuda:
+                torch.cuda.current_stream().wait_event(b["done"])
+            b["busy"] = False
+        b.pop("overflow", None)
+        b.pop("counts", None)
         return b
 
-    def submit(self, b):
-        """Launch the all-gather of b["payload"] (written by work already enqueued on the current stream)."""
+    def submit(self, b, on_side=None):
+        """Hand over b["payload"] (written by work already enqueued on the current stream, or by on_side(), which is called with the side
+        stream current, behind that work).  lag = False: the exchange is issued here.  lag = True: at the next flush()."""
+        b["key"] = self.steps_timed
+        self.steps_timed += 1
         if self.cuda:
             b["scored"].record(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(b["scored"])
-                b["work"] = self._all_gather(b)
-        else:
-            b["work"] = self._all_gather(b)
+        b["busy"], b["pending"], b["on_side"] = True, True, on_side
+        self._pending.append(b)
+        if not self.lag:
+            self.flush()
         return b
+
+    def _wait(self, b):
+        if b["pending"]:
+            self.flush()
+        if self.cuda and b["busy"]:
+            b["done"].synchronize()
 
     def collect(self, b):
         """Host side of one batch: (rows [sum k_r, 4] int64 ordered by global index, counts per rank)."""
-        if b["work"] is not None:
-            if self.cuda:
-                with torch.cuda.stream(self.side):
-                    b["work"].wait()
-                self.side.synchronize()
-            else:
-                b["work"].wait()
+        self._wait(b)
         rows = self.cap + 1
+        if b.get("overflow"):
+            raise OverflowError(f"a rank produced {b['overflow']} records, capacity is {self.cap}: rerun the batch with a larger cap_rows")
         counts = [int(b["all"][r * rows, 0]) for r in range(self.world)]
         if max(counts) > self.cap:
             raise OverflowError(f"a rank produced {max(counts)} records, capacity is {self.cap}: rerun the batch with a larger cap_rows")
+        if self.mode == "direct" and counts != b.get("counts"):
+            raise RuntimeError(f"direct all-gather-v: the counts that travelled with the payloads {counts} are not the gathered counts {b.get('counts')}")
         out = torch.cat([b["all"][r * rows + 1: r * rows + 1 + counts[r]] for r in range(self.world)], dim=0)
         if b.get("unordered"):  # rows appended by the scoring kernel arrive in any order; they carry their index
             out = out[torch.argsort(out[:, 0])]
         return out, counts
 
     def finish(self):
-        for b in self.bufs:
-            if b["work"] is not None:
-                if self.cuda:
-                    with torch.cuda.stream(self.side):
-                        b["work"].wait()
-                else:
-                    b["work"].wait()
-                b["work"] = None
+        self.flush()
         if self.cuda:
             self.side.synchronize()
             torch.cuda.current_stream().synchronize()
+        for b in self.bufs:
+            b["busy"] = False
 
 
 class StreamedGather(PayloadGather):
     """PayloadGather fed by the device — what `bench.py --gpus N` runs: no host round trip per batch.
 
     score_step: `hc_score_pack_device` — the scoring kernel's row-appending twin writes the payload itself (rows
-    unordered), then the all-gather on a side stream, overlapping the scoring kernel of the next batch.
+    unordered); the exchange goes out on a side stream right behind the launch of the NEXT batch's kernel, which it overlaps.
     step: for results that exist already: `hc_compact_pack_device` (the library's own ordered selection + pack kernel, rows ordered) on the
     side stream; call before_write(results) before overwriting a results tensor that a step may still be reading.
     """
 
-    def __init__(self, scorer, n_local, base_index, cap_rows, group=None, depth=2, rec_fmt=0):
-        super().__init__(cap_rows, group, depth, torch.device("cuda", torch.cuda.current_device()))
+    def __init__(self, scorer, n_local, base_index, cap_rows, group=None, depth=2, rec_fmt=0, mode="ring", reserve_cus=0):
+        super().__init__(cap_rows, group, depth, torch.device("cuda", torch.cuda.current_device()), mode, lag=True)
         self.sc, self.n, self.base, self.fmt = scorer, int(n_local), int(base_index), int(rec_fmt)  # rec_fmt: records.REC_FULL / REC_COMPACT
+        # reserve_cus > 0: the scoring launches leave that many CUs to the collective library's kernels, and every exchange waits (a gate
+        # kernel on the side stream) until the scoring kernel it runs beside has taken its CUs: hc_set_comm_reserve / hc_comm_gate_device
+        self.reserve = int(reserve_cus)
+        self.sc.set_comm_reserve(self.reserve)
         # zero-initialised: entries beyond the count of a batch are stale but always valid indices
         self.idx = torch.zeros(max(self.n, 1), dtype=torch.int32, device=self.device)
         self.count = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -188,6 +326,8 @@ class StreamedGather(PayloadGather):
         b = self.next_buffers()
         b["unordered"] = self.sc.score_pack_device(d_in_ptr, self.n, d_results.data_ptr(), self.cap, self.base, b["payload"].data_ptr(),
                                                    torch.cuda.current_stream().cuda_stream, self.fmt)
+        # the exchange of the batch BEFORE this one goes out now: it runs beside this batch's kernel, which is in the stream already
+        self.flush(gate=(lambda: self.sc.comm_gate_device(self.side.cuda_stream)) if self.reserve else None)
         return self.submit(b)
 
     def before_write(self, d_results):
@@ -200,13 +340,13 @@ class StreamedGather(PayloadGather):
         """Collect a batch whose n result records were written by work already enqueued on the current stream."""
         b = self.next_buffers()
         b["unordered"] = False
-        b["scored"].record(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(b["scored"])
-            # (self.idx / self.count are shared: consecutive batches are ordered on the side stream)
+
+        def pack():  # (self.idx / self.count are shared: consecutive batches are ordered on the side stream)
             self.sc.compact_pack_device(d_results.data_ptr(), self.n, self.idx.data_ptr(), self.count.data_ptr(), self.cap, self.base,
                                         b["payload"].data_ptr(), self.side.cuda_stream)
             b["packed"].record(self.side)
             self.packed[d_results.data_ptr()] = b["packed"]
-            b["work"] = self._all_gather(b)
+
+        self.submit(b, on_side=pack)
+        self.flush()  # (results that exist already: nothing to run beside, the pack and the exchange go out at once)
         return b

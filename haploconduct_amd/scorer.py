@@ -292,6 +292,14 @@ class EdgeScorer:
                                            C.c_void_p(d_payload_ptr), C.c_void_p(stream or 0)), "hc_score_pack_device")
         return True
 
+    def set_comm_reserve(self, cus):
+        """hc_set_comm_reserve: launches leave `cus` CUs to the kernels of the multi-GPU exchange (0: none)."""
+        N.check(N.lib.hc_set_comm_reserve(self._ctx, int(cus)), "hc_set_comm_reserve")
+
+    def comm_gate_device(self, stream, timeout_us=0):
+        """hc_comm_gate_device: `stream` continues once the workgroups of the score_pack_device launches enqueued so far have started."""
+        N.check(N.lib.hc_comm_gate_device(self._ctx, C.c_void_p(stream or 0), int(timeout_us)), "hc_comm_gate_device")
+
     def compact_pack_device(self, d_results_ptr, n, d_indices_ptr, d_count_ptr, cap, base_index, d_payload_ptr, stream=None):
         """hc_compact_pack_device: compaction + pack, the count in row 0 of the (cap + 1)-row payload."""
         N.check(N.lib.hc_compact_pack_device(self._ctx, C.c_void_p(d_results_ptr), n, C.c_void_p(d_indices_ptr), C.c_void_p(d_count_ptr),

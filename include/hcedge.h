@@ -290,6 +290,18 @@ int hc_compact_pack_device(hc_ctx* ctx, const void* d_results, uint64_t n, void*
 int hc_score_pack_device(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index,
                          void* d_payload, void* hip_stream);
 
+/* The multi-GPU step: the per-step exchange of the kept rows runs on a side stream BESIDE the next step's scoring
+ * kernel, and the scoring kernel's large launches hold one workgroup per CU for the launch's whole duration (145 KiB of LDS, 480 of a
+ * SIMD's 512 registers): a collective library's kernels find no room on a CU that holds one.  hc_set_comm_reserve(cus): launches of
+ * this context leave `cus` CUs without a workgroup (0: none, the default) — the exchange's kernels run there.  hc_comm_gate_device:
+ * enqueues on `hip_stream` (the exchange's stream) a one-lane kernel that returns once every workgroup of the hc_score_pack_device
+ * launches enqueued on this context SO FAR has started (or after timeout_us; 0 = 2 000): put in front of the collective, it makes
+ * the collective's kernels arrive when the scoring kernel beside them already sits on its CUs, so they take the free ones instead
+ * of being spread over CUs the scoring workgroups then cannot use.  No reference analogue (single process:
+ * src/ViralQuasispecies.cpp:279-283).  Without a reserve nothing is counted and the gate returns at once. */
+int hc_set_comm_reserve(hc_ctx* ctx, uint32_t cus);
+int hc_comm_gate_device(hc_ctx* ctx, void* hip_stream, uint32_t timeout_us);
+
 /* hc_score_batch + compaction in one call for host callers: scores `in` on the device and copies back
  * only the non-DROP records: idx_out[k] (ascending) and res_out[k] = result of in[idx_out[k]].
  * cap = capacity of idx_out / res_out in records; *n_out = number of non-DROP records (if it exceeds

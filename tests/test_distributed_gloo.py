@@ -1,4 +1,4 @@
-"""World-size-2 test of the multi-GPU path on CPU (gloo): ONE candidate set split into contiguous, order-preserving
+"""World-size-2/4/8 test of the multi-GPU path on CPU (gloo): ONE candidate set split into contiguous, order-preserving
 shards (parallel.shard_range — what `bench.py --gpus N --scaling strong` does with the 1e8 candidates; an odd count, so
 the shards differ in size), one all-gather-v of the admitted records, same admitted set as the single-process run.
 The scoring itself is stood in for by the oracle here (no GPU in this container); on the GPU box the same functions
@@ -9,6 +9,7 @@ import sys
 import tempfile
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -42,28 +43,45 @@ np.save(os.path.join(os.environ["HC_OUT"], f"counts{rank}.npy"), np.array(counts
 kept = int((res["n_cls"] >> 28 != 0).sum())
 cap = torch.tensor([kept])
 dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-pg = parallel.PayloadGather(int(cap.item()) + 5, depth=2)
-last = None
-for it in range(5):
-    b = pg.next_buffers()
-    b["payload"].copy_(parallel.pack_payload(res, lo, pg.cap, shuffle_seed=100 * rank + it))
-    b["unordered"] = True
-    last = pg.submit(b)
-prows, pcounts = pg.collect(last)
-pg.finish()
-np.save(os.path.join(os.environ["HC_OUT"], f"prows{rank}.npy"), prows.numpy())
-np.save(os.path.join(os.environ["HC_OUT"], f"pcounts{rank}.npy"), np.array(pcounts))
 lowest = torch.tensor([kept])
 dist.all_reduce(lowest, op=dist.ReduceOp.MIN)  # one capacity for all ranks: the payloads must have one size
-small = parallel.PayloadGather(max(1, int(lowest.item()) // 3))
-b = small.next_buffers()
-b["payload"].copy_(parallel.pack_payload(res, lo, small.cap))
-try:
-    small.collect(small.submit(b))
-    overflow = False
-except OverflowError:
-    overflow = True
-np.save(os.path.join(os.environ["HC_OUT"], f"overflow{rank}.npy"), np.array([overflow]))
+for mode in parallel.GATHER_MODES:  # "ring": one all-gather of the fixed-capacity payload; "direct": counts + per-peer send / recv of 1 + count rows
+    pg = parallel.PayloadGather(int(cap.item()) + 5, depth=2, mode=mode)
+    last = None
+    for it in range(5):
+        b = pg.next_buffers()
+        b["payload"].copy_(parallel.pack_payload(res, lo, pg.cap, shuffle_seed=100 * rank + it))
+        b["unordered"] = True
+        last = pg.submit(b)
+    prows, pcounts = pg.collect(last)
+    pg.finish()
+    assert pg.gather_ms() > 0.0 and pg.steps_timed == 5
+    # lag mode (what StreamedGather.score_step does): the exchange of batch i is issued behind the hand-over of batch i + 1
+    lg = parallel.PayloadGather(int(cap.item()) + 5, depth=2, mode=mode, lag=True)
+    for it in range(5):
+        b = lg.next_buffers()
+        b["payload"].copy_(parallel.pack_payload(res, lo, lg.cap, shuffle_seed=7 * rank + it))
+        b["unordered"] = True
+        lg.flush()
+        assert not lg._pending
+        last = lg.submit(b)
+        assert last["pending"] and len(lg._pending) == 1
+    lrows, lcounts = lg.collect(last)
+    lg.finish()
+    assert torch.equal(lrows, prows) and lcounts == pcounts and lg.steps_timed == 5
+    np.save(os.path.join(os.environ["HC_OUT"], f"prows_{mode}{rank}.npy"), prows.numpy())
+    np.save(os.path.join(os.environ["HC_OUT"], f"pcounts_{mode}{rank}.npy"), np.array(pcounts))
+    small = parallel.PayloadGather(max(1, int(lowest.item()) // 3), mode=mode)
+    b = small.next_buffers()
+    b["payload"].copy_(parallel.pack_payload(res, lo, small.cap))
+    try:
+        small.collect(small.submit(b))
+        overflow = False
+    except OverflowError:
+        overflow = True
+    small.finish()
+    np.save(os.path.join(os.environ["HC_OUT"], f"overflow_{mode}{rank}.npy"), np.array([overflow]))
+    dist.barrier()
 dist.destroy_process_group()
 '''
 
@@ -80,9 +98,10 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gather_equals_single_process(oracle):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_n_rank_gather_equals_single_process(oracle, world):
     import haploconduct_amd as hc
-    from haploconduct_amd import synth
+    from haploconduct_amd import parallel, synth
 
     with tempfile.TemporaryDirectory() as d:
         script = os.path.join(d, "worker.py")
@@ -93,19 +112,20 @@ def test_two_rank_gather_equals_single_process(oracle):
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
         procs = []
-        for r in range(2):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", HC_PORT=port, HC_ROOT=ROOT, HC_OUT=d,
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), HC_PORT=port, HC_ROOT=ROOT, HC_OUT=d,
                        OMP_NUM_THREADS="1")
             procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         for p in procs:
             out, _ = p.communicate(timeout=300)
             assert p.returncode == 0, out.decode()[-2000:]
-        rows0, rows1 = np.load(os.path.join(d, "rows0.npy")), np.load(os.path.join(d, "rows1.npy"))
+        rows = [np.load(os.path.join(d, f"rows{r}.npy")) for r in range(world)]
+        rows0 = rows[0]
         counts = np.load(os.path.join(d, "counts0.npy"))
-        prows = [np.load(os.path.join(d, f"prows{r}.npy")) for r in range(2)]
-        pcounts = [np.load(os.path.join(d, f"pcounts{r}.npy")) for r in range(2)]
-        overflow = [bool(np.load(os.path.join(d, f"overflow{r}.npy"))[0]) for r in range(2)]
-    assert np.array_equal(rows0, rows1), "every rank must hold the same gathered set"
+        prows = {m: [np.load(os.path.join(d, f"prows_{m}{r}.npy")) for r in range(world)] for m in parallel.GATHER_MODES}
+        pcounts = {m: [np.load(os.path.join(d, f"pcounts_{m}{r}.npy")) for r in range(world)] for m in parallel.GATHER_MODES}
+        overflow = {m: [bool(np.load(os.path.join(d, f"overflow_{m}{r}.npy"))[0]) for r in range(world)] for m in parallel.GATHER_MODES}
+    assert all(np.array_equal(rows0, r) for r in rows), "every rank must hold the same gathered set"
     reads, meta = synth.make_paired_dataset(500, 1500, flip_frac=0.2, seed=5)
     reads.quals[:] = ord("I")
     cand = synth.paired_candidates(meta, n_candidates=5001, seed=6)
@@ -114,11 +134,15 @@ def test_two_rank_gather_equals_single_process(oracle):
     assert want.size > 50
     assert np.array_equal(rows0[:, 0], want), "admitted set / order differs from the single-process run"
     assert np.array_equal(rows0[:, 1].view(np.float64).view(np.uint64), ref["x1"][want].view(np.uint64))
-    assert counts.sum() == want.size and len(counts) == 2
-    # the single-all-gather payload form: every non-dropped record (edges and non-edges), on both ranks, in global order
+    assert counts.sum() == want.size and len(counts) == world
+    # the payload forms (ring: one all-gather of the fixed-capacity payload; direct: counts, then 1 + count rows per pair of ranks): every
+    # non-dropped record (edges and non-edges), on every rank, in global order — and the two forms bit-identical
     kept = np.nonzero(ref["cls"] != 0)[0]
-    assert np.array_equal(prows[0], prows[1]) and np.array_equal(pcounts[0], pcounts[1]) and pcounts[0].sum() == kept.size
-    assert np.array_equal(prows[0][:, 0], kept)
-    assert np.array_equal(prows[0][:, 1].view(np.float64).view(np.uint64), ref["x1"][kept].view(np.uint64))
-    assert np.array_equal(prows[0][:, 3] >> 60, ref["cls"][kept].astype(np.int64))
-    assert overflow == [True, True]
+    for m in parallel.GATHER_MODES:
+        assert all(np.array_equal(prows[m][0], r) for r in prows[m]) and all(np.array_equal(pcounts[m][0], c) for c in pcounts[m])
+        assert pcounts[m][0].sum() == kept.size and len(pcounts[m][0]) == world
+        assert np.array_equal(prows[m][0][:, 0], kept)
+        assert np.array_equal(prows[m][0][:, 1].view(np.float64).view(np.uint64), ref["x1"][kept].view(np.uint64))
+        assert np.array_equal(prows[m][0][:, 3] >> 60, ref["cls"][kept].astype(np.int64))
+        assert overflow[m] == [True] * world
+    assert np.array_equal(prows["ring"][0], prows["direct"][0])

@@ -148,40 +148,41 @@ def test_rccl_gather_path_single_rank():
             sc.synchronize()
             rows, counts = parallel.gather_admitted(d_out, 0)
             host = d_out.cpu().numpy().view(hc.RESULT_DTYPE)
-            # the streamed form (no host round trip per batch): non-dropped records, tagged with base + index
-            cls0 = result_cls(host)
-            kept = np.nonzero(cls0 != 0)[0]
-            g = parallel.StreamedGather(sc, cand.size, base_index=1000, cap_rows=kept.size + 7)
-            stream = torch.cuda.current_stream().cuda_stream
-            last = None
-            for _ in range(5):  # more batches than buffers: exercises the reuse
-                sc.score_batch_device(d_in.data_ptr(), cand.size, d_out.data_ptr(), stream)
-                last = g.step(d_out)
-            srows, scounts = g.collect(last)
-            g.finish()
-            srows = srows.cpu().numpy()
-            assert scounts == [kept.size] and np.array_equal(srows[:, 0], kept + 1000)
-            assert np.array_equal(srows[:, 1].view(np.uint64), host["x1"][kept].view(np.uint64))
-            assert np.array_equal(srows[:, 2].view(np.uint64), host["x2"][kept].view(np.uint64))
-            assert np.array_equal(srows[:, 3].view(np.uint64), host["mm"][kept].astype(np.uint64) | (host["n_cls"][kept].astype(np.uint64) << 32))
-            # the fused form: the scoring kernel appends the payload itself (rows unordered until collect() sorts them)
-            g2 = parallel.StreamedGather(sc, cand.size, base_index=7, cap_rows=kept.size + 3)
-            for _ in range(4):
-                last = g2.score_step(d_in.data_ptr(), d_out)
-            assert last["unordered"]
-            frows, fcounts = g2.collect(last)
-            g2.finish()
-            frows = frows.cpu().numpy()
-            assert fcounts == [kept.size] and np.array_equal(frows[:, 0], kept + 7)
-            assert np.array_equal(frows[:, 1].view(np.uint64), host["x1"][kept].view(np.uint64))
-            assert np.array_equal(frows[:, 3].view(np.uint64), host["mm"][kept].astype(np.uint64) | (host["n_cls"][kept].astype(np.uint64) << 32))
-            assert np.array_equal(d_out.cpu().numpy().view(hc.RESULT_DTYPE).tobytes(), host.tobytes())  # the results themselves are unchanged
-            small = parallel.StreamedGather(sc, cand.size, base_index=0, cap_rows=max(1, kept.size // 2))
-            with pytest.raises(OverflowError):
-                small.collect(small.step(d_out))
-            with pytest.raises(OverflowError):  # the fused form (per-workgroup segments moved into a payload that is too small)
-                small.collect(small.score_step(d_in.data_ptr(), d_out))
-            small.finish()
+            for mode in parallel.GATHER_MODES:  # ring: one all-gather of the fixed-capacity payload; direct: counts + per-peer send / recv (no peer at world size 1)
+                # the streamed form (no host round trip per batch): non-dropped records, tagged with base + index
+                cls0 = result_cls(host)
+                kept = np.nonzero(cls0 != 0)[0]
+                g = parallel.StreamedGather(sc, cand.size, base_index=1000, cap_rows=kept.size + 7, mode=mode)
+                stream = torch.cuda.current_stream().cuda_stream
+                last = None
+                for _ in range(5):  # more batches than buffers: exercises the reuse
+                    sc.score_batch_device(d_in.data_ptr(), cand.size, d_out.data_ptr(), stream)
+                    last = g.step(d_out)
+                srows, scounts = g.collect(last)
+                g.finish()
+                srows = srows.cpu().numpy()
+                assert scounts == [kept.size] and np.array_equal(srows[:, 0], kept + 1000)
+                assert np.array_equal(srows[:, 1].view(np.uint64), host["x1"][kept].view(np.uint64))
+                assert np.array_equal(srows[:, 2].view(np.uint64), host["x2"][kept].view(np.uint64))
+                assert np.array_equal(srows[:, 3].view(np.uint64), host["mm"][kept].astype(np.uint64) | (host["n_cls"][kept].astype(np.uint64) << 32))
+                # the fused form: the scoring kernel appends the payload itself (rows unordered until collect() sorts them)
+                g2 = parallel.StreamedGather(sc, cand.size, base_index=7, cap_rows=kept.size + 3, mode=mode)
+                for _ in range(4):
+                    last = g2.score_step(d_in.data_ptr(), d_out)
+                assert last["unordered"]
+                frows, fcounts = g2.collect(last)
+                g2.finish()
+                frows = frows.cpu().numpy()
+                assert fcounts == [kept.size] and np.array_equal(frows[:, 0], kept + 7)
+                assert np.array_equal(frows[:, 1].view(np.uint64), host["x1"][kept].view(np.uint64))
+                assert np.array_equal(frows[:, 3].view(np.uint64), host["mm"][kept].astype(np.uint64) | (host["n_cls"][kept].astype(np.uint64) << 32))
+                assert np.array_equal(d_out.cpu().numpy().view(hc.RESULT_DTYPE).tobytes(), host.tobytes())  # the results themselves are unchanged
+                small = parallel.StreamedGather(sc, cand.size, base_index=0, cap_rows=max(1, kept.size // 2), mode=mode)
+                with pytest.raises(OverflowError):
+                    small.collect(small.step(d_out))
+                with pytest.raises(OverflowError):  # the fused form (per-workgroup segments moved into a payload that is too small)
+                    small.collect(small.score_step(d_in.data_ptr(), d_out))
+                small.finish()
         cls = result_cls(host)
         want = np.nonzero((cls >= 2) & (cls <= 4))[0]
         assert counts == [want.size] and want.size > 100

@@ -1,6 +1,7 @@
 """More than one GPU, when the box has them: bench.py's N-rank step (candidate shards against a replicated read store, one
 RCCL all-gather of the non-dropped records per step) launched the way the driver launches it — torch.distributed.run, one
-process per GPU — as a child process.  RCCL must have seen every rank, and the rows every rank ends up with must be the
+process per GPU — as a child process, with either form of the per-step exchange (ring: one all-gather of the fixed-capacity payload; direct:
+all-gather-v by counts + grouped per-peer send / recv).  RCCL must have seen every rank, and the rows every rank ends up with must be the
 non-dropped records of the whole candidate set, i.e. what ONE device computes for it.  Skipped on a one-GPU box (no curve
 has been measured by the builder: the first real 2/4/8-GPU numbers are the driver's)."""
 import json
@@ -29,8 +30,8 @@ def _n_devices():
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-@pytest.mark.parametrize("scaling", ["strong", "weak"])
-def test_ranks_over_rccl_collect_what_one_device_computes(tmp_path, scaling, world):
+@pytest.mark.parametrize("scaling,gather", [("strong", "ring"), ("strong", "direct"), ("weak", "ring"), ("weak", "direct")])
+def test_ranks_over_rccl_collect_what_one_device_computes(tmp_path, scaling, gather, world):
     n_dev = _n_devices()
     if n_dev < world:
         pytest.skip(f"{n_dev} GPU(s) visible: this case needs {world}")
@@ -38,11 +39,13 @@ def test_ranks_over_rccl_collect_what_one_device_computes(tmp_path, scaling, wor
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-           "--workload", "c2", "--scaling", scaling, "--one-mode", "--no-stage", "--no-cpu-baseline", "--also", "none", "--dump-rows", rows_file]
+           "--workload", "c2", "--scaling", scaling, "--one-mode", "--gather", gather, "--no-stage", "--no-cpu-baseline", "--also", "none",
+           "--dump-rows", rows_file]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == world and line["scaling"] == scaling
+    assert line["n_gpus"] == world and line["scaling"] == scaling and line["config"]["gather"] == gather and line["ranks"]["gather"] == gather
+    assert all(p["gather_ms"] > 0 for p in line["ranks"]["per_rank"]) and line["summary"]["gather"] == gather
     ranks = line["ranks"]
     assert ranks["n_ranks_seen"] == world and len(ranks["per_rank"]) == world, "RCCL did not see every rank"
     assert all(p["n_ranks_seen"] == world and p["kernel_ms"] > 0 for p in ranks["per_rank"])
@@ -73,9 +76,28 @@ def test_ranks_over_rccl_collect_what_one_device_computes(tmp_path, scaling, wor
     assert sum(p["candidates"] for p in ranks["per_rank"]) == expected_total
 
 
+def _check_default_line(line, world):
+    """The driver's command line (no --scaling, no --one-mode, no --gather): the headline is the STRONG split of the one candidate set
+    (BASELINE configs[2]), the weak figure rides along under "weak" with its own per-rank record, both forms of the exchange ran as full
+    legs ("gather_modes") and the faster one is the headline; every leg passed its in-run parity checks; "summary" closes the line."""
+    assert line["n_gpus"] == world and line["scaling"] == "strong"
+    assert line["config"]["candidates_per_step"] == 2000000 and f"split over {world} ranks" in line["config"]["workload"]
+    assert sum(p["candidates"] for p in line["ranks"]["per_rank"]) == line["config"]["candidates_per_step"]
+    assert line["ranks"]["n_ranks_seen"] == world and len(line["ranks"]["per_rank"]) == world
+    wk = line["weak"]
+    assert wk["scaling"] == "weak" and wk["candidates_per_step"] == world * 2000000 and wk["ranks"]["n_ranks_seen"] == world
+    assert sum(p["candidates"] for p in wk["ranks"]["per_rank"]) == wk["candidates_per_step"]
+    assert line["parity"]["digest_matches_untimed_launch"] and wk["parity"]["digest_matches_untimed_launch"] and line["parity"]["parity_checked_records"] > 0
+    gm = line["gather_modes"]
+    assert set(gm) == {"ring", "direct"} and all(v["value"] > 0 and v["parity"]["digest_matches_untimed_launch"] for v in gm.values())
+    assert gm["ring"]["parity"]["digest"] == gm["direct"]["parity"]["digest"], "the two forms of the exchange must leave the same results"
+    best = max(gm, key=lambda m: gm[m]["value"])
+    assert line["config"]["gather"] == best and line["value"] == gm[best]["value"]
+    assert list(line)[-1] == "summary" and line["summary"]["value"] == line["value"] and line["summary"]["weak"]["value"] == wk["value"]
+
+
 def test_one_pass_yields_both_curves():
-    """The driver's command line (no --scaling, no --one-mode) at N = 2: the headline is the weak figure, the strong split of the one
-    candidate set rides along under "strong" with its own per-rank record, and both passed their in-run parity checks."""
+    """The driver's command line at N = 2 over RCCL (see _check_default_line)."""
     n_dev = _n_devices()
     if n_dev < 2:
         pytest.skip(f"{n_dev} GPU(s) visible: the N > 1 path needs two")
@@ -85,12 +107,7 @@ def test_one_pass_yields_both_curves():
            "--workload", "c2", "--no-stage", "--no-cpu-baseline", "--also", "none"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["scaling"] == "weak" and line["config"]["candidates_per_step"] == 2 * line["config"]["candidates_per_gpu"]
-    st = line["strong"]
-    assert st["scaling"] == "strong" and st["candidates_per_step"] == line["config"]["candidates_per_gpu"]
-    assert st["ranks"]["n_ranks_seen"] == 2 and sum(p["candidates"] for p in st["ranks"]["per_rank"]) == st["candidates_per_step"]
-    assert st["parity"]["digest_matches_untimed_launch"] and line["parity"]["parity_checked_records"] > 0
+    _check_default_line(json.loads(r.stdout.strip().splitlines()[-1]), 2)
 
 
 def test_hc_edgecalc_device_mask_over_real_devices(tmp_path):
@@ -135,20 +152,19 @@ def test_n_rank_bench_path_on_one_gpu_over_gloo(tmp_path, world):
                        timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert "test_run" in line["config"] and line["n_gpus"] == world and line["scaling"] == "weak"
-    assert line["config"]["candidates_per_step"] == world * line["config"]["candidates_per_gpu"]
-    assert line["ranks"]["n_ranks_seen"] == world and len(line["ranks"]["per_rank"]) == world
-    st = line["strong"]
-    assert st["candidates_per_step"] == line["config"]["candidates_per_gpu"] and st["ranks"]["n_ranks_seen"] == world
-    assert sum(p["candidates"] for p in st["ranks"]["per_rank"]) == st["candidates_per_step"]
-    assert line["parity"]["digest_matches_untimed_launch"] and st["parity"]["digest_matches_untimed_launch"]
-    assert line["value"] > 0 and st["value"] > 0
-    # (2) the strong split's gathered rows are the one-device result
-    rows_file = str(tmp_path / "rows.npy")
-    r = subprocess.run(base + ["--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + tail +
-                       ["--scaling", "strong", "--one-mode", "--dump-rows", rows_file], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stderr[-3000:]
-    rows = np.load(rows_file)
+    assert "test_run" in line["config"]
+    _check_default_line(line, world)
+    # (2) the strong split's gathered rows are the one-device result, by either form of the exchange
+    rows = {}
+    for gather in ("ring", "direct"):
+        rows_file = str(tmp_path / f"rows_{gather}.npy")
+        r = subprocess.run(base + ["--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + tail +
+                           ["--scaling", "strong", "--one-mode", "--gather", gather, "--dump-rows", rows_file], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        rows[gather] = np.load(rows_file)
+    assert np.array_equal(rows["ring"], rows["direct"])
+    rows = rows["ring"]
     import bench
     import haploconduct_amd as hc
     from haploconduct_amd.records import result_cls
