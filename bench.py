@@ -501,7 +501,7 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
     # CUs the scoring launches leave to the collective library's kernels while an exchange runs beside them (hc_set_comm_reserve; every
     # exchange is gated on the scoring kernel having taken its CUs): the scoring kernel otherwise holds a workgroup on EVERY CU for its whole
     # duration and a collective's kernels cannot share a CU with one (profiles/r05_coresident.json)
-    reserve_cus = (8 if args.reserve_cus < 0 else args.reserve_cus) if with_gather else 0
+    reserve_cus = max(0, args.reserve_cus) if with_gather else 0
     reads, cand, cfg, settings = build_workload(workload, 0 if strong else rank, keep=world > 1)
     cfg = dict(cfg)
     if world > 1 and dist.get_world_size() != world:  # the collective library must have seen every rank: never report N ranks on fewer
@@ -549,8 +549,31 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
         coll = "cuda" if dist.get_backend() == "nccl" else "cpu"  # small tensors of the bookkeeping collectives (gloo: test runs only)
         kept = torch.tensor([int((((d_out.view(torch.int64).view(-1, 3)[:, 2] >> 60) & 0xF) != 0).sum().item())], device=coll)
         dist.all_reduce(kept, op=dist.ReduceOp.MAX)  # one capacity for all ranks
-        gather = parallel.StreamedGather(sc, n, base_index=base_index, cap_rows=int(kept.item()) * 5 // 4 + 1024, rec_fmt=REC_COMPACT, mode=gather_mode,
-                                         reserve_cus=reserve_cus)
+        cap_rows = int(kept.item()) * 5 // 4 + 1024
+        reserve_tried = None
+        if args.reserve_cus < 0:
+            # how many CUs to leave to the exchange's kernels is decided by trying (set-up, before the warm-up; every rank takes the same
+            # decision: the slowest rank's step time counts).  Measured on one GPU with stand-in kernels (profiles/r05_coresident.md): beside
+            # a scoring kernel that holds every CU the exchange is serialised behind it (step = kernel + exchange); with CUs left free and the
+            # gate it overlaps if the exchange's workgroups fit the free CUs — at the price of those CUs for the scoring kernel.  Which is
+            # cheaper depends on N (the shard's kernel time against the payload) and on the collective library's kernels.
+            reserve_tried = {}
+            for r_try in (0, 16, 32):
+                g_try = parallel.StreamedGather(sc, n, base_index=base_index, cap_rows=cap_rows, rec_fmt=REC_COMPACT, mode=gather_mode, reserve_cus=r_try)
+                for _ in range(2):
+                    g_try.score_step(d_in.data_ptr(), d_out)
+                g_try.finish()
+                dist.barrier()
+                t_try = time.perf_counter()
+                for _ in range(6):
+                    g_try.score_step(d_in.data_ptr(), d_out)
+                g_try.finish()
+                t_mine = torch.tensor([(time.perf_counter() - t_try) / 6 * 1e3], device=coll, dtype=torch.float64)
+                dist.all_reduce(t_mine, op=dist.ReduceOp.MAX)
+                reserve_tried[r_try] = float(t_mine.item())
+                del g_try
+            reserve_cus = min(reserve_tried, key=reserve_tried.get)
+        gather = parallel.StreamedGather(sc, n, base_index=base_index, cap_rows=cap_rows, rec_fmt=REC_COMPACT, mode=gather_mode, reserve_cus=reserve_cus)
     last = None
 
     def step():
@@ -619,7 +642,8 @@ def run_workload(workload, order, scaling, args, torch, dist, rank, local_rank, 
                        parallelism=f"candidate shards x{world}, replicated read store" +
                                    ((", one all-gather of the non-dropped records per step (fixed-capacity payload, the library's ring)" if gather_mode == "ring" else
                                      ", one all-gather-v of the non-dropped records per step (counts, then grouped per-peer send / recv of exactly the rows)") if gather else ""),
-                       **({"gather": gather_mode, "reserve_cus": reserve_cus} if gather else {}),
+                       **({"gather": gather_mode, "reserve_cus": reserve_cus,
+                           "reserve_cus_tried_ms_per_step": {str(k): v for k, v in reserve_tried.items()} if reserve_tried else None} if gather else {}),
                        edge_threshold=settings.edge_threshold, mean_positions_per_candidate=positions / max(n, 1)),
         "roofline": roofline_record(workload, order, n, positions, kern_ms, kinfo, symbytes),
         "parity": parity,
@@ -740,7 +764,8 @@ def main():
                     help="N > 1, the per-step exchange: ring = one all-gather of the fixed-capacity payload; direct = all-gather-v (counts, then "
                          "grouped per-peer send / recv); both (default) = ring first, then the headline's mode again with direct behind a watchdog")
     ap.add_argument("--reserve-cus", type=int, default=-1,
-                    help="N > 1: CUs the scoring launches leave free for the exchange's kernels (-1 = 8; 0 = none, the exchange is not gated either)")
+                    help="N > 1: CUs the scoring launches leave free for the exchange's kernels (0 = none, the exchange is not gated either; "
+                         "-1 = decided by trying 0, 16 and 32 during set-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-rows", default=None, help="N > 1 (or HC_BENCH_FORCE_GATHER=1): rank 0 writes the rows collected in the last step to this .npy file")
     ap.add_argument("--no-stage", action="store_true", help="skip the stage end-to-end measurement")
@@ -777,6 +802,9 @@ def main():
     # code path on one GPU; never set by the driver
     with_gather = world > 1 or os.environ.get("HC_BENCH_FORCE_GATHER") == "1"
     if with_gather:
+        # the collective library's kernels run on the CUs the scoring launches leave free (hc_set_comm_reserve): no more workgroups than the
+        # largest reserve tried has CUs (one per free CU is what fits: profiles/r05_coresident.md)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         import torch.distributed as dist
 
         if world > 1 and backend != "nccl":

@@ -5,8 +5,9 @@ The N-rank step of bench.py (parallel.StreamedGather.score_step) with the collec
 stream structure: a device-to-device copy on the side stream, issued right behind the launch of the next step's scoring kernel,
 in two shapes (tools/experiments/comm_like.hip): "thin" (10 registers, no LDS: fits on a CU beside a scoring workgroup) and "fat"
 (128 registers, 32 KiB of LDS: the shape of a collective library's generic kernel — needs a CU without a scoring workgroup).  The
-scoring launch is the strong split's shard at N = 8 (1.25e7 of config 3's 1e8 candidates) or any --candidates; the copy's size is
-calibrated so that the stand-in ALONE takes --comm-ms (0.3: 15 MB to and from each of 7 peers over xGMI at ~50 GB/s per link).
+scoring launch is the strong split's shard at N = 8 (1.25e7 of config 3's 1e8 candidates) or any --candidates; the copy moves
+--comm-bytes (105 MiB: what a rank sends and receives per step at N = 8, 7 x 15 MB) — as many bytes out of and into the rank's HBM as
+the real exchange moves; how long it takes alone depends on the shape (reported).
 
 Per scenario (reserve = CUs the scoring launch leaves free, hc_set_comm_reserve; gate = hc_comm_gate_device in front of the
 stand-in): ms per step over --steps steps, against the step without any exchange; the stand-in's own duration (events on the side
@@ -41,8 +42,9 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--candidates", type=int, default=12500000)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--comm-ms", type=float, default=0.3)
-    ap.add_argument("--reserves", default="0,4,8,16")
+    ap.add_argument("--comm-bytes", type=int, default=105 << 20)
+    ap.add_argument("--reserves", default="0,8,16,32")
+    ap.add_argument("--only", default=None, help="reserve:shape-name:gate(0|1)[,...] — just these scenarios (for a kernel trace)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -82,11 +84,10 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    shapes = [("none", 0, 0, 0), ("thin x28", 28, 0, 0), ("fat x16", 16, 32768, 1), ("fat x32", 32, 32768, 1)]
+    shapes = [("none", 0, 0, 0), ("thin x56", 56, 0, 0), ("fat x16", 16, 32768, 1), ("fat x32", 32, 32768, 1), ("fat x64", 64, 32768, 1)]
     sized = {}
     for name, blocks, lds, fat in shapes[1:]:
-        t8 = alone_ms(8 << 20, blocks, lds, fat)
-        nbytes = int(min(256 << 20, max(1 << 20, (8 << 20) * args.comm_ms / t8))) & ~4095
+        nbytes = args.comm_bytes  # what a rank moves per step at N = 8: 7 x 15 MB out of and into its HBM
         sized[name] = (nbytes, alone_ms(nbytes, blocks, lds, fat))
     print(json.dumps({"what": "stand-in kernels alone", "sized": {k: {"bytes": v[0], "alone_ms": v[1]} for k, v in sized.items()},
                       "scoring": sc.kernel_info(n), "candidates": n, "kept_rows": kept}), flush=True)
@@ -122,10 +123,19 @@ def main():
         sc.set_comm_reserve(0)
         return rec
 
+    print(json.dumps({"what": "scoring kernel alone (hipEvents, back-to-back launches)", "kernel_ms": sc.time_kernel(d_in.data_ptr(), n, d_out.data_ptr(), 50, REC_COMPACT)}), flush=True)
+    if args.only:
+        for item in args.only.split(","):
+            r, nm, gt = item.split(":")
+            print(json.dumps(run(int(r), next(sh for sh in shapes if sh[0] == nm), gt == "1")), flush=True)
+        sc.close()
+        dist.destroy_process_group()
+        return
     for reserve in [int(x) for x in args.reserves.split(",")]:
         for shape in shapes:
             for gate in ((False,) if (shape[0] == "none" or reserve == 0) else (False, True)):
                 print(json.dumps(run(reserve, shape, gate)), flush=True)
+    print(json.dumps(dict(run(0, shapes[0], False), note="the first scenario once more (drift check)")), flush=True)
     sc.close()
     dist.destroy_process_group()
 
