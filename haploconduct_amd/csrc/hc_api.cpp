@@ -155,6 +155,8 @@ static void free_store(hc_ctx* c) {
     if (c->d_sym) (void)hipFree(c->d_sym);
     if (c->d_reads) (void)hipFree(c->d_reads);
     if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_inv_n) (void)hipFree(c->d_inv_n);
+    c->d_inv_n = nullptr;
     c->d_sym = nullptr;
     c->d_reads = nullptr;
     c->d_lut = nullptr;
@@ -290,11 +292,41 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     std::vector<int> phred;
     uint8_t qmap[256];
     memset(qmap, 255, sizeof qmap);
-    for (int b = 33; b <= 127; b++)
-        if (hist[b]) {
-            qmap[b] = (uint8_t)phred.size();
-            phred.push_back(b - 33);
+    {
+        std::vector<int> present;
+        for (int b = 33; b <= 127; b++)
+            if (hist[b]) present.push_back(b);
+        const uint32_t Kq = (uint32_t)present.size();
+        std::vector<uint32_t> index_of(Kq);
+        for (uint32_t k = 0; k < Kq; k++) index_of[k] = k;  // by byte value
+        // The smallest table (K + 2 <= 8 indices, hc_device.h: sparse layout): the LDS bank of an entry is (qa & 3, (qa ^ qb) & 7), so entries
+        // (qa, qb) and (qa ^ 4, qb ^ 4) share a bank at different addresses — the only structural conflict of that table.  The indices are
+        // therefore dealt by FREQUENCY (round 5): the most frequent quality values take the indices whose partner i ^ 4 is the N index, the
+        // invalid index or no index at all (entries that are next to never read), the others are paired hottest with coldest.  Any
+        // assignment gives the same results (table and symbols are built from the same map); HC_QIDX_ORDER=value keeps byte order (A/B knob).
+        const char* qo = getenv("HC_QIDX_ORDER");
+        if (Kq >= 5 && Kq <= 6 && !(qo && strcmp(qo, "value") == 0)) {
+            std::vector<uint32_t> by_freq(Kq);
+            for (uint32_t k = 0; k < Kq; k++) by_freq[k] = k;
+            std::stable_sort(by_freq.begin(), by_freq.end(), [&](uint32_t a, uint32_t b) { return hist[present[a]] > hist[present[b]]; });
+            std::vector<uint32_t> cold, pair_lo;  // indices with a cold partner; the lower index of an occupied pair (i, i ^ 4)
+            for (uint32_t i = 0; i < Kq; i++) {
+                if ((i ^ 4u) >= Kq) cold.push_back(i);
+                else if (i < (i ^ 4u)) pair_lo.push_back(i);
+            }
+            uint32_t next = 0, last = Kq;
+            for (uint32_t i : cold) index_of[by_freq[next++]] = i;
+            for (uint32_t i : pair_lo) {  // hottest remaining with coldest remaining
+                index_of[by_freq[next++]] = i;
+                index_of[by_freq[--last]] = i ^ 4u;
+            }
         }
+        phred.assign(Kq, 0);
+        for (uint32_t k = 0; k < Kq; k++) {
+            qmap[present[k]] = (uint8_t)index_of[k];
+            phred[index_of[k]] = present[k] - 33;
+        }
+    }
     if (phred.empty()) phred.push_back(0);
     const uint32_t K = (uint32_t)phred.size();
     const uint32_t symbytes = hc::sym_bytes_for(K);
@@ -365,6 +397,15 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     HC_HIP(hipMemcpyAsync(t_rc_delta.p, rc_delta.data(), sizeof(uint32_t) * n_seq, hipMemcpyHostToDevice, c->stream));
     HC_HIP(hipMemcpyAsync(d_first, read_first_seq, sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, c->stream));
     HC_HIP(hipMemcpyAsync(c->d_lut, lut.data(), sizeof(double) * lut.size(), hipMemcpyHostToDevice, c->stream));
+    // 1.0 / n for every count a sub-overlap can reach (n <= positions rounded up to 16 <= the longest sequence + 15): the reference's
+    // `1.0/total_len` (:137) as the host's IEEE division — the same quotient the device's gives — read by the kernel instead of divided
+    uint32_t longest = 0;
+    for (uint32_t q = 0; q < n_seq; q++) longest = std::max(longest, seq_len[q]);
+    std::vector<double> inv_n((size_t)longest + 17);
+    inv_n[0] = std::numeric_limits<double>::infinity();
+    for (size_t k = 1; k < inv_n.size(); k++) inv_n[k] = 1.0 / (double)k;
+    HC_HIP(hipMalloc((void**)&c->d_inv_n, sizeof(double) * inv_n.size()));
+    HC_HIP(hipMemcpyAsync(c->d_inv_n, inv_n.data(), sizeof(double) * inv_n.size(), hipMemcpyHostToDevice, c->stream));
     HC_HIP(hc::launch_encode(symbytes, d_bases, d_quals, d_raw_off, d_seq_off, (const uint32_t*)t_rc_delta.p, d_qmap, n_seq, K, c->d_sym, d_seq_bad,
                              d_first, n_reads, c->d_reads, slot_align, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
@@ -400,6 +441,8 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     c->view.K = K;
     c->view.symbytes = symbytes;
     c->view.lut_bytes = (uint32_t)(lut.size() * sizeof(double));
+    c->view.inv_n = c->d_inv_n;
+    c->view.inv_len = (uint32_t)inv_n.size();
     c->store_bytes = sym_bytes_total;
     c->view.store_bytes = sym_bytes_total;
     {  // regular store (hc_device.h): descriptors by arithmetic

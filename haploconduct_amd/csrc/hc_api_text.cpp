@@ -41,6 +41,8 @@ struct hc_textblock {
     hc_line_rec* h_row_lines = nullptr;
     hc_text_reject* h_rejects = nullptr;       // page-locked, mapped: written by the parse kernel
     unsigned long long* h_counters = nullptr;  // page-locked
+    hc_text_nonplain* h_nonplain = nullptr;    // page-locked, mapped: the parse kernel lists the lines it does not read (hc_textblock_list_nonplain)
+    uint32_t nonplain_cap = 0;
     std::vector<hc_text_row> rows;             // what hc_textblock_wait hands out
     hc_bucket_ws bucket;                       // scratch of a length-bucketed scoring launch (read sets of mixed sequence length)
     // the last submit, kept so that hc_textblock_wait can redo its device half with larger row buffers
@@ -216,7 +218,7 @@ int hc_textblock_destroy(hc_textblock* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void* p : {(void*)b->d_slab, (void*)b->d_rowslab})  // (d_text ... d_kept_tiles lie in the slab, d_rows / d_row_lines in the row slab)
         if (p) (void)hipFree(p);
-    for (void* p : {(void*)b->h_text, (void*)b->h_rowslab, (void*)b->h_counters})
+    for (void* p : {(void*)b->h_text, (void*)b->h_rowslab, (void*)b->h_counters, (void*)b->h_nonplain})
         if (p) (void)hipHostFree(p);
     for (void* p : b->old_device) (void)hipFree(p);
     for (void* p : b->old_host) (void)hipHostFree(p);
@@ -243,7 +245,7 @@ static int textblock_device_half(hc_textblock* b) {
     prm.min_overlap_perc = c->settings.min_overlap_perc;
     prm.relax_pe = (c->settings.flags & HC_FLAG_RELAX_PE_EDGES) ? 1u : 0u;
     prm.reject_cap = b->row_cap;
-    prm.pad = 0;
+    prm.nonplain_cap = b->h_nonplain ? b->nonplain_cap : 0u;
     hc::IdTable ids;
     ids.table = c->id_table.as<uint32_t>();
     ids.keys = c->id_keys.as<uint64_t>();
@@ -254,7 +256,10 @@ static int textblock_device_half(hc_textblock* b) {
     HC_HIP(hipHostGetDevicePointer(&d_rejects, b->h_rejects, 0));
     HC_HIP(hipHostGetDevicePointer(&d_rows, b->h_rows, 0));
     HC_HIP(hipHostGetDevicePointer(&d_row_lines, b->h_row_lines, 0));
-    HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, b->d_tally, s));
+    void* d_nonplain = nullptr;
+    if (b->h_nonplain) HC_HIP(hipHostGetDevicePointer(&d_nonplain, b->h_nonplain, 0));
+    HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, b->d_tally,
+                                 (hc_text_nonplain*)d_nonplain, s));
     // the scoring kernel on the records the parse kernel left behind; how many there are is only known on the device
     int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_cands, b->max_lines, b->d_out, s, false, nullptr, nullptr, 0, 0,
                           b->d_counters + hc::kTextLines, nullptr, nullptr, &b->bucket);
@@ -409,7 +414,11 @@ int hc_textblock_wait(hc_textblock* b, hc_text_result* out) {
     HC_HIP(hipEventSynchronize(b->done));
     b->in_flight = false;
     const unsigned long long* k = b->h_counters;
-    if (!(k[hc::kTextOverflow] || k[hc::kTextNonPlain] || k[hc::kTextUnknownId]) &&
+    // lines the device did not read send the block to the host unless they are all in the list (hc_textblock_list_nonplain)
+    auto nonplain_blocks = [&](const unsigned long long* kk) {
+        return kk[hc::kTextNonPlain] != 0 && !(b->h_nonplain && kk[hc::kTextNonPlain] <= b->nonplain_cap && kk[hc::kTextNonPlainSlots] == kk[hc::kTextNonPlain]);
+    };
+    if (!(k[hc::kTextOverflow] || nonplain_blocks(k) || k[hc::kTextUnknownId]) &&
         (k[hc::kTextRows] > b->row_cap || k[hc::kTextRejectSlots] > b->row_cap)) {
         const uint64_t need = k[hc::kTextRows] > k[hc::kTextRejectSlots] ? k[hc::kTextRows] : k[hc::kTextRejectSlots];
         int rc = textblock_regrow(b, need);
@@ -420,7 +429,7 @@ int hc_textblock_wait(hc_textblock* b, hc_text_result* out) {
     out->lines_read = k[hc::kTextRead];
     out->n_nonplain = k[hc::kTextNonPlain];
     out->n_unknown_id = k[hc::kTextUnknownId];
-    out->needs_host = (k[hc::kTextOverflow] || k[hc::kTextNonPlain] || k[hc::kTextUnknownId] || k[hc::kTextRows] > b->row_cap ||
+    out->needs_host = (k[hc::kTextOverflow] || nonplain_blocks(k) || k[hc::kTextUnknownId] || k[hc::kTextRows] > b->row_cap ||
                        k[hc::kTextRejectSlots] > b->row_cap)
                           ? 1
                           : 0;
@@ -441,6 +450,24 @@ int hc_textblock_wait(hc_textblock* b, hc_text_result* out) {
     out->n_rows = n_rows;
     out->rejected = b->h_rejects;
     out->n_rejected = n_rej;
+    if (k[hc::kTextNonPlain]) {  // (all of them are listed, else needs_host)
+        std::sort(b->h_nonplain, b->h_nonplain + k[hc::kTextNonPlain], [](const hc_text_nonplain& x, const hc_text_nonplain& y) { return x.line_index < y.line_index; });
+        out->nonplain = b->h_nonplain;
+        out->n_nonplain_listed = k[hc::kTextNonPlain];
+    }
+    return HC_OK;
+}
+
+int hc_textblock_list_nonplain(hc_textblock* b, uint32_t max_lines) {
+    if (!b) return fail(HC_ERR_ARG, "hc_textblock_list_nonplain: null block");
+    if (b->in_flight) return fail(HC_ERR_STATE, "hc_textblock_list_nonplain: the block is still in flight (hc_textblock_wait first)");
+    HC_HIP(hipSetDevice(b->ctx->device));
+    if (max_lines > b->nonplain_cap || (max_lines == 0 && b->h_nonplain)) {
+        if (b->h_nonplain) HC_HIP(hipHostFree(b->h_nonplain));
+        b->h_nonplain = nullptr;
+        if (max_lines) HC_HIP(hipHostMalloc((void**)&b->h_nonplain, (size_t)max_lines * sizeof(hc_text_nonplain), hipHostMallocMapped));
+    }
+    b->nonplain_cap = max_lines;
     return HC_OK;
 }
 

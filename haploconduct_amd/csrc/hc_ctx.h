@@ -120,6 +120,7 @@ struct hc_ctx {
     void* d_sym = nullptr;
     hc::ReadDesc* d_reads = nullptr;
     double* d_lut = nullptr;
+    double* d_inv_n = nullptr;  // StoreView::inv_n
     uint64_t store_bytes = 0;
     hc::StoreView view{};
     hc::ScoreParams params{};

@@ -85,7 +85,8 @@ struct StoreView {
     // launch therefore keeps 8 waves per CU (BASELINE config 5: 0.97 -> 0.75 ms; 12 waves 0.90, 4 waves 0.86;
     // profiles/r03_occupancy.txt).  Short-read sets want all 16 (10^8 x 2 x 150 bp: 8 waves cost +27 %).
     uint32_t long_rows;
-    uint32_t pad_;
+    uint32_t inv_len;     // entries of inv_n: the longest sequence + 17
+    const double* inv_n;  // inv_n[k] = 1.0 / k (host-built, IEEE division: the reference's `1.0/total_len`, :137), k < inv_len; [0] unused
 };
 
 // Log table layouts (doubles):

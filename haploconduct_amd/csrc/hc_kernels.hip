@@ -433,9 +433,11 @@ __host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t
 
 // What a sub-overlap's walk leaves behind -> its result (x = (1/n) S, mismatches, n), or the exact re-scan when the sum came
 // out NaN (an invalid symbol inside the window, or next to it in the last chunk).
+// inv_n: StoreView::inv_n — 1.0 / n for every n a sub-overlap of this read set can count (built on the host: the same IEEE quotient the
+// device's division gives, :137; round 5: the division was ~15 VALU instructions per sub-overlap)
 template <typename SymT>
 __device__ __forceinline__ void finish_sub(const SymT* __restrict__ sym, uint32_t offA, uint32_t offB, uint32_t L, uint32_t fatal, uint32_t Kp, double S,
-                                           uint32_t skipped, uint32_t cm, bool packed, SubScore& out) {
+                                           uint32_t skipped, uint32_t cm, bool packed, const double* __restrict__ inv_n, SubScore& out) {
     out.x = -__builtin_inf();
     out.mm = 1;
     out.n = 1;
@@ -456,7 +458,7 @@ __device__ __forceinline__ void finish_sub(const SymT* __restrict__ sym, uint32_
     if (S == __builtin_inf()) return;
     const uint32_t cn = 16u * ((L + 15u) >> 4) - skipped;
     if (cn == 0) return;
-    out.x = (1.0 / (double)cn) * S;
+    out.x = inv_n[cn] * S;  // cn <= L + 15 <= the longest sequence + 15 < the table's length
     out.mm = cm;
     out.n = cn;
 }
@@ -465,7 +467,7 @@ __device__ __forceinline__ void finish_sub(const SymT* __restrict__ sym, uint32_
 // offA / offB: byte offsets of the window starts in the store; L: positions (sub_positions()).
 template <typename SymT, int LG, int DEPTH = 1>
 __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint32_t oob, const SymT* __restrict__ sym, uint32_t stage, uint32_t offA,
-                                               uint32_t offB, uint32_t L, uint32_t fatal, uint32_t Kp, SubScore& out) {
+                                               uint32_t offB, uint32_t L, uint32_t fatal, uint32_t Kp, const double* __restrict__ inv_n, SubScore& out) {
     using T = Tr<SymT>;
     constexpr uint32_t kSymB = sizeof(SymT);
     constexpr int kChunks = 4 / kSymB;            // 16-symbol chunks per 64-byte row
@@ -500,10 +502,12 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool on = at < lim[j];
+                // (the step's offset `at` is wave-uniform: it travels as the instruction's scalar offset, the lane's part is la / lb or the
+                // first out-of-range offset — no per-lane add per load; the range check takes the scalar offset into account)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(stage + 1024u * j), 16,
-                                                         on ? la[j] + at : oob, 0, 0, HC_COOP_AUX_A);
+                                                         on ? la[j] : oob, at, 0, HC_COOP_AUX_A);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(stage + 4096u + 1024u * j), 16,
-                                                         on ? lb[j] + at : oob, 0, 0, HC_COOP_AUX_B);
+                                                         on ? lb[j] : oob, at, 0, HC_COOP_AUX_B);
             }
         };
         if (__ballot(Lb != 0u) != 0ull) {  // wave-uniform
@@ -553,7 +557,7 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
                 if (!more) break;
             }
         }
-        finish_sub<SymT>(sym, offA, offB, L, fatal, Kp, S, skipped, cm, kPacked, out);
+        finish_sub<SymT>(sym, offA, offB, L, fatal, Kp, S, skipped, cm, kPacked, inv_n, out);
         return;
     }
     // DEPTH register sets of pieces in flight: set s holds the pieces of the step it is consumed in and is refilled, right
@@ -567,8 +571,8 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
             sA[j] = u32x4{0x01010101u + (on ? (la[j] + at) & 0x02020202u : 0u), 0x01010101u, 0x09090909u, 0x11111111u};  // valid symbols only
             sB[j] = u32x4{0x09090909u + (on ? (lb[j] + at) & 0x02020202u : 0u), 0x09090909u, 0x01010101u, 0x11111111u};
 #else
-            sA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] + at : oob, 0, HC_COOP_AUX_A);
-            sB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] + at : oob, 0, HC_COOP_AUX_B);
+            sA[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? la[j] : oob, at, HC_COOP_AUX_A);
+            sB[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? lb[j] : oob, at, HC_COOP_AUX_B);
 #endif
         }
     };
@@ -640,7 +644,7 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
             step(nA[DEPTH - 1], nB[DEPTH - 1], at + 64u);
         }
     }
-    finish_sub<SymT>(sym, offA, offB, L, fatal, Kp, S, skipped, cm, kPacked, out);
+    finish_sub<SymT>(sym, offA, offB, L, fatal, Kp, S, skipped, cm, kPacked, inv_n, out);
 }
 
 // Result records are written once and read by nobody on the device: streamed past the caches, so they do not push the
@@ -1283,16 +1287,29 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
         }
         uint64_t i = 0;
         int ns = -2;  // no candidate in this lane
-        Sub sub0{}, sub1{};
+        // a sub-overlap as it travels: window starts as byte offsets into the store, positions | fatal << 31
+        uint32_t a0 = 0, b0 = 0, l0 = 0, a1 = 0, b1 = 0, l1 = 0;
         if (slot < n) {
             i = perm ? (uint64_t)perm[slot] : slot;
-            ns = resolve<(int)sizeof(SymT)>(st, load_cand(in, i, fmt), sub0, sub1);
+            const Cand rec = load_cand(in, i, fmt);
+            if (st.regular) {  // kernel-argument-uniform: descriptors are arithmetic, 32-bit offsets, no `fatal` (hc_resolve.h)
+                ns = resolve_regular32<(int)sizeof(SymT)>(st, prm.min_read_len, rec, a0, b0, l0, a1, b1, l1);
+            } else {
+                Sub sub0{}, sub1{};
+                ns = resolve<(int)sizeof(SymT)>(st, rec, sub0, sub1);
+                if (ns >= 1) {
+                    a0 = (uint32_t)((sub0.offA + sub0.pos) * sizeof(SymT));
+                    b0 = (uint32_t)(sub0.offB * sizeof(SymT));
+                    l0 = sub_positions(sub0, prm.min_read_len) | (sub0.fatal << 31);
+                }
+                if (ns == 2) {
+                    a1 = (uint32_t)((sub1.offA + sub1.pos) * sizeof(SymT));
+                    b1 = (uint32_t)(sub1.offB * sizeof(SymT));
+                    l1 = sub_positions(sub1, prm.min_read_len) | (sub1.fatal << 31);
+                }
+            }
         }
-        const uint32_t L0 = ns >= 1 ? sub_positions(sub0, prm.min_read_len) : 0u;
-        const uint32_t L1 = ns == 2 ? sub_positions(sub1, prm.min_read_len) : 0u;
-        // a sub-overlap as it travels: window starts as byte offsets into the store, positions | fatal << 31
-        uint32_t a0 = (uint32_t)((sub0.offA + sub0.pos) * sizeof(SymT)), b0 = (uint32_t)(sub0.offB * sizeof(SymT)), l0 = L0 | (sub0.fatal << 31);
-        uint32_t a1 = (uint32_t)((sub1.offA + sub1.pos) * sizeof(SymT)), b1 = (uint32_t)(sub1.offB * sizeof(SymT)), l1 = L1 | (sub1.fatal << 31);
+        const uint32_t L0 = l0 & 0x7FFFFFFFu, L1 = l1 & 0x7FFFFFFFu;
         SubScore s1, s2;
         if (SORT) {
             // rank of the wave's sub-overlap 2 lane + s, longest class first, by a counting sort over the 128 length classes in the
@@ -1334,13 +1351,13 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
             const u32x4 p0 = lds_load128(x + 16u * lane), p1 = lds_load128(x + 16u * (127u - lane));  // rank `lane`, then the other half mirrored
             wave_lds_order();
             SubScore r[2];
-            score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, p0[0], p0[1], p0[2] & 0x7FFFFFFFu, p0[2] >> 31, Kp, r[0]);
+            score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, p0[0], p0[1], p0[2] & 0x7FFFFFFFu, p0[2] >> 31, Kp, st.inv_n, r[0]);
             r[1].x = -__builtin_inf();
             r[1].mm = 1;
             r[1].n = 1;
             r[1].err = p1[2] >> 31;
             if (__ballot((p1[2] & 0x7FFFFFFFu) != 0u) != 0ull)
-                score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, p1[0], p1[1], p1[2] & 0x7FFFFFFFu, p1[2] >> 31, Kp, r[1]);
+                score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, p1[0], p1[1], p1[2] & 0x7FFFFFFFu, p1[2] >> 31, Kp, st.inv_n, r[1]);
             wave_lds_order();
             lds_store128(x + 16u * p0[3], u32x4{(uint32_t)__double2loint(r[0].x), (uint32_t)__double2hiint(r[0].x), r[0].mm, r[0].n | (r[0].err << 31)});
             lds_store128(x + 16u * p1[3], u32x4{(uint32_t)__double2loint(r[1].x), (uint32_t)__double2hiint(r[1].x), r[1].mm, r[1].n | (r[1].err << 31)});
@@ -1356,8 +1373,8 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
             s2.n = q1[3] & 0x7FFFFFFFu;
             s2.err = q1[3] >> 31;
         } else {
-            score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, a0, b0, L0, sub0.fatal, Kp, s1);
-            if (__ballot(ns == 2) != 0ull) score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, a1, b1, L1, sub1.fatal, Kp, s2);
+            score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, a0, b0, L0, l0 >> 31, Kp, st.inv_n, s1);
+            if (__ballot(ns == 2) != 0ull) score_sub_coop<SymT, LG, DEPTH>(rsrc, oob, sym, stage, a1, b1, L1, l1 >> 31, Kp, st.inv_n, s2);
         }
         if (ns != 2) {  // what a candidate without a second sub-overlap reports (compute_overlap, s-s)
             s2.x = __builtin_nan("");

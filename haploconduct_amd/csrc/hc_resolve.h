@@ -138,6 +138,54 @@ __device__ __forceinline__ int resolve(const StoreView& st, const Cand& r, Sub& 
     return 2;
 }
 
+// resolve() + sub_positions() for a REGULAR store below 4 GiB (StoreView::regular: one sequence length, singles before pairs, no base
+// outside ACGTN — so no descriptor look-up, no `fatal`), as the cooperative kernel wants a sub-overlap: window starts as 32-bit BYTE offsets
+// into the store and the number of positions.  Same decisions as resolve() (the tests run both kernels on the same sets); what is arithmetic
+// there is folded here: with slot = seq_syms / 2 a single's oriented sequence S(R, o) starts at base + (o ? 0 : slot), a pair's front
+// F(R, o) = o ? /1 : rc(/2) at base + (o ? 0 : 3 slot) and its back K(R, o) = o ? /2 : rc(/1) at base + (o ? slot : 2 slot)
+// ([/1 fwd][/2 fwd][/1 rc][/2 rc]); every length is `ulen`, so min(lenA - pos, lenB) = ulen - pos.  Round 5: the generic path cost ~215
+// VALU instructions per candidate of the kernel's 1 856 (profiles/r05_valu_attribution.txt).
+template <int SB>
+__device__ __forceinline__ int resolve_regular32(const StoreView& st, uint32_t min_read_len, const Cand& r, uint32_t& a0, uint32_t& b0, uint32_t& L0,
+                                                 uint32_t& a1, uint32_t& b1, uint32_t& L1) {
+    a0 = b0 = L0 = a1 = b1 = L1 = 0u;
+    if (r.skip) return -1;
+    if (r.read1 >= st.n_reads || r.read2 >= st.n_reads || r.read1 == r.read2) return 0;
+    const uint32_t slot = st.seq_syms >> 1;
+    const bool p1 = r.read1 >= st.n_single, p2 = r.read2 >= st.n_single;
+    const uint32_t base1 = (p1 ? 2u * r.read1 - st.n_single : r.read1) * st.seq_syms;  // n_single + 2 (r - n_single)
+    const uint32_t base2 = (p2 ? 2u * r.read2 - st.n_single : r.read2) * st.seq_syms;
+    const uint32_t F1 = base1 + (r.ori1 ? 0u : (p1 ? 3u * slot : slot));
+    const uint32_t F2 = base2 + (r.ori2 ? 0u : (p2 ? 3u * slot : slot));
+    const uint32_t ok = st.ulen >= min_read_len ? st.ulen : 0u;  // :82-84 (wave-uniform)
+    a0 = (F1 + r.pos1) * SB;
+    b0 = F2 * SB;
+    L0 = r.pos1 < ok ? ok - r.pos1 : 0u;  // :76-79, :88
+    if (!p1 && !p2) return 1;
+    const uint32_t K1 = p1 ? base1 + (r.ori1 ? slot : 2u * slot) : F1;
+    const uint32_t K2 = p2 ? base2 + (r.ori2 ? slot : 2u * slot) : F2;
+    uint32_t A, B;
+    if (!p1) {
+        A = F1;
+        B = K2;
+    } else if (!p2) {
+        A = F2;
+        B = K1;
+    } else if (r.ord == '1') {
+        A = K1;
+        B = K2;
+    } else if (r.ord == '2') {
+        A = K2;
+        B = K1;
+    } else {
+        return 0;
+    }
+    a1 = (A + r.pos2) * SB;
+    b1 = B * SB;
+    L1 = r.pos2 < ok ? ok - r.pos2 : 0u;
+    return 2;
+}
+
 __device__ __forceinline__ uint32_t sub_positions(const Sub& s, uint32_t min_read_len) {
     if (s.pos >= s.lenA) return 0;                                  // :76-79
     if (s.lenA < min_read_len || s.lenB < min_read_len) return 0;  // :82-84

@@ -23,7 +23,7 @@ struct TextParams {
     uint32_t max_lines;      // room in the line arrays; more newlines than that: the block goes to the host
     uint32_t min_overlap_len, min_overlap_perc, relax_pe;
     uint32_t reject_cap;
-    uint32_t pad;
+    uint32_t nonplain_cap;   // hc_textblock_list_nonplain: room in the list of lines that are not plain (0: they are only counted)
 };
 
 // counters of one block (device memory, 16 x u64)
@@ -39,6 +39,7 @@ enum {
     kTextLines = 8,     // lines in the block (newlines + a last line without one)
     kTextOverflow = 9,  // more lines than max_lines
     kTextRows = 10,     // rows the scoring kernel appended
+    kTextNonPlainSlots = 11,  // slots handed out in the list of lines that are not plain (hc_textblock_list_nonplain)
     kTextCounters = 16
 };
 
@@ -52,6 +53,6 @@ hipError_t launch_text_line_starts(const char* text, uint64_t n_bytes, const uin
 // (counters[0..6] are the sums of the workgroups' tallies: launch_kept_rows_flushed adds them up)
 hipError_t launch_text_parse(const TextParams& prm, const char* text, const uint32_t* line_start, const IdTable& ids, hc_cand_rec* cands,
                              hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, uint32_t* tally /* [(max_lines + 255) / 256][8] */,
-                             hipStream_t s);
+                             hc_text_nonplain* nonplain /* [prm.nonplain_cap], mapped host memory, or nullptr */, hipStream_t s);
 
 }  // namespace hc

@@ -10,8 +10,10 @@
 //                       prefilter (:612-635), id -> read index; out come the 16-byte candidate record the scoring kernel
 //                       reads (or a "skip" record), the parsed line (for the few per cent of lines the host sees again)
 //                       and the prefilter's rejects.
-// A line that is not plain — padded, malformed, hexadecimal ids, ... — is only COUNTED here: the host then takes the
-// whole block through its own tokeniser + Overlap constructor, which own every error the reference can raise.
+// A line that is not plain — padded, malformed, hexadecimal ids, ... — is not read here: it is counted and (round 5,
+// hc_textblock_list_nonplain) LISTED with its number and span, so that the host takes just that line through its own tokeniser +
+// Overlap constructor, which own every error the reference can raise, and splices the verdict in at its place in file order;
+// without a list (or with more such lines than the list holds) the host takes the whole block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -253,7 +255,7 @@ constexpr uint32_t kStageBytes = 32 * 1024;  // text of the 256 lines of a workg
 __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const char* __restrict__ text, const uint32_t* __restrict__ line_start,
                                                          IdTable ids, hc_cand_rec* __restrict__ cands, hc_line_rec* __restrict__ lines,
                                                          hc_text_reject* __restrict__ rejects, unsigned long long* __restrict__ counters,
-                                                         uint32_t* __restrict__ tally /* [workgroups][8] */) {
+                                                         uint32_t* __restrict__ tally /* [workgroups][8] */, hc_text_nonplain* __restrict__ nonplain) {
     __shared__ __attribute__((aligned(16))) char stage[kStageBytes + 32];  // + the 16-byte pieces at both ends
     __shared__ uint32_t wave_tally[4][8];
     if (counters[kTextOverflow]) return;  // more lines than room: nothing is parsed here, the host takes the block
@@ -294,6 +296,17 @@ __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const c
         hc_line_rec o;
         if (!(staged ? parse_plain_line<true>(text, stage_at, e - b, o) : parse_plain_line<false>(text, b, e - b, o))) {
             n_nonplain = 1;
+            if (prm.nonplain_cap) {  // the host reads this line alone (src/EdgeCalculator.cpp:584-604)
+                const unsigned long long slot = atomicAdd(&counters[kTextNonPlainSlots], 1ull);
+                if (slot < prm.nonplain_cap) {
+                    hc_text_nonplain np;
+                    np.line_index = i;
+                    np.begin = b;
+                    np.length = e - b;
+                    np.pad = 0;
+                    nonplain[slot] = np;
+                }
+            }
         } else {
             lines[i] = o;
             if (o.id1 == o.id2) {  // :605-607
@@ -383,10 +396,11 @@ hipError_t launch_text_line_starts(const char* text, uint64_t n_bytes, const uin
 }
 
 hipError_t launch_text_parse(const TextParams& prm, const char* text, const uint32_t* line_start, const IdTable& ids, hc_cand_rec* cands,
-                             hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, uint32_t* tally, hipStream_t s) {
+                             hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, uint32_t* tally, hc_text_nonplain* nonplain,
+                             hipStream_t s) {
     if (prm.max_lines == 0) return hipSuccess;
     hipLaunchKernelGGL(text_parse_kernel, dim3((prm.max_lines + 255) / 256), dim3(256), 0, s, prm, text, line_start, ids, cands, lines, rejects,
-                       counters, tally);
+                       counters, tally, nonplain);
     return hipGetLastError();  // (the workgroups' tallies are summed by the one-workgroup scan of launch_kept_rows_flushed)
 }
 

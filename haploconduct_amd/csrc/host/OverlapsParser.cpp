@@ -107,10 +107,42 @@ struct OverlapsParser::Segment {
     FatalError error{0, ""};
 };
 
+// What construct_edges does with ONE line (src/EdgeCalculator.cpp:584-635): tokenise, Overlap's constructor (which owns the reference's
+// exits), the self-overlap test, the prefilter, the id look-up.  Throws what the reference exits on.  Used line by line by the segment
+// parser below and, for the lines the device's parser does not read, by the stage (EdgeCalculator::score_device_parsed).
+OverlapsParser::LineKind OverlapsParser::classify_line(const char* line, size_t n, Overlap& o_slot, hc_cand_rec& rec) const {
+    if (!Overlap::from_plain_line(line, n, o_slot)) {  // nearly every line is plain; the rest: the reference's steps
+        const char* field[14];
+        size_t flen[14];
+        const int nf = split_overlap_line(line, n, m_ps.allow_spaces, field, flen, 14);
+        if (nf != 13) return LineKind::Malformed;  // :598-603
+        o_slot = Overlap::from_fields(field, flen);
+    }
+    const Overlap& o = o_slot;
+    if (o.m_id1 == o.m_id2) return LineKind::Self;  // :605-607
+    const unsigned int perc = o.get_perc();
+    const bool ss = o.m_type1 == 's' && o.m_type2 == 's';
+    const bool anyp = o.m_type1 == 'p' || o.m_type2 == 'p';
+    bool pass = false;
+    if (o.m_len1 >= m_ps.min_overlap_len && ss) {  // :612-617
+        pass = perc >= m_ps.min_overlap_perc;
+    } else if (o.m_len1 >= 0.5 * m_ps.min_overlap_len && o.m_len2 >= 0.5 * m_ps.min_overlap_len && anyp) {  // :618-624
+        pass = perc >= m_ps.min_overlap_perc;
+    } else if (m_ps.relax_PE_edges && o.m_len1 + o.m_len2 >= m_ps.min_overlap_len && anyp) {  // :626-632
+        pass = perc >= m_ps.min_overlap_perc;
+    } else {  // :633-635
+        return LineKind::Rejected;
+    }
+    if (!pass) return LineKind::Silent;
+    // id -> index: std::map::at in compute_overlap, :170-171 (throws => the reference aborts)
+    uint32_t r1, r2;
+    if (!m_ids.find(o.m_id1, r1) || !m_ids.find(o.m_id2, r2))
+        throw FatalError{HC_ERR_BAD_OVERLAP, "overlap refers to a read id that is not in the FASTQ input"};
+    rec = make_cand(o, r1, r2);
+    return LineKind::Pass;
+}
+
 void OverlapsParser::parse_segment(Segment& seg) const {
-    const bool allow_spaces = m_ps.allow_spaces;
-    const char* field[14];
-    size_t flen[14];
     size_t pos = seg.begin;
     uint64_t line_no = seg.first_line;
     try {
@@ -124,40 +156,19 @@ void OverlapsParser::parse_segment(Segment& seg) const {
             line_no++;
             seg.c.lines_read++;
             Overlap o_slot;  // copied into the block only if the line passes
-            if (!Overlap::from_plain_line(line, n, o_slot)) {  // nearly every line is plain; the rest: the reference's steps
-                const int nf = split_overlap_line(line, n, allow_spaces, field, flen, 14);
-                if (nf != 13) {  // :598-603
-                    seg.c.malformed++;
+            hc_cand_rec rec;
+            switch (classify_line(line, n, o_slot, rec)) {
+                case LineKind::Malformed: seg.c.malformed++; continue;
+                case LineKind::Self: seg.c.self_overlaps++; continue;
+                case LineKind::Silent: seg.c.silently_dropped++; continue;
+                case LineKind::Rejected:
+                    seg.rejected.push_back(o_slot);
+                    seg.c.prefilter_rejected++;
                     continue;
-                }
-                o_slot = Overlap::from_fields(field, flen);
+                case LineKind::Pass: break;
             }
-            const Overlap& o = o_slot;
-            if (o.m_id1 == o.m_id2) { seg.c.self_overlaps++; continue; }  // :605-607
-            const unsigned int perc = o.get_perc();
-            const bool ss = o.m_type1 == 's' && o.m_type2 == 's';
-            const bool anyp = o.m_type1 == 'p' || o.m_type2 == 'p';
-            bool pass = false;
-            if (o.m_len1 >= m_ps.min_overlap_len && ss) {  // :612-617
-                pass = perc >= m_ps.min_overlap_perc;
-                if (!pass) seg.c.silently_dropped++;
-            } else if (o.m_len1 >= 0.5 * m_ps.min_overlap_len && o.m_len2 >= 0.5 * m_ps.min_overlap_len && anyp) {  // :618-624
-                pass = perc >= m_ps.min_overlap_perc;
-                if (!pass) seg.c.silently_dropped++;
-            } else if (m_ps.relax_PE_edges && o.m_len1 + o.m_len2 >= m_ps.min_overlap_len && anyp) {  // :626-632
-                pass = perc >= m_ps.min_overlap_perc;
-                if (!pass) seg.c.silently_dropped++;
-            } else {  // :633-635
-                seg.rejected.push_back(o);
-                seg.c.prefilter_rejected++;
-            }
-            if (!pass) continue;
-            // id -> index: std::map::at in compute_overlap, :170-171 (throws => the reference aborts)
-            seg.out_line[seg.n_pass] = o;
-            uint32_t r1, r2;
-            if (!m_ids.find(o.m_id1, r1) || !m_ids.find(o.m_id2, r2))
-                throw FatalError{HC_ERR_BAD_OVERLAP, "overlap refers to a read id that is not in the FASTQ input"};
-            seg.out_rec[seg.n_pass] = make_cand(o, r1, r2);
+            seg.out_line[seg.n_pass] = o_slot;
+            seg.out_rec[seg.n_pass] = rec;
             seg.n_pass++;
         }
     } catch (const FatalError& e) {

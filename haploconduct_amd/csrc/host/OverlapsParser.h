@@ -150,6 +150,9 @@ public:
     // The device-parsing stage reads the file itself: its size, the bytes [begin, end) copied to dst on the parser's
     // threads (pread: no page of the mapping is touched) with the number of newlines among them, the end of the line
     // that holds byte `at` (offset behind its newline, or the size of the file), and the id table.
+    // One line by itself (the per-line fallback of the device-parsing stage): what construct_edges does with it, :584-635
+    enum class LineKind { Malformed, Self, Silent, Rejected, Pass };
+    LineKind classify_line(const char* line, size_t n, Overlap& o, hc_cand_rec& rec) const;
     size_t size() const { return m_size; }
     const char* data() const { return m_data; }  // the file's mapping (PROT_READ, MAP_PRIVATE)
     void copy_range(char* dst, size_t begin, size_t end, uint64_t& newlines, bool count_newlines = true) const;  // false: dst is never read

@@ -373,6 +373,12 @@ typedef struct hc_text_reject {
     uint32_t line_index, pad; /* number of the line in the block */
     hc_line_rec line;
 } hc_text_reject; /* 56 bytes */
+typedef struct hc_text_nonplain { /* a line the device does not read (not of the plain form): the host's tokeniser owns it */
+    uint32_t line_index; /* number of the line in the block */
+    uint32_t begin;      /* offset of its first byte in the block's text */
+    uint32_t length;     /* bytes without the newline */
+    uint32_t pad;
+} hc_text_nonplain; /* 16 bytes */
 typedef struct hc_text_result {
     uint64_t n_lines;          /* lines in the block (a last piece without a newline is a line)              */
     uint64_t lines_read;       /* of them below --max_ov                                                      */
@@ -385,6 +391,12 @@ typedef struct hc_text_result {
     uint64_t n_rows;
     const hc_text_reject* rejected; /* sorted by line_index (the order they are written to nonedge_overlaps.txt) */
     uint64_t n_rejected;
+    /* hc_textblock_list_nonplain: the n_nonplain lines the device did not read, sorted by line_index — the caller tokenises them
+     * (src/EdgeCalculator.cpp:584-604), scores the ones that pass and splices rows, rejects and counters in at their places; every
+     * other field of the result describes the OTHER lines (lines_read counts these lines too: they are below --max_ov).  NULL / 0
+     * without a list; more such lines than the list holds: needs_host, as without one. */
+    const hc_text_nonplain* nonplain;
+    uint64_t n_nonplain_listed;
 } hc_text_result;
 typedef struct hc_textblock hc_textblock;
 /* read_ids[r] = id of m_read_vec[r]; the first occurrence of an id wins (std::map::insert, FastqStorage.h:88-97). */
@@ -410,6 +422,10 @@ int hc_linechain_destroy(hc_linechain* chain);
 int hc_textblock_submit_from(hc_textblock* b, const void* text, uint64_t n_bytes, hc_linechain* chain, uint64_t k, hc_textblock* prev,
                              uint64_t base_index);
 int hc_textblock_wait(hc_textblock* b, hc_text_result* out); /* valid until the next submit on this block */
+/* Per-LINE fallback (round 5; the reference reads every line by itself, src/EdgeCalculator.cpp:581-604): with a list of `max_lines`
+ * entries (0: none, the default) a block that holds up to that many lines which are not plain does NOT go to the host as a whole —
+ * hc_text_result.nonplain names them and the caller handles just those.  Not while the block is in flight. */
+int hc_textblock_list_nonplain(hc_textblock* b, uint32_t max_lines);
 /* A block starts with row buffers for an eighth of its lines; a block with more surviving records (or prefilter rejects)
  * grows them inside hc_textblock_wait and runs its device half again — it does not go to the host.  How often so far: */
 uint64_t hc_textblock_regrown(hc_textblock* b);
