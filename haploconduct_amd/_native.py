@@ -55,7 +55,8 @@ class hc_settings(C.Structure):
 class hc_text_result(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_lines", "lines_read", "needs_host", "n_nonplain", "n_unknown_id", "self_overlaps", "silently_dropped",
                                           "prefilter_rejected", "scored")] + \
-               [("rows", C.c_void_p), ("n_rows", C.c_uint64), ("rejected", C.c_void_p), ("n_rejected", C.c_uint64)]
+               [("rows", C.c_void_p), ("n_rows", C.c_uint64), ("rejected", C.c_void_p), ("n_rejected", C.c_uint64),
+                ("nonplain", C.c_void_p), ("n_nonplain_listed", C.c_uint64)]
 
 
 class hc_graph_counts(C.Structure):
@@ -94,6 +95,7 @@ _sig = {
     "hc_linechain_create": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
     "hc_linechain_destroy": (C.c_int, [_vp]),
     "hc_textblock_wait": (C.c_int, [_vp, C.POINTER(hc_text_result)]),
+    "hc_textblock_list_nonplain": (C.c_int, [_vp, C.c_uint32]),
     "hc_textblock_destroy": (C.c_int, [_vp]),
     "hc_textblock_regrown": (C.c_uint64, [_vp]),
     "hc_textblock_reserve_rows": (C.c_int, [_vp, C.c_uint64]),

@@ -109,6 +109,10 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
     if (const char* m = getenv("HC_INSERT_MODE")) m_serial_insert = std::string(m) == "serial";
     if (const char* m = getenv("HC_RESOLVE")) m_host_resolve = std::string(m) == "host";
     if (const char* m = getenv("HC_PARSE")) m_host_parse = std::string(m) == "host";
+    if (const char* m = getenv("HC_PARSE_FALLBACK")) {  // "block": a line the device does not read sends its whole block to the host (round 4's route)
+        if (std::string(m) == "block") m_odd_line_cap = 0;
+        else if (atoi(m) > 0) m_odd_line_cap = (uint32_t)atoi(m);  // test knob: entries of a block's list
+    }
     if (const char* m = getenv("HC_TEXT_BLOCK")) m_text_block = std::max<size_t>(4096, (size_t)strtoull(m, nullptr, 10));
     m_cs = to_hc_settings(ps);
     if (const char* m = getenv("HC_TEXT_DEPTH")) {
@@ -158,6 +162,7 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
                     const double tb = now_s();
                     for (hc_textblock*& b : dv.tblk) {
                         blocks_rc = hc_textblock_create(dv.ctx, m_text_block, &b);
+                        if (blocks_rc == HC_OK && m_odd_line_cap) blocks_rc = hc_textblock_list_nonplain(b, m_odd_line_cap);
                         if (blocks_rc == HC_OK && !hc_textblock_buffer(b)) {
                             blocks_rc = HC_ERR_NOMEM;
                             blocks_error = "EdgeCalculator: no page-locked buffer for a block of text";
@@ -165,6 +170,13 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
                             blocks_error = std::string("hc_textblock_create: ") + hc_strerror(blocks_rc) + " " + hc_last_error();
                         }
                         if (blocks_rc != HC_OK) break;
+                    }
+                    // the small block the odd lines of a text block are scored in (score_odd_lines), beside the upload as well: its eight
+                    // allocations are a millisecond or two the first file would otherwise pay in the middle of the stage
+                    if (blocks_rc == HC_OK && m_odd_line_cap && m_dev.size() == 1 && !m_odd_blk) {  // (the first device's context)
+                        m_odd_blk_cap = 4096;
+                        blocks_rc = hc_block_create(dv.ctx, m_odd_blk_cap, &m_odd_blk);
+                        if (blocks_rc != HC_OK) blocks_error = std::string("hc_block_create: ") + hc_strerror(blocks_rc) + " " + hc_last_error();
                     }
                     blocks_s = now_s() - tb;
                 });
@@ -198,6 +210,7 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
 
 EdgeCalculator::~EdgeCalculator() {
     if (m_cleanup.joinable()) m_cleanup.join();
+    hc_block_destroy(m_odd_blk);
     for (Device& d : m_dev) {
         for (hc_block* b : d.blk) hc_block_destroy(b);
         for (hc_textblock* b : d.tblk) hc_textblock_destroy(b);
@@ -838,12 +851,87 @@ void EdgeCalculator::finalize_text_block(const IdIndex& ids, const hc_text_row* 
     }
 }
 
+static hc_line_rec line_rec_of(const Overlap& o) {
+    hc_line_rec l;
+    memset(&l, 0, sizeof l);
+    l.id1 = o.m_id1;
+    l.id2 = o.m_id2;
+    l.pos1 = o.m_pos1;
+    l.pos2 = o.m_pos2;
+    l.perc1 = o.m_perc1;
+    l.perc2 = o.m_perc2;
+    l.len1 = o.m_len1;
+    l.len2 = o.m_len2;
+    l.ord = (uint8_t)o.m_ord;
+    l.ori1 = (uint8_t)o.m_ori1;
+    l.ori2 = (uint8_t)o.m_ori2;
+    l.type1 = (uint8_t)o.m_type1;
+    l.type2 = (uint8_t)o.m_type2;
+    return l;
+}
+
+// Per-LINE fallback (round 5; the reference reads every line by itself, src/EdgeCalculator.cpp:581-604).  The device's parser reads the
+// plain lines of a block and LISTS the others (padding the reference trims at :584, an id with a leading zero — strtoul(.., 0) reads it
+// as octal —, --allow_spaced_overlaps input, a line with other than 13 fields, ...): each of those goes through the host's tokeniser +
+// Overlap constructor alone (OverlapsParser::classify_line: every message and every exit is the host parser's), the ones that pass are
+// scored on the device as one small block, and their rows are spliced into the block's rows at their places in file order.  Until round 5 one
+// such line sent its whole 16 MiB block to the host's tokeniser, synchronously, at its place in the order.
+void EdgeCalculator::score_odd_lines(const OverlapsParser& parser, const char* block_text, const hc_text_result& tr, OddLines& odd) {
+    std::vector<hc_cand_rec> recs;
+    std::vector<std::pair<uint32_t, Overlap>> passing;  // (line number in the block, the line)
+    for (uint64_t j = 0; j < tr.n_nonplain_listed; j++) {
+        const hc_text_nonplain& np = tr.nonplain[j];
+        Overlap o;
+        hc_cand_rec rec;
+        switch (parser.classify_line(block_text + np.begin, np.length, o, rec)) {  // throws what the reference exits on
+            case OverlapsParser::LineKind::Malformed: odd.pc.malformed++; break;
+            case OverlapsParser::LineKind::Self: odd.pc.self_overlaps++; break;
+            case OverlapsParser::LineKind::Silent: odd.pc.silently_dropped++; break;
+            case OverlapsParser::LineKind::Rejected:
+                odd.pc.prefilter_rejected++;
+                odd.rejected.emplace_back(np.line_index, o);
+                break;
+            case OverlapsParser::LineKind::Pass:
+                recs.push_back(rec);
+                passing.emplace_back(np.line_index, o);
+                break;
+        }
+    }
+    odd.scored = recs.size();
+    std::vector<hc_text_row> mine;  // the rows of the passing odd lines, in line order
+    if (!recs.empty()) {
+        std::lock_guard<std::mutex> g(m_odd_mu);  // one small block for all collectors: these lines are rare
+        if (!m_odd_blk || recs.size() > m_odd_blk_cap) {
+            hc_block_destroy(m_odd_blk);
+            m_odd_blk = nullptr;
+            m_odd_blk_cap = std::max<size_t>(recs.size() + recs.size() / 4, 4096);
+            check(hc_block_create(m_dev[0].ctx, m_odd_blk_cap, &m_odd_blk), "hc_block_create");
+        }
+        const hc_gather_row* rows = nullptr;
+        uint64_t n_rows = 0;
+        check(hc_block_submit(m_odd_blk, recs.data(), recs.size(), 0), "hc_block_submit");
+        check(hc_block_wait(m_odd_blk, &rows, &n_rows), "hc_block_wait");
+        mine.resize(n_rows);
+        for (uint64_t r = 0; r < n_rows; r++) {  // index = position among the passing odd lines -> the line's number in the block
+            mine[r].row = rows[r];
+            const auto& src = passing[rows[r].index];
+            mine[r].row.index = src.first;
+            mine[r].line = line_rec_of(src.second);
+        }
+    }
+    // splice: both lists are sorted by line number
+    odd.rows.resize(tr.n_rows + mine.size());
+    std::merge(tr.rows, tr.rows + tr.n_rows, mine.begin(), mine.end(), odd.rows.begin(),
+               [](const hc_text_row& a, const hc_text_row& b) { return a.row.index < b.row.index; });
+}
+
 // The file's TEXT sent to the device block by block: the caller's thread copies the next stretch of
 // the file — cut behind a newline — into the page-locked buffer of a text block and submits it (split into lines,
 // parse, --max_ov, prefilter, id lookup and scoring all happen on the device, hc_textblock_*); the collector thread
-// waits for the blocks in file order and runs the serial half on what survived.  A block the device reports as
-// unusual (a line that is not plain, an id that is not in the FASTQ input, ...) is tokenised by the host parser and
-// scored as a block of records, synchronously, at its place in the order: every error and every malformed-line message
+// waits for the blocks in file order and runs the serial half on what survived.  Lines that are not plain are read by the host
+// ONE BY ONE (score_odd_lines) while the rest of their block stays on the device; a block the device reports as unusual beyond that
+// (more such lines than its list holds, an id that is not in the FASTQ input, more lines than it has room for) is tokenised by the host
+// parser and scored as a block of records, synchronously, at its place in the order: every error and every malformed-line message
 // comes out as from the host-parsed pipeline.
 void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc) {
     const size_t N = m_dev.size();
@@ -856,7 +944,10 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     for (Device& d : m_dev) {
         d.tblk.resize(D, nullptr);
         for (hc_textblock*& b : d.tblk)
-            if (!b) check(hc_textblock_create(d.ctx, B, &b), "hc_textblock_create");
+            if (!b) {
+                check(hc_textblock_create(d.ctx, B, &b), "hc_textblock_create");
+                if (m_odd_line_cap) check(hc_textblock_list_nonplain(b, m_odd_line_cap), "hc_textblock_list_nonplain");
+            }
     }
     if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] text blocks ready after %.3f s\n", now_s() - t_setup0);
     struct Slot {
@@ -924,12 +1015,20 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
             memset(&tr, 0, sizeof tr);
             tr.needs_host = 1;
             FatalError mine{0, ""};
+            OddLines odd;  // the block's lines the device did not read, handled one by one (per-line fallback)
             const double t0 = now_s();
             double t_w = t0;
             try {  // side by side with the other collectors
                 if (sl.tb) check(hc_textblock_wait(sl.tb, &tr), "hc_textblock_wait");
                 t_w = now_s();
-                if (!tr.needs_host && !collector_failed) finalize_text_block(parser.ids(), tr.rows, tr.n_rows, out, /*threads=*/1);
+                if (!tr.needs_host && !collector_failed) {
+                    if (tr.n_nonplain_listed) {
+                        score_odd_lines(parser, parser.data() + sl.begin, tr, odd);
+                        finalize_text_block(parser.ids(), odd.rows.data(), odd.rows.size(), out, /*threads=*/1);
+                    } else {
+                        finalize_text_block(parser.ids(), tr.rows, tr.n_rows, out, /*threads=*/1);
+                    }
+                }
             } catch (const FatalError& e) {
                 mine = e;
             } catch (const std::exception& e) {
@@ -967,12 +1066,21 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                         finalize_block(host_batch, rows, n_rows, 0, out);
                     } else {
                         stats.device_blocks++;
-                        pc.lines_read += tr.lines_read;
-                        pc.self_overlaps += tr.self_overlaps;
-                        pc.silently_dropped += tr.silently_dropped;
-                        pc.prefilter_rejected += tr.prefilter_rejected;
-                        stats.scored += tr.scored;
-                        for (uint64_t j = 0; j < tr.n_rejected; j++) rejected.push_back(overlap_of(tr.rejected[j].line));
+                        pc.lines_read += tr.lines_read;  // (the device counts the lines it leaves to the host too)
+                        pc.self_overlaps += tr.self_overlaps + odd.pc.self_overlaps;
+                        pc.silently_dropped += tr.silently_dropped + odd.pc.silently_dropped;
+                        pc.prefilter_rejected += tr.prefilter_rejected + odd.pc.prefilter_rejected;
+                        pc.malformed += odd.pc.malformed;
+                        stats.scored += tr.scored + odd.scored;
+                        stats.host_lines += tr.n_nonplain_listed;
+                        for (uint64_t m = 0; m < odd.pc.malformed; m++) puts("incorrect overlap; skipping");  // :600, in block order
+                        // the prefilter's rejects in file order: the device's (sorted by line) and the odd lines' (sorted by line), merged
+                        size_t jo = 0;
+                        for (uint64_t j = 0; j < tr.n_rejected; j++) {
+                            while (jo < odd.rejected.size() && odd.rejected[jo].first < tr.rejected[j].line_index) rejected.push_back(odd.rejected[jo++].second);
+                            rejected.push_back(overlap_of(tr.rejected[j].line));
+                        }
+                        while (jo < odd.rejected.size()) rejected.push_back(odd.rejected[jo++].second);
                     }
                     consume_block(out);
                     if (sl.tb) lines_consumed += tr.n_lines;  // (a block that never went to the device is the file's last)

@@ -4,6 +4,7 @@
 #pragma once
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <string>
 #include <vector>
@@ -97,6 +98,7 @@ public:
         // blocks of the overlaps file's text: parsed on the device / taken over by the host's tokeniser (a line that is not
         // plain, an unknown id, more lines than room) / device blocks that ran twice because their row buffers had to grow
         uint64_t device_blocks = 0, host_blocks = 0, regrown_blocks = 0;
+        uint64_t host_lines = 0;  // lines of device-parsed blocks the host's tokeniser read one by one (per-line fallback)
     } stats;
 
 private:
@@ -117,6 +119,18 @@ private:
     void score_host_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc);   // the file tokenised on host threads
     void score_device_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc); // the file's text sent to the device
     void finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out, unsigned threads = 0);
+    // per-line fallback (score_device_parsed): what the host makes of the lines of a block the device's parser did not read
+    struct OddLines {
+        std::vector<hc_text_row> rows;  // the block's rows with the odd lines' rows spliced in (file order)
+        std::vector<std::pair<uint32_t, Overlap>> rejected;  // (line number in the block, line) the prefilter rejected
+        ParseCounters pc;
+        uint64_t scored = 0;
+    };
+    void score_odd_lines(const OverlapsParser& parser, const char* block_text, const hc_text_result& tr, OddLines& odd);
+    hc_block* m_odd_blk = nullptr;  // the passing odd lines of a block are scored as one small block
+    size_t m_odd_blk_cap = 0;
+    std::mutex m_odd_mu;
+    uint32_t m_odd_line_cap = 4096;  // entries of a text block's list of such lines (HC_PARSE_FALLBACK=block: 0, the whole block goes to the host)
     void collect_read_info();
     void finalize_block(const ParsedBatch& batch, const hc_gather_row* rows, uint64_t n_rows, uint64_t base, BlockOut& out);
     void consume_block(BlockOut& out);  // serial half: insert (or collect) + nonedge_overlaps.txt, :431-555

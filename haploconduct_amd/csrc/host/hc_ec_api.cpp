@@ -173,6 +173,7 @@ int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* c) {
     c->device_blocks = s.device_blocks;
     c->host_blocks = s.host_blocks;
     c->regrown_blocks = s.regrown_blocks;
+    c->host_lines = s.host_lines;
     return HC_OK;
 }
 

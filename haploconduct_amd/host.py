@@ -27,7 +27,7 @@ class hc_ec_counters(C.Structure):
                 ("self_overlap_count", "inclusion_count", "dup_count", "edges_added", "nonedges_written",
                  "prefilter_rejected", "malformed_lines", "lines_read", "scored", "ambiguous", "silently_dropped")] + \
                [(k, C.c_double) for k in ("t_parse", "t_score", "t_insert", "t_write")] + \
-               [(k, C.c_uint64) for k in ("device_blocks", "host_blocks", "regrown_blocks")]
+               [(k, C.c_uint64) for k in ("device_blocks", "host_blocks", "regrown_blocks", "host_lines")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

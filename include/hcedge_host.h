@@ -38,6 +38,9 @@ typedef struct hc_ec_counters {
      * plain, an id that is not in the FASTQ input, more lines than a block has room for); device blocks whose row buffers
      * had to grow, so that their device half ran twice (more than an eighth of the lines survived scoring) */
     uint64_t device_blocks, host_blocks, regrown_blocks;
+    /* lines of device-parsed blocks that the host's tokeniser read ONE BY ONE (round 5, per-line fallback: a line that is not plain
+     * no longer sends its block to the host) */
+    uint64_t host_lines;
 } hc_ec_counters;
 
 typedef struct hc_ec hc_ec; /* FastqStorage + OverlapGraph + EdgeCalculator */
