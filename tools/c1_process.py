@@ -154,6 +154,39 @@ def main():
                            "edge_calculator_ctor_s) every time; a stage kept open across the iterations of a pipeline (hc_ec_open once, "
                            "hc_ec_construct_edges[_from_reads] per iteration: include/hcedge_host.h) pays them once")
             out["stages"][name] = rec
+        # The same calls through the RESIDENT process (round 5): `hc-edgecalc --resident <the same arguments>` — a thin client that forwards argv, cwd
+        # and its stdout / stderr to a per-user process which keeps the HIP runtime, the code object and the library loaded.  A SAVAGE stage-b/c loop:
+        # the first call starts the resident process, the later ones are what every further iteration of a pipeline pays.  Outputs byte for byte.
+        renv = dict(os.environ, HC_RESIDENT_DIR=d + "resident", HC_RESIDENT_IDLE_S="120")
+        names = ("edges.tsv", "edges_sorted.tsv", "nonedge_overlaps.txt", "edgecalc_stats.txt")
+        res = {}
+        try:
+            for name, (vals, rs, pre) in stages.items():
+                o, o2 = d + name + "/", d + name + "_resident/"
+                os.mkdir(o2)
+                for fn in names:  # the process-per-call outputs of a fresh directory, to compare with
+                    if os.path.exists(o + fn):
+                        os.remove(o + fn)
+                run_cli(argv(o, *vals), 1)
+                want = {fn: open(o + fn, "rb").read() for fn in names}
+                a = argv(o2, *vals)
+                walls = []
+                for k in range(args.reps + 3):
+                    for fn in names:
+                        if os.path.exists(o2 + fn):
+                            os.remove(o2 + fn)
+                    w, outs = run_cli([a[0], "--resident"] + a[1:], 1, env=renv)
+                    walls.append(w[0])
+                    got = {fn: open(o2 + fn, "rb").read() for fn in names}
+                    assert got == want, f"{name}: the resident process wrote other files than a process of its own (call {k})"
+                    last_out = outs[0]
+                later = sorted(walls[1:])
+                res[name] = {"first_call_s": walls[0], "later_calls_s": walls[1:], "later_median_s": later[(len(later) - 1) // 2], "later_min_s": later[0],
+                             "outputs_identical_to_a_process_per_call": True, "breakdown_of_the_last_call": breakdown(last_out)}
+        finally:
+            subprocess.run([exe, "--resident_stop"], env=renv)
+        out["resident"] = dict(res, what="`hc-edgecalc --resident` + the stage's argv: wall time of the client process per call; first_call_s includes starting the "
+                                         "resident process (the first stage's) — later calls are a pipeline's further iterations")
         print(json.dumps(out, indent=1))
     finally:
         shutil.rmtree(d, ignore_errors=True)
