@@ -103,6 +103,7 @@ _sig = {
     "hc_graph_append": (C.c_int, [_vp, _vp, C.c_uint64]),
     "hc_graph_resolve": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, C.POINTER(hc_graph_counts)]),
     "hc_graph_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hc_reset": (C.c_int, [_vp, _vp]),
     "hc_set_comm_reserve": (C.c_int, [_vp, C.c_uint32]),
     "hc_comm_gate_device": (C.c_int, [_vp, _vp, C.c_uint32]),
     "hc_compact_pack_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp]),

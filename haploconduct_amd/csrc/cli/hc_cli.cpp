@@ -362,13 +362,17 @@ extern "C" int hc_cli_main(int argc, char** argv, void (*on_done)(int code, void
             for (const std::string& b : part) fwrite(b.data(), 1, b.size(), ef);
             fclose(ef);
         };
+        double t_w0 = now_s();
         write_edges("edges.tsv");
+        const double t_w1 = now_s();
         {  // overlap_graph->sortEdges(), :297
             std::vector<uint32_t> len(fastq->m_read_vec.size());
             for (size_t r = 0; r < len.size(); r++) len[r] = fastq->m_read_vec[r]->get_len();
             graph->sortEdges(len.data(), ps.n_threads);
         }
+        const double t_w2 = now_s();
         write_edges("edges_sorted.tsv");
+        if (ps.verbose) printf("[hc-edgecalc] edges.tsv %.3f s, sortEdges %.3f s, edges_sorted.tsv %.3f s\n", t_w1 - t_w0, t_w2 - t_w1, now_s() - t_w2);
         FILE* sf = fopen((ps.output_dir + "edgecalc_stats.txt").c_str(), "w");
         if (sf) {
             fprintf(sf, "vertex_count\t%u\nedge_count\t%u\ninclusion_count\t%u\ndup_count\t%u\nself_overlap_count\t%u\n",
@@ -381,7 +385,7 @@ extern "C" int hc_cli_main(int argc, char** argv, void (*on_done)(int code, void
         // 0.3 - 0.4 s run on the SAVAGE example, profiles/r04_c1_process.json) — a pipeline starts this program once per iteration.
         // HC_CLI_TEARDOWN=1 keeps the orderly way out (sanitizer and leak-check runs).
         if (on_done) {
-            done(0);  // the client leaves now; the stage is torn down behind its back (below, by the destructors)
+            done(0);  // the client leaves now; what is left of the stage goes behind its back (its devices stay: keep_devices_resident)
         } else if (!getenv("HC_CLI_TEARDOWN")) {
             fflush(stdout);
             fflush(stderr);
@@ -454,6 +458,7 @@ void send_code(int code, void* arg) {
 extern "C" int hc_cli_daemon(const char* sock_path, int idle_s) {
     const std::string path = sock_path;
     const std::string dir = path.substr(0, path.rfind('/'));
+    hc::keep_devices_resident(true);  // contexts, text blocks and their page-locked buffers serve one request after the other
     signal(SIGPIPE, SIG_IGN);  // a client whose stdout is a closed pipe (`| head`) must not end the resident process
     // one resident process per socket: whoever holds the lock serves it
     const int lock = open((dir + "/lock").c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
@@ -582,6 +587,7 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s) {
         }
     }
     if (warm.joinable()) warm.join();
+    hc::keep_devices_resident(false);
     close(ls);
     unlink(path.c_str());
     return rc;

@@ -95,6 +95,19 @@ int hc_device_count(void) {
     return n;
 }
 
+// what of a context follows from the settings alone (hc_create, hc_reset)
+static void apply_settings(hc_ctx* c, const hc_settings* settings) {
+    c->settings = *settings;
+    c->params.edge = make_band(settings->edge_threshold);
+    c->params.ov = make_band(settings->ov_threshold);
+    c->params.merge_contigs = settings->merge_contigs;
+    c->params.min_read_len = settings->min_read_len;
+    c->params.flags = (settings->edge_threshold < 0 ? kParamEdgeAlways : 0u) | (settings->ov_threshold < 0 ? kParamOvAlways : 0u);
+    c->params.rec_fmt = HC_REC_FULL;
+    c->params.pad = 0;
+    c->params.n_dev = nullptr;
+}
+
 static int create_ctx(hc_ctx* c, const hc_settings* settings) {
     c->settings = *settings;
     c->device = settings->device;
@@ -107,14 +120,7 @@ static int create_ctx(hc_ctx* c, const hc_settings* settings) {
     HC_HIP(hipEventCreate(&c->ev1));
     HC_HIP(hipMalloc((void**)&c->d_totals, 2 * sizeof(unsigned long long)));
     HC_HIP(hc::set_score_kernel_lds_limit());
-    c->params.edge = make_band(settings->edge_threshold);
-    c->params.ov = make_band(settings->ov_threshold);
-    c->params.merge_contigs = settings->merge_contigs;
-    c->params.min_read_len = settings->min_read_len;
-    c->params.flags = (settings->edge_threshold < 0 ? kParamEdgeAlways : 0u) | (settings->ov_threshold < 0 ? kParamOvAlways : 0u);
-    c->params.rec_fmt = HC_REC_FULL;
-    c->params.pad = 0;
-    c->params.n_dev = nullptr;
+    apply_settings(c, settings);
     return HC_OK;
 }
 
@@ -734,6 +740,20 @@ static int ensure_compact_workspace(hc_ctx* c, uint64_t n, bool with_buffers) {
         HC_HIP(hipMalloc((void**)&c->d_compact_res, n * sizeof(hc_result_rec)));
         c->compact_cap = n;
     }
+    return HC_OK;
+}
+
+int hc_reset(hc_ctx* c, const hc_settings* settings) {
+    if (!c || !settings) return fail(HC_ERR_ARG, "hc_reset: null argument");
+    if (settings->device != c->device) return fail(HC_ERR_ARG, "hc_reset: a context stays on its device");
+    HC_HIP(hipSetDevice(c->device));
+    HC_HIP(hipDeviceSynchronize());  // nothing of the previous stage is in flight
+    free_store(c);                   // the read store, the finder's results, the id table's validity: as after hc_create
+    c->have_ids = false;
+    c->reorder_mode = HC_REORDER_AUTO;
+    c->graph.valid = false;
+    c->graph.n_appended = 0;
+    apply_settings(c, settings);
     return HC_OK;
 }
 

@@ -132,14 +132,42 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
     m_node_cpus = cpus_near_device(m_cs.device);
     if (ps.n_threads > 1) m_pool.reset(new WorkerPool(ps.n_threads - 1, [this] { bind_here(); }));
     const FastqStorage& f = *fastq_storage;
+    // The resident process (keep_devices_resident): the contexts, text blocks and small blocks of the stage before this one are taken over —
+    // their streams, events, device scratch and page-locked buffers are what a stage's set-up and tear-down spend their time on — when
+    // that stage ran on the same devices with blocks of text at least as large; hc_reset gives every context the new settings.
+    std::vector<Device> parked;
+    {
+        std::lock_guard<std::mutex> g(g_park.mu);
+        const std::vector<int> want = device_list(ps);
+        if (!m_host_parse && !g_park.devices.empty() && g_park.device_ids == want && g_park.text_block >= m_text_block && g_park.odd_line_cap == m_odd_line_cap) {
+            parked = std::move(g_park.devices);
+            m_text_block = g_park.text_block;
+            m_odd_blk = g_park.odd_blk;
+            m_odd_blk_cap = g_park.odd_blk_cap;
+            g_park.odd_blk = nullptr;
+        } else {
+            park_destroy_locked();
+        }
+        g_park.devices.clear();
+    }
     try {
+        size_t n_dev_done = 0;
         for (int d : device_list(ps)) {  // the read store is replicated: candidates are independent given the reads
             hc_settings cs = m_cs;
             cs.device = d;
             Device dev;
             const double tc0 = now_s();
-            check(hc_create(&dev.ctx, &cs), "hc_create");
-            m_dev.push_back(dev);
+            if (n_dev_done < parked.size()) {
+                dev = parked[n_dev_done];
+                parked[n_dev_done] = Device();  // (ours now: the catch block below destroys what m_dev holds)
+                m_dev.push_back(dev);
+                check(hc_reset(dev.ctx, &cs), "hc_reset");
+            } else {
+                check(hc_create(&dev.ctx, &cs), "hc_create");
+                dev.device_id = d;
+                m_dev.push_back(dev);
+            }
+            n_dev_done++;
             const double tc1 = now_s();
             // the blocks of text construct_edges streams the overlaps file through, with their page-locked buffers (device memory
             // and page-locking belong to setting the stage up, like the read store), are made by a second thread while this one
@@ -156,11 +184,12 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
                 }
             } join_blocks{blocks};
             if (!m_host_parse) {
-                dv.tblk.resize(m_text_depth, nullptr);
+                if (dv.tblk.size() < m_text_depth) dv.tblk.resize(m_text_depth, nullptr);
                 blocks = std::thread([&] {
                     bind_here();
                     const double tb = now_s();
                     for (hc_textblock*& b : dv.tblk) {
+                        if (b) continue;  // taken over from the stage before
                         blocks_rc = hc_textblock_create(dv.ctx, m_text_block, &b);
                         if (blocks_rc == HC_OK && m_odd_line_cap) blocks_rc = hc_textblock_list_nonplain(b, m_odd_line_cap);
                         if (blocks_rc == HC_OK && !hc_textblock_buffer(b)) {
@@ -199,17 +228,55 @@ EdgeCalculator::EdgeCalculator(std::shared_ptr<FastqStorage> fastq, std::shared_
             }
         }
     } catch (...) {
-        for (Device& d : m_dev) {
-            for (hc_textblock* b : d.tblk) hc_textblock_destroy(b);
-            hc_destroy(d.ctx);
-        }
+        hc_block_destroy(m_odd_blk);
+        for (std::vector<Device>* set : {&m_dev, &parked})
+            for (Device& d : *set) {
+                for (hc_block* b : d.blk) hc_block_destroy(b);
+                for (hc_textblock* b : d.tblk) hc_textblock_destroy(b);
+                hc_destroy(d.ctx);
+            }
         throw;
     }
     m_ctx = m_dev[0].ctx;
 }
 
+// keep_devices_resident: what the last stage of this process leaves behind for the next one
+EdgeCalculator::Park EdgeCalculator::g_park;
+
+void EdgeCalculator::park_destroy_locked() {
+    hc_block_destroy(g_park.odd_blk);
+    g_park.odd_blk = nullptr;
+    for (Device& d : g_park.devices) {
+        for (hc_block* b : d.blk) hc_block_destroy(b);
+        for (hc_textblock* b : d.tblk) hc_textblock_destroy(b);
+        hc_destroy(d.ctx);
+    }
+    g_park.devices.clear();
+    g_park.device_ids.clear();
+}
+
+void keep_devices_resident(bool on) {
+    std::lock_guard<std::mutex> g(EdgeCalculator::g_park.mu);
+    EdgeCalculator::g_park.keep = on;
+    if (!on) EdgeCalculator::park_destroy_locked();
+}
+
 EdgeCalculator::~EdgeCalculator() {
     if (m_cleanup.joinable()) m_cleanup.join();
+    {
+        std::lock_guard<std::mutex> g(g_park.mu);
+        if (g_park.keep && !m_host_parse && !m_dev.empty()) {  // the next stage of this process takes them over (constructor)
+            park_destroy_locked();
+            g_park.devices = std::move(m_dev);
+            m_dev.clear();
+            for (const Device& d : g_park.devices) g_park.device_ids.push_back(d.device_id);
+            g_park.text_block = m_text_block;
+            g_park.odd_line_cap = m_odd_line_cap;
+            g_park.odd_blk = m_odd_blk;
+            g_park.odd_blk_cap = m_odd_blk_cap;
+            m_odd_blk = nullptr;
+        }
+    }
     hc_block_destroy(m_odd_blk);
     for (Device& d : m_dev) {
         for (hc_block* b : d.blk) hc_block_destroy(b);

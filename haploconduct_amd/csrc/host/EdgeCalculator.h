@@ -61,6 +61,10 @@ struct ReadInfo {
 // add_duplicates: vertices by orientation (src/EdgeCalculator.cpp:176-179) instead of the normal one (:181-182)
 Edge edge_from_admit(const hc_admit_rec& a, const ReadInfo* read_info, bool add_duplicates = false);
 
+// The resident process: a stage's devices (contexts, text blocks, small blocks) outlive it and serve the process's next stage
+// (EdgeCalculator's constructor takes them over when the device list and block size fit).  off: frees what is parked.
+void keep_devices_resident(bool on);
+
 class EdgeCalculator {
 public:
     unsigned int self_overlap_count = 0;   // never incremented by the reference either (its counting code is commented out)
@@ -105,6 +109,7 @@ private:
     // One device of the stage: a context with its own copy of the read store and the blocks it has in flight.
     struct Device {
         hc_ctx* ctx = nullptr;
+        int device_id = 0;
         hc_block* blk[2] = {nullptr, nullptr};       // blocks of host-parsed records
         std::vector<hc_textblock*> tblk;             // blocks of the file's text (the device parses): m_text_depth per device
     };
@@ -114,6 +119,19 @@ private:
         std::string nonedge_text;
         uint64_t nonedges = 0, ambiguous = 0;
     };
+    // keep_devices_resident (the resident process): the devices of the last stage, parked for the next one
+    struct Park {
+        std::mutex mu;
+        bool keep = false;
+        std::vector<Device> devices;
+        std::vector<int> device_ids;
+        size_t text_block = 0, odd_blk_cap = 0;
+        uint32_t odd_line_cap = 0;
+        hc_block* odd_blk = nullptr;
+    };
+    static Park g_park;
+    static void park_destroy_locked();
+    friend void keep_devices_resident(bool on);
     void run_stage(bool then_sort);
     std::shared_ptr<const std::string> m_text_override;  // construct_edges_from_reads: the overlaps file's text, in memory
     void score_host_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc);   // the file tokenised on host threads

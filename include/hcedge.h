@@ -159,6 +159,10 @@ int hc_device_count(void);
  * pow/log table with the host libm exactly as EdgeCalculator.cpp:41,44,52,60 do. */
 int hc_create(hc_ctx** out, const hc_settings* settings);
 int hc_destroy(hc_ctx* ctx);
+/* A context for another stage without making a new one (round 5, the resident process: a pipeline's iterations keep their contexts, streams,
+ * scratch and text blocks): the read store goes, the settings are replaced — the context is then as hc_create(settings) had left it, on the
+ * same device.  Blocks made on the context (hc_block, hc_textblock) stay valid.  Not while anything is in flight. */
+int hc_reset(hc_ctx* ctx, const hc_settings* settings);
 
 /* Replaces the Read getters used by compute_overlap (Read.h:144-201).
  *   bases, quals : concatenated sequences / quality strings (ASCII, 1 byte per base)

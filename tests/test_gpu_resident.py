@@ -1,0 +1,70 @@
+"""`hc-edgecalc --resident` on the device: a loop of stage calls with CHANGING inputs and settings (another read set, another quality alphabet,
+other thresholds, singles instead of pairs, a file with odd lines) through ONE resident process — whose contexts, text blocks and page-locked
+buffers are taken over from call to call (hc_reset, keep_devices_resident) — must write, call for call, the bytes a process of its own writes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "haploconduct_amd", "csrc", "hc-edgecalc")
+FILES = ("edges.tsv", "edges_sorted.tsv", "nonedge_overlaps.txt", "edgecalc_stats.txt")
+
+
+def _case(d, name, reads, cand, extra):
+    from haploconduct_amd import host
+
+    os.makedirs(d + name)
+    p = d + name + "/"
+    host.write_overlaps(p + "overlaps.txt", cand, reads)
+    paired = reads.is_paired(reads.n_reads - 1)
+    if paired:
+        reads.write_fastq(None, p + "p1.fastq", p + "p2.fastq")
+        inputs = ["--paired1", p + "p1.fastq", "--paired2", p + "p2.fastq"]
+    else:
+        reads.write_fastq(p + "s.fastq", None, None)
+        inputs = ["--singles", p + "s.fastq"]
+    return inputs + ["--overlaps", p + "overlaps.txt", "--original_readcount", str(reads.n_reads), "--threads", "8", "--verbose", "true"] + extra
+
+
+def test_a_pipeline_of_changing_stages_through_one_resident_process(tmp_path):
+    from haploconduct_amd import synth
+
+    d = str(tmp_path) + "/"
+    env = dict(os.environ, HC_RESIDENT_DIR=d + "res", HC_RESIDENT_IDLE_S="60")
+    cases = []
+    r1, m1 = synth.make_paired_dataset(4000, 6000, flip_frac=0.25, seed=21)
+    cases.append(_case(d, "a", r1, synth.paired_candidates(m1, n_candidates=300000, seed=22), ["--edge_threshold", "0.97", "--min_overlap_len", "150"]))
+    r2, m2 = synth.make_single_dataset(3000, 9000, len_lo=150, len_hi=900, n_strains=3, divergence=0.01, flip_frac=0.5, seed=5, log_uniform=True)
+    cases.append(_case(d, "b", r2, synth.single_candidates(m2, min_overlap=100, n_candidates=150000),
+                       ["--edge_threshold", "0.995", "--min_overlap_len", "100", "--merge_contigs", "0.01", "--ignore_inclusions", "true"]))
+    quals = (np.arange(1, 36) + 33).astype(np.uint8)  # 35 quality values: the wide table, another kernel
+    r3, m3 = synth.make_single_dataset(4000, 20000, len_lo=250, len_hi=250, n_strains=2, divergence=0.001, flip_frac=0.5, seed=4, quals=quals)
+    cases.append(_case(d, "c", r3, synth.single_candidates(m3, min_overlap=127), ["--edge_threshold", "1", "--min_overlap_len", "127"]))
+    cases.append(cases[0][:-4] + ["--edge_threshold", "0.9", "--min_overlap_len", "100", "--max_ov", "123457"])  # the first inputs again, other settings
+    try:
+        for rnd in range(2):  # the whole loop twice: every case also FOLLOWS every other kind of case
+            for k, args in enumerate(cases):
+                outs = {}
+                for mode in ("own", "resident"):
+                    o = f"{d}out_{rnd}_{k}_{mode}/"
+                    os.makedirs(o)
+                    r = subprocess.run([EXE] + (["--resident"] if mode == "resident" else []) + args + ["--output", o], env=env, capture_output=True, text=True,
+                                       timeout=600)
+                    assert r.returncode == 0, (mode, k, r.stdout[-1500:], r.stderr[-1500:])
+                    outs[mode] = ({f: open(o + f, "rb").read() for f in FILES}, [ln for ln in r.stdout.splitlines() if "edges have been constructed" in ln])
+                assert outs["own"][0] == outs["resident"][0], f"round {rnd}, case {k}: the resident process wrote other files"
+                assert len(outs["own"][0]["edges_sorted.tsv"]) > 10000
+                assert [ln.split(" in ")[0] for ln in outs["own"][1]] == [ln.split(" in ")[0] for ln in outs["resident"][1]]
+        # a failing job (a FASTQ file that is not there) answers 1 and the resident process goes on
+        bad = subprocess.run([EXE, "--resident", "--singles", d + "nope.fastq", "--overlaps", d + "a/overlaps.txt", "--original_readcount", "3", "--output", d], env=env,
+                             capture_output=True, text=True, timeout=120)
+        assert bad.returncode == 1 and "nope.fastq" in bad.stderr
+        o = d + "after_failure/"
+        os.makedirs(o)
+        ok = subprocess.run([EXE, "--resident"] + cases[1] + ["--output", o], env=env, capture_output=True, text=True, timeout=600)
+        assert ok.returncode == 0 and open(o + "edges.tsv", "rb").read() == open(f"{d}out_1_1_own/edges.tsv", "rb").read()
+    finally:
+        subprocess.run([EXE, "--resident_stop"], env=env, timeout=60)

@@ -1,0 +1,79 @@
+"""`hc-edgecalc --resident` without a GPU: the launcher forwards the command line to a resident process (started on first use as a fresh
+child of the launcher, which links neither libhcedge nor the HIP runtime) and relays its output and exit code; the parts of the program
+that need no device — --help, the reference's argument checks (src/ViralQuasispecies.cpp:103-154), a missing FASTQ file — behave as in a
+process of their own.  The stage itself through the resident process: tests/test_gpu_resident.py."""
+import os
+import subprocess
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "haploconduct_amd", "csrc", "hc-edgecalc")
+
+
+@pytest.fixture
+def resident_env(tmp_path):
+    env = dict(os.environ, HC_RESIDENT_DIR=str(tmp_path / "res"), HC_RESIDENT_IDLE_S="30")
+    yield env
+    subprocess.run([EXE, "--resident_stop"], env=env, timeout=30)
+
+
+def _run(args, env, **kw):
+    return subprocess.run([EXE] + args, env=env, capture_output=True, text=True, timeout=60, **kw)
+
+
+def test_launcher_links_no_hip():
+    out = subprocess.run(["ldd", EXE], capture_output=True, text=True).stdout
+    assert "amdhip" not in out and "libhcedge" not in out, "the launcher must start without loading the HIP runtime"
+
+
+def test_resident_answers_like_a_process_of_its_own(resident_env, tmp_path):
+    cases = [["--help"], ["--nonsense"], ["--overlaps", "x"], ["--singles", "s.fastq", "--overlaps", "o.txt"],
+             ["--singles", "s.fastq", "--overlaps", "o.txt", "--original_readcount", "5", "--add_duplicates=true", "--resolve_orientations=true"],
+             ["--singles", str(tmp_path / "missing.fastq"), "--overlaps", "o.txt", "--original_readcount", "5", "--output", str(tmp_path) + "/"]]
+    for args in cases:
+        own = _run(args, resident_env, cwd=tmp_path)
+        res = _run(["--resident"] + args, resident_env, cwd=tmp_path)
+        assert (res.returncode, res.stdout, res.stderr) == (own.returncode, own.stdout, own.stderr), args
+    assert os.path.exists(os.path.join(resident_env["HC_RESIDENT_DIR"], "sock"))
+    st = os.stat(resident_env["HC_RESIDENT_DIR"])
+    assert (st.st_mode & 0o077) == 0, "the socket's directory is the user's alone"
+
+
+def test_one_resident_process_serves_many_calls_and_a_closed_pipe_does_not_end_it(resident_env, tmp_path):
+    assert _run(["--resident", "--help"], resident_env).returncode == 0
+    log = os.path.join(resident_env["HC_RESIDENT_DIR"], "resident.log")
+    ino = os.stat(os.path.join(resident_env["HC_RESIDENT_DIR"], "sock")).st_ino
+    p = subprocess.Popen([EXE, "--resident", "--help"], env=resident_env, stdout=subprocess.PIPE)
+    p.stdout.close()  # `| head -0`: the resident process writes into a closed pipe
+    p.wait(timeout=30)
+    for _ in range(5):
+        assert _run(["--resident", "--help"], resident_env).returncode == 0
+    assert os.stat(os.path.join(resident_env["HC_RESIDENT_DIR"], "sock")).st_ino == ino, "the same resident process (its socket was never re-made)"
+    assert os.path.exists(log)
+    # the working directory of the CLIENT counts (relative --output)
+    (tmp_path / "wd").mkdir()
+    r = _run(["--resident", "--singles", "nope.fastq", "--overlaps", "o.txt", "--original_readcount", "3"], resident_env, cwd=tmp_path / "wd")
+    assert r.returncode == 1 and "nope.fastq" in r.stderr
+    assert (tmp_path / "wd" / "viralquasispecies.log").exists(), "the log goes where the client stands (default --output is the working directory)"
+
+
+def test_stop_and_idle_time_out(tmp_path):
+    env = dict(os.environ, HC_RESIDENT_DIR=str(tmp_path / "res2"), HC_RESIDENT_IDLE_S="1")
+    assert _run(["--resident", "--help"], env).returncode == 0
+    sock = os.path.join(env["HC_RESIDENT_DIR"], "sock")
+    assert os.path.exists(sock)
+    for _ in range(100):  # leaves by itself after a second without a request
+        if not os.path.exists(sock):
+            break
+        time.sleep(0.1)
+    assert not os.path.exists(sock)
+    assert _run(["--resident", "--help"], env).returncode == 0  # ... and comes back on the next call
+    assert subprocess.run([EXE, "--resident_stop"], env=env, timeout=30).returncode == 0
+    for _ in range(50):
+        if not os.path.exists(sock):
+            break
+        time.sleep(0.1)
+    assert not os.path.exists(sock)
+    assert subprocess.run([EXE, "--resident_stop"], env=env, timeout=30).returncode == 0, "nobody to stop is not an error"
