@@ -36,14 +36,14 @@ def test_a_pipeline_of_changing_stages_through_one_resident_process(tmp_path):
     env = dict(os.environ, HC_RESIDENT_DIR=d + "res", HC_RESIDENT_IDLE_S="60")
     cases = []
     r1, m1 = synth.make_paired_dataset(4000, 6000, flip_frac=0.25, seed=21)
-    cases.append(_case(d, "a", r1, synth.paired_candidates(m1, n_candidates=300000, seed=22), ["--edge_threshold", "0.97", "--min_overlap_len", "150"]))
+    cases.append(_case(d, "a", r1, synth.paired_candidates(m1, n_candidates=100000, seed=22), ["--edge_threshold", "0.97", "--min_overlap_len", "150"]))
     r2, m2 = synth.make_single_dataset(3000, 9000, len_lo=150, len_hi=900, n_strains=3, divergence=0.01, flip_frac=0.5, seed=5, log_uniform=True)
     cases.append(_case(d, "b", r2, synth.single_candidates(m2, min_overlap=100, n_candidates=150000),
                        ["--edge_threshold", "0.995", "--min_overlap_len", "100", "--merge_contigs", "0.01", "--ignore_inclusions", "true"]))
     quals = (np.arange(1, 36) + 33).astype(np.uint8)  # 35 quality values: the wide table, another kernel
     r3, m3 = synth.make_single_dataset(4000, 20000, len_lo=250, len_hi=250, n_strains=2, divergence=0.001, flip_frac=0.5, seed=4, quals=quals)
     cases.append(_case(d, "c", r3, synth.single_candidates(m3, min_overlap=127), ["--edge_threshold", "1", "--min_overlap_len", "127"]))
-    cases.append(cases[0][:-4] + ["--edge_threshold", "0.9", "--min_overlap_len", "100", "--max_ov", "123457"])  # the first inputs again, other settings
+    cases.append(cases[0][:-4] + ["--edge_threshold", "0.9", "--min_overlap_len", "100", "--max_ov", "61234"])  # the first inputs again, other settings
     try:
         for rnd in range(2):  # the whole loop twice: every case also FOLLOWS every other kind of case
             for k, args in enumerate(cases):
