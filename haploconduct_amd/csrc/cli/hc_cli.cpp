@@ -7,7 +7,8 @@
 // (:233-293) on the MI355X, and stops there: graph cleaning, cliques, super-reads and FNO are
 // outside this build's scope.  Outputs: nonedge_overlaps.txt (as the reference),
 // viralquasispecies.log (settings block, :160-218), edges.tsv — the admitted edges in adjacency-list order as
-// construct_edges leaves them, one line per Edge with %.17g score / mismatch rate — and edges_sorted.tsv, the same
+// construct_edges leaves them, one line per Edge, score and mismatch rate in the shortest decimal form that reads back to the same bits
+// (std::to_chars; until round 4 "%.17g": 0.1 was written 0.10000000000000001 — same value, other bytes) — and edges_sorted.tsv, the same
 // after overlap_graph->sortEdges() (:297), the order every later stage of the reference sees.
 #include <algorithm>
 #include <charconv>

@@ -464,11 +464,19 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     }
     c->have_reads = true;
     {
-        uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
-        for (uint32_t q = 0; q < n_seq; q++) {
-            lmin = seq_len[q] < lmin ? seq_len[q] : lmin;
-            lmax = seq_len[q] > lmax ? seq_len[q] : lmax;
+        // How mixed the lengths are, by the 5th and 95th percentile (round 5; until then by the shortest and the longest sequence: ONE short
+        // read — routine after quality trimming — flipped the kernel of an otherwise uniform set)
+        uint32_t lmin = 0, lmax = 0;
+        if (n_seq) {
+            std::vector<uint32_t> sorted_len(seq_len.begin(), seq_len.begin() + n_seq);
+            const size_t k5 = (size_t)n_seq * 5 / 100, k95 = std::min<size_t>(n_seq - 1, (size_t)n_seq * 95 / 100);
+            std::nth_element(sorted_len.begin(), sorted_len.begin() + k5, sorted_len.end());
+            lmin = sorted_len[k5];
+            std::nth_element(sorted_len.begin(), sorted_len.begin() + k95, sorted_len.end());
+            lmax = sorted_len[k95];
         }
+        c->len_p5 = lmin;
+        c->len_p95 = lmax;
         // mixed-length read set (contigs + reads) of sequences that are not short: the launches bucket their candidates by length.
         // Mixed but short sequences keep the plain launch, whose waves deal their sub-overlaps by length themselves: the bucketing's
         // gathered records and scattered results cost more than the idle lanes there.  2 * 10^6 s-s overlaps, plain / bucketed:
@@ -495,11 +503,8 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         // the per-lane kernel's, for the sets that take it (below) and for stores of 4 GiB and more
         const uint64_t mean_len = n_seq ? total / n_seq : 0;
         c->fetch_group = (mean_len > 600 || symbytes == 2) ? 2 : 4;
-        uint32_t lmin = 0xFFFFFFFFu, lmax = 0, n_pairs = 0;
-        for (uint32_t q = 0; q < n_seq; q++) {
-            lmin = seq_len[q] < lmin ? seq_len[q] : lmin;
-            lmax = seq_len[q] > lmax ? seq_len[q] : lmax;
-        }
+        const uint32_t lmin = c->len_p5, lmax = c->len_p95;  // 5th / 95th percentile of the sequence lengths (above)
+        uint32_t n_pairs = 0;
         for (uint32_t r = 0; r < n_reads; r++) n_pairs += read_first_seq[r + 1] - read_first_seq[r] == 2;
         const bool short_mixed_singles = n_seq && n_pairs == 0 && lmax > 2u * lmin && mean_len <= 300 && !c->view.balance;  // (HC_BALANCE=1 forces the bucketed launch)
         c->coop_fetch = !short_mixed_singles;

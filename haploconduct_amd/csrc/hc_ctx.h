@@ -121,6 +121,7 @@ struct hc_ctx {
     hc::ReadDesc* d_reads = nullptr;
     double* d_lut = nullptr;
     double* d_inv_n = nullptr;  // StoreView::inv_n
+    uint32_t len_p5 = 0, len_p95 = 0;  // 5th / 95th percentile of the sequence lengths: what the kernel dispatch calls "mixed"
     uint64_t store_bytes = 0;
     hc::StoreView view{};
     hc::ScoreParams params{};

@@ -67,6 +67,7 @@ struct EdgeCalculator::Appender {
     std::deque<std::pair<const hc_admit_rec*, size_t>> q;
     bool no_more = false;
     FatalError error{0, ""};
+    std::atomic<bool> failed{false};  // consume_block looks here: a failed append stops the stage at the block it is at, not after the whole file
     Appender(hc_ctx* c, std::function<void()> on_start) : ctx(c) {
         th = std::thread([this, on_start] {
             on_start();
@@ -81,7 +82,10 @@ struct EdgeCalculator::Appender {
                 }
                 if (error.status) continue;  // drain
                 const int rc = hc_graph_append(ctx, job.first, job.second);
-                if (rc != HC_OK) error = FatalError{rc, std::string("hc_graph_append: ") + hc_strerror(rc) + " " + hc_last_error()};
+                if (rc != HC_OK) {
+                    error = FatalError{rc, std::string("hc_graph_append: ") + hc_strerror(rc) + " " + hc_last_error()};
+                    failed.store(true, std::memory_order_release);
+                }
             }
         });
     }
@@ -499,7 +503,10 @@ void EdgeCalculator::consume_block(BlockOut& blk) {
         const size_t n_recs = blk.admitted.size();
         m_admitted.emplace_back(std::move(blk.admitted));
         if (m_device_resolve && n_recs) {
-            if (m_appender) m_appender->push(recs, n_recs);
+            if (m_appender) {
+                if (m_appender->failed.load(std::memory_order_acquire)) finish_appender(true);  // throws what the append failed with, here and now
+                if (m_appender) m_appender->push(recs, n_recs);
+            }
             else check(hc_graph_append(m_ctx, recs, n_recs), "hc_graph_append");
         }
         blk.admitted = std::vector<hc_admit_rec>();

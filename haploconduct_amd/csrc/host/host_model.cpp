@@ -1077,7 +1077,8 @@ void OverlapGraph::adopt_csr(const hc_edge_rec* edges, const uint64_t* out_off, 
                 have = edges_arrived->load(std::memory_order_acquire);
                 if (have >= b) break;
                 if (abandon && abandon->load(std::memory_order_acquire)) { my_bad = 2; break; }
-                std::this_thread::yield();
+                // (a short sleep, not a yield: up to 32 of these threads wait for ONE thread that copies, which needs a core of its own)
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
             if (my_bad) break;
             for (size_t k = a; k < b; k++) {

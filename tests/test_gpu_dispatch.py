@@ -86,3 +86,23 @@ def test_contig_length_mixed_singles_take_the_bucketed_launch(oracle, monkeypatc
     cand = synth.single_candidates(meta, min_overlap=100, n_candidates=200000)
     st = hc.Settings(edge_threshold=0.995, min_overlap_len=100)
     small, _ = _check(oracle, reads, cand, st, ["hc::score_kernel_coop<uint8_t, 3, 256, true, true, 2, true>", "length-bucketed"], monkeypatch, {"HC_BALANCE": "0"})
+
+
+def test_a_few_short_outliers_do_not_flip_the_kernel_of_a_uniform_set(oracle, monkeypatch):
+    """the dispatch went by the shortest and the longest sequence, so ONE short read (routine after quality trimming) sent an
+    otherwise uniform 250-bp set to the per-lane kernel.  It goes by the 5th / 95th percentile of the lengths now: 1 % of 60-bp reads among
+    250-bp singles keep the cooperative kernel (and the results are the oracle's, and the per-lane kernel's)."""
+    reads, meta = synth.make_single_dataset(20000, 60000, len_lo=250, len_hi=250, n_strains=2, divergence=0.001, flip_frac=0.5, seed=14)
+    # cut 1 % of the reads down to 60 bp (the read set is rebuilt: sequences of two lengths)
+    rng = np.random.default_rng(3)
+    short = set(rng.choice(reads.n_reads, reads.n_reads // 100, replace=False).tolist())
+    singles = []
+    for r in range(reads.n_reads):
+        b, q = reads.seq(r)
+        singles.append((b[:60], q[:60]) if r in short else (b, q))
+    reads2 = hc.ReadSet.from_lists(singles, [])
+    cand = synth.single_candidates(meta, min_overlap=127, n_candidates=300000)
+    cand = cand[~np.isin(cand["read1"], list(short)) | (cand["pos1"] < 40)]  # (a short read 1 overlaps only near its start)
+    st = hc.Settings(edge_threshold=1.0, min_overlap_len=0)
+    small, large = _check(oracle, reads2, cand, st, ["hc::score_kernel_coop<uint8_t, 3, "], monkeypatch, {"HC_FETCH_GROUP": "2"})
+    assert "hc::score_kernel<" not in small and "length-bucketed" not in small
