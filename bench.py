@@ -102,6 +102,11 @@ def pmc_profile(workload, order, kernel_symbol, kern_ms):
     # window in round 3), else the older files' average / hipEvents pair
     ref = t.get("kernel_ms_rocprof_median") or t.get("kernel_ms_rocprof_avg")
     tol = 0.05 if kern_ms >= 1.0 else 0.10  # hipEvents around back-to-back launches carry the launch gaps: a few per cent of a 0.2 ms kernel
+    lo = t.get("kernel_ms_rocprof_min")
+    # launches of a fraction of a millisecond are stretched by the tracer (C2: minimum 0.141, median 0.171 ms of 63 traced launches for a kernel
+    # hipEvents put at 0.145 - 0.153): such a run matches when it lies between the traced minimum and median (5 % either side)
+    if ref and lo and kern_ms < 1.0 and 0.95 * lo <= kern_ms <= 1.05 * ref:
+        return t, None
     if not ref or abs(ref - kern_ms) > tol * kern_ms:
         return None, f"the PMC file's kernel took {ref} ms (rocprofv3 kernel trace), this run's {kern_ms:.4f} ms: more than {tol:.0%} apart"
     return t, None
