@@ -135,3 +135,86 @@ def test_odd_lines_errors_are_the_host_parsers(tmp_path):
                 _stage_run(st, d + name + ".txt", d + "o_" + name + "/", fastq_kw, env=env)
             msgs.append(str(ei.value))
         assert msgs[0] == msgs[1], name
+
+
+def _small_case(tmp_path, n_pairs=1200, n_cand=20000):
+    import haploconduct_amd as hc
+    from haploconduct_amd import host, synth
+
+    reads, meta = synth.make_paired_dataset(n_pairs, 2500, flip_frac=0.2, seed=41)
+    cand = synth.paired_candidates(meta, n_candidates=n_cand, seed=42)
+    d = str(tmp_path) + "/"
+    host.write_overlaps(d + "clean.txt", cand, reads)
+    reads.write_fastq(None, d + "p1.fastq", d + "p2.fastq")
+    st = hc.Settings(edge_threshold=0.97, min_overlap_len=150)
+    st.n_threads = 4
+    return d, open(d + "clean.txt").read().split("\n")[:-1], st, dict(paired1=d + "p1.fastq", paired2=d + "p2.fastq")
+
+
+def _routes_agree(st, path, d, fastq_kw, tag, env=None):
+    """The per-line route, round 4's whole-block route and the host-parsed route: one graph, one non-edge file, the same counters."""
+    got = {}
+    for name, e in (("line", {}), ("block", {"HC_PARSE_FALLBACK": "block"}), ("host", {"HC_PARSE": "host"})):
+        got[name] = _stage_run(st, path, f"{d}{tag}_{name}/", fastq_kw, env=dict(env or {}, **e))
+    for name in ("block", "host"):
+        assert got["line"][0].tobytes() == got[name][0].tobytes(), f"{tag}: per-line and {name} routes build different graphs"
+        assert got["line"][2] == got[name][2], f"{tag}: nonedge_overlaps.txt differs ({name})"
+        for k in ("edges_added", "nonedges_written", "prefilter_rejected", "malformed_lines", "lines_read", "scored", "silently_dropped", "self_overlap_count",
+                  "inclusion_count", "dup_count"):
+            assert got["line"][1][k] == got[name][1][k], f"{tag}: {k} ({name})"
+    return got["line"]
+
+
+def test_max_ov_cuts_between_and_on_odd_lines(tmp_path):
+    """`&& i < max_overlaps` (:581) counts odd lines like any other: cuts right before, on and right behind an odd line, and behind a junk line."""
+    d, lines, st, fastq_kw = _small_case(tmp_path)
+    odd = list(lines)
+    for k in (100, 101, 5000, 12345):
+        odd[k] = " " + odd[k] + "\t"
+    odd.insert(7000, "not\tan\toverlap")
+    open(d + "odd.txt", "w").write("\n".join(odd) + "\n")
+    for cut in (100, 101, 102, 5001, 7000, 7001, 7002, 12346, len(odd)):
+        st2 = copy.copy(st)
+        st2.max_overlaps = cut
+        e, c, _, _ = _routes_agree(st2, d + "odd.txt", d, fastq_kw, f"cut{cut}")
+        assert c["lines_read"] == cut and c["host_lines"] == sum(1 for k in (100, 101, 5000, 7000, 12346) if k < cut)
+
+
+def test_odd_last_line_without_a_newline_and_odd_lines_across_small_blocks(tmp_path):
+    """A file whose LAST line is odd and has no newline (std::getline still reads it); blocks of 64 KiB so that odd lines sit first and last in
+    blocks; a rejected odd line (prefilter, :633-635) lands in nonedge_overlaps.txt at its place among the device's rejects."""
+    d, lines, st, fastq_kw = _small_case(tmp_path)
+    odd = list(lines)
+    rng = np.random.default_rng(9)
+    for k in rng.choice(len(odd), 300, replace=False):
+        f = odd[k].split("\t")
+        if k % 3 == 0:  # a line the prefilter rejects (LEN below 0.5 M for both mates), padded
+            f[9], f[10] = "20", "30"
+        odd[k] = "\t".join(f) + "  "
+    for k in rng.choice(len(odd), 300, replace=False):  # plain rejected lines too: the two kinds interleave in the rejects' file
+        f = odd[k].split("\t")
+        if not odd[k].endswith(" "):
+            f[9], f[10] = "21", "31"
+            odd[k] = "\t".join(f)
+    odd[-1] = "\t" + odd[-1]
+    open(d + "odd.txt", "w").write("\n".join(odd))  # no trailing newline
+    e, c, ne, _ = _routes_agree(st, d + "odd.txt", d, fastq_kw, "tail", env={"HC_TEXT_BLOCK": "65536"})
+    assert c["host_lines"] >= 300 and c["host_blocks"] == 0 and c["device_blocks"] >= 10 and c["prefilter_rejected"] >= 300
+    assert c["lines_read"] == len(odd)
+
+
+def test_every_line_odd_falls_back_block_by_block(tmp_path):
+    """--allow_spaced_overlaps input (blanks between the fields): no line is plain, the blocks' lists overflow, every block goes to the host's
+    tokeniser as a whole — the same graph as the tab-separated file."""
+    d, lines, st, fastq_kw = _small_case(tmp_path, n_cand=12000)
+    open(d + "spaced.txt", "w").write("\n".join(ln.replace("\t", " \t ") for ln in lines) + "\n")
+    st2 = copy.copy(st)
+    from haploconduct_amd.records import FLAG_ALLOW_SPACES
+
+    st2.flags |= FLAG_ALLOW_SPACES
+    e_sp, c_sp, ne_sp, _ = _stage_run(st2, d + "spaced.txt", d + "sp/", fastq_kw, env={"HC_PARSE_FALLBACK": "64"})
+    e_cl, c_cl, ne_cl, _ = _stage_run(st, d + "clean.txt", d + "cl/", fastq_kw)
+    assert e_sp.tobytes() == e_cl.tobytes() and ne_sp == ne_cl
+    assert c_sp["host_blocks"] >= 1 and c_sp["device_blocks"] == 0 and c_sp["host_lines"] == 0
+    e_ln, c_ln, _, _ = _stage_run(st2, d + "spaced.txt", d + "ln/", fastq_kw, env={"HC_PARSE_FALLBACK": "1000000"})  # a list long enough: line by line
+    assert e_ln.tobytes() == e_cl.tobytes() and c_ln["host_lines"] == len(lines) and c_ln["host_blocks"] == 0
