@@ -456,7 +456,9 @@ void send_code(int code, void* arg) {
 }  // namespace
 
 // Returns the process's exit code: 0 after an idle time-out or a stop request, 3 after a device fault, 2 when the socket cannot be served.
-extern "C" int hc_cli_daemon(const char* sock_path, int idle_s) {
+// lib_stamp: what libhcedge.so looked like when the launcher loaded it (mtime, size); a request that carries another stamp — the library was
+// rebuilt under this process — is answered with kStaleLibrary and the process leaves: the client starts a new one.
+extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long long lib_stamp) {
     const std::string path = sock_path;
     const std::string dir = path.substr(0, path.rfind('/'));
     hc::keep_devices_resident(true);  // contexts, text blocks and their page-locked buffers serve one request after the other
@@ -472,6 +474,10 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s) {
     if (ls < 0 || path.size() >= sizeof addr.sun_path) return 2;
     strcpy(addr.sun_path, path.c_str());
     if (bind(ls, (sockaddr*)&addr, sizeof addr) != 0 || listen(ls, 16) != 0) return 2;
+    if (FILE* pf = fopen((dir + "/pid").c_str(), "w")) {  // who serves the socket (for the operator; tests tell one resident process from the next by it)
+        fprintf(pf, "%ld\n", (long)getpid());
+        fclose(pf);
+    }
     // the HIP runtime and the kernels' code object, beside the first request's way here
     std::thread warm([] {
         if (hc_device_count() > 0) {
@@ -500,7 +506,7 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s) {
             continue;
         }
         // header + the client's stdout and stderr (SCM_RIGHTS)
-        uint32_t head[5];  // magic, argc, n_env, cwd bytes, flags (1 = stop)
+        uint32_t head[7];  // magic, argc, n_env, cwd bytes, flags (1 = stop), the client's library stamp (low, high)
         int fds[2] = {-1, -1};
         {
             iovec iov{head, sizeof head};
@@ -521,6 +527,14 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s) {
                 close(cs);
                 continue;
             }
+        }
+        if (!(head[4] & 1u) && (((unsigned long long)head[6] << 32) | head[5]) != lib_stamp) {
+            const int32_t stale = -1000;  // kStaleLibrary (cli/hc_edgecalc_main.cpp)
+            (void)write_all(cs, &stale, sizeof stale);
+            close(fds[0]);
+            close(fds[1]);
+            close(cs);
+            break;
         }
         if (head[4] & 1u) {  // hc-edgecalc --resident_stop
             const int32_t zero = 0;

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,6 +45,16 @@ static void* load_library() {
     if (!h) h = dlopen("libhcedge.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) fprintf(stderr, "hc-edgecalc: cannot load libhcedge.so: %s\n", dlerror());
     return h;
+}
+
+// what the library next to this executable looks like right now: a resident process that loaded another one (the library was rebuilt
+// under it) must not answer for it
+static uint64_t library_stamp() {
+    std::string p = self_path();
+    p = p.substr(0, p.rfind('/') + 1) + "libhcedge.so";
+    struct stat sb;
+    if (stat(p.c_str(), &sb) != 0) return 0;
+    return (uint64_t)sb.st_mtim.tv_sec * 1000000007ull + (uint64_t)sb.st_mtim.tv_nsec + ((uint64_t)sb.st_size << 20);
 }
 
 static std::string socket_dir() {
@@ -102,7 +113,22 @@ static void spawn_daemon(const std::string& dir, const std::string& sock) {
     waitpid(p, &st, 0);
 }
 
+static const int32_t kStaleLibrary = -1000;  // the resident process's answer when its library is not the one next to the executable any more
+
+static int client_once(int argc, char** argv, bool stop);
+
 static int client(int argc, char** argv, bool stop) {
+    signal(SIGPIPE, SIG_IGN);  // a resident process that has hung up is an answer to read, not a signal to die of
+    int code = client_once(argc, argv, stop);
+    for (int k = 0; k < 3 && code == kStaleLibrary; k++) {  // it has left: the next call starts one with the library as it is now
+        timespec ts{0, 20000000};
+        nanosleep(&ts, nullptr);
+        code = stop ? 0 : client_once(argc, argv, stop);
+    }
+    return code == kStaleLibrary ? 1 : code;
+}
+
+static int client_once(int argc, char** argv, bool stop) {
     const std::string dir = socket_dir(), sock = dir + "/sock";
     mkdir(dir.c_str(), 0700);
     struct stat sb;
@@ -131,7 +157,8 @@ static int client(int argc, char** argv, bool stop) {
         if (strncmp(*e, "HC_", 3) == 0 && strncmp(*e, "HC_RESIDENT_", 12) != 0) env.push_back(*e);
     char cwd[4096];
     if (!getcwd(cwd, sizeof cwd)) strcpy(cwd, "/");
-    uint32_t head[5] = {kResidentMagic, (uint32_t)args.size(), (uint32_t)env.size(), (uint32_t)strlen(cwd), stop ? 1u : 0u};
+    const uint64_t stamp = library_stamp();
+    uint32_t head[7] = {kResidentMagic, (uint32_t)args.size(), (uint32_t)env.size(), (uint32_t)strlen(cwd), stop ? 1u : 0u, (uint32_t)stamp, (uint32_t)(stamp >> 32)};
     int fds[2] = {1, 2};
     {
         iovec iov{head, sizeof head};
@@ -159,15 +186,14 @@ static int client(int argc, char** argv, bool stop) {
         const uint32_t n = (uint32_t)v.size();
         return write_all(s, &n, sizeof n) && write_all(s, v.data(), n);
     };
-    bool ok = true;
-    if (!stop) {
-        ok = send_str(cwd);
+    if (!stop) {  // (a resident process that answers "stale library" at once stops reading: the answer is read all the same)
+        bool ok = send_str(cwd);
         for (const std::string& a : args) ok = ok && send_str(a);
         for (const std::string& e : env) ok = ok && send_str(e);
     }
     int32_t code = 1;
     size_t got = 0;
-    while (ok && got < sizeof code) {
+    while (got < sizeof code) {
         const ssize_t k = read(s, (char*)&code + got, sizeof code - got);
         if (k <= 0) {
             if (k < 0 && errno == EINTR) continue;
@@ -192,11 +218,11 @@ int main(int argc, char** argv) {
     void* lib = load_library();
     if (!lib) return 1;
     if (argc >= 3 && !strcmp(argv[1], "--resident_daemon")) {
-        typedef int (*daemon_fn)(const char*, int);
+        typedef int (*daemon_fn)(const char*, int, unsigned long long);
         daemon_fn fn = (daemon_fn)dlsym(lib, "hc_cli_daemon");
         if (!fn) return 1;
         const char* idle = getenv("HC_RESIDENT_IDLE_S");
-        return fn(argv[2], idle ? atoi(idle) : 600);
+        return fn(argv[2], idle ? atoi(idle) : 600, (unsigned long long)library_stamp());
     }
     typedef int (*main_fn)(int, char**, void (*)(int, void*), void*);
     main_fn fn = (main_fn)dlsym(lib, "hc_cli_main");

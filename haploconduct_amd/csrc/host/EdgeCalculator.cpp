@@ -1016,7 +1016,7 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
     // the calling thread copies text too: next to the device for the length of the call, then back where it was allowed before
     BoundForNow bound(m_node_cpus);
     for (Device& d : m_dev) {
-        d.tblk.resize(D, nullptr);
+        if (d.tblk.size() < D) d.tblk.resize(D, nullptr);  // (never shrunk: a resident process's devices may bring more blocks than this file needs)
         for (hc_textblock*& b : d.tblk)
             if (!b) {
                 check(hc_textblock_create(d.ctx, B, &b), "hc_textblock_create");

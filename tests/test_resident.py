@@ -44,13 +44,13 @@ def test_resident_answers_like_a_process_of_its_own(resident_env, tmp_path):
 def test_one_resident_process_serves_many_calls_and_a_closed_pipe_does_not_end_it(resident_env, tmp_path):
     assert _run(["--resident", "--help"], resident_env).returncode == 0
     log = os.path.join(resident_env["HC_RESIDENT_DIR"], "resident.log")
-    ino = os.stat(os.path.join(resident_env["HC_RESIDENT_DIR"], "sock")).st_ino
+    pid = open(os.path.join(resident_env["HC_RESIDENT_DIR"], "pid")).read()
     p = subprocess.Popen([EXE, "--resident", "--help"], env=resident_env, stdout=subprocess.PIPE)
     p.stdout.close()  # `| head -0`: the resident process writes into a closed pipe
     p.wait(timeout=30)
     for _ in range(5):
         assert _run(["--resident", "--help"], resident_env).returncode == 0
-    assert os.stat(os.path.join(resident_env["HC_RESIDENT_DIR"], "sock")).st_ino == ino, "the same resident process (its socket was never re-made)"
+    assert open(os.path.join(resident_env["HC_RESIDENT_DIR"], "pid")).read() == pid, "the same resident process all along"
     assert os.path.exists(log)
     # the working directory of the CLIENT counts (relative --output)
     (tmp_path / "wd").mkdir()
@@ -77,3 +77,25 @@ def test_stop_and_idle_time_out(tmp_path):
         time.sleep(0.1)
     assert not os.path.exists(sock)
     assert subprocess.run([EXE, "--resident_stop"], env=env, timeout=30).returncode == 0, "nobody to stop is not an error"
+
+
+def test_a_rebuilt_library_retires_the_resident_process(resident_env, tmp_path):
+    """A resident process that loaded ANOTHER libhcedge.so than the one next to the executable now (the library was rebuilt under it) must not
+    answer for it: it says so and leaves, the client starts a new one.  Here: a copy of the executable + library in a directory of its own,
+    the library's mtime bumped between two calls."""
+    import shutil
+
+    d = tmp_path / "bin"
+    d.mkdir()
+    exe, lib = str(d / "hc-edgecalc"), str(d / "libhcedge.so")
+    shutil.copy2(EXE, exe)
+    shutil.copy2(os.path.join(os.path.dirname(EXE), "libhcedge.so"), lib)
+    try:
+        assert subprocess.run([exe, "--resident", "--help"], env=resident_env, capture_output=True, timeout=60).returncode == 0
+        pid = open(os.path.join(resident_env["HC_RESIDENT_DIR"], "pid")).read()
+        os.utime(lib, (time.time() + 5, time.time() + 5))
+        r = subprocess.run([exe, "--resident", "--help"], env=resident_env, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "Program options" in r.stdout
+        assert open(os.path.join(resident_env["HC_RESIDENT_DIR"], "pid")).read() != pid, "a new resident process answers"
+    finally:
+        subprocess.run([exe, "--resident_stop"], env=resident_env, timeout=30)
