@@ -221,4 +221,9 @@ int hc_ec_close(hc_ec* ec) {
     return HC_OK;
 }
 
+int hc_ec_keep_devices(int on) {
+    hc::keep_devices_resident(on != 0);
+    return HC_OK;
+}
+
 }  // extern "C"

@@ -60,6 +60,7 @@ _sig = {
     "hc_ec_overlap_score": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "hc_ec_close": (C.c_int, [_vp]),
+    "hc_ec_keep_devices": (C.c_int, [C.c_int]),
     "hc_host_split_line": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, _vp, _vp, C.c_int]),
     "hc_host_parse_overlap": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(hc_overlap_fields), C.c_char_p]),
     "hc_host_fastq_load": (C.c_int, [C.POINTER(_vp), C.POINTER(hc_ec_paths), C.POINTER(hc_fastq_view)]),
@@ -267,6 +268,11 @@ class HostGraph:
                 N.lib.hc_host_graph_free(self._h)
         except Exception:
             pass
+
+
+def keep_devices(on=True):
+    """hc_ec_keep_devices: closed stages park their devices (contexts, text blocks, page-locked buffers) for the next one of this process."""
+    N.check(N.lib.hc_ec_keep_devices(1 if on else 0), "hc_ec_keep_devices")
 
 
 class EdgeCalculatorStage:

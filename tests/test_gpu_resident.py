@@ -68,3 +68,63 @@ def test_a_pipeline_of_changing_stages_through_one_resident_process(tmp_path):
         assert ok.returncode == 0 and open(o + "edges.tsv", "rb").read() == open(f"{d}out_1_1_own/edges.tsv", "rb").read()
     finally:
         subprocess.run([EXE, "--resident_stop"], env=env, timeout=60)
+
+
+def test_stages_of_one_process_take_over_each_others_devices(tmp_path):
+    """hc_ec_keep_devices (what the resident process does, for a caller that opens stage after stage itself): with it on, a closed stage's
+    contexts and text blocks serve the next one — other reads, other settings, another kernel — and every graph equals the one a stage with
+    devices of its own builds; opening gets cheaper from the second stage on."""
+    import time
+
+    import haploconduct_amd as hc
+    from haploconduct_amd import host, synth
+
+    d = str(tmp_path) + "/"
+    cases = []
+    r1, m1 = synth.make_paired_dataset(4000, 6000, flip_frac=0.25, seed=21)
+    cases.append((r1, synth.paired_candidates(m1, n_candidates=100000, seed=22), hc.Settings(edge_threshold=0.97, min_overlap_len=150)))
+    r2, m2 = synth.make_single_dataset(3000, 9000, len_lo=150, len_hi=900, n_strains=3, divergence=0.01, flip_frac=0.5, seed=5, log_uniform=True)
+    cases.append((r2, synth.single_candidates(m2, min_overlap=100, n_candidates=150000), hc.Settings(edge_threshold=0.995, min_overlap_len=100, merge_contigs=0.01)))
+    cases.append((r1, cases[0][1][:60000], hc.Settings(edge_threshold=0.9, min_overlap_len=100)))
+    files = []
+    for k, (reads, cand, st) in enumerate(cases):
+        p = f"{d}c{k}/"
+        os.makedirs(p)
+        host.write_overlaps(p + "overlaps.txt", cand, reads)
+        if reads.is_paired(0):
+            reads.write_fastq(None, p + "p1.fastq", p + "p2.fastq")
+            kw = dict(paired1=p + "p1.fastq", paired2=p + "p2.fastq")
+        else:
+            reads.write_fastq(p + "s.fastq", None, None)
+            kw = dict(singles=p + "s.fastq")
+        st.n_threads = 8
+        files.append((st, dict(kw, overlaps=p + "overlaps.txt", output_dir=p)))
+
+    def run_all():
+        out, opens = [], []
+        for st, kw in files * 2:
+            if os.path.exists(kw["output_dir"] + "nonedge_overlaps.txt"):
+                os.remove(kw["output_dir"] + "nonedge_overlaps.txt")
+            t0 = time.perf_counter()
+            ec = host.EdgeCalculatorStage(st, **kw)
+            opens.append(time.perf_counter() - t0)
+            ec.construct_edges_sorted()
+            out.append((ec.edges().tobytes(), ec.counters(), open(kw["output_dir"] + "nonedge_overlaps.txt", "rb").read()))
+            ec.close()
+        return out, opens
+
+    own, opens_own = run_all()
+    host.keep_devices(True)
+    try:
+        kept, opens_kept = run_all()
+    finally:
+        host.keep_devices(False)
+    for k, (a, b) in enumerate(zip(own, kept)):
+        assert a[0] == b[0] and a[2] == b[2], f"stage {k}: another graph on taken-over devices"
+        for key in ("edges_added", "nonedges_written", "scored", "lines_read", "dup_count", "inclusion_count"):
+            assert a[1][key] == b[1][key], (k, key)
+    assert len(own[0][0]) > 100000
+    # (opening on taken-over devices is the cheaper one — contexts, streams, page-locked text buffers exist already —, but in a warm process
+    # both are a few milliseconds at this size and the box's noise decides single runs: no bar on the clock here; profiles/r05_c1_process.json
+    # has the resident process's figures)
+    print("open_s with devices of their own:", [round(x, 4) for x in opens_own], "taken over:", [round(x, 4) for x in opens_kept])
