@@ -2,11 +2,13 @@
 
 Candidates are independent given the read store, so the path shards with NO data-path
 collective: rank r scores the contiguous slice shard_range(n, r, world) of the candidate
-array against a replicated read store.  The only exchange is the collection of the admitted
-edge records (class EDGE / EDGE_MC / AMBIG): one all-gather of the per-rank counts, then one
-all-gather of the payload padded to the largest count (RCCL has no native all-gather-v).
-Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU
-tests.  Records travel as int64 rows [global_index, x1_bits, x2_bits, mm | n_cls << 32]."""
+array against a replicated read store.  The only exchange is the collection of the non-dropped
+records, once per batch (PayloadGather / StreamedGather below): either ONE all-gather of a
+fixed-capacity payload whose row 0 is the count ("ring"), or the all-gather-v proper — the
+counts by one small all-gather, then grouped per-peer send / recv of exactly the rows
+("direct": every pair of ranks on its own xGMI link).  Works on any torch.distributed backend:
+"nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  Records travel as int64 rows
+[global_index, x1_bits, x2_bits, mm | n_cls << 32]."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -110,7 +112,7 @@ class PayloadGather:
                       "counts_dev": torch.zeros(self.world, dtype=torch.int64, device=self.device),
                       "counts_host": torch.zeros(self.world, dtype=torch.int64, pin_memory=self.cuda),
                       "scored": ev(), "packed": ev(), "counted": ev(), "done": ev(),
-                      "busy": False, "pending": False, "works": [], "unordered": False} for _ in range(depth)]
+                      "busy": False, "pending": False, "unordered": False} for _ in range(depth)]
         self.i = 0
         self._pending = []   # submitted batches whose exchange has not been issued yet (lag mode: until the next flush())
         self._timed = []     # (start event, end event) pairs on the side stream / (seconds,) on CPU
@@ -204,6 +206,8 @@ class PayloadGather:
                     w.wait()
                 t1.record(self.side)
             self._timed.append((key, t0, t1))
+            if len(self._timed) > 8192:  # a long run keeps the latest few thousand brackets
+                del self._timed[:4096]
         else:
             import time
 
