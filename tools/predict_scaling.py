@@ -56,24 +56,30 @@ def main():
         torch.cuda.synchronize()
         kept = int((((d_out.view(torch.int64).view(-1, 3)[:, 2] >> 60) & 0xF) != 0).sum().item())
         kern_ms = sc.time_kernel(d_in.data_ptr(), n, d_out.data_ptr(), args.steps, REC_COMPACT)
-        g = parallel.StreamedGather(sc, n, base_index=lo, cap_rows=kept * 5 // 4 + 1024, rec_fmt=REC_COMPACT)
-        for _ in range(3):
-            g.score_step(d_in.data_ptr(), d_out)
-        g.finish()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        last = None
-        for _ in range(args.steps):
-            last = g.score_step(d_in.data_ptr(), d_out)
-        stream.synchronize()
-        g.finish()
-        torch.cuda.synchronize()
-        step_ms = (time.perf_counter() - t0) / args.steps * 1e3
-        out_rows, counts = g.collect(last)
-        assert counts == [kept]
+        by_reserve = {}
+        for reserve in (0, 16, 32):  # round 5: CUs the scoring launches leave to the exchange's kernels (hc_set_comm_reserve; profiles/r05_coresident.md)
+            g = parallel.StreamedGather(sc, n, base_index=lo, cap_rows=kept * 5 // 4 + 1024, rec_fmt=REC_COMPACT, reserve_cus=reserve)
+            for _ in range(3):
+                g.score_step(d_in.data_ptr(), d_out)
+            g.finish()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            last = None
+            for _ in range(args.steps):
+                last = g.score_step(d_in.data_ptr(), d_out)
+            stream.synchronize()
+            g.finish()
+            torch.cuda.synchronize()
+            by_reserve[reserve] = (time.perf_counter() - t0) / args.steps * 1e3
+            out_rows, counts = g.collect(last)
+            assert counts == [kept]
+            del g
+        sc.set_comm_reserve(0)
+        step_ms = by_reserve[0]
         rows.append({"N": N, "shard_candidates": n, "kept_rows": kept, "payload_MB_per_rank": (kept + 1) * 32 / 1e6, "kernel_ms": kern_ms,
-                     "step_ms_world1": step_ms, "collection_on_critical_path_ms_world1": max(0.0, step_ms - kern_ms)})
-        del d_out, g
+                     "step_ms_world1": step_ms, "step_ms_world1_by_reserved_cus": {str(k): v for k, v in by_reserve.items()},
+                     "collection_on_critical_path_ms_world1": max(0.0, step_ms - kern_ms)})
+        del d_out
         torch.cuda.empty_cache()
     full = rows[0]
     out = {"workload": cfg["workload"], "measured_on": "one MI355X, world size 1 over RCCL (HC_BENCH_FORCE_GATHER's code path)", "steps": args.steps,
@@ -81,6 +87,11 @@ def main():
            "predicted": [{"N": r["N"],
                           "strong_candidates_per_s_PREDICTED": n_all / (r["step_ms_world1"] * 1e-3),
                           "strong_speedup_over_1_PREDICTED": full["step_ms_world1"] / r["step_ms_world1"],
+                          # round 5 (profiles/r05_coresident.md): the exchange runs BESIDE the kernel only on CUs the launch leaves free; without them it
+                          # is serialised behind the kernel.  xgmi estimate x 2: beside the kernel a transfer shares the memory side (measured with stand-ins)
+                          "strong_speedup_PREDICTED_32_cus_reserved_exchange_overlapped": full["step_ms_world1"] / r["step_ms_world1_by_reserved_cus"]["32"],
+                          "strong_speedup_PREDICTED_no_reserve_exchange_serialised": full["step_ms_world1"] / (
+                              r["step_ms_world1"] + (2.0 * (r["N"] - 1) * r["payload_MB_per_rank"] / 1e3 / (min(r["N"] - 1, 7) * 150.0) * 1e3 if r["N"] > 1 else 0.0)),
                           "weak_candidates_per_s_PREDICTED": r["N"] * n_all / (full["step_ms_world1"] * 1e-3),
                           "xgmi_allgather_ms_ESTIMATE_strong": (r["N"] - 1) * r["payload_MB_per_rank"] / 1e3 / (min(r["N"] - 1, 7) * 150.0) * 1e3 if r["N"] > 1 else 0.0,
                           "xgmi_allgather_ms_ESTIMATE_weak": (r["N"] - 1) * full["payload_MB_per_rank"] / 1e3 / (min(r["N"] - 1, 7) * 150.0) * 1e3 if r["N"] > 1 else 0.0}
