@@ -384,7 +384,9 @@ extern "C" int hc_cli_main(int argc, char** argv, void (*on_done)(int code, void
         // Every output file is written and closed and the device is idle: leave without tearing the stage down (unpinning its text
         // buffers, freeing device memory, joining the worker threads and the HIP runtime's own exit handlers took 0.10 - 0.15 s of a
         // 0.3 - 0.4 s run on the SAVAGE example, profiles/r04_c1_process.json) — a pipeline starts this program once per iteration.
-        // HC_CLI_TEARDOWN=1 keeps the orderly way out (sanitizer and leak-check runs).
+        // HC_CLI_TEARDOWN=1 keeps the orderly way out (sanitizer and leak-check runs).  What this relies on: every output of the
+        // program is a FILE* opened and fclose'd in this function before this point, and the stage's clean-up thread (EdgeCalculator::
+        // defer_cleanup) only gives memory back — nothing that writes may ever be handed to it.
         if (on_done) {
             done(0);  // the client leaves now; what is left of the stage goes behind its back (its devices stay: keep_devices_resident)
         } else if (!getenv("HC_CLI_TEARDOWN")) {
