@@ -419,6 +419,8 @@ extern "C" int hc_cli_main(int argc, char** argv, void (*on_done)(int code, void
 #include <sys/stat.h>
 #include <sys/un.h>
 
+extern char** environ;
+
 namespace {
 constexpr uint32_t kResidentMagic = 0x48435235u;  // "HCR5"
 
@@ -463,6 +465,12 @@ void send_code(int code, void* arg) {
 extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long long lib_stamp) {
     const std::string path = sock_path;
     const std::string dir = path.substr(0, path.rfind('/'));
+    {  // the HC_* environment of a job is its CLIENT's: what this process inherited from the client that started it does not stay behind
+        std::vector<std::string> mine;
+        for (char** e = environ; e && *e; e++)
+            if (strncmp(*e, "HC_", 3) == 0 && strncmp(*e, "HC_RESIDENT_", 12) != 0) mine.push_back(std::string(*e, strcspn(*e, "=")));
+        for (const std::string& n : mine) unsetenv(n.c_str());
+    }
     hc::keep_devices_resident(true);  // contexts, text blocks and their page-locked buffers serve one request after the other
     signal(SIGPIPE, SIG_IGN);  // a client whose stdout is a closed pipe (`| head`) must not end the resident process
     // one resident process per socket: whoever holds the lock serves it

@@ -58,6 +58,19 @@ def test_a_pipeline_of_changing_stages_through_one_resident_process(tmp_path):
                 assert outs["own"][0] == outs["resident"][0], f"round {rnd}, case {k}: the resident process wrote other files"
                 assert len(outs["own"][0]["edges_sorted.tsv"]) > 10000
                 assert [ln.split(" in ")[0] for ln in outs["own"][1]] == [ln.split(" in ")[0] for ln in outs["resident"][1]]
+        # the HC_* environment of a job is its CLIENT's, call by call: HC_STAGE_TIMING (the stage's lap prints on stderr) with, without, with
+        o = d + "env_probe/"
+        os.makedirs(o)
+        laps = []
+        subprocess.run([EXE, "--resident_stop"], env=env, timeout=60)  # the next call STARTS a resident process — with the variable in its environment
+        for e in (dict(env, HC_STAGE_TIMING="1"), env, dict(env, HC_STAGE_TIMING="1")):
+            for fn in FILES:
+                if os.path.exists(o + fn):
+                    os.remove(o + fn)
+            r = subprocess.run([EXE, "--resident"] + cases[0] + ["--output", o], env=e, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0
+            laps.append("[hc stage]" in r.stderr)
+        assert laps == [True, False, True], laps
         # a failing job (a FASTQ file that is not there) answers 1 and the resident process goes on
         bad = subprocess.run([EXE, "--resident", "--singles", d + "nope.fastq", "--overlaps", d + "a/overlaps.txt", "--original_readcount", "3", "--output", d], env=env,
                              capture_output=True, text=True, timeout=120)

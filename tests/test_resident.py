@@ -99,3 +99,4 @@ def test_a_rebuilt_library_retires_the_resident_process(resident_env, tmp_path):
         assert open(os.path.join(resident_env["HC_RESIDENT_DIR"], "pid")).read() != pid, "a new resident process answers"
     finally:
         subprocess.run([exe, "--resident_stop"], env=resident_env, timeout=30)
+
