@@ -474,8 +474,21 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long lo
     hc::keep_devices_resident(true);  // contexts, text blocks and their page-locked buffers serve one request after the other
     signal(SIGPIPE, SIG_IGN);  // a client whose stdout is a closed pipe (`| head`) must not end the resident process
     // one resident process per socket: whoever holds the lock serves it
+    // (waits: the holder is either about to serve the socket — then there is nothing left to do here — or a resident process on its way out)
     const int lock = open((dir + "/lock").c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
-    if (lock < 0 || flock(lock, LOCK_EX | LOCK_NB) != 0) return 0;  // somebody else is (becoming) the resident process
+    if (lock < 0 || flock(lock, LOCK_EX) != 0) return 0;
+    {
+        sockaddr_un probe;
+        memset(&probe, 0, sizeof probe);
+        probe.sun_family = AF_UNIX;
+        const int ps = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+        if (ps >= 0 && path.size() < sizeof probe.sun_path) {
+            strcpy(probe.sun_path, path.c_str());
+            const bool served = connect(ps, (sockaddr*)&probe, sizeof probe) == 0;
+            close(ps);
+            if (served) return 0;  // somebody became the resident process while this one waited for the lock
+        }
+    }
     unlink(path.c_str());
     const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     sockaddr_un addr;
@@ -498,6 +511,16 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long lo
         }
     });
     int rc = 0;
+    bool left = false;
+    auto leave = [&] {  // stop serving: nobody connects to this process any more, a successor may take the lock while this one tears down
+        if (left) return;
+        left = true;
+        close(ls);
+        unlink(path.c_str());
+        unlink((dir + "/pid").c_str());
+        flock(lock, LOCK_UN);
+        close(lock);
+    };
     for (;;) {
         pollfd pf{ls, POLLIN, 0};
         const int pr = poll(&pf, 1, idle_s > 0 ? idle_s * 1000 : -1);
@@ -540,13 +563,15 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long lo
         }
         if (!(head[4] & 1u) && (((unsigned long long)head[6] << 32) | head[5]) != lib_stamp) {
             const int32_t stale = -1000;  // kStaleLibrary (cli/hc_edgecalc_main.cpp)
+            leave();
             (void)write_all(cs, &stale, sizeof stale);
             close(fds[0]);
             close(fds[1]);
             close(cs);
             break;
         }
-        if (head[4] & 1u) {  // hc-edgecalc --resident_stop
+        if (head[4] & 1u) {  // hc-edgecalc --resident_stop: the socket and the lock go BEFORE the answer — the client's next call starts a new process
+            leave();
             const int32_t zero = 0;
             (void)write_all(cs, &zero, sizeof zero);
             close(cs);
@@ -611,9 +636,8 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long lo
             break;
         }
     }
+    leave();
     if (warm.joinable()) warm.join();
     hc::keep_devices_resident(false);
-    close(ls);
-    unlink(path.c_str());
     return rc;
 }
