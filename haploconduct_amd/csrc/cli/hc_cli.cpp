@@ -474,21 +474,32 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long lo
     hc::keep_devices_resident(true);  // contexts, text blocks and their page-locked buffers serve one request after the other
     signal(SIGPIPE, SIG_IGN);  // a client whose stdout is a closed pipe (`| head`) must not end the resident process
     // one resident process per socket: whoever holds the lock serves it
-    // (waits: the holder is either about to serve the socket — then there is nothing left to do here — or a resident process on its way out)
+    // (the holder is either about to serve the socket — then there is nothing left to do here — or a resident process on its way out: a few
+    // seconds of polite waiting decide which)
     const int lock = open((dir + "/lock").c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
-    if (lock < 0 || flock(lock, LOCK_EX) != 0) return 0;
-    {
+    if (lock < 0) return 0;
+    auto served = [&] {
         sockaddr_un probe;
         memset(&probe, 0, sizeof probe);
         probe.sun_family = AF_UNIX;
         const int ps = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
-        if (ps >= 0 && path.size() < sizeof probe.sun_path) {
-            strcpy(probe.sun_path, path.c_str());
-            const bool served = connect(ps, (sockaddr*)&probe, sizeof probe) == 0;
-            close(ps);
-            if (served) return 0;  // somebody became the resident process while this one waited for the lock
+        if (ps < 0 || path.size() >= sizeof probe.sun_path) return false;
+        strcpy(probe.sun_path, path.c_str());
+        const bool yes = connect(ps, (sockaddr*)&probe, sizeof probe) == 0;
+        close(ps);
+        return yes;
+    };
+    bool mine = false;
+    for (int k = 0; k < 500 && !mine; k++) {
+        if (flock(lock, LOCK_EX | LOCK_NB) == 0) {
+            mine = true;
+        } else {
+            if (served()) return 0;  // somebody else is the resident process
+            timespec ts{0, 10000000};
+            nanosleep(&ts, nullptr);
         }
     }
+    if (!mine || served()) return 0;
     unlink(path.c_str());
     const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     sockaddr_un addr;

@@ -100,3 +100,19 @@ def test_a_rebuilt_library_retires_the_resident_process(resident_env, tmp_path):
     finally:
         subprocess.run([exe, "--resident_stop"], env=resident_env, timeout=30)
 
+
+
+def test_many_clients_at_once_start_one_resident_process(tmp_path):
+    """Eight clients started together on a socket nobody serves yet: every one is answered, one resident process remains (the others that
+    were started by the race leave as soon as they see the socket served)."""
+    env = dict(os.environ, HC_RESIDENT_DIR=str(tmp_path / "res4"), HC_RESIDENT_IDLE_S="30")
+    try:
+        ps = [subprocess.Popen([EXE, "--resident", "--help"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for _ in range(8)]
+        for p in ps:
+            out, err = p.communicate(timeout=60)
+            assert p.returncode == 0 and b"Program options" in out, err
+        time.sleep(0.5)
+        alive = subprocess.run(["pgrep", "-c", "-f", f"resident_daemon {env['HC_RESIDENT_DIR']}/sock"], capture_output=True, text=True).stdout.strip()
+        assert alive == "1", f"{alive} resident processes on one socket"
+    finally:
+        subprocess.run([EXE, "--resident_stop"], env=env, timeout=30)
