@@ -112,7 +112,14 @@ def test_many_clients_at_once_start_one_resident_process(tmp_path):
             out, err = p.communicate(timeout=60)
             assert p.returncode == 0 and b"Program options" in out, err
         time.sleep(0.5)
-        alive = subprocess.run(["pgrep", "-c", "-f", f"resident_daemon {env['HC_RESIDENT_DIR']}/sock"], capture_output=True, text=True).stdout.strip()
-        assert alive == "1", f"{alive} resident processes on one socket"
+        want = f"--resident_daemon\0{env['HC_RESIDENT_DIR']}/sock".encode()
+        alive = 0
+        for pid in os.listdir("/proc"):
+            if pid.isdigit():
+                try:
+                    alive += want in open(f"/proc/{pid}/cmdline", "rb").read()
+                except OSError:
+                    pass
+        assert alive == 1, f"{alive} resident processes on one socket"
     finally:
         subprocess.run([EXE, "--resident_stop"], env=env, timeout=30)
