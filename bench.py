@@ -116,7 +116,7 @@ def roofline_record(workload, order, n, positions, kern_ms, kernel_info, symbyte
     """See the module docstring.  `frac` = `achieved` / `peak` with peak = the 8 TB/s HBM spec (the quantity of rounds 1 - 3; round 4 had
     divided by the guide's 7.4 TB/s gather ceiling — that ratio is now `frac_of_fabric_gather`); the numerator is the L2's memory-side
     traffic per launch as the PMC passes count it (Infinity-Cache hits included).  `bound` = the busiest unit by the same file's counters
-    ("valu": issue-bound; "fabric": the memory side, as a share of the HBM peak).  The algorithmic figures (`frac_encoded`, `frac_8d`)
+    ("valu": issue-bound; "hbm": the memory side — the L2's fabric traffic, Infinity-Cache hits included, as a share of the HBM peak).  The algorithmic figures (`frac_encoded`, `frac_8d`)
     need no counters."""
     kernel_symbol = kernel_info.split(" encoding=")[0]
     t_s = kern_ms * 1e-3
@@ -157,7 +157,7 @@ def roofline_record(workload, order, n, positions, kern_ms, kernel_info, symbyte
     if c.get("GRBM_GUI_ACTIVE"):
         cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
         n_cu = 256
-        busy["fabric"] = r["frac"]
+        busy["hbm"] = r["frac"]  # the memory side: fabric bytes (Infinity-Cache hits included) against the HBM peak
         if c.get("TA_BUSY_avr"):
             busy["ta"] = c["TA_BUSY_avr"] / cycles  # vector-memory front end (address processing of the gathers)
         if c.get("SQ_ACTIVE_INST_VALU"):
@@ -721,7 +721,7 @@ def summary_record(out, args):
           "kernel_ms": r.get("kernel_ms"), "roofline_frac": r.get("frac"), "roofline_bound": r.get("bound"),
           "parity_checked_records": out.get("parity_checked_records"), "edges": out.get("edges")}
     busy = r.get("busy") or {}
-    for k in ("valu", "lds", "ta", "fabric", "lds_bank_conflict_share", "valu_instructions_per_candidate"):
+    for k in ("valu", "lds", "ta", "hbm", "lds_bank_conflict_share", "valu_instructions_per_candidate"):
         if k in busy:
             sm["busy_" + k] = round(busy[k], 4)
     st = out.get("stage_end_to_end")
