@@ -47,6 +47,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import sys
 import time
 
@@ -181,6 +182,25 @@ def roofline_record(workload, order, n, positions, kern_ms, kernel_info, symbyte
 
 
 _WORKLOADS = {}
+PAIRED_WORKLOAD = re.compile(r"^(c2|c2-small|c2-mid|c2-100k|c3|c3-lite)(q(\d+)(r?))?$")
+
+
+def cached_candidates(key, make):
+    """HC_WORKLOAD_CACHE=<dir>: the candidate records of a synthetic workload are kept there between processes (the PMC passes of
+    tools/collect_traffic.sh run one process per counter group over the same 10^8 candidates: a minute of numpy each time).  The key names
+    everything the records depend on; unset: generated every time."""
+    d = os.environ.get("HC_WORKLOAD_CACHE")
+    if not d:
+        return make()
+    path = os.path.join(d, "cand_" + "_".join(str(k) for k in key) + ".npy")
+    if os.path.exists(path):
+        return np.load(path)
+    cand = make()
+    os.makedirs(d, exist_ok=True)
+    tmp = path + f".{os.getpid()}.tmp.npy"
+    np.save(tmp, cand)
+    os.replace(tmp, path)
+    return cand
 
 
 def build_workload(workload, rank, keep=False):
@@ -195,13 +215,37 @@ def build_workload(workload, rank, keep=False):
     import haploconduct_amd as hc
 
     st = dict(edge_threshold=0.97, ov_threshold=0.9, merge_contigs=0.0, min_overlap_len=150)
-    if workload in ("c2", "c2-small", "c2-mid", "c2-100k", "c3", "c3-lite"):
+    pw = PAIRED_WORKLOAD.match(workload)
+    if pw:
+        # <base>[q<K>[r]]: the base configuration's pairs and candidates with K distinct quality values — uniform i.i.d. (the HC_C4_K idea at
+        # the north-star size: K = 25 -> the LG = 5 table, 35 -> the wide 8-bit table, 60 -> 16-bit symbols), or with `r` drawn from the
+        # histogram of the reference's example reads that has K values (tests/golden/quality_histograms.json: 35 = polyte/example
+        # forward.fastq, 25 = savage/example singles.fastq, 20 = its paired1.fastq).  Bases, fragments and candidates are the base
+        # configuration's own (synth.make_paired_dataset draws the qualities last).
+        base, nq, real = pw.group(1), pw.group(3), bool(pw.group(4))
         n_pairs, glen, n_cand = {"c2": (50000, 45000, 2000000), "c2-small": (5000, 1800, 200000), "c2-mid": (50000, 45000, 400000), "c2-100k": (50000, 45000, 100000),
-                                 "c3": (500000, 90000, 100000000), "c3-lite": (500000, 90000, 20000000)}[workload]
-        reads, meta = synth.make_paired_dataset(n_pairs, glen, seed=1)
-        cand = synth.paired_candidates(meta, n_candidates=n_cand, seed=2 + rank)
-        desc = f"{workload}: {n_pairs} synthetic 2x150 bp read pairs, {n_cand} p-p candidates per GPU"
-        cfg = {"read_pairs": n_pairs, "genome_len": glen}
+                                 "c3": (500000, 90000, 100000000), "c3-lite": (500000, 90000, 20000000)}[base]
+        quals, qual_p, qdesc = None, None, "6 quality values (SURVEY 8(d))"
+        if nq:
+            nq = int(nq)
+            if real:
+                with open(os.path.join(ROOT, "tests", "golden", "quality_histograms.json")) as f:
+                    hists = json.load(f)
+                pick = [h for h in hists.values() if h["distinct"] == nq]
+                if not pick:
+                    raise SystemExit(f"no example-read histogram with {nq} quality values (have {sorted(h['distinct'] for h in hists.values())})")
+                quals = np.array([int(b) for b in pick[0]["counts"]], dtype=np.uint8)
+                qual_p = np.array(list(pick[0]["counts"].values()), dtype=np.float64)
+                qdesc = f"{nq} quality values drawn from the histogram of the reference's {pick[0]['source']}"
+            else:
+                if not 1 <= nq <= 93:
+                    raise SystemExit("q<K>: 1 <= K <= 93")
+                quals = (np.arange(1, nq + 1) + 33).astype(np.uint8)
+                qdesc = f"{nq} quality values, uniform i.i.d."
+        reads, meta = synth.make_paired_dataset(n_pairs, glen, seed=1, quals=quals, qual_p=qual_p)
+        cand = cached_candidates(("paired", n_pairs, glen, n_cand, 2 + rank), lambda: synth.paired_candidates(meta, n_candidates=n_cand, seed=2 + rank))
+        desc = f"{workload}: {n_pairs} synthetic 2x150 bp read pairs, {qdesc}, {n_cand} p-p candidates per GPU"
+        cfg = {"read_pairs": n_pairs, "genome_len": glen, "quality_alphabet": int(np.unique(reads.quals).size)}
     elif workload == "c4":
         # POLYTE diploid 20x per haplotype, 2x250 bp, every read a single (polyte.py:283-288), both orientations,
         # edge_threshold 1 / merge_contigs 0 (polyte.py:617-626), 35 distinct quality values as in polyte/example

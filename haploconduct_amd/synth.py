@@ -38,8 +38,10 @@ def _mutate(rng, seq, rate):
 
 
 def make_paired_dataset(n_pairs, genome_len, n_strains=3, divergence=0.01, read_len=150, ins_lo=350, ins_hi=600,
-                        err=0.005, n_rate=0.001, flip_frac=0.0, seed=1, trim_lo=None):
+                        err=0.005, n_rate=0.001, flip_frac=0.0, seed=1, trim_lo=None, quals=None, qual_p=None):
     """Returns (ReadSet, meta) where meta has frag start `s`, /2 start `e`, `flipped` per pair.
+    quals: the quality bytes (ASCII, +33 applied) the bases draw from, i.i.d. — uniformly, or with the probabilities `qual_p` (a histogram
+    of real reads); default: QUAL_SET.  The bases, the fragments and hence the candidates do not depend on it (qualities are drawn last).
     trim_lo: every mate keeps only its first U[trim_lo, read_len] bases (quality-trimmed reads: sequences of mixed length; needs
     flip_frac == 0); meta then also has the mates' lengths `l1`, `l2`."""
     rng = np.random.default_rng(seed)
@@ -64,8 +66,15 @@ def make_paired_dataset(n_pairs, genome_len, n_strains=3, divergence=0.01, read_
         return r
 
     r1, r2 = noise(r1), noise(r2)
-    q1 = QUAL_SET[rng.integers(0, QUAL_SET.size, r1.shape)]
-    q2 = QUAL_SET[rng.integers(0, QUAL_SET.size, r2.shape)]
+    qset = QUAL_SET if quals is None else np.asarray(quals, dtype=np.uint8)
+    if qual_p is None:
+        q1 = qset[rng.integers(0, qset.size, r1.shape)]
+        q2 = qset[rng.integers(0, qset.size, r2.shape)]
+    else:  # inverse-CDF draw (rng.choice with p= needs 8 bytes per draw)
+        cdf = np.cumsum(np.asarray(qual_p, dtype=np.float64))
+        cdf /= cdf[-1]
+        q1 = qset[np.minimum(np.searchsorted(cdf, rng.random(r1.shape, dtype=np.float32)), qset.size - 1)]
+        q2 = qset[np.minimum(np.searchsorted(cdf, rng.random(r2.shape, dtype=np.float32)), qset.size - 1)]
     flipped = rng.random(n_pairs) < flip_frac
     if flipped.any():
         f = np.nonzero(flipped)[0]
