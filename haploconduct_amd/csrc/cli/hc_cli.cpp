@@ -452,10 +452,14 @@ bool write_all(int fd, const void* p, size_t n) {
 }
 struct Reply {
     int fd;
+    bool sent;
 };
 void send_code(int code, void* arg) {
+    Reply* r = (Reply*)arg;
+    if (!r || r->sent) return;
+    r->sent = true;
     const int32_t c = code;
-    (void)write_all(((Reply*)arg)->fd, &c, sizeof c);
+    (void)write_all(r->fd, &c, sizeof c);
 }
 }  // namespace
 
@@ -532,10 +536,16 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long lo
         flock(lock, LOCK_UN);
         close(lock);
     };
+    bool draining = false;
     for (;;) {
         pollfd pf{ls, POLLIN, 0};
-        const int pr = poll(&pf, 1, idle_s > 0 ? idle_s * 1000 : -1);
-        if (pr == 0) break;  // idle
+        const int pr = poll(&pf, 1, draining ? 0 : (idle_s > 0 ? idle_s * 1000 : -1));
+        if (pr == 0) {  // idle: the socket's NAME goes first (whoever comes now starts a successor, which waits for the lock), then the
+            if (draining) break;  // clients that connected in the meantime are served — nobody is left un-accepted in the backlog
+            unlink(path.c_str());
+            draining = true;
+            continue;
+        }
         if (pr < 0) {
             if (errno == EINTR) continue;
             rc = 2;
@@ -548,6 +558,10 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long lo
         if (getsockopt(cs, SOL_SOCKET, SO_PEERCRED, &cred, &cl) != 0 || cred.uid != getuid()) {
             close(cs);
             continue;
+        }
+        {  // a peer that connects and then says nothing must not hold the (single-threaded) loop: its request has five seconds to arrive
+            timeval tv{5, 0};
+            setsockopt(cs, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
         }
         // header + the client's stdout and stderr (SCM_RIGHTS)
         uint32_t head[7];  // magic, argc, n_env, cwd bytes, flags (1 = stop), the client's library stamp (low, high)
@@ -622,16 +636,25 @@ extern "C" int hc_cli_daemon(const char* sock_path, int idle_s, unsigned long lo
         close(fds[0]);
         close(fds[1]);
         int code = 1;
-        if (chdir(cwd.c_str()) != 0) {
+        Reply rp{cs, false};
+        if (chdir(cwd.c_str()) != 0) {  // (the client's directory may have been removed, or be unreadable to nobody but it)
             fprintf(stderr, "hc-edgecalc --resident: cannot enter %s\n", cwd.c_str());
-            send_code(1, nullptr);
+            send_code(1, &rp);
         } else {
             std::vector<char*> argv;
             for (std::string& a : args) argv.push_back(&a[0]);
             argv.push_back(nullptr);
-            Reply rp{cs};
             g_device_fault = false;
-            code = hc_cli_main((int)args.size(), argv.data(), send_code, &rp);  // answers as soon as the outputs are closed, then tears down
+            try {
+                code = hc_cli_main((int)args.size(), argv.data(), send_code, &rp);  // answers as soon as the outputs are closed, then tears down
+            } catch (const std::exception& e) {  // (std::bad_alloc and the like: the job is lost, the resident process and its client's descriptors are not)
+                fprintf(stderr, "hc-edgecalc --resident: %s\n", e.what());
+                code = 1;
+            } catch (...) {
+                fprintf(stderr, "hc-edgecalc --resident: the job ended in an exception\n");
+                code = 1;
+            }
+            if (!rp.sent) send_code(code, &rp);
         }
         fflush(stdout);
         fflush(stderr);

@@ -8,6 +8,9 @@
 //   hc-edgecalc --resident_stop             asks the resident process to leave
 //   hc-edgecalc --resident_daemon <socket>  the resident process itself (hc_cli_daemon); not for users
 // Socket: $HC_RESIDENT_DIR, else $XDG_RUNTIME_DIR/hc-edgecalc, else /tmp/hc-edgecalc-<uid>; idle time-out HC_RESIDENT_IDLE_S (600).
+// Clients whose HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES or GPU_DEVICE_ORDINAL differ get resident processes of their own (a sub-directory
+// per setting).  A job sees its client's HC_* variables, with one exception: the experiment-only launch knobs (HC_COOP_DMA, HC_WAVE_QUEUE,
+// HC_GRID_MULT, HC_COOP_DEPTH, HC_COOP_WG_PER_CU) are read once per process and stay what the first job saw.
 // Argv contract: /root/reference/scripts/pipeline_per_stage.py:223-247,272-298 — `--resident` is the one extra word.
 #include <dlfcn.h>
 #include <errno.h>
@@ -61,6 +64,35 @@ static std::string socket_dir() {
     if (const char* d = getenv("HC_RESIDENT_DIR")) return d;
     if (const char* d = getenv("XDG_RUNTIME_DIR")) return std::string(d) + "/hc-edgecalc";
     return "/tmp/hc-edgecalc-" + std::to_string((unsigned)getuid());
+}
+
+// Which devices a process sees is fixed when its HIP runtime starts: two clients with different *_VISIBLE_DEVICES must never share one
+// resident process (round-5 advisor: they landed silently on the first client's device).  The variables that decide it are part of the
+// resident process's identity — a sub-directory of the socket directory named after their hash; none set: the directory itself.
+static std::string visibility_tag() {
+    static const char* const names[] = {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"};
+    uint64_t h = 1469598103934665603ull;  // FNV-1a over name=value of the ones that are set
+    bool any = false;
+    for (const char* n : names) {
+        const char* v = getenv(n);
+        if (!v) continue;
+        any = true;
+        for (const char* c = n; *c; c++) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+        h = (h ^ (unsigned char)'=') * 1099511628211ull;
+        for (const char* c = v; *c; c++) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+        h = (h ^ 0xFFu) * 1099511628211ull;
+    }
+    if (!any) return "";
+    char buf[32];
+    snprintf(buf, sizeof buf, "vis-%016llx", (unsigned long long)h);
+    return buf;
+}
+
+// a directory of this user's, mode 0700, and a directory itself — not a symbolic link somebody else put there (lstat)
+static bool own_private_dir(const std::string& dir) {
+    mkdir(dir.c_str(), 0700);
+    struct stat sb;
+    return lstat(dir.c_str(), &sb) == 0 && S_ISDIR(sb.st_mode) && sb.st_uid == getuid() && !(sb.st_mode & 077);
 }
 
 static bool write_all(int fd, const void* p, size_t n) {
@@ -129,11 +161,16 @@ static int client(int argc, char** argv, bool stop) {
 }
 
 static int client_once(int argc, char** argv, bool stop) {
-    const std::string dir = socket_dir(), sock = dir + "/sock";
-    mkdir(dir.c_str(), 0700);
-    struct stat sb;
-    if (stat(dir.c_str(), &sb) != 0 || sb.st_uid != getuid() || (sb.st_mode & 077)) {
-        fprintf(stderr, "hc-edgecalc --resident: %s must be a directory of this user's with mode 0700\n", dir.c_str());
+    std::string dir = socket_dir();
+    const std::string vis = visibility_tag();
+    bool ok_dir = own_private_dir(dir);
+    if (ok_dir && !vis.empty()) {
+        dir += "/" + vis;
+        ok_dir = own_private_dir(dir);
+    }
+    const std::string sock = dir + "/sock";
+    if (!ok_dir) {
+        fprintf(stderr, "hc-edgecalc --resident: %s must be a directory (not a link) of this user's with mode 0700\n", dir.c_str());
         return 1;
     }
     int s = connect_to(sock);

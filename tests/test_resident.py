@@ -12,9 +12,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "haploconduct_amd", "csrc", "hc-edgecalc")
 
 
+VISIBILITY = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")
+
+
+def _base_env(**kw):
+    """The test's environment without device-visibility variables: they are part of a resident process's identity (a sub-directory per
+    setting, test_device_visibility_is_part_of_the_resident_process_identity), the other tests look for the socket in the directory itself."""
+    env = {k: v for k, v in os.environ.items() if k not in VISIBILITY}
+    env.update(kw)
+    return env
+
+
 @pytest.fixture
 def resident_env(tmp_path):
-    env = dict(os.environ, HC_RESIDENT_DIR=str(tmp_path / "res"), HC_RESIDENT_IDLE_S="30")
+    env = _base_env(HC_RESIDENT_DIR=str(tmp_path / "res"), HC_RESIDENT_IDLE_S="30")
     yield env
     subprocess.run([EXE, "--resident_stop"], env=env, timeout=30)
 
@@ -60,7 +71,7 @@ def test_one_resident_process_serves_many_calls_and_a_closed_pipe_does_not_end_i
 
 
 def test_stop_and_idle_time_out(tmp_path):
-    env = dict(os.environ, HC_RESIDENT_DIR=str(tmp_path / "res2"), HC_RESIDENT_IDLE_S="1")
+    env = _base_env(HC_RESIDENT_DIR=str(tmp_path / "res2"), HC_RESIDENT_IDLE_S="1")
     assert _run(["--resident", "--help"], env).returncode == 0
     sock = os.path.join(env["HC_RESIDENT_DIR"], "sock")
     assert os.path.exists(sock)
@@ -105,7 +116,7 @@ def test_a_rebuilt_library_retires_the_resident_process(resident_env, tmp_path):
 def test_many_clients_at_once_start_one_resident_process(tmp_path):
     """Eight clients started together on a socket nobody serves yet: every one is answered, one resident process remains (the others that
     were started by the race leave as soon as they see the socket served)."""
-    env = dict(os.environ, HC_RESIDENT_DIR=str(tmp_path / "res4"), HC_RESIDENT_IDLE_S="30")
+    env = _base_env(HC_RESIDENT_DIR=str(tmp_path / "res4"), HC_RESIDENT_IDLE_S="30")
     try:
         ps = [subprocess.Popen([EXE, "--resident", "--help"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for _ in range(8)]
         for p in ps:
@@ -123,3 +134,90 @@ def test_many_clients_at_once_start_one_resident_process(tmp_path):
         assert alive == 1, f"{alive} resident processes on one socket"
     finally:
         subprocess.run([EXE, "--resident_stop"], env=env, timeout=30)
+
+
+def test_a_client_whose_directory_is_gone_gets_an_exit_code_and_the_resident_process_lives(resident_env, tmp_path):
+    """Round-5 advisor: chdir() into the client's working directory failing took the resident process down (a null reply handle) with the
+    client's descriptors attached.  The client now gets exit code 1 and the message; the same resident process answers the next call."""
+    assert _run(["--resident", "--help"], resident_env).returncode == 0
+    pid = open(os.path.join(resident_env["HC_RESIDENT_DIR"], "pid")).read()
+    gone = tmp_path / "gone"
+    gone.mkdir()
+    # the client stands in a directory that is removed before it calls (getcwd fails -> "/" is sent? no: the launcher reads its cwd first)
+    code = ("import os, subprocess, sys; os.chdir(sys.argv[1]); os.rmdir(sys.argv[1]); "
+            "r = subprocess.run([sys.argv[2], '--resident', '--help'], capture_output=True, text=True); "
+            "print(r.returncode); sys.stderr.write(r.stderr)")
+    r = subprocess.run(["python3", "-c", code, str(gone), EXE], env=resident_env, capture_output=True, text=True, timeout=60)
+    # a removed directory: getcwd() fails in the launcher, which then sends "/" — the call succeeds from there; either way an answer comes back
+    assert r.stdout.strip() in ("0", "1"), (r.stdout, r.stderr)
+    # a directory the resident process cannot enter: a path that does not exist, sent by a client standing in a directory renamed under it
+    moved = tmp_path / "here"
+    moved.mkdir()
+    code2 = ("import os, subprocess, sys; os.chdir(sys.argv[1]); "
+             "real_getcwd = os.getcwd(); os.rename(sys.argv[1], sys.argv[1] + '.moved'); os.mkdir(sys.argv[1]); os.rmdir(sys.argv[1]); "
+             "r = subprocess.run([sys.argv[2], '--resident', '--help'], capture_output=True, text=True); print(r.returncode); sys.stderr.write(r.stderr)")
+    r2 = subprocess.run(["python3", "-c", code2, str(moved), EXE], env=resident_env, capture_output=True, text=True, timeout=60)
+    assert r2.stdout.strip() in ("0", "1"), (r2.stdout, r2.stderr)
+    assert "went away" not in r.stderr and "went away" not in r2.stderr
+    assert _run(["--resident", "--help"], resident_env).returncode == 0
+    assert open(os.path.join(resident_env["HC_RESIDENT_DIR"], "pid")).read() == pid, "the resident process survived both"
+
+
+def test_unenterable_directory_is_answered_with_code_1(resident_env, tmp_path):
+    """The resident loop's own branch: the request names a working directory that does not exist (sent here by hand, as the launcher would)."""
+    import socket
+    import struct
+
+    assert _run(["--resident", "--help"], resident_env).returncode == 0
+    pid = open(os.path.join(resident_env["HC_RESIDENT_DIR"], "pid")).read()
+    lib = os.path.join(os.path.dirname(EXE), "libhcedge.so")
+    st = os.stat(lib)
+    stamp = (int(st.st_mtime_ns // 10**9) * 1000000007 + int(st.st_mtime_ns % 10**9) + (st.st_size << 20)) & (2**64 - 1)
+    out_r, out_w = os.pipe()
+    err_r, err_w = os.pipe()
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.connect(os.path.join(resident_env["HC_RESIDENT_DIR"], "sock"))
+    cwd = str(tmp_path / "no" / "such" / "dir").encode()
+    args = [b"hc-edgecalc", b"--help"]
+    head = struct.pack("<7I", 0x48435235, len(args), 0, len(cwd), 0, stamp & 0xFFFFFFFF, stamp >> 32)
+    socket.send_fds(s, [head], [out_w, err_w])
+    os.close(out_w)
+    os.close(err_w)
+    for b in [cwd] + args:
+        s.sendall(struct.pack("<I", len(b)) + b)
+    s.settimeout(30)
+    code = s.recv(4)
+    assert len(code) == 4 and struct.unpack("<i", code)[0] == 1
+    assert b"cannot enter" in os.read(err_r, 4096)
+    s.close()
+    assert _run(["--resident", "--help"], resident_env).returncode == 0
+    assert open(os.path.join(resident_env["HC_RESIDENT_DIR"], "pid")).read() == pid, "the resident process is still the same one"
+
+
+def test_device_visibility_is_part_of_the_resident_process_identity(tmp_path):
+    """Round-5 advisor: two clients with different HIP_VISIBLE_DEVICES must not share one resident process (which devices a process sees is
+    fixed when its runtime starts).  Each setting gets a sub-directory — socket, lock, pid — of its own."""
+    base = _base_env(HC_RESIDENT_DIR=str(tmp_path / "res5"), HC_RESIDENT_IDLE_S="30")
+    e0, e1 = dict(base, HIP_VISIBLE_DEVICES="0"), dict(base, HIP_VISIBLE_DEVICES="1")
+    try:
+        for env in (base, e0, e1, e0):
+            assert _run(["--resident", "--help"], env).returncode == 0
+        subs = sorted(d for d in os.listdir(base["HC_RESIDENT_DIR"]) if d.startswith("vis-"))
+        assert len(subs) == 2, subs
+        pids = {open(os.path.join(base["HC_RESIDENT_DIR"], d, "pid")).read() for d in subs}
+        pids.add(open(os.path.join(base["HC_RESIDENT_DIR"], "pid")).read())
+        assert len(pids) == 3, "three settings, three resident processes"
+    finally:
+        for env in (base, e0, e1):
+            subprocess.run([EXE, "--resident_stop"], env=env, timeout=30)
+
+
+def test_socket_directory_must_not_be_a_symbolic_link(tmp_path):
+    real = tmp_path / "real"
+    real.mkdir(mode=0o700)
+    link = tmp_path / "link"
+    os.symlink(real, link)
+    env = _base_env(HC_RESIDENT_DIR=str(link))
+    r = _run(["--resident", "--help"], env)
+    assert r.returncode == 1 and "not a link" in r.stderr
+    assert os.listdir(real) == []
