@@ -182,6 +182,7 @@ def roofline_record(workload, order, n, positions, kern_ms, kernel_info, symbyte
 
 
 _WORKLOADS = {}
+_CAND_MEMO = {}
 PAIRED_WORKLOAD = re.compile(r"^(c2|c2-small|c2-mid|c2-100k|c3|c3-lite)(q(\d+)(r?))?$")
 
 
@@ -189,13 +190,20 @@ def cached_candidates(key, make):
     """HC_WORKLOAD_CACHE=<dir>: the candidate records of a synthetic workload are kept there between processes (the PMC passes of
     tools/collect_traffic.sh run one process per counter group over the same 10^8 candidates: a minute of numpy each time).  The key names
     everything the records depend on; unset: generated every time."""
+    if _CAND_MEMO.get("key") == key:  # the q<K> variants of a configuration score the configuration's own candidates
+        return _CAND_MEMO["cand"]
     d = os.environ.get("HC_WORKLOAD_CACHE")
     if not d:
-        return make()
+        cand = make()
+        _CAND_MEMO.update(key=key, cand=cand)
+        return cand
     path = os.path.join(d, "cand_" + "_".join(str(k) for k in key) + ".npy")
     if os.path.exists(path):
-        return np.load(path)
+        cand = np.load(path)
+        _CAND_MEMO.update(key=key, cand=cand)
+        return cand
     cand = make()
+    _CAND_MEMO.update(key=key, cand=cand)
     os.makedirs(d, exist_ok=True)
     tmp = path + f".{os.getpid()}.tmp.npy"
     np.save(tmp, cand)
@@ -402,11 +410,14 @@ def cpu_baseline_reference(reads, settings, cand, budget_s=10.0, n_lines=200000)
 
     # fixed thread counts on the full sample (round 5: the round-4 sweep picked a count on one short run and the figure wandered 1.1 - 1.9e6
     # with the pick): every count gets the same share of the budget, the best is `value`, all of them are reported
+    # round 6: the smallest count (32 threads, the fastest on every box so far) runs for the whole budget_s (>= 10 s: the driver's and the
+    # builder's runs of round 5 differed by 19 % on 3 s), the others for a quarter of it each
     counts = sorted({t for t in (32, 64, 128) if t <= hw} or {hw})
     per_threads = {}
     for t in counts:
         first = float(run(t, 1)[0])  # spins the OpenMP team up and sizes the repetitions
-        reps = int(max(2, min(50, (budget_s / len(counts)) / max(first, 1e-3))))
+        share = budget_s if t == counts[0] else budget_s / 4.0
+        reps = int(max(2, min(200, share / max(first, 1e-3))))
         secs = run(t, reps)
         per_threads[t] = {"value": len(lines) * reps / float(secs.sum()), "reps": reps, "seconds": float(secs.sum()),
                           "best_rep_value": len(lines) / float(secs.min())}
@@ -505,6 +516,9 @@ def parity_record(torch, sc, reads, settings, cand, d_out, n, digest_timed, dige
     from haploconduct_amd.records import RESULT_DTYPE, result_cls, result_n
     from tests import _oracle
 
+    if os.environ.get("HC_BENCH_ABLATION"):  # experiment builds whose results are garbage by construction (tools/experiments/ablate.sh): timing only
+        return {"parity": "NOT CHECKED: HC_BENCH_ABLATION is set — this line times an ablation build and is not a measurement of the product",
+                "invalid": True, "parity_checked_records": 0, "edges": None}
     if digest_timed != digest_untimed:
         raise SystemExit(f"bench.py: the timed steps left other results than an untimed launch (digest {digest_timed:#x} vs {digest_untimed:#x})")
     stretch = min(stretch, n)
@@ -761,8 +775,12 @@ def stage_end_to_end(reads, cand, settings, threads, reps=4):
 def summary_record(out, args):
     """The line's figures once more, compact and LAST (the driver's record keeps the tail of stdout)."""
     r = out.get("roofline", {})
-    sm = {"value": out["value"], "ms_per_step": out["ms_per_step"], "n_gpus": out["n_gpus"], "scaling": out["scaling"], "workload": args.workload,
-          "kernel_ms": r.get("kernel_ms"), "roofline_frac": r.get("frac"), "roofline_bound": r.get("bound"),
+    def g(x, nd=5):  # compact: the driver's record keeps 2 000 characters of tail
+        return float(f"{x:.{nd}g}") if isinstance(x, float) else x
+
+    sm = {"value": g(out["value"]), "ms_per_step": g(out["ms_per_step"]), "n_gpus": out["n_gpus"], "scaling": out["scaling"], "workload": args.workload,
+          "kernel_ms": g(r.get("kernel_ms")), "roofline_frac": g(r.get("frac"), 4), "roofline_bound": r.get("bound"),
+          "roofline_frac_8d_note": "8(d) bytes give %.2f of peak (not a bound: fused symbol byte + L1/L2 reuse); counter traffic gives frac" % (r.get("frac_8d") or 0.0),
           "parity_checked_records": out.get("parity_checked_records"), "edges": out.get("edges")}
     busy = r.get("busy") or {}
     for k in ("valu", "lds", "ta", "hbm", "lds_bank_conflict_share", "valu_instructions_per_candidate"):
@@ -771,19 +789,21 @@ def summary_record(out, args):
     st = out.get("stage_end_to_end")
     if st:
         runs = [x["construct_edges_sorted_s"] for x in st["runs"]]
-        sm[f"{args.workload}_stage_median_s"], sm[f"{args.workload}_stage_first_s"] = st["median"]["construct_edges_sorted_s"], runs[0]
+        sm[f"{args.workload}_stage_median_s"], sm[f"{args.workload}_stage_first_s"] = g(st["median"]["construct_edges_sorted_s"], 4), g(runs[0], 4)
         sm[f"{args.workload}_stage_runs_s"] = [round(x, 4) for x in runs]
-        sm[f"{args.workload}_stage_lines_per_s"] = st["value"]
+        sm[f"{args.workload}_stage_lines_per_s"] = g(st["value"], 4)
     for w, rec in (out.get("also") or {}).items():
-        sm[f"{w}_ms_per_step"], sm[f"{w}_kernel_ms"] = rec["ms_per_step"], rec["roofline"]["kernel_ms"]
+        sm[f"{w}_ms_per_step"], sm[f"{w}_kernel_ms"] = g(rec["ms_per_step"], 4), g(rec["roofline"]["kernel_ms"], 4)
+        if rec["roofline"].get("frac") is not None:
+            sm[f"{w}_roofline_frac"] = g(rec["roofline"]["frac"], 3)
         if rec.get("stage_end_to_end"):
-            sm[f"{w}_stage_median_s"] = rec["stage_end_to_end"]["median"]["construct_edges_sorted_s"]
+            sm[f"{w}_stage_median_s"] = g(rec["stage_end_to_end"]["median"]["construct_edges_sorted_s"], 4)
     cb = out.get("cpu_baseline")
     if cb:
-        sm["cpu_baseline"] = {"value": cb["value"], "cores": cb["cores"], "kind": cb["kind"],
+        sm["cpu_baseline"] = {"value": g(cb["value"], 4), "cores": cb["cores"], "kind": cb["kind"],
                               "by_threads": {t: round(v["value"]) for t, v in (cb.get("by_threads") or {}).items()}}
         if cb.get("stage"):
-            sm["cpu_baseline_stage"] = {"value": cb["stage"]["value"], "cores": cb["stage"]["cores"], "us_per_line": cb["stage"]["us_per_line"]}
+            sm["cpu_baseline_stage"] = {"value": g(cb["stage"]["value"], 4), "cores": cb["stage"]["cores"], "us_per_line": g(cb["stage"]["us_per_line"], 4)}
     if out.get("ranks"):
         sm["gather"] = out["ranks"].get("gather")
         sm["gather_ms_max"] = out["ranks"].get("gather_ms_max")
@@ -804,7 +824,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3")
-    ap.add_argument("--also", default="c2", help="second workload measured on one GPU and reported under \"also\" ('none' = skip)")
+    ap.add_argument("--also", default="c2,c3q25,c3q35,c3q60",
+                    help="further workloads (comma-separated) measured on one GPU and reported under \"also\" ('none' = skip): config 2, and config 3 with "
+                         "25 / 35 / 60 distinct quality values (the LG = 5, wide 8-bit and 16-bit-symbol kernels at the headline's size)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="N > 1: strong (default) = the workload's ONE candidate set is split over the ranks (BASELINE configs[2]); "
                          "weak = every rank scores its own candidate set of the workload's size")
@@ -966,11 +988,25 @@ def main():
                 # it from a per-line figure taken on another machine)
                 out["cpu_baseline"]["stage"] = cpu_baseline_stage_reference(reads, settings, cand)
         del reads, cand
-        if args.also and args.also not in ("none", args.workload):
-            also_rec, r2, c2, s2 = run_workload(args.also, args.order, "weak", args, torch, None, 0, local_rank, 1, False)
-            if not args.no_stage:
+        also = [w for w in (args.also or "").split(",") if w and w not in ("none", args.workload)]
+        for w in also:
+            also_rec, r2, c2, s2 = run_workload(w, args.order, "weak", args, torch, None, 0, local_rank, 1, False)
+            if not args.no_stage and c2.size <= 4000000:  # (the stage of the 10^8-candidate variants: the headline workload's own record)
                 also_rec["stage_end_to_end"] = stage_end_to_end(r2, c2, s2, args.stage_threads or min(32, os.cpu_count() or 1), reps=3)
-            out["also"] = {args.also: also_rec}
+            out.setdefault("also", {})[w] = also_rec
+            del r2, c2
+        if out.get("also"):
+            # the quality alphabets real reads have, at the headline's size (round 6): every variant's kernel, time, roofline position and
+            # its per-position rate against the headline kernel's — inside `roofline`, which a record that keeps the main keys keeps whole
+            head_rate = out["roofline"].get("kernel_positions_per_s") or 0.0
+            out["roofline"]["alphabets"] = {
+                w: {"quality_alphabet": rec["config"].get("quality_alphabet"), "kernel": rec["roofline"]["kernel"], "kernel_ms": rec["roofline"]["kernel_ms"],
+                    "ms_per_step": rec["ms_per_step"], "positions_per_s": rec["roofline"]["kernel_positions_per_s"],
+                    "rate_vs_headline_kernel": (rec["roofline"]["kernel_positions_per_s"] / head_rate) if head_rate else None,
+                    "frac": rec["roofline"].get("frac"), "bound": rec["roofline"].get("bound"), "traffic": rec["roofline"].get("traffic"),
+                    "busy": {k: round(v, 4) for k, v in (rec["roofline"].get("busy") or {}).items() if k != "kernel_cycles"},
+                    "parity_checked_records": rec["parity"]["parity_checked_records"]}
+                for w, rec in out["also"].items()}
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -979,8 +1015,15 @@ def main():
     os.dup2(real_stdout, 1)
     os.close(real_stdout)
     if rank == 0:
-        out["summary"] = summary_record(out, args)  # last in the line: a record that keeps only the tail of stdout keeps this
-        print(json.dumps(out), flush=True)
+        # the compact summary right behind the contract's keys AND last in the line: a record that keeps the head, the main keys or only the
+        # tail of stdout keeps it (round 6)
+        sm = summary_record(out, args)
+        first = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+        line = {k: out[k] for k in first if k in out}
+        line["summary_first"] = sm
+        line.update({k: v for k, v in out.items() if k not in line})
+        line["summary"] = sm
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

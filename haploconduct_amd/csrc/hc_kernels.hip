@@ -45,8 +45,8 @@
 
 // Experiment builds only (tools/experiments/ablate.sh): HC_ABLATE is a bit mask of parts of the cooperative kernel that are
 // cut out to see what the others cost — results are garbage.  1: no table reads (the LDS look-up of every position becomes a
-// register move), 2: no row loads from memory, 4: no passage of the rows through the LDS image.  The shipped library is
-// built without it.
+// register move), 2: no row loads from memory, 4: no passage of the rows through the LDS image; round 6, LDS-DMA form: 8: no A rows
+// are fetched, 16: only B rows, TWO steps in flight (profiles/r06_second_step.md).  The shipped library is built without it.
 #ifndef HC_ABLATE
 #define HC_ABLATE 0
 #endif
@@ -504,12 +504,75 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
                 const bool on = at < lim[j];
                 // (the step's offset `at` is wave-uniform: it travels as the instruction's scalar offset, the lane's part is la / lb or the
                 // first out-of-range offset — no per-lane add per load; the range check takes the scalar offset into account)
+#if !(HC_ABLATE & 8)  // (ablation 8: no A rows are fetched — the image keeps what it held)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(stage + 1024u * j), 16,
                                                          on ? la[j] : oob, at, 0, HC_COOP_AUX_A);
+#endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(stage + 4096u + 1024u * j), 16,
                                                          on ? lb[j] : oob, at, 0, HC_COOP_AUX_B);
             }
         };
+#if HC_ABLATE & 16
+        // (ablation, garbage results: what would a SECOND step of partner rows in flight buy?  Only the B rows are fetched — as if the A
+        // side came from a wave-shared copy of the common read — and the two 4 KiB halves of the wave's image take turns: the rows of step
+        // k + 2 are requested as soon as step k's have been copied into registers)
+        if (__ballot(Lb != 0u) != 0ull) {
+            auto fetch_b = [&](uint32_t at, uint32_t half) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool on = at < lim[j];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(stage + 4096u * half + 1024u * j), 16,
+                                                             on ? lb[j] : oob, at, 0, HC_COOP_AUX_B);
+                }
+            };
+            fetch_b(0, 0);
+            fetch_b(64u, 1);
+            uint32_t half = 0;
+            for (uint32_t at = 0;; at += 64u, half ^= 1u) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the older of the two steps in flight has landed
+                wave_lds_order();
+                u32x4 xa[4], xb[4];
+                const uint32_t rdH = rdA + 4096u * half;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    xb[p] = lds_load128(rdH ^ ((uint32_t)p << 4));
+                    xa[p] = xb[p];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
+                wave_lds_order();
+                const bool more = __ballot(at + 64u < Lb) != 0ull;
+                fetch_b(at + 128u, half);  // (beyond every window: dropped by the range check, still counted by vmcnt)
+                uint32_t cn4 = 0, cm4 = 0;
+#pragma unroll
+                for (int q = 0; q < kChunks; ++q)
+                    if (at + kChunkB * q < Lb) {
+                        uint32_t wa[T::kWords], wb[T::kWords];
+#pragma unroll
+                        for (int sw = 0; sw < (int)kSymB; ++sw) {
+                            const int p = q * (int)kSymB + sw;
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                wa[4 * sw + w] = xa[p][w] ^ 0x08080808u;
+                                wb[4 * sw + w] = xb[p][w];
+                            }
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            double t[8];
+                            half_chunk_terms<SymT, LG>(wa + h * (T::kWords / 2), wb + h * (T::kWords / 2), Kp, t, cn4, cm4);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) S += t[k];
+                        }
+                    }
+                skipped = __builtin_amdgcn_sad_u8(cn4, 0u, skipped);
+                cm = __builtin_amdgcn_sad_u8(cm4, 0u, cm);
+                if (!more) break;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        finish_sub<SymT>(sym, offA, offB, L, fatal, Kp, S == S ? S : 0.0, skipped, cm, kPacked, inv_n, out);
+        return;
+#endif
         if (__ballot(Lb != 0u) != 0ull) {  // wave-uniform
             fetch_dma(0);
             for (uint32_t at = 0;; at += 64u) {
@@ -518,8 +581,12 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
                 u32x4 xa[4], xb[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    xa[p] = lds_load128(rdA ^ ((uint32_t)p << 4));
                     xb[p] = lds_load128(rdB ^ ((uint32_t)p << 4));
+#if HC_ABLATE & 8
+                    xa[p] = xb[p] ^ 0x08080808u;  // (valid symbols without an A row)
+#else
+                    xa[p] = lds_load128(rdA ^ ((uint32_t)p << 4));
+#endif
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
                 wave_lds_order();

@@ -93,7 +93,8 @@ def _check_default_line(line, world):
     assert gm["ring"]["parity"]["digest"] == gm["direct"]["parity"]["digest"], "the two forms of the exchange must leave the same results"
     best = max(gm, key=lambda m: gm[m]["value"])
     assert line["config"]["gather"] == best and line["value"] == gm[best]["value"]
-    assert list(line)[-1] == "summary" and line["summary"]["value"] == line["value"] and line["summary"]["weak"]["value"] == wk["value"]
+    assert list(line)[-1] == "summary" and abs(line["summary"]["value"] / line["value"] - 1.0) < 1e-4 and line["summary"]["weak"]["value"] == wk["value"]
+    assert line["summary_first"] == line["summary"] and list(line).index("summary_first") < list(line).index("config"), "the summary also sits behind the contract's keys"
 
 
 def test_one_pass_yields_both_curves():
