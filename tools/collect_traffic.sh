@@ -15,6 +15,7 @@ mkdir -p $R/gpurun_out
 rm -rf $O
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export HC_WORKLOAD_CACHE=${HC_WORKLOAD_CACHE:-/tmp/hcw}
 B="python3 $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-stage --also none"
 pass() { d=$1; shift; rocprofv3 "$@" --kernel-trace --output-format csv -d $O/$d -- $B > $O/$d.out 2> $O/$d.err || echo "pass $d failed" >&2; }
 # the duration pass traces >= 30 launches of the kernel and the file keeps their MEDIAN (round 3 kept the mean of nine, one of them an outlier)
