@@ -823,6 +823,13 @@ int hc_compact_pack_device(hc_ctx* c, const void* d_results, uint64_t n, void* d
     return hc_pack_rows_device(c, d_results, d_indices, d_count, cap, base_index, (hc_gather_row*)d_payload + 1, hip_stream);
 }
 
+int hc_narrow_payload_device(hc_ctx* c, const void* d_payload, uint64_t cap, void* d_payload24, void* hip_stream) {
+    if (!c || !d_payload || !d_payload24) return fail(HC_ERR_ARG, "hc_narrow_payload_device: null argument");
+    HC_HIP(hipSetDevice(c->device));
+    HC_HIP(hc::launch_narrow_payload(d_payload, cap, d_payload24, c->n_cu, (hipStream_t)hip_stream));
+    return HC_OK;
+}
+
 int hc_score_pack_device(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index,
                          void* d_payload, void* hip_stream) {
     if (!c || !d_payload) return fail(HC_ERR_ARG, "hc_score_pack_device: null argument");

@@ -36,6 +36,7 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
 size_t compact_temp_bytes(uint32_t n);
 hipError_t launch_compact(const hc_result_rec* res, uint32_t n, uint32_t* idx_out, unsigned long long* count_out, void* temp,
                           size_t temp_bytes, hipStream_t stream);
+hipError_t launch_narrow_payload(const void* in32, uint64_t cap, void* out24, uint32_t n_cu, hipStream_t stream);
 hipError_t launch_pack_rows(const hc_result_rec* res, const uint32_t* idx, const unsigned long long* count, uint64_t cap, uint64_t base,
                             hc_gather_row* rows, uint32_t n_cu, hipStream_t stream);
 hipError_t launch_pack_header(const unsigned long long* count, hc_gather_row* header, hipStream_t stream);

@@ -6,9 +6,13 @@ array against a replicated read store.  The only exchange is the collection of t
 records, once per batch (PayloadGather / StreamedGather below): either ONE all-gather of a
 fixed-capacity payload whose row 0 is the count ("ring"), or the all-gather-v proper — the
 counts by one small all-gather, then grouped per-peer send / recv of exactly the rows
-("direct": every pair of ranks on its own xGMI link).  Works on any torch.distributed backend:
-"nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  Records travel as int64 rows
-[global_index, x1_bits, x2_bits, mm | n_cls << 32]."""
+("direct": every pair of ranks on its own xGMI link), or the same towards ONE rank only ("root":
+the inserting host is the only consumer of the set — SURVEY.md §8(e): "rank 0 (or all ranks)").
+Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU
+tests.  Records travel as int64 rows [global_index, x1_bits, x2_bits, mm | n_cls << 32] (32 bytes)
+or, when every index is below 2^32 and no overlap longer than 16 383 positions (round 6), as
+[x1_bits, x2_bits, index | mm << 32 | n << 46 | class << 60] (24 bytes: three quarters of the bytes
+over every link); collect() always returns the 32-byte form."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -56,7 +60,33 @@ def gather_admitted(results_np_or_tensor, global_offset, group=None, device=None
     return rows, counts
 
 
-def pack_payload(results, base_index, cap_rows, shuffle_seed=None):
+def narrow_rows(rows4):
+    """[k, 4] int64 rows (32-byte form) -> [k, 3] (24-byte form); the caller has checked that they fit (rows_fit_narrow)."""
+    w = rows4[:, 3]
+    mm, n_cls = w & 0xFFFFFFFF, (w >> 32) & 0xFFFFFFFF
+    n, cls = n_cls & 0x0FFFFFFF, (n_cls >> 28) & 0xF
+    out = torch.empty((rows4.shape[0], 3), dtype=torch.int64, device=rows4.device)
+    out[:, 0], out[:, 1] = rows4[:, 1], rows4[:, 2]
+    out[:, 2] = (rows4[:, 0] & 0xFFFFFFFF) | ((mm & 0x3FFF) << 32) | ((n & 0x3FFF) << 46) | (cls << 60)
+    return out
+
+
+def widen_rows(rows3):
+    """[k, 3] int64 rows (24-byte form) -> [k, 4] (32-byte form): what hc_narrow_payload_device / narrow_rows packed, unpacked."""
+    w = rows3[:, 2]
+    out = torch.empty((rows3.shape[0], 4), dtype=torch.int64, device=rows3.device)
+    out[:, 0] = w & 0xFFFFFFFF
+    out[:, 1], out[:, 2] = rows3[:, 0], rows3[:, 1]
+    out[:, 3] = ((w >> 32) & 0x3FFF) | ((((w >> 46) & 0x3FFF) | (((w >> 60) & 0xF) << 28)) << 32)
+    return out
+
+
+def rows_fit_narrow(n_job, longest_sequence):
+    """Whether a job's rows fit the 24-byte form: every global index below 2^32, every count of overlapped positions below 2^14."""
+    return int(n_job) < (1 << 32) and int(longest_sequence) + 16 < (1 << 14)
+
+
+def pack_payload(results, base_index, cap_rows, shuffle_seed=None, width=4):
     """The collection payload of one batch, built on the host (numpy) — the layout `hc_score_pack_device` /
     `hc_compact_pack_device` write on the device: int64 rows [index, x1 bits, x2 bits, mm | n_cls << 32], row 0 =
     [count, 0, 0, 0], then the records whose class is not DROP.  shuffle_seed: emit the rows in a random order,
@@ -73,10 +103,16 @@ def pack_payload(results, base_index, cap_rows, shuffle_seed=None):
     out[1:1 + k.size, 1] = res["x1"][k].view(np.int64)
     out[1:1 + k.size, 2] = res["x2"][k].view(np.int64)
     out[1:1 + k.size, 3] = res["mm"][k].astype(np.int64) | (res["n_cls"][k].astype(np.int64) << 32)
-    return torch.from_numpy(out)
+    out = torch.from_numpy(out)
+    if width == 3:  # the layout hc_narrow_payload_device writes: row 0 = [count, rows that did not fit, 0]
+        narrow = torch.zeros((cap_rows + 1, 3), dtype=torch.int64)
+        narrow[0, 0] = int(kept.size)
+        narrow[1:1 + k.size] = narrow_rows(out[1:1 + k.size])
+        return narrow
+    return out
 
 
-GATHER_MODES = ("ring", "direct")
+GATHER_MODES = ("ring", "direct", "root")
 
 
 class PayloadGather:
@@ -92,13 +128,19 @@ class PayloadGather:
                 The sizes of the send / recv calls must be known on the host: the host waits for the counts.  With lag = True (what
                 StreamedGather.score_step does) the exchange of batch i is issued right behind the launch of batch i + 1's kernel, so
                 the host reads the counts of batch i while the device runs batch i + 1: no bubble on the device.
+      "root"    as "direct", but the rows travel to rank `root` only (the rank whose host inserts the edges): every other rank sends its
+                1 + count rows over one link and receives nothing — a seventh of the bytes "direct" moves at world size 8, none of them
+                into the memory of a rank that is scoring.  collect() returns the rows on the root and None elsewhere.
+    width: 4 = 32-byte rows, 3 = 24-byte rows (module docstring); collect() widens.
 
     Timing: every batch's collective(s) are bracketed by events on the side stream (`gather_ms()`: mean duration since `reset_timings()`)."""
 
-    def __init__(self, cap_rows, group=None, depth=2, device=None, mode="ring", lag=False):
+    def __init__(self, cap_rows, group=None, depth=2, device=None, mode="ring", lag=False, width=4, root=0):
         if mode not in GATHER_MODES:
             raise ValueError(f"gather mode {mode!r}: one of {GATHER_MODES}")
-        self.cap, self.group, self.depth, self.mode, self.lag = int(cap_rows), group, depth, mode, lag
+        if width not in (3, 4):
+            raise ValueError("row width: 4 (32-byte rows) or 3 (24-byte rows)")
+        self.cap, self.group, self.depth, self.mode, self.lag, self.width, self.root = int(cap_rows), group, depth, mode, lag, int(width), int(root)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = device if device is not None else torch.device("cpu")
@@ -107,8 +149,8 @@ class PayloadGather:
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
         rows = self.cap + 1
         ev = (lambda: torch.cuda.Event()) if self.cuda else (lambda: None)
-        self.bufs = [{"payload": torch.zeros((rows, 4), dtype=torch.int64, device=self.device),
-                      "all": torch.zeros((self.world * rows, 4), dtype=torch.int64, device=self.device),
+        self.bufs = [{"payload": torch.zeros((rows, self.width), dtype=torch.int64, device=self.device),
+                      "all": torch.zeros((self.world * rows, self.width), dtype=torch.int64, device=self.device),
                       "counts_dev": torch.zeros(self.world, dtype=torch.int64, device=self.device),
                       "counts_host": torch.zeros(self.world, dtype=torch.int64, pin_memory=self.cuda),
                       "scored": ev(), "packed": ev(), "counted": ev(), "done": ev(),
@@ -174,26 +216,23 @@ class PayloadGather:
         rows = self.cap + 1
         mine = 1 + counts[self.rank]
         src = b["payload"][:mine]
+        # who sends to whom: "direct" every rank to every other; "root" every rank to the root only
+        to = [p for p in range(self.world) if p != self.rank and (self.mode == "direct" or p == self.root)]
+        frm = [p for p in range(self.world) if p != self.rank and (self.mode == "direct" or self.rank == self.root)]
         if self.staged or not self.cuda:
             host_src = src.cpu() if self.cuda else src
             host_all = torch.zeros(b["all"].shape, dtype=b["all"].dtype) if self.cuda else b["all"]
             host_all[self.rank * rows: self.rank * rows + mine] = host_src
-            ops = []
-            for p in range(self.world):
-                if p != self.rank:
-                    ops.append(dist.P2POp(dist.isend, host_src, self._peer(p), self.group))
-                    ops.append(dist.P2POp(dist.irecv, host_all[p * rows: p * rows + 1 + counts[p]], self._peer(p), self.group))
+            ops = [dist.P2POp(dist.isend, host_src, self._peer(p), self.group) for p in to]
+            ops += [dist.P2POp(dist.irecv, host_all[p * rows: p * rows + 1 + counts[p]], self._peer(p), self.group) for p in frm]
             for w in (dist.batch_isend_irecv(ops) if ops else []):
                 w.wait()
             if self.cuda:
                 b["all"].copy_(host_all)
             return []
         b["all"][self.rank * rows: self.rank * rows + mine].copy_(src, non_blocking=True)
-        ops = []
-        for p in range(self.world):
-            if p != self.rank:
-                ops.append(dist.P2POp(dist.isend, src, self._peer(p), self.group))
-                ops.append(dist.P2POp(dist.irecv, b["all"][p * rows: p * rows + 1 + counts[p]], self._peer(p), self.group))
+        ops = [dist.P2POp(dist.isend, src, self._peer(p), self.group) for p in to]
+        ops += [dist.P2POp(dist.irecv, b["all"][p * rows: p * rows + 1 + counts[p]], self._peer(p), self.group) for p in frm]
         return dist.batch_isend_irecv(ops) if ops else []
 
     def _run_timed(self, b, key, fn):
@@ -231,7 +270,7 @@ class PayloadGather:
             on_side()
         if self.mode == "ring":
             self._run_timed(b, key, self._ring)
-        else:
+        else:  # "direct", "root": the counts, then the rows
             self._run_timed(b, key, self._counts)
             self._run_timed(b, key, self._exchange)
         if self.cuda:
@@ -285,12 +324,21 @@ class PayloadGather:
         rows = self.cap + 1
         if b.get("overflow"):
             raise OverflowError(f"a rank produced {b['overflow']} records, capacity is {self.cap}: rerun the batch with a larger cap_rows")
-        counts = [int(b["all"][r * rows, 0]) for r in range(self.world)]
+        if self.mode == "root" and self.rank != self.root:  # this rank sent its rows and holds nobody else's
+            if self.width == 3 and int(b["payload"][0, 1]) != 0:
+                raise OverflowError(f"{int(b['payload'][0, 1])} rows of this rank do not fit the 24-byte form (index >= 2^32 or more than 16 383 positions)")
+            return None, list(b["counts"])
+        heads = [b["all"][r * rows] for r in range(self.world)]
+        counts = [int(h[0]) for h in heads]
         if max(counts) > self.cap:
             raise OverflowError(f"a rank produced {max(counts)} records, capacity is {self.cap}: rerun the batch with a larger cap_rows")
-        if self.mode == "direct" and counts != b.get("counts"):
-            raise RuntimeError(f"direct all-gather-v: the counts that travelled with the payloads {counts} are not the gathered counts {b.get('counts')}")
+        if self.mode != "ring" and counts != b.get("counts"):
+            raise RuntimeError(f"{self.mode} all-gather-v: the counts that travelled with the payloads {counts} are not the gathered counts {b.get('counts')}")
+        if self.width == 3 and any(int(h[1]) != 0 for h in heads):
+            raise OverflowError("rows that do not fit the 24-byte form (index >= 2^32 or more than 16 383 overlapped positions): exchange 32-byte rows (width=4)")
         out = torch.cat([b["all"][r * rows + 1: r * rows + 1 + counts[r]] for r in range(self.world)], dim=0)
+        if self.width == 3:
+            out = widen_rows(out)
         if b.get("unordered"):  # rows appended by the scoring kernel arrive in any order; they carry their index
             out = out[torch.argsort(out[:, 0])]
         return out, counts
@@ -313,8 +361,14 @@ class StreamedGather(PayloadGather):
     side stream; call before_write(results) before overwriting a results tensor that a step may still be reading.
     """
 
-    def __init__(self, scorer, n_local, base_index, cap_rows, group=None, depth=2, rec_fmt=0, mode="ring", reserve_cus=0):
-        super().__init__(cap_rows, group, depth, torch.device("cuda", torch.cuda.current_device()), mode, lag=True)
+    def __init__(self, scorer, n_local, base_index, cap_rows, group=None, depth=2, rec_fmt=0, mode="ring", reserve_cus=0, narrow=False, root=0):
+        super().__init__(cap_rows, group, depth, torch.device("cuda", torch.cuda.current_device()), mode, lag=True, width=3 if narrow else 4, root=root)
+        # narrow: the kernels write 32-byte rows into a payload of their own; hc_narrow_payload_device (on the side stream, in front of the
+        # exchange) makes the 24-byte rows that travel.  The caller decides per job (rows_fit_narrow); a row that does not fit is counted
+        # in the payload's header and collect() raises.
+        if narrow:
+            for b in self.bufs:
+                b["payload32"] = torch.zeros((self.cap + 1, 4), dtype=torch.int64, device=self.device)
         self.sc, self.n, self.base, self.fmt = scorer, int(n_local), int(base_index), int(rec_fmt)  # rec_fmt: records.REC_FULL / REC_COMPACT
         # reserve_cus > 0: the scoring launches leave that many CUs to the collective library's kernels, and every exchange waits (a gate
         # kernel on the side stream) until the scoring kernel it runs beside has taken its CUs: hc_set_comm_reserve / hc_comm_gate_device
@@ -328,11 +382,24 @@ class StreamedGather(PayloadGather):
     def score_step(self, d_in_ptr, d_results):
         """Score this rank's n candidate records (device pointer) into d_results and collect the batch."""
         b = self.next_buffers()
-        b["unordered"] = self.sc.score_pack_device(d_in_ptr, self.n, d_results.data_ptr(), self.cap, self.base, b["payload"].data_ptr(),
+        wide = b.get("payload32", b["payload"])
+        b["unordered"] = self.sc.score_pack_device(d_in_ptr, self.n, d_results.data_ptr(), self.cap, self.base, wide.data_ptr(),
                                                    torch.cuda.current_stream().cuda_stream, self.fmt)
         # the exchange of the batch BEFORE this one goes out now: it runs beside this batch's kernel, which is in the stream already
         self.flush(gate=(lambda: self.sc.comm_gate_device(self.side.cuda_stream)) if self.reserve else None)
-        return self.submit(b)
+        return self.submit(b, on_side=(lambda: self._narrow(b)) if self.width == 3 else None)
+
+    def _narrow(self, b):
+        """32-byte rows -> the 24-byte rows that travel (side stream, behind the work that wrote them)."""
+        self.sc.narrow_payload_device(b["payload32"].data_ptr(), self.cap, b["payload"].data_ptr(), self.side.cuda_stream)
+
+    def close(self):
+        """The scorer goes back to launches over the whole device (round-5 advisor: a reserve left behind made later kernel timings
+        reduced-CU figures)."""
+        self.finish()
+        if self.reserve:
+            self.sc.set_comm_reserve(0)
+            self.reserve = 0
 
     def before_write(self, d_results):
         """The current stream waits until the batch that last used `d_results` has been read out of it."""
@@ -347,7 +414,9 @@ class StreamedGather(PayloadGather):
 
         def pack():  # (self.idx / self.count are shared: consecutive batches are ordered on the side stream)
             self.sc.compact_pack_device(d_results.data_ptr(), self.n, self.idx.data_ptr(), self.count.data_ptr(), self.cap, self.base,
-                                        b["payload"].data_ptr(), self.side.cuda_stream)
+                                        b.get("payload32", b["payload"]).data_ptr(), self.side.cuda_stream)
+            if self.width == 3:
+                self._narrow(b)
             b["packed"].record(self.side)
             self.packed[d_results.data_ptr()] = b["packed"]
 

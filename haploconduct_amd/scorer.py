@@ -292,6 +292,11 @@ class EdgeScorer:
                                            C.c_void_p(d_payload_ptr), C.c_void_p(stream or 0)), "hc_score_pack_device")
         return True
 
+    def narrow_payload_device(self, d_payload_ptr, cap, d_payload24_ptr, stream=None):
+        """hc_narrow_payload_device: a (cap + 1)-row payload of 32-byte rows -> 24-byte rows (x1, x2, index | mm << 32 | n << 46 | class << 60)."""
+        N.check(N.lib.hc_narrow_payload_device(self._ctx, C.c_void_p(d_payload_ptr), cap, C.c_void_p(d_payload24_ptr), C.c_void_p(stream or 0)),
+                "hc_narrow_payload_device")
+
     def set_comm_reserve(self, cus):
         """hc_set_comm_reserve: launches leave `cus` CUs to the kernels of the multi-GPU exchange (0: none)."""
         N.check(N.lib.hc_set_comm_reserve(self._ctx, int(cus)), "hc_set_comm_reserve")

@@ -294,6 +294,13 @@ int hc_compact_pack_device(hc_ctx* ctx, const void* d_results, uint64_t n, void*
 int hc_score_pack_device(hc_ctx* ctx, uint32_t rec_fmt, const void* d_in, uint64_t n, void* d_out, uint64_t cap, uint64_t base_index,
                          void* d_payload, void* hip_stream);
 
+/* The 24-byte form of a collection payload, for the multi-GPU exchange (three quarters of the bytes over every link).  d_payload: (cap + 1)
+ * rows of 32 bytes as hc_score_pack_device / hc_compact_pack_device leave them.  d_payload24: (cap + 1) rows of three 64-bit words —
+ * row 0 = { count, number of rows that did not fit, 0 }, row k = { x1 bits, x2 bits, index | mm << 32 | n << 46 | class << 60 }.  A row
+ * fits when its index < 2^32 and mm, n < 2^14; a caller whose read set allows more overlapped positions, or whose job has 2^32 candidates
+ * and more, exchanges the 32-byte rows.  No reference analogue (the reference is one process: src/ViralQuasispecies.cpp:279-283). */
+int hc_narrow_payload_device(hc_ctx* ctx, const void* d_payload, uint64_t cap, void* d_payload24, void* hip_stream);
+
 /* The multi-GPU step: the per-step exchange of the kept rows runs on a side stream BESIDE the next step's scoring
  * kernel, and the scoring kernel's large launches hold one workgroup per CU for the launch's whole duration (145 KiB of LDS, 480 of a
  * SIMD's 512 registers): a collective library's kernels find no room on a CU that holds one.  hc_set_comm_reserve(cus): launches of
