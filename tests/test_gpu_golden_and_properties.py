@@ -148,11 +148,13 @@ def test_rccl_gather_path_single_rank():
             sc.synchronize()
             rows, counts = parallel.gather_admitted(d_out, 0)
             host = d_out.cpu().numpy().view(hc.RESULT_DTYPE)
-            for mode in parallel.GATHER_MODES:  # ring: one all-gather of the fixed-capacity payload; direct: counts + per-peer send / recv (no peer at world size 1)
+            # ring: one all-gather of the fixed-capacity payload; direct / root: counts + per-peer send / recv (no peer at world size 1);
+            # narrow: the rows travel in the 24-byte form (hc_narrow_payload_device), collect() returns the 32-byte form either way
+            for mode, narrow in [(m, nw) for m in parallel.GATHER_MODES for nw in (False, True)]:
                 # the streamed form (no host round trip per batch): non-dropped records, tagged with base + index
                 cls0 = result_cls(host)
                 kept = np.nonzero(cls0 != 0)[0]
-                g = parallel.StreamedGather(sc, cand.size, base_index=1000, cap_rows=kept.size + 7, mode=mode)
+                g = parallel.StreamedGather(sc, cand.size, base_index=1000, cap_rows=kept.size + 7, mode=mode, narrow=narrow)
                 stream = torch.cuda.current_stream().cuda_stream
                 last = None
                 for _ in range(5):  # more batches than buffers: exercises the reuse
@@ -166,7 +168,7 @@ def test_rccl_gather_path_single_rank():
                 assert np.array_equal(srows[:, 2].view(np.uint64), host["x2"][kept].view(np.uint64))
                 assert np.array_equal(srows[:, 3].view(np.uint64), host["mm"][kept].astype(np.uint64) | (host["n_cls"][kept].astype(np.uint64) << 32))
                 # the fused form: the scoring kernel appends the payload itself (rows unordered until collect() sorts them)
-                g2 = parallel.StreamedGather(sc, cand.size, base_index=7, cap_rows=kept.size + 3, mode=mode)
+                g2 = parallel.StreamedGather(sc, cand.size, base_index=7, cap_rows=kept.size + 3, mode=mode, narrow=narrow)
                 for _ in range(4):
                     last = g2.score_step(d_in.data_ptr(), d_out)
                 assert last["unordered"]
@@ -177,12 +179,33 @@ def test_rccl_gather_path_single_rank():
                 assert np.array_equal(frows[:, 1].view(np.uint64), host["x1"][kept].view(np.uint64))
                 assert np.array_equal(frows[:, 3].view(np.uint64), host["mm"][kept].astype(np.uint64) | (host["n_cls"][kept].astype(np.uint64) << 32))
                 assert np.array_equal(d_out.cpu().numpy().view(hc.RESULT_DTYPE).tobytes(), host.tobytes())  # the results themselves are unchanged
-                small = parallel.StreamedGather(sc, cand.size, base_index=0, cap_rows=max(1, kept.size // 2), mode=mode)
+                small = parallel.StreamedGather(sc, cand.size, base_index=0, cap_rows=max(1, kept.size // 2), mode=mode, narrow=narrow)
                 with pytest.raises(OverflowError):
                     small.collect(small.step(d_out))
                 with pytest.raises(OverflowError):  # the fused form (per-workgroup segments moved into a payload that is too small)
                     small.collect(small.score_step(d_in.data_ptr(), d_out))
                 small.finish()
+            # hc_narrow_payload_device on rows made by hand: the packing itself, and rows that do not fit are counted, not truncated
+            rng = np.random.default_rng(9)
+            k = 5000
+            pay = np.zeros((k + 1, 4), np.uint64)
+            pay[0, 0] = k
+            pay[1:, 0] = rng.integers(0, 1 << 32, k)
+            pay[1:, 1:3] = rng.integers(0, 1 << 63, (k, 2))
+            nn = rng.integers(1, 1 << 14, k).astype(np.uint64)
+            pay[1:, 3] = rng.integers(0, nn + 1).astype(np.uint64) | ((nn | (rng.integers(0, 16, k).astype(np.uint64) << np.uint64(28))) << np.uint64(32))
+            d_pay = torch.from_numpy(pay.view(np.int64)).cuda()
+            d_nar = torch.full((k + 1, 3), -1, dtype=torch.int64, device="cuda")
+            sc.narrow_payload_device(d_pay.data_ptr(), k, d_nar.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert d_nar[0].tolist() == [k, 0, 0]
+            assert torch.equal(parallel.widen_rows(d_nar[1:]), d_pay[1:]) and torch.equal(d_nar[1:], parallel.narrow_rows(d_pay[1:]))
+            pay[7, 3] = np.uint64(3) | (np.uint64(20000 | (2 << 28)) << np.uint64(32))  # 20 000 overlapped positions
+            pay[9, 0] = np.uint64(1 << 32)                                               # an index of 2^32
+            d_pay = torch.from_numpy(pay.view(np.int64)).cuda()
+            sc.narrow_payload_device(d_pay.data_ptr(), k, d_nar.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert d_nar[0].tolist() == [k, 2, 0], "two rows do not fit the 24-byte form"
         cls = result_cls(host)
         want = np.nonzero((cls >= 2) & (cls <= 4))[0]
         assert counts == [want.size] and want.size > 100

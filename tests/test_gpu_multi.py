@@ -1,7 +1,7 @@
 """More than one GPU, when the box has them: bench.py's N-rank step (candidate shards against a replicated read store, one
 RCCL all-gather of the non-dropped records per step) launched the way the driver launches it — torch.distributed.run, one
-process per GPU — as a child process, with either form of the per-step exchange (ring: one all-gather of the fixed-capacity payload; direct:
-all-gather-v by counts + grouped per-peer send / recv).  RCCL must have seen every rank, and the rows every rank ends up with must be the
+process per GPU — as a child process, with every form of the per-step exchange (ring: one all-gather of the fixed-capacity payload; direct:
+all-gather-v by counts + grouped per-peer send / recv; root: the same towards rank 0 only), 24-byte rows where the job allows them.  RCCL must have seen every rank, and the rows every rank ends up with must be the
 non-dropped records of the whole candidate set, i.e. what ONE device computes for it.  Skipped on a one-GPU box (no curve
 has been measured by the builder: the first real 2/4/8-GPU numbers are the driver's)."""
 import json
@@ -30,7 +30,7 @@ def _n_devices():
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-@pytest.mark.parametrize("scaling,gather", [("strong", "ring"), ("strong", "direct"), ("weak", "ring"), ("weak", "direct")])
+@pytest.mark.parametrize("scaling,gather", [("strong", "ring"), ("strong", "direct"), ("strong", "root"), ("weak", "ring"), ("weak", "direct"), ("weak", "root")])
 def test_ranks_over_rccl_collect_what_one_device_computes(tmp_path, scaling, gather, world):
     n_dev = _n_devices()
     if n_dev < world:
@@ -89,8 +89,9 @@ def _check_default_line(line, world):
     assert sum(p["candidates"] for p in wk["ranks"]["per_rank"]) == wk["candidates_per_step"]
     assert line["parity"]["digest_matches_untimed_launch"] and wk["parity"]["digest_matches_untimed_launch"] and line["parity"]["parity_checked_records"] > 0
     gm = line["gather_modes"]
-    assert set(gm) == {"ring", "direct"} and all(v["value"] > 0 and v["parity"]["digest_matches_untimed_launch"] for v in gm.values())
-    assert gm["ring"]["parity"]["digest"] == gm["direct"]["parity"]["digest"], "the two forms of the exchange must leave the same results"
+    assert set(gm) == {"ring", "direct", "root"} and all(v["value"] > 0 and v["parity"]["digest_matches_untimed_launch"] for v in gm.values())
+    assert gm["ring"]["parity"]["digest"] == gm["direct"]["parity"]["digest"] == gm["root"]["parity"]["digest"], "the forms of the exchange must leave the same results"
+    assert all(v["config"]["gather_row_bytes"] == 24 for v in gm.values()), "config 2's rows fit the 24-byte form"
     best = max(gm, key=lambda m: gm[m]["value"])
     assert line["config"]["gather"] == best and line["value"] == gm[best]["value"]
     assert list(line)[-1] == "summary" and abs(line["summary"]["value"] / line["value"] - 1.0) < 1e-4 and line["summary"]["weak"]["value"] == wk["value"]
@@ -157,15 +158,16 @@ def test_n_rank_bench_path_on_one_gpu_over_gloo(tmp_path, world):
     _check_default_line(line, world)
     # (2) the strong split's gathered rows are the one-device result, by either form of the exchange
     rows = {}
-    for gather in ("ring", "direct"):
-        rows_file = str(tmp_path / f"rows_{gather}.npy")
+    for gather, row_bytes in (("ring", "24"), ("direct", "24"), ("root", "24"), ("root", "32")):  # (32: the rows as the kernels write them)
+        rows_file = str(tmp_path / f"rows_{gather}_{row_bytes}.npy")
         r = subprocess.run(base + ["--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + tail +
-                           ["--scaling", "strong", "--one-mode", "--gather", gather, "--dump-rows", rows_file], cwd=ROOT, env=env, capture_output=True,
-                           text=True, timeout=1200)
+                           ["--scaling", "strong", "--one-mode", "--gather", gather, "--dump-rows", rows_file], cwd=ROOT,
+                           env=dict(env, HC_BENCH_ROW_BYTES=row_bytes), capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, r.stderr[-3000:]
-        rows[gather] = np.load(rows_file)
-    assert np.array_equal(rows["ring"], rows["direct"])
-    rows = rows["ring"]
+        assert json.loads(r.stdout.strip().splitlines()[-1])["config"]["gather_row_bytes"] == int(row_bytes)
+        rows[(gather, row_bytes)] = np.load(rows_file)
+    assert all(np.array_equal(rows[("ring", "24")], v) for v in rows.values()), "every form and row width collects the same set"
+    rows = rows[("ring", "24")]
     import bench
     import haploconduct_amd as hc
     from haploconduct_amd.records import result_cls
@@ -178,3 +180,39 @@ def test_n_rank_bench_path_on_one_gpu_over_gloo(tmp_path, world):
     want = np.stack([kept.astype(np.int64), res["x1"][kept].view(np.int64), res["x2"][kept].view(np.int64),
                      res["mm"][kept].astype(np.int64) | (res["n_cls"][kept].astype(np.int64) << 32)], axis=1)
     assert rows.shape == want.shape and np.array_equal(rows, want)
+
+
+@pytest.mark.parametrize("workload,kernel", [("c5", "true, true, 2"), ("c4", "uint8_t, 6, 1024")])
+def test_every_launch_form_through_the_n_rank_path_over_gloo(tmp_path, workload, kernel):
+    """BASELINE configs[4] ("... length-bucketed LDS tiling, 8 MI355X") and configs[3] through the N-rank step (round 6):
+    the length-bucketed launch with its row sink (c5) and the wide-table, register-staged 1 024-lane form (c4) under StreamedGather — two
+    ranks on device 0 over gloo, the strong split's gathered rows against the one-device result, by the ring and the root form."""
+    if _n_devices() < 1:
+        pytest.skip("no GPU")
+    import bench
+    import haploconduct_amd as hc
+    from haploconduct_amd.records import result_cls
+
+    env = dict(os.environ, HC_BENCH_BACKEND="gloo", HC_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1"]
+    tail = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-stage", "--no-cpu-baseline", "--also", "none",
+            "--scaling", "strong", "--one-mode"]
+    got = {}
+    for gather in ("ring", "root"):
+        rows_file = str(tmp_path / f"rows_{gather}.npy")
+        r = subprocess.run(base + ["--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + tail + ["--gather", gather, "--dump-rows", rows_file],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert kernel in line["roofline"]["kernel"], line["roofline"]["kernel"]
+        assert line["config"]["gather_row_bytes"] == 24 and line["ranks"]["n_ranks_seen"] == 2
+        got[gather] = np.load(rows_file)
+    assert np.array_equal(got["ring"], got["root"])
+    reads, cand, cfg, stt = bench.build_workload(workload, 0)
+    with hc.EdgeScorer(stt) as sc:
+        sc.set_reads(reads)
+        res = sc.score_cands(sc.pack_cands(cand))
+    kept = np.nonzero(result_cls(res) != 0)[0]
+    want = np.stack([kept.astype(np.int64), res["x1"][kept].view(np.int64), res["x2"][kept].view(np.int64),
+                     res["mm"][kept].astype(np.int64) | (res["n_cls"][kept].astype(np.int64) << 32)], axis=1)
+    assert kept.size > 1000 and got["ring"].shape == want.shape and np.array_equal(got["ring"], want)
