@@ -908,7 +908,7 @@ def main():
 
     def leg_record(rec, mode_name):
         return {"value": rec["value"], "unit": "candidate overlaps/s", "ms_per_step": rec["ms_per_step"], "scaling": mode_name,
-                "gather": rec["config"].get("gather"), "candidates_per_step": rec["config"]["candidates_per_step"],
+                "gather": rec["config"].get("gather"), "gather_row_bytes": rec["config"].get("gather_row_bytes"), "candidates_per_step": rec["config"]["candidates_per_step"],
                 "candidates_per_gpu": rec["config"]["candidates_per_gpu"], "kernel_ms": rec["roofline"]["kernel_ms"], "ranks": rec.get("ranks"),
                 "parity": rec["parity"]}
 

@@ -91,7 +91,7 @@ def _check_default_line(line, world):
     gm = line["gather_modes"]
     assert set(gm) == {"ring", "direct", "root"} and all(v["value"] > 0 and v["parity"]["digest_matches_untimed_launch"] for v in gm.values())
     assert gm["ring"]["parity"]["digest"] == gm["direct"]["parity"]["digest"] == gm["root"]["parity"]["digest"], "the forms of the exchange must leave the same results"
-    assert all(v["config"]["gather_row_bytes"] == 24 for v in gm.values()), "config 2's rows fit the 24-byte form"
+    assert all(v["gather_row_bytes"] == 24 for v in gm.values()), "config 2's rows fit the 24-byte form"
     best = max(gm, key=lambda m: gm[m]["value"])
     assert line["config"]["gather"] == best and line["value"] == gm[best]["value"]
     assert list(line)[-1] == "summary" and abs(line["summary"]["value"] / line["value"] - 1.0) < 1e-4 and line["summary"]["weak"]["value"] == wk["value"]

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """What a rank of an N-GPU run will see, measured on ONE GPU: the scoring kernel and the N-rank step (kernel +
 row payload + one RCCL all-gather, world size 1) at the shard sizes of the strong split of the 10^8-candidate set — 10^8 / N for
-N = 1, 2, 4, 8 — and at the full size (the weak figure).  From these, a PREDICTED curve: strong(N) = 10^8 / step_ms(10^8 / N),
+N = 1, 2, 4, 8 — and at the full size (the weak figure); round 6: the rows travel in the 24-byte form (hc_narrow_payload_device).  From these, a PREDICTED curve: strong(N) = 10^8 / step_ms(10^8 / N),
 weak(N) = N * 10^8 / step_ms(10^8), both assuming that the all-gather stays hidden behind the next step's kernel as it is at world
 size 1 (the payload a rank contributes: ~3.75 * 10^6 / N rows of 32 B strong, 120 MB weak; over xGMI's 7 links at ~150 GB/s each,
-MI355X_MICROARCH.md, that is 0.1 ms strong at N = 8 and 0.8 ms weak against kernels of 0.9 and 6.9 ms).  Nothing here is a
+MI355X_MICROARCH.md, that is 0.075 ms strong at N = 8 and 0.6 ms weak against kernels of 0.9 and 6.5 ms; the "root" form moves the same bytes per link —
+every rank's rows over ONE link to rank 0 — but nothing INTO the memory of the seven ranks that are scoring).  Nothing here is a
 measurement of N > 1: the output says "predicted" in every figure derived that way.
 
     python tools/predict_scaling.py [--workload c3] [--steps 20] > gpurun_out/r04_predicted_scaling.json
@@ -58,7 +59,7 @@ def main():
         kern_ms = sc.time_kernel(d_in.data_ptr(), n, d_out.data_ptr(), args.steps, REC_COMPACT)
         by_reserve = {}
         for reserve in (0, 16, 32):  # round 5: CUs the scoring launches leave to the exchange's kernels (hc_set_comm_reserve; profiles/r05_coresident.md)
-            g = parallel.StreamedGather(sc, n, base_index=lo, cap_rows=kept * 5 // 4 + 1024, rec_fmt=REC_COMPACT, reserve_cus=reserve)
+            g = parallel.StreamedGather(sc, n, base_index=lo, cap_rows=kept * 5 // 4 + 1024, rec_fmt=REC_COMPACT, reserve_cus=reserve, narrow=True)
             for _ in range(3):
                 g.score_step(d_in.data_ptr(), d_out)
             g.finish()
@@ -73,10 +74,11 @@ def main():
             by_reserve[reserve] = (time.perf_counter() - t0) / args.steps * 1e3
             out_rows, counts = g.collect(last)
             assert counts == [kept]
+            g.close()
             del g
         sc.set_comm_reserve(0)
         step_ms = by_reserve[0]
-        rows.append({"N": N, "shard_candidates": n, "kept_rows": kept, "payload_MB_per_rank": (kept + 1) * 32 / 1e6, "kernel_ms": kern_ms,
+        rows.append({"N": N, "shard_candidates": n, "kept_rows": kept, "payload_MB_per_rank": (kept + 1) * 24 / 1e6, "row_bytes": 24, "kernel_ms": kern_ms,
                      "step_ms_world1": step_ms, "step_ms_world1_by_reserved_cus": {str(k): v for k, v in by_reserve.items()},
                      "collection_on_critical_path_ms_world1": max(0.0, step_ms - kern_ms)})
         del d_out
