@@ -158,6 +158,9 @@ static void free_store(hc_ctx* c) {
     c->d_found = nullptr;
     c->n_found = 0;
     c->found_valid = false;
+    if (c->d_found_lines) (void)hipFree(c->d_found_lines);
+    c->d_found_lines = nullptr;
+    c->found_lines_cap = 0;
     if (c->d_sym) (void)hipFree(c->d_sym);
     if (c->d_reads) (void)hipFree(c->d_reads);
     if (c->d_lut) (void)hipFree(c->d_lut);

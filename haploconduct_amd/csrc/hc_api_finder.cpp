@@ -518,6 +518,155 @@ int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pair
 
 extern "C" {
 
+// The ingest WITHOUT text or host (round 6; SURVEY.md 8(f4): "would remove ... the text file altogether"): flip, the script's sort, its
+// matching and both its `uniq`s on the device; what comes out is the overlaps file's lines as hc_line_rec in device memory, in file
+// order — what the stage's text kernels would parse from the script's output.  *d_lines stays valid until the next call or hc_set_reads.
+// HC_ERR_STATE with "not on the device" in hc_last_error: an SFO id / number the device keys do not hold, an assert of the script's
+// matching, or nothing to do it with — the caller takes hc_found_to_overlaps' route, which raises what the script raises.
+int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs, const hc_line_rec** d_lines, uint64_t* n_lines) {
+    if (!c || !d_lines || !n_lines) return fail(HC_ERR_ARG, "hc_found_to_lines_device: null argument");
+    *d_lines = nullptr;
+    *n_lines = 0;
+    if (!c->found_valid) return fail(HC_ERR_STATE, "hc_found_to_lines_device: hc_find_overlaps has not been called on this read set");
+    const uint64_t n = c->n_found;
+    if (n == 0) return HC_OK;
+    if (n >= 0x7FFFFFF0ull) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (2^31 records and more)");
+    const bool timing = getenv("HC_SFO_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::vector<hc_ctx::Scratch*> idle;
+    for (auto& sl : c->finder_scratch)
+        if (sl.p) idle.push_back(&sl);
+    for (auto& sl : c->ingest_scratch)
+        if (sl.p) idle.push_back(&sl);
+    unsigned n_own = 0;
+    auto dmalloc = [&](size_t bytes, void** p) {
+        const size_t need = bytes ? bytes : 16;
+        int best = -1;
+        for (size_t i = 0; i < idle.size(); i++)
+            if (idle[i] && idle[i]->cap >= need && (best < 0 || idle[i]->cap < idle[(size_t)best]->cap)) best = (int)i;
+        if (best >= 0) {
+            *p = idle[(size_t)best]->p;
+            idle[(size_t)best] = nullptr;
+            return hipSuccess;
+        }
+        while (n_own < 12 && c->ingest_scratch[n_own].p) n_own++;
+        if (n_own >= 12) return hipErrorOutOfMemory;
+        hc_ctx::Scratch& sl = c->ingest_scratch[n_own];
+        const hipError_t e = hipMalloc(&sl.p, need);
+        if (e != hipSuccess) {
+            sl.p = nullptr;
+            return e;
+        }
+        sl.cap = need;
+        *p = sl.p;
+        return hipSuccess;
+    };
+    HC_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const double t0 = now();
+    hc::SfoFlipped *d_flip = nullptr, *d_sorted = nullptr;
+    uint64_t *d_k[3] = {nullptr, nullptr, nullptr}, *d_ka = nullptr, *d_kb = nullptr;
+    uint32_t *d_pa = nullptr, *d_pb = nullptr;
+    unsigned long long* d_status = nullptr;  // [0] status, [1] grouped records, [2] groups, [3] lines, [4] equal neighbours, [5] lines kept
+    void* d_tmp = nullptr;
+    HC_HIP(dmalloc(n * sizeof(hc::SfoFlipped), (void**)&d_flip));
+    HC_HIP(dmalloc(n * sizeof(hc::SfoFlipped), (void**)&d_sorted));
+    for (auto& kk : d_k) HC_HIP(dmalloc(n * 8, (void**)&kk));
+    HC_HIP(dmalloc(n * 8, (void**)&d_ka));
+    HC_HIP(dmalloc(n * 8, (void**)&d_kb));
+    HC_HIP(dmalloc(n * 4, (void**)&d_pa));
+    HC_HIP(dmalloc(n * 4, (void**)&d_pb));
+    HC_HIP(dmalloc(64, (void**)&d_status));
+    size_t tmp_bytes = 0;
+    HC_HIP(hc::sort_pairs_u64_u32(nullptr, tmp_bytes, d_ka, d_kb, d_pa, d_pb, (uint32_t)n, 64, st));
+    tmp_bytes = std::max(tmp_bytes, std::max(hc::prims::select_temp_bytes(n), hc::prims::scan_temp_bytes(n + 1, 4)));
+    HC_HIP(dmalloc(tmp_bytes, &d_tmp));
+    HC_HIP(hipMemsetAsync(d_status, 0, 64, st));
+    // flip + the script's sort (three stable radix sorts over the 192-bit key), as hc_found_to_overlaps does
+    HC_HIP(hc::sfo_flip(c->d_found, n, num_singles, num_pairs, d_flip, d_k[0], d_k[1], d_k[2], d_pa, d_status, st));
+    uint32_t *perm = d_pa, *perm_next = d_pb;
+    for (int ch = 0; ch < 3; ch++) {
+        const uint64_t* keys = d_k[ch];
+        if (ch) {
+            HC_HIP(hc::fno_gather_keys(d_k[ch], perm, n, d_ka, st));
+            keys = d_ka;
+        }
+        size_t b = tmp_bytes;
+        HC_HIP(hc::sort_pairs_u64_u32(d_tmp, b, keys, d_kb, perm, perm_next, (uint32_t)n, 64, st));
+        std::swap(perm, perm_next);
+    }
+    HC_HIP(hc::sfo_gather(d_flip, perm, n, d_sorted, st));
+    // which sorted records the matching sees (its first `uniq`, self overlaps, lines between unpaired reads, groups)
+    uint8_t *d_grouped = (uint8_t*)d_k[0], *d_single = (uint8_t*)d_k[1];
+    uint32_t* d_idx = (uint32_t*)d_k[2];                 // the grouped records' places, in order
+    uint8_t* d_start = (uint8_t*)d_ka;                   // per grouped record: opens a group
+    uint32_t* d_starts = (uint32_t*)d_kb;                // the grouped records that open a group, in order
+    uint32_t* d_emit = (uint32_t*)d_flip;                // per sorted record: lines it makes the script write ([n + 1]: d_flip holds 8 n words)
+    uint32_t* d_off = d_emit + (n + 1);
+    HC_HIP(hc::sfo_classify(d_sorted, n, num_singles, num_pairs, d_grouped, d_single, st));
+    HC_HIP(hc::prims::select_flagged(d_tmp, tmp_bytes, d_grouped, n, d_idx, d_status + 1, st));
+    unsigned long long host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HC_HIP(hipMemcpyAsync(host, d_status, 16, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipStreamSynchronize(st));
+    if (host[0]) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (an SFO id or number the device keys do not hold)");
+    const uint64_t m = host[1];
+    HC_HIP(hc::sfo_group_starts(d_sorted, d_idx, m, num_singles, num_pairs, d_start, st));
+    HC_HIP(hc::prims::select_flagged(d_tmp, tmp_bytes, d_start, m, d_starts, d_status + 2, st));
+    HC_HIP(hipMemsetAsync(d_emit, 0, (n + 1) * 4, st));
+    HC_HIP(hipMemcpyAsync(host + 2, d_status + 2, 8, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipStreamSynchronize(st));
+    const uint64_t G = host[2];
+    // lines per record that makes the script write, their places by a scan, the lines
+    HC_HIP(hc::sfo_single_lines(false, d_sorted, d_single, n, num_singles, num_pairs, d_emit, nullptr, nullptr, d_status, st));
+    HC_HIP(hc::sfo_match_groups(false, d_sorted, d_idx, d_starts, G, num_singles, num_pairs, d_emit, nullptr, nullptr, d_status, st));
+    HC_HIP(hc::prims::exclusive_sum(d_tmp, tmp_bytes, d_emit, d_off, n + 1, st));
+    uint32_t total32 = 0;
+    HC_HIP(hipMemcpyAsync(&total32, d_off + n, 4, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipMemcpyAsync(host, d_status, 8, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipStreamSynchronize(st));
+    if (host[0]) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (an assert of the script's matching)");
+    const uint64_t total = total32;
+    if (total > c->found_lines_cap) {
+        if (c->d_found_lines) (void)hipFree(c->d_found_lines);
+        c->d_found_lines = nullptr;
+        c->found_lines_cap = 0;
+        HC_HIP(hipMalloc((void**)&c->d_found_lines, (total + total / 16 + 1024) * sizeof(hc_line_rec)));
+        c->found_lines_cap = total + total / 16 + 1024;
+    }
+    if (total == 0) return HC_OK;
+    // the lines go to scratch first (the sorted records' keys are spent), the script's last `uniq` decides what stays
+    hc_line_rec* d_raw = nullptr;
+    HC_HIP(dmalloc(total * sizeof(hc_line_rec), (void**)&d_raw));
+    HC_HIP(hc::sfo_single_lines(true, d_sorted, d_single, n, num_singles, num_pairs, d_emit, d_off, d_raw, d_status, st));
+    HC_HIP(hc::sfo_match_groups(true, d_sorted, d_idx, d_starts, G, num_singles, num_pairs, d_emit, d_off, d_raw, d_status, st));
+    uint8_t* d_keep = (uint8_t*)d_k[0];
+    if (total > n * 8) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (more lines than the flags have room for)");
+    HC_HIP(hc::sfo_uniq_lines(d_raw, total, d_keep, d_status + 4, st));
+    HC_HIP(hipMemcpyAsync(host, d_status, 40, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipStreamSynchronize(st));
+    if (host[0]) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (an assert of the script's matching)");
+    uint64_t kept = total;
+    if (host[4]) {  // equal neighbours (rare): the kept lines, in order
+        if (total * 4 > n * 8 || hc::prims::select_temp_bytes(total) > tmp_bytes)
+            return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (more lines than the index has room for)");
+        uint32_t* d_kidx = (uint32_t*)d_k[1];
+        HC_HIP(hc::prims::select_flagged(d_tmp, tmp_bytes, d_keep, total, d_kidx, d_status + 5, st));
+        HC_HIP(hipMemcpyAsync(host + 5, d_status + 5, 8, hipMemcpyDeviceToHost, st));
+        HC_HIP(hipStreamSynchronize(st));
+        kept = host[5];
+        HC_HIP(hc::sfo_gather_lines(d_raw, d_kidx, kept, c->d_found_lines, st));
+    } else {
+        HC_HIP(hipMemcpyAsync(c->d_found_lines, d_raw, total * sizeof(hc_line_rec), hipMemcpyDeviceToDevice, st));
+    }
+    HC_HIP(hipStreamSynchronize(st));
+    if (timing)
+        fprintf(stderr, "hc_found_to_lines_device: %llu SFO records -> %llu grouped, %llu groups -> %llu lines (%llu equal neighbours dropped) in %.3f s, all on the device\n",
+                (unsigned long long)n, (unsigned long long)m, (unsigned long long)G, (unsigned long long)kept, (unsigned long long)(total - kept), now() - t0);
+    *d_lines = c->d_found_lines;
+    *n_lines = kept;
+    return HC_OK;
+}
+
 int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines) {
     if (!c || !out_path) return fail(HC_ERR_ARG, "hc_found_to_overlaps: null argument");
     std::string text;

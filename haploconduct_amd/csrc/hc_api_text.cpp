@@ -48,6 +48,8 @@ struct hc_textblock {
     // the last submit, kept so that hc_textblock_wait can redo its device half with larger row buffers
     uint64_t sub_bytes = 0, sub_first_line = 0, sub_base_index = 0;
     const unsigned long long* sub_first_line_ptr = nullptr;
+    const hc_line_rec* sub_src_lines = nullptr;  // hc_textblock_submit_lines: the block's lines come parsed, from device memory
+    uint32_t sub_n_lines = 0;
     uint64_t n_regrown = 0;                    // how often that happened
     std::vector<void*> old_device, old_host;   // row buffers hc_textblock_reserve_rows replaced: freed with the block (a free waits for the device)
     bool in_flight = false;
@@ -258,8 +260,12 @@ static int textblock_device_half(hc_textblock* b) {
     HC_HIP(hipHostGetDevicePointer(&d_row_lines, b->h_row_lines, 0));
     void* d_nonplain = nullptr;
     if (b->h_nonplain) HC_HIP(hipHostGetDevicePointer(&d_nonplain, b->h_nonplain, 0));
-    HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, b->d_tally,
-                                 (hc_text_nonplain*)d_nonplain, s));
+    if (b->sub_src_lines)
+        HC_HIP(hc::launch_lines_accept(prm, b->sub_src_lines, b->sub_n_lines, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters,
+                                       b->d_tally, s));
+    else
+        HC_HIP(hc::launch_text_parse(prm, b->d_text, b->d_line_start, ids, b->d_cands, b->d_lines, (hc_text_reject*)d_rejects, b->d_counters, b->d_tally,
+                                     (hc_text_nonplain*)d_nonplain, s));
     // the scoring kernel on the records the parse kernel left behind; how many there are is only known on the device
     int rc = hc_ctx_score(c, HC_REC_COMPACT, b->d_cands, b->max_lines, b->d_out, s, false, nullptr, nullptr, 0, 0,
                           b->d_counters + hc::kTextLines, nullptr, nullptr, &b->bucket);
@@ -384,6 +390,8 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
     b->sub_first_line = first_line_no;
     b->sub_first_line_ptr = chain ? d_chain + k : nullptr;
     b->sub_base_index = base_index;
+    b->sub_src_lines = nullptr;
+    b->sub_n_lines = 0;
     if (n_bytes) {
         int rc = textblock_device_half(b);  // (its last launch leaves the counters in h_counters)
         if (rc) return rc;
@@ -394,6 +402,28 @@ static int textblock_submit(hc_textblock* b, const void* src, uint64_t n_bytes, 
     b->in_flight = true;
     return HC_OK;
 }
+
+int hc_textblock_submit_lines(hc_textblock* b, const hc_line_rec* d_lines, uint64_t n_lines, uint64_t first_line_no, uint64_t base_index) {
+    if (!b || (n_lines && !d_lines)) return fail(HC_ERR_ARG, "hc_textblock_submit_lines: null argument");
+    hc_ctx* c = b->ctx;
+    if (!c->have_reads || !c->have_ids) return fail(HC_ERR_STATE, "hc_textblock_submit_lines: hc_set_reads and hc_text_set_ids come first");
+    if (b->in_flight) return fail(HC_ERR_STATE, "hc_textblock_submit_lines: the block is still in flight (hc_textblock_wait first)");
+    if (n_lines > b->max_lines) return fail(HC_ERR_ARG, "hc_textblock_submit_lines: more lines than the block has room for (hc_textblock_max_lines)");
+    HC_HIP(hipSetDevice(c->device));
+    b->sub_bytes = 0;
+    b->sub_first_line = first_line_no;
+    b->sub_first_line_ptr = nullptr;
+    b->sub_base_index = base_index;
+    b->sub_src_lines = d_lines;
+    b->sub_n_lines = (uint32_t)n_lines;
+    int rc = textblock_device_half(b);  // (its last launch leaves the counters in h_counters)
+    if (rc) return rc;
+    HC_HIP(hipEventRecord(b->done, b->stream));
+    b->in_flight = true;
+    return HC_OK;
+}
+
+uint64_t hc_textblock_max_lines(hc_textblock* b) { return b ? b->max_lines : 0; }
 
 uint64_t hc_textblock_regrown(hc_textblock* b) { return b ? b->n_regrown : 0; }
 

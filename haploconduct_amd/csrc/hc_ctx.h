@@ -139,6 +139,8 @@ struct hc_ctx {
     size_t h_ingest_cap = 0;                  // bytes of each
     hc_sfo_rec* d_found = nullptr;
     uint64_t n_found = 0;
+    hc_line_rec* d_found_lines = nullptr;  // hc_found_to_lines_device: the overlap lines of the found records, kept until the store is replaced
+    uint64_t found_lines_cap = 0;
     double found_err = -1;
     uint32_t found_min = 0, found_flags = 0;
     bool found_valid = false;

@@ -26,5 +26,15 @@ hipError_t sfo_classify(const SfoFlipped* sorted, uint64_t n, uint64_t ns, uint6
 hipError_t sfo_groups(const SfoFlipped* sorted, const uint32_t* idx, uint64_t m, uint64_t ns, uint64_t np, uint8_t* keep, hipStream_t s);
 hipError_t sfo_gather_kept(const SfoFlipped* sorted, const uint32_t* idx, uint64_t k, SfoFlipped* out, hipStream_t s);
 
+// The script's matching on the device (round 6; hc_sfo_kernels.hip): the overlap lines as records, in the script's order.
+// kSfoStatusMatch (4) in *status: an assert / division by zero of the script's matching — the caller lets the host's matcher raise it.
+hipError_t sfo_group_starts(const SfoFlipped* sorted, const uint32_t* idx, uint64_t m, uint64_t ns, uint64_t np, uint8_t* start, hipStream_t s);
+hipError_t sfo_match_groups(bool write, const SfoFlipped* sorted, const uint32_t* idx, const uint32_t* starts, uint64_t G, uint64_t ns, uint64_t np,
+                            uint32_t* emit, const uint32_t* off, hc_line_rec* lines, unsigned long long* status, hipStream_t s);
+hipError_t sfo_single_lines(bool write, const SfoFlipped* sorted, const uint8_t* keep, uint64_t n, uint64_t ns, uint64_t np, uint32_t* emit,
+                            const uint32_t* off, hc_line_rec* lines, unsigned long long* status, hipStream_t s);
+hipError_t sfo_uniq_lines(const hc_line_rec* lines, uint64_t n, uint8_t* keep, unsigned long long* n_dup, hipStream_t s);
+hipError_t sfo_gather_lines(const hc_line_rec* in, const uint32_t* idx, uint64_t k, hc_line_rec* out, hipStream_t s);
+
 }  // namespace hc
 #endif

@@ -152,7 +152,246 @@ __global__ __launch_bounds__(kBlock) void sfo_gather_kept_kernel(const SfoFlippe
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < k) out[i] = sorted[idx[i]];
 }
+// ---- the script's matching on the device (round 6: the device-resident stage a) ---------------------------------------------------
+// What host/Sfo2Overlaps.cpp does on the host threads — scripts/sfo2overlaps.py:63-103 (the loop), :150-200 (get_s_s_overlap), :203-219
+// (match_candidates), :221-310 (find_paired_overlap), :312-329 (merge_overlaps) — over the sorted records where they are, writing the
+// overlap LINES as records (hc_line_rec: what the stage's parser would read from the script's text) in the order the script writes them.
+// Asserts and the division by zero of the script are reported through `status` (the caller falls back to the host's matcher, which
+// raises what the script raises).
+enum : unsigned long long { kSfoStatusMatch = 4 };  // an assert of the script's matching (or its division by zero)
+
+struct SfoSS {  // get_s_s_overlap, :150-200
+    uint32_t id1, id2, pos1, perc, len;
+    uint8_t ori1, ori2;
+    bool bad;
+};
+__device__ __forceinline__ SfoSS sfo_ss(const SfoFlipped& r, uint32_t id0, uint32_t id1) {
+    SfoSS o;
+    const uint8_t ori = r.inverted ? '-' : '+';
+    const long ola = (long)r.ola, olb = (long)r.olb, oha = r.oha, ohb = r.ohb;
+    const long ovlen = ola < olb ? ola : olb;
+    long la, lb;
+    if (oha >= 0) {  // read A is first
+        if (ohb >= 0) {
+            la = ola + oha;
+            lb = olb + ohb;
+        } else {
+            la = ola + oha - ohb;
+            lb = olb;
+        }
+        o.id1 = id0;
+        o.id2 = id1;
+        o.pos1 = (uint32_t)oha;
+        o.ori1 = '+';
+        o.ori2 = ori;
+    } else {  // read B is first
+        if (ohb >= 0) {
+            la = ola;
+            lb = -oha + olb + ohb;
+        } else {
+            la = ola - ohb;
+            lb = -oha + olb;
+        }
+        o.id1 = id1;
+        o.id2 = id0;
+        o.pos1 = (uint32_t)(-oha);
+        o.ori1 = ori;
+        o.ori2 = '+';
+    }
+    const long minlen = la < lb ? la : lb;
+    o.bad = minlen <= 0;  // division by zero / `assert minreadlen > 0`
+    // min(round(100 * ovlen / minreadlen), 100) under `from __future__ import division`: the correctly rounded quotient of two exact
+    // doubles, Python 2's round() = C round() (half away from zero)
+    const double q = o.bad ? 0.0 : round(100.0 * (double)ovlen / (double)minlen);
+    o.perc = (uint32_t)(q < 100.0 ? q : 100.0);
+    o.len = (uint32_t)ovlen;
+    return o;
+}
+
+// find_paired_overlap + merge_overlaps for candidates c1, c2 (in the group's order) with the CLOSING line's read types; false: no line
+__device__ __forceinline__ bool sfo_paired_line(const SfoFlipped& c1, const SfoFlipped& c2, uint32_t id0, uint32_t id1, bool type_a, bool type_b,
+                                                hc_line_rec& out, bool& bad) {
+    if (c1.inverted != c2.inverted) return false;
+    const long a1 = c1.s0, b1 = c1.s1, a2 = c2.s0, b2 = c2.s1;
+    const bool normal = !c1.inverted;
+    int first = 0;  // which candidate provides overlap1
+    if (type_a && type_b) {
+        if (normal) first = (a1 < a2 && b1 < b2) ? 1 : ((a1 > a2 && b1 > b2) ? 2 : 0);
+        else first = (a1 < a2 && b1 > b2) ? 1 : ((a1 > a2 && b1 < b2) ? 2 : 0);
+    } else {
+        const long p1 = c1.oha, p2 = c2.oha;
+        const long k1 = (type_a && !type_b) ? a1 : b1, k2 = (type_a && !type_b) ? a2 : b2;
+        if (normal) first = (k1 < k2 && p1 < p2) ? 1 : ((k1 > k2 && p1 > p2) ? 2 : 0);
+        else first = (k1 < k2 && p1 > p2) ? 2 : ((k1 > k2 && p1 < p2) ? 1 : 0);
+    }
+    if (!first) return false;
+    const SfoSS o1 = sfo_ss(first == 1 ? c1 : c2, id0, id1), o2 = sfo_ss(first == 1 ? c2 : c1, id0, id1);
+    if (o1.bad || o2.bad) {
+        bad = true;
+        return false;
+    }
+    uint8_t t1, t2;
+    if (o1.id1 == id0) {  // (both candidates name the group's pair of reads: o1.id2 == id1 follows)
+        t1 = type_a ? 'p' : 's';
+        t2 = type_b ? 'p' : 's';
+    } else {
+        t1 = type_b ? 'p' : 's';
+        t2 = type_a ? 'p' : 's';
+    }
+    uint8_t ord = '-';
+    if (t1 == 'p' && t2 == 'p') ord = o1.id1 != o2.id1 ? '2' : '1';  // (o1.id1 != o2.id1 implies o1.id1 == o2.id2: the same two reads)
+    out.id1 = o1.id1;
+    out.id2 = o1.id2;
+    out.pos1 = o1.pos1;
+    out.pos2 = o2.pos1;
+    out.perc1 = o1.perc;
+    out.perc2 = o2.perc;
+    out.len1 = o1.len;
+    out.len2 = o2.len;
+    out.ord = ord;
+    out.ori1 = o1.ori1;
+    out.ori2 = o1.ori2;
+    out.type1 = t1;
+    out.type2 = t2;
+    out.pad[0] = out.pad[1] = out.pad[2] = 0;
+    return true;
+}
+
+// the j-th grouped record opens a group
+__global__ __launch_bounds__(kBlock) void sfo_group_starts_kernel(const SfoFlipped* __restrict__ sorted, const uint32_t* __restrict__ idx, uint64_t m,
+                                                                  uint64_t ns, uint64_t np, uint8_t* __restrict__ start) {
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= m) return;
+    start[j] = (j == 0 || !sfo_same_pair(sorted[idx[j - 1]], sorted[idx[j]], ns, np)) ? 1 : 0;
+}
+
+// Group g (1 <= g < G) is matched when the line that opens group g — the TRIGGER, whose read types the script passes on (:94) —
+// arrives: every two lines of group g - 1, in the script's order.  WRITE = false: emit[trigger] = the number of lines that come out;
+// WRITE = true: the lines themselves at off[trigger]....  One lane per group (groups of two lines are the rule).
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void sfo_match_groups_kernel(const SfoFlipped* __restrict__ sorted, const uint32_t* __restrict__ idx,
+                                                                  const uint32_t* __restrict__ starts, uint64_t G, uint64_t ns, uint64_t np,
+                                                                  uint32_t* __restrict__ emit, const uint32_t* __restrict__ off,
+                                                                  hc_line_rec* __restrict__ lines, unsigned long long* __restrict__ status) {
+    const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x + 1;
+    if (g >= G) return;
+    const uint32_t b = starts[g - 1], e = starts[g];  // the group in front of the trigger: grouped records [b, e)
+    const uint32_t trig = idx[e];
+    if (e - b < 2) {
+        if (!WRITE) emit[trig] = 0;
+        return;
+    }
+    const SfoFlipped t = sorted[trig];
+    const uint32_t tid0 = sfo_original(t.s0, ns, np), tid1 = sfo_original(t.s1, ns, np);
+    const bool type_a = np != 0 && tid0 >= ns, type_b = np != 0 && tid1 >= ns;  // is_paired of the CLOSING line's reads
+    const SfoFlipped c0 = sorted[idx[b]];
+    const uint32_t id0 = sfo_original(c0.s0, ns, np), id1 = sfo_original(c0.s1, ns, np);
+    uint32_t count = 0;
+    bool bad = false;
+    uint32_t at = WRITE ? off[trig] : 0u;
+    for (uint32_t x = b; x < e; x++) {
+        const SfoFlipped cx = x == b ? c0 : sorted[idx[x]];
+        for (uint32_t y = x + 1; y < e; y++) {
+            hc_line_rec line;
+            if (sfo_paired_line(cx, sorted[idx[y]], id0, id1, type_a, type_b, line, bad)) {
+                if (WRITE) lines[at + count] = line;
+                count++;
+            }
+        }
+    }
+    if (!WRITE) emit[trig] = count;
+    if (bad) atomicOr(status, (unsigned long long)kSfoStatusMatch);
+}
+
+// a line between two unpaired reads is an output line by itself (:79-85)
+__global__ __launch_bounds__(kBlock) void sfo_single_lines_kernel(const SfoFlipped* __restrict__ sorted, const uint8_t* __restrict__ keep, uint64_t n,
+                                                                  uint64_t ns, uint64_t np, uint32_t* __restrict__ emit, const uint32_t* __restrict__ off,
+                                                                  hc_line_rec* __restrict__ lines, unsigned long long* __restrict__ status, int write) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    if (!write) {
+        emit[i] = 1;
+        return;
+    }
+    const SfoFlipped r = sorted[i];
+    const SfoSS o = sfo_ss(r, sfo_original(r.s0, ns, np), sfo_original(r.s1, ns, np));
+    if (o.bad) atomicOr(status, (unsigned long long)kSfoStatusMatch);
+    hc_line_rec line;
+    line.id1 = o.id1;
+    line.id2 = o.id2;
+    line.pos1 = o.pos1;
+    line.pos2 = 0;
+    line.perc1 = o.perc;
+    line.perc2 = 0;
+    line.len1 = o.len;
+    line.len2 = 0;
+    line.ord = '-';
+    line.ori1 = o.ori1;
+    line.ori2 = o.ori2;
+    line.type1 = 's';
+    line.type2 = 's';
+    line.pad[0] = line.pad[1] = line.pad[2] = 0;
+    lines[off[i]] = line;
+}
+
+// the script's last `uniq` (:107): a line equal to the one in front of it goes (keep[k] = 0)
+__global__ __launch_bounds__(kBlock) void sfo_uniq_lines_kernel(const hc_line_rec* __restrict__ lines, uint64_t n, uint8_t* __restrict__ keep,
+                                                                unsigned long long* __restrict__ n_dup) {
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    bool dup = false;
+    if (k) {
+        const uint4* a = reinterpret_cast<const uint4*>(lines + k);
+        const uint4* b = reinterpret_cast<const uint4*>(lines + k - 1);
+        dup = true;
+#pragma unroll
+        for (int w = 0; w < 3; w++) dup = dup && a[w].x == b[w].x && a[w].y == b[w].y && a[w].z == b[w].z && a[w].w == b[w].w;
+    }
+    keep[k] = dup ? 0 : 1;
+    if (dup) atomicAdd(n_dup, 1ull);
+}
+
+__global__ __launch_bounds__(kBlock) void sfo_gather_lines_kernel(const hc_line_rec* __restrict__ in, const uint32_t* __restrict__ idx, uint64_t k,
+                                                                  hc_line_rec* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= k) return;
+    const uint4* src = reinterpret_cast<const uint4*>(in + idx[i]);
+    uint4* dst = reinterpret_cast<uint4*>(out + i);
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+}
 }  // namespace
+
+#define HC_SFO_GRID(n) dim3((unsigned)(((n) + kBlock - 1) / kBlock)), dim3(kBlock)
+hipError_t sfo_group_starts(const SfoFlipped* sorted, const uint32_t* idx, uint64_t m, uint64_t ns, uint64_t np, uint8_t* start, hipStream_t s) {
+    if (!m) return hipSuccess;
+    hipLaunchKernelGGL(sfo_group_starts_kernel, HC_SFO_GRID(m), 0, s, sorted, idx, m, ns, np, start);
+    return hipGetLastError();
+}
+hipError_t sfo_match_groups(bool write, const SfoFlipped* sorted, const uint32_t* idx, const uint32_t* starts, uint64_t G, uint64_t ns, uint64_t np,
+                            uint32_t* emit, const uint32_t* off, hc_line_rec* lines, unsigned long long* status, hipStream_t s) {
+    if (G < 2) return hipSuccess;
+    if (write) hipLaunchKernelGGL((sfo_match_groups_kernel<true>), HC_SFO_GRID(G - 1), 0, s, sorted, idx, starts, G, ns, np, emit, off, lines, status);
+    else hipLaunchKernelGGL((sfo_match_groups_kernel<false>), HC_SFO_GRID(G - 1), 0, s, sorted, idx, starts, G, ns, np, emit, off, lines, status);
+    return hipGetLastError();
+}
+hipError_t sfo_single_lines(bool write, const SfoFlipped* sorted, const uint8_t* keep, uint64_t n, uint64_t ns, uint64_t np, uint32_t* emit,
+                            const uint32_t* off, hc_line_rec* lines, unsigned long long* status, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(sfo_single_lines_kernel, HC_SFO_GRID(n), 0, s, sorted, keep, n, ns, np, emit, off, lines, status, write ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t sfo_uniq_lines(const hc_line_rec* lines, uint64_t n, uint8_t* keep, unsigned long long* n_dup, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(sfo_uniq_lines_kernel, HC_SFO_GRID(n), 0, s, lines, n, keep, n_dup);
+    return hipGetLastError();
+}
+hipError_t sfo_gather_lines(const hc_line_rec* in, const uint32_t* idx, uint64_t k, hc_line_rec* out, hipStream_t s) {
+    if (!k) return hipSuccess;
+    hipLaunchKernelGGL(sfo_gather_lines_kernel, HC_SFO_GRID(k), 0, s, in, idx, k, out);
+    return hipGetLastError();
+}
 
 hipError_t sfo_flip(const hc_sfo_rec* in, uint64_t n, uint64_t ns, uint64_t np, SfoFlipped* out, uint64_t* k0, uint64_t* k1, uint64_t* k2,
                     uint32_t* iota, unsigned long long* status, hipStream_t s) {

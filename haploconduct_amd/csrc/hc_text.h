@@ -55,4 +55,9 @@ hipError_t launch_text_parse(const TextParams& prm, const char* text, const uint
                              hc_line_rec* lines, hc_text_reject* rejects, unsigned long long* counters, uint32_t* tally /* [(max_lines + 255) / 256][8] */,
                              hc_text_nonplain* nonplain /* [prm.nonplain_cap], mapped host memory, or nullptr */, hipStream_t s);
 
+// parsed lines instead of text (the device-resident stage a): the counters as the line scan leaves them (kTextLines = n_lines, or
+// kTextOverflow when there is no room for them), then the parse kernel's second half on src[i]
+hipError_t launch_lines_accept(const TextParams& prm, const hc_line_rec* src, uint32_t n_lines, const IdTable& ids, hc_cand_rec* cands, hc_line_rec* lines,
+                               hc_text_reject* rejects, unsigned long long* counters, uint32_t* tally, hipStream_t s);
+
 }  // namespace hc

@@ -249,6 +249,58 @@ __device__ __forceinline__ bool parse_plain_line(const char* text, uint32_t begi
     return true;
 }
 
+// What construct_edges does with a parsed line before process_overlaps (src/EdgeCalculator.cpp:605-635): self overlaps go, the prefilter
+// passes, drops silently or rejects (kept for nonedge_overlaps.txt), the two ids are looked up (m_ID_to_index, :164-171); a line that passes
+// becomes the candidate record cd.  Shared by the kernel that parses the file's text and the one that takes parsed lines as they are
+// (lines_accept_kernel: the device-resident stage a).
+__device__ __forceinline__ void accept_line(const TextParams& prm, const IdTable& ids, const hc_line_rec& o, uint32_t i, hc_cand_rec& cd,
+                                            hc_text_reject* __restrict__ rejects, unsigned long long* __restrict__ counters, uint32_t& n_self,
+                                            uint32_t& n_silent, uint32_t& n_reject, uint32_t& n_pass, uint32_t& n_unknown) {
+    if (o.id1 == o.id2) {  // :605-607
+        n_self = 1;
+        return;
+    }
+    const uint32_t perc = o.perc2 > 0 ? (o.perc1 + o.perc2) >> 1 : o.perc1;  // Overlap::get_perc: (unsigned)(0.5 * (a + b))
+    const bool ss = o.type1 == 's' && o.type2 == 's', anyp = !ss;
+    const uint64_t M = prm.min_overlap_len;
+    bool pass = false;
+    if (o.len1 >= M && ss) {  // :612-617
+        pass = perc >= prm.min_overlap_perc;
+        n_silent = pass ? 0 : 1;
+    } else if (2ull * o.len1 >= M && 2ull * o.len2 >= M && anyp) {  // :618-624: len >= 0.5 * M, exactly
+        pass = perc >= prm.min_overlap_perc;
+        n_silent = pass ? 0 : 1;
+    } else if (prm.relax_pe && (uint64_t)o.len1 + o.len2 >= M && anyp) {  // :626-632 (unsigned int sum: no wrap below 2^32 here, both < 10^9)
+        pass = perc >= prm.min_overlap_perc;
+        n_silent = pass ? 0 : 1;
+    } else {  // :633-635
+        n_reject = 1;
+        const unsigned long long slot = atomicAdd(&counters[kTextRejectSlots], 1ull);
+        if (slot < prm.reject_cap) {
+            hc_text_reject r;
+            r.line_index = i;
+            r.pad = 0;
+            r.line = o;
+            rejects[slot] = r;
+        }
+    }
+    if (pass) {
+        uint32_t r1, r2;
+        if (!id_lookup(ids, o.id1, r1) || !id_lookup(ids, o.id2, r2)) {
+            n_unknown = 1;  // std::map::at throws, :170-171: the host reproduces the failure
+        } else {
+            n_pass = 1;
+            const uint32_t p1 = o.pos1 < HC_CAND_POS_MASK ? o.pos1 : HC_CAND_POS_MASK;
+            const uint32_t p2 = o.pos2 < HC_CAND_POS_MASK ? o.pos2 : HC_CAND_POS_MASK;
+            const uint32_t oc = o.ord == '-' ? 0u : (o.ord == '1' ? 1u : 2u);
+            cd.read1 = r1;
+            cd.read2 = r2;
+            cd.pos1_bits = p1 | (o.ori1 == '+' ? 1u << 28 : 0u) | (o.ori2 == '+' ? 1u << 29 : 0u) | (oc << 30);
+            cd.pos2_bits = p2;
+        }
+    }
+}
+
 constexpr uint32_t kStageBytes = 32 * 1024;  // text of the 256 lines of a workgroup staged in LDS when it fits (a plain line has ~45 bytes)
 
 // counters: the enum of hc_text.h
@@ -309,49 +361,7 @@ __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const c
             }
         } else {
             lines[i] = o;
-            if (o.id1 == o.id2) {  // :605-607
-                n_self = 1;
-            } else {
-                const uint32_t perc = o.perc2 > 0 ? (o.perc1 + o.perc2) >> 1 : o.perc1;  // Overlap::get_perc: (unsigned)(0.5 * (a + b))
-                const bool ss = o.type1 == 's' && o.type2 == 's', anyp = !ss;
-                const uint64_t M = prm.min_overlap_len;
-                bool pass = false;
-                if (o.len1 >= M && ss) {  // :612-617
-                    pass = perc >= prm.min_overlap_perc;
-                    n_silent = pass ? 0 : 1;
-                } else if (2ull * o.len1 >= M && 2ull * o.len2 >= M && anyp) {  // :618-624: len >= 0.5 * M, exactly
-                    pass = perc >= prm.min_overlap_perc;
-                    n_silent = pass ? 0 : 1;
-                } else if (prm.relax_pe && (uint64_t)o.len1 + o.len2 >= M && anyp) {  // :626-632 (unsigned int sum: no wrap below 2^32 here, both < 10^9)
-                    pass = perc >= prm.min_overlap_perc;
-                    n_silent = pass ? 0 : 1;
-                } else {  // :633-635
-                    n_reject = 1;
-                    const unsigned long long slot = atomicAdd(&counters[kTextRejectSlots], 1ull);
-                    if (slot < prm.reject_cap) {
-                        hc_text_reject r;
-                        r.line_index = i;
-                        r.pad = 0;
-                        r.line = o;
-                        rejects[slot] = r;
-                    }
-                }
-                if (pass) {
-                    uint32_t r1, r2;
-                    if (!id_lookup(ids, o.id1, r1) || !id_lookup(ids, o.id2, r2)) {
-                        n_unknown = 1;  // std::map::at throws, :170-171: the host reproduces the failure
-                    } else {
-                        n_pass = 1;
-                        const uint32_t p1 = o.pos1 < HC_CAND_POS_MASK ? o.pos1 : HC_CAND_POS_MASK;
-                        const uint32_t p2 = o.pos2 < HC_CAND_POS_MASK ? o.pos2 : HC_CAND_POS_MASK;
-                        const uint32_t oc = o.ord == '-' ? 0u : (o.ord == '1' ? 1u : 2u);
-                        cd.read1 = r1;
-                        cd.read2 = r2;
-                        cd.pos1_bits = p1 | (o.ori1 == '+' ? 1u << 28 : 0u) | (o.ori2 == '+' ? 1u << 29 : 0u) | (oc << 30);
-                        cd.pos2_bits = p2;
-                    }
-                }
-            }
+            accept_line(prm, ids, o, i, cd, rejects, counters, n_self, n_silent, n_reject, n_pass, n_unknown);
         }
         cands[i] = cd;
     } else if (i < prm.max_lines) {
@@ -374,6 +384,48 @@ __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const c
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// Parsed lines as they are (round 6: the device-resident stage a — the lines come from the SFO matcher's kernels, hc_sfo_kernels.hip, and
+// no text exists): the block's counters as the line-start scan leaves them, then text_parse_kernel's second half on src[i].
+__global__ void lines_prepare_kernel(unsigned long long* __restrict__ counters, uint32_t n_lines, uint32_t max_lines) {
+    if (threadIdx.x < kTextCounters) counters[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[kTextLines] = n_lines <= max_lines ? n_lines : 0u;
+        counters[kTextOverflow] = n_lines > max_lines ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void lines_accept_kernel(TextParams prm, const hc_line_rec* __restrict__ src, IdTable ids,
+                                                           hc_cand_rec* __restrict__ cands, hc_line_rec* __restrict__ lines,
+                                                           hc_text_reject* __restrict__ rejects, unsigned long long* __restrict__ counters,
+                                                           uint32_t* __restrict__ tally /* [workgroups][8] */) {
+    __shared__ uint32_t wave_tally[4][8];
+    if (counters[kTextOverflow]) return;
+    const uint32_t n = (uint32_t)counters[kTextLines];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t n_read = 0, n_self = 0, n_silent = 0, n_reject = 0, n_pass = 0, n_unknown = 0;
+    hc_cand_rec cd;
+    cd.read1 = cd.read2 = 0;
+    cd.pos1_bits = 0;
+    cd.pos2_bits = HC_CAND_SKIP;
+    if (i < n && prm.first_line_no + i < prm.max_overlaps) {  // `&& i < max_overlaps`, :581
+        n_read = 1;
+        const hc_line_rec o = src[i];
+        lines[i] = o;
+        accept_line(prm, ids, o, i, cd, rejects, counters, n_self, n_silent, n_reject, n_pass, n_unknown);
+    }
+    if (i < prm.max_lines) cands[i] = cd;
+    const uint32_t vals[7] = {n_read, 0u, n_self, n_silent, n_reject, n_pass, n_unknown};
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const uint32_t c = (uint32_t)__popcll(__ballot(vals[k] != 0));
+        if ((threadIdx.x & 63u) == 0) wave_tally[threadIdx.x >> 6][k] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) tally[blockIdx.x * 8u + threadIdx.x] = wave_tally[0][threadIdx.x] + wave_tally[1][threadIdx.x] + wave_tally[2][threadIdx.x] + wave_tally[3][threadIdx.x];
+}
+
 hipError_t launch_text_count(const char* text, uint64_t n_bytes, uint32_t* tile_cnt, hipStream_t s) {
     const uint32_t n_tiles = (uint32_t)((n_bytes + 4095) / 4096);
     if (n_tiles == 0) return hipSuccess;
@@ -402,6 +454,13 @@ hipError_t launch_text_parse(const TextParams& prm, const char* text, const uint
     hipLaunchKernelGGL(text_parse_kernel, dim3((prm.max_lines + 255) / 256), dim3(256), 0, s, prm, text, line_start, ids, cands, lines, rejects,
                        counters, tally, nonplain);
     return hipGetLastError();  // (the workgroups' tallies are summed by the one-workgroup scan of launch_kept_rows_flushed)
+}
+
+hipError_t launch_lines_accept(const TextParams& prm, const hc_line_rec* src, uint32_t n_lines, const IdTable& ids, hc_cand_rec* cands, hc_line_rec* lines,
+                               hc_text_reject* rejects, unsigned long long* counters, uint32_t* tally, hipStream_t s) {
+    hipLaunchKernelGGL(lines_prepare_kernel, dim3(1), dim3(64), 0, s, counters, n_lines, prm.max_lines);
+    hipLaunchKernelGGL(lines_accept_kernel, dim3((prm.max_lines + 255u) / 256u), dim3(256), 0, s, prm, src, ids, cands, lines, rejects, counters, tally);
+    return hipGetLastError();
 }
 
 }  // namespace hc

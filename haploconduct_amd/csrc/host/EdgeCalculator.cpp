@@ -1358,6 +1358,50 @@ void EdgeCalculator::score_device_parsed(OverlapsParser& parser, std::vector<Ove
                 (unsigned long)n_host_blocks, tm_slot, tm_copy, tm_submit, C, tm_wait, tm_final, tm_turn, tm_consume);
 }
 
+// The overlaps file's lines as parsed records in the primary device's memory (construct_edges_from_store): block k = lines
+// [k * L, (k + 1) * L) with L = what a text block has room for; D blocks in flight on the block objects of the primary device; what comes
+// back is consumed strictly in order, as score_device_parsed's collectors do.  No text, no host tokeniser: every line is plain by construction.
+void EdgeCalculator::score_device_lines(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc) {
+    Device& dev = m_dev[0];
+    const size_t D = m_text_depth;
+    if (dev.tblk.size() < D) dev.tblk.resize(D, nullptr);
+    for (hc_textblock*& b : dev.tblk)
+        if (!b) {
+            check(hc_textblock_create(dev.ctx, m_text_block, &b), "hc_textblock_create");
+            if (m_odd_line_cap) check(hc_textblock_list_nonplain(b, m_odd_line_cap), "hc_textblock_list_nonplain");
+        }
+    const uint64_t L = hc_textblock_max_lines(dev.tblk[0]);
+    if (L == 0) throw FatalError{HC_ERR_STATE, "construct_edges: a text block without room for lines"};
+    const uint64_t n_use = std::min<uint64_t>(m_lines_override_n, program_settings.max_overlaps);  // `&& i < max_overlaps`, :581
+    const uint64_t K = (n_use + L - 1) / L;
+    auto submit = [&](uint64_t k) {
+        const uint64_t lo = k * L, n = std::min(L, n_use - lo);
+        check(hc_textblock_submit_lines(dev.tblk[k % D], m_lines_override + lo, n, lo, 0), "hc_textblock_submit_lines");
+    };
+    const double t0 = now_s();
+    for (uint64_t k = 0; k < K && k < D; k++) submit(k);
+    BlockOut out;
+    const unsigned threads = std::max(1u, std::min<unsigned>(8u, program_settings.n_threads));
+    for (uint64_t k = 0; k < K; k++) {
+        hc_text_result tr;
+        check(hc_textblock_wait(dev.tblk[k % D], &tr), "hc_textblock_wait");
+        if (tr.needs_host)  // an id that is not in the FASTQ input, or more rows than a block of this size may grow to: not from this stage's own reads
+            throw FatalError{HC_ERR_STATE, "construct_edges_from_store: a block of lines the device does not take (unknown read id?)"};
+        finalize_text_block(parser.ids(), tr.rows, tr.n_rows, out, threads);
+        stats.device_blocks++;
+        pc.lines_read += tr.lines_read;
+        pc.self_overlaps += tr.self_overlaps;
+        pc.silently_dropped += tr.silently_dropped;
+        pc.prefilter_rejected += tr.prefilter_rejected;
+        stats.scored += tr.scored;
+        for (uint64_t j = 0; j < tr.n_rejected; j++) rejected.push_back(overlap_of(tr.rejected[j].line));
+        consume_block(out);
+        if (k + D < K) submit(k + D);  // (the block object is free again: its rows have been consumed)
+    }
+    stats.t_score = now_s() - t0;
+    for (hc_textblock* tb : dev.tblk) stats.regrown_blocks += hc_textblock_regrown(tb);
+}
+
 // The file tokenised on the host's threads (HC_PARSE=host; also what a block the device's parser does not read goes
 // through).
 void EdgeCalculator::score_host_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc) {
@@ -1527,6 +1571,7 @@ void EdgeCalculator::run_stage(bool then_sort) {
     std::remove("nonedge_overlaps.txt");  // :566 — in the cwd, whatever --output says (kept as is)
     std::vector<Overlap> rejected;
     // (closed by the clean-up thread: unmapping the 4 GB file with the worker threads alive takes 20 ms)
+    if (m_lines_override && !m_text_override) m_text_override = std::make_shared<std::string>();  // (the parser only lends its id index then)
     std::unique_ptr<OverlapsParser> parser_owner(m_text_override
                                                      ? new OverlapsParser(m_text_override, program_settings, *fastq_storage, m_pool.get())
                                                      : new OverlapsParser(program_settings.overlaps_file, program_settings, *fastq_storage, m_pool.get()));
@@ -1540,7 +1585,8 @@ void EdgeCalculator::run_stage(bool then_sort) {
     if (!parser.is_open()) throw FatalError{HC_ERR_IO, "Unable to open overlaps file"};  // :662-665
     if (program_settings.verbose) puts("reading overlaps file... ");
     ParseCounters pc;
-    if (m_host_parse) score_host_parsed(parser, rejected, pc);
+    if (m_lines_override) score_device_lines(parser, rejected, pc);
+    else if (m_host_parse) score_host_parsed(parser, rejected, pc);
     else score_device_parsed(parser, rejected, pc);
     finish_appender(true);
     stage_lap("all blocks scored and consumed");
@@ -1637,6 +1683,56 @@ void EdgeCalculator::construct_edges_from_reads(double err_rate, uint32_t min_ov
     if (getenv("HC_STAGE_TIMING"))
         fprintf(stderr, "[hc stage] reads -> graph: find %.3f s (%lu SFO records), ingest %.3f s (%lu lines, %zu bytes of text in memory), construct %.3f s\n",
                 t1 - t0, (unsigned long)found, t2 - t1, (unsigned long)lines, text->size(), now_s() - t2);
+}
+
+void EdgeCalculator::construct_edges_from_store(double err_rate, uint32_t min_overlap, uint32_t find_flags, bool then_sort, uint64_t* n_found,
+                                                uint64_t* n_lines, int* device_route) {
+    const double t0 = now_s();
+    uint64_t found = 0, lines = 0;
+    int grow_rc = HC_OK;
+    std::thread grower([&] {  // row buffers for lines that mostly survive, beside the finder's kernels (as construct_edges_from_reads)
+        bind_here();
+        Device& d = m_dev[0];
+        for (size_t k = 0; k < d.tblk.size() && k < 6; k++)
+            if (d.tblk[k] && grow_rc == HC_OK) grow_rc = hc_textblock_reserve_rows(d.tblk[k], m_text_block / 32);
+    });
+    struct Join {
+        std::thread& t;
+        ~Join() {
+            if (t.joinable()) t.join();
+        }
+    } join_grower{grower};
+    check(hc_find_overlaps(m_ctx, err_rate, min_overlap, find_flags, nullptr, 0, &found), "hc_find_overlaps");
+    grower.join();
+    check(grow_rc, "hc_textblock_reserve_rows");
+    const double t1 = now_s();
+    const hc_line_rec* d_lines = nullptr;
+    const int rc = hc_found_to_lines_device(m_ctx, fastq_storage->m_readcount_single, fastq_storage->m_readcount_paired, &d_lines, &lines);
+    if (rc == HC_ERR_STATE && strstr(hc_last_error(), "not on the device")) {  // the host's matcher owns the script's errors
+        if (device_route) *device_route = 0;
+        construct_edges_from_reads(err_rate, min_overlap, find_flags, then_sort, n_found, n_lines);
+        return;
+    }
+    check(rc, "hc_found_to_lines_device");
+    const double t2 = now_s();
+    if (device_route) *device_route = 1;
+    if (n_found) *n_found = found;
+    if (n_lines) *n_lines = lines;
+    struct Reset {
+        EdgeCalculator* self;
+        ~Reset() {
+            self->m_lines_override = nullptr;
+            self->m_lines_override_n = 0;
+            self->m_text_override.reset();
+        }
+    } reset{this};
+    static const hc_line_rec none{};
+    m_lines_override = lines ? d_lines : &none;  // (no lines at all: an empty file — the stage still runs, over nothing)
+    m_lines_override_n = lines;
+    run_stage(then_sort);
+    if (getenv("HC_STAGE_TIMING"))
+        fprintf(stderr, "[hc stage] reads -> graph on the device: find %.3f s (%lu SFO records), ingest %.3f s (%lu lines, none of them text), construct %.3f s\n",
+                t1 - t0, (unsigned long)found, t2 - t1, (unsigned long)lines, now_s() - t2);
 }
 
 }  // namespace hc

@@ -87,6 +87,14 @@ public:
     // Same graph as writing that file and calling construct_edges[_sorted] on it.  *n_found / *n_lines: SFO records, overlap lines.
     void construct_edges_from_reads(double err_rate, uint32_t min_overlap, uint32_t find_flags, bool then_sort, uint64_t* n_found,
                                     uint64_t* n_lines);
+    // The same with NOTHING between the reads and the graph but device memory (round 6): the finder's records stay on the
+    // device, the script's flip / sort / matching / uniq run there (hc_found_to_lines_device) and leave the overlaps file's lines as parsed
+    // records, which the stage's text blocks take as they are (hc_textblock_submit_lines): no text is written, copied or parsed.  Where the
+    // device cannot decide (an assert of the script, ids outside its sort keys) the call takes construct_edges_from_reads' route, which
+    // raises what the script raises.  Graph, inclusions, counters and nonedge_overlaps.txt are that route's, byte for byte.
+    // *device_route (may be null): whether the lines stayed on the device.
+    void construct_edges_from_store(double err_rate, uint32_t min_overlap, uint32_t find_flags, bool then_sort, uint64_t* n_found,
+                                    uint64_t* n_lines, int* device_route);
     // src/EdgeCalculator.cpp:67-139 on arbitrary strings (used by SRBuilder::merge_self_overlap in the
     // reference): scored on the device through a two-read scratch store, finalised with the host libm.
     double overlap_score(const std::string& seq1, const std::string& seq2, const std::string& score1,
@@ -134,6 +142,9 @@ private:
     friend void keep_devices_resident(bool on);
     void run_stage(bool then_sort);
     std::shared_ptr<const std::string> m_text_override;  // construct_edges_from_reads: the overlaps file's text, in memory
+    const hc_line_rec* m_lines_override = nullptr;       // construct_edges_from_store: the overlaps file's lines, parsed, in device memory
+    uint64_t m_lines_override_n = 0;
+    void score_device_lines(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc);  // ... sent through the text blocks
     void score_host_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc);   // the file tokenised on host threads
     void score_device_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc); // the file's text sent to the device
     void finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out, unsigned threads = 0);

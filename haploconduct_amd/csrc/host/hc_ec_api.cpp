@@ -143,6 +143,12 @@ int hc_ec_construct_edges_sorted(hc_ec* ec) {
     return rc;
 }
 
+int hc_ec_construct_edges_from_store(hc_ec* ec, double err_rate, uint32_t min_overlap, uint32_t find_flags, int sorted, uint64_t* n_found,
+                                     uint64_t* n_lines, int* device_route) {
+    if (!ec) return set_last_error(HC_ERR_ARG, "hc_ec_construct_edges_from_store: null");
+    return guarded("construct_edges", [&] { ec->calc->construct_edges_from_store(err_rate, min_overlap, find_flags, sorted != 0, n_found, n_lines, device_route); });
+}
+
 int hc_ec_construct_edges_from_reads(hc_ec* ec, double err_rate, uint32_t min_overlap, uint32_t find_flags, int sorted, uint64_t* n_found,
                                      uint64_t* n_lines) {
     if (!ec) return set_last_error(HC_ERR_ARG, "hc_ec_construct_edges_from_reads: null");

@@ -50,6 +50,8 @@ _sig = {
     "hc_ec_construct_edges": (C.c_int, [_vp]),
     "hc_ec_construct_edges_sorted": (C.c_int, [_vp]),
     "hc_ec_construct_edges_from_reads": (C.c_int, [_vp, C.c_double, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hc_ec_construct_edges_from_store": (C.c_int, [_vp, C.c_double, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                                    C.POINTER(C.c_int)]),
     "hc_ec_device_count": (C.c_uint32, [_vp]),
     "hc_ec_get_counters": (C.c_int, [_vp, C.POINTER(hc_ec_counters)]),
     "hc_ec_read_count": (C.c_uint64, [_vp]),
@@ -300,6 +302,15 @@ class EdgeCalculatorStage:
         N.check(N.lib.hc_ec_construct_edges_from_reads(self._h, float(err_rate), int(min_overlap), flags, 1 if sorted_order else 0,
                                                        C.byref(nf), C.byref(nl)), "hc_ec_construct_edges_from_reads")
         return nf.value, nl.value
+
+    def construct_edges_from_store(self, err_rate, min_overlap, reversals=True, inclusions=True, sorted_order=True):
+        """hc_ec_construct_edges_from_store: the same with nothing but device memory between the reads and the graph (no text is written,
+        copied or parsed).  Returns (SFO records found, overlap lines, whether the lines stayed on the device)."""
+        nf, nl, dr = C.c_uint64(), C.c_uint64(), C.c_int()
+        flags = (1 if reversals else 0) | (2 if inclusions else 0)
+        N.check(N.lib.hc_ec_construct_edges_from_store(self._h, float(err_rate), int(min_overlap), flags, 1 if sorted_order else 0,
+                                                       C.byref(nf), C.byref(nl), C.byref(dr)), "hc_ec_construct_edges_from_store")
+        return nf.value, nl.value, bool(dr.value)
 
     def device_count(self):
         return int(N.lib.hc_ec_device_count(self._h))

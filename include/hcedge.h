@@ -274,6 +274,13 @@ int hc_find_overlaps(hc_ctx* ctx, double err_rate, uint32_t min_overlap, uint32_
  * key, the sorted records come back once, the host threads match the paired candidates and write the 13-column overlaps
  * file.  Same bytes as hc_host_write_sfo + hc_sfo2overlaps on those records.  *n_lines = overlap lines written. */
 int hc_found_to_overlaps(hc_ctx* ctx, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines);
+/* The same ingest with nothing leaving the device (round 6): the script's flip, sort, matching (scripts/sfo2overlaps.py:63-103,150-329) and
+ * both its `uniq`s on the records where hc_find_overlaps left them; *d_lines = the overlaps file's lines as hc_line_rec (hcedge.h below) in
+ * DEVICE memory, in file order — what hc_textblock_submit_lines takes.  Valid until the next call or hc_set_reads.  HC_ERR_STATE with "not on
+ * the device" in hc_last_error where the device cannot decide (ids / numbers outside its sort keys, an assert of the script): the caller
+ * takes hc_found_to_overlaps, which raises what the script raises.  Candidate generation itself: parity unpinned (rust-overlaps is absent). */
+struct hc_line_rec;
+int hc_found_to_lines_device(hc_ctx* ctx, uint64_t num_singles, uint64_t num_pairs, const struct hc_line_rec** d_lines, uint64_t* n_lines);
 
 /* hc_compact_device + hc_pack_rows_device in one call, with the count travelling inside the payload: d_payload is
  * (cap + 1) rows; row 0 = { index = *d_count, x1 = x2 = 0, mm = 0, n_cls = 0 }, rows 1.. as hc_pack_rows_device writes
@@ -432,6 +439,11 @@ int hc_linechain_create(hc_ctx* ctx, uint64_t n_blocks, hc_linechain** out);
 int hc_linechain_destroy(hc_linechain* chain);
 int hc_textblock_submit_from(hc_textblock* b, const void* text, uint64_t n_bytes, hc_linechain* chain, uint64_t k, hc_textblock* prev,
                              uint64_t base_index);
+/* Parsed lines instead of text (round 6: the device-resident stage a, hc_found_to_lines_device — no text exists): d_lines = n_lines
+ * hc_line_rec in DEVICE memory of the block's device, in file order, numbered first_line_no... (--max_ov).  Everything behind the parse is the
+ * text route's own: self overlaps, prefilter, id look-up (src/EdgeCalculator.cpp:605-635), scoring, rows.  n_lines <= hc_textblock_max_lines. */
+int hc_textblock_submit_lines(hc_textblock* b, const hc_line_rec* d_lines, uint64_t n_lines, uint64_t first_line_no, uint64_t base_index);
+uint64_t hc_textblock_max_lines(hc_textblock* b);
 int hc_textblock_wait(hc_textblock* b, hc_text_result* out); /* valid until the next submit on this block */
 /* Per-LINE fallback (round 5; the reference reads every line by itself, src/EdgeCalculator.cpp:581-604): with a list of `max_lines`
  * entries (0: none, the default) a block that holds up to that many lines which are not plain does NOT go to the host as a whole —

@@ -64,6 +64,16 @@ int hc_ec_construct_edges_sorted(hc_ec* ec);
  * on it; hc_paths.overlaps_file is not read.  *n_found: SFO records, *n_lines: overlap lines (either may be NULL). */
 int hc_ec_construct_edges_from_reads(hc_ec* ec, double err_rate, uint32_t min_overlap, uint32_t find_flags, int sorted, uint64_t* n_found,
                                      uint64_t* n_lines);
+/* The same call with nothing but device memory between the reads and the graph (round 6; SURVEY.md 8(f4): "would remove ... the text file
+ * altogether"): the finder's records stay on the device, the SFO ingest — flip, sort, the script's matching (scripts/sfo2overlaps.py:63-103,
+ * 150-329) and both its `uniq`s — runs there (hc_found_to_lines_device) and leaves the overlaps file's lines as parsed records, which the
+ * stage's text blocks take as they are (hc_textblock_submit_lines); from there on it is construct_edges' own path (prefilter, scoring,
+ * duplicate resolution, sortEdges order, nonedge_overlaps.txt from the kept rows).  Graph, inclusions, counters and nonedge_overlaps.txt:
+ * hc_ec_construct_edges_from_reads', byte for byte.  Where the device cannot decide (an assert of the script's matching, an id or number
+ * its sort keys do not hold) the call takes that route itself; *device_route (may be NULL) = 1 when the lines stayed on the device.
+ * Candidate generation (hc_find_overlaps) stands in for rust-overlaps, which is not in the reference tree: parity unpinned there. */
+int hc_ec_construct_edges_from_store(hc_ec* ec, double err_rate, uint32_t min_overlap, uint32_t find_flags, int sorted, uint64_t* n_found,
+                                     uint64_t* n_lines, int* device_route);
 /* number of device contexts the stage scores on (hc_settings.device_mask) */
 uint32_t hc_ec_device_count(hc_ec* ec);
 int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* out);

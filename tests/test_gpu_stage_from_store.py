@@ -1,0 +1,142 @@
+"""Stage a with nothing but device memory between the reads and the graph (round 6):
+hc_ec_construct_edges_from_store — the finder's records stay on the device, the SFO ingest's flip, sort, MATCHING (scripts/sfo2overlaps.py:
+63-103, 150-329) and both `uniq`s run there and leave the overlaps file's lines as parsed records, the text blocks take them as they are —
+against today's routes, which are pinned against the reference's own code (hc_ec_construct_edges_from_reads: the same lines as text in
+memory; hc_found_to_overlaps + hc_ec_construct_edges_sorted: as a file): graph in sortEdges order, in-lists, inclusions, counters and
+nonedge_overlaps.txt, byte for byte.  Candidate generation itself (hc_find_overlaps for rust-overlaps): parity unpinned."""
+import os
+
+import numpy as np
+import pytest
+
+import haploconduct_amd as hc
+from haploconduct_amd import host, records
+from tests.test_gpu_example_data import gunzip_to
+from tests.test_gpu_overlap_finder import make_reads
+
+pytestmark = pytest.mark.gpu
+COUNTERS = ("inclusion_count", "dup_count", "edges_added", "nonedges_written", "prefilter_rejected", "lines_read", "scored", "self_overlap_count",
+            "silently_dropped")
+
+
+def _both_routes(tmp_path, st, fq, err, min_overlap, tag, **find_kw):
+    out = {}
+    for route in ("store", "reads"):
+        d = tmp_path / f"{tag}_{route}"
+        d.mkdir()
+        with host.EdgeCalculatorStage(st, output_dir=str(d) + "/", **fq) as ec:
+            if route == "store":
+                n_found, n_lines, on_device = ec.construct_edges_from_store(err, min_overlap, **find_kw)
+                assert on_device, "the lines were expected to stay on the device"
+            else:
+                n_found, n_lines = ec.construct_edges_from_reads(err, min_overlap, **find_kw)
+            out[route] = (n_found, n_lines, ec.edges(), ec.in_lists(), ec.inclusions(), ec.counters(), (d / "nonedge_overlaps.txt").read_bytes())
+    a, b = out["store"], out["reads"]
+    assert a[0] == b[0] and a[1] == b[1], (a[:2], b[:2])
+    assert a[2].size == b[2].size and a[2].tobytes() == b[2].tobytes(), f"{tag}: the graphs differ"
+    assert np.array_equal(a[3][0], b[3][0]) and np.array_equal(a[3][1], b[3][1]) and np.array_equal(a[4], b[4])
+    for k in COUNTERS:
+        if k in a[5]:
+            assert a[5][k] == b[5][k], (tag, k, a[5][k], b[5][k])
+    assert a[6] == b[6], f"{tag}: nonedge_overlaps.txt differs"
+    assert a[5]["host_blocks"] == 0 and a[5]["host_lines"] == 0
+    return a
+
+
+def _write(reads, tmp_path, n_single, n_pairs):
+    d = str(tmp_path) + "/"
+    fq = dict(singles=d + "s.fastq" if n_single else None, paired1=d + "p1.fastq" if n_pairs else None, paired2=d + "p2.fastq" if n_pairs else None)
+    reads.write_fastq(fq["singles"], fq["paired1"], fq["paired2"])
+    return fq
+
+
+def test_c2_pairs(tmp_path):
+    import bench
+
+    reads, cand, cfg, st = bench.build_workload("c2", 0)
+    del cand
+    st.n_threads = 8
+    fq = _write(reads, tmp_path, 0, reads.n_reads)
+    a = _both_routes(tmp_path, st, fq, 0.0, 90, "c2")
+    assert a[1] > 100000 and a[2].size > 10000
+    # ... and the route with a FILE in between (hc_found_to_overlaps -> overlaps.txt -> hc_ec_construct_edges_sorted), which the reference's own
+    # construct_edges + sortEdges pin (tests/test_gpu_c3.py, test_gpu_golden_and_properties.py)
+    d = str(tmp_path) + "/"
+    with hc.EdgeScorer(st) as sc:
+        sc.set_reads(reads)
+        assert sc.find_overlaps(0.0, 90, count_only=True) == a[0]
+        assert sc.found_to_overlaps(d + "overlaps.txt", 0, reads.n_reads) == a[1]
+    os.mkdir(d + "file")
+    with host.EdgeCalculatorStage(st, overlaps=d + "overlaps.txt", output_dir=d + "file/", **fq) as ec:
+        ec.construct_edges_sorted()
+        assert ec.edges().tobytes() == a[2].tobytes()
+    assert open(d + "file/nonedge_overlaps.txt", "rb").read() == a[6]
+
+
+@pytest.mark.parametrize("seed,kw,err,t,settings", [
+    (321, dict(n_single=300, n_pair=500, glen=2500, lo=100, hi=200, err=0.01), 0.03, 70, dict(edge_threshold=0.9, ov_threshold=0.5, min_overlap_len=0)),
+    # the prefilter at work (rejects go to nonedge_overlaps.txt), --max_ov cutting inside the lines, percentages
+    (322, dict(n_single=400, n_pair=400, glen=2000, lo=90, hi=220, err=0.01), 0.03, 60, dict(edge_threshold=0.95, ov_threshold=0.6, min_overlap_len=150,
+                                                                                               min_overlap_perc=40, max_overlaps=7001)),
+    # singles only; pairs only with many candidates per pair of reads (short genome: groups of three lines and more)
+    (323, dict(n_single=900, n_pair=0, glen=1500, lo=80, hi=160, err=0.005), 0.02, 50, dict(edge_threshold=0.97, min_overlap_len=100)),
+    (324, dict(n_single=0, n_pair=700, glen=900, lo=100, hi=180, err=0.005, repeat=True), 0.04, 40, dict(edge_threshold=0.9, ov_threshold=0.3, min_overlap_len=60)),
+    # relaxed paired-end prefilter, merge_contigs, inclusions ignored
+    (325, dict(n_single=200, n_pair=600, glen=1800, lo=100, hi=200, err=0.01), 0.03, 60,
+     dict(edge_threshold=0.995, min_overlap_len=220, merge_contigs=0.01, flags=records.FLAG_RESOLVE_ORIENTATIONS | records.FLAG_IGNORE_INCLUSIONS | records.FLAG_RELAX_PE_EDGES)),
+])
+def test_mixed_sets(tmp_path, seed, kw, err, t, settings):
+    reads = make_reads(seed, **kw)
+    st = hc.Settings(**settings)
+    st.n_threads = 8
+    fq = _write(reads, tmp_path, kw["n_single"], kw["n_pair"])
+    a = _both_routes(tmp_path, st, fq, err, t, f"mixed{seed}")
+    assert a[1] > 500
+    # small blocks: the lines take several text blocks, --max_ov and the row buffers cross their borders
+    old = os.environ.get("HC_TEXT_BLOCK")
+    os.environ["HC_TEXT_BLOCK"] = "65536"
+    try:
+        b = _both_routes(tmp_path, st, fq, err, t, f"mixed{seed}_small")
+    finally:
+        if old is None:
+            del os.environ["HC_TEXT_BLOCK"]
+        else:
+            os.environ["HC_TEXT_BLOCK"] = old
+    assert b[2].tobytes() == a[2].tobytes() and b[6] == a[6]
+
+
+def test_no_reversals_no_inclusions(tmp_path):
+    kw = dict(n_single=300, n_pair=300, glen=2000, lo=100, hi=200, err=0.01)
+    reads = make_reads(326, **kw)
+    st = hc.Settings(edge_threshold=0.9, ov_threshold=0.5, min_overlap_len=0, n_threads=8)
+    fq = _write(reads, tmp_path, 300, 300)
+    _both_routes(tmp_path, st, fq, 0.02, 60, "norev", reversals=False)
+    _both_routes(tmp_path, st, fq, 0.02, 60, "noinc", inclusions=False)
+
+
+def test_savage_example_reads(tmp_path):
+    """BASELINE config 1's reads (the whole savage/example/input_fas set: 2 000 merged singles + 200 pairs, 25 quality values), SAVAGE's
+    stage a settings and finder arguments (savage.py:384,664: rust-overlaps ... 0.02 100)."""
+    fq = dict(singles=gunzip_to("savage_singles.fastq", str(tmp_path / "singles.fastq")), paired1=gunzip_to("savage_paired1.fastq", str(tmp_path / "paired1.fastq")),
+              paired2=gunzip_to("savage_paired2.fastq", str(tmp_path / "paired2.fastq")))
+    for tag, st in (("a", hc.Settings(edge_threshold=0.97, min_overlap_len=200, n_threads=8)),
+                    ("bc", hc.Settings(edge_threshold=0.995, min_overlap_len=100, merge_contigs=0.01, n_threads=8,
+                                       flags=records.FLAG_RESOLVE_ORIENTATIONS | records.FLAG_IGNORE_INCLUSIONS))):
+        a = _both_routes(tmp_path, st, fq, 0.02, 100, "savage_" + tag)
+        assert a[1] > 20000 and a[2].size > 2000
+
+
+def test_polyte_example_reads_as_singles(tmp_path):
+    """The POLYTE example excerpt (35 quality values: the wide 8-bit table), every read a single (polyte.py:283-288), first-iteration settings."""
+    recs = []
+    for name in ("polyte_forward.fastq", "polyte_reverse.fastq"):
+        L = open(gunzip_to(name, str(tmp_path / name))).read().split("\n")
+        for i in range(0, len(L) - 3, 4):
+            recs.append((L[i + 1], L[i + 3]))
+    s = str(tmp_path / "singles.fastq")
+    with open(s, "w") as o:
+        for i, (seq, q) in enumerate(recs):
+            o.write(f"@{i}\n{seq}\n+\n{q}\n")
+    st = hc.Settings(edge_threshold=0.95, min_overlap_len=127, n_threads=8)
+    a = _both_routes(tmp_path, st, dict(singles=s), 0.02, 80, "polyte")
+    assert a[1] > 300
