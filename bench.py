@@ -785,6 +785,58 @@ def stage_end_to_end(reads, cand, settings, threads, reps=4):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def stage_a_from_reads(reads, settings, threads, err=0.0, min_overlap=90, reps=3):
+    """Reads -> sorted graph with no overlaps file (the front of SAVAGE stage a: savage.py:643-717 runs rust-overlaps, scripts/sfo2overlaps.py and
+    the binary as three programs), by both routes of this library on the workload's own reads: `from_reads` — the SFO ingest's matching on the
+    host threads, the overlaps file's text in memory, copied into the device's text blocks and parsed there — and `from_store` (round 6) —
+    nothing but device memory in between (hc_ec_construct_edges_from_store).  Candidate generation (hc_find_overlaps) stands in for
+    rust-overlaps, which is not in the reference tree: PARITY UNPINNED there; both routes score the same lines, and the graphs must be equal."""
+    import shutil
+    import tempfile
+
+    from haploconduct_amd import host
+
+    d = tempfile.mkdtemp(prefix="hcstagea_") + "/"
+    try:
+        paired = reads.is_paired(0)
+        reads.write_fastq(None if paired else d + "singles.fastq", d + "paired1.fastq" if paired else None, d + "paired2.fastq" if paired else None)
+        settings.n_threads = threads
+        kw = dict(singles=None if paired else d + "singles.fastq", paired1=d + "paired1.fastq" if paired else None,
+                  paired2=d + "paired2.fastq" if paired else None, output_dir=d)
+        res, digest = {}, {}
+        for route in ("from_reads", "from_store", "from_reads", "from_store"):  # interleaved: a process's first call pays the finder's allocations
+            for _ in range(reps if route in res else 1):
+                t0 = time.perf_counter()
+                with host.EdgeCalculatorStage(settings, **kw) as ec:
+                    t_open = time.perf_counter() - t0
+                    t1 = time.perf_counter()
+                    if route == "from_store":
+                        n_found, n_lines, on_device = ec.construct_edges_from_store(err, min_overlap)
+                    else:
+                        (n_found, n_lines), on_device = ec.construct_edges_from_reads(err, min_overlap), False
+                    t_call = time.perf_counter() - t1
+                    edges = ec.edges()
+                    dg = (int(edges.size), hash(edges.tobytes()), hash(open(d + "nonedge_overlaps.txt", "rb").read()))
+                res.setdefault(route, []).append({"open_s": t_open, "call_s": t_call, "sfo_records": int(n_found), "overlap_lines": int(n_lines),
+                                                  "edges": dg[0], "lines_stayed_on_device": bool(on_device)})
+                digest.setdefault(route, dg)
+                if digest[route] != dg:
+                    raise SystemExit(f"bench.py: {route} gave two different graphs")
+        if digest["from_reads"] != digest["from_store"]:
+            raise SystemExit("bench.py: the device-resident stage a built another graph than the text route")
+        med = {r: sorted(x["call_s"] for x in v[1:])[len(v[1:]) // 2] for r, v in res.items()}
+        last = res["from_store"][-1]
+        return {"value": med["from_store"], "unit": "s (reads in the stage's store -> sorted graph, median of the runs behind each route's first)",
+                "from_store_s": med["from_store"], "from_reads_s": med["from_reads"], "speedup": med["from_reads"] / med["from_store"],
+                "sfo_records": last["sfo_records"], "overlap_lines": last["overlap_lines"], "edges": last["edges"],
+                "lines_stayed_on_device": last["lines_stayed_on_device"], "graphs_equal": True, "finder": {"err_rate": err, "min_overlap": min_overlap},
+                "runs": {r: [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in x.items()} for x in xs] for r, xs in res.items()},
+                "parity": "the two routes build the same graph and nonedge_overlaps.txt (checked here); the text route is pinned against the reference's "
+                          "own construct_edges + sortEdges (tests/test_gpu_c3.py); candidate generation: parity UNPINNED (rust-overlaps is absent)"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def summary_record(out, args):
     """The line's figures once more, compact and LAST (the driver's record keeps the tail of stdout)."""
     r = out.get("roofline", {})
@@ -805,6 +857,9 @@ def summary_record(out, args):
         sm[f"{args.workload}_stage_median_s"], sm[f"{args.workload}_stage_first_s"] = g(st["median"]["construct_edges_sorted_s"], 4), g(runs[0], 4)
         sm[f"{args.workload}_stage_runs_s"] = [round(x, 4) for x in runs]
         sm[f"{args.workload}_stage_lines_per_s"] = g(st["value"], 4)
+    sa = out.get("stage_a_from_reads")
+    if sa:
+        sm[f"{args.workload}_reads_to_graph_from_store_s"], sm[f"{args.workload}_reads_to_graph_from_reads_s"] = g(sa["from_store_s"], 4), g(sa["from_reads_s"], 4)
     for w, rec in (out.get("also") or {}).items():
         sm[f"{w}_ms_per_step"], sm[f"{w}_kernel_ms"] = g(rec["ms_per_step"], 4), g(rec["roofline"]["kernel_ms"], 4)
         if rec["roofline"].get("frac") is not None:
@@ -996,6 +1051,7 @@ def main():
         if not args.no_stage:
             threads = args.stage_threads or min(32, os.cpu_count() or 1)
             out["stage_end_to_end"] = stage_end_to_end(reads, cand, settings, threads)
+            out["stage_a_from_reads"] = stage_a_from_reads(reads, settings, threads)
         if not args.no_cpu_baseline:
             # the reference's own code where its probe library is present (it is built by __graft_entry__.build() in the
             # build container and travels with the repository), and always the oracle (a port) beside it

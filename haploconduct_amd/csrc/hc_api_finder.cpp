@@ -667,6 +667,36 @@ int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs
     return HC_OK;
 }
 
+// SFO records from elsewhere (a rust-overlaps file parsed by the caller; the tests' hand-made records) take the place of the finder's: the
+// ingest entry points (hc_found_to_overlaps, hc_found_to_lines_device) then run on them.  Needs a read store (the ids are its sequences').
+int hc_set_found_records(hc_ctx* c, const hc_sfo_rec* recs, uint64_t n) {
+    if (!c || (n && !recs)) return fail(HC_ERR_ARG, "hc_set_found_records: null argument");
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_set_found_records: hc_set_reads has not been called");
+    HC_HIP(hipSetDevice(c->device));
+    if (c->d_found) (void)hipFree(c->d_found);
+    c->d_found = nullptr;
+    c->n_found = 0;
+    c->found_valid = false;
+    if (n) {
+        HC_HIP(hipMalloc((void**)&c->d_found, n * sizeof(hc_sfo_rec)));
+        HC_HIP(hipMemcpy(c->d_found, recs, n * sizeof(hc_sfo_rec), hipMemcpyHostToDevice));
+    }
+    c->n_found = n;
+    c->found_err = -1;  // (no finder arguments describe these records: the next hc_find_overlaps computes)
+    c->found_min = 0;
+    c->found_flags = 0;
+    c->found_valid = true;
+    return HC_OK;
+}
+
+// the lines hc_found_to_lines_device left on the device, copied to the host (tests, tools)
+int hc_found_lines_fetch(hc_ctx* c, const hc_line_rec* d_lines, uint64_t n, hc_line_rec* out) {
+    if (!c || (n && (!d_lines || !out))) return fail(HC_ERR_ARG, "hc_found_lines_fetch: null argument");
+    HC_HIP(hipSetDevice(c->device));
+    if (n) HC_HIP(hipMemcpy(out, d_lines, n * sizeof(hc_line_rec), hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+
 int hc_found_to_overlaps(hc_ctx* c, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines) {
     if (!c || !out_path) return fail(HC_ERR_ARG, "hc_found_to_overlaps: null argument");
     std::string text;

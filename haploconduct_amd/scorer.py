@@ -286,6 +286,22 @@ class EdgeScorer:
         N.check(N.lib.hc_found_to_overlaps(self._ctx, str(out_path).encode(), int(num_singles), int(num_pairs), C.byref(n)), "hc_found_to_overlaps")
         return int(n.value)
 
+    def set_found_records(self, recs):
+        """hc_set_found_records: SFO records from elsewhere (records.SFO_DTYPE) in the place of the finder's."""
+        recs = np.ascontiguousarray(recs)
+        N.check(N.lib.hc_set_found_records(self._ctx, _ptr(recs), recs.size), "hc_set_found_records")
+
+    def found_to_lines(self, num_singles, num_pairs):
+        """hc_found_to_lines_device + hc_found_lines_fetch: the SFO ingest entirely on the device; the overlaps file's lines as records
+        (records.LINE_DTYPE), in file order.  Raises RuntimeError("... not on the device ...") where the device cannot decide."""
+        from .records import LINE_DTYPE
+
+        p, n = C.c_void_p(), C.c_uint64()
+        N.check(N.lib.hc_found_to_lines_device(self._ctx, int(num_singles), int(num_pairs), C.byref(p), C.byref(n)), "hc_found_to_lines_device")
+        out = np.zeros(n.value, dtype=LINE_DTYPE)
+        N.check(N.lib.hc_found_lines_fetch(self._ctx, p, n.value, _ptr(out)), "hc_found_lines_fetch")
+        return out
+
     def score_pack_device(self, d_in_ptr, n, d_out_ptr, cap, base_index, d_payload_ptr, stream=None, fmt=REC_FULL):
         """hc_score_pack_device: scoring + the collection payload in one kernel (rows unordered, count in row 0)."""
         N.check(N.lib.hc_score_pack_device(self._ctx, fmt, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), cap, base_index,

@@ -279,7 +279,12 @@ int hc_found_to_overlaps(hc_ctx* ctx, const char* out_path, uint64_t num_singles
  * DEVICE memory, in file order — what hc_textblock_submit_lines takes.  Valid until the next call or hc_set_reads.  HC_ERR_STATE with "not on
  * the device" in hc_last_error where the device cannot decide (ids / numbers outside its sort keys, an assert of the script): the caller
  * takes hc_found_to_overlaps, which raises what the script raises.  Candidate generation itself: parity unpinned (rust-overlaps is absent). */
+/* SFO records from elsewhere — a rust-overlaps output the caller has parsed (8 columns: /root/reference/scripts/sfo2overlaps.py:35-36) — in
+ * the place of the finder's: hc_found_to_overlaps / hc_found_to_lines_device then run the ingest on them.  After hc_set_reads. */
+int hc_set_found_records(hc_ctx* ctx, const hc_sfo_rec* recs, uint64_t n);
 struct hc_line_rec;
+/* n lines of hc_found_to_lines_device copied to the host */
+int hc_found_lines_fetch(hc_ctx* ctx, const struct hc_line_rec* d_lines, uint64_t n, struct hc_line_rec* out);
 int hc_found_to_lines_device(hc_ctx* ctx, uint64_t num_singles, uint64_t num_pairs, const struct hc_line_rec** d_lines, uint64_t* n_lines);
 
 /* hc_compact_device + hc_pack_rows_device in one call, with the count travelling inside the payload: d_payload is
