@@ -804,6 +804,7 @@ def stage_a_from_reads(reads, settings, threads, err=0.0, min_overlap=90, reps=3
         kw = dict(singles=None if paired else d + "singles.fastq", paired1=d + "paired1.fastq" if paired else None,
                   paired2=d + "paired2.fastq" if paired else None, output_dir=d)
         res, digest = {}, {}
+        host.keep_devices(True)  # a pipeline's iterations in one process: the stages take over each other's devices (contexts, scratch, blocks)
         for route in ("from_reads", "from_store", "from_reads", "from_store"):  # interleaved: a process's first call pays the finder's allocations
             for _ in range(reps if route in res else 1):
                 t0 = time.perf_counter()
@@ -834,6 +835,7 @@ def stage_a_from_reads(reads, settings, threads, err=0.0, min_overlap=90, reps=3
                 "parity": "the two routes build the same graph and nonedge_overlaps.txt (checked here); the text route is pinned against the reference's "
                           "own construct_edges + sortEdges (tests/test_gpu_c3.py); candidate generation: parity UNPINNED (rust-overlaps is absent)"}
     finally:
+        host.keep_devices(False)
         shutil.rmtree(d, ignore_errors=True)
 
 

@@ -143,24 +143,30 @@ int hc_create(hc_ctx** out, const hc_settings* settings) {
     return HC_OK;
 }
 
-static void free_store(hc_ctx* c) {
-    for (auto& sl : c->finder_scratch) {
-        if (sl.p) (void)hipFree(sl.p);
-        sl.p = nullptr;
-        sl.cap = 0;
+// scratch_too = false (hc_reset: the resident process, a caller's stage after stage on parked devices): the grow-only scratch of the finder and
+// of the SFO ingest — gigabytes at config 3's size — stays with the context for the next read set.  Giving it back and asking for it again
+// every stage stalled the next stage's first kernels by 0.3 - 0.4 s on this pool (round 6: profiles/r06_stage_a_from_store.md).
+static void free_store(hc_ctx* c, bool scratch_too = true) {
+    if (scratch_too) {
+        for (auto& sl : c->finder_scratch) {
+            if (sl.p) (void)hipFree(sl.p);
+            sl.p = nullptr;
+            sl.cap = 0;
+        }
+        for (auto& sl : c->ingest_scratch) {
+            if (sl.p) (void)hipFree(sl.p);
+            sl.p = nullptr;
+            sl.cap = 0;
+        }
+        if (c->d_found_lines) (void)hipFree(c->d_found_lines);
+        c->d_found_lines = nullptr;
+        c->found_lines_cap = 0;
+        if (c->d_found) (void)hipFree(c->d_found);
+        c->d_found = nullptr;
+        c->found_cap = 0;
     }
-    for (auto& sl : c->ingest_scratch) {
-        if (sl.p) (void)hipFree(sl.p);
-        sl.p = nullptr;
-        sl.cap = 0;
-    }
-    if (c->d_found) (void)hipFree(c->d_found);
-    c->d_found = nullptr;
     c->n_found = 0;
     c->found_valid = false;
-    if (c->d_found_lines) (void)hipFree(c->d_found_lines);
-    c->d_found_lines = nullptr;
-    c->found_lines_cap = 0;
     if (c->d_sym) (void)hipFree(c->d_sym);
     if (c->d_reads) (void)hipFree(c->d_reads);
     if (c->d_lut) (void)hipFree(c->d_lut);
@@ -756,7 +762,7 @@ int hc_reset(hc_ctx* c, const hc_settings* settings) {
     if (settings->device != c->device) return fail(HC_ERR_ARG, "hc_reset: a context stays on its device");
     HC_HIP(hipSetDevice(c->device));
     HC_HIP(hipDeviceSynchronize());  // nothing of the previous stage is in flight
-    free_store(c);                   // the read store, the finder's results, the id table's validity: as after hc_create
+    free_store(c, false);            // the read store, the finder's results, the id table's validity: as after hc_create (the scratch stays)
     c->have_ids = false;
     c->reorder_mode = HC_REORDER_AUTO;
     c->graph.valid = false;

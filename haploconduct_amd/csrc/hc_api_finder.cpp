@@ -88,8 +88,6 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     for (const hc::SeqRef& r : c->seq_refs) max_len = r.len > max_len ? r.len : max_len;
     if (max_len >= (1u << 14)) return fail(HC_ERR_ARG, "hc_find_overlaps: sequences of 16384 symbols or more are not supported");
     if (n_seq < 2 || max_len < min_overlap) {  // nothing can overlap: an empty result, remembered like any other
-        if (c->d_found) (void)hipFree(c->d_found);
-        c->d_found = nullptr;
         c->n_found = 0;
         c->found_err = err_rate;
         c->found_min = min_overlap;
@@ -116,13 +114,11 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         if (take) HC_HIP(hipMemcpy(out, c->d_found, take * sizeof(hc_sfo_rec), hipMemcpyDeviceToHost));
         return HC_OK;
     }
-    if (c->d_found) (void)hipFree(c->d_found);
-    c->d_found = nullptr;
-    c->n_found = 0;
+    c->n_found = 0;  // (the previous result's buffer stays: grow-only — asking the driver for 2 GB per call cost 0.3 - 0.4 s from the second call on)
     c->found_valid = false;
     lap("free previous result");
     auto remember = [&](hc_sfo_rec* d, uint64_t n) {
-        c->d_found = d;
+        if (d) c->d_found = d;
         c->n_found = n;
         c->found_err = err_rate;
         c->found_min = min_overlap;
@@ -316,8 +312,14 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         return HC_OK;
     }
     if (R >= (1ull << 31)) return fail(HC_ERR_ARG, "hc_find_overlaps: more than 2^31 overlaps");
-    HC_HIP(hipMalloc(&d_r1.own, R * sizeof(hc_sfo_rec)));  // the result: the context's until the next call
-    d_r1.p = d_r1.own;
+    if (!c->d_found || c->found_cap < R) {  // the result: the context's until the next call (grow-only)
+        if (c->d_found) (void)hipFree(c->d_found);
+        c->d_found = nullptr;
+        c->found_cap = 0;
+        HC_HIP(hipMalloc((void**)&c->d_found, (R + R / 8) * sizeof(hc_sfo_rec)));
+        c->found_cap = R + R / 8;
+    }
+    d_r1.p = c->d_found;
     if (batches.size() > 1) {  // every batch is sorted; one more sort (key, position) + gather for the global order
         // the batches' buffers are idle now: they hold the keys and positions of this sort when they are large enough
         DevBuf own[5];  // what they cannot hold; freed on every return path
@@ -351,8 +353,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     const uint64_t take = R < cap ? R : cap;
     if (take) HC_HIP(hc::copy_to_pageable_host(out, d_r1.p, take * sizeof(hc_sfo_rec)));
     lap("copy to host");
-    remember((hc_sfo_rec*)d_r1.p, R);  // the context owns the records now
-    d_r1.own = nullptr;
+    remember((hc_sfo_rec*)d_r1.p, R);
     return HC_OK;
 }
 
@@ -673,12 +674,16 @@ int hc_set_found_records(hc_ctx* c, const hc_sfo_rec* recs, uint64_t n) {
     if (!c || (n && !recs)) return fail(HC_ERR_ARG, "hc_set_found_records: null argument");
     if (!c->have_reads) return fail(HC_ERR_STATE, "hc_set_found_records: hc_set_reads has not been called");
     HC_HIP(hipSetDevice(c->device));
-    if (c->d_found) (void)hipFree(c->d_found);
-    c->d_found = nullptr;
     c->n_found = 0;
     c->found_valid = false;
     if (n) {
-        HC_HIP(hipMalloc((void**)&c->d_found, n * sizeof(hc_sfo_rec)));
+        if (!c->d_found || c->found_cap < n) {
+            if (c->d_found) (void)hipFree(c->d_found);
+            c->d_found = nullptr;
+            c->found_cap = 0;
+            HC_HIP(hipMalloc((void**)&c->d_found, n * sizeof(hc_sfo_rec)));
+            c->found_cap = n;
+        }
         HC_HIP(hipMemcpy(c->d_found, recs, n * sizeof(hc_sfo_rec), hipMemcpyHostToDevice));
     }
     c->n_found = n;

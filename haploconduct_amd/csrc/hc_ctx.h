@@ -137,7 +137,8 @@ struct hc_ctx {
     } finder_scratch[24], ingest_scratch[12];  // the second set: hc_found_to_overlaps
     void* h_ingest[2] = {nullptr, nullptr};  // page-locked ring hc_found_to_overlaps copies the sorted records through
     size_t h_ingest_cap = 0;                  // bytes of each
-    hc_sfo_rec* d_found = nullptr;
+    hc_sfo_rec* d_found = nullptr;  // grow-only (round 6): room for found_cap records, n_found of them valid
+    uint64_t found_cap = 0;
     uint64_t n_found = 0;
     hc_line_rec* d_found_lines = nullptr;  // hc_found_to_lines_device: the overlap lines of the found records, kept until the store is replaced
     uint64_t found_lines_cap = 0;

@@ -875,6 +875,8 @@ void EdgeCalculator::finalize_text_block(const IdIndex& ids, const hc_text_row* 
         const unsigned want = n_rows >= 100000 ? std::min(4u, std::max(1u, program_settings.n_threads / 4)) : 1u;
         own_threads = threads == 1 && want > 1;
         T = own_threads ? want : std::min(T, threads);
+        // (a caller that names more threads than the cap gets them: the device-lines route, where nearly every line survives and ONE helper finalises)
+        if (threads > build_cap && n_rows >= 4096) T = std::min<unsigned>(threads, std::max(1u, program_settings.n_threads));
     }
     std::vector<Piece> pieces(T);
     if (T == 1) {
@@ -1370,8 +1372,9 @@ void EdgeCalculator::score_device_lines(OverlapsParser& parser, std::vector<Over
             check(hc_textblock_create(dev.ctx, m_text_block, &b), "hc_textblock_create");
             if (m_odd_line_cap) check(hc_textblock_list_nonplain(b, m_odd_line_cap), "hc_textblock_list_nonplain");
         }
-    const uint64_t L = hc_textblock_max_lines(dev.tblk[0]);
+    uint64_t L = hc_textblock_max_lines(dev.tblk[0]);
     if (L == 0) throw FatalError{HC_ERR_STATE, "construct_edges: a text block without room for lines"};
+    L = std::min<uint64_t>(L, 1u << 18);  // (smaller pieces than a block's capacity: the host's half of piece k runs beside the device's of k + 1)
     const uint64_t n_use = std::min<uint64_t>(m_lines_override_n, program_settings.max_overlaps);  // `&& i < max_overlaps`, :581
     const uint64_t K = (n_use + L - 1) / L;
     auto submit = [&](uint64_t k) {
@@ -1379,27 +1382,110 @@ void EdgeCalculator::score_device_lines(OverlapsParser& parser, std::vector<Over
         check(hc_textblock_submit_lines(dev.tblk[k % D], m_lines_override + lo, n, lo, 0), "hc_textblock_submit_lines");
     };
     const double t0 = now_s();
-    for (uint64_t k = 0; k < K && k < D; k++) submit(k);
-    BlockOut out;
-    const unsigned threads = std::max(1u, std::min<unsigned>(8u, program_settings.n_threads));
-    for (uint64_t k = 0; k < K; k++) {
+    // A helper thread waits for the blocks in order, finalises what survived of block k (exp() of the admitted rows, the non-edges' lines:
+    // finalize_text_block on the build pool) and puts block k + D in flight; this thread runs the serial half in order (consume_block).
+    struct Done {
+        BlockOut out;
         hc_text_result tr;
-        check(hc_textblock_wait(dev.tblk[k % D], &tr), "hc_textblock_wait");
-        if (tr.needs_host)  // an id that is not in the FASTQ input, or more rows than a block of this size may grow to: not from this stage's own reads
-            throw FatalError{HC_ERR_STATE, "construct_edges_from_store: a block of lines the device does not take (unknown read id?)"};
-        finalize_text_block(parser.ids(), tr.rows, tr.n_rows, out, threads);
-        stats.device_blocks++;
-        pc.lines_read += tr.lines_read;
-        pc.self_overlaps += tr.self_overlaps;
-        pc.silently_dropped += tr.silently_dropped;
-        pc.prefilter_rejected += tr.prefilter_rejected;
-        stats.scored += tr.scored;
-        for (uint64_t j = 0; j < tr.n_rejected; j++) rejected.push_back(overlap_of(tr.rejected[j].line));
-        consume_block(out);
-        if (k + D < K) submit(k + D);  // (the block object is free again: its rows have been consumed)
+        std::vector<Overlap> rejected;
+    };
+    const size_t R = 3;
+    std::vector<Done> ring(R);
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t produced = 0, consumed = 0;
+    FatalError failure{0, ""};
+    bool failed = false;
+    const unsigned threads = std::max(1u, std::min<unsigned>(24u, program_settings.n_threads));
+    double tm_wait = 0, tm_final = 0, tm_consume = 0;  // HC_STAGE_TIMING
+    std::thread helper([&] {
+        bind_here();
+        try {
+            for (uint64_t k = 0; k < K && k < D; k++) submit(k);
+            for (uint64_t k = 0; k < K; k++) {
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return consumed + R > k || failed; });
+                    if (failed) return;
+                }
+                Done& dn = ring[k % R];
+                const double tw0 = now_s();
+                check(hc_textblock_wait(dev.tblk[k % D], &dn.tr), "hc_textblock_wait");
+                const double tw1 = now_s();
+                tm_wait += tw1 - tw0;
+                if (dn.tr.needs_host)  // an id that is not in the FASTQ input: not from this stage's own reads
+                    throw FatalError{HC_ERR_STATE, "construct_edges_from_store: a block of lines the device does not take (unknown read id?)"};
+                finalize_text_block(parser.ids(), dn.tr.rows, dn.tr.n_rows, dn.out, threads);
+                dn.rejected.clear();
+                for (uint64_t j = 0; j < dn.tr.n_rejected; j++) dn.rejected.push_back(overlap_of(dn.tr.rejected[j].line));
+                tm_final += now_s() - tw1;
+                if (k + D < K) submit(k + D);  // (the block object is free again: its rows and rejects have been copied)
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    produced = k + 1;
+                }
+                cv.notify_all();
+            }
+        } catch (const FatalError& e) {
+            std::lock_guard<std::mutex> g(mu);
+            failure = e;
+            failed = true;
+            cv.notify_all();
+        } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> g(mu);
+            failure = FatalError{HC_ERR_NOMEM, e.what()};
+            failed = true;
+            cv.notify_all();
+        }
+    });
+    struct JoinHelper {
+        std::thread& t;
+        std::mutex& mu;
+        std::condition_variable& cv;
+        bool& failed;
+        ~JoinHelper() {
+            {
+                std::lock_guard<std::mutex> g(mu);
+                failed = true;  // (an exception on this side: the helper stops waiting)
+            }
+            cv.notify_all();
+            if (t.joinable()) t.join();
+        }
+    };
+    {
+        JoinHelper join{helper, mu, cv, failed};
+        for (uint64_t k = 0; k < K; k++) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return produced > k || (failed && failure.status); });
+                if (produced <= k) throw failure;
+            }
+            Done& dn = ring[k % R];
+            stats.device_blocks++;
+            pc.lines_read += dn.tr.lines_read;
+            pc.self_overlaps += dn.tr.self_overlaps;
+            pc.silently_dropped += dn.tr.silently_dropped;
+            pc.prefilter_rejected += dn.tr.prefilter_rejected;
+            stats.scored += dn.tr.scored;
+            for (Overlap& o : dn.rejected) rejected.push_back(o);
+            const double tc0 = now_s();
+            consume_block(dn.out);
+            tm_consume += now_s() - tc0;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                consumed = k + 1;
+            }
+            cv.notify_all();
+        }
+        helper.join();
+        std::lock_guard<std::mutex> g(mu);
+        if (failure.status) throw failure;
     }
     stats.t_score = now_s() - t0;
     for (hc_textblock* tb : dev.tblk) stats.regrown_blocks += hc_textblock_regrown(tb);
+    if (getenv("HC_STAGE_TIMING"))
+        fprintf(stderr, "[hc stage] device-lines pipeline: %lu piece(s) of up to %lu lines; helper: waiting for the device %.3f s, finalise %.3f s; serial half %.3f s; "
+                        "all %.3f s\n", (unsigned long)K, (unsigned long)L, tm_wait, tm_final, tm_consume, now_s() - t0);
 }
 
 // The file tokenised on the host's threads (HC_PARSE=host; also what a block the device's parser does not read goes
