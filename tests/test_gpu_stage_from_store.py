@@ -210,3 +210,38 @@ def test_an_assert_of_the_script_is_left_to_the_host(tmp_path):
             sc.found_to_lines(3, 0)
         with pytest.raises(Exception):  # the host's matcher raises what the script raises
             sc.found_to_overlaps(str(tmp_path / "x.txt"), 3, 0)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HC_FUZZ_STORE_SEEDS", "6"))))  # soak: HC_FUZZ_STORE_SEEDS=200
+def test_fuzz_both_routes(tmp_path, seed):
+    """Random read sets (singles and / or pairs, lengths, error rates, N bases, repeats), random finder arguments and stage settings: the
+    device-resident route and the text-in-memory route leave the same graph, counters and nonedge_overlaps.txt."""
+    rng = np.random.default_rng(7000 + seed)
+    shape = int(rng.integers(0, 4))
+    n_single = 0 if shape == 1 else int(rng.integers(50, 500))
+    n_pair = 0 if shape == 2 else int(rng.integers(50, 500))
+    lo = int(rng.integers(40, 120))
+    kw = dict(n_single=n_single, n_pair=n_pair, glen=int(rng.integers(600, 3000)), lo=lo, hi=lo + int(rng.integers(10, 150)),
+              err=float(rng.choice([0.0, 0.005, 0.02])), n_rate=float(rng.choice([0.0, 0.0, 0.01])), repeat=bool(rng.integers(0, 2)))
+    reads = make_reads(9000 + seed, **kw)
+    flags = records.FLAG_RESOLVE_ORIENTATIONS
+    if rng.integers(0, 3) == 0:
+        flags |= records.FLAG_IGNORE_INCLUSIONS
+    if rng.integers(0, 3) == 0:
+        flags |= records.FLAG_RELAX_PE_EDGES
+    st = hc.Settings(edge_threshold=float(rng.choice([0.5, 0.9, 0.97, 0.995])), ov_threshold=float(rng.choice([0.1, 0.5, 0.9])),
+                     min_overlap_len=int(rng.choice([0, 60, 150, 260])), min_overlap_perc=int(rng.choice([0, 0, 30, 60])),
+                     merge_contigs=float(rng.choice([0.0, 0.0, 0.01, 0.05])), flags=flags,
+                     max_overlaps=int(rng.choice([100000000, 100000000, 37, 2500])), n_threads=int(rng.choice([1, 4, 8])))
+    fq = _write(reads, tmp_path, n_single, n_pair)
+    old = os.environ.get("HC_TEXT_BLOCK")
+    if rng.integers(0, 2):
+        os.environ["HC_TEXT_BLOCK"] = str(int(rng.choice([16384, 65536, 1 << 20])))
+    try:
+        _both_routes(tmp_path, st, fq, float(rng.choice([0.0, 0.02, 0.05])), int(rng.integers(25, lo + 1)), f"fuzz{seed}",
+                     reversals=bool(rng.integers(0, 4)), inclusions=bool(rng.integers(0, 4)))
+    finally:
+        if old is None:
+            os.environ.pop("HC_TEXT_BLOCK", None)
+        else:
+            os.environ["HC_TEXT_BLOCK"] = old
