@@ -625,7 +625,7 @@ int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs
     HC_HIP(hipMemcpyAsync(&total32, d_off + n, 4, hipMemcpyDeviceToHost, st));
     HC_HIP(hipMemcpyAsync(host, d_status, 8, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
-    if (host[0]) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (an assert of the script's matching)");
+    if (host[0]) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (an assert of the script's matching, or thousands of lines for one pair of reads)");
     const uint64_t total = total32;
     if (total > c->found_lines_cap) {
         if (c->d_found_lines) (void)hipFree(c->d_found_lines);

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(kBlock) void sfo_gather_kept_kernel(const SfoFlippe
 // overlap LINES as records (hc_line_rec: what the stage's parser would read from the script's text) in the order the script writes them.
 // Asserts and the division by zero of the script are reported through `status` (the caller falls back to the host's matcher, which
 // raises what the script raises).
-enum : unsigned long long { kSfoStatusMatch = 4 };  // an assert of the script's matching (or its division by zero)
+enum : unsigned long long { kSfoStatusMatch = 4 };  // an assert of the script's matching (or its division by zero), or a group beyond kSfoMaxGroup
+constexpr uint32_t kSfoMaxGroup = 2048;             // lines of one pair of reads a lane matches (every two of them: 2 * 10^6 pairs)
 
 struct SfoSS {  // get_s_s_overlap, :150-200
     uint32_t id1, id2, pos1, perc, len;
@@ -279,6 +280,11 @@ __global__ __launch_bounds__(kBlock) void sfo_match_groups_kernel(const SfoFlipp
     const uint32_t trig = idx[e];
     if (e - b < 2) {
         if (!WRITE) emit[trig] = 0;
+        return;
+    }
+    if (e - b > kSfoMaxGroup) {  // thousands of lines for ONE pair of reads (millions of pairs to try): not a lane's work — the host's matcher takes the input
+        if (!WRITE) emit[trig] = 0;
+        atomicOr(status, (unsigned long long)kSfoStatusMatch);
         return;
     }
     const SfoFlipped t = sorted[trig];

@@ -114,6 +114,29 @@ def test_no_reversals_no_inclusions(tmp_path):
     _both_routes(tmp_path, st, fq, 0.02, 60, "noinc", inclusions=False)
 
 
+def test_add_duplicates_and_serial_insert(tmp_path):
+    """--add_duplicates (vertices by orientation: the host resolves, addEquivalentEdges follows) and HC_INSERT_MODE=serial (the reference's
+    per-edge insert) behind the device-resident lines: the routes behind the blocks do not care where the lines came from."""
+    kw = dict(n_single=250, n_pair=350, glen=1800, lo=100, hi=200, err=0.01)
+    reads = make_reads(327, **kw)
+    fq = _write(reads, tmp_path, 250, 350)
+    st = hc.Settings(edge_threshold=0.9, ov_threshold=0.5, min_overlap_len=100, flags=records.FLAG_ADD_DUPLICATES, n_threads=8)
+    a = _both_routes(tmp_path, st, fq, 0.03, 60, "adddup")
+    assert a[2].size > 200
+    st = hc.Settings(edge_threshold=0.9, ov_threshold=0.5, min_overlap_len=100, n_threads=8)
+    os.environ["HC_INSERT_MODE"] = "serial"
+    try:
+        b = _both_routes(tmp_path, st, fq, 0.03, 60, "serial")
+    finally:
+        del os.environ["HC_INSERT_MODE"]
+    os.environ["HC_RESOLVE"] = "host"
+    try:
+        c = _both_routes(tmp_path, st, fq, 0.03, 60, "hostresolve")
+    finally:
+        del os.environ["HC_RESOLVE"]
+    assert b[6] == c[6] and sorted(b[2].tolist()) == sorted(c[2].tolist()), "serial insert and bulk resolution: the same edges"
+
+
 def test_savage_example_reads(tmp_path):
     """BASELINE config 1's reads (the whole savage/example/input_fas set: 2 000 merged singles + 200 pairs, 25 quality values), SAVAGE's
     stage a settings and finder arguments (savage.py:384,664: rust-overlaps ... 0.02 100)."""
@@ -245,3 +268,24 @@ def test_fuzz_both_routes(tmp_path, seed):
             os.environ.pop("HC_TEXT_BLOCK", None)
         else:
             os.environ["HC_TEXT_BLOCK"] = old
+
+
+def test_thousands_of_lines_for_one_pair_of_reads_go_to_the_host(tmp_path):
+    """A group beyond what one lane matches (2 048 lines of ONE pair of reads: two million pairs to try) is not the device's: it says so."""
+    from haploconduct_amd.records import SFO_DTYPE
+
+    n = 2100
+    recs = np.zeros(n + 1, dtype=SFO_DTYPE)
+    recs["idA"][:n], recs["idB"][:n] = 0, 3          # the /1 mates of pairs 0 and 1 (ns = 0, np = 2: SFO ids 0, 1 | 2, 3)
+    recs["idA"][n], recs["idB"][n] = 0, 1            # the line that closes the group
+    recs["OLA"] = recs["OLB"] = 40 + np.arange(n + 1) % 50
+    recs["OHA"] = 1 + np.arange(n + 1) % 37
+    recs["OHB"] = 2 + np.arange(n + 1) % 41
+    recs["K"] = np.arange(n + 1) % 7
+    reads = hc.ReadSet.from_lists([], [((b"ACGT" * 10, b"I" * 40), (b"TGCA" * 10, b"I" * 40))] * 2)
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        sc.set_found_records(recs)
+        with pytest.raises(Exception, match="not on the device"):
+            sc.found_to_lines(0, 2)
+        assert sc.found_to_overlaps(str(tmp_path / "x.txt"), 0, 2) >= 0  # the host's matcher takes it
