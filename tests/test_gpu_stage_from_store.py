@@ -276,16 +276,16 @@ def test_thousands_of_lines_for_one_pair_of_reads_go_to_the_host(tmp_path):
 
     n = 2100
     recs = np.zeros(n + 1, dtype=SFO_DTYPE)
-    recs["idA"][:n], recs["idB"][:n] = 0, 3          # the /1 mates of pairs 0 and 1 (ns = 0, np = 2: SFO ids 0, 1 | 2, 3)
-    recs["idA"][n], recs["idB"][n] = 0, 1            # the line that closes the group
+    recs["idA"][:n], recs["idB"][:n] = 0, 4          # pairs 0 and 1 (ns = 0, np = 3: SFO ids 0, 1, 2 are the /1 mates, 3, 4, 5 the /2 mates)
+    recs["idA"][n], recs["idB"][n] = 0, 5            # pairs 0 and 2: the line that closes the group
     recs["OLA"] = recs["OLB"] = 40 + np.arange(n + 1) % 50
     recs["OHA"] = 1 + np.arange(n + 1) % 37
     recs["OHB"] = 2 + np.arange(n + 1) % 41
     recs["K"] = np.arange(n + 1) % 7
-    reads = hc.ReadSet.from_lists([], [((b"ACGT" * 10, b"I" * 40), (b"TGCA" * 10, b"I" * 40))] * 2)
+    reads = hc.ReadSet.from_lists([], [((b"ACGT" * 10, b"I" * 40), (b"TGCA" * 10, b"I" * 40))] * 3)
     with hc.EdgeScorer(hc.Settings()) as sc:
         sc.set_reads(reads)
         sc.set_found_records(recs)
         with pytest.raises(Exception, match="not on the device"):
-            sc.found_to_lines(0, 2)
-        assert sc.found_to_overlaps(str(tmp_path / "x.txt"), 0, 2) >= 0  # the host's matcher takes it
+            sc.found_to_lines(0, 3)
+        assert sc.found_to_overlaps(str(tmp_path / "x.txt"), 0, 3) >= 0  # the host's matcher takes it
