@@ -849,7 +849,9 @@ int hc_score_pack_device(hc_ctx* c, uint32_t fmt, const void* d_in, uint64_t n, 
     HC_HIP(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     hc_gather_row* payload = (hc_gather_row*)d_payload;
-    HC_HIP(hipMemsetAsync(payload, 0, sizeof(hc_gather_row), s));  // row 0: the count
+    // row 0, the header { count, 0, 0, 0 }: written by the launch's own compaction when its rows collect in per-workgroup segments (every
+    // cooperative launch: round 6 — one launch fewer in front of the scoring kernel per step), zeroed by launch_score in front of the other forms
+    if (n == 0) HC_HIP(hipMemsetAsync(payload, 0, sizeof(hc_gather_row), s));
     return hc_ctx_score(c, fmt, d_in, n, d_out, s, c->reorder_mode == HC_REORDER_ALWAYS, payload + 1,
                         (unsigned long long*)&payload[0].index, cap, base_index);
 }

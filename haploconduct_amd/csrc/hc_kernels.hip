@@ -1165,7 +1165,12 @@ __global__ __launch_bounds__(256) void sink_compact_kernel(const hc_gather_row* 
         }
     }
     if (g == G - 1 && tid == 0) {
-        *count = all + spilled;
+        // the payload's whole header row: { count, 0, 0, 0 } (rows == the row behind `count`: hc_score_pack_device's layout — round 6: the
+        // fill in front of every launch that used to zero it is gone from the segmented launches)
+        count[0] = all + spilled;
+        count[1] = 0;
+        count[2] = 0;
+        count[3] = 0;
         *spill_next = 0;
     }
 }
@@ -1600,6 +1605,9 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     if (started_groups) *started_groups = 0;
     if (n == 0) return hipSuccess;
     const uint32_t lg = lut_lg(st.K);
+    // rows != nullptr is hc_score_pack_device's layout: row_count = the first word of the 32-byte header row in front of `rows`.  A launch
+    // that appends through the counter itself (no segments) needs it zeroed first; a segmented launch leaves the header to its compaction.
+    auto zero_header = [&]() -> hipError_t { return rows ? hipMemsetAsync(row_count, 0, sizeof(hc_gather_row), stream) : hipSuccess; };
     if (fetch_group == 0) {
         // a 4 KiB image per wave next to the table: 256-lane workgroups while four of them fit a CU, else one table for 1 024 lanes
         const bool coop = st.store_bytes < 0xFFFF0000ull;
@@ -1679,6 +1687,10 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                     ScoreParams pq = prm;
                     pq.pad = (prm.pad & 0xFFu) | (steps << 8);
                     use_segments(blocks_d);
+                    if (!seg_on) {
+                        const hipError_t ze = zero_header();
+                        if (ze != hipSuccess) return ze;
+                    }
 #define HC_COOP_WQ_LAUNCH(LG_)                                                                                                                  \
     hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_, 1024, true, false, 0, true>), dim3((uint32_t)blocks_d), dim3(1024), lds_dma, stream, st, \
                        pq, lut_g, in, n, out, perm, sink, nullptr)
@@ -1691,6 +1703,10 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                     return hipGetLastError();
                 }
                 use_segments(blocks_d);
+                if (!seg_on) {
+                    const hipError_t ze = zero_header();
+                    if (ze != hipSuccess) return ze;
+                }
 #define HC_COOP_DMA_LAUNCH(LG_)                                                                                                       \
     hipLaunchKernelGGL((score_kernel_coop<uint8_t, LG_, 1024, true, false, 0>), dim3((uint32_t)blocks_d), dim3(1024), lds_dma, stream, st, prm, \
                        lut_g, in, n, out, perm, sink, nullptr)
@@ -1743,6 +1759,10 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 }
             };
             use_segments(blocks_c);
+            if (!seg_on) {
+                const hipError_t ze = zero_header();
+                if (ze != hipSuccess) return ze;
+            }
             if (st.symbytes == 2) {
                 if (wg_c == 256) launch_coop(uint16_t{}, std::integral_constant<int, 5>{}, W256{});
                 else launch_coop(uint16_t{}, std::integral_constant<int, 5>{}, W1024{});
@@ -1774,6 +1794,10 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     uint64_t blocks = (n + per_wg - 1) / per_wg;
     const uint64_t grid_cap = (uint64_t)n_cu * blocks_per_cu * 4;  // grid-stride beyond this
     if (blocks > grid_cap) blocks = grid_cap;
+    {
+        const hipError_t ze = zero_header();
+        if (ze != hipSuccess) return ze;
+    }
     const ScoreLaunch a{st, prm, lut_g, in, n, out, perm, RowSink{rows, row_count, cap, base_index, lines_in, lines_out, nullptr, nullptr, 0u, 0u, nullptr, nullptr}, (uint32_t)blocks, wg, lds, stream};
     if (st.symbytes == 2) launch_lg<uint16_t, 5>(fetch_group, a);
     else if (lg == 3) launch_lg<uint8_t, 3>(fetch_group, a);
