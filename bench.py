@@ -171,6 +171,8 @@ def roofline_record(workload, order, n, positions, kern_ms, kernel_info, symbyte
         r["busiest_unit"] = max(busy, key=busy.get)
         r["bound"] = r["busiest_unit"]
         busy["kernel_cycles"] = cycles
+        if c.get("SQ_WAVE_CYCLES"):
+            busy["waves_resident_per_cu"] = c["SQ_WAVE_CYCLES"] * 4.0 / (n_cu * cycles)  # quad-cycles of resident waves over the CUs' cycles (16 = full)
         if c.get("SQ_LDS_BANK_CONFLICT") is not None and c.get("SQ_LDS_IDX_ACTIVE"):
             busy["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
     if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
