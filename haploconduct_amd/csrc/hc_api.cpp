@@ -83,6 +83,7 @@ const char* hc_strerror(int status) {
         case HC_ERR_IO: return "I/O error";
         case HC_ERR_FORMAT: return "input format the reference rejects";
         case HC_ERR_DATA: return "overlap touches a base/quality the reference asserts on";
+        case HC_ERR_NOT_ON_DEVICE: return "not decided on the device (the host's route takes the input)";
         default: return "unknown status";
     }
 }

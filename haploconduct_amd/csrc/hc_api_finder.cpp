@@ -522,8 +522,8 @@ extern "C" {
 // The ingest WITHOUT text or host (round 6; SURVEY.md 8(f4): "would remove ... the text file altogether"): flip, the script's sort, its
 // matching and both its `uniq`s on the device; what comes out is the overlaps file's lines as hc_line_rec in device memory, in file
 // order — what the stage's text kernels would parse from the script's output.  *d_lines stays valid until the next call or hc_set_reads.
-// HC_ERR_STATE with "not on the device" in hc_last_error: an SFO id / number the device keys do not hold, an assert of the script's
-// matching, or nothing to do it with — the caller takes hc_found_to_overlaps' route, which raises what the script raises.
+// HC_ERR_NOT_ON_DEVICE: an SFO id / number the device keys do not hold, an assert of the script's matching, a group of thousands of
+// lines — the caller takes hc_found_to_overlaps' route, which raises what the script raises.
 int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs, const hc_line_rec** d_lines, uint64_t* n_lines) {
     if (!c || !d_lines || !n_lines) return fail(HC_ERR_ARG, "hc_found_to_lines_device: null argument");
     *d_lines = nullptr;
@@ -531,7 +531,7 @@ int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs
     if (!c->found_valid) return fail(HC_ERR_STATE, "hc_found_to_lines_device: hc_find_overlaps has not been called on this read set");
     const uint64_t n = c->n_found;
     if (n == 0) return HC_OK;
-    if (n >= 0x7FFFFFF0ull) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (2^31 records and more)");
+    if (n >= 0x7FFFFFF0ull) return fail(HC_ERR_NOT_ON_DEVICE, "hc_found_to_lines_device: not on the device (2^31 records and more)");
     const bool timing = getenv("HC_SFO_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::vector<hc_ctx::Scratch*> idle;
@@ -609,7 +609,7 @@ int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs
     unsigned long long host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HC_HIP(hipMemcpyAsync(host, d_status, 16, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
-    if (host[0]) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (an SFO id or number the device keys do not hold)");
+    if (host[0]) return fail(HC_ERR_NOT_ON_DEVICE, "hc_found_to_lines_device: not on the device (an SFO id or number the device keys do not hold)");
     const uint64_t m = host[1];
     HC_HIP(hc::sfo_group_starts(d_sorted, d_idx, m, num_singles, num_pairs, d_start, st));
     HC_HIP(hc::prims::select_flagged(d_tmp, tmp_bytes, d_start, m, d_starts, d_status + 2, st));
@@ -625,7 +625,7 @@ int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs
     HC_HIP(hipMemcpyAsync(&total32, d_off + n, 4, hipMemcpyDeviceToHost, st));
     HC_HIP(hipMemcpyAsync(host, d_status, 8, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
-    if (host[0]) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (an assert of the script's matching, or thousands of lines for one pair of reads)");
+    if (host[0]) return fail(HC_ERR_NOT_ON_DEVICE, "hc_found_to_lines_device: not on the device (an assert of the script's matching, or thousands of lines for one pair of reads)");
     const uint64_t total = total32;
     if (total > c->found_lines_cap) {
         if (c->d_found_lines) (void)hipFree(c->d_found_lines);
@@ -641,15 +641,15 @@ int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs
     HC_HIP(hc::sfo_single_lines(true, d_sorted, d_single, n, num_singles, num_pairs, d_emit, d_off, d_raw, d_status, st));
     HC_HIP(hc::sfo_match_groups(true, d_sorted, d_idx, d_starts, G, num_singles, num_pairs, d_emit, d_off, d_raw, d_status, st));
     uint8_t* d_keep = (uint8_t*)d_k[0];
-    if (total > n * 8) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (more lines than the flags have room for)");
+    if (total > n * 8) return fail(HC_ERR_NOT_ON_DEVICE, "hc_found_to_lines_device: not on the device (more lines than the flags have room for)");
     HC_HIP(hc::sfo_uniq_lines(d_raw, total, d_keep, d_status + 4, st));
     HC_HIP(hipMemcpyAsync(host, d_status, 40, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
-    if (host[0]) return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (an assert of the script's matching)");
+    if (host[0]) return fail(HC_ERR_NOT_ON_DEVICE, "hc_found_to_lines_device: not on the device (an assert of the script's matching)");
     uint64_t kept = total;
     if (host[4]) {  // equal neighbours (rare): the kept lines, in order
         if (total * 4 > n * 8 || hc::prims::select_temp_bytes(total) > tmp_bytes)
-            return fail(HC_ERR_STATE, "hc_found_to_lines_device: not on the device (more lines than the index has room for)");
+            return fail(HC_ERR_NOT_ON_DEVICE, "hc_found_to_lines_device: not on the device (more lines than the index has room for)");
         uint32_t* d_kidx = (uint32_t*)d_k[1];
         HC_HIP(hc::prims::select_flagged(d_tmp, tmp_bytes, d_keep, total, d_kidx, d_status + 5, st));
         HC_HIP(hipMemcpyAsync(host + 5, d_status + 5, 8, hipMemcpyDeviceToHost, st));

@@ -1794,7 +1794,7 @@ void EdgeCalculator::construct_edges_from_store(double err_rate, uint32_t min_ov
     const double t1 = now_s();
     const hc_line_rec* d_lines = nullptr;
     const int rc = hc_found_to_lines_device(m_ctx, fastq_storage->m_readcount_single, fastq_storage->m_readcount_paired, &d_lines, &lines);
-    if (rc == HC_ERR_STATE && strstr(hc_last_error(), "not on the device")) {  // the host's matcher owns the script's errors
+    if (rc == HC_ERR_NOT_ON_DEVICE) {  // the host's matcher owns the script's errors
         if (device_route) *device_route = 0;
         construct_edges_from_reads(err_rate, min_overlap, find_flags, then_sort, n_found, n_lines);
         return;

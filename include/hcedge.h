@@ -54,8 +54,11 @@ typedef enum hc_status {
     HC_ERR_BAD_OVERLAP = -7, /* read index out of range, read1==read2, bad ord/ori      */
     HC_ERR_IO = -8,          /* file could not be opened / read / written               */
     HC_ERR_FORMAT = -9,      /* input the reference would exit(1)/assert on             */
-    HC_ERR_DATA = -10        /* an overlap touched a base/quality byte the reference
+    HC_ERR_DATA = -10,       /* an overlap touched a base/quality byte the reference
                                 asserts on (EdgeCalculator.cpp:29-30,61)                */
+    HC_ERR_NOT_ON_DEVICE = -11 /* hc_found_to_lines_device: an input the device does not decide (an assert of
+                                scripts/sfo2overlaps.py, ids / numbers outside its sort keys): NOT an error of the
+                                input — the caller takes the host's route, which raises what the script raises */
 } hc_status;
 
 /* ---- settings: the ProgramSettings fields the hot path reads (Types.h:19-67) ---- */
@@ -276,8 +279,8 @@ int hc_find_overlaps(hc_ctx* ctx, double err_rate, uint32_t min_overlap, uint32_
 int hc_found_to_overlaps(hc_ctx* ctx, const char* out_path, uint64_t num_singles, uint64_t num_pairs, uint64_t* n_lines);
 /* The same ingest with nothing leaving the device (round 6): the script's flip, sort, matching (scripts/sfo2overlaps.py:63-103,150-329) and
  * both its `uniq`s on the records where hc_find_overlaps left them; *d_lines = the overlaps file's lines as hc_line_rec (hcedge.h below) in
- * DEVICE memory, in file order — what hc_textblock_submit_lines takes.  Valid until the next call or hc_set_reads.  HC_ERR_STATE with "not on
- * the device" in hc_last_error where the device cannot decide (ids / numbers outside its sort keys, an assert of the script): the caller
+ * DEVICE memory, in file order — what hc_textblock_submit_lines takes.  Valid until the next call or hc_set_reads.  HC_ERR_NOT_ON_DEVICE where
+ * the device cannot decide (ids / numbers outside its sort keys, an assert of the script, thousands of lines for one pair of reads): the caller
  * takes hc_found_to_overlaps, which raises what the script raises.  Candidate generation itself: parity unpinned (rust-overlaps is absent). */
 /* SFO records from elsewhere — a rust-overlaps output the caller has parsed (8 columns: /root/reference/scripts/sfo2overlaps.py:35-36) — in
  * the place of the finder's: hc_found_to_overlaps / hc_found_to_lines_device then run the ingest on them.  After hc_set_reads. */
