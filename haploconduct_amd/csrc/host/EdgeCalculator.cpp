@@ -9,6 +9,8 @@
 #include <sched.h>
 #include <sys/stat.h>
 #include <sys/mman.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -26,6 +28,10 @@
 
 struct hc_ctx;
 int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs, std::string& text, uint64_t* n_lines);  // hc_api_finder.cpp
+namespace hc {
+bool sfo_text_to_records(const char* sfo_text, size_t sfo_bytes, std::vector<hc_sfo_rec>& recs);                 // Sfo2Overlaps.cpp
+std::string sfo_to_overlaps(const char* sfo_text, size_t sfo_bytes, long ns, long np, uint64_t& n_lines);  // Sfo2Overlaps.cpp
+}
 
 namespace hc {
 
@@ -1792,17 +1798,27 @@ void EdgeCalculator::construct_edges_from_store(double err_rate, uint32_t min_ov
     grower.join();
     check(grow_rc, "hc_textblock_reserve_rows");
     const double t1 = now_s();
-    const hc_line_rec* d_lines = nullptr;
-    const int rc = hc_found_to_lines_device(m_ctx, fastq_storage->m_readcount_single, fastq_storage->m_readcount_paired, &d_lines, &lines);
-    if (rc == HC_ERR_NOT_ON_DEVICE) {  // the host's matcher owns the script's errors
+    if (!run_stage_from_found(then_sort, &lines)) {  // the host's matcher owns the script's errors
         if (device_route) *device_route = 0;
         construct_edges_from_reads(err_rate, min_overlap, find_flags, then_sort, n_found, n_lines);
         return;
     }
-    check(rc, "hc_found_to_lines_device");
-    const double t2 = now_s();
     if (device_route) *device_route = 1;
     if (n_found) *n_found = found;
+    if (n_lines) *n_lines = lines;
+    if (getenv("HC_STAGE_TIMING"))
+        fprintf(stderr, "[hc stage] reads -> graph on the device: find %.3f s (%lu SFO records), ingest + construct %.3f s (%lu lines, none of them text)\n",
+                t1 - t0, (unsigned long)found, now_s() - t1, (unsigned long)lines);
+}
+
+bool EdgeCalculator::run_stage_from_found(bool then_sort, uint64_t* n_lines) {
+    const hc_line_rec* d_lines = nullptr;
+    uint64_t lines = 0;
+    const double t0 = now_s();
+    const int rc = hc_found_to_lines_device(m_ctx, fastq_storage->m_readcount_single, fastq_storage->m_readcount_paired, &d_lines, &lines);
+    if (rc == HC_ERR_NOT_ON_DEVICE) return false;
+    check(rc, "hc_found_to_lines_device");
+    if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] SFO ingest on the device: %.3f s (%lu lines)\n", now_s() - t0, (unsigned long)lines);
     if (n_lines) *n_lines = lines;
     struct Reset {
         EdgeCalculator* self;
@@ -1816,9 +1832,68 @@ void EdgeCalculator::construct_edges_from_store(double err_rate, uint32_t min_ov
     m_lines_override = lines ? d_lines : &none;  // (no lines at all: an empty file — the stage still runs, over nothing)
     m_lines_override_n = lines;
     run_stage(then_sort);
-    if (getenv("HC_STAGE_TIMING"))
-        fprintf(stderr, "[hc stage] reads -> graph on the device: find %.3f s (%lu SFO records), ingest %.3f s (%lu lines, none of them text), construct %.3f s\n",
-                t1 - t0, (unsigned long)found, t2 - t1, (unsigned long)lines, now_s() - t2);
+    return true;
+}
+
+void EdgeCalculator::construct_edges_from_sfo(const std::string& sfo_path, bool then_sort, uint64_t* n_records, uint64_t* n_lines, int* device_route) {
+    // the file mapped read-only (a pipe or another unmappable input is read whole)
+    const int fd = open(sfo_path.c_str(), O_RDONLY);
+    if (fd < 0) throw FatalError{HC_ERR_IO, "cannot open " + sfo_path};
+    struct stat stt;
+    std::string owned;
+    const char* text = nullptr;
+    size_t bytes = 0;
+    void* map = nullptr;
+    if (fstat(fd, &stt) == 0 && S_ISREG(stt.st_mode) && stt.st_size > 0) {
+        map = mmap(nullptr, (size_t)stt.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (map == MAP_FAILED) map = nullptr;
+    }
+    if (map) {
+        text = (const char*)map;
+        bytes = (size_t)stt.st_size;
+    } else {
+        char buf[1 << 16];
+        ssize_t k;
+        while ((k = read(fd, buf, sizeof buf)) > 0) owned.append(buf, (size_t)k);
+        text = owned.data();
+        bytes = owned.size();
+    }
+    struct Unmap {
+        void* p;
+        size_t n;
+        int fd;
+        ~Unmap() {
+            if (p) munmap(p, n);
+            close(fd);
+        }
+    } unmap{map, bytes, fd};
+    const long ns = (long)fastq_storage->m_readcount_single, np = (long)fastq_storage->m_readcount_paired;
+    uint64_t lines = 0;
+    {
+        std::vector<hc_sfo_rec> recs;
+        if (sfo_text_to_records(text, bytes, recs)) {
+            if (n_records) *n_records = recs.size();
+            check(hc_set_found_records(m_ctx, recs.data(), recs.size()), "hc_set_found_records");
+            std::vector<hc_sfo_rec>().swap(recs);
+            if (run_stage_from_found(then_sort, &lines)) {
+                if (device_route) *device_route = 1;
+                if (n_lines) *n_lines = lines;
+                return;
+            }
+        } else if (n_records) {
+            *n_records = 0;  // (not counted: the general path reads the file line by line)
+        }
+    }
+    // any other file, or an input the device does not decide: the host's ingest, its text in memory, the text blocks
+    auto out = std::make_shared<std::string>(sfo_to_overlaps(text, bytes, ns, np, lines));
+    if (device_route) *device_route = 0;
+    if (n_lines) *n_lines = lines;
+    struct Reset {
+        std::shared_ptr<const std::string>& p;
+        ~Reset() { p.reset(); }
+    } reset{m_text_override};
+    m_text_override = out;
+    run_stage(then_sort);
 }
 
 }  // namespace hc

@@ -95,6 +95,13 @@ public:
     // *device_route (may be null): whether the lines stayed on the device.
     void construct_edges_from_store(double err_rate, uint32_t min_overlap, uint32_t find_flags, bool then_sort, uint64_t* n_found,
                                     uint64_t* n_lines, int* device_route);
+    // The pipelines' own input to stage a — the SFO file `rust-overlaps` wrote (savage.py:664, polyte.py:514) — straight to the graph: what
+    // scripts/sfo2overlaps.py, original_overlaps.txt and the binary's text parser do in three steps.  A canonical file (single tabs, plain
+    // decimal numbers: what the tool writes) is read into records, which take the finder's place on the device (hc_set_found_records), and the
+    // rest is construct_edges_from_store's; any other file, and any input the device does not decide, goes through the host's ingest
+    // (hc_sfo2overlaps' code), its text in memory, and the text blocks — which raise what the script raises.  Pinned end to end: the ingest
+    // by the script's own outputs (tests/golden/sfo), the stage by the reference's construct_edges + sortEdges.
+    void construct_edges_from_sfo(const std::string& sfo_path, bool then_sort, uint64_t* n_records, uint64_t* n_lines, int* device_route);
     // src/EdgeCalculator.cpp:67-139 on arbitrary strings (used by SRBuilder::merge_self_overlap in the
     // reference): scored on the device through a two-read scratch store, finalised with the host libm.
     double overlap_score(const std::string& seq1, const std::string& seq2, const std::string& score1,
@@ -145,6 +152,7 @@ private:
     const hc_line_rec* m_lines_override = nullptr;       // construct_edges_from_store: the overlaps file's lines, parsed, in device memory
     uint64_t m_lines_override_n = 0;
     void score_device_lines(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc);  // ... sent through the text blocks
+    bool run_stage_from_found(bool then_sort, uint64_t* n_lines);  // the found records of m_ctx -> lines on the device -> run_stage; false: not the device's
     void score_host_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc);   // the file tokenised on host threads
     void score_device_parsed(OverlapsParser& parser, std::vector<Overlap>& rejected, ParseCounters& pc); // the file's text sent to the device
     void finalize_text_block(const IdIndex& ids, const hc_text_row* rows, uint64_t n_rows, BlockOut& out, unsigned threads = 0);

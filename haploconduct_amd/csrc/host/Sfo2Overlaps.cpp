@@ -418,6 +418,12 @@ bool parse_canonical_sfo(const char* text, size_t N, std::vector<hc_sfo_rec>& re
 
 }  // namespace
 
+// The records of a CANONICAL SFO text (what rust-overlaps / hc_host_write_sfo write), or false: the general path owns such a file.
+bool sfo_text_to_records(const char* sfo_text, size_t sfo_bytes, std::vector<hc_sfo_rec>& recs) {
+    if (getenv("HC_SFO_TEXT_GENERAL")) return false;  // (test knob: always the general path)
+    return parse_canonical_sfo(sfo_text, sfo_bytes, recs);
+}
+
 // Returns the output text; n_lines receives the number of lines.
 std::string sfo_to_overlaps(const char* sfo_text, size_t sfo_bytes, long ns, long np, uint64_t& n_lines) {
     if (!getenv("HC_SFO_TEXT_GENERAL")) {  // (test knob: always take the general path)

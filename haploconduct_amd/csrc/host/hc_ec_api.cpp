@@ -143,6 +143,11 @@ int hc_ec_construct_edges_sorted(hc_ec* ec) {
     return rc;
 }
 
+int hc_ec_construct_edges_from_sfo(hc_ec* ec, const char* sfo_path, int sorted, uint64_t* n_records, uint64_t* n_lines, int* device_route) {
+    if (!ec || !sfo_path) return set_last_error(HC_ERR_ARG, "hc_ec_construct_edges_from_sfo: null");
+    return guarded("construct_edges", [&] { ec->calc->construct_edges_from_sfo(sfo_path, sorted != 0, n_records, n_lines, device_route); });
+}
+
 int hc_ec_construct_edges_from_store(hc_ec* ec, double err_rate, uint32_t min_overlap, uint32_t find_flags, int sorted, uint64_t* n_found,
                                      uint64_t* n_lines, int* device_route) {
     if (!ec) return set_last_error(HC_ERR_ARG, "hc_ec_construct_edges_from_store: null");

@@ -50,6 +50,7 @@ _sig = {
     "hc_ec_construct_edges": (C.c_int, [_vp]),
     "hc_ec_construct_edges_sorted": (C.c_int, [_vp]),
     "hc_ec_construct_edges_from_reads": (C.c_int, [_vp, C.c_double, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hc_ec_construct_edges_from_sfo": (C.c_int, [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "hc_ec_construct_edges_from_store": (C.c_int, [_vp, C.c_double, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                                     C.POINTER(C.c_int)]),
     "hc_ec_device_count": (C.c_uint32, [_vp]),
@@ -302,6 +303,14 @@ class EdgeCalculatorStage:
         N.check(N.lib.hc_ec_construct_edges_from_reads(self._h, float(err_rate), int(min_overlap), flags, 1 if sorted_order else 0,
                                                        C.byref(nf), C.byref(nl)), "hc_ec_construct_edges_from_reads")
         return nf.value, nl.value
+
+    def construct_edges_from_sfo(self, sfo_path, sorted_order=True):
+        """hc_ec_construct_edges_from_sfo: the SFO file rust-overlaps wrote -> graph (scripts/sfo2overlaps.py + the overlaps file + the text
+        parser in one call; nothing but device memory in between for a canonical file).  Returns (SFO records, overlap lines, on_device)."""
+        nr, nl, dr = C.c_uint64(), C.c_uint64(), C.c_int()
+        N.check(N.lib.hc_ec_construct_edges_from_sfo(self._h, _b(sfo_path), 1 if sorted_order else 0, C.byref(nr), C.byref(nl), C.byref(dr)),
+                "hc_ec_construct_edges_from_sfo")
+        return nr.value, nl.value, bool(dr.value)
 
     def construct_edges_from_store(self, err_rate, min_overlap, reversals=True, inclusions=True, sorted_order=True):
         """hc_ec_construct_edges_from_store: the same with nothing but device memory between the reads and the graph (no text is written,

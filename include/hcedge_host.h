@@ -74,6 +74,16 @@ int hc_ec_construct_edges_from_reads(hc_ec* ec, double err_rate, uint32_t min_ov
  * Candidate generation (hc_find_overlaps) stands in for rust-overlaps, which is not in the reference tree: parity unpinned there. */
 int hc_ec_construct_edges_from_store(hc_ec* ec, double err_rate, uint32_t min_overlap, uint32_t find_flags, int sorted, uint64_t* n_found,
                                      uint64_t* n_lines, int* device_route);
+/* The pipelines' own input — the SFO file `rust-overlaps` wrote (savage.py:664, polyte.py:514, 542) — straight to the graph: what
+ * scripts/sfo2overlaps.py (--in sfo_path --out original_overlaps.txt --num_singles --num_pairs, savage.py:672), the overlaps file and the
+ * binary's own text parser (src/EdgeCalculator.cpp:561-604) do between them.  A canonical file (eight fields, single tabs, plain decimal
+ * numbers: what the tool writes) becomes records, which take the finder's place on the device (hc_set_found_records); the ingest and the stage
+ * are hc_ec_construct_edges_from_store's: no 13-column text is written, copied or parsed.  Any other file, and any input the device does not
+ * decide (HC_ERR_NOT_ON_DEVICE), goes through hc_sfo2overlaps' code with its text kept in memory — every error is the script's.  Same graph,
+ * counters and nonedge_overlaps.txt as hc_sfo2overlaps + hc_ec_construct_edges[_sorted] on the file it writes.  Pinned end to end (the ingest by
+ * the script's own outputs, the stage by the reference's own code); hc_paths.overlaps_file is not read.
+ * *n_records: SFO lines read (0 on the general path), *n_lines: overlap lines, *device_route: 1 = the lines stayed on the device. */
+int hc_ec_construct_edges_from_sfo(hc_ec* ec, const char* sfo_path, int sorted, uint64_t* n_records, uint64_t* n_lines, int* device_route);
 /* number of device contexts the stage scores on (hc_settings.device_mask) */
 uint32_t hc_ec_device_count(hc_ec* ec);
 int hc_ec_get_counters(hc_ec* ec, hc_ec_counters* out);

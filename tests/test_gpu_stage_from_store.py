@@ -289,3 +289,70 @@ def test_thousands_of_lines_for_one_pair_of_reads_go_to_the_host(tmp_path):
         with pytest.raises(Exception, match="not on the device"):
             sc.found_to_lines(0, 3)
         assert sc.found_to_overlaps(str(tmp_path / "x.txt"), 0, 3) >= 0  # the host's matcher takes it
+
+
+def _sfo_routes(tmp_path, st, fq, reads, n_single, n_pairs, err, t, tag, mangle=None):
+    """The SFO file (what rust-overlaps writes) -> graph in one call, against scripts/sfo2overlaps.py's port + the overlaps file + the stage."""
+    d = str(tmp_path) + "/"
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        recs = sc.find_overlaps(err, t)
+    sfo = d + tag + ".sfo"
+    host.write_sfo(sfo, recs)
+    if mangle:
+        open(sfo, "w").write(mangle(open(sfo).read()))
+    n_lines = host.sfo2overlaps(sfo, d + tag + "_overlaps.txt", n_single, n_pairs)
+    out = {}
+    for route in ("sfo", "file"):
+        o = tmp_path / f"{tag}_{route}"
+        o.mkdir()
+        with host.EdgeCalculatorStage(st, output_dir=str(o) + "/", **(fq if route == "sfo" else dict(fq, overlaps=d + tag + "_overlaps.txt"))) as ec:
+            if route == "sfo":
+                n_rec, nl, on_device = ec.construct_edges_from_sfo(sfo)
+                assert nl == n_lines and on_device == (mangle is None), (nl, n_lines, on_device)
+                assert n_rec == (recs.size if mangle is None else 0)
+            else:
+                ec.construct_edges_sorted()
+            out[route] = (ec.edges(), ec.in_lists(), ec.inclusions(), ec.counters(), (o / "nonedge_overlaps.txt").read_bytes())
+    a, b = out["sfo"], out["file"]
+    assert a[0].size == b[0].size and a[0].tobytes() == b[0].tobytes(), f"{tag}: the graphs differ"
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])
+    for k in COUNTERS:
+        if k in a[3]:
+            assert a[3][k] == b[3][k], (tag, k)
+    assert a[4] == b[4]
+    return n_lines, a
+
+
+def test_sfo_file_to_graph_savage_example(tmp_path):
+    """hc_ec_construct_edges_from_sfo on the SAVAGE example's reads: the SFO file in, the sorted graph out — against the three-step route the
+    pipeline runs (savage.py:664-717: the SFO file -> scripts/sfo2overlaps.py -> original_overlaps.txt -> the binary), each step of which is
+    pinned against the reference's own code."""
+    fq = dict(singles=gunzip_to("savage_singles.fastq", str(tmp_path / "singles.fastq")), paired1=gunzip_to("savage_paired1.fastq", str(tmp_path / "paired1.fastq")),
+              paired2=gunzip_to("savage_paired2.fastq", str(tmp_path / "paired2.fastq")))
+    f = host.Fastq(**fq)
+    reads = f.readset()
+    st = hc.Settings(edge_threshold=0.97, min_overlap_len=200, n_threads=8)
+    n_lines, a = _sfo_routes(tmp_path, st, fq, reads, f.n_single, f.n_paired, 0.02, 100, "savage")
+    assert n_lines > 20000 and a[0].size > 2000
+    # a file that is not canonical (blanks for tabs: the script splits on any whitespace): the host's ingest takes it, same graph
+    n2, b = _sfo_routes(tmp_path, st, fq, reads, f.n_single, f.n_paired, 0.02, 100, "savage_blanks", mangle=lambda s: s.replace("\t", "  "))
+    assert n2 == n_lines and b[0].tobytes() == a[0].tobytes() and b[4] == a[4]
+
+
+def test_sfo_file_to_graph_mixed_and_errors(tmp_path):
+    kw = dict(n_single=300, n_pair=400, glen=2200, lo=100, hi=200, err=0.01)
+    reads = make_reads(331, **kw)
+    fq = _write(reads, tmp_path, 300, 400)
+    st = hc.Settings(edge_threshold=0.9, ov_threshold=0.5, min_overlap_len=120, n_threads=8, max_overlaps=9000)
+    n_lines, a = _sfo_routes(tmp_path, st, fq, reads, 300, 400, 0.03, 60, "mixed")
+    assert n_lines > 2000
+    # what the script raises is raised: a line with seven fields (assert len(sfo_line) == 8, scripts/sfo2overlaps.py:35)
+    bad = str(tmp_path / "bad.sfo")
+    open(bad, "w").write("0\t1\tN\t5\t5\t60\t60\n")
+    with host.EdgeCalculatorStage(st, output_dir=str(tmp_path) + "/", **fq) as ec:
+        with pytest.raises(Exception, match="8 fields"):
+            ec.construct_edges_from_sfo(bad)
+    with host.EdgeCalculatorStage(st, output_dir=str(tmp_path) + "/", **fq) as ec:
+        with pytest.raises(Exception, match="cannot open"):
+            ec.construct_edges_from_sfo(str(tmp_path / "missing.sfo"))
