@@ -29,7 +29,7 @@
 struct hc_ctx;
 int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs, std::string& text, uint64_t* n_lines);  // hc_api_finder.cpp
 namespace hc {
-bool sfo_text_to_records(const char* sfo_text, size_t sfo_bytes, std::vector<hc_sfo_rec>& recs);                 // Sfo2Overlaps.cpp
+bool sfo_text_to_records(const char* sfo_text, size_t sfo_bytes, std::vector<hc_sfo_rec, DefaultInitAllocator<hc_sfo_rec>>& recs);  // Sfo2Overlaps.cpp
 std::string sfo_to_overlaps(const char* sfo_text, size_t sfo_bytes, long ns, long np, uint64_t& n_lines);  // Sfo2Overlaps.cpp
 }
 
@@ -1870,11 +1870,18 @@ void EdgeCalculator::construct_edges_from_sfo(const std::string& sfo_path, bool 
     const long ns = (long)fastq_storage->m_readcount_single, np = (long)fastq_storage->m_readcount_paired;
     uint64_t lines = 0;
     {
-        std::vector<hc_sfo_rec> recs;
+        std::vector<hc_sfo_rec, DefaultInitAllocator<hc_sfo_rec>> recs;
+        const double tp0 = now_s();
         if (sfo_text_to_records(text, bytes, recs)) {
             if (n_records) *n_records = recs.size();
+            const double tp1 = now_s();
             check(hc_set_found_records(m_ctx, recs.data(), recs.size()), "hc_set_found_records");
-            std::vector<hc_sfo_rec>().swap(recs);
+            if (getenv("HC_STAGE_TIMING"))
+                fprintf(stderr, "[hc stage] SFO file: %zu bytes -> %zu records in %.3f s, to the device in %.3f s\n", bytes, recs.size(), tp1 - tp0, now_s() - tp1);
+            {  // 2 GB at config 3's size: given back behind the caller's back
+                auto spent = std::make_shared<std::vector<hc_sfo_rec, DefaultInitAllocator<hc_sfo_rec>>>(std::move(recs));
+                defer_cleanup([spent]() mutable { spent.reset(); });
+            }
             if (run_stage_from_found(then_sort, &lines)) {
                 if (device_route) *device_route = 1;
                 if (n_lines) *n_lines = lines;
