@@ -148,6 +148,7 @@ extern "C" int hc_cli_main(int argc, char** argv, void (*on_done)(int code, void
     B("verbose", 'v', &ps.verbose, "output additional information during assembly");
     NUM("device", 0, ps.device, "[hc-edgecalc] HIP device ordinal");
     NUM("device_mask", 0, ps.device_mask, "[hc-edgecalc] bit d set: score blocks on HIP device d too (0 = --device alone)");
+    S("sfo", 0, &ps.sfo_file, "[hc-edgecalc] the SFO file of rust-overlaps IN PLACE of --overlaps: scripts/sfo2overlaps.py's ingest runs inside (on the device)");
 
     auto usage = [&]() {
         puts("Program options:");
@@ -212,7 +213,12 @@ extern "C" int hc_cli_main(int argc, char** argv, void (*on_done)(int code, void
         usage();
         return done(1);
     }
-    if (!count("overlaps")) {  // :128-132
+    if (count("overlaps") && count("sfo")) {
+        fputs("--overlaps and --sfo are exclusive options, use one.\n\n", stderr);
+        usage();
+        return done(1);
+    }
+    if (!count("overlaps") && !count("sfo")) {  // :128-132
         fputs("No overlaps file provided.\n\n", stderr);
         usage();
         return done(1);
@@ -239,7 +245,7 @@ extern "C" int hc_cli_main(int argc, char** argv, void (*on_done)(int code, void
             time_t raw;
             time(&raw);
             fprintf(lf, "%s\n\nInput:\n%s\n%s\n%s\n%s\n\n", ctime(&raw), ps.singles_file.c_str(), ps.paired1_file.c_str(),
-                    ps.paired2_file.c_str(), ps.overlaps_file.c_str());
+                    ps.paired2_file.c_str(), (ps.overlaps_file.empty() ? ps.sfo_file : ps.overlaps_file).c_str());
             fprintf(lf, "Output directory: %s\nMaximum number of overlaps: %lu\nThreads: %u\n", ps.output_dir.c_str(),
                     ps.max_overlaps, ps.n_threads);
             fprintf(lf, "Minimal overlap percentage: %u\nMinimal overlap length: %u\nEdge threshold: %g\nOverlap threshold: %g\n",
@@ -293,7 +299,16 @@ extern "C" int hc_cli_main(int argc, char** argv, void (*on_done)(int code, void
             printf("[hc-edgecalc] HIP runtime start %.3f s (%d device(s)), EdgeCalculator (contexts, read store, text blocks) %.3f s\n", t_hip, n_devices,
                    t_ctor);
         t0 = now_s();
-        calc.construct_edges();  // :281
+        if (!ps.sfo_file.empty()) {  // savage.py:664-717's three steps in one: the SFO file -> the script's ingest -> construct_edges
+            uint64_t n_rec = 0, n_lines = 0;
+            int on_device = 0;
+            calc.construct_edges_from_sfo(ps.sfo_file, false, &n_rec, &n_lines, &on_device);
+            if (ps.verbose)
+                printf("[hc-edgecalc] --sfo: %lu SFO records -> %lu overlap lines (%s)\n", (unsigned long)n_rec, (unsigned long)n_lines,
+                       on_device ? "ingest on the device" : "ingest on the host");
+        } else {
+            calc.construct_edges();  // :281
+        }
         const double dt = now_s() - t0;
         if (graph->getEdgeCount() == 0) {  // :284-291
             if (ps.verbose) puts("There were no edges constructed, so there is nothing to be done.");

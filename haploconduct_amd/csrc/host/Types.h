@@ -57,6 +57,7 @@ struct ProgramSettings {
     bool careful = true;
     int device = 0;  // build-owned addition: HIP device ordinal
     unsigned int device_mask = 0;  // build-owned addition: bit d = the stage scores blocks on device d too (0 = `device` alone)
+    std::string sfo_file;          // build-owned addition (hc-edgecalc --sfo): the SFO file of rust-overlaps in the overlaps file's place
 };
 
 // src/Types.h:99-102: strtoul with base auto-detection ("0x..", leading 0 = octal, junk = 0)

@@ -358,3 +358,37 @@ def test_sfo_file_to_graph_mixed_and_errors(tmp_path):
     with host.EdgeCalculatorStage(st, output_dir=str(tmp_path) + "/", **fq) as ec:
         with pytest.raises(Exception, match="cannot open"):
             ec.construct_edges_from_sfo(str(tmp_path / "missing.sfo"))
+
+
+def test_hc_edgecalc_sfo_flag_equals_the_two_programs(tmp_path):
+    """The process boundary: `hc-edgecalc --sfo sfoverlaps.out <the pipeline's other arguments>` against scripts/sfo2overlaps.py's port followed
+    by `hc-edgecalc --overlaps original_overlaps.txt ...` (savage.py:664-717) on the SAVAGE example's reads: the four output files, byte for byte;
+    --overlaps and --sfo together are refused."""
+    import subprocess
+
+    fq = dict(singles=gunzip_to("savage_singles.fastq", str(tmp_path / "singles.fastq")), paired1=gunzip_to("savage_paired1.fastq", str(tmp_path / "paired1.fastq")),
+              paired2=gunzip_to("savage_paired2.fastq", str(tmp_path / "paired2.fastq")))
+    f = host.Fastq(**fq)
+    reads = f.readset()
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        recs = sc.find_overlaps(0.02, 100)
+    d = str(tmp_path) + "/"
+    host.write_sfo(d + "sfoverlaps.out", recs)
+    host.sfo2overlaps(d + "sfoverlaps.out", d + "original_overlaps.txt", f.n_single, f.n_paired)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "haploconduct_amd", "csrc", "hc-edgecalc")
+    common = ["--singles", fq["singles"], "--paired1", fq["paired1"], "--paired2", fq["paired2"], "--threads", "8", "--edge_threshold", "0.97",
+              "--min_overlap_len", "200", "--first_it", "true", "--original_readcount", str(reads.n_reads), "--verbose", "true"]
+    outs = {}
+    for name, src in (("sfo", ["--sfo", d + "sfoverlaps.out"]), ("overlaps", ["--overlaps", d + "original_overlaps.txt"])):
+        o = d + name + "/"
+        os.mkdir(o)
+        r = subprocess.run([exe] + common + src + ["--output", o], capture_output=True, text=True, timeout=600, cwd=o)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs[name] = {fn: open(o + fn, "rb").read() for fn in ("edges.tsv", "edges_sorted.tsv", "edgecalc_stats.txt")}
+        outs[name]["nonedge_overlaps.txt"] = open(o + "nonedge_overlaps.txt", "rb").read()  # (written in the working directory, src/EdgeCalculator.cpp:566,654)
+        if name == "sfo":
+            assert "ingest on the device" in r.stdout
+    assert outs["sfo"] == outs["overlaps"] and len(outs["sfo"]["edges_sorted.tsv"]) > 10000
+    r = subprocess.run([exe] + common + ["--sfo", d + "sfoverlaps.out", "--overlaps", d + "original_overlaps.txt"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "exclusive" in r.stderr
