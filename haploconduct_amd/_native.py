@@ -80,6 +80,7 @@ _sig = {
     "hc_find_overlaps": (C.c_int, [_vp, C.c_double, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_found_to_overlaps": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_set_found_records": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "hc_set_found_from_sfo_text": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hc_found_to_lines_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "hc_found_lines_fetch": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "hc_score_pack_device": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, _vp]),

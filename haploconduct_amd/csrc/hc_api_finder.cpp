@@ -16,6 +16,7 @@
 #include "hc_hostcopy.h"
 #include "hc_prims.h"
 #include "hc_sfo_device.h"
+#include "hc_text.h"
 #include "host/NumaBind.h"
 #include "host/Types.h"
 
@@ -691,6 +692,137 @@ int hc_set_found_records(hc_ctx* c, const hc_sfo_rec* recs, uint64_t n) {
     c->found_min = 0;
     c->found_flags = 0;
     c->found_valid = true;
+    return HC_OK;
+}
+
+// The SFO FILE's text in the finder's place, read on the device (round 6): 64 MiB chunks of the text (cut behind a newline) go to the device as
+// they are — two buffers, the copy of chunk k + 1 beside the kernels of chunk k — and every chunk's lines (the overlaps file's own line-start
+// kernels, hc_text_kernels.hip) are read by one lane each (sfo_parse_text_kernel) into the context's found records at the place a chain of
+// line counters assigns.  A canonical file only — eight fields, single tabs, plain decimal numbers: what rust-overlaps writes; anything else:
+// HC_ERR_NOT_ON_DEVICE, and the host's general path (hc_sfo2overlaps' code) takes the file and owns its errors.
+int hc_set_found_from_sfo_text(hc_ctx* c, const char* text, uint64_t n_bytes, uint64_t* n_records) {
+    if (!c || (n_bytes && !text)) return fail(HC_ERR_ARG, "hc_set_found_from_sfo_text: null argument");
+    if (!c->have_reads) return fail(HC_ERR_STATE, "hc_set_found_from_sfo_text: hc_set_reads has not been called");
+    if (n_records) *n_records = 0;
+    HC_HIP(hipSetDevice(c->device));
+    c->n_found = 0;
+    c->found_valid = false;
+    // how many lines (= records): newlines counted on the host's threads, a last line without one counts too
+    unsigned T = std::thread::hardware_concurrency();
+    T = T == 0 ? 1 : (T > 32 ? 32 : T);
+    if (n_bytes / (8u << 20) + 1 < T) T = (unsigned)(n_bytes / (8u << 20) + 1);
+    std::vector<uint64_t> part(T, 0);
+    {
+        std::vector<std::thread> th;
+        auto body = [&](unsigned t) {
+            const char* b = text + n_bytes * t / T;
+            const char* e = text + n_bytes * (t + 1) / T;
+            uint64_t k = 0;
+            while (b < e) {
+                const char* nl = (const char*)memchr(b, '\n', (size_t)(e - b));
+                if (!nl) break;
+                k++;
+                b = nl + 1;
+            }
+            part[t] = k;
+        };
+        for (unsigned t = 1; t < T; t++) th.emplace_back(body, t);
+        body(0);
+        for (auto& x : th) x.join();
+    }
+    uint64_t lines = 0;
+    for (uint64_t k : part) lines += k;
+    if (n_bytes && text[n_bytes - 1] != '\n') lines++;
+    if (lines >= 0x7FFFFFF0ull) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (2^31 lines and more)");
+    if (lines == 0) {
+        c->found_err = -1;
+        c->found_min = 0;
+        c->found_flags = 0;
+        c->found_valid = true;
+        return HC_OK;
+    }
+    if (!c->d_found || c->found_cap < lines) {
+        if (c->d_found) (void)hipFree(c->d_found);
+        c->d_found = nullptr;
+        c->found_cap = 0;
+        HC_HIP(hipMalloc((void**)&c->d_found, lines * sizeof(hc_sfo_rec)));
+        c->found_cap = lines;
+    }
+    const uint64_t C = 64ull << 20;            // bytes per chunk
+    const uint32_t max_lines = (uint32_t)(C / 16 + 2);  // (a canonical line has 16 bytes and more; a chunk with more lines is not canonical: overflow -> status)
+    const uint32_t n_tiles = (uint32_t)(C / 4096 + 2);
+    const uint64_t n_chunks_max = n_bytes / (C / 2) + 2;
+    struct Bufs {
+        char* text[2] = {nullptr, nullptr};
+        uint32_t *tile_cnt[2] = {nullptr, nullptr}, *tile_off[2] = {nullptr, nullptr}, *line_start[2] = {nullptr, nullptr};
+        unsigned long long *counters[2] = {nullptr, nullptr}, *chain = nullptr, *status = nullptr;
+        hipEvent_t copied[2] = {nullptr, nullptr}, parsed[2] = {nullptr, nullptr};
+        hipStream_t copy = nullptr;
+        ~Bufs() {
+            for (int k = 0; k < 2; k++) {
+                if (text[k]) (void)hipFree(text[k]);
+                if (tile_cnt[k]) (void)hipFree(tile_cnt[k]);
+                if (tile_off[k]) (void)hipFree(tile_off[k]);
+                if (line_start[k]) (void)hipFree(line_start[k]);
+                if (counters[k]) (void)hipFree(counters[k]);
+                if (copied[k]) (void)hipEventDestroy(copied[k]);
+                if (parsed[k]) (void)hipEventDestroy(parsed[k]);
+            }
+            if (chain) (void)hipFree(chain);
+            if (status) (void)hipFree(status);
+            if (copy) (void)hipStreamDestroy(copy);
+        }
+    } b;
+    for (int k = 0; k < 2; k++) {
+        HC_HIP(hipMalloc((void**)&b.text[k], C + 64));
+        HC_HIP(hipMalloc((void**)&b.tile_cnt[k], (size_t)n_tiles * 4));
+        HC_HIP(hipMalloc((void**)&b.tile_off[k], (size_t)n_tiles * 4));
+        HC_HIP(hipMalloc((void**)&b.line_start[k], ((size_t)max_lines + 2) * 4));
+        HC_HIP(hipMalloc((void**)&b.counters[k], hc::kTextCounters * sizeof(unsigned long long)));
+        HC_HIP(hipEventCreateWithFlags(&b.copied[k], hipEventDisableTiming));
+        HC_HIP(hipEventCreateWithFlags(&b.parsed[k], hipEventDisableTiming));
+    }
+    HC_HIP(hipMalloc((void**)&b.chain, (n_chunks_max + 1) * sizeof(unsigned long long)));
+    HC_HIP(hipMalloc((void**)&b.status, sizeof(unsigned long long)));
+    HC_HIP(hipStreamCreateWithFlags(&b.copy, hipStreamNonBlocking));
+    hipStream_t st = c->stream;
+    HC_HIP(hipMemsetAsync(b.chain, 0, sizeof(unsigned long long), st));
+    HC_HIP(hipMemsetAsync(b.status, 0, sizeof(unsigned long long), st));
+    HC_HIP(hipStreamSynchronize(st));
+    uint64_t pos = 0, k = 0;
+    while (pos < n_bytes) {
+        uint64_t len = n_bytes - pos < C ? n_bytes - pos : C;
+        if (pos + len < n_bytes) {  // cut behind the last newline of the stretch
+            const void* nl = memrchr(text + pos, '\n', (size_t)len);
+            if (!nl) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (a line of 64 MiB and more)");
+            len = (uint64_t)((const char*)nl - (text + pos)) + 1;
+        }
+        if (k >= n_chunks_max) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (more chunks than planned)");
+        const int j = (int)(k & 1);
+        if (k >= 2) HC_HIP(hipStreamWaitEvent(b.copy, b.parsed[j], 0));  // the buffer's previous chunk has been read
+        HC_HIP(hipMemcpyAsync(b.text[j], text + pos, len, hipMemcpyHostToDevice, b.copy));
+        HC_HIP(hipEventRecord(b.copied[j], b.copy));
+        HC_HIP(hipStreamWaitEvent(st, b.copied[j], 0));
+        HC_HIP(hc::launch_text_count(b.text[j], len, b.tile_cnt[j], st));
+        HC_HIP(hc::launch_text_scan(b.text[j], len, b.tile_cnt[j], b.tile_off[j], max_lines, b.line_start[j], b.counters[j], b.chain + k, b.chain + k + 1, st));
+        HC_HIP(hc::launch_text_line_starts(b.text[j], len, b.tile_off[j], max_lines, b.line_start[j], st));
+        HC_HIP(hc::sfo_parse_text(b.text[j], b.line_start[j], max_lines, b.counters[j], b.chain + k, c->d_found, lines, b.status, st));
+        HC_HIP(hipEventRecord(b.parsed[j], st));
+        pos += len;
+        k++;
+    }
+    unsigned long long status = 0, total = 0;
+    HC_HIP(hipMemcpyAsync(&status, b.status, sizeof status, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipMemcpyAsync(&total, b.chain + k, sizeof total, hipMemcpyDeviceToHost, st));
+    HC_HIP(hipStreamSynchronize(st));
+    HC_HIP(hipStreamSynchronize(b.copy));
+    if (status || total != lines) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (a line that is not canonical)");
+    c->n_found = lines;
+    c->found_err = -1;
+    c->found_min = 0;
+    c->found_flags = 0;
+    c->found_valid = true;
+    if (n_records) *n_records = lines;
     return HC_OK;
 }
 

@@ -28,6 +28,10 @@ hipError_t sfo_gather_kept(const SfoFlipped* sorted, const uint32_t* idx, uint64
 
 // The script's matching on the device (round 6; hc_sfo_kernels.hip): the overlap lines as records, in the script's order.
 // kSfoStatusMatch (4) in *status: an assert / division by zero of the script's matching — the caller lets the host's matcher raise it.
+// the SFO file's text -> records (hc_sfo_kernels.hip): one lane per line of a chunk whose line starts / count the overlaps file's kernels left
+// (hc_text.h); bit 8 of *status: a line that is not canonical
+hipError_t sfo_parse_text(const char* text, const uint32_t* line_start, uint32_t max_lines, const unsigned long long* counters,
+                          const unsigned long long* lines_before, hc_sfo_rec* out, uint64_t out_cap, unsigned long long* status, hipStream_t s);
 hipError_t sfo_group_starts(const SfoFlipped* sorted, const uint32_t* idx, uint64_t m, uint64_t ns, uint64_t np, uint8_t* start, hipStream_t s);
 hipError_t sfo_match_groups(bool write, const SfoFlipped* sorted, const uint32_t* idx, const uint32_t* starts, uint64_t G, uint64_t ns, uint64_t np,
                             uint32_t* emit, const uint32_t* off, hc_line_rec* lines, unsigned long long* status, hipStream_t s);

@@ -3,6 +3,7 @@
 // OHA OHB OLA OLB K as decimal texts, a tab ending the shorter one below '-' and every digit.
 #include "hc_fno_device.h"
 #include "hc_sfo_device.h"
+#include "hc_text.h"
 
 namespace hc {
 namespace {
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(kBlock) void sfo_gather_kept_kernel(const SfoFlippe
 // overlap LINES as records (hc_line_rec: what the stage's parser would read from the script's text) in the order the script writes them.
 // Asserts and the division by zero of the script are reported through `status` (the caller falls back to the host's matcher, which
 // raises what the script raises).
+enum : unsigned long long { kSfoStatusText = 8 };   // a line of the SFO text that is not canonical (or more lines than counted): the host's general path
 enum : unsigned long long { kSfoStatusMatch = 4 };  // an assert of the script's matching (or its division by zero), or a group beyond kSfoMaxGroup
 constexpr uint32_t kSfoMaxGroup = 2048;             // lines of one pair of reads a lane matches (every two of them: 2 * 10^6 pairs)
 
@@ -369,7 +371,97 @@ __global__ __launch_bounds__(kBlock) void sfo_gather_lines_kernel(const hc_line_
 }
 }  // namespace
 
+// ---- the SFO file's text read on the device (round 6) -----------------------------------------------------------------------------
+// One lane per line of a chunk of the file (line starts: the overlaps file's own kernels, hc_text_kernels.hip): a CANONICAL line — what
+// rust-overlaps and hc_host_write_sfo write: eight fields, single tabs, "0" or [1-9][0-9]* (one '-' allowed in front of the two overhangs),
+// `N` or `I` — becomes an hc_sfo_rec at out[*lines_before + i]; any other line raises `status` and the whole file goes to the host's general
+// path (host/Sfo2Overlaps.cpp: parse_canonical_sfo is this kernel's twin on the host threads, same acceptance rules).
+struct SfoTextCursor {
+    const char* text;
+    uint32_t at, e;
+    uint32_t w;
+    __device__ __forceinline__ void load() { w = *(const uint32_t*)(text + (at & ~3u)); }
+    __device__ __forceinline__ uint32_t cur() const { return (w >> (8u * (at & 3u))) & 0xFFu; }
+    __device__ __forceinline__ void next() {
+        at++;
+        if ((at & 3u) == 0) w = *(const uint32_t*)(text + at);
+    }
+};
+// one canonical number followed by `end` ('\t', or 0 = the line's end); lo <= value <= hi
+__device__ __forceinline__ bool sfo_take_int(SfoTextCursor& c, bool allow_negative, bool last, long long lo, long long hi, long long& v) {
+    bool neg = false;
+    if (c.at < c.e && c.cur() == '-') {
+        if (!allow_negative) return false;
+        neg = true;
+        c.next();
+    }
+    const uint32_t b = c.at;
+    const uint32_t first = c.at < c.e ? c.cur() : 0u;
+    unsigned long long u = 0;
+    while (c.at < c.e && (c.cur() - '0') <= 9u && c.at - b < 11u) {
+        u = u * 10ull + (unsigned long long)(c.cur() - '0');
+        c.next();
+    }
+    const uint32_t d = c.at - b;
+    if (d == 0 || d > 10 || (first == '0' && (d > 1 || neg))) return false;  // no leading zeros, no "-0"
+    v = neg ? -(long long)u : (long long)u;
+    if (v < lo || v > hi) return false;
+    if (last) return c.at == c.e;
+    if (c.at >= c.e || c.cur() != '\t') return false;
+    c.next();
+    return true;
+}
+
+__global__ __launch_bounds__(kBlock) void sfo_parse_text_kernel(const char* __restrict__ text, const uint32_t* __restrict__ line_start,
+                                                                const unsigned long long* __restrict__ counters /* hc_text.h */,
+                                                                const unsigned long long* __restrict__ lines_before, hc_sfo_rec* __restrict__ out,
+                                                                uint64_t out_cap, unsigned long long* __restrict__ status) {
+    if (counters[kTextOverflow]) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, (unsigned long long)kSfoStatusText);
+        return;
+    }
+    const uint32_t n = (uint32_t)counters[kTextLines];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t at_out = *lines_before + i;
+    SfoTextCursor c{text, line_start[i], line_start[i + 1] - 1u, 0u};
+    c.load();
+    long long a, b, oha, ohb, ola, olb, k;
+    bool good = sfo_take_int(c, false, false, 0, 0xFFFFFFFFll, a) && sfo_take_int(c, false, false, 0, 0xFFFFFFFFll, b);
+    uint32_t ori = 0;
+    if (good) {
+        ori = c.at < c.e ? c.cur() : 0u;
+        good = ori == 'N' || ori == 'I';
+        c.next();
+        good = good && c.at < c.e && c.cur() == '\t';
+        c.next();
+    }
+    good = good && sfo_take_int(c, true, false, -2147483647ll, 2147483647ll, oha) && sfo_take_int(c, true, false, -2147483647ll, 2147483647ll, ohb) &&
+           sfo_take_int(c, false, false, 0, 0xFFFFFFFFll, ola) && sfo_take_int(c, false, false, 0, 0xFFFFFFFFll, olb) &&
+           sfo_take_int(c, false, true, 0, 0xFFFFFFFFll, k);
+    if (!good || at_out >= out_cap) {
+        atomicOr(status, (unsigned long long)kSfoStatusText);
+        return;
+    }
+    hc_sfo_rec r;
+    r.idA = (uint32_t)a;
+    r.idB = (uint32_t)b;
+    r.OHA = (int32_t)oha;
+    r.OHB = (int32_t)ohb;
+    r.OLA = (uint32_t)ola;
+    r.OLB = (uint32_t)olb;
+    r.K = (uint32_t)k;
+    r.inverted = ori == 'I' ? 1u : 0u;
+    out[at_out] = r;
+}
+
 #define HC_SFO_GRID(n) dim3((unsigned)(((n) + kBlock - 1) / kBlock)), dim3(kBlock)
+hipError_t sfo_parse_text(const char* text, const uint32_t* line_start, uint32_t max_lines, const unsigned long long* counters,
+                          const unsigned long long* lines_before, hc_sfo_rec* out, uint64_t out_cap, unsigned long long* status, hipStream_t s) {
+    if (!max_lines) return hipSuccess;
+    hipLaunchKernelGGL(sfo_parse_text_kernel, HC_SFO_GRID(max_lines), 0, s, text, line_start, counters, lines_before, out, out_cap, status);
+    return hipGetLastError();
+}
 hipError_t sfo_group_starts(const SfoFlipped* sorted, const uint32_t* idx, uint64_t m, uint64_t ns, uint64_t np, uint8_t* start, hipStream_t s) {
     if (!m) return hipSuccess;
     hipLaunchKernelGGL(sfo_group_starts_kernel, HC_SFO_GRID(m), 0, s, sorted, idx, m, ns, np, start);

@@ -1870,18 +1870,27 @@ void EdgeCalculator::construct_edges_from_sfo(const std::string& sfo_path, bool 
     const long ns = (long)fastq_storage->m_readcount_single, np = (long)fastq_storage->m_readcount_paired;
     uint64_t lines = 0;
     {
-        std::vector<hc_sfo_rec, DefaultInitAllocator<hc_sfo_rec>> recs;
+        // a canonical file (what the tool writes): its text is read on the device, 64 MiB at a time (hc_set_found_from_sfo_text; HC_SFO_PARSE=host:
+        // on the host's threads, round 6's first form, kept as a route), and the records take the finder's place
         const double tp0 = now_s();
-        if (sfo_text_to_records(text, bytes, recs)) {
-            if (n_records) *n_records = recs.size();
-            const double tp1 = now_s();
-            check(hc_set_found_records(m_ctx, recs.data(), recs.size()), "hc_set_found_records");
-            if (getenv("HC_STAGE_TIMING"))
-                fprintf(stderr, "[hc stage] SFO file: %zu bytes -> %zu records in %.3f s, to the device in %.3f s\n", bytes, recs.size(), tp1 - tp0, now_s() - tp1);
-            {  // 2 GB at config 3's size: given back behind the caller's back
-                auto spent = std::make_shared<std::vector<hc_sfo_rec, DefaultInitAllocator<hc_sfo_rec>>>(std::move(recs));
-                defer_cleanup([spent]() mutable { spent.reset(); });
+        uint64_t n_rec = 0;
+        int rc = HC_ERR_NOT_ON_DEVICE;
+        const char* route = getenv("HC_SFO_PARSE");
+        if (route && !strcmp(route, "host")) {
+            std::vector<hc_sfo_rec, DefaultInitAllocator<hc_sfo_rec>> recs;
+            if (sfo_text_to_records(text, bytes, recs)) {
+                n_rec = recs.size();
+                rc = hc_set_found_records(m_ctx, recs.data(), recs.size());
+                auto spent = std::make_shared<std::vector<hc_sfo_rec, DefaultInitAllocator<hc_sfo_rec>>>(std::move(recs));  // 2 GB at config 3's size:
+                defer_cleanup([spent]() mutable { spent.reset(); });                                                     // given back behind the caller's back
             }
+        } else if (!getenv("HC_SFO_TEXT_GENERAL")) {
+            rc = hc_set_found_from_sfo_text(m_ctx, text, bytes, &n_rec);
+        }
+        if (rc != HC_ERR_NOT_ON_DEVICE) {
+            check(rc, "hc_set_found_from_sfo_text");
+            if (n_records) *n_records = n_rec;
+            if (getenv("HC_STAGE_TIMING")) fprintf(stderr, "[hc stage] SFO file: %zu bytes -> %lu records on the device in %.3f s\n", bytes, (unsigned long)n_rec, now_s() - tp0);
             if (run_stage_from_found(then_sort, &lines)) {
                 if (device_route) *device_route = 1;
                 if (n_lines) *n_lines = lines;

@@ -291,6 +291,13 @@ class EdgeScorer:
         recs = np.ascontiguousarray(recs)
         N.check(N.lib.hc_set_found_records(self._ctx, _ptr(recs), recs.size), "hc_set_found_records")
 
+    def set_found_from_sfo_text(self, text):
+        """hc_set_found_from_sfo_text: the SFO file's text (bytes) read on the device into the finder's place.  Returns the number of records;
+        raises HcError (HC_ERR_NOT_ON_DEVICE) for a text that is not canonical."""
+        n = C.c_uint64()
+        N.check(N.lib.hc_set_found_from_sfo_text(self._ctx, text, len(text), C.byref(n)), "hc_set_found_from_sfo_text")
+        return int(n.value)
+
     def found_to_lines(self, num_singles, num_pairs):
         """hc_found_to_lines_device + hc_found_lines_fetch: the SFO ingest entirely on the device; the overlaps file's lines as records
         (records.LINE_DTYPE), in file order.  Raises RuntimeError("... not on the device ...") where the device cannot decide."""

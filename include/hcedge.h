@@ -285,6 +285,11 @@ int hc_found_to_overlaps(hc_ctx* ctx, const char* out_path, uint64_t num_singles
 /* SFO records from elsewhere — a rust-overlaps output the caller has parsed (8 columns: /root/reference/scripts/sfo2overlaps.py:35-36) — in
  * the place of the finder's: hc_found_to_overlaps / hc_found_to_lines_device then run the ingest on them.  After hc_set_reads. */
 int hc_set_found_records(hc_ctx* ctx, const hc_sfo_rec* recs, uint64_t n);
+/* The same from the SFO FILE's text, read on the device (64 MiB chunks, one lane per line): a canonical file only — eight fields, single tabs,
+ * "0" or [1-9][0-9]* with one '-' allowed in front of the two overhangs, `N` or `I`: what rust-overlaps writes.  Any other text:
+ * HC_ERR_NOT_ON_DEVICE (hc_sfo2overlaps' general path takes such a file and owns its errors).  `text` is host memory as it is (a mapping of
+ * the file will do). */
+int hc_set_found_from_sfo_text(hc_ctx* ctx, const char* text, uint64_t n_bytes, uint64_t* n_records);
 struct hc_line_rec;
 /* n lines of hc_found_to_lines_device copied to the host */
 int hc_found_lines_fetch(hc_ctx* ctx, const struct hc_line_rec* d_lines, uint64_t n, struct hc_line_rec* out);

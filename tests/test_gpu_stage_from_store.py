@@ -392,3 +392,60 @@ def test_hc_edgecalc_sfo_flag_equals_the_two_programs(tmp_path):
     assert outs["sfo"] == outs["overlaps"] and len(outs["sfo"]["edges_sorted.tsv"]) > 10000
     r = subprocess.run([exe] + common + ["--sfo", d + "sfoverlaps.out", "--overlaps", d + "original_overlaps.txt"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "exclusive" in r.stderr
+
+
+def _sfo_text(recs):
+    return "".join(f"{r['idA']}\t{r['idB']}\t{'I' if r['inverted'] else 'N'}\t{r['OHA']}\t{r['OHB']}\t{r['OLA']}\t{r['OLB']}\t{r['K']}\n" for r in recs).encode()
+
+
+def _random_sfo(rng, n_seq, n_rec):
+    from haploconduct_amd.records import SFO_DTYPE
+
+    recs = np.zeros(n_rec, dtype=SFO_DTYPE)
+    recs["idA"] = rng.integers(0, n_seq, n_rec)
+    recs["idB"] = rng.integers(0, n_seq, n_rec)
+    recs["OHA"] = rng.integers(-40, 41, n_rec)
+    recs["OHB"] = rng.integers(-40, 41, n_rec)
+    recs["OLA"] = rng.integers(30, 151, n_rec)
+    recs["OLB"] = np.where(rng.random(n_rec) < 0.7, recs["OLA"], rng.integers(30, 151, n_rec))
+    recs["K"] = rng.integers(0, 4, n_rec)
+    recs["inverted"] = rng.integers(0, 2, n_rec)
+    return recs
+
+
+def test_the_sfo_files_text_read_on_the_device(tmp_path):
+    """hc_set_found_from_sfo_text: the text rust-overlaps writes -> records on the device, one lane per line — the same overlap lines as the
+    records themselves give (hc_set_found_records), with and without a last newline, over several 64 MiB chunks; and every text that is not
+    canonical (the host's parse_canonical_sfo has the same rules) is left to the host's general path."""
+    rng = np.random.default_rng(11)
+    ns, npairs = 40, 60
+    reads = hc.ReadSet.from_lists([(b"ACGT" * 10, b"I" * 40)] * ns, [((b"ACGT" * 10, b"I" * 40), (b"TGCA" * 10, b"I" * 40))] * npairs)
+    recs = _random_sfo(rng, ns + 2 * npairs, 20000)
+    recs["OHA"][:4] = [-2147483647, 2147483647, 0, -1]  # the edges of the accepted ranges are accepted (the ingest's own sort keys then say no: 10^7 and more)
+    text = _sfo_text(recs[4:])
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
+        sc.set_found_records(recs[4:])
+        want = sc.found_to_lines(ns, npairs)
+        for t in (text, text[:-1]):
+            assert sc.set_found_from_sfo_text(t) == recs.size - 4
+            got = sc.found_to_lines(ns, npairs)
+            assert got.tobytes() == want.tobytes()
+        assert sc.set_found_from_sfo_text(b"") == 0 and sc.found_to_lines(ns, npairs).size == 0
+        line = b"3\t7\tN\t5\t-6\t60\t61\t2\n"
+        assert sc.set_found_from_sfo_text(line) == 1
+        for bad in (b"03\t7\tN\t5\t-6\t60\t61\t2\n", b"3\t7\tN\t+5\t-6\t60\t61\t2\n", b"3\t\t7\tN\t5\t-6\t60\t61\t2\n", b"3\t7\tN\t5\t-6\t60\t61\t2\r\n",
+                    b"3\t7\tN\t5\t-6\t60\t61\t2 \n", b"3\t7\tN\t5\t-6\t60\t61\n", b"3\t7\tX\t5\t-6\t60\t61\t2\n", b"3\t7\tN\t5\t-0\t60\t61\t2\n",
+                    b"3 7 N 5 -6 60 61 2\n", line + b"\n" + line, b"3\t7\tN\t5\t-6\t60\t61\t2\t9\n", b"4294967296\t7\tN\t5\t-6\t60\t61\t2\n",
+                    b"3\t7\tN\t-2147483648\t-6\t60\t61\t2\n", b"3\t-7\tN\t5\t-6\t60\t61\t2\n"):
+            with pytest.raises(Exception, match="not on the device"):
+                sc.set_found_from_sfo_text(line * 3 + bad + line)
+        # several chunks: 3 * 10^6 lines, ~90 MB of text
+        big = _random_sfo(rng, ns + 2 * npairs, 3000000)
+        cols = [big[k].astype(str) for k in ("idA", "idB")] + [np.where(big["inverted"] != 0, "I", "N")] + [big[k].astype(str) for k in ("OHA", "OHB", "OLA", "OLB", "K")]
+        big_text = "\n".join("\t".join(t) for t in zip(*cols)).encode() + b"\n"
+        assert len(big_text) > (64 << 20)
+        sc.set_found_records(big)
+        want = sc.found_to_lines(ns, npairs)
+        assert sc.set_found_from_sfo_text(big_text) == big.size
+        assert sc.found_to_lines(ns, npairs).tobytes() == want.tobytes() and want.size > 100000
