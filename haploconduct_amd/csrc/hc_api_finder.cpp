@@ -552,7 +552,25 @@ int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs
             return hipSuccess;
         }
         while (n_own < 12 && c->ingest_scratch[n_own].p) n_own++;
-        if (n_own >= 12) return hipErrorOutOfMemory;
+        if (n_own >= 12) {  // every slot holds a block that is too small (a context that ingests inputs of growing size): the smallest idle one grows
+            int small = -1;
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i] && (small < 0 || idle[i]->cap < idle[(size_t)small]->cap)) small = (int)i;
+            if (small < 0) return hipErrorOutOfMemory;
+            hc_ctx::Scratch& sl = *idle[(size_t)small];
+            idle[(size_t)small] = nullptr;
+            (void)hipFree(sl.p);
+            sl.p = nullptr;
+            sl.cap = 0;
+            const hipError_t e = hipMalloc(&sl.p, need);
+            if (e != hipSuccess) {
+                sl.p = nullptr;
+                return e;
+            }
+            sl.cap = need;
+            *p = sl.p;
+            return hipSuccess;
+        }
         hc_ctx::Scratch& sl = c->ingest_scratch[n_own];
         const hipError_t e = hipMalloc(&sl.p, need);
         if (e != hipSuccess) {

@@ -440,7 +440,12 @@ def test_the_sfo_files_text_read_on_the_device(tmp_path):
                     b"3\t7\tN\t-2147483648\t-6\t60\t61\t2\n", b"3\t-7\tN\t5\t-6\t60\t61\t2\n"):
             with pytest.raises(Exception, match="not on the device"):
                 sc.set_found_from_sfo_text(line * 3 + bad + line)
-        # several chunks: 3 * 10^6 lines, ~90 MB of text
+    # several chunks: 3 * 10^6 lines, ~90 MB of text (many reads: the groups stay small — with few reads the lines outnumber the records
+    # eight to one and the device hands the input to the host, as it should)
+    ns, npairs = 2000, 3000
+    reads = hc.ReadSet.from_lists([(b"ACGT" * 10, b"I" * 40)] * ns, [((b"ACGT" * 10, b"I" * 40), (b"TGCA" * 10, b"I" * 40))] * npairs)
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        sc.set_reads(reads)
         big = _random_sfo(rng, ns + 2 * npairs, 3000000)
         cols = [big[k].astype(str) for k in ("idA", "idB")] + [np.where(big["inverted"] != 0, "I", "N")] + [big[k].astype(str) for k in ("OHA", "OHB", "OLA", "OLB", "K")]
         big_text = "\n".join("\t".join(t) for t in zip(*cols)).encode() + b"\n"
