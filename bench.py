@@ -847,6 +847,65 @@ def stage_a_from_reads(reads, settings, threads, err=0.0, min_overlap=90, reps=3
         shutil.rmtree(d, ignore_errors=True)
 
 
+def stage_a_from_sfo(reads, settings, threads, err=0.0, min_overlap=90, reps=2):
+    """The pipelines' own input to stage a — the SFO file rust-overlaps writes (savage.py:664) — to the sorted graph: ONE call
+    (hc_ec_construct_edges_from_sfo: the file's text, scripts/sfo2overlaps.py's ingest and the stage all on the device) against the THREE steps
+    the pipeline runs (the script -> original_overlaps.txt -> the binary; here their ports hc_sfo2overlaps + hc_ec_construct_edges_sorted).  The
+    SFO file is this library's finder's output on the workload's reads, written once, untimed; from the file on everything is pinned (the ingest
+    by the script's own outputs, the stage by the reference's own construct_edges + sortEdges)."""
+    import shutil
+    import tempfile
+
+    import haploconduct_amd as hc
+    from haploconduct_amd import host
+
+    d = tempfile.mkdtemp(prefix="hcsfo_") + "/"
+    try:
+        paired = reads.is_paired(0)
+        reads.write_fastq(None if paired else d + "singles.fastq", d + "paired1.fastq" if paired else None, d + "paired2.fastq" if paired else None)
+        settings.n_threads = threads
+        fq = dict(singles=None if paired else d + "singles.fastq", paired1=d + "paired1.fastq" if paired else None,
+                  paired2=d + "paired2.fastq" if paired else None)
+        with hc.EdgeScorer(settings) as sc:
+            sc.set_reads(reads)
+            recs = sc.find_overlaps(err, min_overlap)
+        host.write_sfo(d + "sfoverlaps.out", recs)
+        n_rec = int(recs.size)
+        del recs
+        n_single, n_pairs = (0, reads.n_reads) if paired else (reads.n_reads, 0)
+        host.keep_devices(True)
+        one, three = [], []
+        for _ in range(reps + 1):  # (the first round pays a process's first allocations: not counted)
+            with host.EdgeCalculatorStage(settings, output_dir=d, **fq) as ec:
+                t0 = time.perf_counter()
+                nr, nl, on_device = ec.construct_edges_from_sfo(d + "sfoverlaps.out")
+                t1 = time.perf_counter()
+                a = (ec.edge_count(), hash(ec.edges().tobytes()), hash(open(d + "nonedge_overlaps.txt", "rb").read()))
+            one.append({"s": t1 - t0, "sfo_records": int(nr), "overlap_lines": int(nl), "lines_stayed_on_device": bool(on_device)})
+            t0 = time.perf_counter()
+            n_lines = host.sfo2overlaps(d + "sfoverlaps.out", d + "original_overlaps.txt", n_single, n_pairs)
+            t1 = time.perf_counter()
+            with host.EdgeCalculatorStage(settings, output_dir=d, overlaps=d + "original_overlaps.txt", **fq) as ec:
+                t2 = time.perf_counter()
+                ec.construct_edges_sorted()
+                t3 = time.perf_counter()
+                b = (ec.edge_count(), hash(ec.edges().tobytes()), hash(open(d + "nonedge_overlaps.txt", "rb").read()))
+            if a != b or nl != n_lines:
+                raise SystemExit("bench.py: the SFO file in one call built another graph than the three steps")
+            three.append({"sfo2overlaps_s": t1 - t0, "construct_edges_sorted_s": t3 - t2, "s": t1 - t0 + t3 - t2})
+        med = lambda xs: sorted(xs)[len(xs) // 2]
+        return {"value": med([x["s"] for x in one[1:]]), "unit": "s (SFO file -> sorted graph, one call; median of the runs behind the first)",
+                "one_call_s": med([x["s"] for x in one[1:]]), "three_steps_s": med([x["s"] for x in three[1:]]),
+                "speedup": med([x["s"] for x in three[1:]]) / med([x["s"] for x in one[1:]]), "sfo_records": n_rec,
+                "sfo_file_bytes": os.path.getsize(d + "sfoverlaps.out"), "overlap_lines": one[-1]["overlap_lines"], "edges": a[0],
+                "lines_stayed_on_device": one[-1]["lines_stayed_on_device"], "graphs_equal": True,
+                "runs": {"one_call": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in x.items()} for x in one],
+                         "three_steps": [{k: round(v, 4) for k, v in x.items()} for x in three]}}
+    finally:
+        host.keep_devices(False)
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def summary_record(out, args):
     """The line's figures once more, compact and LAST (the driver's record keeps the tail of stdout)."""
     r = out.get("roofline", {})
@@ -870,6 +929,9 @@ def summary_record(out, args):
     sa = out.get("stage_a_from_reads")
     if sa:
         sm[f"{args.workload}_reads_to_graph_from_store_s"], sm[f"{args.workload}_reads_to_graph_from_reads_s"] = g(sa["from_store_s"], 4), g(sa["from_reads_s"], 4)
+    ss = out.get("stage_a_from_sfo")
+    if ss:
+        sm[f"{args.workload}_sfo_file_to_graph_s"], sm[f"{args.workload}_sfo_three_steps_s"] = g(ss["one_call_s"], 4), g(ss["three_steps_s"], 4)
     for w, rec in (out.get("also") or {}).items():
         sm[f"{w}_ms_per_step"], sm[f"{w}_kernel_ms"] = g(rec["ms_per_step"], 4), g(rec["roofline"]["kernel_ms"], 4)
         if rec["roofline"].get("frac") is not None:
@@ -1062,6 +1124,7 @@ def main():
             threads = args.stage_threads or min(32, os.cpu_count() or 1)
             out["stage_end_to_end"] = stage_end_to_end(reads, cand, settings, threads)
             out["stage_a_from_reads"] = stage_a_from_reads(reads, settings, threads)
+            out["stage_a_from_sfo"] = stage_a_from_sfo(reads, settings, threads)
         if not args.no_cpu_baseline:
             # the reference's own code where its probe library is present (it is built by __graft_entry__.build() in the
             # build container and travels with the repository), and always the oracle (a port) beside it

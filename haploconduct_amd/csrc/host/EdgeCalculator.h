@@ -97,7 +97,7 @@ public:
                                     uint64_t* n_lines, int* device_route);
     // The pipelines' own input to stage a — the SFO file `rust-overlaps` wrote (savage.py:664, polyte.py:514) — straight to the graph: what
     // scripts/sfo2overlaps.py, original_overlaps.txt and the binary's text parser do in three steps.  A canonical file (single tabs, plain
-    // decimal numbers: what the tool writes) is read into records, which take the finder's place on the device (hc_set_found_records), and the
+    // decimal numbers: what the tool writes) is read on the device into records that take the finder's place (hc_set_found_from_sfo_text), and the
     // rest is construct_edges_from_store's; any other file, and any input the device does not decide, goes through the host's ingest
     // (hc_sfo2overlaps' code), its text in memory, and the text blocks — which raise what the script raises.  Pinned end to end: the ingest
     // by the script's own outputs (tests/golden/sfo), the stage by the reference's construct_edges + sortEdges.

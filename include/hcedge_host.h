@@ -77,8 +77,9 @@ int hc_ec_construct_edges_from_store(hc_ec* ec, double err_rate, uint32_t min_ov
 /* The pipelines' own input — the SFO file `rust-overlaps` wrote (savage.py:664, polyte.py:514, 542) — straight to the graph: what
  * scripts/sfo2overlaps.py (--in sfo_path --out original_overlaps.txt --num_singles --num_pairs, savage.py:672), the overlaps file and the
  * binary's own text parser (src/EdgeCalculator.cpp:561-604) do between them.  A canonical file (eight fields, single tabs, plain decimal
- * numbers: what the tool writes) becomes records, which take the finder's place on the device (hc_set_found_records); the ingest and the stage
- * are hc_ec_construct_edges_from_store's: no 13-column text is written, copied or parsed.  Any other file, and any input the device does not
+ * numbers: what the tool writes) is read ON THE DEVICE (hc_set_found_from_sfo_text: 64 MiB chunks of the file's text, one lane per line) into
+ * records that take the finder's place; the ingest and the stage are hc_ec_construct_edges_from_store's: no 13-column text is written, copied
+ * or parsed.  Any other file, and any input the device does not
  * decide (HC_ERR_NOT_ON_DEVICE), goes through hc_sfo2overlaps' code with its text kept in memory — every error is the script's.  Same graph,
  * counters and nonedge_overlaps.txt as hc_sfo2overlaps + hc_ec_construct_edges[_sorted] on the file it writes.  Pinned end to end (the ingest by
  * the script's own outputs, the stage by the reference's own code); hc_paths.overlaps_file is not read.
