@@ -20,6 +20,10 @@
 #include "../../include/hcedge.h"
 #include "hc_text.h"
 
+#ifndef HC_TEXT_ABLATE_LINES
+#define HC_TEXT_ABLATE_LINES 0
+#endif
+
 namespace hc {
 
 // bytes of w equal to '\n', as a mask with bit 7 of each such byte set (exact: no borrow artefacts)
@@ -360,7 +364,9 @@ __global__ __launch_bounds__(256) void text_parse_kernel(TextParams prm, const c
                 }
             }
         } else {
+#if !HC_TEXT_ABLATE_LINES  // (experiment builds only, tools/experiments/r06_text_no_lines.sh: what NOT writing every parsed line would save at most)
             lines[i] = o;
+#endif
             accept_line(prm, ids, o, i, cd, rejects, counters, n_self, n_silent, n_reject, n_pass, n_unknown);
         }
         cands[i] = cd;

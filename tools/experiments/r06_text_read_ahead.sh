@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B on ONE box: the text parser's window with and without the two-word read-ahead (HC_TEXT_READ_AHEAD), device time of the C3 stage per
 # (the HC_TEXT_READ_AHEAD switch was part of the withdrawn change: Cursor::load read word(a + 4), word(a + 8) as well, Cursor::next shifted
-#  w <- w1 <- w2 <- word(at + 8); the product has the one-word window only — profiles/r06_text_read_ahead.md)
+#  w <- w1 <- w2 <- word(at + 8); the product has the one-word window only — profiles/r06_stage_device_leg.md)
 # file by kernel (rocprofv3 --kernel-trace --stats over four files), twice each, alternating.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R/haploconduct_amd/csrc
