@@ -41,6 +41,55 @@ struct DevBuf {
     template <typename T>
     T* as() const { return (T*)p; }
 };
+// Device blocks for the SFO ingest: the finder's grow-only scratch is idle then and large enough for most of what is needed; what it cannot
+// serve comes from a second grow-only set (hc_ctx::ingest_scratch).  (Allocating and freeing 8 GB per call costs ten times the sorts.)  Every
+// block handed out is the caller's until the pool goes; a context that ingests inputs of growing size regrows its smallest idle block when
+// the second set is full.
+struct IngestScratch {
+    hc_ctx* c;
+    std::vector<hc_ctx::Scratch*> idle;
+    unsigned n_own = 0;
+    explicit IngestScratch(hc_ctx* ctx) : c(ctx) {
+        for (auto& sl : c->finder_scratch)
+            if (sl.p) idle.push_back(&sl);
+        for (auto& sl : c->ingest_scratch)
+            if (sl.p) idle.push_back(&sl);
+    }
+    hipError_t operator()(size_t bytes, void** p) {
+        const size_t need = bytes ? bytes : 16;
+        int best = -1;
+        for (size_t i = 0; i < idle.size(); i++)
+            if (idle[i] && idle[i]->cap >= need && (best < 0 || idle[i]->cap < idle[(size_t)best]->cap)) best = (int)i;
+        if (best >= 0) {
+            *p = idle[(size_t)best]->p;
+            idle[(size_t)best] = nullptr;
+            return hipSuccess;
+        }
+        while (n_own < 12 && c->ingest_scratch[n_own].p) n_own++;  // an empty slot of the second set
+        hc_ctx::Scratch* sl = nullptr;
+        if (n_own < 12) {
+            sl = &c->ingest_scratch[n_own];
+        } else {  // every slot holds a block that is too small: the smallest idle one grows
+            int small = -1;
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i] && (small < 0 || idle[i]->cap < idle[(size_t)small]->cap)) small = (int)i;
+            if (small < 0) return hipErrorOutOfMemory;
+            sl = idle[(size_t)small];
+            idle[(size_t)small] = nullptr;
+            (void)hipFree(sl->p);
+            sl->p = nullptr;
+            sl->cap = 0;
+        }
+        const hipError_t e = hipMalloc(&sl->p, need);
+        if (e != hipSuccess) {
+            sl->p = nullptr;
+            return e;
+        }
+        sl->cap = need;
+        *p = sl->p;
+        return hipSuccess;
+    }
+};
 }  // namespace
 
 #define HC_ALLOC(buf, bytes)                                                                  \
@@ -373,36 +422,7 @@ int hc_found_to_overlaps_text(hc_ctx* c, uint64_t num_singles, uint64_t num_pair
         void* host = nullptr;
         ~Freed() { free(host); }
     } mem;
-    // Device blocks: the finder's grow-only scratch is idle now and large enough for most of what is needed here; what
-    // it cannot serve comes from a second grow-only set.  (Allocating and freeing 8 GB per call costs ten times the sorts.)
-    std::vector<hc_ctx::Scratch*> idle;
-    for (auto& sl : c->finder_scratch)
-        if (sl.p) idle.push_back(&sl);
-    for (auto& sl : c->ingest_scratch)
-        if (sl.p) idle.push_back(&sl);
-    unsigned n_own = 0;
-    auto dmalloc = [&](size_t bytes, void** p) {
-        const size_t need = bytes ? bytes : 16;
-        int best = -1;
-        for (size_t i = 0; i < idle.size(); i++)
-            if (idle[i] && idle[i]->cap >= need && (best < 0 || idle[i]->cap < idle[(size_t)best]->cap)) best = (int)i;
-        if (best >= 0) {
-            *p = idle[(size_t)best]->p;
-            idle[(size_t)best] = nullptr;
-            return hipSuccess;
-        }
-        while (n_own < 12 && c->ingest_scratch[n_own].p) n_own++;  // an empty slot of the second set
-        if (n_own >= 12) return hipErrorOutOfMemory;
-        hc_ctx::Scratch& sl = c->ingest_scratch[n_own];
-        const hipError_t e = hipMalloc(&sl.p, need);
-        if (e != hipSuccess) {
-            sl.p = nullptr;
-            return e;
-        }
-        sl.cap = need;
-        *p = sl.p;
-        return hipSuccess;
-    };
+    IngestScratch dmalloc(c);
     try {
         HC_HIP(hipSetDevice(c->device));
         hc::BoundForNow bound(hc::cpus_near_device(c->device));  // the matching threads read the page-locked ring: next to the device
@@ -535,52 +555,7 @@ int hc_found_to_lines_device(hc_ctx* c, uint64_t num_singles, uint64_t num_pairs
     if (n >= 0x7FFFFFF0ull) return fail(HC_ERR_NOT_ON_DEVICE, "hc_found_to_lines_device: not on the device (2^31 records and more)");
     const bool timing = getenv("HC_SFO_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    std::vector<hc_ctx::Scratch*> idle;
-    for (auto& sl : c->finder_scratch)
-        if (sl.p) idle.push_back(&sl);
-    for (auto& sl : c->ingest_scratch)
-        if (sl.p) idle.push_back(&sl);
-    unsigned n_own = 0;
-    auto dmalloc = [&](size_t bytes, void** p) {
-        const size_t need = bytes ? bytes : 16;
-        int best = -1;
-        for (size_t i = 0; i < idle.size(); i++)
-            if (idle[i] && idle[i]->cap >= need && (best < 0 || idle[i]->cap < idle[(size_t)best]->cap)) best = (int)i;
-        if (best >= 0) {
-            *p = idle[(size_t)best]->p;
-            idle[(size_t)best] = nullptr;
-            return hipSuccess;
-        }
-        while (n_own < 12 && c->ingest_scratch[n_own].p) n_own++;
-        if (n_own >= 12) {  // every slot holds a block that is too small (a context that ingests inputs of growing size): the smallest idle one grows
-            int small = -1;
-            for (size_t i = 0; i < idle.size(); i++)
-                if (idle[i] && (small < 0 || idle[i]->cap < idle[(size_t)small]->cap)) small = (int)i;
-            if (small < 0) return hipErrorOutOfMemory;
-            hc_ctx::Scratch& sl = *idle[(size_t)small];
-            idle[(size_t)small] = nullptr;
-            (void)hipFree(sl.p);
-            sl.p = nullptr;
-            sl.cap = 0;
-            const hipError_t e = hipMalloc(&sl.p, need);
-            if (e != hipSuccess) {
-                sl.p = nullptr;
-                return e;
-            }
-            sl.cap = need;
-            *p = sl.p;
-            return hipSuccess;
-        }
-        hc_ctx::Scratch& sl = c->ingest_scratch[n_own];
-        const hipError_t e = hipMalloc(&sl.p, need);
-        if (e != hipSuccess) {
-            sl.p = nullptr;
-            return e;
-        }
-        sl.cap = need;
-        *p = sl.p;
-        return hipSuccess;
-    };
+    IngestScratch dmalloc(c);
     HC_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const double t0 = now();
