@@ -213,7 +213,9 @@ int hc_destroy(hc_ctx* c) {
 // (EdgeCalculator.cpp:41,44,52,60) so that every term the device adds is bit-identical to the
 // reference's log(p).  Dimension Kp = K + 2: index K is the N row/column (0.0: the position is
 // skipped, :35-39), index K+1 the invalid-symbol row/column (NaN poison).  Layouts: hc_device.h.
-static bool build_lut(const std::vector<int>& phred, double mismatch_setting, uint32_t symbytes, std::vector<double>& lut) {
+// `wide_rows` (the wide 8-bit encoding only, 64 entries): what each quality index means there — a Phred value, -1 = N, -2 = not a value.
+static bool build_lut(const std::vector<int>& phred, const std::vector<int>& wide_rows, double mismatch_setting, uint32_t symbytes,
+                      std::vector<double>& lut) {
     const size_t K = phred.size(), Kp = K + 2;
     const double inf = std::numeric_limits<double>::infinity();
     const double nan = std::numeric_limits<double>::quiet_NaN();
@@ -225,18 +227,17 @@ static bool build_lut(const std::vector<int>& phred, double mismatch_setting, ui
     for (size_t a = 0; a < dim; a++) {
         for (size_t b = 0; b < dim; b++) {
             // which index means N / invalid depends on the encoding (hc_device.h)
-            const bool bad = wide ? (a >= hc::kWideBadQual || b >= hc::kWideBadQual || (a >= K && a != hc::kWideN) ||
-                                     (b >= K && b != hc::kWideN))
-                                  : (a >= K + 1 || b >= K + 1);
-            const bool isn = wide ? (a == hc::kWideN || b == hc::kWideN) : (a == K || b == K);
+            const bool bad = wide ? (wide_rows[a] == -2 || wide_rows[b] == -2) : (a >= K + 1 || b >= K + 1);
+            const bool isn = wide ? (wide_rows[a] == -1 || wide_rows[b] == -1) : (a == K || b == K);
             double vm, vx;
             if (bad) {
                 vm = vx = nan;
             } else if (isn) {
                 vm = vx = 0.0;
             } else {
-                const double p1 = pow(10, -phred[a] / 10.0);  // phred_to_prob, :59-63
-                const double p2 = pow(10, -phred[b] / 10.0);
+                const int ph1 = wide ? wide_rows[a] : phred[a], ph2 = wide ? wide_rows[b] : phred[b];
+                const double p1 = pow(10, -ph1 / 10.0);  // phred_to_prob, :59-63
+                const double p2 = pow(10, -ph2 / 10.0);
                 const double pm = (1 - p1) * (1 - p2) + (p1 * p2) / 3.0;                               // :41
                 const double px = p1 * (1 - p2) / 3.0 + p2 * (1 - p1) / 3.0 + (2 / 9.0) * p1 * p2;  // :44
                 vm = (pm < mismatch_setting) ? inf : log(pm);  // :49-52
@@ -305,7 +306,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     bool any_bad_base = false;  // a base outside ACGTN somewhere (the encoder flags the sequence; the store is then not "regular")
     for (int b = 0; b < 256; b++)
         if (base_hist[b] && b != 'A' && b != 'C' && b != 'G' && b != 'T' && b != 'N') any_bad_base = true;
-    std::vector<int> phred;
+    std::vector<int> phred, wide_rows;
     uint8_t qmap[256];
     memset(qmap, 255, sizeof qmap);
     {
@@ -338,9 +339,26 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
             }
         }
         phred.assign(Kq, 0);
-        for (uint32_t k = 0; k < Kq; k++) {
-            qmap[present[k]] = (uint8_t)index_of[k];
-            phred[index_of[k]] = present[k] - 33;
+        if (hc::sym_bytes_for(Kq) == 1 && hc::lut_lg(Kq) == 6) {
+            // the wide 8-bit encoding (hc_device.h): indices 16..63, the r-th most frequent value takes kWideRankLabel[r] — the table's rows
+            // are addressed by them, nothing else depends on the assignment (HC_QIDX_ORDER=value: 16 + the value's rank by byte)
+            std::vector<uint32_t> by_freq(Kq);
+            for (uint32_t k = 0; k < Kq; k++) by_freq[k] = k;
+            if (!(qo && strcmp(qo, "value") == 0))
+                std::stable_sort(by_freq.begin(), by_freq.end(), [&](uint32_t a, uint32_t b) { return hist[present[a]] > hist[present[b]]; });
+            wide_rows.assign(64, -2);
+            wide_rows[hc::kWideN] = -1;
+            for (uint32_t r = 0; r < Kq; r++) {
+                const uint32_t label = (qo && strcmp(qo, "value") == 0) ? hc::kWideFirst + r : hc::kWideRankLabel[r];
+                qmap[present[by_freq[r]]] = (uint8_t)label;
+                wide_rows[label] = present[by_freq[r]] - 33;
+                phred[by_freq[r]] = present[by_freq[r]] - 33;  // (K entries; the table is built from wide_rows)
+            }
+        } else {
+            for (uint32_t k = 0; k < Kq; k++) {
+                qmap[present[k]] = (uint8_t)index_of[k];
+                phred[index_of[k]] = present[k] - 33;
+            }
         }
     }
     if (phred.empty()) phred.push_back(0);
@@ -378,7 +396,7 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
         }
     }
     std::vector<double> lut;
-    if (!build_lut(phred, c->settings.mismatch, symbytes, lut))  // (never seen: the reference's expressions commute for every Phred pair)
+    if (!build_lut(phred, wide_rows, c->settings.mismatch, symbytes, lut))  // (never seen: the reference's expressions commute for every Phred pair)
         return fail(HC_ERR_STATE, "hc_set_reads: the log-probability table is not symmetric in its two qualities (--mismatch within one ulp of a term?)");
 
     free_store(c);

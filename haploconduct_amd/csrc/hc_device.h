@@ -20,8 +20,9 @@
 //          would do).  Table dimension Kp = K + 2.
 //   K <= 30 -> uint8 symbols as above (5-bit qidx, 3-bit code); with K <= 6 (3-bit qidx) bits 6-7 of the symbol repeat
 //          the low two bits of qidx (they are address bits of the K <= 6 log table as they stand, see below);
-//   31 <= K <= 48 -> "wide" uint8 symbols  sym = (qidx << 2) | base2  (6-bit qidx, A,C,G,T = 0..3) with the
-//          reserved indices 48 = N, 49 = invalid quality, 50 = invalid base (recognisable by the two top bits);
+//   31 <= K <= 48 -> "wide" uint8 symbols  sym = (qidx << 2) | base2  (6-bit qidx, A,C,G,T = 0..3): the quality values take 48 of the
+//          indices 16..63 (dealt by frequency, kWideRankLabel below), the reserved indices are 0 = N, 1 = invalid quality,
+//          2 = invalid base — recognisable by their two CLEAR top bits: (sym << 1 | sym) has bit 7 set for a base, one VALU op;
 //   K > 48 -> uint16 symbols  (qidx << 3) | code.
 //   Slots are padded with N symbols to a multiple of 16 bytes plus 32 bytes, so chunked
 //   (16-symbol) loads may over-read safely.
@@ -98,6 +99,11 @@ struct StoreView {
 //                   bank, as in the dense layouts.
 //   uint8 symbols, LG in {4,5}: two dense planes (match, mismatch) of 2^LG x 2^LG entries, LG = ceil(log2(Kp)):
 //                   byte address = m * (8 << 2LG) + qa * (8 << LG) + ((qb ^ qa) & (2^LG - 1)) * 8.
+//   uint8 symbols, LG = 6 (the wide encoding, 64 KiB): x = qa ^ qb,
+//                   byte address = m << 15 | qa << 9 | (x >> 5) << 8 | (((x & 31) ^ (qa >> 1)) & 31) << 3
+//                   — the low byte (the LDS bank) mixes the XOR with the ROW's upper bits: with the plain XOR every pair of EQUAL
+//                   qualities (a sixth of all positions of real reads) met in bank 0 at different rows.  Both bytes cost what the
+//                   plain layout's cost: the row bits are the first symbol's own bits 7..3.
 //                   The address of a position is exactly the 16-bit value one v_perm_b32 assembles from two
 //                   pre-masked symbol bytes (no shift, no multiply); the XOR of the column with the row
 //                   spreads the few hot (qa, qb) pairs over the LDS banks (rows of a power-of-two table
@@ -107,10 +113,17 @@ struct StoreView {
 //                   byte address = (m*T + hi*(hi+1)/2 + lo) * 8, hi/lo = larger/smaller of (qa, qb), T = Kp*(Kp+1)/2
 //                   (entry index < 2*4753 fits 16 bits: two positions per packed-16-bit VALU op).  Half the LDS of
 //                   the square layout: 31 KiB for 60 quality values, 74 KiB for the full Phred range.
-constexpr uint32_t kWideN = 48, kWideBadQual = 49, kWideBadBase = 50;  // reserved qidx of the wide 8-bit encoding
+constexpr uint32_t kWideN = 0, kWideBadQual = 1, kWideBadBase = 2;  // reserved qidx of the wide 8-bit encoding (all below kWideFirst)
+constexpr uint32_t kWideFirst = 16, kWideMaxK = 48;                  // quality values take indices kWideFirst .. 63
+// The index of the r-th most frequent quality value of a read set (wide encoding).  Any one-to-one assignment gives the same results
+// (symbols and table are built from the same map); this one was searched (round 6, tools/experiments/r06_wide_labels.py) so that the
+// (qa, qb) pairs of the few values that make up most of real reads' qualities fall into different LDS banks under the table's address
+// mix (lut_addr_u8): simulated LDS cycles per 32-lane group of table reads 2.3 against 4.2 (POLYTE example), 1.4 against 2.7 (SAVAGE).
+constexpr uint8_t kWideRankLabel[kWideMaxK] = {33, 25, 45, 21, 28, 44, 48, 36, 39, 20, 50, 32, 16, 63, 26, 40, 34, 24, 35, 37, 62, 54, 27, 55,
+                                               17, 59, 46, 42, 58, 43, 30, 41, 38, 19, 61, 56, 29, 53, 31, 47, 23, 49, 18, 60, 51, 52, 57, 22};
 // LG: log2 of the 8-bit-symbol table dimension; 6 selects the wide encoding.
 __host__ __device__ inline uint32_t lut_lg(uint32_t K) { return K + 2 <= 8 ? 3u : (K + 2 <= 16 ? 4u : (K + 2 <= 32 ? 5u : 6u)); }
-__host__ __device__ inline uint32_t sym_bytes_for(uint32_t K) { return K <= kWideN ? 1u : 2u; }
+__host__ __device__ inline uint32_t sym_bytes_for(uint32_t K) { return K <= kWideMaxK ? 1u : 2u; }
 __host__ __device__ inline uint32_t lut_tri(uint32_t Kp) { return Kp * (Kp + 1u) / 2u; }
 __host__ __device__ inline uint32_t lut_addr_u16(uint32_t Kp, uint32_t qa, uint32_t qb, uint32_t m) {
     const uint32_t hi = qa > qb ? qa : qb, lo = qa > qb ? qb : qa;
@@ -120,6 +133,7 @@ __host__ __device__ inline uint32_t lut_addr_u16(uint32_t Kp, uint32_t qa, uint3
 __host__ __device__ inline uint32_t lut_doubles_u8(uint32_t lg) { return lg == 3 ? 2048u : (2u << (2 * lg)); }
 __host__ __device__ inline uint32_t lut_addr_u8(uint32_t lg, uint32_t qa, uint32_t qb, uint32_t m) {
     if (lg == 3) return (qa << 11) | (m << 10) | ((qa & 3u) << 6) | (((qb ^ qa) & 7u) << 3);
+    if (lg == 6) return (m << 15) | (qa << 9) | ((((qb ^ qa) >> 5) & 1u) << 8) | ((((qb ^ qa) ^ (qa >> 1)) & 31u) << 3);
     return m * (8u << (2 * lg)) + qa * (8u << lg) + ((qb ^ qa) & ((1u << lg) - 1u)) * 8u;
 }
 

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                     if (code == kCodeN) qx = kWideN;
                     if (code == kCodeBadBase) qx = kWideBadBase;
                     if (qi == 255) { qx = kWideBadQual; b2 = 0; }  // quality outside [33,127]: always fatal inside an overlap
-                    const uint32_t rb2 = qx < kWideN ? 3u - b2 : 0u;
+                    const uint32_t rb2 = qx >= kWideFirst ? 3u - b2 : 0u;
                     sym[f0 + i] = (SymT)((qx << 2) | b2);
                     sym[rc0 + (len - 1 - i)] = (SymT)((qx << 2) | rb2);
                 } else {
@@ -253,14 +253,18 @@ __device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint3
         const uint32_t bw = wb[jj];
         const uint32_t e = aw ^ bw;
         if (sizeof(SymT) == 1 && LG == 6) {
-            // wide 8-bit encoding: byte = qidx << 2 | base2; qidx >= 48 (both top bits set) is N / invalid.
-            // address = m << 15 | qa << 9 | ((qb ^ qa) & 63) << 3
-            const uint32_t nm = ((aw & (aw << 1)) | (bw & (bw << 1))) & 0x80808080u;
-            const uint32_t mk = ((e << 7) | (e << 6)) & 0x80808080u & ~nm;  // base bits differ, neither is N
-            cn4 += __builtin_popcount(nm);
-            cm4 += __builtin_popcount(mk);
-            const uint32_t lo = (e << 1) & 0xF8F8F8F8u;
-            const uint32_t hi = ((e >> 7) & 0x01010101u) | ((aw >> 1) & 0x7E7E7E7Eu) | mk;
+            // wide 8-bit encoding: byte = qidx << 2 | base2; qidx < 16 (both top bits clear) is N / invalid.
+            // address (hc_device.h: lut_addr_u8) = m << 15 | qa << 9 | x5 << 8 | ((x & 31) ^ (qa >> 1)) << 3, x = qa ^ qb.
+            // 23 VALU ops per four positions (round 5's form: 28): the three-input ops written out, the counters kept in one v_bcnt each.
+            constexpr uint32_t k80 = 0x80808080u;
+            const uint32_t ua = (aw << 1) | aw, ub = (bw << 1) | bw;                    // bit 7 of a byte: the symbol is a base
+            const uint32_t nm = __builtin_amdgcn_bitop3_b32(ua, k80, ub, 0x4C);         // ~(ua & ub) & k80
+            const uint32_t mk = __builtin_amdgcn_bitop3_b32((e << 7) | (e << 6), k80, nm, 0x40);  // base bits differ, neither is N
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cn4) : "v"(nm));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cm4) : "v"(mk));
+            const uint32_t lo = __builtin_amdgcn_bitop3_b32(e << 1, 0xF8F8F8F8u, aw, 0x48);   // (e << 1 ^ aw) & 0xF8
+            const uint32_t z = __builtin_amdgcn_bitop3_b32(e >> 7, 0x01010101u, mk, 0xEA);     // (e >> 7 & 0x01) | mk
+            const uint32_t hi = __builtin_amdgcn_bitop3_b32(aw >> 1, 0x7E7E7E7Eu, z, 0xE2);    // bits 6..1 = qa, the others z's
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 t[jj * 4 + k] = lds_f64(__builtin_amdgcn_perm(hi, lo, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k));
