@@ -433,7 +433,12 @@ __device__ __forceinline__ void wave_lds_order() {  // keeps the compiler from r
 
 constexpr uint32_t kStageBytesPerWave = 64u * 64u;
 // LDS of the cooperative kernel: [table][scratch: 32 words][pad to 1 KiB][one image per wave]
-__host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t /*wg*/) { return (lut_bytes + 128u + 1023u) & ~1023u; }
+// The wide 8-bit table's LDS-DMA form (768 lanes: 64 KiB + 12 x 8 KiB = all 160 KiB) keeps the scratch words INSIDE the table, in a row no
+// symbol addresses (quality indices 3..15 are never encoded, hc_device.h: rows 3..15 of either plane are holes of 512 bytes each).
+constexpr uint32_t kWideDmaLanes = 768, kWideDmaScratch = 4u << 9;  // row 4 of the match plane
+__host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t wg) {
+    return (lut_bytes == 65536u && wg == kWideDmaLanes) ? 65536u : (lut_bytes + 128u + 1023u) & ~1023u;
+}
 
 // What a sub-overlap's walk leaves behind -> its result (x = (1/n) S, mismatches, n), or the exact re-scan when the sum came
 // out NaN (an invalid symbol inside the window, or next to it in the last chunk).
@@ -1285,7 +1290,9 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lut_s != 0u) __builtin_trap();  // lds_f64 relies on it
     const uint32_t lut_n = st.lut_bytes >> 3;
     load_log_table<SymT, LG>(lut_s, lut_g, lut_n, threadIdx.x, WG);
-    uint32_t* scratch = (uint32_t*)(lut_s + lut_n);  // row append: [0..17]; segment mode: [24] the workgroup's row counter
+    constexpr bool kScratchInTable = sizeof(SymT) == 1 && LG == 6 && WG == (int)kWideDmaLanes;  // (coop_stage_base)
+    uint32_t* scratch = kScratchInTable ? (uint32_t*)((char*)lut_s + kWideDmaScratch) : (uint32_t*)(lut_s + lut_n);  // row append: [0..17]; segment mode: [24] the workgroup's row counter
+    if (kScratchInTable) __syncthreads();  // the table's loaders have written the hole before its words are set
     const uint32_t seg_counter = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(scratch + 24);
     if (threadIdx.x == 0) {
         scratch[24] = 0;
@@ -1585,6 +1592,11 @@ static bool coop_dma_wanted() {
     static const bool on = !(getenv("HC_COOP_DMA") && atoi(getenv("HC_COOP_DMA")) == 0);
     return on;
 }
+// HC_WIDE_DMA=0: the wide 8-bit table (64 KiB) keeps the register-staged form at every size (round 6's A/B knob; default: its own LDS-DMA form)
+static bool wide_dma_wanted() {  // (read at every launch: the tests switch it inside one process)
+    const char* e = getenv("HC_WIDE_DMA");
+    return !(e && atoi(e) == 0);
+}
 // HC_WAVE_QUEUE=0: the LDS-DMA form on the static grid (round 3's launch; an A/B knob); HC_WAVE_QUEUE_STEPS: 64-candidate steps per item (1)
 static bool wave_queue_on(uint32_t* steps_out) {
     static const bool on = !(getenv("HC_WAVE_QUEUE") && atoi(getenv("HC_WAVE_QUEUE")) == 0);
@@ -1675,6 +1687,27 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             // LDS-DMA form (score_sub_coop, DEPTH = 0): 8 KiB of image per wave, so one 1 024-lane workgroup with one table per CU;
             // 8-bit symbols with a table of at most 16 KiB
             const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
+            {
+                // the wide 8-bit table (64 KiB) in the LDS-DMA form: 12 waves per CU instead of the register-staged form's 16 (round 6;
+                // HC_WIDE_DMA=0: the register-staged form, the A/B knob)
+                uint32_t steps = 1;
+                if (wide_dma_wanted() && coop_dma_wanted() && n >= coop_dma_min() && !bucketed && st.symbytes == 1 && lg == 6 && st.lut_bytes == 65536u &&
+                    wave_queue_on(&steps) && !(rows && !segmented)) {
+                    const uint64_t blocks_w = std::min<uint64_t>((n + kWideDmaLanes - 1) / kWideDmaLanes, n_cu);
+                    ScoreParams pq = prm;
+                    pq.pad = (prm.pad & 0xFFu) | (steps << 8);
+                    use_segments(blocks_w);
+                    if (!seg_on) {
+                        const hipError_t ze = zero_header();
+                        if (ze != hipSuccess) return ze;
+                    }
+                    hipLaunchKernelGGL((score_kernel_coop<uint8_t, 6, (int)kWideDmaLanes, true, false, 0, true>), dim3((uint32_t)blocks_w), dim3(kWideDmaLanes),
+                                       160 * 1024, stream, st, pq, lut_g, in, n, out, perm, sink, nullptr);
+                    compact_segments(blocks_w);
+                    if (started_groups) *started_groups = (uint32_t)blocks_w;
+                    return hipGetLastError();
+                }
+            }
             if (coop_dma_wanted() && n >= coop_dma_min() && !bucketed && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024) {
                 uint64_t blocks_d = (n + 1023) / 1024;
                 // one workgroup is resident per CU; 16 queued per CU even out what the CUs finish at different times (C3: 1 per CU 7.32 ms,
@@ -1832,6 +1865,15 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
             snprintf(small, sizeof small, "hc::score_kernel_coop<%s, %u, %u, true, %s, %d%s>", sym.c_str(), lgt, wg_c, st.balance ? "true" : "false", deep ? 2 : 1,
                      (st.balance || (wg_c == 1024 && wave_queue_on(nullptr))) ? ", true" : "");
             const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
+            // the wide 8-bit table: its own LDS-DMA form, 768 lanes (launch_score)
+            if (!st.balance && st.symbytes == 1 && lg == 6 && st.lut_bytes == 65536u && wide_dma_wanted() && coop_dma_wanted() && wave_queue_on(nullptr) &&
+                (n == 0 || n >= coop_dma_min())) {
+                snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, 6, %u, true, false, 0, true> encoding=%s table_bytes=%u lds_bytes=%u waves_per_cu=%u "
+                                          "LDS-DMA fetch for launches of %llu candidates and more (one workgroup per CU, the waves take their items from a "
+                                          "ticket counter in LDS; the scratch words sit in an unaddressed row of the table); smaller launches: %s",
+                         sym.c_str(), kWideDmaLanes, enc.c_str(), st.lut_bytes, 160u * 1024u, kWideDmaLanes / 64u, (unsigned long long)coop_dma_min(), small);
+                return buf;
+            }
             const bool dma = !st.balance && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024 && coop_dma_wanted();
             // n != 0: the form a launch of n candidates takes; n == 0: the read set's forms in general
             if (dma && (n == 0 || n >= coop_dma_min())) {
@@ -1884,6 +1926,7 @@ hipError_t set_score_kernel_lds_limit() {
 #define HC_COOP_ATTR_DMA(LG_)                                                                                                                                          \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, LG_, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, LG_, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 6, (int)kWideDmaLanes, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     HC_COOP_ATTR_DMA(3)
     HC_COOP_ATTR_DMA(4)
     HC_COOP_ATTR_DMA(5)

@@ -143,7 +143,7 @@ def test_c5_slice_against_the_references_own_code(c5, tmp_path):
 
 def test_full_size_c4_wide_symbols_properties_and_oracle_sample(oracle, c4):
     reads, cand, st = c4
-    cls = _properties_and_oracle_sample(oracle, reads, cand, st, ["score_kernel_coop<uint8_t, 6, 1024", "encoding=wide8", "table_bytes=65536"], 250)
+    cls = _properties_and_oracle_sample(oracle, reads, cand, st, ["score_kernel_coop<uint8_t, 6, 768", "encoding=wide8", "table_bytes=65536"], 250)
     # --edge_threshold 1: an edge is an overlap without a mismatch (polyte.py:617-626)
     assert not (cls == 2).any() and (cls == 3).any()
 

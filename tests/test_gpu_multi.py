@@ -182,10 +182,10 @@ def test_n_rank_bench_path_on_one_gpu_over_gloo(tmp_path, world):
     assert rows.shape == want.shape and np.array_equal(rows, want)
 
 
-@pytest.mark.parametrize("workload,kernel", [("c5", "true, true, 2"), ("c4", "uint8_t, 6, 1024")])
+@pytest.mark.parametrize("workload,kernel", [("c5", "true, true, 2"), ("c4", "uint8_t, 6, 768")])
 def test_every_launch_form_through_the_n_rank_path_over_gloo(tmp_path, workload, kernel):
     """BASELINE configs[4] ("... length-bucketed LDS tiling, 8 MI355X") and configs[3] through the N-rank step (round 6):
-    the length-bucketed launch with its row sink (c5) and the wide-table, register-staged 1 024-lane form (c4) under StreamedGather — two
+    the length-bucketed launch with its row sink (c5) and the wide-table 768-lane LDS-DMA form (c4) under StreamedGather — two
     ranks on device 0 over gloo, the strong split's gathered rows against the one-device result, by the ring and the root form."""
     if _n_devices() < 1:
         pytest.skip("no GPU")

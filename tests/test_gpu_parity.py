@@ -408,6 +408,27 @@ def test_fuzz_through_the_lds_dma_form(oracle, monkeypatch, seed):
     test_fuzz_random_read_sets_settings_and_geometry(oracle, seed)
 
 
+@pytest.mark.parametrize("order", ["frequency", "value"])
+@pytest.mark.parametrize("form", ["dma", "registers"])
+@pytest.mark.parametrize("n_quals", [31, 40, 48])
+def test_the_wide_table_in_both_forms_and_both_index_orders(oracle, monkeypatch, n_quals, form, order):
+    """31..48 quality values take the wide 8-bit encoding (hc_device.h): the quality indices dealt by frequency (kWideRankLabel) or in byte
+    order (HC_QIDX_ORDER=value), the table read by the 768-lane LDS-DMA form (whose scratch words sit in an unaddressed row of the table)
+    or by the register-staged 1 024-lane form (HC_WIDE_DMA=0).  All four must reproduce the oracle, with and without invalid symbols."""
+    monkeypatch.setenv("HC_COOP_DMA_MIN", "1")
+    monkeypatch.setenv("HC_WIDE_DMA", "1" if form == "dma" else "0")
+    if order == "value":
+        monkeypatch.setenv("HC_QIDX_ORDER", "value")
+    test_fetch_and_descriptor_paths_agree(oracle, monkeypatch, "coop", "1", n_quals)
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        from haploconduct_amd import synth
+        reads, _ = synth.make_paired_dataset(n_pairs=300, genome_len=3000, seed=5, quals=np.arange(40, 40 + n_quals, dtype=np.uint8))
+        sc.set_reads(reads)
+        want = "6, 768, true, false, 0, true" if form == "dma" else "6, 1024, true, false, 1, true"
+        assert sc.kernel_info(10 ** 6).startswith("hc::score_kernel_coop<uint8_t, " + want), sc.kernel_info(10 ** 6)
+    test_invalid_bases_and_quals_are_errors(oracle, 40)
+
+
 @pytest.mark.parametrize("align", ["16", "64", "256"])
 @pytest.mark.parametrize("seed", [1, 2, 3, 7, 10])
 def test_slot_alignment_of_the_store_changes_nothing(oracle, monkeypatch, align, seed):
