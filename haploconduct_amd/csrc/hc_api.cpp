@@ -399,7 +399,10 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
     if (!build_lut(phred, wide_rows, c->settings.mismatch, symbytes, lut))  // (never seen: the reference's expressions commute for every Phred pair)
         return fail(HC_ERR_STATE, "hc_set_reads: the log-probability table is not symmetric in its two qualities (--mismatch within one ulp of a term?)");
 
-    free_store(c);
+    // (the grow-only scratch of the finder and of the SFO ingest stays: it is capacity, not state.  A context that takes read set after read
+    // set — a pipeline's stages on parked devices — gave gigabytes back here and asked for them again in the next hc_find_overlaps, and one
+    // hipMalloc in three then took 0.75 - 0.9 s on this pool: tools/experiments/r06_find_stall_trace.sh, round 6.  hc_destroy returns it.)
+    free_store(c, false);
     struct Tmp {  // freed on every return path
         void* p = nullptr;
         ~Tmp() {

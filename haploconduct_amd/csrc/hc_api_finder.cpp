@@ -48,7 +48,13 @@ struct DevBuf {
 struct IngestScratch {
     hc_ctx* c;
     std::vector<hc_ctx::Scratch*> idle;
+    std::vector<void*> mine;  // freed with the pool
     unsigned n_own = 0;
+    IngestScratch(const IngestScratch&) = delete;
+    IngestScratch& operator=(const IngestScratch&) = delete;
+    ~IngestScratch() {
+        for (void* q : mine) (void)hipFree(q);
+    }
     explicit IngestScratch(hc_ctx* ctx) : c(ctx) {
         for (auto& sl : c->finder_scratch)
             if (sl.p) idle.push_back(&sl);
@@ -56,6 +62,12 @@ struct IngestScratch {
             if (sl.p) idle.push_back(&sl);
     }
     hipError_t operator()(size_t bytes, void** p) {
+        const hipError_t e = take(bytes, p);
+        if (getenv("HC_SCRATCH_TRACE")) fprintf(stderr, "[hc scratch] %zu bytes: %s\n", bytes, how);
+        return e;
+    }
+    const char* how = "";
+    hipError_t take(size_t bytes, void** p) {
         const size_t need = bytes ? bytes : 16;
         int best = -1;
         for (size_t i = 0; i < idle.size(); i++)
@@ -63,19 +75,33 @@ struct IngestScratch {
         if (best >= 0) {
             *p = idle[(size_t)best]->p;
             idle[(size_t)best] = nullptr;
+            how = "an idle block";
             return hipSuccess;
         }
         while (n_own < 12 && c->ingest_scratch[n_own].p) n_own++;  // an empty slot of the second set
         hc_ctx::Scratch* sl = nullptr;
+        how = "a new block of the second set";
         if (n_own < 12) {
             sl = &c->ingest_scratch[n_own];
-        } else {  // every slot holds a block that is too small: the smallest idle one grows
+        } else {  // every slot holds a block that is too small: the smallest idle one OF THE SECOND SET grows (a finder slot given another
+                  // size here would be freed and allocated again by the finder's next call, and again here: 0.6 s per call at config 3's size)
             int small = -1;
             for (size_t i = 0; i < idle.size(); i++)
-                if (idle[i] && (small < 0 || idle[i]->cap < idle[(size_t)small]->cap)) small = (int)i;
-            if (small < 0) return hipErrorOutOfMemory;
+                if (idle[i] && idle[i] >= &c->ingest_scratch[0] && idle[i] <= &c->ingest_scratch[11] &&
+                    (small < 0 || idle[i]->cap < idle[(size_t)small]->cap))
+                    small = (int)i;
+            if (small < 0) {  // (every block of the second set is handed out: a block of this call's own)
+                void* q = nullptr;
+                const hipError_t e = hipMalloc(&q, need);
+                if (e != hipSuccess) return e;
+                mine.push_back(q);
+                *p = q;
+                how = "a block of this call's own (hipMalloc + hipFree)";
+                return hipSuccess;
+            }
             sl = idle[(size_t)small];
             idle[(size_t)small] = nullptr;
+            how = "the smallest idle block of the second set regrown (hipFree + hipMalloc)";
             (void)hipFree(sl->p);
             sl->p = nullptr;
             sl->cap = 0;
@@ -372,7 +398,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
     d_r1.p = c->d_found;
     if (batches.size() > 1) {  // every batch is sorted; one more sort (key, position) + gather for the global order
         // the batches' buffers are idle now: they hold the keys and positions of this sort when they are large enough
-        DevBuf own[5];  // what they cannot hold; freed on every return path
+        DevBuf own[4];  // what they cannot hold; freed on every return path
         auto room = [&](const DevBuf& idle, size_t bytes, DevBuf& fallback, void** p) -> hipError_t {
             if (idle.slot && idle.slot->cap >= bytes) {
                 *p = idle.slot->p;
@@ -390,7 +416,13 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
         HC_HIP(hc::finder_rekey((const hc_sfo_rec*)acc.p, R, (uint64_t*)sk0, (uint64_t*)si0, st));
         size_t b = 0;
         HC_HIP(hc::finder_sort_pairs(nullptr, b, (uint64_t*)sk0, (uint64_t*)sk1, (uint64_t*)si0, (uint64_t*)si1, R, 64, st));
-        HC_HIP(room(d_pos, b, own[4], &stmp));
+        if (d_pos.slot && d_pos.slot->cap >= b) {
+            stmp = d_pos.slot->p;
+        } else {  // (a gigabyte at config 3's size: one more grow-only slot, not a block of this call's own)
+            DevBuf d_stmp;
+            HC_ALLOC(d_stmp, b);
+            stmp = d_stmp.p;
+        }
         HC_HIP(hc::finder_sort_pairs(stmp, b, (uint64_t*)sk0, (uint64_t*)sk1, (uint64_t*)si0, (uint64_t*)si1, R, 64, st));
         HC_HIP(hc::finder_gather((const hc_sfo_rec*)acc.p, (const uint64_t*)si1, R, (hc_sfo_rec*)d_r1.p, st));
         HC_HIP(hipStreamSynchronize(st));
