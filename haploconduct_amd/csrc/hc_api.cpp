@@ -202,6 +202,8 @@ int hc_destroy(hc_ctx* c) {
         if (c->h_ingest[t]) (void)hipHostFree(c->h_ingest[t]);
         if (c->graph.stage_free[t]) (void)hipEventDestroy(c->graph.stage_free[t]);
     }
+    for (void* h : c->h_sfo_text)
+        if (h) (void)hipHostFree(h);
     for (hipStream_t s : c->text_copy_stream)
         if (s) (void)hipStreamDestroy(s);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -2,10 +2,13 @@
 // (SURVEY.md §8(f4)); kernels in hc_overlap_finder.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -720,8 +723,8 @@ int hc_set_found_records(hc_ctx* c, const hc_sfo_rec* recs, uint64_t n) {
     return HC_OK;
 }
 
-// The SFO FILE's text in the finder's place, read on the device (round 6): 64 MiB chunks of the text (cut behind a newline) go to the device as
-// they are — two buffers, the copy of chunk k + 1 beside the kernels of chunk k — and every chunk's lines (the overlaps file's own line-start
+// The SFO FILE's text in the finder's place, read on the device (round 6): 32 MiB chunks of the text (cut behind a newline) go to the device as
+// they are — three stations, the copies of chunks k + 1, k + 2 beside the kernels of chunk k — and every chunk's lines (the overlaps file's own line-start
 // kernels, hc_text_kernels.hip) are read by one lane each (sfo_parse_text_kernel) into the context's found records at the place a chain of
 // line counters assigns.  A canonical file only — eight fields, single tabs, plain decimal numbers: what rust-overlaps writes; anything else:
 // HC_ERR_NOT_ON_DEVICE, and the host's general path (hc_sfo2overlaps' code) takes the file and owns its errors.
@@ -732,34 +735,13 @@ int hc_set_found_from_sfo_text(hc_ctx* c, const char* text, uint64_t n_bytes, ui
     HC_HIP(hipSetDevice(c->device));
     c->n_found = 0;
     c->found_valid = false;
-    // how many lines (= records): newlines counted on the host's threads, a last line without one counts too
-    unsigned T = std::thread::hardware_concurrency();
-    T = T == 0 ? 1 : (T > 32 ? 32 : T);
-    if (n_bytes / (8u << 20) + 1 < T) T = (unsigned)(n_bytes / (8u << 20) + 1);
-    std::vector<uint64_t> part(T, 0);
-    {
-        std::vector<std::thread> th;
-        auto body = [&](unsigned t) {
-            const char* b = text + n_bytes * t / T;
-            const char* e = text + n_bytes * (t + 1) / T;
-            uint64_t k = 0;
-            while (b < e) {
-                const char* nl = (const char*)memchr(b, '\n', (size_t)(e - b));
-                if (!nl) break;
-                k++;
-                b = nl + 1;
-            }
-            part[t] = k;
-        };
-        for (unsigned t = 1; t < T; t++) th.emplace_back(body, t);
-        body(0);
-        for (auto& x : th) x.join();
-    }
-    uint64_t lines = 0;
-    for (uint64_t k : part) lines += k;
-    if (n_bytes && text[n_bytes - 1] != '\n') lines++;
-    if (lines >= 0x7FFFFFF0ull) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (2^31 lines and more)");
-    if (lines == 0) {
+    // room for the records: a canonical line has 16 bytes and more ("0\t0\tN\t0\t0\t0\t0\t0\n"), so n_bytes / 16 + 1 bounds their number — a file
+    // with more lines is not canonical and the parse kernel says so (out_cap).  The lines themselves are counted on the device, chunk by
+    // chunk (the line chain).  (Round 6's first form counted the newlines on the host's threads first: 15 ms at config 3's size, in
+    // front of the first copy.)
+    const uint64_t lines = n_bytes / 16 + 1;
+    if (lines >= 0x7FFFFFF0ull) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (34 GB of text and more)");
+    if (n_bytes == 0) {
         c->found_err = -1;
         c->found_min = 0;
         c->found_flags = 0;
@@ -773,18 +755,25 @@ int hc_set_found_from_sfo_text(hc_ctx* c, const char* text, uint64_t n_bytes, ui
         HC_HIP(hipMalloc((void**)&c->d_found, lines * sizeof(hc_sfo_rec)));
         c->found_cap = lines;
     }
-    const uint64_t C = 64ull << 20;            // bytes per chunk
+    // Chunks of 32 MiB, three stations (a page-locked host buffer the context keeps, a device buffer, line-start arrays, counters, events):
+    // the host's threads copy chunk k out of the caller's (pageable, usually mapped-file) memory into station k % 3's page-locked buffer —
+    // in parallel slices: one thread through the runtime's own staging moved 27 GB/s at config 3's size —, the copy stream takes it to the
+    // device, the kernels of chunk k follow on the context's stream; chunk k + 1 is being copied out meanwhile.
+    const uint64_t C = 32ull << 20;            // bytes per chunk
+    constexpr int kStations = 3;
     const uint32_t max_lines = (uint32_t)(C / 16 + 2);  // (a canonical line has 16 bytes and more; a chunk with more lines is not canonical: overflow -> status)
     const uint32_t n_tiles = (uint32_t)(C / 4096 + 2);
     const uint64_t n_chunks_max = n_bytes / (C / 2) + 2;
+    for (int k = 0; k < kStations; k++)
+        if (!c->h_sfo_text[k]) HC_HIP(hipHostMalloc(&c->h_sfo_text[k], C + 64, hipHostMallocDefault));
     struct Bufs {
-        char* text[2] = {nullptr, nullptr};
-        uint32_t *tile_cnt[2] = {nullptr, nullptr}, *tile_off[2] = {nullptr, nullptr}, *line_start[2] = {nullptr, nullptr};
-        unsigned long long *counters[2] = {nullptr, nullptr}, *chain = nullptr, *status = nullptr;
-        hipEvent_t copied[2] = {nullptr, nullptr}, parsed[2] = {nullptr, nullptr};
+        char* text[kStations] = {};
+        uint32_t *tile_cnt[kStations] = {}, *tile_off[kStations] = {}, *line_start[kStations] = {};
+        unsigned long long *counters[kStations] = {}, *chain = nullptr, *status = nullptr;
+        hipEvent_t copied[kStations] = {}, parsed[kStations] = {};
         hipStream_t copy = nullptr;
         ~Bufs() {
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < kStations; k++) {
                 if (text[k]) (void)hipFree(text[k]);
                 if (tile_cnt[k]) (void)hipFree(tile_cnt[k]);
                 if (tile_off[k]) (void)hipFree(tile_off[k]);
@@ -798,7 +787,7 @@ int hc_set_found_from_sfo_text(hc_ctx* c, const char* text, uint64_t n_bytes, ui
             if (copy) (void)hipStreamDestroy(copy);
         }
     } b;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kStations; k++) {
         HC_HIP(hipMalloc((void**)&b.text[k], C + 64));
         HC_HIP(hipMalloc((void**)&b.tile_cnt[k], (size_t)n_tiles * 4));
         HC_HIP(hipMalloc((void**)&b.tile_off[k], (size_t)n_tiles * 4));
@@ -814,18 +803,88 @@ int hc_set_found_from_sfo_text(hc_ctx* c, const char* text, uint64_t n_bytes, ui
     HC_HIP(hipMemsetAsync(b.chain, 0, sizeof(unsigned long long), st));
     HC_HIP(hipMemsetAsync(b.status, 0, sizeof(unsigned long long), st));
     HC_HIP(hipStreamSynchronize(st));
+    // the copiers: T - 1 threads beside the caller's, one slice of the chunk each (HC_SFO_COPY_THREADS; 1: the caller's thread alone)
+    struct Copiers {
+        std::vector<std::thread> th;
+        std::mutex m;
+        std::condition_variable go, done;
+        const char* src = nullptr;
+        char* dst = nullptr;
+        size_t len = 0;
+        unsigned T = 1, gen = 0, pending = 0;
+        bool stop = false;
+        static void slice(const char* src, char* dst, size_t len, unsigned t, unsigned T) {
+            const size_t a = (len * t / T) & ~(size_t)63, e = t + 1 == T ? len : (len * (t + 1) / T) & ~(size_t)63;
+            if (e > a) memcpy(dst + a, src + a, e - a);
+        }
+        void start(unsigned threads) {
+            T = threads < 1 ? 1 : threads;
+            for (unsigned t = 1; t < T; t++)
+                th.emplace_back([this, t] {
+                    unsigned seen = 0;
+                    for (;;) {
+                        std::unique_lock<std::mutex> lk(m);
+                        go.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        const char* s_ = src;
+                        char* d_ = dst;
+                        const size_t n_ = len;
+                        lk.unlock();
+                        slice(s_, d_, n_, t, T);
+                        lk.lock();
+                        if (--pending == 0) done.notify_one();
+                    }
+                });
+        }
+        void copy(const char* s_, char* d_, size_t n_) {
+            if (T == 1 || n_ < (1u << 20)) {
+                memcpy(d_, s_, n_);
+                return;
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                src = s_;
+                dst = d_;
+                len = n_;
+                pending = T - 1;
+                gen++;
+            }
+            go.notify_all();
+            slice(s_, d_, n_, 0, T);
+            std::unique_lock<std::mutex> lk(m);
+            done.wait(lk, [&] { return pending == 0; });
+        }
+        ~Copiers() {
+            {
+                std::lock_guard<std::mutex> lk(m);
+                stop = true;
+            }
+            go.notify_all();
+            for (auto& x : th) x.join();
+        }
+    } copiers;
+    {
+        unsigned T = std::thread::hardware_concurrency();
+        T = T == 0 ? 1 : (T > 16 ? 16 : T);
+        if (const char* e = getenv("HC_SFO_COPY_THREADS")) T = (unsigned)std::max(1, std::min(64, atoi(e)));
+        if (n_bytes < (8u << 20)) T = 1;
+        copiers.start(T);
+    }
     uint64_t pos = 0, k = 0;
     while (pos < n_bytes) {
         uint64_t len = n_bytes - pos < C ? n_bytes - pos : C;
         if (pos + len < n_bytes) {  // cut behind the last newline of the stretch
             const void* nl = memrchr(text + pos, '\n', (size_t)len);
-            if (!nl) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (a line of 64 MiB and more)");
+            if (!nl) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (a line of 32 MiB and more)");
             len = (uint64_t)((const char*)nl - (text + pos)) + 1;
         }
         if (k >= n_chunks_max) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (more chunks than planned)");
-        const int j = (int)(k & 1);
-        if (k >= 2) HC_HIP(hipStreamWaitEvent(b.copy, b.parsed[j], 0));  // the buffer's previous chunk has been read
-        HC_HIP(hipMemcpyAsync(b.text[j], text + pos, len, hipMemcpyHostToDevice, b.copy));
+        const int j = (int)(k % kStations);
+        if (k >= (uint64_t)kStations) HC_HIP(hipEventSynchronize(b.copied[j]));  // the station's host buffer has left for the device
+        copiers.copy(text + pos, (char*)c->h_sfo_text[j], (size_t)len);
+        if (k >= (uint64_t)kStations) HC_HIP(hipStreamWaitEvent(b.copy, b.parsed[j], 0));  // the station's device buffer has been read
+        HC_HIP(hipMemcpyAsync(b.text[j], c->h_sfo_text[j], len, hipMemcpyHostToDevice, b.copy));
         HC_HIP(hipEventRecord(b.copied[j], b.copy));
         HC_HIP(hipStreamWaitEvent(st, b.copied[j], 0));
         HC_HIP(hc::launch_text_count(b.text[j], len, b.tile_cnt[j], st));
@@ -841,13 +900,13 @@ int hc_set_found_from_sfo_text(hc_ctx* c, const char* text, uint64_t n_bytes, ui
     HC_HIP(hipMemcpyAsync(&total, b.chain + k, sizeof total, hipMemcpyDeviceToHost, st));
     HC_HIP(hipStreamSynchronize(st));
     HC_HIP(hipStreamSynchronize(b.copy));
-    if (status || total != lines) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (a line that is not canonical)");
-    c->n_found = lines;
+    if (status || total > lines) return fail(HC_ERR_NOT_ON_DEVICE, "hc_set_found_from_sfo_text: not on the device (a line that is not canonical)");
+    c->n_found = total;
     c->found_err = -1;
     c->found_min = 0;
     c->found_flags = 0;
     c->found_valid = true;
-    if (n_records) *n_records = lines;
+    if (n_records) *n_records = total;
     return HC_OK;
 }
 

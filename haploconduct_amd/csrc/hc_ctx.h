@@ -137,6 +137,7 @@ struct hc_ctx {
     } finder_scratch[24], ingest_scratch[12];  // the second set: hc_found_to_overlaps
     void* h_ingest[2] = {nullptr, nullptr};  // page-locked ring hc_found_to_overlaps copies the sorted records through
     size_t h_ingest_cap = 0;                  // bytes of each
+    void* h_sfo_text[3] = {nullptr, nullptr, nullptr};  // page-locked stations of hc_set_found_from_sfo_text (32 MiB + 64 each), kept
     hc_sfo_rec* d_found = nullptr;  // grow-only (round 6): room for found_cap records, n_found of them valid
     uint64_t found_cap = 0;
     uint64_t n_found = 0;

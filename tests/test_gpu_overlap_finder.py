@@ -83,6 +83,34 @@ def test_wide_and_16_bit_symbol_stores_give_the_same_overlaps():
         assert got == want and len(want) > 50
 
 
+def test_one_context_takes_read_set_after_read_set(tmp_path):
+    """A context keeps its grow-only scratch from read set to read set (hc_set_reads, round 6: a pipeline's stages on parked devices): a
+    large set, a small one, a wide-alphabet one and the large one again on ONE context — finder records and the ingest's overlaps file each
+    time equal to a fresh context's."""
+    sets = [make_reads(41, n_single=400, n_pair=300, glen=4000, lo=80, hi=250, err=0.004),
+            make_reads(42, n_single=12, n_pair=0, glen=500, lo=60, hi=120, err=0.0),
+            make_reads(43, n_single=60, n_pair=90, glen=1500, lo=60, hi=140, err=0.01)]
+    rng = np.random.default_rng(8)
+    sets[2].quals = (33 + rng.integers(0, 40, sets[2].quals.size)).astype(np.uint8)
+    order = [0, 1, 2, 0, 1]
+
+    def run(sc, reads, out):
+        sc.set_reads(reads)
+        recs = as_tuples(sc.find_overlaps(0.02, 50))
+        n_s = sum(1 for r in range(reads.n_reads) if not reads.is_paired(r))
+        n_lines = sc.found_to_overlaps(out, n_s, reads.n_reads - n_s)
+        return recs, n_lines, open(out, "rb").read()
+
+    fresh = []
+    for k in range(3):
+        with hc.EdgeScorer(hc.Settings()) as sc:
+            fresh.append(run(sc, sets[k], str(tmp_path / f"fresh{k}.txt")))
+    assert len(fresh[0][0]) > 2000 and len(fresh[1][0]) < len(fresh[2][0]) < len(fresh[0][0])
+    with hc.EdgeScorer(hc.Settings()) as sc:
+        for i, k in enumerate(order):
+            assert run(sc, sets[k], str(tmp_path / f"one{i}.txt")) == fresh[k], (i, k)
+
+
 def test_argument_errors():
     reads = make_reads(5, n_single=4, n_pair=0, glen=300, lo=60, hi=100, err=0.0)
     with hc.EdgeScorer(hc.Settings()) as sc:
