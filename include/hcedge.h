@@ -173,7 +173,9 @@ int hc_reset(hc_ctx* ctx, const hc_settings* settings);
  *   read_first_seq : n_reads+1; read r owns sequences [read_first_seq[r], read_first_seq[r+1]):
  *                  one (single-end) or two (/1, /2 of a pair)
  * Buffers are borrowed until return; the store (both orientations, re-encoded)
- * lives in HBM until hc_destroy or the next hc_set_reads. */
+ * lives in HBM until hc_destroy or the next hc_set_reads.  The grow-only scratch earlier calls of hc_find_overlaps and of the SFO ingest
+ * left on the context (gigabytes at config 3's size) stays through hc_set_reads and hc_reset — it is capacity for the next read set; only
+ * hc_destroy returns it (round 6: giving it back per read set made one hipMalloc in three take 0.8 s, profiles/r06_stage_a_from_store.md). */
 int hc_set_reads(hc_ctx* ctx, const uint8_t* bases, const uint8_t* quals, const uint64_t* seq_off,
                  const uint32_t* read_first_seq, uint32_t n_reads);
 
