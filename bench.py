@@ -964,10 +964,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3")
-    ap.add_argument("--also", default="c2,c3q25,c3q35,c3q35r,c3q60",
+    ap.add_argument("--also", default="c2,c3q25,c3q35,c3q35r,c3q60,c3q70",
                     help="further workloads (comma-separated) measured on one GPU and reported under \"also\" ('none' = skip): config 2, and config 3 with "
-                         "25 / 35 / 60 distinct quality values (the LG = 5, wide 8-bit and 16-bit-symbol kernels at the headline's size; c3q35r: the 35 "
-                         "values drawn from the histogram of the reference's POLYTE example reads instead of uniformly)")
+                         "25 / 35 / 60 / 70 distinct quality values (the LG = 5 kernel, the two wide 8-bit encodings and the 16-bit-symbol kernel at the headline's "
+                         "size; c3q35r: the 35 values drawn from the histogram of the reference's POLYTE example reads instead of uniformly)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="N > 1: strong (default) = the workload's ONE candidate set is split over the ranks (BASELINE configs[2]); "
                          "weak = every rank scores its own candidate set of the workload's size")

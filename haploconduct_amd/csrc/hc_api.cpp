@@ -222,8 +222,8 @@ static bool build_lut(const std::vector<int>& phred, const std::vector<int>& wid
     const double inf = std::numeric_limits<double>::infinity();
     const double nan = std::numeric_limits<double>::quiet_NaN();
     const uint32_t lg = hc::lut_lg((uint32_t)K);
-    const bool wide = symbytes == 1 && lg == 6;
-    const size_t dim = symbytes == 1 ? ((size_t)1 << lg) : Kp;  // rows / columns that can be addressed
+    const bool wide = symbytes == 1 && lg >= 6;
+    const size_t dim = symbytes == 1 ? (wide ? (size_t)64 : ((size_t)1 << lg)) : Kp;  // rows / columns that can be addressed
     lut.assign(symbytes == 1 ? (size_t)hc::lut_doubles_u8(lg) : (size_t)hc::lut_tri((uint32_t)Kp) * 2, nan);
     bool symmetric = true;  // the 16-bit layout keeps one triangle: every (a, b) must equal (b, a) bit for bit
     for (size_t a = 0; a < dim; a++) {
@@ -341,9 +341,11 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
             }
         }
         phred.assign(Kq, 0);
-        if (hc::sym_bytes_for(Kq) == 1 && hc::lut_lg(Kq) == 6) {
-            // the wide 8-bit encoding (hc_device.h): indices 16..63, the r-th most frequent value takes kWideRankLabel[r] — the table's rows
-            // are addressed by them, nothing else depends on the assignment (HC_QIDX_ORDER=value: 16 + the value's rank by byte)
+        if (hc::sym_bytes_for(Kq) == 1 && hc::lut_lg(Kq) >= 6) {
+            // the wide 8-bit encodings (hc_device.h): indices 16..63 (up to 48 values) or 4..63 (up to 60), the r-th most frequent value takes
+            // kWideRankLabel[r] / kWide7RankLabel[r] — the table's rows are addressed by them, nothing else depends on the assignment
+            // (HC_QIDX_ORDER=value: the first index + the value's rank by byte)
+            const bool seven = hc::lut_lg(Kq) == 7;
             std::vector<uint32_t> by_freq(Kq);
             for (uint32_t k = 0; k < Kq; k++) by_freq[k] = k;
             if (!(qo && strcmp(qo, "value") == 0))
@@ -351,7 +353,8 @@ int hc_set_reads(hc_ctx* c, const uint8_t* bases, const uint8_t* quals, const ui
             wide_rows.assign(64, -2);
             wide_rows[hc::kWideN] = -1;
             for (uint32_t r = 0; r < Kq; r++) {
-                const uint32_t label = (qo && strcmp(qo, "value") == 0) ? hc::kWideFirst + r : hc::kWideRankLabel[r];
+                const uint32_t label = (qo && strcmp(qo, "value") == 0) ? hc::wide_first(seven ? 7u : 6u) + r
+                                                                        : (seven ? hc::kWide7RankLabel[r] : hc::kWideRankLabel[r]);
                 qmap[present[by_freq[r]]] = (uint8_t)label;
                 wide_rows[label] = present[by_freq[r]] - 33;
                 phred[by_freq[r]] = present[by_freq[r]] - 33;  // (K entries; the table is built from wide_rows)

@@ -216,7 +216,7 @@ int hc_find_overlaps(hc_ctx* c, double err_rate, uint32_t min_overlap, uint32_t 
                                                  : "hc_find_overlaps: err_rate too high for this min_overlap: an overlap need not contain 12 error-free positions in a row");
     const uint32_t k = w < 31 ? w : 31, s = w - k + 1;
     const uint32_t n_ori = (flags & HC_FIND_REVERSALS) ? 2u : 1u;
-    const bool wide = c->view.symbytes == 1 && hc::lut_lg(c->view.K) == 6;
+    const bool wide = c->view.symbytes == 1 && hc::lut_lg(c->view.K) >= 6;
     hipStream_t st = c->stream;
     unsigned n_slots = 0;  // HC_ALLOC takes the context's scratch slots in order
 

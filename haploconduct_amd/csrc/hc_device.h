@@ -23,7 +23,9 @@
 //   31 <= K <= 48 -> "wide" uint8 symbols  sym = (qidx << 2) | base2  (6-bit qidx, A,C,G,T = 0..3): the quality values take 48 of the
 //          indices 16..63 (dealt by frequency, kWideRankLabel below), the reserved indices are 0 = N, 1 = invalid quality,
 //          2 = invalid base — recognisable by their two CLEAR top bits: (sym << 1 | sym) has bit 7 set for a base, one VALU op;
-//   K > 48 -> uint16 symbols  (qidx << 3) | code.
+//   49 <= K <= 60 -> the same symbols with the quality values in indices 4..63 (kWide7RankLabel): a base has one of its top FOUR bits
+//          set, two VALU ops per stream — one byte per position where round 5 spent two;
+//   K > 60 -> uint16 symbols  (qidx << 3) | code.
 //   Slots are padded with N symbols to a multiple of 16 bytes plus 32 bytes, so chunked
 //   (16-symbol) loads may over-read safely.
 #pragma once
@@ -113,27 +115,35 @@ struct StoreView {
 //                   byte address = (m*T + hi*(hi+1)/2 + lo) * 8, hi/lo = larger/smaller of (qa, qb), T = Kp*(Kp+1)/2
 //                   (entry index < 2*4753 fits 16 bits: two positions per packed-16-bit VALU op).  Half the LDS of
 //                   the square layout: 31 KiB for 60 quality values, 74 KiB for the full Phred range.
-constexpr uint32_t kWideN = 0, kWideBadQual = 1, kWideBadBase = 2;  // reserved qidx of the wide 8-bit encoding (all below kWideFirst)
-constexpr uint32_t kWideFirst = 16, kWideMaxK = 48;                  // quality values take indices kWideFirst .. 63
+constexpr uint32_t kWideN = 0, kWideBadQual = 1, kWideBadBase = 2;  // reserved qidx of the wide 8-bit encodings (index 3 is never dealt)
+constexpr uint32_t kWideFirst = 16, kWideMaxK = 48;                  // LG = 6: quality values take indices 16 .. 63 (a base: top TWO index bits not both clear)
+constexpr uint32_t kWide7First = 4, kWide7MaxK = 60;                 // LG = 7: 49 .. 60 values take indices 4 .. 63 (a base: top FOUR index bits not all clear)
 // The index of the r-th most frequent quality value of a read set (wide encoding).  Any one-to-one assignment gives the same results
 // (symbols and table are built from the same map); this one was searched (round 6, tools/experiments/r06_wide_labels.py) so that the
 // (qa, qb) pairs of the few values that make up most of real reads' qualities fall into different LDS banks under the table's address
 // mix (lut_addr_u8): simulated LDS cycles per 32-lane group of table reads 2.3 against 4.2 (POLYTE example), 1.4 against 2.7 (SAVAGE).
 constexpr uint8_t kWideRankLabel[kWideMaxK] = {33, 25, 45, 21, 28, 44, 48, 36, 39, 20, 50, 32, 16, 63, 26, 40, 34, 24, 35, 37, 62, 54, 27, 55,
                                                17, 59, 46, 42, 58, 43, 30, 41, 38, 19, 61, 56, 29, 53, 31, 47, 23, 49, 18, 60, 51, 52, 57, 22};
-// LG: log2 of the 8-bit-symbol table dimension; 6 selects the wide encoding.
-__host__ __device__ inline uint32_t lut_lg(uint32_t K) { return K + 2 <= 8 ? 3u : (K + 2 <= 16 ? 4u : (K + 2 <= 32 ? 5u : 6u)); }
-__host__ __device__ inline uint32_t sym_bytes_for(uint32_t K) { return K <= kWideMaxK ? 1u : 2u; }
+constexpr uint8_t kWide7RankLabel[kWide7MaxK] = {8,  15, 4,  19, 24, 35, 49, 31, 6,  42, 20, 9,  61, 37, 18, 58, 16, 22, 23, 21,
+                                                 45, 33, 54, 14, 25, 5,  47, 12, 57, 7,  43, 38, 63, 34, 28, 50, 27, 51, 44, 10,
+                                                 26, 29, 11, 32, 60, 40, 39, 56, 13, 46, 36, 55, 17, 62, 53, 59, 52, 48, 41, 30};
+// LG: log2 of the 8-bit-symbol table dimension; 6 and 7 select the wide encodings (both: 64 x 64 x 2 entries, 64 KiB).  (More than 60 values:
+// 16-bit symbols, for which the value is not used.)
+__host__ __device__ inline uint32_t lut_lg(uint32_t K) {
+    return K + 2 <= 8 ? 3u : (K + 2 <= 16 ? 4u : (K + 2 <= 32 ? 5u : (K <= kWideMaxK ? 6u : (K <= kWide7MaxK ? 7u : 6u))));
+}
+__host__ __device__ inline uint32_t wide_first(uint32_t lg) { return lg == 7 ? kWide7First : kWideFirst; }
+__host__ __device__ inline uint32_t sym_bytes_for(uint32_t K) { return K <= kWide7MaxK ? 1u : 2u; }
 __host__ __device__ inline uint32_t lut_tri(uint32_t Kp) { return Kp * (Kp + 1u) / 2u; }
 __host__ __device__ inline uint32_t lut_addr_u16(uint32_t Kp, uint32_t qa, uint32_t qb, uint32_t m) {
     const uint32_t hi = qa > qb ? qa : qb, lo = qa > qb ? qb : qa;
     return (m * lut_tri(Kp) + hi * (hi + 1u) / 2u + lo) * 8u;
 }
 // doubles of the 8-bit-symbol table as laid out in LDS
-__host__ __device__ inline uint32_t lut_doubles_u8(uint32_t lg) { return lg == 3 ? 2048u : (2u << (2 * lg)); }
+__host__ __device__ inline uint32_t lut_doubles_u8(uint32_t lg) { return lg == 3 ? 2048u : (lg >= 6 ? 8192u : (2u << (2 * lg))); }
 __host__ __device__ inline uint32_t lut_addr_u8(uint32_t lg, uint32_t qa, uint32_t qb, uint32_t m) {
     if (lg == 3) return (qa << 11) | (m << 10) | ((qa & 3u) << 6) | (((qb ^ qa) & 7u) << 3);
-    if (lg == 6) return (m << 15) | (qa << 9) | ((((qb ^ qa) >> 5) & 1u) << 8) | ((((qb ^ qa) ^ (qa >> 1)) & 31u) << 3);
+    if (lg >= 6) return (m << 15) | (qa << 9) | ((((qb ^ qa) >> 5) & 1u) << 8) | ((((qb ^ qa) ^ (qa >> 1)) & 31u) << 3);
     return m * (8u << (2 * lg)) + qa * (8u << lg) + ((qb ^ qa) & ((1u << lg) - 1u)) * 8u;
 }
 

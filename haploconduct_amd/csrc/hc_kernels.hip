@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void encode_store_kernel(const uint8_t* __rest
                     if (code == kCodeN) qx = kWideN;
                     if (code == kCodeBadBase) qx = kWideBadBase;
                     if (qi == 255) { qx = kWideBadQual; b2 = 0; }  // quality outside [33,127]: always fatal inside an overlap
-                    const uint32_t rb2 = qx >= kWideFirst ? 3u - b2 : 0u;
+                    const uint32_t rb2 = qx >= wide_first(lut_lg(K)) ? 3u - b2 : 0u;
                     sym[f0 + i] = (SymT)((qx << 2) | b2);
                     sym[rc0 + (len - 1 - i)] = (SymT)((qx << 2) | rb2);
                 } else {
@@ -194,7 +194,7 @@ __device__ __noinline__ SubScore score_sub_slow(const SymT* __restrict__ a, cons
     r.mm = 1;
     r.n = 1;
     r.err = 0;
-    const bool wide = sizeof(SymT) == 1 && lg == 6;
+    const bool wide = sizeof(SymT) == 1 && lg >= 6;
     // kind of a symbol: 0 = base, 1 = N, 2 = invalid quality, 3 = invalid base
     auto kind = [&](uint32_t sy) -> uint32_t {
         if (wide) {
@@ -252,12 +252,16 @@ __device__ __forceinline__ void half_chunk_terms(const uint32_t* wa, const uint3
         const uint32_t aw = wa[jj];
         const uint32_t bw = wb[jj];
         const uint32_t e = aw ^ bw;
-        if (sizeof(SymT) == 1 && LG == 6) {
-            // wide 8-bit encoding: byte = qidx << 2 | base2; qidx < 16 (both top bits clear) is N / invalid.
+        if (sizeof(SymT) == 1 && LG >= 6) {
+            // wide 8-bit encoding: byte = qidx << 2 | base2; qidx < 16 (both top bits clear; LG = 7: qidx < 4, all four top bits clear) is N / invalid.
             // address (hc_device.h: lut_addr_u8) = m << 15 | qa << 9 | x5 << 8 | ((x & 31) ^ (qa >> 1)) << 3, x = qa ^ qb.
             // 23 VALU ops per four positions (round 5's form: 28): the three-input ops written out, the counters kept in one v_bcnt each.
             constexpr uint32_t k80 = 0x80808080u;
-            const uint32_t ua = (aw << 1) | aw, ub = (bw << 1) | bw;                    // bit 7 of a byte: the symbol is a base
+            uint32_t ua = (aw << 1) | aw, ub = (bw << 1) | bw;                          // bit 7 of a byte: the symbol is a base
+            if (LG == 7) {  // (quality values in indices 4..63: two more of the top bits count)
+                ua |= ua << 2;
+                ub |= ub << 2;
+            }
             const uint32_t nm = __builtin_amdgcn_bitop3_b32(ua, k80, ub, 0x4C);         // ~(ua & ub) & k80
             const uint32_t mk = __builtin_amdgcn_bitop3_b32((e << 7) | (e << 6), k80, nm, 0x40);  // base bits differ, neither is N
             asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cn4) : "v"(nm));
@@ -320,7 +324,7 @@ template <typename SymT, int LG, int G /* 16-symbol chunks per group */>
 __device__ __forceinline__ void score_sub_wide(const SymT* __restrict__ a, const SymT* __restrict__ b, uint32_t L, uint32_t fatal,
                                                uint32_t Kp, SubScore& out) {
     using T = Tr<SymT>;
-    constexpr bool kPacked = !(sizeof(SymT) == 1 && LG == 6);  // per-byte counters (half_chunk_terms)
+    constexpr bool kPacked = !(sizeof(SymT) == 1 && LG >= 6);  // per-byte counters (half_chunk_terms)
     out.x = -__builtin_inf();
     out.mm = 1;
     out.n = 1;
@@ -434,8 +438,8 @@ __device__ __forceinline__ void wave_lds_order() {  // keeps the compiler from r
 constexpr uint32_t kStageBytesPerWave = 64u * 64u;
 // LDS of the cooperative kernel: [table][scratch: 32 words][pad to 1 KiB][one image per wave]
 // The wide 8-bit table's LDS-DMA form (768 lanes: 64 KiB + 12 x 8 KiB = all 160 KiB) keeps the scratch words INSIDE the table, in a row no
-// symbol addresses (quality indices 3..15 are never encoded, hc_device.h: rows 3..15 of either plane are holes of 512 bytes each).
-constexpr uint32_t kWideDmaLanes = 768, kWideDmaScratch = 4u << 9;  // row 4 of the match plane
+// symbol addresses (quality index 3 is never encoded, hc_device.h: row 3 of either plane is a hole of 512 bytes; LG = 6 leaves 3..15 free).
+constexpr uint32_t kWideDmaLanes = 768, kWideDmaScratch = 3u << 9;  // row 3 of the match plane (index 3: dealt by neither wide encoding)
 __host__ __device__ inline uint32_t coop_stage_base(uint32_t lut_bytes, uint32_t wg) {
     return (lut_bytes == 65536u && wg == kWideDmaLanes) ? 65536u : (lut_bytes + 128u + 1023u) & ~1023u;
 }
@@ -481,7 +485,7 @@ __device__ __forceinline__ void score_sub_coop(__amdgpu_buffer_rsrc_t rsrc, uint
     constexpr uint32_t kSymB = sizeof(SymT);
     constexpr int kChunks = 4 / kSymB;            // 16-symbol chunks per 64-byte row
     constexpr uint32_t kChunkB = 16u * kSymB;     // bytes per chunk
-    constexpr bool kPacked = !(sizeof(SymT) == 1 && LG == 6);
+    constexpr bool kPacked = !(sizeof(SymT) == 1 && LG >= 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t piece = (lane & 3u) ^ ((lane >> 4) & 3u);   // of the row, as a loader
     const uint32_t Lb = L * kSymB;
@@ -1290,7 +1294,7 @@ __global__ __launch_bounds__(WG, DEPTH == 2 ? 2 : (WG == 256 ? 4 : (WG == 512 ? 
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lut_s != 0u) __builtin_trap();  // lds_f64 relies on it
     const uint32_t lut_n = st.lut_bytes >> 3;
     load_log_table<SymT, LG>(lut_s, lut_g, lut_n, threadIdx.x, WG);
-    constexpr bool kScratchInTable = sizeof(SymT) == 1 && LG == 6 && WG == (int)kWideDmaLanes;  // (coop_stage_base)
+    constexpr bool kScratchInTable = sizeof(SymT) == 1 && LG >= 6 && WG == (int)kWideDmaLanes;  // (coop_stage_base)
     uint32_t* scratch = kScratchInTable ? (uint32_t*)((char*)lut_s + kWideDmaScratch) : (uint32_t*)(lut_s + lut_n);  // row append: [0..17]; segment mode: [24] the workgroup's row counter
     if (kScratchInTable) __syncthreads();  // the table's loaders have written the hole before its words are set
     const uint32_t seg_counter = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(scratch + 24);
@@ -1524,7 +1528,7 @@ hipError_t launch_encode(uint32_t symbytes, const uint8_t* bases, const uint8_t*
     const uint32_t waves_per_block = 4;
     uint32_t blocks = (n_seq + waves_per_block - 1) / waves_per_block;
     if (blocks > 65536) blocks = 65536;
-    if (symbytes == 1 && lut_lg(K) == 6)
+    if (symbytes == 1 && lut_lg(K) >= 6)
         hipLaunchKernelGGL((encode_store_kernel<uint8_t, true>), dim3(blocks), dim3(256), 0, stream, bases, quals, raw_off,
                            seq_off, rc_delta, qmap, n_seq, K, (uint8_t*)sym, seq_bad, slot_align);
     else if (symbytes == 1)
@@ -1559,7 +1563,7 @@ struct ScoreLaunch {
 template <typename SymT, int G, int LG>
 void launch_one(const ScoreLaunch& a) {
     if (a.wg == 512) {
-        if constexpr (sizeof(SymT) == 1 && LG == 6)
+        if constexpr (sizeof(SymT) == 1 && LG >= 6)
             hipLaunchKernelGGL((score_kernel_wide_wg<SymT, G, LG>), dim3(a.blocks), dim3(512), a.lds, a.stream, a.st, a.prm, a.lut_g,
                                a.in, a.n, a.out, a.perm, a.sink);
         return;
@@ -1691,7 +1695,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                 // the wide 8-bit table (64 KiB) in the LDS-DMA form: 12 waves per CU instead of the register-staged form's 16 (round 6;
                 // HC_WIDE_DMA=0: the register-staged form, the A/B knob)
                 uint32_t steps = 1;
-                if (wide_dma_wanted() && coop_dma_wanted() && n >= coop_dma_min() && !bucketed && st.symbytes == 1 && lg == 6 && st.lut_bytes == 65536u &&
+                if (wide_dma_wanted() && coop_dma_wanted() && n >= coop_dma_min() && !bucketed && st.symbytes == 1 && lg >= 6 && st.lut_bytes == 65536u &&
                     wave_queue_on(&steps) && !(rows && !segmented)) {
                     const uint64_t blocks_w = std::min<uint64_t>((n + kWideDmaLanes - 1) / kWideDmaLanes, n_cu);
                     ScoreParams pq = prm;
@@ -1701,8 +1705,12 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
                         const hipError_t ze = zero_header();
                         if (ze != hipSuccess) return ze;
                     }
-                    hipLaunchKernelGGL((score_kernel_coop<uint8_t, 6, (int)kWideDmaLanes, true, false, 0, true>), dim3((uint32_t)blocks_w), dim3(kWideDmaLanes),
-                                       160 * 1024, stream, st, pq, lut_g, in, n, out, perm, sink, nullptr);
+                    if (lg == 6)
+                        hipLaunchKernelGGL((score_kernel_coop<uint8_t, 6, (int)kWideDmaLanes, true, false, 0, true>), dim3((uint32_t)blocks_w),
+                                           dim3(kWideDmaLanes), 160 * 1024, stream, st, pq, lut_g, in, n, out, perm, sink, nullptr);
+                    else
+                        hipLaunchKernelGGL((score_kernel_coop<uint8_t, 7, (int)kWideDmaLanes, true, false, 0, true>), dim3((uint32_t)blocks_w),
+                                           dim3(kWideDmaLanes), 160 * 1024, stream, st, pq, lut_g, in, n, out, perm, sink, nullptr);
                     compact_segments(blocks_w);
                     if (started_groups) *started_groups = (uint32_t)blocks_w;
                     return hipGetLastError();
@@ -1803,9 +1811,10 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
             if (st.symbytes == 2) {
                 if (wg_c == 256) launch_coop(uint16_t{}, std::integral_constant<int, 5>{}, W256{});
                 else launch_coop(uint16_t{}, std::integral_constant<int, 5>{}, W1024{});
-            } else if (lg == 6) {
+            } else if (lg >= 6) {
                 if (wg_c != 1024) return hipErrorInvalidConfiguration;  // (a 64 KiB table never leaves room for four workgroups)
-                launch_coop(uint8_t{}, std::integral_constant<int, 6>{}, W1024{});
+                if (lg == 6) launch_coop(uint8_t{}, std::integral_constant<int, 6>{}, W1024{});
+                else launch_coop(uint8_t{}, std::integral_constant<int, 7>{}, W1024{});
             } else {
                 if (wg_c != 256) return hipErrorInvalidConfiguration;   // (tables of at most 16 KiB always do)
                 if (lg == 3) launch_coop(uint8_t{}, std::integral_constant<int, 3>{}, W256{});
@@ -1825,7 +1834,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     if (by_lds < blocks_per_cu) blocks_per_cu = by_lds < 1 ? 1 : by_lds;
     // large table, few workgroups per CU: let 512 lanes share each table (measured, C4, 35 quality values, 64 KiB
     // table: 256 lanes 0.169 ms, 512 lanes 0.152 ms, 1 024 lanes 0.174 ms)
-    const uint32_t wg = (!st.balance && st.symbytes == 1 && lg == 6 && blocks_per_cu <= 2) ? 512u : 256u;
+    const uint32_t wg = (!st.balance && st.symbytes == 1 && lg >= 6 && blocks_per_cu <= 2) ? 512u : 256u;
     const size_t lds = lds_for(wg);
     const uint64_t per_wg = (uint64_t)wg * (st.balance ? kBalItems : 1);  // candidates per workgroup iteration
     uint64_t blocks = (n + per_wg - 1) / per_wg;
@@ -1840,7 +1849,8 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
     else if (lg == 3) launch_lg<uint8_t, 3>(fetch_group, a);
     else if (lg == 4) launch_lg<uint8_t, 4>(fetch_group, a);
     else if (lg == 5) launch_lg<uint8_t, 5>(fetch_group, a);
-    else launch_lg<uint8_t, 6>(fetch_group, a);
+    else if (lg == 6) launch_lg<uint8_t, 6>(fetch_group, a);
+    else launch_lg<uint8_t, 7>(fetch_group, a);
     return hipGetLastError();
 }
 
@@ -1848,7 +1858,7 @@ hipError_t launch_score(const StoreView& st, const ScoreParams& prm, const doubl
 std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane_fetch_group, uint32_t n_cu, uint64_t n) {
     const uint32_t lg = lut_lg(st.K);
     const std::string sym = st.symbytes == 2 ? "uint16_t" : "uint8_t";
-    const std::string enc = st.symbytes == 2 ? "u16" : (lg == 6 ? "wide8" : "packed8");
+    const std::string enc = st.symbytes == 2 ? "u16" : (lg >= 6 ? "wide8" : "packed8");
     char buf[640];
     if (fetch_group == 0) {
         const bool coop = st.store_bytes < 0xFFFF0000ull;
@@ -1866,12 +1876,12 @@ std::string describe_score_kernel(const StoreView& st, int fetch_group, int lane
                      (st.balance || (wg_c == 1024 && wave_queue_on(nullptr))) ? ", true" : "");
             const size_t lds_dma = coop_stage_base(st.lut_bytes, 1024) + 16 * 2 * kStageBytesPerWave;
             // the wide 8-bit table: its own LDS-DMA form, 768 lanes (launch_score)
-            if (!st.balance && st.symbytes == 1 && lg == 6 && st.lut_bytes == 65536u && wide_dma_wanted() && coop_dma_wanted() && wave_queue_on(nullptr) &&
+            if (!st.balance && st.symbytes == 1 && lg >= 6 && st.lut_bytes == 65536u && wide_dma_wanted() && coop_dma_wanted() && wave_queue_on(nullptr) &&
                 (n == 0 || n >= coop_dma_min())) {
-                snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, 6, %u, true, false, 0, true> encoding=%s table_bytes=%u lds_bytes=%u waves_per_cu=%u "
+                snprintf(buf, sizeof buf, "hc::score_kernel_coop<%s, %u, %u, true, false, 0, true> encoding=%s table_bytes=%u lds_bytes=%u waves_per_cu=%u "
                                           "LDS-DMA fetch for launches of %llu candidates and more (one workgroup per CU, the waves take their items from a "
                                           "ticket counter in LDS; the scratch words sit in an unaddressed row of the table); smaller launches: %s",
-                         sym.c_str(), kWideDmaLanes, enc.c_str(), st.lut_bytes, 160u * 1024u, kWideDmaLanes / 64u, (unsigned long long)coop_dma_min(), small);
+                         sym.c_str(), lg, kWideDmaLanes, enc.c_str(), st.lut_bytes, 160u * 1024u, kWideDmaLanes / 64u, (unsigned long long)coop_dma_min(), small);
                 return buf;
             }
             const bool dma = !st.balance && st.symbytes == 1 && lg <= 5 && lds_dma <= 160 * 1024 && coop_dma_wanted();
@@ -1907,7 +1917,7 @@ hipError_t set_lds_limit_lg() {
     }
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 2, LG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel<SymT, 2, LG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
-    if constexpr (sizeof(SymT) == 1 && LG == 6) {
+    if constexpr (sizeof(SymT) == 1 && LG >= 6) {
         if ((e = hipFuncSetAttribute((const void*)score_kernel_wide_wg<SymT, 4, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
         if ((e = hipFuncSetAttribute((const void*)score_kernel_wide_wg<SymT, 2, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     }
@@ -1927,6 +1937,7 @@ hipError_t set_score_kernel_lds_limit() {
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, LG_, 1024, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e; \
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, LG_, 1024, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 6, (int)kWideDmaLanes, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 7, (int)kWideDmaLanes, true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     HC_COOP_ATTR_DMA(3)
     HC_COOP_ATTR_DMA(4)
     HC_COOP_ATTR_DMA(5)
@@ -1934,9 +1945,11 @@ hipError_t set_score_kernel_lds_limit() {
     HC_COOP_ATTR(uint8_t, 4, 256)
     HC_COOP_ATTR(uint8_t, 5, 256)
     HC_COOP_ATTR(uint8_t, 6, 1024)
+    HC_COOP_ATTR(uint8_t, 7, 1024)
     HC_COOP_ATTR(uint16_t, 5, 256)
     HC_COOP_ATTR(uint16_t, 5, 1024)
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 6, 1024, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint8_t, 7, 1024, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)score_kernel_coop<uint16_t, 5, 1024, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMax)) != hipSuccess) return e;
     HC_COOP_ATTR_DEEP(uint8_t, 3)
     HC_COOP_ATTR_DEEP(uint8_t, 4)
@@ -1949,6 +1962,7 @@ hipError_t set_score_kernel_lds_limit() {
     if ((e = set_lds_limit_lg<uint8_t, 4>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 5>()) != hipSuccess) return e;
     if ((e = set_lds_limit_lg<uint8_t, 6>()) != hipSuccess) return e;
+    if ((e = set_lds_limit_lg<uint8_t, 7>()) != hipSuccess) return e;
     return set_lds_limit_lg<uint16_t, 5>();
 }
 

@@ -34,7 +34,7 @@ template <int SB, bool WIDE>
 __device__ __forceinline__ uint32_t base_at(const void* __restrict__ sym, uint64_t i) {
     if (SB == 1) {
         const uint32_t s = ((const uint8_t*)sym)[i];
-        if (WIDE) return (s >> 2) < kWideFirst ? 4u : (s & 3u);
+        if (WIDE) return (s >> 2) < kWide7First ? 4u : (s & 3u);  // (quality indices 0..2 are N / invalid, 3 is never dealt: both wide encodings)
         const uint32_t c = s & 7u;
         return c < 4u ? c : 4u;
     }
@@ -239,8 +239,11 @@ __global__ __launch_bounds__(256) void finder_expand_kernel(const SeqRef* __rest
 template <bool WIDE>
 __device__ __forceinline__ uint32_t mismatches8(uint64_t a, uint64_t b, int nbytes) {
     uint64_t m;
-    if (WIDE) {  // base in bits 0-1; a quality index below 16 (both top bits clear) marks N / invalid (hc_device.h)
-        m = ((a ^ b) & 0x0303030303030303ull) | (~((a | (a << 1)) & (b | (b << 1))) & 0x8080808080808080ull);
+    if (WIDE) {  // base in bits 0-1; a quality index below 4 (the four top bits clear) marks N / invalid in both wide encodings (hc_device.h)
+        uint64_t va = a | (a << 1), vb = b | (b << 1);
+        va |= va << 2;
+        vb |= vb << 2;
+        m = ((a ^ b) & 0x0303030303030303ull) | (~(va & vb) & 0x8080808080808080ull);
     } else {  // code in bits 0-2: 0..3 bases, 4 N, 6/7 invalid
         m = ((a ^ b) | (a & 0x0404040404040404ull)) & 0x0707070707070707ull;
     }

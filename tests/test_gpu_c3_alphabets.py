@@ -15,7 +15,8 @@ from haploconduct_amd.records import result_cls, result_n
 pytestmark = pytest.mark.gpu
 
 CASES = [("c3q25", 25, "score_kernel_coop<uint8_t, 5, 1024"), ("c3q35", 35, "score_kernel_coop<uint8_t, 6, 768"),
-         ("c3q60", 60, "score_kernel_coop<uint16_t, 5, 1024"), ("c3q35r", 35, "score_kernel_coop<uint8_t, 6, 768")]
+         ("c3q60", 60, "score_kernel_coop<uint8_t, 7, 768"), ("c3q35r", 35, "score_kernel_coop<uint8_t, 6, 768"),
+         ("c3q70", 70, "score_kernel_coop<uint16_t, 5, 1024")]
 
 
 @pytest.mark.parametrize("workload,nq,kernel", CASES)

@@ -73,7 +73,7 @@ def test_wide_and_16_bit_symbol_stores_give_the_same_overlaps():
     reads = make_reads(31, n_single=30, n_pair=15, glen=600, lo=60, hi=140, err=0.004)
     rng = np.random.default_rng(3)
     want = None
-    for n_qual in (5, 40, 70):  # 8-bit, wide 8-bit, 16-bit symbols: the finder reads the bases out of all three
+    for n_qual in (5, 40, 58, 70):  # 8-bit, the two wide 8-bit encodings, 16-bit symbols: the finder reads the bases out of all four
         reads.quals = (33 + rng.integers(0, n_qual, reads.quals.size)).astype(np.uint8)
         with hc.EdgeScorer(hc.Settings()) as sc:
             sc.set_reads(reads)

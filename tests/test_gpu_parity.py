@@ -195,7 +195,7 @@ def test_threshold_sweep_decisions(oracle):
         check_parity(oracle, reads, hc.Settings(edge_threshold=et, ov_threshold=ot, merge_contigs=mc), cand)
 
 
-@pytest.mark.parametrize("n_quals", [3, 40, 70])  # 8-bit symbols, wide 8-bit symbols (31..48 values), 16-bit symbols
+@pytest.mark.parametrize("n_quals", [3, 40, 55, 70])  # 8-bit symbols, the two wide 8-bit encodings (31..48 / 49..60 values), 16-bit symbols
 def test_invalid_bases_and_quals_are_errors(oracle, n_quals):
     # lower-case bases in a PAIRED read abort the reference (EdgeCalculator.cpp:29-30); quality < '!' too (:61)
     filler = "".join(chr(33 + (i % n_quals)) for i in range(70))  # forces the size of the quality alphabet
@@ -213,7 +213,7 @@ def test_invalid_bases_and_quals_are_errors(oracle, n_quals):
     with hc.EdgeScorer(st) as sc:
         sc.set_reads(reads)
         k = sc.info()["qual_alphabet"]
-        assert (k <= 30) == (n_quals == 3) and (k > 48) == (n_quals == 70)
+        assert (k <= 30) == (n_quals == 3) and (k > 60) == (n_quals == 70) and (48 < k <= 60) == (n_quals == 55)
         res = sc.score_batch(cand)
         cls = result_cls(res)
         # row 3 overlaps read 1 at positions 0..7 only (the lower-case bases sit at 8,9): valid
@@ -410,9 +410,9 @@ def test_fuzz_through_the_lds_dma_form(oracle, monkeypatch, seed):
 
 @pytest.mark.parametrize("order", ["frequency", "value"])
 @pytest.mark.parametrize("form", ["dma", "registers"])
-@pytest.mark.parametrize("n_quals", [31, 40, 48])
+@pytest.mark.parametrize("n_quals", [31, 40, 48, 49, 60])
 def test_the_wide_table_in_both_forms_and_both_index_orders(oracle, monkeypatch, n_quals, form, order):
-    """31..48 quality values take the wide 8-bit encoding (hc_device.h): the quality indices dealt by frequency (kWideRankLabel) or in byte
+    """31..48 / 49..60 quality values take the wide 8-bit encodings (hc_device.h): the quality indices dealt by frequency (kWideRankLabel) or in byte
     order (HC_QIDX_ORDER=value), the table read by the 768-lane LDS-DMA form (whose scratch words sit in an unaddressed row of the table)
     or by the register-staged 1 024-lane form (HC_WIDE_DMA=0).  All four must reproduce the oracle, with and without invalid symbols."""
     monkeypatch.setenv("HC_COOP_DMA_MIN", "1")
@@ -424,9 +424,10 @@ def test_the_wide_table_in_both_forms_and_both_index_orders(oracle, monkeypatch,
         from haploconduct_amd import synth
         reads, _ = synth.make_paired_dataset(n_pairs=300, genome_len=3000, seed=5, quals=np.arange(40, 40 + n_quals, dtype=np.uint8))
         sc.set_reads(reads)
-        want = "6, 768, true, false, 0, true" if form == "dma" else "6, 1024, true, false, 1, true"
+        lg = "6" if n_quals <= 48 else "7"
+        want = lg + (", 768, true, false, 0, true" if form == "dma" else ", 1024, true, false, 1, true")
         assert sc.kernel_info(10 ** 6).startswith("hc::score_kernel_coop<uint8_t, " + want), sc.kernel_info(10 ** 6)
-    test_invalid_bases_and_quals_are_errors(oracle, 40)
+    test_invalid_bases_and_quals_are_errors(oracle, 40 if n_quals <= 48 else 55)
 
 
 @pytest.mark.parametrize("align", ["16", "64", "256"])
@@ -441,7 +442,7 @@ def test_slot_alignment_of_the_store_changes_nothing(oracle, monkeypatch, align,
 
 @pytest.mark.parametrize("fetch", ["coop", "4", "2"])
 @pytest.mark.parametrize("regular", ["1", "0"])
-@pytest.mark.parametrize("n_quals", [5, 12, 25, 40, 60])  # the three dense / sparse 8-bit tables, the wide 8-bit encoding (per lane: 512-lane workgroups), 16-bit symbols
+@pytest.mark.parametrize("n_quals", [5, 12, 25, 40, 60, 75])  # the three dense / sparse 8-bit tables, the two wide 8-bit encodings (per lane: 512-lane workgroups), 16-bit symbols
 def test_fetch_and_descriptor_paths_agree(oracle, monkeypatch, fetch, regular, n_quals):
     """A store of equal-length sequences, singles first ("regular": read descriptors by arithmetic) scored with the
     cooperative fetch and with both per-lane fetch groups, each with and without descriptor look-ups: every combination
